@@ -1,0 +1,407 @@
+"""TEST INFRASTRUCTURE — NOT PART OF THE PRODUCT.
+
+ctypes bindings for
+  * ``liboracle.so``               — the plain-C restatement of the reference hot path
+                                     (oracle/mhte_oracle.c), and
+  * ``_ref/libmonolith_ref*.so``   — the reference's own cuckoohash_map.hpp / avx_utils.h compiled
+                                     in place from /root/reference by oracle/Makefile.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package; ``monolith_amd`` never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+
+OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
+INIT_ZEROS, INIT_ONES, INIT_CONSTANT = 0, 1, 2
+
+
+def build(force=False):
+  """Builds liboracle.so (always possible) and _ref (only where /root/reference exists)."""
+  if force or not os.path.exists(os.path.join(_DIR, "liboracle.so")):
+    subprocess.check_call(["make", "-s", "-C", _DIR, "liboracle.so"])
+  if os.path.isdir("/root/reference") and (
+      force or not os.path.exists(os.path.join(_DIR, "_ref", "libmonolith_ref.so"))):
+    subprocess.check_call(["make", "-s", "-C", _DIR, "ref"])
+
+
+class Segment(C.Structure):
+  _fields_ = [("dim", C.c_int32), ("opt", C.c_int32), ("p", C.c_float * 8),
+              ("init", C.c_int32), ("init_value", C.c_float)]
+
+
+def segment(dim, opt=OPT_SGD, p=(), init=INIT_ZEROS, init_value=0.0):
+  s = Segment()
+  s.dim, s.opt, s.init, s.init_value = dim, opt, init, init_value
+  for i, v in enumerate(p):
+    s.p[i] = v
+  return s
+
+
+def _p(a, t):
+  return a.ctypes.data_as(C.POINTER(t))
+
+
+def _i64(a):
+  return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _f32(a):
+  return np.ascontiguousarray(a, dtype=np.float32)
+
+
+_lib = None
+
+
+def lib():
+  global _lib
+  if _lib is None:
+    build()
+    L = C.CDLL(os.path.join(_DIR, "liboracle.so"))
+    L.mo_table_new.restype = C.c_void_p
+    L.mo_table_new.argtypes = [C.c_int32, C.POINTER(Segment), C.c_uint64]
+    L.mo_hash.restype = C.c_uint64
+    L.mo_hash.argtypes = [C.c_int64]
+    L.mo_partial.restype = C.c_uint8
+    L.mo_partial.argtypes = [C.c_uint64]
+    L.mo_alt_index.restype = C.c_uint64
+    L.mo_alt_index.argtypes = [C.c_int, C.c_uint8, C.c_uint64]
+    for name in ("mo_size", "mo_lookup", "mo_dump", "mo_locate",
+                 "mo_unique_key_with_value_and_offset", "mo_fused_reorder_by_indices"):
+      getattr(L, name).restype = C.c_int64
+    _lib = L
+  return _lib
+
+
+class Table:
+  """Restated single EmbeddingHashTable (cuckoo_embedding_hash_table.cc:117-362)."""
+
+  def __init__(self, segments, initial_capacity=1):
+    if isinstance(segments, Segment):
+      segments = [segments]
+    self.L = lib()
+    arr = (Segment * len(segments))(*segments)
+    self.h = C.c_void_p(self.L.mo_table_new(len(segments), arr, C.c_uint64(initial_capacity)))
+    self.dim = self.L.mo_dim(self.h)
+    self.row_floats = self.L.mo_row_floats(self.h)
+    self.nseg = len(segments)
+
+  def __del__(self):
+    try:
+      self.L.mo_table_free(self.h)
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def size(self):
+    return int(self.L.mo_size(self.h))
+
+  def hashpower(self):
+    return int(self.L.mo_hashpower(self.h))
+
+  def contains(self, i):
+    return bool(self.L.mo_contains(self.h, C.c_int64(int(i))))
+
+  def locate(self, i):
+    return int(self.L.mo_locate(self.h, C.c_int64(int(i))))
+
+  def lookup(self, ids):
+    ids = _i64(ids)
+    out = np.empty((ids.size, self.dim), np.float32)
+    hits = self.L.mo_lookup(self.h, _p(ids, C.c_int64), C.c_int64(ids.size), _p(out, C.c_float))
+    return out, int(hits)
+
+  def assign(self, ids, values, update_time=0):
+    ids, values = _i64(ids), _f32(values)
+    self.L.mo_assign(self.h, _p(ids, C.c_int64), C.c_int64(ids.size), _p(values, C.c_float),
+                     C.c_int64(update_time))
+
+  def assign_add(self, ids, values, update_time=0):
+    ids, values = _i64(ids), _f32(values)
+    self.L.mo_assign_add(self.h, _p(ids, C.c_int64), C.c_int64(ids.size), _p(values, C.c_float),
+                         C.c_int64(update_time))
+
+  def reinitialize(self, ids, now=0):
+    ids = _i64(ids)
+    st = np.empty(ids.size, np.int32)
+    self.L.mo_reinitialize(self.h, _p(ids, C.c_int64), C.c_int64(ids.size), _p(st, C.c_int32),
+                           C.c_int64(now))
+    return st
+
+  def optimize(self, ids, grads, lrs, update_time=0, global_step=0):
+    ids, grads = _i64(ids), _f32(grads)
+    lrs = _f32(np.atleast_1d(lrs))
+    assert lrs.size == self.nseg
+    self.L.mo_optimize(self.h, _p(ids, C.c_int64), C.c_int64(ids.size), _p(grads, C.c_float),
+                       _p(lrs, C.c_float), C.c_int64(update_time), C.c_int64(global_step))
+
+  def set_ttl(self, default_days, slot_to_days=None):
+    slot_to_days = slot_to_days or {}
+    s = _i64(list(slot_to_days.keys()))
+    d = np.ascontiguousarray(list(slot_to_days.values()), dtype=np.int32)
+    self.L.mo_set_ttl(self.h, C.c_int64(default_days), C.c_int32(s.size), _p(s, C.c_int64),
+                      _p(d, C.c_int32))
+
+  def evict(self, max_update_time):
+    self.L.mo_evict(self.h, C.c_int64(max_update_time))
+
+  def dump(self, with_rows=True):
+    n = self.size()
+    ids = np.empty(n, np.int64)
+    pos = np.empty(n, np.int64)
+    ts = np.empty(n, np.uint32)
+    rows = np.empty((n, self.row_floats), np.float32) if with_rows else None
+    m = self.L.mo_dump(self.h, C.c_int64(n), _p(ids, C.c_int64), _p(pos, C.c_int64),
+                       _p(ts, C.c_uint32), _p(rows, C.c_float) if with_rows else None)
+    assert m == n
+    return ids, pos, ts, rows
+
+
+def sgd(num, grad, lr):
+  num, grad = _f32(num).copy(), _f32(grad)
+  lib().mo_sgd(_p(num, C.c_float), _p(grad, C.c_float), C.c_int64(num.size), C.c_float(lr))
+  return num
+
+
+def adagrad(num, norm, grad, lr, wd):
+  num, norm, grad = _f32(num).copy(), _f32(norm).copy(), _f32(grad)
+  lib().mo_adagrad(_p(num, C.c_float), _p(norm, C.c_float), _p(grad, C.c_float),
+                   C.c_int64(num.size), C.c_float(lr), C.c_float(wd))
+  return num, norm
+
+
+def unique_key_with_value_and_offset(key, key_split, dims):
+  key, key_split = _i64(key), _i64(key_split)
+  dims = np.ascontiguousarray(dims, dtype=np.int32)
+  T, n = dims.size, key.size
+  uk = np.empty(n, np.int64)
+  uks = np.empty(T + 1, np.int64)
+  vo = np.empty(n, np.int64)
+  vos = np.empty(n + 1, np.int64)
+  blen = C.c_int64(0)
+  nu = lib().mo_unique_key_with_value_and_offset(
+      _p(key, C.c_int64), _p(key_split, C.c_int64), C.c_int32(T), _p(dims, C.c_int32),
+      _p(uk, C.c_int64), _p(uks, C.c_int64), _p(vo, C.c_int64), _p(vos, C.c_int64),
+      C.byref(blen))
+  return uk[:nu].copy(), uks, vo, vos[:nu + 1].copy(), int(blen.value)
+
+
+def fill_with_offset_map(pos, pos_split, value, value_offset_map, value_offset_map_split, dims,
+                         buffer_len):
+  pos, pos_split = _i64(pos), _i64(pos_split)
+  value = _f32(value)
+  vom, voms = _i64(value_offset_map), _i64(value_offset_map_split)
+  dims = np.ascontiguousarray(dims, dtype=np.int32)
+  buf = np.zeros(buffer_len, np.float32)
+  rc = lib().mo_fill_with_offset_map(_p(pos, C.c_int64), _p(pos_split, C.c_int64),
+                                     C.c_int32(dims.size), _p(dims, C.c_int32),
+                                     _p(value, C.c_float), C.c_int64(value.size),
+                                     _p(vom, C.c_int64), C.c_int64(vom.size),
+                                     _p(voms, C.c_int64), _p(buf, C.c_float))
+  if rc:
+    raise ValueError("InvalidArgument(%d)" % rc)
+  return buf
+
+
+def fill_with_offset_map_gradient(pos, pos_split, grad, grad_offset_map, grad_offset_map_split,
+                                  dims):
+  pos, pos_split = _i64(pos), _i64(pos_split)
+  grad = _f32(grad)
+  gom, goms = _i64(grad_offset_map), _i64(grad_offset_map_split)
+  dims = np.ascontiguousarray(dims, dtype=np.int32)
+  bsize = int(sum(int(dims[j]) * int(pos_split[j + 1] - pos_split[j]) for j in range(dims.size)))
+  out = np.empty(bsize, np.float32)
+  rc = lib().mo_fill_with_offset_map_gradient(_p(pos, C.c_int64), _p(pos_split, C.c_int64),
+                                              C.c_int32(dims.size), _p(dims, C.c_int32),
+                                              _p(grad, C.c_float), _p(gom, C.c_int64),
+                                              C.c_int64(gom.size), _p(goms, C.c_int64),
+                                              _p(out, C.c_float))
+  if rc:
+    raise ValueError("InvalidArgument(%d)" % rc)
+  return out
+
+
+def compute_fused_offsets(slot_size_vec, table_dims, num_tables, num_shards):
+  ss = np.ascontiguousarray(slot_size_vec, dtype=np.int32)
+  td = np.ascontiguousarray(table_dims, dtype=np.int32)
+  ko = np.empty(num_tables * num_shards + 1, np.int32)
+  eo = np.empty(num_tables * num_shards + 1, np.int32)
+  kpt = np.empty(num_tables, np.int32)
+  es = np.empty(num_shards, np.int32)
+  tk, te = C.c_int32(0), C.c_int32(0)
+  lib().mo_compute_fused_offsets(_p(ss, C.c_int32), _p(td, C.c_int32), C.c_int32(num_tables),
+                                 C.c_int32(num_shards), _p(ko, C.c_int32), _p(eo, C.c_int32),
+                                 _p(kpt, C.c_int32), _p(es, C.c_int32), C.byref(tk), C.byref(te))
+  return ko, eo, kpt, es, tk.value, te.value
+
+
+def fused_reorder_by_indices(inputs, num_shards, dims, rank0_empty=False):
+  """inputs: list of M int64 id vectors."""
+  M = len(inputs)
+  split = np.zeros(M + 1, np.int64)
+  for i, a in enumerate(inputs):
+    split[i + 1] = split[i] + len(a)
+  flat = _i64(np.concatenate([_i64(a) for a in inputs]) if M else np.zeros(0, np.int64))
+  dims = np.ascontiguousarray(dims, dtype=np.int32)
+  total = int(split[M])
+  out = np.empty(total, np.int64)
+  shard_sizes = np.empty(num_shards, np.int32)
+  sss = np.empty(num_shards * M, np.int32)
+  eos = np.empty(M, np.int32)
+  feo = np.empty(total, np.int32)
+  nu = lib().mo_fused_reorder_by_indices(_p(flat, C.c_int64), _p(split, C.c_int64), C.c_int32(M),
+                                         C.c_int32(num_shards), _p(dims, C.c_int32),
+                                         C.c_int32(int(rank0_empty)), _p(out, C.c_int64),
+                                         _p(shard_sizes, C.c_int32), _p(sss, C.c_int32),
+                                         _p(eos, C.c_int32), _p(feo, C.c_int32))
+  return out[:nu].copy(), shard_sizes, sss, eos, feo
+
+
+# ---------------------------------------------------------------- reference-built library
+_ref = {}
+
+
+def ref_available(avx=False):
+  return os.path.exists(
+      os.path.join(_DIR, "_ref", "libmonolith_ref_avx.so" if avx else "libmonolith_ref.so"))
+
+
+def ref_lib(avx=False):
+  if avx not in _ref:
+    build()
+    L = C.CDLL(os.path.join(_DIR, "_ref",
+                            "libmonolith_ref_avx.so" if avx else "libmonolith_ref.so"))
+    L.ref_table_new.restype = C.c_void_p
+    L.ref_table_new.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64]
+    L.ref_ps_new.restype = C.c_void_p
+    L.ref_ps_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                             C.c_uint64]
+    for name in ("ref_size", "ref_hashpower", "ref_lookup", "ref_dump", "ref_ps_size",
+                 "ref_ps_step", "ref_ps_lookup"):
+      getattr(L, name).restype = C.c_int64
+    L.ref_adagrad_optimize.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                       C.POINTER(C.c_float), C.c_int64, C.c_float, C.c_float]
+    _ref[avx] = L
+  return _ref[avx]
+
+
+class RefTable:
+  """The reference's cuckoohash_map (compiled from /root/reference) + restated accessor."""
+
+  def __init__(self, dim, opt=OPT_SGD, init_acc=0.1, wd=0.0, init_value=0.0, initial_capacity=1,
+               avx=False):
+    self.L = ref_lib(avx)
+    self.dim = dim
+    self.row_floats = dim + (dim if opt == OPT_ADAGRAD else 0)
+    self.h = C.c_void_p(self.L.ref_table_new(dim, opt, init_acc, wd, init_value,
+                                             initial_capacity))
+
+  def __del__(self):
+    try:
+      self.L.ref_table_free(self.h)
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def size(self):
+    return int(self.L.ref_size(self.h))
+
+  def hashpower(self):
+    return int(self.L.ref_hashpower(self.h))
+
+  def contains(self, i):
+    return bool(self.L.ref_contains(self.h, C.c_int64(int(i))))
+
+  def lookup(self, ids):
+    ids = _i64(ids)
+    out = np.empty((ids.size, self.dim), np.float32)
+    hits = self.L.ref_lookup(self.h, _p(ids, C.c_int64), C.c_int64(ids.size), _p(out, C.c_float))
+    return out, int(hits)
+
+  def assign(self, ids, values, update_time=0):
+    ids, values = _i64(ids), _f32(values)
+    self.L.ref_assign(self.h, _p(ids, C.c_int64), C.c_int64(ids.size), _p(values, C.c_float),
+                      C.c_int64(update_time))
+
+  def assign_add(self, ids, values, update_time=0):
+    ids, values = _i64(ids), _f32(values)
+    self.L.ref_assign_add(self.h, _p(ids, C.c_int64), C.c_int64(ids.size), _p(values, C.c_float),
+                          C.c_int64(update_time))
+
+  def reinitialize(self, ids, now=0):
+    ids = _i64(ids)
+    st = np.empty(ids.size, np.int32)
+    self.L.ref_reinitialize(self.h, _p(ids, C.c_int64), C.c_int64(ids.size), _p(st, C.c_int32),
+                            C.c_int64(now))
+    return st
+
+  def optimize(self, ids, grads, lr, update_time=0):
+    ids, grads = _i64(ids), _f32(grads)
+    self.L.ref_optimize(self.h, _p(ids, C.c_int64), C.c_int64(ids.size), _p(grads, C.c_float),
+                        C.c_float(lr), C.c_int64(update_time))
+
+  def set_ttl(self, default_days, slot_to_days=None):
+    slot_to_days = slot_to_days or {}
+    s = _i64(list(slot_to_days.keys()))
+    d = np.ascontiguousarray(list(slot_to_days.values()), dtype=np.int32)
+    self.L.ref_set_ttl(self.h, C.c_int64(default_days), C.c_int(s.size), _p(s, C.c_int64),
+                       _p(d, C.c_int32))
+
+  def evict(self, max_update_time):
+    self.L.ref_evict(self.h, C.c_int64(max_update_time))
+
+  def dump(self, with_rows=True):
+    n = self.size()
+    ids = np.empty(n, np.int64)
+    pos = np.empty(n, np.int64)
+    ts = np.empty(n, np.uint32)
+    rows = np.empty((n, self.row_floats), np.float32) if with_rows else None
+    m = self.L.ref_dump(self.h, C.c_int64(n), _p(ids, C.c_int64), _p(pos, C.c_int64),
+                        _p(ts, C.c_uint32), _p(rows, C.c_float) if with_rows else None)
+    assert m == n, (m, n)
+    return ids, pos, ts, rows
+
+
+def ref_adagrad(num, norm, grad, lr, wd, avx=False):
+  num, norm, grad = _f32(num).copy(), _f32(norm).copy(), _f32(grad)
+  ref_lib(avx).ref_adagrad_optimize(_p(num, C.c_float), _p(norm, C.c_float), _p(grad, C.c_float),
+                                    num.size, lr, wd)
+  return num, norm
+
+
+class RefPs:
+  """CPU baseline: P single-threaded reference-map shards + worker-side dedup."""
+
+  def __init__(self, P, dim, opt, init_acc=0.1, wd=0.0, init_value=0.0, initial_capacity=1,
+               avx=True):
+    self.L = ref_lib(avx)
+    self.P, self.dim = P, dim
+    self.h = C.c_void_p(self.L.ref_ps_new(P, dim, opt, init_acc, wd, init_value,
+                                          initial_capacity))
+
+  def __del__(self):
+    try:
+      self.L.ref_ps_free(self.h)
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def size(self):
+    return int(self.L.ref_ps_size(self.h))
+
+  def step(self, ids, grads, lr, update_time, want_emb=True):
+    ids, grads = _i64(ids), _f32(grads)
+    emb = np.empty((ids.size, self.dim), np.float32) if want_emb else None
+    u = self.L.ref_ps_step(self.h, _p(ids, C.c_int64), C.c_int64(ids.size), _p(grads, C.c_float),
+                           C.c_float(lr), C.c_int64(update_time),
+                           _p(emb, C.c_float) if want_emb else None)
+    return emb, int(u)
+
+  def lookup(self, ids):
+    ids = _i64(ids)
+    out = np.empty((ids.size, self.dim), np.float32)
+    hits = self.L.ref_ps_lookup(self.h, _p(ids, C.c_int64), C.c_int64(ids.size),
+                                _p(out, C.c_float))
+    return out, int(hits)
