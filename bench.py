@@ -1,0 +1,327 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json's metric on MI355X: embedding lookups+updates/sec, 1B-id universe x
+dim 64, Zipf(1.2), batch 65536, fused Adagrad (configs[2]); HBM-BW% through `roofline`.
+
+One "step" = one pass of the sparse hot path over one batch of B ids already resident in HBM:
+  dedup -> lookup(unique) -> scatter to B rows | duplicate-grad sum -> Adagrad apply(unique)
+(the op sequence of native_training/distributed_ps.py:282-329 + :489-514).  value =
+(B lookups + B updates) * steps * n_gpus / wall time, max over ranks, barrier + synchronize on both
+sides.  With --gpus N > 1 (launched by torch.distributed.run) every rank feeds its own B ids and the
+table is sharded by fid mod N with four all-to-alls per step over RCCL (weak scaling).
+
+Contract: prints ONE JSON line on rank 0.  Extra objects: `roofline` (dominant kernel, HIP-event
+timed on the launch stream), `cpu_baseline` (reference map + AVX Adagrad built from the reference's
+own sources, oracle/_ref, timed on this box's host cores; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable copy
+PROBE_BYTES = 72        # keys+tags of both candidate buckets
+
+
+def parse():
+  p = argparse.ArgumentParser()
+  p.add_argument("--gpus", type=int, default=1)
+  p.add_argument("--steps", type=int, default=200)
+  p.add_argument("--warmup", type=int, default=20)
+  p.add_argument("--batch", type=int, default=65536)
+  p.add_argument("--dim", type=int, default=64)
+  p.add_argument("--universe", type=float, default=1e9)
+  p.add_argument("--resident-rows", type=float, default=float(1 << 27),
+                 help="rows pre-inserted per GPU (the hottest ranks of this GPU's shard)")
+  p.add_argument("--opt", default="adagrad", choices=["adagrad", "sgd"])
+  p.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"])
+  p.add_argument("--no-cpu-baseline", action="store_true")
+  p.add_argument("--cpu-steps", type=int, default=150)
+  p.add_argument("--exact-order", action="store_true")
+  return p.parse_args()
+
+
+def algorithmic_bytes(B, U, D, S):
+  """SURVEY.md §8d / BASELINE.md §3 per step; and per kernel."""
+  P = PROBE_BYTES
+  lookup = 8 * B + P * U + 4 * D * U + 4 * D * B
+  update = 8 * B + 4 * D * B + P * U + (8 * D + 8 * S) * U + 4 * U
+  per_kernel = {
+      "lookup_kernel": 8 * U + P * U + 4 * D * U + 4 * D * U,
+      "gather_rows_kernel": 4 * B + 4 * D * U + 4 * D * B,
+      "segsum_window_kernel": 4 * D * B + 8 * B + 4 * D * U,
+      "upsert_kernel": 8 * U + P * U + 4 * U + 4 * D * U + 2 * 4 * (D + S) * U,
+  }
+  return lookup + update, per_kernel
+
+
+def main():
+  args = parse()
+  import torch
+  import torch.distributed as dist
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if args.gpus != world:
+    if world == 1 and args.gpus > 1:
+      raise SystemExit("--gpus %d needs: python -m torch.distributed.run --nproc-per-node %d "
+                       "bench.py --gpus %d" % (args.gpus, args.gpus, args.gpus))
+  assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+  torch.cuda.set_device(local_rank)
+  dev = torch.device("cuda", local_rank)
+  if world > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+
+  from monolith_amd import _lib, entry, synthetic as S
+  from monolith_amd.fused_step import SparseStep
+  from monolith_amd.multi_hash_table_ops import MultiHashTable
+
+  B, D = args.batch, args.dim
+  V = int(args.universe) * world  # weak scaling: 1B-id universe per GPU
+  K, W = args.steps, args.warmup
+  S_state = D if args.opt == "adagrad" else 0
+  resident = int(args.resident_rows)
+
+  def make_table(res):
+    rows_cap = res + (K + W + 8) * B * (2 if world > 1 else 1) + (1 << 16)
+    slots = 4
+    while slots * 0.5 < rows_cap:
+      slots *= 2
+    opt = (entry.AdagradOptimizer(0.001, 0.1) if args.opt == "adagrad" else
+           entry.SgdOptimizer(0.01))
+    cfg = entry.make_table_config(
+        [entry.CombineAsSegment(D, entry.ZerosInitializer(), opt)],
+        entry.CuckooHashTableConfig(initial_capacity=slots, reserve_rows=rows_cap))
+    return MultiHashTable.from_configs({"emb": cfg}, name_suffix="bench%d_%d" % (rank, res))
+
+  mt = None
+  while mt is None:
+    try:
+      mt = make_table(resident)
+    except _lib.MhteError as e:  # out of HBM: halve the resident set and say so
+      if e.code != _lib.MHTE_RESOURCE_EXHAUSTED or resident < (1 << 16):
+        raise
+      resident //= 2
+      torch.cuda.empty_cache()
+
+  # ---- prefill: the `resident` hottest ranks of this GPU's shard, rows = initializer (zeros) ----
+  t0 = time.time()
+  mult = torch.tensor(0x9E3779B97F4A7C15 - (1 << 64), dtype=torch.int64, device=dev)
+  chunk = 1 << 22
+  zeros = torch.zeros((chunk, D), dtype=torch.float32, device=dev)
+  filled, r0 = 0, 1
+  while filled < resident:
+    ranks = torch.arange(r0, r0 + chunk * world, dtype=torch.int64, device=dev)
+    r0 += chunk * world
+    fid = ((ranks * mult) & ((1 << 48) - 1)) | (1 << 48)
+    if world > 1:
+      fid = fid[torch.remainder(fid, world) == rank]
+    n = min(fid.numel(), resident - filled)
+    fid = fid[:n].contiguous()
+    rg = mt.get_ragged_id({"emb": fid})
+    _lib.check(mt._lib.mhte_assign(mt.handle, _lib.vp(fid),
+                                   rg.row_splits.ctypes.data_as(_lib.C.POINTER(_lib.C.c_int64)),
+                                   _lib.C.c_int64(2), _lib.vp(zeros), _lib.C.c_int64(n * D),
+                                   _lib.C.c_int64(S.update_time(0)),
+                                   _lib.C.c_int32(_lib.MHTE_IDS_UNIQUE), None))
+    filled += n
+  torch.cuda.synchronize()
+  del zeros
+  torch.cuda.empty_cache()
+  prefill_s = time.time() - t0
+  st0 = mt.stats("emb")
+
+  # ---- inputs resident in HBM before the timed region ----
+  n_batches = K + W
+  ids_host = np.stack([S.id_batch(s * world + rank, B, V, "zipf") for s in range(n_batches)])
+  ids_all = torch.from_numpy(ids_host).to(dev)
+  grad_pool = [torch.from_numpy(S.grad_batch(s, B, D)).to(dev) for s in range(8)]
+
+  if world == 1:
+    step = SparseStep(mt, "emb", B, exact_order=args.exact_order)
+
+    def run_step(s, ids):
+      step.forward(ids)
+      step.backward(grad_pool[s % 8], S.update_time(s))
+  else:
+    from monolith_amd.distributed_ps_sync import HipBackend, ShardedEmbedding
+    se = ShardedEmbedding(HipBackend(mt, "emb"))
+
+    def run_step(s, ids):
+      se.lookup(ids)
+      se.apply_gradients(grad_pool[s % 8], S.update_time(s))
+
+  def barrier():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+      torch.cuda.synchronize()
+
+  def timed(fn_step):
+    for s in range(W):
+      fn_step(s, ids_all[s])
+    barrier()
+    t = time.perf_counter()
+    for s in range(W, W + K):
+      fn_step(s, ids_all[s])
+    barrier()
+    return time.perf_counter() - t
+
+  results = {}
+  results["eager"] = timed(run_step)
+
+  # ---- hipGraph replay of the whole step (launch-bound inner loop) ----
+  graph_err = None
+  if world == 1 and args.launch in ("auto", "graph"):
+    try:
+      static_ids = ids_all[0].clone()
+      static_g = grad_pool[0]
+      g = torch.cuda.CUDAGraph()
+      torch.cuda.synchronize()
+      with torch.cuda.graph(g):
+        step.forward(static_ids)
+        step.backward(static_g, S.update_time(W))
+
+      def graph_step(s, ids):
+        static_ids.copy_(ids, non_blocking=True)
+        g.replay()
+
+      results["graph"] = timed(graph_step)
+    except Exception as e:  # pylint: disable=broad-except
+      graph_err = repr(e)[:200]
+      torch.cuda.synchronize()
+  launch = min(results, key=results.get) if args.launch == "auto" else (
+      args.launch if args.launch in results else "eager")
+  elapsed = results[launch]
+  if world > 1:
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+
+  # ---- per-kernel HIP-event timing on the launch stream (N=1) ----
+  roofline, stages, uniq_avg = None, {}, None
+  if world == 1:
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    names = ["dedup(7 kernels)", "lookup_kernel", "gather_rows_kernel", "segsum_window_kernel",
+             "upsert_kernel"]
+    acc = {n: 0.0 for n in names}
+    us = []
+    reps = min(K, 100)
+    for s in range(W, W + reps):
+      ids = ids_all[s]
+      e = [ev() for _ in range(6)]
+      e[0].record()
+      step.ws.unique(ids, want_host_count=False, out=step.u)
+      e[1].record()
+      mt.table_lookup_n(step.idx, step.u.unique_ids, step.u.n_unique_dev, step.emb_u, n_max=B)
+      e[2].record()
+      step.ws.gather_rows(step.emb_u, step.u.inverse, B, D, out=step.emb)
+      e[3].record()
+      step.ws.segment_sum(grad_pool[s % 8], step.u, D, out=step.grad_u,
+                          exact_order=args.exact_order)
+      e[4].record()
+      mt.table_optimize_n(step.idx, step.u.unique_ids, step.u.n_unique_dev, step.grad_u, step.lrs,
+                          S.update_time(s), 0, flags=_lib.MHTE_IDS_UNIQUE, n_max=B)
+      e[5].record()
+      torch.cuda.synchronize()
+      for i, n in enumerate(names):
+        acc[n] += e[i].elapsed_time(e[i + 1]) * 1e3  # us
+      us.append(step.n_unique())
+    uniq_avg = float(np.mean(us))
+    step_bytes, per_kernel = algorithmic_bytes(B, uniq_avg, D, S_state)
+    for n in names:
+      stages[n] = {"avg_us": round(acc[n] / reps, 2)}
+      if n in per_kernel:
+        stages[n]["alg_bytes"] = int(per_kernel[n])
+        stages[n]["GBps"] = round(per_kernel[n] / (acc[n] / reps) / 1e3, 1)
+    dom = max(per_kernel, key=lambda n: acc[n])
+    a_gbps = per_kernel[dom] / (acc[dom] / reps) / 1e3
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(a_gbps, 1), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(a_gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+                "alg_bytes_per_launch": int(per_kernel[dom]),
+                "avg_launch_us": round(acc[dom] / reps, 2),
+                "step_alg_bytes": int(step_bytes),
+                "step_GBps": round(step_bytes / (elapsed / K) / 1e9, 1),
+                "step_frac": round(step_bytes / (elapsed / K) / 1e9 / HBM_PEAK_GBPS, 4)}
+
+  st1 = mt.stats("emb")
+
+  # ---- CPU baseline: the reference's own map + AVX Adagrad on this box's host cores ----
+  cpu = None
+  if world == 1 and rank == 0 and not args.no_cpu_baseline:
+    try:
+      import oracle as O
+      cores = os.cpu_count() or 1
+      opt = O.OPT_ADAGRAD if args.opt == "adagrad" else O.OPT_SGD
+      avx = O.ref_available(True)
+      ps = O.RefPs(cores, D, opt, 0.1, 0.0, 0.0, 1, avx=avx)
+      lr = 0.001 if args.opt == "adagrad" else 0.01
+      cw, ck = 10, args.cpu_steps
+      grads_h = [S.grad_batch(s, B, D) for s in range(4)]
+      times = []
+      for s in range(cw + ck):
+        ids = S.id_batch(s, B, V, "zipf")
+        t = time.perf_counter()
+        ps.step(ids, grads_h[s % 4], lr, S.update_time(s), want_emb=True)
+        times.append(time.perf_counter() - t)
+      med = float(np.median(times[cw:]))
+      cpu = {"value": round(2 * B / med, 1), "unit": "lookups+updates/s", "cores": cores,
+             "kind": "reference",
+             "sample": "%d steps (after %d warm-up) of the same Zipf(1.2) stream, batch %d, dim %d, "
+                       "%s; table grown on demand from empty (%d rows at end); PS-style %d "
+                       "single-threaded shards of the reference cuckoohash_map + %s Adagrad, "
+                       "median step %.2f ms" % (ck, cw, B, D, args.opt, ps.size(), cores,
+                                                "AVX2" if avx else "scalar", med * 1e3)}
+    except Exception as e:  # pylint: disable=broad-except
+      cpu = {"value": None, "unit": "lookups+updates/s", "cores": os.cpu_count(), "kind": "reference",
+             "sample": "failed: %r" % (e,)}
+
+  if rank == 0:
+    value = 2.0 * B * K * world / elapsed
+    out = {
+        "metric": "embedding lookups+updates/sec at 1B ids x dim64, Zipf(1.2) batch=65536",
+        "value": round(value, 1),
+        "unit": "lookups+updates/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": round(elapsed / K * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "configs[2]: 1 MI355X, 1B-id universe (per GPU), dim=%d, Zipf(1.2), "
+                        "batch=%d/GPU, %s; grow-on-demand table" % (D, B, "fused Adagrad" if
+                                                                    args.opt == "adagrad" else "SGD"),
+            "batch_per_gpu": B, "dim": D, "universe_ids": V, "optimizer": args.opt,
+            "resident_rows_per_gpu_start": int(st0.size), "resident_rows_per_gpu_end": int(st1.size),
+            "row_bytes": 4 * (D + S_state), "hashpower": int(st1.hashpower),
+            "table_bytes_per_gpu": int(st1.bytes_buckets + st1.bytes_rows),
+            "unique_ids_per_batch": uniq_avg, "launch": launch,
+            "parallelism": "1 GPU" if world == 1 else "fid mod %d sharding, 4 all-to-all/step (RCCL)" % world,
+            "prefill_s": round(prefill_s, 2),
+        },
+        "timing_ms_per_step": {k: round(v / K * 1e3, 5) for k, v in results.items()},
+        "roofline": roofline,
+        "stages": stages,
+        "cpu_baseline": cpu,
+    }
+    if cpu and cpu.get("value"):
+      out["vs_cpu_baseline"] = round(value / cpu["value"], 2)
+    if graph_err:
+      out["graph_error"] = graph_err
+    print(json.dumps(out))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

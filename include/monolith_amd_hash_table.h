@@ -1,0 +1,248 @@
+/* monolith_amd_hash_table.h — C ABI of the MI355X-native MultiHashTable engine (libmhte.so).
+ *
+ * Drop-in boundary for Monolith's MultiHashTable TensorFlow custom ops.  Every entry point below
+ * names the reference interface it replaces; paths are relative to
+ * /root/reference/monolith/native_training/runtime/ ("RT/") or .../native_training/ ("NT/").
+ * The reference-side binding (a TF OpKernel shim, and the ctypes binding used here) is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - Every function returns an mhte_status; on failure mhte_last_error() (thread-local) holds a
+ *     message.  Codes are TensorFlow's error codes, because the reference maps engine exceptions to
+ *     errors::InvalidArgument / errors::ResourceExhausted
+ *     (RT/ops/embedding_hash_table_tf_bridge.cc:132-134,365-367).
+ *   - "dev" pointers are HIP device pointers on the table's GPU; "host" pointers are ordinary
+ *     host memory.  Shape-determining inputs (row splits, slot sizes, learning rates, scalars) are
+ *     host memory — the TF kernel registers them as HostMemory inputs.
+ *   - `stream` is a hipStream_t passed as void*.  All work is enqueued on it and is ordered with
+ *     respect to earlier calls on the same stream (the reference chains ops through the returned
+ *     resource handle, RT/ops/multi_hash_table_update_op.cc:87; here stream order is that chain).
+ *     A table must be driven from one stream at a time.
+ *   - Tables of a MultiHashTable are ordered by sorted name, as NT/multi_hash_table_ops.py:83 does.
+ */
+#ifndef MONOLITH_AMD_HASH_TABLE_H_
+#define MONOLITH_AMD_HASH_TABLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t mhte_status;
+enum {
+  MHTE_OK = 0,
+  MHTE_INVALID_ARGUMENT = 3,    /* tensorflow::error::INVALID_ARGUMENT */
+  MHTE_NOT_FOUND = 5,
+  MHTE_RESOURCE_EXHAUSTED = 8,  /* tensorflow::error::RESOURCE_EXHAUSTED */
+  MHTE_FAILED_PRECONDITION = 9,
+  MHTE_INTERNAL = 13,
+  MHTE_UNAVAILABLE = 14         /* no HIP device / runtime error */
+};
+
+const char* mhte_last_error(void);
+/* ABI version of this header; mhte_abi_version() must return the same value. */
+#define MHTE_ABI_VERSION 1
+int32_t mhte_abi_version(void);
+
+/* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
+enum { MHTE_OPT_SGD = 0, MHTE_OPT_ADAGRAD = 1, MHTE_OPT_FTRL = 2 };       /* optimizer.proto:210-229 */
+enum { MHTE_INIT_ZEROS = 0, MHTE_INIT_ONES = 1, MHTE_INIT_CONSTANT = 2 }; /* initializer_config.proto */
+
+/* EntryConfig.Segment (embedding_hash_table.proto:23-43) */
+typedef struct {
+  int32_t dim_size;
+  int32_t opt_type;     /* MHTE_OPT_* */
+  float opt_params[4];  /* ADAGRAD: {initial_accumulator_value, weight_decay_factor}
+                           FTRL:    {initial_accumulator_value, beta, l1, l2}        */
+  int32_t init_type;    /* MHTE_INIT_* */
+  float init_value;     /* ConstantsInitializerConfig.constant */
+} mhte_segment_config;
+
+/* EmbeddingHashTableConfig (embedding_hash_table.proto:70-95) + SlotExpireTimeConfig (:54-64) */
+typedef struct {
+  const char* name;
+  int32_t n_segments;
+  const mhte_segment_config* segments;
+  uint64_t initial_capacity;     /* slots; hashpower = reserve_calc(initial_capacity),
+                                    cuckoohash_map.hpp:2114-2121; proto default 1 */
+  uint64_t reserve_rows;         /* MI355X extension: rows of HBM slab to allocate up front (0 = grow
+                                    on demand in 2^20-row slabs) */
+  float max_load_factor;         /* MI355X extension: proactive doubling threshold, 0 -> 0.5 */
+  int64_t default_expire_days;   /* SlotExpireTimeConfig.default_expire_time, 0 -> 36500 */
+  int32_t n_slot_expire;
+  const int64_t* expire_slots;   /* host */
+  const int32_t* expire_days;    /* host */
+} mhte_table_config;
+
+typedef struct mhte_multi_table mhte_multi_table;
+
+/* CreateMonolithMultiHashTable (RT/ops/multi_hash_table_op.cc:44-112).  `configs` may be in any
+ * order; tables are stored sorted by name.  device = HIP device ordinal. */
+mhte_status mhte_multi_table_create(const mhte_table_config* configs, int32_t n_tables,
+                                    int32_t device, const char* shared_name,
+                                    mhte_multi_table** out);
+void mhte_multi_table_destroy(mhte_multi_table* t);
+int32_t mhte_num_tables(const mhte_multi_table* t);
+const char* mhte_table_name(const mhte_multi_table* t, int32_t i);
+int32_t mhte_table_dim(const mhte_multi_table* t, int32_t i);        /* dim_size() */
+int32_t mhte_table_slice_size(const mhte_multi_table* t, int32_t i); /* slice_size() */
+int32_t mhte_table_index(const mhte_multi_table* t, const char* name); /* -1 when absent */
+const char* mhte_shared_name(const mhte_multi_table* t);
+
+/* MonolithMultiHashTableLookup (RT/ops/multi_hash_table_lookup_op.cc:33-89,200-209).
+ * id [dev, id_split[n_split-1]], id_split [host, n_tables+1], embedding [dev, sum n_t*dim_t].
+ * Absent ids produce zeros and are not inserted. */
+mhte_status mhte_lookup(mhte_multi_table* t, const int64_t* id, const int64_t* id_split,
+                        int64_t n_split, float* embedding, int64_t embedding_len, void* stream);
+
+/* flags for the mutating ops */
+enum {
+  MHTE_IDS_UNIQUE = 1,   /* caller guarantees ids are distinct within each table segment (they come
+                            from unique_key_with_value_and_offset / FusedReorderByIndices); skips
+                            the in-op grouping pass */
+  MHTE_SUM_DUPLICATES = 2 /* enable_grad_accumulation / enable_dedup: add duplicates' gradients,
+                            then ONE optimizer step (RT/ops/embedding_hash_table_tf_bridge.cc:270-310).
+                            Default: one optimizer step per occurrence, in order
+                            (cuckoo_embedding_hash_table.cc:229-236). */
+};
+
+/* MonolithMultiHashTableOptimize (RT/ops/multi_hash_table_update_op.cc:47-100).
+ * learning_rate [host, sum slice_size_t]; update_time seconds (stored as uint32). */
+mhte_status mhte_optimize(mhte_multi_table* t, const int64_t* id, const int64_t* id_split,
+                          int64_t n_split, const float* value, int64_t value_len,
+                          const float* learning_rate, int64_t n_learning_rate, int64_t update_time,
+                          int64_t global_step, int32_t flags, void* stream);
+/* MonolithMultiHashTableAssign (:106-145) */
+mhte_status mhte_assign(mhte_multi_table* t, const int64_t* id, const int64_t* id_split,
+                        int64_t n_split, const float* value, int64_t value_len, int64_t update_time,
+                        int32_t flags, void* stream);
+/* MonolithMultiHashTableAssignAdd (:147-190) */
+mhte_status mhte_assign_add(mhte_multi_table* t, const int64_t* id, const int64_t* id_split,
+                            int64_t n_split, const float* value, int64_t value_len,
+                            int64_t update_time, int32_t flags, void* stream);
+/* MonolithMultiHashTableReinitialize (:192-245).  id_status [dev, n]: -1 unknown table (not an
+ * error), 0 inserted, 1 existed.  `now` replaces absl::Now() so runs are reproducible; pass 0 to
+ * use the wall clock. */
+mhte_status mhte_reinitialize(mhte_multi_table* t, const char* table_name, const int64_t* id,
+                              int64_t n, int32_t* id_status, int64_t now, void* stream);
+
+/* ComputeFusedOffsets (RT/hash_table/utils.h:29-61), host arithmetic. */
+mhte_status mhte_compute_fused_offsets(const mhte_multi_table* t, const int32_t* fused_slot_size,
+                                       int32_t num_of_shards, int32_t* id_offsets,
+                                       int32_t* embedding_offsets, int32_t* embedding_splits,
+                                       int64_t* total_ids, int64_t* total_embeddings);
+/* MonolithMultiHashTableFusedLookup (RT/ops/multi_hash_table_lookup_op.cc:128-197,229-255).
+ * ids [dev], fused_slot_size [host, num_of_shards*n_tables] (shard-major, table-minor);
+ * embeddings [dev, total_embeddings from mhte_compute_fused_offsets];
+ * embedding_splits [host, num_of_shards], id_offsets / embedding_offsets [host, N*T+1]. */
+mhte_status mhte_fused_lookup(mhte_multi_table* t, const int64_t* ids,
+                              const int32_t* fused_slot_size, int32_t num_of_shards,
+                              int64_t req_time, float* embeddings, int64_t embeddings_len,
+                              int32_t* embedding_splits, int32_t* id_offsets,
+                              int32_t* embedding_offsets, void* stream);
+/* MonolithMultiHashTableFusedOptimize (RT/ops/multi_hash_table_update_op.cc:247-325).
+ * enable_grad_accumulation == (flags & MHTE_SUM_DUPLICATES). */
+mhte_status mhte_fused_optimize(mhte_multi_table* t, const int64_t* ids,
+                                const int32_t* fused_slot_size, const float* id_grads,
+                                int64_t id_grads_len, const int32_t* id_offsets,
+                                const int32_t* grad_offsets, const float* learning_rates,
+                                int64_t n_learning_rates, int64_t req_time, int64_t global_step,
+                                int32_t num_of_shards, int32_t flags, void* stream);
+
+/* ---- introspection / maintenance ----------------------------------------------------------- */
+/* Size() (RT/hash_table/embedding_hash_table_interface.h); synchronises the stream. */
+mhte_status mhte_table_size(mhte_multi_table* t, int32_t table, int64_t* size, void* stream);
+/* Contains() for a batch: out [dev, n] 0/1 */
+mhte_status mhte_table_contains(mhte_multi_table* t, int32_t table, const int64_t* id, int64_t n,
+                                int32_t* out, void* stream);
+/* Evict(max_update_time) (cuckoo_embedding_hash_table.cc:251-264).  max_update_time < 0 uses the
+ * table's own fuzzy max of all update_times seen (tf_bridge.cc:262-263). */
+mhte_status mhte_table_evict(mhte_multi_table* t, int32_t table, int64_t max_update_time,
+                             void* stream);
+/* Table geometry: hashpower, rows allocated, lookup hits since last call. Synchronises. */
+typedef struct {
+  int64_t size;
+  int32_t hashpower;
+  int64_t rows_allocated;
+  int64_t lookup_hits;
+  int64_t dropped;      /* ids dropped because displacement failed (0 unless max_load_factor ~ 1) */
+  int64_t evicted;
+  int64_t max_update_ts;
+  int64_t bytes_buckets;
+  int64_t bytes_rows;
+} mhte_table_stats;
+mhte_status mhte_table_get_stats(mhte_multi_table* t, int32_t table, mhte_table_stats* out,
+                                 void* stream);
+/* Dump in bucket-major order (Save's iteration order, cuckoohash_map.hpp:740-773).
+ * All outputs dev, capacity `cap` entries; rows may be NULL; row_floats = dim + optimizer state.
+ * Returns the number of entries in *n_out. Synchronises. */
+mhte_status mhte_table_dump(mhte_multi_table* t, int32_t table, int64_t cap, int64_t* ids,
+                            int64_t* positions, uint32_t* ts, float* rows, int64_t* n_out,
+                            void* stream);
+int32_t mhte_table_row_floats(const mhte_multi_table* t, int32_t i);
+
+/* ---- caller-side dedup / packing ops on the device ------------------------------------------ */
+typedef struct mhte_dedup_ws mhte_dedup_ws;
+mhte_status mhte_dedup_ws_create(int32_t device, mhte_dedup_ws** out);
+void mhte_dedup_ws_destroy(mhte_dedup_ws* ws);
+
+/* Device form of the per-table dedup inside MonolithUniqueKeyWithValueAndOffset
+ * (RT/ops/unique_mapping_ops.cc:82-114) and FusedReorderByIndices (RT/ops/fused_reorder_by_indices.cc
+ * :52-60): unique ids in FIRST-OCCURRENCE order, the unique index of every position, and each
+ * unique id's occurrence positions in occurrence order (CSR).
+ *   ids [dev,n] -> unique_ids [dev, cap n], inverse [dev u32, n], seg_off [dev u32, n+1],
+ *   seg_pos [dev u32, n], n_unique_dev [dev u32, 1].
+ * n_unique_host (optional, host): filled after synchronising the stream. */
+mhte_status mhte_unique(mhte_dedup_ws* ws, const int64_t* ids, int64_t n, int64_t* unique_ids,
+                        uint32_t* inverse, uint32_t* seg_off, uint32_t* seg_pos,
+                        uint32_t* n_unique_dev, int64_t* n_unique_host, void* stream);
+/* FillWithOffsetMap in gather form (RT/ops/unique_mapping_ops.cc:225-242):
+ * out[p,:] = src[index[p],:] for p < n. */
+mhte_status mhte_gather_rows(const float* src, const uint32_t* index, int64_t n, int32_t dim,
+                             float* out, void* stream);
+/* FillWithOffsetMapGradient (RT/ops/unique_mapping_ops.cc:307-324): out[u,:] = sum over the
+ * occurrence list of u of grads[p,:].  exact_order != 0: strictly sequential sum (bit-exact with
+ * the reference); 0: windowed deterministic sum (fp32 re-association only). */
+mhte_status mhte_segment_sum(mhte_dedup_ws* ws, const float* grads, const uint32_t* inverse,
+                             const uint32_t* seg_off, const uint32_t* seg_pos,
+                             const uint32_t* n_unique_dev, int64_t n, int32_t dim, float* out,
+                             int32_t exact_order, void* stream);
+/* Lookup / optimize of ONE table taking the id count from device memory (n_dev may be NULL):
+ * lets dedup -> lookup -> ... -> optimize run without a host round trip. */
+mhte_status mhte_table_lookup_n(mhte_multi_table* t, int32_t table, const int64_t* id,
+                                int64_t n_max, const uint32_t* n_dev, float* embedding,
+                                void* stream);
+mhte_status mhte_table_optimize_n(mhte_multi_table* t, int32_t table, const int64_t* id,
+                                  int64_t n_max, const uint32_t* n_dev, const float* value,
+                                  const float* learning_rate, int64_t n_learning_rate,
+                                  int64_t update_time, int64_t global_step, int32_t flags,
+                                  void* stream);
+
+/* MonolithUniqueKeyWithValueAndOffset (RT/ops/unique_mapping_ops.cc:51-155), one table at a time:
+ * value_offset[q] = value_base + position*dim for the occurrence lists, value_offset_split[u] =
+ * split_base + list start.  Inputs are the outputs of mhte_unique. */
+mhte_status mhte_value_offsets(const uint32_t* seg_off, const uint32_t* seg_pos,
+                               const uint32_t* n_unique_dev, int64_t n, int64_t value_base,
+                               int64_t dim, int64_t split_base, int64_t* value_offset,
+                               int64_t* value_offset_split, void* stream);
+
+/* MonolithFillWithOffsetMap / MonolithFillWithOffsetMapGradient for ONE table
+ * (RT/ops/unique_mapping_ops.cc:204-329).  pos [dev,n] indexes the unique-key list whose float
+ * offsets into the flat buffer are offset_map[split[pos] .. split[pos+1]); value / backprop_grad
+ * are [n, dim].  offsets_vec4 != 0 asserts that every offset is a multiple of 4 floats.
+ * The reference's `pos < map size` InvalidArgument check is the caller's responsibility here. */
+mhte_status mhte_fill_with_offset_map(const int64_t* pos, int64_t n, const float* value,
+                                      const int64_t* value_offset_map,
+                                      const int64_t* value_offset_map_split, int32_t dim,
+                                      int32_t offsets_vec4, float* value_buffer, void* stream);
+mhte_status mhte_fill_with_offset_map_gradient(const int64_t* pos, int64_t n, const float* grad,
+                                               const int64_t* grad_offset_map,
+                                               const int64_t* grad_offset_map_split, int32_t dim,
+                                               int32_t offsets_vec4, float* backprop_grad,
+                                               void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONOLITH_AMD_HASH_TABLE_H_ */

@@ -1,0 +1,157 @@
+"""ctypes binding of libmhte.so (include/monolith_amd_hash_table.h).  Fails loudly when the HIP
+extension is missing: the product has no CPU or PyTorch fallback."""
+import ctypes as C
+import os
+import subprocess
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_DIR, "libmhte.so")
+_SRC = os.path.join(_DIR, "csrc", "mhte.hip")
+_DEPS = [_SRC, os.path.join(_DIR, "csrc", "mhte_kernels.h"), os.path.join(_DIR, "csrc", "mhte_core.h"),
+         os.path.join(_DIR, "..", "include", "monolith_amd_hash_table.h")]
+
+MHTE_OK = 0
+MHTE_INVALID_ARGUMENT = 3
+MHTE_NOT_FOUND = 5
+MHTE_RESOURCE_EXHAUSTED = 8
+MHTE_FAILED_PRECONDITION = 9
+MHTE_INTERNAL = 13
+MHTE_UNAVAILABLE = 14
+
+MHTE_IDS_UNIQUE = 1
+MHTE_SUM_DUPLICATES = 2
+
+OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
+INIT_ZEROS, INIT_ONES, INIT_CONSTANT = 0, 1, 2
+
+
+class MhteError(RuntimeError):
+  """Raised for every non-OK status; ``code`` is the TensorFlow error code the reference op would
+  have produced (InvalidArgument = 3, ResourceExhausted = 8, ...)."""
+
+  def __init__(self, code, msg):
+    super().__init__("[mhte status %d] %s" % (code, msg))
+    self.code = code
+
+
+class InvalidArgumentError(MhteError):
+  pass
+
+
+class ResourceExhaustedError(MhteError):
+  pass
+
+
+class SegmentConfig(C.Structure):
+  _fields_ = [("dim_size", C.c_int32), ("opt_type", C.c_int32), ("opt_params", C.c_float * 4),
+              ("init_type", C.c_int32), ("init_value", C.c_float)]
+
+
+class TableConfig(C.Structure):
+  _fields_ = [("name", C.c_char_p), ("n_segments", C.c_int32),
+              ("segments", C.POINTER(SegmentConfig)), ("initial_capacity", C.c_uint64),
+              ("reserve_rows", C.c_uint64), ("max_load_factor", C.c_float),
+              ("default_expire_days", C.c_int64), ("n_slot_expire", C.c_int32),
+              ("expire_slots", C.POINTER(C.c_int64)), ("expire_days", C.POINTER(C.c_int32))]
+
+
+class TableStats(C.Structure):
+  _fields_ = [("size", C.c_int64), ("hashpower", C.c_int32), ("rows_allocated", C.c_int64),
+              ("lookup_hits", C.c_int64), ("dropped", C.c_int64), ("evicted", C.c_int64),
+              ("max_update_ts", C.c_int64), ("bytes_buckets", C.c_int64),
+              ("bytes_rows", C.c_int64)]
+
+
+def library_path():
+  return _SO
+
+
+def _stale():
+  if not os.path.exists(_SO):
+    return True
+  t = os.path.getmtime(_SO)
+  return any(os.path.exists(d) and os.path.getmtime(d) > t for d in _DEPS)
+
+
+def build_library(force=False, verbose=False):
+  """hipcc --offload-arch=gfx950 cross-compiles without a GPU; output stays in-tree."""
+  if not force and not _stale():
+    return _SO
+  cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared",
+         "-fPIC", "-o", _SO, _SRC]
+  if verbose:
+    print(" ".join(cmd))
+  subprocess.check_call(cmd)
+  return _SO
+
+
+# every symbol include/monolith_amd_hash_table.h declares
+EXPORTS = [
+    "mhte_last_error", "mhte_abi_version", "mhte_multi_table_create", "mhte_multi_table_destroy",
+    "mhte_num_tables", "mhte_table_name", "mhte_table_dim", "mhte_table_slice_size",
+    "mhte_table_index", "mhte_shared_name", "mhte_lookup", "mhte_optimize", "mhte_assign",
+    "mhte_assign_add", "mhte_reinitialize", "mhte_compute_fused_offsets", "mhte_fused_lookup",
+    "mhte_fused_optimize", "mhte_table_size", "mhte_table_contains", "mhte_table_evict",
+    "mhte_table_get_stats", "mhte_table_dump", "mhte_table_row_floats", "mhte_dedup_ws_create",
+    "mhte_dedup_ws_destroy", "mhte_unique", "mhte_gather_rows", "mhte_segment_sum",
+    "mhte_table_lookup_n", "mhte_table_optimize_n", "mhte_value_offsets",
+    "mhte_fill_with_offset_map", "mhte_fill_with_offset_map_gradient",
+]
+
+_lib = None
+
+
+def lib():
+  """Loads libmhte.so (building it first if the sources are newer).  Raises if unavailable."""
+  global _lib
+  if _lib is None:
+    if _stale():
+      try:
+        build_library()
+      except Exception as e:  # pylint: disable=broad-except
+        if not os.path.exists(_SO):
+          raise MhteError(MHTE_UNAVAILABLE,
+                          "libmhte.so is missing and could not be built (%s); the MI355X engine "
+                          "has no fallback path" % e)
+    L = C.CDLL(_SO)
+    for name in EXPORTS:
+      if not hasattr(L, name):
+        raise MhteError(MHTE_INTERNAL, "libmhte.so does not export %s" % name)
+    L.mhte_last_error.restype = C.c_char_p
+    for name in ("mhte_table_name", "mhte_shared_name"):
+      getattr(L, name).restype = C.c_char_p
+    L.mhte_multi_table_destroy.restype = None
+    L.mhte_dedup_ws_destroy.restype = None
+    L.mhte_multi_table_destroy.argtypes = [C.c_void_p]
+    L.mhte_dedup_ws_destroy.argtypes = [C.c_void_p]
+    for name in ("mhte_num_tables",):
+      getattr(L, name).argtypes = [C.c_void_p]
+    for name in ("mhte_table_name", "mhte_table_dim", "mhte_table_slice_size",
+                 "mhte_table_row_floats"):
+      getattr(L, name).argtypes = [C.c_void_p, C.c_int32]
+    L.mhte_table_index.argtypes = [C.c_void_p, C.c_char_p]
+    L.mhte_shared_name.argtypes = [C.c_void_p]
+    if L.mhte_abi_version() != 1:
+      raise MhteError(MHTE_INTERNAL, "libmhte.so ABI version mismatch")
+    _lib = L
+  return _lib
+
+
+def check(status):
+  if status == MHTE_OK:
+    return
+  msg = lib().mhte_last_error().decode("utf-8", "replace")
+  if status == MHTE_INVALID_ARGUMENT:
+    raise InvalidArgumentError(status, msg)
+  if status == MHTE_RESOURCE_EXHAUSTED:
+    raise ResourceExhaustedError(status, msg)
+  raise MhteError(status, msg)
+
+
+def vp(x):
+  """torch tensor / int / None -> c_void_p"""
+  if x is None:
+    return C.c_void_p(0)
+  if isinstance(x, int):
+    return C.c_void_p(x)
+  return C.c_void_p(x.data_ptr())

@@ -1,0 +1,1042 @@
+// libmhte.so — MI355X-native MultiHashTable engine: host side + C ABI (include/monolith_amd_hash_table.h).
+//
+// Host responsibilities (everything else is in mhte_kernels.h):
+//   * table geometry in HBM: bucket array (2^hp x 64 B), row slabs, counters
+//   * proactive doubling (load factor <= max_load_factor) so the fast insert path never needs the
+//     reference's "double when displacement fails" (cuckoohash_map.hpp:1296-1299) mid-kernel
+//   * the MultiHashTable op loop over tables sorted by name
+//     (RT/ops/multi_hash_table_{lookup,update}_op.cc), argument checks and status mapping
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC mhte.hip
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/monolith_amd_hash_table.h"
+#include "mhte_kernels.h"
+
+namespace mhte {
+
+// ------------------------------------------------------------------------------------------ errors
+struct Error : std::runtime_error {
+  mhte_status code;
+  Error(mhte_status c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+static thread_local std::string g_last_error;
+
+#define HIP_OK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess) {                                                                  \
+      throw Error(e__ == hipErrorOutOfMemory ? MHTE_RESOURCE_EXHAUSTED : MHTE_UNAVAILABLE,    \
+                  std::string(#expr) + ": " + hipGetErrorString(e__));                        \
+    }                                                                                         \
+  } while (0)
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  void reserve(size_t n) {
+    if (n <= cap) return;
+    if (p) {
+      HIP_OK(hipDeviceSynchronize());
+      HIP_OK(hipFree(p));
+      p = nullptr;
+    }
+    size_t want = std::max<size_t>(n, cap * 2);
+    HIP_OK(hipMalloc(&p, want * sizeof(T)));
+    cap = want;
+  }
+};
+
+static inline uint32_t ceil_log2(uint64_t n) {
+  uint32_t l = 0;
+  while ((uint64_t(1) << l) < n) ++l;
+  return l;
+}
+
+// ------------------------------------------------------------------------------------------ dedup ws
+struct DedupWs {
+  int device = 0;
+  DevBuf<int64_t> hkey;
+  DevBuf<uint32_t> hmin, hcnt, huidx, hcur, slot_of, tile_a, tile_b, heavy, heavy_n;
+  DevBuf<float> part;
+  DevBuf<uint32_t> last_u;
+
+  DedupView view(int64_t n) {
+    uint32_t C = 1u << std::max<uint32_t>(10, ceil_log2(uint64_t(2) * n));
+    hkey.reserve(size_t(C) + 2);
+    hmin.reserve(size_t(C) + 2);
+    hcnt.reserve(size_t(C) + 2);
+    huidx.reserve(size_t(C) + 2);
+    hcur.reserve(size_t(C) + 2);
+    slot_of.reserve(n + 1);
+    size_t ntiles = (n + kDdTile - 1) / kDdTile + 1;
+    tile_a.reserve(ntiles);
+    tile_b.reserve(ntiles);
+    heavy.reserve(n / (kLightMax + 1) + 2);
+    heavy_n.reserve(4);
+    DedupView d;
+    d.hkey = hkey.p; d.hmin = hmin.p; d.hcnt = hcnt.p; d.huidx = huidx.p; d.hcur = hcur.p;
+    d.slot_of = slot_of.p; d.tile_a = tile_a.p; d.tile_b = tile_b.p; d.heavy = heavy.p;
+    d.heavy_n = heavy_n.p; d.cap_mask = C - 1;
+    return d;
+  }
+
+  void unique(const int64_t* ids, int64_t n, int64_t* uids, uint32_t* inverse, uint32_t* seg_off,
+              uint32_t* seg_pos, uint32_t* n_unique_dev, hipStream_t st) {
+    if (n < 0 || n > (int64_t(1) << 31) - 4096)
+      throw Error(MHTE_INVALID_ARGUMENT, "unique: n out of range");
+    if (n == 0) {
+      HIP_OK(hipMemsetAsync(n_unique_dev, 0, sizeof(uint32_t), st));
+      HIP_OK(hipMemsetAsync(seg_off, 0, sizeof(uint32_t), st));
+      return;
+    }
+    DedupView d = view(n);
+    const uint32_t un = uint32_t(n);
+    const uint32_t C = d.cap_mask + 1;
+    const uint32_t ntiles = (un + kDdTile - 1) / kDdTile;
+    dd_clear_kernel<<<(C + 2 + 255) / 256, 256, 0, st>>>(d);
+    dd_insert_kernel<<<(un + 255) / 256, 256, 0, st>>>(d, ids, un);
+    dd_tile_kernel<<<ntiles, 256, 0, st>>>(d, un);
+    dd_emit_kernel<<<ntiles, 256, 0, st>>>(d, ids, un, uids, seg_off, n_unique_dev);
+    dd_place_kernel<<<(un + 255) / 256, 256, 0, st>>>(d, un, seg_off, inverse, seg_pos);
+    dd_order_kernel<<<(un + 255) / 256, 256, 0, st>>>(d, n_unique_dev, seg_off, seg_pos);
+    const uint32_t hgrid = std::min<uint32_t>(256, un / (kLightMax + 1) + 1);
+    dd_heavy_kernel<<<hgrid, 1024, 0, st>>>(d, un, inverse, seg_off, seg_pos);
+    HIP_OK(hipGetLastError());
+  }
+};
+
+// pick lanes-per-id and vector width for a row of `dim` floats
+struct Shape {
+  int G;
+  int VEC;
+};
+static Shape pick_shape(uint32_t dim, bool vec_ok) {
+  Shape s;
+  s.VEC = vec_ok ? 4 : 1;
+  uint32_t units = (dim + s.VEC - 1) / s.VEC;
+  uint32_t g = 8;
+  while (g < units && g < 64) g <<= 1;
+  s.G = int(g);
+  return s;
+}
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define DISPATCH_G_VEC(shape, CALL)                                  \
+  do {                                                               \
+    if ((shape).VEC == 4) {                                          \
+      switch ((shape).G) {                                           \
+        case 8: { CALL(8, 4); } break;                               \
+        case 16: { CALL(16, 4); } break;                             \
+        case 32: { CALL(32, 4); } break;                             \
+        default: { CALL(64, 4); } break;                             \
+      }                                                              \
+    } else {                                                         \
+      switch ((shape).G) {                                           \
+        case 8: { CALL(8, 1); } break;                               \
+        case 16: { CALL(16, 1); } break;                             \
+        case 32: { CALL(32, 1); } break;                             \
+        default: { CALL(64, 1); } break;                             \
+      }                                                              \
+    }                                                                \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------ table
+struct Table {
+  std::string name;
+  int device = 0;
+  std::vector<mhte_segment_config> segs;
+  uint32_t dim = 0, row_floats = 0, nseg = 0;
+  bool vec_ok = false;  // every segment boundary (weights and state) is a multiple of 4 floats
+  double max_load = 0.5;
+  TableView view{};
+  uint32_t hp = 0;
+  Bucket* buckets = nullptr;
+  std::vector<float*> chunks;
+  float** d_chunks = nullptr;
+  uint32_t max_chunks = 0;
+  uint32_t chunk_shift = 0;
+  Counters* ctr = nullptr;
+  Counters* h_ctr = nullptr;  // pinned mirror
+  uint64_t keys_upper = 0, rows_upper = 0;
+  int64_t max_update_ts = 0;
+  int64_t default_expire_days = 36500;
+  std::vector<int64_t> expire_slots;
+  std::vector<int32_t> expire_days;
+  DevBuf<int64_t> d_expire_slots;
+  DevBuf<int32_t> d_expire_days;
+  DevBuf<uint32_t> pending;
+  // in-op grouping scratch (ids not declared unique)
+  DedupWs dd;
+  DevBuf<int64_t> g_uids;
+  DevBuf<uint32_t> g_inverse, g_seg_off, g_seg_pos, g_nu;
+  std::mutex mu;
+
+  ~Table() {
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    if (buckets) (void)hipFree(buckets);
+    for (float* c : chunks) (void)hipFree(c);
+    if (d_chunks) (void)hipFree(d_chunks);
+    if (ctr) (void)hipFree(ctr);
+    if (h_ctr) (void)hipHostFree(h_ctr);
+  }
+
+  void init(const mhte_table_config& c, int dev) {
+    device = dev;
+    name = c.name ? c.name : "";
+    if (c.n_segments < 1 || c.n_segments > kMaxSegments)
+      throw Error(MHTE_INVALID_ARGUMENT, "table " + name + ": n_segments must be 1.." +
+                                             std::to_string(kMaxSegments));
+    segs.assign(c.segments, c.segments + c.n_segments);
+    nseg = c.n_segments;
+    dim = 0;
+    for (auto& s : segs) {
+      if (s.dim_size <= 0) throw Error(MHTE_INVALID_ARGUMENT, "segment dim_size must be > 0");
+      if (s.opt_type < MHTE_OPT_SGD || s.opt_type > MHTE_OPT_FTRL)
+        throw Error(MHTE_INVALID_ARGUMENT, "unknown optimizer type " + std::to_string(s.opt_type));
+      if (s.init_type < MHTE_INIT_ZEROS || s.init_type > MHTE_INIT_CONSTANT)
+        throw Error(MHTE_INVALID_ARGUMENT, "unknown initializer type");
+      dim += s.dim_size;
+    }
+    // row = float num[dim] | ctx(seg0) | ctx(seg1) ... (entry_accessor.cc:113-114)
+    uint32_t w = 0, st = dim;
+    vec_ok = true;
+    for (uint32_t i = 0; i < nseg; ++i) {
+      SegDesc& d = view.seg[i];
+      d.dim = segs[i].dim_size;
+      d.w_off = w;
+      d.st_off = st;
+      d.opt = segs[i].opt_type;
+      for (int k = 0; k < 4; ++k) d.p[k] = segs[i].opt_params[k];
+      d.init = segs[i].init_type;
+      d.init_value = segs[i].init_value;
+      if ((d.dim % 4) || (d.w_off % 4) || (d.st_off % 4)) vec_ok = false;
+      w += d.dim;
+      st += (d.opt == kOptAdagrad ? d.dim : (d.opt == kOptFtrl ? 2 * d.dim : 0));
+    }
+    row_floats = st;
+    if (row_floats % 4) vec_ok = false;
+    max_load = (c.max_load_factor > 0.f && c.max_load_factor <= 1.f) ? c.max_load_factor : 0.5;
+    default_expire_days = c.default_expire_days > 0 ? c.default_expire_days : 36500;
+    if (c.n_slot_expire > 0) {
+      expire_slots.assign(c.expire_slots, c.expire_slots + c.n_slot_expire);
+      expire_days.assign(c.expire_days, c.expire_days + c.n_slot_expire);
+      d_expire_slots.reserve(expire_slots.size());
+      d_expire_days.reserve(expire_days.size());
+      HIP_OK(hipMemcpy(d_expire_slots.p, expire_slots.data(), expire_slots.size() * 8,
+                       hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(d_expire_days.p, expire_days.data(), expire_days.size() * 4,
+                       hipMemcpyHostToDevice));
+    }
+    hp = reserve_calc(c.initial_capacity ? c.initial_capacity : 1);
+    if (hp > 34) throw Error(MHTE_INVALID_ARGUMENT, "initial_capacity too large");
+    alloc_buckets(hp, &buckets, nullptr);
+    // row slabs
+    const size_t row_bytes = size_t(row_floats) * 4;
+    if (c.reserve_rows > 0) {
+      chunk_shift = std::max<uint32_t>(10, ceil_log2(c.reserve_rows));
+    } else {
+      uint32_t s = 12;
+      while (s < 24 && (row_bytes << (s + 1)) <= (size_t(64) << 20)) ++s;
+      chunk_shift = s;
+    }
+    if (chunk_shift > 32) throw Error(MHTE_INVALID_ARGUMENT, "reserve_rows too large");
+    max_chunks = chunk_shift >= 32 ? 1u : std::min<uint64_t>(uint64_t(1) << (32 - chunk_shift), 65536);
+    HIP_OK(hipMalloc(&d_chunks, sizeof(float*) * max_chunks));
+    HIP_OK(hipMemset(d_chunks, 0, sizeof(float*) * max_chunks));
+    HIP_OK(hipMalloc(&ctr, sizeof(Counters)));
+    HIP_OK(hipMemset(ctr, 0, sizeof(Counters)));
+    HIP_OK(hipHostMalloc(&h_ctr, sizeof(Counters), hipHostMallocDefault));
+    memset(h_ctr, 0, sizeof(Counters));
+    add_chunk();
+    refresh_view();
+  }
+
+  void alloc_buckets(uint32_t new_hp, Bucket** out, hipStream_t st) {
+    const uint64_t nb = uint64_t(1) << new_hp;
+    HIP_OK(hipMalloc(out, nb * sizeof(Bucket)));
+    clear_buckets_kernel<<<dim3(uint32_t((nb + 255) / 256)), 256, 0, st>>>(*out, nb);
+    HIP_OK(hipGetLastError());
+  }
+
+  void add_chunk() {
+    if (chunks.size() >= max_chunks)
+      throw Error(MHTE_RESOURCE_EXHAUSTED, "table " + name + ": row handle space exhausted");
+    float* p = nullptr;
+    HIP_OK(hipMalloc(&p, (size_t(1) << chunk_shift) * row_floats * sizeof(float)));
+    chunks.push_back(p);
+    HIP_OK(hipMemcpy(d_chunks + (chunks.size() - 1), &p, sizeof(float*), hipMemcpyHostToDevice));
+  }
+
+  void refresh_view() {
+    view.buckets = buckets;
+    view.chunk0 = chunks.empty() ? nullptr : chunks[0];
+    view.chunks = d_chunks;
+    view.ctr = ctr;
+    view.hp = hp;
+    view.chunk_shift = chunk_shift;
+    view.row_floats = row_floats;
+    view.dim = dim;
+    view.nseg = nseg;
+  }
+
+  void sync_counters(hipStream_t st) {
+    HIP_OK(hipMemcpyAsync(h_ctr, ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (h_ctr->error & 1u) {
+      // surfaced once; the reference maps engine exceptions to ResourceExhausted/InvalidArgument
+      unsigned int zero = 0;
+      HIP_OK(hipMemcpy(&ctr->error, &zero, sizeof(zero), hipMemcpyHostToDevice));
+      throw Error(MHTE_RESOURCE_EXHAUSTED,
+                  "table " + name + ": " + std::to_string(h_ctr->n_dropped) +
+                      " ids dropped: no cuckoo path (raise capacity / lower max_load_factor)");
+    }
+  }
+
+  void double_table(hipStream_t st) {
+    if (hp >= 34) throw Error(MHTE_RESOURCE_EXHAUSTED, "table " + name + ": hashpower limit");
+    Bucket* nb = nullptr;
+    const uint64_t n_old = uint64_t(1) << hp;
+    HIP_OK(hipMalloc(&nb, n_old * 2 * sizeof(Bucket)));
+    split_kernel<<<dim3(uint32_t((n_old + 255) / 256)), 256, 0, st>>>(buckets, nb, hp);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipFree(buckets));
+    buckets = nb;
+    ++hp;
+    refresh_view();
+  }
+
+  // Called before every mutating op with the number of ids it may insert.
+  void ensure_capacity(uint64_t n, hipStream_t st) {
+    keys_upper += n;
+    rows_upper += n;
+    const uint64_t row_cap = uint64_t(chunks.size()) << chunk_shift;
+    const bool need_keys = double(keys_upper) > max_load * double(uint64_t(kSlots) << hp);
+    const bool need_rows = rows_upper > row_cap;
+    if (!need_keys && !need_rows) return;
+    sync_counters(st);
+    keys_upper = h_ctr->n_keys + n;
+    rows_upper = uint64_t(h_ctr->next_row) + n;
+    if (h_ctr->n_keys == 0) {
+      // nothing to migrate: jump straight to the needed hashpower
+      uint32_t want = hp;
+      while (double(keys_upper) > max_load * double(uint64_t(kSlots) << want)) ++want;
+      if (want != hp) {
+        if (want > 34) throw Error(MHTE_RESOURCE_EXHAUSTED, "table " + name + ": hashpower limit");
+        HIP_OK(hipFree(buckets));
+        buckets = nullptr;
+        alloc_buckets(want, &buckets, st);
+        hp = want;
+        refresh_view();
+      }
+    }
+    while (double(keys_upper) > max_load * double(uint64_t(kSlots) << hp)) double_table(st);
+    if (rows_upper > (uint64_t(1) << 32) - 2)
+      throw Error(MHTE_RESOURCE_EXHAUSTED, "table " + name + ": more than 2^32 rows");
+    while (rows_upper > (uint64_t(chunks.size()) << chunk_shift)) {
+      add_chunk();
+      refresh_view();
+    }
+  }
+
+  // ---------------------------------------------------------------- lookup
+  void lookup(const int64_t* ids, int64_t n, const uint32_t* n_dev, float* out, hipStream_t st) {
+    if (n <= 0) return;
+    Shape sh = pick_shape(dim, vec_ok && aligned16(out));
+    const int64_t threads = n * sh.G;
+    const dim3 grid(uint32_t((threads + 255) / 256));
+#define CALL(G_, V_) lookup_kernel<G_, V_><<<grid, 256, 0, st>>>(view, ids, n, n_dev, out, 1)
+    DISPATCH_G_VEC(sh, CALL);
+#undef CALL
+    HIP_OK(hipGetLastError());
+  }
+
+  // ---------------------------------------------------------------- upsert + apply
+  template <int OP>
+  void launch_upsert(const int64_t* ids, int64_t n, const uint32_t* n_dev, const float* values,
+                     const uint32_t* seg_off, const uint32_t* seg_pos, const ApplyArgs& a,
+                     int32_t* status, hipStream_t st) {
+    Shape sh = pick_shape(dim, vec_ok && (values == nullptr || aligned16(values)));
+    pending.reserve(size_t(n) + 1);
+    const int64_t threads = n * sh.G;
+    const dim3 grid(uint32_t((threads + 255) / 256));
+    uint32_t* pend = pending.p;
+#define CALL(G_, V_)                                                                         \
+  upsert_kernel<G_, V_, OP><<<grid, 256, 0, st>>>(view, ids, n, n_dev, values, seg_off, seg_pos, \
+                                                  a, status, pend)
+    DISPATCH_G_VEC(sh, CALL);
+#undef CALL
+    if (sh.VEC == 4) {
+      slowpath_kernel<4, OP><<<1, 64, 0, st>>>(view, ids, values, seg_off, seg_pos, a, status, pend);
+    } else {
+      slowpath_kernel<1, OP><<<1, 64, 0, st>>>(view, ids, values, seg_off, seg_pos, a, status, pend);
+    }
+    HIP_OK(hipGetLastError());
+  }
+
+  template <int OP>
+  void upsert(const int64_t* ids, int64_t n, const uint32_t* n_dev, const float* values,
+              const float* lrs, int64_t update_time, int32_t flags, int32_t* status,
+              hipStream_t st) {
+    if (n <= 0) return;
+    if (n > (int64_t(1) << 31) - 4096) throw Error(MHTE_INVALID_ARGUMENT, "too many ids in one op");
+    ApplyArgs a;
+    for (int i = 0; i < kMaxSegments; ++i) a.lr[i] = (lrs && i < int(nseg)) ? lrs[i] : 0.f;
+    a.ts = static_cast<uint32_t>(update_time);
+    a.sum_dups = (flags & MHTE_SUM_DUPLICATES) ? 1 : 0;
+    ensure_capacity(uint64_t(n), st);
+    if (flags & MHTE_IDS_UNIQUE) {
+      launch_upsert<OP>(ids, n, n_dev, values, nullptr, nullptr, a, status, st);
+      return;
+    }
+    if (n_dev) throw Error(MHTE_INVALID_ARGUMENT, "device-side count requires MHTE_IDS_UNIQUE");
+    // in-op grouping: unique ids in first-occurrence order + ordered occurrence lists, then each
+    // id's occurrences are applied in order by one group (sequential semantics of BatchOptimize)
+    g_uids.reserve(n);
+    g_inverse.reserve(n);
+    g_seg_off.reserve(n + 1);
+    g_seg_pos.reserve(n);
+    g_nu.reserve(4);
+    dd.unique(ids, n, g_uids.p, g_inverse.p, g_seg_off.p, g_seg_pos.p, g_nu.p, st);
+    launch_upsert<OP>(g_uids.p, n, g_nu.p, values, g_seg_off.p, g_seg_pos.p, a, status, st);
+  }
+
+  void note_update_time(int64_t update_time) {
+    // fuzzy max, tf_bridge.cc:262-263
+    max_update_ts = std::max(max_update_ts, update_time);
+  }
+
+  void evict(int64_t max_ts, hipStream_t st) {
+    TtlConfig ttl;
+    ttl.default_days = default_expire_days;
+    ttl.n = int32_t(expire_slots.size());
+    ttl.slots = d_expire_slots.p;
+    ttl.days = d_expire_days.p;
+    const uint64_t nslots = (uint64_t(1) << hp) * kSlots;
+    evict_kernel<<<dim3(uint32_t((nslots + 255) / 256)), 256, 0, st>>>(
+        view, max_ts < 0 ? max_update_ts : max_ts, ttl);
+    HIP_OK(hipGetLastError());
+  }
+};
+
+// ------------------------------------------------------------------------------------------ multi table
+}  // namespace mhte
+
+struct mhte_multi_table {
+  int device = 0;
+  std::string shared_name;
+  std::vector<std::unique_ptr<mhte::Table>> tables;  // sorted by name
+};
+struct mhte_dedup_ws {
+  mhte::DedupWs ws;
+};
+
+namespace mhte {
+
+template <class F>
+static mhte_status guard(F&& f) {
+  try {
+    f();
+    return MHTE_OK;
+  } catch (const Error& e) {
+    g_last_error = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return MHTE_INTERNAL;
+  }
+}
+
+static void check_handle(const mhte_multi_table* t) {
+  if (!t) throw Error(MHTE_INVALID_ARGUMENT, "null table handle");
+}
+static Table& table_at(mhte_multi_table* t, int32_t i) {
+  check_handle(t);
+  if (i < 0 || i >= int32_t(t->tables.size()))
+    throw Error(MHTE_INVALID_ARGUMENT, "table index out of range: " + std::to_string(i));
+  return *t->tables[i];
+}
+
+// ragged (id, id_split) over the tables; multi_hash_table_update_op.cc:34-45 error texts
+static void check_split(const mhte_multi_table* t, const int64_t* id_split, int64_t n_split,
+                        const char* what) {
+  check_handle(t);
+  if (!id_split || n_split - 1 != int64_t(t->tables.size()))
+    throw Error(MHTE_INVALID_ARGUMENT,
+                std::string("The length of tensor `") + what + "` doesn't equal to table num. " +
+                    std::to_string(n_split - 1) + "v.s." + std::to_string(t->tables.size()));
+  for (int64_t i = 0; i + 1 < n_split; ++i)
+    if (id_split[i + 1] < id_split[i]) throw Error(MHTE_INVALID_ARGUMENT, "id_split not monotonic");
+}
+
+template <int OP>
+static void ragged_upsert(mhte_multi_table* t, const int64_t* id, const int64_t* id_split,
+                          int64_t n_split, const float* value, int64_t value_len,
+                          const float* learning_rate, int64_t n_lr, int64_t update_time,
+                          int32_t flags, void* stream) {
+  check_split(t, id_split, n_split, "id");
+  HIP_OK(hipSetDevice(t->device));
+  int64_t value_offset = 0, lr_offset = 0;
+  for (size_t i = 0; i < t->tables.size(); ++i) {
+    Table& tb = *t->tables[i];
+    const int64_t num_ids = id_split[i + 1] - id_split[i];
+    const int64_t value_size = num_ids * tb.dim;
+    if (value_offset + value_size > value_len)
+      throw Error(MHTE_INVALID_ARGUMENT, "The length of tensor `value` is too short. Currently value" +
+                                             std::to_string(value_len));
+    const float* lrs = nullptr;
+    if (OP == kOpOptimize) {
+      lrs = learning_rate + lr_offset;
+      lr_offset += tb.nseg;
+      if (lr_offset > n_lr)
+        throw Error(MHTE_INVALID_ARGUMENT,
+                    "The length of tensor `learning_rate` is too short. Currently value" +
+                        std::to_string(n_lr));
+    }
+    std::lock_guard<std::mutex> g(tb.mu);
+    tb.note_update_time(update_time);
+    tb.upsert<OP>(id + id_split[i], num_ids, nullptr, value + value_offset, lrs, update_time, flags,
+                  nullptr, S(stream));
+    value_offset += value_size;
+  }
+}
+
+}  // namespace mhte
+
+using namespace mhte;
+
+extern "C" {
+
+const char* mhte_last_error(void) { return g_last_error.c_str(); }
+int32_t mhte_abi_version(void) { return MHTE_ABI_VERSION; }
+
+mhte_status mhte_multi_table_create(const mhte_table_config* configs, int32_t n_tables,
+                                    int32_t device, const char* shared_name,
+                                    mhte_multi_table** out) {
+  return guard([&] {
+    if (!configs || n_tables <= 0 || !out)
+      throw Error(MHTE_INVALID_ARGUMENT, "create: bad arguments");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+      throw Error(MHTE_UNAVAILABLE, "no HIP device: the MI355X engine has no CPU fallback");
+    if (device < 0 || device >= ndev)
+      throw Error(MHTE_INVALID_ARGUMENT, "device ordinal out of range");
+    HIP_OK(hipSetDevice(device));
+    std::unique_ptr<mhte_multi_table> mt(new mhte_multi_table);
+    mt->device = device;
+    mt->shared_name = shared_name ? shared_name : "";
+    std::vector<int> order(n_tables);
+    for (int i = 0; i < n_tables; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) {
+      return std::string(configs[a].name ? configs[a].name : "") <
+             std::string(configs[b].name ? configs[b].name : "");
+    });
+    for (int i = 0; i < n_tables; ++i) {
+      if (i > 0 && std::string(configs[order[i]].name ? configs[order[i]].name : "") ==
+                       std::string(configs[order[i - 1]].name ? configs[order[i - 1]].name : ""))
+        throw Error(MHTE_INVALID_ARGUMENT, "duplicate table name");
+      std::unique_ptr<Table> tb(new Table);
+      tb->init(configs[order[i]], device);
+      mt->tables.push_back(std::move(tb));
+    }
+    HIP_OK(hipDeviceSynchronize());
+    *out = mt.release();
+  });
+}
+
+void mhte_multi_table_destroy(mhte_multi_table* t) { delete t; }
+int32_t mhte_num_tables(const mhte_multi_table* t) { return t ? int32_t(t->tables.size()) : 0; }
+const char* mhte_table_name(const mhte_multi_table* t, int32_t i) {
+  return (t && i >= 0 && i < int32_t(t->tables.size())) ? t->tables[i]->name.c_str() : "";
+}
+int32_t mhte_table_dim(const mhte_multi_table* t, int32_t i) {
+  return (t && i >= 0 && i < int32_t(t->tables.size())) ? int32_t(t->tables[i]->dim) : -1;
+}
+int32_t mhte_table_slice_size(const mhte_multi_table* t, int32_t i) {
+  return (t && i >= 0 && i < int32_t(t->tables.size())) ? int32_t(t->tables[i]->nseg) : -1;
+}
+int32_t mhte_table_row_floats(const mhte_multi_table* t, int32_t i) {
+  return (t && i >= 0 && i < int32_t(t->tables.size())) ? int32_t(t->tables[i]->row_floats) : -1;
+}
+int32_t mhte_table_index(const mhte_multi_table* t, const char* name) {
+  if (!t || !name) return -1;
+  for (size_t i = 0; i < t->tables.size(); ++i)
+    if (t->tables[i]->name == name) return int32_t(i);
+  return -1;
+}
+const char* mhte_shared_name(const mhte_multi_table* t) { return t ? t->shared_name.c_str() : ""; }
+
+mhte_status mhte_lookup(mhte_multi_table* t, const int64_t* id, const int64_t* id_split,
+                        int64_t n_split, float* embedding, int64_t embedding_len, void* stream) {
+  return guard([&] {
+    check_handle(t);
+    if (!id_split || n_split != int64_t(t->tables.size()) + 1)
+      throw Error(MHTE_INVALID_ARGUMENT, "table size: " + std::to_string(t->tables.size()) +
+                                             ". Error id_split size: " + std::to_string(n_split));
+    HIP_OK(hipSetDevice(t->device));
+    int64_t emb_size = 0;
+    for (size_t i = 0; i < t->tables.size(); ++i) {
+      if (id_split[i + 1] < id_split[i]) throw Error(MHTE_INVALID_ARGUMENT, "id_split not monotonic");
+      emb_size += (id_split[i + 1] - id_split[i]) * t->tables[i]->dim;
+    }
+    if (emb_size > embedding_len)
+      throw Error(MHTE_INVALID_ARGUMENT, "embedding buffer too short: need " +
+                                             std::to_string(emb_size));
+    int64_t off = 0;
+    for (size_t i = 0; i < t->tables.size(); ++i) {
+      Table& tb = *t->tables[i];
+      const int64_t num_ids = id_split[i + 1] - id_split[i];
+      std::lock_guard<std::mutex> g(tb.mu);
+      tb.lookup(id + id_split[i], num_ids, nullptr, embedding + off, S(stream));
+      off += num_ids * tb.dim;
+    }
+  });
+}
+
+mhte_status mhte_optimize(mhte_multi_table* t, const int64_t* id, const int64_t* id_split,
+                          int64_t n_split, const float* value, int64_t value_len,
+                          const float* learning_rate, int64_t n_learning_rate, int64_t update_time,
+                          int64_t global_step, int32_t flags, void* stream) {
+  (void)global_step;  // consumed only by optimizers with warmup/step-dependent terms (not SGD/Adagrad/FTRL)
+  return guard([&] {
+    if (!learning_rate) throw Error(MHTE_INVALID_ARGUMENT, "learning_rate is null");
+    ragged_upsert<kOpOptimize>(t, id, id_split, n_split, value, value_len, learning_rate,
+                               n_learning_rate, update_time, flags, stream);
+  });
+}
+
+mhte_status mhte_assign(mhte_multi_table* t, const int64_t* id, const int64_t* id_split,
+                        int64_t n_split, const float* value, int64_t value_len, int64_t update_time,
+                        int32_t flags, void* stream) {
+  return guard([&] {
+    ragged_upsert<kOpAssign>(t, id, id_split, n_split, value, value_len, nullptr, 0, update_time,
+                             flags, stream);
+  });
+}
+
+mhte_status mhte_assign_add(mhte_multi_table* t, const int64_t* id, const int64_t* id_split,
+                            int64_t n_split, const float* value, int64_t value_len,
+                            int64_t update_time, int32_t flags, void* stream) {
+  return guard([&] {
+    ragged_upsert<kOpAssignAdd>(t, id, id_split, n_split, value, value_len, nullptr, 0, update_time,
+                                flags, stream);
+  });
+}
+
+mhte_status mhte_reinitialize(mhte_multi_table* t, const char* table_name, const int64_t* id,
+                              int64_t n, int32_t* id_status, int64_t now, void* stream) {
+  return guard([&] {
+    check_handle(t);
+    HIP_OK(hipSetDevice(t->device));
+    if (n <= 0) return;
+    // -1: table_name does not exist (not an error, multi_hash_table_update_op.cc:209-220)
+    HIP_OK(hipMemsetAsync(id_status, 0xff, sizeof(int32_t) * n, S(stream)));
+    const int32_t idx = mhte_table_index(t, table_name);
+    if (idx < 0) {
+      fprintf(stderr, "[mhte] table %s does not exist!\n", table_name ? table_name : "(null)");
+      return;
+    }
+    Table& tb = *t->tables[idx];
+    if (now == 0) {
+      now = std::chrono::duration_cast<std::chrono::seconds>(
+                std::chrono::system_clock::now().time_since_epoch()).count();
+    }
+    std::lock_guard<std::mutex> g(tb.mu);
+    tb.upsert<kOpReinit>(id, n, nullptr, nullptr, nullptr, now, 0, id_status, S(stream));
+  });
+}
+
+mhte_status mhte_compute_fused_offsets(const mhte_multi_table* t, const int32_t* fused_slot_size,
+                                       int32_t num_of_shards, int32_t* id_offsets,
+                                       int32_t* embedding_offsets, int32_t* embedding_splits,
+                                       int64_t* total_ids, int64_t* total_embeddings) {
+  return guard([&] {
+    check_handle(t);
+    if (!fused_slot_size || num_of_shards <= 0)
+      throw Error(MHTE_INVALID_ARGUMENT, "fused offsets: bad arguments");
+    const int T = int(t->tables.size());
+    int64_t tk = 0, te = 0, prev = 0;
+    if (id_offsets) id_offsets[0] = 0;
+    if (embedding_offsets) embedding_offsets[0] = 0;
+    for (int s = 0; s < num_of_shards; ++s) {
+      for (int k = 0; k < T; ++k) {
+        const int idx = T * s + k;
+        const int sz = fused_slot_size[idx];
+        if (sz < 0) throw Error(MHTE_INVALID_ARGUMENT, "negative fused_slot_size");
+        tk += sz;
+        te += int64_t(sz) * t->tables[k]->dim;
+        if (te > INT32_MAX) throw Error(MHTE_INVALID_ARGUMENT, "fused embedding size exceeds int32");
+        if (id_offsets) id_offsets[idx + 1] = int32_t(tk);
+        if (embedding_offsets) embedding_offsets[idx + 1] = int32_t(te);
+      }
+      if (embedding_splits) embedding_splits[s] = int32_t(te - prev);
+      prev = te;
+    }
+    if (total_ids) *total_ids = tk;
+    if (total_embeddings) *total_embeddings = te;
+  });
+}
+
+mhte_status mhte_fused_lookup(mhte_multi_table* t, const int64_t* ids,
+                              const int32_t* fused_slot_size, int32_t num_of_shards,
+                              int64_t req_time, float* embeddings, int64_t embeddings_len,
+                              int32_t* embedding_splits, int32_t* id_offsets,
+                              int32_t* embedding_offsets, void* stream) {
+  (void)req_time;
+  return guard([&] {
+    check_handle(t);
+    const int T = int(t->tables.size());
+    std::vector<int32_t> ko(size_t(T) * num_of_shards + 1), eo(size_t(T) * num_of_shards + 1),
+        es(num_of_shards);
+    int64_t tk = 0, te = 0;
+    mhte_status st = mhte_compute_fused_offsets(t, fused_slot_size, num_of_shards, ko.data(),
+                                                eo.data(), es.data(), &tk, &te);
+    if (st != MHTE_OK) throw Error(st, g_last_error);
+    if (te > embeddings_len)
+      throw Error(MHTE_INVALID_ARGUMENT, "embeddings buffer too short: need " + std::to_string(te));
+    HIP_OK(hipSetDevice(t->device));
+    for (int s = 0; s < num_of_shards; ++s) {
+      for (int k = 0; k < T; ++k) {
+        const int idx = s * T + k;
+        Table& tb = *t->tables[k];
+        std::lock_guard<std::mutex> g(tb.mu);
+        tb.lookup(ids + ko[idx], fused_slot_size[idx], nullptr, embeddings + eo[idx], S(stream));
+      }
+    }
+    if (embedding_splits) memcpy(embedding_splits, es.data(), sizeof(int32_t) * es.size());
+    if (id_offsets) memcpy(id_offsets, ko.data(), sizeof(int32_t) * ko.size());
+    if (embedding_offsets) memcpy(embedding_offsets, eo.data(), sizeof(int32_t) * eo.size());
+  });
+}
+
+mhte_status mhte_fused_optimize(mhte_multi_table* t, const int64_t* ids,
+                                const int32_t* fused_slot_size, const float* id_grads,
+                                int64_t id_grads_len, const int32_t* id_offsets,
+                                const int32_t* grad_offsets, const float* learning_rates,
+                                int64_t n_learning_rates, int64_t req_time, int64_t global_step,
+                                int32_t num_of_shards, int32_t flags, void* stream) {
+  (void)global_step;
+  return guard([&] {
+    check_handle(t);
+    if (!fused_slot_size || !id_offsets || !grad_offsets || !learning_rates)
+      throw Error(MHTE_INVALID_ARGUMENT, "fused optimize: null argument");
+    const int T = int(t->tables.size());
+    int64_t need_lr = 0;
+    for (int k = 0; k < T; ++k) need_lr += t->tables[k]->nseg;
+    if (need_lr > n_learning_rates)
+      throw Error(MHTE_INVALID_ARGUMENT, "learning_rate_tensors too short");
+    HIP_OK(hipSetDevice(t->device));
+    for (int s = 0; s < num_of_shards; ++s) {
+      int64_t lr_off = 0;  // restarts per shard, multi_hash_table_update_op.cc:285-293
+      for (int k = 0; k < T; ++k) {
+        const int idx = s * T + k;
+        Table& tb = *t->tables[k];
+        const float* lrs = learning_rates + lr_off;
+        lr_off += tb.nseg;
+        const int64_t n = fused_slot_size[idx];
+        if (int64_t(grad_offsets[idx]) + n * tb.dim > id_grads_len)
+          throw Error(MHTE_INVALID_ARGUMENT, "id_grads too short");
+        std::lock_guard<std::mutex> g(tb.mu);
+        tb.note_update_time(req_time);
+        tb.upsert<kOpOptimize>(ids + id_offsets[idx], n, nullptr, id_grads + grad_offsets[idx], lrs,
+                               req_time, flags, nullptr, S(stream));
+      }
+    }
+  });
+}
+
+mhte_status mhte_table_size(mhte_multi_table* t, int32_t table, int64_t* size, void* stream) {
+  return guard([&] {
+    Table& tb = table_at(t, table);
+    HIP_OK(hipSetDevice(t->device));
+    std::lock_guard<std::mutex> g(tb.mu);
+    tb.sync_counters(S(stream));
+    *size = int64_t(tb.h_ctr->n_keys) + (tb.h_ctr->special_state ? 1 : 0);
+  });
+}
+
+namespace mhte {
+__global__ __launch_bounds__(256) void contains_kernel(TableView tv, const int64_t* __restrict__ ids,
+                                                       int64_t n, int32_t* __restrict__ out) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t id = ids[i];
+  if (id == kEmptyKey) {
+    out[i] = tv.ctr->special_state == 1;
+    return;
+  }
+  const uint64_t hv = hash_key(id);
+  const uint64_t i1 = index_hash(tv.hp, hv);
+  const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
+  int found = 0;
+  for (int s = 0; s < kSlots; ++s) {
+    found |= (tv.buckets[i1].key[s] == id);
+    found |= (tv.buckets[i2].key[s] == id);
+  }
+  out[i] = found;
+}
+}  // namespace mhte
+
+mhte_status mhte_table_contains(mhte_multi_table* t, int32_t table, const int64_t* id, int64_t n,
+                                int32_t* out, void* stream) {
+  return guard([&] {
+    Table& tb = table_at(t, table);
+    HIP_OK(hipSetDevice(t->device));
+    if (n <= 0) return;
+    std::lock_guard<std::mutex> g(tb.mu);
+    contains_kernel<<<dim3(uint32_t((n + 255) / 256)), 256, 0, S(stream)>>>(tb.view, id, n, out);
+    HIP_OK(hipGetLastError());
+  });
+}
+
+mhte_status mhte_table_evict(mhte_multi_table* t, int32_t table, int64_t max_update_time,
+                             void* stream) {
+  return guard([&] {
+    Table& tb = table_at(t, table);
+    HIP_OK(hipSetDevice(t->device));
+    std::lock_guard<std::mutex> g(tb.mu);
+    tb.evict(max_update_time, S(stream));
+  });
+}
+
+mhte_status mhte_table_get_stats(mhte_multi_table* t, int32_t table, mhte_table_stats* out,
+                                 void* stream) {
+  return guard([&] {
+    Table& tb = table_at(t, table);
+    HIP_OK(hipSetDevice(t->device));
+    std::lock_guard<std::mutex> g(tb.mu);
+    tb.sync_counters(S(stream));
+    out->size = int64_t(tb.h_ctr->n_keys) + (tb.h_ctr->special_state ? 1 : 0);
+    out->hashpower = int32_t(tb.hp);
+    out->rows_allocated = tb.h_ctr->next_row;
+    out->lookup_hits = int64_t(tb.h_ctr->hits);
+    out->dropped = tb.h_ctr->n_dropped;
+    out->evicted = tb.h_ctr->n_evicted;
+    out->max_update_ts = tb.max_update_ts;
+    out->bytes_buckets = int64_t(sizeof(Bucket)) << tb.hp;
+    out->bytes_rows = int64_t(tb.chunks.size()) * (int64_t(tb.row_floats) * 4 << tb.chunk_shift);
+    unsigned long long zero = 0;
+    HIP_OK(hipMemcpy(&tb.ctr->hits, &zero, sizeof(zero), hipMemcpyHostToDevice));
+  });
+}
+
+mhte_status mhte_table_dump(mhte_multi_table* t, int32_t table, int64_t cap, int64_t* ids,
+                            int64_t* positions, uint32_t* ts, float* rows, int64_t* n_out,
+                            void* stream) {
+  return guard([&] {
+    Table& tb = table_at(t, table);
+    HIP_OK(hipSetDevice(t->device));
+    std::lock_guard<std::mutex> g(tb.mu);
+    hipStream_t st = S(stream);
+    const uint64_t nslots = (uint64_t(1) << tb.hp) * kSlots;
+    const uint32_t nblocks = uint32_t((nslots + 1023) / 1024);
+    DevBuf<uint32_t> bc;
+    DevBuf<uint64_t> bo;
+    bc.reserve(nblocks);
+    bo.reserve(nblocks);
+    dump_count_kernel<<<nblocks, 256, 0, st>>>(tb.view, bc.p);
+    HIP_OK(hipGetLastError());
+    std::vector<uint32_t> hc(nblocks);
+    HIP_OK(hipMemcpyAsync(hc.data(), bc.p, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    std::vector<uint64_t> ho(nblocks);
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < nblocks; ++i) {
+      ho[i] = acc;
+      acc += hc[i];
+    }
+    *n_out = int64_t(acc);
+    if (int64_t(acc) > cap)
+      throw Error(MHTE_INVALID_ARGUMENT, "dump buffers too small: need " + std::to_string(acc));
+    if (acc == 0) return;
+    HIP_OK(hipMemcpyAsync(bo.p, ho.data(), sizeof(uint64_t) * nblocks, hipMemcpyHostToDevice, st));
+    dump_emit_kernel<<<nblocks, 256, 0, st>>>(tb.view, bo.p, ids, positions, ts, rows);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(st));
+  });
+}
+
+// ---- dedup / packing ops ---------------------------------------------------------------------
+mhte_status mhte_dedup_ws_create(int32_t device, mhte_dedup_ws** out) {
+  return guard([&] {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+      throw Error(MHTE_UNAVAILABLE, "no such HIP device");
+    mhte_dedup_ws* w = new mhte_dedup_ws;
+    w->ws.device = device;
+    *out = w;
+  });
+}
+void mhte_dedup_ws_destroy(mhte_dedup_ws* ws) { delete ws; }
+
+mhte_status mhte_unique(mhte_dedup_ws* ws, const int64_t* ids, int64_t n, int64_t* unique_ids,
+                        uint32_t* inverse, uint32_t* seg_off, uint32_t* seg_pos,
+                        uint32_t* n_unique_dev, int64_t* n_unique_host, void* stream) {
+  return guard([&] {
+    if (!ws) throw Error(MHTE_INVALID_ARGUMENT, "null workspace");
+    HIP_OK(hipSetDevice(ws->ws.device));
+    ws->ws.unique(ids, n, unique_ids, inverse, seg_off, seg_pos, n_unique_dev, S(stream));
+    if (n_unique_host) {
+      uint32_t u = 0;
+      HIP_OK(hipMemcpyAsync(&u, n_unique_dev, sizeof(u), hipMemcpyDeviceToHost, S(stream)));
+      HIP_OK(hipStreamSynchronize(S(stream)));
+      *n_unique_host = u;
+    }
+  });
+}
+
+mhte_status mhte_gather_rows(const float* src, const uint32_t* index, int64_t n, int32_t dim,
+                             float* out, void* stream) {
+  return guard([&] {
+    if (n <= 0) return;
+    if (dim <= 0) throw Error(MHTE_INVALID_ARGUMENT, "dim must be > 0");
+    Shape sh = pick_shape(uint32_t(dim), dim % 4 == 0 && aligned16(src) && aligned16(out));
+    const dim3 grid(uint32_t((n * sh.G + 255) / 256));
+    hipStream_t st = S(stream);
+#define CALL(G_, V_) gather_rows_kernel<G_, V_><<<grid, 256, 0, st>>>(src, index, n, uint32_t(dim), out)
+    DISPATCH_G_VEC(sh, CALL);
+#undef CALL
+    HIP_OK(hipGetLastError());
+  });
+}
+
+mhte_status mhte_segment_sum(mhte_dedup_ws* ws, const float* grads, const uint32_t* inverse,
+                             const uint32_t* seg_off, const uint32_t* seg_pos,
+                             const uint32_t* n_unique_dev, int64_t n, int32_t dim, float* out,
+                             int32_t exact_order, void* stream) {
+  return guard([&] {
+    if (!ws) throw Error(MHTE_INVALID_ARGUMENT, "null workspace");
+    if (n <= 0) return;
+    if (dim <= 0) throw Error(MHTE_INVALID_ARGUMENT, "dim must be > 0");
+    HIP_OK(hipSetDevice(ws->ws.device));
+    hipStream_t st = S(stream);
+    Shape sh = pick_shape(uint32_t(dim), dim % 4 == 0 && aligned16(grads) && aligned16(out));
+    if (exact_order) {
+      const dim3 grid(uint32_t((n * sh.G + 255) / 256));
+#define CALL(G_, V_) \
+  segsum_exact_kernel<G_, V_><<<grid, 256, 0, st>>>(grads, n_unique_dev, seg_off, seg_pos, uint32_t(dim), out)
+      DISPATCH_G_VEC(sh, CALL);
+#undef CALL
+    } else {
+      const int win = sh.G < 16 ? sh.G : 16;
+      const int64_t nwin = (n + win - 1) / win;
+      ws->ws.part.reserve(size_t(nwin) * 2 * dim + 16);
+      ws->ws.last_u.reserve(nwin + 1);
+      float* part = ws->ws.part.p;
+      uint32_t* last_u = ws->ws.last_u.p;
+      const dim3 grid(uint32_t((nwin * sh.G + 255) / 256));
+#define CALL(G_, V_)                                                                         \
+  segsum_window_kernel<G_, V_><<<grid, 256, 0, st>>>(grads, inverse, seg_off, seg_pos, uint32_t(n), \
+                                                     uint32_t(dim), out, part, last_u);      \
+  segsum_combine_kernel<G_, V_><<<dim3(uint32_t(nwin)), 256, 0, st>>>(seg_off, last_u, uint32_t(dim), out, part)
+      DISPATCH_G_VEC(sh, CALL);
+#undef CALL
+    }
+    HIP_OK(hipGetLastError());
+  });
+}
+
+mhte_status mhte_table_lookup_n(mhte_multi_table* t, int32_t table, const int64_t* id,
+                                int64_t n_max, const uint32_t* n_dev, float* embedding,
+                                void* stream) {
+  return guard([&] {
+    Table& tb = table_at(t, table);
+    HIP_OK(hipSetDevice(t->device));
+    std::lock_guard<std::mutex> g(tb.mu);
+    tb.lookup(id, n_max, n_dev, embedding, S(stream));
+  });
+}
+
+mhte_status mhte_table_optimize_n(mhte_multi_table* t, int32_t table, const int64_t* id,
+                                  int64_t n_max, const uint32_t* n_dev, const float* value,
+                                  const float* learning_rate, int64_t n_learning_rate,
+                                  int64_t update_time, int64_t global_step, int32_t flags,
+                                  void* stream) {
+  (void)global_step;
+  return guard([&] {
+    Table& tb = table_at(t, table);
+    if (!learning_rate || n_learning_rate < int64_t(tb.nseg))
+      throw Error(MHTE_INVALID_ARGUMENT, "The length of tensor `learning_rate` is too short.");
+    HIP_OK(hipSetDevice(t->device));
+    std::lock_guard<std::mutex> g(tb.mu);
+    tb.note_update_time(update_time);
+    tb.upsert<kOpOptimize>(id, n_max, n_dev, value, learning_rate, update_time, flags, nullptr,
+                           S(stream));
+  });
+}
+
+mhte_status mhte_value_offsets(const uint32_t* seg_off, const uint32_t* seg_pos,
+                               const uint32_t* n_unique_dev, int64_t n, int64_t value_base,
+                               int64_t dim, int64_t split_base, int64_t* value_offset,
+                               int64_t* value_offset_split, void* stream) {
+  return guard([&] {
+    if (n <= 0) return;
+    hipStream_t st = S(stream);
+    offsets_from_positions_kernel<<<dim3(uint32_t((n + 255) / 256)), 256, 0, st>>>(
+        seg_pos, uint32_t(n), value_base, dim, value_offset);
+    widen_offsets_kernel<<<dim3(uint32_t((n + 1 + 255) / 256)), 256, 0, st>>>(
+        seg_off, n_unique_dev, split_base, value_offset_split);
+    HIP_OK(hipGetLastError());
+  });
+}
+
+mhte_status mhte_fill_with_offset_map(const int64_t* pos, int64_t n, const float* value,
+                                      const int64_t* value_offset_map,
+                                      const int64_t* value_offset_map_split, int32_t dim,
+                                      int32_t offsets_vec4, float* value_buffer, void* stream) {
+  return guard([&] {
+    if (n <= 0) return;
+    if (dim <= 0) throw Error(MHTE_INVALID_ARGUMENT, "dim must be > 0");
+    Shape sh = pick_shape(uint32_t(dim), offsets_vec4 && dim % 4 == 0 && aligned16(value) &&
+                                             aligned16(value_buffer));
+    const dim3 grid(uint32_t((n * sh.G + 255) / 256));
+    hipStream_t st = S(stream);
+#define CALL(G_, V_)                                                                          \
+  scatter_offsets_kernel<G_, V_><<<grid, 256, 0, st>>>(pos, n, value, value_offset_map,       \
+                                                       value_offset_map_split, uint32_t(dim), \
+                                                       value_buffer)
+    DISPATCH_G_VEC(sh, CALL);
+#undef CALL
+    HIP_OK(hipGetLastError());
+  });
+}
+
+mhte_status mhte_fill_with_offset_map_gradient(const int64_t* pos, int64_t n, const float* grad,
+                                               const int64_t* grad_offset_map,
+                                               const int64_t* grad_offset_map_split, int32_t dim,
+                                               int32_t offsets_vec4, float* backprop_grad,
+                                               void* stream) {
+  return guard([&] {
+    if (n <= 0) return;
+    if (dim <= 0) throw Error(MHTE_INVALID_ARGUMENT, "dim must be > 0");
+    Shape sh = pick_shape(uint32_t(dim), offsets_vec4 && dim % 4 == 0 && aligned16(grad) &&
+                                             aligned16(backprop_grad));
+    const dim3 grid(uint32_t((n * sh.G + 255) / 256));
+    hipStream_t st = S(stream);
+#define CALL(G_, V_)                                                                        \
+  gather_sum_offsets_kernel<G_, V_><<<grid, 256, 0, st>>>(pos, n, grad, grad_offset_map,    \
+                                                          grad_offset_map_split,            \
+                                                          uint32_t(dim), backprop_grad)
+    DISPATCH_G_VEC(sh, CALL);
+#undef CALL
+    HIP_OK(hipGetLastError());
+  });
+}
+
+}  // extern "C"

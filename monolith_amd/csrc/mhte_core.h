@@ -1,0 +1,271 @@
+// Shared host/device core of the MI355X embedding-table engine: table geometry, the fixed hash,
+// the serial cuckoo displacement used by the slow path, and the per-row optimizer arithmetic.
+//
+// Reference behaviour being matched (paths relative to
+// /root/reference/monolith/native_training/runtime/):
+//   hash_table/cuckoohash/cuckoohash_map.hpp:860-888   partial_key / index_hash / alt_index
+//   hash_table/cuckoohash/cuckoohash_map.hpp:1398-1418 slot choice (LAST empty slot of b1, else b2)
+//   hash_table/cuckoohash/cuckoohash_map.hpp:1445-1762 BFS displacement, MAX_BFS_PATH_LEN = 5
+//   hash_table/cuckoohash/cuckoohash_map.hpp:1850-1894 bucket split on doubling
+//   hash_table/entry_accessor.cc:113-195               row = float num[dim] | optimizer ctx
+//   hash_table/optimizer/{sgd,adagrad,ftrl}_optimizer.cc, optimizer/avx_utils.h:29-38
+//
+// This header is compiled by hipcc (device + host) and, for the CPU-side unit test of the serial
+// displacement logic only (tests/test_core_host.py), by g++ with MHTE_HOST_ONLY defined.
+#ifndef MHTE_CORE_H_
+#define MHTE_CORE_H_
+
+#include <stdint.h>
+
+#if defined(MHTE_HOST_ONLY)
+#include <math.h>
+#define MHTE_HD
+#else
+#include <hip/hip_runtime.h>
+#define MHTE_HD __host__ __device__ __forceinline__
+#endif
+
+namespace mhte {
+
+constexpr int kSlots = 4;            // cuckoohash_config.hpp:26
+constexpr int kMaxBfsPathLen = 5;    // cuckoohash_map.hpp:1432
+constexpr int kMaxCuckooCount = 682; // 2*(4^5-1)/3, cuckoohash_map.hpp:1705-1709
+constexpr int kMaxSegments = 8;
+// The one int64 that cannot live in a bucket: it marks an empty slot.  FID v2 keeps bit 63 = 0
+// (data/training_instance/cc/fid.h:61-68), so it never occurs in practice; it is still a legal
+// key for the table API and is served from a side slot in Counters.
+constexpr int64_t kEmptyKey = INT64_MIN;
+constexpr uint32_t kNoRow = 0xFFFFFFFFu;
+
+enum OptType : int32_t { kOptSgd = 0, kOptAdagrad = 1, kOptFtrl = 2 };
+enum InitType : int32_t { kInitZeros = 0, kInitOnes = 1, kInitConstant = 2 };
+
+// One 64-byte line per bucket: 4 keys, 4 row handles, 4 uint32 timestamps.  The reference's
+// PACKED bucket is 4 x (int64 key + {u32 EntryAddress,u32 ts}) + 4 partial + 4 occupied = 72 B
+// (bucket_container.hpp:72-122, entry_defs.h:24-39); here occupancy is "key != kEmptyKey" and the
+// partial tag is recomputed from the key (ALU is free next to an HBM miss), which buys exact
+// cache-line alignment.
+struct alignas(64) Bucket {
+  int64_t key[kSlots];
+  uint32_t row[kSlots];
+  uint32_t ts[kSlots];
+};
+static_assert(sizeof(Bucket) == 64, "bucket must be one 64-byte line");
+
+struct SegDesc {
+  int32_t dim;      // segment dim_size (embedding_hash_table.proto:23-43)
+  int32_t w_off;    // float offset of this segment's weights inside the row
+  int32_t st_off;   // float offset of this segment's optimizer ctx inside the row
+  int32_t opt;      // OptType
+  float p[4];       // adagrad: {initial_accumulator_value, weight_decay_factor}
+                    // ftrl:    {initial_accumulator_value, beta, l1, l2}
+  int32_t init;     // InitType
+  float init_value; // constants initializer value
+};
+
+// fmix64 (murmur3 finaliser).  Stands in for absl::Hash<int64_t> (cuckoohash_map.hpp:64-70), which
+// is ASLR-seeded and not under /root/reference; oracle/ref_shim gives the reference map the same
+// functor so physical placement is comparable.
+MHTE_HD uint64_t hash_key(int64_t key) {
+  uint64_t h = static_cast<uint64_t>(key);
+  h ^= h >> 33;
+  h *= 0xff51afd7ed558ccdULL;
+  h ^= h >> 33;
+  h *= 0xc4ceb9fe1a85ec53ULL;
+  h ^= h >> 33;
+  return h;
+}
+MHTE_HD uint32_t partial_key(uint64_t hash) {  // :860-869
+  uint32_t h32 = static_cast<uint32_t>(hash) ^ static_cast<uint32_t>(hash >> 32);
+  uint32_t h16 = (h32 ^ (h32 >> 16)) & 0xffffu;
+  return (h16 ^ (h16 >> 8)) & 0xffu;
+}
+MHTE_HD uint64_t hash_mask(uint32_t hp) { return (uint64_t(1) << hp) - 1; }
+MHTE_HD uint64_t index_hash(uint32_t hp, uint64_t hv) { return hv & hash_mask(hp); }  // :873-875
+MHTE_HD uint64_t alt_index(uint32_t hp, uint32_t partial, uint64_t index) {          // :882-888
+  uint64_t nonzero_tag = uint64_t(partial) + 1;
+  return (index ^ (nonzero_tag * 0xc6a4a7935bd1e995ULL)) & hash_mask(hp);
+}
+MHTE_HD uint32_t reserve_calc(uint64_t n) {  // :2114-2121
+  uint64_t buckets = (n + kSlots - 1) / kSlots;
+  uint32_t blog2 = 0;
+  while ((uint64_t(1) << blog2) < buckets) ++blog2;
+  return blog2;
+}
+
+// ------------------------------------------------------------------------------------------
+// Serial cuckoo displacement (slow path).  Runs in ONE lane of a single-workgroup kernel that has
+// the table to itself (stream order), so no locks are needed; the search and move order follow
+// the reference exactly, which is what makes sequential-insert placement bit-identical to the
+// reference map (tests/test_parity_gpu.py::test_placement_matches_reference).
+// ------------------------------------------------------------------------------------------
+struct BfsSlot {
+  uint64_t bucket;
+  uint16_t pathcode;
+  int8_t depth;
+};
+struct CuckooRecord {
+  uint64_t bucket;
+  int32_t slot;
+  uint64_t hash;
+  uint32_t partial;
+};
+
+MHTE_HD bool slot_occupied(const Bucket& b, int s) { return b.key[s] != kEmptyKey; }
+
+// cuckoohash_map.hpp:1725-1762.  `q` must hold kMaxCuckooCount entries.
+MHTE_HD BfsSlot slot_search(const Bucket* buckets, uint32_t hp, uint64_t i1, uint64_t i2,
+                            BfsSlot* q) {
+  int first = 0, last = 0;
+  q[last++] = BfsSlot{i1, 0, 0};
+  q[last++] = BfsSlot{i2, 1, 0};
+  while (first != last) {
+    BfsSlot x = q[first++];
+    const Bucket& b = buckets[x.bucket];
+    int starting_slot = x.pathcode % kSlots;
+    for (int i = 0; i < kSlots; ++i) {
+      uint16_t slot = static_cast<uint16_t>((starting_slot + i) % kSlots);
+      if (!slot_occupied(b, slot)) {
+        x.pathcode = static_cast<uint16_t>(x.pathcode * kSlots + slot);
+        return x;
+      }
+      if (x.depth < kMaxBfsPathLen - 1) {
+        uint32_t partial = partial_key(hash_key(b.key[slot]));
+        BfsSlot y;
+        y.bucket = alt_index(hp, partial, x.bucket);
+        y.pathcode = static_cast<uint16_t>(x.pathcode * kSlots + slot);
+        y.depth = static_cast<int8_t>(x.depth + 1);
+        q[last++] = y;
+      }
+    }
+  }
+  return BfsSlot{0, 0, -1};
+}
+
+// cuckoohash_map.hpp:1508-1561
+MHTE_HD int cuckoopath_search(const Bucket* buckets, uint32_t hp, CuckooRecord* path, uint64_t i1,
+                              uint64_t i2, BfsSlot* q) {
+  BfsSlot x = slot_search(buckets, hp, i1, i2, q);
+  if (x.depth == -1) return -1;
+  for (int i = x.depth; i >= 0; --i) {
+    path[i].slot = x.pathcode % kSlots;
+    x.pathcode = static_cast<uint16_t>(x.pathcode / kSlots);
+  }
+  path[0].bucket = (x.pathcode == 0) ? i1 : i2;
+  {
+    const Bucket& b = buckets[path[0].bucket];
+    if (!slot_occupied(b, path[0].slot)) return 0;
+    path[0].hash = hash_key(b.key[path[0].slot]);
+    path[0].partial = partial_key(path[0].hash);
+  }
+  for (int i = 1; i <= x.depth; ++i) {
+    path[i].bucket = alt_index(hp, path[i - 1].partial, path[i - 1].bucket);
+    const Bucket& b = buckets[path[i].bucket];
+    if (!slot_occupied(b, path[i].slot)) return i;
+    path[i].hash = hash_key(b.key[path[i].slot]);
+    path[i].partial = partial_key(path[i].hash);
+  }
+  return x.depth;
+}
+
+// cuckoohash_map.hpp:1569-1636 (single owner: the validity re-checks cannot fail, kept anyway)
+MHTE_HD bool cuckoopath_move(Bucket* buckets, CuckooRecord* path, int depth) {
+  if (depth == 0) return !slot_occupied(buckets[path[0].bucket], path[0].slot);
+  while (depth > 0) {
+    CuckooRecord& from = path[depth - 1];
+    CuckooRecord& to = path[depth];
+    Bucket& fb = buckets[from.bucket];
+    Bucket& tb = buckets[to.bucket];
+    if (slot_occupied(tb, to.slot) || !slot_occupied(fb, from.slot) ||
+        hash_key(fb.key[from.slot]) != from.hash) {
+      return false;
+    }
+    tb.row[to.slot] = fb.row[from.slot];
+    tb.ts[to.slot] = fb.ts[from.slot];
+    tb.key[to.slot] = fb.key[from.slot];
+    fb.key[from.slot] = kEmptyKey;
+    --depth;
+  }
+  return true;
+}
+
+// Finds (and reserves, by writing the key) a slot for `key`, which the caller has established is
+// absent and whose two buckets are both full or contended.  Returns bucket*4+slot, or -1 when no
+// displacement path of length <= 5 exists (the reference would double the table here,
+// cuckoohash_map.hpp:1296-1299; the engine grows proactively on the host instead).
+MHTE_HD int64_t serial_insert_slot(Bucket* buckets, uint32_t hp, int64_t key, BfsSlot* q) {
+  uint64_t hv = hash_key(key);
+  uint32_t partial = partial_key(hv);
+  uint64_t i1 = index_hash(hp, hv);
+  uint64_t i2 = alt_index(hp, partial, i1);
+  // try_find_insert_bucket, :1398-1418 — last empty slot of b1, else of b2
+  for (int pass = 0; pass < 2; ++pass) {
+    uint64_t ib = pass == 0 ? i1 : i2;
+    int found = -1;
+    for (int s = 0; s < kSlots; ++s)
+      if (!slot_occupied(buckets[ib], s)) found = s;
+    if (found >= 0) {
+      buckets[ib].key[found] = key;
+      return static_cast<int64_t>(ib * kSlots + found);
+    }
+  }
+  CuckooRecord path[kMaxBfsPathLen];
+  for (;;) {
+    int depth = cuckoopath_search(buckets, hp, path, i1, i2, q);
+    if (depth < 0) return -1;
+    if (cuckoopath_move(buckets, path, depth)) break;
+  }
+  buckets[path[0].bucket].key[path[0].slot] = key;
+  return static_cast<int64_t>(path[0].bucket * kSlots + path[0].slot);
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-element optimizer arithmetic.  Contraction is disabled so that results are bit-identical
+// to the scalar reference path (avx_utils.h:29-38 BaselineAdagradOptimize; the AVX path differs
+// by FMA rounding only, avx_test.cc:29-62 tolerates 1e-6).
+// ------------------------------------------------------------------------------------------
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+MHTE_HD float sgd_step(float w, float g, float lr) {  // sgd_optimizer.cc:42-49
+  float d = lr * g;
+  return w - d;
+}
+
+MHTE_HD void adagrad_step(float& w, float& n, float grad, float lr, float wd) {  // avx_utils.h:29-38
+  float t = wd * w;
+  float g = grad + t;
+  float g2 = g * g;
+  n = n + g2;
+  float eff = lr / sqrtf(n);
+  float d = eff * g;
+  w = w - d;
+}
+
+// ftrl_optimizer.cc:56-75, including its `std::signbit(z) * l1` term (1*l1 for negative z, else 0)
+MHTE_HD void ftrl_step(float& w, float& n, float& z, float grad, float lr, float beta, float l1,
+                       float l2) {
+  float gg = grad * grad;
+  float norm_new = n + gg;
+  float sigma = (sqrtf(norm_new) - sqrtf(n)) / lr;
+  float sw = sigma * w;
+  z = z + (grad - sw);
+  n = norm_new;
+  if (fabsf(z) > l1) {
+    float sl1 = (z < 0.f || (z == 0.f && (1.f / z) < 0.f)) ? l1 : 0.f;
+    float num = lr * (sl1 - z);
+    float l2lr = l2 * lr;
+    float den = (sqrtf(n) + beta) + l2lr;
+    w = num / den;
+  } else {
+    w = 0.f;
+  }
+}
+
+MHTE_HD float init_weight(const SegDesc& s) {
+  return s.init == kInitOnes ? 1.f : (s.init == kInitConstant ? s.init_value : 0.f);
+}
+
+}  // namespace mhte
+#endif  // MHTE_CORE_H_

@@ -1,0 +1,1081 @@
+// CDNA4 (gfx950) kernels of the embedding-table engine.  Included by mhte.hip only.
+//
+// Execution shape shared by the probe kernels: a GROUP of G lanes (G = 8..64, power of two, G | 64)
+// serves one feature id.  Lanes 0..7 of the group each own one candidate slot (lanes 0-3: the four
+// slots of bucket i1, lanes 4-7: bucket i2) so a probe is ONE round of 8-byte key loads that the
+// coalescer merges into one 32-byte request per bucket line; a wave ballot finds the matching
+// lane; then all G lanes move the row as float4 (G*16 B contiguous per id).  With B = 65 536 ids a
+// launch has B*G/64 wavefronts (16 384 at dim 64) instead of B/64, which is what hides the
+// id -> bucket -> row dependent-miss chain on a 256-CU part.
+#ifndef MHTE_KERNELS_H_
+#define MHTE_KERNELS_H_
+
+#include "mhte_core.h"
+
+namespace mhte {
+
+struct Counters {
+  unsigned long long n_keys;   // live keys in buckets (side-slot key not included)
+  unsigned long long hits;     // lookup hits since last reset
+  unsigned int next_row;       // bump allocator for row handles
+  unsigned int n_pending;      // ids whose two buckets were full in the fast path
+  unsigned int error;          // bit0: displacement failed (id dropped)
+  unsigned int n_dropped;
+  unsigned int special_state;  // 1 when kEmptyKey itself is stored
+  unsigned int special_row;
+  unsigned int special_ts;
+  unsigned int n_evicted;
+  unsigned int scan_count;     // generic scan output counter
+  unsigned int pad;
+};
+
+struct TableView {
+  Bucket* buckets;
+  float* chunk0;          // first row slab (rows [0, 1<<chunk_shift)) — no pointer-table load
+  float* const* chunks;   // device array of slab pointers
+  Counters* ctr;
+  uint32_t hp;
+  uint32_t chunk_shift;
+  uint32_t row_floats;
+  uint32_t dim;
+  uint32_t nseg;
+  SegDesc seg[kMaxSegments];
+};
+
+enum ApplyOp : int { kOpAssign = 0, kOpAssignAdd = 1, kOpOptimize = 2, kOpReinit = 3 };
+
+struct ApplyArgs {
+  float lr[kMaxSegments];  // one per segment (SliceSize), multi_hash_table_update_op.cc:73-77
+  uint32_t ts;             // (uint32)update_time, entry_defs.h:36-38
+  int32_t sum_dups;        // 1: duplicates' values are added first, one optimizer step
+                           //    (enable_grad_accumulation, tf_bridge.cc:270-310)
+                           // 0: one optimizer step per occurrence, in order
+                           //    (cuckoo_embedding_hash_table.cc:229-236)
+};
+
+__device__ __forceinline__ float* row_ptr(const TableView& tv, uint32_t r) {
+  const uint32_t c = r >> tv.chunk_shift;
+  float* base = (c == 0) ? tv.chunk0 : tv.chunks[c];
+  return base + size_t(r & ((1u << tv.chunk_shift) - 1u)) * tv.row_floats;
+}
+
+template <int G>
+__device__ __forceinline__ uint64_t group_mask_of(uint64_t wave_mask, int gbase) {
+  if (G == 64) return wave_mask;
+  return (wave_mask >> gbase) & ((uint64_t(1) << G) - 1);
+}
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<4> {
+  float v[4];
+  __device__ __forceinline__ void load(const float* p) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ __forceinline__ void store(float* p) const {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <>
+struct Vec<1> {
+  float v[1];
+  __device__ __forceinline__ void load(const float* p) { v[0] = *p; }
+  __device__ __forceinline__ void store(float* p) const { *p = v[0]; }
+};
+
+// =============================================================================================
+// Lookup: ids[n] -> out[n, dim].  Absent id -> zeros, never inserts
+// (cuckoo_embedding_hash_table.cc:161-171).  Algorithmic bytes per id: 8 (id) + 36..72 (probe)
+// + 4*dim (row) + 4*dim (output).
+// =============================================================================================
+template <int G, int VEC>
+__global__ __launch_bounds__(256) void lookup_kernel(TableView tv, const int64_t* __restrict__ ids,
+                                                     int64_t n, const uint32_t* __restrict__ n_dev,
+                                                     float* __restrict__ out, int count_hits) {
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (G - 1);
+  const int gbase = lane & ~(G - 1);
+  const int64_t g = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  if (n_dev) n = min(n, int64_t(*n_dev));
+  const bool valid = g < n;
+  const int64_t id = valid ? ids[g] : 0;
+  const uint64_t hv = hash_key(id);
+  const uint64_t i1 = index_hash(tv.hp, hv);
+  const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
+  bool match = false;
+  uint32_t row = kNoRow;
+  if (valid && j < 8 && id != kEmptyKey) {
+    const Bucket* b = tv.buckets + ((j < 4) ? i1 : i2);
+    const int s = j & 3;
+    const int64_t k = b->key[s];
+    row = b->row[s];
+    match = (k == id);
+  }
+  const uint64_t m = group_mask_of<G>(__ballot(match), gbase);
+  bool found = m != 0;
+  const int src = found ? (__ffsll(static_cast<long long>(m)) - 1) : 0;
+  uint32_t r = __shfl(row, gbase + src);
+  if (valid && id == kEmptyKey) {
+    found = tv.ctr->special_state == 1;
+    r = tv.ctr->special_row;
+  }
+  if (valid) {
+    const float* rp = found ? row_ptr(tv, r) : nullptr;
+    float* op = out + g * int64_t(tv.dim);
+    for (uint32_t e = j * VEC; e < tv.dim; e += G * VEC) {
+      Vec<VEC> v;
+      if (found) {
+        v.load(rp + e);
+      } else {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) v.v[c] = 0.f;
+      }
+      v.store(op + e);
+    }
+  }
+  if (count_hits) {
+    const uint64_t hm = __ballot(valid && found && j == 0);
+    if (lane == 0 && hm) atomicAdd(&tv.ctr->hits, (unsigned long long)__popcll(hm));
+  }
+}
+
+// =============================================================================================
+// Row update shared by the fast path and the slow path.  The G lanes of a group own elements
+// e = j*VEC + k*G*VEC of the row; weights and optimizer state stay in registers across all
+// occurrences of the id, so a duplicated id costs one row read + one row write.
+//   rp        row pointer
+//   is_new    row was just allocated: start from initializer + optimizer Init
+//             (entry_accessor.cc:158-162) instead of reading HBM
+//   values    [*, dim] value rows (gradients / assigned values), indexed by occurrence position
+//   seg_pos   optional occurrence list (positions in occurrence order), [q0, q1)
+// =============================================================================================
+template <int G, int VEC, int OP>
+__device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool is_new, int j,
+                                          const float* __restrict__ values,
+                                          const uint32_t* __restrict__ seg_pos, uint32_t q0,
+                                          uint32_t q1, int64_t self_pos, const ApplyArgs& a) {
+  const int64_t dim = tv.dim;
+  for (uint32_t e = j * VEC; e < tv.dim; e += G * VEC) {
+    uint32_t k = 0;
+    while (k + 1 < tv.nseg && e >= uint32_t(tv.seg[k + 1].w_off)) ++k;
+    const SegDesc sd = tv.seg[k];
+    const uint32_t le = e - sd.w_off;  // element index inside the segment
+    const float lr = a.lr[k];
+    Vec<VEC> w, s1, s2;
+    float* st1 = rp + sd.st_off + le;
+    float* st2 = st1 + sd.dim;
+    const bool has1 = sd.opt == kOptAdagrad || sd.opt == kOptFtrl;
+    const bool has2 = sd.opt == kOptFtrl;
+    if (is_new || OP == kOpReinit) {
+      const float w0 = init_weight(sd);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) {
+        w.v[c] = w0;
+        s1.v[c] = sd.p[0];  // adagrad norm / ftrl norm = initial_accumulator_value
+        s2.v[c] = 0.f;      // ftrl zero
+      }
+    } else {
+      if (OP != kOpAssign) w.load(rp + e);
+      if (OP == kOpOptimize) {
+        if (has1) s1.load(st1);
+        if (has2) s2.load(st2);
+      }
+    }
+    if (OP == kOpAssign) {
+      // sequential memcpy per occurrence: the last one wins (cuckoo_embedding_hash_table.cc:186-203)
+      const int64_t pos = seg_pos ? int64_t(seg_pos[q1 - 1]) : self_pos;
+      w.load(values + pos * dim + e);
+    } else if (OP == kOpAssignAdd || OP == kOpOptimize) {
+      Vec<VEC> acc;
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) acc.v[c] = 0.f;
+      const uint32_t nq = seg_pos ? (q1 - q0) : 1u;
+      for (uint32_t t = 0; t < nq; ++t) {
+        const int64_t pos = seg_pos ? int64_t(seg_pos[q0 + t]) : self_pos;
+        Vec<VEC> v;
+        v.load(values + pos * dim + e);
+        if (OP == kOpOptimize && a.sum_dups) {
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) acc.v[c] = acc.v[c] + v.v[c];
+          if (t + 1 < nq) continue;
+          v = acc;
+        }
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+          if (OP == kOpAssignAdd) {
+            w.v[c] = w.v[c] + v.v[c];  // entry_accessor.cc:179-185
+          } else if (sd.opt == kOptSgd) {
+            w.v[c] = sgd_step(w.v[c], v.v[c], lr);
+          } else if (sd.opt == kOptAdagrad) {
+            adagrad_step(w.v[c], s1.v[c], v.v[c], lr, sd.p[1]);
+          } else {
+            ftrl_step(w.v[c], s1.v[c], s2.v[c], v.v[c], lr, sd.p[1], sd.p[2], sd.p[3]);
+          }
+        }
+      }
+    }
+    w.store(rp + e);
+    if (is_new || OP == kOpReinit || OP == kOpOptimize) {
+      if (has1) s1.store(st1);
+      if (has2) s2.store(st2);
+    }
+  }
+}
+
+// =============================================================================================
+// Upsert + apply, fast path.  Precondition: ids[0..n) are pairwise distinct (callers dedup first,
+// or go through the in-op grouping that supplies seg_off/seg_pos).  Phase-separated from lookups by
+// stream order, so the only concurrency is insert vs insert: a slot is claimed with one 64-bit
+// CAS kEmptyKey -> id on the key word.  An id whose two buckets are full is appended to `pending`
+// and finished by slowpath_kernel (displacement must run alone).
+// Algorithmic bytes per unique id: 8 (id) + 36..72 (probe) + 4 (ts) + 4*dim (value)
+//   + 2 * 4 * row_floats (row read-modify-write).
+// =============================================================================================
+template <int G, int VEC, int OP>
+__global__ __launch_bounds__(256) void upsert_kernel(TableView tv, const int64_t* __restrict__ ids,
+                                                     int64_t n, const uint32_t* __restrict__ n_dev,
+                                                     const float* __restrict__ values,
+                                                     const uint32_t* __restrict__ seg_off,
+                                                     const uint32_t* __restrict__ seg_pos,
+                                                     ApplyArgs a, int32_t* __restrict__ status,
+                                                     uint32_t* __restrict__ pending) {
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (G - 1);
+  const int gbase = lane & ~(G - 1);
+  const int64_t g = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  if (n_dev) n = min(n, int64_t(*n_dev));
+  const bool valid = g < n;
+  const int64_t id = valid ? ids[g] : 0;
+  const bool special = valid && id == kEmptyKey;
+  const uint64_t hv = hash_key(id);
+  const uint64_t i1 = index_hash(tv.hp, hv);
+  const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
+
+  Bucket* b = tv.buckets + ((j < 4) ? i1 : i2);
+  const int s = j & 3;
+  const bool prober = valid && !special && j < 8;
+  int64_t k = kEmptyKey;
+  uint32_t row = kNoRow;
+  if (prober) {
+    k = b->key[s];
+    row = b->row[s];
+  }
+  uint64_t m = group_mask_of<G>(__ballot(prober && k == id), gbase);
+  bool found = m != 0;
+  bool is_new = false;
+  bool deferred = false;
+  int owner = found ? (__ffsll(static_cast<long long>(m)) - 1) : -1;  // lane (in group) of the slot
+
+  // ---- insert: claim the LAST empty slot of b1, else of b2 (cuckoohash_map.hpp:1398-1418) ----
+  bool need = valid && !special && !found;
+  while (__any(need)) {
+    const uint64_t em = group_mask_of<G>(__ballot(prober && k == kEmptyKey), gbase) & 0xffull;
+    int pick = -1;
+    if (need) {
+      const uint32_t m1 = uint32_t(em) & 0xfu, m2 = (uint32_t(em) >> 4) & 0xfu;
+      if (m1) pick = 31 - __clz(m1);
+      else if (m2) pick = 4 + (31 - __clz(m2));
+      if (pick < 0) {  // both buckets full -> slow path
+        deferred = true;
+        need = false;
+      }
+    }
+    bool won = false;
+    if (need && j == pick) {
+      const unsigned long long old =
+          atomicCAS(reinterpret_cast<unsigned long long*>(&b->key[s]),
+                    static_cast<unsigned long long>(kEmptyKey), static_cast<unsigned long long>(id));
+      won = (static_cast<int64_t>(old) == kEmptyKey);
+      k = won ? id : static_cast<int64_t>(old);
+    }
+    const uint64_t wm = group_mask_of<G>(__ballot(won), gbase);
+    if (need && wm) {
+      owner = pick;
+      is_new = true;
+      need = false;
+    }
+  }
+
+  // ---- side slot for the one key that cannot live in a bucket ----
+  if (special) {
+    unsigned int st = 0;
+    if (j == 0) st = atomicExch(&tv.ctr->special_state, 1u);
+    st = __shfl(st, gbase);
+    found = true;
+    is_new = (st == 0);
+  }
+
+  // ---- row handles for new ids: one atomic per wave ----
+  const bool leader_new = is_new && j == 0;
+  const uint64_t newm = __ballot(leader_new);
+  const int first_new = newm ? (__ffsll(static_cast<long long>(newm)) - 1) : 0;
+  uint32_t base_row = 0;
+  if (newm && lane == first_new) base_row = atomicAdd(&tv.ctr->next_row, (unsigned int)__popcll(newm));
+  base_row = __shfl(base_row, first_new);
+  const uint32_t found_row = __shfl(row, gbase + (owner < 0 ? 0 : owner));
+  uint32_t r;
+  if (is_new) {
+    const uint32_t rank = __popcll(newm & ((uint64_t(1) << gbase) - 1));
+    r = base_row + rank;
+  } else {
+    r = found_row;
+  }
+  if (special) {
+    if (is_new) {
+      if (j == 0) tv.ctr->special_row = r;
+    } else {
+      r = tv.ctr->special_row;  // written by an earlier kernel
+    }
+    if (j == 0) tv.ctr->special_ts = a.ts;
+  } else if (valid && !deferred && j == owner) {
+    if (is_new) b->row[s] = r;
+    b->ts[s] = a.ts;  // SetTimestamp(update_time), cuckoo_embedding_hash_table.cc:242-246
+  }
+  // live-key counter (bucket keys only)
+  {
+    const uint64_t km = __ballot(leader_new && !special);
+    if (km && lane == (__ffsll(static_cast<long long>(km)) - 1))
+      atomicAdd(&tv.ctr->n_keys, (unsigned long long)__popcll(km));
+  }
+  // ---- defer to the slow path ----
+  if (deferred && j == 0) {
+    const uint32_t slot = atomicAdd(&tv.ctr->n_pending, 1u);
+    pending[slot] = static_cast<uint32_t>(g);
+  }
+  // ---- apply ----
+  if (valid && !deferred) {
+    const uint32_t q0 = seg_off ? seg_off[g] : 0u;
+    const uint32_t q1 = seg_off ? seg_off[g + 1] : 1u;
+    apply_row<G, VEC, OP>(tv, row_ptr(tv, r), is_new, j, values, seg_off ? seg_pos : nullptr, q0,
+                          q1, g, a);
+    if (OP == kOpReinit && j == 0) {
+      // status: 0 inserted, 1 existed (cuckoo_embedding_hash_table.cc:215-226); later duplicates
+      // of an id always see it existing.
+      if (seg_off) {
+        for (uint32_t q = q0; q < q1; ++q) status[seg_pos[q]] = (q == q0 && is_new) ? 0 : 1;
+      } else {
+        status[g] = is_new ? 0 : 1;
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// Slow path: ONE wavefront finishes the ids the fast path deferred.  Lane 0 runs the reference's
+// BFS displacement serially (mhte_core.h), then all 64 lanes apply the row update.  Rare by
+// construction: the host keeps the load factor <= max_load_factor (default 0.5), where both
+// 4-slot buckets of a fresh id are full with probability ~1e-4.
+// =============================================================================================
+template <int VEC, int OP>
+__global__ __launch_bounds__(64) void slowpath_kernel(TableView tv, const int64_t* __restrict__ ids,
+                                                      const float* __restrict__ values,
+                                                      const uint32_t* __restrict__ seg_off,
+                                                      const uint32_t* __restrict__ seg_pos,
+                                                      ApplyArgs a, int32_t* __restrict__ status,
+                                                      const uint32_t* __restrict__ pending) {
+  __shared__ BfsSlot q[kMaxCuckooCount];
+  const int lane = threadIdx.x;
+  const uint32_t np = tv.ctr->n_pending;
+  for (uint32_t i = 0; i < np; ++i) {
+    const uint32_t g = pending[i];
+    const int64_t id = ids[g];
+    long long pos = -1;
+    uint32_t r = kNoRow;
+    if (lane == 0) {
+      pos = serial_insert_slot(tv.buckets, tv.hp, id, q);
+      if (pos >= 0) {
+        r = atomicAdd(&tv.ctr->next_row, 1u);
+        Bucket* b = tv.buckets + (pos >> 2);
+        b->row[pos & 3] = r;
+        b->ts[pos & 3] = a.ts;
+        atomicAdd(&tv.ctr->n_keys, 1ull);
+      } else {
+        atomicOr(&tv.ctr->error, 1u);
+        atomicAdd(&tv.ctr->n_dropped, 1u);
+      }
+    }
+    pos = __shfl(pos, 0);
+    r = __shfl(r, 0);
+    if (pos >= 0) {
+      const uint32_t q0 = seg_off ? seg_off[g] : 0u;
+      const uint32_t q1 = seg_off ? seg_off[g + 1] : 1u;
+      apply_row<64, VEC, OP>(tv, row_ptr(tv, r), true, lane, values, seg_off ? seg_pos : nullptr,
+                             q0, q1, g, a);
+      if (OP == kOpReinit && lane == 0) {
+        if (seg_off) {
+          for (uint32_t t = q0; t < q1; ++t) status[seg_pos[t]] = (t == q0) ? 0 : 1;
+        } else {
+          status[g] = 0;
+        }
+      }
+    }
+    __syncthreads();  // q is reused; also orders lane 0's bucket writes before the next search
+  }
+  if (lane == 0) tv.ctr->n_pending = 0;
+}
+
+// =============================================================================================
+// Doubling (cuckoo_fast_double / move_bucket, cuckoohash_map.hpp:1768-1894): index_hash and
+// alt_index gain one top bit, so every key of old bucket i lands in new bucket i (same slot) or
+// i + 2^hp (compacted from slot 0).  Pure streaming kernel: reads 64 B, writes 128 B per bucket.
+// =============================================================================================
+__global__ __launch_bounds__(256) void split_kernel(const Bucket* __restrict__ oldb,
+                                                    Bucket* __restrict__ newb, uint32_t old_hp) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t n_old = uint64_t(1) << old_hp;
+  if (i >= n_old) return;
+  const Bucket ob = oldb[i];
+  Bucket lo, hi;
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s) {
+    lo.key[s] = kEmptyKey; lo.row[s] = kNoRow; lo.ts[s] = 0;
+    hi.key[s] = kEmptyKey; hi.row[s] = kNoRow; hi.ts[s] = 0;
+  }
+  const uint32_t new_hp = old_hp + 1;
+  const uint64_t new_ind = i + n_old;
+  int new_slot = 0;
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s) {
+    if (ob.key[s] == kEmptyKey) continue;
+    const uint64_t hv = hash_key(ob.key[s]);
+    const uint32_t p = partial_key(hv);
+    const uint64_t old_i = index_hash(old_hp, hv);
+    const uint64_t old_a = alt_index(old_hp, p, old_i);
+    const uint64_t new_i = index_hash(new_hp, hv);
+    const uint64_t new_a = alt_index(new_hp, p, new_i);
+    const bool moves = (i == old_i && new_i == new_ind) || (i == old_a && new_a == new_ind);
+    if (moves) {
+      hi.key[new_slot] = ob.key[s]; hi.row[new_slot] = ob.row[s]; hi.ts[new_slot] = ob.ts[s];
+      ++new_slot;
+    } else {
+      lo.key[s] = ob.key[s]; lo.row[s] = ob.row[s]; lo.ts[s] = ob.ts[s];
+    }
+  }
+  newb[i] = lo;
+  newb[new_ind] = hi;
+}
+
+__global__ __launch_bounds__(256) void clear_buckets_kernel(Bucket* __restrict__ b, uint64_t n) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Bucket e;
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s) { e.key[s] = kEmptyKey; e.row[s] = kNoRow; e.ts[s] = 0; }
+  b[i] = e;
+}
+
+// =============================================================================================
+// Full-table scans.
+//   evict_kernel: cuckoo_embedding_hash_table.cc:251-264 — drop a key when
+//     max_update_time - ts >= ttl_days(slot_id_v2(key)) * 86400; slot_id_v2 = (fid >> 48) & 0x7fff
+//     (data/training_instance/cc/reader_util.h:36-38).
+//   dump_kernel:  bucket-major, slot-minor enumeration (partial_dump, cuckoohash_map.hpp:740-773).
+// =============================================================================================
+struct TtlConfig {
+  int64_t default_days;
+  int32_t n;
+  const int64_t* slots;  // device
+  const int32_t* days;   // device
+};
+
+__global__ __launch_bounds__(256) void evict_kernel(TableView tv, int64_t max_update_time,
+                                                    TtlConfig ttl) {
+  const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t nslots = (uint64_t(1) << tv.hp) * kSlots;
+  bool ev = false;
+  if (t < nslots) {
+    Bucket* b = tv.buckets + (t >> 2);
+    const int s = t & 3;
+    const int64_t key = b->key[s];
+    if (key != kEmptyKey) {
+      const int64_t slot = (key >> 48) & 0x7fff;
+      int64_t days = ttl.default_days;
+      for (int i = 0; i < ttl.n; ++i)
+        if (ttl.slots[i] == slot) days = ttl.days[i];
+      if (max_update_time - int64_t(b->ts[s]) >= days * int64_t(86400)) {
+        b->key[s] = kEmptyKey;
+        b->row[s] = kNoRow;
+        ev = true;
+      }
+    }
+  }
+  const uint64_t em = __ballot(ev);
+  if (em && (threadIdx.x & 63) == 0) {
+    const unsigned long long c = __popcll(em);
+    atomicAdd(&tv.ctr->n_keys, ~c + 1ull);  // -= c
+    atomicAdd(&tv.ctr->n_evicted, (unsigned int)c);
+  }
+}
+
+// count occupied slots per block of 1024 slots -> block_counts; then dump with offsets
+__global__ __launch_bounds__(256) void dump_count_kernel(TableView tv, uint32_t* __restrict__ bc) {
+  __shared__ uint32_t wsum[4];
+  const uint64_t nslots = (uint64_t(1) << tv.hp) * kSlots;
+  const uint64_t base = uint64_t(blockIdx.x) * 1024;
+  uint32_t c = 0;
+  for (int k = 0; k < 4; ++k) {
+    const uint64_t t = base + uint64_t(threadIdx.x) * 4 + k;
+    if (t < nslots && tv.buckets[t >> 2].key[t & 3] != kEmptyKey) ++c;
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) bc[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// block_offsets = exclusive scan of block_counts (done on host for dumps: it is a cold path)
+__global__ __launch_bounds__(256) void dump_emit_kernel(TableView tv,
+                                                        const uint64_t* __restrict__ block_off,
+                                                        int64_t* __restrict__ ids,
+                                                        int64_t* __restrict__ positions,
+                                                        uint32_t* __restrict__ ts,
+                                                        float* __restrict__ rows) {
+  __shared__ uint32_t wsum[4];
+  const uint64_t nslots = (uint64_t(1) << tv.hp) * kSlots;
+  const uint64_t base = uint64_t(blockIdx.x) * 1024;
+  uint32_t occ[4];
+  uint32_t c = 0;
+  for (int k = 0; k < 4; ++k) {
+    const uint64_t t = base + uint64_t(threadIdx.x) * 4 + k;
+    occ[k] = (t < nslots && tv.buckets[t >> 2].key[t & 3] != kEmptyKey) ? 1u : 0u;
+    c += occ[k];
+  }
+  // exclusive scan of c over the block (thread order == slot order)
+  uint32_t incl = c;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int i = 0; i < w; ++i) woff += wsum[i];
+  uint64_t o = block_off[blockIdx.x] + woff + (incl - c);
+  for (int k = 0; k < 4; ++k) {
+    if (!occ[k]) continue;
+    const uint64_t t = base + uint64_t(threadIdx.x) * 4 + k;
+    const Bucket* b = tv.buckets + (t >> 2);
+    const int s = t & 3;
+    ids[o] = b->key[s];
+    positions[o] = static_cast<int64_t>(t);
+    ts[o] = b->ts[s];
+    if (rows) {
+      const float* rp = row_ptr(tv, b->row[s]);
+      for (uint32_t e = 0; e < tv.row_floats; ++e) rows[o * tv.row_floats + e] = rp[e];
+    }
+    ++o;
+  }
+}
+
+// =============================================================================================
+// Batch dedup in first-occurrence order with per-key occurrence lists (CSR), the device form of
+// UniqueKeyWithValueAndOffset / FusedReorderByIndices' per-table dedup
+// (ops/unique_mapping_ops.cc:82-114, ops/fused_reorder_by_indices.cc:52-60).
+//   dd_clear   scratch hash set (capacity C = pow2 >= 2n) <- empty
+//   dd_insert  position p claims/joins the slot of ids[p]; atomicMin first position, count
+//   dd_tile    per 1024-position tile: (#first occurrences, sum of their counts)
+//   dd_emit    two-accumulator exclusive scan over positions: unique index u of each first
+//              occurrence and the start seg_off[u] of its occurrence list; writes uids, U
+//   dd_place   inverse[p] = u; appends p to list u (unordered, atomic cursor)
+//   dd_order   lists of 2..32 positions: in-thread insertion sort; longer: queued as heavy
+//   dd_heavy   one workgroup per heavy key: ordered stream compaction over inverse[]
+// All counts stay on the device (U is read by downstream kernels through n_dev).
+// =============================================================================================
+struct DedupView {
+  int64_t* hkey;      // [C+1]  (+1 = side slot for kEmptyKey)
+  uint32_t* hmin;     // [C+1]
+  uint32_t* hcnt;     // [C+1]
+  uint32_t* huidx;    // [C+1]
+  uint32_t* hcur;     // [C+1]
+  uint32_t* slot_of;  // [n]
+  uint32_t* tile_a;   // [ntiles] first-occurrence counts
+  uint32_t* tile_b;   // [ntiles] occurrence-count sums
+  uint32_t* heavy;    // [n/33 + 1]
+  uint32_t* heavy_n;  // [1]
+  uint32_t cap_mask;  // C-1
+};
+
+constexpr int kDdTile = 1024;   // positions per tile (256 threads x 4)
+constexpr int kLightMax = 32;   // longest list sorted in-thread
+
+__global__ __launch_bounds__(256) void dd_clear_kernel(DedupView d) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= d.cap_mask + 1u) {
+    d.hkey[i] = kEmptyKey;
+    d.hmin[i] = 0xffffffffu;
+    d.hcnt[i] = 0;
+    d.hcur[i] = 0;
+  }
+  if (i == 0) *d.heavy_n = 0;
+}
+
+__global__ __launch_bounds__(256) void dd_insert_kernel(DedupView d, const int64_t* __restrict__ ids,
+                                                        uint32_t n) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int64_t id = ids[p];
+  uint32_t s;
+  if (id == kEmptyKey) {
+    s = d.cap_mask + 1u;
+  } else {
+    s = uint32_t(hash_key(id)) & d.cap_mask;
+    for (;;) {
+      int64_t k = d.hkey[s];
+      if (k == kEmptyKey) {
+        k = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hkey[s]),
+                                           static_cast<unsigned long long>(kEmptyKey),
+                                           static_cast<unsigned long long>(id)));
+        if (k == kEmptyKey) break;
+      }
+      if (k == id) break;
+      s = (s + 1u) & d.cap_mask;
+    }
+  }
+  atomicMin(&d.hmin[s], p);
+  atomicAdd(&d.hcnt[s], 1u);
+  d.slot_of[p] = s;
+}
+
+__device__ __forceinline__ void block_reduce2(uint32_t& a, uint32_t& b, uint32_t* sh) {
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_down(a, o);
+    b += __shfl_down(b, o);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sh[w] = a;
+    sh[4 + w] = b;
+  }
+  __syncthreads();
+  a = sh[0] + sh[1] + sh[2] + sh[3];
+  b = sh[4] + sh[5] + sh[6] + sh[7];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void dd_tile_kernel(DedupView d, uint32_t n) {
+  __shared__ uint32_t sh[8];
+  uint32_t a = 0, b = 0;
+  const uint32_t base = blockIdx.x * kDdTile + threadIdx.x * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t p = base + k;
+    if (p < n) {
+      const uint32_t s = d.slot_of[p];
+      if (d.hmin[s] == p) {
+        ++a;
+        b += d.hcnt[s];
+      }
+    }
+  }
+  block_reduce2(a, b, sh);
+  if (threadIdx.x == 0) {
+    d.tile_a[blockIdx.x] = a;
+    d.tile_b[blockIdx.x] = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void dd_emit_kernel(DedupView d, const int64_t* __restrict__ ids,
+                                                      uint32_t n, int64_t* __restrict__ uids,
+                                                      uint32_t* __restrict__ seg_off,
+                                                      uint32_t* __restrict__ n_unique) {
+  __shared__ uint32_t sh[8];
+  __shared__ uint32_t wa[4], wb[4];
+  // offsets of this tile = sums over the tiles before it (each block recomputes: ntiles is small)
+  uint32_t pa = 0, pb = 0;
+  for (uint32_t t = threadIdx.x; t < blockIdx.x; t += blockDim.x) {
+    pa += d.tile_a[t];
+    pb += d.tile_b[t];
+  }
+  block_reduce2(pa, pb, sh);
+  const uint32_t base = blockIdx.x * kDdTile + threadIdx.x * 4;
+  uint32_t fa[4], fb[4], slot[4];
+  uint32_t a = 0, b = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t p = base + k;
+    fa[k] = 0;
+    fb[k] = 0;
+    slot[k] = 0;
+    if (p < n) {
+      slot[k] = d.slot_of[p];
+      if (d.hmin[slot[k]] == p) {
+        fa[k] = 1;
+        fb[k] = d.hcnt[slot[k]];
+      }
+    }
+    a += fa[k];
+    b += fb[k];
+  }
+  uint32_t ia = a, ib = b;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t va = __shfl_up(ia, o), vb = __shfl_up(ib, o);
+    if (lane >= o) {
+      ia += va;
+      ib += vb;
+    }
+  }
+  if (lane == 63) {
+    wa[w] = ia;
+    wb[w] = ib;
+  }
+  __syncthreads();
+  uint32_t oa = pa + (ia - a), ob = pb + (ib - b);
+  for (int i = 0; i < w; ++i) {
+    oa += wa[i];
+    ob += wb[i];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (fa[k]) {
+      const uint32_t p = base + k;
+      uids[oa] = ids[p];
+      seg_off[oa] = ob;
+      d.huidx[slot[k]] = oa;
+      ++oa;
+      ob += fb[k];
+    }
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == blockDim.x - 1) {
+    *n_unique = oa;   // after the last position: total number of unique ids
+    seg_off[oa] = n;  // == ob
+  }
+}
+
+__global__ __launch_bounds__(256) void dd_place_kernel(DedupView d, uint32_t n,
+                                                       const uint32_t* __restrict__ seg_off,
+                                                       uint32_t* __restrict__ inverse,
+                                                       uint32_t* __restrict__ seg_pos) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t s = d.slot_of[p];
+  const uint32_t u = d.huidx[s];
+  inverse[p] = u;
+  const uint32_t q = atomicAdd(&d.hcur[s], 1u);
+  seg_pos[seg_off[u] + q] = p;
+}
+
+__global__ __launch_bounds__(256) void dd_order_kernel(DedupView d,
+                                                       const uint32_t* __restrict__ n_unique,
+                                                       const uint32_t* __restrict__ seg_off,
+                                                       uint32_t* __restrict__ seg_pos) {
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= *n_unique) return;
+  const uint32_t q0 = seg_off[u], len = seg_off[u + 1] - q0;
+  if (len < 2) return;
+  if (len > kLightMax) {
+    d.heavy[atomicAdd(d.heavy_n, 1u)] = u;
+    return;
+  }
+  uint32_t* a = seg_pos + q0;
+  for (uint32_t i = 1; i < len; ++i) {
+    const uint32_t v = a[i];
+    uint32_t k = i;
+    while (k > 0 && a[k - 1] > v) {
+      a[k] = a[k - 1];
+      --k;
+    }
+    a[k] = v;
+  }
+}
+
+// One workgroup per heavy key; rewrites its list in position order by scanning inverse[].
+__global__ __launch_bounds__(1024) void dd_heavy_kernel(DedupView d, uint32_t n,
+                                                        const uint32_t* __restrict__ inverse,
+                                                        const uint32_t* __restrict__ seg_off,
+                                                        uint32_t* __restrict__ seg_pos) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t running;
+  const uint32_t nh = *d.heavy_n;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+    const uint32_t u = d.heavy[h];
+    uint32_t* outp = seg_pos + seg_off[u];
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 4096) {
+      const uint32_t p0 = base + threadIdx.x * 4;
+      uint32_t f[4];
+      uint32_t c = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f[k] = (p0 + k < n && inverse[p0 + k] == u) ? 1u : 0u;
+        c += f[k];
+      }
+      uint32_t incl = c;
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      if (lane == 63) wsum[w] = incl;
+      __syncthreads();
+      uint32_t off = running + (incl - c);
+      for (int i = 0; i < w; ++i) off += wsum[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (f[k]) outp[off++] = p0 + k;
+      __syncthreads();
+      if (threadIdx.x == 1023) running = off;  // last thread's end offset == total so far
+      __syncthreads();
+    }
+  }
+}
+
+// =============================================================================================
+// Forward scatter of unique rows to every occurrence: out[p] = src[inverse[p]]
+// (FillWithOffsetMap, ops/unique_mapping_ops.cc:225-242, in gather form).
+// =============================================================================================
+template <int G, int VEC>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src,
+                                                          const uint32_t* __restrict__ index,
+                                                          int64_t n, uint32_t dim,
+                                                          float* __restrict__ out) {
+  const int j = threadIdx.x & (G - 1);
+  const int64_t p = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  if (p >= n) return;
+  const float* sp = src + int64_t(index[p]) * dim;
+  float* op = out + p * int64_t(dim);
+  for (uint32_t e = j * VEC; e < dim; e += G * VEC) {
+    Vec<VEC> v;
+    v.load(sp + e);
+    v.store(op + e);
+  }
+}
+
+// =============================================================================================
+// Duplicate-gradient sum in occurrence order (FillWithOffsetMapGradient,
+// ops/unique_mapping_ops.cc:307-324): out[u] = 0 + g[p0] + g[p1] + ...  over list u.
+//
+// Under Zipf(1.2) a 65 536-id batch has a head key with ~12 000 occurrences and ~60 % of all
+// occurrences belong to <100 keys, so the reduction must be spread over the chip by OCCURRENCE,
+// not by key.  The flat CSR position array is cut into windows of WIN = min(G,16) entries, one
+// G-lane group per window: lane t preloads entry t (position, list id, list bounds) and all WIN
+// gradient rows are in flight at once.  A run that covers its whole list is written straight to
+// out[u] — bit-identical to the reference's sequential sum.  A list that crosses a window
+// boundary leaves per-window partials:
+//   part[2*w+0] : the run that entered window w from the previous window
+//   part[2*w+1] : the run that starts inside window w and leaves it unfinished (last_u[w] = list)
+// which segsum_combine_kernel adds in window order with a fixed association (deterministic; it
+// differs from the sequential sum only by fp32 re-association, well inside the 1e-5 bar).
+// segsum_exact_kernel keeps the strictly sequential order for parity runs.
+// =============================================================================================
+constexpr uint32_t kNone = 0xffffffffu;
+
+template <int G, int VEC>
+__global__ __launch_bounds__(256) void segsum_window_kernel(
+    const float* __restrict__ grads, const uint32_t* __restrict__ inverse,
+    const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_pos, uint32_t n,
+    uint32_t dim, float* __restrict__ out, float* __restrict__ part,
+    uint32_t* __restrict__ last_u) {
+  constexpr int WIN = G < 16 ? G : 16;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (G - 1);
+  const int gbase = lane & ~(G - 1);
+  const int64_t w = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  const int64_t qb = w * WIN;
+  const bool live = qb < int64_t(n);  // group-uniform
+  const bool has = live && j < WIN && qb + j < int64_t(n);
+  const uint32_t p = has ? seg_pos[qb + j] : 0u;
+  const uint32_t u = has ? inverse[p] : kNone;
+  const uint32_t s0 = has ? seg_off[u] : 0u;
+  const uint32_t s1 = has ? seg_off[u + 1] : 0u;
+  if (live && j == 0) last_u[w] = kNone;
+  uint32_t pt[WIN], ut[WIN + 1], a0[WIN], a1[WIN];
+#pragma unroll
+  for (int t = 0; t < WIN; ++t) {
+    pt[t] = __shfl(p, gbase + t);
+    ut[t] = __shfl(u, gbase + t);
+    a0[t] = __shfl(s0, gbase + t);
+    a1[t] = __shfl(s1, gbase + t);
+  }
+  ut[WIN] = kNone;
+  if (!live) return;
+  for (uint32_t e = j * VEC; e < dim; e += G * VEC) {
+    Vec<VEC> v[WIN];
+#pragma unroll
+    for (int t = 0; t < WIN; ++t)
+      if (ut[t] != kNone) v[t].load(grads + int64_t(pt[t]) * dim + e);
+    Vec<VEC> acc;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc.v[c] = 0.f;
+    uint32_t cur = ut[0], c0 = a0[0], c1 = a1[0];
+    uint32_t run_start = uint32_t(qb);
+#pragma unroll
+    for (int t = 0; t <= WIN; ++t) {
+      if (ut[t] != cur) {
+        const uint32_t run_end = uint32_t(qb) + t;
+        float* dst;
+        if (run_start == c0 && run_end == c1) {
+          dst = out + int64_t(cur) * dim + e;
+        } else if (run_start != c0) {
+          dst = part + (w * 2 + 0) * int64_t(dim) + e;
+        } else {
+          dst = part + (w * 2 + 1) * int64_t(dim) + e;
+          if (j == 0) last_u[w] = cur;
+        }
+        acc.store(dst);
+        if (ut[t] == kNone) break;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc.v[c] = 0.f;
+        cur = ut[t];
+        c0 = a0[t < WIN ? t : 0];
+        c1 = a1[t < WIN ? t : 0];
+        run_start = run_end;
+      }
+      if (t < WIN) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc.v[c] = acc.v[c] + v[t].v[c];
+      }
+    }
+  }
+}
+
+// One workgroup per window that holds the head of a boundary-crossing list.
+template <int G, int VEC>
+__global__ __launch_bounds__(256) void segsum_combine_kernel(
+    const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ last_u, uint32_t dim,
+    float* __restrict__ out, const float* __restrict__ part) {
+  constexpr int WIN = G < 16 ? G : 16;
+  constexpr int NG = 256 / G;
+  __shared__ float sh[NG * G * VEC];
+  const int64_t w = blockIdx.x;
+  const uint32_t u = last_u[w];
+  if (u == kNone) return;  // block-uniform
+  const int j = threadIdx.x & (G - 1);
+  const int gi = threadIdx.x / G;
+  const uint32_t s1 = seg_off[u + 1];
+  const int64_t w1 = int64_t(s1 - 1) / WIN;
+  const int64_t items = (w1 - w) + 1;  // item 0 = part[2w+1], item i>0 = part[2(w+i)+0]
+  const int64_t per = (items + NG - 1) / NG;
+  const int64_t i0 = gi * per;
+  const int64_t i1 = (i0 + per < items) ? (i0 + per) : items;
+  for (uint32_t e = j * VEC; e < dim; e += G * VEC) {
+    Vec<VEC> acc;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc.v[c] = 0.f;
+    for (int64_t i = i0; i < i1; i += 8) {
+      Vec<VEC> v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int64_t it = i + t;
+        if (it < i1) {
+          const int64_t row = (it == 0) ? (w * 2 + 1) : ((w + it) * 2);
+          v[t].load(part + row * int64_t(dim) + e);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (i + t < i1) {
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) acc.v[c] = acc.v[c] + v[t].v[c];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) sh[(gi * G + j) * VEC + c] = acc.v[c];
+    __syncthreads();
+    if (gi == 0) {
+      Vec<VEC> tot;
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) tot.v[c] = sh[j * VEC + c];
+      for (int g2 = 1; g2 < NG; ++g2) {
+        if (int64_t(g2) * per >= items) break;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) tot.v[c] = tot.v[c] + sh[(g2 * G + j) * VEC + c];
+      }
+      tot.store(out + int64_t(u) * dim + e);
+    }
+    __syncthreads();
+  }
+}
+
+// Strictly sequential per-list sum (bit-exact with the reference; slow for Zipf head keys).
+template <int G, int VEC>
+__global__ __launch_bounds__(256) void segsum_exact_kernel(
+    const float* __restrict__ grads, const uint32_t* __restrict__ n_unique,
+    const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_pos, uint32_t dim,
+    float* __restrict__ out) {
+  const int j = threadIdx.x & (G - 1);
+  const uint32_t u = uint32_t((int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G);
+  if (u >= *n_unique) return;
+  const uint32_t q0 = seg_off[u], q1 = seg_off[u + 1];
+  for (uint32_t e = j * VEC; e < dim; e += G * VEC) {
+    Vec<VEC> acc;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc.v[c] = 0.f;
+    for (uint32_t q = q0; q < q1; ++q) {
+      Vec<VEC> v;
+      v.load(grads + int64_t(seg_pos[q]) * dim + e);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) acc.v[c] = acc.v[c] + v.v[c];
+    }
+    acc.store(out + int64_t(u) * dim + e);
+  }
+}
+
+// value_offset[q] = base + (seg_pos[q] * dim)   (the float offsets the reference op emits)
+__global__ __launch_bounds__(256) void offsets_from_positions_kernel(
+    const uint32_t* __restrict__ seg_pos, uint32_t n, int64_t base, int64_t dim,
+    int64_t* __restrict__ value_offset) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) value_offset[q] = base + int64_t(seg_pos[q]) * dim;
+}
+__global__ __launch_bounds__(256) void widen_offsets_kernel(const uint32_t* __restrict__ seg_off,
+                                                            const uint32_t* __restrict__ n_unique,
+                                                            int64_t base,
+                                                            int64_t* __restrict__ out) {
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u <= *n_unique) out[u] = base + int64_t(seg_off[u]);
+}
+
+// =============================================================================================
+// General (op-level) forms of FillWithOffsetMap / FillWithOffsetMapGradient for one table
+// (ops/unique_mapping_ops.cc:204-329): `pos[i]` names a unique key, whose float offsets into the
+// flat buffer are offset_map[split[pos[i]] .. split[pos[i]+1]).
+// =============================================================================================
+template <int G, int VEC>
+__global__ __launch_bounds__(256) void scatter_offsets_kernel(
+    const int64_t* __restrict__ pos, int64_t n, const float* __restrict__ value,
+    const int64_t* __restrict__ offset_map, const int64_t* __restrict__ offset_split, uint32_t dim,
+    float* __restrict__ buffer) {
+  const int j = threadIdx.x & (G - 1);
+  const int64_t i = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  if (i >= n) return;
+  const int64_t p = pos[i];
+  const int64_t q0 = offset_split[p], q1 = offset_split[p + 1];
+  for (uint32_t e = j * VEC; e < dim; e += G * VEC) {
+    Vec<VEC> v;
+    v.load(value + i * int64_t(dim) + e);
+    for (int64_t q = q0; q < q1; ++q) v.store(buffer + offset_map[q] + e);
+  }
+}
+
+template <int G, int VEC>
+__global__ __launch_bounds__(256) void gather_sum_offsets_kernel(
+    const int64_t* __restrict__ pos, int64_t n, const float* __restrict__ grad,
+    const int64_t* __restrict__ offset_map, const int64_t* __restrict__ offset_split, uint32_t dim,
+    float* __restrict__ out) {
+  const int j = threadIdx.x & (G - 1);
+  const int64_t i = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  if (i >= n) return;
+  const int64_t p = pos[i];
+  const int64_t q0 = offset_split[p], q1 = offset_split[p + 1];
+  for (uint32_t e = j * VEC; e < dim; e += G * VEC) {
+    Vec<VEC> acc;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc.v[c] = 0.f;
+    for (int64_t q = q0; q < q1; ++q) {
+      Vec<VEC> v;
+      v.load(grad + offset_map[q] + e);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) acc.v[c] = acc.v[c] + v.v[c];
+    }
+    acc.store(out + i * int64_t(dim) + e);
+  }
+}
+
+}  // namespace mhte
+#endif  // MHTE_KERNELS_H_

@@ -1,0 +1,211 @@
+"""Device-side dedup / packing ops around the table — host-side mirror of
+monolith/native_training/distribution_ops.py (reference :80-190) for the ops that sit on the hot
+path: ``unique_key_with_value_and_offset``, ``fill_with_offset_map`` and its gradient.
+
+Two API levels:
+  * the reference signatures (ragged key, value_offset ragged-of-ragged, value_buffer), for drop-in
+    call sites and parity tests against the reference's docstring examples;
+  * ``DedupWorkspace`` — the same computation in the form the fused MI355X step uses
+    (unique ids, inverse index, CSR occurrence lists, unique count left on the device so that
+    dedup -> lookup -> scatter -> segment-sum -> optimize runs without a host round trip).
+"""
+import ctypes as C
+from typing import List, NamedTuple, Optional
+
+import numpy as np
+import torch
+
+from monolith_amd import _lib
+from monolith_amd._lib import check, vp
+from monolith_amd.multi_hash_table_ops import Ragged, _stream
+
+
+class UniqueResult(NamedTuple):
+  unique_ids: torch.Tensor    # int64 [n]   (first n_unique entries valid), first-occurrence order
+  inverse: torch.Tensor       # int32 [n]   unique index of every position
+  seg_off: torch.Tensor       # int32 [n+1] CSR offsets of each unique id's occurrence list
+  seg_pos: torch.Tensor       # int32 [n]   positions, grouped by unique id, occurrence order
+  n_unique_dev: torch.Tensor  # int32 [1]
+  n_unique: Optional[int]     # host copy when requested
+
+
+class DedupWorkspace:
+  """Scratch + entry points for the device dedup (libmhte.so: mhte_unique & co)."""
+
+  def __init__(self, device: Optional[int] = None):
+    if not torch.cuda.is_available():
+      raise _lib.MhteError(_lib.MHTE_UNAVAILABLE, "DedupWorkspace needs a HIP device")
+    self._lib = _lib.lib()
+    self._device = torch.cuda.current_device() if device is None else int(device)
+    h = C.c_void_p()
+    check(self._lib.mhte_dedup_ws_create(C.c_int32(self._device), C.byref(h)))
+    self._h = h
+
+  def close(self):
+    if getattr(self, "_h", None):
+      torch.cuda.synchronize(self._device)
+      self._lib.mhte_dedup_ws_destroy(self._h)
+      self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def unique(self, ids: torch.Tensor, want_host_count: bool = True,
+             out: Optional[UniqueResult] = None) -> UniqueResult:
+    """First-occurrence-order unique with occurrence lists (unique_mapping_ops.cc:82-114)."""
+    assert ids.is_cuda and ids.dtype == torch.int64 and ids.is_contiguous()
+    n = ids.numel()
+    dev = ids.device
+    if out is None:
+      uids = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+      inverse = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+      seg_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+      seg_pos = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+      nu = torch.zeros(1, dtype=torch.int32, device=dev)
+    else:
+      uids, inverse, seg_off, seg_pos, nu = out[:5]
+    host = C.c_int64(0)
+    check(self._lib.mhte_unique(self._h, vp(ids), C.c_int64(n), vp(uids), vp(inverse), vp(seg_off),
+                                vp(seg_pos), vp(nu), C.byref(host) if want_host_count else None,
+                                _stream()))
+    return UniqueResult(uids, inverse, seg_off, seg_pos, nu,
+                        int(host.value) if want_host_count else None)
+
+  def gather_rows(self, src: torch.Tensor, index: torch.Tensor, n: int, dim: int,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[p] = src[index[p]] — FillWithOffsetMap in gather form (unique_mapping_ops.cc:225-242)."""
+    if out is None:
+      out = torch.empty((n, dim), dtype=torch.float32, device=src.device)
+    check(self._lib.mhte_gather_rows(vp(src), vp(index), C.c_int64(n), C.c_int32(dim), vp(out),
+                                     _stream()))
+    return out
+
+  def segment_sum(self, grads: torch.Tensor, u: UniqueResult, dim: int,
+                  out: Optional[torch.Tensor] = None, exact_order: bool = False) -> torch.Tensor:
+    """out[k] = sum of grads over the occurrence list of unique id k
+    (FillWithOffsetMapGradient, unique_mapping_ops.cc:307-324).  Rows >= n_unique are untouched."""
+    n = grads.numel() // dim
+    if out is None:
+      out = torch.zeros((max(n, 1), dim), dtype=torch.float32, device=grads.device)
+    check(self._lib.mhte_segment_sum(self._h, vp(grads), vp(u.inverse), vp(u.seg_off),
+                                     vp(u.seg_pos), vp(u.n_unique_dev), C.c_int64(n),
+                                     C.c_int32(dim), vp(out), C.c_int32(1 if exact_order else 0),
+                                     _stream()))
+    return out
+
+
+_default_ws = {}
+
+
+def _ws(device) -> DedupWorkspace:
+  d = device.index if isinstance(device, torch.device) else int(device)
+  if d not in _default_ws:
+    _default_ws[d] = DedupWorkspace(d)
+  return _default_ws[d]
+
+
+class _UniqueKeyWithValueAndOffsetResult(NamedTuple):
+  unique_key: Ragged                 # values int64 [U], row_splits host [T+1]
+  value_offset: torch.Tensor         # int64 [n]: float offsets into value_buffer
+  value_offset_split: torch.Tensor   # int64 [U+1]: list boundaries per unique key
+  value_buffer: Optional[torch.Tensor]
+
+
+def unique_key_with_value_and_offset(key: Ragged, dims: List[int], generate_buffer=True):
+  """reference distribution_ops.py:86-118 / ops/unique_mapping_ops.cc:51-155.
+
+  key = [[0, 1, 0], [0]], dims = [2, 3] =>
+    unique_key = [[0, 1], [0]], value_offset = [[[0, 4], [2]], [[6]]], buffer length 9.
+  The ragged-of-ragged value_offset is returned flat (values + per-unique-key splits); the outer
+  split is unique_key.row_splits, exactly the three tensors the reference op emits."""
+  T = len(dims)
+  if key.row_splits.size != T + 1:
+    raise _lib.InvalidArgumentError(
+        _lib.MHTE_INVALID_ARGUMENT,
+        "RaggedKey should have %d but got %d" % (T, key.row_splits.size - 1))
+  dev = key.values.device
+  ws = _ws(dev)
+  L = _lib.lib()
+  n = key.values.numel()
+  uniq_parts, splits = [], [0]
+  value_offset = torch.empty(n, dtype=torch.int64, device=dev)
+  vo_split_parts = []
+  value_base = 0
+  for t in range(T):
+    lo, hi = int(key.row_splits[t]), int(key.row_splits[t + 1])
+    ids = key.values[lo:hi].contiguous()
+    r = ws.unique(ids, want_host_count=True)
+    U = r.n_unique
+    uniq_parts.append(r.unique_ids[:U])
+    if hi > lo:
+      vos = torch.empty(hi - lo + 1, dtype=torch.int64, device=dev)
+      check(L.mhte_value_offsets(vp(r.seg_off), vp(r.seg_pos), vp(r.n_unique_dev),
+                                 C.c_int64(hi - lo), C.c_int64(value_base), C.c_int64(dims[t]),
+                                 C.c_int64(lo), vp(value_offset[lo:hi]), vp(vos), _stream()))
+      # the reference emits cumulative list ends after a leading 0
+      vo_split_parts.append(vos[1:U + 1])
+    splits.append(splits[-1] + U)
+    value_base += (hi - lo) * dims[t]
+  zero = torch.zeros(1, dtype=torch.int64, device=dev)
+  value_offset_split = torch.cat([zero] + vo_split_parts) if vo_split_parts else zero
+  unique_key = Ragged(torch.cat(uniq_parts) if uniq_parts else key.values[:0],
+                      np.ascontiguousarray(splits, dtype=np.int64))
+  buf = torch.zeros(value_base, dtype=torch.float32, device=dev) if generate_buffer else None
+  return _UniqueKeyWithValueAndOffsetResult(unique_key, value_offset, value_offset_split, buf)
+
+
+def _all_vec4(dims):
+  return all(d % 4 == 0 for d in dims)
+
+
+def fill_with_offset_map(pos: Ragged, value: torch.Tensor, value_offset_map: torch.Tensor,
+                         value_offset_map_split: torch.Tensor, value_buffer: torch.Tensor,
+                         dims: List[int]) -> torch.Tensor:
+  """reference distribution_ops.py:121-148 / ops/unique_mapping_ops.cc:204-268."""
+  T = len(dims)
+  if pos.row_splits.size != T + 1:
+    raise _lib.InvalidArgumentError(
+        _lib.MHTE_INVALID_ARGUMENT, "Pos's first dim doesn't match dim size. %d v.s. %d" %
+        (pos.row_splits.size - 1, T))
+  expected = int(sum(int(pos.row_splits[t + 1] - pos.row_splits[t]) * dims[t] for t in range(T)))
+  if value.numel() < expected:
+    raise _lib.InvalidArgumentError(
+        _lib.MHTE_INVALID_ARGUMENT,
+        "Value size doesn't match expected size. expected: %d, actual: %d. " %
+        (expected, value.numel()))
+  L = _lib.lib()
+  vec = 1 if _all_vec4(dims) else 0
+  voff = 0
+  for t in range(T):
+    lo, hi = int(pos.row_splits[t]), int(pos.row_splits[t + 1])
+    if hi > lo:
+      check(L.mhte_fill_with_offset_map(vp(pos.values[lo:hi]), C.c_int64(hi - lo),
+                                        vp(value[voff:]), vp(value_offset_map),
+                                        vp(value_offset_map_split), C.c_int32(dims[t]),
+                                        C.c_int32(vec), vp(value_buffer), _stream()))
+    voff += (hi - lo) * dims[t]
+  return value_buffer
+
+
+def fill_with_offset_map_gradient(pos: Ragged, grad: torch.Tensor, grad_offset_map: torch.Tensor,
+                                  grad_offset_map_split: torch.Tensor,
+                                  dims: List[int]) -> torch.Tensor:
+  """ops/unique_mapping_ops.cc:284-329: backprop_grad[i] = sum over offsets of pos[i]."""
+  T = len(dims)
+  total = int(sum(int(pos.row_splits[t + 1] - pos.row_splits[t]) * dims[t] for t in range(T)))
+  out = torch.empty(total, dtype=torch.float32, device=grad.device)
+  L = _lib.lib()
+  vec = 1 if _all_vec4(dims) else 0
+  ooff = 0
+  for t in range(T):
+    lo, hi = int(pos.row_splits[t]), int(pos.row_splits[t + 1])
+    if hi > lo:
+      check(L.mhte_fill_with_offset_map_gradient(vp(pos.values[lo:hi]), C.c_int64(hi - lo),
+                                                 vp(grad), vp(grad_offset_map),
+                                                 vp(grad_offset_map_split), C.c_int32(dims[t]),
+                                                 C.c_int32(vec), vp(out[ooff:]), _stream()))
+    ooff += (hi - lo) * dims[t]
+  return out

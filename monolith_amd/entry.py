@@ -1,0 +1,195 @@
+"""Table / optimizer / initializer configuration, mirroring the call-site contract of
+monolith/native_training/entry.py (reference :27-640) without protobuf: the same class names and
+constructor arguments, lowered to the flat C structs of include/monolith_amd_hash_table.h instead of
+EmbeddingHashTableConfig protos (runtime/hash_table/embedding_hash_table.proto:23-95).
+
+Only what the hot path needs is present: SGD / Adagrad / FTRL optimizers, zeros / ones / constants
+initializers, cuckoo table config, per-feature-slot expire times.  Asking for anything else raises
+(no silent downgrade)."""
+import dataclasses
+from typing import Any, Dict, List, Optional, Sequence
+
+from monolith_amd import _lib
+
+
+class Optimizer:
+  opt_type = None
+
+  def params(self) -> Sequence[float]:
+    return ()
+
+
+class SgdOptimizer(Optimizer):
+  """reference entry.py:54-74; proto default learning_rate 0.01 (optimizer.proto:50-54)."""
+  opt_type = _lib.OPT_SGD
+
+  def __init__(self, learning_rate=None):
+    self.learning_rate = 0.01 if learning_rate is None else learning_rate
+
+
+class AdagradOptimizer(Optimizer):
+  """reference entry.py:77-112; proto defaults lr 0.001, initial_accumulator_value 0.1,
+  weight_decay_factor 0 (optimizer.proto:19-26)."""
+  opt_type = _lib.OPT_ADAGRAD
+
+  def __init__(self, learning_rate=None, initial_accumulator_value=None,
+               hessian_compression_times=1, warmup_steps=0, weight_decay_factor=0.0):
+    if hessian_compression_times != 1:
+      raise NotImplementedError("hessian_compression_times != 1 is not on the MI355X hot path")
+    self.learning_rate = 0.001 if learning_rate is None else learning_rate
+    self.initial_accumulator_value = (0.1 if initial_accumulator_value is None else
+                                      initial_accumulator_value)
+    self.weight_decay_factor = weight_decay_factor
+    self.warmup_steps = warmup_steps
+
+  def params(self):
+    return (self.initial_accumulator_value, self.weight_decay_factor)
+
+
+class FtrlOptimizer(Optimizer):
+  """reference entry.py:365-392; proto defaults lr 0.01, beta 0, initial_accumulator_value 0.1,
+  l1 = l2 = 0 (optimizer.proto:59-67)."""
+  opt_type = _lib.OPT_FTRL
+
+  def __init__(self, learning_rate=None, initial_accumulator_value=None, beta=None, warmup_steps=0,
+               l1_regularization=None, l2_regularization=None):
+    self.learning_rate = 0.01 if learning_rate is None else learning_rate
+    self.initial_accumulator_value = (0.1 if initial_accumulator_value is None else
+                                      initial_accumulator_value)
+    self.beta = 0.0 if beta is None else beta
+    self.l1_regularization_strength = 0.0 if l1_regularization is None else l1_regularization
+    self.l2_regularization_strength = 0.0 if l2_regularization is None else l2_regularization
+    self.warmup_steps = warmup_steps
+
+  def params(self):
+    return (self.initial_accumulator_value, self.beta, self.l1_regularization_strength,
+            self.l2_regularization_strength)
+
+
+class Initializer:
+  init_type = None
+  value = 0.0
+
+
+class ZerosInitializer(Initializer):
+  """reference entry.py:404-411"""
+  init_type = _lib.INIT_ZEROS
+
+
+class OnesInitializer(Initializer):
+  """runtime/hash_table/initializer (ones)"""
+  init_type = _lib.INIT_ONES
+
+
+class ConstantsInitializer(Initializer):
+  """reference entry.py:414-423"""
+  init_type = _lib.INIT_CONSTANT
+
+  def __init__(self, constant: float):
+    self.value = float(constant)
+
+
+class Fp32Compressor:
+  """reference entry.py:505-511 — training rows are fp32; the serving-side compressors are out of
+  scope."""
+
+
+@dataclasses.dataclass
+class Segment:
+  """EntryConfig.Segment (embedding_hash_table.proto:23-43)."""
+  dim_size: int
+  initializer: Initializer
+  optimizer: Optimizer
+
+
+def CombineAsSegment(dim_size: int, initializer: Initializer, optimizer: Optimizer,
+                     compressor: Any = None) -> Segment:
+  """reference entry.py:514-537"""
+  if compressor is not None and not isinstance(compressor, Fp32Compressor):
+    raise NotImplementedError("only Fp32Compressor rows are on the MI355X hot path")
+  if not isinstance(initializer, Initializer) or initializer.init_type is None:
+    raise NotImplementedError("initializer %r is not supported" % (initializer,))
+  if not isinstance(optimizer, Optimizer) or optimizer.opt_type is None:
+    raise NotImplementedError("optimizer %r is not supported" % (optimizer,))
+  return Segment(dim_size=int(dim_size), initializer=initializer, optimizer=optimizer)
+
+
+@dataclasses.dataclass
+class SlotExpireTimeConfig:
+  """embedding_hash_table.proto:54-64: per-feature-slot TTL in days, default 36500."""
+  default_expire_time: int = 36500
+  slot_expire_times: Dict[int, int] = dataclasses.field(default_factory=dict)
+
+
+@dataclasses.dataclass
+class EmbeddingHashTableConfig:
+  """embedding_hash_table.proto:70-95 (the fields the hot path reads)."""
+  segments: List[Segment] = dataclasses.field(default_factory=list)
+  initial_capacity: int = 1
+  slot_expire_time_config: SlotExpireTimeConfig = dataclasses.field(
+      default_factory=SlotExpireTimeConfig)
+  enable_feature_eviction: bool = False
+  feature_evict_every_n_hours: int = 240
+  # MI355X extensions
+  reserve_rows: int = 0
+  max_load_factor: float = 0.0
+
+  @property
+  def dim_size(self):
+    return sum(s.dim_size for s in self.segments)
+
+
+class CuckooHashTableConfig:
+  """reference entry.py:549-563"""
+
+  def __init__(self, initial_capacity=1, feature_evict_every_n_hours=0, reserve_rows=0,
+               max_load_factor=0.0):
+    self._initial_capacity = initial_capacity
+    self._feature_evict_every_n_hours = feature_evict_every_n_hours
+    self._reserve_rows = reserve_rows
+    self._max_load_factor = max_load_factor
+
+  def mutate_table(self, table_config: EmbeddingHashTableConfig):
+    table_config.initial_capacity = self._initial_capacity
+    table_config.reserve_rows = self._reserve_rows
+    table_config.max_load_factor = self._max_load_factor
+    if self._feature_evict_every_n_hours > 0:
+      table_config.enable_feature_eviction = True
+      table_config.feature_evict_every_n_hours = self._feature_evict_every_n_hours
+
+
+class HashTableConfigInstance:
+  """reference entry.py:566-628: a table config + one learning-rate fn/value per segment."""
+
+  def __init__(self, table_config: EmbeddingHashTableConfig, learning_rate_fns: List[Any],
+               extra_restore_names=None):
+    self._table_config = table_config
+    self._learning_rate_fns = list(learning_rate_fns)
+    self.extra_restore_names = list(extra_restore_names or [])
+
+  @property
+  def table_config(self):
+    return self._table_config
+
+  @property
+  def learning_rate_fns(self):
+    return self._learning_rate_fns
+
+  def call_learning_rate_fns(self) -> List[float]:
+    if not self._learning_rate_fns:
+      raise Exception("Learning_rate_fns must be not empty.")
+    return [float(fn() if callable(fn) else fn) for fn in self._learning_rate_fns]
+
+
+def make_table_config(segments: Sequence[Segment], hash_table_config: Optional[CuckooHashTableConfig]
+                      = None, slot_expire_time_config: Optional[SlotExpireTimeConfig] = None,
+                      learning_rates: Optional[Sequence[float]] = None) -> HashTableConfigInstance:
+  """Convenience: what the reference's test helpers build by hand (multi_hash_table_ops_test.py
+  :30-48) — segments + cuckoo config -> HashTableConfigInstance with one lr per segment."""
+  tc = EmbeddingHashTableConfig(segments=list(segments))
+  (hash_table_config or CuckooHashTableConfig()).mutate_table(tc)
+  if slot_expire_time_config is not None:
+    tc.slot_expire_time_config = slot_expire_time_config
+  if learning_rates is None:
+    learning_rates = [s.optimizer.learning_rate for s in segments]
+  return HashTableConfigInstance(tc, list(learning_rates))

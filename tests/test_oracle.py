@@ -1,0 +1,244 @@
+"""CPU suite: pins the C restatement (oracle/mhte_oracle.c) to
+  (1) the known-answer values of the reference's own tests,
+  (2) the committed golden fixtures generated from the reference's code (tests/golden/), and
+  (3) where it exists (build container), the reference-built library oracle/_ref directly.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from monolith_amd import synthetic as S
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+needs_ref = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built here")
+
+
+# ------------------------------------------------------------------ reference KATs: optimizers
+def test_adagrad_kat_reference_test():
+  # adagrad_optimizer_test.cc:32-48: init_acc=1, lr=.1, g={1,2} -> {-0.07071067,-0.08944272}
+  num, norm = O.adagrad([0, 0], [1, 1], [1, 2], 0.1, 0.0)
+  np.testing.assert_allclose(num, [-0.07071067, -0.08944272], rtol=0, atol=1e-7)
+  np.testing.assert_array_equal(norm, [2.0, 5.0])
+
+
+def test_adagrad_weight_decay_kat():
+  # adagrad_optimizer_test.cc:60-88 second step with wd=.1 (baseline semantics)
+  num, norm = O.adagrad([0, 0], [1, 1], [1, 2], 0.1, 0.1)
+  num, norm = O.adagrad(num, norm, [1, 2], 0.1, 0.1)
+  np.testing.assert_allclose(num, [-0.128173, -0.155943], rtol=0, atol=1e-5)
+
+
+def test_sgd_kat():
+  # embedding_hash_table_test.h:60-66: Optimize(13, {1}, lr .01) -> -0.01
+  np.testing.assert_array_equal(O.sgd([0.0], [1.0], 0.01), np.float32([-0.01]))
+
+
+def test_adagrad_matches_reference_arithmetic_fixture():
+  z = np.load(os.path.join(GOLD, "adagrad_kat.npz"))
+  for wd in (0.0, 0.1):
+    num, norm = O.adagrad(z["num"], z["norm"], z["grad"], float(z["lr"]), wd)
+    # scalar reference path: bit-exact
+    np.testing.assert_array_equal(num, z["num_wd%g_avx0" % wd])
+    np.testing.assert_array_equal(norm, z["norm_wd%g_avx0" % wd])
+    # AVX2/FMA reference path: avx_test.cc:29-62 allows 1e-6 (only when wd == 0 the two agree,
+    # avx_utils.h:112 subtracts eff_lr*grad, not eff_lr*g)
+    if wd == 0.0:
+      np.testing.assert_allclose(num, z["num_wd0_avx1"], rtol=0, atol=1e-6)
+
+
+# ------------------------------------------------------------------ reference KATs: table ops
+def _table(dim=1, opt=O.OPT_SGD, **kw):
+  return O.Table(O.segment(dim, opt, **kw), 1)
+
+
+def test_lookup_miss_is_zero_and_does_not_insert():
+  # embedding_hash_table_test.h:41-49
+  t = _table(2)
+  e, hits = t.lookup([1, 2, 3])
+  assert hits == 0 and not e.any() and t.size() == 0
+
+
+def test_assign_add_negative_id():
+  # embedding_hash_table_test.h:51-58: AssignAdd(-10, 2.5)
+  t = _table(1)
+  t.assign_add([-10], [[2.5]])
+  np.testing.assert_array_equal(t.lookup([-10])[0], [[2.5]])
+
+
+def test_optimize_duplicates_apply_sequentially():
+  # hash_table_ops_test.py:134-148: ids [0,0,1], grad -1, lr .1 -> [[.2],[.1]]
+  t = _table(1)
+  t.optimize([0, 0, 1], [[-1.0], [-1.0], [-1.0]], [0.1])
+  np.testing.assert_allclose(t.lookup([0, 1])[0], [[0.2], [0.1]], atol=1e-7)
+
+
+def test_multi_table_sgd_kat():
+  # multi_hash_table_ops_test.py:101-127: SGD lr 1: grads 2;[[1,3],[2,4]] -> -2;[[-1,-3],[-2,-4]]
+  t1, t2 = _table(1), _table(2)
+  t1.optimize([0], [[2.0]], [1.0])
+  t2.optimize([1, 2], [[1.0, 3.0], [2.0, 4.0]], [1.0])
+  np.testing.assert_array_equal(t1.lookup([0])[0], [[-2.0]])
+  np.testing.assert_array_equal(t2.lookup([1, 2])[0], [[-1.0, -3.0], [-2.0, -4.0]])
+
+
+def test_reinitialize_status_codes():
+  # multi_hash_table_ops_test.py:52-99: assign_add ids then reinitialize -> [0,1,1] style
+  t = _table(1)
+  t.assign_add([1, 2], [[1.0], [1.0]])
+  st = t.reinitialize([0, 1, 2])
+  np.testing.assert_array_equal(st, [0, 1, 1])
+  assert not t.lookup([0, 1, 2])[0].any()
+
+
+def test_evict_ttl_per_slot():
+  # embedding_hash_table_test.h:282-326: slot 1 TTL 5 d evicted at +5 d 60 s; slot 2 TTL 6 d and
+  # default 14 d kept.
+  t = _table(1)
+  day = 86400
+  f1, f2, f3 = (1 << 48) | 123, (2 << 48) | 123, (3 << 48) | 123
+  t.assign([f1, f2, f3], [[1.0], [2.0], [3.0]], update_time=1000)
+  t.set_ttl(14, {1: 5, 2: 6})
+  t.evict(1000 + 5 * day + 60)
+  assert not t.contains(f1) and t.contains(f2) and t.contains(f3)
+  assert t.size() == 2
+
+
+def test_update_time_truncated_to_uint32():
+  t = _table(1)
+  t.assign([5], [[1.0]], update_time=(1 << 32) + 77)
+  assert int(t.dump()[2][0]) == 77
+
+
+def test_multi_segment_row_layout_and_lrs():
+  # bias FTRL(dim 1) + vector Adagrad(dim 4) as in distributed_ps_test.py:480-505
+  segs = [O.segment(1, O.OPT_FTRL, p=(0.1, 0.0, 0.0, 0.0)), O.segment(4, O.OPT_ADAGRAD, p=(0.1, 0.0))]
+  t = O.Table(segs, 1)
+  assert t.dim == 5 and t.row_floats == 5 + 2 + 4
+  g = np.float32([[1, 1, 2, 3, 4]])
+  t.optimize([9], g, [0.5, 0.1])
+  row = t.dump()[3][0]
+  # adagrad part: n = .1 + g^2 ; w = -lr/sqrt(n)*g
+  gv = g[0, 1:]
+  n = np.float32(0.1) + gv * gv
+  np.testing.assert_allclose(row[7:11], n, rtol=1e-7)
+  np.testing.assert_allclose(row[1:5], -np.float32(0.1) / np.sqrt(n) * gv, rtol=1e-6)
+  # ftrl part (ftrl_optimizer.cc:56-75) with l1=0: z = g - sigma*0 = 1; w = lr*(signbit(z)*0 - z)/(sqrt(n)+beta)
+  nf = np.float32(0.1) + np.float32(1.0)
+  np.testing.assert_allclose(row[5], nf, rtol=1e-7)
+  np.testing.assert_allclose(row[6], 1.0, rtol=1e-7)
+  np.testing.assert_allclose(row[0], 0.5 * (-1.0) / np.sqrt(nf), rtol=1e-6)
+
+
+# ------------------------------------------------------------------ dedup / packing KATs
+def test_unique_key_with_value_and_offset_docstring_example():
+  # reference distribution_ops.py:101-110
+  uk, uks, vo, vos, blen = O.unique_key_with_value_and_offset([0, 1, 0, 0], [0, 3, 4], [2, 3])
+  np.testing.assert_array_equal(uk, [0, 1, 0])
+  np.testing.assert_array_equal(uks, [0, 2, 3])
+  np.testing.assert_array_equal(vo, [0, 4, 2, 6])
+  np.testing.assert_array_equal(vos, [0, 2, 3, 4])
+  assert blen == 9
+
+
+def test_fill_with_offset_map_docstring_example():
+  # reference distribution_ops.py:133-140
+  buf = O.fill_with_offset_map([0, 1, 2], [0, 2, 3], np.arange(7, dtype=np.float32), [0, 4, 2, 6],
+                               [0, 2, 3, 4], [2, 3], 9)
+  np.testing.assert_array_equal(buf, [0, 1, 2, 3, 0, 1, 4, 5, 6])
+
+
+def test_fill_with_offset_map_gradient_sums_in_order():
+  g = np.float32([1, 2, 10, 20, 100, 200, 7, 8, 9])
+  out = O.fill_with_offset_map_gradient([0, 1, 2], [0, 2, 3], g, [0, 4, 2, 6], [0, 2, 3, 4], [2, 3])
+  np.testing.assert_array_equal(out, [101, 202, 10, 20, 7, 8, 9])
+
+
+def test_fused_lookup_offsets_kat():
+  # hash_table_ops_test.py:1086-1107: splits [4,4], id_offsets 0..6, emb_offsets [0,1,2,4,5,6,8]
+  ko, eo, kpt, es, tk, te = O.compute_fused_offsets([1, 1, 1, 1, 1, 1], [1, 1, 2], 3, 2)
+  np.testing.assert_array_equal(ko, [0, 1, 2, 3, 4, 5, 6])
+  np.testing.assert_array_equal(eo, [0, 1, 2, 4, 5, 6, 8])
+  np.testing.assert_array_equal(es, [4, 4])
+  assert (tk, te) == (6, 8)
+
+
+def test_fused_reorder_by_indices_semantics():
+  # fused_reorder_by_indices.cc:38-123: per-table dedup, shard-major table-minor packing
+  out, shard_sizes, sss, eos, feo = O.fused_reorder_by_indices([[0, 1, 2, 1, 4], [3, 3, 6]], 2,
+                                                               [2, 3])
+  # shard 0: table0 {0,2,4}, table1 {6}; shard 1: table0 {1}, table1 {3}
+  np.testing.assert_array_equal(out, [0, 2, 4, 6, 1, 3])
+  np.testing.assert_array_equal(shard_sizes, [4, 2])
+  np.testing.assert_array_equal(sss, [3, 1, 1, 1])
+  np.testing.assert_array_equal(eos, [5, 3])
+  # emb offsets: shard0 t0 at 0 (3 ids x2), shard0 t1 at 6 (1x3), shard1 t0 at 9 (1x2), shard1 t1 at 11
+  np.testing.assert_array_equal(feo, [0, 9, 2, 9, 4, 11, 11, 6])
+
+
+# ------------------------------------------------------------------ golden fixtures from the reference
+@pytest.mark.parametrize("name", ["sgd_d8_uniform", "adagrad_d16_zipf", "adagrad_d64_zipf"])
+def test_training_loop_matches_reference_fixture(name):
+  z = np.load(os.path.join(GOLD, "table_%s.npz" % name))
+  dim, opt = int(z["dim"]), int(z["opt"])
+  t = O.Table(O.segment(dim, opt, p=(float(z["init_acc"]), float(z["wd"]))), 1)
+  for s in range(int(z["steps"])):
+    ids = S.id_batch(s, int(z["batch"]), int(z["universe"]), str(z["dist"]))
+    g = S.grad_batch(s, int(z["batch"]), dim)
+    uk, _, vo, vos, _ = O.unique_key_with_value_and_offset(ids, [0, ids.size], [dim])
+    assert uk.size == int(z["n_unique"][s])
+    emb_u, _ = t.lookup(uk)
+    emb = O.fill_with_offset_map(np.arange(uk.size), [0, uk.size], emb_u.ravel(), vo, vos, [dim],
+                                 ids.size * dim).reshape(-1, dim)
+    np.testing.assert_array_equal(emb[:64], z["step_emb_first"][s])
+    np.testing.assert_allclose(emb.astype(np.float64).sum(0), z["step_emb_sum"][s], rtol=1e-12)
+    gu = O.fill_with_offset_map_gradient(np.arange(uk.size), [0, uk.size], g.ravel(), vo, vos,
+                                         [dim]).reshape(-1, dim)
+    t.optimize(uk, gu, [float(z["lr"])], S.update_time(s))
+  assert t.size() == int(z["size"])
+  final, hits = t.lookup(z["probe_ids"])
+  assert hits == z["probe_ids"].size
+  np.testing.assert_array_equal(final, z["final_rows"])
+
+
+def test_sequential_placement_matches_reference_fixture():
+  z = np.load(os.path.join(GOLD, "placement_seq.npz"))
+  t = O.Table(O.segment(4, O.OPT_SGD), int(z["cap"]))
+  for i in range(z["ids"].size):
+    t.assign(z["ids"][i:i + 1], z["vals"][i:i + 1], 100 + i)
+  ids, pos, ts, rows = t.dump()
+  np.testing.assert_array_equal(ids, z["dump_ids"])
+  np.testing.assert_array_equal(pos, z["dump_pos"])
+  np.testing.assert_array_equal(ts, z["dump_ts"])
+  np.testing.assert_array_equal(rows, z["dump_rows"])
+
+
+# ------------------------------------------------------------------ live cross-check with oracle/_ref
+@needs_ref
+@pytest.mark.parametrize("opt", [O.OPT_SGD, O.OPT_ADAGRAD])
+def test_random_ops_match_reference_map(opt):
+  rng = np.random.default_rng(11 + opt)
+  t = O.Table(O.segment(6, opt, p=(0.1, 0.0)), 1)
+  r = O.RefTable(6, opt, 0.1, 0.0, 0.0, 1)
+  universe = rng.integers(-2**62, 2**62, 30000)
+  for step in range(12):
+    ids = rng.choice(universe, 5000)
+    v = rng.standard_normal((ids.size, 6)).astype(np.float32)
+    kind = step % 4
+    if kind == 0:
+      t.assign(ids, v, 100 + step); r.assign(ids, v, 100 + step)
+    elif kind == 1:
+      t.assign_add(ids, v, 100 + step); r.assign_add(ids, v, 100 + step)
+    elif kind == 2:
+      t.optimize(ids, v, [0.05], 100 + step); r.optimize(ids, v, 0.05, 100 + step)
+    else:
+      np.testing.assert_array_equal(t.reinitialize(ids[:500], 5), r.reinitialize(ids[:500], 5))
+  assert t.size() == r.size() and t.hashpower() == r.hashpower()
+  a, b = t.dump(), r.dump()
+  for x, y in zip(a, b):
+    np.testing.assert_array_equal(x, y)
+  e1, h1 = t.lookup(universe[:4000])
+  e2, h2 = r.lookup(universe[:4000])
+  assert h1 == h2
+  np.testing.assert_array_equal(e1, e2)
