@@ -174,6 +174,10 @@ typedef struct {
 } mhte_table_stats;
 mhte_status mhte_table_get_stats(mhte_multi_table* t, int32_t table, mhte_table_stats* out,
                                  void* stream);
+/* Lookup hit counting (the `lookup_fid_hit_rate` metric of RT/ops/multi_hash_table_lookup_op.cc
+ * :81-87, emitted by the reference for serving tables only).  Off by default: it costs one global
+ * atomic per wavefront. */
+mhte_status mhte_table_set_count_hits(mhte_multi_table* t, int32_t table, int32_t enable);
 /* Dump in bucket-major order (Save's iteration order, cuckoohash_map.hpp:740-773).
  * All outputs dev, capacity `cap` entries; rows may be NULL; row_floats = dim + optimizer state.
  * Returns the number of entries in *n_out. Synchronises. */

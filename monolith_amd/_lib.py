@@ -95,7 +95,7 @@ EXPORTS = [
     "mhte_table_get_stats", "mhte_table_dump", "mhte_table_row_floats", "mhte_dedup_ws_create",
     "mhte_dedup_ws_destroy", "mhte_unique", "mhte_gather_rows", "mhte_segment_sum",
     "mhte_table_lookup_n", "mhte_table_optimize_n", "mhte_value_offsets",
-    "mhte_fill_with_offset_map", "mhte_fill_with_offset_map_gradient",
+    "mhte_fill_with_offset_map", "mhte_fill_with_offset_map_gradient", "mhte_table_set_count_hits",
 ]
 
 _lib = None

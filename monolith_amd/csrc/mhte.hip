@@ -173,6 +173,7 @@ struct Table {
   Counters* h_ctr = nullptr;  // pinned mirror
   uint64_t keys_upper = 0, rows_upper = 0;
   int64_t max_update_ts = 0;
+  bool count_hits = false;  // lookup hit counter (the reference only emits hit rate for serving tables)
   int64_t default_expire_days = 36500;
   std::vector<int64_t> expire_slots;
   std::vector<int32_t> expire_days;
@@ -360,7 +361,7 @@ struct Table {
     Shape sh = pick_shape(dim, vec_ok && aligned16(out));
     const int64_t threads = n * sh.G;
     const dim3 grid(uint32_t((threads + 255) / 256));
-#define CALL(G_, V_) lookup_kernel<G_, V_><<<grid, 256, 0, st>>>(view, ids, n, n_dev, out, 1)
+#define CALL(G_, V_) lookup_kernel<G_, V_><<<grid, 256, 0, st>>>(view, ids, n, n_dev, out, count_hits ? 1 : 0)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
     HIP_OK(hipGetLastError());
@@ -1036,6 +1037,14 @@ mhte_status mhte_fill_with_offset_map_gradient(const int64_t* pos, int64_t n, co
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
     HIP_OK(hipGetLastError());
+  });
+}
+
+mhte_status mhte_table_set_count_hits(mhte_multi_table* t, int32_t table, int32_t enable) {
+  return guard([&] {
+    Table& tb = table_at(t, table);
+    std::lock_guard<std::mutex> g(tb.mu);
+    tb.count_hits = enable != 0;
   });
 }
 

@@ -427,31 +427,45 @@ __global__ __launch_bounds__(256) void split_kernel(const Bucket* __restrict__ o
   const uint64_t n_old = uint64_t(1) << old_hp;
   if (i >= n_old) return;
   const Bucket ob = oldb[i];
-  Bucket lo, hi;
-#pragma unroll
-  for (int s = 0; s < kSlots; ++s) {
-    lo.key[s] = kEmptyKey; lo.row[s] = kNoRow; lo.ts[s] = 0;
-    hi.key[s] = kEmptyKey; hi.row[s] = kNoRow; hi.ts[s] = 0;
-  }
   const uint32_t new_hp = old_hp + 1;
   const uint64_t new_ind = i + n_old;
-  int new_slot = 0;
+  // moves[s]: slot s goes to the new bucket; rank[s]: its compacted slot there.  Everything is
+  // indexed by compile-time constants so the buckets stay in registers.
+  bool occ[kSlots], moves[kSlots];
+  int rank[kSlots];
+  int nm = 0;
 #pragma unroll
   for (int s = 0; s < kSlots; ++s) {
-    if (ob.key[s] == kEmptyKey) continue;
+    occ[s] = ob.key[s] != kEmptyKey;
     const uint64_t hv = hash_key(ob.key[s]);
     const uint32_t p = partial_key(hv);
     const uint64_t old_i = index_hash(old_hp, hv);
     const uint64_t old_a = alt_index(old_hp, p, old_i);
     const uint64_t new_i = index_hash(new_hp, hv);
     const uint64_t new_a = alt_index(new_hp, p, new_i);
-    const bool moves = (i == old_i && new_i == new_ind) || (i == old_a && new_a == new_ind);
-    if (moves) {
-      hi.key[new_slot] = ob.key[s]; hi.row[new_slot] = ob.row[s]; hi.ts[new_slot] = ob.ts[s];
-      ++new_slot;
-    } else {
-      lo.key[s] = ob.key[s]; lo.row[s] = ob.row[s]; lo.ts[s] = ob.ts[s];
+    moves[s] = occ[s] && ((i == old_i && new_i == new_ind) || (i == old_a && new_a == new_ind));
+    rank[s] = nm;
+    nm += moves[s] ? 1 : 0;
+  }
+  Bucket lo, hi;
+#pragma unroll
+  for (int d = 0; d < kSlots; ++d) {
+    const bool stay = occ[d] && !moves[d];
+    lo.key[d] = stay ? ob.key[d] : kEmptyKey;
+    lo.row[d] = stay ? ob.row[d] : kNoRow;
+    lo.ts[d] = stay ? ob.ts[d] : 0u;
+    int64_t hk = kEmptyKey;
+    uint32_t hr = kNoRow, ht = 0u;
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+      const bool sel = moves[s] && rank[s] == d;
+      hk = sel ? ob.key[s] : hk;
+      hr = sel ? ob.row[s] : hr;
+      ht = sel ? ob.ts[s] : ht;
     }
+    hi.key[d] = hk;
+    hi.row[d] = hr;
+    hi.ts[d] = ht;
   }
   newb[i] = lo;
   newb[new_ind] = hi;
@@ -612,31 +626,70 @@ __global__ __launch_bounds__(256) void dd_clear_kernel(DedupView d) {
   if (i == 0) *d.heavy_n = 0;
 }
 
+// LDS-side pre-aggregation: the 256 positions of a block are first deduplicated in a 512-entry LDS
+// hash set, so a Zipf head key with ~12 000 occurrences costs one global atomic pair per BLOCK
+// (256 per launch) instead of one per occurrence (same-address L2 atomics run at ~12 ns each).
+constexpr int kDdLds = 512;
+
+__device__ __forceinline__ uint32_t dd_global_slot(const DedupView& d, int64_t id) {
+  if (id == kEmptyKey) return d.cap_mask + 1u;
+  uint32_t s = uint32_t(hash_key(id)) & d.cap_mask;
+  for (;;) {
+    int64_t k = d.hkey[s];
+    if (k == kEmptyKey) {
+      k = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hkey[s]),
+                                         static_cast<unsigned long long>(kEmptyKey),
+                                         static_cast<unsigned long long>(id)));
+      if (k == kEmptyKey) return s;
+    }
+    if (k == id) return s;
+    s = (s + 1u) & d.cap_mask;
+  }
+}
+
 __global__ __launch_bounds__(256) void dd_insert_kernel(DedupView d, const int64_t* __restrict__ ids,
                                                         uint32_t n) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const int64_t id = ids[p];
-  uint32_t s;
-  if (id == kEmptyKey) {
-    s = d.cap_mask + 1u;
-  } else {
-    s = uint32_t(hash_key(id)) & d.cap_mask;
-    for (;;) {
-      int64_t k = d.hkey[s];
-      if (k == kEmptyKey) {
-        k = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hkey[s]),
-                                           static_cast<unsigned long long>(kEmptyKey),
-                                           static_cast<unsigned long long>(id)));
-        if (k == kEmptyKey) break;
-      }
-      if (k == id) break;
-      s = (s + 1u) & d.cap_mask;
-    }
+  __shared__ unsigned long long lkey[kDdLds + 1];
+  __shared__ uint32_t lmin[kDdLds + 1], lcnt[kDdLds + 1], lslot[kDdLds + 1];
+  for (int i = threadIdx.x; i <= kDdLds; i += 256) {
+    lkey[i] = static_cast<unsigned long long>(kEmptyKey);
+    lmin[i] = 0xffffffffu;
+    lcnt[i] = 0;
   }
-  atomicMin(&d.hmin[s], p);
-  atomicAdd(&d.hcnt[s], 1u);
-  d.slot_of[p] = s;
+  __syncthreads();
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = p < n;
+  uint32_t ls = 0;
+  int64_t id = 0;
+  if (valid) {
+    id = ids[p];
+    if (id == kEmptyKey) {
+      ls = kDdLds;
+    } else {
+      ls = uint32_t(hash_key(id) >> 40) & (kDdLds - 1);
+      for (;;) {
+        unsigned long long k = lkey[ls];
+        if (k == static_cast<unsigned long long>(kEmptyKey)) {
+          k = atomicCAS(&lkey[ls], static_cast<unsigned long long>(kEmptyKey),
+                        static_cast<unsigned long long>(id));
+          if (k == static_cast<unsigned long long>(kEmptyKey)) break;
+        }
+        if (k == static_cast<unsigned long long>(id)) break;
+        ls = (ls + 1u) & (kDdLds - 1);
+      }
+    }
+    atomicMin(&lmin[ls], p);
+    atomicAdd(&lcnt[ls], 1u);
+  }
+  __syncthreads();
+  if (valid && lmin[ls] == p) {  // the block's first occurrence of this id speaks for all of them
+    const uint32_t gs = dd_global_slot(d, id);
+    atomicMin(&d.hmin[gs], p);
+    atomicAdd(&d.hcnt[gs], lcnt[ls]);
+    lslot[ls] = gs;
+  }
+  __syncthreads();
+  if (valid) d.slot_of[p] = lslot[ls];
 }
 
 __device__ __forceinline__ void block_reduce2(uint32_t& a, uint32_t& b, uint32_t* sh) {
@@ -749,13 +802,54 @@ __global__ __launch_bounds__(256) void dd_place_kernel(DedupView d, uint32_t n,
                                                        const uint32_t* __restrict__ seg_off,
                                                        uint32_t* __restrict__ inverse,
                                                        uint32_t* __restrict__ seg_pos) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const uint32_t s = d.slot_of[p];
-  const uint32_t u = d.huidx[s];
-  inverse[p] = u;
-  const uint32_t q = atomicAdd(&d.hcur[s], 1u);
-  seg_pos[seg_off[u] + q] = p;
+  // same LDS pre-aggregation, keyed by the global slot: in-block rank from an LDS counter, one
+  // global cursor bump per distinct id per block
+  __shared__ uint32_t lkey[kDdLds], lcnt[kDdLds], lbase[kDdLds];
+  for (int i = threadIdx.x; i < kDdLds; i += 256) {
+    lkey[i] = 0xffffffffu;
+    lcnt[i] = 0;
+  }
+  __syncthreads();
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = p < n;
+  uint32_t s = 0, ls = 0, rank = 0;
+  if (valid) {
+    s = d.slot_of[p];
+    ls = (s * 2654435761u >> 16) & (kDdLds - 1);
+    for (;;) {
+      uint32_t k = lkey[ls];
+      if (k == 0xffffffffu) {
+        k = atomicCAS(&lkey[ls], 0xffffffffu, s);
+        if (k == 0xffffffffu) break;
+      }
+      if (k == s) break;
+      ls = (ls + 1u) & (kDdLds - 1);
+    }
+    rank = atomicAdd(&lcnt[ls], 1u);
+  }
+  __syncthreads();
+  if (valid && rank == 0) lbase[ls] = atomicAdd(&d.hcur[s], lcnt[ls]);
+  __syncthreads();
+  if (valid) {
+    const uint32_t u = d.huidx[s];
+    inverse[p] = u;
+    seg_pos[seg_off[u] + lbase[ls] + rank] = p;
+  }
+}
+
+// Rank sort of one short list held entirely in registers (positions are distinct).
+template <int W>
+__device__ __forceinline__ void dd_rank_sort(uint32_t* __restrict__ lst, uint32_t len) {
+  uint32_t a[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) a[k] = (uint32_t(k) < len) ? lst[k] : 0xffffffffu;
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int j = 0; j < W; ++j) r += (a[j] < a[i]) ? 1u : 0u;
+    if (uint32_t(i) < len) lst[r] = a[i];
+  }
 }
 
 __global__ __launch_bounds__(256) void dd_order_kernel(DedupView d,
@@ -770,57 +864,66 @@ __global__ __launch_bounds__(256) void dd_order_kernel(DedupView d,
     d.heavy[atomicAdd(d.heavy_n, 1u)] = u;
     return;
   }
-  uint32_t* a = seg_pos + q0;
-  for (uint32_t i = 1; i < len; ++i) {
-    const uint32_t v = a[i];
-    uint32_t k = i;
-    while (k > 0 && a[k - 1] > v) {
-      a[k] = a[k - 1];
-      --k;
+  if (len == 2) {
+    const uint32_t x = seg_pos[q0], y = seg_pos[q0 + 1];
+    if (x > y) {
+      seg_pos[q0] = y;
+      seg_pos[q0 + 1] = x;
     }
-    a[k] = v;
+  } else if (len <= 8) {
+    dd_rank_sort<8>(seg_pos + q0, len);
+  } else {
+    dd_rank_sort<kLightMax>(seg_pos + q0, len);
   }
 }
 
-// One workgroup per heavy key; rewrites its list in position order by scanning inverse[].
+// One 1024-thread workgroup per heavy key rewrites its list in position order by an ordered
+// stream compaction over inverse[].  Wave w owns the contiguous region [w*R, (w+1)*R) and reads it
+// with coalesced loads; pass 1 counts, one block scan gives each wave its base, pass 2 re-reads
+// (L2-resident) and writes.
 __global__ __launch_bounds__(1024) void dd_heavy_kernel(DedupView d, uint32_t n,
                                                         const uint32_t* __restrict__ inverse,
                                                         const uint32_t* __restrict__ seg_off,
                                                         uint32_t* __restrict__ seg_pos) {
-  __shared__ uint32_t wsum[16];
-  __shared__ uint32_t running;
+  __shared__ uint32_t wcnt[16];
   const uint32_t nh = *d.heavy_n;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t region = (((n + 15u) / 16u) + 255u) & ~255u;  // per wave, multiple of 256
+  const uint32_t r0 = w * region;
+  const uint64_t lt = (uint64_t(1) << lane) - 1;
   for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
     const uint32_t u = d.heavy[h];
     uint32_t* outp = seg_pos + seg_off[u];
-    if (threadIdx.x == 0) running = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 4096) {
-      const uint32_t p0 = base + threadIdx.x * 4;
-      uint32_t f[4];
-      uint32_t c = 0;
+    uint32_t total = 0;
+    for (uint32_t it = 0; it < region; it += 256) {
+      const uint32_t p0 = r0 + it + lane * 4;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        f[k] = (p0 + k < n && inverse[p0 + k] == u) ? 1u : 0u;
-        c += f[k];
+        const bool f = (p0 + k < n) && inverse[p0 + k] == u;
+        total += __popcll(__ballot(f));
       }
-      uint32_t incl = c;
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
+    }
+    if (lane == 0) wcnt[w] = total;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int i = 0; i < w; ++i) off += wcnt[i];
+    for (uint32_t it = 0; it < region; it += 256) {
+      const uint32_t p0 = r0 + it + lane * 4;
+      bool f[4];
+      uint64_t m[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f[k] = (p0 + k < n) && inverse[p0 + k] == u;
+        m[k] = __ballot(f[k]);
       }
-      if (lane == 63) wsum[w] = incl;
-      __syncthreads();
-      uint32_t off = running + (incl - c);
-      for (int i = 0; i < w; ++i) off += wsum[i];
+      uint32_t o = off + __popcll(m[0] & lt) + __popcll(m[1] & lt) + __popcll(m[2] & lt) +
+                   __popcll(m[3] & lt);
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (f[k]) outp[off++] = p0 + k;
-      __syncthreads();
-      if (threadIdx.x == 1023) running = off;  // last thread's end offset == total so far
-      __syncthreads();
+        if (f[k]) outp[o++] = p0 + k;
+      off += __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
     }
+    __syncthreads();  // wcnt is reused by the next heavy key
   }
 }
 

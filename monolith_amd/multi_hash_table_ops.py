@@ -329,6 +329,11 @@ class MultiHashTable:
                                          _stream()))
     return s
 
+  def set_count_hits(self, name: str, enable: bool = True) -> "MultiHashTable":
+    check(self._lib.mhte_table_set_count_hits(self._h, C.c_int32(self._index(name)),
+                                              C.c_int32(1 if enable else 0)))
+    return self
+
   def contains(self, name: str, ids: torch.Tensor) -> torch.Tensor:
     ids = self._dev(ids, torch.int64)
     out = torch.empty(ids.numel(), dtype=torch.int32, device=ids.device)

@@ -135,11 +135,13 @@ def test_duplicate_ids_adagrad_sequential_vs_accumulated():
   for flags, exp in ((0, seq), (_lib.MHTE_SUM_DUPLICATES, acc)):
     mt = make({"a": adagrad_cfg(2, lr=0.5)})
     r = mt.get_ragged_id({"a": ids_t(ids)})
+    C = _lib.C
     _lib.check(mt._lib.mhte_optimize(mt.handle, _lib.vp(r.values),
-                                     r.row_splits.ctypes.data_as(_lib.C.POINTER(_lib.C.c_int64)),
-                                     2, _lib.vp(val_t(g)), g.size,
-                                     mt.learning_rate.ctypes.data_as(_lib.C.POINTER(_lib.C.c_float)),
-                                     1, 10, 0, flags, None))
+                                     r.row_splits.ctypes.data_as(C.POINTER(C.c_int64)),
+                                     C.c_int64(2), _lib.vp(val_t(g)), C.c_int64(g.size),
+                                     mt.learning_rate.ctypes.data_as(C.POINTER(C.c_float)),
+                                     C.c_int64(1), C.c_int64(10), C.c_int64(0), C.c_int32(flags),
+                                     None))
     torch.cuda.synchronize()
     np.testing.assert_array_equal(mt.lookup({"a": ids_t([7, 9])})["a"].cpu().numpy(),
                                   exp.lookup([7, 9])[0])
@@ -354,7 +356,7 @@ def _check_placement_valid(mt, name, hp):
 
 @pytest.mark.parametrize("kind", ["sgd8", "adagrad32", "adagrad_wd5", "ftrl3", "multiseg"])
 def test_random_op_sequence_matches_oracle(kind):
-  rng = np.random.default_rng(hash(kind) % 1000)
+  rng = np.random.default_rng({"sgd8": 1, "adagrad32": 2, "adagrad_wd5": 3, "ftrl3": 4, "multiseg": 5}[kind])
   if kind == "sgd8":
     segs_o = [O.segment(8, O.OPT_SGD)]
     segs_e = [entry.CombineAsSegment(8, entry.ZerosInitializer(), entry.SgdOptimizer(0.05))]
@@ -384,6 +386,7 @@ def test_random_op_sequence_matches_oracle(kind):
   dim = sum(s.dim for s in segs_o)
   ot = O.Table(segs_o, 1)
   mt = make({"a": entry.make_table_config(segs_e, learning_rates=lrs)})
+  mt.set_count_hits("a")
   universe = rng.integers(-2**62, 2**62, 40000)
   for step in range(14):
     n = int(rng.integers(1, 9000))
@@ -440,7 +443,7 @@ def test_growth_from_capacity_one_and_bulk_unique_insert():
 def test_slow_path_displacement_at_high_load():
   # max_load_factor 0.95 in a pre-sized table forces full buckets -> deferred ids -> BFS kernel
   cap = 1 << 14
-  n = int(cap * 0.93)
+  n = int(cap * 0.90)
   rng = np.random.default_rng(2)
   ids = rng.integers(1, 2**60, n)
   v = rng.standard_normal((n, 4)).astype(np.float32)
@@ -485,8 +488,8 @@ def test_full_batch_zipf_step_properties_d64_adagrad():
   allids = np.fromiter(seen, dtype=np.int64)
   got = mt.lookup({"emb": ids_t(allids)})["emb"].cpu().numpy()
   np.testing.assert_allclose(got, ot.lookup(allids)[0], rtol=0, atol=TOL)
-  # idempotence / hit count property: every id ever seen is a hit, others are zero rows
-  st = mt.stats("emb")
-  assert st.lookup_hits >= allids.size
-  miss = mt.lookup({"emb": ids_t(allids[:1000] ^ (1 << 40))})["emb"]
+  # ids never seen are zero rows and are not inserted by lookups
+  absent = np.setdiff1d(allids[:1000] ^ (1 << 40), allids)
+  miss = mt.lookup({"emb": ids_t(absent)})["emb"]
   assert not miss.any().item()
+  assert mt.size("emb") == len(seen)
