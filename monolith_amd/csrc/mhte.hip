@@ -70,18 +70,21 @@ static inline uint32_t ceil_log2(uint64_t n) {
 struct DedupWs {
   int device = 0;
   DevBuf<int64_t> hkey;
-  DevBuf<uint32_t> hmin, hcnt, huidx, hcur, slot_of, tile_a, tile_b, heavy, heavy_n;
+  DevBuf<uint32_t> hmin, hcnt, huidx, hcur, slot_of, seg_tmp, tile_a, tile_b, heavy, heavy_n;
+  uint32_t clean_cap = 0;  // hash scratch [0, clean_cap] is in the all-empty state
   DevBuf<float> part;
   DevBuf<uint32_t> last_u;
 
-  DedupView view(int64_t n) {
+  DedupView view(int64_t n, hipStream_t st) {
     uint32_t C = 1u << std::max<uint32_t>(10, ceil_log2(uint64_t(2) * n));
+    const int64_t* old_key = hkey.p;
     hkey.reserve(size_t(C) + 2);
     hmin.reserve(size_t(C) + 2);
     hcnt.reserve(size_t(C) + 2);
     huidx.reserve(size_t(C) + 2);
     hcur.reserve(size_t(C) + 2);
     slot_of.reserve(n + 1);
+    seg_tmp.reserve(n + 1);
     size_t ntiles = (n + kDdTile - 1) / kDdTile + 1;
     tile_a.reserve(ntiles);
     tile_b.reserve(ntiles);
@@ -90,7 +93,13 @@ struct DedupWs {
     DedupView d;
     d.hkey = hkey.p; d.hmin = hmin.p; d.hcnt = hcnt.p; d.huidx = huidx.p; d.hcur = hcur.p;
     d.slot_of = slot_of.p; d.tile_a = tile_a.p; d.tile_b = tile_b.p; d.heavy = heavy.p;
-    d.heavy_n = heavy_n.p; d.cap_mask = C - 1;
+    d.heavy_n = heavy_n.p; d.cap_mask = C - 1; d.seg_tmp = seg_tmp.p;
+    if (hkey.p != old_key || C > clean_cap) {
+      // scratch was (re)allocated or never cleared this far: one clear pass; afterwards every
+      // dedup leaves the slots it touched empty again (dd_finish_kernel)
+      dd_clear_kernel<<<(C + 2 + 255) / 256, 256, 0, st>>>(d);
+      clean_cap = C;
+    }
     return d;
   }
 
@@ -103,19 +112,21 @@ struct DedupWs {
       HIP_OK(hipMemsetAsync(seg_off, 0, sizeof(uint32_t), st));
       return;
     }
-    DedupView d = view(n);
+    DedupView d = view(n, st);
     const uint32_t un = uint32_t(n);
-    const uint32_t C = d.cap_mask + 1;
     const uint32_t ntiles = (un + kDdTile - 1) / kDdTile;
-    dd_clear_kernel<<<(C + 2 + 255) / 256, 256, 0, st>>>(d);
     dd_insert_kernel<<<(un + 255) / 256, 256, 0, st>>>(d, ids, un);
     dd_tile_kernel<<<ntiles, 256, 0, st>>>(d, un);
     dd_emit_kernel<<<ntiles, 256, 0, st>>>(d, ids, un, uids, seg_off, n_unique_dev);
-    dd_place_kernel<<<(un + 255) / 256, 256, 0, st>>>(d, un, seg_off, inverse, seg_pos);
-    dd_order_kernel<<<(un + 255) / 256, 256, 0, st>>>(d, n_unique_dev, seg_off, seg_pos);
+    dd_place_kernel<<<(un + 255) / 256, 256, 0, st>>>(d, un, seg_off, inverse);
+    const uint32_t nb_rank = (un + 1023) / 1024;
     const uint32_t hgrid = std::min<uint32_t>(256, un / (kLightMax + 1) + 1);
-    dd_heavy_kernel<<<hgrid, 1024, 0, st>>>(d, un, inverse, seg_off, seg_pos);
-    HIP_OK(hipGetLastError());
+    dd_finish_kernel<<<nb_rank + hgrid, 1024, 0, st>>>(d, un, nb_rank, inverse, seg_off, seg_pos);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+      clean_cap = 0;  // scratch state unknown: force a clear next time
+      HIP_OK(le);
+    }
   }
 };
 
@@ -331,9 +342,9 @@ struct Table {
     const bool need_rows = rows_upper > row_cap;
     if (!need_keys && !need_rows) return;
     sync_counters(st);
-    keys_upper = h_ctr->n_keys + n;
-    rows_upper = uint64_t(h_ctr->next_row) + n;
-    if (h_ctr->n_keys == 0) {
+    keys_upper = (h_ctr->alloc >> 32) + n;
+    rows_upper = (h_ctr->alloc & 0xffffffffull) + n;
+    if ((h_ctr->alloc >> 32) == 0) {
       // nothing to migrate: jump straight to the needed hashpower
       uint32_t want = hp;
       while (double(keys_upper) > max_load * double(uint64_t(kSlots) << want)) ++want;
@@ -768,7 +779,7 @@ mhte_status mhte_table_size(mhte_multi_table* t, int32_t table, int64_t* size, v
     HIP_OK(hipSetDevice(t->device));
     std::lock_guard<std::mutex> g(tb.mu);
     tb.sync_counters(S(stream));
-    *size = int64_t(tb.h_ctr->n_keys) + (tb.h_ctr->special_state ? 1 : 0);
+    *size = int64_t(tb.h_ctr->alloc >> 32) + (tb.h_ctr->special_state ? 1 : 0);
   });
 }
 
@@ -823,9 +834,9 @@ mhte_status mhte_table_get_stats(mhte_multi_table* t, int32_t table, mhte_table_
     HIP_OK(hipSetDevice(t->device));
     std::lock_guard<std::mutex> g(tb.mu);
     tb.sync_counters(S(stream));
-    out->size = int64_t(tb.h_ctr->n_keys) + (tb.h_ctr->special_state ? 1 : 0);
+    out->size = int64_t(tb.h_ctr->alloc >> 32) + (tb.h_ctr->special_state ? 1 : 0);
     out->hashpower = int32_t(tb.hp);
-    out->rows_allocated = tb.h_ctr->next_row;
+    out->rows_allocated = int64_t(tb.h_ctr->alloc & 0xffffffffull);
     out->lookup_hits = int64_t(tb.h_ctr->hits);
     out->dropped = tb.h_ctr->n_dropped;
     out->evicted = tb.h_ctr->n_evicted;

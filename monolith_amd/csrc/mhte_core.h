@@ -193,7 +193,8 @@ MHTE_HD bool cuckoopath_move(Bucket* buckets, CuckooRecord* path, int depth) {
 // absent and whose two buckets are both full or contended.  Returns bucket*4+slot, or -1 when no
 // displacement path of length <= 5 exists (the reference would double the table here,
 // cuckoohash_map.hpp:1296-1299; the engine grows proactively on the host instead).
-MHTE_HD int64_t serial_insert_slot(Bucket* buckets, uint32_t hp, int64_t key, BfsSlot* q) {
+MHTE_HD int64_t serial_insert_slot(Bucket* buckets, uint32_t hp, int64_t key, BfsSlot* q,
+                                   CuckooRecord* path) {
   uint64_t hv = hash_key(key);
   uint32_t partial = partial_key(hv);
   uint64_t i1 = index_hash(hp, hv);
@@ -209,7 +210,6 @@ MHTE_HD int64_t serial_insert_slot(Bucket* buckets, uint32_t hp, int64_t key, Bf
       return static_cast<int64_t>(ib * kSlots + found);
     }
   }
-  CuckooRecord path[kMaxBfsPathLen];
   for (;;) {
     int depth = cuckoopath_search(buckets, hp, path, i1, i2, q);
     if (depth < 0) return -1;

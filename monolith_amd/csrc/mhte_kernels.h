@@ -15,9 +15,12 @@
 namespace mhte {
 
 struct Counters {
-  unsigned long long n_keys;   // live keys in buckets (side-slot key not included)
+  // One word, one atomic per wavefront that inserts: low 32 bits = next row handle (bump
+  // allocator), high 32 bits = live keys in buckets (side-slot key not included).  Same-address
+  // device atomics cost ~12 ns each on MI355X, so the two counters share a single returning add.
+  unsigned long long alloc;
   unsigned long long hits;     // lookup hits since last reset
-  unsigned int next_row;       // bump allocator for row handles
+  unsigned int unused0;
   unsigned int n_pending;      // ids whose two buckets were full in the fast path
   unsigned int error;          // bit0: displacement failed (id dropped)
   unsigned int n_dropped;
@@ -307,12 +310,17 @@ __global__ __launch_bounds__(256) void upsert_kernel(TableView tv, const int64_t
     is_new = (st == 0);
   }
 
-  // ---- row handles for new ids: one atomic per wave ----
+  // ---- row handles + live-key count for new ids: ONE atomic per wave ----
   const bool leader_new = is_new && j == 0;
   const uint64_t newm = __ballot(leader_new);
+  const uint64_t keym = __ballot(leader_new && !special);
   const int first_new = newm ? (__ffsll(static_cast<long long>(newm)) - 1) : 0;
   uint32_t base_row = 0;
-  if (newm && lane == first_new) base_row = atomicAdd(&tv.ctr->next_row, (unsigned int)__popcll(newm));
+  if (newm && lane == first_new) {
+    const unsigned long long add =
+        (static_cast<unsigned long long>(__popcll(keym)) << 32) | (unsigned long long)__popcll(newm);
+    base_row = static_cast<uint32_t>(atomicAdd(&tv.ctr->alloc, add));
+  }
   base_row = __shfl(base_row, first_new);
   const uint32_t found_row = __shfl(row, gbase + (owner < 0 ? 0 : owner));
   uint32_t r;
@@ -332,12 +340,6 @@ __global__ __launch_bounds__(256) void upsert_kernel(TableView tv, const int64_t
   } else if (valid && !deferred && j == owner) {
     if (is_new) b->row[s] = r;
     b->ts[s] = a.ts;  // SetTimestamp(update_time), cuckoo_embedding_hash_table.cc:242-246
-  }
-  // live-key counter (bucket keys only)
-  {
-    const uint64_t km = __ballot(leader_new && !special);
-    if (km && lane == (__ffsll(static_cast<long long>(km)) - 1))
-      atomicAdd(&tv.ctr->n_keys, (unsigned long long)__popcll(km));
   }
   // ---- defer to the slow path ----
   if (deferred && j == 0) {
@@ -376,21 +378,22 @@ __global__ __launch_bounds__(64) void slowpath_kernel(TableView tv, const int64_
                                                       ApplyArgs a, int32_t* __restrict__ status,
                                                       const uint32_t* __restrict__ pending) {
   __shared__ BfsSlot q[kMaxCuckooCount];
+  __shared__ CuckooRecord path[kMaxBfsPathLen];
   const int lane = threadIdx.x;
   const uint32_t np = tv.ctr->n_pending;
+  if (np == 0) return;
   for (uint32_t i = 0; i < np; ++i) {
     const uint32_t g = pending[i];
     const int64_t id = ids[g];
     long long pos = -1;
     uint32_t r = kNoRow;
     if (lane == 0) {
-      pos = serial_insert_slot(tv.buckets, tv.hp, id, q);
+      pos = serial_insert_slot(tv.buckets, tv.hp, id, q, path);
       if (pos >= 0) {
-        r = atomicAdd(&tv.ctr->next_row, 1u);
+        r = static_cast<uint32_t>(atomicAdd(&tv.ctr->alloc, (1ull << 32) | 1ull));
         Bucket* b = tv.buckets + (pos >> 2);
         b->row[pos & 3] = r;
         b->ts[pos & 3] = a.ts;
-        atomicAdd(&tv.ctr->n_keys, 1ull);
       } else {
         atomicOr(&tv.ctr->error, 1u);
         atomicAdd(&tv.ctr->n_dropped, 1u);
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(256) void evict_kernel(TableView tv, int64_t max_up
   const uint64_t em = __ballot(ev);
   if (em && (threadIdx.x & 63) == 0) {
     const unsigned long long c = __popcll(em);
-    atomicAdd(&tv.ctr->n_keys, ~c + 1ull);  // -= c
+    atomicAdd(&tv.ctr->alloc, ~(c << 32) + 1ull);  // live keys -= c
     atomicAdd(&tv.ctr->n_evicted, (unsigned int)c);
   }
 }
@@ -605,6 +608,7 @@ struct DedupView {
   uint32_t* huidx;    // [C+1]
   uint32_t* hcur;     // [C+1]
   uint32_t* slot_of;  // [n]
+  uint32_t* seg_tmp;  // [n] unordered occurrence lists (ordered copy goes to seg_pos)
   uint32_t* tile_a;   // [ntiles] first-occurrence counts
   uint32_t* tile_b;   // [ntiles] occurrence-count sums
   uint32_t* heavy;    // [n/33 + 1]
@@ -623,7 +627,6 @@ __global__ __launch_bounds__(256) void dd_clear_kernel(DedupView d) {
     d.hcnt[i] = 0;
     d.hcur[i] = 0;
   }
-  if (i == 0) *d.heavy_n = 0;
 }
 
 // LDS-side pre-aggregation: the 256 positions of a block are first deduplicated in a 512-entry LDS
@@ -658,6 +661,7 @@ __global__ __launch_bounds__(256) void dd_insert_kernel(DedupView d, const int64
   }
   __syncthreads();
   const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p == 0) *d.heavy_n = 0;  // dd_emit (next but one kernel) refills the heavy list
   const bool valid = p < n;
   uint32_t ls = 0;
   int64_t id = 0;
@@ -788,6 +792,7 @@ __global__ __launch_bounds__(256) void dd_emit_kernel(DedupView d, const int64_t
       uids[oa] = ids[p];
       seg_off[oa] = ob;
       d.huidx[slot[k]] = oa;
+      if (fb[k] > kLightMax) d.heavy[atomicAdd(d.heavy_n, 1u)] = oa;
       ++oa;
       ob += fb[k];
     }
@@ -800,8 +805,7 @@ __global__ __launch_bounds__(256) void dd_emit_kernel(DedupView d, const int64_t
 
 __global__ __launch_bounds__(256) void dd_place_kernel(DedupView d, uint32_t n,
                                                        const uint32_t* __restrict__ seg_off,
-                                                       uint32_t* __restrict__ inverse,
-                                                       uint32_t* __restrict__ seg_pos) {
+                                                       uint32_t* __restrict__ inverse) {
   // same LDS pre-aggregation, keyed by the global slot: in-block rank from an LDS counter, one
   // global cursor bump per distinct id per block
   __shared__ uint32_t lkey[kDdLds], lcnt[kDdLds], lbase[kDdLds];
@@ -833,97 +837,89 @@ __global__ __launch_bounds__(256) void dd_place_kernel(DedupView d, uint32_t n,
   if (valid) {
     const uint32_t u = d.huidx[s];
     inverse[p] = u;
-    seg_pos[seg_off[u] + lbase[ls] + rank] = p;
+    d.seg_tmp[seg_off[u] + lbase[ls] + rank] = p;
   }
 }
 
-// Rank sort of one short list held entirely in registers (positions are distinct).
-template <int W>
-__device__ __forceinline__ void dd_rank_sort(uint32_t* __restrict__ lst, uint32_t len) {
-  uint32_t a[W];
-#pragma unroll
-  for (int k = 0; k < W; ++k) a[k] = (uint32_t(k) < len) ? lst[k] : 0xffffffffu;
-#pragma unroll
-  for (int i = 0; i < W; ++i) {
-    uint32_t r = 0;
-#pragma unroll
-    for (int j = 0; j < W; ++j) r += (a[j] < a[i]) ? 1u : 0u;
-    if (uint32_t(i) < len) lst[r] = a[i];
-  }
-}
-
-__global__ __launch_bounds__(256) void dd_order_kernel(DedupView d,
-                                                       const uint32_t* __restrict__ n_unique,
-                                                       const uint32_t* __restrict__ seg_off,
-                                                       uint32_t* __restrict__ seg_pos) {
-  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= *n_unique) return;
-  const uint32_t q0 = seg_off[u], len = seg_off[u + 1] - q0;
-  if (len < 2) return;
-  if (len > kLightMax) {
-    d.heavy[atomicAdd(d.heavy_n, 1u)] = u;
+// Final dedup kernel, two roles in one launch (1024-thread workgroups):
+//  * blocks [0, nb_rank): one thread per position p.  Lists of <= kLightMax occurrences are put in
+//    position order by rank-counting: p's rank is the number of smaller positions in its
+//    (unordered) list, so p itself writes seg_pos[list_start + rank].  The same threads reset the
+//    scratch hash slots they used (clean-after-use: the next dedup needs no clear pass).
+//  * blocks [nb_rank, grid): one workgroup per heavy key (> kLightMax occurrences, ~130 under
+//    Zipf(1.2) at B = 65 536) rewrites its list by an ordered stream compaction over inverse[]:
+//    wave w owns positions [w*4096, (w+1)*4096) of a 65 536-position chunk, keeps its 64 match
+//    bits per lane in one register, one block scan orders the waves.
+__global__ __launch_bounds__(1024) void dd_finish_kernel(DedupView d, uint32_t n, uint32_t nb_rank,
+                                                         const uint32_t* __restrict__ inverse,
+                                                         const uint32_t* __restrict__ seg_off,
+                                                         uint32_t* __restrict__ seg_pos) {
+  if (blockIdx.x < nb_rank) {
+    const uint32_t p = blockIdx.x * 1024 + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t u = inverse[p];
+    const uint32_t q0 = seg_off[u], len = seg_off[u + 1] - q0;
+    const uint32_t s = d.slot_of[p];
+    if (len <= kLightMax) {
+      uint32_t r = 0;
+      for (uint32_t k = 0; k < len; ++k) r += (d.seg_tmp[q0 + k] < p) ? 1u : 0u;
+      seg_pos[q0 + r] = p;
+    }
+    d.hkey[s] = kEmptyKey;
+    d.hmin[s] = 0xffffffffu;
+    d.hcnt[s] = 0;
+    d.hcur[s] = 0;
     return;
   }
-  if (len == 2) {
-    const uint32_t x = seg_pos[q0], y = seg_pos[q0 + 1];
-    if (x > y) {
-      seg_pos[q0] = y;
-      seg_pos[q0 + 1] = x;
-    }
-  } else if (len <= 8) {
-    dd_rank_sort<8>(seg_pos + q0, len);
-  } else {
-    dd_rank_sort<kLightMax>(seg_pos + q0, len);
-  }
-}
-
-// One 1024-thread workgroup per heavy key rewrites its list in position order by an ordered
-// stream compaction over inverse[].  Wave w owns the contiguous region [w*R, (w+1)*R) and reads it
-// with coalesced loads; pass 1 counts, one block scan gives each wave its base, pass 2 re-reads
-// (L2-resident) and writes.
-__global__ __launch_bounds__(1024) void dd_heavy_kernel(DedupView d, uint32_t n,
-                                                        const uint32_t* __restrict__ inverse,
-                                                        const uint32_t* __restrict__ seg_off,
-                                                        uint32_t* __restrict__ seg_pos) {
   __shared__ uint32_t wcnt[16];
+  __shared__ uint32_t running;
   const uint32_t nh = *d.heavy_n;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t region = (((n + 15u) / 16u) + 255u) & ~255u;  // per wave, multiple of 256
-  const uint32_t r0 = w * region;
   const uint64_t lt = (uint64_t(1) << lane) - 1;
-  for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+  for (uint32_t h = blockIdx.x - nb_rank; h < nh; h += gridDim.x - nb_rank) {
     const uint32_t u = d.heavy[h];
     uint32_t* outp = seg_pos + seg_off[u];
-    uint32_t total = 0;
-    for (uint32_t it = 0; it < region; it += 256) {
-      const uint32_t p0 = r0 + it + lane * 4;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bool f = (p0 + k < n) && inverse[p0 + k] == u;
-        total += __popcll(__ballot(f));
-      }
-    }
-    if (lane == 0) wcnt[w] = total;
+    if (threadIdx.x == 0) running = 0;
     __syncthreads();
-    uint32_t off = 0;
-    for (int i = 0; i < w; ++i) off += wcnt[i];
-    for (uint32_t it = 0; it < region; it += 256) {
-      const uint32_t p0 = r0 + it + lane * 4;
-      bool f[4];
-      uint64_t m[4];
+    for (uint32_t chunk = 0; chunk < n; chunk += 65536u) {
+      const uint32_t r0 = chunk + w * 4096u + lane * 4u;
+      uint64_t bits = 0;  // bit (it*4+k): position r0 + it*256 + k belongs to list u
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        f[k] = (p0 + k < n) && inverse[p0 + k] == u;
-        m[k] = __ballot(f[k]);
+      for (int it4 = 0; it4 < 16; it4 += 4) {
+        uint32_t v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const uint32_t pos = r0 + (it4 + (t >> 2)) * 256u + (t & 3);
+          v[t] = (pos < n) ? inverse[pos] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) bits |= uint64_t(v[t] == u ? 1u : 0u) << (it4 * 4 + t);
       }
-      uint32_t o = off + __popcll(m[0] & lt) + __popcll(m[1] & lt) + __popcll(m[2] & lt) +
-                   __popcll(m[3] & lt);
+      uint32_t total = __popcll(bits);
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (f[k]) outp[o++] = p0 + k;
-      off += __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
+      for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+      if (lane == 0) wcnt[w] = total;
+      __syncthreads();
+      uint32_t off = running;
+      for (int i = 0; i < w; ++i) off += wcnt[i];
+#pragma unroll 1
+      for (int it = 0; it < 16; ++it) {
+        const uint32_t nib = uint32_t(bits >> (it * 4)) & 0xfu;
+        const uint64_t m0 = __ballot(nib & 1u), m1 = __ballot(nib & 2u), m2 = __ballot(nib & 4u),
+                       m3 = __ballot(nib & 8u);
+        uint32_t o = off + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) +
+                     __popcll(m3 & lt);
+        const uint32_t pbase = r0 + it * 256u;
+        if (nib & 1u) outp[o++] = pbase;
+        if (nib & 2u) outp[o++] = pbase + 1;
+        if (nib & 4u) outp[o++] = pbase + 2;
+        if (nib & 8u) outp[o++] = pbase + 3;
+        off += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+      }
+      __syncthreads();
+      if (threadIdx.x == 1023) running = off;  // wave 15's final offset = everything so far
+      __syncthreads();
     }
-    __syncthreads();  // wcnt is reused by the next heavy key
   }
 }
 

@@ -25,8 +25,9 @@ int main(int argc, char** argv) {
       x.ts[s] = 0;
     }
   std::vector<mhte::BfsSlot> q(mhte::kMaxCuckooCount);
+  mhte::CuckooRecord path[mhte::kMaxBfsPathLen];
   for (size_t i = 0; i < ids.size(); ++i) {
-    long long pos = mhte::serial_insert_slot(b.data(), hp, ids[i], q.data());
+    long long pos = mhte::serial_insert_slot(b.data(), hp, ids[i], q.data(), path);
     if (pos < 0) {
       std::printf("FAIL %zu\n", i);
       return 1;
