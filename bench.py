@@ -52,8 +52,9 @@ def algorithmic_bytes(B, U, D, S):
   lookup = 8 * B + P * U + 4 * D * U + 4 * D * B
   update = 8 * B + 4 * D * B + P * U + (8 * D + 8 * S) * U + 4 * U
   per_kernel = {
-      "lookup_kernel": 8 * U + P * U + 4 * D * U + 4 * D * U,
-      "gather_rows_kernel": 4 * B + 4 * D * U + 4 * D * B,
+      # one probe+gather launch over the B occurrences: distinct buckets and rows are fetched from
+      # HBM once (duplicates hit L2) == SURVEY's bytes_lookup
+      "lookup_kernel": lookup,
       "segsum_window_kernel": 4 * D * B + 8 * B + 4 * D * U,
       "upsert_kernel": 8 * U + P * U + 4 * U + 4 * D * U + 2 * 4 * (D + S) * U,
   }
@@ -208,27 +209,24 @@ def main():
   roofline, stages, uniq_avg = None, {}, None
   if world == 1:
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
-    names = ["dedup(7 kernels)", "lookup_kernel", "gather_rows_kernel", "segsum_window_kernel",
-             "upsert_kernel"]
+    names = ["dedup(5 kernels)", "lookup_kernel", "segsum_window_kernel", "upsert_kernel"]
     acc = {n: 0.0 for n in names}
     us = []
     reps = min(K, 100)
     for s in range(W, W + reps):
       ids = ids_all[s]
-      e = [ev() for _ in range(6)]
+      e = [ev() for _ in range(5)]
       e[0].record()
       step.ws.unique(ids, want_host_count=False, out=step.u)
       e[1].record()
-      mt.table_lookup_n(step.idx, step.u.unique_ids, step.u.n_unique_dev, step.emb_u, n_max=B)
+      mt.table_lookup_n(step.idx, ids, None, step.emb, n_max=B)
       e[2].record()
-      step.ws.gather_rows(step.emb_u, step.u.inverse, B, D, out=step.emb)
-      e[3].record()
       step.ws.segment_sum(grad_pool[s % 8], step.u, D, out=step.grad_u,
                           exact_order=args.exact_order)
-      e[4].record()
+      e[3].record()
       mt.table_optimize_n(step.idx, step.u.unique_ids, step.u.n_unique_dev, step.grad_u, step.lrs,
                           S.update_time(s), 0, flags=_lib.MHTE_IDS_UNIQUE, n_max=B)
-      e[5].record()
+      e[4].record()
       torch.cuda.synchronize()
       for i, n in enumerate(names):
         acc[n] += e[i].elapsed_time(e[i + 1]) * 1e3  # us

@@ -115,10 +115,10 @@ struct DedupWs {
     DedupView d = view(n, st);
     const uint32_t un = uint32_t(n);
     const uint32_t ntiles = (un + kDdTile - 1) / kDdTile;
-    dd_insert_kernel<<<(un + 255) / 256, 256, 0, st>>>(d, ids, un);
+    dd_insert_kernel<<<(un + kDdBlock - 1) / kDdBlock, kDdBlock, 0, st>>>(d, ids, un);
     dd_tile_kernel<<<ntiles, 256, 0, st>>>(d, un);
     dd_emit_kernel<<<ntiles, 256, 0, st>>>(d, ids, un, uids, seg_off, n_unique_dev);
-    dd_place_kernel<<<(un + 255) / 256, 256, 0, st>>>(d, un, seg_off, inverse);
+    dd_place_kernel<<<(un + kDdBlock - 1) / kDdBlock, kDdBlock, 0, st>>>(d, un, seg_off, inverse);
     const uint32_t nb_rank = (un + 1023) / 1024;
     const uint32_t hgrid = std::min<uint32_t>(256, un / (kLightMax + 1) + 1);
     dd_finish_kernel<<<nb_rank + hgrid, 1024, 0, st>>>(d, un, nb_rank, inverse, seg_off, seg_pos);

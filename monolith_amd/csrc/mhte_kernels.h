@@ -632,7 +632,8 @@ __global__ __launch_bounds__(256) void dd_clear_kernel(DedupView d) {
 // LDS-side pre-aggregation: the 256 positions of a block are first deduplicated in a 512-entry LDS
 // hash set, so a Zipf head key with ~12 000 occurrences costs one global atomic pair per BLOCK
 // (256 per launch) instead of one per occurrence (same-address L2 atomics run at ~12 ns each).
-constexpr int kDdLds = 512;
+constexpr int kDdBlock = 1024;  // positions per workgroup in dd_insert / dd_place
+constexpr int kDdLds = 2048;   // LDS hash entries (2x the positions)
 
 __device__ __forceinline__ uint32_t dd_global_slot(const DedupView& d, int64_t id) {
   if (id == kEmptyKey) return d.cap_mask + 1u;
@@ -650,17 +651,18 @@ __device__ __forceinline__ uint32_t dd_global_slot(const DedupView& d, int64_t i
   }
 }
 
-__global__ __launch_bounds__(256) void dd_insert_kernel(DedupView d, const int64_t* __restrict__ ids,
-                                                        uint32_t n) {
+__global__ __launch_bounds__(kDdBlock) void dd_insert_kernel(DedupView d,
+                                                             const int64_t* __restrict__ ids,
+                                                             uint32_t n) {
   __shared__ unsigned long long lkey[kDdLds + 1];
   __shared__ uint32_t lmin[kDdLds + 1], lcnt[kDdLds + 1], lslot[kDdLds + 1];
-  for (int i = threadIdx.x; i <= kDdLds; i += 256) {
+  for (int i = threadIdx.x; i <= kDdLds; i += kDdBlock) {
     lkey[i] = static_cast<unsigned long long>(kEmptyKey);
     lmin[i] = 0xffffffffu;
     lcnt[i] = 0;
   }
   __syncthreads();
-  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t p = blockIdx.x * kDdBlock + threadIdx.x;
   if (p == 0) *d.heavy_n = 0;  // dd_emit (next but one kernel) refills the heavy list
   const bool valid = p < n;
   uint32_t ls = 0;
@@ -803,18 +805,18 @@ __global__ __launch_bounds__(256) void dd_emit_kernel(DedupView d, const int64_t
   }
 }
 
-__global__ __launch_bounds__(256) void dd_place_kernel(DedupView d, uint32_t n,
-                                                       const uint32_t* __restrict__ seg_off,
-                                                       uint32_t* __restrict__ inverse) {
+__global__ __launch_bounds__(kDdBlock) void dd_place_kernel(DedupView d, uint32_t n,
+                                                            const uint32_t* __restrict__ seg_off,
+                                                            uint32_t* __restrict__ inverse) {
   // same LDS pre-aggregation, keyed by the global slot: in-block rank from an LDS counter, one
   // global cursor bump per distinct id per block
   __shared__ uint32_t lkey[kDdLds], lcnt[kDdLds], lbase[kDdLds];
-  for (int i = threadIdx.x; i < kDdLds; i += 256) {
+  for (int i = threadIdx.x; i < kDdLds; i += kDdBlock) {
     lkey[i] = 0xffffffffu;
     lcnt[i] = 0;
   }
   __syncthreads();
-  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t p = blockIdx.x * kDdBlock + threadIdx.x;
   const bool valid = p < n;
   uint32_t s = 0, ls = 0, rank = 0;
   if (valid) {
@@ -862,7 +864,14 @@ __global__ __launch_bounds__(1024) void dd_finish_kernel(DedupView d, uint32_t n
     const uint32_t s = d.slot_of[p];
     if (len <= kLightMax) {
       uint32_t r = 0;
-      for (uint32_t k = 0; k < len; ++k) r += (d.seg_tmp[q0 + k] < p) ? 1u : 0u;
+      if (len > 1) {
+        uint32_t t[kLightMax];
+#pragma unroll
+        for (int k = 0; k < kLightMax; ++k)
+          t[k] = (uint32_t(k) < len) ? d.seg_tmp[q0 + k] : 0xffffffffu;  // all loads in flight
+#pragma unroll
+        for (int k = 0; k < kLightMax; ++k) r += (t[k] < p) ? 1u : 0u;
+      }
       seg_pos[q0 + r] = p;
     }
     d.hkey[s] = kEmptyKey;

@@ -24,7 +24,8 @@ from monolith_amd.multi_hash_table_ops import MultiHashTable
 class SparseStep:
 
   def __init__(self, table: MultiHashTable, table_name: str, batch: int,
-               exact_order: bool = False):
+               exact_order: bool = False, direct: bool = True):
+    self.direct = direct
     self.table = table
     self.name = table_name
     self.idx = table._index(table_name)  # pylint: disable=protected-access
@@ -47,11 +48,18 @@ class SparseStep:
         table.learning_rate[lr0:lr0 + table._slice_sizes[self.idx]])  # pylint: disable=protected-access
 
   def forward(self, ids: torch.Tensor) -> torch.Tensor:
+    """Rows for every occurrence.  ``direct`` (default): ONE probe+gather kernel over the B
+    occurrences (duplicates of a Zipf head key are served from L2) — the same values as the
+    reference's dedup -> lookup(unique) -> FillWithOffsetMap, without waiting for the dedup.
+    ``direct=False`` keeps the reference's three-op shape."""
     assert ids.numel() == self.batch
     self.ws.unique(ids, want_host_count=False, out=self.u)
-    self.table.table_lookup_n(self.idx, self.u.unique_ids, self.u.n_unique_dev, self.emb_u,
-                              n_max=self.batch)
-    self.ws.gather_rows(self.emb_u, self.u.inverse, self.batch, self.dim, out=self.emb)
+    if self.direct:
+      self.table.table_lookup_n(self.idx, ids, None, self.emb, n_max=self.batch)
+    else:
+      self.table.table_lookup_n(self.idx, self.u.unique_ids, self.u.n_unique_dev, self.emb_u,
+                                n_max=self.batch)
+      self.ws.gather_rows(self.emb_u, self.u.inverse, self.batch, self.dim, out=self.emb)
     return self.emb
 
   def backward(self, grads: torch.Tensor, update_time: int, global_step: int = 0):
