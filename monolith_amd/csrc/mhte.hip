@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -121,7 +122,13 @@ struct DedupWs {
     dd_place_kernel<<<(un + kDdBlock - 1) / kDdBlock, kDdBlock, 0, st>>>(d, un, seg_off, inverse);
     const uint32_t nb_rank = (un + 1023) / 1024;
     const uint32_t hgrid = std::min<uint32_t>(256, un / (kLightMax + 1) + 1);
-    dd_finish_kernel<<<nb_rank + hgrid, 1024, 0, st>>>(d, un, nb_rank, inverse, seg_off, seg_pos);
+    static const bool split_finish = getenv("MHTE_SPLIT_FINISH") != nullptr;  // profiling aid
+    if (split_finish) {
+      dd_finish_kernel<<<nb_rank, 1024, 0, st>>>(d, un, nb_rank, inverse, seg_off, seg_pos);
+      dd_finish_kernel<<<hgrid, 1024, 0, st>>>(d, un, 0, inverse, seg_off, seg_pos);
+    } else {
+      dd_finish_kernel<<<nb_rank + hgrid, 1024, 0, st>>>(d, un, nb_rank, inverse, seg_off, seg_pos);
+    }
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
       clean_cap = 0;  // scratch state unknown: force a clear next time

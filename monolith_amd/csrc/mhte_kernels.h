@@ -897,9 +897,15 @@ __global__ __launch_bounds__(1024) void dd_finish_kernel(DedupView d, uint32_t n
       for (int it4 = 0; it4 < 16; it4 += 4) {
         uint32_t v[16];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const uint32_t pos = r0 + (it4 + (t >> 2)) * 256u + (t & 3);
-          v[t] = (pos < n) ? inverse[pos] : 0xffffffffu;
+        for (int q = 0; q < 4; ++q) {  // one 16-byte load per lane: 1 KiB per wave-instruction
+          const uint32_t pos = r0 + (it4 + q) * 256u;
+          if (pos + 3 < n) {
+            const uint4 t4 = *reinterpret_cast<const uint4*>(inverse + pos);
+            v[q * 4 + 0] = t4.x; v[q * 4 + 1] = t4.y; v[q * 4 + 2] = t4.z; v[q * 4 + 3] = t4.w;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[q * 4 + k] = (pos + k < n) ? inverse[pos + k] : 0xffffffffu;
+          }
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t) bits |= uint64_t(v[t] == u ? 1u : 0u) << (it4 * 4 + t);

@@ -26,6 +26,7 @@ class SparseStep:
   def __init__(self, table: MultiHashTable, table_name: str, batch: int,
                exact_order: bool = False, direct: bool = True):
     self.direct = direct
+    self._joined = True
     self.table = table
     self.name = table_name
     self.idx = table._index(table_name)  # pylint: disable=protected-access
@@ -34,6 +35,7 @@ class SparseStep:
     self.exact_order = exact_order
     dev = torch.device("cuda:%d" % table._device)  # pylint: disable=protected-access
     self.ws = DedupWorkspace(dev.index)
+    self.side = torch.cuda.Stream(device=dev)
     n = batch
     self.u = UniqueResult(torch.empty(n, dtype=torch.int64, device=dev),
                           torch.empty(n, dtype=torch.int32, device=dev),
@@ -53,20 +55,32 @@ class SparseStep:
     reference's dedup -> lookup(unique) -> FillWithOffsetMap, without waiting for the dedup.
     ``direct=False`` keeps the reference's three-op shape."""
     assert ids.numel() == self.batch
-    self.ws.unique(ids, want_host_count=False, out=self.u)
     if self.direct:
+      # the dedup chain (needed by backward only) runs on a side stream beside the lookup
+      main = torch.cuda.current_stream()
+      self.side.wait_stream(main)
+      with torch.cuda.stream(self.side):
+        self.ws.unique(ids, want_host_count=False, out=self.u)
       self.table.table_lookup_n(self.idx, ids, None, self.emb, n_max=self.batch)
+      self._joined = False
     else:
+      self.ws.unique(ids, want_host_count=False, out=self.u)
       self.table.table_lookup_n(self.idx, self.u.unique_ids, self.u.n_unique_dev, self.emb_u,
                                 n_max=self.batch)
       self.ws.gather_rows(self.emb_u, self.u.inverse, self.batch, self.dim, out=self.emb)
     return self.emb
 
   def backward(self, grads: torch.Tensor, update_time: int, global_step: int = 0):
+    if self.direct and not self._joined:
+      torch.cuda.current_stream().wait_stream(self.side)
+      self._joined = True
     self.ws.segment_sum(grads, self.u, self.dim, out=self.grad_u, exact_order=self.exact_order)
     self.table.table_optimize_n(self.idx, self.u.unique_ids, self.u.n_unique_dev, self.grad_u,
                                 self.lrs, update_time, global_step, flags=_lib.MHTE_IDS_UNIQUE,
                                 n_max=self.batch)
 
   def n_unique(self) -> int:
+    if self.direct and not self._joined:
+      torch.cuda.current_stream().wait_stream(self.side)
+      self._joined = True
     return int(self.u.n_unique_dev.item())
