@@ -105,6 +105,10 @@ def lib():
   """Loads libmhte.so (building it first if the sources are newer).  Raises if unavailable."""
   global _lib
   if _lib is None:
+    # torch ships its own libamdhip64/libhsa-runtime64; loading libmhte.so first would pull
+    # /opt/rocm's copies into the process as well and the second HSA runtime then finds no device.
+    # Import torch first so libmhte.so binds to the runtime that owns the tensors and streams.
+    import torch  # noqa: F401  pylint: disable=unused-import,import-outside-toplevel
     if _stale():
       try:
         build_library()

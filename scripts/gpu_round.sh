@@ -1,0 +1,38 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, bench line, rocprofv3 kernel trace of a short bench.
+# Usage (from the repo root on the GPU box): bash scripts/gpu_round.sh <tag> [what...]
+#   what: tests bench prof pmc (default: tests bench prof)
+set -u
+TAG=${1:-r01}; shift || true
+WHAT=${*:-tests bench prof}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+for w in $WHAT; do
+case $w in
+tests)
+  timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+  tail -5 $OUT/pytest_gpu.log ;;
+smoke)
+  timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $OUT/smoke.log ;;
+bench)
+  timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+  cat $OUT/bench.json; tail -5 $OUT/bench.err ;;
+prof)
+  rm -rf /tmp/prof && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof -o trace -- \
+    python bench.py --steps 100 --warmup 10 --no-cpu-baseline --resident-rows 16777216 > $OUT/prof_bench.json 2> $OUT/prof.err
+  echo "prof rc=$?"; find /tmp/prof -type f | head -20
+  for f in $(find /tmp/prof -name '*kernel_stats*.csv'); do cp $f $OUT/; done
+  db=$(find /tmp/prof -name '*.db' | head -1)
+  if [ -n "$db" ]; then python scripts/rocpd_stats.py $db $OUT/kernel_stats.md | head -40; fi
+  cat $OUT/prof_bench.json ;;
+pmc)
+  for c in "FETCH_SIZE" "WRITE_SIZE"; do
+    rm -rf /tmp/pmc_$c && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o pmc -- \
+      python bench.py --steps 30 --warmup 5 --no-cpu-baseline --resident-rows 16777216 --launch eager > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err
+    echo "pmc $c rc=$?"
+    find /tmp/pmc_$c -type f | head
+    for f in $(find /tmp/pmc_$c -name '*counter_collection*.csv'); do python scripts/pmc_csv.py $f > $OUT/pmc_${c}.md; head -30 $OUT/pmc_${c}.md; done
+  done ;;
+esac
+done
