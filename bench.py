@@ -43,6 +43,8 @@ def parse():
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--cpu-steps", type=int, default=150)
   p.add_argument("--exact-order", action="store_true")
+  p.add_argument("--no-stage-timing", action="store_true",
+                 help="skip the per-kernel HIP-event pass (profiling the overlapped step only)")
   return p.parse_args()
 
 
@@ -55,8 +57,8 @@ def algorithmic_bytes(B, U, D, S):
       # one probe+gather launch over the B occurrences: distinct buckets and rows are fetched from
       # HBM once (duplicates hit L2) == SURVEY's bytes_lookup
       "lookup_kernel": lookup,
-      "segsum_window_kernel": 4 * D * B + 8 * B + 4 * D * U,
-      "upsert_kernel": 8 * U + P * U + 4 * U + 4 * D * U + 2 * 4 * (D + S) * U,
+      # fused backward launch (gradient sum + upsert + optimizer) == SURVEY's bytes_update
+      "sum_apply_kernel": update,
   }
   return lookup + update, per_kernel
 
@@ -139,24 +141,10 @@ def main():
   st0 = mt.stats("emb")
 
   # ---- inputs resident in HBM before the timed region ----
-  n_batches = K + W
+  n_batches = K + W + 1  # + the batch the last timed step deduplicates ahead (never trained)
   ids_host = np.stack([S.id_batch(s * world + rank, B, V, "zipf") for s in range(n_batches)])
   ids_all = torch.from_numpy(ids_host).to(dev)
   grad_pool = [torch.from_numpy(S.grad_batch(s, B, D)).to(dev) for s in range(8)]
-
-  if world == 1:
-    step = SparseStep(mt, "emb", B, exact_order=args.exact_order)
-
-    def run_step(s, ids):
-      step.forward(ids)
-      step.backward(grad_pool[s % 8], S.update_time(s))
-  else:
-    from monolith_amd.distributed_ps_sync import HipBackend, ShardedEmbedding
-    se = ShardedEmbedding(HipBackend(mt, "emb"))
-
-    def run_step(s, ids):
-      se.lookup(ids)
-      se.apply_gradients(grad_pool[s % 8], S.update_time(s))
 
   def barrier():
     torch.cuda.synchronize()
@@ -164,39 +152,79 @@ def main():
       dist.barrier()
       torch.cuda.synchronize()
 
-  def timed(fn_step):
-    for s in range(W):
-      fn_step(s, ids_all[s])
+  results = {}
+  graph_err = None
+  if world == 1:
+    # Steady-state pipeline (fused_step.py): while batch s is looked up and updated, the dedup of
+    # batch s+1 — which depends on the ids only — runs on a side stream, as the reference's
+    # prefetch queue does.  Every timed step executes exactly one dedup, one lookup and one
+    # update: the first timed batch was deduplicated by the last warm-up step, the last timed
+    # step deduplicates batch W+K.
+    step = SparseStep(mt, "emb", B, exact_order=args.exact_order)
+
+    def run_eager(lo, hi):
+      for s in range(lo, hi):
+        step.forward(ids_all[s], next_ids=ids_all[s + 1])
+        step.backward(grad_pool[s % 8], S.update_time(s))
+
+    run_eager(0, W)
     barrier()
     t = time.perf_counter()
-    for s in range(W, W + K):
-      fn_step(s, ids_all[s])
+    run_eager(W, W + K)
     barrier()
-    return time.perf_counter() - t
+    results["eager"] = time.perf_counter() - t
 
-  results = {}
-  results["eager"] = timed(run_step)
+    # ---- hipGraph replay: two pipelined steps per graph (the slots alternate) ----
+    if args.launch in ("auto", "graph") and K % 2 == 0 and W % 2 == 0:
+      try:
+        buf_a, buf_b, stage_a = ids_all[0].clone(), ids_all[1].clone(), ids_all[2].clone()
+        static_g = grad_pool[0]
+        # prime: leave the dedup of buf_a in flight, as every later replay will find it
+        step.forward(ids_all[W + K], next_ids=buf_a)
+        step.backward(static_g, S.update_time(0))
+        step.quiesce()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+          step.forward(buf_a, next_ids=buf_b)
+          step.backward(static_g, S.update_time(W))
+          buf_a.copy_(stage_a)                     # the batch after next, for the dedup below
+          step.forward(buf_b, next_ids=buf_a)
+          step.backward(static_g, S.update_time(W + 1))
+          torch.cuda.current_stream().wait_stream(step.side)  # join the dedup of buf_a
+        step.quiesce()
 
-  # ---- hipGraph replay of the whole step (launch-bound inner loop) ----
-  graph_err = None
-  if world == 1 and args.launch in ("auto", "graph"):
-    try:
-      static_ids = ids_all[0].clone()
-      static_g = grad_pool[0]
-      g = torch.cuda.CUDAGraph()
-      torch.cuda.synchronize()
-      with torch.cuda.graph(g):
-        step.forward(static_ids)
-        step.backward(static_g, S.update_time(W))
+        def run_graph(lo, hi):
+          for s in range(lo, hi, 2):
+            buf_b.copy_(ids_all[s + 1], non_blocking=True)
+            stage_a.copy_(ids_all[s + 2], non_blocking=True)
+            g.replay()
 
-      def graph_step(s, ids):
-        static_ids.copy_(ids, non_blocking=True)
-        g.replay()
+        # buf_a currently holds ids_all[0] and its dedup is done -> start at step 0
+        run_graph(0, W)
+        barrier()
+        t = time.perf_counter()
+        run_graph(W, W + K)
+        barrier()
+        results["graph"] = time.perf_counter() - t
+      except Exception as e:  # pylint: disable=broad-except
+        graph_err = repr(e)[:300]
+        print("graph path failed: %s" % graph_err, file=sys.stderr)
+        torch.cuda.synchronize()
+  else:
+    from monolith_amd.distributed_ps_sync import HipBackend, ShardedEmbedding
+    se = ShardedEmbedding(HipBackend(mt, "emb"))
 
-      results["graph"] = timed(graph_step)
-    except Exception as e:  # pylint: disable=broad-except
-      graph_err = repr(e)[:200]
-      torch.cuda.synchronize()
+    def run_sharded(lo, hi):
+      for s in range(lo, hi):
+        se.lookup(ids_all[s])
+        se.apply_gradients(grad_pool[s % 8], S.update_time(s))
+
+    run_sharded(0, W)
+    barrier()
+    t = time.perf_counter()
+    run_sharded(W, W + K)
+    barrier()
+    results["eager"] = time.perf_counter() - t
   launch = min(results, key=results.get) if args.launch == "auto" else (
       args.launch if args.launch in results else "eager")
   elapsed = results[launch]
@@ -207,9 +235,9 @@ def main():
 
   # ---- per-kernel HIP-event timing on the launch stream (N=1) ----
   roofline, stages, uniq_avg = None, {}, None
-  if world == 1:
+  if world == 1 and not args.no_stage_timing:
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
-    names = ["dedup(5 kernels)", "lookup_kernel", "segsum_window_kernel", "upsert_kernel"]
+    names = ["dedup(3 kernels)", "lookup_kernel", "sum_apply_kernel", "slowpath_kernel"]
     acc = {n: 0.0 for n in names}
     us = []
     reps = min(K, 100)
@@ -217,15 +245,15 @@ def main():
       ids = ids_all[s]
       e = [ev() for _ in range(5)]
       e[0].record()
-      step.ws.unique(ids, want_host_count=False, out=step.u)
+      step._unique(ids)  # pylint: disable=protected-access
       e[1].record()
       mt.table_lookup_n(step.idx, ids, None, step.emb, n_max=B)
       e[2].record()
-      step.ws.segment_sum(grad_pool[s % 8], step.u, D, out=step.grad_u,
-                          exact_order=args.exact_order)
+      mt.table_sum_optimize_n(step.idx, step.ws, step.u, grad_pool[s % 8], step.grad_u, step.lrs,
+                              S.update_time(s), 0, exact_order=args.exact_order, n_max=B,
+                              defer_slowpath=True)
       e[3].record()
-      mt.table_optimize_n(step.idx, step.u.unique_ids, step.u.n_unique_dev, step.grad_u, step.lrs,
-                          S.update_time(s), 0, flags=_lib.MHTE_IDS_UNIQUE, n_max=B)
+      mt.table_finish_pending(step.idx)
       e[4].record()
       torch.cuda.synchronize()
       for i, n in enumerate(names):

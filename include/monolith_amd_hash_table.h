@@ -201,6 +201,17 @@ void mhte_dedup_ws_destroy(mhte_dedup_ws* ws);
 mhte_status mhte_unique(mhte_dedup_ws* ws, const int64_t* ids, int64_t n, int64_t* unique_ids,
                         uint32_t* inverse, uint32_t* seg_off, uint32_t* seg_pos,
                         uint32_t* n_unique_dev, int64_t* n_unique_host, void* stream);
+/* Dedup for the fused training step: same key set and occurrence lists as mhte_unique, but the
+ * numbering of the unique ids is unspecified (it follows atomic arrival order, like the iteration
+ * order of the absl::flat_hash_map the reference dedups with, RT/ops/unique_mapping_ops.cc:82-114
+ * keeps insertion order only because it also stores a vector).  Saves the two scan launches that
+ * first-occurrence numbering needs.  list_start / list_end [dev u32, n]: positions of unique id u
+ * are seg_pos[list_start[u] .. list_end[u]); lists longer than 32 positions are in ascending
+ * position order, shorter ones in any order (mhte_table_sum_optimize_n orders them itself). */
+mhte_status mhte_unique_unordered(mhte_dedup_ws* ws, const int64_t* ids, int64_t n,
+                                  int64_t* unique_ids, uint32_t* inverse, uint32_t* list_start,
+                                  uint32_t* list_end, uint32_t* seg_pos, uint32_t* n_unique_dev,
+                                  int64_t* n_unique_host, void* stream);
 /* FillWithOffsetMap in gather form (RT/ops/unique_mapping_ops.cc:225-242):
  * out[p,:] = src[index[p],:] for p < n. */
 mhte_status mhte_gather_rows(const float* src, const uint32_t* index, int64_t n, int32_t dim,
@@ -222,6 +233,42 @@ mhte_status mhte_table_optimize_n(mhte_multi_table* t, int32_t table, const int6
                                   const float* learning_rate, int64_t n_learning_rate,
                                   int64_t update_time, int64_t global_step, int32_t flags,
                                   void* stream);
+
+/* Fused backward of one table: MonolithFillWithOffsetMapGradient (RT/ops/unique_mapping_ops.cc
+ * :284-329) followed by MonolithMultiHashTableOptimize (RT/ops/multi_hash_table_update_op.cc:47-100)
+ * on the unique ids, as ONE launch: out-of-order duplicates are summed per unique id and the
+ * optimizer is applied once per id, without materialising the summed gradients.
+ *   ws              the workspace whose most recent mhte_unique / mhte_unique_unordered produced
+ *                   unique_ids / inverse / lists for this batch of n ids
+ *                   (MHTE_FAILED_PRECONDITION otherwise)
+ *   list_start/end  per unique id, its positions are seg_pos[list_start[u] .. list_end[u]);
+ *                   after mhte_unique pass (seg_off, seg_off + 1)
+ *   grads           [dev, n, dim] gradient of every occurrence
+ *   grad_unique     [dev, n_max, dim] scratch (summed gradients of ids that take the displacement
+ *                   slow path; all unique ids when the row is too wide for the fused kernel)
+ *   flags           MHTE_EXACT_ORDER: every list is summed strictly in occurrence order (bit-exact
+ *                   with the reference); otherwise lists of > 32 occurrences are summed in
+ *                   256-entry chunks in a fixed association (deterministic; fp32 re-association
+ *                   only).  MHTE_DEFER_SLOWPATH: do not launch the displacement pass for ids whose
+ *                   two buckets are full; see mhte_table_finish_pending. */
+enum { MHTE_EXACT_ORDER = 1, MHTE_DEFER_SLOWPATH = 2 };
+mhte_status mhte_table_sum_optimize_n(mhte_multi_table* t, int32_t table, mhte_dedup_ws* ws,
+                                      const int64_t* unique_ids, int64_t n_max,
+                                      const uint32_t* n_unique_dev, const float* grads,
+                                      const uint32_t* inverse, const uint32_t* list_start,
+                                      const uint32_t* list_end, const uint32_t* seg_pos, int64_t n,
+                                      float* grad_unique, const float* learning_rate,
+                                      int64_t n_learning_rate, int64_t update_time,
+                                      int64_t global_step, int32_t flags, void* stream);
+/* Displacement (BFS) pass for the ids a MHTE_DEFER_SLOWPATH call left queued.  Every other entry
+ * point on the table runs it first if it is still outstanding, so calling it is optional; callers
+ * that time kernels, or that update several tables back to back, call it once at the end. */
+mhte_status mhte_table_finish_pending(mhte_multi_table* t, int32_t table, void* stream);
+
+/* 1 when table i's row fits the single-launch backward (dim <= 256 floats, or <= 64 when segment
+ * boundaries are not multiples of 4 floats); otherwise mhte_table_sum_optimize_n runs segment sum +
+ * optimize and needs the ordered mhte_unique. */
+int32_t mhte_table_fused_backward_ok(const mhte_multi_table* t, int32_t i);
 
 /* MonolithUniqueKeyWithValueAndOffset (RT/ops/unique_mapping_ops.cc:51-155), one table at a time:
  * value_offset[q] = value_base + position*dim for the occurrence lists, value_offset_split[u] =

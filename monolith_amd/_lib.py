@@ -20,6 +20,8 @@ MHTE_UNAVAILABLE = 14
 
 MHTE_IDS_UNIQUE = 1
 MHTE_SUM_DUPLICATES = 2
+MHTE_EXACT_ORDER = 1       # flags of mhte_table_sum_optimize_n
+MHTE_DEFER_SLOWPATH = 2
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 INIT_ZEROS, INIT_ONES, INIT_CONSTANT = 0, 1, 2
@@ -96,6 +98,7 @@ EXPORTS = [
     "mhte_dedup_ws_destroy", "mhte_unique", "mhte_gather_rows", "mhte_segment_sum",
     "mhte_table_lookup_n", "mhte_table_optimize_n", "mhte_value_offsets",
     "mhte_fill_with_offset_map", "mhte_fill_with_offset_map_gradient", "mhte_table_set_count_hits",
+    "mhte_table_sum_optimize_n", "mhte_unique_unordered", "mhte_table_fused_backward_ok", "mhte_table_finish_pending",
 ]
 
 _lib = None
@@ -131,7 +134,7 @@ def lib():
     for name in ("mhte_num_tables",):
       getattr(L, name).argtypes = [C.c_void_p]
     for name in ("mhte_table_name", "mhte_table_dim", "mhte_table_slice_size",
-                 "mhte_table_row_floats"):
+                 "mhte_table_row_floats", "mhte_table_fused_backward_ok"):
       getattr(L, name).argtypes = [C.c_void_p, C.c_int32]
     L.mhte_table_index.argtypes = [C.c_void_p, C.c_char_p]
     L.mhte_shared_name.argtypes = [C.c_void_p]

@@ -71,7 +71,11 @@ static inline uint32_t ceil_log2(uint64_t n) {
 struct DedupWs {
   int device = 0;
   DevBuf<int64_t> hkey;
-  DevBuf<uint32_t> hmin, hcnt, huidx, hcur, slot_of, seg_tmp, tile_a, tile_b, heavy, heavy_n;
+  DevBuf<uint32_t> hmin, hcnt, huidx, hcur, hstart, slot_of, seg_tmp, work, tile_a, tile_b, heavy,
+      heavy_n;
+  DevBuf<uint32_t> arrive;     // per-list arrival counters of the fused backward, kept zeroed
+  size_t arrive_clean = 0;     // arrive[0, arrive_clean) is known to be zero
+  int64_t last_n = -1;         // n of the most recent unique(): seg_u describes that batch
   uint32_t clean_cap = 0;  // hash scratch [0, clean_cap] is in the all-empty state
   DevBuf<float> part;
   DevBuf<uint32_t> last_u;
@@ -84,18 +88,22 @@ struct DedupWs {
     hcnt.reserve(size_t(C) + 2);
     huidx.reserve(size_t(C) + 2);
     hcur.reserve(size_t(C) + 2);
+    hstart.reserve(size_t(C) + 2);
     slot_of.reserve(n + 1);
     seg_tmp.reserve(n + 1);
+    work.reserve(2 * (size_t(n) / kChunk + size_t(n) / (kLightMax + 1) + 2));
     size_t ntiles = (n + kDdTile - 1) / kDdTile + 1;
     tile_a.reserve(ntiles);
     tile_b.reserve(ntiles);
     heavy.reserve(n / (kLightMax + 1) + 2);
+    const uint32_t* old_ctr = heavy_n.p;
     heavy_n.reserve(4);
     DedupView d;
+    d.hstart = hstart.p;
     d.hkey = hkey.p; d.hmin = hmin.p; d.hcnt = hcnt.p; d.huidx = huidx.p; d.hcur = hcur.p;
     d.slot_of = slot_of.p; d.tile_a = tile_a.p; d.tile_b = tile_b.p; d.heavy = heavy.p;
-    d.heavy_n = heavy_n.p; d.cap_mask = C - 1; d.seg_tmp = seg_tmp.p;
-    if (hkey.p != old_key || C > clean_cap) {
+    d.heavy_n = heavy_n.p; d.cap_mask = C - 1; d.seg_tmp = seg_tmp.p; d.work = work.p;
+    if (hkey.p != old_key || heavy_n.p != old_ctr || C > clean_cap) {
       // scratch was (re)allocated or never cleared this far: one clear pass; afterwards every
       // dedup leaves the slots it touched empty again (dd_finish_kernel)
       dd_clear_kernel<<<(C + 2 + 255) / 256, 256, 0, st>>>(d);
@@ -104,10 +112,23 @@ struct DedupWs {
     return d;
   }
 
+  // scratch of the fused backward (sum_apply_kernel): block partial rows + zeroed arrival counters
+  void backward_scratch(int64_t n, uint32_t dim, uint32_t nblk_b, hipStream_t st) {
+    part.reserve(size_t(nblk_b) * 2 * dim + 16);
+    const uint32_t* old = arrive.p;
+    arrive.reserve(size_t(n) + 2);
+    if (arrive.p != old) arrive_clean = 0;
+    if (arrive_clean < size_t(n) + 2) {
+      HIP_OK(hipMemsetAsync(arrive.p, 0, arrive.cap * sizeof(uint32_t), st));
+      arrive_clean = arrive.cap;
+    }
+  }
+
   void unique(const int64_t* ids, int64_t n, int64_t* uids, uint32_t* inverse, uint32_t* seg_off,
               uint32_t* seg_pos, uint32_t* n_unique_dev, hipStream_t st) {
     if (n < 0 || n > (int64_t(1) << 31) - 4096)
       throw Error(MHTE_INVALID_ARGUMENT, "unique: n out of range");
+    last_n = n;
     if (n == 0) {
       HIP_OK(hipMemsetAsync(n_unique_dev, 0, sizeof(uint32_t), st));
       HIP_OK(hipMemsetAsync(seg_off, 0, sizeof(uint32_t), st));
@@ -124,14 +145,45 @@ struct DedupWs {
     const uint32_t hgrid = std::min<uint32_t>(256, un / (kLightMax + 1) + 1);
     static const bool split_finish = getenv("MHTE_SPLIT_FINISH") != nullptr;  // profiling aid
     if (split_finish) {
-      dd_finish_kernel<<<nb_rank, 1024, 0, st>>>(d, un, nb_rank, inverse, seg_off, seg_pos);
-      dd_finish_kernel<<<hgrid, 1024, 0, st>>>(d, un, 0, inverse, seg_off, seg_pos);
+      dd_finish_kernel<<<nb_rank, 1024, 0, st>>>(d, un, nb_rank, inverse, seg_off, seg_off + 1,
+                                                 seg_pos, 1, n_unique_dev);
+      dd_finish_kernel<<<hgrid, 1024, 0, st>>>(d, un, 0, inverse, seg_off, seg_off + 1, seg_pos, 1,
+                                               n_unique_dev);
     } else {
-      dd_finish_kernel<<<nb_rank + hgrid, 1024, 0, st>>>(d, un, nb_rank, inverse, seg_off, seg_pos);
+      dd_finish_kernel<<<nb_rank + hgrid, 1024, 0, st>>>(d, un, nb_rank, inverse, seg_off,
+                                                         seg_off + 1, seg_pos, 1, n_unique_dev);
     }
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
       clean_cap = 0;  // scratch state unknown: force a clear next time
+      HIP_OK(le);
+    }
+  }
+
+  // Unordered dedup (3 launches): unique ids in unspecified order, list bounds per unique index,
+  // positions grouped by list (lists of > kLightMax positions ordered, shorter ones not).
+  void unique_unordered(const int64_t* ids, int64_t n, int64_t* uids, uint32_t* inverse,
+                        uint32_t* lst_start, uint32_t* lst_end, uint32_t* seg_pos,
+                        uint32_t* n_unique_dev, hipStream_t st) {
+    if (n < 0 || n > (int64_t(1) << 31) - 4096)
+      throw Error(MHTE_INVALID_ARGUMENT, "unique: n out of range");
+    last_n = n;
+    if (n == 0) {
+      HIP_OK(hipMemsetAsync(n_unique_dev, 0, sizeof(uint32_t), st));
+      return;
+    }
+    DedupView d = view(n, st);
+    const uint32_t un = uint32_t(n);
+    const uint32_t nb = (un + kDdBlock - 1) / kDdBlock;
+    dd_insert_fast_kernel<<<nb, kDdBlock, 0, st>>>(d, ids, un, uids);
+    dd_place_fast_kernel<<<nb, kDdBlock, 0, st>>>(d, un, inverse, lst_start, lst_end, seg_pos);
+    const uint32_t nb_rank = (un + 1023) / 1024;
+    const uint32_t hgrid = std::min<uint32_t>(256, un / (kLightMax + 1) + 1);
+    dd_finish_kernel<<<nb_rank + hgrid, 1024, 0, st>>>(d, un, nb_rank, inverse, lst_start, lst_end,
+                                                       seg_pos, 0, n_unique_dev);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+      clean_cap = 0;
       HIP_OK(le);
     }
   }
@@ -314,6 +366,7 @@ struct Table {
   }
 
   void sync_counters(hipStream_t st) {
+    finish_pending(st);
     HIP_OK(hipMemcpyAsync(h_ctr, ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     if (h_ctr->error & 1u) {
@@ -375,6 +428,7 @@ struct Table {
 
   // ---------------------------------------------------------------- lookup
   void lookup(const int64_t* ids, int64_t n, const uint32_t* n_dev, float* out, hipStream_t st) {
+    finish_pending(st);  // a deferred displacement pass always precedes the next op on the table
     if (n <= 0) return;
     Shape sh = pick_shape(dim, vec_ok && aligned16(out));
     const int64_t threads = n * sh.G;
@@ -412,6 +466,7 @@ struct Table {
   void upsert(const int64_t* ids, int64_t n, const uint32_t* n_dev, const float* values,
               const float* lrs, int64_t update_time, int32_t flags, int32_t* status,
               hipStream_t st) {
+    finish_pending(st);
     if (n <= 0) return;
     if (n > (int64_t(1) << 31) - 4096) throw Error(MHTE_INVALID_ARGUMENT, "too many ids in one op");
     ApplyArgs a;
@@ -435,12 +490,80 @@ struct Table {
     launch_upsert<OP>(g_uids.p, n, g_nu.p, values, g_seg_off.p, g_seg_pos.p, a, status, st);
   }
 
+  // ---------------------------------------------------------------- fused backward
+  // duplicate-gradient sum + upsert + optimizer apply of the unique ids of ws's most recent
+  // unique() in one launch (sum_apply_kernel); falls back to segment-sum + upsert for wide rows.
+  bool fusable() const {
+    Shape sh = pick_shape(dim, vec_ok);
+    return dim <= uint32_t(sh.G * sh.VEC);
+  }
+  void sum_optimize(DedupWs& ws, const int64_t* uids, int64_t n_max, const uint32_t* n_dev,
+                    const float* grads, const uint32_t* lst_start, const uint32_t* lst_end,
+                    const uint32_t* seg_pos, int64_t n, float* grad_u, const float* lrs,
+                    int64_t update_time, bool exact_order, bool defer_slowpath, hipStream_t st) {
+    finish_pending(st);
+    if (n <= 0 || n_max <= 0) return;
+    if (n != ws.last_n)
+      throw Error(MHTE_FAILED_PRECONDITION,
+                  "sum_optimize: workspace does not hold the occurrence lists of this batch");
+    ApplyArgs a;
+    for (int i = 0; i < kMaxSegments; ++i) a.lr[i] = (lrs && i < int(nseg)) ? lrs[i] : 0.f;
+    a.ts = static_cast<uint32_t>(update_time);
+    a.sum_dups = 1;
+    ensure_capacity(uint64_t(n_max), st);
+    Shape sh = pick_shape(dim, vec_ok && aligned16(grads) && aligned16(grad_u));
+    pending.reserve(size_t(n_max) + 1);
+    // upper bound of the work items dd_finish may have queued (each heavy list has > kLightMax
+    // entries and at most one partly filled chunk); surplus blocks exit on the device-side count
+    const uint32_t nblk_b =
+        exact_order ? 0u : uint32_t(n / kChunk + n / (kLightMax + 1) + 1);
+    const uint32_t nblk_a = uint32_t((n_max * sh.G + 255) / 256);
+    ws.backward_scratch(n, dim, nblk_b, st);
+    const uint32_t light_max = exact_order ? 0xffffffffu : uint32_t(kLightMax);
+    uint32_t* pend = pending.p;
+#define CALL(G_, V_)                                                                              \
+  sum_apply_kernel<G_, V_><<<dim3(nblk_a + nblk_b), 256, 0, st>>>(                                \
+      view, uids, n_dev, n_max, grads, lst_start, lst_end, seg_pos, ws.work.p,                    \
+      ws.heavy_n.p + 3, nblk_b,                                                                   \
+      light_max, ws.part.p, ws.arrive.p, grad_u, a, pend)
+    DISPATCH_G_VEC(sh, CALL);
+#undef CALL
+    HIP_OK(hipGetLastError());
+    pend_valid = true;
+    pend_uids = uids;
+    pend_grad = grad_u;
+    pend_args = a;
+    pend_vec = sh.VEC;
+    if (!defer_slowpath) finish_pending(st);
+  }
+
+  // displacement pass for the ids the last fused backward could not place (both buckets full);
+  // a no-op kernel when there are none, which is the usual case
+  bool pend_valid = false;
+  const int64_t* pend_uids = nullptr;
+  const float* pend_grad = nullptr;
+  ApplyArgs pend_args{};
+  int pend_vec = 4;
+  void finish_pending(hipStream_t st) {
+    if (!pend_valid) return;
+    pend_valid = false;
+    if (pend_vec == 4) {
+      slowpath_kernel<4, kOpOptimize><<<1, 64, 0, st>>>(view, pend_uids, pend_grad, nullptr,
+                                                        nullptr, pend_args, nullptr, pending.p);
+    } else {
+      slowpath_kernel<1, kOpOptimize><<<1, 64, 0, st>>>(view, pend_uids, pend_grad, nullptr,
+                                                        nullptr, pend_args, nullptr, pending.p);
+    }
+    HIP_OK(hipGetLastError());
+  }
+
   void note_update_time(int64_t update_time) {
     // fuzzy max, tf_bridge.cc:262-263
     max_update_ts = std::max(max_update_ts, update_time);
   }
 
   void evict(int64_t max_ts, hipStream_t st) {
+    finish_pending(st);
     TtlConfig ttl;
     ttl.default_days = default_expire_days;
     ttl.n = int32_t(expire_slots.size());
@@ -819,6 +942,7 @@ mhte_status mhte_table_contains(mhte_multi_table* t, int32_t table, const int64_
     HIP_OK(hipSetDevice(t->device));
     if (n <= 0) return;
     std::lock_guard<std::mutex> g(tb.mu);
+    tb.finish_pending(S(stream));
     contains_kernel<<<dim3(uint32_t((n + 255) / 256)), 256, 0, S(stream)>>>(tb.view, id, n, out);
     HIP_OK(hipGetLastError());
   });
@@ -863,6 +987,7 @@ mhte_status mhte_table_dump(mhte_multi_table* t, int32_t table, int64_t cap, int
     HIP_OK(hipSetDevice(t->device));
     std::lock_guard<std::mutex> g(tb.mu);
     hipStream_t st = S(stream);
+    tb.finish_pending(st);
     const uint64_t nslots = (uint64_t(1) << tb.hp) * kSlots;
     const uint32_t nblocks = uint32_t((nslots + 1023) / 1024);
     DevBuf<uint32_t> bc;
@@ -911,6 +1036,24 @@ mhte_status mhte_unique(mhte_dedup_ws* ws, const int64_t* ids, int64_t n, int64_
     if (!ws) throw Error(MHTE_INVALID_ARGUMENT, "null workspace");
     HIP_OK(hipSetDevice(ws->ws.device));
     ws->ws.unique(ids, n, unique_ids, inverse, seg_off, seg_pos, n_unique_dev, S(stream));
+    if (n_unique_host) {
+      uint32_t u = 0;
+      HIP_OK(hipMemcpyAsync(&u, n_unique_dev, sizeof(u), hipMemcpyDeviceToHost, S(stream)));
+      HIP_OK(hipStreamSynchronize(S(stream)));
+      *n_unique_host = u;
+    }
+  });
+}
+
+mhte_status mhte_unique_unordered(mhte_dedup_ws* ws, const int64_t* ids, int64_t n,
+                                  int64_t* unique_ids, uint32_t* inverse, uint32_t* list_start,
+                                  uint32_t* list_end, uint32_t* seg_pos, uint32_t* n_unique_dev,
+                                  int64_t* n_unique_host, void* stream) {
+  return guard([&] {
+    if (!ws) throw Error(MHTE_INVALID_ARGUMENT, "null workspace");
+    HIP_OK(hipSetDevice(ws->ws.device));
+    ws->ws.unique_unordered(ids, n, unique_ids, inverse, list_start, list_end, seg_pos,
+                            n_unique_dev, S(stream));
     if (n_unique_host) {
       uint32_t u = 0;
       HIP_OK(hipMemcpyAsync(&u, n_unique_dev, sizeof(u), hipMemcpyDeviceToHost, S(stream)));
@@ -998,6 +1141,59 @@ mhte_status mhte_table_optimize_n(mhte_multi_table* t, int32_t table, const int6
     tb.upsert<kOpOptimize>(id, n_max, n_dev, value, learning_rate, update_time, flags, nullptr,
                            S(stream));
   });
+}
+
+mhte_status mhte_table_sum_optimize_n(mhte_multi_table* t, int32_t table, mhte_dedup_ws* ws,
+                                      const int64_t* unique_ids, int64_t n_max,
+                                      const uint32_t* n_unique_dev, const float* grads,
+                                      const uint32_t* inverse, const uint32_t* list_start,
+                                      const uint32_t* list_end, const uint32_t* seg_pos, int64_t n,
+                                      float* grad_unique, const float* learning_rate,
+                                      int64_t n_learning_rate, int64_t update_time,
+                                      int64_t global_step, int32_t flags, void* stream) {
+  (void)global_step;
+  return guard([&] {
+    Table& tb = table_at(t, table);
+    if (!ws) throw Error(MHTE_INVALID_ARGUMENT, "null workspace");
+    if (!learning_rate || n_learning_rate < int64_t(tb.nseg))
+      throw Error(MHTE_INVALID_ARGUMENT, "The length of tensor `learning_rate` is too short.");
+    if (!n_unique_dev || !grad_unique)
+      throw Error(MHTE_INVALID_ARGUMENT, "sum_optimize: null argument");
+    HIP_OK(hipSetDevice(t->device));
+    std::lock_guard<std::mutex> g(tb.mu);
+    tb.note_update_time(update_time);
+    hipStream_t st = S(stream);
+    if (tb.fusable()) {
+      tb.sum_optimize(ws->ws, unique_ids, n_max, n_unique_dev, grads, list_start, list_end,
+                      seg_pos, n, grad_unique, learning_rate, update_time,
+                      (flags & MHTE_EXACT_ORDER) != 0, (flags & MHTE_DEFER_SLOWPATH) != 0, st);
+      return;
+    }
+    // wide rows: segment sum, then the ordinary upsert over the unique ids (needs the CSR form of
+    // the ordered dedup: list_end == list_start + 1)
+    if (list_end != list_start + 1)
+      throw Error(MHTE_INVALID_ARGUMENT,
+                  "rows wider than 256 floats need the ordered mhte_unique (CSR occurrence lists)");
+    mhte_status s2 = mhte_segment_sum(ws, grads, inverse, list_start, seg_pos, n_unique_dev, n,
+                                      int32_t(tb.dim), grad_unique,
+                                      (flags & MHTE_EXACT_ORDER) ? 1 : 0, stream);
+    if (s2 != MHTE_OK) throw Error(s2, g_last_error);
+    tb.upsert<kOpOptimize>(unique_ids, n_max, n_unique_dev, grad_unique, learning_rate, update_time,
+                           MHTE_IDS_UNIQUE, nullptr, st);
+  });
+}
+
+mhte_status mhte_table_finish_pending(mhte_multi_table* t, int32_t table, void* stream) {
+  return guard([&] {
+    Table& tb = table_at(t, table);
+    HIP_OK(hipSetDevice(t->device));
+    std::lock_guard<std::mutex> g(tb.mu);
+    tb.finish_pending(S(stream));
+  });
+}
+
+int32_t mhte_table_fused_backward_ok(const mhte_multi_table* t, int32_t i) {
+  return (t && i >= 0 && i < int32_t(t->tables.size()) && t->tables[i]->fusable()) ? 1 : 0;
 }
 
 mhte_status mhte_value_offsets(const uint32_t* seg_off, const uint32_t* seg_pos,

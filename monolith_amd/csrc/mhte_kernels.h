@@ -236,35 +236,27 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
 // Algorithmic bytes per unique id: 8 (id) + 36..72 (probe) + 4 (ts) + 4*dim (value)
 //   + 2 * 4 * row_floats (row read-modify-write).
 // =============================================================================================
-template <int G, int VEC, int OP>
-__global__ __launch_bounds__(256) void upsert_kernel(TableView tv, const int64_t* __restrict__ ids,
-                                                     int64_t n, const uint32_t* __restrict__ n_dev,
-                                                     const float* __restrict__ values,
-                                                     const uint32_t* __restrict__ seg_off,
-                                                     const uint32_t* __restrict__ seg_pos,
-                                                     ApplyArgs a, int32_t* __restrict__ status,
-                                                     uint32_t* __restrict__ pending) {
-  const int lane = threadIdx.x & 63;
+// Probe + insert for ONE id per G-lane group; every lane of the wavefront must call it (it uses
+// wave ballots).  The caller has already issued the slot loads: lane j < 8 of the group holds
+// key `k` / handle `row` of slot (j & 3) of bucket i1 (j < 4) or i2 (j >= 4), `b` points at that
+// bucket.  On return: `r` row handle, `is_new` (row just allocated: start from the initializer),
+// `deferred` (both buckets full: caller queues the id for slowpath_kernel).  Timestamps and new
+// handles are written here.
+struct SlotResult {
+  uint32_t r;
+  bool is_new;
+  bool deferred;
+};
+
+template <int G>
+__device__ __forceinline__ SlotResult upsert_resolve(const TableView& tv, Bucket* b, int64_t id,
+                                                     bool valid, int64_t k, uint32_t row, int lane,
+                                                     uint32_t ts) {
   const int j = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
-  const int64_t g = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
-  if (n_dev) n = min(n, int64_t(*n_dev));
-  const bool valid = g < n;
-  const int64_t id = valid ? ids[g] : 0;
-  const bool special = valid && id == kEmptyKey;
-  const uint64_t hv = hash_key(id);
-  const uint64_t i1 = index_hash(tv.hp, hv);
-  const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
-
-  Bucket* b = tv.buckets + ((j < 4) ? i1 : i2);
   const int s = j & 3;
+  const bool special = valid && id == kEmptyKey;
   const bool prober = valid && !special && j < 8;
-  int64_t k = kEmptyKey;
-  uint32_t row = kNoRow;
-  if (prober) {
-    k = b->key[s];
-    row = b->row[s];
-  }
   uint64_t m = group_mask_of<G>(__ballot(prober && k == id), gbase);
   bool found = m != 0;
   bool is_new = false;
@@ -336,29 +328,62 @@ __global__ __launch_bounds__(256) void upsert_kernel(TableView tv, const int64_t
     } else {
       r = tv.ctr->special_row;  // written by an earlier kernel
     }
-    if (j == 0) tv.ctr->special_ts = a.ts;
+    if (j == 0) tv.ctr->special_ts = ts;
   } else if (valid && !deferred && j == owner) {
     if (is_new) b->row[s] = r;
-    b->ts[s] = a.ts;  // SetTimestamp(update_time), cuckoo_embedding_hash_table.cc:242-246
+    b->ts[s] = ts;  // SetTimestamp(update_time), cuckoo_embedding_hash_table.cc:242-246
   }
+  SlotResult out;
+  out.r = r;
+  out.is_new = is_new;
+  out.deferred = deferred;
+  return out;
+}
+
+template <int G, int VEC, int OP>
+__global__ __launch_bounds__(256) void upsert_kernel(TableView tv, const int64_t* __restrict__ ids,
+                                                     int64_t n, const uint32_t* __restrict__ n_dev,
+                                                     const float* __restrict__ values,
+                                                     const uint32_t* __restrict__ seg_off,
+                                                     const uint32_t* __restrict__ seg_pos,
+                                                     ApplyArgs a, int32_t* __restrict__ status,
+                                                     uint32_t* __restrict__ pending) {
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (G - 1);
+  const int64_t g = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  if (n_dev) n = min(n, int64_t(*n_dev));
+  const bool valid = g < n;
+  const int64_t id = valid ? ids[g] : 0;
+  const uint64_t hv = hash_key(id);
+  const uint64_t i1 = index_hash(tv.hp, hv);
+  const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
+
+  Bucket* b = tv.buckets + ((j < 4) ? i1 : i2);
+  int64_t k = kEmptyKey;
+  uint32_t row = kNoRow;
+  if (valid && id != kEmptyKey && j < 8) {
+    k = b->key[j & 3];
+    row = b->row[j & 3];
+  }
+  const SlotResult sr = upsert_resolve<G>(tv, b, id, valid, k, row, lane, a.ts);
   // ---- defer to the slow path ----
-  if (deferred && j == 0) {
+  if (sr.deferred && j == 0) {
     const uint32_t slot = atomicAdd(&tv.ctr->n_pending, 1u);
     pending[slot] = static_cast<uint32_t>(g);
   }
   // ---- apply ----
-  if (valid && !deferred) {
+  if (valid && !sr.deferred) {
     const uint32_t q0 = seg_off ? seg_off[g] : 0u;
     const uint32_t q1 = seg_off ? seg_off[g + 1] : 1u;
-    apply_row<G, VEC, OP>(tv, row_ptr(tv, r), is_new, j, values, seg_off ? seg_pos : nullptr, q0,
-                          q1, g, a);
+    apply_row<G, VEC, OP>(tv, row_ptr(tv, sr.r), sr.is_new, j, values, seg_off ? seg_pos : nullptr,
+                          q0, q1, g, a);
     if (OP == kOpReinit && j == 0) {
       // status: 0 inserted, 1 existed (cuckoo_embedding_hash_table.cc:215-226); later duplicates
       // of an id always see it existing.
       if (seg_off) {
-        for (uint32_t q = q0; q < q1; ++q) status[seg_pos[q]] = (q == q0 && is_new) ? 0 : 1;
+        for (uint32_t q = q0; q < q1; ++q) status[seg_pos[q]] = (q == q0 && sr.is_new) ? 0 : 1;
       } else {
-        status[g] = is_new ? 0 : 1;
+        status[g] = sr.is_new ? 0 : 1;
       }
     }
   }
@@ -609,15 +634,19 @@ struct DedupView {
   uint32_t* hcur;     // [C+1]
   uint32_t* slot_of;  // [n]
   uint32_t* seg_tmp;  // [n] unordered occurrence lists (ordered copy goes to seg_pos)
+  uint32_t* work;     // [2 * (n/kChunk + n/33 + 2)] (unique index, chunk) items over the heavy lists
   uint32_t* tile_a;   // [ntiles] first-occurrence counts
   uint32_t* tile_b;   // [ntiles] occurrence-count sums
   uint32_t* heavy;    // [n/33 + 1]
-  uint32_t* heavy_n;  // [1]
+  uint32_t* heavy_n;  // [4]: [0] heavy-list length, [1] unique counter, [2] list-space cursor,
+                      //      [3] number of work items
+  uint32_t* hstart;   // [C+1] list start of the slot's id (unordered dedup), kUnset when unclaimed
   uint32_t cap_mask;  // C-1
 };
 
 constexpr int kDdTile = 1024;   // positions per tile (256 threads x 4)
 constexpr int kLightMax = 32;   // longest list sorted in-thread
+constexpr uint32_t kChunk = 256;  // entries per work item of the fused backward (sum_apply_kernel)
 
 __global__ __launch_bounds__(256) void dd_clear_kernel(DedupView d) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -626,7 +655,9 @@ __global__ __launch_bounds__(256) void dd_clear_kernel(DedupView d) {
     d.hmin[i] = 0xffffffffu;
     d.hcnt[i] = 0;
     d.hcur[i] = 0;
+    d.hstart[i] = 0xffffffffu;
   }
+  if (i < 4) d.heavy_n[i] = 0;
 }
 
 // LDS-side pre-aggregation: the 256 positions of a block are first deduplicated in a 512-entry LDS
@@ -663,7 +694,10 @@ __global__ __launch_bounds__(kDdBlock) void dd_insert_kernel(DedupView d,
   }
   __syncthreads();
   const uint32_t p = blockIdx.x * kDdBlock + threadIdx.x;
-  if (p == 0) *d.heavy_n = 0;  // dd_emit (next but one kernel) refills the heavy list
+  if (p == 0) {  // dd_emit / dd_finish (later kernels) refill these
+    d.heavy_n[0] = 0;
+    d.heavy_n[3] = 0;
+  }
   const bool valid = p < n;
   uint32_t ls = 0;
   int64_t id = 0;
@@ -843,26 +877,231 @@ __global__ __launch_bounds__(kDdBlock) void dd_place_kernel(DedupView d, uint32_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Unordered dedup for the fused training step (mhte_unique_unordered): the step only needs SOME
+// numbering of the distinct ids and their occurrence lists, not the first-occurrence numbering
+// the reference op emits, which costs a two-kernel scan over the batch.  Three launches:
+//   dd_insert_fast  as dd_insert, and the thread that claims a scratch slot numbers the id
+//                   (one LDS counter per block, one global atomic per block)
+//   dd_place_fast   the first block that touches an id carves its list [start, start+count) out
+//                   of [0, n) (block-aggregated cursor), publishes it; other blocks wait for the
+//                   publication, then positions are appended as in dd_place.  Light lists go
+//                   straight to seg_pos (the consumer sorts <= kLightMax positions in registers),
+//                   heavy lists to seg_tmp for the bitmap ordering pass of dd_finish.
+//   dd_finish       (order_light = 0) heavy lists only + scratch reset.
+// Unique numbering and list placement depend on atomic arrival order; every VALUE computed from
+// them downstream (sums in position order, optimizer steps) does not.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kUnset = 0xffffffffu;
+constexpr uint32_t kBusy = 0xfffffffeu;
+
+__device__ __forceinline__ uint32_t dd_global_slot_claim(const DedupView& d, int64_t id,
+                                                         bool* claimed) {
+  *claimed = false;
+  if (id == kEmptyKey) {
+    const uint32_t s = d.cap_mask + 1u;
+    const unsigned long long old =
+        atomicCAS(reinterpret_cast<unsigned long long*>(&d.hkey[s]),
+                  static_cast<unsigned long long>(kEmptyKey), 0ull);
+    *claimed = static_cast<int64_t>(old) == kEmptyKey;
+    return s;
+  }
+  uint32_t s = uint32_t(hash_key(id)) & d.cap_mask;
+  for (;;) {
+    int64_t k = d.hkey[s];
+    if (k == kEmptyKey) {
+      k = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hkey[s]),
+                                         static_cast<unsigned long long>(kEmptyKey),
+                                         static_cast<unsigned long long>(id)));
+      if (k == kEmptyKey) {
+        *claimed = true;
+        return s;
+      }
+    }
+    if (k == id) return s;
+    s = (s + 1u) & d.cap_mask;
+  }
+}
+
+__global__ __launch_bounds__(kDdBlock) void dd_insert_fast_kernel(DedupView d,
+                                                                  const int64_t* __restrict__ ids,
+                                                                  uint32_t n,
+                                                                  int64_t* __restrict__ uids) {
+  __shared__ unsigned long long lkey[kDdLds + 1];
+  __shared__ uint32_t lmin[kDdLds + 1], lcnt[kDdLds + 1], lslot[kDdLds + 1];
+  __shared__ uint32_t l_nclaim, l_base;
+  for (int i = threadIdx.x; i <= kDdLds; i += kDdBlock) {
+    lkey[i] = static_cast<unsigned long long>(kEmptyKey);
+    lmin[i] = 0xffffffffu;
+    lcnt[i] = 0;
+  }
+  if (threadIdx.x == 0) l_nclaim = 0;
+  __syncthreads();
+  const uint32_t p = blockIdx.x * kDdBlock + threadIdx.x;
+  if (p == 0) {  // dd_place_fast / dd_finish (later kernels) refill these
+    d.heavy_n[0] = 0;
+    d.heavy_n[3] = 0;
+  }
+  const bool valid = p < n;
+  uint32_t ls = 0;
+  int64_t id = 0;
+  if (valid) {
+    id = ids[p];
+    if (id == kEmptyKey) {
+      ls = kDdLds;
+    } else {
+      ls = uint32_t(hash_key(id) >> 40) & (kDdLds - 1);
+      for (;;) {
+        unsigned long long k = lkey[ls];
+        if (k == static_cast<unsigned long long>(kEmptyKey)) {
+          k = atomicCAS(&lkey[ls], static_cast<unsigned long long>(kEmptyKey),
+                        static_cast<unsigned long long>(id));
+          if (k == static_cast<unsigned long long>(kEmptyKey)) break;
+        }
+        if (k == static_cast<unsigned long long>(id)) break;
+        ls = (ls + 1u) & (kDdLds - 1);
+      }
+    }
+    atomicMin(&lmin[ls], p);
+    atomicAdd(&lcnt[ls], 1u);
+  }
+  __syncthreads();
+  bool claimed = false;
+  uint32_t gs = 0, crank = 0;
+  if (valid && lmin[ls] == p) {  // the block's first occurrence of this id speaks for all of them
+    gs = dd_global_slot_claim(d, id, &claimed);
+    atomicAdd(&d.hcnt[gs], lcnt[ls]);
+    lslot[ls] = gs;
+    if (claimed) crank = atomicAdd(&l_nclaim, 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && l_nclaim) l_base = atomicAdd(&d.heavy_n[1], l_nclaim);
+  __syncthreads();
+  if (claimed) {
+    const uint32_t u = l_base + crank;
+    d.huidx[gs] = u;
+    uids[u] = id;
+  }
+  if (valid) d.slot_of[p] = lslot[ls];
+}
+
+__global__ __launch_bounds__(kDdBlock) void dd_place_fast_kernel(
+    DedupView d, uint32_t n, uint32_t* __restrict__ inverse, uint32_t* __restrict__ lst_start,
+    uint32_t* __restrict__ lst_end, uint32_t* __restrict__ seg_pos) {
+  __shared__ uint32_t lkey[kDdLds], lcnt[kDdLds], lbase[kDdLds], lstart[kDdLds];
+  __shared__ uint32_t l_total, l_gbase;
+  for (int i = threadIdx.x; i < kDdLds; i += kDdBlock) {
+    lkey[i] = 0xffffffffu;
+    lcnt[i] = 0;
+  }
+  if (threadIdx.x == 0) l_total = 0;
+  __syncthreads();
+  const uint32_t p = blockIdx.x * kDdBlock + threadIdx.x;
+  const bool valid = p < n;
+  uint32_t s = 0, ls = 0, rank = 0;
+  if (valid) {
+    s = d.slot_of[p];
+    ls = (s * 2654435761u >> 16) & (kDdLds - 1);
+    for (;;) {
+      uint32_t k = lkey[ls];
+      if (k == 0xffffffffu) {
+        k = atomicCAS(&lkey[ls], 0xffffffffu, s);
+        if (k == 0xffffffffu) break;
+      }
+      if (k == s) break;
+      ls = (ls + 1u) & (kDdLds - 1);
+    }
+    rank = atomicAdd(&lcnt[ls], 1u);
+  }
+  __syncthreads();
+  // ---- phase 1 (never waits): the first block to reach an id allocates its list
+  const bool rep = valid && rank == 0;
+  bool won = false;
+  uint32_t cnt = 0, loff = 0;
+  if (rep) {
+    won = atomicCAS(&d.hstart[s], kUnset, kBusy) == kUnset;
+    if (won) {
+      cnt = d.hcnt[s];
+      loff = atomicAdd(&l_total, cnt);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && l_total) l_gbase = atomicAdd(&d.heavy_n[2], l_total);
+  __syncthreads();
+  uint32_t st = 0;
+  if (won) {
+    st = l_gbase + loff;
+    const uint32_t u = d.huidx[s];
+    lst_start[u] = st;
+    lst_end[u] = st + cnt;
+    if (cnt > kLightMax) d.heavy[atomicAdd(&d.heavy_n[0], 1u)] = u;
+    __hip_atomic_store(&d.hstart[s], st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- phase 2: everybody else waits for the publication (the allocator is already past its
+  // last barrier, so it cannot be waiting for anything in turn)
+  if (rep) {
+    if (!won) {
+      for (;;) {
+        st = __hip_atomic_load(&d.hstart[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st < kBusy) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    lstart[ls] = st;
+    lbase[ls] = atomicAdd(&d.hcur[s], lcnt[ls]);
+  }
+  __syncthreads();
+  if (valid) {
+    const uint32_t u = d.huidx[s];
+    const uint32_t c = d.hcnt[s];
+    const uint32_t q = lstart[ls] + lbase[ls] + rank;
+    inverse[p] = u;
+    if (c > kLightMax) {
+      d.seg_tmp[q] = p;
+    } else {
+      seg_pos[q] = p;
+    }
+  }
+}
+
 // Final dedup kernel, two roles in one launch (1024-thread workgroups):
 //  * blocks [0, nb_rank): one thread per position p.  Lists of <= kLightMax occurrences are put in
 //    position order by rank-counting: p's rank is the number of smaller positions in its
 //    (unordered) list, so p itself writes seg_pos[list_start + rank].  The same threads reset the
 //    scratch hash slots they used (clean-after-use: the next dedup needs no clear pass).
 //  * blocks [nb_rank, grid): one workgroup per heavy key (> kLightMax occurrences, ~130 under
-//    Zipf(1.2) at B = 65 536) rewrites its list by an ordered stream compaction over inverse[]:
-//    wave w owns positions [w*4096, (w+1)*4096) of a 65 536-position chunk, keeps its 64 match
-//    bits per lane in one register, one block scan orders the waves.
+//    Zipf(1.2) at B = 65 536).  Positions are distinct integers below n, so ordering the list is a
+//    bitmap problem: the workgroup sets one LDS bit per position of the (unordered) list, then
+//    emits the set bits in ascending order with one popcount scan — O(len/1024 + n/32768) per
+//    thread instead of a scan over the whole inverse[] array.  n > kBmBits is handled in chunks.
+// Thread 0 of a heavy workgroup also appends the list's (unique index, chunk) work items for the
+// fused backward (sum_apply_kernel).
+constexpr int kBmWords = 8192;               // 32 KiB of LDS: 262 144 positions per chunk
+constexpr uint32_t kBmBits = kBmWords * 32u;
+
+//   lst_start / lst_end: list bounds per unique index (ordered dedup: seg_off and seg_off + 1).
+//   order_light = 0 (unordered dedup): light lists are already in seg_pos, unordered; only the
+//   scratch reset remains for the per-position blocks, and block 0 publishes the unique count.
 __global__ __launch_bounds__(1024) void dd_finish_kernel(DedupView d, uint32_t n, uint32_t nb_rank,
                                                          const uint32_t* __restrict__ inverse,
-                                                         const uint32_t* __restrict__ seg_off,
-                                                         uint32_t* __restrict__ seg_pos) {
+                                                         const uint32_t* __restrict__ lst_start,
+                                                         const uint32_t* __restrict__ lst_end,
+                                                         uint32_t* __restrict__ seg_pos,
+                                                         int order_light,
+                                                         uint32_t* __restrict__ n_unique_out) {
   if (blockIdx.x < nb_rank) {
     const uint32_t p = blockIdx.x * 1024 + threadIdx.x;
+    if (!order_light && p == 0) {
+      *n_unique_out = d.heavy_n[1];
+      d.heavy_n[1] = 0;
+      d.heavy_n[2] = 0;
+    }
     if (p >= n) return;
-    const uint32_t u = inverse[p];
-    const uint32_t q0 = seg_off[u], len = seg_off[u + 1] - q0;
     const uint32_t s = d.slot_of[p];
-    if (len <= kLightMax) {
+    if (order_light) {
+      const uint32_t u = inverse[p];
+      const uint32_t q0 = lst_start[u], len = lst_end[u] - q0;
+      if (len <= kLightMax) {
       uint32_t r = 0;
       if (len > 1) {
         uint32_t t[kLightMax];
@@ -873,67 +1112,74 @@ __global__ __launch_bounds__(1024) void dd_finish_kernel(DedupView d, uint32_t n
         for (int k = 0; k < kLightMax; ++k) r += (t[k] < p) ? 1u : 0u;
       }
       seg_pos[q0 + r] = p;
+      }
     }
     d.hkey[s] = kEmptyKey;
     d.hmin[s] = 0xffffffffu;
     d.hcnt[s] = 0;
     d.hcur[s] = 0;
+    d.hstart[s] = kUnset;
     return;
   }
+  __shared__ uint32_t bm[kBmWords];
   __shared__ uint32_t wcnt[16];
-  __shared__ uint32_t running;
   const uint32_t nh = *d.heavy_n;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint64_t lt = (uint64_t(1) << lane) - 1;
   for (uint32_t h = blockIdx.x - nb_rank; h < nh; h += gridDim.x - nb_rank) {
     const uint32_t u = d.heavy[h];
-    uint32_t* outp = seg_pos + seg_off[u];
-    if (threadIdx.x == 0) running = 0;
-    __syncthreads();
-    for (uint32_t chunk = 0; chunk < n; chunk += 65536u) {
-      const uint32_t r0 = chunk + w * 4096u + lane * 4u;
-      uint64_t bits = 0;  // bit (it*4+k): position r0 + it*256 + k belongs to list u
+    const uint32_t q0 = lst_start[u], len = lst_end[u] - q0;
+    uint32_t* outp = seg_pos + q0;
+    if (threadIdx.x == 0) {  // work items of the fused backward: consecutive per list
+      const uint32_t nc = (len + kChunk - 1) / kChunk;
+      const uint32_t w0 = atomicAdd(&d.heavy_n[3], nc);
+      for (uint32_t k = 0; k < nc; ++k) {
+        d.work[2 * (w0 + k)] = u;
+        d.work[2 * (w0 + k) + 1] = k;
+      }
+    }
+    uint32_t running = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += kBmBits) {
+      const uint32_t nbits = min(kBmBits, n - c0);
+      const uint32_t nw = (nbits + 31u) >> 5;
+      const uint32_t wpt = (nw + 1023u) >> 10;  // words per thread (contiguous)
+      for (uint32_t i = threadIdx.x; i < nw; i += 1024) bm[i] = 0;
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < len; i += 1024) {
+        const uint32_t rel = d.seg_tmp[q0 + i] - c0;
+        if (rel < nbits) atomicOr(&bm[rel >> 5], 1u << (rel & 31u));
+      }
+      __syncthreads();
+      const uint32_t w0 = threadIdx.x * wpt;
+      uint32_t cnt = 0;
+      for (uint32_t i = 0; i < wpt; ++i)
+        if (w0 + i < nw) cnt += __popc(bm[w0 + i]);
+      uint32_t incl = cnt;
 #pragma unroll
-      for (int it4 = 0; it4 < 16; it4 += 4) {
-        uint32_t v[16];
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+      }
+      if (lane == 63) wcnt[w] = incl;
+      __syncthreads();
+      uint32_t off = running + (incl - cnt), total = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {  // one 16-byte load per lane: 1 KiB per wave-instruction
-          const uint32_t pos = r0 + (it4 + q) * 256u;
-          if (pos + 3 < n) {
-            const uint4 t4 = *reinterpret_cast<const uint4*>(inverse + pos);
-            v[q * 4 + 0] = t4.x; v[q * 4 + 1] = t4.y; v[q * 4 + 2] = t4.z; v[q * 4 + 3] = t4.w;
-          } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[q * 4 + k] = (pos + k < n) ? inverse[pos + k] : 0xffffffffu;
-          }
+      for (int i = 0; i < 16; ++i) {
+        off += (i < w) ? wcnt[i] : 0u;
+        total += wcnt[i];
+      }
+      for (uint32_t i = 0; i < wpt; ++i) {
+        if (w0 + i >= nw) break;
+        uint32_t bits = bm[w0 + i];
+        const uint32_t pbase = c0 + ((w0 + i) << 5);
+        while (bits) {
+          const uint32_t bit = __ffs(bits) - 1;
+          bits &= bits - 1;
+          outp[off] = pbase + bit;
+          ++off;
         }
-#pragma unroll
-        for (int t = 0; t < 16; ++t) bits |= uint64_t(v[t] == u ? 1u : 0u) << (it4 * 4 + t);
       }
-      uint32_t total = __popcll(bits);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-      if (lane == 0) wcnt[w] = total;
-      __syncthreads();
-      uint32_t off = running;
-      for (int i = 0; i < w; ++i) off += wcnt[i];
-#pragma unroll 1
-      for (int it = 0; it < 16; ++it) {
-        const uint32_t nib = uint32_t(bits >> (it * 4)) & 0xfu;
-        const uint64_t m0 = __ballot(nib & 1u), m1 = __ballot(nib & 2u), m2 = __ballot(nib & 4u),
-                       m3 = __ballot(nib & 8u);
-        uint32_t o = off + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) +
-                     __popcll(m3 & lt);
-        const uint32_t pbase = r0 + it * 256u;
-        if (nib & 1u) outp[o++] = pbase;
-        if (nib & 2u) outp[o++] = pbase + 1;
-        if (nib & 4u) outp[o++] = pbase + 2;
-        if (nib & 8u) outp[o++] = pbase + 3;
-        off += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
-      }
-      __syncthreads();
-      if (threadIdx.x == 1023) running = off;  // wave 15's final offset = everything so far
-      __syncthreads();
+      running += total;
+      __syncthreads();  // bm / wcnt are reused
     }
   }
 }
@@ -1127,6 +1373,306 @@ __global__ __launch_bounds__(256) void segsum_exact_kernel(
       for (int c = 0; c < VEC; ++c) acc.v[c] = acc.v[c] + v.v[c];
     }
     acc.store(out + int64_t(u) * dim + e);
+  }
+}
+
+// =============================================================================================
+// Fused backward of the sparse step: duplicate-gradient sum (FillWithOffsetMapGradient,
+// ops/unique_mapping_ops.cc:307-324) + upsert + optimizer apply (multi_hash_table_update_op.cc
+// :47-100) in ONE launch, for rows of dim <= G*VEC (one element vector per lane).
+//
+//   blocks [nblk_b, grid)  "id-major": one G-lane group per unique id u.  Lists of <= light_max
+//       occurrences are summed by the group itself in occurrence order (bit-identical to the
+//       reference's sequential sum) while the group's probe of the table is in flight, then the
+//       optimizer is applied from registers.  Longer lists are left to the window blocks.
+//   blocks [0, nblk_b)     "chunk blocks": block b takes work item b = (heavy list u, chunk k of
+//       kChunk = 256 entries) from the list dd_finish left behind (blocks past the item count
+//       exit).  The block's groups sum windows of 16 gradient rows each, LDS adds the groups in
+//       order.  A one-chunk list is applied on the spot; otherwise the chunk sum is handed over
+//       (write-through partial row + arrival counter) and the block that arrives last adds the
+//       chunk sums in chunk order and applies the optimizer.  Chunks are cut relative to the
+//       list's start, so the association — and with it every bit of the result — depends on the
+//       list only (deterministic), and differs from the sequential sum by fp32 re-association.
+//       arrive[] is left zeroed (clean-after-use).
+//
+// With exact order requested the host passes light_max = 0xffffffff and nblk_b = 0.
+// Deferred ids (both buckets full) get their summed gradient stored to grad_u[u] and are finished by
+// slowpath_kernel<VEC, kOpOptimize>(values = grad_u) in stream order.
+// =============================================================================================
+
+template <int VEC>
+__device__ __forceinline__ void vec_zero(Vec<VEC>& v) {
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) v.v[c] = 0.f;
+}
+template <int VEC>
+__device__ __forceinline__ void vec_add(Vec<VEC>& a, const Vec<VEC>& b) {
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) a.v[c] = a.v[c] + b.v[c];
+}
+
+// Cross-workgroup hand-off of the block partial rows (cdna_hip_programming.md §6 Guideline 16, R1):
+// the payload is stored write-through (agent-scope relaxed atomic stores = sc1), every storing
+// wave drains its stores, ONE lane bumps the arrival counter; the last arriver reads the payload
+// with agent-scope loads.  No release/acquire fence: on gfx950 an agent-scope fence writes back /
+// invalidates the whole per-XCD L2, which costs far more than the rows being handed over.
+template <int VEC>
+__device__ __forceinline__ void store_wt(float* p, const Vec<VEC>& v) {
+#pragma unroll
+  for (int c = 0; c < VEC; ++c)
+    __hip_atomic_store(p + c, v.v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int VEC>
+__device__ __forceinline__ void load_agent(const float* p, Vec<VEC>& v) {
+#pragma unroll
+  for (int c = 0; c < VEC; ++c)
+    v.v[c] = __hip_atomic_load(p + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one optimizer step on the lane's element vector, gradient in registers (kOpOptimize only)
+template <int VEC>
+__device__ __forceinline__ void optimize_row_reg(const TableView& tv, float* rp, bool is_new,
+                                                 uint32_t e, const Vec<VEC>& g, const ApplyArgs& a) {
+  if (e >= tv.dim) return;
+  uint32_t k = 0;
+  while (k + 1 < tv.nseg && e >= uint32_t(tv.seg[k + 1].w_off)) ++k;
+  const SegDesc sd = tv.seg[k];
+  const uint32_t le = e - sd.w_off;
+  const float lr = a.lr[k];
+  Vec<VEC> w, s1, s2;
+  float* st1 = rp + sd.st_off + le;
+  float* st2 = st1 + sd.dim;
+  const bool has1 = sd.opt == kOptAdagrad || sd.opt == kOptFtrl;
+  const bool has2 = sd.opt == kOptFtrl;
+  if (is_new) {
+    const float w0 = init_weight(sd);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      w.v[c] = w0;
+      s1.v[c] = sd.p[0];
+      s2.v[c] = 0.f;
+    }
+  } else {
+    w.load(rp + e);
+    if (has1) s1.load(st1);
+    if (has2) s2.load(st2);
+  }
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) {
+    if (sd.opt == kOptSgd) {
+      w.v[c] = sgd_step(w.v[c], g.v[c], lr);
+    } else if (sd.opt == kOptAdagrad) {
+      adagrad_step(w.v[c], s1.v[c], g.v[c], lr, sd.p[1]);
+    } else {
+      ftrl_step(w.v[c], s1.v[c], s2.v[c], g.v[c], lr, sd.p[1], sd.p[2], sd.p[3]);
+    }
+  }
+  w.store(rp + e);
+  if (has1) s1.store(st1);
+  if (has2) s2.store(st2);
+}
+
+// probe + insert + apply for the id of unique index u, gradient vector in registers.  Wave-uniform
+// call (every lane of the wavefront), `valid` per group.
+template <int G, int VEC>
+__device__ __forceinline__ void upsert_reg(const TableView& tv, const int64_t* __restrict__ uids,
+                                           uint32_t u, bool valid, const Vec<VEC>& g, int lane,
+                                           const ApplyArgs& a, float* __restrict__ grad_u,
+                                           uint32_t* __restrict__ pending) {
+  const int j = lane & (G - 1);
+  const int64_t id = valid ? uids[u] : 0;
+  const uint64_t hv = hash_key(id);
+  const uint64_t i1 = index_hash(tv.hp, hv);
+  const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
+  Bucket* b = tv.buckets + ((j < 4) ? i1 : i2);
+  int64_t k = kEmptyKey;
+  uint32_t row = kNoRow;
+  if (valid && id != kEmptyKey && j < 8) {
+    k = b->key[j & 3];
+    row = b->row[j & 3];
+  }
+  const SlotResult sr = upsert_resolve<G>(tv, b, id, valid, k, row, lane, a.ts);
+  const uint32_t e = uint32_t(j) * VEC;
+  if (sr.deferred) {
+    if (e < tv.dim) g.store(grad_u + int64_t(u) * tv.dim + e);
+    if (j == 0) pending[atomicAdd(&tv.ctr->n_pending, 1u)] = u;
+  } else if (valid) {
+    optimize_row_reg<VEC>(tv, row_ptr(tv, sr.r), sr.is_new, e, g, a);
+  }
+}
+
+template <int G, int VEC>
+__global__ __launch_bounds__(256) void sum_apply_kernel(
+    TableView tv, const int64_t* __restrict__ uids, const uint32_t* __restrict__ n_unique,
+    int64_t n_max, const float* __restrict__ grads, const uint32_t* __restrict__ lst_start,
+    const uint32_t* __restrict__ lst_end, const uint32_t* __restrict__ seg_pos,
+    const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work,
+    uint32_t nblk_b, uint32_t light_max, float* part, uint32_t* arrive,
+    float* __restrict__ grad_u, ApplyArgs a, uint32_t* __restrict__ pending) {
+  constexpr int WIN = G < 16 ? G : 16;
+  constexpr int NG = 256 / G;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (G - 1);
+  const int gbase = lane & ~(G - 1);
+  const uint32_t dim = tv.dim;
+  const uint32_t e = uint32_t(j) * VEC;
+  const bool ev = e < dim;
+
+  if (blockIdx.x >= nblk_b) {
+    // ------------------------------------------------------------------ id-major part
+    const int64_t g = (int64_t(blockIdx.x - nblk_b) * 256 + threadIdx.x) / G;
+    const int64_t nu = min(n_max, int64_t(*n_unique));
+    bool valid = g < nu;
+    const int64_t id = valid ? uids[g] : 0;
+    __shared__ uint32_t sh_sorted[NG][kLightMax];
+    const int grp = threadIdx.x / G;
+    const uint32_t q0 = valid ? lst_start[g] : 0u;
+    const uint32_t q1 = valid ? lst_end[g] : 0u;
+    if (q1 - q0 > light_max) valid = false;  // heavy list: the window blocks own it
+    const uint32_t len = valid ? q1 - q0 : 0u;
+    // lists of <= kLightMax positions may arrive unordered (mhte_unique_unordered): rank them in
+    // registers (positions are distinct, so the ranks are a permutation) and read them back in
+    // position order from LDS.  Longer lists are always stored ordered (dd_finish).
+    const bool small = len <= uint32_t(kLightMax);
+    constexpr int PER = (kLightMax + G - 1) / G;
+    uint32_t x[PER], xr[PER];
+#pragma unroll
+    for (int c = 0; c < PER; ++c) {
+      const uint32_t idx = uint32_t(j) + uint32_t(c) * G;
+      x[c] = (small && idx < len) ? seg_pos[q0 + idx] : 0xffffffffu;
+      xr[c] = 0;
+    }
+    const uint64_t hv = hash_key(id);
+    const uint64_t i1 = index_hash(tv.hp, hv);
+    const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
+    Bucket* b = tv.buckets + ((j < 4) ? i1 : i2);
+    int64_t k = kEmptyKey;
+    uint32_t row = kNoRow;
+    if (valid && id != kEmptyKey && j < 8) {  // probe loads go out first ...
+      k = b->key[j & 3];
+      row = b->row[j & 3];
+    }
+#pragma unroll
+    for (int t = 0; t < kLightMax; ++t) {
+      const uint32_t y = __shfl(x[t / G], gbase + (t % G));
+#pragma unroll
+      for (int c = 0; c < PER; ++c) xr[c] += (y < x[c]) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < PER; ++c)
+      if (x[c] != 0xffffffffu) sh_sorted[grp][xr[c]] = x[c];
+    __syncthreads();
+    Vec<VEC> acc;  // ... and the gradient chain seg_pos -> grads overlaps them
+    vec_zero(acc);
+    if (valid) {
+      for (uint32_t q = q0; q < q1; q += 8) {
+        uint32_t pos[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          pos[t] = (q + t < q1) ? (small ? sh_sorted[grp][q - q0 + t] : seg_pos[q + t]) : 0u;
+        Vec<VEC> v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (q + t < q1 && ev) v[t].load(grads + int64_t(pos[t]) * dim + e);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (q + t < q1 && ev) vec_add(acc, v[t]);
+      }
+    }
+    const SlotResult sr = upsert_resolve<G>(tv, b, id, valid, k, row, lane, a.ts);
+    if (sr.deferred) {
+      if (ev) acc.store(grad_u + g * int64_t(dim) + e);
+      if (j == 0) pending[atomicAdd(&tv.ctr->n_pending, 1u)] = uint32_t(g);
+    } else if (valid) {
+      optimize_row_reg<VEC>(tv, row_ptr(tv, sr.r), sr.is_new, e, acc, a);
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- chunk blocks
+  // Block b takes work item b of the list dd_finish built: chunk k (kChunk entries) of heavy list u.
+  // Chunks are cut relative to the list's own start, so the association of the sum is a function
+  // of the list alone, wherever the dedup happened to place it.
+  __shared__ float sh_sum[NG][G * VEC];
+  __shared__ uint32_t sh_last;
+  if (blockIdx.x >= *n_work) return;
+  const int wl = threadIdx.x / G;
+  const uint32_t u = work[2 * blockIdx.x], kc = work[2 * blockIdx.x + 1];
+  const uint32_t st = lst_start[u], en = lst_end[u];
+  const uint32_t c0 = st + kc * kChunk, c1 = min(en, c0 + kChunk);
+  const uint32_t nchunk = (en - st + kChunk - 1) / kChunk;
+  Vec<VEC> acc;
+  vec_zero(acc);
+#pragma unroll 1
+  for (uint32_t qb = c0 + wl * WIN; qb < c1; qb += NG * WIN) {  // this group's windows, in order
+    const uint32_t p = (j < WIN && qb + j < c1) ? seg_pos[qb + j] : kNone;
+    uint32_t pt[WIN];
+#pragma unroll
+    for (int t = 0; t < WIN; ++t) pt[t] = __shfl(p, gbase + t);
+    Vec<VEC> v[WIN];
+#pragma unroll
+    for (int t = 0; t < WIN; ++t)
+      if (pt[t] != kNone && ev) v[t].load(grads + int64_t(pt[t]) * dim + e);
+#pragma unroll
+    for (int t = 0; t < WIN; ++t)
+      if (pt[t] != kNone && ev) vec_add(acc, v[t]);
+  }
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) sh_sum[wl][j * VEC + c] = acc.v[c];
+  __syncthreads();
+  // groups in order -> the chunk's sum (wave 0 holds it; group 0 uses it)
+  Vec<VEC> tot;
+  vec_zero(tot);
+  if (threadIdx.x < 64) {
+#pragma unroll 1
+    for (int g2 = 0; g2 < NG; ++g2) {
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) tot.v[c] = tot.v[c] + sh_sum[g2][j * VEC + c];
+    }
+  }
+  if (nchunk == 1) {  // the whole list: apply on the spot
+    if (threadIdx.x < 64)
+      upsert_reg<G, VEC>(tv, uids, u, threadIdx.x < G, tot, lane, a, grad_u, pending);
+    return;
+  }
+  // one partial row per chunk, stored where the work items of the list sit (they are consecutive)
+  const uint32_t b0 = blockIdx.x - kc;
+  if (threadIdx.x < G && ev) store_wt<VEC>(part + int64_t(blockIdx.x) * dim + e, tot);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave drains its partial row
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t last = (atomicAdd(&arrive[u], 1u) == nchunk - 1) ? 1u : 0u;
+    if (last) arrive[u] = 0;  // clean-after-use
+    sh_last = last;
+  }
+  __syncthreads();
+  if (!sh_last) return;  // block-uniform
+  // last arriver: add the chunk sums in chunk order (fixed association), then apply
+  const uint32_t per = (nchunk + NG - 1) / NG;
+  const uint32_t k0 = min(nchunk, uint32_t(wl) * per), k1 = min(nchunk, k0 + per);
+  Vec<VEC> sacc;
+  vec_zero(sacc);
+  for (uint32_t kk = k0; kk < k1; kk += 8) {
+    Vec<VEC> r[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      if (kk + t < k1 && ev) load_agent<VEC>(part + int64_t(b0 + kk + t) * dim + e, r[t]);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      if (kk + t < k1 && ev) vec_add(sacc, r[t]);
+  }
+  __syncthreads();  // sh_sum is reused
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) sh_sum[wl][j * VEC + c] = sacc.v[c];
+  __syncthreads();
+  if (threadIdx.x < 64) {  // wave 0; group 0 applies
+    Vec<VEC> fin;
+    vec_zero(fin);
+    for (int g2 = 0; g2 < NG && uint32_t(g2) * per < nchunk; ++g2) {
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) fin.v[c] = fin.v[c] + sh_sum[g2][j * VEC + c];
+    }
+    upsert_reg<G, VEC>(tv, uids, u, threadIdx.x < G, fin, lane, a, grad_u, pending);
   }
 }
 

@@ -27,6 +27,8 @@ class UniqueResult(NamedTuple):
   seg_pos: torch.Tensor       # int32 [n]   positions, grouped by unique id, occurrence order
   n_unique_dev: torch.Tensor  # int32 [1]
   n_unique: Optional[int]     # host copy when requested
+  list_end: Optional[torch.Tensor] = None  # int32 [n]: set by unique_unordered, where seg_off holds
+                                           # the list STARTS and the lists are not in CSR order
 
 
 class DedupWorkspace:
@@ -73,6 +75,31 @@ class DedupWorkspace:
                                 _stream()))
     return UniqueResult(uids, inverse, seg_off, seg_pos, nu,
                         int(host.value) if want_host_count else None)
+
+  def unique_unordered(self, ids: torch.Tensor, want_host_count: bool = False,
+                       out: Optional[UniqueResult] = None) -> UniqueResult:
+    """Same key set and occurrence lists as ``unique`` with an unspecified numbering of the unique
+    ids (mhte_unique_unordered, 3 launches instead of 5) — what the fused step needs.  In the
+    result ``seg_off[u]`` / ``list_end[u]`` bound the positions of unique id u inside seg_pos."""
+    assert ids.is_cuda and ids.dtype == torch.int64 and ids.is_contiguous()
+    n = ids.numel()
+    dev = ids.device
+    if out is None or out.list_end is None:
+      uids = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+      inverse = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+      lst_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+      lst_end = torch.empty(n + 1, dtype=torch.int32, device=dev)
+      seg_pos = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+      nu = torch.zeros(1, dtype=torch.int32, device=dev)
+    else:
+      uids, inverse, lst_start, seg_pos, nu = out[:5]
+      lst_end = out.list_end
+    host = C.c_int64(0)
+    check(self._lib.mhte_unique_unordered(self._h, vp(ids), C.c_int64(n), vp(uids), vp(inverse),
+                                          vp(lst_start), vp(lst_end), vp(seg_pos), vp(nu),
+                                          C.byref(host) if want_host_count else None, _stream()))
+    return UniqueResult(uids, inverse, lst_start, seg_pos, nu,
+                        int(host.value) if want_host_count else None, lst_end)
 
   def gather_rows(self, src: torch.Tensor, index: torch.Tensor, n: int, dim: int,
                   out: Optional[torch.Tensor] = None) -> torch.Tensor:

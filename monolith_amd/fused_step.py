@@ -6,11 +6,16 @@ stage on the GPU and no host round trip inside the step:
    lookup of the unique ids                       MonolithMultiHashTableLookup
    scatter of unique rows to every occurrence     MonolithFillWithOffsetMap
    ... dense forward / backward (the caller's) ...
-   duplicate-gradient sum (occurrence order)      MonolithFillWithOffsetMapGradient
-   optimizer apply on the unique ids              MonolithMultiHashTableOptimize
+   duplicate-gradient sum (occurrence order)      MonolithFillWithOffsetMapGradient   } one fused
+   optimizer apply on the unique ids              MonolithMultiHashTableOptimize      } launch
 
 The unique-id count stays in device memory; kernels are launched for the batch-size upper bound
-and mask themselves."""
+and mask themselves.
+
+Pipelining.  The dedup depends on the ids only, not on the table, so — like the reference's
+prefetch queue in front of the lookup (distributed_ps_sync.py:199-203) — the dedup of batch s+1 may
+run on a side HIP stream while batch s is looked up and updated: ``forward(ids, next_ids=...)``.
+Two dedup workspaces / result buffers alternate so the two batches never share scratch."""
 from typing import Optional
 
 import numpy as np
@@ -24,24 +29,41 @@ from monolith_amd.multi_hash_table_ops import MultiHashTable
 class SparseStep:
 
   def __init__(self, table: MultiHashTable, table_name: str, batch: int,
-               exact_order: bool = False, direct: bool = True):
+               exact_order: bool = False, direct: bool = True, fused_backward: bool = True,
+               ordered_unique: bool = False):
     self.direct = direct
-    self._joined = True
+    self.fused_backward = fused_backward
+    # the reference's first-occurrence numbering of the unique ids is only needed by the unfused
+    # three-op forward (its gather indexes rows by that numbering) and by wide rows
+    self.ordered_unique = ordered_unique or not (direct and fused_backward)
     self.table = table
     self.name = table_name
     self.idx = table._index(table_name)  # pylint: disable=protected-access
     self.dim = table.get_table_dim_sizes()[self.idx]
+    if not table._lib.mhte_table_fused_backward_ok(table.handle, self.idx):  # pylint: disable=protected-access
+      self.ordered_unique = True  # wide rows: segment sum + optimize on CSR lists
     self.batch = batch
     self.exact_order = exact_order
     dev = torch.device("cuda:%d" % table._device)  # pylint: disable=protected-access
-    self.ws = DedupWorkspace(dev.index)
     self.side = torch.cuda.Stream(device=dev)
     n = batch
-    self.u = UniqueResult(torch.empty(n, dtype=torch.int64, device=dev),
+
+    def result():
+      return UniqueResult(torch.empty(n, dtype=torch.int64, device=dev),
                           torch.empty(n, dtype=torch.int32, device=dev),
                           torch.empty(n + 1, dtype=torch.int32, device=dev),
                           torch.empty(n, dtype=torch.int32, device=dev),
-                          torch.zeros(1, dtype=torch.int32, device=dev), None)
+                          torch.zeros(1, dtype=torch.int32, device=dev), None,
+                          None if self.ordered_unique else
+                          torch.empty(n + 1, dtype=torch.int32, device=dev))
+
+    # two slots: the batch being trained and the batch being deduplicated ahead of it
+    self._ws = [DedupWorkspace(dev.index), DedupWorkspace(dev.index)]
+    self._u = [result(), result()]
+    self._done = [None, None]   # event: slot's dedup finished (side stream)
+    self._key = [None, None]    # (data_ptr, numel) of the ids the slot holds
+    self._cur = 0
+    self._joined = True
     self.emb_u = torch.empty((n, self.dim), dtype=torch.float32, device=dev)
     self.emb = torch.empty((n, self.dim), dtype=torch.float32, device=dev)
     self.grad_u = torch.empty((n, self.dim), dtype=torch.float32, device=dev)
@@ -49,38 +71,91 @@ class SparseStep:
     self.lrs = np.ascontiguousarray(
         table.learning_rate[lr0:lr0 + table._slice_sizes[self.idx]])  # pylint: disable=protected-access
 
-  def forward(self, ids: torch.Tensor) -> torch.Tensor:
+  # the slot of the batch being trained
+  @property
+  def ws(self) -> DedupWorkspace:
+    return self._ws[self._cur]
+
+  @property
+  def u(self) -> UniqueResult:
+    return self._u[self._cur]
+
+  def _unique(self, ids, slot=None):
+    slot = self._cur if slot is None else slot
+    if self.ordered_unique:
+      self._ws[slot].unique(ids, want_host_count=False, out=self._u[slot])
+    else:
+      self._ws[slot].unique_unordered(ids, want_host_count=False, out=self._u[slot])
+
+  def _dedup_on_side(self, slot, ids, after: torch.cuda.Event):
+    self.side.wait_event(after)
+    with torch.cuda.stream(self.side):
+      self._unique(ids, slot)
+      ev = torch.cuda.Event()
+      ev.record(self.side)
+    self._done[slot] = ev
+    self._key[slot] = (ids.data_ptr(), ids.numel())
+
+  def forward(self, ids: torch.Tensor, next_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Rows for every occurrence.  ``direct`` (default): ONE probe+gather kernel over the B
     occurrences (duplicates of a Zipf head key are served from L2) — the same values as the
     reference's dedup -> lookup(unique) -> FillWithOffsetMap, without waiting for the dedup.
-    ``direct=False`` keeps the reference's three-op shape."""
+    ``direct=False`` keeps the reference's three-op shape.
+    ``next_ids``: the following batch; its dedup is started on the side stream now and picked up
+    by the next ``forward`` (which must receive that same tensor)."""
     assert ids.numel() == self.batch
-    if self.direct:
-      # the dedup chain (needed by backward only) runs on a side stream beside the lookup
-      main = torch.cuda.current_stream()
-      self.side.wait_stream(main)
-      with torch.cuda.stream(self.side):
-        self.ws.unique(ids, want_host_count=False, out=self.u)
-      self.table.table_lookup_n(self.idx, ids, None, self.emb, n_max=self.batch)
-      self._joined = False
-    else:
-      self.ws.unique(ids, want_host_count=False, out=self.u)
+    main = torch.cuda.current_stream()
+    if not self.direct:
+      self._cur = 0
+      self._unique(ids)
       self.table.table_lookup_n(self.idx, self.u.unique_ids, self.u.n_unique_dev, self.emb_u,
                                 n_max=self.batch)
       self.ws.gather_rows(self.emb_u, self.u.inverse, self.batch, self.dim, out=self.emb)
+      self._joined = True
+      return self.emb
+    # everything enqueued on `main` so far (the previous backward) precedes the dedups below
+    here = torch.cuda.Event()
+    here.record(main)
+    key = (ids.data_ptr(), ids.numel())
+    other = 1 - self._cur
+    if self._key[other] == key:
+      self._cur = other          # deduplicated ahead of time by the previous forward
+    else:
+      self._dedup_on_side(self._cur, ids, here)
+    self.table.table_lookup_n(self.idx, ids, None, self.emb, n_max=self.batch)
+    if next_ids is not None:
+      assert next_ids.numel() == self.batch
+      self._dedup_on_side(1 - self._cur, next_ids, here)
+    self._joined = False
     return self.emb
 
-  def backward(self, grads: torch.Tensor, update_time: int, global_step: int = 0):
+  def _join(self):
     if self.direct and not self._joined:
-      torch.cuda.current_stream().wait_stream(self.side)
+      if self._done[self._cur] is not None:
+        torch.cuda.current_stream().wait_event(self._done[self._cur])
       self._joined = True
-    self.ws.segment_sum(grads, self.u, self.dim, out=self.grad_u, exact_order=self.exact_order)
-    self.table.table_optimize_n(self.idx, self.u.unique_ids, self.u.n_unique_dev, self.grad_u,
-                                self.lrs, update_time, global_step, flags=_lib.MHTE_IDS_UNIQUE,
-                                n_max=self.batch)
+
+  def quiesce(self):
+    """Host-synchronise and forget the side-stream events (a prefetched dedup stays valid).  Call
+    before capturing the step into a hipGraph: a capture must not wait on events recorded outside
+    it, and events recorded inside one are meaningless afterwards."""
+    torch.cuda.synchronize()
+    self._done = [None, None]
+
+  def backward(self, grads: torch.Tensor, update_time: int, global_step: int = 0):
+    self._join()
+    if self.fused_backward:
+      # one launch: per-id gradient sum + upsert + optimizer (mhte_table_sum_optimize_n)
+      self.table.table_sum_optimize_n(self.idx, self.ws, self.u, grads, self.grad_u, self.lrs,
+                                      update_time, global_step, exact_order=self.exact_order,
+                                      n_max=self.batch)
+    else:
+      self.ws.segment_sum(grads, self.u, self.dim, out=self.grad_u, exact_order=self.exact_order)
+      self.table.table_optimize_n(self.idx, self.u.unique_ids, self.u.n_unique_dev, self.grad_u,
+                                  self.lrs, update_time, global_step, flags=_lib.MHTE_IDS_UNIQUE,
+                                  n_max=self.batch)
+    self._key[self._cur] = None  # the slot's lists are consumed
 
   def n_unique(self) -> int:
-    if self.direct and not self._joined:
-      torch.cuda.current_stream().wait_stream(self.side)
-      self._joined = True
+    self._join()
     return int(self.u.n_unique_dev.item())

@@ -382,3 +382,28 @@ class MultiHashTable:
                                           C.c_int64(int(update_time)), C.c_int64(int(global_step)),
                                           C.c_int32(flags), _stream()))
     return self
+
+  def table_sum_optimize_n(self, name_or_idx, ws, u, grads: torch.Tensor, grad_unique: torch.Tensor,
+                           lrs: np.ndarray, update_time: int, global_step: int = 0,
+                           exact_order: bool = False, n_max: Optional[int] = None,
+                           defer_slowpath: bool = False):
+    """Fused backward (mhte_table_sum_optimize_n): duplicate-gradient sum over the occurrence
+    lists of ``u`` (the UniqueResult of ``ws``'s most recent ``unique``) + optimizer apply on the
+    unique ids, one launch."""
+    i = name_or_idx if isinstance(name_or_idx, int) else self._index(name_or_idx)
+    lrs = np.ascontiguousarray(lrs, dtype=np.float32)
+    n = u.inverse.numel() if n_max is None else n_max
+    list_end = u.list_end if u.list_end is not None else u.seg_off[1:]
+    check(self._lib.mhte_table_sum_optimize_n(
+        self._h, C.c_int32(i), ws._h, vp(u.unique_ids), C.c_int64(n), vp(u.n_unique_dev),  # pylint: disable=protected-access
+        vp(grads), vp(u.inverse), vp(u.seg_off), vp(list_end), vp(u.seg_pos), C.c_int64(n),
+        vp(grad_unique),
+        _f32p(lrs), C.c_int64(lrs.size), C.c_int64(int(update_time)), C.c_int64(int(global_step)),
+        C.c_int32((_lib.MHTE_EXACT_ORDER if exact_order else 0) |
+                  (_lib.MHTE_DEFER_SLOWPATH if defer_slowpath else 0)), _stream()))
+    return self
+
+  def table_finish_pending(self, name_or_idx):
+    i = name_or_idx if isinstance(name_or_idx, int) else self._index(name_or_idx)
+    check(self._lib.mhte_table_finish_pending(self._h, C.c_int32(i), _stream()))
+    return self

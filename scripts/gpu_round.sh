@@ -24,8 +24,14 @@ prof)
   echo "prof rc=$?"; find /tmp/prof -type f | head -20
   for f in $(find /tmp/prof -name '*kernel_stats*.csv'); do cp $f $OUT/; done
   db=$(find /tmp/prof -name '*.db' | head -1)
-  if [ -n "$db" ]; then python scripts/rocpd_stats.py $db $OUT/kernel_stats.md | head -40; fi
+  if [ -n "$db" ]; then python scripts/rocpd_stats.py $db $OUT/kernel_stats.md --by-grid --timeline 40 | head -100; fi
   cat $OUT/prof_bench.json ;;
+tl)
+  # timeline of the overlapped step (graph replay is the last thing the process runs)
+  rm -rf /tmp/tl && timeout 600 rocprofv3 --kernel-trace -d /tmp/tl -o trace -- \
+    python bench.py --steps 20 --warmup 4 --no-cpu-baseline --resident-rows 16777216 --no-stage-timing > $OUT/tl_bench.json 2> $OUT/tl.err
+  db=$(find /tmp/tl -name '*.db' | head -1)
+  if [ -n "$db" ]; then python scripts/rocpd_stats.py $db $OUT/timeline.md --by-grid --timeline 24 | tail -30; fi ;;
 pmc)
   for c in "FETCH_SIZE" "WRITE_SIZE"; do
     rm -rf /tmp/pmc_$c && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o pmc -- \

@@ -262,6 +262,38 @@ def test_unique_matches_oracle_bit_exact(n, universe, dist):
   np.testing.assert_array_equal(uk[inv], ids)
 
 
+@pytest.mark.parametrize("n,universe,dist", [(1, 10, "uniform"), (257, 40, "uniform"),
+                                             (5000, 300, "zipf"), (65536, 10**9, "zipf"),
+                                             (300000, 10**5, "zipf")])
+def test_unique_unordered_same_sets_and_lists(n, universe, dist):
+  """mhte_unique_unordered: unspecified numbering, but the same key set, the same occurrence
+  list per key, lists > 32 positions in ascending order (including n > one bitmap chunk)."""
+  ids = S.id_batch(3, n, universe, dist)
+  if n > 100:
+    ids[5] = np.iinfo(np.int64).min  # the reserved key is a legal id
+    ids[77] = np.iinfo(np.int64).min
+  ws = D.DedupWorkspace()
+  for _ in range(2):  # second call runs on the cleaned-after-use scratch
+    r = ws.unique_unordered(ids_t(ids), want_host_count=True)
+    U = r.n_unique
+    uk = np.unique(ids)
+    assert U == uk.size
+    uids = r.unique_ids[:U].cpu().numpy()
+    np.testing.assert_array_equal(np.sort(uids), uk)
+    inv = r.inverse.cpu().numpy()
+    np.testing.assert_array_equal(uids[inv], ids)
+    st, en = r.seg_off[:U].cpu().numpy().astype(np.int64), r.list_end[:U].cpu().numpy().astype(np.int64)
+    pos = r.seg_pos.cpu().numpy()
+    order = np.argsort(st)
+    assert st[order][0] == 0 and en[order][-1] == n
+    np.testing.assert_array_equal(st[order][1:], en[order][:-1])  # the lists tile [0, n)
+    for u in list(range(min(U, 50))) + list(np.argsort(st - en)[:20]):
+      lst = pos[st[u]:en[u]]
+      np.testing.assert_array_equal(np.sort(lst), np.flatnonzero(ids == uids[u]))
+      if lst.size > 32:
+        assert np.all(np.diff(lst.astype(np.int64)) > 0)
+
+
 def test_unique_empty():
   ws = D.DedupWorkspace()
   r = ws.unique(torch.empty(0, dtype=torch.int64, device="cuda"))
@@ -461,6 +493,90 @@ def test_slow_path_displacement_at_high_load():
   _check_placement_valid(mt, "a", 12)
 
 
+# =============================================================================== fused backward
+def _oracle_step(ot, ids, g, dim, lr, t):
+  n = ids.size
+  uk, _, vo, vos, _ = O.unique_key_with_value_and_offset(ids, [0, n], [dim])
+  gu = O.fill_with_offset_map_gradient(np.arange(uk.size), [0, uk.size], g.ravel(), vo, vos,
+                                       [dim]).reshape(-1, dim)
+  ot.optimize(uk, gu, [lr], t)
+  return uk
+
+
+@pytest.mark.parametrize("dim,opt", [(4, "sgd"), (8, "adagrad"), (13, "adagrad"), (32, "sgd"),
+                                     (64, "adagrad"), (100, "adagrad"), (200, "sgd"),
+                                     (256, "adagrad"), (300, "adagrad")])
+@pytest.mark.parametrize("exact", [True, False])
+def test_fused_backward_matches_oracle(dim, opt, exact):
+  """mhte_table_sum_optimize_n (one launch: duplicate-gradient sum + upsert + optimizer) against
+  FillWithOffsetMapGradient + Optimize of the oracle, for every lanes-per-id shape (dim 4..256),
+  the wide-row fallback (dim 300), lists that cross window-block boundaries (Zipf head keys) and
+  ragged batch sizes."""
+  n = 30001
+  lr = 0.05
+  cfg = sgd_cfg(dim, lr) if opt == "sgd" else adagrad_cfg(dim, lr, 0.1)
+  mt = make({"emb": cfg})
+  step = SparseStep(mt, "emb", n, exact_order=exact)
+  ot = O.Table(O.segment(dim, O.OPT_SGD if opt == "sgd" else O.OPT_ADAGRAD, p=(0.1, 0.0)), 1)
+  seen = set()
+  for s_ in range(3):
+    ids = S.id_batch(100 + s_, n, 5 * 10**4, "zipf")
+    if s_ == 1:
+      ids[::3] = ids[0]        # one list with n/3 occurrences, interleaved with everything else
+    g = S.grad_batch(s_, n, dim)
+    step.forward(ids_t(ids))
+    step.backward(val_t(g), S.update_time(s_))
+    _oracle_step(ot, ids, g, dim, lr, S.update_time(s_))
+    seen.update(ids.tolist())
+  allids = np.fromiter(seen, dtype=np.int64)
+  got = mt.lookup({"emb": ids_t(allids)})["emb"].cpu().numpy()
+  exp = ot.lookup(allids)[0]
+  if exact:
+    np.testing.assert_array_equal(got, exp)
+  else:
+    np.testing.assert_allclose(got, exp, rtol=0, atol=TOL)
+  assert mt.size("emb") == len(seen) == ot.size()
+
+
+def test_fused_backward_equals_unfused_and_is_deterministic():
+  n, dim = 65536, 64
+  rows = []
+  for fused in (True, False, True):
+    mt = make({"emb": adagrad_cfg(dim, 0.01, 0.1)})
+    step = SparseStep(mt, "emb", n, fused_backward=fused)
+    for s_ in range(2):
+      ids = S.id_batch(7 + s_, n, 10**9, "zipf")
+      step.forward(ids_t(ids))
+      step.backward(val_t(S.grad_batch(s_, n, dim)), S.update_time(s_))
+    probe = np.unique(np.concatenate([S.id_batch(7 + s_, n, 10**9, "zipf") for s_ in range(2)]))
+    rows.append(mt.lookup({"emb": ids_t(probe)})["emb"].cpu().numpy())
+  np.testing.assert_array_equal(rows[0], rows[2])            # run-to-run identical
+  np.testing.assert_allclose(rows[0], rows[1], rtol=0, atol=TOL)
+
+
+def test_fused_backward_slow_path_at_high_load():
+  # full buckets -> deferred ids keep their summed gradient in grad_unique for slowpath_kernel
+  cap, dim, n = 1 << 13, 8, 3000
+  mt = make({"a": adagrad_cfg(dim, 0.1, 0.1, initial_capacity=cap, max_load_factor=0.97)})
+  ot = O.Table(O.segment(dim, O.OPT_ADAGRAD, p=(0.1, 0.0)), cap)
+  step = SparseStep(mt, "a", n)
+  rng = np.random.default_rng(11)
+  seen = set()
+  for s_ in range(3):
+    ids = rng.integers(1, 2**60, n)
+    ids[n // 2:] = ids[:n - n // 2]  # every id twice
+    g = S.grad_batch(s_, n, dim)
+    step.forward(ids_t(ids))
+    step.backward(val_t(g), S.update_time(s_))
+    _oracle_step(ot, ids, g, dim, 0.1, S.update_time(s_))
+    seen.update(ids.tolist())
+  st = mt.stats("a")
+  assert st.dropped == 0 and st.hashpower == 11 and st.size > 0.5 * cap
+  allids = np.fromiter(seen, dtype=np.int64)
+  np.testing.assert_array_equal(mt.lookup({"a": ids_t(allids)})["a"].cpu().numpy(),
+                                ot.lookup(allids)[0])
+
+
 # =============================================================================== full-size properties
 def test_full_batch_zipf_step_properties_d64_adagrad():
   """BASELINE.json configs[2] shape: dim 64, Adagrad, Zipf(1.2) over 1e9 ids, batch 65536."""
@@ -475,9 +591,7 @@ def test_full_batch_zipf_step_properties_d64_adagrad():
     emb = step.forward(ids_t(ids))
     # oracle: same step
     uk, _, vo, vos, _ = O.unique_key_with_value_and_offset(ids, [0, B], [D_])
-    emb_u, _ = ot.lookup(uk)
-    inv = step.u.inverse.cpu().numpy()
-    np.testing.assert_allclose(emb.cpu().numpy(), emb_u[inv], rtol=0, atol=TOL)
+    np.testing.assert_allclose(emb.cpu().numpy(), ot.lookup(ids)[0], rtol=0, atol=TOL)
     gu = O.fill_with_offset_map_gradient(np.arange(uk.size), [0, uk.size], g.ravel(), vo, vos,
                                          [D_]).reshape(-1, D_)
     ot.optimize(uk, gu, [0.001], S.update_time(s))
