@@ -265,6 +265,34 @@ mhte_status mhte_table_sum_optimize_n(mhte_multi_table* t, int32_t table, mhte_d
  * that time kernels, or that update several tables back to back, call it once at the end. */
 mhte_status mhte_table_finish_pending(mhte_multi_table* t, int32_t table, void* stream);
 
+/* Pipelined training step of one table: the dedup of the NEXT batch (which depends on its ids
+ * only — the reference prefetches it too, NT/distributed_ps_sync.py:199-203) is carried by the
+ * same three launches that look up and update the CURRENT batch, different workgroups doing the
+ * two jobs side by side on one queue:
+ *   mhte_table_step_forward   launch 1: lookup of id[n] -> embedding (as mhte_table_lookup_n)
+ *                                       + first third of mhte_unique_unordered(ws_next, id_next)
+ *   mhte_table_step_backward  launch 2: mhte_table_sum_optimize_n of the current batch (lists
+ *                                       from ws) + second third of the dedup
+ *                             launch 3: displacement pass + last third of the dedup
+ * After step_backward the *_next outputs are what mhte_unique_unordered would have produced and
+ * ws_next can be passed as `ws` of the following step.  ws and ws_next must be distinct; the
+ * table row must satisfy mhte_table_fused_backward_ok. */
+mhte_status mhte_table_step_forward(mhte_multi_table* t, int32_t table, const int64_t* id,
+                                    int64_t n, float* embedding, mhte_dedup_ws* ws_next,
+                                    const int64_t* id_next, int64_t n_next,
+                                    int64_t* unique_ids_next, uint32_t* inverse_next,
+                                    uint32_t* list_start_next, uint32_t* list_end_next,
+                                    uint32_t* seg_pos_next, uint32_t* n_unique_dev_next,
+                                    void* stream);
+mhte_status mhte_table_step_backward(mhte_multi_table* t, int32_t table, mhte_dedup_ws* ws,
+                                     mhte_dedup_ws* ws_next, const int64_t* unique_ids,
+                                     int64_t n_max, const uint32_t* n_unique_dev,
+                                     const float* grads, const uint32_t* list_start,
+                                     const uint32_t* list_end, const uint32_t* seg_pos, int64_t n,
+                                     float* grad_unique, const float* learning_rate,
+                                     int64_t n_learning_rate, int64_t update_time,
+                                     int64_t global_step, int32_t flags, void* stream);
+
 /* 1 when table i's row fits the single-launch backward (dim <= 256 floats, or <= 64 when segment
  * boundaries are not multiples of 4 floats); otherwise mhte_table_sum_optimize_n runs segment sum +
  * optimize and needs the ordered mhte_unique. */

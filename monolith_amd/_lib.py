@@ -99,6 +99,7 @@ EXPORTS = [
     "mhte_table_lookup_n", "mhte_table_optimize_n", "mhte_value_offsets",
     "mhte_fill_with_offset_map", "mhte_fill_with_offset_map_gradient", "mhte_table_set_count_hits",
     "mhte_table_sum_optimize_n", "mhte_unique_unordered", "mhte_table_fused_backward_ok", "mhte_table_finish_pending",
+    "mhte_table_step_forward", "mhte_table_step_backward",
 ]
 
 _lib = None

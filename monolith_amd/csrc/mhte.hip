@@ -160,6 +160,31 @@ struct DedupWs {
     }
   }
 
+  // --- pipelined step: the dedup of the next batch rides in the table kernels of the current one
+  bool pf_active = false;
+  NextBatch pf{};
+  NextBatch begin_prefetch(const int64_t* ids, int64_t n, int64_t* uids, uint32_t* inverse,
+                           uint32_t* lst_start, uint32_t* lst_end, uint32_t* seg_pos,
+                           uint32_t* n_unique_dev, hipStream_t st) {
+    if (n <= 0 || n > (int64_t(1) << 31) - 4096)
+      throw Error(MHTE_INVALID_ARGUMENT, "prefetch: n out of range");
+    NextBatch nb;
+    nb.d = view(n, st);
+    nb.ids = ids;
+    nb.n = uint32_t(n);
+    nb.nblk = (nb.n + kDdBlock - 1) / kDdBlock;
+    nb.uids = uids;
+    nb.inverse = inverse;
+    nb.lst_start = lst_start;
+    nb.lst_end = lst_end;
+    nb.seg_pos = seg_pos;
+    nb.n_unique = n_unique_dev;
+    pf = nb;
+    pf_active = true;
+    last_n = -1;  // lists are not valid until the step's third launch has run
+    return nb;
+  }
+
   // Unordered dedup (3 launches): unique ids in unspecified order, list bounds per unique index,
   // positions grouped by list (lists of > kLightMax positions ordered, shorter ones not).
   void unique_unordered(const int64_t* ids, int64_t n, int64_t* uids, uint32_t* inverse,
@@ -535,6 +560,82 @@ struct Table {
     pend_args = a;
     pend_vec = sh.VEC;
     if (!defer_slowpath) finish_pending(st);
+  }
+
+  // ---------------------------------------------------------------- pipelined step (3 launches)
+  void step_forward(const int64_t* ids, int64_t n, float* out, const NextBatch& nb,
+                    hipStream_t st) {
+    finish_pending(st);
+    if (n <= 0) throw Error(MHTE_INVALID_ARGUMENT, "step_forward: empty batch");
+    Shape sh = pick_shape(dim, vec_ok && aligned16(out));
+    const uint32_t nblk_l = uint32_t((n * sh.G + 1023) / 1024);
+    const dim3 grid(nb.nblk + nblk_l);
+#define CALL(G_, V_) \
+  step_k1_kernel<G_, V_><<<grid, 1024, 0, st>>>(nb, view, ids, n, out, count_hits ? 1 : 0)
+    DISPATCH_G_VEC(sh, CALL);
+#undef CALL
+    HIP_OK(hipGetLastError());
+  }
+
+  void step_backward(DedupWs& ws, DedupWs& ws_next, const int64_t* uids, int64_t n_max,
+                     const uint32_t* n_dev, const float* grads, const uint32_t* lst_start,
+                     const uint32_t* lst_end, const uint32_t* seg_pos, int64_t n, float* grad_u,
+                     const float* lrs, int64_t update_time, bool exact_order, hipStream_t st) {
+    finish_pending(st);
+    if (n <= 0 || n_max <= 0) throw Error(MHTE_INVALID_ARGUMENT, "step_backward: empty batch");
+    if (n != ws.last_n)
+      throw Error(MHTE_FAILED_PRECONDITION,
+                  "step_backward: workspace does not hold the occurrence lists of this batch");
+    if (!ws_next.pf_active)
+      throw Error(MHTE_FAILED_PRECONDITION, "step_backward: no dedup was started by step_forward");
+    ApplyArgs a;
+    for (int i = 0; i < kMaxSegments; ++i) a.lr[i] = (lrs && i < int(nseg)) ? lrs[i] : 0.f;
+    a.ts = static_cast<uint32_t>(update_time);
+    a.sum_dups = 1;
+    ensure_capacity(uint64_t(n_max), st);
+    Shape sh = pick_shape(dim, vec_ok && aligned16(grads) && aligned16(grad_u));
+    pending.reserve(size_t(n_max) + 1);
+    BackwardArgs b;
+    b.uids = uids;
+    b.n_unique = n_dev;
+    b.n_max = n_max;
+    b.grads = grads;
+    b.lst_start = lst_start;
+    b.lst_end = lst_end;
+    b.seg_pos = seg_pos;
+    b.work = ws.work.p;
+    b.n_work = ws.heavy_n.p + 3;
+    b.nblk_b = exact_order ? 0u : uint32_t(n / kChunk + n / (kLightMax + 1) + 1);
+    b.light_max = exact_order ? 0xffffffffu : uint32_t(kLightMax);
+    ws.backward_scratch(n, dim, b.nblk_b, st);
+    b.part = ws.part.p;
+    b.arrive = ws.arrive.p;
+    b.grad_u = grad_u;
+    b.pending = pending.p;
+    const NextBatch nb = ws_next.pf;
+    const uint32_t nblk_a = uint32_t((n_max * sh.G + 255) / 256);
+    const dim3 grid2(nb.nblk + b.nblk_b + nblk_a);
+#define CALL(G_, V_) step_k2_kernel<G_, V_><<<grid2, 256, 0, st>>>(nb, view, b, a)
+    DISPATCH_G_VEC(sh, CALL);
+#undef CALL
+    const uint32_t nb_rank = (nb.n + 1023) / 1024;
+    const uint32_t hgrid = std::min<uint32_t>(256, nb.n / (kLightMax + 1) + 1);
+    const uint32_t nfin = nb_rank + hgrid;
+    if (sh.VEC == 4) {
+      step_k3_kernel<4><<<nfin + 1, 1024, 0, st>>>(nb, nb_rank, nfin, view, uids, grad_u, a,
+                                                   pending.p);
+    } else {
+      step_k3_kernel<1><<<nfin + 1, 1024, 0, st>>>(nb, nb_rank, nfin, view, uids, grad_u, a,
+                                                   pending.p);
+    }
+    hipError_t le = hipGetLastError();
+    ws_next.pf_active = false;
+    if (le != hipSuccess) {
+      ws_next.clean_cap = 0;
+      HIP_OK(le);
+    }
+    ws_next.last_n = nb.n;
+    pend_valid = false;
   }
 
   // displacement pass for the ids the last fused backward could not place (both buckets full);
@@ -1180,6 +1281,54 @@ mhte_status mhte_table_sum_optimize_n(mhte_multi_table* t, int32_t table, mhte_d
     if (s2 != MHTE_OK) throw Error(s2, g_last_error);
     tb.upsert<kOpOptimize>(unique_ids, n_max, n_unique_dev, grad_unique, learning_rate, update_time,
                            MHTE_IDS_UNIQUE, nullptr, st);
+  });
+}
+
+mhte_status mhte_table_step_forward(mhte_multi_table* t, int32_t table, const int64_t* id,
+                                    int64_t n, float* embedding, mhte_dedup_ws* ws_next,
+                                    const int64_t* id_next, int64_t n_next,
+                                    int64_t* unique_ids_next, uint32_t* inverse_next,
+                                    uint32_t* list_start_next, uint32_t* list_end_next,
+                                    uint32_t* seg_pos_next, uint32_t* n_unique_dev_next,
+                                    void* stream) {
+  return guard([&] {
+    Table& tb = table_at(t, table);
+    if (!ws_next) throw Error(MHTE_INVALID_ARGUMENT, "null workspace");
+    HIP_OK(hipSetDevice(t->device));
+    std::lock_guard<std::mutex> g(tb.mu);
+    hipStream_t st = S(stream);
+    const NextBatch nb = ws_next->ws.begin_prefetch(id_next, n_next, unique_ids_next, inverse_next,
+                                                    list_start_next, list_end_next, seg_pos_next,
+                                                    n_unique_dev_next, st);
+    tb.step_forward(id, n, embedding, nb, st);
+  });
+}
+
+mhte_status mhte_table_step_backward(mhte_multi_table* t, int32_t table, mhte_dedup_ws* ws,
+                                     mhte_dedup_ws* ws_next, const int64_t* unique_ids,
+                                     int64_t n_max, const uint32_t* n_unique_dev,
+                                     const float* grads, const uint32_t* list_start,
+                                     const uint32_t* list_end, const uint32_t* seg_pos, int64_t n,
+                                     float* grad_unique, const float* learning_rate,
+                                     int64_t n_learning_rate, int64_t update_time,
+                                     int64_t global_step, int32_t flags, void* stream) {
+  (void)global_step;
+  return guard([&] {
+    Table& tb = table_at(t, table);
+    if (!ws || !ws_next || ws == ws_next)
+      throw Error(MHTE_INVALID_ARGUMENT, "step_backward needs two distinct workspaces");
+    if (!learning_rate || n_learning_rate < int64_t(tb.nseg))
+      throw Error(MHTE_INVALID_ARGUMENT, "The length of tensor `learning_rate` is too short.");
+    if (!n_unique_dev || !grad_unique)
+      throw Error(MHTE_INVALID_ARGUMENT, "step_backward: null argument");
+    if (!tb.fusable())
+      throw Error(MHTE_INVALID_ARGUMENT, "step_backward: row too wide for the fused backward");
+    HIP_OK(hipSetDevice(t->device));
+    std::lock_guard<std::mutex> g(tb.mu);
+    tb.note_update_time(update_time);
+    tb.step_backward(ws->ws, ws_next->ws, unique_ids, n_max, n_unique_dev, grads, list_start,
+                     list_end, seg_pos, n, grad_unique, learning_rate, update_time,
+                     (flags & MHTE_EXACT_ORDER) != 0, S(stream));
   });
 }
 

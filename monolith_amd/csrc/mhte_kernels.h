@@ -94,13 +94,13 @@ struct Vec<1> {
 // + 4*dim (row) + 4*dim (output).
 // =============================================================================================
 template <int G, int VEC>
-__global__ __launch_bounds__(256) void lookup_kernel(TableView tv, const int64_t* __restrict__ ids,
-                                                     int64_t n, const uint32_t* __restrict__ n_dev,
-                                                     float* __restrict__ out, int count_hits) {
+__device__ __forceinline__ void lookup_role(const TableView& tv, const int64_t* __restrict__ ids,
+                                            int64_t n, const uint32_t* __restrict__ n_dev,
+                                            float* __restrict__ out, int count_hits, uint32_t bid) {
   const int lane = threadIdx.x & 63;
   const int j = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
-  const int64_t g = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  const int64_t g = (int64_t(bid) * blockDim.x + threadIdx.x) / G;
   if (n_dev) n = min(n, int64_t(*n_dev));
   const bool valid = g < n;
   const int64_t id = valid ? ids[g] : 0;
@@ -143,6 +143,13 @@ __global__ __launch_bounds__(256) void lookup_kernel(TableView tv, const int64_t
     if (lane == 0 && hm) atomicAdd(&tv.ctr->hits, (unsigned long long)__popcll(hm));
   }
 }
+template <int G, int VEC>
+__global__ __launch_bounds__(256) void lookup_kernel(TableView tv, const int64_t* __restrict__ ids,
+                                                     int64_t n, const uint32_t* __restrict__ n_dev,
+                                                     float* __restrict__ out, int count_hits) {
+  lookup_role<G, VEC>(tv, ids, n, n_dev, out, count_hits, blockIdx.x);
+}
+
 
 // =============================================================================================
 // Row update shared by the fast path and the slow path.  The G lanes of a group own elements
@@ -395,13 +402,15 @@ __global__ __launch_bounds__(256) void upsert_kernel(TableView tv, const int64_t
 // construction: the host keeps the load factor <= max_load_factor (default 0.5), where both
 // 4-slot buckets of a fresh id are full with probability ~1e-4.
 // =============================================================================================
-template <int VEC, int OP>
-__global__ __launch_bounds__(64) void slowpath_kernel(TableView tv, const int64_t* __restrict__ ids,
-                                                      const float* __restrict__ values,
-                                                      const uint32_t* __restrict__ seg_off,
-                                                      const uint32_t* __restrict__ seg_pos,
-                                                      ApplyArgs a, int32_t* __restrict__ status,
-                                                      const uint32_t* __restrict__ pending) {
+// SOLO: the role is the whole (64-thread) workgroup; otherwise it is wave 0 of a larger one
+// and must not use workgroup barriers (lane 0 alone reads and writes q/path and the buckets).
+template <int VEC, int OP, bool SOLO>
+__device__ __forceinline__ void slowpath_role(const TableView& tv, const int64_t* __restrict__ ids,
+                                              const float* __restrict__ values,
+                                              const uint32_t* __restrict__ seg_off,
+                                              const uint32_t* __restrict__ seg_pos,
+                                              const ApplyArgs& a, int32_t* __restrict__ status,
+                                              const uint32_t* __restrict__ pending) {
   __shared__ BfsSlot q[kMaxCuckooCount];
   __shared__ CuckooRecord path[kMaxBfsPathLen];
   const int lane = threadIdx.x;
@@ -439,10 +448,20 @@ __global__ __launch_bounds__(64) void slowpath_kernel(TableView tv, const int64_
         }
       }
     }
-    __syncthreads();  // q is reused; also orders lane 0's bucket writes before the next search
+    if (SOLO) __syncthreads();  // (lane 0 alone touches q, path and the buckets)
   }
   if (lane == 0) tv.ctr->n_pending = 0;
 }
+template <int VEC, int OP>
+__global__ __launch_bounds__(64) void slowpath_kernel(TableView tv, const int64_t* __restrict__ ids,
+                                                      const float* __restrict__ values,
+                                                      const uint32_t* __restrict__ seg_off,
+                                                      const uint32_t* __restrict__ seg_pos,
+                                                      ApplyArgs a, int32_t* __restrict__ status,
+                                                      const uint32_t* __restrict__ pending) {
+  slowpath_role<VEC, OP, true>(tv, ids, values, seg_off, seg_pos, a, status, pending);
+}
+
 
 // =============================================================================================
 // Doubling (cuckoo_fast_double / move_bucket, cuckoohash_map.hpp:1768-1894): index_hash and
@@ -923,10 +942,9 @@ __device__ __forceinline__ uint32_t dd_global_slot_claim(const DedupView& d, int
   }
 }
 
-__global__ __launch_bounds__(kDdBlock) void dd_insert_fast_kernel(DedupView d,
-                                                                  const int64_t* __restrict__ ids,
-                                                                  uint32_t n,
-                                                                  int64_t* __restrict__ uids) {
+__device__ __forceinline__ void dd_insert_fast_role(const DedupView& d,
+                                                    const int64_t* __restrict__ ids, uint32_t n,
+                                                    int64_t* __restrict__ uids, uint32_t bid) {
   __shared__ unsigned long long lkey[kDdLds + 1];
   __shared__ uint32_t lmin[kDdLds + 1], lcnt[kDdLds + 1], lslot[kDdLds + 1];
   __shared__ uint32_t l_nclaim, l_base;
@@ -937,7 +955,7 @@ __global__ __launch_bounds__(kDdBlock) void dd_insert_fast_kernel(DedupView d,
   }
   if (threadIdx.x == 0) l_nclaim = 0;
   __syncthreads();
-  const uint32_t p = blockIdx.x * kDdBlock + threadIdx.x;
+  const uint32_t p = bid * kDdBlock + threadIdx.x;
   if (p == 0) {  // dd_place_fast / dd_finish (later kernels) refill these
     d.heavy_n[0] = 0;
     d.heavy_n[3] = 0;
@@ -984,85 +1002,128 @@ __global__ __launch_bounds__(kDdBlock) void dd_insert_fast_kernel(DedupView d,
   }
   if (valid) d.slot_of[p] = lslot[ls];
 }
+__global__ __launch_bounds__(kDdBlock) void dd_insert_fast_kernel(DedupView d,
+                                                                  const int64_t* __restrict__ ids,
+                                                                  uint32_t n,
+                                                                  int64_t* __restrict__ uids) {
+  dd_insert_fast_role(d, ids, n, uids, blockIdx.x);
+}
 
-__global__ __launch_bounds__(kDdBlock) void dd_place_fast_kernel(
-    DedupView d, uint32_t n, uint32_t* __restrict__ inverse, uint32_t* __restrict__ lst_start,
-    uint32_t* __restrict__ lst_end, uint32_t* __restrict__ seg_pos) {
+
+template <int BLOCK>  // threads per workgroup; every workgroup still covers kDdBlock positions
+__device__ __forceinline__ void dd_place_fast_role(
+    const DedupView& d, uint32_t n, uint32_t* __restrict__ inverse,
+    uint32_t* __restrict__ lst_start, uint32_t* __restrict__ lst_end,
+    uint32_t* __restrict__ seg_pos, uint32_t bid) {
+  constexpr int PPT = kDdBlock / BLOCK;  // positions per thread
   __shared__ uint32_t lkey[kDdLds], lcnt[kDdLds], lbase[kDdLds], lstart[kDdLds];
   __shared__ uint32_t l_total, l_gbase;
-  for (int i = threadIdx.x; i < kDdLds; i += kDdBlock) {
+  for (int i = threadIdx.x; i < kDdLds; i += BLOCK) {
     lkey[i] = 0xffffffffu;
     lcnt[i] = 0;
   }
   if (threadIdx.x == 0) l_total = 0;
   __syncthreads();
-  const uint32_t p = blockIdx.x * kDdBlock + threadIdx.x;
-  const bool valid = p < n;
-  uint32_t s = 0, ls = 0, rank = 0;
-  if (valid) {
-    s = d.slot_of[p];
-    ls = (s * 2654435761u >> 16) & (kDdLds - 1);
-    for (;;) {
-      uint32_t k = lkey[ls];
-      if (k == 0xffffffffu) {
-        k = atomicCAS(&lkey[ls], 0xffffffffu, s);
-        if (k == 0xffffffffu) break;
+  uint32_t p[PPT], s[PPT], ls[PPT], rank[PPT];
+  bool valid[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    p[k] = bid * kDdBlock + k * BLOCK + threadIdx.x;
+    valid[k] = p[k] < n;
+    s[k] = valid[k] ? d.slot_of[p[k]] : 0u;
+    ls[k] = 0;
+    rank[k] = 0;
+  }
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    if (valid[k]) {
+      uint32_t l = (s[k] * 2654435761u >> 16) & (kDdLds - 1);
+      for (;;) {
+        uint32_t kk = lkey[l];
+        if (kk == 0xffffffffu) {
+          kk = atomicCAS(&lkey[l], 0xffffffffu, s[k]);
+          if (kk == 0xffffffffu) break;
+        }
+        if (kk == s[k]) break;
+        l = (l + 1u) & (kDdLds - 1);
       }
-      if (k == s) break;
-      ls = (ls + 1u) & (kDdLds - 1);
+      ls[k] = l;
+      rank[k] = atomicAdd(&lcnt[l], 1u);
     }
-    rank = atomicAdd(&lcnt[ls], 1u);
   }
   __syncthreads();
   // ---- phase 1 (never waits): the first block to reach an id allocates its list
-  const bool rep = valid && rank == 0;
-  bool won = false;
-  uint32_t cnt = 0, loff = 0;
-  if (rep) {
-    won = atomicCAS(&d.hstart[s], kUnset, kBusy) == kUnset;
-    if (won) {
-      cnt = d.hcnt[s];
-      loff = atomicAdd(&l_total, cnt);
+  bool rep[PPT], won[PPT];
+  uint32_t cnt[PPT], loff[PPT], st[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    rep[k] = valid[k] && rank[k] == 0;
+    won[k] = false;
+    cnt[k] = 0;
+    loff[k] = 0;
+    st[k] = 0;
+    if (rep[k]) won[k] = atomicCAS(&d.hstart[s[k]], kUnset, kBusy) == kUnset;
+  }
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    if (won[k]) {
+      cnt[k] = d.hcnt[s[k]];
+      loff[k] = atomicAdd(&l_total, cnt[k]);
     }
   }
   __syncthreads();
   if (threadIdx.x == 0 && l_total) l_gbase = atomicAdd(&d.heavy_n[2], l_total);
   __syncthreads();
-  uint32_t st = 0;
-  if (won) {
-    st = l_gbase + loff;
-    const uint32_t u = d.huidx[s];
-    lst_start[u] = st;
-    lst_end[u] = st + cnt;
-    if (cnt > kLightMax) d.heavy[atomicAdd(&d.heavy_n[0], 1u)] = u;
-    __hip_atomic_store(&d.hstart[s], st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // ---- phase 2: everybody else waits for the publication (the allocator is already past its
-  // last barrier, so it cannot be waiting for anything in turn)
-  if (rep) {
-    if (!won) {
-      for (;;) {
-        st = __hip_atomic_load(&d.hstart[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (st < kBusy) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    if (won[k]) {
+      st[k] = l_gbase + loff[k];
+      const uint32_t u = d.huidx[s[k]];
+      lst_start[u] = st[k];
+      lst_end[u] = st[k] + cnt[k];
+      if (cnt[k] > kLightMax) d.heavy[atomicAdd(&d.heavy_n[0], 1u)] = u;
+      __hip_atomic_store(&d.hstart[s[k]], st[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    lstart[ls] = st;
-    lbase[ls] = atomicAdd(&d.hcur[s], lcnt[ls]);
+  }
+  // ---- phase 2: everybody else waits for the publication (every allocator of this workgroup is
+  // past its last barrier and has published, so a waiter can only depend on another workgroup's
+  // allocator, which in turn waits for nobody before publishing)
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    if (rep[k]) {
+      if (!won[k]) {
+        for (;;) {
+          st[k] = __hip_atomic_load(&d.hstart[s[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (st[k] < kBusy) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      lstart[ls[k]] = st[k];
+      lbase[ls[k]] = atomicAdd(&d.hcur[s[k]], lcnt[ls[k]]);
+    }
   }
   __syncthreads();
-  if (valid) {
-    const uint32_t u = d.huidx[s];
-    const uint32_t c = d.hcnt[s];
-    const uint32_t q = lstart[ls] + lbase[ls] + rank;
-    inverse[p] = u;
-    if (c > kLightMax) {
-      d.seg_tmp[q] = p;
-    } else {
-      seg_pos[q] = p;
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    if (valid[k]) {
+      const uint32_t u = d.huidx[s[k]];
+      const uint32_t c = d.hcnt[s[k]];
+      const uint32_t q = lstart[ls[k]] + lbase[ls[k]] + rank[k];
+      inverse[p[k]] = u;
+      if (c > kLightMax) {
+        d.seg_tmp[q] = p[k];
+      } else {
+        seg_pos[q] = p[k];
+      }
     }
   }
 }
+__global__ __launch_bounds__(kDdBlock) void dd_place_fast_kernel(
+    DedupView d, uint32_t n, uint32_t* __restrict__ inverse, uint32_t* __restrict__ lst_start,
+    uint32_t* __restrict__ lst_end, uint32_t* __restrict__ seg_pos) {
+  dd_place_fast_role<kDdBlock>(d, n, inverse, lst_start, lst_end, seg_pos, blockIdx.x);
+}
+
 
 // Final dedup kernel, two roles in one launch (1024-thread workgroups):
 //  * blocks [0, nb_rank): one thread per position p.  Lists of <= kLightMax occurrences are put in
@@ -1082,15 +1143,15 @@ constexpr uint32_t kBmBits = kBmWords * 32u;
 //   lst_start / lst_end: list bounds per unique index (ordered dedup: seg_off and seg_off + 1).
 //   order_light = 0 (unordered dedup): light lists are already in seg_pos, unordered; only the
 //   scratch reset remains for the per-position blocks, and block 0 publishes the unique count.
-__global__ __launch_bounds__(1024) void dd_finish_kernel(DedupView d, uint32_t n, uint32_t nb_rank,
-                                                         const uint32_t* __restrict__ inverse,
-                                                         const uint32_t* __restrict__ lst_start,
-                                                         const uint32_t* __restrict__ lst_end,
-                                                         uint32_t* __restrict__ seg_pos,
-                                                         int order_light,
-                                                         uint32_t* __restrict__ n_unique_out) {
-  if (blockIdx.x < nb_rank) {
-    const uint32_t p = blockIdx.x * 1024 + threadIdx.x;
+__device__ __forceinline__ void dd_finish_role(const DedupView& d, uint32_t n, uint32_t nb_rank,
+                                               const uint32_t* __restrict__ inverse,
+                                               const uint32_t* __restrict__ lst_start,
+                                               const uint32_t* __restrict__ lst_end,
+                                               uint32_t* __restrict__ seg_pos, int order_light,
+                                               uint32_t* __restrict__ n_unique_out, uint32_t bid,
+                                               uint32_t nblocks) {
+  if (bid < nb_rank) {
+    const uint32_t p = bid * 1024 + threadIdx.x;
     if (!order_light && p == 0) {
       *n_unique_out = d.heavy_n[1];
       d.heavy_n[1] = 0;
@@ -1125,7 +1186,7 @@ __global__ __launch_bounds__(1024) void dd_finish_kernel(DedupView d, uint32_t n
   __shared__ uint32_t wcnt[16];
   const uint32_t nh = *d.heavy_n;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (uint32_t h = blockIdx.x - nb_rank; h < nh; h += gridDim.x - nb_rank) {
+  for (uint32_t h = bid - nb_rank; h < nh; h += nblocks - nb_rank) {
     const uint32_t u = d.heavy[h];
     const uint32_t q0 = lst_start[u], len = lst_end[u] - q0;
     uint32_t* outp = seg_pos + q0;
@@ -1183,6 +1244,17 @@ __global__ __launch_bounds__(1024) void dd_finish_kernel(DedupView d, uint32_t n
     }
   }
 }
+__global__ __launch_bounds__(1024) void dd_finish_kernel(DedupView d, uint32_t n, uint32_t nb_rank,
+                                                         const uint32_t* __restrict__ inverse,
+                                                         const uint32_t* __restrict__ lst_start,
+                                                         const uint32_t* __restrict__ lst_end,
+                                                         uint32_t* __restrict__ seg_pos,
+                                                         int order_light,
+                                                         uint32_t* __restrict__ n_unique_out) {
+  dd_finish_role(d, n, nb_rank, inverse, lst_start, lst_end, seg_pos, order_light, n_unique_out,
+                 blockIdx.x, gridDim.x);
+}
+
 
 // =============================================================================================
 // Forward scatter of unique rows to every occurrence: out[p] = src[inverse[p]]
@@ -1501,16 +1573,17 @@ __device__ __forceinline__ void upsert_reg(const TableView& tv, const int64_t* _
   }
 }
 
-template <int G, int VEC>
-__global__ __launch_bounds__(256) void sum_apply_kernel(
-    TableView tv, const int64_t* __restrict__ uids, const uint32_t* __restrict__ n_unique,
+template <int G, int VEC, int BLOCK>
+__device__ __forceinline__ void sum_apply_role(
+    const TableView& tv, const int64_t* __restrict__ uids, const uint32_t* __restrict__ n_unique,
     int64_t n_max, const float* __restrict__ grads, const uint32_t* __restrict__ lst_start,
     const uint32_t* __restrict__ lst_end, const uint32_t* __restrict__ seg_pos,
     const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work,
     uint32_t nblk_b, uint32_t light_max, float* part, uint32_t* arrive,
-    float* __restrict__ grad_u, ApplyArgs a, uint32_t* __restrict__ pending) {
+    float* __restrict__ grad_u, const ApplyArgs& a, uint32_t* __restrict__ pending, uint32_t bid) {
   constexpr int WIN = G < 16 ? G : 16;
-  constexpr int NG = 256 / G;
+  constexpr int NG = 256 / G;    // groups of the chunk role (its first 256 threads)
+  constexpr int NGA = BLOCK / G;  // groups of the id-major role
   const int lane = threadIdx.x & 63;
   const int j = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
@@ -1518,13 +1591,13 @@ __global__ __launch_bounds__(256) void sum_apply_kernel(
   const uint32_t e = uint32_t(j) * VEC;
   const bool ev = e < dim;
 
-  if (blockIdx.x >= nblk_b) {
+  if (bid >= nblk_b) {
     // ------------------------------------------------------------------ id-major part
-    const int64_t g = (int64_t(blockIdx.x - nblk_b) * 256 + threadIdx.x) / G;
+    const int64_t g = (int64_t(bid - nblk_b) * BLOCK + threadIdx.x) / G;
     const int64_t nu = min(n_max, int64_t(*n_unique));
     bool valid = g < nu;
     const int64_t id = valid ? uids[g] : 0;
-    __shared__ uint32_t sh_sorted[NG][kLightMax];
+    __shared__ uint32_t sh_sorted[NGA][kLightMax];
     const int grp = threadIdx.x / G;
     const uint32_t q0 = valid ? lst_start[g] : 0u;
     const uint32_t q1 = valid ? lst_end[g] : 0u;
@@ -1595,16 +1668,17 @@ __global__ __launch_bounds__(256) void sum_apply_kernel(
   // of the list alone, wherever the dedup happened to place it.
   __shared__ float sh_sum[NG][G * VEC];
   __shared__ uint32_t sh_last;
-  if (blockIdx.x >= *n_work) return;
-  const int wl = threadIdx.x / G;
-  const uint32_t u = work[2 * blockIdx.x], kc = work[2 * blockIdx.x + 1];
+  if (bid >= *n_work) return;
+  const bool act = BLOCK == 256 || threadIdx.x < 256;  // wider workgroups: the rest only sync
+  const int wl = act ? threadIdx.x / G : 0;
+  const uint32_t u = work[2 * bid], kc = work[2 * bid + 1];
   const uint32_t st = lst_start[u], en = lst_end[u];
   const uint32_t c0 = st + kc * kChunk, c1 = min(en, c0 + kChunk);
   const uint32_t nchunk = (en - st + kChunk - 1) / kChunk;
   Vec<VEC> acc;
   vec_zero(acc);
 #pragma unroll 1
-  for (uint32_t qb = c0 + wl * WIN; qb < c1; qb += NG * WIN) {  // this group's windows, in order
+  for (uint32_t qb = act ? c0 + wl * WIN : c1; qb < c1; qb += NG * WIN) {  // this group's windows
     const uint32_t p = (j < WIN && qb + j < c1) ? seg_pos[qb + j] : kNone;
     uint32_t pt[WIN];
 #pragma unroll
@@ -1617,8 +1691,10 @@ __global__ __launch_bounds__(256) void sum_apply_kernel(
     for (int t = 0; t < WIN; ++t)
       if (pt[t] != kNone && ev) vec_add(acc, v[t]);
   }
+  if (act) {
 #pragma unroll
-  for (int c = 0; c < VEC; ++c) sh_sum[wl][j * VEC + c] = acc.v[c];
+    for (int c = 0; c < VEC; ++c) sh_sum[wl][j * VEC + c] = acc.v[c];
+  }
   __syncthreads();
   // groups in order -> the chunk's sum (wave 0 holds it; group 0 uses it)
   Vec<VEC> tot;
@@ -1636,8 +1712,8 @@ __global__ __launch_bounds__(256) void sum_apply_kernel(
     return;
   }
   // one partial row per chunk, stored where the work items of the list sit (they are consecutive)
-  const uint32_t b0 = blockIdx.x - kc;
-  if (threadIdx.x < G && ev) store_wt<VEC>(part + int64_t(blockIdx.x) * dim + e, tot);
+  const uint32_t b0 = bid - kc;
+  if (threadIdx.x < G && ev) store_wt<VEC>(part + int64_t(bid) * dim + e, tot);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave drains its partial row
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1649,7 +1725,7 @@ __global__ __launch_bounds__(256) void sum_apply_kernel(
   if (!sh_last) return;  // block-uniform
   // last arriver: add the chunk sums in chunk order (fixed association), then apply
   const uint32_t per = (nchunk + NG - 1) / NG;
-  const uint32_t k0 = min(nchunk, uint32_t(wl) * per), k1 = min(nchunk, k0 + per);
+  const uint32_t k0 = act ? min(nchunk, uint32_t(wl) * per) : nchunk, k1 = min(nchunk, k0 + per);
   Vec<VEC> sacc;
   vec_zero(sacc);
   for (uint32_t kk = k0; kk < k1; kk += 8) {
@@ -1662,8 +1738,10 @@ __global__ __launch_bounds__(256) void sum_apply_kernel(
       if (kk + t < k1 && ev) vec_add(sacc, r[t]);
   }
   __syncthreads();  // sh_sum is reused
+  if (act) {
 #pragma unroll
-  for (int c = 0; c < VEC; ++c) sh_sum[wl][j * VEC + c] = sacc.v[c];
+    for (int c = 0; c < VEC; ++c) sh_sum[wl][j * VEC + c] = sacc.v[c];
+  }
   __syncthreads();
   if (threadIdx.x < 64) {  // wave 0; group 0 applies
     Vec<VEC> fin;
@@ -1673,6 +1751,101 @@ __global__ __launch_bounds__(256) void sum_apply_kernel(
       for (int c = 0; c < VEC; ++c) fin.v[c] = fin.v[c] + sh_sum[g2][j * VEC + c];
     }
     upsert_reg<G, VEC>(tv, uids, u, threadIdx.x < G, fin, lane, a, grad_u, pending);
+  }
+}
+template <int G, int VEC>
+__global__ __launch_bounds__(256) void sum_apply_kernel(
+    TableView tv, const int64_t* __restrict__ uids, const uint32_t* __restrict__ n_unique,
+    int64_t n_max, const float* __restrict__ grads, const uint32_t* __restrict__ lst_start,
+    const uint32_t* __restrict__ lst_end, const uint32_t* __restrict__ seg_pos,
+    const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work,
+    uint32_t nblk_b, uint32_t light_max, float* part, uint32_t* arrive,
+    float* __restrict__ grad_u, ApplyArgs a, uint32_t* __restrict__ pending) {
+  sum_apply_role<G, VEC, 256>(tv, uids, n_unique, n_max, grads, lst_start, lst_end, seg_pos, work,
+                              n_work, nblk_b, light_max, part, arrive, grad_u, a, pending,
+                              blockIdx.x);
+}
+
+
+// =============================================================================================
+// Pipelined training step: three launches on ONE queue, each doing the table work of batch s and a
+// third of the dedup of batch s+1 side by side in different workgroups (the dedup depends on the
+// ids only).  Cross-queue dependencies cost ~10 us each on this part, same-queue kernel
+// boundaries next to nothing, so the two chains are zipped into one instead of being run on two
+// streams:
+//   step_k1  dd_insert_fast(s+1) | lookup(s)
+//   step_k2  dd_place_fast(s+1)  | sum_apply(s)
+//   step_k3  dd_finish(s+1)      | slowpath(s)
+// Dedup workgroups come first in the grid (few, latency-bound).  Launches 1 and 3 use 1024-thread
+// workgroups; launch 2 uses 256 (what sum_apply wants), its dedup role taking 4 positions per thread.
+// =============================================================================================
+struct NextBatch {  // dedup of the following batch (mhte_unique_unordered's arguments)
+  DedupView d;
+  const int64_t* ids;
+  uint32_t n;
+  uint32_t nblk;  // ceil(n / kDdBlock); 0 = no next batch
+  int64_t* uids;
+  uint32_t* inverse;
+  uint32_t* lst_start;
+  uint32_t* lst_end;
+  uint32_t* seg_pos;
+  uint32_t* n_unique;
+};
+
+template <int G, int VEC>
+__global__ __launch_bounds__(1024) void step_k1_kernel(NextBatch nb, TableView tv,
+                                                       const int64_t* __restrict__ ids, int64_t n,
+                                                       float* __restrict__ out, int count_hits) {
+  if (blockIdx.x < nb.nblk) {
+    dd_insert_fast_role(nb.d, nb.ids, nb.n, nb.uids, blockIdx.x);
+  } else {
+    lookup_role<G, VEC>(tv, ids, n, nullptr, out, count_hits, blockIdx.x - nb.nblk);
+  }
+}
+
+struct BackwardArgs {  // sum_apply_role's arguments
+  const int64_t* uids;
+  const uint32_t* n_unique;
+  int64_t n_max;
+  const float* grads;
+  const uint32_t* lst_start;
+  const uint32_t* lst_end;
+  const uint32_t* seg_pos;
+  const uint32_t* work;
+  const uint32_t* n_work;
+  uint32_t nblk_b;
+  uint32_t light_max;
+  float* part;
+  uint32_t* arrive;
+  float* grad_u;
+  uint32_t* pending;
+};
+
+template <int G, int VEC>
+__global__ __launch_bounds__(256) void step_k2_kernel(NextBatch nb, TableView tv, BackwardArgs b,
+                                                      ApplyArgs a) {
+  if (blockIdx.x < nb.nblk) {
+    dd_place_fast_role<256>(nb.d, nb.n, nb.inverse, nb.lst_start, nb.lst_end, nb.seg_pos,
+                            blockIdx.x);
+  } else {
+    sum_apply_role<G, VEC, 256>(tv, b.uids, b.n_unique, b.n_max, b.grads, b.lst_start, b.lst_end,
+                                 b.seg_pos, b.work, b.n_work, b.nblk_b, b.light_max, b.part,
+                                 b.arrive, b.grad_u, a, b.pending, blockIdx.x - nb.nblk);
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(1024) void step_k3_kernel(NextBatch nb, uint32_t nb_rank,
+                                                       uint32_t nfin, TableView tv,
+                                                       const int64_t* __restrict__ uids,
+                                                       const float* __restrict__ grad_u,
+                                                       ApplyArgs a,
+                                                       const uint32_t* __restrict__ pending) {
+  if (blockIdx.x < nfin) {
+    dd_finish_role(nb.d, nb.n, nb_rank, nb.inverse, nb.lst_start, nb.lst_end, nb.seg_pos, 0,
+                   nb.n_unique, blockIdx.x, nfin);
+  } else if (threadIdx.x < 64) {
+    slowpath_role<VEC, kOpOptimize, false>(tv, uids, grad_u, nullptr, nullptr, a, nullptr, pending);
   }
 }
 

@@ -13,9 +13,13 @@ The unique-id count stays in device memory; kernels are launched for the batch-s
 and mask themselves.
 
 Pipelining.  The dedup depends on the ids only, not on the table, so — like the reference's
-prefetch queue in front of the lookup (distributed_ps_sync.py:199-203) — the dedup of batch s+1 may
-run on a side HIP stream while batch s is looked up and updated: ``forward(ids, next_ids=...)``.
-Two dedup workspaces / result buffers alternate so the two batches never share scratch."""
+prefetch queue in front of the lookup (distributed_ps_sync.py:199-203) — the dedup of batch s+1 is
+done while batch s is looked up and updated: ``forward(ids, next_ids=...)``.  The two chains are
+zipped into the SAME three launches (mhte_table_step_forward / _backward: different workgroups of
+one kernel do the two jobs), because a dependency between two HIP queues costs ~10 us on this part
+and a kernel boundary on one queue next to nothing.  Two dedup workspaces / result buffers alternate
+so the two batches never share scratch.  Without ``next_ids`` the dedup of the current batch runs
+on a side stream beside the lookup."""
 from typing import Optional
 
 import numpy as np
@@ -60,8 +64,9 @@ class SparseStep:
     # two slots: the batch being trained and the batch being deduplicated ahead of it
     self._ws = [DedupWorkspace(dev.index), DedupWorkspace(dev.index)]
     self._u = [result(), result()]
-    self._done = [None, None]   # event: slot's dedup finished (side stream)
-    self._key = [None, None]    # (data_ptr, numel) of the ids the slot holds
+    self._done = None           # event: the side-stream dedup of the current batch finished
+    self._key = [None, None]    # (data_ptr, numel) of the ids whose lists the slot holds
+    self._pending_next = None   # dedup of the next batch started by step_forward
     self._cur = 0
     self._joined = True
     self.emb_u = torch.empty((n, self.dim), dtype=torch.float32, device=dev)
@@ -87,22 +92,13 @@ class SparseStep:
     else:
       self._ws[slot].unique_unordered(ids, want_host_count=False, out=self._u[slot])
 
-  def _dedup_on_side(self, slot, ids, after: torch.cuda.Event):
-    self.side.wait_event(after)
-    with torch.cuda.stream(self.side):
-      self._unique(ids, slot)
-      ev = torch.cuda.Event()
-      ev.record(self.side)
-    self._done[slot] = ev
-    self._key[slot] = (ids.data_ptr(), ids.numel())
-
   def forward(self, ids: torch.Tensor, next_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Rows for every occurrence.  ``direct`` (default): ONE probe+gather kernel over the B
     occurrences (duplicates of a Zipf head key are served from L2) — the same values as the
     reference's dedup -> lookup(unique) -> FillWithOffsetMap, without waiting for the dedup.
     ``direct=False`` keeps the reference's three-op shape.
-    ``next_ids``: the following batch; its dedup is started on the side stream now and picked up
-    by the next ``forward`` (which must receive that same tensor)."""
+    ``next_ids``: the following batch; its dedup is folded into this step's launches and picked
+    up by the next ``forward`` (which must receive that same tensor)."""
     assert ids.numel() == self.batch
     main = torch.cuda.current_stream()
     if not self.direct:
@@ -113,38 +109,51 @@ class SparseStep:
       self.ws.gather_rows(self.emb_u, self.u.inverse, self.batch, self.dim, out=self.emb)
       self._joined = True
       return self.emb
-    # everything enqueued on `main` so far (the previous backward) precedes the dedups below
-    here = torch.cuda.Event()
-    here.record(main)
     key = (ids.data_ptr(), ids.numel())
     other = 1 - self._cur
+    zipped = next_ids is not None and not self.ordered_unique and self.fused_backward
     if self._key[other] == key:
-      self._cur = other          # deduplicated ahead of time by the previous forward
+      self._cur = other          # deduplicated ahead of time by the previous step
+      self._joined = True
+    elif zipped:
+      self._unique(ids)          # first step of a pipeline: dedup in stream order
+      self._joined = True
     else:
-      self._dedup_on_side(self._cur, ids, here)
-    self.table.table_lookup_n(self.idx, ids, None, self.emb, n_max=self.batch)
-    if next_ids is not None:
+      # the dedup (needed by backward only) runs on the side stream beside the lookup
+      here = torch.cuda.Event()
+      here.record(main)
+      self.side.wait_event(here)
+      with torch.cuda.stream(self.side):
+        self._unique(ids)
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+      self._done = ev
+      self._joined = False
+    if zipped:
       assert next_ids.numel() == self.batch
-      self._dedup_on_side(1 - self._cur, next_ids, here)
-    self._joined = False
+      nxt = 1 - self._cur
+      self.table.table_step_forward(self.idx, ids, self.emb, self._ws[nxt], self._u[nxt], next_ids)
+      self._pending_next = (next_ids.data_ptr(), next_ids.numel())
+    else:
+      self.table.table_lookup_n(self.idx, ids, None, self.emb, n_max=self.batch)
+      self._pending_next = None
     return self.emb
 
   def _join(self):
-    if self.direct and not self._joined:
-      if self._done[self._cur] is not None:
-        torch.cuda.current_stream().wait_event(self._done[self._cur])
+    if not self._joined:
+      torch.cuda.current_stream().wait_event(self._done)
       self._joined = True
-
-  def quiesce(self):
-    """Host-synchronise and forget the side-stream events (a prefetched dedup stays valid).  Call
-    before capturing the step into a hipGraph: a capture must not wait on events recorded outside
-    it, and events recorded inside one are meaningless afterwards."""
-    torch.cuda.synchronize()
-    self._done = [None, None]
 
   def backward(self, grads: torch.Tensor, update_time: int, global_step: int = 0):
     self._join()
-    if self.fused_backward:
+    if self._pending_next is not None:
+      nxt = 1 - self._cur
+      self.table.table_step_backward(self.idx, self.ws, self._ws[nxt], self.u, grads, self.grad_u,
+                                     self.lrs, update_time, global_step,
+                                     exact_order=self.exact_order)
+      self._key[nxt] = self._pending_next
+      self._pending_next = None
+    elif self.fused_backward:
       # one launch: per-id gradient sum + upsert + optimizer (mhte_table_sum_optimize_n)
       self.table.table_sum_optimize_n(self.idx, self.ws, self.u, grads, self.grad_u, self.lrs,
                                       update_time, global_step, exact_order=self.exact_order,
@@ -155,6 +164,13 @@ class SparseStep:
                                   self.lrs, update_time, global_step, flags=_lib.MHTE_IDS_UNIQUE,
                                   n_max=self.batch)
     self._key[self._cur] = None  # the slot's lists are consumed
+
+  def quiesce(self):
+    """Host-synchronise and forget the side-stream event.  Call before capturing steps into a
+    hipGraph: a capture must not wait on events recorded outside it."""
+    torch.cuda.synchronize()
+    self._done = None
+    self._joined = True
 
   def n_unique(self) -> int:
     self._join()

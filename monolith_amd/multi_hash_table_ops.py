@@ -407,3 +407,28 @@ class MultiHashTable:
     i = name_or_idx if isinstance(name_or_idx, int) else self._index(name_or_idx)
     check(self._lib.mhte_table_finish_pending(self._h, C.c_int32(i), _stream()))
     return self
+
+  # pipelined step: the dedup of the next batch rides in the launches of the current one
+  def table_step_forward(self, name_or_idx, ids: torch.Tensor, out: torch.Tensor, ws_next, u_next,
+                         next_ids: torch.Tensor):
+    i = name_or_idx if isinstance(name_or_idx, int) else self._index(name_or_idx)
+    check(self._lib.mhte_table_step_forward(
+        self._h, C.c_int32(i), vp(ids), C.c_int64(ids.numel()), vp(out), ws_next._h,  # pylint: disable=protected-access
+        vp(next_ids), C.c_int64(next_ids.numel()), vp(u_next.unique_ids), vp(u_next.inverse),
+        vp(u_next.seg_off), vp(u_next.list_end), vp(u_next.seg_pos), vp(u_next.n_unique_dev),
+        _stream()))
+    return out
+
+  def table_step_backward(self, name_or_idx, ws, ws_next, u, grads: torch.Tensor,
+                          grad_unique: torch.Tensor, lrs: np.ndarray, update_time: int,
+                          global_step: int = 0, exact_order: bool = False):
+    i = name_or_idx if isinstance(name_or_idx, int) else self._index(name_or_idx)
+    lrs = np.ascontiguousarray(lrs, dtype=np.float32)
+    n = u.inverse.numel()
+    check(self._lib.mhte_table_step_backward(
+        self._h, C.c_int32(i), ws._h, ws_next._h, vp(u.unique_ids), C.c_int64(n),  # pylint: disable=protected-access
+        vp(u.n_unique_dev), vp(grads), vp(u.seg_off), vp(u.list_end), vp(u.seg_pos), C.c_int64(n),
+        vp(grad_unique), _f32p(lrs), C.c_int64(lrs.size), C.c_int64(int(update_time)),
+        C.c_int64(int(global_step)), C.c_int32(_lib.MHTE_EXACT_ORDER if exact_order else 0),
+        _stream()))
+    return self

@@ -554,6 +554,41 @@ def test_fused_backward_equals_unfused_and_is_deterministic():
   np.testing.assert_allclose(rows[0], rows[1], rtol=0, atol=TOL)
 
 
+def test_pipelined_step_matches_oracle_and_unpipelined():
+  """forward(ids, next_ids=...): the dedup of the next batch rides in the three launches of the
+  current one (mhte_table_step_forward / _backward).  Same rows as the step-by-step path, bit for
+  bit, and within 1e-5 of the oracle; exact order -> bit-exact with the oracle."""
+  n, dim, steps = 20000, 32, 5
+  batches = [S.id_batch(40 + s_, n, 10**5, "zipf") for s_ in range(steps + 1)]
+  batches[2][::2] = batches[2][1]  # a list of n/2 occurrences (39 chunks)
+  ids_dev = [ids_t(b) for b in batches]
+  probe = np.unique(np.concatenate(batches[:steps]))
+  out = {}
+  for mode in ("pipelined", "plain", "pipelined_exact"):
+    mt = make({"emb": adagrad_cfg(dim, 0.01, 0.1)})
+    step = SparseStep(mt, "emb", n, exact_order=(mode == "pipelined_exact"))
+    for s_ in range(steps):
+      nxt = ids_dev[s_ + 1] if mode != "plain" else None
+      emb = step.forward(ids_dev[s_], next_ids=nxt)
+      if s_ == 3:
+        first = emb.cpu().numpy().copy()
+      step.backward(val_t(S.grad_batch(s_, n, dim)), S.update_time(s_))
+      assert step.n_unique() == np.unique(batches[s_]).size
+    out[mode] = (mt.lookup({"emb": ids_t(probe)})["emb"].cpu().numpy(), first, mt.size("emb"))
+  ot = O.Table(O.segment(dim, O.OPT_ADAGRAD, p=(0.1, 0.0)), 1)
+  for s_ in range(steps):
+    if s_ == 3:
+      exp_first = ot.lookup(batches[3])[0]
+    _oracle_step(ot, batches[s_], S.grad_batch(s_, n, dim), dim, 0.01, S.update_time(s_))
+  exp = ot.lookup(probe)[0]
+  np.testing.assert_array_equal(out["pipelined"][0], out["plain"][0])
+  np.testing.assert_array_equal(out["pipelined"][1], out["plain"][1])
+  np.testing.assert_allclose(out["pipelined"][0], exp, rtol=0, atol=TOL)
+  np.testing.assert_array_equal(out["pipelined_exact"][0], exp)
+  np.testing.assert_array_equal(out["pipelined_exact"][1], exp_first)
+  assert out["pipelined"][2] == out["plain"][2] == ot.size() == probe.size
+
+
 def test_fused_backward_slow_path_at_high_load():
   # full buckets -> deferred ids keep their summed gradient in grad_unique for slowpath_kernel
   cap, dim, n = 1 << 13, 8, 3000
