@@ -63,6 +63,21 @@ def algorithmic_bytes(B, U, D, S):
   return lookup + update, per_kernel
 
 
+def pmc_traffic(kernel):
+  """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json,
+  written by scripts/pmc_traffic.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+  runs of this same command; corrections as MI355X_MICROARCH.md prescribes, see that file's
+  "method").  bench.py cannot collect counters itself; null when no summary is committed."""
+  path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+  try:
+    with open(path) as f:
+      d = json.load(f)
+    k = d["kernels"][kernel]
+    return int(k["hbm_bytes_per_launch"]), "profiles/pmc_traffic.json (%s)" % d.get("source", "")
+  except Exception:  # pylint: disable=broad-except
+    return None, None
+
+
 def main():
   args = parse()
   import torch
@@ -141,7 +156,14 @@ def main():
   st0 = mt.stats("emb")
 
   # ---- inputs resident in HBM before the timed region ----
-  n_batches = K + W + 1  # + the batch the last timed step deduplicates ahead (never trained)
+  # Every launch mode trains FRESH batches (a replay of batches the table has already seen would
+  # find every id resident and skip the insert path): eager [0, W+K), one priming batch, graph
+  # [G0, G0+W+K), then `reps` batches for the kernel-timing passes; +1 = the batch the last step
+  # deduplicates ahead (never trained).
+  reps = min(K, 100)
+  G0 = W + K + 1
+  P0 = G0 + W + K
+  n_batches = (P0 + 2 * reps + 2) if world == 1 else (K + W + 1)
   ids_host = np.stack([S.id_batch(s * world + rank, B, V, "zipf") for s in range(n_batches)])
   ids_all = torch.from_numpy(ids_host).to(dev)
   grad_pool = [torch.from_numpy(S.grad_batch(s, B, D)).to(dev) for s in range(8)]
@@ -181,17 +203,18 @@ def main():
     if args.launch in ("auto", "graph") and K % gc == 0 and W % gc == 0:
       try:
         step.quiesce()
-        # prime: leave batch 0 deduplicated ahead, as every chunk will find its first batch
-        step.forward(ids_all[W + K], next_ids=ids_all[0])
-        step.backward(grad_pool[0], S.update_time(0))
+        # prime: train batch W+K (so far only deduplicated ahead) and leave batch G0 deduplicated
+        # ahead, as every chunk will find its first batch
+        step.forward(ids_all[W + K], next_ids=ids_all[G0])
+        step.backward(grad_pool[0], S.update_time(W + K))
         graphs = []
-        for c0 in range(0, W + K, gc):
+        for c0 in range(G0, G0 + W + K, gc):
           g = torch.cuda.CUDAGraph()
           with torch.cuda.graph(g):
             run_eager(c0, c0 + gc)
           graphs.append(g)
         torch.cuda.synchronize()
-        # capture also executed nothing: replay from batch 0
+        # capture executed nothing: replay from batch G0
         for g in graphs[:W // gc]:
           g.replay()
         barrier()
@@ -227,45 +250,62 @@ def main():
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
 
-  # ---- per-kernel HIP-event timing on the launch stream (N=1) ----
+  # ---- per-kernel timing (N=1): HIP events stamped with each kernel's own begin/end on the launch
+  # stream (mhte_profile_arm -> hipExtLaunchKernelGGL), the interval rocprofv3 --kernel-trace
+  # reports.  Pass 1: the pipelined step as timed above (3 zipped launches per step).  Pass 2: the
+  # same work as separate launches, which attributes time to lookup / backward / dedup.
   roofline, stages, uniq_avg = None, {}, None
   if world == 1 and not args.no_stage_timing:
-    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
-    names = ["dedup(3 kernels)", "lookup_kernel", "sum_apply_kernel", "slowpath_kernel"]
-    acc = {n: 0.0 for n in names}
+    step.quiesce()
+    acc = {}
+
+    def collect():
+      torch.cuda.synchronize()
+      for name, us in _lib.profile_read():
+        a = acc.setdefault(name, [0, 0.0])
+        a[0] += 1
+        a[1] += us
+
+    _lib.profile_arm(3 * reps)
+    run_eager(P0, P0 + reps)
+    collect()
+    pipelined = {k: v[1] / v[0] for k, v in acc.items()}
+    acc = {}
     us = []
-    reps = min(K, 100)
-    for s in range(W, W + reps):
+    step.quiesce()
+    for s in range(P0 + reps + 1, P0 + 2 * reps + 1):
       ids = ids_all[s]
-      e = [ev() for _ in range(5)]
-      e[0].record()
+      _lib.profile_arm(8)
       step._unique(ids)  # pylint: disable=protected-access
-      e[1].record()
       mt.table_lookup_n(step.idx, ids, None, step.emb, n_max=B)
-      e[2].record()
       mt.table_sum_optimize_n(step.idx, step.ws, step.u, grad_pool[s % 8], step.grad_u, step.lrs,
                               S.update_time(s), 0, exact_order=args.exact_order, n_max=B,
                               defer_slowpath=True)
-      e[3].record()
       mt.table_finish_pending(step.idx)
-      e[4].record()
-      torch.cuda.synchronize()
-      for i, n in enumerate(names):
-        acc[n] += e[i].elapsed_time(e[i + 1]) * 1e3  # us
+      collect()
       us.append(step.n_unique())
     uniq_avg = float(np.mean(us))
     step_bytes, per_kernel = algorithmic_bytes(B, uniq_avg, D, S_state)
-    for n in names:
-      stages[n] = {"avg_us": round(acc[n] / reps, 2)}
-      if n in per_kernel:
-        stages[n]["alg_bytes"] = int(per_kernel[n])
-        stages[n]["GBps"] = round(per_kernel[n] / (acc[n] / reps) / 1e3, 1)
-    dom = max(per_kernel, key=lambda n: acc[n])
-    a_gbps = per_kernel[dom] / (acc[dom] / reps) / 1e3
+    alg = {"step_k1_kernel": per_kernel["lookup_kernel"], "step_k2_kernel": per_kernel["sum_apply_kernel"],
+           "lookup_kernel": per_kernel["lookup_kernel"], "sum_apply_kernel": per_kernel["sum_apply_kernel"]}
+    for name, avg in sorted(pipelined.items()):
+      stages[name] = {"avg_us": round(avg, 2), "launches_per_step": 1}
+    for name, (cnt, tot) in sorted(acc.items()):
+      stages["unzipped:" + name] = {"avg_us": round(tot / cnt, 2), "launches_per_step": cnt // reps}
+    for name, st_ in stages.items():
+      base = name.split(":")[-1]
+      if base in alg:
+        st_["alg_bytes"] = int(alg[base])
+        st_["GBps"] = round(alg[base] / st_["avg_us"] / 1e3, 1)
+    dom = max((k for k in pipelined if k in alg), key=lambda k: pipelined[k])
+    a_gbps = alg[dom] / pipelined[dom] / 1e3
+    traffic, traffic_src = pmc_traffic(dom)
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(a_gbps, 1), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(a_gbps / HBM_PEAK_GBPS, 4), "traffic": None,
-                "alg_bytes_per_launch": int(per_kernel[dom]),
-                "avg_launch_us": round(acc[dom] / reps, 2),
+                "unit": "GB/s", "frac": round(a_gbps / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
+                "alg_bytes_per_launch": int(alg[dom]),
+                "avg_launch_us": round(pipelined[dom], 2),
+                "timing": "hipExtLaunchKernelGGL start/stop events on the launch stream, %d launches" % reps,
                 "step_alg_bytes": int(step_bytes),
                 "step_GBps": round(step_bytes / (elapsed / K) / 1e9, 1),
                 "step_frac": round(step_bytes / (elapsed / K) / 1e9 / HBM_PEAK_GBPS, 4)}

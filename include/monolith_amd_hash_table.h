@@ -321,6 +321,18 @@ mhte_status mhte_fill_with_offset_map_gradient(const int64_t* pos, int64_t n, co
                                                int32_t offsets_vec4, float* backprop_grad,
                                                void* stream);
 
+/* ---- measurement aid (no reference counterpart) ---------------------------------------------
+ * Kernel-exact timing of the hot kernels for bench.py's `roofline`: after mhte_profile_arm(n) the
+ * next n launches of the step kernels made by the calling thread go through
+ * hipExtLaunchKernelGGL, whose start/stop HIP events carry the kernel's own begin/end timestamps
+ * on its queue (the interval rocprofv3 --kernel-trace reports).  mhte_profile_read disarms,
+ * waits for the recorded launches and returns per launch the kernel tag and the duration in
+ * microseconds.  Tags: 1 lookup_kernel, 2 sum_apply_kernel, 3 step_k1_kernel, 4 step_k2_kernel,
+ * 5 step_k3_kernel, 6 slowpath_kernel, 7 dd_* (unordered dedup), 8 upsert_kernel.
+ * Not for use inside a stream capture. */
+mhte_status mhte_profile_arm(int32_t n);
+mhte_status mhte_profile_read(int32_t cap, int32_t* kernel_tag, float* usec, int32_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

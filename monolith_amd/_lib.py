@@ -99,7 +99,7 @@ EXPORTS = [
     "mhte_table_lookup_n", "mhte_table_optimize_n", "mhte_value_offsets",
     "mhte_fill_with_offset_map", "mhte_fill_with_offset_map_gradient", "mhte_table_set_count_hits",
     "mhte_table_sum_optimize_n", "mhte_unique_unordered", "mhte_table_fused_backward_ok", "mhte_table_finish_pending",
-    "mhte_table_step_forward", "mhte_table_step_backward",
+    "mhte_table_step_forward", "mhte_table_step_backward", "mhte_profile_arm", "mhte_profile_read",
 ]
 
 _lib = None
@@ -163,3 +163,22 @@ def vp(x):
   if isinstance(x, int):
     return C.c_void_p(x)
   return C.c_void_p(x.data_ptr())
+
+
+PROFILE_TAGS = {1: "lookup_kernel", 2: "sum_apply_kernel", 3: "step_k1_kernel", 4: "step_k2_kernel",
+                5: "step_k3_kernel", 6: "slowpath_kernel", 7: "dd_kernels", 8: "upsert_kernel"}
+
+
+def profile_arm(n):
+  """Kernel-exact timing of the next ``n`` hot launches of this thread (mhte_profile_arm)."""
+  check(lib().mhte_profile_arm(C.c_int32(int(n))))
+
+
+def profile_read(cap=65536):
+  """-> [(kernel name, microseconds)] of the launches recorded since profile_arm; disarms."""
+  tags = (C.c_int32 * cap)()
+  us = (C.c_float * cap)()
+  n = C.c_int32(0)
+  check(lib().mhte_profile_read(C.c_int32(cap), tags, us, C.byref(n)))
+  m = min(cap, n.value)
+  return [(PROFILE_TAGS.get(tags[i], str(tags[i])), float(us[i])) for i in range(m)]

@@ -8,6 +8,7 @@
 //     (RT/ops/multi_hash_table_{lookup,update}_op.cc), argument checks and status mapping
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC mhte.hip
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -66,6 +67,40 @@ static inline uint32_t ceil_log2(uint64_t n) {
   while ((uint64_t(1) << l) < n) ++l;
   return l;
 }
+
+
+// ------------------------------------------------------------------------------------------ timing
+// Kernel-exact timing of the step kernels (mhte_profile_arm / mhte_profile_read): while armed, a
+// hot launch goes through hipExtLaunchKernelGGL, whose start/stop events are stamped with the
+// kernel's own begin and end on its queue — the same interval rocprofv3 --kernel-trace reports —
+// instead of events recorded around the launch, which also contain the dispatch gap.
+enum ProfTag : int32_t {
+  kTagLookup = 1, kTagSumApply = 2, kTagStepK1 = 3, kTagStepK2 = 4, kTagStepK3 = 5,
+  kTagSlowpath = 6, kTagDedup = 7, kTagUpsert = 8
+};
+struct Prof {
+  std::vector<hipEvent_t> ev;  // 2 per recorded launch
+  std::vector<int32_t> tag;
+  int32_t armed = 0;
+};
+static thread_local Prof g_prof;
+
+#define LAUNCH_HOT(TAG, KERNEL, GRID, BLOCK, ST, ...)                                          \
+  do {                                                                                         \
+    if (g_prof.armed > 0) {                                                                    \
+      hipEvent_t e0__, e1__;                                                                   \
+      HIP_OK(hipEventCreate(&e0__));                                                           \
+      HIP_OK(hipEventCreate(&e1__));                                                           \
+      hipExtLaunchKernelGGL((KERNEL), dim3(GRID), dim3(BLOCK), 0, (ST), e0__, e1__, 0,         \
+                            __VA_ARGS__);                                                      \
+      g_prof.ev.push_back(e0__);                                                               \
+      g_prof.ev.push_back(e1__);                                                               \
+      g_prof.tag.push_back(TAG);                                                               \
+      --g_prof.armed;                                                                          \
+    } else {                                                                                   \
+      (KERNEL)<<<dim3(GRID), dim3(BLOCK), 0, (ST)>>>(__VA_ARGS__);                             \
+    }                                                                                          \
+  } while (0)
 
 // ------------------------------------------------------------------------------------------ dedup ws
 struct DedupWs {
@@ -200,12 +235,13 @@ struct DedupWs {
     DedupView d = view(n, st);
     const uint32_t un = uint32_t(n);
     const uint32_t nb = (un + kDdBlock - 1) / kDdBlock;
-    dd_insert_fast_kernel<<<nb, kDdBlock, 0, st>>>(d, ids, un, uids);
-    dd_place_fast_kernel<<<nb, kDdBlock, 0, st>>>(d, un, inverse, lst_start, lst_end, seg_pos);
+    LAUNCH_HOT(kTagDedup, dd_insert_fast_kernel, nb, kDdBlock, st, d, ids, un, uids);
+    LAUNCH_HOT(kTagDedup, dd_place_fast_kernel, nb, kDdBlock, st, d, un, inverse, lst_start, lst_end,
+               seg_pos);
     const uint32_t nb_rank = (un + 1023) / 1024;
     const uint32_t hgrid = std::min<uint32_t>(256, un / (kLightMax + 1) + 1);
-    dd_finish_kernel<<<nb_rank + hgrid, 1024, 0, st>>>(d, un, nb_rank, inverse, lst_start, lst_end,
-                                                       seg_pos, 0, n_unique_dev);
+    LAUNCH_HOT(kTagDedup, dd_finish_kernel, nb_rank + hgrid, 1024, st, d, un, nb_rank, inverse,
+               lst_start, lst_end, seg_pos, 0, n_unique_dev);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
       clean_cap = 0;
@@ -458,7 +494,8 @@ struct Table {
     Shape sh = pick_shape(dim, vec_ok && aligned16(out));
     const int64_t threads = n * sh.G;
     const dim3 grid(uint32_t((threads + 255) / 256));
-#define CALL(G_, V_) lookup_kernel<G_, V_><<<grid, 256, 0, st>>>(view, ids, n, n_dev, out, count_hits ? 1 : 0)
+#define CALL(G_, V_) \
+  LAUNCH_HOT(kTagLookup, (lookup_kernel<G_, V_>), grid, 256, st, view, ids, n, n_dev, out, count_hits ? 1 : 0)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
     HIP_OK(hipGetLastError());
@@ -475,8 +512,8 @@ struct Table {
     const dim3 grid(uint32_t((threads + 255) / 256));
     uint32_t* pend = pending.p;
 #define CALL(G_, V_)                                                                         \
-  upsert_kernel<G_, V_, OP><<<grid, 256, 0, st>>>(view, ids, n, n_dev, values, seg_off, seg_pos, \
-                                                  a, status, pend)
+  LAUNCH_HOT(kTagUpsert, (upsert_kernel<G_, V_, OP>), grid, 256, st, view, ids, n, n_dev, values, \
+             seg_off, seg_pos, a, status, pend)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
     if (sh.VEC == 4) {
@@ -547,10 +584,9 @@ struct Table {
     const uint32_t light_max = exact_order ? 0xffffffffu : uint32_t(kLightMax);
     uint32_t* pend = pending.p;
 #define CALL(G_, V_)                                                                              \
-  sum_apply_kernel<G_, V_><<<dim3(nblk_a + nblk_b), 256, 0, st>>>(                                \
-      view, uids, n_dev, n_max, grads, lst_start, lst_end, seg_pos, ws.work.p,                    \
-      ws.heavy_n.p + 3, nblk_b,                                                                   \
-      light_max, ws.part.p, ws.arrive.p, grad_u, a, pend)
+  LAUNCH_HOT(kTagSumApply, (sum_apply_kernel<G_, V_>), nblk_a + nblk_b, 256, st,                  \
+             view, uids, n_dev, n_max, grads, lst_start, lst_end, seg_pos, ws.work.p,             \
+             ws.heavy_n.p + 3, nblk_b, light_max, ws.part.p, ws.arrive.p, grad_u, a, pend)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
     HIP_OK(hipGetLastError());
@@ -571,7 +607,7 @@ struct Table {
     const uint32_t nblk_l = uint32_t((n * sh.G + 1023) / 1024);
     const dim3 grid(nb.nblk + nblk_l);
 #define CALL(G_, V_) \
-  step_k1_kernel<G_, V_><<<grid, 1024, 0, st>>>(nb, view, ids, n, out, count_hits ? 1 : 0)
+  LAUNCH_HOT(kTagStepK1, (step_k1_kernel<G_, V_>), grid, 1024, st, nb, view, ids, n, out, count_hits ? 1 : 0)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
     HIP_OK(hipGetLastError());
@@ -615,18 +651,18 @@ struct Table {
     const NextBatch nb = ws_next.pf;
     const uint32_t nblk_a = uint32_t((n_max * sh.G + 255) / 256);
     const dim3 grid2(nb.nblk + b.nblk_b + nblk_a);
-#define CALL(G_, V_) step_k2_kernel<G_, V_><<<grid2, 256, 0, st>>>(nb, view, b, a)
+#define CALL(G_, V_) LAUNCH_HOT(kTagStepK2, (step_k2_kernel<G_, V_>), grid2, 256, st, nb, view, b, a)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
     const uint32_t nb_rank = (nb.n + 1023) / 1024;
     const uint32_t hgrid = std::min<uint32_t>(256, nb.n / (kLightMax + 1) + 1);
     const uint32_t nfin = nb_rank + hgrid;
     if (sh.VEC == 4) {
-      step_k3_kernel<4><<<nfin + 1, 1024, 0, st>>>(nb, nb_rank, nfin, view, uids, grad_u, a,
-                                                   pending.p);
+      LAUNCH_HOT(kTagStepK3, (step_k3_kernel<4>), nfin + 1, 1024, st, nb, nb_rank, nfin, view, uids,
+                 grad_u, a, pending.p);
     } else {
-      step_k3_kernel<1><<<nfin + 1, 1024, 0, st>>>(nb, nb_rank, nfin, view, uids, grad_u, a,
-                                                   pending.p);
+      LAUNCH_HOT(kTagStepK3, (step_k3_kernel<1>), nfin + 1, 1024, st, nb, nb_rank, nfin, view, uids,
+                 grad_u, a, pending.p);
     }
     hipError_t le = hipGetLastError();
     ws_next.pf_active = false;
@@ -649,11 +685,11 @@ struct Table {
     if (!pend_valid) return;
     pend_valid = false;
     if (pend_vec == 4) {
-      slowpath_kernel<4, kOpOptimize><<<1, 64, 0, st>>>(view, pend_uids, pend_grad, nullptr,
-                                                        nullptr, pend_args, nullptr, pending.p);
+      LAUNCH_HOT(kTagSlowpath, (slowpath_kernel<4, kOpOptimize>), 1, 64, st, view, pend_uids,
+                 pend_grad, nullptr, nullptr, pend_args, nullptr, pending.p);
     } else {
-      slowpath_kernel<1, kOpOptimize><<<1, 64, 0, st>>>(view, pend_uids, pend_grad, nullptr,
-                                                        nullptr, pend_args, nullptr, pending.p);
+      LAUNCH_HOT(kTagSlowpath, (slowpath_kernel<1, kOpOptimize>), 1, 64, st, view, pend_uids,
+                 pend_grad, nullptr, nullptr, pend_args, nullptr, pending.p);
     }
     HIP_OK(hipGetLastError());
   }
@@ -1408,6 +1444,32 @@ mhte_status mhte_table_set_count_hits(mhte_multi_table* t, int32_t table, int32_
     Table& tb = table_at(t, table);
     std::lock_guard<std::mutex> g(tb.mu);
     tb.count_hits = enable != 0;
+  });
+}
+
+mhte_status mhte_profile_arm(int32_t n) {
+  return guard([&] {
+    if (n < 0 || n > 65536) throw Error(MHTE_INVALID_ARGUMENT, "profile_arm: n out of range");
+    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.clear();
+    g_prof.tag.clear();
+    g_prof.armed = n;
+  });
+}
+
+mhte_status mhte_profile_read(int32_t cap, int32_t* kernel_tag, float* usec, int32_t* n_out) {
+  return guard([&] {
+    if (!n_out) throw Error(MHTE_INVALID_ARGUMENT, "profile_read: null n_out");
+    g_prof.armed = 0;
+    const int32_t n = int32_t(g_prof.tag.size());
+    *n_out = n;
+    for (int32_t i = 0; i < n && i < cap; ++i) {
+      HIP_OK(hipEventSynchronize(g_prof.ev[2 * i + 1]));
+      float ms = 0.f;
+      HIP_OK(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+      if (kernel_tag) kernel_tag[i] = g_prof.tag[i];
+      if (usec) usec[i] = ms * 1e3f;
+    }
   });
 }
 
