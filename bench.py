@@ -43,6 +43,8 @@ def parse():
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--cpu-steps", type=int, default=150)
   p.add_argument("--exact-order", action="store_true")
+  p.add_argument("--trace-out", default="",
+                 help="write a per-wavefront timeline (.npz) of three pipelined steps")
   p.add_argument("--no-stage-timing", action="store_true",
                  help="skip the per-kernel HIP-event pass (profiling the overlapped step only)")
   return p.parse_args()
@@ -157,13 +159,12 @@ def main():
 
   # ---- inputs resident in HBM before the timed region ----
   # Every launch mode trains FRESH batches (a replay of batches the table has already seen would
-  # find every id resident and skip the insert path): eager [0, W+K), one priming batch, graph
-  # [G0, G0+W+K), then `reps` batches for the kernel-timing passes; +1 = the batch the last step
-  # deduplicates ahead (never trained).
+  # find every id resident and skip the insert path).  The modes run back to back over one
+  # contiguous batch sequence: the last step of a mode deduplicates the first batch of the next
+  # mode ahead, exactly as it does inside a mode.
   reps = min(K, 100)
-  G0 = W + K + 1
-  P0 = G0 + W + K
-  n_batches = (P0 + 2 * reps + 2) if world == 1 else (K + W + 1)
+  K3, W3 = min(K, 100), min(W, 10)   # the round-1 three-launch step, timed for comparison
+  n_batches = (2 * (W + K) + W3 + K3 + 2 * reps + 8) if world == 1 else (K + W + 1)
   ids_host = np.stack([S.id_batch(s * world + rank, B, V, "zipf") for s in range(n_batches)])
   ids_all = torch.from_numpy(ids_host).to(dev)
   grad_pool = [torch.from_numpy(S.grad_batch(s, B, D)).to(dev) for s in range(8)]
@@ -175,44 +176,55 @@ def main():
       torch.cuda.synchronize()
 
   results = {}
+  steps_of = {}
   graph_err = None
   if world == 1:
     # Steady-state pipeline (fused_step.py): while batch s is looked up and updated, the dedup of
-    # batch s+1 — which depends on the ids only — runs on a side stream, as the reference's
+    # batch s+1 — which depends on the ids only — rides in the same launches, as the reference's
     # prefetch queue does.  Every timed step executes exactly one dedup, one lookup and one
     # update: the first timed batch was deduplicated by the last warm-up step, the last timed
-    # step deduplicates batch W+K.
-    step = SparseStep(mt, "emb", B, exact_order=args.exact_order)
+    # step deduplicates the batch after it.
+    step = SparseStep(mt, "emb", B, exact_order=args.exact_order, launches=2)
 
     def run_eager(lo, hi):
       for s in range(lo, hi):
         step.forward(ids_all[s], next_ids=ids_all[s + 1])
         step.backward(grad_pool[s % 8], S.update_time(s))
 
-    run_eager(0, W)
-    barrier()
-    t = time.perf_counter()
-    run_eager(W, W + K)
-    barrier()
-    results["eager"] = time.perf_counter() - t
+    def timed(name, c, w, k):
+      run_eager(c, c + w)
+      barrier()
+      t = time.perf_counter()
+      run_eager(c + w, c + w + k)
+      barrier()
+      results[name] = time.perf_counter() - t
+      steps_of[name] = k
+      return c + w + k
+
+    cur = timed("eager", 0, W, K)          # two launches per step
+    step.launches = 3
+    cur = timed("eager3", cur, W3, K3)     # three launches per step (round-1 form)
+    step.launches = 2
 
     # ---- hipGraph replay: the launch-bound loop captured in chunks of `gc` pipelined steps
-    # (3 launches per step on one queue).  Each chunk graph reads its batches straight from the
+    # (2 launches per step on one queue).  Each chunk graph reads its batches straight from the
     # resident id array, so nothing is copied or skipped inside the timed region.
     gc = 10
     if args.launch in ("auto", "graph") and K % gc == 0 and W % gc == 0:
       try:
+        # one eager step first: leaves batch cur+1 deduplicated ahead and a displacement pass
+        # outstanding, the state every chunk starts from
+        run_eager(cur, cur + 1)
+        cur += 1
         step.quiesce()
-        # prime: train batch W+K (so far only deduplicated ahead) and leave batch G0 deduplicated
-        # ahead, as every chunk will find its first batch
-        step.forward(ids_all[W + K], next_ids=ids_all[G0])
-        step.backward(grad_pool[0], S.update_time(W + K))
+        G0 = cur
         graphs = []
         for c0 in range(G0, G0 + W + K, gc):
           g = torch.cuda.CUDAGraph()
           with torch.cuda.graph(g):
             run_eager(c0, c0 + gc)
           graphs.append(g)
+        cur = G0 + W + K
         torch.cuda.synchronize()
         # capture executed nothing: replay from batch G0
         for g in graphs[:W // gc]:
@@ -223,10 +235,12 @@ def main():
           g.replay()
         barrier()
         results["graph"] = time.perf_counter() - t
+        steps_of["graph"] = K
       except Exception as e:  # pylint: disable=broad-except
         graph_err = repr(e)[:300]
         print("graph path failed: %s" % graph_err, file=sys.stderr)
         torch.cuda.synchronize()
+    P0 = cur
   else:
     from monolith_amd.distributed_ps_sync import HipBackend, ShardedEmbedding
     se = ShardedEmbedding(HipBackend(mt, "emb"))
@@ -242,8 +256,10 @@ def main():
     run_sharded(W, W + K)
     barrier()
     results["eager"] = time.perf_counter() - t
-  launch = min(results, key=results.get) if args.launch == "auto" else (
-      args.launch if args.launch in results else "eager")
+    steps_of["eager"] = K
+  full = {k: v for k, v in results.items() if steps_of[k] == K}   # modes timed over exactly K steps
+  launch = min(full, key=full.get) if args.launch == "auto" else (
+      args.launch if args.launch in full else "eager")
   elapsed = results[launch]
   if world > 1:
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -266,14 +282,27 @@ def main():
         a[0] += 1
         a[1] += us
 
-    _lib.profile_arm(3 * reps)
-    run_eager(P0, P0 + reps)
+    run_eager(P0, P0 + 1)   # (first step after a mode switch may use the plain forward launch)
+    step.quiesce()
+    _lib.profile_arm(2 * reps)
+    run_eager(P0 + 1, P0 + 1 + reps)
     collect()
     pipelined = {k: v[1] / v[0] for k, v in acc.items()}
+    pipelined_cnt = {k: v[0] for k, v in acc.items()}
+    if args.trace_out:   # per-wavefront timeline of three more pipelined steps
+      tcap = 1 << 20
+      tbuf = torch.zeros(3 * tcap, dtype=torch.int64, device=dev)
+      _lib.trace_begin(tbuf, tcap)
+      run_eager(P0 + 1 + reps, P0 + 4 + reps)
+      torch.cuda.synchronize()
+      tl = _lib.trace_end()
+      np.savez_compressed(args.trace_out, records=tbuf.cpu().numpy().reshape(-1, 3),
+                          launches=np.array([(t_[0], t_[1], t_[2], t_[3]) for t_ in tl], dtype=object),
+                          allow_pickle=True)
     acc = {}
     us = []
     step.quiesce()
-    for s in range(P0 + reps + 1, P0 + 2 * reps + 1):
+    for s in range(P0 + reps + 5, P0 + 2 * reps + 5):
       ids = ids_all[s]
       _lib.profile_arm(8)
       step._unique(ids)  # pylint: disable=protected-access
@@ -286,10 +315,12 @@ def main():
       us.append(step.n_unique())
     uniq_avg = float(np.mean(us))
     step_bytes, per_kernel = algorithmic_bytes(B, uniq_avg, D, S_state)
-    alg = {"step_k1_kernel": per_kernel["lookup_kernel"], "step_k2_kernel": per_kernel["sum_apply_kernel"],
+    alg = {"step_k1_kernel": per_kernel["lookup_kernel"], "step_ka_kernel": per_kernel["lookup_kernel"],
+           "step_k2_kernel": per_kernel["sum_apply_kernel"],
            "lookup_kernel": per_kernel["lookup_kernel"], "sum_apply_kernel": per_kernel["sum_apply_kernel"]}
     for name, avg in sorted(pipelined.items()):
-      stages[name] = {"avg_us": round(avg, 2), "launches_per_step": 1}
+      stages[name] = {"avg_us": round(avg, 2),
+                      "launches_per_step": round(pipelined_cnt[name] / reps, 2)}
     for name, (cnt, tot) in sorted(acc.items()):
       stages["unzipped:" + name] = {"avg_us": round(tot / cnt, 2), "launches_per_step": cnt // reps}
     for name, st_ in stages.items():
@@ -369,7 +400,7 @@ def main():
             "parallelism": "1 GPU" if world == 1 else "fid mod %d sharding, 4 all-to-all/step (RCCL)" % world,
             "prefill_s": round(prefill_s, 2),
         },
-        "timing_ms_per_step": {k: round(v / K * 1e3, 5) for k, v in results.items()},
+        "timing_ms_per_step": {k: round(v / steps_of[k] * 1e3, 5) for k, v in results.items()},
         "roofline": roofline,
         "stages": stages,
         "cpu_baseline": cpu,

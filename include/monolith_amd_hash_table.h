@@ -42,7 +42,7 @@ enum {
 
 const char* mhte_last_error(void);
 /* ABI version of this header; mhte_abi_version() must return the same value. */
-#define MHTE_ABI_VERSION 1
+#define MHTE_ABI_VERSION 2
 int32_t mhte_abi_version(void);
 
 /* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
@@ -267,19 +267,28 @@ mhte_status mhte_table_finish_pending(mhte_multi_table* t, int32_t table, void* 
 
 /* Pipelined training step of one table: the dedup of the NEXT batch (which depends on its ids
  * only — the reference prefetches it too, NT/distributed_ps_sync.py:199-203) is carried by the
- * same three launches that look up and update the CURRENT batch, different workgroups doing the
- * two jobs side by side on one queue:
- *   mhte_table_step_forward   launch 1: lookup of id[n] -> embedding (as mhte_table_lookup_n)
- *                                       + first third of mhte_unique_unordered(ws_next, id_next)
- *   mhte_table_step_backward  launch 2: mhte_table_sum_optimize_n of the current batch (lists
- *                                       from ws) + second third of the dedup
- *                             launch 3: displacement pass + last third of the dedup
- * After step_backward the *_next outputs are what mhte_unique_unordered would have produced and
- * ws_next can be passed as `ws` of the following step.  ws and ws_next must be distinct; the
- * table row must satisfy mhte_table_fused_backward_ok. */
+ * same launches that look up and update the CURRENT batch, different workgroups doing the jobs
+ * side by side on one queue.  Two launches per step:
+ *   mhte_table_step_forward   lookup of id[n] -> embedding (as mhte_table_lookup_n)
+ *                             + first third of mhte_unique_unordered(ws_next, id_next)
+ *                             + last third of the dedup of THIS batch, when ws_cur holds one the
+ *                               previous mhte_table_step_backward left unfinished
+ *                             + the displacement pass of the previous update (one wavefront; the
+ *                               lookup workgroups wait for it only when it has work)
+ *   mhte_table_step_backward  mhte_table_sum_optimize_n of the current batch (lists from ws)
+ *                             + second third of the dedup of the next batch
+ * so a batch's dedup spans one and a half steps and no launch exists for its sake alone.  After
+ * step_backward the *_next outputs are complete once the following step_forward (given ws_next as
+ * its ws_cur) has been enqueued; any other call that uses ws_next or the table enqueues the
+ * missing parts itself first.  With MHTE_STEP_FINISH_NOW step_backward adds a third launch that
+ * completes the dedup and runs the displacement pass at once (then the *_next outputs are what
+ * mhte_unique_unordered would have produced as soon as step_backward returns).
+ * ws_cur may be NULL (first step: the caller ran mhte_unique_unordered itself).  ws and ws_next
+ * must be distinct; the table row must satisfy mhte_table_fused_backward_ok. */
+enum { MHTE_STEP_FINISH_NOW = 4 }; /* with MHTE_EXACT_ORDER in step_backward's flags */
 mhte_status mhte_table_step_forward(mhte_multi_table* t, int32_t table, const int64_t* id,
-                                    int64_t n, float* embedding, mhte_dedup_ws* ws_next,
-                                    const int64_t* id_next, int64_t n_next,
+                                    int64_t n, float* embedding, mhte_dedup_ws* ws_cur,
+                                    mhte_dedup_ws* ws_next, const int64_t* id_next, int64_t n_next,
                                     int64_t* unique_ids_next, uint32_t* inverse_next,
                                     uint32_t* list_start_next, uint32_t* list_end_next,
                                     uint32_t* seg_pos_next, uint32_t* n_unique_dev_next,
@@ -328,10 +337,21 @@ mhte_status mhte_fill_with_offset_map_gradient(const int64_t* pos, int64_t n, co
  * on its queue (the interval rocprofv3 --kernel-trace reports).  mhte_profile_read disarms,
  * waits for the recorded launches and returns per launch the kernel tag and the duration in
  * microseconds.  Tags: 1 lookup_kernel, 2 sum_apply_kernel, 3 step_k1_kernel, 4 step_k2_kernel,
- * 5 step_k3_kernel, 6 slowpath_kernel, 7 dd_* (unordered dedup), 8 upsert_kernel.
- * Not for use inside a stream capture. */
+ * 5 step_k3_kernel, 6 slowpath_kernel, 7 dd_* (unordered dedup), 8 upsert_kernel,
+ * 9 step_ka_kernel.  Not for use inside a stream capture. */
 mhte_status mhte_profile_arm(int32_t n);
 mhte_status mhte_profile_read(int32_t cap, int32_t* kernel_tag, float* usec, int32_t* n_out);
+/* Per-wavefront timeline of the step kernels, for finding what bounds a launch.  Between
+ * mhte_trace_begin(dev_buf, cap) and mhte_trace_end every launch of a step / lookup / fused-backward
+ * kernel made by the calling thread writes, per wavefront w of the launch, three uint64 words at
+ * dev_buf[3 * (offset + w)]: {begin, end} on the 100 MHz wall clock and the role the wavefront
+ * played (1 dedup reset, 2 heavy-list ordering, 3 dedup insert, 4 displacement pass, 5 lookup,
+ * 6 dedup place, 7 chunk block of the fused backward, 8 id-major group of the fused backward).
+ * dev_buf [dev, 3 * cap_records uint64].  mhte_trace_end stops tracing and returns, per traced
+ * launch, the kernel tag (as above), grid and block size and `offset`. */
+mhte_status mhte_trace_begin(void* dev_buf, int64_t cap_records);
+mhte_status mhte_trace_end(int32_t cap, int32_t* kernel_tag, int32_t* grid, int32_t* block,
+                           int64_t* offset, int32_t* n_out);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,8 @@ MHTE_IDS_UNIQUE = 1
 MHTE_SUM_DUPLICATES = 2
 MHTE_EXACT_ORDER = 1       # flags of mhte_table_sum_optimize_n
 MHTE_DEFER_SLOWPATH = 2
+MHTE_STEP_FINISH_NOW = 4   # flag of mhte_table_step_backward
+ABI_VERSION = 2            # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 INIT_ZEROS, INIT_ONES, INIT_CONSTANT = 0, 1, 2
@@ -100,6 +102,7 @@ EXPORTS = [
     "mhte_fill_with_offset_map", "mhte_fill_with_offset_map_gradient", "mhte_table_set_count_hits",
     "mhte_table_sum_optimize_n", "mhte_unique_unordered", "mhte_table_fused_backward_ok", "mhte_table_finish_pending",
     "mhte_table_step_forward", "mhte_table_step_backward", "mhte_profile_arm", "mhte_profile_read",
+    "mhte_trace_begin", "mhte_trace_end",
 ]
 
 _lib = None
@@ -139,7 +142,7 @@ def lib():
       getattr(L, name).argtypes = [C.c_void_p, C.c_int32]
     L.mhte_table_index.argtypes = [C.c_void_p, C.c_char_p]
     L.mhte_shared_name.argtypes = [C.c_void_p]
-    if L.mhte_abi_version() != 1:
+    if L.mhte_abi_version() != ABI_VERSION:
       raise MhteError(MHTE_INTERNAL, "libmhte.so ABI version mismatch")
     _lib = L
   return _lib
@@ -166,7 +169,10 @@ def vp(x):
 
 
 PROFILE_TAGS = {1: "lookup_kernel", 2: "sum_apply_kernel", 3: "step_k1_kernel", 4: "step_k2_kernel",
-                5: "step_k3_kernel", 6: "slowpath_kernel", 7: "dd_kernels", 8: "upsert_kernel"}
+                5: "step_k3_kernel", 6: "slowpath_kernel", 7: "dd_kernels", 8: "upsert_kernel",
+                9: "step_ka_kernel"}
+TRACE_ROLES = {1: "dd_reset", 2: "dd_heavy_order", 3: "dd_insert", 4: "displacement", 5: "lookup",
+               6: "dd_place", 7: "backward_chunk", 8: "backward_id_major"}
 
 
 def profile_arm(n):
@@ -182,3 +188,21 @@ def profile_read(cap=65536):
   check(lib().mhte_profile_read(C.c_int32(cap), tags, us, C.byref(n)))
   m = min(cap, n.value)
   return [(PROFILE_TAGS.get(tags[i], str(tags[i])), float(us[i])) for i in range(m)]
+
+
+def trace_begin(buf, cap_records):
+  """Per-wavefront timeline of the step kernels into ``buf`` (uint64 cuda tensor, 3 words per
+  record) — mhte_trace_begin."""
+  check(lib().mhte_trace_begin(vp(buf), C.c_int64(int(cap_records))))
+
+
+def trace_end(cap=4096):
+  """-> [(kernel name, grid, block, record offset)] of the traced launches; stops tracing."""
+  tag = (C.c_int32 * cap)()
+  grid = (C.c_int32 * cap)()
+  block = (C.c_int32 * cap)()
+  off = (C.c_int64 * cap)()
+  n = C.c_int32(0)
+  check(lib().mhte_trace_end(C.c_int32(cap), tag, grid, block, off, C.byref(n)))
+  m = min(cap, n.value)
+  return [(PROFILE_TAGS.get(tag[i], str(tag[i])), grid[i], block[i], off[i]) for i in range(m)]

@@ -76,8 +76,30 @@ static inline uint32_t ceil_log2(uint64_t n) {
 // instead of events recorded around the launch, which also contain the dispatch gap.
 enum ProfTag : int32_t {
   kTagLookup = 1, kTagSumApply = 2, kTagStepK1 = 3, kTagStepK2 = 4, kTagStepK3 = 5,
-  kTagSlowpath = 6, kTagDedup = 7, kTagUpsert = 8
+  kTagSlowpath = 6, kTagDedup = 7, kTagUpsert = 8, kTagStepKa = 9
 };
+
+// Per-wavefront timeline of the step kernels (mhte_trace_begin / mhte_trace_end): each traced
+// launch gets a region of 3 words per wavefront in the caller's device buffer.
+struct TraceLaunch {
+  int32_t tag, grid, block;
+  int64_t offset;  // first record (in records of 3 words)
+};
+struct Trace {
+  unsigned long long* buf = nullptr;
+  int64_t cap = 0, cursor = 0;
+  std::vector<TraceLaunch> launches;
+};
+static thread_local Trace g_trace;
+static unsigned long long* trace_region(int32_t tag, uint32_t grid, uint32_t block) {
+  if (!g_trace.buf) return nullptr;
+  const int64_t waves = int64_t(grid) * ((block + 63) / 64);
+  if (g_trace.cursor + waves > g_trace.cap) return nullptr;
+  unsigned long long* p = g_trace.buf + 3 * g_trace.cursor;
+  g_trace.launches.push_back(TraceLaunch{tag, int32_t(grid), int32_t(block), g_trace.cursor});
+  g_trace.cursor += waves;
+  return p;
+}
 struct Prof {
   std::vector<hipEvent_t> ev;  // 2 per recorded launch
   std::vector<int32_t> tag;
@@ -163,6 +185,7 @@ struct DedupWs {
               uint32_t* seg_pos, uint32_t* n_unique_dev, hipStream_t st) {
     if (n < 0 || n > (int64_t(1) << 31) - 4096)
       throw Error(MHTE_INVALID_ARGUMENT, "unique: n out of range");
+    settle(st);
     last_n = n;
     if (n == 0) {
       HIP_OK(hipMemsetAsync(n_unique_dev, 0, sizeof(uint32_t), st));
@@ -196,13 +219,36 @@ struct DedupWs {
   }
 
   // --- pipelined step: the dedup of the next batch rides in the table kernels of the current one
-  bool pf_active = false;
+  bool pf_active = false;  // dd_insert_fast of `pf` is (being) launched, dd_place_fast not yet
+  bool pf_placed = false;  // ... dd_place_fast launched, dd_finish not yet (two-launch step)
   NextBatch pf{};
+  // before the scratch is reused: complete a placed-but-unfinished dedup (its last third also
+  // resets the scratch); a dedup abandoned after its first third leaves the scratch dirty
+  void settle(hipStream_t st) {
+    finish_prefetch(st);
+    if (pf_active) {
+      pf_active = false;
+      clean_cap = 0;
+    }
+  }
+  // completes a dedup the pipelined step left unfinished (its last third normally rides in the
+  // next step_forward); lets any other consumer of the workspace proceed
+  void finish_prefetch(hipStream_t st) {
+    if (!pf_placed) return;
+    const uint32_t nb_rank = (pf.n + 1023) / 1024;
+    const uint32_t hgrid = std::min<uint32_t>(256, pf.n / (kLightMax + 1) + 1);
+    LAUNCH_HOT(kTagDedup, dd_finish_kernel, nb_rank + hgrid, 1024, st, pf.d, pf.n, nb_rank,
+               pf.inverse, pf.lst_start, pf.lst_end, pf.seg_pos, 0, pf.n_unique);
+    pf_placed = false;
+    last_n = pf.n;
+    HIP_OK(hipGetLastError());
+  }
   NextBatch begin_prefetch(const int64_t* ids, int64_t n, int64_t* uids, uint32_t* inverse,
                            uint32_t* lst_start, uint32_t* lst_end, uint32_t* seg_pos,
                            uint32_t* n_unique_dev, hipStream_t st) {
     if (n <= 0 || n > (int64_t(1) << 31) - 4096)
       throw Error(MHTE_INVALID_ARGUMENT, "prefetch: n out of range");
+    settle(st);
     NextBatch nb;
     nb.d = view(n, st);
     nb.ids = ids;
@@ -227,6 +273,7 @@ struct DedupWs {
                         uint32_t* n_unique_dev, hipStream_t st) {
     if (n < 0 || n > (int64_t(1) << 31) - 4096)
       throw Error(MHTE_INVALID_ARGUMENT, "unique: n out of range");
+    settle(st);
     last_n = n;
     if (n == 0) {
       HIP_OK(hipMemsetAsync(n_unique_dev, 0, sizeof(uint32_t), st));
@@ -424,6 +471,7 @@ struct Table {
     view.row_floats = row_floats;
     view.dim = dim;
     view.nseg = nseg;
+    view.trace = nullptr;
   }
 
   void sync_counters(hipStream_t st) {
@@ -494,8 +542,10 @@ struct Table {
     Shape sh = pick_shape(dim, vec_ok && aligned16(out));
     const int64_t threads = n * sh.G;
     const dim3 grid(uint32_t((threads + 255) / 256));
+    TableView v = view;
+    v.trace = trace_region(kTagLookup, grid.x, 256);
 #define CALL(G_, V_) \
-  LAUNCH_HOT(kTagLookup, (lookup_kernel<G_, V_>), grid, 256, st, view, ids, n, n_dev, out, count_hits ? 1 : 0)
+  LAUNCH_HOT(kTagLookup, (lookup_kernel<G_, V_>), grid, 256, st, v, ids, n, n_dev, out, count_hits ? 1 : 0)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
     HIP_OK(hipGetLastError());
@@ -565,6 +615,7 @@ struct Table {
                     int64_t update_time, bool exact_order, bool defer_slowpath, hipStream_t st) {
     finish_pending(st);
     if (n <= 0 || n_max <= 0) return;
+    ws.finish_prefetch(st);
     if (n != ws.last_n)
       throw Error(MHTE_FAILED_PRECONDITION,
                   "sum_optimize: workspace does not hold the occurrence lists of this batch");
@@ -583,9 +634,11 @@ struct Table {
     ws.backward_scratch(n, dim, nblk_b, st);
     const uint32_t light_max = exact_order ? 0xffffffffu : uint32_t(kLightMax);
     uint32_t* pend = pending.p;
+    TableView v = view;
+    v.trace = trace_region(kTagSumApply, nblk_a + nblk_b, 256);
 #define CALL(G_, V_)                                                                              \
   LAUNCH_HOT(kTagSumApply, (sum_apply_kernel<G_, V_>), nblk_a + nblk_b, 256, st,                  \
-             view, uids, n_dev, n_max, grads, lst_start, lst_end, seg_pos, ws.work.p,             \
+             v, uids, n_dev, n_max, grads, lst_start, lst_end, seg_pos, ws.work.p,             \
              ws.heavy_n.p + 3, nblk_b, light_max, ws.part.p, ws.arrive.p, grad_u, a, pend)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
@@ -598,27 +651,74 @@ struct Table {
     if (!defer_slowpath) finish_pending(st);
   }
 
-  // ---------------------------------------------------------------- pipelined step (3 launches)
-  void step_forward(const int64_t* ids, int64_t n, float* out, const NextBatch& nb,
+  // ---------------------------------------------------------------- pipelined step
+  // Two launches per step (three with finish_now, the round-1 form kept for comparison):
+  //   step_forward   lookup of this batch | first third of the next batch's dedup
+  //                  | last third of this batch's dedup (ws_cur, when the previous step_backward
+  //                    left it placed-but-unfinished) | displacement pass of the previous update
+  //   step_backward  fused backward of this batch | second third of the next batch's dedup
+  void step_forward(const int64_t* ids, int64_t n, float* out, DedupWs* ws_cur, const NextBatch& nb,
                     hipStream_t st) {
-    finish_pending(st);
     if (n <= 0) throw Error(MHTE_INVALID_ARGUMENT, "step_forward: empty batch");
     Shape sh = pick_shape(dim, vec_ok && aligned16(out));
     const uint32_t nblk_l = uint32_t((n * sh.G + 1023) / 1024);
-    const dim3 grid(nb.nblk + nblk_l);
+    const bool fin = ws_cur && ws_cur->pf_placed;
+    if (!fin && !pend_valid) {  // nothing to carry: the plain zipped launch
+      const dim3 grid(nb.nblk + nblk_l);
+      TableView v = view;
+      v.trace = trace_region(kTagStepK1, grid.x, 1024);
 #define CALL(G_, V_) \
-  LAUNCH_HOT(kTagStepK1, (step_k1_kernel<G_, V_>), grid, 1024, st, nb, view, ids, n, out, count_hits ? 1 : 0)
+  LAUNCH_HOT(kTagStepK1, (step_k1_kernel<G_, V_>), grid, 1024, st, nb, v, ids, n, out, count_hits ? 1 : 0)
+      DISPATCH_G_VEC(sh, CALL);
+#undef CALL
+      HIP_OK(hipGetLastError());
+      return;
+    }
+    NextBatch cur{};
+    uint32_t nb_rank = 0, nfin = 0;
+    if (fin) {
+      cur = ws_cur->pf;
+      nb_rank = (cur.n + 1023) / 1024;
+      nfin = nb_rank + std::min<uint32_t>(256, cur.n / (kLightMax + 1) + 1);
+    }
+    SlowArgs sp{};
+    sp.enabled = pend_valid ? 1 : 0;
+    if (pend_valid) {
+      sp.uids = pend_uids;
+      sp.grad_u = pend_grad;
+      sp.pending = pending.p;
+      sp.a = pend_args;
+      if (pend_vec != sh.VEC) {  // (cannot happen for one table: same row shape both ways)
+        finish_pending(st);
+        sp.enabled = 0;
+      }
+      pend_valid = false;
+    }
+    const dim3 grid(nfin + nb.nblk + uint32_t(sp.enabled) + nblk_l);
+    TableView v = view;
+    v.trace = trace_region(kTagStepKa, grid.x, 1024);
+#define CALL(G_, V_)                                                                            \
+  LAUNCH_HOT(kTagStepKa, (step_ka_kernel<G_, V_>), grid, 1024, st, cur, nb_rank, nfin, nb, v, ids, \
+             n, out, count_hits ? 1 : 0, sp)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
-    HIP_OK(hipGetLastError());
+    hipError_t le = hipGetLastError();
+    if (fin) {
+      ws_cur->pf_placed = false;
+      ws_cur->last_n = cur.n;
+      if (le != hipSuccess) ws_cur->clean_cap = 0;
+    }
+    HIP_OK(le);
   }
 
   void step_backward(DedupWs& ws, DedupWs& ws_next, const int64_t* uids, int64_t n_max,
                      const uint32_t* n_dev, const float* grads, const uint32_t* lst_start,
                      const uint32_t* lst_end, const uint32_t* seg_pos, int64_t n, float* grad_u,
-                     const float* lrs, int64_t update_time, bool exact_order, hipStream_t st) {
+                     const float* lrs, int64_t update_time, bool exact_order, bool finish_now,
+                     hipStream_t st) {
     finish_pending(st);
     if (n <= 0 || n_max <= 0) throw Error(MHTE_INVALID_ARGUMENT, "step_backward: empty batch");
+    ws.finish_prefetch(st);  // (normally done by step_forward)
     if (n != ws.last_n)
       throw Error(MHTE_FAILED_PRECONDITION,
                   "step_backward: workspace does not hold the occurrence lists of this batch");
@@ -651,17 +751,38 @@ struct Table {
     const NextBatch nb = ws_next.pf;
     const uint32_t nblk_a = uint32_t((n_max * sh.G + 255) / 256);
     const dim3 grid2(nb.nblk + b.nblk_b + nblk_a);
-#define CALL(G_, V_) LAUNCH_HOT(kTagStepK2, (step_k2_kernel<G_, V_>), grid2, 256, st, nb, view, b, a)
+    TableView v = view;
+    v.trace = trace_region(kTagStepK2, grid2.x, 256);
+#define CALL(G_, V_) LAUNCH_HOT(kTagStepK2, (step_k2_kernel<G_, V_>), grid2, 256, st, nb, v, b, a)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
+    if (!finish_now) {
+      // two-launch step: the dedup's last third and the displacement pass ride in the next
+      // step_forward (or run on their own if anything else touches the workspace / table first)
+      hipError_t le2 = hipGetLastError();
+      ws_next.pf_active = false;
+      ws_next.pf_placed = true;
+      if (le2 != hipSuccess) {
+        ws_next.clean_cap = 0;
+        ws_next.pf_placed = false;
+        HIP_OK(le2);
+      }
+      pend_valid = true;
+      pend_uids = uids;
+      pend_grad = grad_u;
+      pend_args = a;
+      pend_vec = sh.VEC;
+      return;
+    }
     const uint32_t nb_rank = (nb.n + 1023) / 1024;
     const uint32_t hgrid = std::min<uint32_t>(256, nb.n / (kLightMax + 1) + 1);
     const uint32_t nfin = nb_rank + hgrid;
+    v.trace = trace_region(kTagStepK3, nfin + 1, 1024);
     if (sh.VEC == 4) {
-      LAUNCH_HOT(kTagStepK3, (step_k3_kernel<4>), nfin + 1, 1024, st, nb, nb_rank, nfin, view, uids,
+      LAUNCH_HOT(kTagStepK3, (step_k3_kernel<4>), nfin + 1, 1024, st, nb, nb_rank, nfin, v, uids,
                  grad_u, a, pending.p);
     } else {
-      LAUNCH_HOT(kTagStepK3, (step_k3_kernel<1>), nfin + 1, 1024, st, nb, nb_rank, nfin, view, uids,
+      LAUNCH_HOT(kTagStepK3, (step_k3_kernel<1>), nfin + 1, 1024, st, nb, nb_rank, nfin, v, uids,
                  grad_u, a, pending.p);
     }
     hipError_t le = hipGetLastError();
@@ -1321,7 +1442,8 @@ mhte_status mhte_table_sum_optimize_n(mhte_multi_table* t, int32_t table, mhte_d
 }
 
 mhte_status mhte_table_step_forward(mhte_multi_table* t, int32_t table, const int64_t* id,
-                                    int64_t n, float* embedding, mhte_dedup_ws* ws_next,
+                                    int64_t n, float* embedding, mhte_dedup_ws* ws_cur,
+                                    mhte_dedup_ws* ws_next,
                                     const int64_t* id_next, int64_t n_next,
                                     int64_t* unique_ids_next, uint32_t* inverse_next,
                                     uint32_t* list_start_next, uint32_t* list_end_next,
@@ -1329,14 +1451,16 @@ mhte_status mhte_table_step_forward(mhte_multi_table* t, int32_t table, const in
                                     void* stream) {
   return guard([&] {
     Table& tb = table_at(t, table);
-    if (!ws_next) throw Error(MHTE_INVALID_ARGUMENT, "null workspace");
+    if (!ws_next || ws_next == ws_cur)
+      throw Error(MHTE_INVALID_ARGUMENT, "step_forward needs a workspace for the next batch, "
+                                         "distinct from the current one");
     HIP_OK(hipSetDevice(t->device));
     std::lock_guard<std::mutex> g(tb.mu);
     hipStream_t st = S(stream);
     const NextBatch nb = ws_next->ws.begin_prefetch(id_next, n_next, unique_ids_next, inverse_next,
                                                     list_start_next, list_end_next, seg_pos_next,
                                                     n_unique_dev_next, st);
-    tb.step_forward(id, n, embedding, nb, st);
+    tb.step_forward(id, n, embedding, ws_cur ? &ws_cur->ws : nullptr, nb, st);
   });
 }
 
@@ -1364,7 +1488,8 @@ mhte_status mhte_table_step_backward(mhte_multi_table* t, int32_t table, mhte_de
     tb.note_update_time(update_time);
     tb.step_backward(ws->ws, ws_next->ws, unique_ids, n_max, n_unique_dev, grads, list_start,
                      list_end, seg_pos, n, grad_unique, learning_rate, update_time,
-                     (flags & MHTE_EXACT_ORDER) != 0, S(stream));
+                     (flags & MHTE_EXACT_ORDER) != 0, (flags & MHTE_STEP_FINISH_NOW) != 0,
+                     S(stream));
   });
 }
 
@@ -1469,6 +1594,32 @@ mhte_status mhte_profile_read(int32_t cap, int32_t* kernel_tag, float* usec, int
       HIP_OK(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
       if (kernel_tag) kernel_tag[i] = g_prof.tag[i];
       if (usec) usec[i] = ms * 1e3f;
+    }
+  });
+}
+
+mhte_status mhte_trace_begin(void* dev_buf, int64_t cap_records) {
+  return guard([&] {
+    g_trace.buf = static_cast<unsigned long long*>(dev_buf);
+    g_trace.cap = dev_buf ? cap_records : 0;
+    g_trace.cursor = 0;
+    g_trace.launches.clear();
+  });
+}
+
+mhte_status mhte_trace_end(int32_t cap, int32_t* kernel_tag, int32_t* grid, int32_t* block,
+                           int64_t* offset, int32_t* n_out) {
+  return guard([&] {
+    if (!n_out) throw Error(MHTE_INVALID_ARGUMENT, "trace_end: null n_out");
+    g_trace.buf = nullptr;
+    const int32_t n = int32_t(g_trace.launches.size());
+    *n_out = n;
+    for (int32_t i = 0; i < n && i < cap; ++i) {
+      const TraceLaunch& l = g_trace.launches[size_t(i)];
+      if (kernel_tag) kernel_tag[i] = l.tag;
+      if (grid) grid[i] = l.grid;
+      if (block) block[i] = l.block;
+      if (offset) offset[i] = l.offset;
     }
   });
 }

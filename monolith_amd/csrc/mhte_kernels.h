@@ -43,6 +43,28 @@ struct TableView {
   uint32_t dim;
   uint32_t nseg;
   SegDesc seg[kMaxSegments];
+  // measurement aid (mhte_trace_begin): when non-null, every wavefront of a step kernel records
+  // {begin, end, role} of its role at trace[3 * global wave index]; 100 MHz wall clock.
+  unsigned long long* trace;
+};
+
+// Per-wavefront timeline record of the step kernels (null trace pointer: two wave-uniform branches).
+struct WaveTrace {
+  unsigned long long* rec;
+  unsigned long long t0;
+  __device__ __forceinline__ WaveTrace(unsigned long long* trace) : rec(nullptr), t0(0) {
+    if (trace) {
+      rec = trace + 3ull * (uint64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
+      t0 = wall_clock64();
+    }
+  }
+  __device__ __forceinline__ void end(uint32_t role) {
+    if (rec && (threadIdx.x & 63) == 0) {
+      rec[0] = t0;
+      rec[1] = wall_clock64();
+      rec[2] = role;
+    }
+  }
 };
 
 enum ApplyOp : int { kOpAssign = 0, kOpAssignAdd = 1, kOpOptimize = 2, kOpReinit = 3 };
@@ -96,7 +118,8 @@ struct Vec<1> {
 template <int G, int VEC>
 __device__ __forceinline__ void lookup_role(const TableView& tv, const int64_t* __restrict__ ids,
                                             int64_t n, const uint32_t* __restrict__ n_dev,
-                                            float* __restrict__ out, int count_hits, uint32_t bid) {
+                                            float* __restrict__ out, int count_hits, uint32_t bid,
+                                            int gate = 0) {
   const int lane = threadIdx.x & 63;
   const int j = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
@@ -104,6 +127,17 @@ __device__ __forceinline__ void lookup_role(const TableView& tv, const int64_t* 
   if (n_dev) n = min(n, int64_t(*n_dev));
   const bool valid = g < n;
   const int64_t id = valid ? ids[g] : 0;
+  if (gate) {
+    // A displacement pass for the previous update runs in another workgroup of this launch
+    // (step_ka_kernel).  No table word is read before it has finished: n_pending drops to 0 only
+    // after its stores were written back (release), and every load below is control-dependent on
+    // having seen the 0, so no stale bucket or row line can be in this XCD's L2.
+    if (__hip_atomic_load(&tv.ctr->n_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      while (__hip_atomic_load(&tv.ctr->n_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+        __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+  }
   const uint64_t hv = hash_key(id);
   const uint64_t i1 = index_hash(tv.hp, hv);
   const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
@@ -147,7 +181,9 @@ template <int G, int VEC>
 __global__ __launch_bounds__(256) void lookup_kernel(TableView tv, const int64_t* __restrict__ ids,
                                                      int64_t n, const uint32_t* __restrict__ n_dev,
                                                      float* __restrict__ out, int count_hits) {
+  WaveTrace wt(tv.trace);
   lookup_role<G, VEC>(tv, ids, n, n_dev, out, count_hits, blockIdx.x);
+  wt.end(5u);
 }
 
 
@@ -404,15 +440,17 @@ __global__ __launch_bounds__(256) void upsert_kernel(TableView tv, const int64_t
 // =============================================================================================
 // SOLO: the role is the whole (64-thread) workgroup; otherwise it is wave 0 of a larger one
 // and must not use workgroup barriers (lane 0 alone reads and writes q/path and the buckets).
-template <int VEC, int OP, bool SOLO>
+// GATED: other workgroups of the same launch wait for n_pending == 0 before they touch the table
+// (lookup_role's gate): the pass ends with an agent-scope release (its bucket and row stores are
+// written back from this XCD's L2) followed by an agent-scope store of the 0.
+template <int VEC, int OP, bool SOLO, bool GATED = false>
 __device__ __forceinline__ void slowpath_role(const TableView& tv, const int64_t* __restrict__ ids,
                                               const float* __restrict__ values,
                                               const uint32_t* __restrict__ seg_off,
                                               const uint32_t* __restrict__ seg_pos,
                                               const ApplyArgs& a, int32_t* __restrict__ status,
-                                              const uint32_t* __restrict__ pending) {
-  __shared__ BfsSlot q[kMaxCuckooCount];
-  __shared__ CuckooRecord path[kMaxBfsPathLen];
+                                              const uint32_t* __restrict__ pending,
+                                              BfsSlot* q, CuckooRecord* path) {
   const int lane = threadIdx.x;
   const uint32_t np = tv.ctr->n_pending;
   if (np == 0) return;
@@ -450,7 +488,13 @@ __device__ __forceinline__ void slowpath_role(const TableView& tv, const int64_t
     }
     if (SOLO) __syncthreads();  // (lane 0 alone touches q, path and the buckets)
   }
-  if (lane == 0) tv.ctr->n_pending = 0;
+  if (GATED) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0)
+      __hip_atomic_store(&tv.ctr->n_pending, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (lane == 0) tv.ctr->n_pending = 0;
+  }
 }
 template <int VEC, int OP>
 __global__ __launch_bounds__(64) void slowpath_kernel(TableView tv, const int64_t* __restrict__ ids,
@@ -459,7 +503,9 @@ __global__ __launch_bounds__(64) void slowpath_kernel(TableView tv, const int64_
                                                       const uint32_t* __restrict__ seg_pos,
                                                       ApplyArgs a, int32_t* __restrict__ status,
                                                       const uint32_t* __restrict__ pending) {
-  slowpath_role<VEC, OP, true>(tv, ids, values, seg_off, seg_pos, a, status, pending);
+  __shared__ BfsSlot q[kMaxCuckooCount];
+  __shared__ CuckooRecord path[kMaxBfsPathLen];
+  slowpath_role<VEC, OP, true>(tv, ids, values, seg_off, seg_pos, a, status, pending, q, path);
 }
 
 
@@ -1149,7 +1195,7 @@ __device__ __forceinline__ void dd_finish_role(const DedupView& d, uint32_t n, u
                                                const uint32_t* __restrict__ lst_end,
                                                uint32_t* __restrict__ seg_pos, int order_light,
                                                uint32_t* __restrict__ n_unique_out, uint32_t bid,
-                                               uint32_t nblocks) {
+                                               uint32_t nblocks, uint32_t* bm /* LDS [kBmWords + 16] */) {
   if (bid < nb_rank) {
     const uint32_t p = bid * 1024 + threadIdx.x;
     if (!order_light && p == 0) {
@@ -1182,8 +1228,7 @@ __device__ __forceinline__ void dd_finish_role(const DedupView& d, uint32_t n, u
     d.hstart[s] = kUnset;
     return;
   }
-  __shared__ uint32_t bm[kBmWords];
-  __shared__ uint32_t wcnt[16];
+  uint32_t* wcnt = bm + kBmWords;
   const uint32_t nh = *d.heavy_n;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (uint32_t h = bid - nb_rank; h < nh; h += nblocks - nb_rank) {
@@ -1251,8 +1296,9 @@ __global__ __launch_bounds__(1024) void dd_finish_kernel(DedupView d, uint32_t n
                                                          uint32_t* __restrict__ seg_pos,
                                                          int order_light,
                                                          uint32_t* __restrict__ n_unique_out) {
+  __shared__ uint32_t bm[kBmWords + 16];
   dd_finish_role(d, n, nb_rank, inverse, lst_start, lst_end, seg_pos, order_light, n_unique_out,
-                 blockIdx.x, gridDim.x);
+                 blockIdx.x, gridDim.x, bm);
 }
 
 
@@ -1761,9 +1807,11 @@ __global__ __launch_bounds__(256) void sum_apply_kernel(
     const uint32_t* __restrict__ work, const uint32_t* __restrict__ n_work,
     uint32_t nblk_b, uint32_t light_max, float* part, uint32_t* arrive,
     float* __restrict__ grad_u, ApplyArgs a, uint32_t* __restrict__ pending) {
+  WaveTrace wt(tv.trace);
   sum_apply_role<G, VEC, 256>(tv, uids, n_unique, n_max, grads, lst_start, lst_end, seg_pos, work,
                               n_work, nblk_b, light_max, part, arrive, grad_u, a, pending,
                               blockIdx.x);
+  wt.end(blockIdx.x < nblk_b ? 7u : 8u);
 }
 
 
@@ -1796,11 +1844,70 @@ template <int G, int VEC>
 __global__ __launch_bounds__(1024) void step_k1_kernel(NextBatch nb, TableView tv,
                                                        const int64_t* __restrict__ ids, int64_t n,
                                                        float* __restrict__ out, int count_hits) {
+  WaveTrace wt(tv.trace);
   if (blockIdx.x < nb.nblk) {
     dd_insert_fast_role(nb.d, nb.ids, nb.n, nb.uids, blockIdx.x);
+    wt.end(3u);
   } else {
     lookup_role<G, VEC>(tv, ids, n, nullptr, out, count_hits, blockIdx.x - nb.nblk);
+    wt.end(5u);
   }
+}
+
+// Two-launch form of the pipelined step (the dedup of a batch is spread over one and a half steps
+// so that no launch exists for the dedup's sake alone):
+//   step_ka(s)  dd_finish(s) | dd_insert_fast(s+1) | displacement pass of update s-1 | lookup(s)
+//   step_k2(s)  dd_place_fast(s+1) | sum_apply(s)
+// The displacement pass (ids of update s-1 whose two buckets were full; usually none) is one
+// wavefront of launch ka; the lookup workgroups gate on its completion (lookup_role).
+struct SlowArgs {  // slowpath_role's arguments; enabled = 0: no pass outstanding
+  const int64_t* uids;
+  const float* grad_u;
+  const uint32_t* pending;
+  ApplyArgs a;
+  int32_t enabled;
+};
+
+template <int G, int VEC>
+__global__ __launch_bounds__(1024) void step_ka_kernel(NextBatch cur, uint32_t nb_rank,
+                                                       uint32_t nfin, NextBatch nxt, TableView tv,
+                                                       const int64_t* __restrict__ ids, int64_t n,
+                                                       float* __restrict__ out, int count_hits,
+                                                       SlowArgs sp) {
+  // one LDS region serves the heavy-list bitmap and the displacement pass's BFS queue
+  static_assert(sizeof(BfsSlot) * kMaxCuckooCount + sizeof(CuckooRecord) * kMaxBfsPathLen <=
+                    sizeof(uint32_t) * kBmWords, "BFS scratch must fit the bitmap region");
+  __shared__ __attribute__((aligned(16))) uint32_t bm[kBmWords + 16];
+  WaveTrace wt(tv.trace);
+  uint32_t bid = blockIdx.x;
+  if (bid < nfin) {
+    dd_finish_role(cur.d, cur.n, nb_rank, cur.inverse, cur.lst_start, cur.lst_end, cur.seg_pos, 0,
+                   cur.n_unique, bid, nfin, bm);
+    wt.end(bid < nb_rank ? 1u : 2u);
+    return;
+  }
+  bid -= nfin;
+  if (bid < nxt.nblk) {
+    dd_insert_fast_role(nxt.d, nxt.ids, nxt.n, nxt.uids, bid);
+    wt.end(3u);
+    return;
+  }
+  bid -= nxt.nblk;
+  if (sp.enabled) {
+    if (bid == 0) {
+      if (threadIdx.x < 64) {
+        BfsSlot* q = reinterpret_cast<BfsSlot*>(bm);
+        CuckooRecord* path = reinterpret_cast<CuckooRecord*>(q + kMaxCuckooCount);
+        slowpath_role<VEC, kOpOptimize, false, true>(tv, sp.uids, sp.grad_u, nullptr, nullptr, sp.a,
+                                                     nullptr, sp.pending, q, path);
+      }
+      wt.end(4u);
+      return;
+    }
+    bid -= 1;
+  }
+  lookup_role<G, VEC>(tv, ids, n, nullptr, out, count_hits, bid, sp.enabled);
+  wt.end(5u);
 }
 
 struct BackwardArgs {  // sum_apply_role's arguments
@@ -1824,13 +1931,26 @@ struct BackwardArgs {  // sum_apply_role's arguments
 template <int G, int VEC>
 __global__ __launch_bounds__(256) void step_k2_kernel(NextBatch nb, TableView tv, BackwardArgs b,
                                                       ApplyArgs a) {
+  WaveTrace wt(tv.trace);
   if (blockIdx.x < nb.nblk) {
     dd_place_fast_role<256>(nb.d, nb.n, nb.inverse, nb.lst_start, nb.lst_end, nb.seg_pos,
                             blockIdx.x);
+    wt.end(6u);
   } else {
     sum_apply_role<G, VEC, 256>(tv, b.uids, b.n_unique, b.n_max, b.grads, b.lst_start, b.lst_end,
                                  b.seg_pos, b.work, b.n_work, b.nblk_b, b.light_max, b.part,
                                  b.arrive, b.grad_u, a, b.pending, blockIdx.x - nb.nblk);
+    if (tv.trace) {  // 9 / 10: wavefronts that found no work (past the device-side counts)
+      const uint32_t rb = blockIdx.x - nb.nblk;
+      uint32_t role;
+      if (rb < b.nblk_b) {
+        role = rb < *b.n_work ? 7u : 10u;
+      } else {
+        const int64_t g0 = (int64_t(rb - b.nblk_b) * 256 + (threadIdx.x & ~63)) / G;
+        role = g0 < min(b.n_max, int64_t(*b.n_unique)) ? 8u : 9u;
+      }
+      wt.end(role);
+    }
   }
 }
 
@@ -1841,11 +1961,20 @@ __global__ __launch_bounds__(1024) void step_k3_kernel(NextBatch nb, uint32_t nb
                                                        const float* __restrict__ grad_u,
                                                        ApplyArgs a,
                                                        const uint32_t* __restrict__ pending) {
+  __shared__ __attribute__((aligned(16))) uint32_t bm[kBmWords + 16];
+  WaveTrace wt(tv.trace);
   if (blockIdx.x < nfin) {
     dd_finish_role(nb.d, nb.n, nb_rank, nb.inverse, nb.lst_start, nb.lst_end, nb.seg_pos, 0,
-                   nb.n_unique, blockIdx.x, nfin);
-  } else if (threadIdx.x < 64) {
-    slowpath_role<VEC, kOpOptimize, false>(tv, uids, grad_u, nullptr, nullptr, a, nullptr, pending);
+                   nb.n_unique, blockIdx.x, nfin, bm);
+    wt.end(blockIdx.x < nb_rank ? 1u : 2u);
+  } else {
+    if (threadIdx.x < 64) {
+      BfsSlot* q = reinterpret_cast<BfsSlot*>(bm);
+      CuckooRecord* path = reinterpret_cast<CuckooRecord*>(q + kMaxCuckooCount);
+      slowpath_role<VEC, kOpOptimize, false>(tv, uids, grad_u, nullptr, nullptr, a, nullptr, pending,
+                                             q, path);
+    }
+    wt.end(4u);
   }
 }
 

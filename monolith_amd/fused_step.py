@@ -15,11 +15,14 @@ and mask themselves.
 Pipelining.  The dedup depends on the ids only, not on the table, so — like the reference's
 prefetch queue in front of the lookup (distributed_ps_sync.py:199-203) — the dedup of batch s+1 is
 done while batch s is looked up and updated: ``forward(ids, next_ids=...)``.  The two chains are
-zipped into the SAME three launches (mhte_table_step_forward / _backward: different workgroups of
-one kernel do the two jobs), because a dependency between two HIP queues costs ~10 us on this part
-and a kernel boundary on one queue next to nothing.  Two dedup workspaces / result buffers alternate
-so the two batches never share scratch.  Without ``next_ids`` the dedup of the current batch runs
-on a side stream beside the lookup."""
+zipped into the SAME launches (mhte_table_step_forward / _backward: different workgroups of one
+kernel do the jobs), because a dependency between two HIP queues costs ~10 us on this part and a
+kernel boundary on one queue next to nothing.  ``launches=2`` (default): a batch's dedup spans one
+and a half steps — its last third and the displacement pass of the previous update ride in the
+next forward launch — so a step is exactly two launches.  ``launches=3`` completes both in a third
+launch at the end of ``backward``.  Two dedup workspaces / result buffers alternate so the two
+batches never share scratch.  Without ``next_ids`` the dedup of the current batch runs on a side
+stream beside the lookup."""
 from typing import Optional
 
 import numpy as np
@@ -34,7 +37,9 @@ class SparseStep:
 
   def __init__(self, table: MultiHashTable, table_name: str, batch: int,
                exact_order: bool = False, direct: bool = True, fused_backward: bool = True,
-               ordered_unique: bool = False):
+               ordered_unique: bool = False, launches: int = 2):
+    assert launches in (2, 3)
+    self.launches = launches
     self.direct = direct
     self.fused_backward = fused_backward
     # the reference's first-occurrence numbering of the unique ids is only needed by the unfused
@@ -112,9 +117,11 @@ class SparseStep:
     key = (ids.data_ptr(), ids.numel())
     other = 1 - self._cur
     zipped = next_ids is not None and not self.ordered_unique and self.fused_backward
+    ws_cur = None
     if self._key[other] == key:
       self._cur = other          # deduplicated ahead of time by the previous step
       self._joined = True
+      ws_cur = self._ws[other]   # (two-launch step: its last third rides in this forward)
     elif zipped:
       self._unique(ids)          # first step of a pipeline: dedup in stream order
       self._joined = True
@@ -132,7 +139,8 @@ class SparseStep:
     if zipped:
       assert next_ids.numel() == self.batch
       nxt = 1 - self._cur
-      self.table.table_step_forward(self.idx, ids, self.emb, self._ws[nxt], self._u[nxt], next_ids)
+      self.table.table_step_forward(self.idx, ids, self.emb, self._ws[nxt], self._u[nxt], next_ids,
+                                    ws_cur=ws_cur)
       self._pending_next = (next_ids.data_ptr(), next_ids.numel())
     else:
       self.table.table_lookup_n(self.idx, ids, None, self.emb, n_max=self.batch)
@@ -150,7 +158,8 @@ class SparseStep:
       nxt = 1 - self._cur
       self.table.table_step_backward(self.idx, self.ws, self._ws[nxt], self.u, grads, self.grad_u,
                                      self.lrs, update_time, global_step,
-                                     exact_order=self.exact_order)
+                                     exact_order=self.exact_order,
+                                     finish_now=(self.launches == 3))
       self._key[nxt] = self._pending_next
       self._pending_next = None
     elif self.fused_backward:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit: parity tests, bench line, rocprofv3 kernel trace of a short bench.
 # Usage (from the repo root on the GPU box): bash scripts/gpu_round.sh <tag> [what...]
-#   what: tests bench prof pmc (default: tests bench prof)
+#   what: tests smoke bench prof tl trace pmc calib (default: tests bench prof)
 set -u
 TAG=${1:-r01}; shift || true
 WHAT=${*:-tests bench prof}
@@ -32,6 +32,12 @@ tl)
     python bench.py --steps 20 --warmup 4 --no-cpu-baseline --resident-rows 16777216 --no-stage-timing > $OUT/tl_bench.json 2> $OUT/tl.err
   db=$(find /tmp/tl -name '*.db' | head -1)
   if [ -n "$db" ]; then python scripts/rocpd_stats.py $db $OUT/timeline.md --by-grid --timeline 24 | tail -30; fi ;;
+trace)
+  # per-wavefront timeline of three pipelined steps (mhte_trace_begin) + the bench line of the run
+  timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --trace-out $OUT/trace.npz \
+    > $OUT/trace_bench.json 2> $OUT/trace.err
+  echo "trace rc=$?"; cat $OUT/trace_bench.json; tail -5 $OUT/trace.err
+  python scripts/trace_report.py $OUT/trace.npz > $OUT/trace_report.md 2>> $OUT/trace.err; cat $OUT/trace_report.md ;;
 pmc)
   for c in "FETCH_SIZE" "WRITE_SIZE"; do
     rm -rf /tmp/pmc_$c && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o pmc -- \

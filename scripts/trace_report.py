@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Summarise a per-wavefront timeline written by `bench.py --trace-out x.npz` (mhte_trace_begin).
+
+For every traced launch and every role inside it: number of wavefronts, when they started and
+ended relative to the launch's first wavefront (min / median / p95 / max, microseconds) and how
+long they lived.  The 100 MHz wall clock gives 10 ns resolution.  Output is markdown."""
+import sys
+
+import numpy as np
+
+ROLES = {1: "dd_reset", 2: "dd_heavy_order", 3: "dd_insert", 4: "displacement", 5: "lookup",
+         6: "dd_place", 7: "backward_chunk", 8: "backward_id_major", 9: "backward_id_major(idle)",
+         10: "backward_chunk(idle)", 0: "(no record)"}
+
+
+def q(a, p):
+  return float(np.percentile(a, p)) if a.size else float("nan")
+
+
+def main(path):
+  z = np.load(path, allow_pickle=True)
+  rec = z["records"].astype(np.int64)
+  launches = z["launches"]
+  print("| launch | kernel | grid x block | role | waves | start min/med/p95/max us | "
+        "end med/p95/max us | life med/p95/max us |")
+  print("|---|---|---|---|---|---|---|---|")
+  for li, (name, grid, block, off) in enumerate(launches):
+    grid, block, off = int(grid), int(block), int(off)
+    waves = grid * ((block + 63) // 64)
+    r = rec[off:off + waves]
+    live = r[:, 0] != 0
+    if not live.any():
+      continue
+    t0 = r[live, 0].min()
+    span = (r[live, 1].max() - t0) / 100.0
+    print("| %d | %s | %d x %d | ALL | %d | span %.2f us | | |" % (li, name, grid, block,
+                                                                   int(live.sum()), span))
+    for role in sorted(set(r[live, 2].tolist())):
+      m = live & (r[:, 2] == role)
+      st = (r[m, 0] - t0) / 100.0
+      en = (r[m, 1] - t0) / 100.0
+      life = en - st
+      print("| %d | | | %s | %d | %.2f / %.2f / %.2f / %.2f | %.2f / %.2f / %.2f | "
+            "%.2f / %.2f / %.2f |" % (li, ROLES.get(int(role), str(role)), int(m.sum()),
+                                      st.min(), q(st, 50), q(st, 95), st.max(),
+                                      q(en, 50), q(en, 95), en.max(),
+                                      q(life, 50), q(life, 95), life.max()))
+  # gaps between consecutive launches (end of one to first wave of the next)
+  prev_end = None
+  gaps = []
+  for (name, grid, block, off) in launches:
+    waves = int(grid) * ((int(block) + 63) // 64)
+    r = rec[int(off):int(off) + waves]
+    live = r[:, 0] != 0
+    if not live.any():
+      continue
+    if prev_end is not None:
+      gaps.append((r[live, 0].min() - prev_end) / 100.0)
+    prev_end = r[live, 1].max()
+  if gaps:
+    print("\ngaps between launches (last wave end -> next first wave start), us: " +
+          ", ".join("%.2f" % g for g in gaps))
+
+
+if __name__ == "__main__":
+  main(sys.argv[1])

@@ -29,7 +29,7 @@ def test_library_builds_and_exports_header_symbols():
   missing = [s for s in declared if not hasattr(L, s)]
   assert not missing, missing
   assert set(declared) == set(_lib.EXPORTS), set(declared) ^ set(_lib.EXPORTS)
-  assert L.mhte_abi_version() == 1
+  assert L.mhte_abi_version() == _lib.ABI_VERSION
 
 
 def test_library_contains_gfx950_code_object():

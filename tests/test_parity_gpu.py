@@ -555,18 +555,20 @@ def test_fused_backward_equals_unfused_and_is_deterministic():
 
 
 def test_pipelined_step_matches_oracle_and_unpipelined():
-  """forward(ids, next_ids=...): the dedup of the next batch rides in the three launches of the
-  current one (mhte_table_step_forward / _backward).  Same rows as the step-by-step path, bit for
-  bit, and within 1e-5 of the oracle; exact order -> bit-exact with the oracle."""
+  """forward(ids, next_ids=...): the dedup of the next batch rides in the launches of the current
+  one (mhte_table_step_forward / _backward; two launches per step, or three with
+  MHTE_STEP_FINISH_NOW).  Same rows as the step-by-step path, bit for bit, and within 1e-5 of the
+  oracle; exact order -> bit-exact with the oracle."""
   n, dim, steps = 20000, 32, 5
   batches = [S.id_batch(40 + s_, n, 10**5, "zipf") for s_ in range(steps + 1)]
   batches[2][::2] = batches[2][1]  # a list of n/2 occurrences (39 chunks)
   ids_dev = [ids_t(b) for b in batches]
   probe = np.unique(np.concatenate(batches[:steps]))
   out = {}
-  for mode in ("pipelined", "plain", "pipelined_exact"):
+  for mode in ("pipelined", "plain", "pipelined_exact", "pipelined3"):
     mt = make({"emb": adagrad_cfg(dim, 0.01, 0.1)})
-    step = SparseStep(mt, "emb", n, exact_order=(mode == "pipelined_exact"))
+    step = SparseStep(mt, "emb", n, exact_order=(mode == "pipelined_exact"),
+                      launches=(3 if mode == "pipelined3" else 2))
     for s_ in range(steps):
       nxt = ids_dev[s_ + 1] if mode != "plain" else None
       emb = step.forward(ids_dev[s_], next_ids=nxt)
@@ -583,6 +585,8 @@ def test_pipelined_step_matches_oracle_and_unpipelined():
   exp = ot.lookup(probe)[0]
   np.testing.assert_array_equal(out["pipelined"][0], out["plain"][0])
   np.testing.assert_array_equal(out["pipelined"][1], out["plain"][1])
+  np.testing.assert_array_equal(out["pipelined3"][0], out["plain"][0])
+  np.testing.assert_array_equal(out["pipelined3"][1], out["plain"][1])
   np.testing.assert_allclose(out["pipelined"][0], exp, rtol=0, atol=TOL)
   np.testing.assert_array_equal(out["pipelined_exact"][0], exp)
   np.testing.assert_array_equal(out["pipelined_exact"][1], exp_first)
@@ -605,6 +609,40 @@ def test_fused_backward_slow_path_at_high_load():
     step.backward(val_t(g), S.update_time(s_))
     _oracle_step(ot, ids, g, dim, 0.1, S.update_time(s_))
     seen.update(ids.tolist())
+  st = mt.stats("a")
+  assert st.dropped == 0 and st.hashpower == 11 and st.size > 0.5 * cap
+  allids = np.fromiter(seen, dtype=np.int64)
+  np.testing.assert_array_equal(mt.lookup({"a": ids_t(allids)})["a"].cpu().numpy(),
+                                ot.lookup(allids)[0])
+
+
+@pytest.mark.parametrize("launches", [2, 3])
+def test_pipelined_step_slow_path_at_high_load(launches):
+  """Pipelined step at load factor ~0.97: many ids find both buckets full, so the displacement
+  pass has work in every step.  With two launches per step it runs as one wavefront of the NEXT
+  forward launch and the lookup workgroups gate on it (a looked-up id may be one it just placed):
+  the forward outputs and the final rows must still be the oracle's, bit for bit."""
+  cap, dim, n, steps = 1 << 13, 8, 3000, 4
+  mt = make({"a": adagrad_cfg(dim, 0.1, 0.1, initial_capacity=cap, max_load_factor=0.97)})
+  ot = O.Table(O.segment(dim, O.OPT_ADAGRAD, p=(0.1, 0.0)), cap)
+  step = SparseStep(mt, "a", n, launches=launches, exact_order=True)
+  rng = np.random.default_rng(12)
+  batches = []
+  for s_ in range(steps + 1):
+    ids = rng.integers(1, 2**60, n)
+    ids[n // 2:] = ids[:n - n // 2]          # every id twice
+    if s_ > 0:
+      ids[:n // 4] = batches[-1][:n // 4]    # a quarter of the previous batch again: the lookup
+    batches.append(ids)                      # right after an update sees what that update inserted
+  dev = [ids_t(b) for b in batches]
+  seen = set()
+  for s_ in range(steps):
+    g = S.grad_batch(s_, n, dim)
+    emb = step.forward(dev[s_], next_ids=dev[s_ + 1])
+    np.testing.assert_array_equal(emb.cpu().numpy(), ot.lookup(batches[s_])[0])
+    step.backward(val_t(g), S.update_time(s_))
+    _oracle_step(ot, batches[s_], g, dim, 0.1, S.update_time(s_))
+    seen.update(batches[s_].tolist())
   st = mt.stats("a")
   assert st.dropped == 0 and st.hashpower == 11 and st.size > 0.5 * cap
   allids = np.fromiter(seen, dtype=np.int64)
