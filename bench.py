@@ -163,8 +163,7 @@ def main():
   # contiguous batch sequence: the last step of a mode deduplicates the first batch of the next
   # mode ahead, exactly as it does inside a mode.
   reps = min(K, 100)
-  K3, W3 = min(K, 100), min(W, 10)   # the round-1 three-launch step, timed for comparison
-  n_batches = (2 * (W + K) + W3 + K3 + 2 * reps + 8) if world == 1 else (K + W + 1)
+  n_batches = (2 * (W + K) + 2 * reps + 8) if world == 1 else (K + W + 1)
   ids_host = np.stack([S.id_batch(s * world + rank, B, V, "zipf") for s in range(n_batches)])
   ids_all = torch.from_numpy(ids_host).to(dev)
   grad_pool = [torch.from_numpy(S.grad_batch(s, B, D)).to(dev) for s in range(8)]
@@ -184,7 +183,7 @@ def main():
     # prefetch queue does.  Every timed step executes exactly one dedup, one lookup and one
     # update: the first timed batch was deduplicated by the last warm-up step, the last timed
     # step deduplicates the batch after it.
-    step = SparseStep(mt, "emb", B, exact_order=args.exact_order, launches=2)
+    step = SparseStep(mt, "emb", B, exact_order=args.exact_order)
 
     def run_eager(lo, hi):
       for s in range(lo, hi):
@@ -202,9 +201,6 @@ def main():
       return c + w + k
 
     cur = timed("eager", 0, W, K)          # two launches per step
-    step.launches = 3
-    cur = timed("eager3", cur, W3, K3)     # three launches per step (round-1 form)
-    step.launches = 2
 
     # ---- hipGraph replay: the launch-bound loop captured in chunks of `gc` pipelined steps
     # (2 launches per step on one queue).  Each chunk graph reads its batches straight from the
@@ -315,8 +311,8 @@ def main():
       us.append(step.n_unique())
     uniq_avg = float(np.mean(us))
     step_bytes, per_kernel = algorithmic_bytes(B, uniq_avg, D, S_state)
-    alg = {"step_k1_kernel": per_kernel["lookup_kernel"], "step_ka_kernel": per_kernel["lookup_kernel"],
-           "step_k2_kernel": per_kernel["sum_apply_kernel"],
+    alg = {"step_fwd_kernel": per_kernel["lookup_kernel"],
+           "step_bwd_kernel": per_kernel["sum_apply_kernel"],
            "lookup_kernel": per_kernel["lookup_kernel"], "sum_apply_kernel": per_kernel["sum_apply_kernel"]}
     for name, avg in sorted(pipelined.items()):
       stages[name] = {"avg_us": round(avg, 2),

@@ -265,42 +265,42 @@ mhte_status mhte_table_sum_optimize_n(mhte_multi_table* t, int32_t table, mhte_d
  * that time kernels, or that update several tables back to back, call it once at the end. */
 mhte_status mhte_table_finish_pending(mhte_multi_table* t, int32_t table, void* stream);
 
-/* Pipelined training step of one table: the dedup of the NEXT batch (which depends on its ids
- * only — the reference prefetches it too, NT/distributed_ps_sync.py:199-203) is carried by the
- * same launches that look up and update the CURRENT batch, different workgroups doing the jobs
- * side by side on one queue.  Two launches per step:
+/* Pipelined training step of one table: TWO launches per step, the dedup of the NEXT batch (it
+ * depends on the ids only — the reference prefetches it too, NT/distributed_ps_sync.py:199-203)
+ * riding in them, different workgroups doing the jobs side by side on one queue:
  *   mhte_table_step_forward   lookup of id[n] -> embedding (as mhte_table_lookup_n)
- *                             + first third of mhte_unique_unordered(ws_next, id_next)
- *                             + last third of the dedup of THIS batch, when ws_cur holds one the
- *                               previous mhte_table_step_backward left unfinished
+ *                             + dedup of id_next[n_next] into ws_next (one phase: per-workgroup
+ *                               occurrence runs, see csrc/mhte_step_kernels.h)
  *                             + the displacement pass of the previous update (one wavefront; the
  *                               lookup workgroups wait for it only when it has work)
- *   mhte_table_step_backward  mhte_table_sum_optimize_n of the current batch (lists from ws)
- *                             + second third of the dedup of the next batch
- * so a batch's dedup spans one and a half steps and no launch exists for its sake alone.  After
- * step_backward the *_next outputs are complete once the following step_forward (given ws_next as
- * its ws_cur) has been enqueued; any other call that uses ws_next or the table enqueues the
- * missing parts itself first.  With MHTE_STEP_FINISH_NOW step_backward adds a third launch that
- * completes the dedup and runs the displacement pass at once (then the *_next outputs are what
- * mhte_unique_unordered would have produced as soon as step_backward returns).
- * ws_cur may be NULL (first step: the caller ran mhte_unique_unordered itself).  ws and ws_next
- * must be distinct; the table row must satisfy mhte_table_fused_backward_ok. */
-enum { MHTE_STEP_FINISH_NOW = 4 }; /* with MHTE_EXACT_ORDER in step_backward's flags */
+ *   mhte_table_step_backward  duplicate-gradient sum + upsert + optimizer of the batch held by ws
+ *                             (MonolithFillWithOffsetMapGradient + MonolithMultiHashTableOptimize,
+ *                             RT/ops/unique_mapping_ops.cc:284-329, multi_hash_table_update_op.cc
+ *                             :47-100) + the heavy-list work items of the batch held by ws_next
+ * Batches of 1..65 536 ids.  The dedup's device-side results are the unique ids (unspecified
+ * order, like the iteration order of the flat_hash_map the reference dedups with) and their count;
+ * the occurrence lists stay in the workspace in the step's own run format.
+ *   ws / ws_next   two workspaces used alternately; ws_next may be NULL (no following batch)
+ *   flags          MHTE_EXACT_ORDER: every list is summed strictly in occurrence order (bit-exact
+ *                  with the reference); otherwise lists of > 32 occurrences are summed as a fixed
+ *                  tree over position ranges (deterministic; fp32 re-association only)
+ * The first batch of a pipeline is deduplicated by mhte_step_dedup.  The displacement pass left
+ * by step_backward is run by the next step_forward, or by any other call on the table
+ * (mhte_table_finish_pending).  The table row must satisfy mhte_table_fused_backward_ok. */
+mhte_status mhte_step_dedup(mhte_dedup_ws* ws, const int64_t* id, int64_t n, int64_t* unique_ids,
+                            uint32_t* n_unique_dev, void* stream);
 mhte_status mhte_table_step_forward(mhte_multi_table* t, int32_t table, const int64_t* id,
-                                    int64_t n, float* embedding, mhte_dedup_ws* ws_cur,
-                                    mhte_dedup_ws* ws_next, const int64_t* id_next, int64_t n_next,
-                                    int64_t* unique_ids_next, uint32_t* inverse_next,
-                                    uint32_t* list_start_next, uint32_t* list_end_next,
-                                    uint32_t* seg_pos_next, uint32_t* n_unique_dev_next,
+                                    int64_t n, float* embedding, mhte_dedup_ws* ws_next,
+                                    const int64_t* id_next, int64_t n_next,
+                                    int64_t* unique_ids_next, uint32_t* n_unique_dev_next,
                                     void* stream);
 mhte_status mhte_table_step_backward(mhte_multi_table* t, int32_t table, mhte_dedup_ws* ws,
                                      mhte_dedup_ws* ws_next, const int64_t* unique_ids,
                                      int64_t n_max, const uint32_t* n_unique_dev,
-                                     const float* grads, const uint32_t* list_start,
-                                     const uint32_t* list_end, const uint32_t* seg_pos, int64_t n,
-                                     float* grad_unique, const float* learning_rate,
-                                     int64_t n_learning_rate, int64_t update_time,
-                                     int64_t global_step, int32_t flags, void* stream);
+                                     const float* grads, int64_t n, float* grad_unique,
+                                     const float* learning_rate, int64_t n_learning_rate,
+                                     int64_t update_time, int64_t global_step, int32_t flags,
+                                     void* stream);
 
 /* 1 when table i's row fits the single-launch backward (dim <= 256 floats, or <= 64 when segment
  * boundaries are not multiples of 4 floats); otherwise mhte_table_sum_optimize_n runs segment sum +
@@ -336,17 +336,17 @@ mhte_status mhte_fill_with_offset_map_gradient(const int64_t* pos, int64_t n, co
  * hipExtLaunchKernelGGL, whose start/stop HIP events carry the kernel's own begin/end timestamps
  * on its queue (the interval rocprofv3 --kernel-trace reports).  mhte_profile_read disarms,
  * waits for the recorded launches and returns per launch the kernel tag and the duration in
- * microseconds.  Tags: 1 lookup_kernel, 2 sum_apply_kernel, 3 step_k1_kernel, 4 step_k2_kernel,
- * 5 step_k3_kernel, 6 slowpath_kernel, 7 dd_* (unordered dedup), 8 upsert_kernel,
- * 9 step_ka_kernel.  Not for use inside a stream capture. */
+ * microseconds.  Tags: 1 lookup_kernel, 2 sum_apply_kernel, 6 slowpath_kernel, 7 dd_* / rd_*
+ * (dedup on its own), 8 upsert_kernel, 9 step_fwd_kernel, 10 step_bwd_kernel.
+ * Not for use inside a stream capture. */
 mhte_status mhte_profile_arm(int32_t n);
 mhte_status mhte_profile_read(int32_t cap, int32_t* kernel_tag, float* usec, int32_t* n_out);
 /* Per-wavefront timeline of the step kernels, for finding what bounds a launch.  Between
  * mhte_trace_begin(dev_buf, cap) and mhte_trace_end every launch of a step / lookup / fused-backward
  * kernel made by the calling thread writes, per wavefront w of the launch, three uint64 words at
  * dev_buf[3 * (offset + w)]: {begin, end} on the 100 MHz wall clock and the role the wavefront
- * played (1 dedup reset, 2 heavy-list ordering, 3 dedup insert, 4 displacement pass, 5 lookup,
- * 6 dedup place, 7 chunk block of the fused backward, 8 id-major group of the fused backward).
+ * played (3 run dedup, 4 displacement pass, 5 lookup, 6 heavy work list, 7 item workgroup of the
+ * apply, 8 id-major workgroup of the apply).
  * dev_buf [dev, 3 * cap_records uint64].  mhte_trace_end stops tracing and returns, per traced
  * launch, the kernel tag (as above), grid and block size and `offset`. */
 mhte_status mhte_trace_begin(void* dev_buf, int64_t cap_records);

@@ -22,7 +22,6 @@ MHTE_IDS_UNIQUE = 1
 MHTE_SUM_DUPLICATES = 2
 MHTE_EXACT_ORDER = 1       # flags of mhte_table_sum_optimize_n
 MHTE_DEFER_SLOWPATH = 2
-MHTE_STEP_FINISH_NOW = 4   # flag of mhte_table_step_backward
 ABI_VERSION = 2            # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
@@ -102,7 +101,7 @@ EXPORTS = [
     "mhte_fill_with_offset_map", "mhte_fill_with_offset_map_gradient", "mhte_table_set_count_hits",
     "mhte_table_sum_optimize_n", "mhte_unique_unordered", "mhte_table_fused_backward_ok", "mhte_table_finish_pending",
     "mhte_table_step_forward", "mhte_table_step_backward", "mhte_profile_arm", "mhte_profile_read",
-    "mhte_trace_begin", "mhte_trace_end",
+    "mhte_trace_begin", "mhte_trace_end", "mhte_step_dedup",
 ]
 
 _lib = None
@@ -168,11 +167,10 @@ def vp(x):
   return C.c_void_p(x.data_ptr())
 
 
-PROFILE_TAGS = {1: "lookup_kernel", 2: "sum_apply_kernel", 3: "step_k1_kernel", 4: "step_k2_kernel",
-                5: "step_k3_kernel", 6: "slowpath_kernel", 7: "dd_kernels", 8: "upsert_kernel",
-                9: "step_ka_kernel"}
-TRACE_ROLES = {1: "dd_reset", 2: "dd_heavy_order", 3: "dd_insert", 4: "displacement", 5: "lookup",
-               6: "dd_place", 7: "backward_chunk", 8: "backward_id_major"}
+PROFILE_TAGS = {1: "lookup_kernel", 2: "sum_apply_kernel", 6: "slowpath_kernel", 7: "dd_kernels",
+                8: "upsert_kernel", 9: "step_fwd_kernel", 10: "step_bwd_kernel"}
+TRACE_ROLES = {3: "run_dedup", 4: "displacement", 5: "lookup", 6: "work_list", 7: "apply_items",
+               8: "apply_ids"}
 
 
 def profile_arm(n):

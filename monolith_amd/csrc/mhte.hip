@@ -22,7 +22,7 @@
 #include <vector>
 
 #include "../../include/monolith_amd_hash_table.h"
-#include "mhte_kernels.h"
+#include "mhte_step_kernels.h"
 
 namespace mhte {
 
@@ -75,8 +75,8 @@ static inline uint32_t ceil_log2(uint64_t n) {
 // kernel's own begin and end on its queue — the same interval rocprofv3 --kernel-trace reports —
 // instead of events recorded around the launch, which also contain the dispatch gap.
 enum ProfTag : int32_t {
-  kTagLookup = 1, kTagSumApply = 2, kTagStepK1 = 3, kTagStepK2 = 4, kTagStepK3 = 5,
-  kTagSlowpath = 6, kTagDedup = 7, kTagUpsert = 8, kTagStepKa = 9
+  kTagLookup = 1, kTagSumApply = 2,
+  kTagSlowpath = 6, kTagDedup = 7, kTagUpsert = 8, kTagStepFwd = 9, kTagStepBwd = 10
 };
 
 // Per-wavefront timeline of the step kernels (mhte_trace_begin / mhte_trace_end): each traced
@@ -185,7 +185,6 @@ struct DedupWs {
               uint32_t* seg_pos, uint32_t* n_unique_dev, hipStream_t st) {
     if (n < 0 || n > (int64_t(1) << 31) - 4096)
       throw Error(MHTE_INVALID_ARGUMENT, "unique: n out of range");
-    settle(st);
     last_n = n;
     if (n == 0) {
       HIP_OK(hipMemsetAsync(n_unique_dev, 0, sizeof(uint32_t), st));
@@ -218,52 +217,62 @@ struct DedupWs {
     }
   }
 
-  // --- pipelined step: the dedup of the next batch rides in the table kernels of the current one
-  bool pf_active = false;  // dd_insert_fast of `pf` is (being) launched, dd_place_fast not yet
-  bool pf_placed = false;  // ... dd_place_fast launched, dd_finish not yet (two-launch step)
-  NextBatch pf{};
-  // before the scratch is reused: complete a placed-but-unfinished dedup (its last third also
-  // resets the scratch); a dedup abandoned after its first third leaves the scratch dirty
-  void settle(hipStream_t st) {
-    finish_prefetch(st);
-    if (pf_active) {
-      pf_active = false;
-      clean_cap = 0;
+  // --- run dedup of the pipelined step (mhte_step_kernels.h); own scratch, independent of the
+  // list-building dedup above
+  DevBuf<int64_t> r_hkey, r_btab_key;
+  DevBuf<uint32_t> r_hcnt, r_uslot, r_btab_val, r_item_runs, r_ctr;
+  DevBuf<unsigned long long> r_hblk;
+  DevBuf<uint16_t> r_seg;
+  DevBuf<ItemHdr> r_item_hdr;
+  uint32_t r_clean_cap = 0;  // run scratch [0, r_clean_cap] is all-empty
+  int r_stage = 0;           // 0 idle, 1 dedup enqueued, 2 work list enqueued (ready for apply)
+  RunView rv{};
+
+  static uint32_t max_items(int64_t n) {
+    return uint32_t(n / 128 + n / (kLightMax + 1) + 2);
+  }
+
+  // Arguments of a run dedup of ids[0, n), n <= 65 536; the caller enqueues rd_dedup (on its own or
+  // inside step_fwd).  A dedup that was never applied leaves the scratch dirty: clear first.
+  RunView begin_run_dedup(const int64_t* ids, int64_t n, int64_t* uids, uint32_t* n_unique_dev,
+                          hipStream_t st) {
+    if (n <= 0 || n > int64_t(kRdMaxBlocks) * kRdBlock)
+      throw Error(MHTE_INVALID_ARGUMENT, "step: batch must have 1.." +
+                                             std::to_string(kRdMaxBlocks * kRdBlock) + " ids");
+    const uint32_t C = 1u << std::max<uint32_t>(10, ceil_log2(uint64_t(2) * n));
+    const int64_t* old_key = r_hkey.p;
+    const uint32_t* old_ctr = r_ctr.p;
+    r_hkey.reserve(size_t(C) + 2);
+    r_hcnt.reserve(size_t(C) + 2);
+    r_hblk.reserve(size_t(C) + 2);
+    r_ctr.reserve(4);
+    const uint32_t nblk = uint32_t((n + kRdBlock - 1) / kRdBlock);
+    r_uslot.reserve(size_t(n) + 1);
+    r_btab_key.reserve(size_t(nblk) * kRdStride);
+    r_btab_val.reserve(size_t(nblk) * kRdStride);
+    r_seg.reserve(size_t(nblk) * kRdBlock);
+    r_item_hdr.reserve(max_items(n));
+    r_item_runs.reserve(size_t(max_items(n)) * 64);
+    RunView d{};
+    d.hkey = r_hkey.p; d.hcnt = r_hcnt.p; d.hblk = r_hblk.p; d.cap_mask = C - 1;
+    d.uslot = r_uslot.p; d.btab_key = r_btab_key.p; d.btab_val = r_btab_val.p; d.seg = r_seg.p;
+    d.item_hdr = r_item_hdr.p; d.item_runs = r_item_runs.p; d.ctr = r_ctr.p;
+    d.ids = ids; d.n = uint32_t(n); d.nblk = nblk; d.uids = uids; d.n_unique = n_unique_dev;
+    if (r_hkey.p != old_key || r_ctr.p != old_ctr || C > r_clean_cap || r_stage != 0) {
+      rd_clear_kernel<<<(C + 2 + 255) / 256, 256, 0, st>>>(d);
+      r_clean_cap = C;
     }
+    rv = d;
+    r_stage = 1;
+    return d;
   }
-  // completes a dedup the pipelined step left unfinished (its last third normally rides in the
-  // next step_forward); lets any other consumer of the workspace proceed
-  void finish_prefetch(hipStream_t st) {
-    if (!pf_placed) return;
-    const uint32_t nb_rank = (pf.n + 1023) / 1024;
-    const uint32_t hgrid = std::min<uint32_t>(256, pf.n / (kLightMax + 1) + 1);
-    LAUNCH_HOT(kTagDedup, dd_finish_kernel, nb_rank + hgrid, 1024, st, pf.d, pf.n, nb_rank,
-               pf.inverse, pf.lst_start, pf.lst_end, pf.seg_pos, 0, pf.n_unique);
-    pf_placed = false;
-    last_n = pf.n;
+  // heavy work list of the deduplicated batch on its own (normally it rides in step_bwd)
+  void build_work_list(hipStream_t st) {
+    if (r_stage != 1) return;
+    rd_build_kernel<<<std::max<uint32_t>(1, std::min<uint32_t>(64, (rv.n + 255) / 256)), 256, 0,
+                      st>>>(rv, uint32_t(kLightMax));
     HIP_OK(hipGetLastError());
-  }
-  NextBatch begin_prefetch(const int64_t* ids, int64_t n, int64_t* uids, uint32_t* inverse,
-                           uint32_t* lst_start, uint32_t* lst_end, uint32_t* seg_pos,
-                           uint32_t* n_unique_dev, hipStream_t st) {
-    if (n <= 0 || n > (int64_t(1) << 31) - 4096)
-      throw Error(MHTE_INVALID_ARGUMENT, "prefetch: n out of range");
-    settle(st);
-    NextBatch nb;
-    nb.d = view(n, st);
-    nb.ids = ids;
-    nb.n = uint32_t(n);
-    nb.nblk = (nb.n + kDdBlock - 1) / kDdBlock;
-    nb.uids = uids;
-    nb.inverse = inverse;
-    nb.lst_start = lst_start;
-    nb.lst_end = lst_end;
-    nb.seg_pos = seg_pos;
-    nb.n_unique = n_unique_dev;
-    pf = nb;
-    pf_active = true;
-    last_n = -1;  // lists are not valid until the step's third launch has run
-    return nb;
+    r_stage = 2;
   }
 
   // Unordered dedup (3 launches): unique ids in unspecified order, list bounds per unique index,
@@ -273,7 +282,6 @@ struct DedupWs {
                         uint32_t* n_unique_dev, hipStream_t st) {
     if (n < 0 || n > (int64_t(1) << 31) - 4096)
       throw Error(MHTE_INVALID_ARGUMENT, "unique: n out of range");
-    settle(st);
     last_n = n;
     if (n == 0) {
       HIP_OK(hipMemsetAsync(n_unique_dev, 0, sizeof(uint32_t), st));
@@ -540,6 +548,39 @@ struct Table {
     finish_pending(st);  // a deferred displacement pass always precedes the next op on the table
     if (n <= 0) return;
     Shape sh = pick_shape(dim, vec_ok && aligned16(out));
+    // ---- sweep knobs (measurement only; removed once the best shape is fixed)
+    const int sw_unr = getenv("MHTE_LOOKUP_UNR") ? atoi(getenv("MHTE_LOOKUP_UNR")) : 0;
+    const int sw_blk = getenv("MHTE_LOOKUP_BLOCK") ? atoi(getenv("MHTE_LOOKUP_BLOCK")) : 256;
+    const int sw_nt = getenv("MHTE_LOOKUP_NT") ? atoi(getenv("MHTE_LOOKUP_NT")) : 0;
+    if (sw_unr > 0 && sh.VEC == 4 && sh.G == 16) {
+      const int64_t groups = (n + sw_unr - 1) / sw_unr;
+      const uint32_t g = uint32_t((groups * 16 + sw_blk - 1) / sw_blk);
+      TableView v = view;
+      v.trace = trace_region(kTagLookup, g, uint32_t(sw_blk));
+#define LK(U_, NT_, B_)                                                                        \
+  LAUNCH_HOT(kTagLookup, (lookup_kernel_u<16, 4, U_, NT_, B_>), g, B_, st, v, ids, n, n_dev, out, \
+             count_hits ? 1 : 0)
+#define LKB(U_, NT_)                                  \
+  do {                                                \
+    if (sw_blk == 256) { LK(U_, NT_, 256); }          \
+    else if (sw_blk == 512) { LK(U_, NT_, 512); }     \
+    else { LK(U_, NT_, 1024); }                       \
+  } while (0)
+#define LKN(U_)                                  \
+  do {                                           \
+    if (sw_nt) { LKB(U_, true); } else { LKB(U_, false); } \
+  } while (0)
+      if (sw_unr == 1) LKN(1);
+      else if (sw_unr == 2) LKN(2);
+      else if (sw_unr == 4) LKN(4);
+      else if (sw_unr == 8) LKN(8);
+      else LKN(16);
+#undef LKN
+#undef LKB
+#undef LK
+      HIP_OK(hipGetLastError());
+      return;
+    }
     const int64_t threads = n * sh.G;
     const dim3 grid(uint32_t((threads + 255) / 256));
     TableView v = view;
@@ -615,7 +656,6 @@ struct Table {
                     int64_t update_time, bool exact_order, bool defer_slowpath, hipStream_t st) {
     finish_pending(st);
     if (n <= 0 || n_max <= 0) return;
-    ws.finish_prefetch(st);
     if (n != ws.last_n)
       throw Error(MHTE_FAILED_PRECONDITION,
                   "sum_optimize: workspace does not hold the occurrence lists of this batch");
@@ -651,36 +691,15 @@ struct Table {
     if (!defer_slowpath) finish_pending(st);
   }
 
-  // ---------------------------------------------------------------- pipelined step
-  // Two launches per step (three with finish_now, the round-1 form kept for comparison):
-  //   step_forward   lookup of this batch | first third of the next batch's dedup
-  //                  | last third of this batch's dedup (ws_cur, when the previous step_backward
-  //                    left it placed-but-unfinished) | displacement pass of the previous update
-  //   step_backward  fused backward of this batch | second third of the next batch's dedup
-  void step_forward(const int64_t* ids, int64_t n, float* out, DedupWs* ws_cur, const NextBatch& nb,
-                    hipStream_t st) {
+  // ---------------------------------------------------------------- pipelined step (2 launches)
+  //   step_forward   lookup of this batch | run dedup of the next batch
+  //                  | displacement pass of the previous update (gated, usually idle)
+  //   step_backward  apply of this batch | heavy work list of the next batch
+  void step_forward(const int64_t* ids, int64_t n, float* out, const RunView& nxt, hipStream_t st) {
     if (n <= 0) throw Error(MHTE_INVALID_ARGUMENT, "step_forward: empty batch");
     Shape sh = pick_shape(dim, vec_ok && aligned16(out));
-    const uint32_t nblk_l = uint32_t((n * sh.G + 1023) / 1024);
-    const bool fin = ws_cur && ws_cur->pf_placed;
-    if (!fin && !pend_valid) {  // nothing to carry: the plain zipped launch
-      const dim3 grid(nb.nblk + nblk_l);
-      TableView v = view;
-      v.trace = trace_region(kTagStepK1, grid.x, 1024);
-#define CALL(G_, V_) \
-  LAUNCH_HOT(kTagStepK1, (step_k1_kernel<G_, V_>), grid, 1024, st, nb, v, ids, n, out, count_hits ? 1 : 0)
-      DISPATCH_G_VEC(sh, CALL);
-#undef CALL
-      HIP_OK(hipGetLastError());
-      return;
-    }
-    NextBatch cur{};
-    uint32_t nb_rank = 0, nfin = 0;
-    if (fin) {
-      cur = ws_cur->pf;
-      nb_rank = (cur.n + 1023) / 1024;
-      nfin = nb_rank + std::min<uint32_t>(256, cur.n / (kLightMax + 1) + 1);
-    }
+    const int64_t groups = (n + kLookupUnroll - 1) / kLookupUnroll;
+    const uint32_t nblk_l = uint32_t((groups * sh.G + kRdBlock - 1) / kRdBlock);
     SlowArgs sp{};
     sp.enabled = pend_valid ? 1 : 0;
     if (pend_valid) {
@@ -694,105 +713,87 @@ struct Table {
       }
       pend_valid = false;
     }
-    const dim3 grid(nfin + nb.nblk + uint32_t(sp.enabled) + nblk_l);
+    const dim3 grid(nxt.nblk + uint32_t(sp.enabled) + nblk_l);
     TableView v = view;
-    v.trace = trace_region(kTagStepKa, grid.x, 1024);
-#define CALL(G_, V_)                                                                            \
-  LAUNCH_HOT(kTagStepKa, (step_ka_kernel<G_, V_>), grid, 1024, st, cur, nb_rank, nfin, nb, v, ids, \
-             n, out, count_hits ? 1 : 0, sp)
+    v.trace = trace_region(kTagStepFwd, grid.x, kRdBlock);
+#define CALL(G_, V_)                                                                             \
+  LAUNCH_HOT(kTagStepFwd, (step_fwd_kernel<G_, V_>), grid, kRdBlock, st, nxt, v, ids, n, out, \
+             count_hits ? 1 : 0, sp)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
-    hipError_t le = hipGetLastError();
-    if (fin) {
-      ws_cur->pf_placed = false;
-      ws_cur->last_n = cur.n;
-      if (le != hipSuccess) ws_cur->clean_cap = 0;
-    }
-    HIP_OK(le);
+    HIP_OK(hipGetLastError());
   }
 
-  void step_backward(DedupWs& ws, DedupWs& ws_next, const int64_t* uids, int64_t n_max,
-                     const uint32_t* n_dev, const float* grads, const uint32_t* lst_start,
-                     const uint32_t* lst_end, const uint32_t* seg_pos, int64_t n, float* grad_u,
-                     const float* lrs, int64_t update_time, bool exact_order, bool finish_now,
-                     hipStream_t st) {
+  void step_backward(DedupWs& ws, DedupWs* ws_next, const int64_t* uids, int64_t n_max,
+                     const uint32_t* n_dev, const float* grads, int64_t n, float* grad_u,
+                     const float* lrs, int64_t update_time, bool exact_order, hipStream_t st) {
     finish_pending(st);
     if (n <= 0 || n_max <= 0) throw Error(MHTE_INVALID_ARGUMENT, "step_backward: empty batch");
-    ws.finish_prefetch(st);  // (normally done by step_forward)
-    if (n != ws.last_n)
+    if (ws.r_stage == 0 || int64_t(ws.rv.n) != n || ws.rv.uids != uids || ws.rv.n_unique != n_dev)
       throw Error(MHTE_FAILED_PRECONDITION,
-                  "step_backward: workspace does not hold the occurrence lists of this batch");
-    if (!ws_next.pf_active)
-      throw Error(MHTE_FAILED_PRECONDITION, "step_backward: no dedup was started by step_forward");
+                  "step_backward: workspace does not hold the run dedup of this batch");
+    ws.build_work_list(st);  // (first step of a pipeline; later ones were built a step ahead)
     ApplyArgs a;
     for (int i = 0; i < kMaxSegments; ++i) a.lr[i] = (lrs && i < int(nseg)) ? lrs[i] : 0.f;
     a.ts = static_cast<uint32_t>(update_time);
     a.sum_dups = 1;
-    ensure_capacity(uint64_t(n_max), st);
+    ensure_capacity(uint64_t(std::min<int64_t>(n_max, n)), st);
     Shape sh = pick_shape(dim, vec_ok && aligned16(grads) && aligned16(grad_u));
     pending.reserve(size_t(n_max) + 1);
-    BackwardArgs b;
-    b.uids = uids;
-    b.n_unique = n_dev;
-    b.n_max = n_max;
-    b.grads = grads;
-    b.lst_start = lst_start;
-    b.lst_end = lst_end;
-    b.seg_pos = seg_pos;
-    b.work = ws.work.p;
-    b.n_work = ws.heavy_n.p + 3;
-    b.nblk_b = exact_order ? 0u : uint32_t(n / kChunk + n / (kLightMax + 1) + 1);
-    b.light_max = exact_order ? 0xffffffffu : uint32_t(kLightMax);
-    ws.backward_scratch(n, dim, b.nblk_b, st);
-    b.part = ws.part.p;
-    b.arrive = ws.arrive.p;
-    b.grad_u = grad_u;
-    b.pending = pending.p;
-    const NextBatch nb = ws_next.pf;
-    const uint32_t nblk_a = uint32_t((n_max * sh.G + 255) / 256);
-    const dim3 grid2(nb.nblk + b.nblk_b + nblk_a);
+    const uint32_t cap_items = DedupWs::max_items(n);
+    ws.part.reserve(size_t(cap_items) * dim + 16);
+    {
+      const uint32_t* old = ws.arrive.p;
+      ws.arrive.reserve(size_t(n) + 2);
+      if (ws.arrive.p != old) ws.arrive_clean = 0;
+      if (ws.arrive_clean < size_t(n) + 2) {
+        HIP_OK(hipMemsetAsync(ws.arrive.p, 0, ws.arrive.cap * sizeof(uint32_t), st));
+        ws.arrive_clean = ws.arrive.cap;
+      }
+    }
+    ApplyCtl c{};
+    c.grads = grads;
+    c.grad_u = grad_u;
+    c.pending = pending.p;
+    c.part = ws.part.p;
+    c.arrive = ws.arrive.p;
+    c.n_max = n_max;
+    c.light_max = exact_order ? 0xffffffffu : uint32_t(kLightMax);
+    // fixed grids with grid-stride loops: item workgroups first (longest chain), sized for the
+    // work a Zipf batch has; more ids / items than workgroups just means more trips
+    const uint32_t groups_per_wg = uint32_t(256 / sh.G);
+    c.nblk_items = exact_order ? 0u : std::min<uint32_t>(cap_items, 512);
+    c.nblk_ids = std::max<uint32_t>(
+        1, std::min<uint32_t>(uint32_t((std::min<int64_t>(n_max, n) + groups_per_wg - 1) / groups_per_wg), 1024));
+    RunView nxt{};
+    uint32_t nblk_build = 0;
+    if (ws_next && ws_next->r_stage == 1) {
+      nxt = ws_next->rv;
+      nblk_build = std::max<uint32_t>(1, std::min<uint32_t>(64, (nxt.n + 255) / 256));
+    }
+    const dim3 grid(nblk_build + c.nblk_items + c.nblk_ids);
     TableView v = view;
-    v.trace = trace_region(kTagStepK2, grid2.x, 256);
-#define CALL(G_, V_) LAUNCH_HOT(kTagStepK2, (step_k2_kernel<G_, V_>), grid2, 256, st, nb, v, b, a)
+    v.trace = trace_region(kTagStepBwd, grid.x, 256);
+    const RunView cur = ws.rv;
+#define CALL(G_, V_) \
+  LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_>), grid, 256, st, nxt, nblk_build, v, cur, c, a)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
-    if (!finish_now) {
-      // two-launch step: the dedup's last third and the displacement pass ride in the next
-      // step_forward (or run on their own if anything else touches the workspace / table first)
-      hipError_t le2 = hipGetLastError();
-      ws_next.pf_active = false;
-      ws_next.pf_placed = true;
-      if (le2 != hipSuccess) {
-        ws_next.clean_cap = 0;
-        ws_next.pf_placed = false;
-        HIP_OK(le2);
-      }
-      pend_valid = true;
-      pend_uids = uids;
-      pend_grad = grad_u;
-      pend_args = a;
-      pend_vec = sh.VEC;
-      return;
-    }
-    const uint32_t nb_rank = (nb.n + 1023) / 1024;
-    const uint32_t hgrid = std::min<uint32_t>(256, nb.n / (kLightMax + 1) + 1);
-    const uint32_t nfin = nb_rank + hgrid;
-    v.trace = trace_region(kTagStepK3, nfin + 1, 1024);
-    if (sh.VEC == 4) {
-      LAUNCH_HOT(kTagStepK3, (step_k3_kernel<4>), nfin + 1, 1024, st, nb, nb_rank, nfin, v, uids,
-                 grad_u, a, pending.p);
-    } else {
-      LAUNCH_HOT(kTagStepK3, (step_k3_kernel<1>), nfin + 1, 1024, st, nb, nb_rank, nfin, v, uids,
-                 grad_u, a, pending.p);
-    }
     hipError_t le = hipGetLastError();
-    ws_next.pf_active = false;
+    ws.r_stage = 0;  // the apply leaves the scratch all-empty
+    if (nblk_build) ws_next->r_stage = 2;
     if (le != hipSuccess) {
-      ws_next.clean_cap = 0;
+      ws.r_clean_cap = 0;
+      if (ws_next) ws_next->r_clean_cap = 0;
       HIP_OK(le);
     }
-    ws_next.last_n = nb.n;
-    pend_valid = false;
+    // the displacement pass rides in the next step_forward (or runs on its own if anything else
+    // touches the table first)
+    pend_valid = true;
+    pend_uids = uids;
+    pend_grad = grad_u;
+    pend_args = a;
+    pend_vec = sh.VEC;
   }
 
   // displacement pass for the ids the last fused backward could not place (both buckets full);
@@ -1441,55 +1442,67 @@ mhte_status mhte_table_sum_optimize_n(mhte_multi_table* t, int32_t table, mhte_d
   });
 }
 
+mhte_status mhte_step_dedup(mhte_dedup_ws* ws, const int64_t* id, int64_t n, int64_t* unique_ids,
+                            uint32_t* n_unique_dev, void* stream) {
+  return guard([&] {
+    if (!ws || !id || !unique_ids || !n_unique_dev)
+      throw Error(MHTE_INVALID_ARGUMENT, "step_dedup: null argument");
+    HIP_OK(hipSetDevice(ws->ws.device));
+    hipStream_t st = S(stream);
+    const RunView d = ws->ws.begin_run_dedup(id, n, unique_ids, n_unique_dev, st);
+    LAUNCH_HOT(kTagDedup, rd_dedup_kernel, d.nblk, kRdBlock, st, d);
+    HIP_OK(hipGetLastError());
+    ws->ws.build_work_list(st);
+  });
+}
+
 mhte_status mhte_table_step_forward(mhte_multi_table* t, int32_t table, const int64_t* id,
-                                    int64_t n, float* embedding, mhte_dedup_ws* ws_cur,
-                                    mhte_dedup_ws* ws_next,
+                                    int64_t n, float* embedding, mhte_dedup_ws* ws_next,
                                     const int64_t* id_next, int64_t n_next,
-                                    int64_t* unique_ids_next, uint32_t* inverse_next,
-                                    uint32_t* list_start_next, uint32_t* list_end_next,
-                                    uint32_t* seg_pos_next, uint32_t* n_unique_dev_next,
+                                    int64_t* unique_ids_next, uint32_t* n_unique_dev_next,
                                     void* stream) {
   return guard([&] {
     Table& tb = table_at(t, table);
-    if (!ws_next || ws_next == ws_cur)
-      throw Error(MHTE_INVALID_ARGUMENT, "step_forward needs a workspace for the next batch, "
-                                         "distinct from the current one");
+    if (!tb.fusable())
+      throw Error(MHTE_INVALID_ARGUMENT, "step_forward: row too wide for the fused step");
     HIP_OK(hipSetDevice(t->device));
     std::lock_guard<std::mutex> g(tb.mu);
     hipStream_t st = S(stream);
-    const NextBatch nb = ws_next->ws.begin_prefetch(id_next, n_next, unique_ids_next, inverse_next,
-                                                    list_start_next, list_end_next, seg_pos_next,
-                                                    n_unique_dev_next, st);
-    tb.step_forward(id, n, embedding, ws_cur ? &ws_cur->ws : nullptr, nb, st);
+    RunView nxt{};
+    if (ws_next) {
+      if (!id_next || !unique_ids_next || !n_unique_dev_next)
+        throw Error(MHTE_INVALID_ARGUMENT, "step_forward: null argument for the next batch");
+      nxt = ws_next->ws.begin_run_dedup(id_next, n_next, unique_ids_next, n_unique_dev_next, st);
+    }
+    tb.step_forward(id, n, embedding, nxt, st);
   });
 }
 
 mhte_status mhte_table_step_backward(mhte_multi_table* t, int32_t table, mhte_dedup_ws* ws,
                                      mhte_dedup_ws* ws_next, const int64_t* unique_ids,
                                      int64_t n_max, const uint32_t* n_unique_dev,
-                                     const float* grads, const uint32_t* list_start,
-                                     const uint32_t* list_end, const uint32_t* seg_pos, int64_t n,
-                                     float* grad_unique, const float* learning_rate,
-                                     int64_t n_learning_rate, int64_t update_time,
-                                     int64_t global_step, int32_t flags, void* stream) {
+                                     const float* grads, int64_t n, float* grad_unique,
+                                     const float* learning_rate, int64_t n_learning_rate,
+                                     int64_t update_time, int64_t global_step, int32_t flags,
+                                     void* stream) {
   (void)global_step;
   return guard([&] {
     Table& tb = table_at(t, table);
-    if (!ws || !ws_next || ws == ws_next)
-      throw Error(MHTE_INVALID_ARGUMENT, "step_backward needs two distinct workspaces");
+    if (!ws || ws == ws_next)
+      throw Error(MHTE_INVALID_ARGUMENT, "step_backward needs the batch's workspace, distinct "
+                                         "from the next batch's");
     if (!learning_rate || n_learning_rate < int64_t(tb.nseg))
       throw Error(MHTE_INVALID_ARGUMENT, "The length of tensor `learning_rate` is too short.");
-    if (!n_unique_dev || !grad_unique)
+    if (!n_unique_dev || !grad_unique || !unique_ids || !grads)
       throw Error(MHTE_INVALID_ARGUMENT, "step_backward: null argument");
     if (!tb.fusable())
-      throw Error(MHTE_INVALID_ARGUMENT, "step_backward: row too wide for the fused backward");
+      throw Error(MHTE_INVALID_ARGUMENT, "step_backward: row too wide for the fused step");
     HIP_OK(hipSetDevice(t->device));
     std::lock_guard<std::mutex> g(tb.mu);
     tb.note_update_time(update_time);
-    tb.step_backward(ws->ws, ws_next->ws, unique_ids, n_max, n_unique_dev, grads, list_start,
-                     list_end, seg_pos, n, grad_unique, learning_rate, update_time,
-                     (flags & MHTE_EXACT_ORDER) != 0, (flags & MHTE_STEP_FINISH_NOW) != 0,
-                     S(stream));
+    tb.step_backward(ws->ws, ws_next ? &ws_next->ws : nullptr, unique_ids, n_max, n_unique_dev,
+                     grads, n, grad_unique, learning_rate, update_time,
+                     (flags & MHTE_EXACT_ORDER) != 0, S(stream));
   });
 }
 

@@ -177,6 +177,103 @@ __device__ __forceinline__ void lookup_role(const TableView& tv, const int64_t* 
     if (lane == 0 && hm) atomicAdd(&tv.ctr->hits, (unsigned long long)__popcll(hm));
   }
 }
+// Unrolled form: a G-lane group serves UNR consecutive ids with all UNR probes, then all UNR row
+// loads in flight at once.  A launch is bound by how many wavefronts the chip can start and hold
+// (profiles/r01/e_wave_timeline_2launch.md), not by bytes, so fewer, fatter wavefronts win:
+// B = 65 536 ids at dim 64 are 16 384 / UNR wavefronts.
+template <int VEC>
+__device__ __forceinline__ void store_stream(float* p, const Vec<VEC>& v) {
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) __builtin_nontemporal_store(v.v[c], p + c);
+}
+template <int G, int VEC, int UNR, bool NT>
+__device__ __forceinline__ void lookup_role_u(const TableView& tv, const int64_t* __restrict__ ids,
+                                              int64_t n, const uint32_t* __restrict__ n_dev,
+                                              float* __restrict__ out, int count_hits,
+                                              int64_t group, int gate) {
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (G - 1);
+  const int gbase = lane & ~(G - 1);
+  if (n_dev) n = min(n, int64_t(*n_dev));
+  const int64_t g0 = group * UNR;
+  if (g0 >= n) return;
+  // one 8-byte load per lane for the group's ids, then broadcast
+  const int64_t myid = (j < UNR && g0 + j < n) ? ids[g0 + j] : 0;
+  if (gate) {
+    if (__hip_atomic_load(&tv.ctr->n_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      while (__hip_atomic_load(&tv.ctr->n_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+        __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+  }
+  int64_t id[UNR];
+  bool valid[UNR], match[UNR];
+  uint32_t row[UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    id[u] = __shfl(myid, gbase + (u & (G - 1)));
+    valid[u] = g0 + u < n;
+    match[u] = false;
+    row[u] = kNoRow;
+    if (valid[u] && j < 8 && id[u] != kEmptyKey) {
+      const uint64_t hv = hash_key(id[u]);
+      const uint64_t i1 = index_hash(tv.hp, hv);
+      const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
+      const Bucket* b = tv.buckets + ((j < 4) ? i1 : i2);
+      const int64_t k = b->key[j & 3];
+      row[u] = b->row[j & 3];
+      match[u] = (k == id[u]);
+    }
+  }
+  bool found[UNR];
+  const float* rp[UNR];
+  uint64_t hits = 0;
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    const uint64_t m = group_mask_of<G>(__ballot(match[u]), gbase);
+    found[u] = m != 0;
+    const int src = found[u] ? (__ffsll(static_cast<long long>(m)) - 1) : 0;
+    uint32_t r = __shfl(row[u], gbase + src);
+    if (valid[u] && id[u] == kEmptyKey) {
+      found[u] = tv.ctr->special_state == 1;
+      r = tv.ctr->special_row;
+    }
+    found[u] = found[u] && valid[u];
+    rp[u] = found[u] ? row_ptr(tv, r) : nullptr;
+    if (count_hits) hits += __popcll(__ballot(found[u] && j == 0));
+  }
+  for (uint32_t e = j * VEC; e < tv.dim; e += G * VEC) {
+    Vec<VEC> v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (found[u]) {
+        v[u].load(rp[u] + e);
+      } else {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) v[u].v[c] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (valid[u]) {
+        float* op = out + (g0 + u) * int64_t(tv.dim) + e;
+        if (NT) store_stream<VEC>(op, v[u]); else v[u].store(op);
+      }
+    }
+  }
+  if (count_hits && lane == 0 && hits) atomicAdd(&tv.ctr->hits, (unsigned long long)hits);
+}
+template <int G, int VEC, int UNR, bool NT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void lookup_kernel_u(TableView tv,
+                                                         const int64_t* __restrict__ ids, int64_t n,
+                                                         const uint32_t* __restrict__ n_dev,
+                                                         float* __restrict__ out, int count_hits) {
+  WaveTrace wt(tv.trace);
+  lookup_role_u<G, VEC, UNR, NT>(tv, ids, n, n_dev, out, count_hits,
+                                 (int64_t(blockIdx.x) * BLOCK + threadIdx.x) / G, 0);
+  wt.end(5u);
+}
+
 template <int G, int VEC>
 __global__ __launch_bounds__(256) void lookup_kernel(TableView tv, const int64_t* __restrict__ ids,
                                                      int64_t n, const uint32_t* __restrict__ n_dev,
@@ -1814,169 +1911,6 @@ __global__ __launch_bounds__(256) void sum_apply_kernel(
   wt.end(blockIdx.x < nblk_b ? 7u : 8u);
 }
 
-
-// =============================================================================================
-// Pipelined training step: three launches on ONE queue, each doing the table work of batch s and a
-// third of the dedup of batch s+1 side by side in different workgroups (the dedup depends on the
-// ids only).  Cross-queue dependencies cost ~10 us each on this part, same-queue kernel
-// boundaries next to nothing, so the two chains are zipped into one instead of being run on two
-// streams:
-//   step_k1  dd_insert_fast(s+1) | lookup(s)
-//   step_k2  dd_place_fast(s+1)  | sum_apply(s)
-//   step_k3  dd_finish(s+1)      | slowpath(s)
-// Dedup workgroups come first in the grid (few, latency-bound).  Launches 1 and 3 use 1024-thread
-// workgroups; launch 2 uses 256 (what sum_apply wants), its dedup role taking 4 positions per thread.
-// =============================================================================================
-struct NextBatch {  // dedup of the following batch (mhte_unique_unordered's arguments)
-  DedupView d;
-  const int64_t* ids;
-  uint32_t n;
-  uint32_t nblk;  // ceil(n / kDdBlock); 0 = no next batch
-  int64_t* uids;
-  uint32_t* inverse;
-  uint32_t* lst_start;
-  uint32_t* lst_end;
-  uint32_t* seg_pos;
-  uint32_t* n_unique;
-};
-
-template <int G, int VEC>
-__global__ __launch_bounds__(1024) void step_k1_kernel(NextBatch nb, TableView tv,
-                                                       const int64_t* __restrict__ ids, int64_t n,
-                                                       float* __restrict__ out, int count_hits) {
-  WaveTrace wt(tv.trace);
-  if (blockIdx.x < nb.nblk) {
-    dd_insert_fast_role(nb.d, nb.ids, nb.n, nb.uids, blockIdx.x);
-    wt.end(3u);
-  } else {
-    lookup_role<G, VEC>(tv, ids, n, nullptr, out, count_hits, blockIdx.x - nb.nblk);
-    wt.end(5u);
-  }
-}
-
-// Two-launch form of the pipelined step (the dedup of a batch is spread over one and a half steps
-// so that no launch exists for the dedup's sake alone):
-//   step_ka(s)  dd_finish(s) | dd_insert_fast(s+1) | displacement pass of update s-1 | lookup(s)
-//   step_k2(s)  dd_place_fast(s+1) | sum_apply(s)
-// The displacement pass (ids of update s-1 whose two buckets were full; usually none) is one
-// wavefront of launch ka; the lookup workgroups gate on its completion (lookup_role).
-struct SlowArgs {  // slowpath_role's arguments; enabled = 0: no pass outstanding
-  const int64_t* uids;
-  const float* grad_u;
-  const uint32_t* pending;
-  ApplyArgs a;
-  int32_t enabled;
-};
-
-template <int G, int VEC>
-__global__ __launch_bounds__(1024) void step_ka_kernel(NextBatch cur, uint32_t nb_rank,
-                                                       uint32_t nfin, NextBatch nxt, TableView tv,
-                                                       const int64_t* __restrict__ ids, int64_t n,
-                                                       float* __restrict__ out, int count_hits,
-                                                       SlowArgs sp) {
-  // one LDS region serves the heavy-list bitmap and the displacement pass's BFS queue
-  static_assert(sizeof(BfsSlot) * kMaxCuckooCount + sizeof(CuckooRecord) * kMaxBfsPathLen <=
-                    sizeof(uint32_t) * kBmWords, "BFS scratch must fit the bitmap region");
-  __shared__ __attribute__((aligned(16))) uint32_t bm[kBmWords + 16];
-  WaveTrace wt(tv.trace);
-  uint32_t bid = blockIdx.x;
-  if (bid < nfin) {
-    dd_finish_role(cur.d, cur.n, nb_rank, cur.inverse, cur.lst_start, cur.lst_end, cur.seg_pos, 0,
-                   cur.n_unique, bid, nfin, bm);
-    wt.end(bid < nb_rank ? 1u : 2u);
-    return;
-  }
-  bid -= nfin;
-  if (bid < nxt.nblk) {
-    dd_insert_fast_role(nxt.d, nxt.ids, nxt.n, nxt.uids, bid);
-    wt.end(3u);
-    return;
-  }
-  bid -= nxt.nblk;
-  if (sp.enabled) {
-    if (bid == 0) {
-      if (threadIdx.x < 64) {
-        BfsSlot* q = reinterpret_cast<BfsSlot*>(bm);
-        CuckooRecord* path = reinterpret_cast<CuckooRecord*>(q + kMaxCuckooCount);
-        slowpath_role<VEC, kOpOptimize, false, true>(tv, sp.uids, sp.grad_u, nullptr, nullptr, sp.a,
-                                                     nullptr, sp.pending, q, path);
-      }
-      wt.end(4u);
-      return;
-    }
-    bid -= 1;
-  }
-  lookup_role<G, VEC>(tv, ids, n, nullptr, out, count_hits, bid, sp.enabled);
-  wt.end(5u);
-}
-
-struct BackwardArgs {  // sum_apply_role's arguments
-  const int64_t* uids;
-  const uint32_t* n_unique;
-  int64_t n_max;
-  const float* grads;
-  const uint32_t* lst_start;
-  const uint32_t* lst_end;
-  const uint32_t* seg_pos;
-  const uint32_t* work;
-  const uint32_t* n_work;
-  uint32_t nblk_b;
-  uint32_t light_max;
-  float* part;
-  uint32_t* arrive;
-  float* grad_u;
-  uint32_t* pending;
-};
-
-template <int G, int VEC>
-__global__ __launch_bounds__(256) void step_k2_kernel(NextBatch nb, TableView tv, BackwardArgs b,
-                                                      ApplyArgs a) {
-  WaveTrace wt(tv.trace);
-  if (blockIdx.x < nb.nblk) {
-    dd_place_fast_role<256>(nb.d, nb.n, nb.inverse, nb.lst_start, nb.lst_end, nb.seg_pos,
-                            blockIdx.x);
-    wt.end(6u);
-  } else {
-    sum_apply_role<G, VEC, 256>(tv, b.uids, b.n_unique, b.n_max, b.grads, b.lst_start, b.lst_end,
-                                 b.seg_pos, b.work, b.n_work, b.nblk_b, b.light_max, b.part,
-                                 b.arrive, b.grad_u, a, b.pending, blockIdx.x - nb.nblk);
-    if (tv.trace) {  // 9 / 10: wavefronts that found no work (past the device-side counts)
-      const uint32_t rb = blockIdx.x - nb.nblk;
-      uint32_t role;
-      if (rb < b.nblk_b) {
-        role = rb < *b.n_work ? 7u : 10u;
-      } else {
-        const int64_t g0 = (int64_t(rb - b.nblk_b) * 256 + (threadIdx.x & ~63)) / G;
-        role = g0 < min(b.n_max, int64_t(*b.n_unique)) ? 8u : 9u;
-      }
-      wt.end(role);
-    }
-  }
-}
-
-template <int VEC>
-__global__ __launch_bounds__(1024) void step_k3_kernel(NextBatch nb, uint32_t nb_rank,
-                                                       uint32_t nfin, TableView tv,
-                                                       const int64_t* __restrict__ uids,
-                                                       const float* __restrict__ grad_u,
-                                                       ApplyArgs a,
-                                                       const uint32_t* __restrict__ pending) {
-  __shared__ __attribute__((aligned(16))) uint32_t bm[kBmWords + 16];
-  WaveTrace wt(tv.trace);
-  if (blockIdx.x < nfin) {
-    dd_finish_role(nb.d, nb.n, nb_rank, nb.inverse, nb.lst_start, nb.lst_end, nb.seg_pos, 0,
-                   nb.n_unique, blockIdx.x, nfin, bm);
-    wt.end(blockIdx.x < nb_rank ? 1u : 2u);
-  } else {
-    if (threadIdx.x < 64) {
-      BfsSlot* q = reinterpret_cast<BfsSlot*>(bm);
-      CuckooRecord* path = reinterpret_cast<CuckooRecord*>(q + kMaxCuckooCount);
-      slowpath_role<VEC, kOpOptimize, false>(tv, uids, grad_u, nullptr, nullptr, a, nullptr, pending,
-                                             q, path);
-    }
-    wt.end(4u);
-  }
-}
 
 // value_offset[q] = base + (seg_pos[q] * dim)   (the float offsets the reference op emits)
 __global__ __launch_bounds__(256) void offsets_from_positions_kernel(

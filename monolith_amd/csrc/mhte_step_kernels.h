@@ -1,0 +1,749 @@
+// Pipelined training step of one table (mhte_table_step_forward / _backward): two launches per
+// step, every wavefront of which has work.  Included by mhte.hip after mhte_kernels.h.
+//
+// What bounds a launch at B = 65 536 ids is not bytes but (a) the number of dependent memory round
+// trips on the longest chain and (b) how many wavefronts must be started and held
+// (profiles/r01/e_wave_timeline_2launch.md: the list-building dedup needed three dependent
+// phases — insert, place with cross-workgroup waits, heavy-list ordering — of 9-20 us each, and the
+// backward launched 21 000 wavefronts that found no work).  Hence:
+//
+//  * RUN DEDUP (rd_dedup_role) — ONE phase instead of three.  Workgroup b owns positions
+//    [1024 b, 1024 b + 1024).  It deduplicates them in an LDS hash set, claims each distinct id's slot
+//    in a global scratch hash (CAS; the claimer numbers the id), ORs bit b into the id's 64-bit
+//    workgroup mask and adds its occurrence count; the positions are grouped by id INSIDE the
+//    workgroup's own 1024-entry region ("runs", each sorted ascending), and the LDS table
+//    (id -> run offset, length, first position) is dumped as is.  No list space is allocated
+//    globally, nobody waits for anybody, and since workgroups are position ranges, "runs in
+//    workgroup order" IS occurrence order — nothing is left to sort.
+//  * HEAVY WORK LIST (rd_build_role) — ids with > kLightMax occurrences are cut into items of
+//    ~256 entries (a power-of-two range of workgroups each), with their run descriptors copied next
+//    to the item.  Rides in the previous step's backward launch.
+//  * APPLY (rd_apply_role) — fixed-size grid with grid-stride loops.  Id-major groups: probe of the
+//    table, workgroup mask and count in one round trip; run table(s) and the row itself in the
+//    next; gradients; optimizer.  Item workgroups: 16 gradient rows in flight per group, LDS adds
+//    the groups in order, multi-item ids hand over through write-through partial rows.
+//
+// Summation order: every id's gradients are added in ascending position order inside a light list
+// (bit-identical to the reference's sequential sum, unique_mapping_ops.cc:307-324); a heavy list is
+// a fixed tree over (item, group, window) that depends on the positions only — deterministic, fp32
+// re-association only.  MHTE_EXACT_ORDER sums every list strictly sequentially.
+#ifndef MHTE_STEP_KERNELS_H_
+#define MHTE_STEP_KERNELS_H_
+
+#include "mhte_kernels.h"
+
+namespace mhte {
+
+constexpr int kRdBlock = 1024;          // positions per dedup workgroup (one per thread)
+constexpr int kRdLds = 2048;            // LDS hash entries per workgroup
+constexpr int kRdStride = kRdLds + 1;   // + side entry for kEmptyKey
+constexpr int kRdMaxBlocks = 64;        // bits of the workgroup mask: n <= 65 536 positions
+constexpr uint32_t kItemTarget = 256;   // entries per heavy work item (expected)
+
+// run descriptor: first local position | offset in the workgroup's region | length (0..1024)
+__device__ __forceinline__ uint32_t run_pack(uint32_t first, uint32_t off, uint32_t cnt) {
+  return (first << 21) | (off << 11) | cnt;
+}
+__device__ __forceinline__ uint32_t run_cnt(uint32_t v) { return v & 0x7ffu; }
+__device__ __forceinline__ uint32_t run_off(uint32_t v) { return (v >> 11) & 0x3ffu; }
+__device__ __forceinline__ uint32_t run_first(uint32_t v) { return v >> 21; }
+
+struct ItemHdr {   // one heavy work item: workgroups [b0, b0 + nbk) of list u
+  int64_t id;
+  uint32_t u;      // unique index
+  uint32_t meta;   // b0 | nbk << 8 | k << 16 | nitems << 24   (nbk 1..64, k < nitems <= 64)
+};
+
+struct RunView {
+  // global scratch hash, capacity cap_mask + 1 (+1 side slot); all-empty between uses
+  int64_t* hkey;
+  uint32_t* hcnt;               // occurrences of the slot's id in the batch
+  unsigned long long* hblk;     // mask of the workgroups that hold a run of it
+  uint32_t cap_mask;
+  // per batch
+  uint32_t* uslot;              // [n] scratch slot of unique index u
+  int64_t* btab_key;            // [nblk][kRdStride] dumped LDS tables
+  uint32_t* btab_val;           // [nblk][kRdStride] run_pack
+  uint16_t* seg;                // [nblk * 1024] local positions grouped by run, ascending in a run
+  ItemHdr* item_hdr;            // heavy work items
+  uint32_t* item_runs;          // [items][64] run_pack of workgroup b0 + t (0: no run)
+  uint32_t* ctr;                // [0] unique counter, [1] workgroups done, [2] number of items
+  const int64_t* ids;
+  uint32_t n;
+  uint32_t nblk;                // ceil(n / 1024) <= 64; 0 = nothing to do
+  int64_t* uids;                // out: unique ids, unspecified order
+  uint32_t* n_unique;           // out
+};
+
+__global__ __launch_bounds__(256) void rd_clear_kernel(RunView d) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= d.cap_mask + 1u) {
+    d.hkey[i] = kEmptyKey;
+    d.hcnt[i] = 0;
+    d.hblk[i] = 0ull;
+  }
+  if (i < 4) d.ctr[i] = 0;
+}
+
+__device__ __forceinline__ uint32_t rd_claim(const RunView& d, int64_t id, bool* claimed) {
+  *claimed = false;
+  if (id == kEmptyKey) {
+    const uint32_t s = d.cap_mask + 1u;
+    const unsigned long long old =
+        atomicCAS(reinterpret_cast<unsigned long long*>(&d.hkey[s]),
+                  static_cast<unsigned long long>(kEmptyKey), 0ull);
+    *claimed = static_cast<int64_t>(old) == kEmptyKey;
+    return s;
+  }
+  uint32_t s = uint32_t(hash_key(id)) & d.cap_mask;
+  for (;;) {
+    int64_t k = d.hkey[s];
+    if (k == kEmptyKey) {
+      k = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hkey[s]),
+                                         static_cast<unsigned long long>(kEmptyKey),
+                                         static_cast<unsigned long long>(id)));
+      if (k == kEmptyKey) {
+        *claimed = true;
+        return s;
+      }
+    }
+    if (k == id) return s;
+    s = (s + 1u) & d.cap_mask;
+  }
+}
+
+// LDS of the dedup role; the caller declares it (and may alias it with other roles' scratch)
+struct RdLds {
+  unsigned long long key[kRdStride];
+  uint32_t cnt[kRdStride];
+  uint32_t off[kRdStride];
+  uint32_t first[kRdStride];
+  uint16_t pos[kRdBlock];
+  uint32_t wtot[16];
+  uint32_t nclaim, base;
+};
+
+// probe start of an id in a workgroup's dumped table (the side entry for kEmptyKey)
+__device__ __forceinline__ uint32_t rd_home(int64_t id) {
+  return uint32_t(hash_key(id) >> 40) & (kRdLds - 1);
+}
+
+__device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, RdLds& L) {
+  const uint32_t t = threadIdx.x;
+  for (uint32_t i = t; i < uint32_t(kRdStride); i += kRdBlock) {
+    L.key[i] = static_cast<unsigned long long>(kEmptyKey);
+    L.cnt[i] = 0;
+  }
+  if (t == 0) L.nclaim = 0;
+  if (bid == 0 && t == 0) d.ctr[2] = 0;  // the work list of this batch is built after this launch
+  __syncthreads();
+  const uint32_t p = bid * kRdBlock + t;
+  const bool valid = p < d.n;
+  uint32_t ls = 0, arr = 0;
+  int64_t id = 0;
+  if (valid) {
+    id = d.ids[p];
+    if (id == kEmptyKey) {
+      ls = kRdLds;
+    } else {
+      ls = rd_home(id);
+      for (;;) {
+        unsigned long long k = L.key[ls];
+        if (k == static_cast<unsigned long long>(kEmptyKey)) {
+          k = atomicCAS(&L.key[ls], static_cast<unsigned long long>(kEmptyKey),
+                        static_cast<unsigned long long>(id));
+          if (k == static_cast<unsigned long long>(kEmptyKey)) break;
+        }
+        if (k == static_cast<unsigned long long>(id)) break;
+        ls = (ls + 1u) & (kRdLds - 1);
+      }
+    }
+    arr = atomicAdd(&L.cnt[ls], 1u);
+    if (arr == 0) L.first[ls] = t;
+  }
+  __syncthreads();
+  // ---- the run's first arrival speaks for the whole run in the global scratch
+  bool claimed = false;
+  uint32_t gs = 0, crank = 0;
+  if (valid && arr == 0) {
+    gs = rd_claim(d, id, &claimed);
+    atomicAdd(&d.hcnt[gs], L.cnt[ls]);
+    atomicOr(&d.hblk[gs], 1ull << bid);
+    if (claimed) crank = atomicAdd(&L.nclaim, 1u);
+  }
+  // ---- run offsets: exclusive scan of the LDS counts (two entries per thread, side entry last)
+  {
+    const uint32_t a = L.cnt[2 * t], b = L.cnt[2 * t + 1];
+    uint32_t incl = a + b;
+    const int lane = t & 63, w = t >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) L.wtot[w] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) woff += (i < w) ? L.wtot[i] : 0u;
+    const uint32_t excl = woff + incl - (a + b);
+    L.off[2 * t] = excl;
+    L.off[2 * t + 1] = excl + a;
+    if (t == kRdBlock - 1) L.off[kRdLds] = woff + incl;
+  }
+  __syncthreads();
+  if (t == 0 && L.nclaim) L.base = atomicAdd(&d.ctr[0], L.nclaim);
+  if (valid) L.pos[L.off[ls] + arr] = uint16_t(t);  // grouped by run, arrival order
+  __syncthreads();
+  if (claimed) {
+    const uint32_t u = L.base + crank;
+    d.uids[u] = id;
+    d.uslot[u] = gs;
+  }
+  // ---- ascending order inside the run: rank = number of smaller positions in it
+  if (valid) {
+    const uint32_t c = L.cnt[ls], o = L.off[ls];
+    uint32_t rank = 0;
+    if (c > 1) {
+      for (uint32_t i = 0; i < c; ++i) rank += (uint32_t(L.pos[o + i]) < t) ? 1u : 0u;
+    }
+    d.seg[bid * kRdBlock + o + rank] = uint16_t(t);
+  }
+  // ---- the LDS table is the workgroup's run directory
+  for (uint32_t i = t; i < uint32_t(kRdStride); i += kRdBlock) {
+    d.btab_key[size_t(bid) * kRdStride + i] = static_cast<int64_t>(L.key[i]);
+    d.btab_val[size_t(bid) * kRdStride + i] = run_pack(L.first[i] & 0x3ffu, L.off[i] & 0x3ffu, L.cnt[i]);
+  }
+  // ---- the last workgroup publishes the unique count and re-arms the counters
+  if (t == 0) {
+    if (atomicAdd(&d.ctr[1], 1u) == d.nblk - 1) {
+      *d.n_unique = atomicAdd(&d.ctr[0], 0u);
+      d.ctr[0] = 0;
+      d.ctr[1] = 0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kRdBlock) void rd_dedup_kernel(RunView d) {
+  __shared__ RdLds L;
+  rd_dedup_role(d, blockIdx.x, L);
+}
+
+// run descriptor of `id` in workgroup b's table (the id is known to have a run there)
+__device__ __forceinline__ uint32_t rd_find_run(const RunView& d, uint32_t b, int64_t id) {
+  const int64_t* kt = d.btab_key + size_t(b) * kRdStride;
+  uint32_t ls = (id == kEmptyKey) ? uint32_t(kRdLds) : rd_home(id);
+  if (id != kEmptyKey) {
+    int left = kRdLds;  // (bounded: a directory that lacks the id would mean a corrupted dedup)
+    while (kt[ls] != id) {
+      if (--left == 0) return 0u;
+      ls = (ls + 1u) & (kRdLds - 1);
+    }
+  }
+  return d.btab_val[size_t(b) * kRdStride + ls];
+}
+
+// workgroups per item for a list of c occurrences: power of two, ~kItemTarget entries expected
+__device__ __forceinline__ uint32_t rd_item_blocks(uint32_t c) {
+  uint32_t nbk = 64;
+  while (nbk > 1 && uint64_t(c) * nbk > uint64_t(kItemTarget) * 64 * 2) nbk >>= 1;
+  return nbk;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Heavy work list of a deduplicated batch.  256-thread workgroups, grid-stride over unique ids;
+// one wavefront per heavy id (lane = workgroup index of a potential run).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_max, uint32_t bid,
+                                              uint32_t nblocks) {
+  __shared__ uint32_t l_heavy[256];
+  __shared__ uint32_t l_nheavy;
+  const uint32_t t = threadIdx.x;
+  const int lane = t & 63, w = t >> 6;
+  const uint32_t nu = *d.n_unique;
+  for (uint32_t base = bid * 256u; base < nu; base += nblocks * 256u) {
+    if (t == 0) l_nheavy = 0;
+    __syncthreads();
+    const uint32_t u = base + t;
+    if (u < nu) {
+      const uint32_t c = d.hcnt[d.uslot[u]];
+      if (c > light_max) l_heavy[atomicAdd(&l_nheavy, 1u)] = u;
+    }
+    __syncthreads();
+    const uint32_t nh = l_nheavy;
+    for (uint32_t h = w; h < nh; h += 4) {
+      const uint32_t hu = l_heavy[h];
+      const int64_t id = d.uids[hu];
+      const uint32_t gs = d.uslot[hu];
+      const uint32_t c = d.hcnt[gs];
+      const unsigned long long bm = d.hblk[gs];
+      const bool has = (bm >> lane) & 1ull;
+      const uint32_t val = has ? rd_find_run(d, uint32_t(lane), id) : 0u;
+      const uint32_t nbk = rd_item_blocks(c);
+      const uint32_t b0 = uint32_t(lane) & ~(nbk - 1u);
+      const unsigned long long rmask =
+          (nbk == 64 ? ~0ull : ((1ull << nbk) - 1ull)) << b0;
+      const bool leader = (uint32_t(lane) == b0) && (bm & rmask) != 0ull;
+      const unsigned long long lm = __ballot(leader);
+      const uint32_t nitems = __popcll(lm);
+      uint32_t w0 = 0;
+      if (lane == 0) w0 = atomicAdd(&d.ctr[2], nitems);
+      w0 = __shfl(w0, 0);
+      // item index of this lane's range = rank of its leader among the leaders
+      const uint32_t k = __popcll(lm & ((1ull << b0) - 1ull));
+      if (leader) {
+        ItemHdr hd;
+        hd.id = id;
+        hd.u = hu;
+        hd.meta = b0 | (nbk << 8) | (k << 16) | (nitems << 24);
+        d.item_hdr[w0 + k] = hd;
+      }
+      if ((bm & rmask) != 0ull) d.item_runs[size_t(w0 + k) * 64 + (uint32_t(lane) - b0)] = val;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void rd_build_kernel(RunView d, uint32_t light_max) {
+  rd_build_role(d, light_max, blockIdx.x, gridDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Apply: duplicate-gradient sum + upsert + optimizer of a deduplicated batch.
+// ---------------------------------------------------------------------------------------------
+struct ApplyCtl {
+  const float* grads;
+  float* grad_u;          // [n_max, dim] summed gradients of ids deferred to the displacement pass
+  uint32_t* pending;
+  float* part;            // [items, dim] partial rows of multi-item lists
+  uint32_t* arrive;       // [n] arrival counters, kept zeroed
+  int64_t n_max;
+  uint32_t light_max;     // 0xffffffff: every list strictly sequential (MHTE_EXACT_ORDER)
+  uint32_t nblk_items;    // workgroups [0, nblk_items) take work items, the rest ids
+  uint32_t nblk_ids;
+};
+
+// row of a found id, fetched while the gradient chain is in flight
+template <int VEC>
+struct RowRegs {
+  Vec<VEC> w, s1, s2;
+};
+
+template <int VEC>
+__device__ __forceinline__ void row_prefetch(const TableView& tv, const float* rp, uint32_t e,
+                                             RowRegs<VEC>& r) {
+  if (e >= tv.dim) return;
+  uint32_t k = 0;
+  while (k + 1 < tv.nseg && e >= uint32_t(tv.seg[k + 1].w_off)) ++k;
+  const SegDesc sd = tv.seg[k];
+  const uint32_t le = e - sd.w_off;
+  r.w.load(rp + e);
+  if (sd.opt == kOptAdagrad || sd.opt == kOptFtrl) r.s1.load(rp + sd.st_off + le);
+  if (sd.opt == kOptFtrl) r.s2.load(rp + sd.st_off + sd.dim + le);
+}
+
+// one optimizer step with the row already in registers (is_new: start from the initializer)
+template <int VEC>
+__device__ __forceinline__ void optimize_row_pre(const TableView& tv, float* rp, bool is_new,
+                                                 uint32_t e, const Vec<VEC>& g, const ApplyArgs& a,
+                                                 RowRegs<VEC>& r) {
+  if (e >= tv.dim) return;
+  uint32_t k = 0;
+  while (k + 1 < tv.nseg && e >= uint32_t(tv.seg[k + 1].w_off)) ++k;
+  const SegDesc sd = tv.seg[k];
+  const uint32_t le = e - sd.w_off;
+  const float lr = a.lr[k];
+  float* st1 = rp + sd.st_off + le;
+  float* st2 = st1 + sd.dim;
+  const bool has1 = sd.opt == kOptAdagrad || sd.opt == kOptFtrl;
+  const bool has2 = sd.opt == kOptFtrl;
+  if (is_new) {
+    const float w0 = init_weight(sd);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      r.w.v[c] = w0;
+      r.s1.v[c] = sd.p[0];
+      r.s2.v[c] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) {
+    if (sd.opt == kOptSgd) {
+      r.w.v[c] = sgd_step(r.w.v[c], g.v[c], lr);
+    } else if (sd.opt == kOptAdagrad) {
+      adagrad_step(r.w.v[c], r.s1.v[c], g.v[c], lr, sd.p[1]);
+    } else {
+      ftrl_step(r.w.v[c], r.s1.v[c], r.s2.v[c], g.v[c], lr, sd.p[1], sd.p[2], sd.p[3]);
+    }
+  }
+  r.w.store(rp + e);
+  if (has1) r.s1.store(st1);
+  if (has2) r.s2.store(st2);
+}
+
+// Probe state of one id per G-lane group, split in two so the caller can put work between the
+// bucket loads and their use.
+template <int G>
+struct Probe {
+  Bucket* b;
+  int64_t k;
+  uint32_t row;
+};
+template <int G>
+__device__ __forceinline__ Probe<G> probe_issue(const TableView& tv, int64_t id, bool valid, int j) {
+  const uint64_t hv = hash_key(id);
+  const uint64_t i1 = index_hash(tv.hp, hv);
+  const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
+  Probe<G> p;
+  p.b = tv.buckets + ((j < 4) ? i1 : i2);
+  p.k = kEmptyKey;
+  p.row = kNoRow;
+  if (valid && id != kEmptyKey && j < 8) {
+    p.k = p.b->key[j & 3];
+    p.row = p.b->row[j & 3];
+  }
+  return p;
+}
+
+// Sum of grads[pos[q]] for q in [0, c) in list order, positions in LDS, 8 rows in flight.
+template <int VEC>
+__device__ __forceinline__ void sum_list_lds(const float* __restrict__ grads, uint32_t dim,
+                                             uint32_t e, bool ev, const uint32_t* pos, uint32_t c,
+                                             Vec<VEC>& acc) {
+#pragma unroll 1
+  for (uint32_t q = 0; q < c; q += 8) {
+    uint32_t ps[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) ps[t] = (q + t < c) ? pos[q + t] : 0u;
+    Vec<VEC> v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) vec_zero(v[t]);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      if (q + t < c && ev) v[t].load(grads + int64_t(ps[t]) * dim + e);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      if (q + t < c && ev) vec_add(acc, v[t]);
+  }
+}
+
+template <int G, int VEC>
+__device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView& d,
+                                              const ApplyCtl& c, const ApplyArgs& a, uint32_t bid) {
+  constexpr int WIN = G < 16 ? G : 16;
+  constexpr int NG = 256 / G;  // groups per workgroup
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (G - 1);
+  const int gbase = lane & ~(G - 1);
+  const int grp = threadIdx.x / G;
+  const uint32_t dim = tv.dim;
+  const uint32_t e = uint32_t(j) * VEC;
+  const bool ev = e < dim;
+
+  if (bid >= c.nblk_items) {
+    // ------------------------------------------------------------------ id-major groups
+    __shared__ uint32_t sh_pos[NG][kLightMax];
+    const int64_t nu = min(c.n_max, int64_t(*d.n_unique));
+    const int64_t stride = int64_t(c.nblk_ids) * NG;
+#pragma unroll 1
+    for (int64_t gb = int64_t(bid - c.nblk_items) * NG; gb < nu; gb += stride) {  // block-uniform
+      const int64_t g = gb + grp;
+      bool valid = g < nu;
+      const int64_t id = valid ? d.uids[g] : 0;
+      const uint32_t gs = valid ? d.uslot[g] : 0u;
+      // round trip 2: table probe | occurrence count and workgroup mask
+      Probe<G> pr = probe_issue<G>(tv, id, valid, j);
+      uint32_t cnt = 0;
+      unsigned long long bm = 0ull;
+      if (valid) {
+        cnt = d.hcnt[gs];
+        bm = d.hblk[gs];
+      }
+      if (valid && j == 0) {  // clean-after-use: the scratch is all-empty again after this launch
+        d.hkey[gs] = kEmptyKey;
+        d.hcnt[gs] = 0;
+        d.hblk[gs] = 0ull;
+      }
+      if (cnt > c.light_max) valid = false;  // heavy list: the item workgroups own it
+      const bool big = valid && cnt > uint32_t(kLightMax);  // (exact order only)
+      // round trip 3: run descriptors (lane j: the j-th run, then the (j+G)-th ...) | the row
+      const uint32_t nr = valid ? uint32_t(__popcll(bm)) : 0u;
+      Vec<VEC> acc;
+      vec_zero(acc);
+      const SlotResult sr = upsert_resolve<G>(tv, pr.b, id, valid, pr.k, pr.row, lane, a.ts);
+      RowRegs<VEC> rr;
+      vec_zero(rr.w);
+      vec_zero(rr.s1);
+      vec_zero(rr.s2);
+      float* rp = nullptr;
+      if (valid && !sr.deferred) {
+        rp = row_ptr(tv, sr.r);
+        if (!sr.is_new) row_prefetch<VEC>(tv, rp, e, rr);
+      }
+      if (!big) {
+        // flat list of <= kLightMax positions in LDS, runs in workgroup order
+        uint32_t filled = 0;
+        unsigned long long rest = bm;
+#pragma unroll 1
+        for (uint32_t r0 = 0; r0 < nr; r0 += G) {  // group-uniform
+          // my run: the (r0 + j)-th set bit
+          unsigned long long m = rest;
+          for (int s = 0; s < j; ++s) m &= m - 1ull;
+          const bool mine = valid && (r0 + uint32_t(j) < nr) && m != 0ull;
+          const uint32_t b = mine ? uint32_t(__ffsll(static_cast<long long>(m)) - 1) : 0u;
+          const uint32_t val = mine ? rd_find_run(d, b, id) : 0u;
+          const uint32_t cb = run_cnt(val);
+          // offsets of the runs inside the flat list: exclusive scan over the group's lanes
+          uint32_t incl = cb;
+#pragma unroll
+          for (int o = 1; o < G; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, G);
+            if (j >= o) incl += v;
+          }
+          const uint32_t off = filled + incl - cb;
+          if (mine) {
+            if (cb == 1) {
+              sh_pos[grp][off] = b * kRdBlock + run_first(val);
+            } else {
+              const uint16_t* sp = d.seg + b * kRdBlock + run_off(val);
+#pragma unroll 1
+              for (uint32_t i = 0; i < cb; ++i) sh_pos[grp][off + i] = b * kRdBlock + sp[i];
+            }
+          }
+          filled += __shfl(incl, gbase + G - 1);
+          for (int s = 0; s < G && rest; ++s) rest &= rest - 1ull;
+        }
+      }
+      __syncthreads();
+      if (valid && !big) sum_list_lds<VEC>(c.grads, dim, e, ev, sh_pos[grp], cnt, acc);
+      if (big) {
+        // strictly sequential sum of a long list (MHTE_EXACT_ORDER): run after run
+        unsigned long long rest = bm;
+#pragma unroll 1
+        while (rest) {
+          const uint32_t b = uint32_t(__ffsll(static_cast<long long>(rest)) - 1);
+          rest &= rest - 1ull;
+          const uint32_t val = rd_find_run(d, b, id);
+          const uint32_t cb = run_cnt(val);
+          const uint16_t* sp = d.seg + b * kRdBlock + run_off(val);
+#pragma unroll 1
+          for (uint32_t i = 0; i < cb; i += 8) {
+            Vec<VEC> v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) vec_zero(v[t]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+              if (i + t < cb && ev)
+                v[t].load(c.grads + int64_t(b * kRdBlock + sp[i + t]) * dim + e);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+              if (i + t < cb && ev) vec_add(acc, v[t]);
+          }
+        }
+      }
+      if (sr.deferred) {
+        if (ev) acc.store(c.grad_u + g * int64_t(dim) + e);
+        if (j == 0) c.pending[atomicAdd(&tv.ctr->n_pending, 1u)] = uint32_t(g);
+      } else if (valid) {
+        optimize_row_pre<VEC>(tv, rp, sr.is_new, e, acc, a, rr);
+      }
+      __syncthreads();  // sh_pos is reused
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- item workgroups
+  __shared__ uint32_t sh_rstart[65];   // first flat entry of run t of the item
+  __shared__ uint32_t sh_rval[64];
+  __shared__ float sh_sum[NG][G * VEC];
+  __shared__ uint32_t sh_last;
+  const uint32_t nitems_all = d.ctr[2];
+#pragma unroll 1
+  for (uint32_t w = bid; w < nitems_all; w += c.nblk_items) {  // block-uniform
+    const ItemHdr hd = d.item_hdr[w];
+    const uint32_t b0 = hd.meta & 0xffu, nbk = (hd.meta >> 8) & 0xffu, kk = (hd.meta >> 16) & 0xffu,
+                   nitems = hd.meta >> 24;
+    // the table probe of the id goes out now and is used by whoever applies (wave 0, group 0)
+    Probe<G> pr = probe_issue<G>(tv, hd.id, threadIdx.x < G, j);
+    if (threadIdx.x < 64) {
+      const uint32_t val = (uint32_t(lane) < nbk) ? d.item_runs[size_t(w) * 64 + lane] : 0u;
+      uint32_t incl = run_cnt(val);
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      sh_rval[lane] = val;
+      sh_rstart[lane + 1] = incl;
+      if (lane == 0) sh_rstart[0] = 0;
+    }
+    __syncthreads();
+    const uint32_t E = sh_rstart[64];
+    Vec<VEC> acc;
+    vec_zero(acc);
+#pragma unroll 1
+    for (uint32_t qb = uint32_t(grp) * WIN; qb < E; qb += NG * WIN) {  // this group's windows
+      uint32_t p = kNone;
+      if (j < WIN && qb + j < E) {
+        const uint32_t q = qb + j;
+        uint32_t lo = 0, hi = 63;  // run r with rstart[r] <= q < rstart[r+1]
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi + 1) >> 1;
+          if (sh_rstart[mid] <= q) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t val = sh_rval[lo];
+        const uint32_t i = q - sh_rstart[lo];
+        const uint32_t b = b0 + lo;
+        p = b * kRdBlock + ((run_cnt(val) == 1) ? run_first(val)
+                                                 : uint32_t(d.seg[b * kRdBlock + run_off(val) + i]));
+      }
+      Vec<VEC> v[WIN];
+#pragma unroll
+      for (int t = 0; t < WIN; ++t) vec_zero(v[t]);
+#pragma unroll
+      for (int t = 0; t < WIN; ++t) {
+        const uint32_t pt = __shfl(p, gbase + t);
+        if (qb + t < E && ev) v[t].load(c.grads + int64_t(pt) * dim + e);
+      }
+#pragma unroll
+      for (int t = 0; t < WIN; ++t)
+        if (qb + t < E && ev) vec_add(acc, v[t]);
+    }
+#pragma unroll
+    for (int cc = 0; cc < VEC; ++cc) sh_sum[grp][j * VEC + cc] = acc.v[cc];
+    __syncthreads();
+    Vec<VEC> tot;  // groups in order -> the item's sum (wave 0 holds it; group 0 uses it)
+    vec_zero(tot);
+    if (threadIdx.x < 64) {
+#pragma unroll 1
+      for (int g2 = 0; g2 < NG; ++g2) {
+#pragma unroll
+        for (int cc = 0; cc < VEC; ++cc) tot.v[cc] = tot.v[cc] + sh_sum[g2][j * VEC + cc];
+      }
+    }
+    bool apply = nitems == 1;  // block-uniform
+    if (nitems > 1) {
+      // partial row per item (the items of a list are consecutive), write-through hand-off
+      if (threadIdx.x < G && ev) store_wt<VEC>(c.part + int64_t(w) * dim + e, tot);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const uint32_t last = (atomicAdd(&c.arrive[hd.u], 1u) == nitems - 1) ? 1u : 0u;
+        if (last) c.arrive[hd.u] = 0;  // clean-after-use
+        sh_last = last;
+      }
+      __syncthreads();
+      if (sh_last) {  // add the item sums in item order (fixed association), then apply
+        apply = true;
+        const uint32_t w0 = w - kk;
+        const uint32_t per = (nitems + NG - 1) / NG;
+        const uint32_t k0 = min(nitems, uint32_t(grp) * per), k1 = min(nitems, k0 + per);
+        Vec<VEC> sacc;
+        vec_zero(sacc);
+#pragma unroll 1
+        for (uint32_t q = k0; q < k1; q += 8) {
+          Vec<VEC> r[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) vec_zero(r[t]);
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            if (q + t < k1 && ev) load_agent<VEC>(c.part + int64_t(w0 + q + t) * dim + e, r[t]);
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            if (q + t < k1 && ev) vec_add(sacc, r[t]);
+        }
+        __syncthreads();  // sh_sum is reused
+#pragma unroll
+        for (int cc = 0; cc < VEC; ++cc) sh_sum[grp][j * VEC + cc] = sacc.v[cc];
+        __syncthreads();
+        vec_zero(tot);
+        if (threadIdx.x < 64) {
+          for (int g2 = 0; g2 < NG && uint32_t(g2) * per < nitems; ++g2) {
+#pragma unroll
+            for (int cc = 0; cc < VEC; ++cc) tot.v[cc] = tot.v[cc] + sh_sum[g2][j * VEC + cc];
+          }
+        }
+      }
+    }
+    if (apply && threadIdx.x < 64) {
+      const bool valid = threadIdx.x < G;
+      const SlotResult sr = upsert_resolve<G>(tv, pr.b, hd.id, valid, pr.k, pr.row, lane, a.ts);
+      if (sr.deferred) {
+        if (ev) tot.store(c.grad_u + int64_t(hd.u) * dim + e);
+        if (j == 0) c.pending[atomicAdd(&tv.ctr->n_pending, 1u)] = hd.u;
+      } else if (valid) {
+        optimize_row_reg<VEC>(tv, row_ptr(tv, sr.r), sr.is_new, e, tot, a);
+      }
+    }
+    __syncthreads();  // LDS is reused by the next item
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The two launches.
+// ---------------------------------------------------------------------------------------------
+struct SlowArgs {  // slowpath_role's arguments; enabled = 0: no displacement pass outstanding
+  const int64_t* uids;
+  const float* grad_u;
+  const uint32_t* pending;
+  ApplyArgs a;
+  int32_t enabled;
+};
+
+constexpr int kLookupUnroll = 2;  // ids per group of the forward lookup (scripts/lookup_sweep.py)
+
+// step_fwd:  run dedup of the NEXT batch | displacement pass of the previous update (one wavefront,
+//            the lookup workgroups gate on it) | lookup of this batch
+template <int G, int VEC>
+__global__ __launch_bounds__(kRdBlock) void step_fwd_kernel(RunView nxt, TableView tv,
+                                                            const int64_t* __restrict__ ids,
+                                                            int64_t n, float* __restrict__ out,
+                                                            int count_hits, SlowArgs sp) {
+  __shared__ __attribute__((aligned(16))) RdLds L;
+  static_assert(sizeof(BfsSlot) * kMaxCuckooCount + sizeof(CuckooRecord) * kMaxBfsPathLen <=
+                    sizeof(RdLds), "BFS scratch must fit the dedup's LDS");
+  WaveTrace wt(tv.trace);
+  uint32_t bid = blockIdx.x;
+  if (bid < nxt.nblk) {
+    rd_dedup_role(nxt, bid, L);
+    wt.end(3u);
+    return;
+  }
+  bid -= nxt.nblk;
+  if (sp.enabled) {
+    if (bid == 0) {
+      if (threadIdx.x < 64) {
+        BfsSlot* q = reinterpret_cast<BfsSlot*>(&L);
+        CuckooRecord* path = reinterpret_cast<CuckooRecord*>(q + kMaxCuckooCount);
+        slowpath_role<VEC, kOpOptimize, false, true>(tv, sp.uids, sp.grad_u, nullptr, nullptr, sp.a,
+                                                     nullptr, sp.pending, q, path);
+      }
+      wt.end(4u);
+      return;
+    }
+    bid -= 1;
+  }
+  lookup_role_u<G, VEC, kLookupUnroll, true>(tv, ids, n, nullptr, out, count_hits,
+                                             (int64_t(bid) * kRdBlock + threadIdx.x) / G,
+                                             sp.enabled);
+  wt.end(5u);
+}
+
+// step_bwd:  heavy work list of the NEXT batch | apply of this batch
+template <int G, int VEC>
+__global__ __launch_bounds__(256, 4) void step_bwd_kernel(RunView nxt, uint32_t nblk_build,
+                                                       TableView tv, RunView cur, ApplyCtl c,
+                                                       ApplyArgs a) {
+  WaveTrace wt(tv.trace);
+  if (blockIdx.x < nblk_build) {
+    rd_build_role(nxt, uint32_t(kLightMax), blockIdx.x, nblk_build);
+    wt.end(6u);
+    return;
+  }
+  const uint32_t bid = blockIdx.x - nblk_build;
+  rd_apply_role<G, VEC>(tv, cur, c, a, bid);
+  wt.end(bid < c.nblk_items ? 7u : 8u);
+}
+
+}  // namespace mhte
+#endif  // MHTE_STEP_KERNELS_H_

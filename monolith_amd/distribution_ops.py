@@ -76,6 +76,14 @@ class DedupWorkspace:
     return UniqueResult(uids, inverse, seg_off, seg_pos, nu,
                         int(host.value) if want_host_count else None)
 
+  def step_dedup(self, ids: torch.Tensor, uids: torch.Tensor, n_unique_dev: torch.Tensor):
+    """Run dedup of the FIRST batch of a pipelined step (mhte_step_dedup): unique ids in
+    unspecified order + count on the device; the occurrence runs stay in this workspace for
+    ``MultiHashTable.table_step_backward``."""
+    assert ids.is_cuda and ids.dtype == torch.int64 and ids.is_contiguous()
+    check(self._lib.mhte_step_dedup(self._h, vp(ids), C.c_int64(ids.numel()), vp(uids),
+                                    vp(n_unique_dev), _stream()))
+
   def unique_unordered(self, ids: torch.Tensor, want_host_count: bool = False,
                        out: Optional[UniqueResult] = None) -> UniqueResult:
     """Same key set and occurrence lists as ``unique`` with an unspecified numbering of the unique

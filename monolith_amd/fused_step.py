@@ -9,20 +9,24 @@ stage on the GPU and no host round trip inside the step:
    duplicate-gradient sum (occurrence order)      MonolithFillWithOffsetMapGradient   } one fused
    optimizer apply on the unique ids              MonolithMultiHashTableOptimize      } launch
 
-The unique-id count stays in device memory; kernels are launched for the batch-size upper bound
-and mask themselves.
+The unique-id count stays in device memory; kernels are launched with fixed grids and mask / loop
+themselves.
 
 Pipelining.  The dedup depends on the ids only, not on the table, so — like the reference's
 prefetch queue in front of the lookup (distributed_ps_sync.py:199-203) — the dedup of batch s+1 is
-done while batch s is looked up and updated: ``forward(ids, next_ids=...)``.  The two chains are
-zipped into the SAME launches (mhte_table_step_forward / _backward: different workgroups of one
-kernel do the jobs), because a dependency between two HIP queues costs ~10 us on this part and a
-kernel boundary on one queue next to nothing.  ``launches=2`` (default): a batch's dedup spans one
-and a half steps — its last third and the displacement pass of the previous update ride in the
-next forward launch — so a step is exactly two launches.  ``launches=3`` completes both in a third
-launch at the end of ``backward``.  Two dedup workspaces / result buffers alternate so the two
-batches never share scratch.  Without ``next_ids`` the dedup of the current batch runs on a side
-stream beside the lookup."""
+done while batch s is looked up and updated: ``forward(ids, next_ids=...)``.  A step is then exactly
+TWO launches on one queue (mhte_table_step_forward / _backward, csrc/mhte_step_kernels.h):
+
+   forward   lookup(s)  | run dedup(s+1) | displacement pass of update s-1 (usually idle)
+   backward  gradient sum + upsert + optimizer(s) | heavy work list(s+1)
+
+different workgroups of one kernel doing the jobs (a dependency between two HIP queues costs ~10 us
+on this part, a kernel boundary on one queue ~2 us).  Two dedup workspaces / result buffers
+alternate so the two batches never share scratch.  Batches of up to 65 536 ids.
+
+Without ``next_ids`` (and for rows too wide for the fused kernels) the step runs unpipelined: the
+list-building dedup (mhte_unique_unordered / mhte_unique) on a side stream beside the lookup, then
+mhte_table_sum_optimize_n."""
 from typing import Optional
 
 import numpy as np
@@ -32,14 +36,14 @@ from monolith_amd import _lib
 from monolith_amd.distribution_ops import DedupWorkspace, UniqueResult
 from monolith_amd.multi_hash_table_ops import MultiHashTable
 
+MAX_PIPELINED_BATCH = 65536  # 64 dedup workgroups x 1024 positions (mhte_step_kernels.h)
+
 
 class SparseStep:
 
   def __init__(self, table: MultiHashTable, table_name: str, batch: int,
                exact_order: bool = False, direct: bool = True, fused_backward: bool = True,
-               ordered_unique: bool = False, launches: int = 2):
-    assert launches in (2, 3)
-    self.launches = launches
+               ordered_unique: bool = False):
     self.direct = direct
     self.fused_backward = fused_backward
     # the reference's first-occurrence numbering of the unique ids is only needed by the unfused
@@ -49,7 +53,8 @@ class SparseStep:
     self.name = table_name
     self.idx = table._index(table_name)  # pylint: disable=protected-access
     self.dim = table.get_table_dim_sizes()[self.idx]
-    if not table._lib.mhte_table_fused_backward_ok(table.handle, self.idx):  # pylint: disable=protected-access
+    self.fusable = bool(table._lib.mhte_table_fused_backward_ok(table.handle, self.idx))  # pylint: disable=protected-access
+    if not self.fusable:
       self.ordered_unique = True  # wide rows: segment sum + optimize on CSR lists
     self.batch = batch
     self.exact_order = exact_order
@@ -57,22 +62,23 @@ class SparseStep:
     self.side = torch.cuda.Stream(device=dev)
     n = batch
 
-    def result():
-      return UniqueResult(torch.empty(n, dtype=torch.int64, device=dev),
-                          torch.empty(n, dtype=torch.int32, device=dev),
-                          torch.empty(n + 1, dtype=torch.int32, device=dev),
-                          torch.empty(n, dtype=torch.int32, device=dev),
-                          torch.zeros(1, dtype=torch.int32, device=dev), None,
-                          None if self.ordered_unique else
-                          torch.empty(n + 1, dtype=torch.int32, device=dev))
-
-    # two slots: the batch being trained and the batch being deduplicated ahead of it
+    # unpipelined path: list-building dedup
+    self._ws0 = DedupWorkspace(dev.index)
+    self._u0 = UniqueResult(torch.empty(n, dtype=torch.int64, device=dev),
+                            torch.empty(n, dtype=torch.int32, device=dev),
+                            torch.empty(n + 1, dtype=torch.int32, device=dev),
+                            torch.empty(n, dtype=torch.int32, device=dev),
+                            torch.zeros(1, dtype=torch.int32, device=dev), None,
+                            None if self.ordered_unique else
+                            torch.empty(n + 1, dtype=torch.int32, device=dev))
+    # pipelined path: two slots — the batch being trained and the batch deduplicated ahead of it
     self._ws = [DedupWorkspace(dev.index), DedupWorkspace(dev.index)]
-    self._u = [result(), result()]
-    self._done = None           # event: the side-stream dedup of the current batch finished
-    self._key = [None, None]    # (data_ptr, numel) of the ids whose lists the slot holds
-    self._pending_next = None   # dedup of the next batch started by step_forward
+    self._uids = [torch.empty(n, dtype=torch.int64, device=dev) for _ in range(2)]
+    self._nu = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
+    self._key = [None, None]    # (data_ptr, numel) of the ids whose run dedup the slot holds
     self._cur = 0
+    self._mode = None           # "pipe" / "plain": how the current batch was deduplicated
+    self._done = None           # event: the side-stream dedup of the current batch finished
     self._joined = True
     self.emb_u = torch.empty((n, self.dim), dtype=torch.float32, device=dev)
     self.emb = torch.empty((n, self.dim), dtype=torch.float32, device=dev)
@@ -81,21 +87,20 @@ class SparseStep:
     self.lrs = np.ascontiguousarray(
         table.learning_rate[lr0:lr0 + table._slice_sizes[self.idx]])  # pylint: disable=protected-access
 
-  # the slot of the batch being trained
+  # unpipelined dedup state (used by the bench's per-kernel timing pass too)
   @property
   def ws(self) -> DedupWorkspace:
-    return self._ws[self._cur]
+    return self._ws0
 
   @property
   def u(self) -> UniqueResult:
-    return self._u[self._cur]
+    return self._u0
 
-  def _unique(self, ids, slot=None):
-    slot = self._cur if slot is None else slot
+  def _unique(self, ids):
     if self.ordered_unique:
-      self._ws[slot].unique(ids, want_host_count=False, out=self._u[slot])
+      self._ws0.unique(ids, want_host_count=False, out=self._u0)
     else:
-      self._ws[slot].unique_unordered(ids, want_host_count=False, out=self._u[slot])
+      self._ws0.unique_unordered(ids, want_host_count=False, out=self._u0)
 
   def forward(self, ids: torch.Tensor, next_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Rows for every occurrence.  ``direct`` (default): ONE probe+gather kernel over the B
@@ -107,44 +112,48 @@ class SparseStep:
     assert ids.numel() == self.batch
     main = torch.cuda.current_stream()
     if not self.direct:
-      self._cur = 0
       self._unique(ids)
       self.table.table_lookup_n(self.idx, self.u.unique_ids, self.u.n_unique_dev, self.emb_u,
                                 n_max=self.batch)
       self.ws.gather_rows(self.emb_u, self.u.inverse, self.batch, self.dim, out=self.emb)
       self._joined = True
+      self._mode = "plain"
       return self.emb
     key = (ids.data_ptr(), ids.numel())
+    pipelined = (self.fusable and self.fused_backward and not self.ordered_unique and
+                 self.batch <= MAX_PIPELINED_BATCH)
     other = 1 - self._cur
-    zipped = next_ids is not None and not self.ordered_unique and self.fused_backward
-    ws_cur = None
-    if self._key[other] == key:
-      self._cur = other          # deduplicated ahead of time by the previous step
-      self._joined = True
-      ws_cur = self._ws[other]   # (two-launch step: its last third rides in this forward)
-    elif zipped:
-      self._unique(ids)          # first step of a pipeline: dedup in stream order
-      self._joined = True
-    else:
-      # the dedup (needed by backward only) runs on the side stream beside the lookup
-      here = torch.cuda.Event()
-      here.record(main)
-      self.side.wait_event(here)
-      with torch.cuda.stream(self.side):
-        self._unique(ids)
-        ev = torch.cuda.Event()
-        ev.record(self.side)
-      self._done = ev
-      self._joined = False
-    if zipped:
-      assert next_ids.numel() == self.batch
+    have = pipelined and self._key[other] == key   # deduplicated ahead by the previous step
+    if have or (pipelined and next_ids is not None):
+      if have:
+        self._cur = other
+      else:  # first step of a pipeline: dedup in stream order
+        self._ws[self._cur].step_dedup(ids, self._uids[self._cur], self._nu[self._cur])
+        self._key[self._cur] = key
       nxt = 1 - self._cur
-      self.table.table_step_forward(self.idx, ids, self.emb, self._ws[nxt], self._u[nxt], next_ids,
-                                    ws_cur=ws_cur)
-      self._pending_next = (next_ids.data_ptr(), next_ids.numel())
-    else:
-      self.table.table_lookup_n(self.idx, ids, None, self.emb, n_max=self.batch)
-      self._pending_next = None
+      if next_ids is not None:
+        assert next_ids.numel() == self.batch
+        self.table.table_step_forward(self.idx, ids, self.emb, self._ws[nxt], next_ids,
+                                      self._uids[nxt], self._nu[nxt])
+        self._key[nxt] = (next_ids.data_ptr(), next_ids.numel())
+      else:
+        self.table.table_step_forward(self.idx, ids, self.emb)
+        self._key[nxt] = None
+      self._mode = "pipe"
+      self._joined = True
+      return self.emb
+    # unpipelined: the dedup (needed by backward only) runs on the side stream beside the lookup
+    here = torch.cuda.Event()
+    here.record(main)
+    self.side.wait_event(here)
+    with torch.cuda.stream(self.side):
+      self._unique(ids)
+      ev = torch.cuda.Event()
+      ev.record(self.side)
+    self._done = ev
+    self._joined = False
+    self._mode = "plain"
+    self.table.table_lookup_n(self.idx, ids, None, self.emb, n_max=self.batch)
     return self.emb
 
   def _join(self):
@@ -154,14 +163,13 @@ class SparseStep:
 
   def backward(self, grads: torch.Tensor, update_time: int, global_step: int = 0):
     self._join()
-    if self._pending_next is not None:
-      nxt = 1 - self._cur
-      self.table.table_step_backward(self.idx, self.ws, self._ws[nxt], self.u, grads, self.grad_u,
-                                     self.lrs, update_time, global_step,
-                                     exact_order=self.exact_order,
-                                     finish_now=(self.launches == 3))
-      self._key[nxt] = self._pending_next
-      self._pending_next = None
+    if self._mode == "pipe":
+      cur, nxt = self._cur, 1 - self._cur
+      ws_next = self._ws[nxt] if self._key[nxt] is not None else None
+      self.table.table_step_backward(self.idx, self._ws[cur], ws_next, self._uids[cur],
+                                     self._nu[cur], grads, self.grad_u, self.lrs, update_time,
+                                     global_step, exact_order=self.exact_order)
+      self._key[cur] = None  # the slot's runs are consumed
     elif self.fused_backward:
       # one launch: per-id gradient sum + upsert + optimizer (mhte_table_sum_optimize_n)
       self.table.table_sum_optimize_n(self.idx, self.ws, self.u, grads, self.grad_u, self.lrs,
@@ -172,7 +180,6 @@ class SparseStep:
       self.table.table_optimize_n(self.idx, self.u.unique_ids, self.u.n_unique_dev, self.grad_u,
                                   self.lrs, update_time, global_step, flags=_lib.MHTE_IDS_UNIQUE,
                                   n_max=self.batch)
-    self._key[self._cur] = None  # the slot's lists are consumed
 
   def quiesce(self):
     """Host-synchronise and forget the side-stream event.  Call before capturing steps into a
@@ -183,4 +190,6 @@ class SparseStep:
 
   def n_unique(self) -> int:
     self._join()
+    if self._mode == "pipe":
+      return int(self._nu[self._cur].item())
     return int(self.u.n_unique_dev.item())

@@ -408,34 +408,35 @@ class MultiHashTable:
     check(self._lib.mhte_table_finish_pending(self._h, C.c_int32(i), _stream()))
     return self
 
-  # pipelined step: the dedup of the next batch rides in the launches of the current one
-  def table_step_forward(self, name_or_idx, ids: torch.Tensor, out: torch.Tensor, ws_next, u_next,
-                         next_ids: torch.Tensor, ws_cur=None):
-    """mhte_table_step_forward.  ``ws_cur``: the workspace holding this batch's dedup when the
-    previous ``table_step_backward`` left its last third to this launch (two-launch step)."""
+  # pipelined step: the dedup of the next batch rides in the two launches of the current one
+  def table_step_forward(self, name_or_idx, ids: torch.Tensor, out: torch.Tensor, ws_next=None,
+                         next_ids: Optional[torch.Tensor] = None,
+                         uids_next: Optional[torch.Tensor] = None,
+                         n_unique_next: Optional[torch.Tensor] = None):
+    """mhte_table_step_forward: lookup of ``ids`` + run dedup of ``next_ids`` into ``ws_next``
+    (+ the displacement pass the previous ``table_step_backward`` left)."""
     i = name_or_idx if isinstance(name_or_idx, int) else self._index(name_or_idx)
     check(self._lib.mhte_table_step_forward(
         self._h, C.c_int32(i), vp(ids), C.c_int64(ids.numel()), vp(out),
-        ws_cur._h if ws_cur is not None else C.c_void_p(0),  # pylint: disable=protected-access
-        ws_next._h,  # pylint: disable=protected-access
-        vp(next_ids), C.c_int64(next_ids.numel()), vp(u_next.unique_ids), vp(u_next.inverse),
-        vp(u_next.seg_off), vp(u_next.list_end), vp(u_next.seg_pos), vp(u_next.n_unique_dev),
-        _stream()))
+        ws_next._h if ws_next is not None else C.c_void_p(0),  # pylint: disable=protected-access
+        vp(next_ids), C.c_int64(next_ids.numel() if next_ids is not None else 0), vp(uids_next),
+        vp(n_unique_next), _stream()))
     return out
 
-  def table_step_backward(self, name_or_idx, ws, ws_next, u, grads: torch.Tensor,
+  def table_step_backward(self, name_or_idx, ws, ws_next, uids: torch.Tensor,
+                          n_unique_dev: torch.Tensor, grads: torch.Tensor,
                           grad_unique: torch.Tensor, lrs: np.ndarray, update_time: int,
-                          global_step: int = 0, exact_order: bool = False,
-                          finish_now: bool = False):
+                          global_step: int = 0, exact_order: bool = False):
+    """mhte_table_step_backward: gradient sum + upsert + optimizer of the batch ``ws`` holds
+    (+ the heavy work list of the batch ``ws_next`` holds)."""
     i = name_or_idx if isinstance(name_or_idx, int) else self._index(name_or_idx)
     lrs = np.ascontiguousarray(lrs, dtype=np.float32)
-    n = u.inverse.numel()
+    n = grads.shape[0]
     check(self._lib.mhte_table_step_backward(
-        self._h, C.c_int32(i), ws._h, ws_next._h, vp(u.unique_ids), C.c_int64(n),  # pylint: disable=protected-access
-        vp(u.n_unique_dev), vp(grads), vp(u.seg_off), vp(u.list_end), vp(u.seg_pos), C.c_int64(n),
+        self._h, C.c_int32(i), ws._h,  # pylint: disable=protected-access
+        ws_next._h if ws_next is not None else C.c_void_p(0),  # pylint: disable=protected-access
+        vp(uids), C.c_int64(uids.numel()), vp(n_unique_dev), vp(grads), C.c_int64(n),
         vp(grad_unique), _f32p(lrs), C.c_int64(lrs.size), C.c_int64(int(update_time)),
-        C.c_int64(int(global_step)),
-        C.c_int32((_lib.MHTE_EXACT_ORDER if exact_order else 0) |
-                  (_lib.MHTE_STEP_FINISH_NOW if finish_now else 0)),
+        C.c_int64(int(global_step)), C.c_int32(_lib.MHTE_EXACT_ORDER if exact_order else 0),
         _stream()))
     return self

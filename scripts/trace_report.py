@@ -8,9 +8,8 @@ import sys
 
 import numpy as np
 
-ROLES = {1: "dd_reset", 2: "dd_heavy_order", 3: "dd_insert", 4: "displacement", 5: "lookup",
-         6: "dd_place", 7: "backward_chunk", 8: "backward_id_major", 9: "backward_id_major(idle)",
-         10: "backward_chunk(idle)", 0: "(no record)"}
+ROLES = {3: "run_dedup", 4: "displacement", 5: "lookup", 6: "work_list", 7: "apply_items",
+         8: "apply_ids", 0: "(no record)"}
 
 
 def q(a, p):
