@@ -287,12 +287,12 @@ def main():
     pipelined_cnt = {k: v[0] for k, v in acc.items()}
     if args.trace_out:   # per-wavefront timeline of three more pipelined steps
       tcap = 1 << 20
-      tbuf = torch.zeros(3 * tcap, dtype=torch.int64, device=dev)
+      tbuf = torch.zeros(_lib.TRACE_WORDS * tcap, dtype=torch.int64, device=dev)
       _lib.trace_begin(tbuf, tcap)
       run_eager(P0 + 1 + reps, P0 + 4 + reps)
       torch.cuda.synchronize()
       tl = _lib.trace_end()
-      np.savez_compressed(args.trace_out, records=tbuf.cpu().numpy().reshape(-1, 3),
+      np.savez_compressed(args.trace_out, records=tbuf.cpu().numpy().reshape(-1, _lib.TRACE_WORDS),
                           launches=np.array([(t_[0], t_[1], t_[2], t_[3]) for t_ in tl], dtype=object),
                           allow_pickle=True)
     acc = {}

@@ -343,11 +343,12 @@ mhte_status mhte_profile_arm(int32_t n);
 mhte_status mhte_profile_read(int32_t cap, int32_t* kernel_tag, float* usec, int32_t* n_out);
 /* Per-wavefront timeline of the step kernels, for finding what bounds a launch.  Between
  * mhte_trace_begin(dev_buf, cap) and mhte_trace_end every launch of a step / lookup / fused-backward
- * kernel made by the calling thread writes, per wavefront w of the launch, three uint64 words at
- * dev_buf[3 * (offset + w)]: {begin, end} on the 100 MHz wall clock and the role the wavefront
+ * kernel made by the calling thread writes, per wavefront w of the launch, eight uint64 words at
+ * dev_buf[8 * (offset + w)]: {begin, end} on the 100 MHz wall clock, the role the wavefront played
+ * and up to five intermediate time marks (0 = not reached); roles: the role the wavefront
  * played (3 run dedup, 4 displacement pass, 5 lookup, 6 heavy work list, 7 item workgroup of the
  * apply, 8 id-major workgroup of the apply).
- * dev_buf [dev, 3 * cap_records uint64].  mhte_trace_end stops tracing and returns, per traced
+ * dev_buf [dev, 8 * cap_records uint64].  mhte_trace_end stops tracing and returns, per traced
  * launch, the kernel tag (as above), grid and block size and `offset`. */
 mhte_status mhte_trace_begin(void* dev_buf, int64_t cap_records);
 mhte_status mhte_trace_end(int32_t cap, int32_t* kernel_tag, int32_t* grid, int32_t* block,

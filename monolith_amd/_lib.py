@@ -169,6 +169,7 @@ def vp(x):
 
 PROFILE_TAGS = {1: "lookup_kernel", 2: "sum_apply_kernel", 6: "slowpath_kernel", 7: "dd_kernels",
                 8: "upsert_kernel", 9: "step_fwd_kernel", 10: "step_bwd_kernel"}
+TRACE_WORDS = 8
 TRACE_ROLES = {3: "run_dedup", 4: "displacement", 5: "lookup", 6: "work_list", 7: "apply_items",
                8: "apply_ids"}
 
@@ -189,8 +190,8 @@ def profile_read(cap=65536):
 
 
 def trace_begin(buf, cap_records):
-  """Per-wavefront timeline of the step kernels into ``buf`` (uint64 cuda tensor, 3 words per
-  record) — mhte_trace_begin."""
+  """Per-wavefront timeline of the step kernels into ``buf`` (uint64 cuda tensor, TRACE_WORDS
+  words per record) — mhte_trace_begin."""
   check(lib().mhte_trace_begin(vp(buf), C.c_int64(int(cap_records))))
 
 

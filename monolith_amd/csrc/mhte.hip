@@ -80,7 +80,7 @@ enum ProfTag : int32_t {
 };
 
 // Per-wavefront timeline of the step kernels (mhte_trace_begin / mhte_trace_end): each traced
-// launch gets a region of 3 words per wavefront in the caller's device buffer.
+// launch gets a region of kTraceWords words per wavefront in the caller's device buffer.
 struct TraceLaunch {
   int32_t tag, grid, block;
   int64_t offset;  // first record (in records of 3 words)
@@ -95,7 +95,7 @@ static unsigned long long* trace_region(int32_t tag, uint32_t grid, uint32_t blo
   if (!g_trace.buf) return nullptr;
   const int64_t waves = int64_t(grid) * ((block + 63) / 64);
   if (g_trace.cursor + waves > g_trace.cap) return nullptr;
-  unsigned long long* p = g_trace.buf + 3 * g_trace.cursor;
+  unsigned long long* p = g_trace.buf + size_t(kTraceWords) * g_trace.cursor;
   g_trace.launches.push_back(TraceLaunch{tag, int32_t(grid), int32_t(block), g_trace.cursor});
   g_trace.cursor += waves;
   return p;
@@ -220,8 +220,8 @@ struct DedupWs {
   // --- run dedup of the pipelined step (mhte_step_kernels.h); own scratch, independent of the
   // list-building dedup above
   DevBuf<int64_t> r_hkey, r_btab_key;
-  DevBuf<uint32_t> r_hcnt, r_uslot, r_btab_val, r_item_runs, r_ctr;
-  DevBuf<unsigned long long> r_hblk;
+  DevBuf<uint32_t> r_hcnt, r_hpos, r_ucnt, r_upos, r_btab_val, r_item_runs, r_ctr;
+  DevBuf<unsigned long long> r_hblk, r_ublk;
   DevBuf<uint16_t> r_seg;
   DevBuf<ItemHdr> r_item_hdr;
   uint32_t r_clean_cap = 0;  // run scratch [0, r_clean_cap] is all-empty
@@ -245,17 +245,20 @@ struct DedupWs {
     r_hkey.reserve(size_t(C) + 2);
     r_hcnt.reserve(size_t(C) + 2);
     r_hblk.reserve(size_t(C) + 2);
+    r_hpos.reserve(size_t(C) + 2);
     r_ctr.reserve(4);
     const uint32_t nblk = uint32_t((n + kRdBlock - 1) / kRdBlock);
-    r_uslot.reserve(size_t(n) + 1);
+    r_ucnt.reserve(size_t(n) + 1);
+    r_ublk.reserve(size_t(n) + 1);
+    r_upos.reserve(size_t(n) + 1);
     r_btab_key.reserve(size_t(nblk) * kRdStride);
     r_btab_val.reserve(size_t(nblk) * kRdStride);
     r_seg.reserve(size_t(nblk) * kRdBlock);
     r_item_hdr.reserve(max_items(n));
     r_item_runs.reserve(size_t(max_items(n)) * 64);
     RunView d{};
-    d.hkey = r_hkey.p; d.hcnt = r_hcnt.p; d.hblk = r_hblk.p; d.cap_mask = C - 1;
-    d.uslot = r_uslot.p; d.btab_key = r_btab_key.p; d.btab_val = r_btab_val.p; d.seg = r_seg.p;
+    d.hkey = r_hkey.p; d.hcnt = r_hcnt.p; d.hblk = r_hblk.p; d.hpos = r_hpos.p; d.cap_mask = C - 1;
+    d.ucnt = r_ucnt.p; d.ublk = r_ublk.p; d.upos = r_upos.p; d.btab_key = r_btab_key.p; d.btab_val = r_btab_val.p; d.seg = r_seg.p;
     d.item_hdr = r_item_hdr.p; d.item_runs = r_item_runs.p; d.ctr = r_ctr.p;
     d.ids = ids; d.n = uint32_t(n); d.nblk = nblk; d.uids = uids; d.n_unique = n_unique_dev;
     if (r_hkey.p != old_key || r_ctr.p != old_ctr || C > r_clean_cap || r_stage != 0) {
@@ -266,11 +269,16 @@ struct DedupWs {
     r_stage = 1;
     return d;
   }
-  // heavy work list of the deduplicated batch on its own (normally it rides in step_bwd)
+  // workgroups of the build role: one trip of 256 slots per wavefront, at most 128 workgroups
+  static uint32_t build_blocks(const RunView& d) {
+    const uint32_t trips = (d.cap_mask + 2u + 64u * kBuildSlotsPerLane - 1) / (64u * kBuildSlotsPerLane);
+    return std::max<uint32_t>(1, std::min<uint32_t>(128, (trips + 3) / 4));
+  }
+  // unique numbering + heavy work list of the deduplicated batch on its own (normally it rides in
+  // step_bwd)
   void build_work_list(hipStream_t st) {
     if (r_stage != 1) return;
-    rd_build_kernel<<<std::max<uint32_t>(1, std::min<uint32_t>(64, (rv.n + 255) / 256)), 256, 0,
-                      st>>>(rv, uint32_t(kLightMax));
+    rd_build_kernel<<<build_blocks(rv), 256, 0, st>>>(rv, uint32_t(kLightMax));
     HIP_OK(hipGetLastError());
     r_stage = 2;
   }
@@ -344,6 +352,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 struct Table {
   std::string name;
   int device = 0;
+  int num_cus = 256;   // compute units of the device (residency budget of the step launches)
   std::vector<mhte_segment_config> segs;
   uint32_t dim = 0, row_floats = 0, nseg = 0;
   bool vec_ok = false;  // every segment boundary (weights and state) is a multiple of 4 floats
@@ -384,6 +393,11 @@ struct Table {
 
   void init(const mhte_table_config& c, int dev) {
     device = dev;
+    {
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+        num_cus = cus;
+    }
     name = c.name ? c.name : "";
     if (c.n_segments < 1 || c.n_segments > kMaxSegments)
       throw Error(MHTE_INVALID_ARGUMENT, "table " + name + ": n_segments must be 1.." +
@@ -698,8 +712,6 @@ struct Table {
   void step_forward(const int64_t* ids, int64_t n, float* out, const RunView& nxt, hipStream_t st) {
     if (n <= 0) throw Error(MHTE_INVALID_ARGUMENT, "step_forward: empty batch");
     Shape sh = pick_shape(dim, vec_ok && aligned16(out));
-    const int64_t groups = (n + kLookupUnroll - 1) / kLookupUnroll;
-    const uint32_t nblk_l = uint32_t((groups * sh.G + kRdBlock - 1) / kRdBlock);
     SlowArgs sp{};
     sp.enabled = pend_valid ? 1 : 0;
     if (pend_valid) {
@@ -713,14 +725,34 @@ struct Table {
       }
       pend_valid = false;
     }
-    const dim3 grid(nxt.nblk + uint32_t(sp.enabled) + nblk_l);
+    // every workgroup of the launch resident at once (two 1024-thread workgroups per CU); the lookup
+    // role covers its groups in grid-stride trips
+    const uint32_t others = nxt.nblk + uint32_t(sp.enabled);
+    const uint32_t slots = uint32_t(2 * num_cus);
+    const uint32_t room = slots > others + 64 ? slots - others : 64u;
+    auto blocks_for = [&](int unr) {
+      const int64_t groups = (n + unr - 1) / unr;
+      return uint32_t((groups * sh.G + kRdBlock - 1) / kRdBlock);
+    };
+    // (measured: 2 ids per group with a second trip for a few workgroups has a shorter tail than 3
+    // per group in one trip; a wavefront's life is the max over its ids of two dependent misses)
+    int unr = 2;
+    while (unr < 3 && blocks_for(unr) > 2 * room) ++unr;
+    const uint32_t nblk_l = std::min(blocks_for(unr), room);
+    const dim3 grid(others + nblk_l);
     TableView v = view;
     v.trace = trace_region(kTagStepFwd, grid.x, kRdBlock);
-#define CALL(G_, V_)                                                                             \
-  LAUNCH_HOT(kTagStepFwd, (step_fwd_kernel<G_, V_>), grid, kRdBlock, st, nxt, v, ids, n, out, \
-             count_hits ? 1 : 0, sp)
+#define CALLU(G_, V_, U_)                                                                        \
+  LAUNCH_HOT(kTagStepFwd, (step_fwd_kernel<G_, V_, U_>), grid, kRdBlock, st, nxt, v, ids, n, out, \
+             count_hits ? 1 : 0, sp, nblk_l)
+#define CALL(G_, V_)                              \
+  do {                                            \
+    if (unr == 2) { CALLU(G_, V_, 2); }           \
+    else { CALLU(G_, V_, 3); }                    \
+  } while (0)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
+#undef CALLU
     HIP_OK(hipGetLastError());
   }
 
@@ -762,14 +794,17 @@ struct Table {
     // fixed grids with grid-stride loops: item workgroups first (longest chain), sized for the
     // work a Zipf batch has; more ids / items than workgroups just means more trips
     const uint32_t groups_per_wg = uint32_t(256 / sh.G);
-    c.nblk_items = exact_order ? 0u : std::min<uint32_t>(cap_items, 512);
+    // residency budget: 4 workgroups of 256 threads per CU (launch bounds of step_bwd_kernel)
+    const uint32_t slots = uint32_t(kBwdBlocksPerCu * num_cus);
+    c.nblk_items = exact_order ? 0u : std::min<uint32_t>(cap_items, uint32_t(num_cus) * 9 / 8);
     c.nblk_ids = std::max<uint32_t>(
-        1, std::min<uint32_t>(uint32_t((std::min<int64_t>(n_max, n) + groups_per_wg - 1) / groups_per_wg), 1024));
+        1, std::min<uint32_t>(uint32_t((std::min<int64_t>(n_max, n) + groups_per_wg - 1) / groups_per_wg),
+                              slots - c.nblk_items - 128));
     RunView nxt{};
     uint32_t nblk_build = 0;
     if (ws_next && ws_next->r_stage == 1) {
       nxt = ws_next->rv;
-      nblk_build = std::max<uint32_t>(1, std::min<uint32_t>(64, (nxt.n + 255) / 256));
+      nblk_build = DedupWs::build_blocks(nxt);
     }
     const dim3 grid(nblk_build + c.nblk_items + c.nblk_ids);
     TableView v = view;

@@ -44,19 +44,24 @@ struct TableView {
   uint32_t nseg;
   SegDesc seg[kMaxSegments];
   // measurement aid (mhte_trace_begin): when non-null, every wavefront of a step kernel records
-  // {begin, end, role} of its role at trace[3 * global wave index]; 100 MHz wall clock.
+  // {begin, end, role, marks} at trace[kTraceWords * global wave index]; 100 MHz wall clock.
   unsigned long long* trace;
 };
 
-// Per-wavefront timeline record of the step kernels (null trace pointer: two wave-uniform branches).
+// Per-wavefront timeline record of the step kernels (null trace pointer: wave-uniform branches).
+// Record = kTraceWords uint64: begin, end, role, then up to 5 intermediate marks.
+constexpr int kTraceWords = 8;
 struct WaveTrace {
   unsigned long long* rec;
   unsigned long long t0;
   __device__ __forceinline__ WaveTrace(unsigned long long* trace) : rec(nullptr), t0(0) {
     if (trace) {
-      rec = trace + 3ull * (uint64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
+      rec = trace + uint64_t(kTraceWords) * (uint64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
       t0 = wall_clock64();
     }
+  }
+  __device__ __forceinline__ void mark(int i) {
+    if (rec && (threadIdx.x & 63) == 0) rec[3 + i] = wall_clock64();
   }
   __device__ __forceinline__ void end(uint32_t role) {
     if (rec && (threadIdx.x & 63) == 0) {
@@ -261,7 +266,8 @@ __device__ __forceinline__ void lookup_role_u(const TableView& tv, const int64_t
       }
     }
   }
-  if (count_hits && lane == 0 && hits) atomicAdd(&tv.ctr->hits, (unsigned long long)hits);
+  if (count_hits && hits && lane == __ffsll(static_cast<long long>(__ballot(1))) - 1)
+    atomicAdd(&tv.ctr->hits, (unsigned long long)hits);
 }
 template <int G, int VEC, int UNR, bool NT, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void lookup_kernel_u(TableView tv,

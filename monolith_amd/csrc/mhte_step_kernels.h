@@ -9,19 +9,22 @@
 //
 //  * RUN DEDUP (rd_dedup_role) — ONE phase instead of three.  Workgroup b owns positions
 //    [1024 b, 1024 b + 1024).  It deduplicates them in an LDS hash set, claims each distinct id's slot
-//    in a global scratch hash (CAS; the claimer numbers the id), ORs bit b into the id's 64-bit
-//    workgroup mask and adds its occurrence count; the positions are grouped by id INSIDE the
+//    in a global scratch hash with ONE CAS, ORs bit b into the id's 64-bit workgroup mask and adds
+//    its occurrence count (fire-and-forget atomics); the positions are grouped by id INSIDE the
 //    workgroup's own 1024-entry region ("runs", each sorted ascending), and the LDS table
 //    (id -> run offset, length, first position) is dumped as is.  No list space is allocated
-//    globally, nobody waits for anybody, and since workgroups are position ranges, "runs in
-//    workgroup order" IS occurrence order — nothing is left to sort.
-//  * HEAVY WORK LIST (rd_build_role) — ids with > kLightMax occurrences are cut into items of
-//    ~256 entries (a power-of-two range of workgroups each), with their run descriptors copied next
-//    to the item.  Rides in the previous step's backward launch.
-//  * APPLY (rd_apply_role) — fixed-size grid with grid-stride loops.  Id-major groups: probe of the
-//    table, workgroup mask and count in one round trip; run table(s) and the row itself in the
-//    next; gradients; optimizer.  Item workgroups: 16 gradient rows in flight per group, LDS adds
-//    the groups in order, multi-item ids hand over through write-through partial rows.
+//    globally, nothing is numbered, nobody waits for anybody, and since workgroups are position
+//    ranges, "runs in workgroup order" IS occurrence order — nothing is left to sort.
+//  * BUILD (rd_build_role) — off the critical path, in the previous step's backward launch: a
+//    coalesced scan of the scratch compacts the occupied slots into dense arrays (unique id, count,
+//    workgroup mask, a position) — the unique numbering — resets the scratch, and cuts ids with
+//    > kLightMax occurrences into work items of ~256 entries (a power-of-two range of workgroups
+//    each) with their run descriptors copied next to the item.
+//  * APPLY (rd_apply_role) — fixed-size grid with grid-stride loops.  Id-major groups: everything
+//    about the id in one round trip; then table probe | gradient of a lone occurrence | run tables
+//    of a short list; then the row; optimizer.  Item workgroups: 16 gradient rows in flight per
+//    group, LDS adds the groups in order, multi-item ids hand over through write-through partial
+//    rows.
 //
 // Summation order: every id's gradients are added in ascending position order inside a light list
 // (bit-identical to the reference's sequential sum, unique_mapping_ops.cc:307-324); a heavy list is
@@ -38,7 +41,24 @@ constexpr int kRdBlock = 1024;          // positions per dedup workgroup (one pe
 constexpr int kRdLds = 2048;            // LDS hash entries per workgroup
 constexpr int kRdStride = kRdLds + 1;   // + side entry for kEmptyKey
 constexpr int kRdMaxBlocks = 64;        // bits of the workgroup mask: n <= 65 536 positions
+constexpr int kLongRun = 16;
+constexpr int kMaxLongRuns = 16;
 constexpr uint32_t kItemTarget = 256;   // entries per heavy work item (expected)
+constexpr int kBwdBlocksPerCu = 5;      // 256-thread workgroups of step_bwd resident per CU (<= 96 VGPRs)
+
+// Workgroup barrier for LDS traffic only.  __syncthreads() also drains every outstanding global
+// store and atomic of the wavefront (s_waitcnt vmcnt(0)), which costs a full memory round trip per
+// barrier on these latency-bound chains; the roles below only exchange data through LDS, and
+// global results are consumed by the NEXT launch.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// Same for lanes of ONE wavefront exchanging data through LDS (a G-lane group never spans
+// wavefronts): LDS operations of a wavefront execute in order, so only the compiler and the
+// operation counter have to be told.
+__device__ __forceinline__ void lds_wave_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
 
 // run descriptor: first local position | offset in the workgroup's region | length (0..1024)
 __device__ __forceinline__ uint32_t run_pack(uint32_t first, uint32_t off, uint32_t cnt) {
@@ -59,20 +79,23 @@ struct RunView {
   int64_t* hkey;
   uint32_t* hcnt;               // occurrences of the slot's id in the batch
   unsigned long long* hblk;     // mask of the workgroups that hold a run of it
+  uint32_t* hpos;               // position of an occurrence (the only one when hcnt == 1)
   uint32_t cap_mask;
   // per batch
-  uint32_t* uslot;              // [n] scratch slot of unique index u
+  uint32_t* ucnt;               // [n] dense copies made by the build role: occurrences,
+  unsigned long long* ublk;     //     workgroup mask,
+  uint32_t* upos;               //     a position (the only one when ucnt == 1) of unique index u
   int64_t* btab_key;            // [nblk][kRdStride] dumped LDS tables
   uint32_t* btab_val;           // [nblk][kRdStride] run_pack
   uint16_t* seg;                // [nblk * 1024] local positions grouped by run, ascending in a run
   ItemHdr* item_hdr;            // heavy work items
   uint32_t* item_runs;          // [items][64] run_pack of workgroup b0 + t (0: no run)
-  uint32_t* ctr;                // [0] unique counter, [1] workgroups done, [2] number of items
+  uint32_t* ctr;                // [0] unique counter, [1] build waves done, [2] number of items
   const int64_t* ids;
   uint32_t n;
   uint32_t nblk;                // ceil(n / 1024) <= 64; 0 = nothing to do
-  int64_t* uids;                // out: unique ids, unspecified order
-  uint32_t* n_unique;           // out
+  int64_t* uids;                // out (build role): unique ids, unspecified order
+  uint32_t* n_unique;           // out (build role)
 };
 
 __global__ __launch_bounds__(256) void rd_clear_kernel(RunView d) {
@@ -81,35 +104,9 @@ __global__ __launch_bounds__(256) void rd_clear_kernel(RunView d) {
     d.hkey[i] = kEmptyKey;
     d.hcnt[i] = 0;
     d.hblk[i] = 0ull;
+    d.hpos[i] = 0;
   }
   if (i < 4) d.ctr[i] = 0;
-}
-
-__device__ __forceinline__ uint32_t rd_claim(const RunView& d, int64_t id, bool* claimed) {
-  *claimed = false;
-  if (id == kEmptyKey) {
-    const uint32_t s = d.cap_mask + 1u;
-    const unsigned long long old =
-        atomicCAS(reinterpret_cast<unsigned long long*>(&d.hkey[s]),
-                  static_cast<unsigned long long>(kEmptyKey), 0ull);
-    *claimed = static_cast<int64_t>(old) == kEmptyKey;
-    return s;
-  }
-  uint32_t s = uint32_t(hash_key(id)) & d.cap_mask;
-  for (;;) {
-    int64_t k = d.hkey[s];
-    if (k == kEmptyKey) {
-      k = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hkey[s]),
-                                         static_cast<unsigned long long>(kEmptyKey),
-                                         static_cast<unsigned long long>(id)));
-      if (k == kEmptyKey) {
-        *claimed = true;
-        return s;
-      }
-    }
-    if (k == id) return s;
-    s = (s + 1u) & d.cap_mask;
-  }
 }
 
 // LDS of the dedup role; the caller declares it (and may alias it with other roles' scratch)
@@ -120,7 +117,12 @@ struct RdLds {
   uint32_t first[kRdStride];
   uint16_t pos[kRdBlock];
   uint32_t wtot[16];
-  uint32_t nclaim, base;
+  // runs of > kLongRun positions are ordered through a 1024-bit bitmap each (rank = set bits
+  // below), the first kMaxLongRuns of a workgroup; shorter ones by counting smaller entries
+  uint32_t bm[kMaxLongRuns][32];
+  uint32_t bmpre[kMaxLongRuns][32];
+  uint8_t lslot[kRdStride + 3];
+  uint32_t nlong;
 };
 
 // probe start of an id in a workgroup's dumped table (the side entry for kEmptyKey)
@@ -128,21 +130,23 @@ __device__ __forceinline__ uint32_t rd_home(int64_t id) {
   return uint32_t(hash_key(id) >> 40) & (kRdLds - 1);
 }
 
-__device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, RdLds& L) {
+__device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, RdLds& L,
+                                              WaveTrace& wt) {
   const uint32_t t = threadIdx.x;
   for (uint32_t i = t; i < uint32_t(kRdStride); i += kRdBlock) {
     L.key[i] = static_cast<unsigned long long>(kEmptyKey);
     L.cnt[i] = 0;
+    L.lslot[i] = 0xff;
   }
-  if (t == 0) L.nclaim = 0;
-  if (bid == 0 && t == 0) d.ctr[2] = 0;  // the work list of this batch is built after this launch
-  __syncthreads();
+  if (t < kMaxLongRuns * 32) (&L.bm[0][0])[t] = 0;
+  if (t == 0) L.nlong = 0;
+  if (bid == 0 && t < 3) d.ctr[t] = 0;  // counters of the build role, which runs after this launch
   const uint32_t p = bid * kRdBlock + t;
   const bool valid = p < d.n;
+  const int64_t id = valid ? d.ids[p] : 0;   // round trip 1
+  lds_barrier();
   uint32_t ls = 0, arr = 0;
-  int64_t id = 0;
   if (valid) {
-    id = d.ids[p];
     if (id == kEmptyKey) {
       ls = kRdLds;
     } else {
@@ -161,16 +165,31 @@ __device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, Rd
     arr = atomicAdd(&L.cnt[ls], 1u);
     if (arr == 0) L.first[ls] = t;
   }
-  __syncthreads();
-  // ---- the run's first arrival speaks for the whole run in the global scratch
-  bool claimed = false;
-  uint32_t gs = 0, crank = 0;
-  if (valid && arr == 0) {
-    gs = rd_claim(d, id, &claimed);
-    atomicAdd(&d.hcnt[gs], L.cnt[ls]);
-    atomicOr(&d.hblk[gs], 1ull << bid);
-    if (claimed) crank = atomicAdd(&L.nclaim, 1u);
+  lds_barrier();
+  wt.mark(0);
+  // ---- the run's first arrival speaks for the whole run in the global scratch.  Round trip 2 is
+  // its CAS on the id's home slot; the result is only looked at after the LDS work below, which
+  // therefore overlaps the atomic's latency (and nobody waits at a barrier for the slowest CAS).
+  const bool speaker = valid && arr == 0;
+  uint32_t gs = 0;
+  int64_t cas_old = kEmptyKey;
+  if (speaker) {
+    if (id == kEmptyKey) {
+      gs = d.cap_mask + 1u;
+      cas_old = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hkey[gs]),
+                                               static_cast<unsigned long long>(kEmptyKey), 0ull));
+    } else {
+      gs = uint32_t(hash_key(id)) & d.cap_mask;
+      cas_old = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hkey[gs]),
+                                               static_cast<unsigned long long>(kEmptyKey),
+                                               static_cast<unsigned long long>(id)));
+    }
+    if (L.cnt[ls] > uint32_t(kLongRun)) {
+      const uint32_t sl = atomicAdd(&L.nlong, 1u);
+      if (sl < uint32_t(kMaxLongRuns)) L.lslot[ls] = uint8_t(sl);
+    }
   }
+  wt.mark(1);
   // ---- run offsets: exclusive scan of the LDS counts (two entries per thread, side entry last)
   {
     const uint32_t a = L.cnt[2 * t], b = L.cnt[2 * t + 1];
@@ -182,7 +201,7 @@ __device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, Rd
       if (lane >= o) incl += v;
     }
     if (lane == 63) L.wtot[w] = incl;
-    __syncthreads();
+    lds_barrier();
     uint32_t woff = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) woff += (i < w) ? L.wtot[i] : 0u;
@@ -191,56 +210,93 @@ __device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, Rd
     L.off[2 * t + 1] = excl + a;
     if (t == kRdBlock - 1) L.off[kRdLds] = woff + incl;
   }
-  __syncthreads();
-  if (t == 0 && L.nclaim) L.base = atomicAdd(&d.ctr[0], L.nclaim);
-  if (valid) L.pos[L.off[ls] + arr] = uint16_t(t);  // grouped by run, arrival order
-  __syncthreads();
-  if (claimed) {
-    const uint32_t u = L.base + crank;
-    d.uids[u] = id;
-    d.uslot[u] = gs;
+  lds_barrier();
+  wt.mark(2);
+  const uint32_t lsl = valid ? uint32_t(L.lslot[ls]) : 0xffu;
+  if (valid) {
+    if (lsl != 0xffu) atomicOr(&L.bm[lsl][t >> 5], 1u << (t & 31u));
+    else L.pos[L.off[ls] + arr] = uint16_t(t);  // grouped by run, arrival order
   }
-  // ---- ascending order inside the run: rank = number of smaller positions in it
+  lds_barrier();
+  if (t < kMaxLongRuns * 32) {  // exclusive prefix of the set-bit counts over each bitmap's 32 words
+    const uint32_t w = (&L.bm[0][0])[t];
+    uint32_t incl = __popc(w);
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const uint32_t v = __shfl_up(incl, o, 32);
+      if ((t & 31u) >= uint32_t(o)) incl += v;
+    }
+    (&L.bmpre[0][0])[t] = incl - __popc(w);
+  }
+  lds_barrier();
+  // ---- ascending order inside the run: rank = number of smaller positions in it (8 LDS reads in
+  // flight: a Zipf head key has runs of ~200)
   if (valid) {
     const uint32_t c = L.cnt[ls], o = L.off[ls];
     uint32_t rank = 0;
-    if (c > 1) {
-      for (uint32_t i = 0; i < c; ++i) rank += (uint32_t(L.pos[o + i]) < t) ? 1u : 0u;
+    if (lsl != 0xffu) {
+      rank = L.bmpre[lsl][t >> 5] + __popc(L.bm[lsl][t >> 5] & ((1u << (t & 31u)) - 1u));
+    } else if (c > 1) {
+      uint32_t i = 0;
+      for (; i + 8 <= c; i += 8) {
+        uint32_t x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = L.pos[o + i + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rank += (x[q] < t) ? 1u : 0u;
+      }
+      for (; i < c; ++i) rank += (uint32_t(L.pos[o + i]) < t) ? 1u : 0u;
     }
     d.seg[bid * kRdBlock + o + rank] = uint16_t(t);
   }
+  wt.mark(3);
   // ---- the LDS table is the workgroup's run directory
   for (uint32_t i = t; i < uint32_t(kRdStride); i += kRdBlock) {
     d.btab_key[size_t(bid) * kRdStride + i] = static_cast<int64_t>(L.key[i]);
     d.btab_val[size_t(bid) * kRdStride + i] = run_pack(L.first[i] & 0x3ffu, L.off[i] & 0x3ffu, L.cnt[i]);
   }
-  // ---- the last workgroup publishes the unique count and re-arms the counters
-  if (t == 0) {
-    if (atomicAdd(&d.ctr[1], 1u) == d.nblk - 1) {
-      *d.n_unique = atomicAdd(&d.ctr[0], 0u);
-      d.ctr[0] = 0;
-      d.ctr[1] = 0;
+  // ---- now the CAS: the home slot was free or already held the id (usual), else linear probing
+  if (speaker) {
+    const int64_t want = (id == kEmptyKey) ? kEmptyKey : id;  // side slot: anything but empty = taken
+    if (id != kEmptyKey) {
+      while (cas_old != kEmptyKey && cas_old != want) {
+        gs = (gs + 1u) & d.cap_mask;
+        cas_old = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hkey[gs]),
+                                                 static_cast<unsigned long long>(kEmptyKey),
+                                                 static_cast<unsigned long long>(id)));
+      }
     }
+    atomicAdd(&d.hcnt[gs], L.cnt[ls]);       // (no return value: fire and forget)
+    atomicOr(&d.hblk[gs], 1ull << bid);
+    d.hpos[gs] = p;                          // read only when the id turns out to occur once
   }
+  wt.mark(4);
 }
 
 __global__ __launch_bounds__(kRdBlock) void rd_dedup_kernel(RunView d) {
   __shared__ RdLds L;
-  rd_dedup_role(d, blockIdx.x, L);
+  WaveTrace wt(nullptr);
+  rd_dedup_role(d, blockIdx.x, L, wt);
 }
 
-// run descriptor of `id` in workgroup b's table (the id is known to have a run there)
+// run descriptor of `id` in workgroup b's table (the id is known to have a run there).  Key and
+// descriptor of the home entry are fetched together: one round trip unless the LDS set had a
+// collision there.
 __device__ __forceinline__ uint32_t rd_find_run(const RunView& d, uint32_t b, int64_t id) {
   const int64_t* kt = d.btab_key + size_t(b) * kRdStride;
-  uint32_t ls = (id == kEmptyKey) ? uint32_t(kRdLds) : rd_home(id);
-  if (id != kEmptyKey) {
-    int left = kRdLds;  // (bounded: a directory that lacks the id would mean a corrupted dedup)
-    while (kt[ls] != id) {
-      if (--left == 0) return 0u;
-      ls = (ls + 1u) & (kRdLds - 1);
-    }
+  const uint32_t* vt = d.btab_val + size_t(b) * kRdStride;
+  if (id == kEmptyKey) return vt[kRdLds];
+  uint32_t ls = rd_home(id);
+  int64_t k = kt[ls];
+  uint32_t v = vt[ls];
+  int left = kRdLds;  // (bounded: a directory that lacks the id would mean a corrupted dedup)
+  while (k != id) {
+    if (--left == 0) return 0u;
+    ls = (ls + 1u) & (kRdLds - 1);
+    k = kt[ls];
+    v = vt[ls];
   }
-  return d.btab_val[size_t(b) * kRdStride + ls];
+  return v;
 }
 
 // workgroups per item for a list of c occurrences: power of two, ~kItemTarget entries expected
@@ -251,56 +307,113 @@ __device__ __forceinline__ uint32_t rd_item_blocks(uint32_t c) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Heavy work list of a deduplicated batch.  256-thread workgroups, grid-stride over unique ids;
-// one wavefront per heavy id (lane = workgroup index of a potential run).
+// Build: unique numbering + heavy work list of a deduplicated batch, and the scratch reset.
+// Every wavefront scans 256 scratch slots per trip (four coalesced 64-slot reads of each array in
+// flight), compacts the occupied ones into the dense arrays with ONE counter bump, and handles the
+// heavy ids it found with the whole wavefront (lane = workgroup index of a potential run).
+// Slot order is hash order, so hot ids are spread evenly over the wavefronts.
 // ---------------------------------------------------------------------------------------------
+constexpr int kBuildSlotsPerLane = 4;
+
 __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_max, uint32_t bid,
                                               uint32_t nblocks) {
-  __shared__ uint32_t l_heavy[256];
-  __shared__ uint32_t l_nheavy;
+  constexpr int Q = kBuildSlotsPerLane;
+  __shared__ uint32_t sh_tot[4];
+  __shared__ uint32_t sh_base;
   const uint32_t t = threadIdx.x;
-  const int lane = t & 63, w = t >> 6;
-  const uint32_t nu = *d.n_unique;
-  for (uint32_t base = bid * 256u; base < nu; base += nblocks * 256u) {
-    if (t == 0) l_nheavy = 0;
-    __syncthreads();
-    const uint32_t u = base + t;
-    if (u < nu) {
-      const uint32_t c = d.hcnt[d.uslot[u]];
-      if (c > light_max) l_heavy[atomicAdd(&l_nheavy, 1u)] = u;
+  const int lane = t & 63;
+  const uint32_t nslots = d.cap_mask + 2u;  // + the side slot of kEmptyKey
+  // (256-thread workgroups; the trip count is the same for the four wavefronts of a workgroup)
+  for (uint32_t bb = bid * (256u * Q); bb < nslots; bb += nblocks * (256u * Q)) {
+    const uint32_t base = bb + (t >> 6) * (64u * Q);
+    int64_t key[Q];
+    uint32_t cnt[Q], pos[Q];
+    unsigned long long blk[Q], occ[Q];
+    uint32_t total = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const uint32_t sl = base + q * 64 + lane;
+      const bool in = sl < nslots;
+      key[q] = in ? d.hkey[sl] : kEmptyKey;
+      cnt[q] = in ? d.hcnt[sl] : 0u;
+      blk[q] = in ? d.hblk[sl] : 0ull;
+      pos[q] = in ? d.hpos[sl] : 0u;
     }
-    __syncthreads();
-    const uint32_t nh = l_nheavy;
-    for (uint32_t h = w; h < nh; h += 4) {
-      const uint32_t hu = l_heavy[h];
-      const int64_t id = d.uids[hu];
-      const uint32_t gs = d.uslot[hu];
-      const uint32_t c = d.hcnt[gs];
-      const unsigned long long bm = d.hblk[gs];
-      const bool has = (bm >> lane) & 1ull;
-      const uint32_t val = has ? rd_find_run(d, uint32_t(lane), id) : 0u;
-      const uint32_t nbk = rd_item_blocks(c);
-      const uint32_t b0 = uint32_t(lane) & ~(nbk - 1u);
-      const unsigned long long rmask =
-          (nbk == 64 ? ~0ull : ((1ull << nbk) - 1ull)) << b0;
-      const bool leader = (uint32_t(lane) == b0) && (bm & rmask) != 0ull;
-      const unsigned long long lm = __ballot(leader);
-      const uint32_t nitems = __popcll(lm);
-      uint32_t w0 = 0;
-      if (lane == 0) w0 = atomicAdd(&d.ctr[2], nitems);
-      w0 = __shfl(w0, 0);
-      // item index of this lane's range = rank of its leader among the leaders
-      const uint32_t k = __popcll(lm & ((1ull << b0) - 1ull));
-      if (leader) {
-        ItemHdr hd;
-        hd.id = id;
-        hd.u = hu;
-        hd.meta = b0 | (nbk << 8) | (k << 16) | (nitems << 24);
-        d.item_hdr[w0 + k] = hd;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const uint32_t sl = base + q * 64 + lane;
+      const bool o = key[q] != kEmptyKey;
+      if (o) {  // clean-after-use: the scratch is all-empty again after this launch
+        d.hkey[sl] = kEmptyKey;
+        d.hcnt[sl] = 0;
+        d.hblk[sl] = 0ull;
+        if (sl == d.cap_mask + 1u) key[q] = kEmptyKey;  // the side slot stands for that id itself
       }
-      if ((bm & rmask) != 0ull) d.item_runs[size_t(w0 + k) * 64 + (uint32_t(lane) - b0)] = val;
+      occ[q] = __ballot(o);
+      total += uint32_t(__popcll(occ[q]));
     }
-    __syncthreads();
+    // one counter bump per WORKGROUP and trip (hundreds of wavefronts bumping one address would
+    // queue behind each other for longer than the whole launch should take)
+    if (lane == 0) sh_tot[t >> 6] = total;
+    lds_barrier();
+    if (t == 0) {
+      const uint32_t all = sh_tot[0] + sh_tot[1] + sh_tot[2] + sh_tot[3];
+      sh_base = all ? atomicAdd(&d.ctr[0], all) : 0u;
+    }
+    lds_barrier();
+    uint32_t k0 = sh_base;
+    for (uint32_t w2 = 0; w2 < (t >> 6); ++w2) k0 += sh_tot[w2];
+    lds_barrier();  // (sh_tot / sh_base are rewritten by the next trip)
+    uint32_t kq[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      kq[q] = k0 + uint32_t(__popcll(occ[q] & ((1ull << lane) - 1ull)));
+      k0 += uint32_t(__popcll(occ[q]));
+      if ((occ[q] >> lane) & 1ull) {
+        d.uids[kq[q]] = key[q];
+        d.ucnt[kq[q]] = cnt[q];
+        d.ublk[kq[q]] = blk[q];
+        d.upos[kq[q]] = pos[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      unsigned long long hm = occ[q] & __ballot(cnt[q] > light_max);
+      while (hm) {
+        const int src = __ffsll(static_cast<long long>(hm)) - 1;
+        hm &= hm - 1ull;
+        const uint32_t hu = __shfl(kq[q], src);
+        const uint32_t c = __shfl(cnt[q], src);
+        const int64_t id = __shfl(key[q], src);
+        const unsigned long long bm = __shfl(blk[q], src);
+        const bool has = (bm >> lane) & 1ull;
+        const uint32_t nbk = rd_item_blocks(c);
+        const uint32_t b0 = uint32_t(lane) & ~(nbk - 1u);
+        const unsigned long long rmask = (nbk == 64 ? ~0ull : ((1ull << nbk) - 1ull)) << b0;
+        const bool leader = (uint32_t(lane) == b0) && (bm & rmask) != 0ull;
+        const unsigned long long lm = __ballot(leader);
+        const uint32_t nitems = __popcll(lm);
+        uint32_t w0 = 0;
+        if (lane == 0) w0 = atomicAdd(&d.ctr[2], nitems);  // in flight beside the run probes
+        const uint32_t val = has ? rd_find_run(d, uint32_t(lane), id) : 0u;
+        w0 = __shfl(w0, 0);
+        // item index of this lane's range = rank of its leader among the leaders
+        const uint32_t k = __popcll(lm & ((1ull << b0) - 1ull));
+        if (leader) {
+          ItemHdr hd;
+          hd.id = id;
+          hd.u = hu;
+          hd.meta = b0 | (nbk << 8) | (k << 16) | (nitems << 24);
+          d.item_hdr[w0 + k] = hd;
+        }
+        if ((bm & rmask) != 0ull) d.item_runs[size_t(w0 + k) * 64 + (uint32_t(lane) - b0)] = val;
+      }
+    }
+  }
+  // ---- the last workgroup to finish publishes the unique count (thread 0 made every bump of
+  // ctr[0] itself and they have returned, so they are ordered before its arrival here)
+  if (t == 0) {
+    if (atomicAdd(&d.ctr[1], 1u) == nblocks - 1) *d.n_unique = atomicAdd(&d.ctr[0], 0u);
   }
 }
 
@@ -429,8 +542,9 @@ __device__ __forceinline__ void sum_list_lds(const float* __restrict__ grads, ui
 
 template <int G, int VEC>
 __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView& d,
-                                              const ApplyCtl& c, const ApplyArgs& a, uint32_t bid) {
-  constexpr int WIN = G < 16 ? G : 16;
+                                              const ApplyCtl& c, const ApplyArgs& a, uint32_t bid,
+                                              WaveTrace& wt) {
+  constexpr int WIN = G < 8 ? G : 8;   // gradient rows in flight per group of an item workgroup
   constexpr int NG = 256 / G;  // groups per workgroup
   const int lane = threadIdx.x & 63;
   const int j = lane & (G - 1);
@@ -442,59 +556,51 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
 
   if (bid >= c.nblk_items) {
     // ------------------------------------------------------------------ id-major groups
+    // Group `grp` of workgroup k takes the unique indices u = it * stride + grp * nblk_ids + k:
+    // consecutive indices (the claim order puts the hot ids first) land in different workgroups.
+    // A group lives inside one wavefront, so its LDS hand-offs need no workgroup barrier.
     __shared__ uint32_t sh_pos[NG][kLightMax];
-    const int64_t nu = min(c.n_max, int64_t(*d.n_unique));
     const int64_t stride = int64_t(c.nblk_ids) * NG;
+    const int64_t k = bid - c.nblk_items;
+    int64_t nu = c.n_max;  // refined below, once the count has arrived with the first trip's loads
 #pragma unroll 1
-    for (int64_t gb = int64_t(bid - c.nblk_items) * NG; gb < nu; gb += stride) {  // block-uniform
-      const int64_t g = gb + grp;
+    for (int64_t it = 0; it * stride < nu; ++it) {
+      const int64_t g = it * stride + int64_t(grp) * c.nblk_ids + k;
+      // round trip 1: everything about unique index g (the build role's dense arrays; an index past
+      // the count reads stale entries of the preallocated arrays and is dropped)
+      const bool inb = g < c.n_max;
+      const int64_t id = inb ? d.uids[g] : 0;
+      uint32_t cnt = inb ? d.ucnt[g] : 0u;
+      const unsigned long long bm = inb ? d.ublk[g] : 0ull;
+      const uint32_t hp = inb ? d.upos[g] : 0u;
+      if (it == 0) nu = min(c.n_max, int64_t(d.ctr[0]));
       bool valid = g < nu;
-      const int64_t id = valid ? d.uids[g] : 0;
-      const uint32_t gs = valid ? d.uslot[g] : 0u;
-      // round trip 2: table probe | occurrence count and workgroup mask
+      if (!valid) cnt = 0;
+      // round trip 2: table probe | gradient of a lone occurrence | run tables of a short list
       Probe<G> pr = probe_issue<G>(tv, id, valid, j);
-      uint32_t cnt = 0;
-      unsigned long long bm = 0ull;
-      if (valid) {
-        cnt = d.hcnt[gs];
-        bm = d.hblk[gs];
-      }
-      if (valid && j == 0) {  // clean-after-use: the scratch is all-empty again after this launch
-        d.hkey[gs] = kEmptyKey;
-        d.hcnt[gs] = 0;
-        d.hblk[gs] = 0ull;
-      }
+      if (it == 0) wt.mark(0);
       if (cnt > c.light_max) valid = false;  // heavy list: the item workgroups own it
+      const bool single = valid && cnt == 1;
       const bool big = valid && cnt > uint32_t(kLightMax);  // (exact order only)
-      // round trip 3: run descriptors (lane j: the j-th run, then the (j+G)-th ...) | the row
-      const uint32_t nr = valid ? uint32_t(__popcll(bm)) : 0u;
-      Vec<VEC> acc;
-      vec_zero(acc);
-      const SlotResult sr = upsert_resolve<G>(tv, pr.b, id, valid, pr.k, pr.row, lane, a.ts);
-      RowRegs<VEC> rr;
-      vec_zero(rr.w);
-      vec_zero(rr.s1);
-      vec_zero(rr.s2);
-      float* rp = nullptr;
-      if (valid && !sr.deferred) {
-        rp = row_ptr(tv, sr.r);
-        if (!sr.is_new) row_prefetch<VEC>(tv, rp, e, rr);
-      }
-      if (!big) {
-        // flat list of <= kLightMax positions in LDS, runs in workgroup order
+      const bool flat = valid && !single && !big;
+      Vec<VEC> g1;
+      vec_zero(g1);
+      if (single && ev) g1.load(c.grads + int64_t(hp) * dim + e);
+      if (flat) {
+        // flat list of <= kLightMax positions in LDS, runs in workgroup order; lane j takes the
+        // j-th run, then the (j+G)-th ...
+        const uint32_t nr = uint32_t(__popcll(bm));
         uint32_t filled = 0;
         unsigned long long rest = bm;
 #pragma unroll 1
         for (uint32_t r0 = 0; r0 < nr; r0 += G) {  // group-uniform
-          // my run: the (r0 + j)-th set bit
           unsigned long long m = rest;
           for (int s = 0; s < j; ++s) m &= m - 1ull;
-          const bool mine = valid && (r0 + uint32_t(j) < nr) && m != 0ull;
+          const bool mine = (r0 + uint32_t(j) < nr) && m != 0ull;
           const uint32_t b = mine ? uint32_t(__ffsll(static_cast<long long>(m)) - 1) : 0u;
           const uint32_t val = mine ? rd_find_run(d, b, id) : 0u;
           const uint32_t cb = run_cnt(val);
-          // offsets of the runs inside the flat list: exclusive scan over the group's lanes
-          uint32_t incl = cb;
+          uint32_t incl = cb;  // offsets of the runs inside the flat list
 #pragma unroll
           for (int o = 1; o < G; o <<= 1) {
             const uint32_t v = __shfl_up(incl, o, G);
@@ -514,8 +620,24 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
           for (int s = 0; s < G && rest; ++s) rest &= rest - 1ull;
         }
       }
-      __syncthreads();
-      if (valid && !big) sum_list_lds<VEC>(c.grads, dim, e, ev, sh_pos[grp], cnt, acc);
+      if (it == 0) wt.mark(1);
+      // round trip 3: the row
+      const SlotResult sr = upsert_resolve<G>(tv, pr.b, id, valid, pr.k, pr.row, lane, a.ts);
+      RowRegs<VEC> rr;
+      vec_zero(rr.w);
+      vec_zero(rr.s1);
+      vec_zero(rr.s2);
+      float* rp = nullptr;
+      if (valid && !sr.deferred) {
+        rp = row_ptr(tv, sr.r);
+        if (!sr.is_new) row_prefetch<VEC>(tv, rp, e, rr);
+      }
+      lds_wave_sync();
+      if (it == 0) wt.mark(2);
+      Vec<VEC> acc;
+      vec_zero(acc);
+      if (single) vec_add(acc, g1);  // 0 + g, as the sequential sum starts
+      if (flat) sum_list_lds<VEC>(c.grads, dim, e, ev, sh_pos[grp], cnt, acc);
       if (big) {
         // strictly sequential sum of a long list (MHTE_EXACT_ORDER): run after run
         unsigned long long rest = bm;
@@ -541,13 +663,15 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
           }
         }
       }
+      if (it == 0) wt.mark(3);
       if (sr.deferred) {
         if (ev) acc.store(c.grad_u + g * int64_t(dim) + e);
         if (j == 0) c.pending[atomicAdd(&tv.ctr->n_pending, 1u)] = uint32_t(g);
       } else if (valid) {
         optimize_row_pre<VEC>(tv, rp, sr.is_new, e, acc, a, rr);
       }
-      __syncthreads();  // sh_pos is reused
+      if (it == 0) wt.mark(4);
+      lds_wave_sync();  // sh_pos is reused
     }
     return;
   }
@@ -557,16 +681,21 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
   __shared__ uint32_t sh_rval[64];
   __shared__ float sh_sum[NG][G * VEC];
   __shared__ uint32_t sh_last;
-  const uint32_t nitems_all = d.ctr[2];
 #pragma unroll 1
-  for (uint32_t w = bid; w < nitems_all; w += c.nblk_items) {  // block-uniform
+  for (uint32_t w = bid;; w += c.nblk_items) {  // block-uniform
+    // round trip 1: item count, header and run descriptors together (an index past the count reads
+    // stale entries of the preallocated list and is dropped)
+    const uint32_t nitems_all = d.ctr[2];
     const ItemHdr hd = d.item_hdr[w];
+    const uint32_t rval = (threadIdx.x < 64) ? d.item_runs[size_t(w) * 64 + lane] : 0u;
+    if (w >= nitems_all) break;
+    wt.mark(0);
     const uint32_t b0 = hd.meta & 0xffu, nbk = (hd.meta >> 8) & 0xffu, kk = (hd.meta >> 16) & 0xffu,
                    nitems = hd.meta >> 24;
-    // the table probe of the id goes out now and is used by whoever applies (wave 0, group 0)
+    // round trip 2: the table probe of the id (used by whoever applies: wave 0, group 0) | positions
     Probe<G> pr = probe_issue<G>(tv, hd.id, threadIdx.x < G, j);
     if (threadIdx.x < 64) {
-      const uint32_t val = (uint32_t(lane) < nbk) ? d.item_runs[size_t(w) * 64 + lane] : 0u;
+      const uint32_t val = (uint32_t(lane) < nbk) ? rval : 0u;
       uint32_t incl = run_cnt(val);
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
@@ -577,13 +706,14 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       sh_rstart[lane + 1] = incl;
       if (lane == 0) sh_rstart[0] = 0;
     }
-    __syncthreads();
+    lds_barrier();
+    wt.mark(1);
     const uint32_t E = sh_rstart[64];
     Vec<VEC> acc;
     vec_zero(acc);
 #pragma unroll 1
     for (uint32_t qb = uint32_t(grp) * WIN; qb < E; qb += NG * WIN) {  // this group's windows
-      uint32_t p = kNone;
+      uint32_t p = 0;
       if (j < WIN && qb + j < E) {
         const uint32_t q = qb + j;
         uint32_t lo = 0, hi = 63;  // run r with rstart[r] <= q < rstart[r+1]
@@ -597,6 +727,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         p = b * kRdBlock + ((run_cnt(val) == 1) ? run_first(val)
                                                  : uint32_t(d.seg[b * kRdBlock + run_off(val) + i]));
       }
+      // round trip 3: WIN gradient rows in flight
       Vec<VEC> v[WIN];
 #pragma unroll
       for (int t = 0; t < WIN; ++t) vec_zero(v[t]);
@@ -611,7 +742,8 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
     }
 #pragma unroll
     for (int cc = 0; cc < VEC; ++cc) sh_sum[grp][j * VEC + cc] = acc.v[cc];
-    __syncthreads();
+    wt.mark(2);
+    lds_barrier();
     Vec<VEC> tot;  // groups in order -> the item's sum (wave 0 holds it; group 0 uses it)
     vec_zero(tot);
     if (threadIdx.x < 64) {
@@ -621,18 +753,19 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         for (int cc = 0; cc < VEC; ++cc) tot.v[cc] = tot.v[cc] + sh_sum[g2][j * VEC + cc];
       }
     }
+    wt.mark(3);
     bool apply = nitems == 1;  // block-uniform
     if (nitems > 1) {
       // partial row per item (the items of a list are consecutive), write-through hand-off
       if (threadIdx.x < G && ev) store_wt<VEC>(c.part + int64_t(w) * dim + e, tot);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      lds_barrier();
       if (threadIdx.x == 0) {
         const uint32_t last = (atomicAdd(&c.arrive[hd.u], 1u) == nitems - 1) ? 1u : 0u;
         if (last) c.arrive[hd.u] = 0;  // clean-after-use
         sh_last = last;
       }
-      __syncthreads();
+      lds_barrier();
       if (sh_last) {  // add the item sums in item order (fixed association), then apply
         apply = true;
         const uint32_t w0 = w - kk;
@@ -652,10 +785,10 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
           for (int t = 0; t < 8; ++t)
             if (q + t < k1 && ev) vec_add(sacc, r[t]);
         }
-        __syncthreads();  // sh_sum is reused
+        lds_barrier();  // sh_sum is reused
 #pragma unroll
         for (int cc = 0; cc < VEC; ++cc) sh_sum[grp][j * VEC + cc] = sacc.v[cc];
-        __syncthreads();
+        lds_barrier();
         vec_zero(tot);
         if (threadIdx.x < 64) {
           for (int g2 = 0; g2 < NG && uint32_t(g2) * per < nitems; ++g2) {
@@ -675,7 +808,8 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         optimize_row_reg<VEC>(tv, row_ptr(tv, sr.r), sr.is_new, e, tot, a);
       }
     }
-    __syncthreads();  // LDS is reused by the next item
+    wt.mark(4);
+    lds_barrier();  // LDS is reused by the next item
   }
 }
 
@@ -690,22 +824,26 @@ struct SlowArgs {  // slowpath_role's arguments; enabled = 0: no displacement pa
   int32_t enabled;
 };
 
-constexpr int kLookupUnroll = 2;  // ids per group of the forward lookup (scripts/lookup_sweep.py)
+// ids per group of the forward lookup: 2 is the fastest shape (scripts/lookup_sweep.py); the host
+// picks 3 or 4 when that is what it takes to have every workgroup of the launch resident at once
 
 // step_fwd:  run dedup of the NEXT batch | displacement pass of the previous update (one wavefront,
 //            the lookup workgroups gate on it) | lookup of this batch
-template <int G, int VEC>
-__global__ __launch_bounds__(kRdBlock) void step_fwd_kernel(RunView nxt, TableView tv,
+// (<= 80 SGPRs: with more, the hardware admits 7 wavefronts per SIMD and only ONE of these
+// 16-wavefront workgroups per CU instead of two — MI355X_MICROARCH.md, residency)
+template <int G, int VEC, int UNR>
+__global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void step_fwd_kernel(RunView nxt, TableView tv,
                                                             const int64_t* __restrict__ ids,
                                                             int64_t n, float* __restrict__ out,
-                                                            int count_hits, SlowArgs sp) {
+                                                            int count_hits, SlowArgs sp,
+                                                            uint32_t nblk_l) {
   __shared__ __attribute__((aligned(16))) RdLds L;
   static_assert(sizeof(BfsSlot) * kMaxCuckooCount + sizeof(CuckooRecord) * kMaxBfsPathLen <=
                     sizeof(RdLds), "BFS scratch must fit the dedup's LDS");
   WaveTrace wt(tv.trace);
   uint32_t bid = blockIdx.x;
   if (bid < nxt.nblk) {
-    rd_dedup_role(nxt, bid, L);
+    rd_dedup_role(nxt, bid, L, wt);
     wt.end(3u);
     return;
   }
@@ -723,15 +861,18 @@ __global__ __launch_bounds__(kRdBlock) void step_fwd_kernel(RunView nxt, TableVi
     }
     bid -= 1;
   }
-  lookup_role_u<G, VEC, kLookupUnroll, true>(tv, ids, n, nullptr, out, count_hits,
-                                             (int64_t(bid) * kRdBlock + threadIdx.x) / G,
-                                             sp.enabled);
+  // lookup workgroups: as many as are resident beside the other roles (nblk_l), grid-stride
+  const int64_t ngroups = (n + UNR - 1) / UNR;
+#pragma unroll 1
+  for (int64_t g = (int64_t(bid) * kRdBlock + threadIdx.x) / G; g < ngroups;
+       g += int64_t(nblk_l) * kRdBlock / G)
+    lookup_role_u<G, VEC, UNR, true>(tv, ids, n, nullptr, out, count_hits, g, sp.enabled);
   wt.end(5u);
 }
 
 // step_bwd:  heavy work list of the NEXT batch | apply of this batch
 template <int G, int VEC>
-__global__ __launch_bounds__(256, 4) void step_bwd_kernel(RunView nxt, uint32_t nblk_build,
+__global__ __launch_bounds__(256, kBwdBlocksPerCu) void step_bwd_kernel(RunView nxt, uint32_t nblk_build,
                                                        TableView tv, RunView cur, ApplyCtl c,
                                                        ApplyArgs a) {
   WaveTrace wt(tv.trace);
@@ -741,7 +882,7 @@ __global__ __launch_bounds__(256, 4) void step_bwd_kernel(RunView nxt, uint32_t 
     return;
   }
   const uint32_t bid = blockIdx.x - nblk_build;
-  rd_apply_role<G, VEC>(tv, cur, c, a, bid);
+  rd_apply_role<G, VEC>(tv, cur, c, a, bid, wt);
   wt.end(bid < c.nblk_items ? 7u : 8u);
 }
 

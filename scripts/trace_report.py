@@ -39,11 +39,21 @@ def main(path):
       st = (r[m, 0] - t0) / 100.0
       en = (r[m, 1] - t0) / 100.0
       life = en - st
+      marks = ""
+      if r.shape[1] > 3:
+        parts = []
+        for k in range(3, r.shape[1]):
+          mk = r[m, k]
+          ok = mk != 0
+          if ok.any():
+            rel = (mk[ok] - r[m, 0][ok]) / 100.0
+            parts.append("m%d %.2f/%.2f/%.2f (%d)" % (k - 3, q(rel, 50), q(rel, 95), rel.max(), int(ok.sum())))
+        marks = " marks since wave start med/p95/max us: " + ", ".join(parts) if parts else ""
       print("| %d | | | %s | %d | %.2f / %.2f / %.2f / %.2f | %.2f / %.2f / %.2f | "
-            "%.2f / %.2f / %.2f |" % (li, ROLES.get(int(role), str(role)), int(m.sum()),
+            "%.2f / %.2f / %.2f |%s" % (li, ROLES.get(int(role), str(role)), int(m.sum()),
                                       st.min(), q(st, 50), q(st, 95), st.max(),
                                       q(en, 50), q(en, 95), en.max(),
-                                      q(life, 50), q(life, 95), life.max()))
+                                      q(life, 50), q(life, 95), life.max(), marks))
   # gaps between consecutive launches (end of one to first wave of the next)
   prev_end = None
   gaps = []
