@@ -207,6 +207,7 @@ def main():
     # resident id array, so nothing is copied or skipped inside the timed region.
     gc = 10
     if args.launch in ("auto", "graph") and K % gc == 0 and W % gc == 0:
+      graphs = []
       try:
         # one eager step first: leaves batch cur+1 deduplicated ahead and a displacement pass
         # outstanding, the state every chunk starts from
@@ -214,7 +215,6 @@ def main():
         cur += 1
         step.quiesce()
         G0 = cur
-        graphs = []
         for c0 in range(G0, G0 + W + K, gc):
           g = torch.cuda.CUDAGraph()
           with torch.cuda.graph(g):
@@ -236,6 +236,10 @@ def main():
         graph_err = repr(e)[:300]
         print("graph path failed: %s" % graph_err, file=sys.stderr)
         torch.cuda.synchronize()
+        # the aborted capture advanced the host-side pipeline state without executing anything:
+        # start the following passes from a fresh pipeline
+        step = SparseStep(mt, "emb", B, exact_order=args.exact_order)
+        cur += gc * (len(graphs) + 1)
     P0 = cur
   else:
     from monolith_amd.distributed_ps_sync import HipBackend, ShardedEmbedding

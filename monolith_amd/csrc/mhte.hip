@@ -220,7 +220,7 @@ struct DedupWs {
   // --- run dedup of the pipelined step (mhte_step_kernels.h); own scratch, independent of the
   // list-building dedup above
   DevBuf<int64_t> r_hkey, r_btab_key;
-  DevBuf<uint32_t> r_hcnt, r_hpos, r_ucnt, r_upos, r_btab_val, r_item_runs, r_ctr;
+  DevBuf<uint32_t> r_hcnt, r_hpos, r_hlist, r_uslot, r_ucnt, r_upos, r_btab_val, r_item_runs, r_ctr;
   DevBuf<unsigned long long> r_hblk, r_ublk;
   DevBuf<uint16_t> r_seg;
   DevBuf<ItemHdr> r_item_hdr;
@@ -246,8 +246,10 @@ struct DedupWs {
     r_hcnt.reserve(size_t(C) + 2);
     r_hblk.reserve(size_t(C) + 2);
     r_hpos.reserve(size_t(C) + 2);
+    r_hlist.reserve((size_t(C) + 2) * kLightMax);
     r_ctr.reserve(4);
     const uint32_t nblk = uint32_t((n + kRdBlock - 1) / kRdBlock);
+    r_uslot.reserve(size_t(n) + 1);
     r_ucnt.reserve(size_t(n) + 1);
     r_ublk.reserve(size_t(n) + 1);
     r_upos.reserve(size_t(n) + 1);
@@ -257,8 +259,8 @@ struct DedupWs {
     r_item_hdr.reserve(max_items(n));
     r_item_runs.reserve(size_t(max_items(n)) * 64);
     RunView d{};
-    d.hkey = r_hkey.p; d.hcnt = r_hcnt.p; d.hblk = r_hblk.p; d.hpos = r_hpos.p; d.cap_mask = C - 1;
-    d.ucnt = r_ucnt.p; d.ublk = r_ublk.p; d.upos = r_upos.p; d.btab_key = r_btab_key.p; d.btab_val = r_btab_val.p; d.seg = r_seg.p;
+    d.hkey = r_hkey.p; d.hcnt = r_hcnt.p; d.hblk = r_hblk.p; d.hpos = r_hpos.p; d.hlist = r_hlist.p; d.cap_mask = C - 1;
+    d.uslot = r_uslot.p; d.ucnt = r_ucnt.p; d.ublk = r_ublk.p; d.upos = r_upos.p; d.btab_key = r_btab_key.p; d.btab_val = r_btab_val.p; d.seg = r_seg.p;
     d.item_hdr = r_item_hdr.p; d.item_runs = r_item_runs.p; d.ctr = r_ctr.p;
     d.ids = ids; d.n = uint32_t(n); d.nblk = nblk; d.uids = uids; d.n_unique = n_unique_dev;
     if (r_hkey.p != old_key || r_ctr.p != old_ctr || C > r_clean_cap || r_stage != 0) {
@@ -532,6 +534,15 @@ struct Table {
     const bool need_keys = double(keys_upper) > max_load * double(uint64_t(kSlots) << hp);
     const bool need_rows = rows_upper > row_cap;
     if (!need_keys && !need_rows) return;
+    {
+      // growing needs the live counts (a host round trip) and possibly a re-hash: not something a
+      // stream capture can record
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        throw Error(MHTE_FAILED_PRECONDITION,
+                    "table " + name + " must grow, which cannot be captured into a hipGraph: "
+                    "reserve capacity (initial_capacity / reserve_rows) before capturing");
+    }
     sync_counters(st);
     keys_upper = (h_ctr->alloc >> 32) + n;
     rows_upper = (h_ctr->alloc & 0xffffffffull) + n;

@@ -195,7 +195,7 @@ template <int G, int VEC, int UNR, bool NT>
 __device__ __forceinline__ void lookup_role_u(const TableView& tv, const int64_t* __restrict__ ids,
                                               int64_t n, const uint32_t* __restrict__ n_dev,
                                               float* __restrict__ out, int count_hits,
-                                              int64_t group, int gate) {
+                                              int64_t group) {
   const int lane = threadIdx.x & 63;
   const int j = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
@@ -204,13 +204,6 @@ __device__ __forceinline__ void lookup_role_u(const TableView& tv, const int64_t
   if (g0 >= n) return;
   // one 8-byte load per lane for the group's ids, then broadcast
   const int64_t myid = (j < UNR && g0 + j < n) ? ids[g0 + j] : 0;
-  if (gate) {
-    if (__hip_atomic_load(&tv.ctr->n_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-      while (__hip_atomic_load(&tv.ctr->n_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
-        __builtin_amdgcn_s_sleep(8);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-  }
   int64_t id[UNR];
   bool valid[UNR], match[UNR];
   uint32_t row[UNR];
@@ -276,7 +269,7 @@ __global__ __launch_bounds__(BLOCK) void lookup_kernel_u(TableView tv,
                                                          float* __restrict__ out, int count_hits) {
   WaveTrace wt(tv.trace);
   lookup_role_u<G, VEC, UNR, NT>(tv, ids, n, n_dev, out, count_hits,
-                                 (int64_t(blockIdx.x) * BLOCK + threadIdx.x) / G, 0);
+                                 (int64_t(blockIdx.x) * BLOCK + threadIdx.x) / G);
   wt.end(5u);
 }
 
@@ -543,6 +536,147 @@ __global__ __launch_bounds__(256) void upsert_kernel(TableView tv, const int64_t
 // =============================================================================================
 // SOLO: the role is the whole (64-thread) workgroup; otherwise it is wave 0 of a larger one
 // and must not use workgroup barriers (lane 0 alone reads and writes q/path and the buckets).
+// Wave-parallel form of slot_search (mhte_core.h; cuckoohash_map.hpp:1725-1762) with the SAME
+// result: the BFS queue is processed level by level, 64 queue entries per round, every lane
+// loading one candidate bucket.  The serial search returns at the first queue entry (in queue
+// order) that has an empty slot; entries of one depth are independent of each other and, when
+// none of a round has an empty slot, each pushes exactly its four children in slot order — so
+// child positions are arithmetic and the first hit in lane order is the serial answer.  A
+// displacement then costs ~one memory round trip per BFS level instead of one per bucket looked
+// at (each is a random HBM line: ~3 us on a table of this size).
+__device__ __forceinline__ BfsSlot slot_search_wave(const Bucket* buckets, uint32_t hp, uint64_t i1,
+                                                    uint64_t i2, BfsSlot* q, int lane) {
+  if (lane == 0) {
+    q[0] = BfsSlot{i1, 0, 0};
+    q[1] = BfsSlot{i2, 1, 0};
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int first = 0, last = 2;
+  for (int depth = 0; depth < kMaxBfsPathLen; ++depth) {
+    const int next0 = last;  // children of this level start here
+    for (int c = first; c < last; c += 64) {
+      const int idx = c + lane;
+      const bool has = idx < last;
+      BfsSlot x = has ? q[idx] : BfsSlot{0, 0, 0};
+      int64_t key[kSlots];
+#pragma unroll
+      for (int s = 0; s < kSlots; ++s) key[s] = has ? buckets[x.bucket].key[s] : 0;
+      const int starting_slot = x.pathcode % kSlots;
+      int empty_i = -1;  // first empty slot in scan order
+#pragma unroll
+      for (int i = kSlots - 1; i >= 0; --i) {
+        const int slot = (starting_slot + i) % kSlots;
+        int64_t k = key[0];
+#pragma unroll
+        for (int s = 1; s < kSlots; ++s) k = (slot == s) ? key[s] : k;
+        if (k == kEmptyKey) empty_i = i;
+      }
+      const uint64_t fm = __ballot(has && empty_i >= 0);
+      if (fm) {
+        const int src = __ffsll(static_cast<long long>(fm)) - 1;
+        const int slot = (starting_slot + empty_i) % kSlots;
+        BfsSlot r = x;
+        r.pathcode = static_cast<uint16_t>(x.pathcode * kSlots + slot);
+        BfsSlot out;
+        out.bucket = __shfl(r.bucket, src);
+        out.pathcode = static_cast<uint16_t>(__shfl(int(r.pathcode), src));
+        out.depth = static_cast<int8_t>(__shfl(int(r.depth), src));
+        return out;
+      }
+      if (has && depth < kMaxBfsPathLen - 1) {
+#pragma unroll
+        for (int i = 0; i < kSlots; ++i) {
+          const int slot = (starting_slot + i) % kSlots;
+          int64_t k = key[0];
+#pragma unroll
+          for (int s = 1; s < kSlots; ++s) k = (slot == s) ? key[s] : k;
+          BfsSlot y;
+          y.bucket = alt_index(hp, partial_key(hash_key(k)), x.bucket);
+          y.pathcode = static_cast<uint16_t>(x.pathcode * kSlots + slot);
+          y.depth = static_cast<int8_t>(depth + 1);
+          q[next0 + (idx - first) * kSlots + i] = y;
+        }
+      }
+    }
+    if (depth == kMaxBfsPathLen - 1) break;
+    const int n = last - first;
+    first = last;
+    last = next0 + n * kSlots;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  return BfsSlot{0, 0, -1};
+}
+
+// serial_insert_slot (mhte_core.h) with the path search done by the whole wavefront; every lane
+// calls it, lane 0 alone writes the buckets.  Same placement as the serial form.
+__device__ __forceinline__ long long wave_insert_slot(Bucket* buckets, uint32_t hp, int64_t key,
+                                                      BfsSlot* q, CuckooRecord* path, int lane) {
+  const uint64_t hv = hash_key(key);
+  const uint32_t partial = partial_key(hv);
+  const uint64_t i1 = index_hash(hp, hv);
+  const uint64_t i2 = alt_index(hp, partial, i1);
+  long long pos = -2;
+  if (lane == 0) {  // try_find_insert_bucket, :1398-1418 — last empty slot of b1, else of b2
+    for (int pass = 0; pass < 2 && pos == -2; ++pass) {
+      const uint64_t ib = pass == 0 ? i1 : i2;
+      int found = -1;
+      for (int s = 0; s < kSlots; ++s)
+        if (!slot_occupied(buckets[ib], s)) found = s;
+      if (found >= 0) {
+        buckets[ib].key[found] = key;
+        pos = static_cast<long long>(ib * kSlots + found);
+      }
+    }
+  }
+  pos = __shfl(pos, 0);
+  if (pos != -2) return pos;
+  for (int attempt = 0; attempt < 64; ++attempt) {  // (single owner: the first path always moves)
+    BfsSlot x = slot_search_wave(buckets, hp, i1, i2, q, lane);
+    int done = 0;  // 1 placed, -1 no path
+    if (lane == 0) {
+      if (x.depth == -1) {
+        done = -1;
+      } else {  // cuckoopath_search's path reconstruction, :1508-1561
+        const int d0 = x.depth;
+        for (int i = x.depth; i >= 0; --i) {
+          path[i].slot = x.pathcode % kSlots;
+          x.pathcode = static_cast<uint16_t>(x.pathcode / kSlots);
+        }
+        path[0].bucket = (x.pathcode == 0) ? i1 : i2;
+        int depth = d0;
+        {
+          const Bucket& b = buckets[path[0].bucket];
+          if (!slot_occupied(b, path[0].slot)) {
+            depth = 0;
+          } else {
+            path[0].hash = hash_key(b.key[path[0].slot]);
+            path[0].partial = partial_key(path[0].hash);
+            for (int i = 1; i <= d0; ++i) {
+              path[i].bucket = alt_index(hp, path[i - 1].partial, path[i - 1].bucket);
+              const Bucket& bi = buckets[path[i].bucket];
+              if (!slot_occupied(bi, path[i].slot)) {
+                depth = i;
+                break;
+              }
+              path[i].hash = hash_key(bi.key[path[i].slot]);
+              path[i].partial = partial_key(path[i].hash);
+            }
+          }
+        }
+        if (cuckoopath_move(buckets, path, depth)) {
+          buckets[path[0].bucket].key[path[0].slot] = key;
+          pos = static_cast<long long>(path[0].bucket * kSlots + path[0].slot);
+          done = 1;
+        }
+      }
+    }
+    done = __shfl(done, 0);
+    if (done == -1) return -1;
+    if (done == 1) return __shfl(pos, 0);
+  }
+  return -1;
+}
+
 // GATED: other workgroups of the same launch wait for n_pending == 0 before they touch the table
 // (lookup_role's gate): the pass ends with an agent-scope release (its bucket and row stores are
 // written back from this XCD's L2) followed by an agent-scope store of the 0.
@@ -560,10 +694,9 @@ __device__ __forceinline__ void slowpath_role(const TableView& tv, const int64_t
   for (uint32_t i = 0; i < np; ++i) {
     const uint32_t g = pending[i];
     const int64_t id = ids[g];
-    long long pos = -1;
+    long long pos = wave_insert_slot(tv.buckets, tv.hp, id, q, path, lane);
     uint32_t r = kNoRow;
     if (lane == 0) {
-      pos = serial_insert_slot(tv.buckets, tv.hp, id, q, path);
       if (pos >= 0) {
         r = static_cast<uint32_t>(atomicAdd(&tv.ctr->alloc, (1ull << 32) | 1ull));
         Bucket* b = tv.buckets + (pos >> 2);
@@ -574,7 +707,6 @@ __device__ __forceinline__ void slowpath_role(const TableView& tv, const int64_t
         atomicAdd(&tv.ctr->n_dropped, 1u);
       }
     }
-    pos = __shfl(pos, 0);
     r = __shfl(r, 0);
     if (pos >= 0) {
       const uint32_t q0 = seg_off ? seg_off[g] : 0u;

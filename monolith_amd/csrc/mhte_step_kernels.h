@@ -41,7 +41,7 @@ constexpr int kRdBlock = 1024;          // positions per dedup workgroup (one pe
 constexpr int kRdLds = 2048;            // LDS hash entries per workgroup
 constexpr int kRdStride = kRdLds + 1;   // + side entry for kEmptyKey
 constexpr int kRdMaxBlocks = 64;        // bits of the workgroup mask: n <= 65 536 positions
-constexpr int kLongRun = 16;
+constexpr int kLongRun = kLightMax;  // (a run that may belong to a light list keeps its positions in LDS)
 constexpr int kMaxLongRuns = 16;
 constexpr uint32_t kItemTarget = 256;   // entries per heavy work item (expected)
 constexpr int kBwdBlocksPerCu = 5;      // 256-thread workgroups of step_bwd resident per CU (<= 96 VGPRs)
@@ -80,9 +80,12 @@ struct RunView {
   uint32_t* hcnt;               // occurrences of the slot's id in the batch
   unsigned long long* hblk;     // mask of the workgroups that hold a run of it
   uint32_t* hpos;               // position of an occurrence (the only one when hcnt == 1)
+  uint32_t* hlist;              // [slots][kLightMax] the positions of a light list (<= kLightMax
+                                //     occurrences), runs in arrival order; never scanned or reset
   uint32_t cap_mask;
   // per batch
-  uint32_t* ucnt;               // [n] dense copies made by the build role: occurrences,
+  uint32_t* uslot;              // [n] dense copies made by the build role: scratch slot,
+  uint32_t* ucnt;               //     occurrences,
   unsigned long long* ublk;     //     workgroup mask,
   uint32_t* upos;               //     a position (the only one when ucnt == 1) of unique index u
   int64_t* btab_key;            // [nblk][kRdStride] dumped LDS tables
@@ -250,25 +253,37 @@ __device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, Rd
     d.seg[bid * kRdBlock + o + rank] = uint16_t(t);
   }
   wt.mark(3);
-  // ---- the LDS table is the workgroup's run directory
-  for (uint32_t i = t; i < uint32_t(kRdStride); i += kRdBlock) {
-    d.btab_key[size_t(bid) * kRdStride + i] = static_cast<int64_t>(L.key[i]);
-    d.btab_val[size_t(bid) * kRdStride + i] = run_pack(L.first[i] & 0x3ffu, L.off[i] & 0x3ffu, L.cnt[i]);
-  }
-  // ---- now the CAS: the home slot was free or already held the id (usual), else linear probing
+  // ---- now the CAS: the home slot was free or already held the id (usual), else linear probing.
+  // The count bump returns the number of occurrences other workgroups have registered so far =
+  // where this run goes in the id's position list; it is in flight during the table dump.
+  uint32_t lbase = 0;
   if (speaker) {
-    const int64_t want = (id == kEmptyKey) ? kEmptyKey : id;  // side slot: anything but empty = taken
     if (id != kEmptyKey) {
-      while (cas_old != kEmptyKey && cas_old != want) {
+      while (cas_old != kEmptyKey && cas_old != id) {
         gs = (gs + 1u) & d.cap_mask;
         cas_old = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hkey[gs]),
                                                  static_cast<unsigned long long>(kEmptyKey),
                                                  static_cast<unsigned long long>(id)));
       }
     }
-    atomicAdd(&d.hcnt[gs], L.cnt[ls]);       // (no return value: fire and forget)
-    atomicOr(&d.hblk[gs], 1ull << bid);
+    lbase = atomicAdd(&d.hcnt[gs], L.cnt[ls]);
+    atomicOr(&d.hblk[gs], 1ull << bid);      // (no return value: fire and forget)
     d.hpos[gs] = p;                          // read only when the id turns out to occur once
+  }
+  // ---- the LDS table is the workgroup's run directory
+  for (uint32_t i = t; i < uint32_t(kRdStride); i += kRdBlock) {
+    d.btab_key[size_t(bid) * kRdStride + i] = static_cast<int64_t>(L.key[i]);
+    d.btab_val[size_t(bid) * kRdStride + i] = run_pack(L.first[i] & 0x3ffu, L.off[i] & 0x3ffu, L.cnt[i]);
+  }
+  // ---- position list of a (so far) light id: this run's positions behind those already there.
+  // A list that outgrows kLightMax is simply left incomplete — its id is heavy and served by runs.
+  if (speaker) {
+    const uint32_t c = L.cnt[ls];
+    if (lbase + c <= uint32_t(kLightMax)) {
+      const uint32_t o = L.off[ls];
+      for (uint32_t i = 0; i < c; ++i)
+        d.hlist[size_t(gs) * kLightMax + lbase + i] = bid * kRdBlock + uint32_t(L.pos[o + i]);
+    }
   }
   wt.mark(4);
 }
@@ -371,6 +386,7 @@ __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_m
       k0 += uint32_t(__popcll(occ[q]));
       if ((occ[q] >> lane) & 1ull) {
         d.uids[kq[q]] = key[q];
+        d.uslot[kq[q]] = base + q * 64 + lane;
         d.ucnt[kq[q]] = cnt[q];
         d.ublk[kq[q]] = blk[q];
         d.upos[kq[q]] = pos[q];
@@ -573,6 +589,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       uint32_t cnt = inb ? d.ucnt[g] : 0u;
       const unsigned long long bm = inb ? d.ublk[g] : 0ull;
       const uint32_t hp = inb ? d.upos[g] : 0u;
+      const uint32_t gs = inb ? d.uslot[g] : 0u;
       if (it == 0) nu = min(c.n_max, int64_t(d.ctr[0]));
       bool valid = g < nu;
       if (!valid) cnt = 0;
@@ -586,39 +603,15 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       Vec<VEC> g1;
       vec_zero(g1);
       if (single && ev) g1.load(c.grads + int64_t(hp) * dim + e);
-      if (flat) {
-        // flat list of <= kLightMax positions in LDS, runs in workgroup order; lane j takes the
-        // j-th run, then the (j+G)-th ...
-        const uint32_t nr = uint32_t(__popcll(bm));
-        uint32_t filled = 0;
-        unsigned long long rest = bm;
-#pragma unroll 1
-        for (uint32_t r0 = 0; r0 < nr; r0 += G) {  // group-uniform
-          unsigned long long m = rest;
-          for (int s = 0; s < j; ++s) m &= m - 1ull;
-          const bool mine = (r0 + uint32_t(j) < nr) && m != 0ull;
-          const uint32_t b = mine ? uint32_t(__ffsll(static_cast<long long>(m)) - 1) : 0u;
-          const uint32_t val = mine ? rd_find_run(d, b, id) : 0u;
-          const uint32_t cb = run_cnt(val);
-          uint32_t incl = cb;  // offsets of the runs inside the flat list
+      // a short list (2..kLightMax occurrences): its positions from the dedup's per-id list, runs in
+      // arrival order -> ranked in registers (positions are distinct, so the ranks are a
+      // permutation) and handed over in position order through LDS
+      constexpr int PER = (kLightMax + G - 1) / G;
+      uint32_t x[PER];
 #pragma unroll
-          for (int o = 1; o < G; o <<= 1) {
-            const uint32_t v = __shfl_up(incl, o, G);
-            if (j >= o) incl += v;
-          }
-          const uint32_t off = filled + incl - cb;
-          if (mine) {
-            if (cb == 1) {
-              sh_pos[grp][off] = b * kRdBlock + run_first(val);
-            } else {
-              const uint16_t* sp = d.seg + b * kRdBlock + run_off(val);
-#pragma unroll 1
-              for (uint32_t i = 0; i < cb; ++i) sh_pos[grp][off + i] = b * kRdBlock + sp[i];
-            }
-          }
-          filled += __shfl(incl, gbase + G - 1);
-          for (int s = 0; s < G && rest; ++s) rest &= rest - 1ull;
-        }
+      for (int q = 0; q < PER; ++q) {
+        const uint32_t idx = uint32_t(j) + uint32_t(q) * G;
+        x[q] = (flat && idx < cnt) ? d.hlist[size_t(gs) * kLightMax + idx] : 0xffffffffu;
       }
       if (it == 0) wt.mark(1);
       // round trip 3: the row
@@ -631,6 +624,23 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       if (valid && !sr.deferred) {
         rp = row_ptr(tv, sr.r);
         if (!sr.is_new) row_prefetch<VEC>(tv, rp, e, rr);
+      }
+      if (__any(flat)) {
+        uint32_t xr[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) xr[q] = 0;
+#pragma unroll
+        for (int q2 = 0; q2 < PER; ++q2) {
+#pragma unroll 4
+          for (int t2 = 0; t2 < G; ++t2) {
+            const uint32_t y = __shfl(x[q2], gbase + t2);
+#pragma unroll
+            for (int q = 0; q < PER; ++q) xr[q] += (y < x[q]) ? 1u : 0u;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+          if (x[q] != 0xffffffffu) sh_pos[grp][xr[q]] = x[q];
       }
       lds_wave_sync();
       if (it == 0) wt.mark(2);
@@ -862,11 +872,26 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
     bid -= 1;
   }
   // lookup workgroups: as many as are resident beside the other roles (nblk_l), grid-stride
+  if (sp.enabled) {
+    // A displacement pass for the previous update runs in another workgroup of this launch.  No
+    // table word is read before it has finished: ONE lane polls n_pending (it drops to 0 only
+    // after the pass's stores were written back: agent-scope release), then ONE agent-scope
+    // acquire for the workgroup (cdna_hip_programming.md G16: per-wavefront acquires multiply the
+    // cost), then plain loads.  Usually the first poll already reads 0.
+    if (threadIdx.x == 0) {
+      if (__hip_atomic_load(&tv.ctr->n_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        while (__hip_atomic_load(&tv.ctr->n_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+          __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+    }
+    __syncthreads();
+  }
   const int64_t ngroups = (n + UNR - 1) / UNR;
 #pragma unroll 1
   for (int64_t g = (int64_t(bid) * kRdBlock + threadIdx.x) / G; g < ngroups;
        g += int64_t(nblk_l) * kRdBlock / G)
-    lookup_role_u<G, VEC, UNR, true>(tv, ids, n, nullptr, out, count_hits, g, sp.enabled);
+    lookup_role_u<G, VEC, UNR, true>(tv, ids, n, nullptr, out, count_hits, g);
   wt.end(5u);
 }
 
