@@ -268,7 +268,7 @@ def main():
 
   # ---- per-kernel timing (N=1): HIP events stamped with each kernel's own begin/end on the launch
   # stream (mhte_profile_arm -> hipExtLaunchKernelGGL), the interval rocprofv3 --kernel-trace
-  # reports.  Pass 1: the pipelined step as timed above (3 zipped launches per step).  Pass 2: the
+  # reports.  Pass 1: the pipelined step as timed above (2 launches per step).  Pass 2: the
   # same work as separate launches, which attributes time to lookup / backward / dedup.
   roofline, stages, uniq_avg = None, {}, None
   if world == 1 and not args.no_stage_timing:

@@ -87,7 +87,7 @@ class DedupWorkspace:
   def unique_unordered(self, ids: torch.Tensor, want_host_count: bool = False,
                        out: Optional[UniqueResult] = None) -> UniqueResult:
     """Same key set and occurrence lists as ``unique`` with an unspecified numbering of the unique
-    ids (mhte_unique_unordered, 3 launches instead of 5) — what the fused step needs.  In the
+    ids (mhte_unique_unordered, 3 launches instead of 5) — what the unpipelined fused backward needs.  In the
     result ``seg_off[u]`` / ``list_end[u]`` bound the positions of unique id u inside seg_pos."""
     assert ids.is_cuda and ids.dtype == torch.int64 and ids.is_contiguous()
     n = ids.numel()
