@@ -289,6 +289,27 @@ mhte_status mhte_table_finish_pending(mhte_multi_table* t, int32_t table, void* 
  * (mhte_table_finish_pending).  The table row must satisfy mhte_table_fused_backward_ok. */
 mhte_status mhte_step_dedup(mhte_dedup_ws* ws, const int64_t* id, int64_t n, int64_t* unique_ids,
                             uint32_t* n_unique_dev, void* stream);
+/* Sender side of the id-sharded step (NT/distributed_ps_sync.py:95-490), on the batch held by ws
+ * (mhte_step_dedup):
+ *   mhte_shard_partition  FusedReorderByIndices' shard-major packing (RT/ops/fused_reorder_by_indices.cc
+ *                         :75-123; shard = floormod(id, num_shards), NT/distributed_ps.py:289) of ids
+ *                         that are already unique: send_ids [dev, n_max] shard-major, send_pos
+ *                         [dev u32, n_max] position of ids[u] in it, counts [dev u32, num_shards].
+ *                         The id count comes from device memory (n_dev).  num_shards <= 64.
+ *   mhte_step_scatter     out[p, :] = rows[idx(u), :] for every occurrence p of unique index u
+ *                         (MonolithFillWithOffsetMap, RT/ops/unique_mapping_ops.cc:204-268)
+ *   mhte_step_sum         out[idx(u), :] = sum over the occurrences p of u of grads[p, :], in
+ *                         occurrence order for lists of <= 32, a fixed tree otherwise
+ *                         (MonolithFillWithOffsetMapGradient, :284-329)
+ * idx(u) = index ? index[u] : u (pass send_pos: rows arrive / gradients leave in send order).
+ * dim <= 256. */
+mhte_status mhte_shard_partition(mhte_dedup_ws* ws, const int64_t* ids, int64_t n_max,
+                                 const uint32_t* n_dev, int32_t num_shards, int64_t* send_ids,
+                                 uint32_t* send_pos, uint32_t* counts, void* stream);
+mhte_status mhte_step_scatter(mhte_dedup_ws* ws, const float* rows, const uint32_t* index,
+                              int32_t dim, float* out, void* stream);
+mhte_status mhte_step_sum(mhte_dedup_ws* ws, const float* grads, const uint32_t* index, int32_t dim,
+                          float* out, void* stream);
 mhte_status mhte_table_step_forward(mhte_multi_table* t, int32_t table, const int64_t* id,
                                     int64_t n, float* embedding, mhte_dedup_ws* ws_next,
                                     const int64_t* id_next, int64_t n_next,

@@ -224,6 +224,7 @@ struct DedupWs {
   DevBuf<unsigned long long> r_hblk, r_ublk;
   DevBuf<uint16_t> r_seg;
   DevBuf<ItemHdr> r_item_hdr;
+  DevBuf<uint32_t> r_cursor;   // shard packing cursors
   uint32_t r_clean_cap = 0;  // run scratch [0, r_clean_cap] is all-empty
   int r_stage = 0;           // 0 idle, 1 dedup enqueued, 2 work list enqueued (ready for apply)
   RunView rv{};
@@ -233,7 +234,8 @@ struct DedupWs {
   }
 
   // Arguments of a run dedup of ids[0, n), n <= 65 536; the caller enqueues rd_dedup (on its own or
-  // inside step_fwd).  A dedup that was never applied leaves the scratch dirty: clear first.
+  // inside step_fwd).  A dedup that was never built leaves the scratch dirty: clear first (the
+  // build role resets the scratch; the apply only consumes the dense arrays).
   RunView begin_run_dedup(const int64_t* ids, int64_t n, int64_t* uids, uint32_t* n_unique_dev,
                           hipStream_t st) {
     if (n <= 0 || n > int64_t(kRdMaxBlocks) * kRdBlock)
@@ -263,7 +265,7 @@ struct DedupWs {
     d.uslot = r_uslot.p; d.ucnt = r_ucnt.p; d.ublk = r_ublk.p; d.upos = r_upos.p; d.btab_key = r_btab_key.p; d.btab_val = r_btab_val.p; d.seg = r_seg.p;
     d.item_hdr = r_item_hdr.p; d.item_runs = r_item_runs.p; d.ctr = r_ctr.p;
     d.ids = ids; d.n = uint32_t(n); d.nblk = nblk; d.uids = uids; d.n_unique = n_unique_dev;
-    if (r_hkey.p != old_key || r_ctr.p != old_ctr || C > r_clean_cap || r_stage != 0) {
+    if (r_hkey.p != old_key || r_ctr.p != old_ctr || C > r_clean_cap || r_stage == 1) {
       rd_clear_kernel<<<(C + 2 + 255) / 256, 256, 0, st>>>(d);
       r_clean_cap = C;
     }
@@ -1499,6 +1501,95 @@ mhte_status mhte_step_dedup(mhte_dedup_ws* ws, const int64_t* id, int64_t n, int
     LAUNCH_HOT(kTagDedup, rd_dedup_kernel, d.nblk, kRdBlock, st, d);
     HIP_OK(hipGetLastError());
     ws->ws.build_work_list(st);
+  });
+}
+
+extern "C++" {
+namespace mhte {
+// SCATTER / SUM over the run format of ws's deduplicated + built batch (rd_gather_kernel)
+template <bool SCATTER>
+static void step_gather(DedupWs& ws, const float* in, const uint32_t* index, int32_t dim, float* out,
+                        hipStream_t st) {
+  if (ws.r_stage == 1) ws.build_work_list(st);
+  if (ws.r_stage != 2)
+    throw Error(MHTE_FAILED_PRECONDITION, "workspace holds no deduplicated batch (mhte_step_dedup)");
+  if (dim <= 0 || dim > 256) throw Error(MHTE_INVALID_ARGUMENT, "dim must be 1..256");
+  if (!in || !out) throw Error(MHTE_INVALID_ARGUMENT, "null argument");
+  const bool vec = dim % 4 == 0 && aligned16(in) && aligned16(out);
+  Shape sh = pick_shape(uint32_t(dim), vec);
+  if (uint32_t(dim) > uint32_t(sh.G * sh.VEC))
+    throw Error(MHTE_INVALID_ARGUMENT, "rows of more than 64 floats must be 16-byte aligned and a "
+                                       "multiple of 4 floats wide");
+  const int64_t n = ws.rv.n;
+  const uint32_t cap_items = DedupWs::max_items(n);
+  GatherCtl c{};
+  c.in = in;
+  c.out = out;
+  c.index = index;
+  c.n_max = n;
+  c.dim = uint32_t(dim);
+  if (!SCATTER) {
+    ws.part.reserve(size_t(cap_items) * dim + 16);
+    const uint32_t* old = ws.arrive.p;
+    ws.arrive.reserve(size_t(n) + 2);
+    if (ws.arrive.p != old) ws.arrive_clean = 0;
+    if (ws.arrive_clean < size_t(n) + 2) {
+      HIP_OK(hipMemsetAsync(ws.arrive.p, 0, ws.arrive.cap * sizeof(uint32_t), st));
+      ws.arrive_clean = ws.arrive.cap;
+    }
+    c.part = ws.part.p;
+    c.arrive = ws.arrive.p;
+  }
+  const uint32_t groups_per_wg = uint32_t(256 / sh.G);
+  c.nblk_items = std::min<uint32_t>(cap_items, 288);
+  c.nblk_ids = std::max<uint32_t>(1, std::min<uint32_t>(uint32_t((n + groups_per_wg - 1) / groups_per_wg), 1024));
+  const dim3 grid(c.nblk_items + c.nblk_ids);
+  const RunView d = ws.rv;
+#define CALL(G_, V_) rd_gather_kernel<G_, V_, SCATTER><<<grid, 256, 0, st>>>(d, c)
+  DISPATCH_G_VEC(sh, CALL);
+#undef CALL
+  HIP_OK(hipGetLastError());
+}
+}  // namespace mhte
+}  // extern "C++"
+
+mhte_status mhte_step_scatter(mhte_dedup_ws* ws, const float* rows, const uint32_t* index,
+                              int32_t dim, float* out, void* stream) {
+  return guard([&] {
+    if (!ws) throw Error(MHTE_INVALID_ARGUMENT, "null workspace");
+    HIP_OK(hipSetDevice(ws->ws.device));
+    step_gather<true>(ws->ws, rows, index, dim, out, S(stream));
+  });
+}
+
+mhte_status mhte_step_sum(mhte_dedup_ws* ws, const float* grads, const uint32_t* index, int32_t dim,
+                          float* out, void* stream) {
+  return guard([&] {
+    if (!ws) throw Error(MHTE_INVALID_ARGUMENT, "null workspace");
+    HIP_OK(hipSetDevice(ws->ws.device));
+    step_gather<false>(ws->ws, grads, index, dim, out, S(stream));
+  });
+}
+
+mhte_status mhte_shard_partition(mhte_dedup_ws* ws, const int64_t* ids, int64_t n_max,
+                                 const uint32_t* n_dev, int32_t num_shards, int64_t* send_ids,
+                                 uint32_t* send_pos, uint32_t* counts, void* stream) {
+  return guard([&] {
+    if (!ws || !ids || !n_dev || !send_ids || !send_pos || !counts)
+      throw Error(MHTE_INVALID_ARGUMENT, "shard_partition: null argument");
+    if (num_shards < 1 || num_shards > kMaxShards)
+      throw Error(MHTE_INVALID_ARGUMENT, "num_shards must be 1.." + std::to_string(kMaxShards));
+    HIP_OK(hipSetDevice(ws->ws.device));
+    hipStream_t st = S(stream);
+    HIP_OK(hipMemsetAsync(counts, 0, sizeof(uint32_t) * num_shards, st));
+    if (n_max <= 0) return;
+    ws->ws.r_cursor.reserve(kMaxShards);
+    HIP_OK(hipMemsetAsync(ws->ws.r_cursor.p, 0, sizeof(uint32_t) * kMaxShards, st));
+    const uint32_t nb = uint32_t((n_max + 1023) / 1024);
+    rd_shard_count_kernel<<<nb, 1024, 0, st>>>(ids, n_dev, n_max, uint32_t(num_shards), counts);
+    rd_shard_place_kernel<<<nb, 1024, 0, st>>>(ids, n_dev, n_max, uint32_t(num_shards), counts,
+                                               ws->ws.r_cursor.p, send_ids, send_pos);
+    HIP_OK(hipGetLastError());
   });
 }
 

@@ -911,5 +911,315 @@ __global__ __launch_bounds__(256, kBwdBlocksPerCu) void step_bwd_kernel(RunView 
   wt.end(bid < c.nblk_items ? 7u : 8u);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sender side of the id-sharded step (monolith_amd/distributed_ps_sync.py): the two ops of the
+// reference's worker that sit between its dedup and the all-to-all, on the run format of a
+// deduplicated + built batch:
+//   SCATTER  out[p, :]   = rows[idx(u), :]  for every occurrence p of unique index u
+//            (MonolithFillWithOffsetMap, RT/ops/unique_mapping_ops.cc:204-268)
+//   SUM      out[idx(u), :] = sum over the occurrences p of u of grads[p, :], occurrence order
+//            (MonolithFillWithOffsetMapGradient, :284-329)
+// idx(u) = index ? index[u] : u — the position of u in the shard-major send buffer
+// (rd_partition below), so rows come back / gradients leave in send order with no extra permute.
+// Same traversal as rd_apply_role: id-major groups for lists of <= kLightMax occurrences, item
+// workgroups for the heavy ones; same summation order, so a sharded run adds up exactly as the
+// single-GPU step would have.
+// ---------------------------------------------------------------------------------------------
+struct GatherCtl {
+  const float* in;        // SCATTER: rows [*, dim]; SUM: gradients [n, dim]
+  float* out;             // SCATTER: [n, dim];      SUM: [*, dim]
+  const uint32_t* index;  // optional indirection of the unique index
+  float* part;            // SUM: [items, dim] partial rows of multi-item lists
+  uint32_t* arrive;       // SUM: arrival counters, kept zeroed
+  int64_t n_max;          // capacity of the dense arrays
+  uint32_t dim;
+  uint32_t nblk_items;
+  uint32_t nblk_ids;
+};
+
+template <int G, int VEC, bool SCATTER>
+__global__ __launch_bounds__(256) void rd_gather_kernel(RunView d, GatherCtl c) {
+  constexpr int WIN = G < 8 ? G : 8;
+  constexpr int NG = 256 / G;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (G - 1);
+  const int gbase = lane & ~(G - 1);
+  const int grp = threadIdx.x / G;
+  const uint32_t dim = c.dim;
+  const int64_t n_max = c.n_max;
+  const uint32_t e = uint32_t(j) * VEC;
+  const bool ev = e < dim;
+  const uint32_t bid = blockIdx.x;
+
+  if (bid >= c.nblk_items) {
+    __shared__ uint32_t sh_pos[NG][kLightMax];
+    const int64_t stride = int64_t(c.nblk_ids) * NG;
+    const int64_t k = bid - c.nblk_items;
+    int64_t nu = n_max;
+#pragma unroll 1
+    for (int64_t it = 0; it * stride < nu; ++it) {
+      const int64_t g = it * stride + int64_t(grp) * c.nblk_ids + k;
+      const bool inb = g < n_max;
+      uint32_t cnt = inb ? d.ucnt[g] : 0u;
+      const uint32_t hp = inb ? d.upos[g] : 0u;
+      const uint32_t gs = inb ? d.uslot[g] : 0u;
+      const uint32_t ix = inb ? (c.index ? c.index[g] : uint32_t(g)) : 0u;
+      if (it == 0) nu = min(n_max, int64_t(d.ctr[0]));
+      const bool valid = g < nu && cnt <= uint32_t(kLightMax);
+      if (!valid) cnt = 0;
+      constexpr int PER = (kLightMax + G - 1) / G;
+      uint32_t x[PER];
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const uint32_t idx = uint32_t(j) + uint32_t(q) * G;
+        x[q] = (cnt > 1 && idx < cnt) ? d.hlist[size_t(gs) * kLightMax + idx] : 0xffffffffu;
+      }
+      if (SCATTER) {
+        Vec<VEC> row;
+        vec_zero(row);
+        if (valid && ev) row.load(c.in + int64_t(ix) * dim + e);
+        if (cnt == 1) {
+          if (ev) row.store(c.out + int64_t(hp) * dim + e);
+        } else if (cnt > 1) {
+#pragma unroll
+          for (int q = 0; q < PER; ++q) {
+#pragma unroll 4
+            for (int t2 = 0; t2 < G; ++t2) {
+              const uint32_t p = __shfl(x[q], gbase + t2);
+              if (p != 0xffffffffu && ev) row.store(c.out + int64_t(p) * dim + e);
+            }
+          }
+        }
+      } else {
+        Vec<VEC> acc;
+        vec_zero(acc);
+        if (cnt == 1) {
+          Vec<VEC> g1;
+          vec_zero(g1);
+          if (ev) g1.load(c.in + int64_t(hp) * dim + e);
+          vec_add(acc, g1);
+        }
+        if (__any(cnt > 1)) {  // rank the positions in registers, hand over in position order
+          uint32_t xr[PER];
+#pragma unroll
+          for (int q = 0; q < PER; ++q) xr[q] = 0;
+#pragma unroll
+          for (int q2 = 0; q2 < PER; ++q2) {
+#pragma unroll 4
+            for (int t2 = 0; t2 < G; ++t2) {
+              const uint32_t y = __shfl(x[q2], gbase + t2);
+#pragma unroll
+              for (int q = 0; q < PER; ++q) xr[q] += (y < x[q]) ? 1u : 0u;
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < PER; ++q)
+            if (x[q] != 0xffffffffu) sh_pos[grp][xr[q]] = x[q];
+          lds_wave_sync();
+          if (cnt > 1) sum_list_lds<VEC>(c.in, dim, e, ev, sh_pos[grp], cnt, acc);
+          lds_wave_sync();
+        }
+        if (valid && ev) acc.store(c.out + int64_t(ix) * dim + e);
+      }
+    }
+    return;
+  }
+
+  // ---- item workgroups
+  __shared__ uint32_t sh_rstart[65];
+  __shared__ uint32_t sh_rval[64];
+  __shared__ float sh_sum[NG][G * VEC];
+  __shared__ uint32_t sh_last;
+#pragma unroll 1
+  for (uint32_t w = bid;; w += c.nblk_items) {
+    const uint32_t nitems_all = d.ctr[2];
+    const ItemHdr hd = d.item_hdr[w];
+    const uint32_t rval = (threadIdx.x < 64) ? d.item_runs[size_t(w) * 64 + lane] : 0u;
+    if (w >= nitems_all) break;
+    const uint32_t b0 = hd.meta & 0xffu, nbk = (hd.meta >> 8) & 0xffu, kk = (hd.meta >> 16) & 0xffu,
+                   nitems = hd.meta >> 24;
+    const uint32_t ix = c.index ? c.index[hd.u] : hd.u;
+    if (threadIdx.x < 64) {
+      const uint32_t val = (uint32_t(lane) < nbk) ? rval : 0u;
+      uint32_t incl = run_cnt(val);
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      sh_rval[lane] = val;
+      sh_rstart[lane + 1] = incl;
+      if (lane == 0) sh_rstart[0] = 0;
+    }
+    lds_barrier();
+    const uint32_t E = sh_rstart[64];
+    Vec<VEC> acc, row;
+    vec_zero(acc);
+    vec_zero(row);
+    if (SCATTER && ev) row.load(c.in + int64_t(ix) * dim + e);
+#pragma unroll 1
+    for (uint32_t qb = uint32_t(grp) * WIN; qb < E; qb += NG * WIN) {
+      uint32_t p = 0;
+      if (j < WIN && qb + j < E) {
+        const uint32_t q = qb + j;
+        uint32_t lo = 0, hi = 63;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi + 1) >> 1;
+          if (sh_rstart[mid] <= q) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t val = sh_rval[lo];
+        const uint32_t i = q - sh_rstart[lo];
+        const uint32_t b = b0 + lo;
+        p = b * kRdBlock + ((run_cnt(val) == 1) ? run_first(val)
+                                                 : uint32_t(d.seg[b * kRdBlock + run_off(val) + i]));
+      }
+      if (SCATTER) {
+#pragma unroll
+        for (int t = 0; t < WIN; ++t) {
+          const uint32_t pt = __shfl(p, gbase + t);
+          if (qb + t < E && ev) row.store(c.out + int64_t(pt) * dim + e);
+        }
+      } else {
+        Vec<VEC> v[WIN];
+#pragma unroll
+        for (int t = 0; t < WIN; ++t) vec_zero(v[t]);
+#pragma unroll
+        for (int t = 0; t < WIN; ++t) {
+          const uint32_t pt = __shfl(p, gbase + t);
+          if (qb + t < E && ev) v[t].load(c.in + int64_t(pt) * dim + e);
+        }
+#pragma unroll
+        for (int t = 0; t < WIN; ++t)
+          if (qb + t < E && ev) vec_add(acc, v[t]);
+      }
+    }
+    if (!SCATTER) {
+#pragma unroll
+      for (int cc = 0; cc < VEC; ++cc) sh_sum[grp][j * VEC + cc] = acc.v[cc];
+      lds_barrier();
+      Vec<VEC> tot;
+      vec_zero(tot);
+      if (threadIdx.x < 64) {
+#pragma unroll 1
+        for (int g2 = 0; g2 < NG; ++g2) {
+#pragma unroll
+          for (int cc = 0; cc < VEC; ++cc) tot.v[cc] = tot.v[cc] + sh_sum[g2][j * VEC + cc];
+        }
+      }
+      bool fin = nitems == 1;
+      if (nitems > 1) {
+        if (threadIdx.x < G && ev) store_wt<VEC>(c.part + int64_t(w) * dim + e, tot);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (threadIdx.x == 0) {
+          const uint32_t last = (atomicAdd(&c.arrive[hd.u], 1u) == nitems - 1) ? 1u : 0u;
+          if (last) c.arrive[hd.u] = 0;
+          sh_last = last;
+        }
+        lds_barrier();
+        if (sh_last) {
+          fin = true;
+          const uint32_t w0 = w - kk;
+          const uint32_t per = (nitems + NG - 1) / NG;
+          const uint32_t k0 = min(nitems, uint32_t(grp) * per), k1 = min(nitems, k0 + per);
+          Vec<VEC> sacc;
+          vec_zero(sacc);
+#pragma unroll 1
+          for (uint32_t q = k0; q < k1; q += 8) {
+            Vec<VEC> r[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) vec_zero(r[t]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+              if (q + t < k1 && ev) load_agent<VEC>(c.part + int64_t(w0 + q + t) * dim + e, r[t]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+              if (q + t < k1 && ev) vec_add(sacc, r[t]);
+          }
+          lds_barrier();
+#pragma unroll
+          for (int cc = 0; cc < VEC; ++cc) sh_sum[grp][j * VEC + cc] = sacc.v[cc];
+          lds_barrier();
+          vec_zero(tot);
+          if (threadIdx.x < 64) {
+            for (int g2 = 0; g2 < NG && uint32_t(g2) * per < nitems; ++g2) {
+#pragma unroll
+              for (int cc = 0; cc < VEC; ++cc) tot.v[cc] = tot.v[cc] + sh_sum[g2][j * VEC + cc];
+            }
+          }
+        }
+      }
+      if (fin && threadIdx.x < G && ev) tot.store(c.out + int64_t(ix) * dim + e);
+    }
+    lds_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shard packing of the unique ids of a batch: FusedReorderByIndices' shard-major layout
+// (RT/ops/fused_reorder_by_indices.cc:75-123; shard = floormod(id, N), NT/distributed_ps.py:289)
+// for one table, on ids that are already unique.  Two launches:
+//   rd_shard_count   counts[s] = number of ids of shard s (LDS histogram, one global add per
+//                    workgroup and shard)
+//   rd_shard_place   send_pos[u] = position of unique index u in the shard-major buffer,
+//                    send_ids[send_pos[u]] = id.  The order inside a shard is arrival order:
+//                    every consumer goes through send_pos, nothing depends on it.
+// n comes from device memory (the build role's unique count).
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxShards = 64;
+
+__device__ __forceinline__ uint32_t shard_of_id(int64_t id, uint32_t nshards) {
+  const int64_t m = id % int64_t(nshards);
+  return uint32_t(m < 0 ? m + int64_t(nshards) : m);
+}
+
+__global__ __launch_bounds__(1024) void rd_shard_count_kernel(const int64_t* __restrict__ ids,
+                                                              const uint32_t* __restrict__ n_dev,
+                                                              int64_t n_max, uint32_t nshards,
+                                                              uint32_t* __restrict__ counts) {
+  __shared__ uint32_t h[kMaxShards];
+  if (threadIdx.x < kMaxShards) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t n = min(n_max, int64_t(*n_dev));
+  const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u < n) atomicAdd(&h[shard_of_id(ids[u], nshards)], 1u);
+  __syncthreads();
+  if (threadIdx.x < nshards && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(1024) void rd_shard_place_kernel(const int64_t* __restrict__ ids,
+                                                              const uint32_t* __restrict__ n_dev,
+                                                              int64_t n_max, uint32_t nshards,
+                                                              const uint32_t* __restrict__ counts,
+                                                              uint32_t* __restrict__ cursor,
+                                                              int64_t* __restrict__ send_ids,
+                                                              uint32_t* __restrict__ send_pos) {
+  __shared__ uint32_t h[kMaxShards], base[kMaxShards], off[kMaxShards];
+  if (threadIdx.x < kMaxShards) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t n = min(n_max, int64_t(*n_dev));
+  const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  uint32_t sh = 0, rank = 0;
+  int64_t id = 0;
+  if (u < n) {
+    id = ids[u];
+    sh = shard_of_id(id, nshards);
+    rank = atomicAdd(&h[sh], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < nshards) {
+    uint32_t o = 0;
+    for (uint32_t s2 = 0; s2 < threadIdx.x; ++s2) o += counts[s2];
+    off[threadIdx.x] = o;
+    base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]) : 0u;
+  }
+  __syncthreads();
+  if (u < n) {
+    const uint32_t q = off[sh] + base[sh] + rank;
+    send_pos[u] = q;
+    send_ids[q] = id;
+  }
+}
+
 }  // namespace mhte
 #endif  // MHTE_STEP_KERNELS_H_

@@ -711,6 +711,50 @@ def test_pipelined_step_slow_path_at_high_load():
                                 ot.lookup(allids)[0])
 
 
+@pytest.mark.parametrize("n,dim,shards,dist", [(30000, 16, 8, "zipf"), (65536, 64, 2, "zipf"),
+                                               (5000, 8, 64, "uniform"), (1, 4, 3, "uniform")])
+def test_sender_side_partition_scatter_sum(n, dim, shards, dist):
+  """mhte_shard_partition / mhte_step_scatter / mhte_step_sum (the sharded step's sender side):
+  shard-major packing by floormod(id, N) (fused_reorder_by_indices.cc:75-123), rows of the unique
+  ids scattered to every occurrence (FillWithOffsetMap) and per-id gradient sums in send order
+  (FillWithOffsetMapGradient) — against numpy."""
+  from monolith_amd.distributed_ps_sync import HipBackend
+  mt = make({"emb": adagrad_cfg(dim)})
+  be = HipBackend(mt, "emb")
+  ids = S.id_batch(77, n, 10**5 if dist == "zipf" else 10**9, dist)
+  if n > 10:
+    ids[3] = -5                       # floormod of a negative id
+  g = S.grad_batch(77, n, dim)
+  uids_t, nu_t = be.dedup(ids_t(ids))
+  send_ids_t, send_pos_t, counts_t = be.partition(uids_t, nu_t, shards)
+  U = int(nu_t.item())
+  uids = uids_t.cpu().numpy()[:U]
+  assert sorted(uids.tolist()) == sorted(np.unique(ids).tolist())
+  send_ids = send_ids_t.cpu().numpy()[:U]
+  send_pos = send_pos_t.cpu().numpy()[:U].astype(np.int64)
+  counts = counts_t.cpu().numpy().astype(np.int64)
+  np.testing.assert_array_equal(counts, np.bincount(np.mod(uids, shards), minlength=shards))
+  assert sorted(send_pos.tolist()) == list(range(U))                 # a permutation
+  np.testing.assert_array_equal(send_ids[send_pos], uids)
+  np.testing.assert_array_equal(np.mod(send_ids, shards), np.repeat(np.arange(shards), counts))
+  # scatter
+  index = {int(k): i for i, k in enumerate(uids)}
+  inv = np.array([index[int(x)] for x in ids], dtype=np.int64)
+  rows = np.random.default_rng(5).standard_normal((U, dim)).astype(np.float32)
+  out = be.scatter(val_t(rows), send_pos_t, n).cpu().numpy()
+  np.testing.assert_array_equal(out, rows[send_pos[inv]])
+  # sum: sequential in occurrence order for lists of <= 32, 1e-5 otherwise
+  gs = be.sum(val_t(g), send_pos_t).cpu().numpy()[:U]
+  exp = np.zeros((U, dim), np.float32)
+  for p in range(n):
+    exp[send_pos[inv[p]]] += g[p]
+  cnt = np.bincount(inv, minlength=U)
+  light = np.zeros(U, bool)
+  light[send_pos] = cnt <= 32
+  np.testing.assert_array_equal(gs[light], exp[light])
+  np.testing.assert_allclose(gs, exp, rtol=0, atol=TOL)
+
+
 # =============================================================================== full-size properties
 def test_full_batch_zipf_step_properties_d64_adagrad():
   """BASELINE.json configs[2] shape: dim 64, Adagrad, Zipf(1.2) over 1e9 ids, batch 65536."""
