@@ -43,6 +43,9 @@ def parse():
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--cpu-steps", type=int, default=150)
   p.add_argument("--exact-order", action="store_true")
+  p.add_argument("--dist-backend", default="nccl",
+                 help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo stages through "
+                      "host memory and lets several ranks share one GPU: a functional check only)")
   p.add_argument("--trace-out", default="",
                  help="write a per-wavefront timeline (.npz) of three pipelined steps")
   p.add_argument("--no-stage-timing", action="store_true",
@@ -92,11 +95,12 @@ def main():
       raise SystemExit("--gpus %d needs: python -m torch.distributed.run --nproc-per-node %d "
                        "bench.py --gpus %d" % (args.gpus, args.gpus, args.gpus))
   assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+  local_rank %= torch.cuda.device_count()
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
   if world > 1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", rank=rank, world_size=world)
+    dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
   from monolith_amd import _lib, entry, synthetic as S
   from monolith_amd.fused_step import SparseStep
@@ -248,7 +252,7 @@ def main():
     def run_sharded(lo, hi):
       for s in range(lo, hi):
         se.lookup(ids_all[s])
-        se.apply_gradients(grad_pool[s % 8], S.update_time(s))
+        se.apply_gradients(grad_pool[s % 8], S.update_time(s), next_ids=ids_all[s + 1])
 
     run_sharded(0, W)
     barrier()
@@ -262,7 +266,8 @@ def main():
       args.launch if args.launch in full else "eager")
   elapsed = results[launch]
   if world > 1:
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tt = torch.tensor([elapsed], dtype=torch.float64,
+                      device=dev if args.dist_backend == "nccl" else "cpu")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
 
@@ -389,15 +394,19 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "configs[2]: 1 MI355X, 1B-id universe (per GPU), dim=%d, Zipf(1.2), "
-                        "batch=%d/GPU, %s; grow-on-demand table" % (D, B, "fused Adagrad" if
-                                                                    args.opt == "adagrad" else "SGD"),
+            "workload": ("configs[2]: 1 MI355X, 1B-id universe (per GPU), dim=%d, Zipf(1.2), "
+                         "batch=%d/GPU, %s; grow-on-demand table" if world == 1 else
+                         "configs[3] shape: %d MI355X, %dB ids sharded by fid mod N (1B-id universe "
+                         "per GPU), dim=%%d, Zipf(1.2), batch=%%d/GPU, %%s; all-to-all id dispatch + "
+                         "row / gradient return" % (world, world)) %
+                        (D, B, "fused Adagrad" if args.opt == "adagrad" else "SGD"),
             "batch_per_gpu": B, "dim": D, "universe_ids": V, "optimizer": args.opt,
             "resident_rows_per_gpu_start": int(st0.size), "resident_rows_per_gpu_end": int(st1.size),
             "row_bytes": 4 * (D + S_state), "hashpower": int(st1.hashpower),
             "table_bytes_per_gpu": int(st1.bytes_buckets + st1.bytes_rows),
             "unique_ids_per_batch": uniq_avg, "launch": launch,
-            "parallelism": "1 GPU" if world == 1 else "fid mod %d sharding, 4 all-to-all/step (RCCL)" % world,
+            "parallelism": "1 GPU" if world == 1 else
+                           "fid mod %d sharding, 4 all-to-all/step (%s)" % (world, args.dist_backend),
             "prefill_s": round(prefill_s, 2),
         },
         "timing_ms_per_step": {k: round(v / steps_of[k] * 1e3, 5) for k, v in results.items()},

@@ -75,13 +75,24 @@ class LocalBackend:
 
 class HipBackend(LocalBackend):
   """Local shard on this process's MI355X (libmhte.so): run dedup + shard packing + scatter / sum
-  on the sender side, MultiHashTable lookup and the fused sum + apply on the owner side."""
+  on the sender side, MultiHashTable lookup and the fused sum + apply on the owner side.  Two
+  slots of sender / owner state alternate (``use_slot``), so that the id dispatch of the next batch
+  can be prepared while the current one is still being trained."""
 
   MAX_STEP_BATCH = 65536
 
+  class _Slot:
+    def __init__(self, device):
+      from monolith_amd.distribution_ops import DedupWorkspace
+      self.ws_s = DedupWorkspace(device)  # sender side
+      self.ws_o = DedupWorkspace(device)  # owner side
+      self.cap = 0
+      self.ocap = 0
+      self.n = 0
+      self.owner_n = -1   # number of received ids whose run dedup ws_o holds (-1: none)
+
   def __init__(self, table, table_name: str):
     from monolith_amd import _lib
-    from monolith_amd.distribution_ops import DedupWorkspace
     from monolith_amd.multi_hash_table_ops import _stream
     self._lib = _lib
     self._L = _lib.lib()
@@ -91,31 +102,35 @@ class HipBackend(LocalBackend):
     self.idx = table._index(table_name)  # pylint: disable=protected-access
     self.dim = table.get_table_dim_sizes()[self.idx]
     self.dev = torch.device("cuda:%d" % table._device)  # pylint: disable=protected-access
-    self.ws_s = DedupWorkspace(table._device)  # sender side  # pylint: disable=protected-access
-    self.ws_o = DedupWorkspace(table._device)  # owner side  # pylint: disable=protected-access
+    self._slots = [HipBackend._Slot(table._device), HipBackend._Slot(table._device)]  # pylint: disable=protected-access
+    self._s = self._slots[0]
+    self._fused_ok = bool(table._lib.mhte_table_fused_backward_ok(table.handle, self.idx))  # pylint: disable=protected-access
     lr0 = sum(table._slice_sizes[:self.idx])  # pylint: disable=protected-access
     self.lrs = np.ascontiguousarray(
         table.learning_rate[lr0:lr0 + table._slice_sizes[self.idx]])  # pylint: disable=protected-access
-    self._cap = 0
-    self._ocap = 0
+
+  def use_slot(self, i: int):
+    self._s = self._slots[i & 1]
 
   def _sender_buffers(self, n):
-    if n > self._cap:
+    sl = self._s
+    if n > sl.cap:
       d = self.dev
-      self.uids = torch.empty(n, dtype=torch.int64, device=d)
-      self.nu = torch.zeros(1, dtype=torch.int32, device=d)
-      self.send_ids = torch.empty(n, dtype=torch.int64, device=d)
-      self.send_pos = torch.empty(n, dtype=torch.int32, device=d)
-      self.gsum = torch.empty((n, self.dim), dtype=torch.float32, device=d)
-      self._cap = n
+      sl.uids = torch.empty(n, dtype=torch.int64, device=d)
+      sl.nu = torch.zeros(1, dtype=torch.int32, device=d)
+      sl.send_ids = torch.empty(n, dtype=torch.int64, device=d)
+      sl.send_pos = torch.empty(n, dtype=torch.int32, device=d)
+      sl.gsum = torch.empty((n, self.dim), dtype=torch.float32, device=d)
+      sl.cap = n
 
   def _owner_buffers(self, m):
-    if m > self._ocap:
+    sl = self._s
+    if m > sl.ocap:
       d = self.dev
-      self.o_uids = torch.empty(m, dtype=torch.int64, device=d)
-      self.o_nu = torch.zeros(1, dtype=torch.int32, device=d)
-      self.o_grad_u = torch.empty((m, self.dim), dtype=torch.float32, device=d)
-      self._ocap = m
+      sl.o_uids = torch.empty(m, dtype=torch.int64, device=d)
+      sl.o_nu = torch.zeros(1, dtype=torch.int32, device=d)
+      sl.o_grad_u = torch.empty((m, self.dim), dtype=torch.float32, device=d)
+      sl.ocap = m
 
   def dedup(self, ids):
     n = ids.numel()
@@ -124,32 +139,36 @@ class HipBackend(LocalBackend):
                                            "sharded step: at most %d ids per rank and step" %
                                            self.MAX_STEP_BATCH)
     self._sender_buffers(n)
-    self._n = n
-    self.ws_s.step_dedup(ids, self.uids, self.nu)
-    return self.uids, self.nu
+    sl = self._s
+    sl.n = n
+    sl.owner_n = -1
+    sl.ws_s.step_dedup(ids, sl.uids, sl.nu)
+    return sl.uids, sl.nu
 
   def partition(self, unique_ids, n_unique, num_shards):
+    sl = self._s
     counts = torch.empty(num_shards, dtype=torch.int32, device=self.dev)
     vp, check = self._lib.vp, self._lib.check
-    check(self._L.mhte_shard_partition(self.ws_s._h, vp(unique_ids), C.c_int64(self._n),  # pylint: disable=protected-access
-                                       vp(n_unique), C.c_int32(num_shards), vp(self.send_ids),
-                                       vp(self.send_pos), vp(counts), self._stream()))
-    return self.send_ids, self.send_pos, counts
+    check(self._L.mhte_shard_partition(sl.ws_s._h, vp(unique_ids), C.c_int64(sl.n),  # pylint: disable=protected-access
+                                       vp(n_unique), C.c_int32(num_shards), vp(sl.send_ids),
+                                       vp(sl.send_pos), vp(counts), self._stream()))
+    return sl.send_ids, sl.send_pos, counts
 
   def scatter(self, rows, send_pos, n_out):
     out = torch.empty((n_out, self.dim), dtype=torch.float32, device=self.dev)
     if rows.numel() == 0:  # nothing came back: every occurrence misses
       return out.zero_()
     vp, check = self._lib.vp, self._lib.check
-    check(self._L.mhte_step_scatter(self.ws_s._h, vp(rows), vp(send_pos), C.c_int32(self.dim),  # pylint: disable=protected-access
+    check(self._L.mhte_step_scatter(self._s.ws_s._h, vp(rows), vp(send_pos), C.c_int32(self.dim),  # pylint: disable=protected-access
                                     vp(out), self._stream()))
     return out
 
   def sum(self, grads, send_pos):
+    sl = self._s
     vp, check = self._lib.vp, self._lib.check
-    check(self._L.mhte_step_sum(self.ws_s._h, vp(grads), vp(send_pos), C.c_int32(self.dim),  # pylint: disable=protected-access
-                                vp(self.gsum), self._stream()))
-    return self.gsum
+    check(self._L.mhte_step_sum(sl.ws_s._h, vp(grads), vp(send_pos), C.c_int32(self.dim),  # pylint: disable=protected-access
+                                vp(sl.gsum), self._stream()))
+    return sl.gsum
 
   def owner_lookup(self, ids):
     out = torch.empty((ids.numel(), self.dim), dtype=torch.float32, device=self.dev)
@@ -157,18 +176,31 @@ class HipBackend(LocalBackend):
       self.table.table_lookup_n(self.idx, ids, None, out)
     return out
 
+  def _owner_fast(self, m):
+    return 0 < m <= self.MAX_STEP_BATCH and self._fused_ok
+
+  def owner_prepare(self, ids):
+    """Run dedup of the received ids ahead of their gradients (it depends on the ids only)."""
+    m = ids.numel()
+    if self._owner_fast(m):
+      self._owner_buffers(m)
+      sl = self._s
+      sl.ws_o.step_dedup(ids, sl.o_uids[:m], sl.o_nu)
+      sl.owner_n = m
+
   def owner_apply(self, ids, grads, update_time, global_step):
     m = ids.numel()
     if m == 0:
       return
-    if m <= self.MAX_STEP_BATCH and self.table._lib.mhte_table_fused_backward_ok(  # pylint: disable=protected-access
-        self.table.handle, self.idx):
+    sl = self._s
+    if self._owner_fast(m):
       # the received ids are a batch with duplicates (one occurrence per sender): run dedup + the
       # fused sum / upsert / optimizer launch of the single-GPU step
-      self._owner_buffers(m)
-      self.ws_o.step_dedup(ids, self.o_uids[:m], self.o_nu)
-      self.table.table_step_backward(self.idx, self.ws_o, None, self.o_uids[:m], self.o_nu, grads,
-                                     self.o_grad_u, self.lrs, update_time, global_step)
+      if sl.owner_n != m:
+        self.owner_prepare(ids)
+      self.table.table_step_backward(self.idx, sl.ws_o, None, sl.o_uids[:m], sl.o_nu, grads,
+                                     sl.o_grad_u, self.lrs, update_time, global_step)
+      sl.owner_n = -1
     else:
       self.table.table_optimize_n(self.idx, ids, None, grads, self.lrs, update_time, global_step,
                                   flags=self._lib.MHTE_SUM_DUPLICATES)
@@ -180,7 +212,13 @@ def shard_of(ids: torch.Tensor, num_shards: int) -> torch.Tensor:
 
 
 class ShardedEmbedding:
-  """All-to-all sharded lookup / apply_gradients for one table."""
+  """All-to-all sharded lookup / apply_gradients for one table.
+
+  ``apply_gradients(..., next_ids=...)`` starts the id dispatch of the following batch (dedup,
+  shard packing, size + id exchanges, owner-side dedup — everything that depends on ids only) on a
+  side stream, as the reference's prefetch queue does (distributed_ps_sync.py:199-203); the next
+  ``lookup`` (which must receive that same tensor) then only has the owner lookup, the row
+  exchange and the scatter on its critical path."""
 
   def __init__(self, backend: LocalBackend, group: Optional[dist.ProcessGroup] = None):
     self.backend = backend
@@ -192,6 +230,9 @@ class ShardedEmbedding:
     # several ranks sharing one GPU)
     self._gloo = dist.get_backend(group) == "gloo"
     self._ctx = None
+    self._pre = None      # dispatch prepared ahead: (key, dispatch tuple, event)
+    self._slot = 0
+    self._side = None
 
   def _a2a(self, out, inp, out_splits=None, in_splits=None):
     if self._gloo and inp.is_cuda:
@@ -203,9 +244,11 @@ class ShardedEmbedding:
     dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits,
                            group=self.group)
 
-  def lookup(self, ids: torch.Tensor) -> torch.Tensor:
-    """ids int64 [B] on this rank -> rows fp32 [B, D]."""
-    N, D, be = self.world, self.dim, self.backend
+  def _dispatch(self, ids: torch.Tensor, slot: int):
+    """Everything of a step that depends on the ids only."""
+    N, be = self.world, self.backend
+    if hasattr(be, "use_slot"):
+      be.use_slot(slot)
     dev = ids.device
     uids, nu = be.dedup(ids)
     send_ids, send_pos, counts = be.partition(uids, nu, N)
@@ -217,19 +260,64 @@ class ShardedEmbedding:
     U, M = int(sum(sc)), int(sum(rc))
     recv_ids = torch.empty(M, dtype=torch.int64, device=dev)
     self._a2a(recv_ids, send_ids[:U], rc, sc)                           # exchange #2: ids
+    if hasattr(be, "owner_prepare"):
+      be.owner_prepare(recv_ids)
+    return (slot, send_pos, sc, rc, recv_ids, U, M)
+
+  def lookup(self, ids: torch.Tensor) -> torch.Tensor:
+    """ids int64 [B] on this rank -> rows fp32 [B, D]."""
+    D, be = self.dim, self.backend
+    dev = ids.device
+    key = (ids.data_ptr(), ids.numel())
+    if self._pre is not None and self._pre[0] == key:
+      _, disp, ev = self._pre
+      if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+    else:
+      disp = self._dispatch(ids, self._slot)
+    self._pre = None
+    slot, send_pos, sc, rc, recv_ids, U, M = disp
+    if hasattr(be, "use_slot"):
+      be.use_slot(slot)
     rows = be.owner_lookup(recv_ids)                                    # owner-side lookup
     back = torch.empty((U, D), dtype=torch.float32, device=dev)
     self._a2a(back, rows, sc, rc)                                       # exchange #3: rows
     out = be.scatter(back, send_pos, ids.numel())                       # rows -> occurrences
-    self._ctx = (send_pos, sc, rc, recv_ids, U, M)
+    self._ctx = disp
     return out
 
-  def apply_gradients(self, grads: torch.Tensor, update_time: int, global_step: int = 0):
+  def apply_gradients(self, grads: torch.Tensor, update_time: int, global_step: int = 0,
+                      next_ids: Optional[torch.Tensor] = None):
     """grads fp32 [B, D] for the ids of the preceding lookup()."""
-    send_pos, sc, rc, recv_ids, U, M = self._ctx
+    slot, send_pos, sc, rc, recv_ids, U, M = self._ctx
     D, be = self.dim, self.backend
+    if hasattr(be, "use_slot"):
+      be.use_slot(slot)
     gsum = be.sum(grads, send_pos)                                      # [*, D], send order
     recv = torch.empty((M, D), dtype=torch.float32, device=grads.device)
     self._a2a(recv, gsum[:U], rc, sc)                                   # exchange #4: gradients
     be.owner_apply(recv_ids, recv, update_time, global_step)
     self._ctx = None
+    self._slot = 1 - slot
+    if next_ids is not None:
+      self._prefetch(next_ids)
+
+  def _prefetch(self, ids: torch.Tensor):
+    key = (ids.data_ptr(), ids.numel())
+    if not ids.is_cuda:
+      self._pre = (key, self._dispatch(ids, self._slot), None)
+      return
+    if self._side is None:
+      self._side = torch.cuda.Stream(device=ids.device)
+    main = torch.cuda.current_stream()
+    start = torch.cuda.Event()
+    start.record(main)               # (the ids may have been produced on the main stream)
+    self._side.wait_event(start)
+    with torch.cuda.stream(self._side):
+      disp = self._dispatch(ids, self._slot)
+      ev = torch.cuda.Event()
+      ev.record(self._side)
+    for t in (disp[1], disp[4]):     # consumed on the main stream later
+      if isinstance(t, torch.Tensor) and t.is_cuda:
+        t.record_stream(main)
+    self._pre = (key, disp, ev)
