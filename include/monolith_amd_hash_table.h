@@ -186,6 +186,22 @@ mhte_status mhte_table_dump(mhte_multi_table* t, int32_t table, int64_t cap, int
                             void* stream);
 int32_t mhte_table_row_floats(const mhte_multi_table* t, int32_t i);
 
+/* MonolithMultiHashTableSave / Restore (RT/ops/multi_hash_table_save_restore_ops.cc:115-263,
+ * 266-420) in the reference's on-disk format, so checkpoints are interchangeable:
+ *   <basename>-%05d-of-%05d       TFRecord + SNAPPY stream of EntryDump (embedding_hash_table.proto
+ *                                 :45-50: id, num, opt {one SingleOptimizerDump per segment},
+ *                                 last_update_ts_sec), tables in sorted-name order, each shard a
+ *                                 contiguous bucket range (cuckoohash_map.hpp:740-773)
+ *   <basename>.meta-%05d-of-%05d  TFRecord stream of MultiHashTableMetadata {table_name, num_entries}
+ * Save drops rows expired relative to the table's max_update_ts (:203-211; per-slot TTLs of the
+ * table config).  nshards < 0: min(4, max(1, total_size / 1e6)) (:240-248).
+ * Restore upserts every entry of every table it knows (whole row + the entry's own timestamp),
+ * skips tables it does not know, reports a short or corrupted shard as an error.  Both synchronise
+ * the stream; host-side work is proportional to the table. */
+mhte_status mhte_multi_table_save(mhte_multi_table* t, const char* basename, int32_t nshards,
+                                  void* stream);
+mhte_status mhte_multi_table_restore(mhte_multi_table* t, const char* basename, void* stream);
+
 /* ---- caller-side dedup / packing ops on the device ------------------------------------------ */
 typedef struct mhte_dedup_ws mhte_dedup_ws;
 mhte_status mhte_dedup_ws_create(int32_t device, mhte_dedup_ws** out);

@@ -22,6 +22,9 @@
 #include <vector>
 
 #include "../../include/monolith_amd_hash_table.h"
+#include <unistd.h>
+
+#include "mhte_ckpt.h"
 #include "mhte_step_kernels.h"
 
 namespace mhte {
@@ -1301,7 +1304,7 @@ mhte_status mhte_table_dump(mhte_multi_table* t, int32_t table, int64_t cap, int
     DevBuf<uint64_t> bo;
     bc.reserve(nblocks);
     bo.reserve(nblocks);
-    dump_count_kernel<<<nblocks, 256, 0, st>>>(tb.view, bc.p);
+    dump_count_kernel<<<nblocks, 256, 0, st>>>(tb.view, uint64_t(0), nslots, bc.p);
     HIP_OK(hipGetLastError());
     std::vector<uint32_t> hc(nblocks);
     HIP_OK(hipMemcpyAsync(hc.data(), bc.p, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToHost, st));
@@ -1317,9 +1320,286 @@ mhte_status mhte_table_dump(mhte_multi_table* t, int32_t table, int64_t cap, int
       throw Error(MHTE_INVALID_ARGUMENT, "dump buffers too small: need " + std::to_string(acc));
     if (acc == 0) return;
     HIP_OK(hipMemcpyAsync(bo.p, ho.data(), sizeof(uint64_t) * nblocks, hipMemcpyHostToDevice, st));
-    dump_emit_kernel<<<nblocks, 256, 0, st>>>(tb.view, bo.p, ids, positions, ts, rows);
+    dump_emit_kernel<<<nblocks, 256, 0, st>>>(tb.view, uint64_t(0), nslots, bo.p, ids, positions, ts, rows);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(st));
+  });
+}
+
+// ---- checkpoints in the reference's on-disk format --------------------------------------------
+extern "C++" {
+namespace mhte {
+
+static std::vector<ckpt::SegLayout> seg_layout(const Table& tb) {
+  std::vector<ckpt::SegLayout> v;
+  for (uint32_t i = 0; i < tb.nseg; ++i) {
+    const SegDesc& d = tb.view.seg[i];
+    ckpt::SegLayout s;
+    s.dim = d.dim;
+    s.kind = d.opt == kOptSgd ? ckpt::kSegSgd : (d.opt == kOptAdagrad ? ckpt::kSegAdagrad : ckpt::kSegFtrl);
+    s.w_off = d.w_off;
+    s.st_off = d.st_off;
+    v.push_back(s);
+  }
+  return v;
+}
+
+static int64_t ttl_days_of(const Table& tb, int64_t id) {
+  const int64_t slot = (id >> 48) & 0x7fff;  // slot_id_v2, reader_util.h:36-38
+  int64_t days = tb.default_expire_days;
+  for (size_t i = 0; i < tb.expire_slots.size(); ++i)
+    if (tb.expire_slots[i] == slot) days = tb.expire_days[i];
+  return days;
+}
+
+// One shard of one table: buckets [begin, end) of partial_dump (cuckoohash_map.hpp:740-773), in
+// chunks; rows expired relative to the table's max_update_ts are dropped
+// (multi_hash_table_save_restore_ops.cc:203-211).  Returns the number of entries written.
+static uint64_t save_table_shard(Table& tb, int shard, int total, ckpt::RecordWriter& w,
+                                 hipStream_t st) {
+  const uint64_t nb = uint64_t(1) << tb.hp;
+  const uint64_t Q = nb / uint64_t(total), R = nb % uint64_t(total);
+  const uint64_t begin = uint64_t(shard) * Q + std::min<uint64_t>(shard, R);
+  const uint64_t end = begin + Q + (uint64_t(shard) < R ? 1 : 0);
+  const std::vector<ckpt::SegLayout> segs = seg_layout(tb);
+  const uint32_t rf = tb.row_floats;
+  const uint64_t kChunkSlots = uint64_t(1) << 22;
+  DevBuf<uint32_t> bc;
+  DevBuf<uint64_t> bo;
+  DevBuf<int64_t> d_ids, d_pos;
+  DevBuf<uint32_t> d_ts;
+  DevBuf<float> d_rows;
+  std::vector<int64_t> h_ids;
+  std::vector<uint32_t> h_ts;
+  std::vector<float> h_rows;
+  std::string rec;
+  uint64_t written = 0;
+  auto emit = [&](int64_t id, const float* row, uint32_t ts) {
+    if (tb.max_update_ts - int64_t(ts) >= ttl_days_of(tb, id) * int64_t(86400)) return;
+    ckpt::encode_entry(rec, id, row, segs, int(tb.dim), ts);
+    w.write(rec);
+    ++written;
+  };
+  for (uint64_t s0 = begin * kSlots; s0 < end * kSlots; s0 += kChunkSlots) {
+    const uint64_t s1 = std::min(end * kSlots, s0 + kChunkSlots);
+    const uint32_t nblocks = uint32_t((s1 - s0 + 1023) / 1024);
+    bc.reserve(nblocks);
+    bo.reserve(nblocks);
+    dump_count_kernel<<<nblocks, 256, 0, st>>>(tb.view, s0, s1, bc.p);
+    HIP_OK(hipGetLastError());
+    std::vector<uint32_t> hc(nblocks);
+    HIP_OK(hipMemcpyAsync(hc.data(), bc.p, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    std::vector<uint64_t> ho(nblocks);
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < nblocks; ++i) {
+      ho[i] = acc;
+      acc += hc[i];
+    }
+    if (acc == 0) continue;
+    d_ids.reserve(acc);
+    d_pos.reserve(acc);
+    d_ts.reserve(acc);
+    d_rows.reserve(acc * rf);
+    HIP_OK(hipMemcpyAsync(bo.p, ho.data(), sizeof(uint64_t) * nblocks, hipMemcpyHostToDevice, st));
+    dump_emit_kernel<<<nblocks, 256, 0, st>>>(tb.view, s0, s1, bo.p, d_ids.p, d_pos.p, d_ts.p, d_rows.p);
+    HIP_OK(hipGetLastError());
+    h_ids.resize(acc);
+    h_ts.resize(acc);
+    h_rows.resize(acc * rf);
+    HIP_OK(hipMemcpyAsync(h_ids.data(), d_ids.p, acc * 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(h_ts.data(), d_ts.p, acc * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(h_rows.data(), d_rows.p, acc * rf * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    for (uint64_t i = 0; i < acc; ++i) emit(h_ids[i], h_rows.data() + i * rf, h_ts[i]);
+  }
+  if (shard == 0 && tb.h_ctr->special_state == 1) {
+    // the one key that lives in the side slot (kEmptyKey itself): last entry of shard 0
+    std::vector<float> row(rf);
+    Counters c;
+    HIP_OK(hipMemcpy(&c, tb.ctr, sizeof(Counters), hipMemcpyDeviceToHost));
+    const uint32_t r = c.special_row;
+    const uint32_t ch = r >> tb.chunk_shift;
+    const float* src = tb.chunks[ch] + size_t(r & ((1u << tb.chunk_shift) - 1u)) * rf;
+    HIP_OK(hipMemcpy(row.data(), src, rf * 4, hipMemcpyDeviceToHost));
+    emit(kEmptyKey, row.data(), c.special_ts);
+  }
+  return written;
+}
+
+static void save_multi_table(mhte_multi_table* t, const std::string& basename, int nshards,
+                             hipStream_t st) {
+  int64_t total = 0;
+  for (auto& tb : t->tables) {
+    std::lock_guard<std::mutex> g(tb->mu);
+    tb->sync_counters(st);
+    total += int64_t(tb->h_ctr->alloc >> 32) + (tb->h_ctr->special_state == 1 ? 1 : 0);
+  }
+  // PickNshards, multi_hash_table_save_restore_ops.cc:240-248
+  if (nshards < 0) nshards = int(std::min<int64_t>(4, std::max<int64_t>(1, total / 1000000)));
+  if (nshards < 1) nshards = 1;
+  for (int sh = 0; sh < nshards; ++sh) {
+    const std::string fn = ckpt::shard_name(basename, "", sh, nshards);
+    const std::string mfn = ckpt::shard_name(basename, ".meta", sh, nshards);
+    const std::string tmp = fn + "-tmp-" + std::to_string(uint64_t(getpid())) + "-" + std::to_string(sh);
+    const std::string mtmp = mfn + "-tmp-" + std::to_string(uint64_t(getpid())) + "-" + std::to_string(sh);
+    {
+      ckpt::RecordWriter w(tmp, true), mw(mtmp, false);
+      std::string meta;
+      for (auto& tb : t->tables) {
+        std::lock_guard<std::mutex> g(tb->mu);
+        const uint64_t n = save_table_shard(*tb, sh, nshards, w, st);
+        ckpt::encode_meta(meta, tb->name, n);
+        mw.write(meta);
+      }
+      w.close();
+      mw.close();
+    }
+    if (rename(tmp.c_str(), fn.c_str()) != 0 || rename(mtmp.c_str(), mfn.c_str()) != 0)
+      throw Error(MHTE_INTERNAL, "checkpoint: cannot rename into " + fn);
+  }
+}
+
+// rows of one restore batch -> table (upsert of whole rows with their own timestamps)
+static void restore_batch(Table& tb, const std::vector<int64_t>& ids, const std::vector<float>& rows,
+                          const std::vector<uint32_t>& ts, hipStream_t st) {
+  const int64_t n = int64_t(ids.size());
+  if (n == 0) return;
+  tb.finish_pending(st);
+  tb.ensure_capacity(uint64_t(n), st);
+  DevBuf<int64_t> d_ids;
+  DevBuf<uint32_t> d_ts;
+  DevBuf<float> d_rows;
+  d_ids.reserve(n);
+  d_ts.reserve(n);
+  d_rows.reserve(size_t(n) * tb.row_floats);
+  HIP_OK(hipMemcpyAsync(d_ids.p, ids.data(), n * 8, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(d_ts.p, ts.data(), n * 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(d_rows.p, rows.data(), size_t(n) * tb.row_floats * 4, hipMemcpyHostToDevice, st));
+  tb.pending.reserve(size_t(n) + 1);
+  const dim3 grid(uint32_t((n * 16 + 255) / 256));
+  restore_rows_kernel<16><<<grid, 256, 0, st>>>(tb.view, d_ids.p, n, d_rows.p, d_ts.p, tb.pending.p);
+  restore_slowpath_kernel<<<1, 64, 0, st>>>(tb.view, d_ids.p, d_rows.p, d_ts.p, tb.pending.p);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(st));  // the staging buffers go out of scope
+}
+
+static void restore_multi_table(mhte_multi_table* t, const std::string& basename, hipStream_t st) {
+  // the shard count is in the file names: <basename>-00000-of-<total>
+  int total = 0;
+  for (int cand = 1; cand <= 4096 && !total; ++cand) {
+    FILE* f = fopen(ckpt::shard_name(basename, "", 0, cand).c_str(), "rb");
+    if (f) {
+      fclose(f);
+      total = cand;
+    }
+  }
+  if (!total) throw Error(MHTE_NOT_FOUND, "no checkpoint shards found for " + basename);
+  std::vector<bool> seen(t->tables.size(), false);
+  for (int sh = 0; sh < total; ++sh) {
+    ckpt::RecordReader data(ckpt::shard_name(basename, "", sh, total), true);
+    ckpt::RecordReader meta(ckpt::shard_name(basename, ".meta", sh, total), false);
+    std::string mrec, rec, name;
+    while (meta.read(&mrec)) {
+      uint64_t num = 0;
+      ckpt::decode_meta(reinterpret_cast<const uint8_t*>(mrec.data()), mrec.size(), &name, &num);
+      int idx = -1;
+      for (size_t i = 0; i < t->tables.size(); ++i)
+        if (t->tables[i]->name == name) idx = int(i);
+      if (idx < 0) {  // table in the checkpoint but not in this MultiHashTable: skipped (:352-361)
+        for (uint64_t i = 0; i < num; ++i)
+          if (!data.read(&rec)) throw Error(MHTE_INTERNAL, "checkpoint shard ends early");
+        continue;
+      }
+      seen[size_t(idx)] = true;
+      Table& tb = *t->tables[size_t(idx)];
+      std::lock_guard<std::mutex> g(tb.mu);
+      const std::vector<ckpt::SegLayout> segs = seg_layout(tb);
+      const uint32_t rf = tb.row_floats;
+      // a row starts from initializer + optimizer Init (UpsertEntry's init_fn), then the dump
+      // overwrites what it carries
+      std::vector<float> init(rf, 0.f);
+      for (uint32_t k = 0; k < tb.nseg; ++k) {
+        const SegDesc& d = tb.view.seg[k];
+        const float w0 = init_weight(d);
+        for (int e = 0; e < d.dim; ++e) {
+          init[size_t(d.w_off + e)] = w0;
+          if (d.opt == kOptAdagrad || d.opt == kOptFtrl) init[size_t(d.st_off + e)] = d.p[0];
+          if (d.opt == kOptFtrl) init[size_t(d.st_off + d.dim + e)] = 0.f;
+        }
+      }
+      const size_t kBatch = size_t(1) << 18;
+      std::vector<int64_t> ids;
+      std::vector<uint32_t> ts;
+      std::vector<float> rows;
+      auto flush = [&] {
+        restore_batch(tb, ids, rows, ts, st);
+        ids.clear();
+        ts.clear();
+        rows.clear();
+      };
+      // ids inside one batch must be distinct for the upsert: a checkpoint holds each id once per
+      // table, but two shards of a foreign writer could repeat one — later entries win by flushing
+      std::vector<int64_t> sorted;
+      for (uint64_t i = 0; i < num; ++i) {
+        if (!data.read(&rec)) throw Error(MHTE_INTERNAL, "checkpoint shard ends early");
+        int64_t id;
+        uint32_t tsv;
+        rows.insert(rows.end(), init.begin(), init.end());
+        ckpt::decode_entry(reinterpret_cast<const uint8_t*>(rec.data()), rec.size(), segs,
+                           int(tb.dim), &id, rows.data() + rows.size() - rf, &tsv);
+        ids.push_back(id);
+        ts.push_back(tsv);
+        tb.max_update_ts = std::max<int64_t>(tb.max_update_ts, int64_t(tsv));
+        if (ids.size() == kBatch) {
+          sorted = ids;
+          std::sort(sorted.begin(), sorted.end());
+          if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+            throw Error(MHTE_INVALID_ARGUMENT, "checkpoint repeats an id inside table " + name);
+          flush();
+        }
+      }
+      sorted = ids;
+      std::sort(sorted.begin(), sorted.end());
+      if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+        throw Error(MHTE_INVALID_ARGUMENT, "checkpoint repeats an id inside table " + name);
+      flush();
+    }
+    if (data.read(&rec)) throw Error(MHTE_INTERNAL, "Couldn't read all of checkpoint shard");
+  }
+}
+
+}  // namespace mhte
+}  // extern "C++"
+
+mhte_status mhte_multi_table_save(mhte_multi_table* t, const char* basename, int32_t nshards,
+                                  void* stream) {
+  return guard([&] {
+    check_handle(t);
+    if (!basename || !*basename) throw Error(MHTE_INVALID_ARGUMENT, "save: empty basename");
+    HIP_OK(hipSetDevice(t->device));
+    try {
+      save_multi_table(t, basename, nshards, S(stream));
+    } catch (const Error&) {
+      throw;
+    } catch (const std::exception& e) {
+      throw Error(MHTE_INTERNAL, e.what());
+    }
+  });
+}
+
+mhte_status mhte_multi_table_restore(mhte_multi_table* t, const char* basename, void* stream) {
+  return guard([&] {
+    check_handle(t);
+    if (!basename || !*basename) throw Error(MHTE_INVALID_ARGUMENT, "restore: empty basename");
+    HIP_OK(hipSetDevice(t->device));
+    try {
+      restore_multi_table(t, basename, S(stream));
+    } catch (const Error&) {
+      throw;
+    } catch (const std::exception& e) {
+      throw Error(MHTE_INTERNAL, std::string("DataLoss: ") + e.what());
+    }
   });
 }
 

@@ -1,0 +1,517 @@
+// Host-side codec of the reference's MultiHashTable checkpoint format
+// (monolith/native_training/runtime/ops/multi_hash_table_save_restore_ops.cc:107-238,323-404):
+//
+//   <basename>-%05d-of-%05d        TFRecord stream, SNAPPY-compressed, of serialized EntryDump
+//                                  (hash_table/embedding_hash_table.proto:45-50), the tables of
+//                                  the MultiHashTable one after another (sorted by name)
+//   <basename>.meta-%05d-of-%05d   TFRecord stream, uncompressed, one MultiHashTableMetadata
+//                                  {table_name, num_entries} (:139-142) per table
+//
+// The container formats are TensorFlow 2.4.0's (WORKSPACE:61-67; not under /root/reference), restated
+// from their published definitions:
+//   * TFRecord (tensorflow/core/lib/io/record_writer.cc): uint64 length | uint32 masked crc32c of
+//     the length bytes | data | uint32 masked crc32c of the data; little-endian;
+//     mask(c) = ((c >> 15) | (c << 17)) + 0xa282ead8; crc32c = CRC-32C (Castagnoli).
+//   * SNAPPY compression of a record file (tensorflow/core/lib/io/snappy/snappy_outputbuffer.cc):
+//     the record stream is cut into blocks of <= 256 KiB, each written as a 4-byte BIG-endian
+//     compressed length followed by one raw snappy block (varint uncompressed length + elements,
+//     google/snappy format_description.txt).  This writer emits literal elements only (a valid
+//     snappy stream; fp32 payload does not compress anyway); the reader handles every element type.
+//   * protobuf wire format (proto2: repeated scalars unpacked on write, either form accepted on read).
+#ifndef MHTE_CKPT_H_
+#define MHTE_CKPT_H_
+
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace mhte {
+namespace ckpt {
+
+// ------------------------------------------------------------------------------------ crc32c
+inline const uint32_t* crc32c_table() {
+  static uint32_t table[256];
+  static bool init = false;
+  if (!init) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : (c >> 1);
+      table[i] = c;
+    }
+    init = true;
+  }
+  return table;
+}
+inline uint32_t crc32c(const void* data, size_t n) {
+  const uint32_t* t = crc32c_table();
+  const uint8_t* p = static_cast<const uint8_t*>(data);
+  uint32_t c = 0xffffffffu;
+  for (size_t i = 0; i < n; ++i) c = t[(c ^ p[i]) & 0xffu] ^ (c >> 8);
+  return c ^ 0xffffffffu;
+}
+inline uint32_t masked_crc(const void* data, size_t n) {
+  const uint32_t c = crc32c(data, n);
+  return ((c >> 15) | (c << 17)) + 0xa282ead8u;
+}
+
+// ------------------------------------------------------------------------------------ varint / proto
+inline void put_varint(std::string& out, uint64_t v) {
+  while (v >= 0x80) {
+    out.push_back(char((v & 0x7f) | 0x80));
+    v >>= 7;
+  }
+  out.push_back(char(v));
+}
+inline bool get_varint(const uint8_t*& p, const uint8_t* end, uint64_t* v) {
+  uint64_t r = 0;
+  for (int shift = 0; shift < 64 && p < end; shift += 7) {
+    const uint8_t b = *p++;
+    r |= uint64_t(b & 0x7f) << shift;
+    if (!(b & 0x80)) {
+      *v = r;
+      return true;
+    }
+  }
+  return false;
+}
+inline void put_f32(std::string& out, uint8_t tag, float f) {
+  out.push_back(char(tag));
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  char b[4] = {char(u), char(u >> 8), char(u >> 16), char(u >> 24)};
+  out.append(b, 4);
+}
+
+// Optimizer kinds of a segment as the codec sees them (SingleOptimizerDump's oneof,
+// hash_table/optimizer/optimizer.proto:231-247)
+enum SegKind { kSegSgd = 0, kSegAdagrad = 1, kSegFtrl = 2 };
+struct SegLayout {
+  int dim;
+  int kind;    // SegKind
+  int w_off;   // float offsets inside the engine's row
+  int st_off;
+};
+
+// EntryDump of one row (embedding_hash_table.proto:45-50; EntryAccessor::Save, entry_accessor.cc
+// :218-226; optimizer Save()s: sgd_optimizer.cc:50-54, adagrad_optimizer.cc:62-70,
+// ftrl_optimizer.cc:78-88; one SingleOptimizerDump per segment, optimizer_combination.cc:73-84)
+inline void encode_entry(std::string& out, int64_t id, const float* row,
+                         const std::vector<SegLayout>& segs, int dim, uint32_t ts) {
+  out.clear();
+  out.push_back(char(0x09));  // id: field 1, sfixed64
+  uint64_t u = uint64_t(id);
+  for (int i = 0; i < 8; ++i) out.push_back(char(u >> (8 * i)));
+  for (int i = 0; i < dim; ++i) put_f32(out, 0x15, row[i]);  // num: field 2, float, unpacked
+  std::string opt;
+  for (const SegLayout& s : segs) {
+    std::string single;
+    if (s.kind == kSegSgd) {
+      single.push_back(char(0x12));  // sgd: field 2, empty message
+      single.push_back(char(0x00));
+    } else if (s.kind == kSegAdagrad) {
+      std::string m;
+      for (int i = 0; i < s.dim; ++i) put_f32(m, 0x0d, row[s.st_off + i]);  // norm = 1
+      single.push_back(char(0x0a));  // adagrad: field 1
+      put_varint(single, m.size());
+      single += m;
+    } else {
+      std::string m;
+      // engine row: norm[d] | zero[d] (as ftrl_optimizer.cc:80-81); wire: zero = 1, norm = 2
+      for (int i = 0; i < s.dim; ++i) put_f32(m, 0x0d, row[s.st_off + s.dim + i]);
+      for (int i = 0; i < s.dim; ++i) put_f32(m, 0x15, row[s.st_off + i]);
+      single.push_back(char(0x1a));  // ftrl: field 3
+      put_varint(single, m.size());
+      single += m;
+    }
+    opt.push_back(char(0x0a));  // OptimizerDump.dump: field 1
+    put_varint(opt, single.size());
+    opt += single;
+  }
+  out.push_back(char(0x1a));  // opt: field 3
+  put_varint(out, opt.size());
+  out += opt;
+  out.push_back(char(0x20));  // last_update_ts_sec: field 4, varint
+  put_varint(out, ts);
+}
+
+struct ProtoError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+inline bool skip_field(const uint8_t*& p, const uint8_t* end, uint32_t wt) {
+  uint64_t v;
+  switch (wt) {
+    case 0: return get_varint(p, end, &v);
+    case 1: if (end - p < 8) return false; p += 8; return true;
+    case 2: if (!get_varint(p, end, &v) || uint64_t(end - p) < v) return false; p += v; return true;
+    case 5: if (end - p < 4) return false; p += 4; return true;
+    default: return false;
+  }
+}
+inline float rd_f32(const uint8_t* p) {
+  uint32_t u = uint32_t(p[0]) | (uint32_t(p[1]) << 8) | (uint32_t(p[2]) << 16) | (uint32_t(p[3]) << 24);
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+// repeated float field (packed or not) -> appends to dst (at most cap values kept)
+inline bool read_floats(const uint8_t*& p, const uint8_t* end, uint32_t wt, float* dst, int cap,
+                        int* n) {
+  if (wt == 5) {
+    if (end - p < 4) return false;
+    if (*n < cap) dst[*n] = rd_f32(p);
+    ++*n;
+    p += 4;
+    return true;
+  }
+  if (wt == 2) {
+    uint64_t len;
+    if (!get_varint(p, end, &len) || uint64_t(end - p) < len || (len & 3)) return false;
+    for (uint64_t i = 0; i < len; i += 4) {
+      if (*n < cap) dst[*n] = rd_f32(p + i);
+      ++*n;
+    }
+    p += len;
+    return true;
+  }
+  return false;
+}
+
+// Parses one EntryDump into the engine's row layout.  Missing optimizer state keeps the values
+// already in `row` (the caller pre-fills Init()); missing timestamp -> 0
+// (multi_hash_table_save_restore_ops.cc:384-386).
+inline void decode_entry(const uint8_t* p, size_t n, const std::vector<SegLayout>& segs, int dim,
+                         int64_t* id, float* row, uint32_t* ts) {
+  const uint8_t* end = p + n;
+  *id = 0;
+  *ts = 0;
+  int nnum = 0;
+  size_t seg_i = 0;
+  while (p < end) {
+    uint64_t key;
+    if (!get_varint(p, end, &key)) throw ProtoError("EntryDump: bad tag");
+    const uint32_t field = uint32_t(key >> 3), wt = uint32_t(key & 7);
+    if (field == 1 && wt == 1) {
+      if (end - p < 8) throw ProtoError("EntryDump: truncated id");
+      uint64_t u = 0;
+      for (int i = 0; i < 8; ++i) u |= uint64_t(p[i]) << (8 * i);
+      *id = int64_t(u);
+      p += 8;
+    } else if (field == 2 && (wt == 5 || wt == 2)) {
+      if (!read_floats(p, end, wt, row, dim, &nnum)) throw ProtoError("EntryDump: bad num");
+    } else if (field == 3 && wt == 2) {
+      uint64_t len;
+      if (!get_varint(p, end, &len) || uint64_t(end - p) < len) throw ProtoError("EntryDump: bad opt");
+      const uint8_t* q = p;
+      const uint8_t* qend = p + len;
+      p = qend;
+      while (q < qend) {  // OptimizerDump: repeated SingleOptimizerDump dump = 1
+        uint64_t k2;
+        if (!get_varint(q, qend, &k2)) throw ProtoError("OptimizerDump: bad tag");
+        if ((k2 >> 3) != 1 || (k2 & 7) != 2) {
+          if (!skip_field(q, qend, uint32_t(k2 & 7))) throw ProtoError("OptimizerDump: bad field");
+          continue;
+        }
+        uint64_t l2;
+        if (!get_varint(q, qend, &l2) || uint64_t(qend - q) < l2) throw ProtoError("OptimizerDump: bad dump");
+        const uint8_t* r = q;
+        const uint8_t* rend = q + l2;
+        q = rend;
+        if (seg_i >= segs.size()) continue;  // more dumps than segments: ignored
+        const SegLayout& sg = segs[seg_i++];
+        while (r < rend) {  // SingleOptimizerDump: oneof
+          uint64_t k3;
+          if (!get_varint(r, rend, &k3)) throw ProtoError("SingleOptimizerDump: bad tag");
+          const uint32_t f3 = uint32_t(k3 >> 3), w3 = uint32_t(k3 & 7);
+          if (w3 != 2) {
+            if (!skip_field(r, rend, w3)) throw ProtoError("SingleOptimizerDump: bad field");
+            continue;
+          }
+          uint64_t l3;
+          if (!get_varint(r, rend, &l3) || uint64_t(rend - r) < l3) throw ProtoError("SingleOptimizerDump: bad len");
+          const uint8_t* m = r;
+          const uint8_t* mend = r + l3;
+          r = mend;
+          if (f3 == 1 && sg.kind == kSegAdagrad) {
+            int c = 0;
+            while (m < mend) {
+              uint64_t k4;
+              if (!get_varint(m, mend, &k4)) throw ProtoError("AdagradOptimizerDump: bad tag");
+              if ((k4 >> 3) == 1) {
+                if (!read_floats(m, mend, uint32_t(k4 & 7), row + sg.st_off, sg.dim, &c))
+                  throw ProtoError("AdagradOptimizerDump: bad norm");
+              } else if (!skip_field(m, mend, uint32_t(k4 & 7))) {
+                throw ProtoError("AdagradOptimizerDump: bad field");
+              }
+            }
+          } else if (f3 == 3 && sg.kind == kSegFtrl) {
+            int cz = 0, cn = 0;
+            while (m < mend) {
+              uint64_t k4;
+              if (!get_varint(m, mend, &k4)) throw ProtoError("FtrlOptimizerDump: bad tag");
+              const uint32_t f4 = uint32_t(k4 >> 3);
+              if (f4 == 1) {
+                if (!read_floats(m, mend, uint32_t(k4 & 7), row + sg.st_off + sg.dim, sg.dim, &cz))
+                  throw ProtoError("FtrlOptimizerDump: bad zero");
+              } else if (f4 == 2) {
+                if (!read_floats(m, mend, uint32_t(k4 & 7), row + sg.st_off, sg.dim, &cn))
+                  throw ProtoError("FtrlOptimizerDump: bad norm");
+              } else if (!skip_field(m, mend, uint32_t(k4 & 7))) {
+                throw ProtoError("FtrlOptimizerDump: bad field");
+              }
+            }
+          }
+          // sgd (field 2) carries nothing; a dump of another optimizer type is ignored
+        }
+      }
+    } else if (field == 4 && wt == 0) {
+      uint64_t v;
+      if (!get_varint(p, end, &v)) throw ProtoError("EntryDump: bad timestamp");
+      *ts = uint32_t(v);
+    } else if (!skip_field(p, end, wt)) {
+      throw ProtoError("EntryDump: bad field");
+    }
+  }
+}
+
+inline void encode_meta(std::string& out, const std::string& table_name, uint64_t num_entries) {
+  out.clear();
+  out.push_back(char(0x0a));
+  put_varint(out, table_name.size());
+  out += table_name;
+  out.push_back(char(0x10));
+  put_varint(out, num_entries);
+}
+inline void decode_meta(const uint8_t* p, size_t n, std::string* name, uint64_t* num_entries) {
+  const uint8_t* end = p + n;
+  name->clear();
+  *num_entries = 0;
+  while (p < end) {
+    uint64_t key;
+    if (!get_varint(p, end, &key)) throw ProtoError("MultiHashTableMetadata: bad tag");
+    if ((key >> 3) == 1 && (key & 7) == 2) {
+      uint64_t len;
+      if (!get_varint(p, end, &len) || uint64_t(end - p) < len) throw ProtoError("metadata: bad name");
+      name->assign(reinterpret_cast<const char*>(p), len);
+      p += len;
+    } else if ((key >> 3) == 2 && (key & 7) == 0) {
+      if (!get_varint(p, end, num_entries)) throw ProtoError("metadata: bad count");
+    } else if (!skip_field(p, end, uint32_t(key & 7))) {
+      throw ProtoError("metadata: bad field");
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ snappy
+inline void snappy_compress_literals(const char* in, size_t n, std::string& out) {
+  put_varint(out, n);
+  size_t i = 0;
+  while (i < n) {
+    const size_t len = std::min<size_t>(n - i, 65536);
+    const size_t l1 = len - 1;
+    if (l1 < 60) {
+      out.push_back(char(l1 << 2));
+    } else if (l1 < 256) {
+      out.push_back(char(60 << 2));
+      out.push_back(char(l1));
+    } else {
+      out.push_back(char(61 << 2));
+      out.push_back(char(l1 & 0xff));
+      out.push_back(char(l1 >> 8));
+    }
+    out.append(in + i, len);
+    i += len;
+  }
+}
+inline bool snappy_uncompress(const uint8_t* p, size_t n, std::string& out) {
+  const uint8_t* end = p + n;
+  uint64_t ulen;
+  if (!get_varint(p, end, &ulen)) return false;
+  const size_t base = out.size();
+  out.reserve(base + ulen);
+  while (p < end) {
+    const uint8_t tag = *p++;
+    const uint32_t type = tag & 3u;
+    if (type == 0) {
+      uint64_t len = (tag >> 2);
+      if (len >= 60) {
+        const int nb = int(len) - 59;
+        if (end - p < nb) return false;
+        len = 0;
+        for (int i = 0; i < nb; ++i) len |= uint64_t(p[i]) << (8 * i);
+        p += nb;
+      }
+      len += 1;
+      if (uint64_t(end - p) < len) return false;
+      out.append(reinterpret_cast<const char*>(p), len);
+      p += len;
+    } else {
+      uint64_t len, off;
+      if (type == 1) {
+        if (end - p < 1) return false;
+        len = 4 + ((tag >> 2) & 7u);
+        off = (uint64_t(tag >> 5) << 8) | p[0];
+        p += 1;
+      } else if (type == 2) {
+        if (end - p < 2) return false;
+        len = 1 + (tag >> 2);
+        off = uint64_t(p[0]) | (uint64_t(p[1]) << 8);
+        p += 2;
+      } else {
+        if (end - p < 4) return false;
+        len = 1 + (tag >> 2);
+        off = uint64_t(p[0]) | (uint64_t(p[1]) << 8) | (uint64_t(p[2]) << 16) | (uint64_t(p[3]) << 24);
+        p += 4;
+      }
+      const size_t cur = out.size() - base;
+      if (off == 0 || off > cur) return false;
+      for (uint64_t i = 0; i < len; ++i) out.push_back(out[out.size() - off]);  // may overlap
+    }
+  }
+  return out.size() - base == ulen;
+}
+
+// ------------------------------------------------------------------------------------ record files
+constexpr size_t kSnappyBlock = 262144;  // RecordWriterOptions' snappy input buffer, TF 2.4
+
+class RecordWriter {
+ public:
+  RecordWriter(const std::string& path, bool snappy) : snappy_(snappy) {
+    fp_ = fopen(path.c_str(), "wb");
+    if (!fp_) throw std::runtime_error("cannot create " + path);
+  }
+  ~RecordWriter() {
+    if (fp_) fclose(fp_);
+  }
+  void write(const std::string& rec) {
+    char hdr[12];
+    const uint64_t len = rec.size();
+    for (int i = 0; i < 8; ++i) hdr[i] = char(len >> (8 * i));
+    const uint32_t c1 = masked_crc(hdr, 8);
+    for (int i = 0; i < 4; ++i) hdr[8 + i] = char(c1 >> (8 * i));
+    const uint32_t c2 = masked_crc(rec.data(), rec.size());
+    char ftr[4];
+    for (int i = 0; i < 4; ++i) ftr[i] = char(c2 >> (8 * i));
+    emit(hdr, 12);
+    emit(rec.data(), rec.size());
+    emit(ftr, 4);
+  }
+  void close() {
+    if (!fp_) return;
+    if (snappy_) flush_block();
+    if (fclose(fp_) != 0) {
+      fp_ = nullptr;
+      throw std::runtime_error("checkpoint write failed (close)");
+    }
+    fp_ = nullptr;
+  }
+
+ private:
+  void emit(const char* p, size_t n) {
+    if (!snappy_) {
+      if (n && fwrite(p, 1, n, fp_) != n) throw std::runtime_error("checkpoint write failed");
+      return;
+    }
+    while (n) {
+      const size_t take = std::min(n, kSnappyBlock - buf_.size());
+      buf_.append(p, take);
+      p += take;
+      n -= take;
+      if (buf_.size() == kSnappyBlock) flush_block();
+    }
+  }
+  void flush_block() {
+    if (buf_.empty()) return;
+    std::string comp;
+    snappy_compress_literals(buf_.data(), buf_.size(), comp);
+    const uint32_t cl = uint32_t(comp.size());
+    const char be[4] = {char(cl >> 24), char(cl >> 16), char(cl >> 8), char(cl)};
+    if (fwrite(be, 1, 4, fp_) != 4 || fwrite(comp.data(), 1, comp.size(), fp_) != comp.size())
+      throw std::runtime_error("checkpoint write failed");
+    buf_.clear();
+  }
+  FILE* fp_ = nullptr;
+  bool snappy_;
+  std::string buf_;
+};
+
+class RecordReader {
+ public:
+  RecordReader(const std::string& path, bool snappy) : snappy_(snappy), path_(path) {
+    fp_ = fopen(path.c_str(), "rb");
+    if (!fp_) throw std::runtime_error("cannot open " + path);
+  }
+  ~RecordReader() {
+    if (fp_) fclose(fp_);
+  }
+  // false at a clean end of file; throws on corruption (errors::DataLoss in the reference)
+  bool read(std::string* rec) {
+    char hdr[12];
+    const size_t got = fetch(hdr, 12);
+    if (got == 0) return false;
+    if (got != 12) throw std::runtime_error("truncated record header in " + path_);
+    uint64_t len = 0;
+    for (int i = 0; i < 8; ++i) len |= uint64_t(uint8_t(hdr[i])) << (8 * i);
+    uint32_t c1 = 0;
+    for (int i = 0; i < 4; ++i) c1 |= uint32_t(uint8_t(hdr[8 + i])) << (8 * i);
+    if (c1 != masked_crc(hdr, 8)) throw std::runtime_error("corrupted record length in " + path_);
+    rec->resize(len);
+    if (fetch(&(*rec)[0], len) != len) throw std::runtime_error("truncated record in " + path_);
+    char ftr[4];
+    if (fetch(ftr, 4) != 4) throw std::runtime_error("truncated record in " + path_);
+    uint32_t c2 = 0;
+    for (int i = 0; i < 4; ++i) c2 |= uint32_t(uint8_t(ftr[i])) << (8 * i);
+    if (c2 != masked_crc(rec->data(), rec->size()))
+      throw std::runtime_error("corrupted record data in " + path_);
+    return true;
+  }
+
+ private:
+  size_t fetch(char* dst, size_t n) {
+    if (!snappy_) return fread(dst, 1, n, fp_);
+    size_t done = 0;
+    while (done < n) {
+      if (pos_ == buf_.size()) {
+        if (!next_block()) break;
+      }
+      const size_t take = std::min(n - done, buf_.size() - pos_);
+      memcpy(dst + done, buf_.data() + pos_, take);
+      pos_ += take;
+      done += take;
+    }
+    return done;
+  }
+  bool next_block() {
+    uint8_t be[4];
+    const size_t got = fread(be, 1, 4, fp_);
+    if (got == 0) return false;
+    if (got != 4) throw std::runtime_error("truncated snappy block header in " + path_);
+    const uint32_t cl = (uint32_t(be[0]) << 24) | (uint32_t(be[1]) << 16) | (uint32_t(be[2]) << 8) | be[3];
+    comp_.resize(cl);
+    if (fread(&comp_[0], 1, cl, fp_) != cl) throw std::runtime_error("truncated snappy block in " + path_);
+    buf_.clear();
+    pos_ = 0;
+    if (!snappy_uncompress(reinterpret_cast<const uint8_t*>(comp_.data()), cl, buf_))
+      throw std::runtime_error("corrupted snappy block in " + path_);
+    return true;
+  }
+  FILE* fp_ = nullptr;
+  bool snappy_;
+  std::string path_, buf_, comp_;
+  size_t pos_ = 0;
+};
+
+inline std::string shard_name(const std::string& base, const char* infix, int shard, int total) {
+  char buf[64];
+  snprintf(buf, sizeof(buf), "%s-%05d-of-%05d", infix, shard, total);
+  return base + buf;
+}
+
+}  // namespace ckpt
+}  // namespace mhte
+#endif  // MHTE_CKPT_H_

@@ -73,6 +73,7 @@ struct WaveTrace {
 };
 
 enum ApplyOp : int { kOpAssign = 0, kOpAssignAdd = 1, kOpOptimize = 2, kOpReinit = 3 };
+// (checkpoint restore is its own small kernel: restore_rows_kernel)
 
 struct ApplyArgs {
   float lr[kMaxSegments];  // one per segment (SliceSize), multi_hash_table_update_op.cc:73-77
@@ -745,6 +746,78 @@ __global__ __launch_bounds__(64) void slowpath_kernel(TableView tv, const int64_
 
 
 // =============================================================================================
+// Checkpoint restore (cuckoo_embedding_hash_table.cc:299-320; EntryAccessor::Restore,
+// entry_accessor.cc:228-239): upsert of distinct ids, the WHOLE row (weights and optimizer state)
+// and the row's own timestamp taken from the checkpoint.  values [n, row_floats], ts [n].
+// =============================================================================================
+template <int G>
+__global__ __launch_bounds__(256) void restore_rows_kernel(TableView tv,
+                                                           const int64_t* __restrict__ ids,
+                                                           int64_t n,
+                                                           const float* __restrict__ values,
+                                                           const uint32_t* __restrict__ ts,
+                                                           uint32_t* __restrict__ pending) {
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (G - 1);
+  const int64_t g = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  const bool valid = g < n;
+  const int64_t id = valid ? ids[g] : 0;
+  const uint64_t hv = hash_key(id);
+  const uint64_t i1 = index_hash(tv.hp, hv);
+  const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
+  Bucket* b = tv.buckets + ((j < 4) ? i1 : i2);
+  int64_t k = kEmptyKey;
+  uint32_t row = kNoRow;
+  if (valid && id != kEmptyKey && j < 8) {
+    k = b->key[j & 3];
+    row = b->row[j & 3];
+  }
+  const uint32_t t = valid ? ts[g] : 0u;
+  const SlotResult sr = upsert_resolve<G>(tv, b, id, valid, k, row, lane, t);
+  if (sr.deferred && j == 0) pending[atomicAdd(&tv.ctr->n_pending, 1u)] = static_cast<uint32_t>(g);
+  if (valid && !sr.deferred) {
+    float* rp = row_ptr(tv, sr.r);
+    const float* vp = values + g * int64_t(tv.row_floats);
+    for (uint32_t e = j; e < tv.row_floats; e += G) rp[e] = vp[e];
+  }
+}
+// displacement pass of a restore: ids[pending[i]] get a slot, then the whole row
+__global__ __launch_bounds__(64) void restore_slowpath_kernel(TableView tv,
+                                                              const int64_t* __restrict__ ids,
+                                                              const float* __restrict__ values,
+                                                              const uint32_t* __restrict__ ts,
+                                                              const uint32_t* __restrict__ pending) {
+  __shared__ BfsSlot q[kMaxCuckooCount];
+  __shared__ CuckooRecord path[kMaxBfsPathLen];
+  const int lane = threadIdx.x;
+  const uint32_t np = tv.ctr->n_pending;
+  for (uint32_t i = 0; i < np; ++i) {
+    const uint32_t g = pending[i];
+    const long long pos = wave_insert_slot(tv.buckets, tv.hp, ids[g], q, path, lane);
+    uint32_t r = kNoRow;
+    if (lane == 0) {
+      if (pos >= 0) {
+        r = static_cast<uint32_t>(atomicAdd(&tv.ctr->alloc, (1ull << 32) | 1ull));
+        Bucket* b = tv.buckets + (pos >> 2);
+        b->row[pos & 3] = r;
+        b->ts[pos & 3] = ts[g];
+      } else {
+        atomicOr(&tv.ctr->error, 1u);
+        atomicAdd(&tv.ctr->n_dropped, 1u);
+      }
+    }
+    r = __shfl(r, 0);
+    if (pos >= 0) {
+      float* rp = row_ptr(tv, r);
+      const float* vp = values + int64_t(g) * tv.row_floats;
+      for (uint32_t e = lane; e < tv.row_floats; e += 64) rp[e] = vp[e];
+    }
+    __syncthreads();
+  }
+  if (lane == 0) tv.ctr->n_pending = 0;
+}
+
+// =============================================================================================
 // Doubling (cuckoo_fast_double / move_bucket, cuckoohash_map.hpp:1768-1894): index_hash and
 // alt_index gain one top bit, so every key of old bucket i lands in new bucket i (same slot) or
 // i + 2^hp (compacted from slot 0).  Pure streaming kernel: reads 64 B, writes 128 B per bucket.
@@ -852,10 +925,13 @@ __global__ __launch_bounds__(256) void evict_kernel(TableView tv, int64_t max_up
 }
 
 // count occupied slots per block of 1024 slots -> block_counts; then dump with offsets
-__global__ __launch_bounds__(256) void dump_count_kernel(TableView tv, uint32_t* __restrict__ bc) {
+// (slot range [slot0, slot1): Save's bucket-range shards and chunks)
+__global__ __launch_bounds__(256) void dump_count_kernel(TableView tv, uint64_t slot0,
+                                                         uint64_t slot1,
+                                                         uint32_t* __restrict__ bc) {
   __shared__ uint32_t wsum[4];
-  const uint64_t nslots = (uint64_t(1) << tv.hp) * kSlots;
-  const uint64_t base = uint64_t(blockIdx.x) * 1024;
+  const uint64_t nslots = slot1;
+  const uint64_t base = slot0 + uint64_t(blockIdx.x) * 1024;
   uint32_t c = 0;
   for (int k = 0; k < 4; ++k) {
     const uint64_t t = base + uint64_t(threadIdx.x) * 4 + k;
@@ -868,15 +944,16 @@ __global__ __launch_bounds__(256) void dump_count_kernel(TableView tv, uint32_t*
 }
 
 // block_offsets = exclusive scan of block_counts (done on host for dumps: it is a cold path)
-__global__ __launch_bounds__(256) void dump_emit_kernel(TableView tv,
+__global__ __launch_bounds__(256) void dump_emit_kernel(TableView tv, uint64_t slot0,
+                                                        uint64_t slot1,
                                                         const uint64_t* __restrict__ block_off,
                                                         int64_t* __restrict__ ids,
                                                         int64_t* __restrict__ positions,
                                                         uint32_t* __restrict__ ts,
                                                         float* __restrict__ rows) {
   __shared__ uint32_t wsum[4];
-  const uint64_t nslots = (uint64_t(1) << tv.hp) * kSlots;
-  const uint64_t base = uint64_t(blockIdx.x) * 1024;
+  const uint64_t nslots = slot1;
+  const uint64_t base = slot0 + uint64_t(blockIdx.x) * 1024;
   uint32_t occ[4];
   uint32_t c = 0;
   for (int k = 0; k < 4; ++k) {

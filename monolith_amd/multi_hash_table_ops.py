@@ -341,6 +341,25 @@ class MultiHashTable:
                                         C.c_int64(ids.numel()), vp(out), _stream()))
     return out.bool()
 
+  def save(self, basename: str, nshards: int = -1) -> "MultiHashTable":
+    """MultiHashTable.save (NT/multi_hash_table_ops.py:478-497): the reference's on-disk format
+    (``<basename>-%05d-of-%05d`` TFRecord+SNAPPY EntryDump shards and ``.meta`` sidecars); rows
+    expired relative to the table's max update time are dropped."""
+    import os
+    d = os.path.dirname(basename)
+    if d:
+      os.makedirs(d, exist_ok=True)
+    check(self._lib.mhte_multi_table_save(self._h, basename.encode("utf-8"), C.c_int32(int(nshards)),
+                                          _stream()))
+    return self
+
+  def restore(self, basename: str) -> "MultiHashTable":
+    """MultiHashTable.restore (NT/multi_hash_table_ops.py:499-513): tables of the checkpoint this
+    MultiHashTable does not have are skipped, tables it has but the checkpoint lacks stay as they
+    are."""
+    check(self._lib.mhte_multi_table_restore(self._h, basename.encode("utf-8"), _stream()))
+    return self
+
   def evict(self, name: str, max_update_time: int = -1) -> "MultiHashTable":
     check(self._lib.mhte_table_evict(self._h, C.c_int32(self._index(name)),
                                      C.c_int64(int(max_update_time)), _stream()))

@@ -1,0 +1,201 @@
+"""Test infrastructure: the reference's checkpoint messages as protobuf runtime classes, built
+from descriptors that restate the .proto definitions (no protoc in this image), plus an independent
+pure-Python TFRecord / TF-snappy-stream reader and writer.  Used to check the C++ codec
+(monolith_amd/csrc/mhte_ckpt.h) byte for byte.
+
+  EntryDump, MultiHashTableMetadata   runtime/hash_table/embedding_hash_table.proto:45-50,139-142
+  OptimizerDump & co                  runtime/hash_table/optimizer/optimizer.proto:28-31,56-58,
+                                      69-72,231-252
+"""
+import struct
+
+from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+
+F = descriptor_pb2.FieldDescriptorProto
+
+
+def _build():
+  fd = descriptor_pb2.FileDescriptorProto()
+  fd.name = "mhte_ckpt_test.proto"
+  fd.package = "monolith.hash_table"
+  fd.syntax = "proto2"
+
+  def msg(name, fields, oneof=None):
+    m = fd.message_type.add()
+    m.name = name
+    if oneof:
+      m.oneof_decl.add().name = oneof
+    for (fname, num, ftype, label, tname, in_oneof) in fields:
+      f = m.field.add()
+      f.name, f.number, f.type, f.label = fname, num, ftype, label
+      if tname:
+        f.type_name = ".monolith.hash_table." + tname
+      if in_oneof:
+        f.oneof_index = 0
+    return m
+
+  OPT, REP = F.LABEL_OPTIONAL, F.LABEL_REPEATED
+  msg("AdagradOptimizerDump", [("norm", 1, F.TYPE_FLOAT, REP, None, False)])
+  msg("SgdOptimizerDump", [])
+  msg("FtrlOptimizerDump", [("zero", 1, F.TYPE_FLOAT, REP, None, False),
+                            ("norm", 2, F.TYPE_FLOAT, REP, None, False)])
+  msg("SingleOptimizerDump", [("adagrad", 1, F.TYPE_MESSAGE, OPT, "AdagradOptimizerDump", True),
+                              ("sgd", 2, F.TYPE_MESSAGE, OPT, "SgdOptimizerDump", True),
+                              ("ftrl", 3, F.TYPE_MESSAGE, OPT, "FtrlOptimizerDump", True)], oneof="type")
+  msg("OptimizerDump", [("dump", 1, F.TYPE_MESSAGE, REP, "SingleOptimizerDump", False)])
+  msg("EntryDump", [("id", 1, F.TYPE_SFIXED64, OPT, None, False),
+                    ("num", 2, F.TYPE_FLOAT, REP, None, False),
+                    ("opt", 3, F.TYPE_MESSAGE, OPT, "OptimizerDump", False),
+                    ("last_update_ts_sec", 4, F.TYPE_INT64, OPT, None, False)])
+  msg("MultiHashTableMetadata", [("table_name", 1, F.TYPE_STRING, OPT, None, False),
+                                 ("num_entries", 2, F.TYPE_UINT64, OPT, None, False)])
+  pool = descriptor_pool.DescriptorPool()
+  pool.Add(fd)
+  get = lambda n: message_factory.GetMessageClass(pool.FindMessageTypeByName("monolith.hash_table." + n))
+  return get("EntryDump"), get("MultiHashTableMetadata")
+
+
+EntryDump, MultiHashTableMetadata = _build()
+
+
+# ---------------------------------------------------------------------------------- crc32c / TFRecord
+_TABLE = []
+for _i in range(256):
+  _c = _i
+  for _ in range(8):
+    _c = (_c >> 1) ^ 0x82F63B78 if _c & 1 else _c >> 1
+  _TABLE.append(_c)
+
+
+def crc32c(b: bytes) -> int:
+  c = 0xFFFFFFFF
+  for x in b:
+    c = _TABLE[(c ^ x) & 0xFF] ^ (c >> 8)
+  return c ^ 0xFFFFFFFF
+
+
+def masked(b: bytes) -> int:
+  c = crc32c(b)
+  return (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def frame(rec: bytes) -> bytes:
+  hdr = struct.pack("<Q", len(rec))
+  return hdr + struct.pack("<I", masked(hdr)) + rec + struct.pack("<I", masked(rec))
+
+
+def unframe(stream: bytes):
+  out, p = [], 0
+  while p < len(stream):
+    (n,) = struct.unpack_from("<Q", stream, p)
+    (c1,) = struct.unpack_from("<I", stream, p + 8)
+    assert c1 == masked(stream[p:p + 8]), "length crc"
+    rec = stream[p + 12:p + 12 + n]
+    (c2,) = struct.unpack_from("<I", stream, p + 12 + n)
+    assert c2 == masked(rec), "data crc"
+    out.append(rec)
+    p += 16 + n
+  return out
+
+
+# ---------------------------------------------------------------------------------- snappy (raw block)
+def _varint(n):
+  out = bytearray()
+  while n >= 0x80:
+    out.append((n & 0x7F) | 0x80)
+    n >>= 7
+  out.append(n)
+  return bytes(out)
+
+
+def snappy_uncompress(b: bytes) -> bytes:
+  p, n, shift = 0, 0, 0
+  while True:
+    x = b[p]
+    p += 1
+    n |= (x & 0x7F) << shift
+    shift += 7
+    if not x & 0x80:
+      break
+  out = bytearray()
+  while p < len(b):
+    tag = b[p]
+    p += 1
+    t = tag & 3
+    if t == 0:
+      ln = tag >> 2
+      if ln >= 60:
+        nb = ln - 59
+        ln = int.from_bytes(b[p:p + nb], "little")
+        p += nb
+      ln += 1
+      out += b[p:p + ln]
+      p += ln
+    else:
+      if t == 1:
+        ln, off = 4 + ((tag >> 2) & 7), ((tag >> 5) << 8) | b[p]
+        p += 1
+      elif t == 2:
+        ln, off = 1 + (tag >> 2), int.from_bytes(b[p:p + 2], "little")
+        p += 2
+      else:
+        ln, off = 1 + (tag >> 2), int.from_bytes(b[p:p + 4], "little")
+        p += 4
+      for _ in range(ln):
+        out.append(out[-off])
+  assert len(out) == n
+  return bytes(out)
+
+
+def snappy_compress_with_copies(data: bytes) -> bytes:
+  """A small greedy compressor that DOES emit copy elements (2-byte offsets), so that files made
+  here exercise the reader's copy paths."""
+  out = bytearray(_varint(len(data)))
+  lit = bytearray()
+  table = {}
+
+  def flush():
+    nonlocal lit
+    i = 0
+    while i < len(lit):
+      chunk = lit[i:i + 60]
+      out.append((len(chunk) - 1) << 2)
+      out.extend(chunk)
+      i += 60
+    lit = bytearray()
+
+  i = 0
+  while i < len(data):
+    key = data[i:i + 4]
+    j = table.get(key) if len(key) == 4 else None
+    table[key] = i
+    if j is not None and 0 < i - j < 65536:
+      ln = 4
+      while ln < 64 and i + ln < len(data) and data[j + ln] == data[i + ln]:
+        ln += 1
+      flush()
+      out.append(((ln - 1) << 2) | 2)
+      out += struct.pack("<H", i - j)
+      i += ln
+    else:
+      lit.append(data[i])
+      i += 1
+  flush()
+  return bytes(out)
+
+
+def read_tf_snappy(stream: bytes) -> bytes:
+  out, p = bytearray(), 0
+  while p < len(stream):
+    (cl,) = struct.unpack_from(">I", stream, p)
+    out += snappy_uncompress(stream[p + 4:p + 4 + cl])
+    p += 4 + cl
+  return bytes(out)
+
+
+def write_tf_snappy(raw: bytes, block=262144) -> bytes:
+  out = bytearray()
+  for i in range(0, len(raw), block):
+    c = snappy_compress_with_copies(raw[i:i + block])
+    out += struct.pack(">I", len(c)) + c
+  return bytes(out)

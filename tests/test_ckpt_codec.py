@@ -1,0 +1,150 @@
+"""CPU suite: the checkpoint codec (monolith_amd/csrc/mhte_ckpt.h, compiled host-only with g++)
+against (a) the reference's own golden EntryDump (embedding_hash_table_test.h:78-93), (b) the
+protobuf runtime on message classes restating the reference's .proto files, (c) the standard
+CRC-32C check value, (d) an independent pure-Python TFRecord / TF-snappy reader and writer."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import ckpt_proto as P  # noqa: E402
+
+SGD, ADAGRAD, FTRL = 0, 1, 2
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+  exe = str(tmp_path_factory.mktemp("ckpt") / "ckpt_driver")
+  subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe,
+                         os.path.join(ROOT, "tests", "ckpt_host_driver.cc")])
+  return exe
+
+
+def run(exe, *args):
+  return subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True,
+                        check=True).stdout.strip()
+
+
+def reference_entry(id_, ts, segs, row, dim, with_id=True, packed=False):
+  """EntryAccessor::Save (entry_accessor.cc:218-226) through the protobuf runtime."""
+  e = P.EntryDump()
+  if with_id:
+    e.id = id_
+  e.num.extend(row[:dim])
+  st = dim
+  for kind, d in segs:
+    s = e.opt.dump.add()
+    if kind == SGD:
+      s.sgd.SetInParent()
+    elif kind == ADAGRAD:
+      s.adagrad.norm.extend(row[st:st + d])
+      st += d
+    else:
+      s.ftrl.norm.extend(row[st:st + d])
+      s.ftrl.zero.extend(row[st + d:st + 2 * d])
+      st += 2 * d
+  e.last_update_ts_sec = ts
+  return e.SerializeToString()
+
+
+def test_crc32c_check_value(driver):
+  crc, m = run(driver, "crc", "123456789").split()
+  assert crc == "e3069283"                       # CRC-32C check value (RFC 3720 B.4)
+  assert int(m, 16) == P.masked(b"123456789")
+
+
+def test_reference_golden_entry_dump(driver):
+  """embedding_hash_table_test.h:78-93: Sgd table, id 1 after AssignAdd -> EntryDump
+  {num: 1, opt {dump {sgd {}}}, last_update_ts_sec: 0}; the Save path adds the id (field 1)."""
+  golden = bytes.fromhex("150000803f" "1a040a021200" "2000")
+  e = P.EntryDump()
+  e.num.append(1.0)
+  e.opt.dump.add().sgd.SetInParent()
+  e.last_update_ts_sec = 0
+  assert e.SerializeToString() == golden         # the descriptors restate the .proto faithfully
+  got = bytes.fromhex(run(driver, "entry", 7, 0, 1, 1, SGD, 1, 1.0))
+  assert got[:9] == b"\x09" + (7).to_bytes(8, "little")
+  assert got[9:] == golden
+
+
+@pytest.mark.parametrize("segs", [[(SGD, 3)], [(ADAGRAD, 4)], [(FTRL, 2)],
+                                  [(FTRL, 1), (ADAGRAD, 5), (SGD, 2)]])
+def test_entry_bytes_equal_protobuf_runtime(driver, segs):
+  rng = np.random.default_rng(len(segs) * 11 + segs[0][1])
+  dim = sum(d for _, d in segs)
+  rf = dim + sum(d if k == ADAGRAD else (2 * d if k == FTRL else 0) for k, d in segs)
+  row = rng.standard_normal(rf).astype(np.float32)
+  for id_, ts in ((-3, 0), (1 << 62, 1700000123), (-(1 << 63), 4294967295)):
+    args = ["entry", id_, ts, dim, len(segs)] + [x for s in segs for x in s] + [repr(float(v)) for v in row]
+    got = bytes.fromhex(run(driver, *args))
+    assert got == reference_entry(id_, ts, segs, row.tolist(), dim)
+
+
+def test_decode_accepts_unpacked_packed_and_missing_fields(driver, tmp_path):
+  segs = [(FTRL, 2), (ADAGRAD, 3)]
+  dim, rf = 5, 5 + 4 + 3
+  row = (np.arange(rf) * 0.5 + 0.25).astype(np.float32)
+  seg_args = [x for s in segs for x in s]
+  raw = reference_entry(99, 1234, segs, row.tolist(), dim)
+  (tmp_path / "a.hex").write_text(raw.hex())
+  out = run(driver, "decode", tmp_path / "a.hex", dim, len(segs), *seg_args).split()
+  assert int(out[0]) == 99 and int(out[1]) == 1234
+  np.testing.assert_array_equal(np.array(out[2:], np.float32), row)
+  # packed repeated floats (a proto3-style writer) decode the same
+  def packed(field, vals):
+    b = np.asarray(vals, np.float32).tobytes()
+    return bytes([(field << 3) | 2]) + P._varint(len(b)) + b
+  ftrl = packed(1, row[7:9]) + packed(2, row[5:7])
+  ada = packed(1, row[9:12])
+  opt = b"".join(b"\x0a" + P._varint(len(m) + 2) + bytes([t]) + P._varint(len(m)) + m
+                 for t, m in ((0x1a, ftrl), (0x0a, ada)))
+  raw2 = b"\x09" + (99).to_bytes(8, "little") + packed(2, row[:5]) + b"\x1a" + P._varint(len(opt)) + opt
+  (tmp_path / "b.hex").write_text(raw2.hex())
+  out = run(driver, "decode", tmp_path / "b.hex", dim, len(segs), *seg_args).split()
+  assert int(out[0]) == 99 and int(out[1]) == 0     # no timestamp in the dump -> 0 (:384-386)
+  np.testing.assert_array_equal(np.array(out[2:], np.float32), row)
+  # an entry without optimizer dump keeps the pre-filled state (driver pre-fills -7)
+  e = P.EntryDump()
+  e.id = 5
+  e.num.extend(row[:5].tolist())
+  (tmp_path / "c.hex").write_text(e.SerializeToString().hex())
+  out = run(driver, "decode", tmp_path / "c.hex", dim, len(segs), *seg_args).split()
+  np.testing.assert_array_equal(np.array(out[2:7], np.float32), row[:5])
+  assert all(float(x) == -7.0 for x in out[7:])
+
+
+@pytest.mark.parametrize("snappy", [0, 1])
+def test_record_files_roundtrip_and_match_python_reader(driver, tmp_path, snappy):
+  path = tmp_path / ("f%d" % snappy)
+  n, ln = 3000, 300                                 # ~1 MB: several 256 KiB snappy blocks
+  run(driver, "write", path, snappy, n, ln)
+  cnt, x, total = (int(v) for v in run(driver, "read", path, snappy).split())
+  recs = [bytes([i & 0xff]) * (ln + i % 7) for i in range(n)]
+  assert cnt == n and total == sum(len(r) for r in recs)
+  stream = path.read_bytes()
+  raw = P.read_tf_snappy(stream) if snappy else stream
+  assert P.unframe(raw) == recs
+  # and the other way: a file framed (and compressed WITH copy elements) by the Python writer
+  path2 = tmp_path / ("g%d" % snappy)
+  raw2 = b"".join(P.frame(r) for r in recs)
+  path2.write_bytes(P.write_tf_snappy(raw2) if snappy else raw2)
+  if snappy:
+    assert len(path2.read_bytes()) < len(raw2) // 4   # copies were emitted
+  cnt2, x2, total2 = (int(v) for v in run(driver, "read", path2, snappy).split())
+  assert (cnt2, x2, total2) == (cnt, x, total)
+
+
+def test_corruption_is_reported(driver, tmp_path):
+  path = tmp_path / "c"
+  run(driver, "write", path, 1, 50, 100)
+  b = bytearray(path.read_bytes())
+  b[40] ^= 0x55
+  path.write_bytes(bytes(b))
+  r = subprocess.run([driver, "read", str(path), "1"], capture_output=True, text=True)
+  assert r.returncode == 1 and "ERROR" in r.stdout

@@ -9,6 +9,7 @@ Bars: bit-exact for ids, sizes, hit counts, status codes, dedup order / offsets,
 fp32 rows bit-exact wherever the summation order is the reference's, else |diff| <= 1e-5.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -753,6 +754,149 @@ def test_sender_side_partition_scatter_sum(n, dim, shards, dist):
   light[send_pos] = cnt <= 32
   np.testing.assert_array_equal(gs[light], exp[light])
   np.testing.assert_allclose(gs, exp, rtol=0, atol=TOL)
+
+
+# =============================================================================== checkpoints
+def test_save_restore_reference_scenario(tmp_path):
+  """multi_hash_table_ops_test.py:129-170: save {slot0, slot1, slot2}, restore into
+  {slot0, slot2, slot3}: known tables come back, unknown ones are skipped, missing ones stay empty."""
+  t0 = make({"slot0": sgd_cfg(1), "slot1": sgd_cfg(2), "slot2": sgd_cfg(2)})
+  t0.assign_add({"slot0": (ids_t([0, 1]), val_t([[1], [2]])),
+                 "slot1": (ids_t([2, 3, 4, 5]), val_t([[1, 2], [2, 3], [3, 4], [4, 5]])),
+                 "slot2": (ids_t([6, 7, 8, 9, 10]), val_t([[1, 1], [2, 2], [3, 3], [4, 4], [5, 5]]))})
+  base = str(tmp_path / "test_save_restore" / "table")
+  t0.save(base)
+  t1 = make({"slot0": sgd_cfg(1), "slot2": sgd_cfg(2), "slot3": sgd_cfg(3)})
+  t1.restore(base)
+  got = t1.lookup({"slot0": ids_t([0, 1]), "slot2": ids_t([6, 7, 8, 9, 10])})
+  np.testing.assert_array_equal(got["slot0"].cpu().numpy(), [[1], [2]])
+  np.testing.assert_array_equal(got["slot2"].cpu().numpy(), [[1, 1], [2, 2], [3, 3], [4, 4], [5, 5]])
+  assert t1.size("slot3") == 0 and t1.size("slot0") == 2 and t1.size("slot2") == 5
+
+
+@pytest.mark.parametrize("nshards", [1, 3])
+def test_checkpoint_files_are_the_reference_format_and_roundtrip(tmp_path, nshards):
+  """Save -> the files parse with an independent reader (TFRecord framing + masked crc32c, TF's
+  snappy block stream, EntryDump / MultiHashTableMetadata through the protobuf runtime) into
+  exactly the table's content, bucket-range sharded; restore into a fresh table reproduces every
+  row, optimizer state and timestamp, and training continues bit-identically."""
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  import ckpt_proto as P
+  segs = [entry.CombineAsSegment(1, entry.ZerosInitializer(),
+                                 entry.FtrlOptimizer(0.03, 0.1, 1.0, 0, 0.01, 0.02)),
+          entry.CombineAsSegment(8, entry.ConstantsInitializer(0.5), entry.AdagradOptimizer(0.05, 0.1)),
+          entry.CombineAsSegment(3, entry.ZerosInitializer(), entry.SgdOptimizer(0.1))]
+  cfgs = {"b_multi": entry.make_table_config(segs), "a_sgd": sgd_cfg(2, 0.5)}
+  mt = make(cfgs)
+  rng = np.random.default_rng(3)
+  n = 5000
+  ids = np.unique(rng.integers(-2**62, 2**62, n))
+  ids[0] = np.iinfo(np.int64).min                       # the side-slot key travels too
+  for step in range(3):
+    mt.apply_gradients(
+        {"b_multi": (ids_t(ids), val_t(rng.standard_normal((ids.size, 12)).astype(np.float32))),
+         "a_sgd": (ids_t(ids[:ids.size // 2]),
+                   val_t(rng.standard_normal((ids.size // 2, 2)).astype(np.float32)))},
+        req_time=1_700_000_000 + step)
+  base = str(tmp_path / "ckpt" / "model")
+  mt.save(base, nshards=nshards)
+  # ---- independent parse
+  seen = {"a_sgd": {}, "b_multi": {}}
+  for sh in range(nshards):
+    meta = P.unframe(open("%s.meta-%05d-of-%05d" % (base, sh, nshards), "rb").read())
+    data = P.unframe(P.read_tf_snappy(open("%s-%05d-of-%05d" % (base, sh, nshards), "rb").read()))
+    p = 0
+    names = []
+    for m in meta:
+      md = P.MultiHashTableMetadata.FromString(m)
+      names.append(md.table_name)
+      for rec in data[p:p + md.num_entries]:
+        e = P.EntryDump.FromString(rec)
+        assert e.id not in seen[md.table_name]
+        seen[md.table_name][e.id] = e
+      p += md.num_entries
+    assert names == ["a_sgd", "b_multi"] and p == len(data)   # sorted-name order, nothing left over
+  d_ids, _, d_ts, d_rows = mt.dump("b_multi")
+  d_ids, d_ts, d_rows = d_ids.cpu().numpy(), d_ts.cpu().numpy(), d_rows.cpu().numpy()
+  assert len(seen["b_multi"]) == ids.size == d_ids.size + 1   # (dump() leaves the side-slot key out)
+  for k, i in enumerate(d_ids.tolist()):
+    e = seen["b_multi"][i]
+    row = d_rows[k]
+    np.testing.assert_array_equal(np.array(e.num, np.float32), row[:12])
+    assert e.last_update_ts_sec == int(d_ts[k]) == 1_700_000_002
+    assert [d.WhichOneof("type") for d in e.opt.dump] == ["ftrl", "adagrad", "sgd"]
+    np.testing.assert_array_equal(np.array(e.opt.dump[0].ftrl.norm, np.float32), row[12:13])
+    np.testing.assert_array_equal(np.array(e.opt.dump[0].ftrl.zero, np.float32), row[13:14])
+    np.testing.assert_array_equal(np.array(e.opt.dump[1].adagrad.norm, np.float32), row[14:22])
+  assert np.iinfo(np.int64).min in seen["b_multi"]
+  # ---- restore into a fresh table, then both continue training identically
+  mt2 = make(cfgs)
+  mt2.restore(base)
+  assert mt2.size("b_multi") == ids.size and mt2.size("a_sgd") == ids.size // 2
+  probe = {"b_multi": ids_t(ids), "a_sgd": ids_t(ids)}
+  a, b = mt.lookup(probe), mt2.lookup(probe)
+  for k in probe:
+    np.testing.assert_array_equal(a[k].cpu().numpy(), b[k].cpu().numpy())
+  g = val_t(rng.standard_normal((ids.size, 12)).astype(np.float32))
+  for m_ in (mt, mt2):
+    m_.apply_gradients({"b_multi": (ids_t(ids), g)}, req_time=1_700_000_010)
+  np.testing.assert_array_equal(mt.lookup(probe)["b_multi"].cpu().numpy(),
+                                mt2.lookup(probe)["b_multi"].cpu().numpy())
+  r1, r2 = mt.dump("b_multi"), mt2.dump("b_multi")
+  o1, o2 = np.argsort(r1[0].cpu().numpy()), np.argsort(r2[0].cpu().numpy())
+  np.testing.assert_array_equal(r1[3].cpu().numpy()[o1], r2[3].cpu().numpy()[o2])   # state too
+  np.testing.assert_array_equal(r1[2].cpu().numpy()[o1], r2[2].cpu().numpy()[o2])   # timestamps
+
+
+def test_restore_reads_a_foreign_writer_and_save_expires_rows(tmp_path):
+  """(1) A checkpoint written by another implementation — here the Python writer of
+  tests/ckpt_proto.py: protobuf-runtime EntryDumps, snappy WITH copy elements — restores;
+  (2) Save drops rows whose age reaches their slot's TTL relative to the table's max update time
+  (multi_hash_table_save_restore_ops.cc:203-211; embedding_hash_table_test.h:282-326 values)."""
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  import ckpt_proto as P
+  base = str(tmp_path / "foreign")
+  ents = []
+  for i in range(300):
+    e = P.EntryDump()
+    e.id = 1000 + i
+    e.num.extend([float(i), float(-i)])
+    e.opt.dump.add().adagrad.norm.extend([0.1 + i, 0.2 + i])
+    if i % 2:
+      e.last_update_ts_sec = 500 + i
+    ents.append(e.SerializeToString())
+  md = P.MultiHashTableMetadata(table_name="emb", num_entries=len(ents)).SerializeToString()
+  other = P.MultiHashTableMetadata(table_name="zzz_unknown", num_entries=2).SerializeToString()
+  raw = b"".join(P.frame(r) for r in ents + ents[:2])
+  open(base + "-00000-of-00001", "wb").write(P.write_tf_snappy(raw, block=4096))
+  open(base + ".meta-00000-of-00001", "wb").write(P.frame(md) + P.frame(other))
+  mt = make({"emb": adagrad_cfg(2, 0.1, 0.1)})
+  mt.restore(base)
+  assert mt.size("emb") == 300
+  d_ids, _, d_ts, d_rows = mt.dump("emb")
+  o = np.argsort(d_ids.cpu().numpy())
+  rows = d_rows.cpu().numpy()[o]
+  i = np.arange(300, dtype=np.float32)
+  np.testing.assert_array_equal(rows, np.stack([i, -i, 0.1 + i, 0.2 + i], 1).astype(np.float32))
+  np.testing.assert_array_equal(d_ts.cpu().numpy()[o], np.where(np.arange(300) % 2, 500 + np.arange(300), 0))
+  # ---- expiry on save
+  day = 86400
+  ttl = entry.SlotExpireTimeConfig(default_expire_time=14, slot_expire_times={1: 5, 2: 6})
+  cfg = entry.make_table_config(
+      [entry.CombineAsSegment(1, entry.ZerosInitializer(), entry.SgdOptimizer(1.0))],
+      slot_expire_time_config=ttl)
+  t = make({"t": cfg})
+  t0 = 1_600_000_000
+  fids = [(1 << 48) | 123, (2 << 48) | 456, 789]
+  t.assign_add({"t": (ids_t(fids), val_t([[1.0], [2.0], [3.0]]))}, req_time=t0)
+  t.assign_add({"t": (ids_t([55]), val_t([[9.0]]))}, req_time=t0 + 5 * day + 60)   # moves max_update_ts
+  b2 = str(tmp_path / "exp")
+  t.save(b2, nshards=1)
+  recs = P.unframe(P.read_tf_snappy(open(b2 + "-00000-of-00001", "rb").read()))
+  kept = sorted(P.EntryDump.FromString(r).id for r in recs)
+  assert kept == sorted([(2 << 48) | 456, 789, 55])      # slot 1 (TTL 5 d) expired, slot 2 / default kept
+  assert P.MultiHashTableMetadata.FromString(
+      P.unframe(open(b2 + ".meta-00000-of-00001", "rb").read())[0]).num_entries == 3
 
 
 # =============================================================================== full-size properties
