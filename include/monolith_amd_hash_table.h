@@ -42,7 +42,7 @@ enum {
 
 const char* mhte_last_error(void);
 /* ABI version of this header; mhte_abi_version() must return the same value. */
-#define MHTE_ABI_VERSION 2
+#define MHTE_ABI_VERSION 3
 int32_t mhte_abi_version(void);
 
 /* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
@@ -73,6 +73,12 @@ typedef struct {
   int32_t n_slot_expire;
   const int64_t* expire_slots;   /* host */
   const int32_t* expire_days;    /* host */
+  /* SlotOccurrenceThresholdConfig (embedding_hash_table.proto:98-110): an id that is not in the
+     table yet is admitted once the attached hash filter has seen it this many times; <= 0: always */
+  int32_t default_occurrence_threshold;
+  int32_t n_slot_occurrence;
+  const int64_t* occurrence_slots;      /* host */
+  const int32_t* occurrence_thresholds; /* host */
 } mhte_table_config;
 
 typedef struct mhte_multi_table mhte_multi_table;
@@ -185,6 +191,23 @@ mhte_status mhte_table_dump(mhte_multi_table* t, int32_t table, int64_t cap, int
                             int64_t* positions, uint32_t* ts, float* rows, int64_t* n_out,
                             void* stream);
 int32_t mhte_table_row_floats(const mhte_multi_table* t, int32_t i);
+
+/* Admission filter (RT/hash_filter/hash_filter.h:33-214, the `filter_handle` input of
+ * CreateMonolithMultiHashTable, RT/ops/multi_hash_table_op.cc:104-112): a counting filter with 4-bit
+ * saturating counts shared by the tables of a MultiHashTable.  While attached, Optimize / Assign
+ * (and the training step's apply) drop an id that is not in the table yet and has been seen fewer
+ * times than its feature slot's occurrence threshold (RT/ops/embedding_hash_table_tf_bridge.cc
+ * :182-185,300-321); AssignAdd consults the filter without the Contains guard, as the reference's
+ * multi-table path does (:230-232).  One filter split; the sliding window over several splits
+ * (sliding_hash_filter.cc) is not built, `split_num` is accepted for signature parity. */
+typedef struct mhte_hash_filter mhte_hash_filter;
+mhte_status mhte_hash_filter_create(uint64_t capacity, int32_t split_num, int32_t device,
+                                    mhte_hash_filter** out);
+void mhte_hash_filter_destroy(mhte_hash_filter* f);
+mhte_status mhte_multi_table_set_filter(mhte_multi_table* t, mhte_hash_filter* f /* NULL detaches */);
+/* Filter::get: the seen count of ids (0..15), out [dev u32, n] */
+mhte_status mhte_hash_filter_get(mhte_hash_filter* f, const int64_t* id, int64_t n, uint32_t* out,
+                                 void* stream);
 
 /* MonolithMultiHashTableSave / Restore (RT/ops/multi_hash_table_save_restore_ops.cc:115-263,
  * 266-420) in the reference's on-disk format, so checkpoints are interchangeable:

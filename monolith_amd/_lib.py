@@ -22,7 +22,7 @@ MHTE_IDS_UNIQUE = 1
 MHTE_SUM_DUPLICATES = 2
 MHTE_EXACT_ORDER = 1       # flags of mhte_table_sum_optimize_n
 MHTE_DEFER_SLOWPATH = 2
-ABI_VERSION = 2            # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
+ABI_VERSION = 3            # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 INIT_ZEROS, INIT_ONES, INIT_CONSTANT = 0, 1, 2
@@ -55,7 +55,10 @@ class TableConfig(C.Structure):
               ("segments", C.POINTER(SegmentConfig)), ("initial_capacity", C.c_uint64),
               ("reserve_rows", C.c_uint64), ("max_load_factor", C.c_float),
               ("default_expire_days", C.c_int64), ("n_slot_expire", C.c_int32),
-              ("expire_slots", C.POINTER(C.c_int64)), ("expire_days", C.POINTER(C.c_int32))]
+              ("expire_slots", C.POINTER(C.c_int64)), ("expire_days", C.POINTER(C.c_int32)),
+              ("default_occurrence_threshold", C.c_int32), ("n_slot_occurrence", C.c_int32),
+              ("occurrence_slots", C.POINTER(C.c_int64)),
+              ("occurrence_thresholds", C.POINTER(C.c_int32))]
 
 
 class TableStats(C.Structure):
@@ -103,6 +106,8 @@ EXPORTS = [
     "mhte_table_step_forward", "mhte_table_step_backward", "mhte_profile_arm", "mhte_profile_read",
     "mhte_trace_begin", "mhte_trace_end", "mhte_step_dedup", "mhte_shard_partition",
     "mhte_step_scatter", "mhte_step_sum", "mhte_multi_table_save", "mhte_multi_table_restore",
+    "mhte_hash_filter_create", "mhte_hash_filter_destroy", "mhte_multi_table_set_filter",
+    "mhte_hash_filter_get",
 ]
 
 _lib = None
@@ -133,6 +138,8 @@ def lib():
       getattr(L, name).restype = C.c_char_p
     L.mhte_multi_table_destroy.restype = None
     L.mhte_dedup_ws_destroy.restype = None
+    L.mhte_hash_filter_destroy.restype = None
+    L.mhte_hash_filter_destroy.argtypes = [C.c_void_p]
     L.mhte_multi_table_destroy.argtypes = [C.c_void_p]
     L.mhte_dedup_ws_destroy.argtypes = [C.c_void_p]
     for name in ("mhte_num_tables",):

@@ -382,6 +382,15 @@ struct Table {
   DevBuf<int64_t> d_expire_slots;
   DevBuf<int32_t> d_expire_days;
   DevBuf<uint32_t> pending;
+  DevBuf<uint32_t> skip;            // first admitted occurrence of deferred ids (admission filter)
+  // admission: per-feature-slot occurrence thresholds (SlotOccurrenceThresholdConfig) + the filter
+  int32_t occ_default = 0;
+  std::vector<int64_t> occ_slots;
+  std::vector<int32_t> occ_thr;
+  DevBuf<int64_t> d_occ_slots;
+  DevBuf<int32_t> d_occ_thr;
+  uint32_t* flt_slots = nullptr;    // owned by the mhte_hash_filter attached to the MultiHashTable
+  uint64_t flt_total = 0;
   // in-op grouping scratch (ids not declared unique)
   DedupWs dd;
   DevBuf<int64_t> g_uids;
@@ -450,6 +459,15 @@ struct Table {
       HIP_OK(hipMemcpy(d_expire_days.p, expire_days.data(), expire_days.size() * 4,
                        hipMemcpyHostToDevice));
     }
+    occ_default = c.default_occurrence_threshold;
+    if (c.n_slot_occurrence > 0) {
+      occ_slots.assign(c.occurrence_slots, c.occurrence_slots + c.n_slot_occurrence);
+      occ_thr.assign(c.occurrence_thresholds, c.occurrence_thresholds + c.n_slot_occurrence);
+      d_occ_slots.reserve(occ_slots.size());
+      d_occ_thr.reserve(occ_thr.size());
+      HIP_OK(hipMemcpy(d_occ_slots.p, occ_slots.data(), occ_slots.size() * 8, hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(d_occ_thr.p, occ_thr.data(), occ_thr.size() * 4, hipMemcpyHostToDevice));
+    }
     hp = reserve_calc(c.initial_capacity ? c.initial_capacity : 1);
     if (hp > 34) throw Error(MHTE_INVALID_ARGUMENT, "initial_capacity too large");
     alloc_buckets(hp, &buckets, nullptr);
@@ -501,6 +519,12 @@ struct Table {
     view.dim = dim;
     view.nseg = nseg;
     view.trace = nullptr;
+    view.flt_slots = flt_slots;
+    view.flt_total = flt_total;
+    view.occ_default = occ_default;
+    view.occ_n = int32_t(occ_slots.size());
+    view.occ_slots = d_occ_slots.p;
+    view.occ_thr = d_occ_thr.p;
   }
 
   void sync_counters(hipStream_t st) {
@@ -629,18 +653,23 @@ struct Table {
                      int32_t* status, hipStream_t st) {
     Shape sh = pick_shape(dim, vec_ok && (values == nullptr || aligned16(values)));
     pending.reserve(size_t(n) + 1);
+    uint32_t* skp = nullptr;
+    if (flt_slots && a.filter_mode && seg_off) {
+      skip.reserve(size_t(n) + 1);
+      skp = skip.p;
+    }
     const int64_t threads = n * sh.G;
     const dim3 grid(uint32_t((threads + 255) / 256));
     uint32_t* pend = pending.p;
 #define CALL(G_, V_)                                                                         \
   LAUNCH_HOT(kTagUpsert, (upsert_kernel<G_, V_, OP>), grid, 256, st, view, ids, n, n_dev, values, \
-             seg_off, seg_pos, a, status, pend)
+             seg_off, seg_pos, a, status, pend, skp)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
     if (sh.VEC == 4) {
-      slowpath_kernel<4, OP><<<1, 64, 0, st>>>(view, ids, values, seg_off, seg_pos, a, status, pend);
+      slowpath_kernel<4, OP><<<1, 64, 0, st>>>(view, ids, values, seg_off, seg_pos, a, status, pend, skp);
     } else {
-      slowpath_kernel<1, OP><<<1, 64, 0, st>>>(view, ids, values, seg_off, seg_pos, a, status, pend);
+      slowpath_kernel<1, OP><<<1, 64, 0, st>>>(view, ids, values, seg_off, seg_pos, a, status, pend, skp);
     }
     HIP_OK(hipGetLastError());
   }
@@ -656,6 +685,9 @@ struct Table {
     for (int i = 0; i < kMaxSegments; ++i) a.lr[i] = (lrs && i < int(nseg)) ? lrs[i] : 0.f;
     a.ts = static_cast<uint32_t>(update_time);
     a.sum_dups = (flags & MHTE_SUM_DUPLICATES) ? 1 : 0;
+    // admission filter (tf_bridge.cc): Assign / Optimize are guarded by Contains; the multi-table
+    // AssignAdd goes through AssignAdd2, which is not (:230-232); Reinitialize never filters
+    a.filter_mode = (OP == kOpReinit) ? 0 : (OP == kOpAssignAdd ? 3 : 1);
     ensure_capacity(uint64_t(n), st);
     if (flags & MHTE_IDS_UNIQUE) {
       launch_upsert<OP>(ids, n, n_dev, values, nullptr, nullptr, a, status, st);
@@ -693,6 +725,7 @@ struct Table {
     for (int i = 0; i < kMaxSegments; ++i) a.lr[i] = (lrs && i < int(nseg)) ? lrs[i] : 0.f;
     a.ts = static_cast<uint32_t>(update_time);
     a.sum_dups = 1;
+    a.filter_mode = 1;
     ensure_capacity(uint64_t(n_max), st);
     Shape sh = pick_shape(dim, vec_ok && aligned16(grads) && aligned16(grad_u));
     pending.reserve(size_t(n_max) + 1);
@@ -785,6 +818,7 @@ struct Table {
     for (int i = 0; i < kMaxSegments; ++i) a.lr[i] = (lrs && i < int(nseg)) ? lrs[i] : 0.f;
     a.ts = static_cast<uint32_t>(update_time);
     a.sum_dups = 1;
+    a.filter_mode = 1;
     ensure_capacity(uint64_t(std::min<int64_t>(n_max, n)), st);
     Shape sh = pick_shape(dim, vec_ok && aligned16(grads) && aligned16(grad_u));
     pending.reserve(size_t(n_max) + 1);
@@ -859,10 +893,10 @@ struct Table {
     pend_valid = false;
     if (pend_vec == 4) {
       LAUNCH_HOT(kTagSlowpath, (slowpath_kernel<4, kOpOptimize>), 1, 64, st, view, pend_uids,
-                 pend_grad, nullptr, nullptr, pend_args, nullptr, pending.p);
+                 pend_grad, nullptr, nullptr, pend_args, nullptr, pending.p, nullptr);
     } else {
       LAUNCH_HOT(kTagSlowpath, (slowpath_kernel<1, kOpOptimize>), 1, 64, st, view, pend_uids,
-                 pend_grad, nullptr, nullptr, pend_args, nullptr, pending.p);
+                 pend_grad, nullptr, nullptr, pend_args, nullptr, pending.p, nullptr);
     }
     HIP_OK(hipGetLastError());
   }
@@ -896,6 +930,17 @@ struct mhte_multi_table {
 };
 struct mhte_dedup_ws {
   mhte::DedupWs ws;
+};
+struct mhte_hash_filter {
+  int device = 0;
+  uint32_t* slots = nullptr;
+  uint64_t total = 0;
+  ~mhte_hash_filter() {
+    if (slots) {
+      (void)hipSetDevice(device);
+      (void)hipFree(slots);
+    }
+  }
 };
 
 namespace mhte {
@@ -1323,6 +1368,53 @@ mhte_status mhte_table_dump(mhte_multi_table* t, int32_t table, int64_t cap, int
     dump_emit_kernel<<<nblocks, 256, 0, st>>>(tb.view, uint64_t(0), nslots, bo.p, ids, positions, ts, rows);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(st));
+  });
+}
+
+// ---- admission filter ---------------------------------------------------------------------------
+mhte_status mhte_hash_filter_create(uint64_t capacity, int32_t split_num, int32_t device,
+                                    mhte_hash_filter** out) {
+  return guard([&] {
+    if (!out) throw Error(MHTE_INVALID_ARGUMENT, "null out");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+      throw Error(MHTE_UNAVAILABLE, "no such HIP device");
+    HIP_OK(hipSetDevice(device));
+    (void)split_num;  // (one split: the sliding window of SlidingHashFilter is not built)
+    if (capacity < 300) capacity = 300;  // sliding_hash_filter.cc:31
+    std::unique_ptr<mhte_hash_filter> f(new mhte_hash_filter);
+    f->device = device;
+    f->total = uint64_t(double(capacity) * 1.5);  // HashFilter(capacity, fill_rate = 1.5)
+    HIP_OK(hipMalloc(&f->slots, f->total * sizeof(uint32_t)));
+    HIP_OK(hipMemset(f->slots, 0, f->total * sizeof(uint32_t)));
+    *out = f.release();
+  });
+}
+void mhte_hash_filter_destroy(mhte_hash_filter* f) { delete f; }
+
+mhte_status mhte_multi_table_set_filter(mhte_multi_table* t, mhte_hash_filter* f) {
+  return guard([&] {
+    check_handle(t);
+    if (f && f->device != t->device)
+      throw Error(MHTE_INVALID_ARGUMENT, "hash filter lives on another device");
+    for (auto& tb : t->tables) {
+      std::lock_guard<std::mutex> g(tb->mu);
+      tb->flt_slots = f ? f->slots : nullptr;
+      tb->flt_total = f ? f->total : 0;
+      tb->refresh_view();
+    }
+  });
+}
+
+/* seen count of ids (Filter::get, hash_filter.h:109-111): out [dev u32, n] */
+mhte_status mhte_hash_filter_get(mhte_hash_filter* f, const int64_t* id, int64_t n, uint32_t* out,
+                                 void* stream) {
+  return guard([&] {
+    if (!f || !id || !out) throw Error(MHTE_INVALID_ARGUMENT, "null argument");
+    if (n <= 0) return;
+    HIP_OK(hipSetDevice(f->device));
+    filter_get_kernel<<<dim3(uint32_t((n + 255) / 256)), 256, 0, S(stream)>>>(f->slots, f->total, id, n, out);
+    HIP_OK(hipGetLastError());
   });
 }
 

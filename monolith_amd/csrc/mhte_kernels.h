@@ -43,6 +43,13 @@ struct TableView {
   uint32_t dim;
   uint32_t nseg;
   SegDesc seg[kMaxSegments];
+  // admission (hash filter, runtime/hash_filter/hash_filter.h): null = no filter attached
+  uint32_t* flt_slots;            // signature << 4 | count (0 = empty)
+  uint64_t flt_total;             // number of filter slots
+  int32_t occ_default;            // SlotOccurrenceThresholdConfig.default_occurrence_threshold
+  int32_t occ_n;
+  const int64_t* occ_slots;       // device: per-feature-slot overrides
+  const int32_t* occ_thr;
   // measurement aid (mhte_trace_begin): when non-null, every wavefront of a step kernel records
   // {begin, end, role, marks} at trace[kTraceWords * global wave index]; 100 MHz wall clock.
   unsigned long long* trace;
@@ -78,6 +85,7 @@ enum ApplyOp : int { kOpAssign = 0, kOpAssignAdd = 1, kOpOptimize = 2, kOpReinit
 struct ApplyArgs {
   float lr[kMaxSegments];  // one per segment (SliceSize), multi_hash_table_update_op.cc:73-77
   uint32_t ts;             // (uint32)update_time, entry_defs.h:36-38
+  int32_t filter_mode;     // admission (filter_consult): 0 off, 1 guarded by Contains, 3 unguarded
   int32_t sum_dups;        // 1: duplicates' values are added first, one optimizer step
                            //    (enable_grad_accumulation, tf_bridge.cc:270-310)
                            // 0: one optimizer step per occurrence, in order
@@ -115,6 +123,101 @@ struct Vec<1> {
   __device__ __forceinline__ void load(const float* p) { v[0] = *p; }
   __device__ __forceinline__ void store(float* p) const { *p = v[0]; }
 };
+
+// =============================================================================================
+// Admission filter (runtime/hash_filter/hash_filter.h:33-214; bridge call sites
+// ops/embedding_hash_table_tf_bridge.cc:182-185,208-211,230-232,300-321): a counting filter with
+// 4-bit saturating counts; an id that is not in the table yet is dropped while the number of times
+// it has been seen is below its feature slot's occurrence threshold.
+//   slot word = signature << 4 | count; signature = (fid >> 17 | fid << 15) (hash_filter.h:149),
+//   28 bits here (the reference's HashFilter<uint16_t> keeps 12), open addressing, <= 64 probes;
+//   no free slot within 64 probes counts as "seen max_count times" (:100-107), i.e. admitted.
+// Physical placement uses the engine's fixed hash (the reference's absl::Hash is unpinned), so
+// parity is semantic: counts and admission decisions.
+// =============================================================================================
+constexpr uint32_t kFilterMaxCount = 15;   // count_bit = 4, filter.h:56-57
+constexpr int kFilterMaxStep = 64;         // hash_filter.h:190
+
+__device__ __forceinline__ int32_t occurrence_threshold(const TableView& tv, int64_t id) {
+  const int64_t slot = (id >> 48) & 0x7fff;  // slot_id_v2
+  int32_t thr = tv.occ_default;
+  for (int i = 0; i < tv.occ_n; ++i)
+    if (tv.occ_slots[i] == slot) thr = tv.occ_thr[i];
+  return thr;
+}
+
+// The decision for ONE id whose k occurrences arrive in order (one lane calls it).
+//   mode 1 (Assign / AssignAdd / BatchOptimize without dedup): occurrence i is dropped iff the id is
+//          still absent and the count seen before it is < thr; the first admitted occurrence inserts
+//          the id, the rest no longer consult the filter.  Returns the index of the first admitted
+//          occurrence (k: all dropped).
+//   mode 2 (BatchOptimize with dedup, tf_bridge.cc:300-310): one consultation with count k.
+//   mode 3 (multi-table AssignAdd = AssignAdd2, :230-232): no Contains guard — every occurrence
+//          consults the filter; returns the first admitted index (later ones are admitted too, as
+//          the count only grows).
+// `contained`: the id is in the table already (modes 1, 2: filter untouched, everything admitted).
+__device__ __forceinline__ uint32_t filter_consult(const TableView& tv, int64_t id, uint32_t k,
+                                                   int mode, bool contained) {
+  const int32_t thr_i = occurrence_threshold(tv, id);
+  if (thr_i <= 0 || k == 0) return 0u;              // ShouldBeFiltered: threshold <= 0 disables
+  if (contained && mode != 3) return 0u;
+  const uint32_t thr = uint32_t(thr_i);
+  const uint64_t fid = uint64_t(id);
+  const uint32_t sign = uint32_t((fid >> 17) | (fid << 15)) & 0x0fffffffu;
+  uint64_t pos = hash_key(id ^ 0x5bd1e995) % tv.flt_total;
+  for (int step = 0; step < kFilterMaxStep; ++step) {
+    uint32_t v = __hip_atomic_load(&tv.flt_slots[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+      if (v != 0u && (v >> 4) != sign) break;       // another id's slot: next probe
+      const uint32_t c0 = v & kFilterMaxCount;      // (0 for an empty slot)
+      uint32_t first, adds;
+      if (mode == 2) {
+        first = (c0 < thr) ? k : 0u;
+        adds = k;
+      } else if (mode == 3) {
+        first = (c0 >= thr) ? 0u : min(k, thr - c0);
+        adds = k;
+      } else {
+        first = (c0 >= thr) ? 0u : (thr - c0);
+        adds = min(k, first + 1u);                  // the admitted occurrence is the last to ask
+        first = min(first, k);
+      }
+      const uint32_t c1 = min(kFilterMaxCount, c0 + min(adds, kFilterMaxCount));
+      const uint32_t nv = (sign << 4) | c1;
+      const uint32_t old = atomicCAS(&tv.flt_slots[pos], v, nv);
+      if (old == v) return first;
+      v = old;
+    }
+    pos = (pos + 1 == tv.flt_total) ? 0 : pos + 1;
+  }
+  return 0u;  // no slot: add() returns max_count -> admitted
+}
+
+__global__ __launch_bounds__(256) void filter_get_kernel(const uint32_t* __restrict__ slots,
+                                                         uint64_t total,
+                                                         const int64_t* __restrict__ ids, int64_t n,
+                                                         uint32_t* __restrict__ out) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t id = ids[i];
+  const uint64_t fid = uint64_t(id);
+  const uint32_t sign = uint32_t((fid >> 17) | (fid << 15)) & 0x0fffffffu;
+  uint64_t pos = hash_key(id ^ 0x5bd1e995) % total;
+  uint32_t c = kFilterMaxCount;  // no slot within the probe limit: get() returns max_count
+  for (int step = 0; step < kFilterMaxStep; ++step) {
+    const uint32_t v = slots[pos];
+    if (v == 0u) {
+      c = 0;
+      break;
+    }
+    if ((v >> 4) == sign) {
+      c = v & kFilterMaxCount;
+      break;
+    }
+    pos = (pos + 1 == total) ? 0 : pos + 1;
+  }
+  out[i] = c;
+}
 
 // =============================================================================================
 // Lookup: ids[n] -> out[n, dim].  Absent id -> zeros, never inserts
@@ -487,12 +590,13 @@ __global__ __launch_bounds__(256) void upsert_kernel(TableView tv, const int64_t
                                                      const uint32_t* __restrict__ seg_off,
                                                      const uint32_t* __restrict__ seg_pos,
                                                      ApplyArgs a, int32_t* __restrict__ status,
-                                                     uint32_t* __restrict__ pending) {
+                                                     uint32_t* __restrict__ pending,
+                                                     uint32_t* __restrict__ skip) {
   const int lane = threadIdx.x & 63;
   const int j = lane & (G - 1);
   const int64_t g = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
   if (n_dev) n = min(n, int64_t(*n_dev));
-  const bool valid = g < n;
+  bool valid = g < n;
   const int64_t id = valid ? ids[g] : 0;
   const uint64_t hv = hash_key(id);
   const uint64_t i1 = index_hash(tv.hp, hv);
@@ -505,16 +609,31 @@ __global__ __launch_bounds__(256) void upsert_kernel(TableView tv, const int64_t
     k = b->key[j & 3];
     row = b->row[j & 3];
   }
+  uint32_t q0 = (valid && seg_off) ? seg_off[g] : 0u;
+  const uint32_t q1 = (valid && seg_off) ? seg_off[g + 1] : 1u;
+  // ---- admission filter: may drop the first occurrences of an id that is not in the table yet
+  if (tv.flt_slots && a.filter_mode) {
+    const int gbase = lane & ~(G - 1);
+    bool contained = group_mask_of<G>(__ballot(valid && id != kEmptyKey && j < 8 && k == id), gbase) != 0;
+    if (valid && id == kEmptyKey) contained = tv.ctr->special_state == 1;
+    uint32_t first = 0;
+    if (valid && j == 0) {
+      const int mode = (a.filter_mode == 1 && a.sum_dups) ? 2 : a.filter_mode;
+      first = filter_consult(tv, id, q1 - q0, mode, contained);
+    }
+    first = __shfl(first, gbase);
+    if (first >= q1 - q0) valid = false;  // every occurrence dropped: the id is not inserted
+    q0 += first;
+  }
   const SlotResult sr = upsert_resolve<G>(tv, b, id, valid, k, row, lane, a.ts);
   // ---- defer to the slow path ----
   if (sr.deferred && j == 0) {
     const uint32_t slot = atomicAdd(&tv.ctr->n_pending, 1u);
     pending[slot] = static_cast<uint32_t>(g);
+    if (skip) skip[g] = q0;
   }
   // ---- apply ----
   if (valid && !sr.deferred) {
-    const uint32_t q0 = seg_off ? seg_off[g] : 0u;
-    const uint32_t q1 = seg_off ? seg_off[g + 1] : 1u;
     apply_row<G, VEC, OP>(tv, row_ptr(tv, sr.r), sr.is_new, j, values, seg_off ? seg_pos : nullptr,
                           q0, q1, g, a);
     if (OP == kOpReinit && j == 0) {
@@ -688,7 +807,8 @@ __device__ __forceinline__ void slowpath_role(const TableView& tv, const int64_t
                                               const uint32_t* __restrict__ seg_pos,
                                               const ApplyArgs& a, int32_t* __restrict__ status,
                                               const uint32_t* __restrict__ pending,
-                                              BfsSlot* q, CuckooRecord* path) {
+                                              BfsSlot* q, CuckooRecord* path,
+                                              const uint32_t* __restrict__ skip = nullptr) {
   const int lane = threadIdx.x;
   const uint32_t np = tv.ctr->n_pending;
   if (np == 0) return;
@@ -710,7 +830,8 @@ __device__ __forceinline__ void slowpath_role(const TableView& tv, const int64_t
     }
     r = __shfl(r, 0);
     if (pos >= 0) {
-      const uint32_t q0 = seg_off ? seg_off[g] : 0u;
+      // (skip: first occurrence the admission filter let through, upsert_kernel)
+      const uint32_t q0 = (skip && seg_off) ? skip[g] : (seg_off ? seg_off[g] : 0u);
       const uint32_t q1 = seg_off ? seg_off[g + 1] : 1u;
       apply_row<64, VEC, OP>(tv, row_ptr(tv, r), true, lane, values, seg_off ? seg_pos : nullptr,
                              q0, q1, g, a);
@@ -738,10 +859,11 @@ __global__ __launch_bounds__(64) void slowpath_kernel(TableView tv, const int64_
                                                       const uint32_t* __restrict__ seg_off,
                                                       const uint32_t* __restrict__ seg_pos,
                                                       ApplyArgs a, int32_t* __restrict__ status,
-                                                      const uint32_t* __restrict__ pending) {
+                                                      const uint32_t* __restrict__ pending,
+                                                      const uint32_t* __restrict__ skip) {
   __shared__ BfsSlot q[kMaxCuckooCount];
   __shared__ CuckooRecord path[kMaxBfsPathLen];
-  slowpath_role<VEC, OP, true>(tv, ids, values, seg_off, seg_pos, a, status, pending, q, path);
+  slowpath_role<VEC, OP, true>(tv, ids, values, seg_off, seg_pos, a, status, pending, q, path, skip);
 }
 
 

@@ -614,6 +614,16 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         x[q] = (flat && idx < cnt) ? d.hlist[size_t(gs) * kLightMax + idx] : 0xffffffffu;
       }
       if (it == 0) wt.mark(1);
+      // admission filter (one consultation with the occurrence count: BatchOptimize with dedup,
+      // tf_bridge.cc:300-310): an id that is not in the table yet and has not been seen often
+      // enough is dropped — no insert, no update
+      if (tv.flt_slots) {
+        bool contained = group_mask_of<G>(__ballot(valid && id != kEmptyKey && j < 8 && pr.k == id), gbase) != 0;
+        if (valid && id == kEmptyKey) contained = tv.ctr->special_state == 1;
+        uint32_t first = 0;
+        if (valid && j == 0) first = filter_consult(tv, id, cnt, 2, contained);
+        if (__shfl(first, gbase) != 0u) valid = false;
+      }
       // round trip 3: the row
       const SlotResult sr = upsert_resolve<G>(tv, pr.b, id, valid, pr.k, pr.row, lane, a.ts);
       RowRegs<VEC> rr;
@@ -809,7 +819,14 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       }
     }
     if (apply && threadIdx.x < 64) {
-      const bool valid = threadIdx.x < G;
+      bool valid = threadIdx.x < G;
+      if (tv.flt_slots) {  // (as in the id-major groups; the list's length is its count)
+        bool contained = group_mask_of<G>(__ballot(valid && hd.id != kEmptyKey && j < 8 && pr.k == hd.id), gbase) != 0;
+        if (valid && hd.id == kEmptyKey) contained = tv.ctr->special_state == 1;
+        uint32_t first = 0;
+        if (valid && j == 0) first = filter_consult(tv, hd.id, d.ucnt[hd.u], 2, contained);
+        if (__shfl(first, gbase) != 0u) valid = false;
+      }
       const SlotResult sr = upsert_resolve<G>(tv, pr.b, hd.id, valid, pr.k, pr.row, lane, a.ts);
       if (sr.deferred) {
         if (ev) tot.store(c.grad_u + int64_t(hd.u) * dim + e);

@@ -122,12 +122,22 @@ class SlotExpireTimeConfig:
 
 
 @dataclasses.dataclass
+class SlotOccurrenceThresholdConfig:
+  """embedding_hash_table.proto:98-110: per-feature-slot admission thresholds of the hash filter,
+  default 0 (= admit at once)."""
+  default_occurrence_threshold: int = 0
+  slot_occurrence_thresholds: Dict[int, int] = dataclasses.field(default_factory=dict)
+
+
+@dataclasses.dataclass
 class EmbeddingHashTableConfig:
   """embedding_hash_table.proto:70-95 (the fields the hot path reads)."""
   segments: List[Segment] = dataclasses.field(default_factory=list)
   initial_capacity: int = 1
   slot_expire_time_config: SlotExpireTimeConfig = dataclasses.field(
       default_factory=SlotExpireTimeConfig)
+  slot_occurrence_threshold_config: SlotOccurrenceThresholdConfig = dataclasses.field(
+      default_factory=SlotOccurrenceThresholdConfig)
   enable_feature_eviction: bool = False
   feature_evict_every_n_hours: int = 240
   # MI355X extensions
@@ -183,13 +193,17 @@ class HashTableConfigInstance:
 
 def make_table_config(segments: Sequence[Segment], hash_table_config: Optional[CuckooHashTableConfig]
                       = None, slot_expire_time_config: Optional[SlotExpireTimeConfig] = None,
-                      learning_rates: Optional[Sequence[float]] = None) -> HashTableConfigInstance:
+                      learning_rates: Optional[Sequence[float]] = None,
+                      slot_occurrence_threshold_config: Optional[SlotOccurrenceThresholdConfig] = None
+                      ) -> HashTableConfigInstance:
   """Convenience: what the reference's test helpers build by hand (multi_hash_table_ops_test.py
   :30-48) — segments + cuckoo config -> HashTableConfigInstance with one lr per segment."""
   tc = EmbeddingHashTableConfig(segments=list(segments))
   (hash_table_config or CuckooHashTableConfig()).mutate_table(tc)
   if slot_expire_time_config is not None:
     tc.slot_expire_time_config = slot_expire_time_config
+  if slot_occurrence_threshold_config is not None:
+    tc.slot_occurrence_threshold_config = slot_occurrence_threshold_config
   if learning_rates is None:
     learning_rates = [s.optimizer.learning_rate for s in segments]
   return HashTableConfigInstance(tc, list(learning_rates))

@@ -11,6 +11,7 @@ include/monolith_amd_hash_table.h (libmhte.so).  Differences that follow from le
     (reference ``_copy_with_new_table`` :425-428).
 """
 import ctypes as C
+import time
 from typing import Dict, List, NamedTuple, Optional, Sequence, Tuple
 
 import numpy as np
@@ -75,8 +76,51 @@ def _lower_config(name: str, cfg: entry.HashTableConfigInstance, keep: list):
   c.n_slot_expire = int(slots.size)
   c.expire_slots = _i64p(slots)
   c.expire_days = _i32p(days)
-  keep.extend([segs, bname, slots, days])
+  so = tc.slot_occurrence_threshold_config
+  c.default_occurrence_threshold = int(so.default_occurrence_threshold)
+  oslots = np.ascontiguousarray(list(so.slot_occurrence_thresholds.keys()), dtype=np.int64)
+  othr = np.ascontiguousarray(list(so.slot_occurrence_thresholds.values()), dtype=np.int32)
+  c.n_slot_occurrence = int(oslots.size)
+  c.occurrence_slots = _i64p(oslots)
+  c.occurrence_thresholds = _i32p(othr)
+  keep.extend([segs, bname, slots, days, oslots, othr])
   return c
+
+
+class HashFilter:
+  """The hash filter resource of the reference (hash_filter_ops.create_hash_filter; the
+  ``filter_handle`` input of CreateMonolithMultiHashTable): a counting admission filter in HBM,
+  shared by the tables of the MultiHashTable it is attached to."""
+
+  def __init__(self, capacity: int = 300000000, split_num: int = 7, device: Optional[int] = None):
+    if not torch.cuda.is_available():
+      raise _lib.MhteError(_lib.MHTE_UNAVAILABLE, "HashFilter needs a HIP device")
+    self._lib = _lib.lib()
+    self._device = torch.cuda.current_device() if device is None else int(device)
+    h = C.c_void_p()
+    check(self._lib.mhte_hash_filter_create(C.c_uint64(int(capacity)), C.c_int32(int(split_num)),
+                                            C.c_int32(self._device), C.byref(h)))
+    self._h = h
+
+  def get(self, ids: torch.Tensor) -> torch.Tensor:
+    """Seen counts (0..15) of ``ids`` (Filter::get)."""
+    ids = ids.to(device="cuda:%d" % self._device, dtype=torch.int64).contiguous()
+    out = torch.empty(ids.numel(), dtype=torch.int32, device=ids.device)
+    check(self._lib.mhte_hash_filter_get(self._h, vp(ids), C.c_int64(ids.numel()), vp(out),
+                                         _stream()))
+    return out
+
+  def close(self):
+    if getattr(self, "_h", None):
+      torch.cuda.synchronize(self._device)
+      self._lib.mhte_hash_filter_destroy(self._h)
+      self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
 
 
 class MultiHashTable:
@@ -86,7 +130,7 @@ class MultiHashTable:
   _names_in_use = set()
 
   def __init__(self, configs: Dict[str, entry.HashTableConfigInstance], name_suffix: str = "",
-               device: Optional[int] = None):
+               device: Optional[int] = None, hash_filter: Optional["HashFilter"] = None):
     if not torch.cuda.is_available():
       raise _lib.MhteError(_lib.MHTE_UNAVAILABLE,
                            "MultiHashTable needs a HIP device; there is no CPU fallback")
@@ -112,9 +156,22 @@ class MultiHashTable:
     check(self._lib.mhte_multi_table_create(arr, len(self._table_names), self._device,
                                             self._shared_name.encode(), C.byref(h)))
     self._h = h
+    self._hash_filter = hash_filter   # (kept alive with the table)
+    if hash_filter is not None:
+      check(self._lib.mhte_multi_table_set_filter(self._h, hash_filter._h))  # pylint: disable=protected-access
     MultiHashTable._names_in_use.add(self._shared_name)
     self._slice_sizes = tuple(
         self._lib.mhte_table_slice_size(self._h, i) for i in range(len(self._table_names)))
+    # Feature eviction (tf_bridge.cc:73-104: a thread per table wakes every 10 s and evicts once
+    # `feature_evict_every_n_hours` have passed).  A scan that rewrites buckets must be ordered with
+    # the table's other work, which on the GPU means: on the caller's stream.  So the check rides on
+    # the update calls instead of a thread; same cadence, no race.
+    self._evict_clock = time.time
+    self._evict_every_s = {
+        n: configs[n].table_config.feature_evict_every_n_hours * 3600.0
+        for n in self._table_names if configs[n].table_config.enable_feature_eviction}
+    self._last_evict = {n: self._evict_clock() for n in self._evict_every_s}
+    self._last_evict_check = self._evict_clock()
 
   @classmethod
   def from_configs(cls, configs: Dict[str, entry.HashTableConfigInstance], *args, **kwargs):
@@ -260,8 +317,27 @@ class MultiHashTable:
                                 C.c_int64(out.numel()), _stream()))
     return out
 
+  def maybe_evict(self, force_check: bool = False) -> List[str]:
+    """Runs the TTL eviction scan of every table whose ``feature_evict_every_n_hours`` have passed
+    (on the current stream); called by the update paths, at most every 10 s.  Returns the names of
+    the tables scanned."""
+    if not self._evict_every_s:
+      return []
+    now = self._evict_clock()
+    if not force_check and now - self._last_evict_check < 10.0:
+      return []
+    self._last_evict_check = now
+    done = []
+    for n, period in self._evict_every_s.items():
+      if now - self._last_evict[n] >= period:
+        self.evict(n)
+        self._last_evict[n] = now
+        done.append(n)
+    return done
+
   def raw_apply_gradients(self, ragged_id: Ragged, flat_grad: torch.Tensor, global_step: int = 0,
                           req_time: int = 0, ids_unique: bool = False) -> "MultiHashTable":
+    self.maybe_evict()
     flat_grad = self._dev(flat_grad, torch.float32)
     check(self._lib.mhte_optimize(self._h, vp(ragged_id.values), _i64p(ragged_id.row_splits),
                                   C.c_int64(ragged_id.row_splits.size), vp(flat_grad),
@@ -449,6 +525,7 @@ class MultiHashTable:
     """mhte_table_step_backward: gradient sum + upsert + optimizer of the batch ``ws`` holds
     (+ the heavy work list of the batch ``ws_next`` holds)."""
     i = name_or_idx if isinstance(name_or_idx, int) else self._index(name_or_idx)
+    self.maybe_evict()
     lrs = np.ascontiguousarray(lrs, dtype=np.float32)
     n = grads.shape[0]
     check(self._lib.mhte_table_step_backward(

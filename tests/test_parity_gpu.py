@@ -756,6 +756,138 @@ def test_sender_side_partition_scatter_sum(n, dim, shards, dist):
   np.testing.assert_allclose(gs, exp, rtol=0, atol=TOL)
 
 
+# =============================================================================== admission + eviction
+def _filtered_cfg(dim, opt, default_thr, slot_thr=None, **kw):
+  return entry.make_table_config(
+      [entry.CombineAsSegment(dim, entry.ZerosInitializer(), opt)],
+      slot_occurrence_threshold_config=entry.SlotOccurrenceThresholdConfig(default_thr, slot_thr or {}),
+      **kw)
+
+
+def test_hash_filter_golden_sequence():
+  """hash_table_ops_test.py:223-260: SGD lr 0.1, occurrence_threshold 3, ids [0, 0, 1], gradient -1
+  per occurrence, one optimizer step per occurrence: after each of four applies the rows are
+  [[0],[0]] -> [[.1],[0]] -> [[.3],[0]] -> [[.5],[.1]]."""
+  from monolith_amd.multi_hash_table_ops import HashFilter
+  flt = HashFilter(capacity=1000)
+  mt = MultiHashTable.from_configs({"t": _filtered_cfg(1, entry.SgdOptimizer(0.1), 3)},
+                                   name_suffix=_name(), hash_filter=flt)
+  expected = [[[0], [0]], [[0.1], [0]], [[0.3], [0]], [[0.5], [0.1]]]
+  for i in range(4):
+    mt.apply_gradients({"t": (ids_t([0, 0, 1]), val_t([[-1], [-1], [-1]]))})
+    got = mt.lookup({"t": ids_t([0, 1])})["t"].cpu().numpy()
+    np.testing.assert_allclose(got, np.array(expected[i], np.float32), rtol=0, atol=1e-7)
+  # id 0 stopped consulting the filter once it was in the table (4 consultations), id 1 asked 4 times
+  np.testing.assert_array_equal(flt.get(ids_t([0, 1, 2])).cpu().numpy(), [4, 4, 0])
+  assert mt.size("t") == 2
+
+
+def test_hash_filter_modes_thresholds_and_saturation():
+  """(a) enable_dedup semantics (MHTE_SUM_DUPLICATES): one consultation with the occurrence count
+  (tf_bridge.cc:300-310); (b) per-slot thresholds, <= 0 admits at once (hash_filter.h:158-165);
+  (c) the multi-table AssignAdd consults the filter WITHOUT the Contains guard (:230-232);
+  (d) counts saturate at 15 (filter.h:56-57)."""
+  from monolith_amd.multi_hash_table_ops import HashFilter
+  flt = HashFilter(capacity=1000)
+  cfg = _filtered_cfg(2, entry.SgdOptimizer(1.0), 4, {7: 2, 9: 0})
+  mt = MultiHashTable.from_configs({"t": cfg}, name_suffix=_name(), hash_filter=flt)
+  a, b, c = 5, (7 << 48) | 5, (9 << 48) | 5
+  ids = ids_t([a, b, c, a, b, a])                # a x3 (thr 4), b x2 (thr 2), c x1 (thr 0)
+  g = val_t(np.ones((6, 2), np.float32))
+  lrs = np.array([1.0], np.float32)
+  # (a) dedup: a seen 0 < 4 -> dropped (count 3); b seen 0 < 2 -> dropped (count 2); c admitted
+  mt.table_optimize_n("t", ids, None, g, lrs, 100, flags=_lib.MHTE_SUM_DUPLICATES)
+  assert mt.contains("t", ids_t([a, b, c])).cpu().tolist() == [False, False, True]
+  np.testing.assert_array_equal(flt.get(ids_t([a, b, c])).cpu().numpy(), [3, 2, 0])
+  # again: a seen 3 < 4 -> dropped (count 6); b seen 2 >= 2 -> admitted with the summed gradient
+  mt.table_optimize_n("t", ids, None, g, lrs, 101, flags=_lib.MHTE_SUM_DUPLICATES)
+  assert mt.contains("t", ids_t([a, b, c])).cpu().tolist() == [False, True, True]
+  np.testing.assert_array_equal(mt.lookup({"t": ids_t([b, c])})["t"].cpu().numpy(),
+                                [[-2, -2], [-2, -2]])
+  # third time: a seen 6 >= 4 -> admitted
+  mt.table_optimize_n("t", ids, None, g, lrs, 102, flags=_lib.MHTE_SUM_DUPLICATES)
+  np.testing.assert_array_equal(mt.lookup({"t": ids_t([a])})["t"].cpu().numpy(), [[-3, -3]])
+  np.testing.assert_array_equal(flt.get(ids_t([a])).cpu().numpy(), [9])
+  # (c) AssignAdd: a is in the table but keeps asking the filter; a fresh id x: seen 0,1,2,3 dropped
+  x = 77
+  for k in range(5):
+    mt.assign_add({"t": (ids_t([x]), val_t([[1.0, 1.0]]))})
+    assert mt.contains("t", ids_t([x])).cpu().tolist() == [k >= 4]
+  # (d) saturation
+  for _ in range(20):
+    mt.assign_add({"t": (ids_t([x]), val_t([[0.0, 0.0]]))})
+  np.testing.assert_array_equal(flt.get(ids_t([x])).cpu().numpy(), [15])
+
+
+def test_pipelined_step_with_hash_filter_matches_model():
+  """The training step consults the filter once per distinct id with its occurrence count (the
+  step sums duplicates first = enable_dedup).  Against a host model: dict of saturating counts +
+  oracle table that only sees the admitted ids."""
+  from monolith_amd.multi_hash_table_ops import HashFilter
+  n, dim, steps, thr = 8000, 8, 6, 3
+  flt = HashFilter(capacity=200000)
+  mt = MultiHashTable.from_configs({"emb": _filtered_cfg(dim, entry.AdagradOptimizer(0.05, 0.1), thr)},
+                                   name_suffix=_name(), hash_filter=flt)
+  ot = O.Table(O.segment(dim, O.OPT_ADAGRAD, p=(0.1, 0.0)), 1)
+  batches = [S.id_batch(300 + s_, n, 3000, "zipf") for s_ in range(steps + 1)]
+  dev = [ids_t(b) for b in batches]
+  step = SparseStep(mt, "emb", n, exact_order=True)
+  seen, present = {}, set()
+  for s_ in range(steps):
+    g = S.grad_batch(s_, n, dim)
+    emb = step.forward(dev[s_], next_ids=dev[s_ + 1])
+    np.testing.assert_array_equal(emb.cpu().numpy(), ot.lookup(batches[s_])[0])
+    step.backward(val_t(g), S.update_time(s_))
+    uk, _, vo, vos, _ = O.unique_key_with_value_and_offset(batches[s_], [0, n], [dim])
+    gu = O.fill_with_offset_map_gradient(np.arange(uk.size), [0, uk.size], g.ravel(), vo, vos,
+                                         [dim]).reshape(-1, dim)
+    cnt = dict(zip(*np.unique(batches[s_], return_counts=True)))
+    keep = []
+    for k_, i in enumerate(uk.tolist()):
+      if i in present:
+        keep.append(k_)
+        continue
+      c0 = seen.get(i, 0)
+      seen[i] = min(15, c0 + min(15, int(cnt[i])))
+      if c0 >= thr:
+        keep.append(k_)
+        present.add(i)
+    ot.optimize(uk[keep], gu[keep], [0.05], S.update_time(s_))
+  probe = np.unique(np.concatenate(batches[:steps]))
+  np.testing.assert_array_equal(mt.lookup({"emb": ids_t(probe)})["emb"].cpu().numpy(),
+                                ot.lookup(probe)[0])
+  assert mt.size("emb") == len(present) == ot.size() and 0 < len(present) < probe.size
+  np.testing.assert_array_equal(flt.get(ids_t(probe)).cpu().numpy(),
+                                [seen.get(int(i), 0) for i in probe])
+
+
+def test_feature_eviction_cadence_and_ttl():
+  """tf_bridge.cc:73-104 + cuckoo_embedding_hash_table.cc:251-264: every feature_evict_every_n_hours
+  the table drops rows with max_update_time - ts >= ttl(slot) days; the check rides on the update
+  calls.  TTL values of embedding_hash_table_test.h:282-326."""
+  day = 86400
+  ttl = entry.SlotExpireTimeConfig(default_expire_time=14, slot_expire_times={1: 5, 2: 6})
+  cfg = entry.make_table_config(
+      [entry.CombineAsSegment(1, entry.ZerosInitializer(), entry.SgdOptimizer(1.0))],
+      entry.CuckooHashTableConfig(feature_evict_every_n_hours=2), slot_expire_time_config=ttl)
+  mt = make({"t": cfg})
+  clock = [1000.0]
+  mt._evict_clock = lambda: clock[0]  # pylint: disable=protected-access
+  mt._last_evict = {"t": 1000.0}  # pylint: disable=protected-access
+  mt._last_evict_check = 1000.0  # pylint: disable=protected-access
+  t0 = 1_600_000_000
+  fids = [(1 << 48) | 123, (2 << 48) | 456, 789]
+  mt.assign_add({"t": (ids_t(fids), val_t([[1.0], [2.0], [3.0]]))}, req_time=t0)
+  g = val_t([[0.0]])
+  clock[0] += 3600           # one hour: nothing is due
+  mt.apply_gradients({"t": (ids_t([55]), g)}, req_time=t0 + 5 * day + 60)
+  assert mt.size("t") == 4
+  clock[0] += 3600 + 11      # two hours passed: the scan runs on the next update call
+  mt.apply_gradients({"t": (ids_t([55]), g)}, req_time=t0 + 5 * day + 61)
+  assert mt.contains("t", ids_t(fids + [55])).cpu().tolist() == [False, True, True, True]
+  assert mt.stats("t").evicted == 1
+
+
 # =============================================================================== checkpoints
 def test_save_restore_reference_scenario(tmp_path):
   """multi_hash_table_ops_test.py:129-170: save {slot0, slot1, slot2}, restore into
