@@ -731,34 +731,46 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
     const uint32_t E = sh_rstart[64];
     Vec<VEC> acc;
     vec_zero(acc);
+    // this group's windows: qb = (grp + k * NG) * WIN.  The positions of kPre windows are fetched
+    // together (one round trip), then each window's WIN gradient rows
+    constexpr int kPre = 4;
 #pragma unroll 1
-    for (uint32_t qb = uint32_t(grp) * WIN; qb < E; qb += NG * WIN) {  // this group's windows
-      uint32_t p = 0;
-      if (j < WIN && qb + j < E) {
-        const uint32_t q = qb + j;
-        uint32_t lo = 0, hi = 63;  // run r with rstart[r] <= q < rstart[r+1]
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi + 1) >> 1;
-          if (sh_rstart[mid] <= q) lo = mid; else hi = mid - 1;
+    for (uint32_t qb0 = uint32_t(grp) * WIN; qb0 < E; qb0 += kPre * NG * WIN) {
+      uint32_t pp[kPre];
+#pragma unroll
+      for (int w2 = 0; w2 < kPre; ++w2) {
+        const uint32_t q = qb0 + uint32_t(w2) * (NG * WIN) + uint32_t(j);
+        pp[w2] = 0;
+        if (j < WIN && q < E) {
+          uint32_t lo = 0, hi = 63;  // run r with rstart[r] <= q < rstart[r+1]
+          while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (sh_rstart[mid] <= q) lo = mid; else hi = mid - 1;
+          }
+          const uint32_t val = sh_rval[lo];
+          const uint32_t i = q - sh_rstart[lo];
+          const uint32_t b = b0 + lo;
+          pp[w2] = b * kRdBlock + ((run_cnt(val) == 1) ? run_first(val)
+                                                       : uint32_t(d.seg[b * kRdBlock + run_off(val) + i]));
         }
-        const uint32_t val = sh_rval[lo];
-        const uint32_t i = q - sh_rstart[lo];
-        const uint32_t b = b0 + lo;
-        p = b * kRdBlock + ((run_cnt(val) == 1) ? run_first(val)
-                                                 : uint32_t(d.seg[b * kRdBlock + run_off(val) + i]));
-      }
-      // round trip 3: WIN gradient rows in flight
-      Vec<VEC> v[WIN];
-#pragma unroll
-      for (int t = 0; t < WIN; ++t) vec_zero(v[t]);
-#pragma unroll
-      for (int t = 0; t < WIN; ++t) {
-        const uint32_t pt = __shfl(p, gbase + t);
-        if (qb + t < E && ev) v[t].load(c.grads + int64_t(pt) * dim + e);
       }
 #pragma unroll
-      for (int t = 0; t < WIN; ++t)
-        if (qb + t < E && ev) vec_add(acc, v[t]);
+      for (int w2 = 0; w2 < kPre; ++w2) {
+        const uint32_t qb = qb0 + uint32_t(w2) * (NG * WIN);
+        if (qb >= E) break;  // group-uniform
+        // WIN gradient rows in flight
+        Vec<VEC> v[WIN];
+#pragma unroll
+        for (int t = 0; t < WIN; ++t) vec_zero(v[t]);
+#pragma unroll
+        for (int t = 0; t < WIN; ++t) {
+          const uint32_t pt = __shfl(pp[w2], gbase + t);
+          if (qb + t < E && ev) v[t].load(c.grads + int64_t(pt) * dim + e);
+        }
+#pragma unroll
+        for (int t = 0; t < WIN; ++t)
+          if (qb + t < E && ev) vec_add(acc, v[t]);
+      }
     }
 #pragma unroll
     for (int cc = 0; cc < VEC; ++cc) sh_sum[grp][j * VEC + cc] = acc.v[cc];
