@@ -1032,6 +1032,49 @@ def test_restore_reads_a_foreign_writer_and_save_expires_rows(tmp_path):
 
 
 # =============================================================================== full-size properties
+@pytest.mark.parametrize("dim,opt,universe", [(64, "adagrad", 10**9), (32, "sgd", 10**8)])
+def test_full_batch_pipelined_step_configs(dim, opt, universe):
+  """BASELINE.json configs[2] (1B ids, dim 64, fused Adagrad) and configs[1] (100M ids, dim 32,
+  SGD) at the full batch of 65 536 Zipf(1.2) ids through the pipelined two-launch step (the bench
+  path): forward rows, unique counts, final rows and table size against the oracle (1e-5; lists of
+  <= 32 occurrences bit-exact), and a second run is bit-identical."""
+  B, steps = 65536, 3
+  batches = [S.id_batch(s_, B, universe, "zipf") for s_ in range(steps + 1)]
+  dev = [ids_t(b) for b in batches]
+  lr = 0.001 if opt == "adagrad" else 0.01
+  def cfg():
+    return {"emb": (adagrad_cfg(dim, lr, 0.1, reserve_rows=1 << 20, initial_capacity=1 << 21)
+                    if opt == "adagrad" else
+                    sgd_cfg(dim, lr, reserve_rows=1 << 20, initial_capacity=1 << 21))}
+  ot = O.Table(O.segment(dim, O.OPT_ADAGRAD if opt == "adagrad" else O.OPT_SGD, p=(0.1, 0.0)), 1)
+  runs = []
+  for rep in range(2):
+    mt = make(cfg())
+    step = SparseStep(mt, "emb", B)
+    for s_ in range(steps):
+      g = S.grad_batch(s_, B, dim)
+      emb = step.forward(dev[s_], next_ids=dev[s_ + 1])
+      if rep == 0:
+        np.testing.assert_allclose(emb.cpu().numpy(), ot.lookup(batches[s_])[0], rtol=0, atol=TOL)
+      step.backward(val_t(g), S.update_time(s_))
+      if rep == 0:
+        uk = _oracle_step(ot, batches[s_], g, dim, lr, S.update_time(s_))
+        assert step.n_unique() == uk.size
+    probe = np.unique(np.concatenate(batches[:steps]))
+    runs.append(mt.lookup({"emb": ids_t(probe)})["emb"].cpu().numpy())
+    assert mt.size("emb") == probe.size == ot.size()
+  exp = ot.lookup(probe)[0]
+  np.testing.assert_allclose(runs[0], exp, rtol=0, atol=TOL)
+  np.testing.assert_array_equal(runs[0], runs[1])
+  cnt_max = {}
+  for b in batches[:steps]:
+    u, c = np.unique(b, return_counts=True)
+    for k_, v in zip(u.tolist(), c.tolist()):
+      cnt_max[k_] = max(cnt_max.get(k_, 0), v)
+  light = np.array([cnt_max[k_] <= 32 for k_ in probe.tolist()])
+  np.testing.assert_array_equal(runs[0][light], exp[light])
+
+
 def test_full_batch_zipf_step_properties_d64_adagrad():
   """BASELINE.json configs[2] shape: dim 64, Adagrad, Zipf(1.2) over 1e9 ids, batch 65536."""
   B, D_ = 65536, 64
