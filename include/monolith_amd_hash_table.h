@@ -192,6 +192,30 @@ mhte_status mhte_table_dump(mhte_multi_table* t, int32_t table, int64_t cap, int
                             void* stream);
 int32_t mhte_table_row_floats(const mhte_multi_table* t, int32_t i);
 
+/* ---- the step right after the exchange: gather per merged slot, its gradient, ragged reductions --
+ * MonolithFusedGatherEmbeddingsByInput (+Gradient) (RT/ops/map_id_to_embedding.cu.cc:31-118,
+ * NT/distribution_ops.py:671-686): outputs[i][j, :] = fused_embeddings[offsets[i][j] + 0 .. dims[i]);
+ * gradient: fused_grad (zero-filled, fused_len floats) += grads[i][j, :] * scale at the same offsets
+ * (float atomics, as the reference's GpuAtomicAdd).  offsets / outputs / grads: HOST arrays of
+ * n_inputs device pointers; n, dims: host arrays.
+ * MonolithReduceSum / ReduceMean / ReduceSquareNorm (RT/ops/reduce_op.cc:29-125,
+ * NT/embedding_combiners.py:41-102): out[b, :] over the rows i with indices[i] == b; mode 0 sum,
+ * 1 mean, 2 sqrt of the sum of squares.  indices_sorted != 0 (the layout sparse/ragged inputs
+ * have): sequential in-order accumulation, bit-identical to the reference; otherwise atomics. */
+mhte_status mhte_fused_gather_embeddings_by_input(const float* fused_embeddings, int32_t n_inputs,
+                                                  const int32_t* const* offsets, const int64_t* n,
+                                                  const int32_t* dims, float* const* outputs,
+                                                  void* stream);
+mhte_status mhte_fused_gather_embeddings_by_input_gradient(float* fused_grad, int64_t fused_len,
+                                                           int32_t n_inputs,
+                                                           const float* const* grads,
+                                                           const int32_t* const* offsets,
+                                                           const int64_t* n, const int32_t* dims,
+                                                           float scale, void* stream);
+mhte_status mhte_reduce_rows(const int64_t* indices, const float* values, int64_t n, int32_t dim,
+                             int64_t batch, int32_t mode, int32_t indices_sorted, float* out,
+                             void* stream);
+
 /* Admission filter (RT/hash_filter/hash_filter.h:33-214, the `filter_handle` input of
  * CreateMonolithMultiHashTable, RT/ops/multi_hash_table_op.cc:104-112): a counting filter with 4-bit
  * saturating counts shared by the tables of a MultiHashTable.  While attached, Optimize / Assign

@@ -25,6 +25,7 @@
 #include <unistd.h>
 
 #include "mhte_ckpt.h"
+#include "mhte_pool_kernels.h"
 #include "mhte_step_kernels.h"
 
 namespace mhte {
@@ -1368,6 +1369,91 @@ mhte_status mhte_table_dump(mhte_multi_table* t, int32_t table, int64_t cap, int
     dump_emit_kernel<<<nblocks, 256, 0, st>>>(tb.view, uint64_t(0), nslots, bo.p, ids, positions, ts, rows);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(st));
+  });
+}
+
+// ---- post-exchange gather + pooling -------------------------------------------------------------
+extern "C++" {
+namespace mhte {
+template <bool GATHER>
+static void fused_gather(float* fused, int32_t n_inputs, const int32_t* const* offsets,
+                         const int64_t* n, const int32_t* dims, float* const* rows, float scale,
+                         hipStream_t st) {
+  if (n_inputs < 0) throw Error(MHTE_INVALID_ARGUMENT, "n_inputs must be >= 0");
+  for (int32_t i0 = 0; i0 < n_inputs; i0 += kMaxGatherInputs) {
+    GatherInputs in{};
+    in.n_inputs = std::min<int32_t>(kMaxGatherInputs, n_inputs - i0);
+    int64_t acc = 0;
+    for (int32_t k = 0; k < in.n_inputs; ++k) {
+      if (n[i0 + k] < 0 || dims[i0 + k] <= 0)
+        throw Error(MHTE_INVALID_ARGUMENT, "fused gather: bad size or dim of input " + std::to_string(i0 + k));
+      in.offsets[k] = offsets[i0 + k];
+      in.rows[k] = rows[i0 + k];
+      in.dim[k] = dims[i0 + k];
+      in.start[k] = acc;
+      acc += n[i0 + k];
+    }
+    in.start[in.n_inputs] = acc;
+    if (acc == 0) continue;
+    const dim3 grid(uint32_t((acc * 8 + 255) / 256));
+    fused_gather_kernel<GATHER><<<grid, 256, 0, st>>>(fused, in, scale);
+    HIP_OK(hipGetLastError());
+  }
+}
+}  // namespace mhte
+}  // extern "C++"
+
+mhte_status mhte_fused_gather_embeddings_by_input(const float* fused_embeddings, int32_t n_inputs,
+                                                  const int32_t* const* offsets, const int64_t* n,
+                                                  const int32_t* dims, float* const* outputs,
+                                                  void* stream) {
+  return guard([&] {
+    fused_gather<true>(const_cast<float*>(fused_embeddings), n_inputs, offsets, n, dims, outputs, 1.f,
+                       S(stream));
+  });
+}
+
+mhte_status mhte_fused_gather_embeddings_by_input_gradient(float* fused_grad, int64_t fused_len,
+                                                           int32_t n_inputs,
+                                                           const float* const* grads,
+                                                           const int32_t* const* offsets,
+                                                           const int64_t* n, const int32_t* dims,
+                                                           float scale, void* stream) {
+  return guard([&] {
+    if (fused_len < 0) throw Error(MHTE_INVALID_ARGUMENT, "fused_len must be >= 0");
+    if (fused_len) HIP_OK(hipMemsetAsync(fused_grad, 0, size_t(fused_len) * sizeof(float), S(stream)));
+    fused_gather<false>(fused_grad, n_inputs, offsets, n, dims, const_cast<float* const*>(grads),
+                        scale, S(stream));
+  });
+}
+
+mhte_status mhte_reduce_rows(const int64_t* indices, const float* values, int64_t n, int32_t dim,
+                             int64_t batch, int32_t mode, int32_t indices_sorted, float* out,
+                             void* stream) {
+  return guard([&] {
+    if (dim <= 0 || batch < 0 || n < 0 || mode < 0 || mode > 2)
+      throw Error(MHTE_INVALID_ARGUMENT, "reduce_rows: bad argument");
+    if (batch == 0) return;
+    hipStream_t st = S(stream);
+    if (indices_sorted) {
+      reduce_rows_sorted_kernel<<<dim3(uint32_t((batch * 16 + 255) / 256)), 256, 0, st>>>(
+          indices, values, n, dim, batch, mode, out);
+    } else {
+      HIP_OK(hipMemsetAsync(out, 0, size_t(batch) * dim * sizeof(float), st));
+      uint32_t* cnt = nullptr;
+      if (mode == 1) {
+        HIP_OK(hipMallocAsync(reinterpret_cast<void**>(&cnt), size_t(batch) * 4, st));
+        HIP_OK(hipMemsetAsync(cnt, 0, size_t(batch) * 4, st));
+      }
+      if (n)
+        reduce_rows_atomic_kernel<<<dim3(uint32_t((n * 16 + 255) / 256)), 256, 0, st>>>(
+            indices, values, n, dim, mode, out, cnt);
+      if (mode != 0)
+        reduce_rows_finish_kernel<<<dim3(uint32_t((batch * dim + 255) / 256)), 256, 0, st>>>(
+            out, cnt, batch, dim, mode);
+      if (cnt) HIP_OK(hipFreeAsync(cnt, st));
+    }
+    HIP_OK(hipGetLastError());
   });
 }
 

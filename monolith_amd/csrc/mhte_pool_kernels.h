@@ -1,0 +1,120 @@
+// The step right after the embedding exchange: gathering rows of the fused
+// embedding buffer per merged slot, its gradient, and the ragged reductions of the combiners.
+// Reference: runtime/ops/map_id_to_embedding.cu.cc:31-118 (FusedGatherEmbeddingsByInput and its
+// gradient, CUDA kernels), runtime/ops/reduce_op.cc:29-125 (ReduceSum / ReduceMean /
+// ReduceSquareNorm), native_training/embedding_combiners.py:41-102.  Included by mhte.hip.
+//
+// All three are HBM-streaming copy/add work: one group of lanes per output row moving float4s.
+#ifndef MHTE_POOL_KERNELS_H_
+#define MHTE_POOL_KERNELS_H_
+
+#include "mhte_kernels.h"
+
+namespace mhte {
+
+constexpr int kMaxGatherInputs = 32;  // inputs per launch (more: several launches)
+
+struct GatherInputs {
+  const int32_t* offsets[kMaxGatherInputs];  // [n_i] float offset of row j in the fused buffer
+  float* rows[kMaxGatherInputs];             // [n_i, dim_i] output (gather) / gradient (scatter)
+  int64_t start[kMaxGatherInputs + 1];       // row-index prefix over the inputs
+  int32_t dim[kMaxGatherInputs];
+  int32_t n_inputs;
+};
+
+// MonolithFusedGatherEmbeddingsByInput: outputs[i][j, :] = fused[offsets[i][j] + 0 .. dim_i)
+// (map_id_to_embedding.cu.cc:31-72).  One thread per element would re-read the offset dim times;
+// here a lane group takes one row.  GATHER = false: the gradient,
+// fused_grad[offsets[i][j] + k] += grads[i][j, k] * scale (:74-118) — float atomics, like the
+// reference's GpuAtomicAdd (rows that share an offset are added in arrival order).
+template <bool GATHER>
+__global__ __launch_bounds__(256) void fused_gather_kernel(float* __restrict__ fused, GatherInputs in,
+                                                           float scale) {
+  constexpr int G = 8;
+  const int j = threadIdx.x & (G - 1);
+  const int64_t r = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  if (r >= in.start[in.n_inputs]) return;
+  int i = 0;
+  while (in.start[i + 1] <= r) ++i;  // n_inputs < 100: linear search, as the reference does
+  const int64_t local = r - in.start[i];
+  const int32_t dim = in.dim[i];
+  const int64_t off = in.offsets[i][local];
+  float* row = in.rows[i] + local * dim;
+  for (int k = j; k < dim; k += G) {
+    if (GATHER) {
+      row[k] = fused[off + k];
+    } else {
+      atomicAdd(&fused[off + k], row[k] * scale);
+    }
+  }
+}
+
+// ReduceSum / ReduceMean / ReduceSquareNorm over sorted row indices (reduce_op.cc:29-125):
+// out[b, :] = reduce over {i : indices[i] == b} of values[i, :], IN ORDER of i — the reference's
+// sequential accumulation, bit for bit.  One lane group per output row; its segment is found by
+// binary search.  mode 0 sum, 1 mean (sum * (1 / count), count 0 -> the reference's 0 * inf),
+// 2 square norm (sqrt of the sum of squares).
+__global__ __launch_bounds__(256) void reduce_rows_sorted_kernel(const int64_t* __restrict__ indices,
+                                                                 const float* __restrict__ values,
+                                                                 int64_t n, int32_t dim,
+                                                                 int64_t batch, int32_t mode,
+                                                                 float* __restrict__ out) {
+  constexpr int G = 16;
+  const int j = threadIdx.x & (G - 1);
+  const int64_t b = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  if (b >= batch) return;
+  int64_t lo = 0, hi = n;  // first i with indices[i] >= b
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (indices[mid] < b) lo = mid + 1; else hi = mid;
+  }
+  const int64_t s0 = lo;
+  hi = n;                  // first i with indices[i] > b
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (indices[mid] <= b) lo = mid + 1; else hi = mid;
+  }
+  const int64_t s1 = lo;
+  const float mult = 1.0f / static_cast<float>(s1 - s0);
+  for (int k = j; k < dim; k += G) {
+    float acc = 0.f;
+    for (int64_t i = s0; i < s1; ++i) {
+      const float v = values[i * dim + k];
+      acc = acc + (mode == 2 ? v * v : v);
+    }
+    if (mode == 1) acc = acc * mult;
+    if (mode == 2) acc = sqrtf(acc);
+    out[b * int64_t(dim) + k] = acc;
+  }
+}
+
+// The same for indices in any order: atomics (sums of equal rows in arrival order), then a
+// finishing pass for mean / square norm.
+__global__ __launch_bounds__(256) void reduce_rows_atomic_kernel(const int64_t* __restrict__ indices,
+                                                                 const float* __restrict__ values,
+                                                                 int64_t n, int32_t dim, int32_t mode,
+                                                                 float* __restrict__ out,
+                                                                 uint32_t* __restrict__ count) {
+  constexpr int G = 16;
+  const int j = threadIdx.x & (G - 1);
+  const int64_t i = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  if (i >= n) return;
+  const int64_t b = indices[i];
+  if (j == 0 && mode == 1) atomicAdd(&count[b], 1u);
+  for (int k = j; k < dim; k += G) {
+    const float v = values[i * dim + k];
+    atomicAdd(&out[b * int64_t(dim) + k], mode == 2 ? v * v : v);
+  }
+}
+__global__ __launch_bounds__(256) void reduce_rows_finish_kernel(float* __restrict__ out,
+                                                                 const uint32_t* __restrict__ count,
+                                                                 int64_t batch, int32_t dim,
+                                                                 int32_t mode) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= batch * dim) return;
+  if (mode == 1) out[t] = out[t] * (1.0f / static_cast<float>(count[t / dim]));
+  if (mode == 2) out[t] = sqrtf(out[t]);
+}
+
+}  // namespace mhte
+#endif  // MHTE_POOL_KERNELS_H_

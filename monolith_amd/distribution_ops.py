@@ -244,3 +244,74 @@ def fill_with_offset_map_gradient(pos: Ragged, grad: torch.Tensor, grad_offset_m
                                                  C.c_int32(vec), vp(out[ooff:]), _stream()))
     ooff += (hi - lo) * dims[t]
   return out
+
+
+# ---------------------------------------------------------------------------------------------
+# the step right after the exchange (reference distribution_ops.py:671-760, embedding_combiners.py)
+# ---------------------------------------------------------------------------------------------
+def _ptr_array(tensors):
+  arr = (C.c_void_p * len(tensors))(*[C.c_void_p(t.data_ptr()) for t in tensors])
+  return arr
+
+
+def fused_gather_embeddings_by_input(fused_embeddings: torch.Tensor,
+                                     fused_embedding_offsets: List[torch.Tensor],
+                                     embedding_dims: List[int]) -> List[torch.Tensor]:
+  """distribution_ops.fused_gather_embeddings_by_input (reference :671-675): for every merged slot i,
+  rows of ``embedding_dims[i]`` floats gathered from the flat fused buffer at the given offsets."""
+  assert fused_embeddings.is_cuda and fused_embeddings.dtype == torch.float32
+  offs = [o.to(device=fused_embeddings.device, dtype=torch.int32).contiguous()
+          for o in fused_embedding_offsets]
+  outs = [torch.empty((o.numel(), d), dtype=torch.float32, device=fused_embeddings.device)
+          for o, d in zip(offs, embedding_dims)]
+  n = (C.c_int64 * len(offs))(*[o.numel() for o in offs])
+  dims = (C.c_int32 * len(offs))(*[int(d) for d in embedding_dims])
+  check(_lib.lib().mhte_fused_gather_embeddings_by_input(vp(fused_embeddings.contiguous()),
+                                                         C.c_int32(len(offs)), _ptr_array(offs), n,
+                                                         dims, _ptr_array(outs), _stream()))
+  return outs
+
+
+def fused_gather_embeddings_by_input_gradient(fused_embeddings_size: int, grads: List[torch.Tensor],
+                                              embedding_offsets: List[torch.Tensor],
+                                              embedding_dims: List[int], scale: float = 1.0):
+  """reference :678-686: the flat gradient of the fused buffer (float atomics, like the reference)."""
+  dev = grads[0].device
+  offs = [o.to(device=dev, dtype=torch.int32).contiguous() for o in embedding_offsets]
+  gs = [g.to(device=dev, dtype=torch.float32).contiguous() for g in grads]
+  out = torch.empty(int(fused_embeddings_size), dtype=torch.float32, device=dev)
+  n = (C.c_int64 * len(offs))(*[o.numel() for o in offs])
+  dims = (C.c_int32 * len(offs))(*[int(d) for d in embedding_dims])
+  check(_lib.lib().mhte_fused_gather_embeddings_by_input_gradient(
+      vp(out), C.c_int64(out.numel()), C.c_int32(len(offs)), _ptr_array(gs), _ptr_array(offs), n,
+      dims, C.c_float(float(scale)), _stream()))
+  return out
+
+
+def _reduce(id_indices, id_values, id_length, mode, indices_sorted):
+  idx = id_indices.reshape(-1).to(dtype=torch.int64).contiguous()
+  vals = id_values.to(dtype=torch.float32).contiguous()
+  assert vals.is_cuda and idx.is_cuda and vals.dim() == 2 and idx.numel() == vals.shape[0]
+  batch = int(id_length[0]) if not isinstance(id_length, int) else id_length
+  out = torch.empty((batch, vals.shape[1]), dtype=torch.float32, device=vals.device)
+  check(_lib.lib().mhte_reduce_rows(vp(idx), vp(vals), C.c_int64(idx.numel()),
+                                    C.c_int32(vals.shape[1]), C.c_int64(batch), C.c_int32(mode),
+                                    C.c_int32(1 if indices_sorted else 0), vp(out), _stream()))
+  return out
+
+
+def reduce_sum(id_indices, id_values, id_length, indices_sorted: bool = True):
+  """distribution_ops.reduce_sum (reduce_op.cc:29-51).  ``indices_sorted``: row indices ascend, as
+  a sparse / ragged input's do — sequential, bit-identical accumulation."""
+  return _reduce(id_indices, id_values, id_length, 0, indices_sorted)
+
+
+def reduce_mean(id_indices, id_values, id_length, indices_sorted: bool = True):
+  """distribution_ops.reduce_mean (reduce_op.cc:55-87)."""
+  return _reduce(id_indices, id_values, id_length, 1, indices_sorted)
+
+
+def reduce_sqrtn(id_indices, id_values, id_length, indices_sorted: bool = True):
+  """distribution_ops.reduce_sqrtn (ReduceSquareNorm, reduce_op.cc:91-125): sqrt of the sum of
+  squares."""
+  return _reduce(id_indices, id_values, id_length, 2, indices_sorted)

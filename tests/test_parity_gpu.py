@@ -756,6 +756,76 @@ def test_sender_side_partition_scatter_sum(n, dim, shards, dist):
   np.testing.assert_allclose(gs, exp, rtol=0, atol=TOL)
 
 
+# =============================================================================== gather + pooling
+def test_fused_gather_embeddings_by_input_golden():
+  """distribution_ops_test.py:221-249 (forward, with its 12345x / 11777x tiling) and :251-304
+  (gradient, 888x tiling, rtol 1e-7 * 888)."""
+  fused = val_t([1.1, 1.2, 1.3, 2.1, 2.2, 3.1, 3.2, 3.3, 4.1, 4.2, 4.3, 5.1, 5.2, 6.1, 6.2, 6.3,
+                 7.1, 7.2, 8.1, 8.2, 9.1, 9.2])
+  scale = (12345, 11777)
+  offs = [torch.tensor([13, 0, 5, 13, 8, 13] * scale[0], dtype=torch.int32).cuda(),
+          torch.tensor([16, 18, 11, 11, 16, 20, 3] * scale[1], dtype=torch.int32).cuda()]
+  outs = D.fused_gather_embeddings_by_input(fused, offs, [3, 2])
+  exp0 = np.array([[6.1, 6.2, 6.3], [1.1, 1.2, 1.3], [3.1, 3.2, 3.3], [6.1, 6.2, 6.3],
+                   [4.1, 4.2, 4.3], [6.1, 6.2, 6.3]] * scale[0], np.float32)
+  exp1 = np.array([[7.1, 7.2], [8.1, 8.2], [5.1, 5.2], [5.1, 5.2], [7.1, 7.2], [9.1, 9.2],
+                   [2.1, 2.2]] * scale[1], np.float32)
+  np.testing.assert_array_equal(outs[0].cpu().numpy(), exp0)
+  np.testing.assert_array_equal(outs[1].cpu().numpy(), exp1)
+  k = 888
+  grads = [val_t(np.array([[1.1, 1.2, 1.3], [2.1, 2.2, 2.3], [3.1, 3.2, 3.3], [4.1, 4.2, 4.3],
+                           [5.1, 5.2, 5.3], [6.1, 6.2, 6.3]] * k, np.float32)),
+           val_t(np.array([[1.4, 1.5], [2.4, 2.5], [3.4, 3.5], [4.4, 4.5], [5.4, 5.5], [6.4, 6.5],
+                           [7.4, 7.5]] * k, np.float32))]
+  eo = [torch.tensor([13, 0, 5, 13, 8, 13] * k, dtype=torch.int32).cuda(),
+        torch.tensor([16, 18, 11, 11, 16, 20, 3] * k, dtype=torch.int32).cuda()]
+  out = D.fused_gather_embeddings_by_input_gradient(22, grads, eo, [3, 2]).cpu().numpy()
+  exp = np.array([2.1, 2.2, 2.3, 7.4, 7.5, 3.1, 3.2, 3.3, 5.1, 5.2, 5.3, 7.8, 8.0, 11.3, 11.6, 11.9,
+                  6.8, 7.0, 2.4, 2.5, 6.4, 6.5]) * k
+  np.testing.assert_allclose(out, exp, rtol=1e-7 * k)
+  out2 = D.fused_gather_embeddings_by_input_gradient(22, grads, eo, [3, 2], scale=0.5).cpu().numpy()
+  np.testing.assert_allclose(out2, exp * 0.5, rtol=1e-7 * k)
+
+
+@pytest.mark.parametrize("sorted_", [True, False])
+def test_reduce_sum_mean_sqrtn(sorted_):
+  """distribution_ops_test.py:306-352 goldens, then a ragged batch against the reference's
+  sequential accumulation (reduce_op.cc:29-125): bit-exact with sorted indices, 1e-6 with the
+  atomic path."""
+  idx = torch.tensor([[0], [0], [1]], dtype=torch.int64).cuda()
+  np.testing.assert_array_equal(
+      D.reduce_mean(idx, val_t([[4, 4], [2, 2], [1, 1]]), [2], sorted_).cpu().numpy(), [[3, 3], [1, 1]])
+  np.testing.assert_array_equal(
+      D.reduce_sum(idx, val_t([[1, 1], [2, 2], [4, 4]]), [2], sorted_).cpu().numpy(), [[3, 3], [4, 4]])
+  np.testing.assert_allclose(
+      D.reduce_sqrtn(idx, val_t([[3, 3], [4, 4], [2, 2]]), [2], sorted_).cpu().numpy(), [[5, 5], [2, 2]])
+  rng = np.random.default_rng(9)
+  batch, dim = 500, 24
+  lens = rng.integers(0, 9, batch)
+  lens[7] = 0
+  ind = np.repeat(np.arange(batch), lens)
+  vals = rng.standard_normal((ind.size, dim)).astype(np.float32)
+  if not sorted_:
+    perm = rng.permutation(ind.size)
+    ind, vals = ind[perm], vals[perm]
+  for mode, fn in ((0, D.reduce_sum), (1, D.reduce_mean), (2, D.reduce_sqrtn)):
+    exp = np.zeros((batch, dim), np.float32)
+    cnt = np.zeros(batch, np.int64)
+    for i, b in enumerate(ind):
+      exp[b] = exp[b] + (vals[i] * vals[i] if mode == 2 else vals[i])
+      cnt[b] += 1
+    with np.errstate(divide="ignore", invalid="ignore"):
+      if mode == 1:
+        exp = exp * (np.float32(1.0) / cnt.astype(np.float32))[:, None]
+      if mode == 2:
+        exp = np.sqrt(exp)
+    got = fn(torch.from_numpy(ind[:, None]).cuda(), val_t(vals), [batch], sorted_).cpu().numpy()
+    if sorted_:
+      np.testing.assert_array_equal(got, exp)        # incl. the NaN row of an empty mean
+    else:
+      np.testing.assert_allclose(got, exp, rtol=1e-5, atol=1e-6)
+
+
 # =============================================================================== admission + eviction
 def _filtered_cfg(dim, opt, default_thr, slot_thr=None, **kw):
   return entry.make_table_config(
