@@ -46,15 +46,27 @@ const char* mhte_last_error(void);
 int32_t mhte_abi_version(void);
 
 /* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
-enum { MHTE_OPT_SGD = 0, MHTE_OPT_ADAGRAD = 1, MHTE_OPT_FTRL = 2 };       /* optimizer.proto:210-229 */
+enum {                                                                     /* optimizer.proto:210-229 */
+  MHTE_OPT_SGD = 0, MHTE_OPT_ADAGRAD = 1, MHTE_OPT_FTRL = 2,
+  /* the following run in the op-level kernels (mhte_optimize & co, mhte_table_optimize_n); a table
+     that uses one of them is not mhte_table_fused_backward_ok */
+  MHTE_OPT_MOMENTUM = 3, MHTE_OPT_ADADELTA = 4, MHTE_OPT_RMSPROP = 5, MHTE_OPT_RMSPROPV2 = 6,
+  MHTE_OPT_ADAM = 7, MHTE_OPT_AMSGRAD = 8
+};
 enum { MHTE_INIT_ZEROS = 0, MHTE_INIT_ONES = 1, MHTE_INIT_CONSTANT = 2 }; /* initializer_config.proto */
 
 /* EntryConfig.Segment (embedding_hash_table.proto:23-43) */
 typedef struct {
   int32_t dim_size;
   int32_t opt_type;     /* MHTE_OPT_* */
-  float opt_params[4];  /* ADAGRAD: {initial_accumulator_value, weight_decay_factor}
-                           FTRL:    {initial_accumulator_value, beta, l1, l2}        */
+  float opt_params[8];  /* ADAGRAD:  {initial_accumulator_value, weight_decay_factor}
+                           FTRL:     {initial_accumulator_value, beta, l1, l2}
+                           MOMENTUM: {momentum, weight_decay_factor, use_nesterov}
+                           ADADELTA: {averaging_ratio, epsilon, weight_decay_factor}
+                           RMSPROP / RMSPROPV2: {momentum, weight_decay_factor, learning_rate of the
+                                     config (v1 ignores the op's learning-rate input,
+                                     rmsprop_optimizer.cc:66)}
+                           ADAM / AMSGRAD: {beta1, beta2, epsilon, weight_decay_factor, use_nesterov} */
   int32_t init_type;    /* MHTE_INIT_* */
   float init_value;     /* ConstantsInitializerConfig.constant */
 } mhte_segment_config;

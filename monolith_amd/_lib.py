@@ -25,6 +25,7 @@ MHTE_DEFER_SLOWPATH = 2
 ABI_VERSION = 3            # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
+OPT_MOMENTUM, OPT_ADADELTA, OPT_RMSPROP, OPT_RMSPROPV2, OPT_ADAM, OPT_AMSGRAD = 3, 4, 5, 6, 7, 8
 INIT_ZEROS, INIT_ONES, INIT_CONSTANT = 0, 1, 2
 
 
@@ -46,7 +47,7 @@ class ResourceExhaustedError(MhteError):
 
 
 class SegmentConfig(C.Structure):
-  _fields_ = [("dim_size", C.c_int32), ("opt_type", C.c_int32), ("opt_params", C.c_float * 4),
+  _fields_ = [("dim_size", C.c_int32), ("opt_type", C.c_int32), ("opt_params", C.c_float * 8),
               ("init_type", C.c_int32), ("init_value", C.c_float)]
 
 

@@ -424,7 +424,7 @@ struct Table {
     dim = 0;
     for (auto& s : segs) {
       if (s.dim_size <= 0) throw Error(MHTE_INVALID_ARGUMENT, "segment dim_size must be > 0");
-      if (s.opt_type < MHTE_OPT_SGD || s.opt_type > MHTE_OPT_FTRL)
+      if (s.opt_type < MHTE_OPT_SGD || s.opt_type >= kOptCount)
         throw Error(MHTE_INVALID_ARGUMENT, "unknown optimizer type " + std::to_string(s.opt_type));
       if (s.init_type < MHTE_INIT_ZEROS || s.init_type > MHTE_INIT_CONSTANT)
         throw Error(MHTE_INVALID_ARGUMENT, "unknown initializer type");
@@ -439,12 +439,12 @@ struct Table {
       d.w_off = w;
       d.st_off = st;
       d.opt = segs[i].opt_type;
-      for (int k = 0; k < 4; ++k) d.p[k] = segs[i].opt_params[k];
+      for (int k = 0; k < 8; ++k) d.p[k] = segs[i].opt_params[k];
       d.init = segs[i].init_type;
       d.init_value = segs[i].init_value;
       if ((d.dim % 4) || (d.w_off % 4) || (d.st_off % 4)) vec_ok = false;
       w += d.dim;
-      st += (d.opt == kOptAdagrad ? d.dim : (d.opt == kOptFtrl ? 2 * d.dim : 0));
+      st += uint32_t(opt_state_floats(d.opt, d.dim));
     }
     row_floats = st;
     if (row_floats % 4) vec_ok = false;
@@ -710,6 +710,8 @@ struct Table {
   // duplicate-gradient sum + upsert + optimizer apply of the unique ids of ws's most recent
   // unique() in one launch (sum_apply_kernel); falls back to segment-sum + upsert for wide rows.
   bool fusable() const {
+    for (uint32_t i = 0; i < nseg; ++i)
+      if (view.seg[i].opt > kOptFtrl) return false;  // the step kernels take sgd / adagrad / ftrl
     Shape sh = pick_shape(dim, vec_ok);
     return dim <= uint32_t(sh.G * sh.VEC);
   }
@@ -1514,7 +1516,7 @@ static std::vector<ckpt::SegLayout> seg_layout(const Table& tb) {
     const SegDesc& d = tb.view.seg[i];
     ckpt::SegLayout s;
     s.dim = d.dim;
-    s.kind = d.opt == kOptSgd ? ckpt::kSegSgd : (d.opt == kOptAdagrad ? ckpt::kSegAdagrad : ckpt::kSegFtrl);
+    s.kind = d.opt;  // (SegKind values are the engine's OptType)
     s.w_off = d.w_off;
     s.st_off = d.st_off;
     v.push_back(s);
@@ -1700,10 +1702,14 @@ static void restore_multi_table(mhte_multi_table* t, const std::string& basename
       for (uint32_t k = 0; k < tb.nseg; ++k) {
         const SegDesc& d = tb.view.seg[k];
         const float w0 = init_weight(d);
+        const int nv = opt_vectors(d.opt);
         for (int e = 0; e < d.dim; ++e) {
           init[size_t(d.w_off + e)] = w0;
-          if (d.opt == kOptAdagrad || d.opt == kOptFtrl) init[size_t(d.st_off + e)] = d.p[0];
-          if (d.opt == kOptFtrl) init[size_t(d.st_off + d.dim + e)] = 0.f;
+          for (int v2 = 0; v2 < nv; ++v2) init[size_t(d.st_off + v2 * d.dim + e)] = opt_state_init(d, v2);
+        }
+        if (opt_scalars(d.opt)) {  // adam_optimizer.cc:52-53
+          init[size_t(d.st_off + nv * d.dim)] = d.p[0];
+          init[size_t(d.st_off + nv * d.dim + 1)] = d.p[1];
         }
       }
       const size_t kBatch = size_t(1) << 18;

@@ -89,7 +89,33 @@ inline void put_f32(std::string& out, uint8_t tag, float f) {
 
 // Optimizer kinds of a segment as the codec sees them (SingleOptimizerDump's oneof,
 // hash_table/optimizer/optimizer.proto:231-247)
-enum SegKind { kSegSgd = 0, kSegAdagrad = 1, kSegFtrl = 2 };
+// (values = the engine's OptType)
+enum SegKind {
+  kSegSgd = 0, kSegAdagrad = 1, kSegFtrl = 2, kSegMomentum = 3, kSegAdadelta = 4, kSegRmsprop = 5,
+  kSegRmspropV2 = 6, kSegAdam = 7, kSegAmsgrad = 8
+};
+// wire description of an optimizer's dump: field number in SingleOptimizerDump's oneof
+// (optimizer.proto:231-247), the dump message's repeated-float fields in the order of the engine's
+// state vectors, and the field numbers of the two scalars (0: none)
+struct DumpSpec {
+  int oneof_field;
+  int nvec;
+  int vec_field[3];
+  int scal_field[2];
+};
+inline DumpSpec dump_spec(int kind) {
+  switch (kind) {
+    case kSegSgd: return {2, 0, {0, 0, 0}, {0, 0}};
+    case kSegAdagrad: return {1, 1, {1, 0, 0}, {0, 0}};          // norm
+    case kSegFtrl: return {3, 2, {2, 1, 0}, {0, 0}};             // engine: norm | zero; wire zero=1 norm=2
+    case kSegMomentum: return {9, 1, {1, 0, 0}, {0, 0}};         // n
+    case kSegAdadelta: return {6, 2, {1, 2, 0}, {0, 0}};         // accum, accum_update
+    case kSegRmsprop: return {11, 1, {1, 0, 0}, {0, 0}};         // n
+    case kSegRmspropV2: return {12, 1, {1, 0, 0}, {0, 0}};       // n
+    case kSegAdam: return {7, 2, {1, 2, 0}, {3, 4}};             // m, v, beta1_power, beta2_power
+    default: return {8, 3, {1, 2, 3}, {4, 5}};                   // amsgrad: m, v, vhat, powers
+  }
+}
 struct SegLayout {
   int dim;
   int kind;    // SegKind
@@ -110,24 +136,19 @@ inline void encode_entry(std::string& out, int64_t id, const float* row,
   std::string opt;
   for (const SegLayout& s : segs) {
     std::string single;
-    if (s.kind == kSegSgd) {
-      single.push_back(char(0x12));  // sgd: field 2, empty message
-      single.push_back(char(0x00));
-    } else if (s.kind == kSegAdagrad) {
-      std::string m;
-      for (int i = 0; i < s.dim; ++i) put_f32(m, 0x0d, row[s.st_off + i]);  // norm = 1
-      single.push_back(char(0x0a));  // adagrad: field 1
-      put_varint(single, m.size());
-      single += m;
-    } else {
-      std::string m;
-      // engine row: norm[d] | zero[d] (as ftrl_optimizer.cc:80-81); wire: zero = 1, norm = 2
-      for (int i = 0; i < s.dim; ++i) put_f32(m, 0x0d, row[s.st_off + s.dim + i]);
-      for (int i = 0; i < s.dim; ++i) put_f32(m, 0x15, row[s.st_off + i]);
-      single.push_back(char(0x1a));  // ftrl: field 3
-      put_varint(single, m.size());
-      single += m;
+    const DumpSpec ds = dump_spec(s.kind);
+    std::string m;
+    // protobuf serialises in field-number order: vectors (and scalars) sorted by field number
+    for (int f = 1; f <= 5; ++f) {
+      for (int k = 0; k < ds.nvec; ++k)
+        if (ds.vec_field[k] == f)
+          for (int i = 0; i < s.dim; ++i) put_f32(m, uint8_t((f << 3) | 5), row[s.st_off + k * s.dim + i]);
+      for (int k = 0; k < 2; ++k)
+        if (ds.scal_field[k] == f) put_f32(m, uint8_t((f << 3) | 5), row[s.st_off + ds.nvec * s.dim + k]);
     }
+    single.push_back(char((ds.oneof_field << 3) | 2));
+    put_varint(single, m.size());
+    single += m;
     opt.push_back(char(0x0a));  // OptimizerDump.dump: field 1
     put_varint(opt, single.size());
     opt += single;
@@ -237,33 +258,30 @@ inline void decode_entry(const uint8_t* p, size_t n, const std::vector<SegLayout
           const uint8_t* m = r;
           const uint8_t* mend = r + l3;
           r = mend;
-          if (f3 == 1 && sg.kind == kSegAdagrad) {
-            int c = 0;
+          const DumpSpec ds = dump_spec(sg.kind);
+          if (int(f3) == ds.oneof_field) {
+            int cnt[3] = {0, 0, 0};
             while (m < mend) {
               uint64_t k4;
-              if (!get_varint(m, mend, &k4)) throw ProtoError("AdagradOptimizerDump: bad tag");
-              if ((k4 >> 3) == 1) {
-                if (!read_floats(m, mend, uint32_t(k4 & 7), row + sg.st_off, sg.dim, &c))
-                  throw ProtoError("AdagradOptimizerDump: bad norm");
-              } else if (!skip_field(m, mend, uint32_t(k4 & 7))) {
-                throw ProtoError("AdagradOptimizerDump: bad field");
+              if (!get_varint(m, mend, &k4)) throw ProtoError("optimizer dump: bad tag");
+              const int f4 = int(k4 >> 3);
+              bool done = false;
+              for (int k = 0; k < ds.nvec && !done; ++k) {
+                if (ds.vec_field[k] == f4) {
+                  if (!read_floats(m, mend, uint32_t(k4 & 7), row + sg.st_off + k * sg.dim, sg.dim, &cnt[k]))
+                    throw ProtoError("optimizer dump: bad state vector");
+                  done = true;
+                }
               }
-            }
-          } else if (f3 == 3 && sg.kind == kSegFtrl) {
-            int cz = 0, cn = 0;
-            while (m < mend) {
-              uint64_t k4;
-              if (!get_varint(m, mend, &k4)) throw ProtoError("FtrlOptimizerDump: bad tag");
-              const uint32_t f4 = uint32_t(k4 >> 3);
-              if (f4 == 1) {
-                if (!read_floats(m, mend, uint32_t(k4 & 7), row + sg.st_off + sg.dim, sg.dim, &cz))
-                  throw ProtoError("FtrlOptimizerDump: bad zero");
-              } else if (f4 == 2) {
-                if (!read_floats(m, mend, uint32_t(k4 & 7), row + sg.st_off, sg.dim, &cn))
-                  throw ProtoError("FtrlOptimizerDump: bad norm");
-              } else if (!skip_field(m, mend, uint32_t(k4 & 7))) {
-                throw ProtoError("FtrlOptimizerDump: bad field");
+              for (int k = 0; k < 2 && !done; ++k) {
+                if (ds.scal_field[k] == f4 && (k4 & 7) == 5) {
+                  if (mend - m < 4) throw ProtoError("optimizer dump: bad scalar");
+                  row[sg.st_off + ds.nvec * sg.dim + k] = rd_f32(m);
+                  m += 4;
+                  done = true;
+                }
               }
+              if (!done && !skip_field(m, mend, uint32_t(k4 & 7))) throw ProtoError("optimizer dump: bad field");
             }
           }
           // sgd (field 2) carries nothing; a dump of another optimizer type is ignored

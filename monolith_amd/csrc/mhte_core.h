@@ -37,7 +37,12 @@ constexpr int kMaxSegments = 8;
 constexpr int64_t kEmptyKey = INT64_MIN;
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 
-enum OptType : int32_t { kOptSgd = 0, kOptAdagrad = 1, kOptFtrl = 2 };
+enum OptType : int32_t {
+  kOptSgd = 0, kOptAdagrad = 1, kOptFtrl = 2,
+  // op-level kernels only (the fused training-step kernels take the three above):
+  kOptMomentum = 3, kOptAdadelta = 4, kOptRmsprop = 5, kOptRmspropV2 = 6, kOptAdam = 7, kOptAmsgrad = 8,
+  kOptCount = 9
+};
 enum InitType : int32_t { kInitZeros = 0, kInitOnes = 1, kInitConstant = 2 };
 
 // One 64-byte line per bucket: 4 keys, 4 row handles, 4 uint32 timestamps.  The reference's
@@ -57,8 +62,12 @@ struct SegDesc {
   int32_t w_off;    // float offset of this segment's weights inside the row
   int32_t st_off;   // float offset of this segment's optimizer ctx inside the row
   int32_t opt;      // OptType
-  float p[4];       // adagrad: {initial_accumulator_value, weight_decay_factor}
-                    // ftrl:    {initial_accumulator_value, beta, l1, l2}
+  float p[8];       // adagrad:  {initial_accumulator_value, weight_decay_factor}
+                    // ftrl:     {initial_accumulator_value, beta, l1, l2}
+                    // momentum: {momentum, weight_decay_factor, use_nesterov}
+                    // adadelta: {averaging_ratio, epsilon, weight_decay_factor}
+                    // rmsprop / rmspropv2: {momentum, weight_decay_factor, config learning_rate}
+                    // adam / amsgrad: {beta1, beta2, epsilon, weight_decay_factor, use_nesterov}
   int32_t init;     // InitType
   float init_value; // constants initializer value
 };
@@ -261,6 +270,122 @@ MHTE_HD void ftrl_step(float& w, float& n, float& z, float grad, float lr, float
   } else {
     w = 0.f;
   }
+}
+
+// Optimizer context of a segment inside the row: `opt_vectors` state vectors of dim floats each,
+// then (adam / amsgrad) the two running beta powers in a 4-float slot.  The reference keeps the
+// vectors in the same order and the two scalars right behind them (adam_optimizer.cc:30-32,47-50;
+// the padding to 4 floats is this engine's, for float4 alignment of the next segment).
+MHTE_HD int opt_vectors(int opt) {
+  switch (opt) {
+    case kOptSgd: return 0;
+    case kOptAdagrad: case kOptMomentum: case kOptRmsprop: case kOptRmspropV2: return 1;
+    case kOptFtrl: case kOptAdadelta: case kOptAdam: return 2;
+    case kOptAmsgrad: return 3;
+    default: return 0;
+  }
+}
+MHTE_HD int opt_scalars(int opt) { return (opt == kOptAdam || opt == kOptAmsgrad) ? 2 : 0; }
+MHTE_HD int opt_state_floats(int opt, int dim) {
+  return opt_vectors(opt) * dim + (opt_scalars(opt) ? 4 : 0);
+}
+// initial value of state vector k (optimizer Init()); scalars: adam/amsgrad {beta1, beta2}
+MHTE_HD float opt_state_init(const SegDesc& s, int k) {
+  if (s.opt == kOptAdagrad) return s.p[0];               // adagrad_optimizer.cc:47-52
+  if (s.opt == kOptFtrl) return k == 0 ? s.p[0] : 0.f;   // ftrl_optimizer.cc:44-51: norm | zero
+  return 0.f;                                            // momentum / adadelta / rmsprop / adam / amsgrad
+}
+
+// momentum_optimizer.cc:50-71
+MHTE_HD void momentum_step(float& w, float& n, float grad, float lr, float mom, float wd,
+                           bool nesterov) {
+  float t = wd * w;
+  float gg = grad + t;
+  float dx = lr * gg;
+  if (nesterov) {
+    float prev_n = n;
+    float mn = mom * n;
+    n = mn - dx;
+    float a = -mom * prev_n;
+    float b = (1 + mom) * n;
+    float d = a + b;
+    w = w + d;
+  } else {
+    float mn = mom * n;
+    n = mn - dx;
+    w = w + n;
+  }
+}
+
+// adadelta_optimizer.cc:51-72
+MHTE_HD void adadelta_step(float& w, float& accum, float& accum_update, float grad, float lr,
+                           float rho, float eps, float wd) {
+  float t = wd * w;
+  float g = grad + t;
+  float a1 = accum * rho;
+  float gg = g * g;
+  float a2 = gg * (1 - rho);
+  float new_accum = a1 + a2;
+  float num = sqrtf(accum_update + eps);
+  float den = sqrtf(new_accum + eps);
+  float q = num / den;
+  float update = q * g;
+  float ul = update * lr;
+  float u1 = accum_update * rho;
+  float uu = update * update;
+  float u2 = uu * (1 - rho);
+  w = w - ul;
+  accum = new_accum;
+  accum_update = u1 + u2;
+}
+
+// rmsprop_optimizer.cc:54-72 (v1: the CONFIG's learning rate, double arithmetic) and :127-144 (v2)
+MHTE_HD void rmsprop_step(float& w, float& n, float grad, double lr, float mom, float wd, bool v2) {
+  double dx = grad + static_cast<double>(wd) * w;
+  float new_n;
+  if (v2) {
+    new_n = static_cast<float>(static_cast<double>(mom) * n + dx * dx);
+  } else {
+    new_n = static_cast<float>(static_cast<double>(mom) * n + (1 - static_cast<double>(mom)) * dx * dx);
+  }
+  double eta = lr / (sqrtf(new_n) + 1);  // (std::sqrt of a float: float; the sum too)
+  w = static_cast<float>(w - eta * dx);
+  n = new_n;
+}
+
+// adam_optimizer.cc:56-86 / amsgrad_optimizer.cc; lr_eff = lr * sqrt(1 - beta2_power) / (1 - beta1_power)
+MHTE_HD float adam_lr(float lr, float b1p, float b2p) {
+  float a = sqrtf(1 - b2p);
+  float b = lr * a;
+  return b / (1 - b1p);
+}
+MHTE_HD void adam_step(float& w, float& m, float& v, float* vhat, float grad, float lr_eff,
+                       float beta1, float beta2, float eps, float wd, bool nesterov) {
+  float t = wd * w;
+  float g = grad + t;
+  float dm = (g - m) * (1 - beta1);
+  float new_m = m + dm;
+  float gg = g * g;
+  float dv = (gg - v) * (1 - beta2);
+  float new_v = v + dv;
+  float vv = new_v;
+  if (vhat) {
+    vv = (*vhat > new_v) ? *vhat : new_v;
+    *vhat = vv;
+  }
+  float den = sqrtf(vv) + eps;
+  float numr;
+  if (nesterov) {
+    float a = g * (1 - beta1);
+    float b = beta1 * new_m;
+    numr = (a + b) * lr_eff;
+  } else {
+    numr = new_m * lr_eff;
+  }
+  float q = numr / den;
+  w = w - q;
+  m = new_m;
+  v = new_v;
 }
 
 MHTE_HD float init_weight(const SegDesc& s) {

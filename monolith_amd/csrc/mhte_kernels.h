@@ -409,24 +409,35 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
     const SegDesc sd = tv.seg[k];
     const uint32_t le = e - sd.w_off;  // element index inside the segment
     const float lr = a.lr[k];
-    Vec<VEC> w, s1, s2;
+    const int nv = opt_vectors(sd.opt);
+    const bool scal = opt_scalars(sd.opt) != 0;
+    Vec<VEC> w, s1, s2, s3;
     float* st1 = rp + sd.st_off + le;
     float* st2 = st1 + sd.dim;
-    const bool has1 = sd.opt == kOptAdagrad || sd.opt == kOptFtrl;
-    const bool has2 = sd.opt == kOptFtrl;
+    float* st3 = st2 + sd.dim;
+    float* sc = rp + sd.st_off + nv * sd.dim;  // adam / amsgrad: {beta1_power, beta2_power}
+    float c1 = 0.f, c2 = 0.f;
     if (is_new || OP == kOpReinit) {
       const float w0 = init_weight(sd);
 #pragma unroll
       for (int c = 0; c < VEC; ++c) {
         w.v[c] = w0;
-        s1.v[c] = sd.p[0];  // adagrad norm / ftrl norm = initial_accumulator_value
-        s2.v[c] = 0.f;      // ftrl zero
+        s1.v[c] = opt_state_init(sd, 0);
+        s2.v[c] = opt_state_init(sd, 1);
+        s3.v[c] = opt_state_init(sd, 2);
       }
+      c1 = sd.p[0];  // adam_optimizer.cc:52-53: the powers start at beta1, beta2
+      c2 = sd.p[1];
     } else {
       if (OP != kOpAssign) w.load(rp + e);
       if (OP == kOpOptimize) {
-        if (has1) s1.load(st1);
-        if (has2) s2.load(st2);
+        if (nv > 0) s1.load(st1);
+        if (nv > 1) s2.load(st2);
+        if (nv > 2) s3.load(st3);
+        if (scal) {
+          c1 = sc[0];
+          c2 = sc[1];
+        }
       }
     }
     if (OP == kOpAssign) {
@@ -448,24 +459,58 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
           if (t + 1 < nq) continue;
           v = acc;
         }
+        const float lr_eff = scal ? adam_lr(lr, c1, c2) : lr;
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
           if (OP == kOpAssignAdd) {
             w.v[c] = w.v[c] + v.v[c];  // entry_accessor.cc:179-185
-          } else if (sd.opt == kOptSgd) {
-            w.v[c] = sgd_step(w.v[c], v.v[c], lr);
-          } else if (sd.opt == kOptAdagrad) {
-            adagrad_step(w.v[c], s1.v[c], v.v[c], lr, sd.p[1]);
           } else {
-            ftrl_step(w.v[c], s1.v[c], s2.v[c], v.v[c], lr, sd.p[1], sd.p[2], sd.p[3]);
+            switch (sd.opt) {
+              case kOptSgd: w.v[c] = sgd_step(w.v[c], v.v[c], lr); break;
+              case kOptAdagrad: adagrad_step(w.v[c], s1.v[c], v.v[c], lr, sd.p[1]); break;
+              case kOptFtrl:
+                ftrl_step(w.v[c], s1.v[c], s2.v[c], v.v[c], lr, sd.p[1], sd.p[2], sd.p[3]);
+                break;
+              case kOptMomentum:
+                momentum_step(w.v[c], s1.v[c], v.v[c], lr, sd.p[0], sd.p[1], sd.p[2] != 0.f);
+                break;
+              case kOptAdadelta:
+                adadelta_step(w.v[c], s1.v[c], s2.v[c], v.v[c], lr, sd.p[0], sd.p[1], sd.p[2]);
+                break;
+              case kOptRmsprop:
+                rmsprop_step(w.v[c], s1.v[c], v.v[c], double(sd.p[2]), sd.p[0], sd.p[1], false);
+                break;
+              case kOptRmspropV2:
+                rmsprop_step(w.v[c], s1.v[c], v.v[c], double(lr), sd.p[0], sd.p[1], true);
+                break;
+              case kOptAdam:
+                adam_step(w.v[c], s1.v[c], s2.v[c], nullptr, v.v[c], lr_eff, sd.p[0], sd.p[1],
+                          sd.p[2], sd.p[3], sd.p[4] != 0.f);
+                break;
+              default:  // kOptAmsgrad
+                adam_step(w.v[c], s1.v[c], s2.v[c], &s3.v[c], v.v[c], lr_eff, sd.p[0], sd.p[1],
+                          sd.p[2], sd.p[3], sd.p[4] != 0.f);
+                break;
+            }
           }
+        }
+        if (OP == kOpOptimize && scal) {  // one Optimize() call done: the powers move on
+          c1 = c1 * sd.p[0];
+          c2 = c2 * sd.p[1];
         }
       }
     }
     w.store(rp + e);
     if (is_new || OP == kOpReinit || OP == kOpOptimize) {
-      if (has1) s1.store(st1);
-      if (has2) s2.store(st2);
+      if (nv > 0) s1.store(st1);
+      if (nv > 1) s2.store(st2);
+      if (nv > 2) s3.store(st3);
+      if (scal && le == 0) {  // (every lane of the segment computed the same powers)
+        sc[0] = c1;
+        sc[1] = c2;
+        sc[2] = 0.f;
+        sc[3] = 0.f;
+      }
     }
   }
 }

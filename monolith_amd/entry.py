@@ -66,6 +66,76 @@ class FtrlOptimizer(Optimizer):
             self.l2_regularization_strength)
 
 
+class MomentumOptimizer(Optimizer):
+  """reference entry.py MomentumOptimizer; proto defaults lr 0.01, momentum 0.9, weight decay 0,
+  use_nesterov false (optimizer.proto:156-163).  Op-level kernels only."""
+  opt_type = _lib.OPT_MOMENTUM
+
+  def __init__(self, learning_rate=None, weight_decay_factor=0.0, use_nesterov=False, momentum=None,
+               warmup_steps=0):
+    self.learning_rate = 0.01 if learning_rate is None else learning_rate
+    self.weight_decay_factor = weight_decay_factor
+    self.use_nesterov = use_nesterov
+    self.momentum = 0.9 if momentum is None else momentum
+    self.warmup_steps = warmup_steps
+
+  def params(self):
+    return (self.momentum, self.weight_decay_factor, 1.0 if self.use_nesterov else 0.0)
+
+
+class AdadeltaOptimizer(Optimizer):
+  """proto defaults lr 0.01, averaging_ratio 0.9, epsilon 0.01, weight decay 0
+  (optimizer.proto:104-111).  Op-level kernels only."""
+  opt_type = _lib.OPT_ADADELTA
+
+  def __init__(self, learning_rate=None, weight_decay_factor=0.0, averaging_ratio=None, epsilon=None,
+               warmup_steps=0):
+    self.learning_rate = 0.01 if learning_rate is None else learning_rate
+    self.weight_decay_factor = weight_decay_factor
+    self.averaging_ratio = 0.9 if averaging_ratio is None else averaging_ratio
+    self.epsilon = 0.01 if epsilon is None else epsilon
+    self.warmup_steps = warmup_steps
+
+  def params(self):
+    return (self.averaging_ratio, self.epsilon, self.weight_decay_factor)
+
+
+class RmspropOptimizer(Optimizer):
+  """proto defaults lr 0.01, weight decay 0, momentum 0.9 (optimizer.proto:186-191).  v1 steps
+  with the CONFIG's learning rate (rmsprop_optimizer.cc:66); ``v2=True`` is RmspropV2
+  (:127-144), which uses the op's learning-rate input.  Op-level kernels only."""
+
+  def __init__(self, learning_rate=None, weight_decay_factor=0.0, momentum=None, v2=False):
+    self.opt_type = _lib.OPT_RMSPROPV2 if v2 else _lib.OPT_RMSPROP
+    self.learning_rate = 0.01 if learning_rate is None else learning_rate
+    self.weight_decay_factor = weight_decay_factor
+    self.momentum = 0.9 if momentum is None else momentum
+
+  def params(self):
+    return (self.momentum, self.weight_decay_factor, self.learning_rate)
+
+
+class AdamOptimizer(Optimizer):
+  """proto defaults lr 0.01, beta1 0.9, beta2 0.99, weight decay 0, use_nesterov false,
+  epsilon 0.01 (optimizer.proto:137-146); ``amsgrad=True`` is AmsgradOptimizer (same config
+  fields, :118-128).  Op-level kernels only."""
+
+  def __init__(self, learning_rate=None, beta1=None, beta2=None, weight_decay_factor=0.0,
+               use_nesterov=False, epsilon=None, warmup_steps=0, amsgrad=False):
+    self.opt_type = _lib.OPT_AMSGRAD if amsgrad else _lib.OPT_ADAM
+    self.learning_rate = 0.01 if learning_rate is None else learning_rate
+    self.beta1 = 0.9 if beta1 is None else beta1
+    self.beta2 = 0.99 if beta2 is None else beta2
+    self.weight_decay_factor = weight_decay_factor
+    self.use_nesterov = use_nesterov
+    self.epsilon = 0.01 if epsilon is None else epsilon
+    self.warmup_steps = warmup_steps
+
+  def params(self):
+    return (self.beta1, self.beta2, self.epsilon, self.weight_decay_factor,
+            1.0 if self.use_nesterov else 0.0)
+
+
 class Initializer:
   init_type = None
   value = 0.0

@@ -18,6 +18,7 @@ import numpy as np
 _DIR = os.path.dirname(os.path.abspath(__file__))
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
+OPT_MOMENTUM, OPT_ADADELTA, OPT_RMSPROP, OPT_RMSPROPV2, OPT_ADAM, OPT_AMSGRAD = 3, 4, 5, 6, 7, 8
 INIT_ZEROS, INIT_ONES, INIT_CONSTANT = 0, 1, 2
 
 

@@ -74,6 +74,12 @@ static int32_t state_floats(const mo_segment* s) {
     case MO_OPT_SGD: return 0;               /* optimizer/sgd_optimizer.cc:28 */
     case MO_OPT_ADAGRAD: return s->dim;      /* optimizer/adagrad_optimizer.cc:30-32 */
     case MO_OPT_FTRL: return 2 * s->dim;     /* optimizer/ftrl_optimizer.cc:31-33 */
+    case MO_OPT_MOMENTUM: return s->dim;     /* optimizer/momentum_optimizer.cc:30-32 */
+    case MO_OPT_ADADELTA: return 2 * s->dim; /* optimizer/adadelta_optimizer.cc:30-32 */
+    case MO_OPT_RMSPROP:
+    case MO_OPT_RMSPROPV2: return s->dim;    /* optimizer/rmsprop_optimizer.cc:33-35,106-108 */
+    case MO_OPT_ADAM: return 2 * s->dim + 2;     /* optimizer/adam_optimizer.cc:30-32 */
+    case MO_OPT_AMSGRAD: return 3 * s->dim + 2;  /* optimizer/amsgrad_optimizer.cc:30-32 */
     default: return 0;
   }
 }
@@ -383,6 +389,15 @@ static void init_row(const mo_table* t, float* row) {
         st[k] = s->p[0];
         st[s->dim + k] = 0.f;
       }
+    } else if (s->opt == MO_OPT_ADAM || s->opt == MO_OPT_AMSGRAD) {
+      /* adam_optimizer.cc:43-54 / amsgrad_optimizer.cc: vectors 0, powers = beta1, beta2 */
+      int nv = s->opt == MO_OPT_ADAM ? 2 : 3;
+      for (int k = 0; k < nv * s->dim; ++k) st[k] = 0.f;
+      st[nv * s->dim] = s->p[0];
+      st[nv * s->dim + 1] = s->p[1];
+    } else {
+      /* momentum / adadelta / rmsprop: Init() zeroes the context */
+      for (int k = 0; k < state_floats(s); ++k) st[k] = 0.f;
     }
     w += s->dim;
   }
@@ -487,6 +502,90 @@ static void mo_ftrl(float* num, float* norm, float* zero, const float* grad, int
   }
 }
 
+/* optimizer/momentum_optimizer.cc:50-71; p = {momentum, weight_decay_factor, use_nesterov} */
+static void mo_momentum(float* num, float* n, const float* grad, int64_t len, float lr,
+                        const float* p) {
+  for (int64_t i = 0; i < len; ++i) {
+    float dx = lr * (grad[i] + p[1] * num[i]);
+    float new_n = n[i];
+    float new_w = num[i];
+    if (p[2] != 0.f) {
+      float prev_n = new_n;
+      new_n = p[0] * new_n - dx;
+      new_w += -p[0] * prev_n + (1 + p[0]) * new_n;
+    } else {
+      new_n = p[0] * new_n - dx;
+      new_w += new_n;
+    }
+    n[i] = new_n;
+    num[i] = new_w;
+  }
+}
+/* optimizer/adadelta_optimizer.cc:51-72; p = {averaging_ratio, epsilon, weight_decay_factor} */
+static void mo_adadelta(float* num, float* accum, float* accum_update, const float* grad,
+                        int64_t len, float lr, const float* p) {
+  for (int64_t i = 0; i < len; ++i) {
+    float cur_grad = grad[i] + p[2] * num[i];
+    float new_accum = accum[i] * p[0] + cur_grad * cur_grad * (1 - p[0]);
+    float update = sqrtf(accum_update[i] + p[1]) / sqrtf(new_accum + p[1]) * cur_grad;
+    float new_w = num[i] - update * lr;
+    float new_accum_update = accum_update[i] * p[0] + update * update * (1 - p[0]);
+    num[i] = new_w;
+    accum[i] = new_accum;
+    accum_update[i] = new_accum_update;
+  }
+}
+/* optimizer/rmsprop_optimizer.cc:54-72 (v1: conf learning rate p[2]) and :127-144 (v2: lrs[0]);
+ * p = {momentum, weight_decay_factor, conf learning_rate} */
+static void mo_rmsprop(float* num, float* n, const float* grad, int64_t len, float lr,
+                       const float* p, int v2) {
+  for (int64_t i = 0; i < len; ++i) {
+    float new_n = n[i];
+    float new_w = num[i];
+    double dx = grad[i] + (double)p[1] * new_w;
+    if (v2) {
+      new_n = (double)p[0] * new_n + dx * dx;
+    } else {
+      new_n = (double)p[0] * new_n + (1 - (double)p[0]) * dx * dx;
+    }
+    double eta = (double)(v2 ? lr : p[2]) / (sqrtf(new_n) + 1);
+    new_w -= eta * dx;
+    n[i] = new_n;
+    num[i] = new_w;
+  }
+}
+/* optimizer/adam_optimizer.cc:56-86, amsgrad_optimizer.cc (vhat != NULL);
+ * p = {beta1, beta2, epsilon, weight_decay_factor, use_nesterov}; ctx = m | v | [vhat |] powers */
+static void mo_adam(float* num, float* ctx, const float* grad, int64_t len, float lr0,
+                    const float* p, int amsgrad) {
+  float* m = ctx;
+  float* v = m + len;
+  float* vhat = amsgrad ? v + len : NULL;
+  float* pw = (amsgrad ? vhat : v) + len;
+  float lr = lr0 * sqrtf(1 - pw[1]) / (1 - pw[0]);
+  for (int64_t i = 0; i < len; ++i) {
+    float cur_grad = grad[i] + p[3] * num[i];
+    float new_m = m[i] + (cur_grad - m[i]) * (1 - p[0]);
+    float new_v = v[i] + (cur_grad * cur_grad - v[i]) * (1 - p[1]);
+    float den_v = new_v;
+    if (amsgrad) {
+      den_v = vhat[i] > new_v ? vhat[i] : new_v;
+      vhat[i] = den_v;
+    }
+    float new_w = num[i];
+    if (p[4] != 0.f) {
+      new_w -= ((cur_grad * (1 - p[0]) + p[0] * new_m) * lr) / (sqrtf(den_v) + p[2]);
+    } else {
+      new_w -= (new_m * lr) / (sqrtf(den_v) + p[2]);
+    }
+    num[i] = new_w;
+    m[i] = new_m;
+    v[i] = new_v;
+  }
+  pw[0] *= p[0];
+  pw[1] *= p[1];
+}
+
 /* :229-247 + entry_accessor.cc:187-195 + optimizer_combination.cc:63-72 */
 void mo_optimize(mo_table* t, const int64_t* ids, int64_t n, const float* grads, const float* lrs,
                  int64_t update_time, int64_t global_step) {
@@ -508,6 +607,14 @@ void mo_optimize(mo_table* t, const int64_t* ids, int64_t n, const float* grads,
         mo_adagrad(row + w, st, g + w, sg->dim, lrs[k], sg->p[1]);
       } else if (sg->opt == MO_OPT_FTRL) {
         mo_ftrl(row + w, st, st + sg->dim, g + w, sg->dim, lrs[k], sg->p[1], sg->p[2], sg->p[3]);
+      } else if (sg->opt == MO_OPT_MOMENTUM) {
+        mo_momentum(row + w, st, g + w, sg->dim, lrs[k], sg->p);
+      } else if (sg->opt == MO_OPT_ADADELTA) {
+        mo_adadelta(row + w, st, st + sg->dim, g + w, sg->dim, lrs[k], sg->p);
+      } else if (sg->opt == MO_OPT_RMSPROP || sg->opt == MO_OPT_RMSPROPV2) {
+        mo_rmsprop(row + w, st, g + w, sg->dim, lrs[k], sg->p, sg->opt == MO_OPT_RMSPROPV2);
+      } else if (sg->opt == MO_OPT_ADAM || sg->opt == MO_OPT_AMSGRAD) {
+        mo_adam(row + w, st, g + w, sg->dim, lrs[k], sg->p, sg->opt == MO_OPT_AMSGRAD);
       }
       w += sg->dim;
     }

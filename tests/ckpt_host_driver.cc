@@ -25,7 +25,10 @@ static std::vector<SegLayout> segs_from(char** a, int nseg, int dim, int* row_fl
     s.w_off = w;
     s.st_off = st;
     w += s.dim;
-    st += s.kind == kSegAdagrad ? s.dim : (s.kind == kSegFtrl ? 2 * s.dim : 0);
+    {
+      const DumpSpec ds = dump_spec(s.kind);
+      st += ds.nvec * s.dim + (ds.scal_field[0] ? 4 : 0);
+    }
     v.push_back(s);
   }
   *row_floats = st;

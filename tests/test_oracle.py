@@ -242,3 +242,37 @@ def test_random_ops_match_reference_map(opt):
   e2, h2 = r.lookup(universe[:4000])
   assert h1 == h2
   np.testing.assert_array_equal(e1, e2)
+
+
+# ---- the remaining sparse optimizers: KATs of the reference's own *_optimizer_test.cc -------------
+OPT_KATS = [
+    # (name, opt, p, lr, grads, after first step, after second step, file:line)
+    ("momentum", O.OPT_MOMENTUM, (0.9, 0.0, 0.0), 0.01, [10.0, 1.0], [-0.1, -0.01], [-0.29, -0.029],
+     "momentum_optimizer_test.cc:32-75"),
+    ("adadelta", O.OPT_ADADELTA, (0.9, 0.01, 0.0), 0.01, [10.0, 1.0], [-0.0031607, -0.0030151],
+     [-0.0064035, None], "adadelta_optimizer_test.cc:32-64"),
+    ("rmsprop", O.OPT_RMSPROP, (0.9, 0.0, 0.01), 0.01, [10.0], [-0.024025], [-0.042686],
+     "rmsprop_optimizer_test.cc:32-51"),
+    ("rmspropv2", O.OPT_RMSPROPV2, (0.9, 0.0, 0.01), 0.01, [10.0, 1.0], [-0.0090909, -0.005],
+     [None, None], "rmsprop_optimizer_test.cc:53-62"),
+    ("adam", O.OPT_ADAM, (0.9, 0.99, 0.01, 0.0, 0.0), 0.01, [10.0, 1.0], [-0.00990099, -0.00909091],
+     [-0.01983060, -0.01842895], "adam_optimizer_test.cc:32-76"),
+    ("amsgrad", O.OPT_AMSGRAD, (0.9, 0.99, 0.01, 0.0, 0.0), 0.01, [10.0], [-0.00990099],
+     [-0.01983060], "amsgrad_optimizer_test.cc:32-51"),
+]
+
+
+@pytest.mark.parametrize("kat", OPT_KATS, ids=[k[0] for k in OPT_KATS])
+def test_remaining_optimizer_kats(kat):
+  _, opt, p, lr, grads, exp1, exp2, _ = kat
+  dim = len(grads)
+  t = O.Table([O.segment(dim, opt, p=p)], 1)
+  g = np.array([grads], np.float32)
+  t.optimize(np.array([7], np.int64), g, [lr], 0)
+  got1 = t.lookup(np.array([7], np.int64))[0][0]
+  np.testing.assert_allclose(got1, exp1, rtol=0, atol=1e-6)
+  t.optimize(np.array([7], np.int64), g, [lr], 0)
+  got2 = t.lookup(np.array([7], np.int64))[0][0]
+  for a, b in zip(got2, exp2):
+    if b is not None:
+      assert abs(a - b) < 1e-6

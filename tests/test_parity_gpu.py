@@ -756,6 +756,67 @@ def test_sender_side_partition_scatter_sum(n, dim, shards, dist):
   np.testing.assert_allclose(gs, exp, rtol=0, atol=TOL)
 
 
+# =============================================================================== remaining optimizers
+_OPT_ENTRY = {
+    "momentum": lambda: entry.MomentumOptimizer(0.01),
+    "adadelta": lambda: entry.AdadeltaOptimizer(0.01),
+    "rmsprop": lambda: entry.RmspropOptimizer(0.01),
+    "rmspropv2": lambda: entry.RmspropOptimizer(0.01, v2=True),
+    "adam": lambda: entry.AdamOptimizer(0.01),
+    "amsgrad": lambda: entry.AdamOptimizer(0.01, amsgrad=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(_OPT_ENTRY))
+def test_remaining_optimizers_kat_and_oracle(name, tmp_path):
+  """Momentum / Adadelta / RMSProp (v1, v2) / Adam / AMSGrad in the op-level kernels: the
+  reference's own KATs (*_optimizer_test.cc), then a multi-step run with duplicates (one optimizer
+  step per occurrence, in order) bit-exact against the oracle's restatement, a table that is not
+  mhte_table_fused_backward_ok, and a checkpoint round trip that carries the state."""
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from test_oracle import OPT_KATS
+  kat = [k for k in OPT_KATS if k[0] == name][0]
+  _, oopt, p, lr, grads, exp1, exp2, _ = kat
+  dim = len(grads)
+  mt = make({"t": entry.make_table_config(
+      [entry.CombineAsSegment(dim, entry.ZerosInitializer(), _OPT_ENTRY[name]())])})
+  g = val_t([grads])
+  mt.apply_gradients({"t": (ids_t([7]), g)})
+  np.testing.assert_allclose(mt.lookup({"t": ids_t([7])})["t"].cpu().numpy()[0], exp1, rtol=0, atol=1e-6)
+  mt.apply_gradients({"t": (ids_t([7]), g)})
+  got2 = mt.lookup({"t": ids_t([7])})["t"].cpu().numpy()[0]
+  for a, b in zip(got2, exp2):
+    if b is not None:
+      assert abs(a - b) < 1e-6
+  # ---- multi-segment, duplicates, several steps vs the oracle
+  d1, d2 = 8, 4
+  segs = [entry.CombineAsSegment(d1, entry.ConstantsInitializer(0.25), _OPT_ENTRY[name]()),
+          entry.CombineAsSegment(d2, entry.ZerosInitializer(), entry.AdagradOptimizer(0.05, 0.1))]
+  mt2 = make({"t": entry.make_table_config(segs)})
+  assert not mt2._lib.mhte_table_fused_backward_ok(mt2.handle, 0)  # pylint: disable=protected-access
+  ot = O.Table([O.segment(d1, oopt, p=p, init=O.INIT_CONSTANT, init_value=0.25),
+                O.segment(d2, O.OPT_ADAGRAD, p=(0.1, 0.0))], 1)
+  rng = np.random.default_rng(len(name))
+  for step in range(4):
+    ids = rng.integers(0, 300, 1000).astype(np.int64)
+    gr = rng.standard_normal((1000, d1 + d2)).astype(np.float32)
+    mt2.apply_gradients({"t": (ids_t(ids), val_t(gr))}, req_time=100 + step)
+    ot.optimize(ids, gr, [lr, 0.05], 100 + step)
+  probe = np.arange(300, dtype=np.int64)
+  np.testing.assert_array_equal(mt2.lookup({"t": ids_t(probe)})["t"].cpu().numpy(), ot.lookup(probe)[0])
+  # ---- checkpoint round trip keeps the optimizer state (training continues identically)
+  base = str(tmp_path / "ck")
+  mt2.save(base)
+  mt3 = make({"t": entry.make_table_config(segs)})
+  mt3.restore(base)
+  ids = rng.integers(0, 300, 500).astype(np.int64)
+  gr = rng.standard_normal((500, d1 + d2)).astype(np.float32)
+  for m_ in (mt2, mt3):
+    m_.apply_gradients({"t": (ids_t(ids), val_t(gr))}, req_time=200)
+  np.testing.assert_array_equal(mt2.lookup({"t": ids_t(probe)})["t"].cpu().numpy(),
+                                mt3.lookup({"t": ids_t(probe)})["t"].cpu().numpy())
+
+
 # =============================================================================== gather + pooling
 def test_fused_gather_embeddings_by_input_golden():
   """distribution_ops_test.py:221-249 (forward, with its 12345x / 11777x tiling) and :251-304
