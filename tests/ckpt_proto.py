@@ -39,9 +39,25 @@ def _build():
   msg("SgdOptimizerDump", [])
   msg("FtrlOptimizerDump", [("zero", 1, F.TYPE_FLOAT, REP, None, False),
                             ("norm", 2, F.TYPE_FLOAT, REP, None, False)])
+  fl = lambda name, num: (name, num, F.TYPE_FLOAT, REP, None, False)
+  sc = lambda name, num: (name, num, F.TYPE_FLOAT, OPT, None, False)
+  msg("AdadeltaOptimizerDump", [fl("accum", 1), fl("accum_update", 2)])          # optimizer.proto:113-116
+  msg("AdamOptimizerDump", [fl("m", 1), fl("v", 2), sc("beta1_power", 3), sc("beta2_power", 4)])  # :130-135
+  msg("AmsgradOptimizerDump", [fl("m", 1), fl("v", 2), fl("vhat", 3), sc("beta1_power", 4),
+                               sc("beta2_power", 5)])                             # :148-154
+  msg("MomentumOptimizerDump", [fl("n", 1)])                                      # :165-167
+  msg("RmspropOptimizerDump", [fl("n", 1)])                                       # :193-195
+  msg("RmspropV2OptimizerDump", [fl("n", 1)])                                     # :204-206
   msg("SingleOptimizerDump", [("adagrad", 1, F.TYPE_MESSAGE, OPT, "AdagradOptimizerDump", True),
                               ("sgd", 2, F.TYPE_MESSAGE, OPT, "SgdOptimizerDump", True),
-                              ("ftrl", 3, F.TYPE_MESSAGE, OPT, "FtrlOptimizerDump", True)], oneof="type")
+                              ("ftrl", 3, F.TYPE_MESSAGE, OPT, "FtrlOptimizerDump", True),
+                              ("adadelta", 6, F.TYPE_MESSAGE, OPT, "AdadeltaOptimizerDump", True),
+                              ("adam", 7, F.TYPE_MESSAGE, OPT, "AdamOptimizerDump", True),
+                              ("amsgrad", 8, F.TYPE_MESSAGE, OPT, "AmsgradOptimizerDump", True),
+                              ("momentum", 9, F.TYPE_MESSAGE, OPT, "MomentumOptimizerDump", True),
+                              ("rmsprop", 11, F.TYPE_MESSAGE, OPT, "RmspropOptimizerDump", True),
+                              ("rmspropv2", 12, F.TYPE_MESSAGE, OPT, "RmspropV2OptimizerDump", True)],
+      oneof="type")
   msg("OptimizerDump", [("dump", 1, F.TYPE_MESSAGE, REP, "SingleOptimizerDump", False)])
   msg("EntryDump", [("id", 1, F.TYPE_SFIXED64, OPT, None, False),
                     ("num", 2, F.TYPE_FLOAT, REP, None, False),

@@ -15,7 +15,10 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import ckpt_proto as P  # noqa: E402
 
-SGD, ADAGRAD, FTRL = 0, 1, 2
+SGD, ADAGRAD, FTRL, MOMENTUM, ADADELTA, RMSPROP, RMSPROPV2, ADAM, AMSGRAD = range(9)
+# (state vectors, scalars) per kind, in the engine's row (scalars sit in a 4-float slot)
+STATE = {SGD: (0, 0), ADAGRAD: (1, 0), FTRL: (2, 0), MOMENTUM: (1, 0), ADADELTA: (2, 0), RMSPROP: (1, 0),
+         RMSPROPV2: (1, 0), ADAM: (2, 2), AMSGRAD: (3, 2)}
 
 
 @pytest.fixture(scope="module")
@@ -44,11 +47,29 @@ def reference_entry(id_, ts, segs, row, dim, with_id=True, packed=False):
       s.sgd.SetInParent()
     elif kind == ADAGRAD:
       s.adagrad.norm.extend(row[st:st + d])
-      st += d
-    else:
+    elif kind == FTRL:
       s.ftrl.norm.extend(row[st:st + d])
       s.ftrl.zero.extend(row[st + d:st + 2 * d])
-      st += 2 * d
+    elif kind == MOMENTUM:
+      s.momentum.n.extend(row[st:st + d])
+    elif kind == RMSPROP:
+      s.rmsprop.n.extend(row[st:st + d])
+    elif kind == RMSPROPV2:
+      s.rmspropv2.n.extend(row[st:st + d])
+    elif kind == ADADELTA:
+      s.adadelta.accum.extend(row[st:st + d])
+      s.adadelta.accum_update.extend(row[st + d:st + 2 * d])
+    elif kind == ADAM:
+      s.adam.m.extend(row[st:st + d])
+      s.adam.v.extend(row[st + d:st + 2 * d])
+      s.adam.beta1_power, s.adam.beta2_power = row[st + 2 * d], row[st + 2 * d + 1]
+    else:
+      s.amsgrad.m.extend(row[st:st + d])
+      s.amsgrad.v.extend(row[st + d:st + 2 * d])
+      s.amsgrad.vhat.extend(row[st + 2 * d:st + 3 * d])
+      s.amsgrad.beta1_power, s.amsgrad.beta2_power = row[st + 3 * d], row[st + 3 * d + 1]
+    nv, ns = STATE[kind]
+    st += nv * d + (4 if ns else 0)
   e.last_update_ts_sec = ts
   return e.SerializeToString()
 
@@ -74,11 +95,13 @@ def test_reference_golden_entry_dump(driver):
 
 
 @pytest.mark.parametrize("segs", [[(SGD, 3)], [(ADAGRAD, 4)], [(FTRL, 2)],
-                                  [(FTRL, 1), (ADAGRAD, 5), (SGD, 2)]])
+                                  [(FTRL, 1), (ADAGRAD, 5), (SGD, 2)], [(MOMENTUM, 3)],
+                                  [(ADADELTA, 2)], [(RMSPROP, 2), (RMSPROPV2, 1)], [(ADAM, 4)],
+                                  [(AMSGRAD, 2), (ADAM, 1), (SGD, 1)]])
 def test_entry_bytes_equal_protobuf_runtime(driver, segs):
   rng = np.random.default_rng(len(segs) * 11 + segs[0][1])
   dim = sum(d for _, d in segs)
-  rf = dim + sum(d if k == ADAGRAD else (2 * d if k == FTRL else 0) for k, d in segs)
+  rf = dim + sum(STATE[k][0] * d + (4 if STATE[k][1] else 0) for k, d in segs)
   row = rng.standard_normal(rf).astype(np.float32)
   for id_, ts in ((-3, 0), (1 << 62, 1700000123), (-(1 << 63), 4294967295)):
     args = ["entry", id_, ts, dim, len(segs)] + [x for s in segs for x in s] + [repr(float(v)) for v in row]
