@@ -7,8 +7,11 @@ import subprocess
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_DIR, "libmhte.so")
 _SRC = os.path.join(_DIR, "csrc", "mhte.hip")
-_DEPS = [_SRC, os.path.join(_DIR, "csrc", "mhte_kernels.h"), os.path.join(_DIR, "csrc", "mhte_core.h"),
-         os.path.join(_DIR, "..", "include", "monolith_amd_hash_table.h")]
+_DEPS = [_SRC] + [os.path.join(_DIR, "csrc", h) for h in
+                  ("mhte_kernels.h", "mhte_core.h", "mhte_step_kernels.h", "mhte_pool_kernels.h",
+                   "mhte_ckpt.h")] + [os.path.join(_DIR, "..", "include", "monolith_amd_hash_table.h")]
+# A/B measurements: MHTE_LIBRARY=<other build of libmhte.so> (same ABI) is loaded instead
+_OVERRIDE = os.environ.get("MHTE_LIBRARY")
 
 MHTE_OK = 0
 MHTE_INVALID_ARGUMENT = 3
@@ -131,7 +134,7 @@ def lib():
           raise MhteError(MHTE_UNAVAILABLE,
                           "libmhte.so is missing and could not be built (%s); the MI355X engine "
                           "has no fallback path" % e)
-    L = C.CDLL(_SO)
+    L = C.CDLL(_OVERRIDE or _SO)
     for name in EXPORTS:
       if not hasattr(L, name):
         raise MhteError(MHTE_INTERNAL, "libmhte.so does not export %s" % name)
