@@ -251,8 +251,8 @@ def main():
 
     def run_sharded(lo, hi):
       for s in range(lo, hi):
-        se.lookup(ids_all[s])
-        se.apply_gradients(grad_pool[s % 8], S.update_time(s), next_ids=ids_all[s + 1])
+        se.lookup(ids_all[s], next_ids=ids_all[s + 1])
+        se.apply_gradients(grad_pool[s % 8], S.update_time(s))
 
     run_sharded(0, W)
     barrier()

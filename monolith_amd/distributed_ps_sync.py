@@ -214,11 +214,14 @@ def shard_of(ids: torch.Tensor, num_shards: int) -> torch.Tensor:
 class ShardedEmbedding:
   """All-to-all sharded lookup / apply_gradients for one table.
 
-  ``apply_gradients(..., next_ids=...)`` starts the id dispatch of the following batch (dedup,
-  shard packing, size + id exchanges, owner-side dedup — everything that depends on ids only) on a
-  side stream, as the reference's prefetch queue does (distributed_ps_sync.py:199-203); the next
-  ``lookup`` (which must receive that same tensor) then only has the owner lookup, the row
-  exchange and the scatter on its critical path."""
+  ``lookup(ids, next_ids=...)`` also starts the id dispatch of the FOLLOWING batch (dedup, shard
+  packing, size + id exchanges, owner-side dedup — everything that depends on ids only) on a side
+  stream, as the reference's prefetch queue does (distributed_ps_sync.py:199-203): it runs beside
+  this step's row exchange, scatter, dense model and backward, and the next ``lookup`` (which must
+  receive that same tensor) only has the owner lookup, the row exchange and the scatter on its
+  critical path.  ``next_ids`` must already be materialised (it comes from the input pipeline): the
+  side stream does not wait for work queued on the caller's stream, only for the previous user of
+  the state slot it writes."""
 
   def __init__(self, backend: LocalBackend, group: Optional[dist.ProcessGroup] = None):
     self.backend = backend
@@ -233,6 +236,7 @@ class ShardedEmbedding:
     self._pre = None      # dispatch prepared ahead: (key, dispatch tuple, event)
     self._slot = 0
     self._side = None
+    self._slot_free = [None, None]   # event: the step that last used the slot has been enqueued
 
   def _a2a(self, out, inp, out_splits=None, in_splits=None):
     if self._gloo and inp.is_cuda:
@@ -264,7 +268,7 @@ class ShardedEmbedding:
       be.owner_prepare(recv_ids)
     return (slot, send_pos, sc, rc, recv_ids, U, M)
 
-  def lookup(self, ids: torch.Tensor) -> torch.Tensor:
+  def lookup(self, ids: torch.Tensor, next_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
     """ids int64 [B] on this rank -> rows fp32 [B, D]."""
     D, be = self.dim, self.backend
     dev = ids.device
@@ -284,6 +288,8 @@ class ShardedEmbedding:
     self._a2a(back, rows, sc, rc)                                       # exchange #3: rows
     out = be.scatter(back, send_pos, ids.numel())                       # rows -> occurrences
     self._ctx = disp
+    if next_ids is not None:
+      self._prefetch(next_ids, 1 - slot)
     return out
 
   def apply_gradients(self, grads: torch.Tensor, update_time: int, global_step: int = 0,
@@ -299,22 +305,25 @@ class ShardedEmbedding:
     be.owner_apply(recv_ids, recv, update_time, global_step)
     self._ctx = None
     self._slot = 1 - slot
-    if next_ids is not None:
-      self._prefetch(next_ids)
+    if grads.is_cuda:
+      ev = torch.cuda.Event()
+      ev.record(torch.cuda.current_stream())
+      self._slot_free[slot] = ev
+    if next_ids is not None and self._pre is None:
+      self._prefetch(next_ids, self._slot)
 
-  def _prefetch(self, ids: torch.Tensor):
+  def _prefetch(self, ids: torch.Tensor, slot: int):
     key = (ids.data_ptr(), ids.numel())
     if not ids.is_cuda:
-      self._pre = (key, self._dispatch(ids, self._slot), None)
+      self._pre = (key, self._dispatch(ids, slot), None)
       return
     if self._side is None:
       self._side = torch.cuda.Stream(device=ids.device)
     main = torch.cuda.current_stream()
-    start = torch.cuda.Event()
-    start.record(main)               # (the ids may have been produced on the main stream)
-    self._side.wait_event(start)
+    if self._slot_free[slot] is not None:   # the slot's previous step must have finished with it
+      self._side.wait_event(self._slot_free[slot])
     with torch.cuda.stream(self._side):
-      disp = self._dispatch(ids, self._slot)
+      disp = self._dispatch(ids, slot)
       ev = torch.cuda.Event()
       ev.record(self._side)
     for t in (disp[1], disp[4]):     # consumed on the main stream later

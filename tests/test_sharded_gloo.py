@@ -28,6 +28,19 @@ class OracleBackend:
     self.O = O
     self.dim = DIM
     self.t = O.Table(O.segment(DIM, O.OPT_ADAGRAD, p=(0.1, 0.0)), 1)
+    self._inv = [None, None]   # per state slot: the next batch is dispatched beside this one
+    self._slot = 0
+
+  def use_slot(self, i):
+    self._slot = i & 1
+
+  @property
+  def inv(self):
+    return self._inv[self._slot]
+
+  @inv.setter
+  def inv(self, v):
+    self._inv[self._slot] = v
 
   def dedup(self, ids):
     a = ids.numpy()
@@ -93,10 +106,10 @@ def _worker(rank, world, port, out_dir):
   batches = [torch.from_numpy(_batch(rank, s)[0]) for s in range(STEPS + 1)]
   for s in range(STEPS):
     _, g = _batch(rank, s)
-    e = se.lookup(batches[s])
-    embs.append(e.numpy().copy())
     # odd steps also prepare the id dispatch of the next batch ahead (prefetch path)
-    se.apply_gradients(torch.from_numpy(g), 100 + s, next_ids=batches[s + 1] if s % 2 else None)
+    e = se.lookup(batches[s], next_ids=batches[s + 1] if s % 2 else None)
+    embs.append(e.numpy().copy())
+    se.apply_gradients(torch.from_numpy(g), 100 + s)
   d_ids, _, _, d_rows = be.t.dump()
   np.savez(os.path.join(out_dir, "rank%d.npz" % rank), embs=np.stack(embs), ids=d_ids, rows=d_rows)
   dist.destroy_process_group()
@@ -181,11 +194,10 @@ def _gpu_worker(rank, world, port, out_dir):
   batches = [torch.from_numpy(_gpu_batch(rank, s)[0]).cuda() for s in range(GPU_STEPS + 1)]
   for s in range(GPU_STEPS):
     _, g = _gpu_batch(rank, s)
-    e = se.lookup(batches[s])
-    embs.append(e.cpu().numpy().copy())
     # the id dispatch of the next batch is prepared on a side stream (prefetch path), except once
-    se.apply_gradients(torch.from_numpy(g).cuda(), 100 + s,
-                       next_ids=batches[s + 1] if s != 1 else None)
+    e = se.lookup(batches[s], next_ids=batches[s + 1] if s != 1 else None)
+    embs.append(e.cpu().numpy().copy())
+    se.apply_gradients(torch.from_numpy(g).cuda(), 100 + s)
   d_ids, _, _, d_rows = mt.dump("emb")
   np.savez(os.path.join(out_dir, "rank%d.npz" % rank), embs=np.stack(embs),
            ids=d_ids.cpu().numpy(), rows=d_rows.cpu().numpy())
