@@ -233,9 +233,11 @@ struct DedupWs {
   int r_stage = 0;           // 0 idle, 1 dedup enqueued, 2 work list enqueued (ready for apply)
   RunView rv{};
 
+  // items of a list of c occurrences < c / target + 1 (rd_item_blocks), lists > kLightMax
   static uint32_t max_items(int64_t n) {
-    return uint32_t(n / 128 + n / (kLightMax + 1) + 2);
+    return uint32_t(n / item_target() + n / (kLightMax + 1) + 2);
   }
+  static uint32_t item_target() { return kItemTarget; }
 
   // Arguments of a run dedup of ids[0, n), n <= 65 536; the caller enqueues rd_dedup (on its own or
   // inside step_fwd).  A dedup that was never built leaves the scratch dirty: clear first (the
@@ -269,6 +271,7 @@ struct DedupWs {
     d.uslot = r_uslot.p; d.ucnt = r_ucnt.p; d.ublk = r_ublk.p; d.upos = r_upos.p; d.btab_key = r_btab_key.p; d.btab_val = r_btab_val.p; d.seg = r_seg.p;
     d.item_hdr = r_item_hdr.p; d.item_runs = r_item_runs.p; d.ctr = r_ctr.p;
     d.ids = ids; d.n = uint32_t(n); d.nblk = nblk; d.uids = uids; d.n_unique = n_unique_dev;
+    d.item_target = item_target();
     if (r_hkey.p != old_key || r_ctr.p != old_ctr || C > r_clean_cap || r_stage == 1) {
       rd_clear_kernel<<<(C + 2 + 255) / 256, 256, 0, st>>>(d);
       r_clean_cap = C;
@@ -559,7 +562,7 @@ struct Table {
   // Called before every mutating op with the number of ids it may insert.
   void ensure_capacity(uint64_t n, hipStream_t st) {
     keys_upper += n;
-    rows_upper += n;
+    rows_upper += n + kSpecSlackRows;
     const uint64_t row_cap = uint64_t(chunks.size()) << chunk_shift;
     const bool need_keys = double(keys_upper) > max_load * double(uint64_t(kSlots) << hp);
     const bool need_rows = rows_upper > row_cap;
@@ -575,7 +578,7 @@ struct Table {
     }
     sync_counters(st);
     keys_upper = (h_ctr->alloc >> 32) + n;
-    rows_upper = (h_ctr->alloc & 0xffffffffull) + n;
+    rows_upper = (h_ctr->alloc & 0xffffffffull) + n + kSpecSlackRows;
     if ((h_ctr->alloc >> 32) == 0) {
       // nothing to migrate: jump straight to the needed hashpower
       uint32_t want = hp;

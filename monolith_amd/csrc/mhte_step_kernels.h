@@ -44,6 +44,7 @@ constexpr int kRdMaxBlocks = 64;        // bits of the workgroup mask: n <= 65 5
 constexpr int kLongRun = kLightMax;  // (a run that may belong to a light list keeps its positions in LDS)
 constexpr int kMaxLongRuns = 16;
 constexpr uint32_t kItemTarget = 256;   // entries per heavy work item (expected)
+constexpr uint32_t kSpecSlackRows = 32; // row handles an update may strand (upsert_issue), per op
 constexpr int kBwdBlocksPerCu = 5;      // 256-thread workgroups of step_bwd resident per CU (<= 96 VGPRs)
 
 // Workgroup barrier for LDS traffic only.  __syncthreads() also drains every outstanding global
@@ -97,6 +98,7 @@ struct RunView {
   const int64_t* ids;
   uint32_t n;
   uint32_t nblk;                // ceil(n / 1024) <= 64; 0 = nothing to do
+  uint32_t item_target;         // expected entries per heavy work item
   int64_t* uids;                // out (build role): unique ids, unspecified order
   uint32_t* n_unique;           // out (build role)
 };
@@ -315,9 +317,9 @@ __device__ __forceinline__ uint32_t rd_find_run(const RunView& d, uint32_t b, in
 }
 
 // workgroups per item for a list of c occurrences: power of two, ~kItemTarget entries expected
-__device__ __forceinline__ uint32_t rd_item_blocks(uint32_t c) {
+__device__ __forceinline__ uint32_t rd_item_blocks(uint32_t c, uint32_t target) {
   uint32_t nbk = 64;
-  while (nbk > 1 && uint64_t(c) * nbk > uint64_t(kItemTarget) * 64 * 2) nbk >>= 1;
+  while (nbk > 1 && uint64_t(c) * nbk > uint64_t(target) * 64 * 2) nbk >>= 1;
   return nbk;
 }
 
@@ -403,7 +405,7 @@ __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_m
         const int64_t id = __shfl(key[q], src);
         const unsigned long long bm = __shfl(blk[q], src);
         const bool has = (bm >> lane) & 1ull;
-        const uint32_t nbk = rd_item_blocks(c);
+        const uint32_t nbk = rd_item_blocks(c, d.item_target);
         const uint32_t b0 = uint32_t(lane) & ~(nbk - 1u);
         const unsigned long long rmask = (nbk == 64 ? ~0ull : ((1ull << nbk) - 1ull)) << b0;
         const bool leader = (uint32_t(lane) == b0) && (bm & rmask) != 0ull;
@@ -556,6 +558,162 @@ __device__ __forceinline__ void sum_list_lds(const float* __restrict__ grads, ui
   }
 }
 
+// upsert_resolve (mhte_kernels.h) in two halves.  A new id costs two returning atomics — the slot
+// claim (CAS on the key word) and the row allocation — of 2-3 us each under load, and a wavefront
+// holds several ids: done one after the other they also hold back the row loads of the FOUND ids
+// next to them.  upsert_issue puts the claims in flight and says which groups need a row; the
+// caller allocates for them speculatively (ONE bump of the table's counter per workgroup: that
+// address takes every allocation of the launch, and same-address atomics are served one after the
+// other) and issues its row / gradient loads; upsert_complete consumes the results.  A claim lost
+// to another id falls back to upsert_resolve's loop (the row is kept); an id that then finds both
+// buckets full is deferred: its speculative row handle is never used (the host's row accounting
+// carries slack for these, kSpecSlackRows) and its key count is taken back.
+template <int G>
+struct UpsertFlight {
+  unsigned long long cas_old;
+  uint64_t specm;     // leader lanes of the groups that get a speculative row
+  int owner, pick;
+  bool found, need, special, deferred;
+};
+
+template <int G>
+__device__ __forceinline__ UpsertFlight<G> upsert_issue(const TableView& tv, Bucket* b, int64_t id,
+                                                        bool valid, int64_t k, int lane) {
+  const int j = lane & (G - 1);
+  const int gbase = lane & ~(G - 1);
+  UpsertFlight<G> f;
+  f.special = valid && id == kEmptyKey;
+  const bool prober = valid && !f.special && j < 8;
+  const uint64_t m = group_mask_of<G>(__ballot(prober && k == id), gbase);
+  f.found = m != 0;
+  f.owner = f.found ? (__ffsll(static_cast<long long>(m)) - 1) : -1;
+  f.need = valid && !f.special && !f.found;
+  f.deferred = false;
+  const uint64_t em = group_mask_of<G>(__ballot(prober && k == kEmptyKey), gbase) & 0xffull;
+  const uint32_t m1 = uint32_t(em) & 0xfu, m2 = (uint32_t(em) >> 4) & 0xfu;
+  f.pick = -1;
+  if (m1) f.pick = 31 - __clz(m1);
+  else if (m2) f.pick = 4 + (31 - __clz(m2));
+  if (f.need && f.pick < 0) {  // both buckets full -> displacement pass
+    f.deferred = true;
+    f.need = false;
+  }
+  f.cas_old = 0ull;
+  if (f.need && j == f.pick)
+    f.cas_old = atomicCAS(reinterpret_cast<unsigned long long*>(&b->key[j & 3]),
+                          static_cast<unsigned long long>(kEmptyKey), static_cast<unsigned long long>(id));
+  f.specm = __ballot(f.need && j == 0);
+  return f;
+}
+
+template <int G>
+__device__ __forceinline__ SlotResult upsert_complete(const TableView& tv, Bucket* b, int64_t id,
+                                                      bool valid, uint32_t row, int lane, uint32_t ts,
+                                                      const UpsertFlight<G>& f, uint32_t base_row) {
+  const int j = lane & (G - 1);
+  const int gbase = lane & ~(G - 1);
+  const int s = j & 3;
+  const bool prober = valid && !f.special && j < 8;
+  bool need = f.need, deferred = f.deferred, found = f.found, is_new = false;
+  int owner = f.owner;
+  int64_t k = 0;  // (only read by lanes that lost a claim)
+  bool won = false;
+  if (need && j == f.pick) {
+    won = static_cast<int64_t>(f.cas_old) == kEmptyKey;
+    k = won ? id : static_cast<int64_t>(f.cas_old);
+  }
+  {
+    const uint64_t wm = group_mask_of<G>(__ballot(won), gbase);
+    if (need && wm) {
+      owner = f.pick;
+      is_new = true;
+      need = false;
+    }
+  }
+  if (__any(need)) {
+    // the slot went to another id in the meantime: re-read the two buckets and claim again
+    // (cuckoohash_map.hpp:1398-1418, as upsert_resolve does)
+    if (prober) k = __hip_atomic_load(&b->key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__any(need)) {
+      const uint64_t em = group_mask_of<G>(__ballot(prober && k == kEmptyKey), gbase) & 0xffull;
+      int pick = -1;
+      if (need) {
+        const uint32_t m1 = uint32_t(em) & 0xfu, m2 = (uint32_t(em) >> 4) & 0xfu;
+        if (m1) pick = 31 - __clz(m1);
+        else if (m2) pick = 4 + (31 - __clz(m2));
+        if (pick < 0) {
+          deferred = true;
+          need = false;
+        }
+      }
+      bool w2 = false;
+      if (need && j == pick) {
+        const unsigned long long old =
+            atomicCAS(reinterpret_cast<unsigned long long*>(&b->key[s]),
+                      static_cast<unsigned long long>(kEmptyKey), static_cast<unsigned long long>(id));
+        w2 = (static_cast<int64_t>(old) == kEmptyKey);
+        k = w2 ? id : static_cast<int64_t>(old);
+      }
+      const uint64_t wm = group_mask_of<G>(__ballot(w2), gbase);
+      if (need && wm) {
+        owner = pick;
+        is_new = true;
+        need = false;
+      }
+    }
+  }
+  if (f.special) {  // side slot of the one key that cannot live in a bucket
+    unsigned int st = 0;
+    if (j == 0) st = atomicExch(&tv.ctr->special_state, 1u);
+    st = __shfl(st, gbase);
+    found = true;
+    is_new = (st == 0);
+  }
+  (void)found;
+  // rows: the speculative handles (base_row = this wavefront's first; the bump counted them as
+  // live keys too); the side slot's row (rare) with its own bump; speculated keys that ended up
+  // deferred are taken back
+  const bool leader_new = is_new && j == 0;
+  const uint64_t newm = __ballot(leader_new);
+  const uint64_t extra = newm & ~f.specm;
+  const uint64_t lostm = f.specm & ~newm;
+  uint32_t base2 = 0;
+  if (extra) {
+    const int first2 = __ffsll(static_cast<long long>(extra)) - 1;
+    if (lane == first2)
+      base2 = static_cast<uint32_t>(
+          atomicAdd(&tv.ctr->alloc, static_cast<unsigned long long>(__popcll(extra))));
+    base2 = __shfl(base2, first2);
+  }
+  if (lostm && lane == __ffsll(static_cast<long long>(lostm)) - 1)
+    atomicAdd(&tv.ctr->alloc, ~((static_cast<unsigned long long>(__popcll(lostm)) << 32) - 1ull));
+  const uint32_t found_row = __shfl(row, gbase + (owner < 0 ? 0 : owner));
+  const uint64_t below = (uint64_t(1) << gbase) - 1;
+  uint32_t r;
+  if (is_new) {
+    r = ((f.specm >> gbase) & 1ull) ? base_row + uint32_t(__popcll(f.specm & below))
+                                    : base2 + uint32_t(__popcll(extra & below));
+  } else {
+    r = found_row;
+  }
+  if (f.special) {
+    if (is_new) {
+      if (j == 0) tv.ctr->special_row = r;
+    } else {
+      r = tv.ctr->special_row;  // written by an earlier kernel
+    }
+    if (j == 0) tv.ctr->special_ts = ts;
+  } else if (valid && !deferred && j == owner) {
+    if (is_new) b->row[s] = r;
+    b->ts[s] = ts;  // SetTimestamp(update_time), cuckoo_embedding_hash_table.cc:242-246
+  }
+  SlotResult out;
+  out.r = r;
+  out.is_new = is_new;
+  out.deferred = deferred;
+  return out;
+}
+
 template <int G, int VEC>
 __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView& d,
                                               const ApplyCtl& c, const ApplyArgs& a, uint32_t bid,
@@ -576,6 +734,9 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
     // consecutive indices (the claim order puts the hot ids first) land in different workgroups.
     // A group lives inside one wavefront, so its LDS hand-offs need no workgroup barrier.
     __shared__ uint32_t sh_pos[NG][kLightMax];
+    __shared__ uint32_t sh_need[4];   // rows each wavefront needs this trip
+    __shared__ uint32_t sh_rowbase;
+    const int wave = threadIdx.x >> 6;
     const int64_t stride = int64_t(c.nblk_ids) * NG;
     const int64_t k = bid - c.nblk_items;
     int64_t nu = c.n_max;  // refined below, once the count has arrived with the first trip's loads
@@ -624,16 +785,24 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         if (valid && j == 0) first = filter_consult(tv, id, cnt, 2, contained);
         if (__shfl(first, gbase) != 0u) valid = false;
       }
-      // round trip 3: the row
-      const SlotResult sr = upsert_resolve<G>(tv, pr.b, id, valid, pr.k, pr.row, lane, a.ts);
+      // round trip 3: slot claim + row handle of a new id | the row of a found one | (below) the
+      // gradients of a list — all in flight together
+      const UpsertFlight<G> uf = upsert_issue<G>(tv, pr.b, id, valid, pr.k, lane);
+      if (lane == 0) sh_need[wave] = uint32_t(__popcll(uf.specm));
+      lds_barrier();  // (the trip count is the same for the four wavefronts)
+      unsigned long long rows0 = 0;
+      if (threadIdx.x == 0) {
+        const unsigned long long tot = sh_need[0] + sh_need[1] + sh_need[2] + sh_need[3];
+        if (tot) rows0 = atomicAdd(&tv.ctr->alloc, (tot << 32) | tot);
+      }
       RowRegs<VEC> rr;
       vec_zero(rr.w);
       vec_zero(rr.s1);
       vec_zero(rr.s2);
-      float* rp = nullptr;
-      if (valid && !sr.deferred) {
-        rp = row_ptr(tv, sr.r);
-        if (!sr.is_new) row_prefetch<VEC>(tv, rp, e, rr);
+      const bool pre = valid && uf.found;
+      if (__any(pre)) {
+        const uint32_t frow = __shfl(pr.row, gbase + (uf.owner < 0 ? 0 : uf.owner));
+        if (pre) row_prefetch<VEC>(tv, row_ptr(tv, frow), e, rr);
       }
       if (__any(flat)) {
         uint32_t xr[PER];
@@ -683,6 +852,16 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
           }
         }
       }
+      if (threadIdx.x == 0) sh_rowbase = uint32_t(rows0);
+      lds_barrier();
+      uint32_t base_row = sh_rowbase;
+      for (int w2 = 0; w2 < wave; ++w2) base_row += sh_need[w2];
+      const SlotResult sr = upsert_complete<G>(tv, pr.b, id, valid, pr.row, lane, a.ts, uf, base_row);
+      float* rp = nullptr;
+      if (valid && !sr.deferred) {
+        rp = row_ptr(tv, sr.r);
+        if (!sr.is_new && !pre) row_prefetch<VEC>(tv, rp, e, rr);  // (the side slot's row)
+      }
       if (it == 0) wt.mark(3);
       if (sr.deferred) {
         if (ev) acc.store(c.grad_u + g * int64_t(dim) + e);
@@ -691,7 +870,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         optimize_row_pre<VEC>(tv, rp, sr.is_new, e, acc, a, rr);
       }
       if (it == 0) wt.mark(4);
-      lds_wave_sync();  // sh_pos is reused
+      lds_barrier();  // sh_pos / sh_need are reused
     }
     return;
   }
