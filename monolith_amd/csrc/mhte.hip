@@ -16,7 +16,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <atomic>
+#include <exception>
 #include <mutex>
+#include <thread>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -1566,6 +1569,11 @@ static uint64_t save_table_shard(Table& tb, int shard, int total, ckpt::RecordWr
   for (uint64_t s0 = begin * kSlots; s0 < end * kSlots; s0 += kChunkSlots) {
     const uint64_t s1 = std::min(end * kSlots, s0 + kChunkSlots);
     const uint32_t nblocks = uint32_t((s1 - s0 + 1023) / 1024);
+    uint64_t acc = 0;
+    {
+    // the table is held for the device scan + copy of a chunk only; the (much longer) encoding of
+    // the chunk runs beside the other shards' threads
+    std::lock_guard<std::mutex> g(tb.mu);
     bc.reserve(nblocks);
     bo.reserve(nblocks);
     dump_count_kernel<<<nblocks, 256, 0, st>>>(tb.view, s0, s1, bc.p);
@@ -1574,7 +1582,6 @@ static uint64_t save_table_shard(Table& tb, int shard, int total, ckpt::RecordWr
     HIP_OK(hipMemcpyAsync(hc.data(), bc.p, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     std::vector<uint64_t> ho(nblocks);
-    uint64_t acc = 0;
     for (uint32_t i = 0; i < nblocks; ++i) {
       ho[i] = acc;
       acc += hc[i];
@@ -1594,9 +1601,11 @@ static uint64_t save_table_shard(Table& tb, int shard, int total, ckpt::RecordWr
     HIP_OK(hipMemcpyAsync(h_ts.data(), d_ts.p, acc * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(h_rows.data(), d_rows.p, acc * rf * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
+    }
     for (uint64_t i = 0; i < acc; ++i) emit(h_ids[i], h_rows.data() + i * rf, h_ts[i]);
   }
   if (shard == 0 && tb.h_ctr->special_state == 1) {
+    std::lock_guard<std::mutex> g(tb.mu);
     // the one key that lives in the side slot (kEmptyKey itself): last entry of shard 0
     std::vector<float> row(rf);
     Counters c;
@@ -1610,6 +1619,20 @@ static uint64_t save_table_shard(Table& tb, int shard, int total, ckpt::RecordWr
   return written;
 }
 
+// shard jobs 0..n-1 on at most 16 host threads (the caller's included); jobs catch their own errors
+template <typename F>
+static void run_shard_jobs(int n, F&& job) {
+  std::atomic<int> next{0};
+  auto worker = [&] {
+    for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) job(i);
+  };
+  std::vector<std::thread> th;
+  const int extra = std::min(n, 16) - 1;
+  for (int i = 0; i < extra; ++i) th.emplace_back(worker);
+  worker();
+  for (auto& x : th) x.join();
+}
+
 static void save_multi_table(mhte_multi_table* t, const std::string& basename, int nshards,
                              hipStream_t st) {
   int64_t total = 0;
@@ -1621,26 +1644,41 @@ static void save_multi_table(mhte_multi_table* t, const std::string& basename, i
   // PickNshards, multi_hash_table_save_restore_ops.cc:240-248
   if (nshards < 0) nshards = int(std::min<int64_t>(4, std::max<int64_t>(1, total / 1000000)));
   if (nshards < 1) nshards = 1;
-  for (int sh = 0; sh < nshards; ++sh) {
-    const std::string fn = ckpt::shard_name(basename, "", sh, nshards);
-    const std::string mfn = ckpt::shard_name(basename, ".meta", sh, nshards);
-    const std::string tmp = fn + "-tmp-" + std::to_string(uint64_t(getpid())) + "-" + std::to_string(sh);
-    const std::string mtmp = mfn + "-tmp-" + std::to_string(uint64_t(getpid())) + "-" + std::to_string(sh);
-    {
-      ckpt::RecordWriter w(tmp, true), mw(mtmp, false);
-      std::string meta;
-      for (auto& tb : t->tables) {
-        std::lock_guard<std::mutex> g(tb->mu);
-        const uint64_t n = save_table_shard(*tb, sh, nshards, w, st);
-        ckpt::encode_meta(meta, tb->name, n);
-        mw.write(meta);
+  // one thread per shard (the reference schedules its shards on the op's thread pool,
+  // multi_hash_table_save_restore_ops.cc:250-262), each with a stream of its own
+  HIP_OK(hipStreamSynchronize(st));
+  std::vector<std::exception_ptr> err;
+  err.resize(size_t(nshards));
+  auto shard_job = [&](int sh) {
+    hipStream_t s2 = nullptr;
+    try {
+      HIP_OK(hipSetDevice(t->device));
+      HIP_OK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+      const std::string fn = ckpt::shard_name(basename, "", sh, nshards);
+      const std::string mfn = ckpt::shard_name(basename, ".meta", sh, nshards);
+      const std::string tmp = fn + "-tmp-" + std::to_string(uint64_t(getpid())) + "-" + std::to_string(sh);
+      const std::string mtmp = mfn + "-tmp-" + std::to_string(uint64_t(getpid())) + "-" + std::to_string(sh);
+      {
+        ckpt::RecordWriter w(tmp, true), mw(mtmp, false);
+        std::string meta;
+        for (auto& tb : t->tables) {
+          const uint64_t n = save_table_shard(*tb, sh, nshards, w, s2);
+          ckpt::encode_meta(meta, tb->name, n);
+          mw.write(meta);
+        }
+        w.close();
+        mw.close();
       }
-      w.close();
-      mw.close();
+      if (rename(tmp.c_str(), fn.c_str()) != 0 || rename(mtmp.c_str(), mfn.c_str()) != 0)
+        throw Error(MHTE_INTERNAL, "checkpoint: cannot rename into " + fn);
+    } catch (...) {
+      err[size_t(sh)] = std::current_exception();
     }
-    if (rename(tmp.c_str(), fn.c_str()) != 0 || rename(mtmp.c_str(), mfn.c_str()) != 0)
-      throw Error(MHTE_INTERNAL, "checkpoint: cannot rename into " + fn);
-  }
+    if (s2) (void)hipStreamDestroy(s2);
+  };
+  run_shard_jobs(nshards, shard_job);
+  for (auto& e : err)
+    if (e) std::rethrow_exception(e);
 }
 
 // rows of one restore batch -> table (upsert of whole rows with their own timestamps)
@@ -1667,19 +1705,9 @@ static void restore_batch(Table& tb, const std::vector<int64_t>& ids, const std:
   HIP_OK(hipStreamSynchronize(st));  // the staging buffers go out of scope
 }
 
-static void restore_multi_table(mhte_multi_table* t, const std::string& basename, hipStream_t st) {
-  // the shard count is in the file names: <basename>-00000-of-<total>
-  int total = 0;
-  for (int cand = 1; cand <= 4096 && !total; ++cand) {
-    FILE* f = fopen(ckpt::shard_name(basename, "", 0, cand).c_str(), "rb");
-    if (f) {
-      fclose(f);
-      total = cand;
-    }
-  }
-  if (!total) throw Error(MHTE_NOT_FOUND, "no checkpoint shards found for " + basename);
-  std::vector<bool> seen(t->tables.size(), false);
-  for (int sh = 0; sh < total; ++sh) {
+static void restore_shard(mhte_multi_table* t, const std::string& basename, int sh, int total,
+                          hipStream_t st) {
+  {
     ckpt::RecordReader data(ckpt::shard_name(basename, "", sh, total), true);
     ckpt::RecordReader meta(ckpt::shard_name(basename, ".meta", sh, total), false);
     std::string mrec, rec, name;
@@ -1694,9 +1722,8 @@ static void restore_multi_table(mhte_multi_table* t, const std::string& basename
           if (!data.read(&rec)) throw Error(MHTE_INTERNAL, "checkpoint shard ends early");
         continue;
       }
-      seen[size_t(idx)] = true;
       Table& tb = *t->tables[size_t(idx)];
-      std::lock_guard<std::mutex> g(tb.mu);
+      // (layout and initial values are fixed at creation: read without the table's lock)
       const std::vector<ckpt::SegLayout> segs = seg_layout(tb);
       const uint32_t rf = tb.row_floats;
       // a row starts from initializer + optimizer Init (UpsertEntry's init_fn), then the dump
@@ -1719,15 +1746,24 @@ static void restore_multi_table(mhte_multi_table* t, const std::string& basename
       std::vector<int64_t> ids;
       std::vector<uint32_t> ts;
       std::vector<float> rows;
+      std::vector<int64_t> sorted;
+      int64_t max_ts = 0;
+      // ids inside one batch must be distinct for the upsert: a checkpoint holds each id once per
+      // table, but two shards of a foreign writer could repeat one — later entries win by flushing
       auto flush = [&] {
-        restore_batch(tb, ids, rows, ts, st);
+        sorted = ids;
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+          throw Error(MHTE_INVALID_ARGUMENT, "checkpoint repeats an id inside table " + name);
+        {
+          std::lock_guard<std::mutex> g(tb.mu);
+          tb.max_update_ts = std::max<int64_t>(tb.max_update_ts, max_ts);
+          restore_batch(tb, ids, rows, ts, st);
+        }
         ids.clear();
         ts.clear();
         rows.clear();
       };
-      // ids inside one batch must be distinct for the upsert: a checkpoint holds each id once per
-      // table, but two shards of a foreign writer could repeat one — later entries win by flushing
-      std::vector<int64_t> sorted;
       for (uint64_t i = 0; i < num; ++i) {
         if (!data.read(&rec)) throw Error(MHTE_INTERNAL, "checkpoint shard ends early");
         int64_t id;
@@ -1737,23 +1773,45 @@ static void restore_multi_table(mhte_multi_table* t, const std::string& basename
                            int(tb.dim), &id, rows.data() + rows.size() - rf, &tsv);
         ids.push_back(id);
         ts.push_back(tsv);
-        tb.max_update_ts = std::max<int64_t>(tb.max_update_ts, int64_t(tsv));
-        if (ids.size() == kBatch) {
-          sorted = ids;
-          std::sort(sorted.begin(), sorted.end());
-          if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
-            throw Error(MHTE_INVALID_ARGUMENT, "checkpoint repeats an id inside table " + name);
-          flush();
-        }
+        max_ts = std::max<int64_t>(max_ts, int64_t(tsv));
+        if (ids.size() == kBatch) flush();
       }
-      sorted = ids;
-      std::sort(sorted.begin(), sorted.end());
-      if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
-        throw Error(MHTE_INVALID_ARGUMENT, "checkpoint repeats an id inside table " + name);
       flush();
     }
     if (data.read(&rec)) throw Error(MHTE_INTERNAL, "Couldn't read all of checkpoint shard");
   }
+}
+
+static void restore_multi_table(mhte_multi_table* t, const std::string& basename, hipStream_t st) {
+  // the shard count is in the file names: <basename>-00000-of-<total>
+  int total = 0;
+  for (int cand = 1; cand <= 4096 && !total; ++cand) {
+    FILE* f = fopen(ckpt::shard_name(basename, "", 0, cand).c_str(), "rb");
+    if (f) {
+      fclose(f);
+      total = cand;
+    }
+  }
+  if (!total) throw Error(MHTE_NOT_FOUND, "no checkpoint shards found for " + basename);
+  // one thread per shard file: decoding (the long part) runs in parallel, a table is held only
+  // while a decoded batch is upserted
+  HIP_OK(hipStreamSynchronize(st));
+  std::vector<std::exception_ptr> err;
+  err.resize(size_t(total));
+  auto shard_job = [&](int sh) {
+    hipStream_t s2 = nullptr;
+    try {
+      HIP_OK(hipSetDevice(t->device));
+      HIP_OK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+      restore_shard(t, basename, sh, total, s2);
+    } catch (...) {
+      err[size_t(sh)] = std::current_exception();
+    }
+    if (s2) (void)hipStreamDestroy(s2);
+  };
+  run_shard_jobs(total, shard_job);
+  for (auto& e : err)
+    if (e) std::rethrow_exception(e);
 }
 
 }  // namespace mhte

@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <stdexcept>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -34,25 +35,61 @@ namespace mhte {
 namespace ckpt {
 
 // ------------------------------------------------------------------------------------ crc32c
-inline const uint32_t* crc32c_table() {
-  static uint32_t table[256];
-  static bool init = false;
-  if (!init) {
+// Slicing-by-8 tables (8 bytes per step); the SSE4.2 crc32 instruction (the same polynomial) is
+// used when the host has it — the record stream of a large table is gigabytes of this.
+struct Crc32cTables {
+  uint32_t t[8][256];
+  Crc32cTables() {
     for (uint32_t i = 0; i < 256; ++i) {
       uint32_t c = i;
       for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : (c >> 1);
-      table[i] = c;
+      t[0][i] = c;
     }
-    init = true;
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int k = 1; k < 8; ++k) t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xffu];
   }
-  return table;
+};
+inline const Crc32cTables& crc32c_tables() {
+  static const Crc32cTables tabs;  // (thread-safe initialisation)
+  return tabs;
 }
+inline uint32_t crc32c_soft(uint32_t c, const uint8_t* p, size_t n) {
+  const Crc32cTables& T = crc32c_tables();
+  while (n >= 8) {
+    uint64_t v;
+    memcpy(&v, p, 8);
+    v ^= c;
+    c = T.t[7][v & 0xff] ^ T.t[6][(v >> 8) & 0xff] ^ T.t[5][(v >> 16) & 0xff] ^
+        T.t[4][(v >> 24) & 0xff] ^ T.t[3][(v >> 32) & 0xff] ^ T.t[2][(v >> 40) & 0xff] ^
+        T.t[1][(v >> 48) & 0xff] ^ T.t[0][v >> 56];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) c = T.t[0][(c ^ *p++) & 0xffu] ^ (c >> 8);
+  return c;
+}
+#if defined(__x86_64__)
+__attribute__((target("sse4.2"))) inline uint32_t crc32c_hw(uint32_t c, const uint8_t* p, size_t n) {
+  uint64_t c64 = c;
+  while (n >= 8) {
+    uint64_t v;
+    memcpy(&v, p, 8);
+    c64 = __builtin_ia32_crc32di(c64, v);
+    p += 8;
+    n -= 8;
+  }
+  c = uint32_t(c64);
+  while (n--) c = __builtin_ia32_crc32qi(c, *p++);
+  return c;
+}
+#endif
 inline uint32_t crc32c(const void* data, size_t n) {
-  const uint32_t* t = crc32c_table();
   const uint8_t* p = static_cast<const uint8_t*>(data);
-  uint32_t c = 0xffffffffu;
-  for (size_t i = 0; i < n; ++i) c = t[(c ^ p[i]) & 0xffu] ^ (c >> 8);
-  return c ^ 0xffffffffu;
+#if defined(__x86_64__)
+  static const bool hw = __builtin_cpu_supports("sse4.2");
+  if (hw) return crc32c_hw(0xffffffffu, p, n) ^ 0xffffffffu;
+#endif
+  return crc32c_soft(0xffffffffu, p, n) ^ 0xffffffffu;
 }
 inline uint32_t masked_crc(const void* data, size_t n) {
   const uint32_t c = crc32c(data, n);
@@ -126,38 +163,67 @@ struct SegLayout {
 // EntryDump of one row (embedding_hash_table.proto:45-50; EntryAccessor::Save, entry_accessor.cc
 // :218-226; optimizer Save()s: sgd_optimizer.cc:50-54, adagrad_optimizer.cc:62-70,
 // ftrl_optimizer.cc:78-88; one SingleOptimizerDump per segment, optimizer_combination.cc:73-84)
+inline int varint_len(uint64_t v) {
+  int n = 1;
+  while (v >= 0x80) {
+    v >>= 7;
+    ++n;
+  }
+  return n;
+}
+inline char* put_varint_raw(char* p, uint64_t v) {
+  while (v >= 0x80) {
+    *p++ = char((v & 0x7f) | 0x80);
+    v >>= 7;
+  }
+  *p++ = char(v);
+  return p;
+}
+inline char* put_f32_raw(char* p, uint8_t tag, float f) {
+  *p++ = char(tag);
+  memcpy(p, &f, 4);  // (little-endian host)
+  return p + 4;
+}
+// (sizes first, then one pass over a buffer of the final size: a checkpoint is one of these per row)
 inline void encode_entry(std::string& out, int64_t id, const float* row,
                          const std::vector<SegLayout>& segs, int dim, uint32_t ts) {
-  out.clear();
-  out.push_back(char(0x09));  // id: field 1, sfixed64
-  uint64_t u = uint64_t(id);
-  for (int i = 0; i < 8; ++i) out.push_back(char(u >> (8 * i)));
-  for (int i = 0; i < dim; ++i) put_f32(out, 0x15, row[i]);  // num: field 2, float, unpacked
-  std::string opt;
+  size_t opt_size = 0;
   for (const SegLayout& s : segs) {
-    std::string single;
     const DumpSpec ds = dump_spec(s.kind);
-    std::string m;
+    const size_t m = 5u * (size_t(ds.nvec) * s.dim + (ds.scal_field[0] ? 1 : 0) + (ds.scal_field[1] ? 1 : 0));
+    const size_t single = 1 + varint_len(m) + m;
+    opt_size += 1 + varint_len(single) + single;
+  }
+  out.resize(9 + 5u * size_t(dim) + 1 + varint_len(opt_size) + opt_size + 1 + varint_len(ts));
+  char* p = &out[0];
+  *p++ = char(0x09);  // id: field 1, sfixed64
+  const uint64_t u = uint64_t(id);
+  memcpy(p, &u, 8);
+  p += 8;
+  for (int i = 0; i < dim; ++i) p = put_f32_raw(p, 0x15, row[i]);  // num: field 2, float, unpacked
+  *p++ = char(0x1a);  // opt: field 3
+  p = put_varint_raw(p, opt_size);
+  for (const SegLayout& s : segs) {
+    const DumpSpec ds = dump_spec(s.kind);
+    const size_t m = 5u * (size_t(ds.nvec) * s.dim + (ds.scal_field[0] ? 1 : 0) + (ds.scal_field[1] ? 1 : 0));
+    *p++ = char(0x0a);  // OptimizerDump.dump: field 1
+    p = put_varint_raw(p, 1 + varint_len(m) + m);
+    *p++ = char((ds.oneof_field << 3) | 2);
+    p = put_varint_raw(p, m);
     // protobuf serialises in field-number order: vectors (and scalars) sorted by field number
     for (int f = 1; f <= 5; ++f) {
       for (int k = 0; k < ds.nvec; ++k)
-        if (ds.vec_field[k] == f)
-          for (int i = 0; i < s.dim; ++i) put_f32(m, uint8_t((f << 3) | 5), row[s.st_off + k * s.dim + i]);
+        if (ds.vec_field[k] == f) {
+          const float* v = row + s.st_off + k * s.dim;
+          for (int i = 0; i < s.dim; ++i) p = put_f32_raw(p, uint8_t((f << 3) | 5), v[i]);
+        }
       for (int k = 0; k < 2; ++k)
-        if (ds.scal_field[k] == f) put_f32(m, uint8_t((f << 3) | 5), row[s.st_off + ds.nvec * s.dim + k]);
+        if (ds.scal_field[k] == f)
+          p = put_f32_raw(p, uint8_t((f << 3) | 5), row[s.st_off + ds.nvec * s.dim + k]);
     }
-    single.push_back(char((ds.oneof_field << 3) | 2));
-    put_varint(single, m.size());
-    single += m;
-    opt.push_back(char(0x0a));  // OptimizerDump.dump: field 1
-    put_varint(opt, single.size());
-    opt += single;
   }
-  out.push_back(char(0x1a));  // opt: field 3
-  put_varint(out, opt.size());
-  out += opt;
-  out.push_back(char(0x20));  // last_update_ts_sec: field 4, varint
-  put_varint(out, ts);
+  *p++ = char(0x20);  // last_update_ts_sec: field 4, varint
+  p = put_varint_raw(p, ts);
 }
 
 struct ProtoError : std::runtime_error {
@@ -443,14 +509,46 @@ class RecordWriter {
       if (buf_.size() == kSnappyBlock) flush_block();
     }
   }
+  // one raw snappy block made of literal elements (snappy_compress_literals' bytes, written
+  // straight from the buffer)
   void flush_block() {
     if (buf_.empty()) return;
-    std::string comp;
-    snappy_compress_literals(buf_.data(), buf_.size(), comp);
-    const uint32_t cl = uint32_t(comp.size());
-    const char be[4] = {char(cl >> 24), char(cl >> 16), char(cl >> 8), char(cl)};
-    if (fwrite(be, 1, 4, fp_) != 4 || fwrite(comp.data(), 1, comp.size(), fp_) != comp.size())
-      throw std::runtime_error("checkpoint write failed");
+    const size_t n = buf_.size();
+    auto tag_of = [](size_t len, char* t) -> size_t {
+      const size_t l1 = len - 1;
+      if (l1 < 60) {
+        t[0] = char(l1 << 2);
+        return 1;
+      }
+      if (l1 < 256) {
+        t[0] = char(60 << 2);
+        t[1] = char(l1);
+        return 2;
+      }
+      t[0] = char(61 << 2);
+      t[1] = char(l1 & 0xff);
+      t[2] = char(l1 >> 8);
+      return 3;
+    };
+    char t[3];
+    size_t cl = size_t(varint_len(n));
+    for (size_t i = 0; i < n; i += 65536) {
+      const size_t len = std::min<size_t>(n - i, 65536);
+      cl += tag_of(len, t) + len;
+    }
+    char head[4 + 10];
+    head[0] = char(cl >> 24);
+    head[1] = char(cl >> 16);
+    head[2] = char(cl >> 8);
+    head[3] = char(cl);
+    char* e = put_varint_raw(head + 4, n);
+    bool ok = fwrite(head, 1, size_t(e - head), fp_) == size_t(e - head);
+    for (size_t i = 0; i < n && ok; i += 65536) {
+      const size_t len = std::min<size_t>(n - i, 65536);
+      const size_t tl = tag_of(len, t);
+      ok = fwrite(t, 1, tl, fp_) == tl && fwrite(buf_.data() + i, 1, len, fp_) == len;
+    }
+    if (!ok) throw std::runtime_error("checkpoint write failed");
     buf_.clear();
   }
   FILE* fp_ = nullptr;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit: parity tests, bench line, rocprofv3 kernel trace of a short bench.
 # Usage (from the repo root on the GPU box): bash scripts/gpu_round.sh <tag> [what...]
-#   what: tests smoke bench prof tl trace pmc calib (default: tests bench prof)
+#   what: tests smoke bench prof tl trace pmc calib next (default: tests bench prof)
 set -u
 TAG=${1:-r01}; shift || true
 WHAT=${*:-tests bench prof}
@@ -54,5 +54,9 @@ calib)
     echo "calib $c rc=$?"
     for f in $(find /tmp/cal_$c -name '*counter_collection*.csv'); do python scripts/pmc_csv.py $f > $OUT/calib_${c}.md; head -8 $OUT/calib_${c}.md; done
   done ;;
+next)
+  # the rows next to the hot path: checkpoint, eviction, filter, gather, reductions, optimizers
+  NEXT_ROWS_MD=$OUT/next_rows.md timeout 900 python scripts/next_rows_bench.py > $OUT/next_rows.jsonl 2> $OUT/next_rows.err
+  echo "next rc=$?"; cat $OUT/next_rows.md; tail -5 $OUT/next_rows.err ;;
 esac
 done
