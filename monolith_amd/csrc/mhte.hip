@@ -363,6 +363,10 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
   } while (0)
 
 // ------------------------------------------------------------------------------------------ table
+// global_step of the API call being served on this thread (every entry point is synchronous on
+// its caller's thread); read by Table::upsert for the one optimizer that uses it (batch softmax)
+static thread_local int64_t t_global_step = 0;
+
 struct Table {
   std::string name;
   int device = 0;
@@ -434,6 +438,8 @@ struct Table {
         throw Error(MHTE_INVALID_ARGUMENT, "unknown optimizer type " + std::to_string(s.opt_type));
       if (s.init_type < MHTE_INIT_ZEROS || s.init_type > MHTE_INIT_CONSTANT)
         throw Error(MHTE_INVALID_ARGUMENT, "unknown initializer type");
+      if (s.opt_type == MHTE_OPT_BATCH_SOFTMAX && s.dim_size != 1)  // batch_softmax_optimizer.cc:29
+        throw Error(MHTE_INVALID_ARGUMENT, "a batch softmax segment has dim_size 1");
       dim += s.dim_size;
     }
     // row = float num[dim] | ctx(seg0) | ctx(seg1) ... (entry_accessor.cc:113-114)
@@ -692,6 +698,7 @@ struct Table {
     for (int i = 0; i < kMaxSegments; ++i) a.lr[i] = (lrs && i < int(nseg)) ? lrs[i] : 0.f;
     a.ts = static_cast<uint32_t>(update_time);
     a.sum_dups = (flags & MHTE_SUM_DUPLICATES) ? 1 : 0;
+    a.global_step = t_global_step;
     // admission filter (tf_bridge.cc): Assign / Optimize are guarded by Contains; the multi-table
     // AssignAdd goes through AssignAdd2, which is not (:230-232); Reinitialize never filters
     a.filter_mode = (OP == kOpReinit) ? 0 : (OP == kOpAssignAdd ? 3 : 1);
@@ -735,6 +742,7 @@ struct Table {
     a.ts = static_cast<uint32_t>(update_time);
     a.sum_dups = 1;
     a.filter_mode = 1;
+    a.global_step = 0;  // (the fused kernels take SGD / Adagrad / FTRL only)
     ensure_capacity(uint64_t(n_max), st);
     Shape sh = pick_shape(dim, vec_ok && aligned16(grads) && aligned16(grad_u));
     pending.reserve(size_t(n_max) + 1);
@@ -828,6 +836,7 @@ struct Table {
     a.ts = static_cast<uint32_t>(update_time);
     a.sum_dups = 1;
     a.filter_mode = 1;
+    a.global_step = 0;  // (the fused kernels take SGD / Adagrad / FTRL only)
     ensure_capacity(uint64_t(std::min<int64_t>(n_max, n)), st);
     Shape sh = pick_shape(dim, vec_ok && aligned16(grads) && aligned16(grad_u));
     pending.reserve(size_t(n_max) + 1);
@@ -1119,8 +1128,8 @@ mhte_status mhte_optimize(mhte_multi_table* t, const int64_t* id, const int64_t*
                           int64_t n_split, const float* value, int64_t value_len,
                           const float* learning_rate, int64_t n_learning_rate, int64_t update_time,
                           int64_t global_step, int32_t flags, void* stream) {
-  (void)global_step;  // consumed only by optimizers with warmup/step-dependent terms (not SGD/Adagrad/FTRL)
   return guard([&] {
+    mhte::t_global_step = global_step;  // (batch softmax)
     if (!learning_rate) throw Error(MHTE_INVALID_ARGUMENT, "learning_rate is null");
     ragged_upsert<kOpOptimize>(t, id, id_split, n_split, value, value_len, learning_rate,
                                n_learning_rate, update_time, flags, stream);
@@ -1237,8 +1246,8 @@ mhte_status mhte_fused_optimize(mhte_multi_table* t, const int64_t* ids,
                                 const int32_t* grad_offsets, const float* learning_rates,
                                 int64_t n_learning_rates, int64_t req_time, int64_t global_step,
                                 int32_t num_of_shards, int32_t flags, void* stream) {
-  (void)global_step;
   return guard([&] {
+    mhte::t_global_step = global_step;
     check_handle(t);
     if (!fused_slot_size || !id_offsets || !grad_offsets || !learning_rates)
       throw Error(MHTE_INVALID_ARGUMENT, "fused optimize: null argument");
@@ -1402,6 +1411,9 @@ static void fused_gather(float* fused, int32_t n_inputs, const int32_t* const* o
       acc += n[i0 + k];
     }
     in.start[in.n_inputs] = acc;
+    in.aligned = aligned16(fused) ? 1 : 0;
+    for (int32_t k = 0; k < in.n_inputs; ++k)
+      if (!aligned16(in.rows[k])) in.aligned = 0;
     if (acc == 0) continue;
     const dim3 grid(uint32_t((acc * 8 + 255) / 256));
     fused_gather_kernel<GATHER><<<grid, 256, 0, st>>>(fused, in, scale);
@@ -1444,8 +1456,11 @@ mhte_status mhte_reduce_rows(const int64_t* indices, const float* values, int64_
     if (batch == 0) return;
     hipStream_t st = S(stream);
     if (indices_sorted) {
-      reduce_rows_sorted_kernel<<<dim3(uint32_t((batch * 16 + 255) / 256)), 256, 0, st>>>(
-          indices, values, n, dim, batch, mode, out);
+      const dim3 grid(uint32_t((batch * 16 + 255) / 256));
+      if (dim % 4 == 0 && aligned16(values) && aligned16(out))
+        reduce_rows_sorted_kernel<4><<<grid, 256, 0, st>>>(indices, values, n, dim, batch, mode, out);
+      else
+        reduce_rows_sorted_kernel<1><<<grid, 256, 0, st>>>(indices, values, n, dim, batch, mode, out);
     } else {
       HIP_OK(hipMemsetAsync(out, 0, size_t(batch) * dim * sizeof(float), st));
       uint32_t* cnt = nullptr;
@@ -1962,8 +1977,8 @@ mhte_status mhte_table_optimize_n(mhte_multi_table* t, int32_t table, const int6
                                   const float* learning_rate, int64_t n_learning_rate,
                                   int64_t update_time, int64_t global_step, int32_t flags,
                                   void* stream) {
-  (void)global_step;
   return guard([&] {
+    mhte::t_global_step = global_step;
     Table& tb = table_at(t, table);
     if (!learning_rate || n_learning_rate < int64_t(tb.nseg))
       throw Error(MHTE_INVALID_ARGUMENT, "The length of tensor `learning_rate` is too short.");

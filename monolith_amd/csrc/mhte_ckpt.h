@@ -129,28 +129,37 @@ inline void put_f32(std::string& out, uint8_t tag, float f) {
 // (values = the engine's OptType)
 enum SegKind {
   kSegSgd = 0, kSegAdagrad = 1, kSegFtrl = 2, kSegMomentum = 3, kSegAdadelta = 4, kSegRmsprop = 5,
-  kSegRmspropV2 = 6, kSegAdam = 7, kSegAmsgrad = 8
+  kSegRmspropV2 = 6, kSegAdam = 7, kSegAmsgrad = 8, kSegMovingAverage = 9, kSegBatchSoftmax = 10
 };
 // wire description of an optimizer's dump: field number in SingleOptimizerDump's oneof
 // (optimizer.proto:231-247), the dump message's repeated-float fields in the order of the engine's
 // state vectors, and the field numbers of the two scalars (0: none)
+// oneof_field 0: the optimizer's Save() returns an EMPTY OptimizerDump (moving average,
+// moving_average_optimizer.cc:54-57) — the segment contributes no SingleOptimizerDump at all and
+// OptimizerCombination::Restore hands it none (optimizer_combination.cc:86-97, dump_size 0).
+// step_field: the dump is one int64 varint (batch softmax's global_step, field 1), kept in the
+// first two words of the segment's 4-float slot.
 struct DumpSpec {
   int oneof_field;
   int nvec;
   int vec_field[3];
   int scal_field[2];
+  int step_field;
+  bool has_slot() const { return scal_field[0] != 0 || step_field != 0; }
 };
 inline DumpSpec dump_spec(int kind) {
   switch (kind) {
-    case kSegSgd: return {2, 0, {0, 0, 0}, {0, 0}};
-    case kSegAdagrad: return {1, 1, {1, 0, 0}, {0, 0}};          // norm
-    case kSegFtrl: return {3, 2, {2, 1, 0}, {0, 0}};             // engine: norm | zero; wire zero=1 norm=2
-    case kSegMomentum: return {9, 1, {1, 0, 0}, {0, 0}};         // n
-    case kSegAdadelta: return {6, 2, {1, 2, 0}, {0, 0}};         // accum, accum_update
-    case kSegRmsprop: return {11, 1, {1, 0, 0}, {0, 0}};         // n
-    case kSegRmspropV2: return {12, 1, {1, 0, 0}, {0, 0}};       // n
-    case kSegAdam: return {7, 2, {1, 2, 0}, {3, 4}};             // m, v, beta1_power, beta2_power
-    default: return {8, 3, {1, 2, 3}, {4, 5}};                   // amsgrad: m, v, vhat, powers
+    case kSegSgd: return {2, 0, {0, 0, 0}, {0, 0}, 0};
+    case kSegAdagrad: return {1, 1, {1, 0, 0}, {0, 0}, 0};          // norm
+    case kSegFtrl: return {3, 2, {2, 1, 0}, {0, 0}, 0};             // engine: norm | zero; wire zero=1 norm=2
+    case kSegMomentum: return {9, 1, {1, 0, 0}, {0, 0}, 0};         // n
+    case kSegAdadelta: return {6, 2, {1, 2, 0}, {0, 0}, 0};         // accum, accum_update
+    case kSegRmsprop: return {11, 1, {1, 0, 0}, {0, 0}, 0};         // n
+    case kSegRmspropV2: return {12, 1, {1, 0, 0}, {0, 0}, 0};       // n
+    case kSegAdam: return {7, 2, {1, 2, 0}, {3, 4}, 0};             // m, v, beta1_power, beta2_power
+    case kSegMovingAverage: return {0, 0, {0, 0, 0}, {0, 0}, 0};    // (no dump)
+    case kSegBatchSoftmax: return {14, 0, {0, 0, 0}, {0, 0}, 1};    // global_step
+    default: return {8, 3, {1, 2, 3}, {4, 5}, 0};                   // amsgrad: m, v, vhat, powers
   }
 }
 struct SegLayout {
@@ -187,10 +196,22 @@ inline char* put_f32_raw(char* p, uint8_t tag, float f) {
 // (sizes first, then one pass over a buffer of the final size: a checkpoint is one of these per row)
 inline void encode_entry(std::string& out, int64_t id, const float* row,
                          const std::vector<SegLayout>& segs, int dim, uint32_t ts) {
+  auto step_of = [&](const SegLayout& s) {
+    uint64_t a;
+    memcpy(&a, row + s.st_off, 8);
+    return a;
+  };
+  auto dump_len = [&](const SegLayout& s, const DumpSpec& ds) -> size_t {
+    size_t m = 5u * (size_t(ds.nvec) * s.dim + (ds.scal_field[0] ? 1 : 0) + (ds.scal_field[1] ? 1 : 0));
+    // (proto2 optional: Save() always sets the field, so it is written even when 0)
+    if (ds.step_field) m += 1 + varint_len(step_of(s));
+    return m;
+  };
   size_t opt_size = 0;
   for (const SegLayout& s : segs) {
     const DumpSpec ds = dump_spec(s.kind);
-    const size_t m = 5u * (size_t(ds.nvec) * s.dim + (ds.scal_field[0] ? 1 : 0) + (ds.scal_field[1] ? 1 : 0));
+    if (!ds.oneof_field) continue;
+    const size_t m = dump_len(s, ds);
     const size_t single = 1 + varint_len(m) + m;
     opt_size += 1 + varint_len(single) + single;
   }
@@ -205,7 +226,8 @@ inline void encode_entry(std::string& out, int64_t id, const float* row,
   p = put_varint_raw(p, opt_size);
   for (const SegLayout& s : segs) {
     const DumpSpec ds = dump_spec(s.kind);
-    const size_t m = 5u * (size_t(ds.nvec) * s.dim + (ds.scal_field[0] ? 1 : 0) + (ds.scal_field[1] ? 1 : 0));
+    if (!ds.oneof_field) continue;
+    const size_t m = dump_len(s, ds);
     *p++ = char(0x0a);  // OptimizerDump.dump: field 1
     p = put_varint_raw(p, 1 + varint_len(m) + m);
     *p++ = char((ds.oneof_field << 3) | 2);
@@ -220,6 +242,10 @@ inline void encode_entry(std::string& out, int64_t id, const float* row,
       for (int k = 0; k < 2; ++k)
         if (ds.scal_field[k] == f)
           p = put_f32_raw(p, uint8_t((f << 3) | 5), row[s.st_off + ds.nvec * s.dim + k]);
+      if (ds.step_field == f) {
+        *p++ = char((f << 3) | 0);
+        p = put_varint_raw(p, step_of(s));
+      }
     }
   }
   *p++ = char(0x20);  // last_update_ts_sec: field 4, varint
@@ -309,6 +335,7 @@ inline void decode_entry(const uint8_t* p, size_t n, const std::vector<SegLayout
         const uint8_t* r = q;
         const uint8_t* rend = q + l2;
         q = rend;
+        while (seg_i < segs.size() && dump_spec(segs[seg_i].kind).oneof_field == 0) ++seg_i;
         if (seg_i >= segs.size()) continue;  // more dumps than segments: ignored
         const SegLayout& sg = segs[seg_i++];
         while (r < rend) {  // SingleOptimizerDump: oneof
@@ -338,6 +365,12 @@ inline void decode_entry(const uint8_t* p, size_t n, const std::vector<SegLayout
                     throw ProtoError("optimizer dump: bad state vector");
                   done = true;
                 }
+              }
+              if (ds.step_field == f4 && (k4 & 7) == 0) {
+                uint64_t a;
+                if (!get_varint(m, mend, &a)) throw ProtoError("optimizer dump: bad step");
+                memcpy(row + sg.st_off, &a, 8);
+                done = true;
               }
               for (int k = 0; k < 2 && !done; ++k) {
                 if (ds.scal_field[k] == f4 && (k4 & 7) == 5) {

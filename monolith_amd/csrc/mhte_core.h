@@ -41,7 +41,8 @@ enum OptType : int32_t {
   kOptSgd = 0, kOptAdagrad = 1, kOptFtrl = 2,
   // op-level kernels only (the fused training-step kernels take the three above):
   kOptMomentum = 3, kOptAdadelta = 4, kOptRmsprop = 5, kOptRmspropV2 = 6, kOptAdam = 7, kOptAmsgrad = 8,
-  kOptCount = 9
+  kOptMovingAverage = 9, kOptBatchSoftmax = 10,
+  kOptCount = 11
 };
 enum InitType : int32_t { kInitZeros = 0, kInitOnes = 1, kInitConstant = 2 };
 
@@ -286,14 +287,32 @@ MHTE_HD int opt_vectors(int opt) {
   }
 }
 MHTE_HD int opt_scalars(int opt) { return (opt == kOptAdam || opt == kOptAmsgrad) ? 2 : 0; }
+// batch softmax keeps one int64 (the global step of the id's last update, batch_softmax_optimizer.cc
+// :33,52-63) in the first two words of the same 4-float slot
+MHTE_HD bool opt_has_slot(int opt) { return opt_scalars(opt) != 0 || opt == kOptBatchSoftmax; }
 MHTE_HD int opt_state_floats(int opt, int dim) {
-  return opt_vectors(opt) * dim + (opt_scalars(opt) ? 4 : 0);
+  return opt_vectors(opt) * dim + (opt_has_slot(opt) ? 4 : 0);
 }
 // initial value of state vector k (optimizer Init()); scalars: adam/amsgrad {beta1, beta2}
 MHTE_HD float opt_state_init(const SegDesc& s, int k) {
   if (s.opt == kOptAdagrad) return s.p[0];               // adagrad_optimizer.cc:47-52
   if (s.opt == kOptFtrl) return k == 0 ? s.p[0] : 0.f;   // ftrl_optimizer.cc:44-51: norm | zero
   return 0.f;                                            // momentum / adadelta / rmsprop / adam / amsgrad
+}
+
+// moving_average_optimizer.cc:44-52 (no state, no learning rate)
+MHTE_HD float moving_average_step(float w, float grad, float mom) {
+  float a = mom * w;
+  float b = (1 - mom) * grad;
+  return a + b;
+}
+
+// batch_softmax_optimizer.cc:52-63: B = (1 - alpha) B + alpha (global_step - A); A = global_step
+MHTE_HD void batch_softmax_step(float& w, long long& last_step, float alpha, long long global_step) {
+  float a = (1 - alpha) * w;
+  float b = alpha * static_cast<float>(global_step - last_step);
+  w = a + b;
+  last_step = global_step;
 }
 
 // momentum_optimizer.cc:50-71

@@ -86,6 +86,7 @@ struct ApplyArgs {
   float lr[kMaxSegments];  // one per segment (SliceSize), multi_hash_table_update_op.cc:73-77
   uint32_t ts;             // (uint32)update_time, entry_defs.h:36-38
   int32_t filter_mode;     // admission (filter_consult): 0 off, 1 guarded by Contains, 3 unguarded
+  long long global_step;   // batch softmax only
   int32_t sum_dups;        // 1: duplicates' values are added first, one optimizer step
                            //    (enable_grad_accumulation, tf_bridge.cc:270-310)
                            // 0: one optimizer step per occurrence, in order
@@ -417,6 +418,8 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
     float* st3 = st2 + sd.dim;
     float* sc = rp + sd.st_off + nv * sd.dim;  // adam / amsgrad: {beta1_power, beta2_power}
     float c1 = 0.f, c2 = 0.f;
+    const bool bsm = sd.opt == kOptBatchSoftmax;  // the slot holds the id's last global step
+    long long last_step = 0;
     if (is_new || OP == kOpReinit) {
       const float w0 = init_weight(sd);
 #pragma unroll
@@ -438,6 +441,9 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
           c1 = sc[0];
           c2 = sc[1];
         }
+        if (bsm)
+          last_step = static_cast<long long>(
+              (static_cast<unsigned long long>(__float_as_uint(sc[1])) << 32) | __float_as_uint(sc[0]));
       }
     }
     if (OP == kOpAssign) {
@@ -487,6 +493,8 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
                 adam_step(w.v[c], s1.v[c], s2.v[c], nullptr, v.v[c], lr_eff, sd.p[0], sd.p[1],
                           sd.p[2], sd.p[3], sd.p[4] != 0.f);
                 break;
+              case kOptMovingAverage: w.v[c] = moving_average_step(w.v[c], v.v[c], sd.p[0]); break;
+              case kOptBatchSoftmax: batch_softmax_step(w.v[c], last_step, lr, a.global_step); break;
               default:  // kOptAmsgrad
                 adam_step(w.v[c], s1.v[c], s2.v[c], &s3.v[c], v.v[c], lr_eff, sd.p[0], sd.p[1],
                           sd.p[2], sd.p[3], sd.p[4] != 0.f);
@@ -508,6 +516,12 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
       if (scal && le == 0) {  // (every lane of the segment computed the same powers)
         sc[0] = c1;
         sc[1] = c2;
+        sc[2] = 0.f;
+        sc[3] = 0.f;
+      }
+      if (bsm && le == 0) {
+        sc[0] = __uint_as_float(static_cast<uint32_t>(static_cast<unsigned long long>(last_step)));
+        sc[1] = __uint_as_float(static_cast<uint32_t>(static_cast<unsigned long long>(last_step) >> 32));
         sc[2] = 0.f;
         sc[3] = 0.f;
       }

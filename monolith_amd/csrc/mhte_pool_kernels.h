@@ -4,7 +4,8 @@
 // gradient, CUDA kernels), runtime/ops/reduce_op.cc:29-125 (ReduceSum / ReduceMean /
 // ReduceSquareNorm), native_training/embedding_combiners.py:41-102.  Included by mhte.hip.
 //
-// All three are HBM-streaming copy/add work: one group of lanes per output row moving float4s.
+// All three are HBM-streaming copy/add work: one group of lanes per output row moving float4s
+// (scalar forms for dims / offsets that are not multiples of 4 floats).
 #ifndef MHTE_POOL_KERNELS_H_
 #define MHTE_POOL_KERNELS_H_
 
@@ -20,6 +21,7 @@ struct GatherInputs {
   int64_t start[kMaxGatherInputs + 1];       // row-index prefix over the inputs
   int32_t dim[kMaxGatherInputs];
   int32_t n_inputs;
+  int32_t aligned;  // fused and every rows[i] are 16-byte aligned
 };
 
 // MonolithFusedGatherEmbeddingsByInput: outputs[i][j, :] = fused[offsets[i][j] + 0 .. dim_i)
@@ -27,6 +29,8 @@ struct GatherInputs {
 // here a lane group takes one row.  GATHER = false: the gradient,
 // fused_grad[offsets[i][j] + k] += grads[i][j, k] * scale (:74-118) — float atomics, like the
 // reference's GpuAtomicAdd (rows that share an offset are added in arrival order).
+// A row whose offset and dim are multiples of 4 floats moves as float4s (in.aligned: the host
+// found every base pointer 16-byte aligned); any other row takes the scalar loop.
 template <bool GATHER>
 __global__ __launch_bounds__(256) void fused_gather_kernel(float* __restrict__ fused, GatherInputs in,
                                                            float scale) {
@@ -40,6 +44,16 @@ __global__ __launch_bounds__(256) void fused_gather_kernel(float* __restrict__ f
   const int32_t dim = in.dim[i];
   const int64_t off = in.offsets[i][local];
   float* row = in.rows[i] + local * dim;
+  // (the gradient keeps the scalar loop: neighbouring lanes on neighbouring floats is the shape
+  // the atomic units coalesce; four floats per lane halves its rate — measured)
+  if (GATHER && in.aligned && ((off | int64_t(dim)) & 3) == 0) {
+    for (int k = j * 4; k < dim; k += G * 4) {
+      Vec<4> v;
+      v.load(fused + off + k);
+      v.store(row + k);
+    }
+    return;
+  }
   for (int k = j; k < dim; k += G) {
     if (GATHER) {
       row[k] = fused[off + k];
@@ -54,6 +68,7 @@ __global__ __launch_bounds__(256) void fused_gather_kernel(float* __restrict__ f
 // sequential accumulation, bit for bit.  One lane group per output row; its segment is found by
 // binary search.  mode 0 sum, 1 mean (sum * (1 / count), count 0 -> the reference's 0 * inf),
 // 2 square norm (sqrt of the sum of squares).
+template <int VEC>
 __global__ __launch_bounds__(256) void reduce_rows_sorted_kernel(const int64_t* __restrict__ indices,
                                                                  const float* __restrict__ values,
                                                                  int64_t n, int32_t dim,
@@ -76,15 +91,34 @@ __global__ __launch_bounds__(256) void reduce_rows_sorted_kernel(const int64_t* 
   }
   const int64_t s1 = lo;
   const float mult = 1.0f / static_cast<float>(s1 - s0);
-  for (int k = j; k < dim; k += G) {
-    float acc = 0.f;
-    for (int64_t i = s0; i < s1; ++i) {
-      const float v = values[i * dim + k];
-      acc = acc + (mode == 2 ? v * v : v);
+  for (int k = j * VEC; k < dim; k += G * VEC) {
+    Vec<VEC> acc;
+    vec_zero(acc);
+    // 4 rows in flight, added in order
+    for (int64_t i = s0; i < s1; i += 4) {
+      Vec<VEC> v[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) vec_zero(v[t]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (i + t < s1) v[t].load(values + (i + t) * dim + k);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (i + t < s1) {
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) {
+            const float x = v[t].v[c];
+            acc.v[c] = acc.v[c] + (mode == 2 ? x * x : x);
+          }
+        }
+      }
     }
-    if (mode == 1) acc = acc * mult;
-    if (mode == 2) acc = sqrtf(acc);
-    out[b * int64_t(dim) + k] = acc;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      if (mode == 1) acc.v[c] = acc.v[c] * mult;
+      if (mode == 2) acc.v[c] = sqrtf(acc.v[c]);
+    }
+    acc.store(out + b * int64_t(dim) + k);
   }
 }
 

@@ -3,9 +3,10 @@ monolith/native_training/entry.py (reference :27-640) without protobuf: the same
 constructor arguments, lowered to the flat C structs of include/monolith_amd_hash_table.h instead of
 EmbeddingHashTableConfig protos (runtime/hash_table/embedding_hash_table.proto:23-95).
 
-Only what the hot path needs is present: SGD / Adagrad / FTRL optimizers, zeros / ones / constants
-initializers, cuckoo table config, per-feature-slot expire times.  Asking for anything else raises
-(no silent downgrade)."""
+What is present: the SGD / Adagrad / FTRL optimizers of the fused training step, the op-level ones
+(momentum, adadelta, rmsprop, adam, amsgrad, moving average, batch softmax), zeros / ones /
+constants initializers, cuckoo table config, per-feature-slot expire times and occurrence
+thresholds.  Asking for anything else raises (no silent downgrade)."""
 import dataclasses
 from typing import Any, Dict, List, Optional, Sequence
 
@@ -134,6 +135,29 @@ class AdamOptimizer(Optimizer):
   def params(self):
     return (self.beta1, self.beta2, self.epsilon, self.weight_decay_factor,
             1.0 if self.use_nesterov else 0.0)
+
+
+class MovingAverageOptimizer(Optimizer):
+  """reference entry.py:247-256; proto default momentum 0.9 (optimizer.proto:169-172).  No state and
+  no learning rate: w <- momentum w + (1 - momentum) g.  Op-level kernels only."""
+  opt_type = _lib.OPT_MOVING_AVERAGE
+  learning_rate = 0.0
+
+  def __init__(self, momentum=0.9):
+    self.momentum = momentum
+
+  def params(self):
+    return (self.momentum,)
+
+
+class BatchSoftmaxOptimizer(Optimizer):
+  """reference entry.py:207-223; proto default learning_rate 0.1 (optimizer.proto:174-177).  A
+  one-float segment holding the moving average of the steps between two occurrences of the id
+  (https://research.google/pubs/pub48840/); reads the ops' ``global_step``.  Op-level kernels only."""
+  opt_type = _lib.OPT_BATCH_SOFTMAX
+
+  def __init__(self, learning_rate=None):
+    self.learning_rate = 0.1 if learning_rate is None else learning_rate
 
 
 class Initializer:

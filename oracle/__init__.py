@@ -19,13 +19,14 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 OPT_MOMENTUM, OPT_ADADELTA, OPT_RMSPROP, OPT_RMSPROPV2, OPT_ADAM, OPT_AMSGRAD = 3, 4, 5, 6, 7, 8
+OPT_MOVING_AVERAGE, OPT_BATCH_SOFTMAX = 9, 10
 INIT_ZEROS, INIT_ONES, INIT_CONSTANT = 0, 1, 2
 
 
 def build(force=False):
   """Builds liboracle.so (always possible) and _ref (only where /root/reference exists)."""
-  if force or not os.path.exists(os.path.join(_DIR, "liboracle.so")):
-    subprocess.check_call(["make", "-s", "-C", _DIR, "liboracle.so"])
+  # (make compares time stamps: an edited restatement is rebuilt, an up-to-date one is left alone)
+  subprocess.check_call(["make", "-s", "-C", _DIR] + (["-B"] if force else []) + ["liboracle.so"])
   if os.path.isdir("/root/reference") and (
       force or not os.path.exists(os.path.join(_DIR, "_ref", "libmonolith_ref.so"))):
     subprocess.check_call(["make", "-s", "-C", _DIR, "ref"])

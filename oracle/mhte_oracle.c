@@ -80,6 +80,8 @@ static int32_t state_floats(const mo_segment* s) {
     case MO_OPT_RMSPROPV2: return s->dim;    /* optimizer/rmsprop_optimizer.cc:33-35,106-108 */
     case MO_OPT_ADAM: return 2 * s->dim + 2;     /* optimizer/adam_optimizer.cc:30-32 */
     case MO_OPT_AMSGRAD: return 3 * s->dim + 2;  /* optimizer/amsgrad_optimizer.cc:30-32 */
+    case MO_OPT_MOVING_AVERAGE: return 0;        /* optimizer/moving_average_optimizer.cc:29 */
+    case MO_OPT_BATCH_SOFTMAX: return 2;         /* optimizer/batch_softmax_optimizer.cc:33: one int64 */
     default: return 0;
   }
 }
@@ -396,7 +398,7 @@ static void init_row(const mo_table* t, float* row) {
       st[nv * s->dim] = s->p[0];
       st[nv * s->dim + 1] = s->p[1];
     } else {
-      /* momentum / adadelta / rmsprop: Init() zeroes the context */
+      /* momentum / adadelta / rmsprop / batch softmax: Init() zeroes the context */
       for (int k = 0; k < state_floats(s); ++k) st[k] = 0.f;
     }
     w += s->dim;
@@ -586,10 +588,27 @@ static void mo_adam(float* num, float* ctx, const float* grad, int64_t len, floa
   pw[1] *= p[1];
 }
 
+/* optimizer/moving_average_optimizer.cc:44-52 */
+static void mo_moving_average(float* num, const float* grad, int64_t len, const float* p) {
+  const float momentum = p[0];
+  for (int64_t i = 0; i < len; ++i) {
+    float new_w = momentum * num[i] + (1 - momentum) * grad[i];
+    num[i] = new_w;
+  }
+}
+
+/* optimizer/batch_softmax_optimizer.cc:52-63 (dim_size 1; ctx = int64 A, the id's last step) */
+static void mo_batch_softmax(float* num, float* ctx, float alpha, int64_t global_step) {
+  int64_t A;
+  memcpy(&A, ctx, sizeof(A));
+  num[0] = (1 - alpha) * num[0] + alpha * (float)(global_step - A);
+  A = global_step;
+  memcpy(ctx, &A, sizeof(A));
+}
+
 /* :229-247 + entry_accessor.cc:187-195 + optimizer_combination.cc:63-72 */
 void mo_optimize(mo_table* t, const int64_t* ids, int64_t n, const float* grads, const float* lrs,
                  int64_t update_time, int64_t global_step) {
-  (void)global_step;
   for (int64_t i = 0; i < n; ++i) {
     bucket_t* b;
     int s;
@@ -615,6 +634,10 @@ void mo_optimize(mo_table* t, const int64_t* ids, int64_t n, const float* grads,
         mo_rmsprop(row + w, st, g + w, sg->dim, lrs[k], sg->p, sg->opt == MO_OPT_RMSPROPV2);
       } else if (sg->opt == MO_OPT_ADAM || sg->opt == MO_OPT_AMSGRAD) {
         mo_adam(row + w, st, g + w, sg->dim, lrs[k], sg->p, sg->opt == MO_OPT_AMSGRAD);
+      } else if (sg->opt == MO_OPT_MOVING_AVERAGE) {
+        mo_moving_average(row + w, g + w, sg->dim, sg->p);
+      } else if (sg->opt == MO_OPT_BATCH_SOFTMAX) {
+        mo_batch_softmax(row + w, st, lrs[k], global_step);
       }
       w += sg->dim;
     }

@@ -27,7 +27,7 @@ static std::vector<SegLayout> segs_from(char** a, int nseg, int dim, int* row_fl
     w += s.dim;
     {
       const DumpSpec ds = dump_spec(s.kind);
-      st += ds.nvec * s.dim + (ds.scal_field[0] ? 4 : 0);
+      st += ds.nvec * s.dim + (ds.has_slot() ? 4 : 0);
     }
     v.push_back(s);
   }

@@ -48,6 +48,7 @@ def _build():
   msg("MomentumOptimizerDump", [fl("n", 1)])                                      # :165-167
   msg("RmspropOptimizerDump", [fl("n", 1)])                                       # :193-195
   msg("RmspropV2OptimizerDump", [fl("n", 1)])                                     # :204-206
+  msg("BatchSoftmaxOptimizerDump", [("global_step", 1, F.TYPE_INT64, OPT, None, False)])  # :179-181
   msg("SingleOptimizerDump", [("adagrad", 1, F.TYPE_MESSAGE, OPT, "AdagradOptimizerDump", True),
                               ("sgd", 2, F.TYPE_MESSAGE, OPT, "SgdOptimizerDump", True),
                               ("ftrl", 3, F.TYPE_MESSAGE, OPT, "FtrlOptimizerDump", True),
@@ -56,7 +57,8 @@ def _build():
                               ("amsgrad", 8, F.TYPE_MESSAGE, OPT, "AmsgradOptimizerDump", True),
                               ("momentum", 9, F.TYPE_MESSAGE, OPT, "MomentumOptimizerDump", True),
                               ("rmsprop", 11, F.TYPE_MESSAGE, OPT, "RmspropOptimizerDump", True),
-                              ("rmspropv2", 12, F.TYPE_MESSAGE, OPT, "RmspropV2OptimizerDump", True)],
+                              ("rmspropv2", 12, F.TYPE_MESSAGE, OPT, "RmspropV2OptimizerDump", True),
+                              ("batch_softmax", 14, F.TYPE_MESSAGE, OPT, "BatchSoftmaxOptimizerDump", True)],
       oneof="type")
   msg("OptimizerDump", [("dump", 1, F.TYPE_MESSAGE, REP, "SingleOptimizerDump", False)])
   msg("EntryDump", [("id", 1, F.TYPE_SFIXED64, OPT, None, False),

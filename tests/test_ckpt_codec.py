@@ -15,10 +15,12 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import ckpt_proto as P  # noqa: E402
 
-SGD, ADAGRAD, FTRL, MOMENTUM, ADADELTA, RMSPROP, RMSPROPV2, ADAM, AMSGRAD = range(9)
-# (state vectors, scalars) per kind, in the engine's row (scalars sit in a 4-float slot)
+(SGD, ADAGRAD, FTRL, MOMENTUM, ADADELTA, RMSPROP, RMSPROPV2, ADAM, AMSGRAD, MOVING_AVERAGE,
+ BATCH_SOFTMAX) = range(11)
+# (state vectors, scalars) per kind, in the engine's row (scalars sit in a 4-float slot; batch
+# softmax keeps its int64 step in the first two words of one)
 STATE = {SGD: (0, 0), ADAGRAD: (1, 0), FTRL: (2, 0), MOMENTUM: (1, 0), ADADELTA: (2, 0), RMSPROP: (1, 0),
-         RMSPROPV2: (1, 0), ADAM: (2, 2), AMSGRAD: (3, 2)}
+         RMSPROPV2: (1, 0), ADAM: (2, 2), AMSGRAD: (3, 2), MOVING_AVERAGE: (0, 0), BATCH_SOFTMAX: (0, 2)}
 
 
 @pytest.fixture(scope="module")
@@ -42,8 +44,12 @@ def reference_entry(id_, ts, segs, row, dim, with_id=True, packed=False):
   e.num.extend(row[:dim])
   st = dim
   for kind, d in segs:
+    if kind == MOVING_AVERAGE:   # Save() returns an empty OptimizerDump (moving_average_optimizer.cc:54-57)
+      continue
     s = e.opt.dump.add()
-    if kind == SGD:
+    if kind == BATCH_SOFTMAX:
+      s.batch_softmax.global_step = int(np.array(row[st:st + 2], np.float32).view(np.int64)[0])
+    elif kind == SGD:
       s.sgd.SetInParent()
     elif kind == ADAGRAD:
       s.adagrad.norm.extend(row[st:st + d])
@@ -140,6 +146,32 @@ def test_decode_accepts_unpacked_packed_and_missing_fields(driver, tmp_path):
   out = run(driver, "decode", tmp_path / "c.hex", dim, len(segs), *seg_args).split()
   np.testing.assert_array_equal(np.array(out[2:7], np.float32), row[:5])
   assert all(float(x) == -7.0 for x in out[7:])
+
+
+def test_moving_average_and_batch_softmax_dumps(driver, tmp_path):
+  """A segment whose optimizer saves nothing contributes no SingleOptimizerDump (and takes none
+  back on restore, optimizer_combination.cc:86-97); batch softmax dumps one int64."""
+  segs = [(MOVING_AVERAGE, 2), (BATCH_SOFTMAX, 1), (ADAGRAD, 2), (MOVING_AVERAGE, 1)]
+  dim = 6
+  rf = dim + 4 + 2
+  for step in (0, 5, (1 << 40) + 12345):
+    row = (np.arange(rf) * 0.25 + 1.0).astype(np.float32)
+    row[dim:dim + 2] = np.array([step], np.int64).view(np.float32)
+    row[dim + 2:dim + 4] = 0.0
+    seg_args = [x for s_ in segs for x in s_]
+    args = ["entry", 42, 77, dim, len(segs)] + seg_args + [repr(float(v)) for v in row]
+    got = bytes.fromhex(run(driver, *args))
+    ref = reference_entry(42, 77, segs, row, dim)
+    assert got == ref
+    e = P.EntryDump()
+    e.ParseFromString(got)
+    assert len(e.opt.dump) == 2 and e.opt.dump[0].batch_softmax.global_step == step
+    (tmp_path / "m.hex").write_text(got.hex())
+    out = run(driver, "decode", tmp_path / "m.hex", dim, len(segs), *seg_args).split()
+    dec = np.array(out[2:], np.float32)
+    np.testing.assert_array_equal(dec[:dim], row[:dim])
+    assert int(dec[dim:dim + 2].view(np.int64)[0]) == step
+    np.testing.assert_array_equal(dec[dim + 4:], row[dim + 4:])
 
 
 @pytest.mark.parametrize("snappy", [0, 1])

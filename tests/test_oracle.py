@@ -259,6 +259,8 @@ OPT_KATS = [
      [-0.01983060, -0.01842895], "adam_optimizer_test.cc:32-76"),
     ("amsgrad", O.OPT_AMSGRAD, (0.9, 0.99, 0.01, 0.0, 0.0), 0.01, [10.0], [-0.00990099],
      [-0.01983060], "amsgrad_optimizer_test.cc:32-51"),
+    ("moving_average", O.OPT_MOVING_AVERAGE, (0.9,), 0.01, [10.0, 1.0], [1.0, 0.1], [1.9, 0.19],
+     "moving_average_optimizer_test.cc:32-68"),
 ]
 
 
@@ -276,3 +278,20 @@ def test_remaining_optimizer_kats(kat):
   for a, b in zip(got2, exp2):
     if b is not None:
       assert abs(a - b) < 1e-6
+
+
+def test_batch_softmax_kat():
+  """batch_softmax_optimizer_test.cc:32-42: alpha 0.1, global_step 1 -> B = 0.1; then the
+  recurrence B = (1 - alpha) B + alpha (step - last step) by hand."""
+  t = O.Table([O.segment(1, O.OPT_BATCH_SOFTMAX)], 1)
+  one = np.array([7], np.int64)
+  g = np.array([[2.0]], np.float32)
+  t.optimize(one, g, [0.1], 0, global_step=1)
+  assert t.lookup(one)[0][0][0] == np.float32(0.1)
+  t.optimize(one, g, [0.1], 0, global_step=5)
+  exp = np.float32(np.float32(np.float32(0.9) * np.float32(0.1)) + np.float32(np.float32(0.1) * np.float32(4.0)))
+  assert t.lookup(one)[0][0][0] == exp
+  # a second occurrence in the same call sees step - last step = 0
+  t.optimize(np.array([9, 9], np.int64), np.zeros((2, 1), np.float32), [0.1], 0, global_step=3)
+  first = np.float32(np.float32(0.1) * np.float32(3.0))
+  assert t.lookup(np.array([9], np.int64))[0][0][0] == np.float32(np.float32(0.9) * first)

@@ -764,6 +764,7 @@ _OPT_ENTRY = {
     "rmspropv2": lambda: entry.RmspropOptimizer(0.01, v2=True),
     "adam": lambda: entry.AdamOptimizer(0.01),
     "amsgrad": lambda: entry.AdamOptimizer(0.01, amsgrad=True),
+    "moving_average": lambda: entry.MovingAverageOptimizer(0.9),
 }
 
 
@@ -815,6 +816,43 @@ def test_remaining_optimizers_kat_and_oracle(name, tmp_path):
     m_.apply_gradients({"t": (ids_t(ids), val_t(gr))}, req_time=200)
   np.testing.assert_array_equal(mt2.lookup({"t": ids_t(probe)})["t"].cpu().numpy(),
                                 mt3.lookup({"t": ids_t(probe)})["t"].cpu().numpy())
+
+
+def test_batch_softmax_optimizer(tmp_path):
+  """BatchSoftmaxOptimizer (batch_softmax_optimizer.cc:52-63): the reference's KAT, then several
+  steps with duplicates and a growing global_step bit-exact against the oracle (a one-float
+  segment next to an Adagrad one), and a checkpoint round trip that carries the int64 step."""
+  mt = make({"t": entry.make_table_config(
+      [entry.CombineAsSegment(1, entry.ZerosInitializer(), entry.BatchSoftmaxOptimizer(0.1))])})
+  mt.apply_gradients({"t": (ids_t([7]), val_t([[2.0]]))}, global_step=1)
+  assert mt.lookup({"t": ids_t([7])})["t"].cpu().numpy()[0][0] == np.float32(0.1)
+  segs = [entry.CombineAsSegment(1, entry.ZerosInitializer(), entry.BatchSoftmaxOptimizer(0.1)),
+          entry.CombineAsSegment(4, entry.ZerosInitializer(), entry.AdagradOptimizer(0.05, 0.1))]
+  mt2 = make({"t": entry.make_table_config(segs)})
+  ot = O.Table([O.segment(1, O.OPT_BATCH_SOFTMAX), O.segment(4, O.OPT_ADAGRAD, p=(0.1, 0.0))], 1)
+  rng = np.random.default_rng(11)
+  step = (1 << 33) + 5   # (the stored step is a full int64)
+  for k in range(5):
+    ids = rng.integers(0, 200, 700).astype(np.int64)
+    gr = rng.standard_normal((700, 5)).astype(np.float32)
+    step += int(rng.integers(1, 50))
+    mt2.apply_gradients({"t": (ids_t(ids), val_t(gr))}, global_step=step, req_time=100 + k)
+    ot.optimize(ids, gr, [0.1, 0.05], 100 + k, global_step=step)
+  probe = np.arange(200, dtype=np.int64)
+  np.testing.assert_array_equal(mt2.lookup({"t": ids_t(probe)})["t"].cpu().numpy(), ot.lookup(probe)[0])
+  base = str(tmp_path / "ck")
+  mt2.save(base)
+  mt3 = make({"t": entry.make_table_config(segs)})
+  mt3.restore(base)
+  ids = rng.integers(0, 200, 300).astype(np.int64)
+  gr = rng.standard_normal((300, 5)).astype(np.float32)
+  for m_ in (mt2, mt3):
+    m_.apply_gradients({"t": (ids_t(ids), val_t(gr))}, global_step=step + 17, req_time=200)
+  np.testing.assert_array_equal(mt2.lookup({"t": ids_t(probe)})["t"].cpu().numpy(),
+                                mt3.lookup({"t": ids_t(probe)})["t"].cpu().numpy())
+  with pytest.raises(_lib.MhteError):
+    make({"bad": entry.make_table_config(
+        [entry.CombineAsSegment(2, entry.ZerosInitializer(), entry.BatchSoftmaxOptimizer(0.1))])})
 
 
 # =============================================================================== gather + pooling
