@@ -52,7 +52,8 @@ enum {                                                                     /* op
      that uses one of them is not mhte_table_fused_backward_ok */
   MHTE_OPT_MOMENTUM = 3, MHTE_OPT_ADADELTA = 4, MHTE_OPT_RMSPROP = 5, MHTE_OPT_RMSPROPV2 = 6,
   MHTE_OPT_ADAM = 7, MHTE_OPT_AMSGRAD = 8, MHTE_OPT_MOVING_AVERAGE = 9,
-  MHTE_OPT_BATCH_SOFTMAX = 10 /* dim_size 1; uses the ops' global_step argument */
+  MHTE_OPT_BATCH_SOFTMAX = 10, /* dim_size 1; uses the ops' global_step argument */
+  MHTE_OPT_GROUP_ADAGRAD = 11  /* AdaGradWithGroupLasso: one step needs the whole segment */
 };
 enum { MHTE_INIT_ZEROS = 0, MHTE_INIT_ONES = 1, MHTE_INIT_CONSTANT = 2 }; /* initializer_config.proto */
 
@@ -68,7 +69,9 @@ typedef struct {
                                      config (v1 ignores the op's learning-rate input,
                                      rmsprop_optimizer.cc:66)}
                            ADAM / AMSGRAD: {beta1, beta2, epsilon, weight_decay_factor, use_nesterov}
-                           MOVING_AVERAGE: {momentum}     BATCH_SOFTMAX: none */
+                           MOVING_AVERAGE: {momentum}     BATCH_SOFTMAX: none
+                           GROUP_ADAGRAD: {initial_accumulator_value, beta,
+                                     l2_regularization_strength, weight_decay_factor} */
   int32_t init_type;    /* MHTE_INIT_* */
   float init_value;     /* ConstantsInitializerConfig.constant */
 } mhte_segment_config;

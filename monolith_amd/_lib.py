@@ -29,7 +29,7 @@ ABI_VERSION = 3            # MHTE_ABI_VERSION of include/monolith_amd_hash_table
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 OPT_MOMENTUM, OPT_ADADELTA, OPT_RMSPROP, OPT_RMSPROPV2, OPT_ADAM, OPT_AMSGRAD = 3, 4, 5, 6, 7, 8
-OPT_MOVING_AVERAGE, OPT_BATCH_SOFTMAX = 9, 10
+OPT_MOVING_AVERAGE, OPT_BATCH_SOFTMAX, OPT_GROUP_ADAGRAD = 9, 10, 11
 INIT_ZEROS, INIT_ONES, INIT_CONSTANT = 0, 1, 2
 
 

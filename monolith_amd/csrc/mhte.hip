@@ -1756,6 +1756,7 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
           init[size_t(d.st_off + nv * d.dim)] = d.p[0];
           init[size_t(d.st_off + nv * d.dim + 1)] = d.p[1];
         }
+        if (d.opt == kOptGroupAdagrad) init[size_t(d.st_off)] = d.p[0];  // group_adagrad_optimizer.cc:45-48
       }
       const size_t kBatch = size_t(1) << 18;
       std::vector<int64_t> ids;

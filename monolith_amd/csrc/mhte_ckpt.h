@@ -129,7 +129,8 @@ inline void put_f32(std::string& out, uint8_t tag, float f) {
 // (values = the engine's OptType)
 enum SegKind {
   kSegSgd = 0, kSegAdagrad = 1, kSegFtrl = 2, kSegMomentum = 3, kSegAdadelta = 4, kSegRmsprop = 5,
-  kSegRmspropV2 = 6, kSegAdam = 7, kSegAmsgrad = 8, kSegMovingAverage = 9, kSegBatchSoftmax = 10
+  kSegRmspropV2 = 6, kSegAdam = 7, kSegAmsgrad = 8, kSegMovingAverage = 9, kSegBatchSoftmax = 10,
+  kSegGroupAdagrad = 11
 };
 // wire description of an optimizer's dump: field number in SingleOptimizerDump's oneof
 // (optimizer.proto:231-247), the dump message's repeated-float fields in the order of the engine's
@@ -159,6 +160,7 @@ inline DumpSpec dump_spec(int kind) {
     case kSegAdam: return {7, 2, {1, 2, 0}, {3, 4}, 0};             // m, v, beta1_power, beta2_power
     case kSegMovingAverage: return {0, 0, {0, 0, 0}, {0, 0}, 0};    // (no dump)
     case kSegBatchSoftmax: return {14, 0, {0, 0, 0}, {0, 0}, 1};    // global_step
+    case kSegGroupAdagrad: return {15, 0, {0, 0, 0}, {1, 0}, 0};    // grad_square_sum
     default: return {8, 3, {1, 2, 3}, {4, 5}, 0};                   // amsgrad: m, v, vhat, powers
   }
 }

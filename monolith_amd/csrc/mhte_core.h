@@ -41,8 +41,8 @@ enum OptType : int32_t {
   kOptSgd = 0, kOptAdagrad = 1, kOptFtrl = 2,
   // op-level kernels only (the fused training-step kernels take the three above):
   kOptMomentum = 3, kOptAdadelta = 4, kOptRmsprop = 5, kOptRmspropV2 = 6, kOptAdam = 7, kOptAmsgrad = 8,
-  kOptMovingAverage = 9, kOptBatchSoftmax = 10,
-  kOptCount = 11
+  kOptMovingAverage = 9, kOptBatchSoftmax = 10, kOptGroupAdagrad = 11,
+  kOptCount = 12
 };
 enum InitType : int32_t { kInitZeros = 0, kInitOnes = 1, kInitConstant = 2 };
 
@@ -288,8 +288,12 @@ MHTE_HD int opt_vectors(int opt) {
 }
 MHTE_HD int opt_scalars(int opt) { return (opt == kOptAdam || opt == kOptAmsgrad) ? 2 : 0; }
 // batch softmax keeps one int64 (the global step of the id's last update, batch_softmax_optimizer.cc
-// :33,52-63) in the first two words of the same 4-float slot
-MHTE_HD bool opt_has_slot(int opt) { return opt_scalars(opt) != 0 || opt == kOptBatchSoftmax; }
+// :33,52-63)
+// in the first two words of the same 4-float slot; group adagrad one float (the running sum of the
+// largest squared gradient of the segment, group_adagrad_optimizer.cc:31)
+MHTE_HD bool opt_has_slot(int opt) {
+  return opt_scalars(opt) != 0 || opt == kOptBatchSoftmax || opt == kOptGroupAdagrad;
+}
 MHTE_HD int opt_state_floats(int opt, int dim) {
   return opt_vectors(opt) * dim + (opt_has_slot(opt) ? 4 : 0);
 }

@@ -398,17 +398,154 @@ __global__ __launch_bounds__(256) void lookup_kernel(TableView tv, const int64_t
 //   values    [*, dim] value rows (gradients / assigned values), indexed by occurrence position
 //   seg_pos   optional occurrence list (positions in occurrence order), [q0, q1)
 // =============================================================================================
+// GroupAdaGrad (group_adagrad_optimizer.cc:50-93) on segment k of a row: the one optimizer whose
+// step needs the whole segment — the largest squared (decayed) gradient feeds the accumulator,
+// and the group-lasso shrinkage needs the norm of the intermediate vector.  The G lanes of the
+// group cooperate: max by butterfly, the norm as ONE chain in element order (every lane adds the
+// same broadcast values), so it is the reference's sequential sum bit for bit.  The vector is
+// written in place between the passes, as the reference does.  params: {initial_accumulator_value,
+// beta, l2_regularization_strength, weight_decay_factor}.
+template <int G, int VEC>
+__device__ __forceinline__ void group_adagrad_segment(const TableView& tv, float* rp, bool is_new,
+                                                      int j, const float* __restrict__ values,
+                                                      const uint32_t* __restrict__ seg_pos,
+                                                      uint32_t q0, uint32_t q1, int64_t self_pos,
+                                                      const ApplyArgs& a, uint32_t k) {
+  const SegDesc sd = tv.seg[k];
+  const int gbase = (threadIdx.x & 63) & ~(G - 1);
+  const int64_t dim = tv.dim;
+  const uint32_t lo = uint32_t(sd.w_off), hi = uint32_t(sd.w_off + sd.dim);
+  const uint32_t t0 = lo / (G * VEC), t1 = (hi + G * VEC - 1) / (G * VEC);  // trips that touch it
+  const float beta = sd.p[1], l2 = sd.p[2], wd = sd.p[3], lr0 = a.lr[k];
+  float* sc = rp + sd.st_off;
+  float gss = is_new ? sd.p[0] : sc[0];
+  if (is_new) {
+    const float w0 = init_weight(sd);
+    for (uint32_t t = t0; t < t1; ++t) {
+      const uint32_t e = uint32_t(j) * VEC + t * G * VEC;
+      if (e >= lo && e < hi) {
+        Vec<VEC> w;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) w.v[c] = w0;
+        w.store(rp + e);
+      }
+    }
+  }
+  const uint32_t nq = seg_pos ? (q1 - q0) : 1u;
+  const uint32_t steps = a.sum_dups ? 1u : nq;
+  for (uint32_t s = 0; s < steps; ++s) {
+    // gradient of this step for the chunk at e: one occurrence, or the occurrences added in order
+    auto grad_of = [&](uint32_t e, Vec<VEC>& g) {
+      if (a.sum_dups) {
+        vec_zero(g);
+        for (uint32_t q = 0; q < nq; ++q) {
+          const int64_t pos = seg_pos ? int64_t(seg_pos[q0 + q]) : self_pos;
+          Vec<VEC> v;
+          v.load(values + pos * dim + e);
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) g.v[c] = g.v[c] + v.v[c];
+        }
+      } else {
+        const int64_t pos = seg_pos ? int64_t(seg_pos[q0 + s]) : self_pos;
+        g.load(values + pos * dim + e);
+      }
+    };
+    // pass 1: largest squared decayed gradient
+    float mx = 0.f;
+    for (uint32_t t = t0; t < t1; ++t) {
+      const uint32_t e = uint32_t(j) * VEC + t * G * VEC;
+      if (e >= lo && e < hi) {
+        Vec<VEC> w, g;
+        w.load(rp + e);
+        grad_of(e, g);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+          const float t2 = wd * w.v[c];
+          const float gd = g.v[c] + t2;
+          const float sq = gd * gd;
+          if (sq > mx) mx = sq;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = G / 2; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    gss = gss + mx;
+    const float lr = lr0 / (beta + sqrtf(gss));
+    // pass 2: z = g_decayed - w / lr in place; ||z||^2 as one chain in element order
+    float zn = 0.f;
+    for (uint32_t t = t0; t < t1; ++t) {
+      const uint32_t e = uint32_t(j) * VEC + t * G * VEC;
+      const bool in = e >= lo && e < hi;
+      Vec<VEC> z;
+      vec_zero(z);
+      if (in) {
+        Vec<VEC> w, g;
+        w.load(rp + e);
+        grad_of(e, g);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+          const float t2 = wd * w.v[c];
+          const float gd = g.v[c] + t2;
+          const float q = w.v[c] / lr;
+          z.v[c] = gd - q;
+        }
+        z.store(rp + e);
+      }
+      for (int j2 = 0; j2 < G; ++j2) {
+        const uint32_t e2 = uint32_t(j2) * VEC + t * G * VEC;
+        const bool in2 = e2 >= lo && e2 < hi;  // group-uniform
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+          const float zz = __shfl(z.v[c], gbase + j2);
+          if (in2) {
+            const float sq = zz * zz;
+            zn = zn + sq;
+          }
+        }
+      }
+    }
+    const float z_norm = sqrtf(zn);
+    const bool zero = z_norm < l2;
+    const float num = -lr * (z_norm - l2);
+    const float coeff = num / z_norm;
+    // pass 3: shrink
+    for (uint32_t t = t0; t < t1; ++t) {
+      const uint32_t e = uint32_t(j) * VEC + t * G * VEC;
+      if (e >= lo && e < hi) {
+        Vec<VEC> z;
+        z.load(rp + e);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) z.v[c] = zero ? 0.f : coeff * z.v[c];
+        z.store(rp + e);
+      }
+    }
+  }
+  if (j == 0) {
+    sc[0] = gss;
+    sc[1] = 0.f;
+    sc[2] = 0.f;
+    sc[3] = 0.f;
+  }
+}
+
 template <int G, int VEC, int OP>
 __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool is_new, int j,
                                           const float* __restrict__ values,
                                           const uint32_t* __restrict__ seg_pos, uint32_t q0,
                                           uint32_t q1, int64_t self_pos, const ApplyArgs& a) {
   const int64_t dim = tv.dim;
+  if (OP == kOpOptimize) {  // (group-uniform: every lane of the group walks the segments)
+    for (uint32_t k = 0; k < tv.nseg; ++k)
+      if (tv.seg[k].opt == kOptGroupAdagrad)
+        group_adagrad_segment<G, VEC>(tv, rp, is_new, j, values, seg_pos, q0, q1, self_pos, a, k);
+  }
   for (uint32_t e = j * VEC; e < tv.dim; e += G * VEC) {
     uint32_t k = 0;
     while (k + 1 < tv.nseg && e >= uint32_t(tv.seg[k + 1].w_off)) ++k;
     const SegDesc sd = tv.seg[k];
     const uint32_t le = e - sd.w_off;  // element index inside the segment
+    const bool gag = sd.opt == kOptGroupAdagrad;
+    if (gag && OP == kOpOptimize) continue;  // done above, by the whole group
     const float lr = a.lr[k];
     const int nv = opt_vectors(sd.opt);
     const bool scal = opt_scalars(sd.opt) != 0;
@@ -516,6 +653,12 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
       if (scal && le == 0) {  // (every lane of the segment computed the same powers)
         sc[0] = c1;
         sc[1] = c2;
+        sc[2] = 0.f;
+        sc[3] = 0.f;
+      }
+      if (gag && le == 0 && (is_new || OP == kOpReinit)) {  // GroupAdaGrad Init()
+        sc[0] = sd.p[0];
+        sc[1] = 0.f;
         sc[2] = 0.f;
         sc[3] = 0.f;
       }

@@ -4,7 +4,7 @@ constructor arguments, lowered to the flat C structs of include/monolith_amd_has
 EmbeddingHashTableConfig protos (runtime/hash_table/embedding_hash_table.proto:23-95).
 
 What is present: the SGD / Adagrad / FTRL optimizers of the fused training step, the op-level ones
-(momentum, adadelta, rmsprop, adam, amsgrad, moving average, batch softmax), zeros / ones /
+(momentum, adadelta, rmsprop, adam, amsgrad, moving average, batch softmax, group-lasso adagrad), zeros / ones /
 constants initializers, cuckoo table config, per-feature-slot expire times and occurrence
 thresholds.  Asking for anything else raises (no silent downgrade)."""
 import dataclasses
@@ -158,6 +158,26 @@ class BatchSoftmaxOptimizer(Optimizer):
 
   def __init__(self, learning_rate=None):
     self.learning_rate = 0.1 if learning_rate is None else learning_rate
+
+
+class AdaGradWithGroupLassoOptimizer(Optimizer):
+  """reference entry.py:310-331 (GroupAdaGradOptimizerConfig, optimizer.proto:90-98: lr 0.01,
+  beta 0, initial_accumulator_value 0.1, l2 0, weight decay 0).  Op-level kernels only."""
+  opt_type = _lib.OPT_GROUP_ADAGRAD
+
+  def __init__(self, learning_rate=None, beta=None, initial_accumulator_value=None,
+               l2_regularization=None, weight_decay_factor=0.0, warmup_steps=0):
+    self.learning_rate = 0.01 if learning_rate is None else learning_rate
+    self.beta = 0.0 if beta is None else beta
+    self.initial_accumulator_value = (0.1 if initial_accumulator_value is None else
+                                      initial_accumulator_value)
+    self.l2_regularization_strength = 0.0 if l2_regularization is None else l2_regularization
+    self.weight_decay_factor = weight_decay_factor
+    self.warmup_steps = warmup_steps
+
+  def params(self):
+    return (self.initial_accumulator_value, self.beta, self.l2_regularization_strength,
+            self.weight_decay_factor)
 
 
 class Initializer:

@@ -82,6 +82,7 @@ static int32_t state_floats(const mo_segment* s) {
     case MO_OPT_AMSGRAD: return 3 * s->dim + 2;  /* optimizer/amsgrad_optimizer.cc:30-32 */
     case MO_OPT_MOVING_AVERAGE: return 0;        /* optimizer/moving_average_optimizer.cc:29 */
     case MO_OPT_BATCH_SOFTMAX: return 2;         /* optimizer/batch_softmax_optimizer.cc:33: one int64 */
+    case MO_OPT_GROUP_ADAGRAD: return 1;         /* optimizer/group_adagrad_optimizer.cc:31: one float */
     default: return 0;
   }
 }
@@ -384,7 +385,9 @@ static void init_row(const mo_table* t, float* row) {
     if (s->init == MO_INIT_CONSTANT) v = s->init_value;
     for (int k = 0; k < s->dim; ++k) row[w + k] = v;
     float* st = row + t->state_off[i];
-    if (s->opt == MO_OPT_ADAGRAD) {
+    if (s->opt == MO_OPT_GROUP_ADAGRAD) {
+      st[0] = s->p[0]; /* group_adagrad_optimizer.cc:45-48 */
+    } else if (s->opt == MO_OPT_ADAGRAD) {
       for (int k = 0; k < s->dim; ++k) st[k] = s->p[0]; /* adagrad_optimizer.cc:47-52 */
     } else if (s->opt == MO_OPT_FTRL) {
       for (int k = 0; k < s->dim; ++k) { /* ftrl_optimizer.cc:44-51: norm | zero */
@@ -588,6 +591,35 @@ static void mo_adam(float* num, float* ctx, const float* grad, int64_t len, floa
   pw[1] *= p[1];
 }
 
+/* optimizer/group_adagrad_optimizer.cc:50-93; p = {initial_accumulator_value, beta,
+ * l2_regularization_strength, weight_decay_factor} */
+static void mo_group_adagrad(float* num, float* grad_square_sum, const float* grad, int64_t len,
+                             float effective_lr, const float* p) {
+  const float beta = p[1], l2 = p[2], wd = p[3];
+  float max_grad_square = 0.f;
+  float* g_decayed = (float*)malloc(sizeof(float) * (size_t)(len > 0 ? len : 1));
+  for (int64_t i = 0; i < len; ++i) {
+    float g = grad[i] + wd * num[i];
+    if (g * g > max_grad_square) max_grad_square = g * g;
+    g_decayed[i] = g;
+  }
+  *grad_square_sum = *grad_square_sum + max_grad_square;
+  float lr = effective_lr / (beta + sqrtf(*grad_square_sum));
+  float z_norm = 0.f;
+  for (int64_t i = 0; i < len; ++i) {
+    num[i] = g_decayed[i] - num[i] / lr;
+    z_norm += num[i] * num[i];
+  }
+  z_norm = sqrtf(z_norm);
+  if (z_norm < l2) {
+    for (int64_t i = 0; i < len; ++i) num[i] = 0;
+  } else {
+    float coeffi = -lr * (z_norm - l2) / z_norm;
+    for (int64_t i = 0; i < len; ++i) num[i] = coeffi * num[i];
+  }
+  free(g_decayed);
+}
+
 /* optimizer/moving_average_optimizer.cc:44-52 */
 static void mo_moving_average(float* num, const float* grad, int64_t len, const float* p) {
   const float momentum = p[0];
@@ -638,6 +670,8 @@ void mo_optimize(mo_table* t, const int64_t* ids, int64_t n, const float* grads,
         mo_moving_average(row + w, g + w, sg->dim, sg->p);
       } else if (sg->opt == MO_OPT_BATCH_SOFTMAX) {
         mo_batch_softmax(row + w, st, lrs[k], global_step);
+      } else if (sg->opt == MO_OPT_GROUP_ADAGRAD) {
+        mo_group_adagrad(row + w, st, g + w, sg->dim, lrs[k], sg->p);
       }
       w += sg->dim;
     }

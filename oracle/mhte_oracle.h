@@ -24,7 +24,7 @@ extern "C" {
 
 enum { MO_OPT_SGD = 0, MO_OPT_ADAGRAD = 1, MO_OPT_FTRL = 2, MO_OPT_MOMENTUM = 3, MO_OPT_ADADELTA = 4,
        MO_OPT_RMSPROP = 5, MO_OPT_RMSPROPV2 = 6, MO_OPT_ADAM = 7, MO_OPT_AMSGRAD = 8,
-       MO_OPT_MOVING_AVERAGE = 9, MO_OPT_BATCH_SOFTMAX = 10 };
+       MO_OPT_MOVING_AVERAGE = 9, MO_OPT_BATCH_SOFTMAX = 10, MO_OPT_GROUP_ADAGRAD = 11 };
 enum { MO_INIT_ZEROS = 0, MO_INIT_ONES = 1, MO_INIT_CONSTANT = 2 };
 
 /* One EntryConfig.Segment (hash_table/embedding_hash_table.proto:23-43). */

@@ -49,6 +49,7 @@ def _build():
   msg("RmspropOptimizerDump", [fl("n", 1)])                                       # :193-195
   msg("RmspropV2OptimizerDump", [fl("n", 1)])                                     # :204-206
   msg("BatchSoftmaxOptimizerDump", [("global_step", 1, F.TYPE_INT64, OPT, None, False)])  # :179-181
+  msg("GroupAdaGradOptimizerDump", [sc("grad_square_sum", 1)])                    # :100-102
   msg("SingleOptimizerDump", [("adagrad", 1, F.TYPE_MESSAGE, OPT, "AdagradOptimizerDump", True),
                               ("sgd", 2, F.TYPE_MESSAGE, OPT, "SgdOptimizerDump", True),
                               ("ftrl", 3, F.TYPE_MESSAGE, OPT, "FtrlOptimizerDump", True),
@@ -58,7 +59,8 @@ def _build():
                               ("momentum", 9, F.TYPE_MESSAGE, OPT, "MomentumOptimizerDump", True),
                               ("rmsprop", 11, F.TYPE_MESSAGE, OPT, "RmspropOptimizerDump", True),
                               ("rmspropv2", 12, F.TYPE_MESSAGE, OPT, "RmspropV2OptimizerDump", True),
-                              ("batch_softmax", 14, F.TYPE_MESSAGE, OPT, "BatchSoftmaxOptimizerDump", True)],
+                              ("batch_softmax", 14, F.TYPE_MESSAGE, OPT, "BatchSoftmaxOptimizerDump", True),
+                              ("group_adagrad", 15, F.TYPE_MESSAGE, OPT, "GroupAdaGradOptimizerDump", True)],
       oneof="type")
   msg("OptimizerDump", [("dump", 1, F.TYPE_MESSAGE, REP, "SingleOptimizerDump", False)])
   msg("EntryDump", [("id", 1, F.TYPE_SFIXED64, OPT, None, False),

@@ -16,11 +16,12 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import ckpt_proto as P  # noqa: E402
 
 (SGD, ADAGRAD, FTRL, MOMENTUM, ADADELTA, RMSPROP, RMSPROPV2, ADAM, AMSGRAD, MOVING_AVERAGE,
- BATCH_SOFTMAX) = range(11)
+ BATCH_SOFTMAX, GROUP_ADAGRAD) = range(12)
 # (state vectors, scalars) per kind, in the engine's row (scalars sit in a 4-float slot; batch
 # softmax keeps its int64 step in the first two words of one)
 STATE = {SGD: (0, 0), ADAGRAD: (1, 0), FTRL: (2, 0), MOMENTUM: (1, 0), ADADELTA: (2, 0), RMSPROP: (1, 0),
-         RMSPROPV2: (1, 0), ADAM: (2, 2), AMSGRAD: (3, 2), MOVING_AVERAGE: (0, 0), BATCH_SOFTMAX: (0, 2)}
+         RMSPROPV2: (1, 0), ADAM: (2, 2), AMSGRAD: (3, 2), MOVING_AVERAGE: (0, 0), BATCH_SOFTMAX: (0, 2),
+         GROUP_ADAGRAD: (0, 1)}
 
 
 @pytest.fixture(scope="module")
@@ -49,6 +50,8 @@ def reference_entry(id_, ts, segs, row, dim, with_id=True, packed=False):
     s = e.opt.dump.add()
     if kind == BATCH_SOFTMAX:
       s.batch_softmax.global_step = int(np.array(row[st:st + 2], np.float32).view(np.int64)[0])
+    elif kind == GROUP_ADAGRAD:
+      s.group_adagrad.grad_square_sum = row[st]
     elif kind == SGD:
       s.sgd.SetInParent()
     elif kind == ADAGRAD:
@@ -103,7 +106,7 @@ def test_reference_golden_entry_dump(driver):
 @pytest.mark.parametrize("segs", [[(SGD, 3)], [(ADAGRAD, 4)], [(FTRL, 2)],
                                   [(FTRL, 1), (ADAGRAD, 5), (SGD, 2)], [(MOMENTUM, 3)],
                                   [(ADADELTA, 2)], [(RMSPROP, 2), (RMSPROPV2, 1)], [(ADAM, 4)],
-                                  [(AMSGRAD, 2), (ADAM, 1), (SGD, 1)]])
+                                  [(AMSGRAD, 2), (ADAM, 1), (SGD, 1)], [(GROUP_ADAGRAD, 3), (ADAGRAD, 2)]])
 def test_entry_bytes_equal_protobuf_runtime(driver, segs):
   rng = np.random.default_rng(len(segs) * 11 + segs[0][1])
   dim = sum(d for _, d in segs)

@@ -261,6 +261,8 @@ OPT_KATS = [
      [-0.01983060], "amsgrad_optimizer_test.cc:32-51"),
     ("moving_average", O.OPT_MOVING_AVERAGE, (0.9,), 0.01, [10.0, 1.0], [1.0, 0.1], [1.9, 0.19],
      "moving_average_optimizer_test.cc:32-68"),
+    ("group_adagrad", O.OPT_GROUP_ADAGRAD, (0.0, 1.0, 1.0, 0.0), 0.01, [10.0], [-0.008182], [-0.014125],
+     "group_adagrad_optimizer_test.cc:32-56"),
 ]
 
 
@@ -295,3 +297,13 @@ def test_batch_softmax_kat():
   t.optimize(np.array([9, 9], np.int64), np.zeros((2, 1), np.float32), [0.1], 0, global_step=3)
   first = np.float32(np.float32(0.1) * np.float32(3.0))
   assert t.lookup(np.array([9], np.int64))[0][0][0] == np.float32(np.float32(0.9) * first)
+
+
+def test_group_adagrad_list_kat():
+  """group_adagrad_optimizer_test.cc:58-84: dim 2, l2 0.5, beta 1, accumulator 0."""
+  t = O.Table([O.segment(2, O.OPT_GROUP_ADAGRAD, p=(0.0, 1.0, 0.5, 0.0))], 1)
+  one = np.array([7], np.int64)
+  t.optimize(one, np.array([[10.0, 1.0]], np.float32), [0.01], 0)
+  np.testing.assert_allclose(t.lookup(one)[0][0], [-0.008639, -0.000864], rtol=0, atol=1e-6)
+  t.optimize(one, np.array([[1.0, 5.0]], np.float32), [0.01], 0)
+  np.testing.assert_allclose(t.lookup(one)[0][0], [-0.009096, -0.004778], rtol=0, atol=1e-6)

@@ -765,6 +765,8 @@ _OPT_ENTRY = {
     "adam": lambda: entry.AdamOptimizer(0.01),
     "amsgrad": lambda: entry.AdamOptimizer(0.01, amsgrad=True),
     "moving_average": lambda: entry.MovingAverageOptimizer(0.9),
+    "group_adagrad": lambda: entry.AdaGradWithGroupLassoOptimizer(0.01, beta=1.0, initial_accumulator_value=0.0,
+                                                                  l2_regularization=1.0),
 }
 
 
