@@ -61,9 +61,13 @@ constexpr int kTraceWords = 8;
 struct WaveTrace {
   unsigned long long* rec;
   unsigned long long t0;
+  // (the record pointer is the same for the whole wavefront: computed from the scalar wave index so
+  // that it lives in SGPRs — as a VGPR pair it gets spilled in the tight kernels, and a spill
+  // reload waits for EVERY outstanding global access of the wavefront)
   __device__ __forceinline__ WaveTrace(unsigned long long* trace) : rec(nullptr), t0(0) {
     if (trace) {
-      rec = trace + uint64_t(kTraceWords) * (uint64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
+      const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+      rec = trace + uint64_t(kTraceWords) * (uint64_t(blockIdx.x) * (blockDim.x >> 6) + wave);
       t0 = wall_clock64();
     }
   }
@@ -528,13 +532,16 @@ __device__ __forceinline__ void group_adagrad_segment(const TableView& tv, float
   }
 }
 
-template <int G, int VEC, int OP>
+// BASIC: the table is known to use SGD / Adagrad / FTRL only (the fused training-step kernels:
+// Table::fusable) — the other optimizers are compiled out, which is what keeps the displacement
+// role of step_fwd inside that kernel's register budget.
+template <int G, int VEC, int OP, bool BASIC = false>
 __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool is_new, int j,
                                           const float* __restrict__ values,
                                           const uint32_t* __restrict__ seg_pos, uint32_t q0,
                                           uint32_t q1, int64_t self_pos, const ApplyArgs& a) {
   const int64_t dim = tv.dim;
-  if (OP == kOpOptimize) {  // (group-uniform: every lane of the group walks the segments)
+  if (OP == kOpOptimize && !BASIC) {  // (group-uniform: every lane of the group walks the segments)
     for (uint32_t k = 0; k < tv.nseg; ++k)
       if (tv.seg[k].opt == kOptGroupAdagrad)
         group_adagrad_segment<G, VEC>(tv, rp, is_new, j, values, seg_pos, q0, q1, self_pos, a, k);
@@ -544,18 +551,18 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
     while (k + 1 < tv.nseg && e >= uint32_t(tv.seg[k + 1].w_off)) ++k;
     const SegDesc sd = tv.seg[k];
     const uint32_t le = e - sd.w_off;  // element index inside the segment
-    const bool gag = sd.opt == kOptGroupAdagrad;
+    const bool gag = !BASIC && sd.opt == kOptGroupAdagrad;
     if (gag && OP == kOpOptimize) continue;  // done above, by the whole group
     const float lr = a.lr[k];
-    const int nv = opt_vectors(sd.opt);
-    const bool scal = opt_scalars(sd.opt) != 0;
+    const int nv = BASIC ? (sd.opt == kOptFtrl ? 2 : (sd.opt == kOptAdagrad ? 1 : 0)) : opt_vectors(sd.opt);
+    const bool scal = !BASIC && opt_scalars(sd.opt) != 0;
     Vec<VEC> w, s1, s2, s3;
     float* st1 = rp + sd.st_off + le;
     float* st2 = st1 + sd.dim;
     float* st3 = st2 + sd.dim;
     float* sc = rp + sd.st_off + nv * sd.dim;  // adam / amsgrad: {beta1_power, beta2_power}
     float c1 = 0.f, c2 = 0.f;
-    const bool bsm = sd.opt == kOptBatchSoftmax;  // the slot holds the id's last global step
+    const bool bsm = !BASIC && sd.opt == kOptBatchSoftmax;  // the slot holds the id's last global step
     long long last_step = 0;
     if (is_new || OP == kOpReinit) {
       const float w0 = init_weight(sd);
@@ -608,6 +615,11 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
           if (OP == kOpAssignAdd) {
             w.v[c] = w.v[c] + v.v[c];  // entry_accessor.cc:179-185
           } else {
+            if (BASIC) {
+              if (sd.opt == kOptSgd) w.v[c] = sgd_step(w.v[c], v.v[c], lr);
+              else if (sd.opt == kOptAdagrad) adagrad_step(w.v[c], s1.v[c], v.v[c], lr, sd.p[1]);
+              else ftrl_step(w.v[c], s1.v[c], s2.v[c], v.v[c], lr, sd.p[1], sd.p[2], sd.p[3]);
+            } else
             switch (sd.opt) {
               case kOptSgd: w.v[c] = sgd_step(w.v[c], v.v[c], lr); break;
               case kOptAdagrad: adagrad_step(w.v[c], s1.v[c], v.v[c], lr, sd.p[1]); break;
@@ -1035,7 +1047,7 @@ __device__ __forceinline__ void slowpath_role(const TableView& tv, const int64_t
       // (skip: first occurrence the admission filter let through, upsert_kernel)
       const uint32_t q0 = (skip && seg_off) ? skip[g] : (seg_off ? seg_off[g] : 0u);
       const uint32_t q1 = seg_off ? seg_off[g + 1] : 1u;
-      apply_row<64, VEC, OP>(tv, row_ptr(tv, r), true, lane, values, seg_off ? seg_pos : nullptr,
+      apply_row<64, VEC, OP, GATED>(tv, row_ptr(tv, r), true, lane, values, seg_off ? seg_pos : nullptr,
                              q0, q1, g, a);
       if (OP == kOpReinit && lane == 0) {
         if (seg_off) {

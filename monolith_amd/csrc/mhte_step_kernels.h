@@ -199,7 +199,8 @@ __device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, Rd
   {
     const uint32_t a = L.cnt[2 * t], b = L.cnt[2 * t + 1];
     uint32_t incl = a + b;
-    const int lane = t & 63, w = t >> 6;
+    const int lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // (scalar: see WaveTrace)
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const uint32_t v = __shfl_up(incl, o);
@@ -457,7 +458,8 @@ struct ApplyCtl {
 // row of a found id, fetched while the gradient chain is in flight
 template <int VEC>
 struct RowRegs {
-  Vec<VEC> w, s1, s2;
+  Vec<VEC> w, s1;   // (FTRL's second state vector is read by optimize_row_pre itself: keeping
+                    // it here as well costs four registers of every SGD / Adagrad step)
 };
 
 template <int VEC>
@@ -470,7 +472,6 @@ __device__ __forceinline__ void row_prefetch(const TableView& tv, const float* r
   const uint32_t le = e - sd.w_off;
   r.w.load(rp + e);
   if (sd.opt == kOptAdagrad || sd.opt == kOptFtrl) r.s1.load(rp + sd.st_off + le);
-  if (sd.opt == kOptFtrl) r.s2.load(rp + sd.st_off + sd.dim + le);
 }
 
 // one optimizer step with the row already in registers (is_new: start from the initializer)
@@ -488,14 +489,17 @@ __device__ __forceinline__ void optimize_row_pre(const TableView& tv, float* rp,
   float* st2 = st1 + sd.dim;
   const bool has1 = sd.opt == kOptAdagrad || sd.opt == kOptFtrl;
   const bool has2 = sd.opt == kOptFtrl;
+  Vec<VEC> s2;
+  vec_zero(s2);
   if (is_new) {
     const float w0 = init_weight(sd);
 #pragma unroll
     for (int c = 0; c < VEC; ++c) {
       r.w.v[c] = w0;
       r.s1.v[c] = sd.p[0];
-      r.s2.v[c] = 0.f;
     }
+  } else if (has2) {
+    s2.load(st2);
   }
 #pragma unroll
   for (int c = 0; c < VEC; ++c) {
@@ -504,12 +508,12 @@ __device__ __forceinline__ void optimize_row_pre(const TableView& tv, float* rp,
     } else if (sd.opt == kOptAdagrad) {
       adagrad_step(r.w.v[c], r.s1.v[c], g.v[c], lr, sd.p[1]);
     } else {
-      ftrl_step(r.w.v[c], r.s1.v[c], r.s2.v[c], g.v[c], lr, sd.p[1], sd.p[2], sd.p[3]);
+      ftrl_step(r.w.v[c], r.s1.v[c], s2.v[c], g.v[c], lr, sd.p[1], sd.p[2], sd.p[3]);
     }
   }
   r.w.store(rp + e);
   if (has1) r.s1.store(st1);
-  if (has2) r.s2.store(st2);
+  if (has2) s2.store(st2);
 }
 
 // Probe state of one id per G-lane group, split in two so the caller can put work between the
@@ -688,7 +692,11 @@ __device__ __forceinline__ SlotResult upsert_complete(const TableView& tv, Bucke
   if (lostm && lane == __ffsll(static_cast<long long>(lostm)) - 1)
     atomicAdd(&tv.ctr->alloc, ~((static_cast<unsigned long long>(__popcll(lostm)) << 32) - 1ull));
   const uint32_t found_row = __shfl(row, gbase + (owner < 0 ? 0 : owner));
-  const uint64_t below = (uint64_t(1) << gbase) - 1;
+  // (computed from a value the compiler cannot trace back to the lane id: hoisted out of the
+  // caller's loop, this mask gets spilled, and a spill reload waits for every load in flight)
+  int gb = gbase;
+  asm volatile("" : "+v"(gb));
+  const uint64_t below = (uint64_t(1) << gb) - 1;
   uint32_t r;
   if (is_new) {
     r = ((f.specm >> gbase) & 1ull) ? base_row + uint32_t(__popcll(f.specm & below))
@@ -736,7 +744,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
     __shared__ uint32_t sh_pos[NG][kLightMax];
     __shared__ uint32_t sh_need[4];   // rows each wavefront needs this trip
     __shared__ uint32_t sh_rowbase;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t stride = int64_t(c.nblk_ids) * NG;
     const int64_t k = bid - c.nblk_items;
     int64_t nu = c.n_max;  // refined below, once the count has arrived with the first trip's loads
@@ -748,7 +756,6 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       const bool inb = g < c.n_max;
       const int64_t id = inb ? d.uids[g] : 0;
       uint32_t cnt = inb ? d.ucnt[g] : 0u;
-      const unsigned long long bm = inb ? d.ublk[g] : 0ull;
       const uint32_t hp = inb ? d.upos[g] : 0u;
       const uint32_t gs = inb ? d.uslot[g] : 0u;
       if (it == 0) nu = min(c.n_max, int64_t(d.ctr[0]));
@@ -761,9 +768,9 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       const bool single = valid && cnt == 1;
       const bool big = valid && cnt > uint32_t(kLightMax);  // (exact order only)
       const bool flat = valid && !single && !big;
-      Vec<VEC> g1;
-      vec_zero(g1);
-      if (single && ev) g1.load(c.grads + int64_t(hp) * dim + e);
+      Vec<VEC> acc;  // (a lone occurrence's gradient is loaded straight into the accumulator)
+      vec_zero(acc);
+      if (single && ev) acc.load(c.grads + int64_t(hp) * dim + e);
       // a short list (2..kLightMax occurrences): its positions from the dedup's per-id list, runs in
       // arrival order -> ranked in registers (positions are distinct, so the ranks are a
       // permutation) and handed over in position order through LDS
@@ -798,7 +805,6 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       RowRegs<VEC> rr;
       vec_zero(rr.w);
       vec_zero(rr.s1);
-      vec_zero(rr.s2);
       const bool pre = valid && uf.found;
       if (__any(pre)) {
         const uint32_t frow = __shfl(pr.row, gbase + (uf.owner < 0 ? 0 : uf.owner));
@@ -823,13 +829,14 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       }
       lds_wave_sync();
       if (it == 0) wt.mark(2);
-      Vec<VEC> acc;
-      vec_zero(acc);
-      if (single) vec_add(acc, g1);  // 0 + g, as the sequential sum starts
+      if (single) {  // 0 + g, as the sequential sum starts
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc.v[q] = 0.f + acc.v[q];
+      }
       if (flat) sum_list_lds<VEC>(c.grads, dim, e, ev, sh_pos[grp], cnt, acc);
       if (big) {
         // strictly sequential sum of a long list (MHTE_EXACT_ORDER): run after run
-        unsigned long long rest = bm;
+        unsigned long long rest = d.ublk[g];
 #pragma unroll 1
         while (rest) {
           const uint32_t b = uint32_t(__ffsll(static_cast<long long>(rest)) - 1);
