@@ -238,7 +238,7 @@ struct DedupWs {
 
   // items of a list of c occurrences < c / target + 1 (rd_item_blocks), lists > kLightMax
   static uint32_t max_items(int64_t n) {
-    return uint32_t(n / item_target() + n / (kLightMax + 1) + 2);
+    return uint32_t(n / item_target() + n / (kStepLightMax + 1) + 2);
   }
   static uint32_t item_target() { return kItemTarget; }
 
@@ -292,7 +292,7 @@ struct DedupWs {
   // step_bwd)
   void build_work_list(hipStream_t st) {
     if (r_stage != 1) return;
-    rd_build_kernel<<<build_blocks(rv), 256, 0, st>>>(rv, uint32_t(kLightMax));
+    rd_build_kernel<<<build_blocks(rv), 256, 0, st>>>(rv, uint32_t(kStepLightMax));
     HIP_OK(hipGetLastError());
     r_stage = 2;
   }
@@ -858,7 +858,7 @@ struct Table {
     c.part = ws.part.p;
     c.arrive = ws.arrive.p;
     c.n_max = n_max;
-    c.light_max = exact_order ? 0xffffffffu : uint32_t(kLightMax);
+    c.light_max = exact_order ? 0xffffffffu : uint32_t(kStepLightMax);
     // fixed grids with grid-stride loops: item workgroups first (longest chain), sized for the
     // work a Zipf batch has; more ids / items than workgroups just means more trips
     const uint32_t groups_per_wg = uint32_t(256 / sh.G);
@@ -879,7 +879,13 @@ struct Table {
     v.trace = trace_region(kTagStepBwd, grid.x, 256);
     const RunView cur = ws.rv;
 #define CALL(G_, V_) \
-  LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_>), grid, 256, st, nxt, nblk_build, v, cur, c, a)
+  do {                                                                                               \
+    if (nseg == 1) {                                                                                 \
+      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a);  \
+    } else {                                                                                         \
+      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, false>), grid, 256, st, nxt, nblk_build, v, cur, c, a); \
+    }                                                                                                \
+  } while (0)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
     hipError_t le = hipGetLastError();

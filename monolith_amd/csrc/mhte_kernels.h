@@ -97,10 +97,48 @@ struct ApplyArgs {
                            //    (cuckoo_embedding_hash_table.cc:229-236)
 };
 
+// Tells the compiler that p points into global memory (HBM).  A pointer it cannot trace back to a
+// kernel argument — the slab table's entries are loaded from memory — is otherwise accessed with
+// FLAT instructions, which count on the LDS/scalar counter as well: every LDS wait, scalar load
+// and LDS-only barrier of the wavefront then also waits for the HBM access to come back.
+template <typename T>
+__device__ __forceinline__ T* assume_global(T* p) {
+  return (T*)(__attribute__((address_space(1))) T*)(p);
+}
+// (the cast pair above does not always survive to instruction selection; the hot accesses below
+// go through pointers that are global BY TYPE)
+#define MHTE_GLOBAL __attribute__((address_space(1)))
+typedef MHTE_GLOBAL Bucket GBucket;
+__device__ __forceinline__ GBucket* global_bucket(Bucket* b) { return (GBucket*)b; }
+// 64-bit CAS on a bucket's key word (what atomicCAS does, on a global-typed pointer); returns the old value
+__device__ __forceinline__ unsigned long long cas_key(MHTE_GLOBAL int64_t* p, int64_t expect,
+                                                      int64_t desired) {
+  unsigned long long e = static_cast<unsigned long long>(expect);
+  __hip_atomic_compare_exchange_strong((MHTE_GLOBAL unsigned long long*)p, &e,
+                                       static_cast<unsigned long long>(desired), __ATOMIC_RELAXED,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return e;
+}
+
+// Segment descriptor of row element e (k: its index).  One-segment tables — the usual case — read
+// it with scalar loads at a constant offset; indexing tv.seg with a per-lane k is a vector load
+// from the kernel-argument buffer, i.e. one more dependent round trip in front of the row's
+// optimizer state.
+// ONESEG is a compile-time fact of the caller's code path (the step kernels branch on tv.nseg once,
+// at the top): mixing the two forms under one result keeps the descriptor in 14 vector registers.
+template <bool ONESEG>
+__device__ __forceinline__ SegDesc seg_of(const TableView& tv, uint32_t e, uint32_t& k) {
+  k = 0;
+  if (ONESEG) return tv.seg[0];
+  while (k + 1 < tv.nseg && e >= uint32_t(tv.seg[k + 1].w_off)) ++k;
+  return tv.seg[k];
+}
+
 __device__ __forceinline__ float* row_ptr(const TableView& tv, uint32_t r) {
   const uint32_t c = r >> tv.chunk_shift;
-  float* base = (c == 0) ? tv.chunk0 : tv.chunks[c];
-  return base + size_t(r & ((1u << tv.chunk_shift) - 1u)) * tv.row_floats;
+  typedef float* slab_ptr;
+  float* base = (c == 0) ? tv.chunk0 : *(const MHTE_GLOBAL slab_ptr*)(tv.chunks + c);
+  return assume_global(base + size_t(r & ((1u << tv.chunk_shift) - 1u)) * tv.row_floats);
 }
 
 template <int G>
@@ -114,19 +152,23 @@ struct Vec;
 template <>
 struct Vec<4> {
   float v[4];
+  // (rows, gradients and outputs all live in HBM: global loads / stores by pointer type)
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
   __device__ __forceinline__ void load(const float* p) {
-    float4 t = *reinterpret_cast<const float4*>(p);
+    const f32x4 t = *(const MHTE_GLOBAL f32x4*)(p);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
   }
   __device__ __forceinline__ void store(float* p) const {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    f32x4 t;
+    t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+    *(MHTE_GLOBAL f32x4*)(p) = t;
   }
 };
 template <>
 struct Vec<1> {
   float v[1];
-  __device__ __forceinline__ void load(const float* p) { v[0] = *p; }
-  __device__ __forceinline__ void store(float* p) const { *p = v[0]; }
+  __device__ __forceinline__ void load(const float* p) { v[0] = *(const MHTE_GLOBAL float*)(p); }
+  __device__ __forceinline__ void store(float* p) const { *(MHTE_GLOBAL float*)(p) = v[0]; }
 };
 
 // =============================================================================================
@@ -258,7 +300,7 @@ __device__ __forceinline__ void lookup_role(const TableView& tv, const int64_t* 
   bool match = false;
   uint32_t row = kNoRow;
   if (valid && j < 8 && id != kEmptyKey) {
-    const Bucket* b = tv.buckets + ((j < 4) ? i1 : i2);
+    const Bucket* b = assume_global(tv.buckets + ((j < 4) ? i1 : i2));
     const int s = j & 3;
     const int64_t k = b->key[s];
     row = b->row[s];
@@ -326,7 +368,7 @@ __device__ __forceinline__ void lookup_role_u(const TableView& tv, const int64_t
       const uint64_t hv = hash_key(id[u]);
       const uint64_t i1 = index_hash(tv.hp, hv);
       const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
-      const Bucket* b = tv.buckets + ((j < 4) ? i1 : i2);
+      const Bucket* b = assume_global(tv.buckets + ((j < 4) ? i1 : i2));
       const int64_t k = b->key[j & 3];
       row[u] = b->row[j & 3];
       match[u] = (k == id[u]);
@@ -548,8 +590,7 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
   }
   for (uint32_t e = j * VEC; e < tv.dim; e += G * VEC) {
     uint32_t k = 0;
-    while (k + 1 < tv.nseg && e >= uint32_t(tv.seg[k + 1].w_off)) ++k;
-    const SegDesc sd = tv.seg[k];
+    const SegDesc sd = seg_of<false>(tv, e, k);
     const uint32_t le = e - sd.w_off;  // element index inside the segment
     const bool gag = !BASIC && sd.opt == kOptGroupAdagrad;
     if (gag && OP == kOpOptimize) continue;  // done above, by the whole group
@@ -706,12 +747,13 @@ struct SlotResult {
 };
 
 template <int G>
-__device__ __forceinline__ SlotResult upsert_resolve(const TableView& tv, Bucket* b, int64_t id,
+__device__ __forceinline__ SlotResult upsert_resolve(const TableView& tv, Bucket* b_generic, int64_t id,
                                                      bool valid, int64_t k, uint32_t row, int lane,
                                                      uint32_t ts) {
   const int j = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
   const int s = j & 3;
+  GBucket* b = global_bucket(b_generic);
   const bool special = valid && id == kEmptyKey;
   const bool prober = valid && !special && j < 8;
   uint64_t m = group_mask_of<G>(__ballot(prober && k == id), gbase);
@@ -736,9 +778,7 @@ __device__ __forceinline__ SlotResult upsert_resolve(const TableView& tv, Bucket
     }
     bool won = false;
     if (need && j == pick) {
-      const unsigned long long old =
-          atomicCAS(reinterpret_cast<unsigned long long*>(&b->key[s]),
-                    static_cast<unsigned long long>(kEmptyKey), static_cast<unsigned long long>(id));
+      const unsigned long long old = cas_key(&b->key[s], kEmptyKey, id);
       won = (static_cast<int64_t>(old) == kEmptyKey);
       k = won ? id : static_cast<int64_t>(old);
     }
@@ -816,7 +856,7 @@ __global__ __launch_bounds__(256) void upsert_kernel(TableView tv, const int64_t
   const uint64_t i1 = index_hash(tv.hp, hv);
   const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
 
-  Bucket* b = tv.buckets + ((j < 4) ? i1 : i2);
+  Bucket* b = assume_global(tv.buckets + ((j < 4) ? i1 : i2));
   int64_t k = kEmptyKey;
   uint32_t row = kNoRow;
   if (valid && id != kEmptyKey && j < 8) {
@@ -1101,7 +1141,7 @@ __global__ __launch_bounds__(256) void restore_rows_kernel(TableView tv,
   const uint64_t hv = hash_key(id);
   const uint64_t i1 = index_hash(tv.hp, hv);
   const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
-  Bucket* b = tv.buckets + ((j < 4) ? i1 : i2);
+  Bucket* b = assume_global(tv.buckets + ((j < 4) ? i1 : i2));
   int64_t k = kEmptyKey;
   uint32_t row = kNoRow;
   if (valid && id != kEmptyKey && j < 8) {
@@ -2196,13 +2236,12 @@ __device__ __forceinline__ void load_agent(const float* p, Vec<VEC>& v) {
 }
 
 // one optimizer step on the lane's element vector, gradient in registers (kOpOptimize only)
-template <int VEC>
+template <int VEC, bool ONESEG = false>
 __device__ __forceinline__ void optimize_row_reg(const TableView& tv, float* rp, bool is_new,
                                                  uint32_t e, const Vec<VEC>& g, const ApplyArgs& a) {
   if (e >= tv.dim) return;
   uint32_t k = 0;
-  while (k + 1 < tv.nseg && e >= uint32_t(tv.seg[k + 1].w_off)) ++k;
-  const SegDesc sd = tv.seg[k];
+  const SegDesc sd = seg_of<ONESEG>(tv, e, k);
   const uint32_t le = e - sd.w_off;
   const float lr = a.lr[k];
   Vec<VEC> w, s1, s2;
@@ -2250,7 +2289,7 @@ __device__ __forceinline__ void upsert_reg(const TableView& tv, const int64_t* _
   const uint64_t hv = hash_key(id);
   const uint64_t i1 = index_hash(tv.hp, hv);
   const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
-  Bucket* b = tv.buckets + ((j < 4) ? i1 : i2);
+  Bucket* b = assume_global(tv.buckets + ((j < 4) ? i1 : i2));
   int64_t k = kEmptyKey;
   uint32_t row = kNoRow;
   if (valid && id != kEmptyKey && j < 8) {
@@ -2312,7 +2351,7 @@ __device__ __forceinline__ void sum_apply_role(
     const uint64_t hv = hash_key(id);
     const uint64_t i1 = index_hash(tv.hp, hv);
     const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
-    Bucket* b = tv.buckets + ((j < 4) ? i1 : i2);
+    Bucket* b = assume_global(tv.buckets + ((j < 4) ? i1 : i2));
     int64_t k = kEmptyKey;
     uint32_t row = kNoRow;
     if (valid && id != kEmptyKey && j < 8) {  // probe loads go out first ...

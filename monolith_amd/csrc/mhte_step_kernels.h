@@ -42,6 +42,10 @@ constexpr int kRdLds = 2048;            // LDS hash entries per workgroup
 constexpr int kRdStride = kRdLds + 1;   // + side entry for kEmptyKey
 constexpr int kRdMaxBlocks = 64;        // bits of the workgroup mask: n <= 65 536 positions
 constexpr int kLongRun = kLightMax;  // (a run that may belong to a light list keeps its positions in LDS)
+// Lists of up to this many occurrences are summed by ONE lane group, 8 gradient rows in flight at
+// a time; longer ones go to the item workgroups.  (16 instead: +4 us on step_bwd — the extra
+// ~70 items land on the critical path of the launch.)
+constexpr int kStepLightMax = 32;
 constexpr int kMaxLongRuns = 16;
 constexpr uint32_t kItemTarget = 256;   // entries per heavy work item (expected)
 constexpr uint32_t kSpecSlackRows = 32; // row handles an update may strand (upsert_issue), per op
@@ -462,27 +466,25 @@ struct RowRegs {
                     // it here as well costs four registers of every SGD / Adagrad step)
 };
 
-template <int VEC>
+template <int VEC, bool ONESEG>
 __device__ __forceinline__ void row_prefetch(const TableView& tv, const float* rp, uint32_t e,
                                              RowRegs<VEC>& r) {
   if (e >= tv.dim) return;
   uint32_t k = 0;
-  while (k + 1 < tv.nseg && e >= uint32_t(tv.seg[k + 1].w_off)) ++k;
-  const SegDesc sd = tv.seg[k];
+  const SegDesc sd = seg_of<ONESEG>(tv, e, k);
   const uint32_t le = e - sd.w_off;
   r.w.load(rp + e);
   if (sd.opt == kOptAdagrad || sd.opt == kOptFtrl) r.s1.load(rp + sd.st_off + le);
 }
 
 // one optimizer step with the row already in registers (is_new: start from the initializer)
-template <int VEC>
+template <int VEC, bool ONESEG>
 __device__ __forceinline__ void optimize_row_pre(const TableView& tv, float* rp, bool is_new,
                                                  uint32_t e, const Vec<VEC>& g, const ApplyArgs& a,
                                                  RowRegs<VEC>& r) {
   if (e >= tv.dim) return;
   uint32_t k = 0;
-  while (k + 1 < tv.nseg && e >= uint32_t(tv.seg[k + 1].w_off)) ++k;
-  const SegDesc sd = tv.seg[k];
+  const SegDesc sd = seg_of<ONESEG>(tv, e, k);
   const uint32_t le = e - sd.w_off;
   const float lr = a.lr[k];
   float* st1 = rp + sd.st_off + le;
@@ -520,7 +522,7 @@ __device__ __forceinline__ void optimize_row_pre(const TableView& tv, float* rp,
 // bucket loads and their use.
 template <int G>
 struct Probe {
-  Bucket* b;
+  GBucket* b;
   int64_t k;
   uint32_t row;
 };
@@ -530,7 +532,7 @@ __device__ __forceinline__ Probe<G> probe_issue(const TableView& tv, int64_t id,
   const uint64_t i1 = index_hash(tv.hp, hv);
   const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
   Probe<G> p;
-  p.b = tv.buckets + ((j < 4) ? i1 : i2);
+  p.b = global_bucket(tv.buckets + ((j < 4) ? i1 : i2));
   p.k = kEmptyKey;
   p.row = kNoRow;
   if (valid && id != kEmptyKey && j < 8) {
@@ -581,7 +583,7 @@ struct UpsertFlight {
 };
 
 template <int G>
-__device__ __forceinline__ UpsertFlight<G> upsert_issue(const TableView& tv, Bucket* b, int64_t id,
+__device__ __forceinline__ UpsertFlight<G> upsert_issue(const TableView& tv, GBucket* b, int64_t id,
                                                         bool valid, int64_t k, int lane) {
   const int j = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
@@ -604,14 +606,13 @@ __device__ __forceinline__ UpsertFlight<G> upsert_issue(const TableView& tv, Buc
   }
   f.cas_old = 0ull;
   if (f.need && j == f.pick)
-    f.cas_old = atomicCAS(reinterpret_cast<unsigned long long*>(&b->key[j & 3]),
-                          static_cast<unsigned long long>(kEmptyKey), static_cast<unsigned long long>(id));
+    f.cas_old = cas_key(&b->key[j & 3], kEmptyKey, id);
   f.specm = __ballot(f.need && j == 0);
   return f;
 }
 
 template <int G>
-__device__ __forceinline__ SlotResult upsert_complete(const TableView& tv, Bucket* b, int64_t id,
+__device__ __forceinline__ SlotResult upsert_complete(const TableView& tv, GBucket* b, int64_t id,
                                                       bool valid, uint32_t row, int lane, uint32_t ts,
                                                       const UpsertFlight<G>& f, uint32_t base_row) {
   const int j = lane & (G - 1);
@@ -652,9 +653,7 @@ __device__ __forceinline__ SlotResult upsert_complete(const TableView& tv, Bucke
       }
       bool w2 = false;
       if (need && j == pick) {
-        const unsigned long long old =
-            atomicCAS(reinterpret_cast<unsigned long long*>(&b->key[s]),
-                      static_cast<unsigned long long>(kEmptyKey), static_cast<unsigned long long>(id));
+        const unsigned long long old = cas_key(&b->key[s], kEmptyKey, id);
         w2 = (static_cast<int64_t>(old) == kEmptyKey);
         k = w2 ? id : static_cast<int64_t>(old);
       }
@@ -722,7 +721,7 @@ __device__ __forceinline__ SlotResult upsert_complete(const TableView& tv, Bucke
   return out;
 }
 
-template <int G, int VEC>
+template <int G, int VEC, bool ONESEG>
 __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView& d,
                                               const ApplyCtl& c, const ApplyArgs& a, uint32_t bid,
                                               WaveTrace& wt) {
@@ -741,7 +740,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
     // Group `grp` of workgroup k takes the unique indices u = it * stride + grp * nblk_ids + k:
     // consecutive indices (the claim order puts the hot ids first) land in different workgroups.
     // A group lives inside one wavefront, so its LDS hand-offs need no workgroup barrier.
-    __shared__ uint32_t sh_pos[NG][kLightMax];
+    __shared__ uint32_t sh_pos[NG][kStepLightMax];
     __shared__ uint32_t sh_need[4];   // rows each wavefront needs this trip
     __shared__ uint32_t sh_rowbase;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -766,7 +765,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       if (it == 0) wt.mark(0);
       if (cnt > c.light_max) valid = false;  // heavy list: the item workgroups own it
       const bool single = valid && cnt == 1;
-      const bool big = valid && cnt > uint32_t(kLightMax);  // (exact order only)
+      const bool big = valid && cnt > uint32_t(kStepLightMax);  // (exact order only)
       const bool flat = valid && !single && !big;
       Vec<VEC> acc;  // (a lone occurrence's gradient is loaded straight into the accumulator)
       vec_zero(acc);
@@ -774,7 +773,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       // a short list (2..kLightMax occurrences): its positions from the dedup's per-id list, runs in
       // arrival order -> ranked in registers (positions are distinct, so the ranks are a
       // permutation) and handed over in position order through LDS
-      constexpr int PER = (kLightMax + G - 1) / G;
+      constexpr int PER = (kStepLightMax + G - 1) / G;
       uint32_t x[PER];
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
@@ -797,18 +796,13 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       const UpsertFlight<G> uf = upsert_issue<G>(tv, pr.b, id, valid, pr.k, lane);
       if (lane == 0) sh_need[wave] = uint32_t(__popcll(uf.specm));
       lds_barrier();  // (the trip count is the same for the four wavefronts)
-      unsigned long long rows0 = 0;
-      if (threadIdx.x == 0) {
-        const unsigned long long tot = sh_need[0] + sh_need[1] + sh_need[2] + sh_need[3];
-        if (tot) rows0 = atomicAdd(&tv.ctr->alloc, (tot << 32) | tot);
-      }
       RowRegs<VEC> rr;
       vec_zero(rr.w);
       vec_zero(rr.s1);
       const bool pre = valid && uf.found;
       if (__any(pre)) {
         const uint32_t frow = __shfl(pr.row, gbase + (uf.owner < 0 ? 0 : uf.owner));
-        if (pre) row_prefetch<VEC>(tv, row_ptr(tv, frow), e, rr);
+        if (pre) row_prefetch<VEC, ONESEG>(tv, row_ptr(tv, frow), e, rr);
       }
       if (__any(flat)) {
         uint32_t xr[PER];
@@ -826,6 +820,14 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
 #pragma unroll
         for (int q = 0; q < PER; ++q)
           if (x[q] != 0xffffffffu) sh_pos[grp][xr[q]] = x[q];
+      }
+      // the workgroup's allocation, placed behind the row loads: the compiler waits for a result
+      // produced under a branch where the branch ends, and here that wait is shared with loads this
+      // wavefront needs next anyway
+      unsigned long long rows0 = 0;
+      if (threadIdx.x == 0) {
+        const unsigned long long tot = sh_need[0] + sh_need[1] + sh_need[2] + sh_need[3];
+        if (tot) rows0 = atomicAdd(&tv.ctr->alloc, (tot << 32) | tot);
       }
       lds_wave_sync();
       if (it == 0) wt.mark(2);
@@ -867,14 +869,14 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       float* rp = nullptr;
       if (valid && !sr.deferred) {
         rp = row_ptr(tv, sr.r);
-        if (!sr.is_new && !pre) row_prefetch<VEC>(tv, rp, e, rr);  // (the side slot's row)
+        if (!sr.is_new && !pre) row_prefetch<VEC, ONESEG>(tv, rp, e, rr);  // (the side slot's row)
       }
       if (it == 0) wt.mark(3);
       if (sr.deferred) {
         if (ev) acc.store(c.grad_u + g * int64_t(dim) + e);
         if (j == 0) c.pending[atomicAdd(&tv.ctr->n_pending, 1u)] = uint32_t(g);
       } else if (valid) {
-        optimize_row_pre<VEC>(tv, rp, sr.is_new, e, acc, a, rr);
+        optimize_row_pre<VEC, ONESEG>(tv, rp, sr.is_new, e, acc, a, rr);
       }
       if (it == 0) wt.mark(4);
       lds_barrier();  // sh_pos / sh_need are reused
@@ -1025,12 +1027,12 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         if (valid && j == 0) first = filter_consult(tv, hd.id, d.ucnt[hd.u], 2, contained);
         if (__shfl(first, gbase) != 0u) valid = false;
       }
-      const SlotResult sr = upsert_resolve<G>(tv, pr.b, hd.id, valid, pr.k, pr.row, lane, a.ts);
+      const SlotResult sr = upsert_resolve<G>(tv, (Bucket*)pr.b, hd.id, valid, pr.k, pr.row, lane, a.ts);
       if (sr.deferred) {
         if (ev) tot.store(c.grad_u + int64_t(hd.u) * dim + e);
         if (j == 0) c.pending[atomicAdd(&tv.ctr->n_pending, 1u)] = hd.u;
       } else if (valid) {
-        optimize_row_reg<VEC>(tv, row_ptr(tv, sr.r), sr.is_new, e, tot, a);
+        optimize_row_reg<VEC, ONESEG>(tv, row_ptr(tv, sr.r), sr.is_new, e, tot, a);
       }
     }
     wt.mark(4);
@@ -1111,18 +1113,19 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
 }
 
 // step_bwd:  heavy work list of the NEXT batch | apply of this batch
-template <int G, int VEC>
+// ONESEG: the table has one segment (the host picks the instantiation: see seg_of)
+template <int G, int VEC, bool ONESEG>
 __global__ __launch_bounds__(256, kBwdBlocksPerCu) void step_bwd_kernel(RunView nxt, uint32_t nblk_build,
                                                        TableView tv, RunView cur, ApplyCtl c,
                                                        ApplyArgs a) {
   WaveTrace wt(tv.trace);
   if (blockIdx.x < nblk_build) {
-    rd_build_role(nxt, uint32_t(kLightMax), blockIdx.x, nblk_build);
+    rd_build_role(nxt, uint32_t(kStepLightMax), blockIdx.x, nblk_build);
     wt.end(6u);
     return;
   }
   const uint32_t bid = blockIdx.x - nblk_build;
-  rd_apply_role<G, VEC>(tv, cur, c, a, bid, wt);
+  rd_apply_role<G, VEC, ONESEG>(tv, cur, c, a, bid, wt);
   wt.end(bid < c.nblk_items ? 7u : 8u);
 }
 
@@ -1167,7 +1170,7 @@ __global__ __launch_bounds__(256) void rd_gather_kernel(RunView d, GatherCtl c) 
   const uint32_t bid = blockIdx.x;
 
   if (bid >= c.nblk_items) {
-    __shared__ uint32_t sh_pos[NG][kLightMax];
+    __shared__ uint32_t sh_pos[NG][kStepLightMax];
     const int64_t stride = int64_t(c.nblk_ids) * NG;
     const int64_t k = bid - c.nblk_items;
     int64_t nu = n_max;
@@ -1180,9 +1183,9 @@ __global__ __launch_bounds__(256) void rd_gather_kernel(RunView d, GatherCtl c) 
       const uint32_t gs = inb ? d.uslot[g] : 0u;
       const uint32_t ix = inb ? (c.index ? c.index[g] : uint32_t(g)) : 0u;
       if (it == 0) nu = min(n_max, int64_t(d.ctr[0]));
-      const bool valid = g < nu && cnt <= uint32_t(kLightMax);
+      const bool valid = g < nu && cnt <= uint32_t(kStepLightMax);
       if (!valid) cnt = 0;
-      constexpr int PER = (kLightMax + G - 1) / G;
+      constexpr int PER = (kStepLightMax + G - 1) / G;
       uint32_t x[PER];
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
