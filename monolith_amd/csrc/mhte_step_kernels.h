@@ -921,27 +921,40 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
     vec_zero(acc);
     // this group's windows: qb = (grp + k * NG) * WIN.  The positions of kPre windows are fetched
     // together (one round trip), then each window's WIN gradient rows
-    constexpr int kPre = 4;
+    constexpr int kPre = 2;
 #pragma unroll 1
     for (uint32_t qb0 = uint32_t(grp) * WIN; qb0 < E; qb0 += kPre * NG * WIN) {
-      uint32_t pp[kPre];
+      // positions of the group's next kPre windows: kPre * WIN entries, PPL per lane (entry
+      // idx = r * G + j belongs to window idx / WIN).  Every lane loads — from entry 0 where it has
+      // nothing to fetch — and all loads are issued before any is used: a load under a branch makes
+      // the compiler wait for it where the branch ends, and the fetches would queue up one round
+      // trip after the other.
+      constexpr int PPL = (kPre * WIN + G - 1) / G;
+      uint32_t pp[PPL], pbv[PPL];
+      uint16_t ps[PPL];
 #pragma unroll
-      for (int w2 = 0; w2 < kPre; ++w2) {
-        const uint32_t q = qb0 + uint32_t(w2) * (NG * WIN) + uint32_t(j);
-        pp[w2] = 0;
-        if (j < WIN && q < E) {
-          uint32_t lo = 0, hi = 63;  // run r with rstart[r] <= q < rstart[r+1]
-          while (lo < hi) {
-            const uint32_t mid = (lo + hi + 1) >> 1;
-            if (sh_rstart[mid] <= q) lo = mid; else hi = mid - 1;
-          }
-          const uint32_t val = sh_rval[lo];
-          const uint32_t i = q - sh_rstart[lo];
-          const uint32_t b = b0 + lo;
-          pp[w2] = b * kRdBlock + ((run_cnt(val) == 1) ? run_first(val)
-                                                       : uint32_t(d.seg[b * kRdBlock + run_off(val) + i]));
+      for (int r = 0; r < PPL; ++r) {
+        const uint32_t idx = uint32_t(r) * G + uint32_t(j);
+        const uint32_t q = qb0 + (idx / WIN) * (NG * WIN) + (idx % WIN);
+        const bool has = idx < uint32_t(kPre * WIN) && q < E;
+        const uint32_t qq = has ? q : 0u;
+        uint32_t lo = 0, hi = 63;  // run r with rstart[r] <= q < rstart[r+1]
+#pragma unroll
+        for (int it2 = 0; it2 < 6; ++it2) {
+          const uint32_t mid = (lo + hi + 1) >> 1;
+          const bool le = sh_rstart[mid] <= qq;
+          lo = le ? mid : lo;
+          hi = le ? hi : mid - 1;
         }
+        const uint32_t val = has ? sh_rval[lo] : 0u;
+        const uint32_t base = (b0 + lo) * kRdBlock;
+        ps[r] = d.seg[has ? base + run_off(val) + (qq - sh_rstart[lo]) : 0u];
+        // (base and the run's first position in one word: base < 2^16, first < 2^10, count flag)
+        pbv[r] = base | (run_first(val) << 16) | ((run_cnt(val) == 1 ? 1u : 0u) << 31);
       }
+#pragma unroll
+      for (int r = 0; r < PPL; ++r)
+        pp[r] = (pbv[r] & 0xffffu) + ((pbv[r] >> 31) ? ((pbv[r] >> 16) & 0x3ffu) : uint32_t(ps[r]));
 #pragma unroll
       for (int w2 = 0; w2 < kPre; ++w2) {
         const uint32_t qb = qb0 + uint32_t(w2) * (NG * WIN);
@@ -952,7 +965,8 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         for (int t = 0; t < WIN; ++t) vec_zero(v[t]);
 #pragma unroll
         for (int t = 0; t < WIN; ++t) {
-          const uint32_t pt = __shfl(pp[w2], gbase + t);
+          const int idx = w2 * WIN + t;  // (compile-time: which lane and register hold the position)
+          const uint32_t pt = __shfl(pp[idx / G], gbase + (idx % G));
           if (qb + t < E && ev) v[t].load(c.grads + int64_t(pt) * dim + e);
         }
 #pragma unroll
