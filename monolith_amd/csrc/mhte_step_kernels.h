@@ -263,7 +263,10 @@ __device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, Rd
   // ---- now the CAS: the home slot was free or already held the id (usual), else linear probing.
   // The count bump returns the number of occurrences other workgroups have registered so far =
   // where this run goes in the id's position list; it is in flight during the table dump.
-  uint32_t lbase = 0;
+  // (deliberately not initialised: only speakers read it, and a value merged with a constant at
+  // the end of the branch would make the compiler wait for the atomic right there instead of
+  // after the table dump below)
+  uint32_t lbase;
   if (speaker) {
     if (id != kEmptyKey) {
       while (cas_old != kEmptyKey && cas_old != id) {
@@ -753,11 +756,12 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       // round trip 1: everything about unique index g (the build role's dense arrays; an index past
       // the count reads stale entries of the preallocated arrays and is dropped)
       const bool inb = g < c.n_max;
+      const uint32_t n_unique = d.ctr[0];  // (issued with the rest of the trip: not behind its wait)
       const int64_t id = inb ? d.uids[g] : 0;
       uint32_t cnt = inb ? d.ucnt[g] : 0u;
       const uint32_t hp = inb ? d.upos[g] : 0u;
       const uint32_t gs = inb ? d.uslot[g] : 0u;
-      if (it == 0) nu = min(c.n_max, int64_t(d.ctr[0]));
+      nu = min(c.n_max, int64_t(n_unique));
       bool valid = g < nu;
       if (!valid) cnt = 0;
       // round trip 2: table probe | gradient of a lone occurrence | run tables of a short list
@@ -824,10 +828,10 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       // the workgroup's allocation, placed behind the row loads: the compiler waits for a result
       // produced under a branch where the branch ends, and here that wait is shared with loads this
       // wavefront needs next anyway
-      unsigned long long rows0 = 0;
+      unsigned long long rows0;  // (not initialised on purpose: see lbase in rd_dedup_role)
       if (threadIdx.x == 0) {
         const unsigned long long tot = sh_need[0] + sh_need[1] + sh_need[2] + sh_need[3];
-        if (tot) rows0 = atomicAdd(&tv.ctr->alloc, (tot << 32) | tot);
+        if (tot) rows0 = atomicAdd(&tv.ctr->alloc, (tot << 32) | tot);  // (no rows needed: unread)
       }
       lds_wave_sync();
       if (it == 0) wt.mark(2);
@@ -895,7 +899,10 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
     // stale entries of the preallocated list and is dropped)
     const uint32_t nitems_all = d.ctr[2];
     const ItemHdr hd = d.item_hdr[w];
-    const uint32_t rval = (threadIdx.x < 64) ? d.item_runs[size_t(w) * 64 + lane] : 0u;
+    const uint32_t rval = d.item_runs[size_t(w) * 64 + lane];  // (every wavefront: no branch, no queueing)
+    // (pins the three loads above in front of the exit test: sunk below it, they would wait for
+    // the count's round trip first)
+    asm volatile("" ::"v"(hd.meta), "v"(rval), "v"(nitems_all));
     if (w >= nitems_all) break;
     wt.mark(0);
     const uint32_t b0 = hd.meta & 0xffu, nbk = (hd.meta >> 8) & 0xffu, kk = (hd.meta >> 16) & 0xffu,
@@ -1266,7 +1273,10 @@ __global__ __launch_bounds__(256) void rd_gather_kernel(RunView d, GatherCtl c) 
   for (uint32_t w = bid;; w += c.nblk_items) {
     const uint32_t nitems_all = d.ctr[2];
     const ItemHdr hd = d.item_hdr[w];
-    const uint32_t rval = (threadIdx.x < 64) ? d.item_runs[size_t(w) * 64 + lane] : 0u;
+    const uint32_t rval = d.item_runs[size_t(w) * 64 + lane];  // (every wavefront: no branch, no queueing)
+    // (pins the three loads above in front of the exit test: sunk below it, they would wait for
+    // the count's round trip first)
+    asm volatile("" ::"v"(hd.meta), "v"(rval), "v"(nitems_all));
     if (w >= nitems_all) break;
     const uint32_t b0 = hd.meta & 0xffu, nbk = (hd.meta >> 8) & 0xffu, kk = (hd.meta >> 16) & 0xffu,
                    nitems = hd.meta >> 24;
