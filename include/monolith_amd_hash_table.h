@@ -42,7 +42,7 @@ enum {
 
 const char* mhte_last_error(void);
 /* ABI version of this header; mhte_abi_version() must return the same value. */
-#define MHTE_ABI_VERSION 3
+#define MHTE_ABI_VERSION 4
 int32_t mhte_abi_version(void);
 
 /* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
@@ -361,6 +361,10 @@ mhte_status mhte_table_finish_pending(mhte_multi_table* t, int32_t table, void* 
  * order, like the iteration order of the flat_hash_map the reference dedups with) and their count;
  * the occurrence lists stay in the workspace in the step's own run format.
  *   ws / ws_next   two workspaces used alternately; ws_next may be NULL (no following batch)
+ *   ws_cur         (step_forward, optional) the workspace that holds THIS batch's run dedup: the
+ *                  launch then also reserves, with one counter bump per workgroup, the row handles
+ *                  of the ids its update will have to insert (the update's own reservations all
+ *                  hit one counter word and pace that launch); NULL: the update reserves itself
  *   flags          MHTE_EXACT_ORDER: every list is summed strictly in occurrence order (bit-exact
  *                  with the reference); otherwise lists of > 32 occurrences are summed as a fixed
  *                  tree over position ranges (deterministic; fp32 re-association only)
@@ -394,7 +398,7 @@ mhte_status mhte_table_step_forward(mhte_multi_table* t, int32_t table, const in
                                     int64_t n, float* embedding, mhte_dedup_ws* ws_next,
                                     const int64_t* id_next, int64_t n_next,
                                     int64_t* unique_ids_next, uint32_t* n_unique_dev_next,
-                                    void* stream);
+                                    mhte_dedup_ws* ws_cur, void* stream);
 mhte_status mhte_table_step_backward(mhte_multi_table* t, int32_t table, mhte_dedup_ws* ws,
                                      mhte_dedup_ws* ws_next, const int64_t* unique_ids,
                                      int64_t n_max, const uint32_t* n_unique_dev,

@@ -232,6 +232,8 @@ struct DedupWs {
   DevBuf<uint16_t> r_seg;
   DevBuf<ItemHdr> r_item_hdr;
   DevBuf<uint32_t> r_cursor;   // shard packing cursors
+  DevBuf<uint32_t> r_spec;     // row handles reserved for the batch's unique ids (rd_prealloc_role)
+  bool r_prealloc = false;     // r_spec holds the reservations of the deduplicated batch
   uint32_t r_clean_cap = 0;  // run scratch [0, r_clean_cap] is all-empty
   int r_stage = 0;           // 0 idle, 1 dedup enqueued, 2 work list enqueued (ready for apply)
   RunView rv{};
@@ -281,6 +283,7 @@ struct DedupWs {
     }
     rv = d;
     r_stage = 1;
+    r_prealloc = false;
     return d;
   }
   // workgroups of the build role: one trip of 256 slots per wavefront, at most 128 workgroups
@@ -569,6 +572,13 @@ struct Table {
   }
 
   // Called before every mutating op with the number of ids it may insert.
+  // true if ensure_capacity(n) would have to grow the table (a displacement pass still
+  // outstanding must be finished first: growing re-hashes)
+  bool would_grow(uint64_t n) const {
+    const uint64_t row_cap = uint64_t(chunks.size()) << chunk_shift;
+    return double(keys_upper + n) > max_load * double(uint64_t(kSlots) << hp) ||
+           rows_upper + n + kSpecSlackRows > row_cap;
+  }
   void ensure_capacity(uint64_t n, hipStream_t st) {
     keys_upper += n;
     rows_upper += n + kSpecSlackRows;
@@ -775,9 +785,26 @@ struct Table {
   //   step_forward   lookup of this batch | run dedup of the next batch
   //                  | displacement pass of the previous update (gated, usually idle)
   //   step_backward  apply of this batch | heavy work list of the next batch
-  void step_forward(const int64_t* ids, int64_t n, float* out, const RunView& nxt, hipStream_t st) {
+  // ws_cur: the workspace that holds THIS batch's deduplicated + built ids (or nullptr): the launch
+  // then also reserves the row handles its update will need (rd_prealloc_role)
+  void step_forward(const int64_t* ids, int64_t n, float* out, const RunView& nxt, DedupWs* ws_cur,
+                    hipStream_t st) {
     if (n <= 0) throw Error(MHTE_INVALID_ARGUMENT, "step_forward: empty batch");
     Shape sh = pick_shape(dim, vec_ok && aligned16(out));
+    PreArgs pre{};
+    if (ws_cur && ws_cur->r_stage == 2 && !flt_slots && int64_t(ws_cur->rv.n) == n) {
+      // (with an admission filter an id the table lacks may not be inserted at all: the update
+      // keeps its own allocation then)
+      if (would_grow(uint64_t(n))) finish_pending(st);
+      ensure_capacity(uint64_t(n), st);
+      ws_cur->r_spec.reserve(size_t(n) + 1);
+      pre.uids = ws_cur->rv.uids;
+      pre.ctr = ws_cur->rv.ctr;
+      pre.spec_row = ws_cur->r_spec.p;
+      pre.n_max = uint32_t(n);
+      pre.nblk = std::min<uint32_t>(16, uint32_t((n + kRdBlock - 1) / kRdBlock));
+      ws_cur->r_prealloc = true;
+    }
     SlowArgs sp{};
     sp.enabled = pend_valid ? 1 : 0;
     if (pend_valid) {
@@ -793,7 +820,7 @@ struct Table {
     }
     // every workgroup of the launch resident at once (two 1024-thread workgroups per CU); the lookup
     // role covers its groups in grid-stride trips
-    const uint32_t others = nxt.nblk + uint32_t(sp.enabled);
+    const uint32_t others = nxt.nblk + uint32_t(sp.enabled) + pre.nblk;
     const uint32_t slots = uint32_t(2 * num_cus);
     const uint32_t room = slots > others + 64 ? slots - others : 64u;
     auto blocks_for = [&](int unr) {
@@ -810,7 +837,7 @@ struct Table {
     v.trace = trace_region(kTagStepFwd, grid.x, kRdBlock);
 #define CALLU(G_, V_, U_)                                                                        \
   LAUNCH_HOT(kTagStepFwd, (step_fwd_kernel<G_, V_, U_>), grid, kRdBlock, st, nxt, v, ids, n, out, \
-             count_hits ? 1 : 0, sp, nblk_l)
+             count_hits ? 1 : 0, sp, nblk_l, pre)
 #define CALL(G_, V_)                              \
   do {                                            \
     if (unr == 2) { CALLU(G_, V_, 2); }           \
@@ -837,7 +864,9 @@ struct Table {
     a.sum_dups = 1;
     a.filter_mode = 1;
     a.global_step = 0;  // (the fused kernels take SGD / Adagrad / FTRL only)
-    ensure_capacity(uint64_t(std::min<int64_t>(n_max, n)), st);
+    const bool prealloc = ws.r_prealloc;  // (rows reserved — and room ensured — by step_forward)
+    ws.r_prealloc = false;
+    if (!prealloc) ensure_capacity(uint64_t(std::min<int64_t>(n_max, n)), st);
     Shape sh = pick_shape(dim, vec_ok && aligned16(grads) && aligned16(grad_u));
     pending.reserve(size_t(n_max) + 1);
     const uint32_t cap_items = DedupWs::max_items(n);
@@ -859,6 +888,7 @@ struct Table {
     c.arrive = ws.arrive.p;
     c.n_max = n_max;
     c.light_max = exact_order ? 0xffffffffu : uint32_t(kStepLightMax);
+    c.spec_row = prealloc ? ws.r_spec.p : nullptr;
     // fixed grids with grid-stride loops: item workgroups first (longest chain), sized for the
     // work a Zipf batch has; more ids / items than workgroups just means more trips
     const uint32_t groups_per_wg = uint32_t(256 / sh.G);
@@ -2144,7 +2174,7 @@ mhte_status mhte_table_step_forward(mhte_multi_table* t, int32_t table, const in
                                     int64_t n, float* embedding, mhte_dedup_ws* ws_next,
                                     const int64_t* id_next, int64_t n_next,
                                     int64_t* unique_ids_next, uint32_t* n_unique_dev_next,
-                                    void* stream) {
+                                    mhte_dedup_ws* ws_cur, void* stream) {
   return guard([&] {
     Table& tb = table_at(t, table);
     if (!tb.fusable())
@@ -2158,7 +2188,9 @@ mhte_status mhte_table_step_forward(mhte_multi_table* t, int32_t table, const in
         throw Error(MHTE_INVALID_ARGUMENT, "step_forward: null argument for the next batch");
       nxt = ws_next->ws.begin_run_dedup(id_next, n_next, unique_ids_next, n_unique_dev_next, st);
     }
-    tb.step_forward(id, n, embedding, nxt, st);
+    if (ws_cur && ws_cur == ws_next)
+      throw Error(MHTE_INVALID_ARGUMENT, "step_forward: ws_cur must differ from ws_next");
+    tb.step_forward(id, n, embedding, nxt, ws_cur ? &ws_cur->ws : nullptr, st);
   });
 }
 

@@ -749,7 +749,7 @@ struct SlotResult {
 template <int G>
 __device__ __forceinline__ SlotResult upsert_resolve(const TableView& tv, Bucket* b_generic, int64_t id,
                                                      bool valid, int64_t k, uint32_t row, int lane,
-                                                     uint32_t ts) {
+                                                     uint32_t ts, uint32_t reserved = kNoRow) {
   const int j = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
   const int s = j & 3;
@@ -800,9 +800,17 @@ __device__ __forceinline__ SlotResult upsert_resolve(const TableView& tv, Bucket
   }
 
   // ---- row handles + live-key count for new ids: ONE atomic per wave ----
-  const bool leader_new = is_new && j == 0;
+  // (reserved != kNoRow: the row was allocated — and the key counted — ahead, rd_prealloc_role;
+  // such a group needs nothing from the counter and returns its key if it did not insert)
+  const bool has_res = reserved != kNoRow;
+  const bool leader_new = is_new && j == 0 && !has_res;
   const uint64_t newm = __ballot(leader_new);
   const uint64_t keym = __ballot(leader_new && !special);
+  {
+    const uint64_t back = __ballot(valid && has_res && j == 0 && !is_new);
+    if (back && lane == __ffsll(static_cast<long long>(back)) - 1)
+      atomicAdd(&tv.ctr->alloc, ~((static_cast<unsigned long long>(__popcll(back)) << 32) - 1ull));
+  }
   const int first_new = newm ? (__ffsll(static_cast<long long>(newm)) - 1) : 0;
   uint32_t base_row = 0;
   if (newm && lane == first_new) {
@@ -815,7 +823,7 @@ __device__ __forceinline__ SlotResult upsert_resolve(const TableView& tv, Bucket
   uint32_t r;
   if (is_new) {
     const uint32_t rank = __popcll(newm & ((uint64_t(1) << gbase) - 1));
-    r = base_row + rank;
+    r = has_res ? reserved : base_row + rank;
   } else {
     r = found_row;
   }

@@ -460,6 +460,8 @@ struct ApplyCtl {
   uint32_t light_max;     // 0xffffffff: every list strictly sequential (MHTE_EXACT_ORDER)
   uint32_t nblk_items;    // workgroups [0, nblk_items) take work items, the rest ids
   uint32_t nblk_ids;
+  const uint32_t* spec_row;  // [n] row handle reserved for unique index u by the forward launch
+                             // (rd_prealloc_role; kNoRow: the id was in the table), or nullptr
 };
 
 // row of a found id, fetched while the gradient chain is in flight
@@ -587,7 +589,8 @@ struct UpsertFlight {
 
 template <int G>
 __device__ __forceinline__ UpsertFlight<G> upsert_issue(const TableView& tv, GBucket* b, int64_t id,
-                                                        bool valid, int64_t k, int lane) {
+                                                        bool valid, int64_t k, int lane,
+                                                        uint32_t reserved) {
   const int j = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
   UpsertFlight<G> f;
@@ -610,14 +613,15 @@ __device__ __forceinline__ UpsertFlight<G> upsert_issue(const TableView& tv, GBu
   f.cas_old = 0ull;
   if (f.need && j == f.pick)
     f.cas_old = cas_key(&b->key[j & 3], kEmptyKey, id);
-  f.specm = __ballot(f.need && j == 0);
+  f.specm = __ballot(f.need && j == 0 && reserved == kNoRow);
   return f;
 }
 
 template <int G>
 __device__ __forceinline__ SlotResult upsert_complete(const TableView& tv, GBucket* b, int64_t id,
                                                       bool valid, uint32_t row, int lane, uint32_t ts,
-                                                      const UpsertFlight<G>& f, uint32_t base_row) {
+                                                      const UpsertFlight<G>& f, uint32_t base_row,
+                                                      uint32_t reserved) {
   const int j = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
   const int s = j & 3;
@@ -679,10 +683,14 @@ __device__ __forceinline__ SlotResult upsert_complete(const TableView& tv, GBuck
   // rows: the speculative handles (base_row = this wavefront's first; the bump counted them as
   // live keys too); the side slot's row (rare) with its own bump; speculated keys that ended up
   // deferred are taken back
+  // (reserved: the forward launch allocated the row — and counted the key — when it found the id
+  // missing; such a group needs nothing from the counter, and gives its key back if it does not
+  // insert after all)
   const bool leader_new = is_new && j == 0;
   const uint64_t newm = __ballot(leader_new);
-  const uint64_t extra = newm & ~f.specm;
-  const uint64_t lostm = f.specm & ~newm;
+  const uint64_t resm = __ballot(valid && reserved != kNoRow && j == 0);
+  const uint64_t extra = newm & ~f.specm & ~resm;
+  const uint64_t lostm = (f.specm | resm) & ~newm;
   uint32_t base2 = 0;
   if (extra) {
     const int first2 = __ffsll(static_cast<long long>(extra)) - 1;
@@ -701,8 +709,9 @@ __device__ __forceinline__ SlotResult upsert_complete(const TableView& tv, GBuck
   const uint64_t below = (uint64_t(1) << gb) - 1;
   uint32_t r;
   if (is_new) {
-    r = ((f.specm >> gbase) & 1ull) ? base_row + uint32_t(__popcll(f.specm & below))
-                                    : base2 + uint32_t(__popcll(extra & below));
+    r = (reserved != kNoRow) ? reserved
+        : ((f.specm >> gbase) & 1ull) ? base_row + uint32_t(__popcll(f.specm & below))
+                                      : base2 + uint32_t(__popcll(extra & below));
   } else {
     r = found_row;
   }
@@ -757,6 +766,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       // the count reads stale entries of the preallocated arrays and is dropped)
       const bool inb = g < c.n_max;
       const uint32_t n_unique = d.ctr[0];  // (issued with the rest of the trip: not behind its wait)
+      const uint32_t reserved = (c.spec_row && inb) ? c.spec_row[g] : kNoRow;
       const int64_t id = inb ? d.uids[g] : 0;
       uint32_t cnt = inb ? d.ucnt[g] : 0u;
       const uint32_t hp = inb ? d.upos[g] : 0u;
@@ -797,7 +807,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       }
       // round trip 3: slot claim + row handle of a new id | the row of a found one | (below) the
       // gradients of a list — all in flight together
-      const UpsertFlight<G> uf = upsert_issue<G>(tv, pr.b, id, valid, pr.k, lane);
+      const UpsertFlight<G> uf = upsert_issue<G>(tv, pr.b, id, valid, pr.k, lane, reserved);
       if (lane == 0) sh_need[wave] = uint32_t(__popcll(uf.specm));
       lds_barrier();  // (the trip count is the same for the four wavefronts)
       RowRegs<VEC> rr;
@@ -869,7 +879,8 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       lds_barrier();
       uint32_t base_row = sh_rowbase;
       for (int w2 = 0; w2 < wave; ++w2) base_row += sh_need[w2];
-      const SlotResult sr = upsert_complete<G>(tv, pr.b, id, valid, pr.row, lane, a.ts, uf, base_row);
+      const SlotResult sr =
+          upsert_complete<G>(tv, pr.b, id, valid, pr.row, lane, a.ts, uf, base_row, reserved);
       float* rp = nullptr;
       if (valid && !sr.deferred) {
         rp = row_ptr(tv, sr.r);
@@ -909,6 +920,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
                    nitems = hd.meta >> 24;
     // round trip 2: the table probe of the id (used by whoever applies: wave 0, group 0) | positions
     Probe<G> pr = probe_issue<G>(tv, hd.id, threadIdx.x < G, j);
+    const uint32_t reserved = (c.spec_row && threadIdx.x < G) ? c.spec_row[hd.u] : kNoRow;
     if (threadIdx.x < 64) {
       const uint32_t val = (uint32_t(lane) < nbk) ? rval : 0u;
       uint32_t incl = run_cnt(val);
@@ -1048,7 +1060,8 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         if (valid && j == 0) first = filter_consult(tv, hd.id, d.ucnt[hd.u], 2, contained);
         if (__shfl(first, gbase) != 0u) valid = false;
       }
-      const SlotResult sr = upsert_resolve<G>(tv, (Bucket*)pr.b, hd.id, valid, pr.k, pr.row, lane, a.ts);
+      const SlotResult sr =
+          upsert_resolve<G>(tv, (Bucket*)pr.b, hd.id, valid, pr.k, pr.row, lane, a.ts, reserved);
       if (sr.deferred) {
         if (ev) tot.store(c.grad_u + int64_t(hd.u) * dim + e);
         if (j == 0) c.pending[atomicAdd(&tv.ctr->n_pending, 1u)] = hd.u;
@@ -1075,6 +1088,82 @@ struct SlowArgs {  // slowpath_role's arguments; enabled = 0: no displacement pa
 // ids per group of the forward lookup: 2 is the fastest shape (scripts/lookup_sweep.py); the host
 // picks 3 or 4 when that is what it takes to have every workgroup of the launch resident at once
 
+// Row handles for the ids of THIS batch that are not in the table yet, reserved one launch before
+// the update needs them.  Every allocation bumps ONE counter, and same-address atomics are served
+// one at a time (~18 ns each here): reserved per workgroup inside the update they were ~750 bumps
+// that paced step_bwd — its last allocation came back ~13 us after its first was issued.  Here a
+// lane takes one unique id (the dense numbering of the build role), probes its two buckets and
+// the workgroup reserves for all its misses with ONE bump: ~13 bumps per step.  Nothing inserts
+// between this launch and the update (the displacement pass of the previous update runs in front of
+// it, behind the same gate as the lookups), so a miss here is a miss there; an id evicted in
+// between simply finds no reservation and takes the update's own (per-workgroup) path.
+struct PreArgs {
+  const int64_t* uids;   // dense unique ids of this batch (build role)
+  const uint32_t* ctr;   // [0] their number
+  uint32_t* spec_row;    // out [n_max]
+  uint32_t n_max;
+  uint32_t nblk;         // workgroups of the role (0: off)
+};
+
+__device__ __forceinline__ void rd_prealloc_role(const TableView& tv, const PreArgs& p, uint32_t bid,
+                                                 WaveTrace& wt) {
+  __shared__ uint32_t sh_cnt[kRdBlock / 64];
+  __shared__ uint32_t sh_base;
+  const uint32_t t = threadIdx.x;
+  const int lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  // (the count and the first trip's ids are fetched together: an index past the count reads a
+  // stale entry of the preallocated array and is dropped)
+  const uint32_t first = bid * kRdBlock + t;
+  int64_t id_next = p.uids[first < p.n_max ? first : 0u];
+  const uint32_t nu = min(p.n_max, p.ctr[0]);
+#pragma unroll 1
+  for (uint32_t u0 = bid * kRdBlock; u0 < nu; u0 += p.nblk * kRdBlock) {  // (workgroup-uniform)
+    const uint32_t u = u0 + t;
+    const bool in = u < nu;
+    const int64_t id = id_next;
+    {
+      const uint32_t un = u + p.nblk * kRdBlock;
+      id_next = p.uids[un < nu ? un : 0u];  // (the next trip's, in flight behind this one's probes)
+    }
+    const uint64_t hv = hash_key(id);
+    const uint64_t i1 = index_hash(tv.hp, hv);
+    const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
+    const GBucket* b1 = global_bucket(tv.buckets + i1);
+    const GBucket* b2 = global_bucket(tv.buckets + i2);
+    // (the eight keys as four 16-byte loads issued together, compared without short-circuit:
+    // `a || b` on loads lets the compiler fetch b only after a has come back and failed — eight
+    // round trips in a row)
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    const i64x2 a0 = *(const MHTE_GLOBAL i64x2*)(&b1->key[0]);
+    const i64x2 a1 = *(const MHTE_GLOBAL i64x2*)(&b1->key[2]);
+    const i64x2 c0 = *(const MHTE_GLOBAL i64x2*)(&b2->key[0]);
+    const i64x2 c1 = *(const MHTE_GLOBAL i64x2*)(&b2->key[2]);
+    const bool found = (a0.x == id) | (a0.y == id) | (a1.x == id) | (a1.y == id) | (c0.x == id) |
+                       (c0.y == id) | (c1.x == id) | (c1.y == id);
+    // (the one key that lives in the side slot is left to the update's own path)
+    const bool miss = in && id != kEmptyKey && !found;
+    const uint64_t mm = __ballot(miss);
+    wt.mark(0);
+    if (lane == 0) sh_cnt[w] = uint32_t(__popcll(mm));
+    lds_barrier();
+    wt.mark(1);
+    if (t == 0) {
+      unsigned long long tot = 0;
+      for (int i = 0; i < kRdBlock / 64; ++i) tot += sh_cnt[i];
+      sh_base = tot ? uint32_t(atomicAdd(&tv.ctr->alloc, (tot << 32) | tot)) : 0u;
+    }
+    lds_barrier();
+    wt.mark(2);
+    uint32_t base = sh_base;
+    for (int i = 0; i < w; ++i) base += sh_cnt[i];
+    base += uint32_t(__popcll(mm & ((1ull << lane) - 1ull)));
+    if (in) p.spec_row[u] = miss ? base : kNoRow;
+    wt.mark(3);
+    lds_barrier();  // (sh_cnt / sh_base are rewritten by the next trip)
+  }
+}
+
 // step_fwd:  run dedup of the NEXT batch | displacement pass of the previous update (one wavefront,
 //            the lookup workgroups gate on it) | lookup of this batch
 // (<= 80 SGPRs: with more, the hardware admits 7 wavefronts per SIMD and only ONE of these
@@ -1084,7 +1173,7 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
                                                             const int64_t* __restrict__ ids,
                                                             int64_t n, float* __restrict__ out,
                                                             int count_hits, SlowArgs sp,
-                                                            uint32_t nblk_l) {
+                                                            uint32_t nblk_l, PreArgs pre) {
   __shared__ __attribute__((aligned(16))) RdLds L;
   static_assert(sizeof(BfsSlot) * kMaxCuckooCount + sizeof(CuckooRecord) * kMaxBfsPathLen <=
                     sizeof(RdLds), "BFS scratch must fit the dedup's LDS");
@@ -1125,6 +1214,12 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
     }
     __syncthreads();
   }
+  if (bid < pre.nblk) {  // (behind the gate: it reads the table)
+    rd_prealloc_role(tv, pre, bid, wt);
+    wt.end(9u);
+    return;
+  }
+  bid -= pre.nblk;
   const int64_t ngroups = (n + UNR - 1) / UNR;
 #pragma unroll 1
   for (int64_t g = (int64_t(bid) * kRdBlock + threadIdx.x) / G; g < ngroups;

@@ -18,6 +18,8 @@ done while batch s is looked up and updated: ``forward(ids, next_ids=...)``.  A 
 TWO launches on one queue (mhte_table_step_forward / _backward, csrc/mhte_step_kernels.h):
 
    forward   lookup(s)  | run dedup(s+1) | displacement pass of update s-1 (usually idle)
+             [| row handles for the ids update s will insert: ``reserve_ahead``, off by default —
+              it takes 1.2 us off the backward launch and puts 2.6 us on this one]
    backward  gradient sum + upsert + optimizer(s) | heavy work list(s+1)
 
 different workgroups of one kernel doing the jobs (a dependency between two HIP queues costs ~10 us
@@ -43,8 +45,9 @@ class SparseStep:
 
   def __init__(self, table: MultiHashTable, table_name: str, batch: int,
                exact_order: bool = False, direct: bool = True, fused_backward: bool = True,
-               ordered_unique: bool = False):
+               ordered_unique: bool = False, reserve_ahead: bool = False):
     self.direct = direct
+    self.reserve_ahead = reserve_ahead
     self.fused_backward = fused_backward
     # the reference's first-occurrence numbering of the unique ids is only needed by the unfused
     # three-op forward (its gather indexes rows by that numbering) and by wide rows
@@ -134,10 +137,12 @@ class SparseStep:
       if next_ids is not None:
         assert next_ids.numel() == self.batch
         self.table.table_step_forward(self.idx, ids, self.emb, self._ws[nxt], next_ids,
-                                      self._uids[nxt], self._nu[nxt])
+                                      self._uids[nxt], self._nu[nxt],
+                                      ws_cur=self._ws[self._cur] if self.reserve_ahead else None)
         self._key[nxt] = (next_ids.data_ptr(), next_ids.numel())
       else:
-        self.table.table_step_forward(self.idx, ids, self.emb)
+        self.table.table_step_forward(self.idx, ids, self.emb,
+                                      ws_cur=self._ws[self._cur] if self.reserve_ahead else None)
         self._key[nxt] = None
       self._mode = "pipe"
       self._joined = True

@@ -507,15 +507,19 @@ class MultiHashTable:
   def table_step_forward(self, name_or_idx, ids: torch.Tensor, out: torch.Tensor, ws_next=None,
                          next_ids: Optional[torch.Tensor] = None,
                          uids_next: Optional[torch.Tensor] = None,
-                         n_unique_next: Optional[torch.Tensor] = None):
+                         n_unique_next: Optional[torch.Tensor] = None, ws_cur=None):
     """mhte_table_step_forward: lookup of ``ids`` + run dedup of ``next_ids`` into ``ws_next``
-    (+ the displacement pass the previous ``table_step_backward`` left)."""
+    (+ the displacement pass the previous ``table_step_backward`` left).  ``ws_cur``: the workspace
+    holding the run dedup of ``ids`` itself — the launch then also reserves the row handles its
+    update will need."""
     i = name_or_idx if isinstance(name_or_idx, int) else self._index(name_or_idx)
     check(self._lib.mhte_table_step_forward(
         self._h, C.c_int32(i), vp(ids), C.c_int64(ids.numel()), vp(out),
         ws_next._h if ws_next is not None else C.c_void_p(0),  # pylint: disable=protected-access
         vp(next_ids), C.c_int64(next_ids.numel() if next_ids is not None else 0), vp(uids_next),
-        vp(n_unique_next), _stream()))
+        vp(n_unique_next),
+        ws_cur._h if ws_cur is not None else C.c_void_p(0),  # pylint: disable=protected-access
+        _stream()))
     return out
 
   def table_step_backward(self, name_or_idx, ws, ws_next, uids: torch.Tensor,

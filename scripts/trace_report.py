@@ -9,7 +9,7 @@ import sys
 import numpy as np
 
 ROLES = {3: "run_dedup", 4: "displacement", 5: "lookup", 6: "work_list", 7: "apply_items",
-         8: "apply_ids", 0: "(no record)"}
+         8: "apply_ids", 9: "reserve_rows", 0: "(no record)"}
 
 
 def q(a, p):
