@@ -403,6 +403,7 @@ struct Table {
   std::vector<int32_t> occ_thr;
   DevBuf<int64_t> d_occ_slots;
   DevBuf<int32_t> d_occ_thr;
+  bool has_group_opt = false;       // a segment uses GroupAdaGrad (picks the kernel instantiation)
   uint32_t* flt_slots = nullptr;    // owned by the mhte_hash_filter attached to the MultiHashTable
   uint64_t flt_total = 0;
   // in-op grouping scratch (ids not declared unique)
@@ -443,6 +444,7 @@ struct Table {
         throw Error(MHTE_INVALID_ARGUMENT, "unknown initializer type");
       if (s.opt_type == MHTE_OPT_BATCH_SOFTMAX && s.dim_size != 1)  // batch_softmax_optimizer.cc:29
         throw Error(MHTE_INVALID_ARGUMENT, "a batch softmax segment has dim_size 1");
+      if (s.opt_type == MHTE_OPT_GROUP_ADAGRAD) has_group_opt = true;
       dim += s.dim_size;
     }
     // row = float num[dim] | ctx(seg0) | ctx(seg1) ... (entry_accessor.cc:113-114)
@@ -684,9 +686,16 @@ struct Table {
     const int64_t threads = n * sh.G;
     const dim3 grid(uint32_t((threads + 255) / 256));
     uint32_t* pend = pending.p;
-#define CALL(G_, V_)                                                                         \
-  LAUNCH_HOT(kTagUpsert, (upsert_kernel<G_, V_, OP>), grid, 256, st, view, ids, n, n_dev, values, \
-             seg_off, seg_pos, a, status, pend, skp)
+#define CALL(G_, V_)                                                                               \
+  do {                                                                                             \
+    if (OP == kOpOptimize && has_group_opt) {                                                      \
+      LAUNCH_HOT(kTagUpsert, (upsert_kernel<G_, V_, OP, true>), grid, 256, st, view, ids, n, n_dev, \
+                 values, seg_off, seg_pos, a, status, pend, skp);                                  \
+    } else {                                                                                       \
+      LAUNCH_HOT(kTagUpsert, (upsert_kernel<G_, V_, OP>), grid, 256, st, view, ids, n, n_dev,      \
+                 values, seg_off, seg_pos, a, status, pend, skp);                                  \
+    }                                                                                              \
+  } while (0)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
     if (sh.VEC == 4) {

@@ -577,13 +577,16 @@ __device__ __forceinline__ void group_adagrad_segment(const TableView& tv, float
 // BASIC: the table is known to use SGD / Adagrad / FTRL only (the fused training-step kernels:
 // Table::fusable) — the other optimizers are compiled out, which is what keeps the displacement
 // role of step_fwd inside that kernel's register budget.
-template <int G, int VEC, int OP, bool BASIC = false>
+// GROUP = false: the table has no GroupAdaGrad segment (the host picks the instantiation): the
+// whole-segment pass is compiled out — with it, the compiler keeps the table descriptor in scratch
+// memory and every other optimizer's update runs three times slower.
+template <int G, int VEC, int OP, bool BASIC = false, bool GROUP = true>
 __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool is_new, int j,
                                           const float* __restrict__ values,
                                           const uint32_t* __restrict__ seg_pos, uint32_t q0,
                                           uint32_t q1, int64_t self_pos, const ApplyArgs& a) {
   const int64_t dim = tv.dim;
-  if (OP == kOpOptimize && !BASIC) {  // (group-uniform: every lane of the group walks the segments)
+  if (OP == kOpOptimize && !BASIC && GROUP) {  // (group-uniform: every lane walks the segments)
     for (uint32_t k = 0; k < tv.nseg; ++k)
       if (tv.seg[k].opt == kOptGroupAdagrad)
         group_adagrad_segment<G, VEC>(tv, rp, is_new, j, values, seg_pos, q0, q1, self_pos, a, k);
@@ -592,7 +595,7 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
     uint32_t k = 0;
     const SegDesc sd = seg_of<false>(tv, e, k);
     const uint32_t le = e - sd.w_off;  // element index inside the segment
-    const bool gag = !BASIC && sd.opt == kOptGroupAdagrad;
+    const bool gag = !BASIC && GROUP && sd.opt == kOptGroupAdagrad;
     if (gag && OP == kOpOptimize) continue;  // done above, by the whole group
     const float lr = a.lr[k];
     const int nv = BASIC ? (sd.opt == kOptFtrl ? 2 : (sd.opt == kOptAdagrad ? 1 : 0)) : opt_vectors(sd.opt);
@@ -845,7 +848,7 @@ __device__ __forceinline__ SlotResult upsert_resolve(const TableView& tv, Bucket
   return out;
 }
 
-template <int G, int VEC, int OP>
+template <int G, int VEC, int OP, bool GROUP = false>
 __global__ __launch_bounds__(256) void upsert_kernel(TableView tv, const int64_t* __restrict__ ids,
                                                      int64_t n, const uint32_t* __restrict__ n_dev,
                                                      const float* __restrict__ values,
@@ -896,7 +899,7 @@ __global__ __launch_bounds__(256) void upsert_kernel(TableView tv, const int64_t
   }
   // ---- apply ----
   if (valid && !sr.deferred) {
-    apply_row<G, VEC, OP>(tv, row_ptr(tv, sr.r), sr.is_new, j, values, seg_off ? seg_pos : nullptr,
+    apply_row<G, VEC, OP, false, GROUP>(tv, row_ptr(tv, sr.r), sr.is_new, j, values, seg_off ? seg_pos : nullptr,
                           q0, q1, g, a);
     if (OP == kOpReinit && j == 0) {
       // status: 0 inserted, 1 existed (cuckoo_embedding_hash_table.cc:215-226); later duplicates
