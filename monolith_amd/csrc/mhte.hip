@@ -240,7 +240,7 @@ struct DedupWs {
 
   // items of a list of c occurrences < c / target + 1 (rd_item_blocks), lists > kLightMax
   static uint32_t max_items(int64_t n) {
-    return uint32_t(n / item_target() + n / (kStepLightMax + 1) + 2);
+    return uint32_t(2 * n / item_target() + n / (kStepLightMax + 1) + 2);
   }
   static uint32_t item_target() { return kItemTarget; }
 
@@ -903,7 +903,7 @@ struct Table {
     const uint32_t groups_per_wg = uint32_t(256 / sh.G);
     // residency budget: 4 workgroups of 256 threads per CU (launch bounds of step_bwd_kernel)
     const uint32_t slots = uint32_t(kBwdBlocksPerCu * num_cus);
-    c.nblk_items = exact_order ? 0u : std::min<uint32_t>(cap_items, uint32_t(num_cus) * 9 / 8);
+    c.nblk_items = exact_order ? 0u : std::min<uint32_t>(cap_items, uint32_t(num_cus) * 10 / 8);
     c.nblk_ids = std::max<uint32_t>(
         1, std::min<uint32_t>(uint32_t((std::min<int64_t>(n_max, n) + groups_per_wg - 1) / groups_per_wg),
                               slots - c.nblk_items - 128));

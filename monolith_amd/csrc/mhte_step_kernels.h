@@ -325,9 +325,14 @@ __device__ __forceinline__ uint32_t rd_find_run(const RunView& d, uint32_t b, in
 }
 
 // workgroups per item for a list of c occurrences: power of two, ~kItemTarget entries expected
+// A list that fits one item (<= 2 * target entries) stays whole; a longer one is cut into items of
+// target / 2 .. target expected entries: its items are followed by a hand-off (partial rows, arrival
+// counter, last arriver) and are the longest chain of the launch, so each of them gets one window
+// round instead of two.
 __device__ __forceinline__ uint32_t rd_item_blocks(uint32_t c, uint32_t target) {
   uint32_t nbk = 64;
-  while (nbk > 1 && uint64_t(c) * nbk > uint64_t(target) * 64 * 2) nbk >>= 1;
+  const uint64_t lim = uint64_t(target) * 64 * (c > 2 * target ? 1 : 2);
+  while (nbk > 1 && uint64_t(c) * nbk > lim) nbk >>= 1;
   return nbk;
 }
 
