@@ -43,6 +43,8 @@ def parse():
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--cpu-steps", type=int, default=150)
   p.add_argument("--exact-order", action="store_true")
+  p.add_argument("--reserve-ahead", action="store_true",
+                 help="forward launch reserves the row handles of the update (SparseStep.reserve_ahead)")
   p.add_argument("--dist-backend", default="nccl",
                  help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo stages through "
                       "host memory and lets several ranks share one GPU: a functional check only)")
@@ -187,7 +189,8 @@ def main():
     # prefetch queue does.  Every timed step executes exactly one dedup, one lookup and one
     # update: the first timed batch was deduplicated by the last warm-up step, the last timed
     # step deduplicates the batch after it.
-    step = SparseStep(mt, "emb", B, exact_order=args.exact_order)
+    step = SparseStep(mt, "emb", B, exact_order=args.exact_order,
+                      reserve_ahead=args.reserve_ahead)
 
     def run_eager(lo, hi):
       for s in range(lo, hi):
@@ -242,7 +245,8 @@ def main():
         torch.cuda.synchronize()
         # the aborted capture advanced the host-side pipeline state without executing anything:
         # start the following passes from a fresh pipeline
-        step = SparseStep(mt, "emb", B, exact_order=args.exact_order)
+        step = SparseStep(mt, "emb", B, exact_order=args.exact_order,
+                      reserve_ahead=args.reserve_ahead)
         cur += gc * (len(graphs) + 1)
     P0 = cur
   else:
