@@ -43,6 +43,9 @@ def parse():
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--cpu-steps", type=int, default=150)
   p.add_argument("--exact-order", action="store_true")
+  p.add_argument("--force-sharded", action="store_true",
+                 help="N=1 through the id-sharded code path (one-rank process group): the floor of "
+                      "the multi-GPU step without any link traffic; a measurement, not the bench line")
   p.add_argument("--reserve-ahead", action="store_true",
                  help="forward launch reserves the row handles of the update (SparseStep.reserve_ahead)")
   p.add_argument("--dist-backend", default="nccl",
@@ -100,8 +103,10 @@ def main():
   local_rank %= torch.cuda.device_count()
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
-  if world > 1:
+  sharded = world > 1 or args.force_sharded
+  if sharded:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
   from monolith_amd import _lib, entry, synthetic as S
@@ -115,7 +120,7 @@ def main():
   resident = int(args.resident_rows)
 
   def make_table(res):
-    rows_cap = res + (K + W + 8) * B * (2 if world > 1 else 1) + (1 << 16)
+    rows_cap = res + (K + W + 8) * B * (2 if sharded else 1) + (1 << 16)
     slots = 4
     while slots * 0.5 < rows_cap:
       slots *= 2
@@ -169,7 +174,7 @@ def main():
   # contiguous batch sequence: the last step of a mode deduplicates the first batch of the next
   # mode ahead, exactly as it does inside a mode.
   reps = min(K, 100)
-  n_batches = (2 * (W + K) + 2 * reps + 8) if world == 1 else (K + W + 1)
+  n_batches = (2 * (W + K) + 2 * reps + 8) if not sharded else (K + W + 1)
   ids_host = np.stack([S.id_batch(s * world + rank, B, V, "zipf") for s in range(n_batches)])
   ids_all = torch.from_numpy(ids_host).to(dev)
   grad_pool = [torch.from_numpy(S.grad_batch(s, B, D)).to(dev) for s in range(8)]
@@ -183,7 +188,7 @@ def main():
   results = {}
   steps_of = {}
   graph_err = None
-  if world == 1:
+  if not sharded:
     # Steady-state pipeline (fused_step.py): while batch s is looked up and updated, the dedup of
     # batch s+1 — which depends on the ids only — rides in the same launches, as the reference's
     # prefetch queue does.  Every timed step executes exactly one dedup, one lookup and one
@@ -280,7 +285,7 @@ def main():
   # reports.  Pass 1: the pipelined step as timed above (2 launches per step).  Pass 2: the
   # same work as separate launches, which attributes time to lookup / backward / dedup.
   roofline, stages, uniq_avg = None, {}, None
-  if world == 1 and not args.no_stage_timing:
+  if not sharded and not args.no_stage_timing:
     step.quiesce()
     acc = {}
 
@@ -354,7 +359,7 @@ def main():
 
   # ---- CPU baseline: the reference's own map + AVX Adagrad on this box's host cores ----
   cpu = None
-  if world == 1 and rank == 0 and not args.no_cpu_baseline:
+  if not sharded and rank == 0 and not args.no_cpu_baseline:
     try:
       import oracle as O
       cores = os.cpu_count() or 1
@@ -409,7 +414,7 @@ def main():
             "row_bytes": 4 * (D + S_state), "hashpower": int(st1.hashpower),
             "table_bytes_per_gpu": int(st1.bytes_buckets + st1.bytes_rows),
             "unique_ids_per_batch": uniq_avg, "launch": launch,
-            "parallelism": "1 GPU" if world == 1 else
+            "parallelism": "1 GPU" if not sharded else
                            "fid mod %d sharding, 4 all-to-all/step (%s)" % (world, args.dist_backend),
             "prefill_s": round(prefill_s, 2),
         },
@@ -423,7 +428,7 @@ def main():
     if graph_err:
       out["graph_error"] = graph_err
     print(json.dumps(out))
-  if world > 1:
+  if sharded:
     dist.destroy_process_group()
 
 
