@@ -1075,20 +1075,27 @@ __device__ __forceinline__ void slowpath_role(const TableView& tv, const int64_t
                                               BfsSlot* q, CuckooRecord* path,
                                               const uint32_t* __restrict__ skip = nullptr) {
   const int lane = threadIdx.x;
+  // (the count and the first entry of the list are fetched together: the other workgroups of a
+  // gated launch wait for this pass, every dependent round trip in it is paid by all of them)
+  const uint32_t first = pending[0];
   const uint32_t np = tv.ctr->n_pending;
   if (np == 0) return;
   for (uint32_t i = 0; i < np; ++i) {
-    const uint32_t g = pending[i];
+    const uint32_t g = i == 0 ? first : pending[i];
     const int64_t id = ids[g];
+    // the row handle is allocated while the slot search runs (a search that fails — the table is
+    // over its load limit — gives the key back and strands the handle)
+    uint32_t r;  // (only lane 0's value is read; merging it with a constant here would make the
+                 // compiler wait for the atomic before the search instead of after it)
+    if (lane == 0) r = static_cast<uint32_t>(atomicAdd(&tv.ctr->alloc, (1ull << 32) | 1ull));
     long long pos = wave_insert_slot(tv.buckets, tv.hp, id, q, path, lane);
-    uint32_t r = kNoRow;
     if (lane == 0) {
       if (pos >= 0) {
-        r = static_cast<uint32_t>(atomicAdd(&tv.ctr->alloc, (1ull << 32) | 1ull));
         Bucket* b = tv.buckets + (pos >> 2);
         b->row[pos & 3] = r;
         b->ts[pos & 3] = a.ts;
       } else {
+        atomicAdd(&tv.ctr->alloc, ~((1ull << 32) - 1ull));  // - (1 << 32): not a live key
         atomicOr(&tv.ctr->error, 1u);
         atomicAdd(&tv.ctr->n_dropped, 1u);
       }
