@@ -627,35 +627,23 @@ struct Table {
     finish_pending(st);  // a deferred displacement pass always precedes the next op on the table
     if (n <= 0) return;
     Shape sh = pick_shape(dim, vec_ok && aligned16(out));
-    // ---- sweep knobs (measurement only; removed once the best shape is fixed)
-    const int sw_unr = getenv("MHTE_LOOKUP_UNR") ? atoi(getenv("MHTE_LOOKUP_UNR")) : 0;
-    const int sw_blk = getenv("MHTE_LOOKUP_BLOCK") ? atoi(getenv("MHTE_LOOKUP_BLOCK")) : 256;
-    const int sw_nt = getenv("MHTE_LOOKUP_NT") ? atoi(getenv("MHTE_LOOKUP_NT")) : 0;
-    if (sw_unr > 0 && sh.VEC == 4 && sh.G == 16) {
-      const int64_t groups = (n + sw_unr - 1) / sw_unr;
-      const uint32_t g = uint32_t((groups * 16 + sw_blk - 1) / sw_blk);
+    // two ids per lane group, 512-thread workgroups, streaming stores: the fastest shape of the
+    // sweep over ids per group x workgroup size x store kind (profiles/r01/f_lookup_sweep.jsonl:
+    // 6.9 us for 65 536 ids against 9.4 us for one id per group)
+    if (sh.VEC == 4 && n >= 4096) {
+      const int64_t groups = (n + 1) / 2;
+      const uint32_t g = uint32_t((groups * sh.G + 511) / 512);
       TableView v = view;
-      v.trace = trace_region(kTagLookup, g, uint32_t(sw_blk));
-#define LK(U_, NT_, B_)                                                                        \
-  LAUNCH_HOT(kTagLookup, (lookup_kernel_u<16, 4, U_, NT_, B_>), g, B_, st, v, ids, n, n_dev, out, \
+      v.trace = trace_region(kTagLookup, g, 512);
+#define LK(G_)                                                                                   \
+  LAUNCH_HOT(kTagLookup, (lookup_kernel_u<G_, 4, 2, true, 512>), g, 512, st, v, ids, n, n_dev, out, \
              count_hits ? 1 : 0)
-#define LKB(U_, NT_)                                  \
-  do {                                                \
-    if (sw_blk == 256) { LK(U_, NT_, 256); }          \
-    else if (sw_blk == 512) { LK(U_, NT_, 512); }     \
-    else { LK(U_, NT_, 1024); }                       \
-  } while (0)
-#define LKN(U_)                                  \
-  do {                                           \
-    if (sw_nt) { LKB(U_, true); } else { LKB(U_, false); } \
-  } while (0)
-      if (sw_unr == 1) LKN(1);
-      else if (sw_unr == 2) LKN(2);
-      else if (sw_unr == 4) LKN(4);
-      else if (sw_unr == 8) LKN(8);
-      else LKN(16);
-#undef LKN
-#undef LKB
+      switch (sh.G) {
+        case 8: LK(8); break;
+        case 16: LK(16); break;
+        case 32: LK(32); break;
+        default: LK(64); break;
+      }
 #undef LK
       HIP_OK(hipGetLastError());
       return;

@@ -1090,7 +1090,7 @@ struct SlowArgs {  // slowpath_role's arguments; enabled = 0: no displacement pa
   int32_t enabled;
 };
 
-// ids per group of the forward lookup: 2 is the fastest shape (scripts/lookup_sweep.py); the host
+// ids per group of the forward lookup: 2 is the fastest shape (profiles/r01/f_lookup_sweep.jsonl); the host
 // picks 3 or 4 when that is what it takes to have every workgroup of the launch resident at once
 
 // Row handles for the ids of THIS batch that are not in the table yet, reserved one launch before
