@@ -358,21 +358,26 @@ __device__ __forceinline__ void lookup_role_u(const TableView& tv, const int64_t
   int64_t id[UNR];
   bool valid[UNR], match[UNR];
   uint32_t row[UNR];
+  // (every lane loads a slot of one of the id's two buckets — lines that are fetched anyway; an
+  // index past the end probes the buckets of id 0 — and the result is masked afterwards: probes
+  // under `if (valid ...)` are waited for where the branch ends, one id after the other)
+  int64_t kk[UNR];
 #pragma unroll
   for (int u = 0; u < UNR; ++u) {
     id[u] = __shfl(myid, gbase + (u & (G - 1)));
     valid[u] = g0 + u < n;
-    match[u] = false;
-    row[u] = kNoRow;
-    if (valid[u] && j < 8 && id[u] != kEmptyKey) {
-      const uint64_t hv = hash_key(id[u]);
-      const uint64_t i1 = index_hash(tv.hp, hv);
-      const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
-      const Bucket* b = assume_global(tv.buckets + ((j < 4) ? i1 : i2));
-      const int64_t k = b->key[j & 3];
-      row[u] = b->row[j & 3];
-      match[u] = (k == id[u]);
-    }
+    const uint64_t hv = hash_key(id[u]);
+    const uint64_t i1 = index_hash(tv.hp, hv);
+    const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
+    const GBucket* b = global_bucket(tv.buckets + ((j & 4) ? i2 : i1));
+    kk[u] = b->key[j & 3];
+    row[u] = b->row[j & 3];
+  }
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    const bool use = valid[u] && j < 8 && id[u] != kEmptyKey;
+    match[u] = use && kk[u] == id[u];
+    row[u] = use ? row[u] : kNoRow;
   }
   bool found[UNR];
   const float* rp[UNR];
