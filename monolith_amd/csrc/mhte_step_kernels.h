@@ -844,9 +844,13 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       // produced under a branch where the branch ends, and here that wait is shared with loads this
       // wavefront needs next anyway
       unsigned long long rows0;  // (not initialised on purpose: see lbase in rd_dedup_role)
+      bool bumped = false;
       if (threadIdx.x == 0) {
         const unsigned long long tot = sh_need[0] + sh_need[1] + sh_need[2] + sh_need[3];
-        if (tot) rows0 = atomicAdd(&tv.ctr->alloc, (tot << 32) | tot);  // (no rows needed: unread)
+        if (tot) {
+          rows0 = atomicAdd(&tv.ctr->alloc, (tot << 32) | tot);
+          bumped = true;
+        }
       }
       lds_wave_sync();
       if (it == 0) wt.mark(2);
@@ -880,7 +884,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
           }
         }
       }
-      if (threadIdx.x == 0) sh_rowbase = uint32_t(rows0);
+      if (bumped) sh_rowbase = uint32_t(rows0);  // (only thread 0, only when rows were needed)
       lds_barrier();
       uint32_t base_row = sh_rowbase;
       for (int w2 = 0; w2 < wave; ++w2) base_row += sh_need[w2];
