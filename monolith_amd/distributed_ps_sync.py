@@ -221,10 +221,14 @@ class ShardedEmbedding:
   receive that same tensor) only has the owner lookup, the row exchange and the scatter on its
   critical path.  ``next_ids`` must already be materialised (it comes from the input pipeline): the
   side stream does not wait for work queued on the caller's stream, only for the previous user of
-  the state slot it writes."""
+  the state slot it writes.  ``prefetch_on_side_stream=False`` runs that dispatch on the caller's
+  stream instead (no overlap on the GPU, fewer cross-stream dependencies for the host: with one rank
+  and no link latency to hide it is ≈10 % faster, 210-230 µs against 250 µs per step)."""
 
-  def __init__(self, backend: LocalBackend, group: Optional[dist.ProcessGroup] = None):
+  def __init__(self, backend: LocalBackend, group: Optional[dist.ProcessGroup] = None,
+               prefetch_on_side_stream: bool = True):
     self.backend = backend
+    self.prefetch_on_side_stream = prefetch_on_side_stream
     self.group = group
     self.world = dist.get_world_size(group)
     self.rank = dist.get_rank(group)
@@ -314,7 +318,8 @@ class ShardedEmbedding:
 
   def _prefetch(self, ids: torch.Tensor, slot: int):
     key = (ids.data_ptr(), ids.numel())
-    if not ids.is_cuda:
+    if not ids.is_cuda or not self.prefetch_on_side_stream:
+      # (same stream: the dispatch simply runs behind this step's forward)
       self._pre = (key, self._dispatch(ids, slot), None)
       return
     if self._side is None:
