@@ -2,6 +2,7 @@
 // against golden bytes, the protobuf runtime and an independent Python reader / writer
 // (tests/test_ckpt_codec.py).  Commands:
 //   crc <string>                         -> crc32c and masked crc, hex
+//   crcsoft <string>                     -> crc32c by the sliced tables (no SSE4.2), hex
 //   entry <id> <ts> <dim> <nseg> {<kind> <dim>}... <row floats...>  -> EntryDump bytes, hex
 //   decode <hexfile> <dim> <nseg> {<kind> <dim>}...                 -> id ts row...
 //   write <path> <snappy 0|1> <n> <len>  -> n records of len bytes, record i filled with byte i
@@ -42,6 +43,9 @@ int main(int argc, char** argv) {
     if (cmd == "crc") {
       const std::string s = argv[2];
       printf("%08x %08x\n", crc32c(s.data(), s.size()), masked_crc(s.data(), s.size()));
+    } else if (cmd == "crcsoft") {  // the table-driven form, whatever the host CPU offers
+      const std::string s = argv[2];
+      printf("%08x\n", crc32c_soft(0xffffffffu, reinterpret_cast<const uint8_t*>(s.data()), s.size()) ^ 0xffffffffu);
     } else if (cmd == "entry") {
       const long long id = atoll(argv[2]);
       const unsigned ts = unsigned(strtoul(argv[3], nullptr, 10));
