@@ -909,6 +909,8 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
   }
 
   // -------------------------------------------------------------------- item workgroups
+  // (the longest chain of the launch: its wavefronts go first when a SIMD has a choice)
+  __builtin_amdgcn_s_setprio(3);
   __shared__ uint32_t sh_rstart[65];   // first flat entry of run t of the item
   __shared__ uint32_t sh_rval[64];
   __shared__ float sh_sum[NG][G * VEC];
