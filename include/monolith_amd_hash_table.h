@@ -42,7 +42,7 @@ enum {
 
 const char* mhte_last_error(void);
 /* ABI version of this header; mhte_abi_version() must return the same value. */
-#define MHTE_ABI_VERSION 4
+#define MHTE_ABI_VERSION 5
 int32_t mhte_abi_version(void);
 
 /* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
@@ -158,14 +158,19 @@ mhte_status mhte_compute_fused_offsets(const mhte_multi_table* t, const int32_t*
 /* MonolithMultiHashTableFusedLookup (RT/ops/multi_hash_table_lookup_op.cc:128-197,229-255).
  * ids [dev], fused_slot_size [host, num_of_shards*n_tables] (shard-major, table-minor);
  * embeddings [dev, total_embeddings from mhte_compute_fused_offsets];
- * embedding_splits [host, num_of_shards], id_offsets / embedding_offsets [host, N*T+1]. */
+ * embedding_splits [host, num_of_shards], id_offsets / embedding_offsets [host, N*T+1].
+ * ONE launch over the N*T segments (the reference loops over the tables inside Shard() over the
+ * shards, :150-196) when every table's row is made of float4s and <= 32 tables. */
 mhte_status mhte_fused_lookup(mhte_multi_table* t, const int64_t* ids,
                               const int32_t* fused_slot_size, int32_t num_of_shards,
                               int64_t req_time, float* embeddings, int64_t embeddings_len,
                               int32_t* embedding_splits, int32_t* id_offsets,
                               int32_t* embedding_offsets, void* stream);
 /* MonolithMultiHashTableFusedOptimize (RT/ops/multi_hash_table_update_op.cc:247-325).
- * enable_grad_accumulation == (flags & MHTE_SUM_DUPLICATES). */
+ * enable_grad_accumulation == (flags & MHTE_SUM_DUPLICATES).
+ * With MHTE_IDS_UNIQUE (ids distinct inside every segment, which is what FusedReorderByIndices
+ * hands over) the N*T segments are ONE upsert launch + one displacement launch; without it every
+ * segment is grouped and applied on its own. */
 mhte_status mhte_fused_optimize(mhte_multi_table* t, const int64_t* ids,
                                 const int32_t* fused_slot_size, const float* id_grads,
                                 int64_t id_grads_len, const int32_t* id_offsets,
@@ -406,6 +411,43 @@ mhte_status mhte_table_step_backward(mhte_multi_table* t, int32_t table, mhte_de
                                      const float* learning_rate, int64_t n_learning_rate,
                                      int64_t update_time, int64_t global_step, int32_t flags,
                                      void* stream);
+
+/* Pipelined training step over ALL tables of a MultiHashTable: what a MonolithModel does per step
+ * with MonolithMultiHashTableLookup (RT/ops/multi_hash_table_lookup_op.cc:33-89) and
+ * MonolithMultiHashTableOptimize (RT/ops/multi_hash_table_update_op.cc:47-100) on the ragged
+ * (id, id_split) batch of its T feature tables (NT/multi_hash_table_ops.py:349-413,
+ * NT/multi_type_hash_table.py:253-303), as ONE forward and ONE backward launch for every table
+ * together (+ a displacement launch that usually finds nothing to do) instead of 2 T launches:
+ *   mhte_multi_step_forward   embedding[sum n_t*dim_t] = rows of id (layout of mhte_lookup: tables in
+ *                             sorted-name order, per OCCURRENCE, absent ids -> zeros, no insert)
+ *                             + the run dedup of the NEXT batch (id_next, id_split_next; NULL: none)
+ *   mhte_multi_step_backward  value[sum n_t*dim_t] = gradient of every occurrence of the forward
+ *                             batch: per table duplicate-gradient sum in occurrence order
+ *                             (MonolithFillWithOffsetMapGradient, RT/ops/unique_mapping_ops.cc:284-329)
+ *                             + upsert + one optimizer step per distinct id, + the numbering of the
+ *                             next batch's distinct ids
+ * prefetched != 0: the caller states that (id, id_split) is the batch the previous forward call
+ * received as id_next (its dedup is picked up; MHTE_FAILED_PRECONDITION if there is none of that
+ * shape); 0: the batch is deduplicated now (two more launches), any batch deduplicated ahead is
+ * dropped.  Up to max_batch_per_table (<= 65 536) ids per table and step; empty tables are fine.
+ * Every table must satisfy mhte_table_fused_backward_ok with segment boundaries on 4-float
+ * multiples; embedding / value 16-byte aligned.  flags: MHTE_EXACT_ORDER as in
+ * mhte_table_step_backward.  learning_rate [host, sum slice_size_t] as in mhte_optimize.
+ * mhte_multi_step_unique_counts: distinct ids per table of the forward batch (host int64[T]);
+ * synchronises. */
+typedef struct mhte_multi_step mhte_multi_step;
+mhte_status mhte_multi_step_create(mhte_multi_table* t, int64_t max_batch_per_table,
+                                   mhte_multi_step** out);
+void mhte_multi_step_destroy(mhte_multi_step* s);
+mhte_status mhte_multi_step_forward(mhte_multi_step* s, const int64_t* id, const int64_t* id_split,
+                                    int64_t n_split, float* embedding, int64_t embedding_len,
+                                    const int64_t* id_next, const int64_t* id_split_next,
+                                    int64_t n_split_next, int32_t prefetched, void* stream);
+mhte_status mhte_multi_step_backward(mhte_multi_step* s, const float* value, int64_t value_len,
+                                     const float* learning_rate, int64_t n_learning_rate,
+                                     int64_t update_time, int64_t global_step, int32_t flags,
+                                     void* stream);
+mhte_status mhte_multi_step_unique_counts(mhte_multi_step* s, int64_t* counts, void* stream);
 
 /* 1 when table i's row fits the single-launch backward (dim <= 256 floats, or <= 64 when segment
  * boundaries are not multiples of 4 floats); otherwise mhte_table_sum_optimize_n runs segment sum +

@@ -9,7 +9,7 @@ _SO = os.path.join(_DIR, "libmhte.so")
 _SRC = os.path.join(_DIR, "csrc", "mhte.hip")
 _DEPS = [_SRC] + [os.path.join(_DIR, "csrc", h) for h in
                   ("mhte_kernels.h", "mhte_core.h", "mhte_step_kernels.h", "mhte_pool_kernels.h",
-                   "mhte_ckpt.h")] + [os.path.join(_DIR, "..", "include", "monolith_amd_hash_table.h")]
+                   "mhte_ckpt.h", "mhte_mstep_kernels.h", "mhte_mstep_host.h")] + [os.path.join(_DIR, "..", "include", "monolith_amd_hash_table.h")]
 # A/B measurements: MHTE_LIBRARY=<other build of libmhte.so> (same ABI) is loaded instead
 _OVERRIDE = os.environ.get("MHTE_LIBRARY")
 
@@ -25,7 +25,7 @@ MHTE_IDS_UNIQUE = 1
 MHTE_SUM_DUPLICATES = 2
 MHTE_EXACT_ORDER = 1       # flags of mhte_table_sum_optimize_n
 MHTE_DEFER_SLOWPATH = 2
-ABI_VERSION = 4            # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
+ABI_VERSION = 5            # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 OPT_MOMENTUM, OPT_ADADELTA, OPT_RMSPROP, OPT_RMSPROPV2, OPT_ADAM, OPT_AMSGRAD = 3, 4, 5, 6, 7, 8
@@ -114,6 +114,8 @@ EXPORTS = [
     "mhte_hash_filter_create", "mhte_hash_filter_destroy", "mhte_multi_table_set_filter",
     "mhte_hash_filter_get", "mhte_fused_gather_embeddings_by_input",
     "mhte_fused_gather_embeddings_by_input_gradient", "mhte_reduce_rows",
+    "mhte_multi_step_create", "mhte_multi_step_destroy", "mhte_multi_step_forward",
+    "mhte_multi_step_backward", "mhte_multi_step_unique_counts",
 ]
 
 _lib = None
@@ -145,6 +147,8 @@ def lib():
     L.mhte_multi_table_destroy.restype = None
     L.mhte_dedup_ws_destroy.restype = None
     L.mhte_hash_filter_destroy.restype = None
+    L.mhte_multi_step_destroy.restype = None
+    L.mhte_multi_step_destroy.argtypes = [C.c_void_p]
     L.mhte_hash_filter_destroy.argtypes = [C.c_void_p]
     L.mhte_multi_table_destroy.argtypes = [C.c_void_p]
     L.mhte_dedup_ws_destroy.argtypes = [C.c_void_p]
@@ -182,7 +186,8 @@ def vp(x):
 
 
 PROFILE_TAGS = {1: "lookup_kernel", 2: "sum_apply_kernel", 6: "slowpath_kernel", 7: "dd_kernels",
-                8: "upsert_kernel", 9: "step_fwd_kernel", 10: "step_bwd_kernel"}
+                8: "upsert_kernel", 9: "step_fwd_kernel", 10: "step_bwd_kernel",
+                11: "mstep_fwd_kernel", 12: "mstep_bwd_kernel"}
 TRACE_WORDS = 8
 TRACE_ROLES = {3: "run_dedup", 4: "displacement", 5: "lookup", 6: "work_list", 7: "apply_items",
                8: "apply_ids", 9: "reserve_rows"}

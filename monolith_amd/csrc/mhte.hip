@@ -30,6 +30,7 @@
 #include "mhte_ckpt.h"
 #include "mhte_pool_kernels.h"
 #include "mhte_step_kernels.h"
+#include "mhte_mstep_kernels.h"
 
 namespace mhte {
 
@@ -83,7 +84,8 @@ static inline uint32_t ceil_log2(uint64_t n) {
 // instead of events recorded around the launch, which also contain the dispatch gap.
 enum ProfTag : int32_t {
   kTagLookup = 1, kTagSumApply = 2,
-  kTagSlowpath = 6, kTagDedup = 7, kTagUpsert = 8, kTagStepFwd = 9, kTagStepBwd = 10
+  kTagSlowpath = 6, kTagDedup = 7, kTagUpsert = 8, kTagStepFwd = 9, kTagStepBwd = 10,
+  kTagMStepFwd = 11, kTagMStepBwd = 12
 };
 
 // Per-wavefront timeline of the step kernels (mhte_trace_begin / mhte_trace_end): each traced
@@ -526,7 +528,10 @@ struct Table {
     HIP_OK(hipMemcpy(d_chunks + (chunks.size() - 1), &p, sizeof(float*), hipMemcpyHostToDevice));
   }
 
+  // bumped whenever `view` (or count_hits) changes: holders of device copies re-upload
+  uint64_t view_version = 0;
   void refresh_view() {
+    ++view_version;
     view.buckets = buckets;
     view.chunk0 = chunks.empty() ? nullptr : chunks[0];
     view.chunks = d_chunks;
@@ -978,6 +983,9 @@ struct mhte_multi_table {
   int device = 0;
   std::string shared_name;
   std::vector<std::unique_ptr<mhte::Table>> tables;  // sorted by name
+  // device copies of the tables' views, read by the multi-table launches (mhte_mstep_host.h)
+  mhte::DevBuf<mhte::TableView> d_views;
+  std::vector<uint64_t> view_uploaded;
 };
 struct mhte_dedup_ws {
   mhte::DedupWs ws;
@@ -1065,6 +1073,12 @@ static void ragged_upsert(mhte_multi_table* t, const int64_t* id, const int64_t*
 }
 
 }  // namespace mhte
+
+#include "mhte_mstep_host.h"
+
+struct mhte_multi_step {
+  mhte::MultiStep ms;
+};
 
 using namespace mhte;
 
@@ -1259,12 +1273,19 @@ mhte_status mhte_fused_lookup(mhte_multi_table* t, const int64_t* ids,
     if (te > embeddings_len)
       throw Error(MHTE_INVALID_ARGUMENT, "embeddings buffer too short: need " + std::to_string(te));
     HIP_OK(hipSetDevice(t->device));
-    for (int s = 0; s < num_of_shards; ++s) {
-      for (int k = 0; k < T; ++k) {
-        const int idx = s * T + k;
-        Table& tb = *t->tables[k];
-        std::lock_guard<std::mutex> g(tb.mu);
-        tb.lookup(ids + ko[idx], fused_slot_size[idx], nullptr, embeddings + eo[idx], S(stream));
+    if (seg_kernels_ok(t) && aligned16(embeddings)) {
+      // ONE launch over the [shard][table] segments (mhte_mstep_kernels.h)
+      std::vector<std::unique_lock<std::mutex>> locks;
+      for (auto& tb : t->tables) locks.emplace_back(tb->mu);
+      fused_lookup_segments(t, ids, ko.data(), eo.data(), T * num_of_shards, embeddings, S(stream));
+    } else {
+      for (int s = 0; s < num_of_shards; ++s) {
+        for (int k = 0; k < T; ++k) {
+          const int idx = s * T + k;
+          Table& tb = *t->tables[k];
+          std::lock_guard<std::mutex> g(tb.mu);
+          tb.lookup(ids + ko[idx], fused_slot_size[idx], nullptr, embeddings + eo[idx], S(stream));
+        }
       }
     }
     if (embedding_splits) memcpy(embedding_splits, es.data(), sizeof(int32_t) * es.size());
@@ -1290,6 +1311,22 @@ mhte_status mhte_fused_optimize(mhte_multi_table* t, const int64_t* ids,
     if (need_lr > n_learning_rates)
       throw Error(MHTE_INVALID_ARGUMENT, "learning_rate_tensors too short");
     HIP_OK(hipSetDevice(t->device));
+    for (int idx = 0; idx < T * num_of_shards; ++idx) {
+      if (fused_slot_size[idx] < 0) throw Error(MHTE_INVALID_ARGUMENT, "negative fused_slot_size");
+      if (int64_t(grad_offsets[idx]) + int64_t(fused_slot_size[idx]) * t->tables[idx % T]->dim > id_grads_len)
+        throw Error(MHTE_INVALID_ARGUMENT, "id_grads too short");
+    }
+    bool filtered = false;
+    for (auto& tb : t->tables) filtered = filtered || tb->flt_slots != nullptr;
+    if ((flags & MHTE_IDS_UNIQUE) && !filtered && seg_kernels_ok(t) && aligned16(id_grads)) {
+      // ids distinct inside every segment (the caller's FusedReorderByIndices deduplicated them):
+      // ONE upsert launch over the segments + the displacement pass
+      std::vector<std::unique_lock<std::mutex>> locks;
+      for (auto& tb : t->tables) locks.emplace_back(tb->mu);
+      fused_optimize_segments(t, ids, fused_slot_size, id_grads, id_offsets, grad_offsets,
+                              learning_rates, req_time, global_step, num_of_shards, S(stream));
+      return;
+    }
     for (int s = 0; s < num_of_shards; ++s) {
       int64_t lr_off = 0;  // restarts per shard, multi_hash_table_update_op.cc:285-293
       for (int k = 0; k < T; ++k) {
@@ -2295,6 +2332,69 @@ mhte_status mhte_table_set_count_hits(mhte_multi_table* t, int32_t table, int32_
     Table& tb = table_at(t, table);
     std::lock_guard<std::mutex> g(tb.mu);
     tb.count_hits = enable != 0;
+    ++tb.view_version;
+  });
+}
+
+// ---- multi-table pipelined step -----------------------------------------------------------------
+mhte_status mhte_multi_step_create(mhte_multi_table* t, int64_t max_batch_per_table,
+                                   mhte_multi_step** out) {
+  return guard([&] {
+    check_handle(t);
+    if (!out) throw Error(MHTE_INVALID_ARGUMENT, "null out");
+    HIP_OK(hipSetDevice(t->device));
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (auto& tb : t->tables) locks.emplace_back(tb->mu);
+    std::unique_ptr<mhte_multi_step> s(new mhte_multi_step);
+    s->ms.init(t, max_batch_per_table);
+    *out = s.release();
+  });
+}
+void mhte_multi_step_destroy(mhte_multi_step* s) { delete s; }
+
+mhte_status mhte_multi_step_forward(mhte_multi_step* s, const int64_t* id, const int64_t* id_split,
+                                    int64_t n_split, float* embedding, int64_t embedding_len,
+                                    const int64_t* id_next, const int64_t* id_split_next,
+                                    int64_t n_split_next, int32_t prefetched, void* stream) {
+  return guard([&] {
+    if (!s) throw Error(MHTE_INVALID_ARGUMENT, "null multi step");
+    HIP_OK(hipSetDevice(s->ms.device));
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (auto& tb : s->ms.mt->tables) locks.emplace_back(tb->mu);
+    s->ms.forward(id, id_split, n_split, embedding, embedding_len, id_next, id_split_next,
+                  n_split_next, prefetched, S(stream));
+  });
+}
+
+mhte_status mhte_multi_step_backward(mhte_multi_step* s, const float* value, int64_t value_len,
+                                     const float* learning_rate, int64_t n_learning_rate,
+                                     int64_t update_time, int64_t global_step, int32_t flags,
+                                     void* stream) {
+  (void)global_step;
+  return guard([&] {
+    if (!s) throw Error(MHTE_INVALID_ARGUMENT, "null multi step");
+    HIP_OK(hipSetDevice(s->ms.device));
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (auto& tb : s->ms.mt->tables) locks.emplace_back(tb->mu);
+    s->ms.backward(value, value_len, learning_rate, n_learning_rate, update_time,
+                   (flags & MHTE_EXACT_ORDER) != 0, S(stream));
+  });
+}
+
+mhte_status mhte_multi_step_unique_counts(mhte_multi_step* s, int64_t* counts, void* stream) {
+  return guard([&] {
+    if (!s || !counts) throw Error(MHTE_INVALID_ARGUMENT, "null argument");
+    MultiStep& ms = s->ms;
+    HIP_OK(hipSetDevice(ms.device));
+    if (ms.stage[ms.cur] != 2)
+      throw Error(MHTE_FAILED_PRECONDITION, "multi step: the current batch has not been numbered");
+    std::vector<uint32_t> h(ms.T, 0);
+    for (uint32_t t = 0; t < ms.T; ++t)
+      if (ms.n_slot[ms.cur][t])
+        HIP_OK(hipMemcpyAsync(&h[t], ms.h_st[t].rv[ms.cur].n_unique, sizeof(uint32_t),
+                              hipMemcpyDeviceToHost, S(stream)));
+    HIP_OK(hipStreamSynchronize(S(stream)));
+    for (uint32_t t = 0; t < ms.T; ++t) counts[t] = h[t];
   });
 }
 

@@ -1,0 +1,519 @@
+// Host side of the multi-table step and of the one-launch fused ops (kernels:
+// mhte_mstep_kernels.h).  Included by mhte.hip, inside namespace-level scope, after Table and
+// mhte_multi_table are defined.
+//
+// Reference call sites this replaces as ONE pair of launches per training step:
+//   NT/multi_hash_table_ops.py:349-413 (lookup / apply_gradients over every table of the model),
+//   RT/ops/multi_hash_table_lookup_op.cc:33-89, RT/ops/multi_hash_table_update_op.cc:47-100.
+#ifndef MHTE_MSTEP_HOST_H_
+#define MHTE_MSTEP_HOST_H_
+
+namespace mhte {
+
+// ---- device copies of the tables' views ---------------------------------------------------------
+// (a view changes when the table doubles, gets a filter, ...: Table::view_version)
+static void sync_views(mhte_multi_table* mt, hipStream_t st) {
+  const size_t T = mt->tables.size();
+  if (mt->view_uploaded.size() != T) {
+    mt->d_views.reserve(T);
+    mt->view_uploaded.assign(T, 0);
+  }
+  bool synced = false;
+  for (size_t i = 0; i < T; ++i) {
+    Table& tb = *mt->tables[i];
+    if (mt->view_uploaded[i] == tb.view_version) continue;
+    if (!synced) {  // launches in flight still read the old descriptors
+      HIP_OK(hipStreamSynchronize(st));
+      synced = true;
+    }
+    TableView v = tb.view;
+    v.trace = nullptr;
+    HIP_OK(hipMemcpy(mt->d_views.p + i, &v, sizeof(TableView), hipMemcpyHostToDevice));
+    mt->view_uploaded[i] = tb.view_version;
+  }
+}
+
+static uint32_t group_lanes(uint32_t dim) {
+  uint32_t g = 8;
+  while (g * 4 < dim && g < 64) g <<= 1;
+  return g;
+}
+
+// bump allocator over one hipMalloc (first pass with base == nullptr sizes it)
+struct Arena {
+  char* base = nullptr;
+  size_t off = 0;
+  template <class T>
+  T* take(size_t n) {
+    off = (off + 255) & ~size_t(255);
+    T* p = reinterpret_cast<T*>(base + off);
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct MultiStep {
+  mhte_multi_table* mt = nullptr;
+  int device = 0;
+  uint32_t T = 0;
+  int64_t max_batch = 0;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  std::vector<MStepStatic> h_st;
+  MStepStatic* d_st = nullptr;
+  std::vector<uint64_t> st_version;     // Table::view_version the static descriptor was built for
+  int cur = 0;                          // slot of the batch being trained
+  int stage[2] = {0, 0};                // 0 empty, 1 deduplicated (scratch dirty), 2 numbered
+  std::vector<uint32_t> n_slot[2];      // per table: batch size held by the slot
+  int num_cus = 256;
+  uint32_t ovs = 4;                     // workgroups launched per resident slot (T > 1)
+  uint32_t lookup_cap = 0;              // lookup workgroups per table (0: one trip each)
+
+  ~MultiStep() {
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    if (arena) (void)hipFree(arena);
+    if (d_st) (void)hipFree(d_st);
+  }
+
+  static uint32_t scratch_cap(int64_t n) {
+    return 1u << std::max<uint32_t>(10, ceil_log2(uint64_t(2) * uint64_t(n)));
+  }
+
+  void layout(Arena& A, uint32_t t, MStepStatic& s) {
+    const Table& tb = *mt->tables[t];
+    const int64_t n = max_batch;
+    const uint32_t C = scratch_cap(n);
+    const uint32_t nblk = uint32_t((n + kRdBlock - 1) / kRdBlock);
+    const uint32_t items = DedupWs::max_items(n);
+    for (int sl = 0; sl < 2; ++sl) {
+      RunView d{};
+      d.hkey = A.take<int64_t>(size_t(C) + 2);
+      d.hcnt = A.take<uint32_t>(size_t(C) + 2);
+      d.hblk = A.take<unsigned long long>(size_t(C) + 2);
+      d.hpos = A.take<uint32_t>(size_t(C) + 2);
+      d.hlist = A.take<uint32_t>((size_t(C) + 2) * kLightMax);
+      d.cap_mask = C - 1;
+      d.uslot = A.take<uint32_t>(size_t(n) + 1);
+      d.ucnt = A.take<uint32_t>(size_t(n) + 1);
+      d.ublk = A.take<unsigned long long>(size_t(n) + 1);
+      d.upos = A.take<uint32_t>(size_t(n) + 1);
+      d.btab_key = A.take<int64_t>(size_t(nblk) * kRdStride);
+      d.btab_val = A.take<uint32_t>(size_t(nblk) * kRdStride);
+      d.seg = A.take<uint16_t>(size_t(nblk) * kRdBlock);
+      d.item_hdr = A.take<ItemHdr>(items);
+      d.item_runs = A.take<uint32_t>(size_t(items) * 64);
+      d.ctr = A.take<uint32_t>(4);
+      d.ids = nullptr;
+      d.n = 0;
+      d.nblk = 0;
+      d.item_target = DedupWs::item_target();
+      d.uids = A.take<int64_t>(size_t(n) + 1);
+      d.n_unique = A.take<uint32_t>(4);
+      s.rv[sl] = d;
+      s.part[sl] = A.take<float>(size_t(items) * tb.dim + 16);
+      s.arrive[sl] = A.take<uint32_t>(size_t(n) + 2);
+    }
+    s.grad_u = A.take<float>(size_t(n) * tb.dim + 16);
+    s.pending = A.take<uint32_t>(size_t(n) + 2);
+    s.n_max = n;
+    s.g = group_lanes(tb.dim);
+    s.oneseg = tb.nseg == 1 ? 1u : 0u;
+    s.nblk_build = DedupWs::build_blocks(s.rv[0]);
+    s.count_hits = tb.count_hits ? 1u : 0u;
+  }
+
+  void init(mhte_multi_table* m, int64_t mb) {
+    mt = m;
+    device = m->device;
+    T = uint32_t(m->tables.size());
+    max_batch = mb;
+    if (mb <= 0 || mb > int64_t(kRdMaxBlocks) * kRdBlock)
+      throw Error(MHTE_INVALID_ARGUMENT, "multi step: max batch per table must be 1.." +
+                                             std::to_string(kRdMaxBlocks * kRdBlock));
+    for (uint32_t t = 0; t < T; ++t) {
+      const Table& tb = *m->tables[t];
+      if (!tb.fusable() || !tb.vec_ok)
+        throw Error(MHTE_INVALID_ARGUMENT,
+                    "multi step: table " + tb.name + " does not fit the fused step (SGD / Adagrad / "
+                    "FTRL segments on 4-float boundaries, dim <= 256)");
+    }
+    {
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+        num_cus = cus;
+    }
+    if (const char* e = getenv("MHTE_MSTEP_OVERSUB")) ovs = std::max(1, atoi(e));
+    if (const char* e = getenv("MHTE_MSTEP_LOOKUP_WGS")) lookup_cap = std::max(0, atoi(e));
+    h_st.assign(T, MStepStatic{});
+    Arena sizing;
+    for (uint32_t t = 0; t < T; ++t) layout(sizing, t, h_st[t]);
+    arena_bytes = sizing.off + 256;
+    HIP_OK(hipMalloc(&arena, arena_bytes));
+    HIP_OK(hipMemset(arena, 0, arena_bytes));
+    Arena real;
+    real.base = arena;
+    for (uint32_t t = 0; t < T; ++t) layout(real, t, h_st[t]);
+    HIP_OK(hipMalloc(&d_st, sizeof(MStepStatic) * T));
+    HIP_OK(hipMemcpy(d_st, h_st.data(), sizeof(MStepStatic) * T, hipMemcpyHostToDevice));
+    st_version.assign(T, 0);
+    for (uint32_t t = 0; t < T; ++t) st_version[t] = m->tables[t]->view_version;
+    n_slot[0].assign(T, 0);
+    n_slot[1].assign(T, 0);
+    clear_slots(3u, nullptr);
+    HIP_OK(hipDeviceSynchronize());
+  }
+
+  void clear_slots(uint32_t mask, hipStream_t st) {
+    const uint32_t C = scratch_cap(max_batch);
+    mstep_clear_kernel<<<dim3((C + 2 + 255) / 256, T), 256, 0, st>>>(ConstStatics(d_st), mask);
+    HIP_OK(hipGetLastError());
+  }
+
+  // count_hits is the one per-table switch that can change after creation
+  void sync_static(hipStream_t st) {
+    for (uint32_t t = 0; t < T; ++t) {
+      Table& tb = *mt->tables[t];
+      if (st_version[t] == tb.view_version) continue;
+      const uint32_t ch = tb.count_hits ? 1u : 0u;
+      if (h_st[t].count_hits != ch) {
+        h_st[t].count_hits = ch;
+        HIP_OK(hipStreamSynchronize(st));
+        HIP_OK(hipMemcpy(d_st + t, &h_st[t], sizeof(MStepStatic), hipMemcpyHostToDevice));
+      }
+      st_version[t] = tb.view_version;
+    }
+  }
+
+  void check_ragged(const int64_t* split, int64_t n_split, const char* what) const {
+    if (!split || n_split != int64_t(T) + 1)
+      throw Error(MHTE_INVALID_ARGUMENT,
+                  std::string("The length of tensor `") + what + "` doesn't equal to table num. " +
+                      std::to_string(n_split - 1) + "v.s." + std::to_string(T));
+    for (uint32_t t = 0; t < T; ++t) {
+      const int64_t n = split[t + 1] - split[t];
+      if (n < 0) throw Error(MHTE_INVALID_ARGUMENT, "id_split not monotonic");
+      if (n > max_batch)
+        throw Error(MHTE_INVALID_ARGUMENT, "multi step: table " + mt->tables[t]->name + " has " +
+                                               std::to_string(n) + " ids, the step was created for " +
+                                               std::to_string(max_batch));
+    }
+    if (split[T] - split[0] > int64_t(0xffffffffu))
+      throw Error(MHTE_INVALID_ARGUMENT, "multi step: more than 2^32 ids");
+  }
+
+  // one forward launch per chunk of kMaxStepTables tables: lookups of (ids, split) when `out`,
+  // run dedup of (ids_next, split_next) into slot `slot_next` when ids_next
+  void launch_fwd(const int64_t* ids, const int64_t* split, float* out, const int64_t* ids_next,
+                  const int64_t* split_next, int slot_next, hipStream_t st) {
+    int64_t emb_off = 0;
+    for (uint32_t t0 = 0; t0 < T; t0 += kMaxStepTables) {
+      const uint32_t tc = std::min<uint32_t>(kMaxStepTables, T - t0);
+      MFwdArgs A{};
+      A.views = ConstViews(mt->d_views.p + t0);
+      A.st = ConstStatics(d_st + t0);
+      A.ids = ids ? ids + split[0] : nullptr;
+      A.ids_next = ids_next ? ids_next + split_next[0] : nullptr;
+      A.out = out;
+      A.cur = uint32_t(slot_next ^ 1);
+      uint32_t max_d = 0, max_l = 0;
+      for (uint32_t k = 0; k < tc; ++k) {
+        const uint32_t t = t0 + k;
+        MFwdTab& ft = A.tab[k];
+        const Table& tb = *mt->tables[t];
+        if (ids && out) {
+          ft.id_off = uint32_t(split[t] - split[0]);
+          ft.n = uint32_t(split[t + 1] - split[t]);
+          if (uint64_t(emb_off) > 0xffffffffull)
+            throw Error(MHTE_INVALID_ARGUMENT, "multi step: embedding buffer exceeds 2^32 floats");
+          ft.emb_off = uint32_t(emb_off);
+          emb_off += int64_t(ft.n) * tb.dim;
+          const uint32_t groups = (ft.n + 1) / 2;
+          max_l = std::max(max_l, uint32_t((uint64_t(groups) * h_st[t].g + kRdBlock - 1) / kRdBlock));
+        }
+        if (ids_next) {
+          ft.next_off = uint32_t(split_next[t] - split_next[0]);
+          ft.n_next = uint32_t(split_next[t + 1] - split_next[t]);
+          max_d = std::max(max_d, (ft.n_next + kRdBlock - 1) / kRdBlock);
+        }
+      }
+      if (lookup_cap && max_l > lookup_cap) max_l = lookup_cap;
+      if (max_d + max_l == 0) continue;
+      const dim3 grid(max_d + max_l, tc);
+      LAUNCH_HOT(kTagMStepFwd, (mstep_fwd_kernel<2>), grid, kRdBlock, st, A);
+      HIP_OK(hipGetLastError());
+    }
+  }
+
+  struct BwdPlan {
+    const float* grads = nullptr;
+    const int64_t* split = nullptr;   // of the batch in slot `cur` (nullptr: build only)
+    const float* lrs = nullptr;
+    int64_t update_time = 0;
+    bool exact_order = false;
+  };
+
+  // one backward launch per chunk: apply of slot `slot_cur` (when p.grads) | numbering of slot
+  // slot_cur ^ 1 (when build_next); then the displacement pass
+  void launch_bwd(const BwdPlan& p, int slot_cur, bool build_next, hipStream_t st) {
+    int64_t grad_off = 0;
+    int64_t lr_off = 0;
+    uint32_t active = 0;
+    if (p.grads)
+      for (uint32_t t = 0; t < T; ++t) active += n_slot[slot_cur][t] ? 1u : 0u;
+    const uint32_t budget = uint32_t(kBwdBlocksPerCu * num_cus);
+    const uint32_t share = std::max<uint32_t>(32, budget * (active > 1 ? ovs : 1u) / std::max(1u, active));
+    for (uint32_t t0 = 0; t0 < T; t0 += kMaxStepTables) {
+      const uint32_t tc = std::min<uint32_t>(kMaxStepTables, T - t0);
+      MBwdArgs A{};
+      A.views = ConstViews(mt->d_views.p + t0);
+      A.st = ConstStatics(d_st + t0);
+      A.grads = p.grads;
+      A.cur = uint32_t(slot_cur);
+      uint32_t gx = 0;
+      bool any_apply = false;
+      for (uint32_t k = 0; k < tc; ++k) {
+        const uint32_t t = t0 + k;
+        MBwdTab& bt = A.tab[k];
+        const Table& tb = *mt->tables[t];
+        const uint32_t n = p.grads ? n_slot[slot_cur][t] : 0u;
+        bt.build_next = (build_next && n_slot[slot_cur ^ 1][t]) ? 1u : 0u;
+        uint32_t blocks = bt.build_next ? h_st[t].nblk_build : 0u;
+        if (n) {
+          bt.apply = 1;
+          any_apply = true;
+          bt.grad_off = uint32_t(grad_off);
+          grad_off += int64_t(n) * tb.dim;
+          for (int i = 0; i < kMaxSegments; ++i)
+            bt.a.lr[i] = (i < int(tb.nseg)) ? p.lrs[lr_off + i] : 0.f;
+          bt.a.ts = static_cast<uint32_t>(p.update_time);
+          bt.a.sum_dups = 1;
+          bt.a.filter_mode = 1;
+          bt.a.global_step = 0;
+          bt.light_max = p.exact_order ? 0xffffffffu : uint32_t(kStepLightMax);
+          const uint32_t groups_per_wg = 256u / h_st[t].g;
+          const uint32_t cap_items = DedupWs::max_items(n);
+          bt.nblk_items = p.exact_order ? 0u
+                                        : std::min<uint32_t>(cap_items, std::min<uint32_t>(
+                                              uint32_t(num_cus) * 10 / 8, std::max<uint32_t>(8, share / 4)));
+          const uint32_t need = (n + groups_per_wg - 1) / groups_per_wg;
+          const uint32_t room = share > bt.nblk_items + std::min<uint32_t>(128, share / 8) + 16
+                                    ? share - bt.nblk_items - std::min<uint32_t>(128, share / 8)
+                                    : 16u;
+          bt.nblk_ids = std::max<uint32_t>(1, std::min(need, room));
+          blocks += bt.nblk_items + bt.nblk_ids;
+        }
+        lr_off += tb.nseg;
+        gx = std::max(gx, blocks);
+      }
+      if (gx == 0) continue;
+      LAUNCH_HOT(kTagMStepBwd, mstep_bwd_kernel, dim3(gx, tc), 256, st, A);
+      HIP_OK(hipGetLastError());
+      if (any_apply) {
+        mstep_slow_kernel<<<tc, 64, 0, st>>>(A);
+        HIP_OK(hipGetLastError());
+      }
+    }
+  }
+
+  // dedup + numbering of (ids, split) into `slot`, on its own (first batch of a pipeline)
+  void dedup_now(const int64_t* ids, const int64_t* split, int slot, hipStream_t st) {
+    if (stage[slot] == 1) clear_slots(1u << slot, st);
+    for (uint32_t t = 0; t < T; ++t) n_slot[slot][t] = uint32_t(split[t + 1] - split[t]);
+    launch_fwd(nullptr, nullptr, nullptr, ids, split, slot, st);
+    BwdPlan none;
+    launch_bwd(none, slot ^ 1, true, st);
+    stage[slot] = 2;
+  }
+
+  void forward(const int64_t* id, const int64_t* split, int64_t n_split, float* emb, int64_t emb_len,
+               const int64_t* id_next, const int64_t* split_next, int64_t n_split_next,
+               int prefetched, hipStream_t st) {
+    check_ragged(split, n_split, "id");
+    if (id_next) check_ragged(split_next, n_split_next, "id_next");
+    if (!id || !emb) throw Error(MHTE_INVALID_ARGUMENT, "multi step forward: null argument");
+    if (!aligned16(emb)) throw Error(MHTE_INVALID_ARGUMENT, "multi step: embedding must be 16-byte aligned");
+    int64_t need = 0;
+    for (uint32_t t = 0; t < T; ++t) need += (split[t + 1] - split[t]) * int64_t(mt->tables[t]->dim);
+    if (need > emb_len)
+      throw Error(MHTE_INVALID_ARGUMENT, "embedding buffer too short: need " + std::to_string(need));
+    for (auto& tb : mt->tables) tb->finish_pending(st);
+    sync_views(mt, st);
+    sync_static(st);
+    if (prefetched) {
+      const int nxt = cur ^ 1;
+      bool same = stage[nxt] >= 1;
+      for (uint32_t t = 0; same && t < T; ++t) same = n_slot[nxt][t] == uint32_t(split[t + 1] - split[t]);
+      if (!same)
+        throw Error(MHTE_FAILED_PRECONDITION,
+                    "multi step forward: this batch was not deduplicated ahead by the previous forward");
+      cur = nxt;
+    } else {
+      dedup_now(id, split, cur, st);
+    }
+    const int nxt = cur ^ 1;
+    if (id_next) {
+      if (stage[nxt] == 1) clear_slots(1u << nxt, st);
+      for (uint32_t t = 0; t < T; ++t) n_slot[nxt][t] = uint32_t(split_next[t + 1] - split_next[t]);
+    }
+    launch_fwd(id, split, emb, id_next, split_next, nxt, st);
+    if (id_next) stage[nxt] = 1;
+  }
+
+  void backward(const float* grads, int64_t grads_len, const float* lrs, int64_t n_lr,
+                int64_t update_time, bool exact_order, hipStream_t st) {
+    if (stage[cur] == 0)
+      throw Error(MHTE_FAILED_PRECONDITION, "multi step backward: no forward batch outstanding");
+    if (!grads || !lrs) throw Error(MHTE_INVALID_ARGUMENT, "multi step backward: null argument");
+    if (!aligned16(grads)) throw Error(MHTE_INVALID_ARGUMENT, "multi step: gradients must be 16-byte aligned");
+    int64_t need = 0, need_lr = 0;
+    for (uint32_t t = 0; t < T; ++t) {
+      need += int64_t(n_slot[cur][t]) * int64_t(mt->tables[t]->dim);
+      need_lr += mt->tables[t]->nseg;
+    }
+    if (need > grads_len)
+      throw Error(MHTE_INVALID_ARGUMENT, "The length of tensor `value` is too short. Currently value" +
+                                             std::to_string(grads_len));
+    if (need_lr > n_lr)
+      throw Error(MHTE_INVALID_ARGUMENT,
+                  "The length of tensor `learning_rate` is too short. Currently value" + std::to_string(n_lr));
+    for (uint32_t t = 0; t < T; ++t) {
+      Table& tb = *mt->tables[t];
+      tb.finish_pending(st);
+      if (!n_slot[cur][t]) continue;
+      tb.note_update_time(update_time);
+      tb.ensure_capacity(uint64_t(n_slot[cur][t]), st);
+    }
+    sync_views(mt, st);
+    sync_static(st);
+    if (stage[cur] == 1) {  // (forward, forward, backward: the batch was never numbered)
+      BwdPlan none;
+      launch_bwd(none, cur ^ 1, true, st);
+      stage[cur] = 2;
+    }
+    BwdPlan p;
+    p.grads = grads;
+    p.lrs = lrs;
+    p.update_time = update_time;
+    p.exact_order = exact_order;
+    const int nxt = cur ^ 1;
+    const bool build_next = stage[nxt] == 1;
+    launch_bwd(p, cur, build_next, st);
+    stage[cur] = 0;
+    if (build_next) stage[nxt] = 2;
+  }
+};
+
+// =================================================================================================
+// One-launch fused ops
+// =================================================================================================
+// true when every table can take the segment kernels (float4 rows, no whole-segment optimizer)
+static bool seg_kernels_ok(const mhte_multi_table* t) {
+  if (t->tables.size() > size_t(kMaxStepTables)) return false;
+  for (auto& tb : t->tables) {
+    if (!tb->vec_ok || tb->has_group_opt) return false;
+    Shape sh = pick_shape(tb->dim, true);
+    if (tb->dim > uint32_t(sh.G * sh.VEC)) return false;
+  }
+  return true;
+}
+
+static void fused_lookup_segments(mhte_multi_table* t, const int64_t* ids, const int32_t* ko,
+                                  const int32_t* eo, int nseg_all, float* embeddings, hipStream_t st) {
+  const int T = int(t->tables.size());
+  for (auto& tb : t->tables) tb->finish_pending(st);
+  sync_views(t, st);
+  const int per = std::max(T, (kMaxSegs / T) * T);  // whole shards per launch
+  for (int s0 = 0; s0 < nseg_all; s0 += per) {
+    const int ns = std::min(per, nseg_all - s0);
+    SegLookupArgs A{};
+    A.views = ConstViews(t->d_views.p);
+    A.ids = ids;
+    A.out = embeddings;
+    A.T = uint32_t(T);
+    A.seg0 = uint32_t(s0);
+    uint32_t gx = 0;
+    for (int y = 0; y <= ns; ++y) {
+      A.id_off[y] = uint32_t(ko[s0 + y]);
+      A.emb_off[y] = uint32_t(eo[s0 + y]);
+    }
+    for (int k = 0; k < T; ++k) {
+      A.g[k] = uint8_t(group_lanes(t->tables[k]->dim));
+      A.count_hits[k] = t->tables[k]->count_hits ? 1 : 0;
+    }
+    for (int y = 0; y < ns; ++y) {
+      const uint32_t n = A.id_off[y + 1] - A.id_off[y];
+      const uint32_t g = A.g[(s0 + y) % T];
+      gx = std::max(gx, uint32_t((uint64_t((n + 1) / 2) * g + 511) / 512));
+    }
+    if (gx == 0) continue;
+    LAUNCH_HOT(kTagLookup, seg_lookup_kernel, dim3(gx, ns), 512, st, A);
+    HIP_OK(hipGetLastError());
+  }
+}
+
+// FusedOptimize over segments whose ids are pairwise distinct (MHTE_IDS_UNIQUE): one upsert launch
+// per kMaxSegs segments + one displacement launch.
+static void fused_optimize_segments(mhte_multi_table* t, const int64_t* ids,
+                                    const int32_t* fused_slot_size, const float* id_grads,
+                                    const int32_t* id_offsets, const int32_t* grad_offsets,
+                                    const float* learning_rates, int64_t req_time,
+                                    int64_t global_step, int num_of_shards, hipStream_t st) {
+  const int T = int(t->tables.size());
+  const int nseg_all = T * num_of_shards;
+  std::vector<uint64_t> per_table(size_t(T), 0);
+  for (int y = 0; y < nseg_all; ++y) per_table[size_t(y % T)] += uint64_t(fused_slot_size[y]);
+  for (int k = 0; k < T; ++k) {
+    Table& tb = *t->tables[k];
+    tb.finish_pending(st);
+    if (!per_table[size_t(k)]) continue;
+    tb.note_update_time(req_time);
+    tb.ensure_capacity(per_table[size_t(k)], st);
+    tb.pending.reserve(2 * size_t(per_table[size_t(k)]) + 2);
+  }
+  sync_views(t, st);
+  const int per = std::max(T, (kMaxSegs / T) * T);
+  for (int s0 = 0; s0 < nseg_all; s0 += per) {
+    const int ns = std::min(per, nseg_all - s0);
+    SegUpsertArgs A{};
+    A.views = ConstViews(t->d_views.p);
+    A.ids = ids;
+    A.grads = id_grads;
+    A.T = uint32_t(T);
+    A.seg0 = uint32_t(s0);
+    A.nseg = uint32_t(ns);
+    uint32_t gx = 0;
+    int64_t lr_off = 0;
+    for (int k = 0; k < T; ++k) {
+      Table& tb = *t->tables[k];
+      A.g[k] = uint8_t(group_lanes(tb.dim));
+      A.pending[k] = tb.pending.p;
+      ApplyArgs& a = A.a[k];
+      for (int i = 0; i < kMaxSegments; ++i)
+        a.lr[i] = (i < int(tb.nseg)) ? learning_rates[lr_off + i] : 0.f;
+      lr_off += tb.nseg;  // (restarts per shard in the reference: the same slice for every shard)
+      a.ts = static_cast<uint32_t>(req_time);
+      a.sum_dups = 0;
+      a.filter_mode = 0;
+      a.global_step = global_step;
+    }
+    for (int y = 0; y < ns; ++y) {
+      const uint32_t n = uint32_t(fused_slot_size[s0 + y]);
+      A.id_off[y] = uint32_t(id_offsets[s0 + y]);
+      A.grad_off[y] = uint32_t(grad_offsets[s0 + y]);
+      if (y == ns - 1) A.id_off[ns] = A.id_off[y] + n;
+      else if (uint32_t(id_offsets[s0 + y + 1]) != A.id_off[y] + n)
+        throw Error(MHTE_INVALID_ARGUMENT, "id_offsets do not follow fused_slot_size");
+      const uint32_t gl = A.g[(s0 + y) % T];
+      gx = std::max(gx, (n + 256 / gl - 1) / (256 / gl));
+    }
+    if (gx == 0) continue;
+    gx = std::min<uint32_t>(gx, 1024);
+    LAUNCH_HOT(kTagUpsert, seg_upsert_kernel, dim3(gx, ns), 256, st, A);
+    seg_slow_kernel<<<T, 64, 0, st>>>(A);
+    HIP_OK(hipGetLastError());
+  }
+}
+
+}  // namespace mhte
+#endif  // MHTE_MSTEP_HOST_H_

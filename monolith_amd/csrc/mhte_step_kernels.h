@@ -738,10 +738,23 @@ __device__ __forceinline__ SlotResult upsert_complete(const TableView& tv, GBuck
   return out;
 }
 
+// LDS of the apply role, declared by the kernel: a kernel that instantiates the role for several
+// lane-group widths (mstep_bwd_kernel) would otherwise get one copy of the role's scratch per
+// instantiation.  Sized for G = 8 (32 groups per workgroup).
+struct ApplyLds {
+  uint32_t pos[(256 / 8) * kStepLightMax];  // [group][kStepLightMax] positions of a short list
+  uint32_t need[4];                         // rows each wavefront needs this trip
+  uint32_t rowbase;
+  uint32_t rstart[65];                      // first flat entry of run t of the item
+  uint32_t rval[64];
+  float sum[256 * 4];                       // [group][G * VEC]
+  uint32_t last;
+};
+
 template <int G, int VEC, bool ONESEG>
 __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView& d,
                                               const ApplyCtl& c, const ApplyArgs& a, uint32_t bid,
-                                              WaveTrace& wt) {
+                                              WaveTrace& wt, ApplyLds& L) {
   constexpr int WIN = G < 8 ? G : 8;   // gradient rows in flight per group of an item workgroup
   constexpr int NG = 256 / G;  // groups per workgroup
   const int lane = threadIdx.x & 63;
@@ -757,9 +770,9 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
     // Group `grp` of workgroup k takes the unique indices u = it * stride + grp * nblk_ids + k:
     // consecutive indices (the claim order puts the hot ids first) land in different workgroups.
     // A group lives inside one wavefront, so its LDS hand-offs need no workgroup barrier.
-    __shared__ uint32_t sh_pos[NG][kStepLightMax];
-    __shared__ uint32_t sh_need[4];   // rows each wavefront needs this trip
-    __shared__ uint32_t sh_rowbase;
+    uint32_t* const sh_pos = L.pos + grp * kStepLightMax;  // this group's slice
+    uint32_t* const sh_need = L.need;
+    uint32_t& sh_rowbase = L.rowbase;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t stride = int64_t(c.nblk_ids) * NG;
     const int64_t k = bid - c.nblk_items;
@@ -838,7 +851,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         }
 #pragma unroll
         for (int q = 0; q < PER; ++q)
-          if (x[q] != 0xffffffffu) sh_pos[grp][xr[q]] = x[q];
+          if (x[q] != 0xffffffffu) sh_pos[xr[q]] = x[q];
       }
       // the workgroup's allocation, placed behind the row loads: the compiler waits for a result
       // produced under a branch where the branch ends, and here that wait is shared with loads this
@@ -858,7 +871,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
 #pragma unroll
         for (int q = 0; q < VEC; ++q) acc.v[q] = 0.f + acc.v[q];
       }
-      if (flat) sum_list_lds<VEC>(c.grads, dim, e, ev, sh_pos[grp], cnt, acc);
+      if (flat) sum_list_lds<VEC>(c.grads, dim, e, ev, sh_pos, cnt, acc);
       if (big) {
         // strictly sequential sum of a long list (MHTE_EXACT_ORDER): run after run
         unsigned long long rest = d.ublk[g];
@@ -911,10 +924,10 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
   // -------------------------------------------------------------------- item workgroups
   // (the longest chain of the launch: its wavefronts go first when a SIMD has a choice)
   __builtin_amdgcn_s_setprio(3);
-  __shared__ uint32_t sh_rstart[65];   // first flat entry of run t of the item
-  __shared__ uint32_t sh_rval[64];
-  __shared__ float sh_sum[NG][G * VEC];
-  __shared__ uint32_t sh_last;
+  uint32_t* const sh_rstart = L.rstart;
+  uint32_t* const sh_rval = L.rval;
+  float (*const sh_sum)[G * VEC] = reinterpret_cast<float (*)[G * VEC]>(L.sum);
+  uint32_t& sh_last = L.last;
 #pragma unroll 1
   for (uint32_t w = bid;; w += c.nblk_items) {  // block-uniform
     // round trip 1: item count, header and run descriptors together (an index past the count reads
@@ -1252,7 +1265,8 @@ __global__ __launch_bounds__(256, kBwdBlocksPerCu) void step_bwd_kernel(RunView 
     return;
   }
   const uint32_t bid = blockIdx.x - nblk_build;
-  rd_apply_role<G, VEC, ONESEG>(tv, cur, c, a, bid, wt);
+  __shared__ ApplyLds L;
+  rd_apply_role<G, VEC, ONESEG>(tv, cur, c, a, bid, wt, L);
   wt.end(bid < c.nblk_items ? 7u : 8u);
 }
 

@@ -198,3 +198,95 @@ class SparseStep:
     if self._mode == "pipe":
       return int(self._nu[self._cur].item())
     return int(self.u.n_unique_dev.item())
+
+
+class MultiSparseStep:
+  """The sparse step of a model over EVERY table of a ``MultiHashTable`` — what the reference runs
+  per step as ``MultiHashTable.lookup`` / ``apply_gradients`` on the ragged (id, id_split) batch of
+  its feature tables (native_training/multi_hash_table_ops.py:349-413;
+  multi_type_hash_table.py:253-303 builds that layout for a model) — as ONE forward and ONE
+  backward launch for all tables together (mhte_multi_step_forward / _backward,
+  csrc/mhte_mstep_kernels.h), the dedup of the next batch riding in them:
+
+     forward   per table: lookup(s) | run dedup(s+1)
+     backward  per table: gradient sum + upsert + optimizer(s) | numbering of batch s+1
+               (+ a displacement launch, usually idle)
+
+  ``forward(ragged, next_ragged)`` returns the flat embedding of ``MultiHashTable.raw_lookup``
+  (tables in sorted-name order, rows per OCCURRENCE); ``backward(flat_grad, ...)`` takes the
+  gradient in the same layout.  A batch handed over as ``next_ragged`` is picked up by the next
+  ``forward`` when it receives that same ``Ragged`` object, unmodified (tensor identity and version
+  are checked); any other batch is deduplicated on the spot (two more launches)."""
+
+  def __init__(self, table: MultiHashTable, batch_per_table: int, exact_order: bool = False):
+    self.table = table
+    self.batch = int(batch_per_table)
+    self.exact_order = exact_order
+    self._lib = table._lib  # pylint: disable=protected-access
+    self._dims = table.get_table_dim_sizes()
+    h = _lib.C.c_void_p()
+    _lib.check(self._lib.mhte_multi_step_create(table.handle, _lib.C.c_int64(self.batch),
+                                                _lib.C.byref(h)))
+    self._h = h
+    self._ahead = None   # (values tensor, its _version, row_splits bytes) deduplicated ahead
+    self._keep = None    # arguments of the launches in flight
+
+  def close(self):
+    if getattr(self, "_h", None):
+      torch.cuda.synchronize()
+      self._lib.mhte_multi_step_destroy(self._h)
+      self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  @staticmethod
+  def _key(r):
+    return (r.values, r.values._version, r.row_splits.tobytes())  # pylint: disable=protected-access
+
+  def _stream(self):
+    return _lib.C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+  def forward(self, ragged, next_ragged=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    C = _lib.C
+    lens = ragged.row_lengths()
+    total = int(sum(int(l) * d for l, d in zip(lens, self._dims)))
+    if out is None:
+      out = torch.empty(total, dtype=torch.float32, device=ragged.values.device)
+    a = self._ahead
+    pre = (a is not None and a[0] is ragged.values and a[1] == ragged.values._version and  # pylint: disable=protected-access
+           a[2] == ragged.row_splits.tobytes())
+    sp = np.ascontiguousarray(ragged.row_splits, dtype=np.int64)
+    if next_ragged is not None:
+      nsp = np.ascontiguousarray(next_ragged.row_splits, dtype=np.int64)
+      nv, nsp_p, nsp_n = _lib.vp(next_ragged.values), nsp.ctypes.data_as(C.POINTER(C.c_int64)), nsp.size
+    else:
+      nsp = None
+      nv, nsp_p, nsp_n = C.c_void_p(0), None, 0
+    _lib.check(self._lib.mhte_multi_step_forward(
+        self._h, _lib.vp(ragged.values), sp.ctypes.data_as(C.POINTER(C.c_int64)), C.c_int64(sp.size),
+        _lib.vp(out), C.c_int64(out.numel()), nv, nsp_p, C.c_int64(nsp_n),
+        C.c_int32(1 if pre else 0), self._stream()))
+    self._ahead = self._key(next_ragged) if next_ragged is not None else None
+    self._keep = (ragged, next_ragged, out)
+    return out
+
+  def backward(self, flat_grad: torch.Tensor, update_time: int, global_step: int = 0):
+    C = _lib.C
+    lrs = np.ascontiguousarray(self.table.learning_rate, dtype=np.float32)
+    self.table.maybe_evict()
+    _lib.check(self._lib.mhte_multi_step_backward(
+        self._h, _lib.vp(flat_grad), C.c_int64(flat_grad.numel()),
+        lrs.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(lrs.size), C.c_int64(int(update_time)),
+        C.c_int64(int(global_step)), C.c_int32(_lib.MHTE_EXACT_ORDER if self.exact_order else 0),
+        self._stream()))
+
+  def unique_counts(self) -> np.ndarray:
+    """Distinct ids per table of the batch last given to ``forward`` (synchronises)."""
+    out = np.zeros(len(self._dims), dtype=np.int64)
+    _lib.check(self._lib.mhte_multi_step_unique_counts(
+        self._h, out.ctypes.data_as(_lib.C.POINTER(_lib.C.c_int64)), self._stream()))
+    return out
