@@ -39,6 +39,18 @@ def parse():
   p.add_argument("--resident-rows", type=float, default=float(1 << 27),
                  help="rows pre-inserted per GPU (the hottest ranks of this GPU's shard)")
   p.add_argument("--opt", default="adagrad", choices=["adagrad", "sgd"])
+  p.add_argument("--config", default="configs2", choices=["configs2", "dlrm26"],
+                 help="configs2 (default, the bench line): BASELINE.json configs[2]/[1] single table; "
+                      "dlrm26: configs[4]'s shape on one GPU — 26 feature tables of dims 16/32/64, "
+                      "batch ids per table and step, online insert + TTL eviction scans, all tables in "
+                      "one launch pair per step (a measurement kept under profiles/, not the bench line)")
+  p.add_argument("--tables", type=int, default=26, help="dlrm26: number of feature tables")
+  p.add_argument("--evict-every", type=int, default=100,
+                 help="dlrm26: TTL eviction scan of every table each N steps (0: never)")
+  p.add_argument("--grad-pool", type=int, default=17,
+                 help="gradient buffers rotated by the timed loop (17 x 16.8 MB > the 256 MiB "
+                      "Infinity Cache: gradients are read from HBM, not from the LLC)")
+  p.add_argument("--no-parity-check", action="store_true")
   p.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"])
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--cpu-steps", type=int, default=150)
@@ -88,8 +100,263 @@ def pmc_traffic(kernel):
     return None, None
 
 
+def oracle_subset_rows(probe, D, opt, lr, applied, ids_of, grads_of):
+  """Rows of the `probe` ids after the update sequence `applied` = [(batch, grad buffer, time)],
+  by the CPU oracle restricted to those ids (a row depends on its own id's gradient history only):
+  per step first-occurrence dedup, duplicate gradients added in occurrence order, one optimizer
+  step — the reference's sequence (unique_mapping_ops.cc:284-329 + multi_hash_table_update_op.cc
+  :47-100).  The checker of `parity_check`, never the thing measured."""
+  import oracle as O
+  seg = O.segment(D, O.OPT_ADAGRAD if opt == "adagrad" else O.OPT_SGD, p=(0.1, 0.0))
+  ot = O.Table(seg, 1)
+  ps = np.sort(probe)
+  for (b, g, t) in applied:
+    ids = ids_of(b)
+    m = np.isin(ids, ps)
+    sub = ids[m]
+    if not sub.size:
+      continue
+    gr = grads_of(g)[m]
+    uk, _, vo, vos, _ = O.unique_key_with_value_and_offset(sub, [0, sub.size], [D])
+    gu = O.fill_with_offset_map_gradient(np.arange(uk.size), [0, uk.size], gr.ravel(), vo, vos,
+                                         [D]).reshape(-1, D)
+    ot.optimize(uk, gu, [lr], t)
+  return ot.lookup(probe)[0]
+
+
+def parity_numbers(got, exp):
+  diff = np.abs(got.astype(np.float64) - exp.astype(np.float64))
+  den = np.maximum(np.abs(exp.astype(np.float64)), 1e-30)
+  big = np.abs(exp) > 1e-6
+  return {"n": int(got.shape[0]), "max_abs": float(diff.max()) if diff.size else 0.0,
+          "max_rel": float((diff[big] / den[big]).max()) if big.any() else 0.0,
+          "rows_bit_exact": int((got == exp).all(axis=1).sum()),
+          "rel_floor": 1e-6}
+
+
+def main_dlrm(args):
+  """BASELINE.json configs[4]'s shape on ONE MI355X (the 8-GPU sharding of it is the driver's
+  --gpus run of the default config): T feature tables of dims 16 / 32 / 64 (fused Adagrad), B
+  Zipf(1.2) ids per table and step, ids inserted online, a TTL eviction scan of every table each
+  --evict-every steps — lookups and updates of ALL tables in one launch pair per step
+  (mhte_multi_step_forward / _backward)."""
+  import torch
+  assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+  torch.cuda.set_device(0)
+  dev = torch.device("cuda", 0)
+  from monolith_amd import _lib, entry, synthetic as S
+  from monolith_amd.fused_step import MultiSparseStep
+  from monolith_amd.multi_hash_table_ops import MultiHashTable, Ragged
+
+  T, B = args.tables, args.batch
+  K, W = args.steps, args.warmup
+  V = int(args.universe) // T                      # ids per feature
+  resident = min(int(args.resident_rows) // T, V)  # prefilled rows per table
+  dims = [(16, 32, 64)[i % 3] for i in range(T)]
+  names = ["f%02d" % (i + 1) for i in range(T)]    # sorted order == slot order
+  reps = min(K, 50)
+  n_steps = W + K + reps + 4
+  lr = 0.001
+  configs = {}
+  for i, n in enumerate(names):
+    rows_cap = resident + n_steps * 24000 + (1 << 16)   # ~13 k distinct ids per batch, < 40 % new
+    slots = 4
+    while slots * 0.5 < rows_cap:
+      slots *= 2
+    configs[n] = entry.make_table_config(
+        [entry.CombineAsSegment(dims[i], entry.ZerosInitializer(), entry.AdagradOptimizer(lr, 0.1))],
+        entry.CuckooHashTableConfig(initial_capacity=slots, reserve_rows=rows_cap))
+  mt = MultiHashTable.from_configs(configs, name_suffix="dlrm")
+  splits0 = np.zeros(T + 1, dtype=np.int64)
+
+  # ---- prefill: the `resident` hottest ranks of every feature, rows = initializer ----
+  t0 = time.time()
+  mult = torch.tensor(0x9E3779B97F4A7C15 - (1 << 64), dtype=torch.int64, device=dev)
+  chunk = 1 << 21
+  for i, n in enumerate(names):
+    zeros = torch.zeros((chunk, dims[i]), dtype=torch.float32, device=dev)
+    for r0 in range(1, resident + 1, chunk):
+      m = min(chunk, resident + 1 - r0)
+      ranks = torch.arange(r0, r0 + m, dtype=torch.int64, device=dev)
+      fid = ((ranks * mult) & ((1 << 48) - 1)) | ((i + 1) << 48)
+      sp = splits0.copy()
+      sp[i + 1:] = m
+      _lib.check(mt._lib.mhte_assign(mt.handle, _lib.vp(fid), sp.ctypes.data_as(_lib.C.POINTER(_lib.C.c_int64)),
+                                     _lib.C.c_int64(T + 1), _lib.vp(zeros), _lib.C.c_int64(m * dims[i]),
+                                     _lib.C.c_int64(S.update_time(0)), _lib.C.c_int32(_lib.MHTE_IDS_UNIQUE), None))
+    torch.cuda.synchronize()
+    del zeros
+  torch.cuda.empty_cache()
+  prefill_s = time.time() - t0
+  size0 = [mt.size(n) for n in names]
+
+  # ---- inputs resident in HBM: one ragged batch per step (tables in slot order), two gradient
+  # buffers of sum(B * dim) floats each (2 x 247 MB at 26 tables: beyond the 256 MiB LLC)
+  splits = np.arange(T + 1, dtype=np.int64) * B
+  ids_host = np.empty((n_steps + 1, T * B), dtype=np.int64)
+  for s in range(n_steps + 1):
+    for i in range(T):
+      ids_host[s, i * B:(i + 1) * B] = S.id_batch(s * 64 + i + 1, B, V, "zipf", feature_slot=i + 1)
+  ids_all = torch.from_numpy(ids_host).to(dev)
+  rag = [Ragged(ids_all[s], splits) for s in range(n_steps + 1)]
+  gsz = B * sum(dims)
+  goff = np.concatenate([[0], np.cumsum([B * d for d in dims])])
+
+  def grad_host(g):
+    rng = np.random.Generator(np.random.PCG64(S.SEED0 + 10**9 + g))
+    return rng.standard_normal(gsz, dtype=np.float32) * np.float32(0.01)
+
+  NG = 2
+  grad_pool = [torch.from_numpy(grad_host(g)).to(dev) for g in range(NG)]
+  out = torch.empty(gsz, dtype=torch.float32, device=dev)
+  step = MultiSparseStep(mt, B, exact_order=args.exact_order)
+  applied = []
+  evictions = [0]
+
+  def run(lo, hi):
+    for s in range(lo, hi):
+      step.forward(rag[s], rag[s + 1], out=out)
+      step.backward(grad_pool[s % NG], S.update_time(s))
+      applied.append((s, s % NG, S.update_time(s)))
+      if args.evict_every and (s + 1) % args.evict_every == 0:
+        for n in names:
+          mt.evict(n)
+        evictions[0] += 1
+
+  run(0, W)
+  torch.cuda.synchronize()
+  evictions[0] = 0
+  t = time.perf_counter()
+  run(W, W + K)
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t
+
+  # ---- per-kernel timing: HIP events with the kernels' own begin/end (mhte_profile_arm) ----
+  acc, uniq = {}, []
+  _lib.profile_arm(2 * reps)
+  for s in range(W + K, W + K + reps):
+    step.forward(rag[s], rag[s + 1], out=out)
+    if s % 10 == 0:
+      uniq.append(step.unique_counts())
+    step.backward(grad_pool[s % NG], S.update_time(s))
+    applied.append((s, s % NG, S.update_time(s)))
+  torch.cuda.synchronize()
+  for name, us in _lib.profile_read():
+    a = acc.setdefault(name, [0, 0.0])
+    a[0] += 1
+    a[1] += us
+  U = np.mean(np.stack(uniq), axis=0)              # distinct ids per table and batch
+  alg_fwd = alg_bwd = 0
+  for i in range(T):
+    _, pk = algorithmic_bytes(B, float(U[i]), dims[i], dims[i])
+    alg_fwd += pk["lookup_kernel"]
+    alg_bwd += pk["sum_apply_kernel"]
+  alg = {"mstep_fwd_kernel": alg_fwd, "mstep_bwd_kernel": alg_bwd}
+  stages = {}
+  for name, (cnt, tot) in sorted(acc.items()):
+    stages[name] = {"avg_us": round(tot / cnt, 2), "launches_per_step": round(cnt / reps, 2)}
+    if name in alg:
+      stages[name]["alg_bytes"] = int(alg[name])
+      stages[name]["GBps"] = round(alg[name] / (tot / cnt) / 1e3, 1)
+  dom = max((k for k in stages if k in alg), key=lambda k: stages[k]["avg_us"])
+  a_gbps = alg[dom] / stages[dom]["avg_us"] / 1e3
+  step_bytes = alg_fwd + alg_bwd
+  roofline = {"bound": "hbm", "kernel": dom, "achieved": round(a_gbps, 1), "peak": HBM_PEAK_GBPS,
+              "unit": "GB/s", "frac": round(a_gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+              "alg_bytes_per_launch": int(alg[dom]), "avg_launch_us": stages[dom]["avg_us"],
+              "timing": "hipExtLaunchKernelGGL start/stop events on the launch stream, %d launches" % reps,
+              "step_alg_bytes": int(step_bytes),
+              "step_GBps": round(step_bytes / (elapsed / K) / 1e9, 1),
+              "step_frac": round(step_bytes / (elapsed / K) / 1e9 / HBM_PEAK_GBPS, 4)}
+
+  # ---- parity of the benched state against the oracle's replay, three tables (one per dim) ----
+  parity = None
+  if not args.no_parity_check:
+    try:
+      t0p = time.time()
+      parity = {}
+      last = applied[-1][0]
+      gcache = {}
+
+      def grads_flat(g):
+        if g not in gcache:
+          gcache[g] = grad_host(g)
+        return gcache[g]
+
+      for i in (0, 1, 2):
+        sl = slice(i * B, (i + 1) * B)
+        probe = np.unique(ids_host[last, sl])
+        exp = oracle_subset_rows(
+            probe, dims[i], "adagrad", lr, applied, lambda b, sl=sl: ids_host[b, sl],
+            lambda g, i=i: grads_flat(g)[goff[i]:goff[i + 1]].reshape(B, dims[i]))
+        got = mt.lookup({names[i]: torch.from_numpy(probe).to(dev)})[names[i]].cpu().numpy()
+        parity[names[i]] = parity_numbers(got, exp)
+      parity["updates_replayed"] = len(applied)
+      parity["seconds"] = round(time.time() - t0p, 1)
+    except Exception as e:  # pylint: disable=broad-except
+      parity = {"failed": repr(e)[:300]}
+
+  # ---- CPU baseline: the reference map + AVX Adagrad (oracle/_ref), one table per dim class ----
+  cpu = None
+  if not args.no_cpu_baseline:
+    try:
+      import oracle as O
+      cores = os.cpu_count() or 1
+      avx = O.ref_available(True)
+      per_dim = {}
+      for d in (16, 32, 64):
+        i = dims.index(d)
+        ps = O.RefPs(cores, d, O.OPT_ADAGRAD, 0.1, 0.0, 0.0, 1, avx=avx)
+        gh = grad_host(0)[goff[i]:goff[i + 1]].reshape(B, d)
+        times = []
+        for s in range(5 + 30):
+          tt = time.perf_counter()
+          ps.step(ids_host[s, i * B:(i + 1) * B], gh, lr, S.update_time(s), want_emb=True)
+          times.append(time.perf_counter() - tt)
+        per_dim[d] = float(np.median(times[5:]))
+      t_step = sum(per_dim[d] for d in dims)
+      cpu = {"value": round(2 * B * T / t_step, 1), "unit": "lookups+updates/s", "cores": cores,
+             "kind": "reference",
+             "sample": "30 steps (after 5) of one table per dim class (16/32/64: %.2f / %.2f / %.2f ms "
+                       "median), tables grown from empty, summed over the %d tables as the reference's "
+                       "loop over tables would run them; PS-style %d single-threaded shards of the "
+                       "reference cuckoohash_map + %s Adagrad" %
+                       (per_dim[16] * 1e3, per_dim[32] * 1e3, per_dim[64] * 1e3, T, cores,
+                        "AVX2" if avx else "scalar")}
+    except Exception as e:  # pylint: disable=broad-except
+      cpu = {"value": None, "unit": "lookups+updates/s", "cores": os.cpu_count(), "kind": "reference",
+             "sample": "failed: %r" % (e,)}
+
+  size1 = [mt.size(n) for n in names]
+  value = 2.0 * B * T * K / elapsed
+  out_json = {
+      "metric": "embedding lookups+updates/sec, %d-feature multi-table step, Zipf(1.2) batch=%d per feature" % (T, B),
+      "value": round(value, 1), "unit": "lookups+updates/s", "n_gpus": 1, "steps": K, "warmup": W,
+      "ms_per_step": round(elapsed / K * 1e3, 5), "steps_per_sec": round(K / elapsed, 1),
+      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+      "data": "synthetic",
+      "config": {
+          "workload": "configs[4] shape on 1 MI355X: %d feature tables, dims 16/32/64, fused Adagrad, "
+                      "Zipf(1.2) over %d ids per feature, batch %d ids per feature and step, online "
+                      "insert, TTL eviction scan every %d steps; sparse path only (no dense model)" %
+                      (T, V, B, args.evict_every),
+          "tables": T, "dims": dims, "batch_per_table": B, "universe_per_table": V,
+          "resident_rows_start": int(sum(size0)), "resident_rows_end": int(sum(size1)),
+          "unique_ids_per_batch_mean": float(U.mean()), "eviction_scans_in_timed_region": evictions[0],
+          "gradient_bytes_rotated": int(NG * gsz * 4), "prefill_s": round(prefill_s, 2),
+          "launch": "eager",
+      },
+      "roofline": roofline, "stages": stages, "cpu_baseline": cpu, "parity_check": parity,
+  }
+  if cpu and cpu.get("value"):
+    out_json["vs_cpu_baseline"] = round(value / cpu["value"], 2)
+  print(json.dumps(out_json))
+
+
 def main():
   args = parse()
+  if args.config == "dlrm26":
+    return main_dlrm(args)
   import torch
   import torch.distributed as dist
   world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -177,7 +444,10 @@ def main():
   n_batches = (2 * (W + K) + 2 * reps + 8) if not sharded else (K + W + 1)
   ids_host = np.stack([S.id_batch(s * world + rank, B, V, "zipf") for s in range(n_batches)])
   ids_all = torch.from_numpy(ids_host).to(dev)
-  grad_pool = [torch.from_numpy(S.grad_batch(s, B, D)).to(dev) for s in range(8)]
+  NG = max(1, args.grad_pool)
+  grad_pool = [torch.from_numpy(S.grad_batch(s, B, D)).to(dev) for s in range(NG)]
+  applied = []        # (batch, gradient buffer, update_time) of every update enqueued, in order
+  applied_ok = True
 
   def barrier():
     torch.cuda.synchronize()
@@ -200,7 +470,8 @@ def main():
     def run_eager(lo, hi):
       for s in range(lo, hi):
         step.forward(ids_all[s], next_ids=ids_all[s + 1])
-        step.backward(grad_pool[s % 8], S.update_time(s))
+        step.backward(grad_pool[s % NG], S.update_time(s))
+        applied.append((s, s % NG, S.update_time(s)))
 
     def timed(name, c, w, k):
       run_eager(c, c + w)
@@ -246,6 +517,7 @@ def main():
         steps_of["graph"] = K
       except Exception as e:  # pylint: disable=broad-except
         graph_err = repr(e)[:300]
+        applied_ok = False   # (the aborted capture logged updates that never ran)
         print("graph path failed: %s" % graph_err, file=sys.stderr)
         torch.cuda.synchronize()
         # the aborted capture advanced the host-side pipeline state without executing anything:
@@ -261,7 +533,8 @@ def main():
     def run_sharded(lo, hi):
       for s in range(lo, hi):
         se.lookup(ids_all[s], next_ids=ids_all[s + 1])
-        se.apply_gradients(grad_pool[s % 8], S.update_time(s))
+        se.apply_gradients(grad_pool[s % NG], S.update_time(s))
+        applied.append((s, s % NG, S.update_time(s)))
 
     run_sharded(0, W)
     barrier()
@@ -321,10 +594,11 @@ def main():
       _lib.profile_arm(8)
       step._unique(ids)  # pylint: disable=protected-access
       mt.table_lookup_n(step.idx, ids, None, step.emb, n_max=B)
-      mt.table_sum_optimize_n(step.idx, step.ws, step.u, grad_pool[s % 8], step.grad_u, step.lrs,
+      mt.table_sum_optimize_n(step.idx, step.ws, step.u, grad_pool[s % NG], step.grad_u, step.lrs,
                               S.update_time(s), 0, exact_order=args.exact_order, n_max=B,
                               defer_slowpath=True)
       mt.table_finish_pending(step.idx)
+      applied.append((s, s % NG, S.update_time(s)))
       collect()
       us.append(step.n_unique())
     uniq_avg = float(np.mean(us))
@@ -356,6 +630,34 @@ def main():
                 "step_frac": round(step_bytes / (elapsed / K) / 1e9 / HBM_PEAK_GBPS, 4)}
 
   st1 = mt.stats("emb")
+
+  # ---- parity of the benched state: the rows of >= 10 000 ids of the timed stream, read back
+  # after everything above, against the oracle's replay of the same update sequence
+  parity = None
+  if not sharded and rank == 0 and not args.no_parity_check:
+    if not applied_ok:
+      parity = {"skipped": "update log invalid after a failed graph capture"}
+    else:
+      try:
+        last = applied[-1][0]
+        probe = np.unique(np.concatenate([ids_host[last], ids_host[W + K // 2]]))
+        lr = 0.001 if args.opt == "adagrad" else 0.01
+        t0p = time.time()
+        gcache = {}
+
+        def grads_of(g):
+          if g not in gcache:
+            gcache[g] = S.grad_batch(g, B, D)
+          return gcache[g]
+
+        exp = oracle_subset_rows(probe, D, args.opt, lr, applied, lambda b: ids_host[b], grads_of)
+        got = mt.lookup({"emb": torch.from_numpy(probe).to(dev)})["emb"].cpu().numpy()
+        parity = parity_numbers(got, exp)
+        parity.update({"updates_replayed": len(applied), "seconds": round(time.time() - t0p, 1),
+                       "exact_order": bool(args.exact_order),
+                       "checker": "oracle/ restricted to the probe ids (sequential sums)"})
+      except Exception as e:  # pylint: disable=broad-except
+        parity = {"failed": repr(e)[:300]}
 
   # ---- CPU baseline: the reference's own map + AVX Adagrad on this box's host cores ----
   cpu = None
@@ -422,6 +724,7 @@ def main():
         "roofline": roofline,
         "stages": stages,
         "cpu_baseline": cpu,
+        "parity_check": parity,
     }
     if cpu and cpu.get("value"):
       out["vs_cpu_baseline"] = round(value / cpu["value"], 2)

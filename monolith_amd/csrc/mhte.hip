@@ -530,6 +530,10 @@ struct Table {
 
   // bumped whenever `view` (or count_hits) changes: holders of device copies re-upload
   uint64_t view_version = 0;
+  // bumped by everything that may insert, move, or delete a bucket entry (updates, displacement,
+  // eviction, doubling, restore): a (row handle, bucket slot) resolved before stays valid only
+  // while this stands still (the multi-table step's forward -> backward hints)
+  uint64_t mut_epoch = 1;
   void refresh_view() {
     ++view_version;
     view.buckets = buckets;
@@ -565,6 +569,7 @@ struct Table {
   }
 
   void double_table(hipStream_t st) {
+    ++mut_epoch;
     if (hp >= 34) throw Error(MHTE_RESOURCE_EXHAUSTED, "table " + name + ": hashpower limit");
     Bucket* nb = nullptr;
     const uint64_t n_old = uint64_t(1) << hp;
@@ -615,6 +620,7 @@ struct Table {
         buckets = nullptr;
         alloc_buckets(want, &buckets, st);
         hp = want;
+        ++mut_epoch;
         refresh_view();
       }
     }
@@ -670,6 +676,7 @@ struct Table {
                      const uint32_t* seg_off, const uint32_t* seg_pos, const ApplyArgs& a,
                      int32_t* status, hipStream_t st) {
     Shape sh = pick_shape(dim, vec_ok && (values == nullptr || aligned16(values)));
+    ++mut_epoch;
     pending.reserve(size_t(n) + 1);
     uint32_t* skp = nullptr;
     if (flt_slots && a.filter_mode && seg_off) {
@@ -755,6 +762,7 @@ struct Table {
     a.sum_dups = 1;
     a.filter_mode = 1;
     a.global_step = 0;  // (the fused kernels take SGD / Adagrad / FTRL only)
+    ++mut_epoch;
     ensure_capacity(uint64_t(n_max), st);
     Shape sh = pick_shape(dim, vec_ok && aligned16(grads) && aligned16(grad_u));
     pending.reserve(size_t(n_max) + 1);
@@ -866,6 +874,7 @@ struct Table {
     a.sum_dups = 1;
     a.filter_mode = 1;
     a.global_step = 0;  // (the fused kernels take SGD / Adagrad / FTRL only)
+    ++mut_epoch;
     const bool prealloc = ws.r_prealloc;  // (rows reserved — and room ensured — by step_forward)
     ws.r_prealloc = false;
     if (!prealloc) ensure_capacity(uint64_t(std::min<int64_t>(n_max, n)), st);
@@ -947,6 +956,7 @@ struct Table {
   void finish_pending(hipStream_t st) {
     if (!pend_valid) return;
     pend_valid = false;
+    ++mut_epoch;
     if (pend_vec == 4) {
       LAUNCH_HOT(kTagSlowpath, (slowpath_kernel<4, kOpOptimize>), 1, 64, st, view, pend_uids,
                  pend_grad, nullptr, nullptr, pend_args, nullptr, pending.p, nullptr);
@@ -964,6 +974,7 @@ struct Table {
 
   void evict(int64_t max_ts, hipStream_t st) {
     finish_pending(st);
+    ++mut_epoch;
     TtlConfig ttl;
     ttl.default_days = default_expire_days;
     ttl.n = int32_t(expire_slots.size());
@@ -1772,6 +1783,7 @@ static void restore_batch(Table& tb, const std::vector<int64_t>& ids, const std:
   const int64_t n = int64_t(ids.size());
   if (n == 0) return;
   tb.finish_pending(st);
+  ++tb.mut_epoch;
   tb.ensure_capacity(uint64_t(n), st);
   DevBuf<int64_t> d_ids;
   DevBuf<uint32_t> d_ts;

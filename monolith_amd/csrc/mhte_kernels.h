@@ -67,7 +67,9 @@ struct WaveTrace {
   __device__ __forceinline__ WaveTrace(unsigned long long* trace) : rec(nullptr), t0(0) {
     if (trace) {
       const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-      rec = trace + uint64_t(kTraceWords) * (uint64_t(blockIdx.x) * (blockDim.x >> 6) + wave);
+      // (multi-table launches: blockIdx.y = table; 0 elsewhere)
+      rec = trace + uint64_t(kTraceWords) *
+                        ((uint64_t(blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave);
       t0 = wall_clock64();
     }
   }

@@ -67,13 +67,22 @@ struct MultiStep {
   std::vector<uint32_t> n_slot[2];      // per table: batch size held by the slot
   int num_cus = 256;
   uint32_t ovs = 4;                     // workgroups launched per resident slot (T > 1)
-  uint32_t lookup_cap = 0;              // lookup workgroups per table (0: one trip each)
+  uint32_t scatter_ovs = 2;             // lookup workgroups launched per resident slot
+  uint32_t item_target = 4 * kItemTarget;  // expected occurrences per heavy work item: bigger than
+                                        // the single-table step's, whose items are its longest
+                                        // chain; here the fixed round trips per item are what costs
+  std::vector<uint64_t> fwd_epoch[2];   // Table::mut_epoch when the slot's batch was looked up
+  bool has_hints[2] = {false, false};   // the slot's urow / uloc were written by a forward launch
 
   ~MultiStep() {
     (void)hipSetDevice(device);
     (void)hipDeviceSynchronize();
     if (arena) (void)hipFree(arena);
     if (d_st) (void)hipFree(d_st);
+    if (side) (void)hipStreamDestroy(side);
+    if (ev_now) (void)hipEventDestroy(ev_now);
+    for (int i = 0; i < 2; ++i)
+      if (ev_dedup[i]) (void)hipEventDestroy(ev_dedup[i]);
   }
 
   static uint32_t scratch_cap(int64_t n) {
@@ -107,12 +116,14 @@ struct MultiStep {
       d.ids = nullptr;
       d.n = 0;
       d.nblk = 0;
-      d.item_target = DedupWs::item_target();
+      d.item_target = item_target;
       d.uids = A.take<int64_t>(size_t(n) + 1);
       d.n_unique = A.take<uint32_t>(4);
       s.rv[sl] = d;
       s.part[sl] = A.take<float>(size_t(items) * tb.dim + 16);
       s.arrive[sl] = A.take<uint32_t>(size_t(n) + 2);
+      s.urow[sl] = A.take<uint32_t>(size_t(n) + 2);
+      s.uloc[sl] = A.take<unsigned long long>(size_t(n) + 2);
     }
     s.grad_u = A.take<float>(size_t(n) * tb.dim + 16);
     s.pending = A.take<uint32_t>(size_t(n) + 2);
@@ -144,7 +155,8 @@ struct MultiStep {
         num_cus = cus;
     }
     if (const char* e = getenv("MHTE_MSTEP_OVERSUB")) ovs = std::max(1, atoi(e));
-    if (const char* e = getenv("MHTE_MSTEP_LOOKUP_WGS")) lookup_cap = std::max(0, atoi(e));
+    if (const char* e = getenv("MHTE_MSTEP_SCATTER_OVS")) scatter_ovs = std::max(1, atoi(e));
+    if (const char* e = getenv("MHTE_MSTEP_ITEM_TARGET")) item_target = std::max<int>(int(kItemTarget), atoi(e));
     h_st.assign(T, MStepStatic{});
     Arena sizing;
     for (uint32_t t = 0; t < T; ++t) layout(sizing, t, h_st[t]);
@@ -160,7 +172,10 @@ struct MultiStep {
     for (uint32_t t = 0; t < T; ++t) st_version[t] = m->tables[t]->view_version;
     n_slot[0].assign(T, 0);
     n_slot[1].assign(T, 0);
+    fwd_epoch[0].assign(T, 0);
+    fwd_epoch[1].assign(T, 0);
     clear_slots(3u, nullptr);
+    make_streams();
     HIP_OK(hipDeviceSynchronize());
   }
 
@@ -202,45 +217,73 @@ struct MultiStep {
       throw Error(MHTE_INVALID_ARGUMENT, "multi step: more than 2^32 ids");
   }
 
-  // one forward launch per chunk of kMaxStepTables tables: lookups of (ids, split) when `out`,
-  // run dedup of (ids_next, split_next) into slot `slot_next` when ids_next
-  void launch_fwd(const int64_t* ids, const int64_t* split, float* out, const int64_t* ids_next,
-                  const int64_t* split_next, int slot_next, hipStream_t st) {
+  static constexpr int kFwdBlock = 256;   // threads per workgroup of the lookup launch
+
+  // lookup of the batch held (numbered) by `slot` into `out`: one launch per chunk of
+  // kMaxStepTables tables
+  void launch_fwd(float* out, int slot, hipStream_t st) {
     int64_t emb_off = 0;
+    uint32_t active = 0;
+    for (uint32_t t = 0; t < T; ++t) active += n_slot[slot][t] ? 1u : 0u;
     for (uint32_t t0 = 0; t0 < T; t0 += kMaxStepTables) {
       const uint32_t tc = std::min<uint32_t>(kMaxStepTables, T - t0);
       MFwdArgs A{};
       A.views = ConstViews(mt->d_views.p + t0);
       A.st = ConstStatics(d_st + t0);
-      A.ids = ids ? ids + split[0] : nullptr;
-      A.ids_next = ids_next ? ids_next + split_next[0] : nullptr;
       A.out = out;
-      A.cur = uint32_t(slot_next ^ 1);
-      uint32_t max_d = 0, max_l = 0;
+      A.cur = uint32_t(slot);
+      A.item_split = std::max<uint32_t>(1, item_target / kItemTarget);
+      uint32_t gx = 0;
       for (uint32_t k = 0; k < tc; ++k) {
         const uint32_t t = t0 + k;
         MFwdTab& ft = A.tab[k];
         const Table& tb = *mt->tables[t];
-        if (ids && out) {
-          ft.id_off = uint32_t(split[t] - split[0]);
-          ft.n = uint32_t(split[t + 1] - split[t]);
-          if (uint64_t(emb_off) > 0xffffffffull)
-            throw Error(MHTE_INVALID_ARGUMENT, "multi step: embedding buffer exceeds 2^32 floats");
-          ft.emb_off = uint32_t(emb_off);
-          emb_off += int64_t(ft.n) * tb.dim;
-          const uint32_t groups = (ft.n + 1) / 2;
-          max_l = std::max(max_l, uint32_t((uint64_t(groups) * h_st[t].g + kRdBlock - 1) / kRdBlock));
-        }
-        if (ids_next) {
-          ft.next_off = uint32_t(split_next[t] - split_next[0]);
-          ft.n_next = uint32_t(split_next[t + 1] - split_next[t]);
-          max_d = std::max(max_d, (ft.n_next + kRdBlock - 1) / kRdBlock);
+        ft.n = n_slot[slot][t];
+        if (uint64_t(emb_off) > 0xffffffffull)
+          throw Error(MHTE_INVALID_ARGUMENT, "multi step: embedding buffer exceeds 2^32 floats");
+        ft.emb_off = uint32_t(emb_off);
+        emb_off += int64_t(ft.n) * tb.dim;
+        if (ft.n) {
+          // persistent workgroups: the launch's share of the resident slots (8 per CU) times the
+          // oversubscription, split evenly over the tables; enough for one trip at most
+          const uint32_t groups_per_wg = uint32_t(kFwdBlock) / h_st[t].g;
+          const uint32_t one_trip = (ft.n + groups_per_wg - 1) / groups_per_wg;
+          const uint32_t share = std::max<uint32_t>(8, uint32_t(8 * num_cus) * scatter_ovs / std::max(1u, active));
+          ft.nblk_s = std::max<uint32_t>(1, std::min(one_trip, share));
+          gx = std::max(gx, ft.nblk_s);
         }
       }
-      if (lookup_cap && max_l > lookup_cap) max_l = lookup_cap;
-      if (max_d + max_l == 0) continue;
-      const dim3 grid(max_d + max_l, tc);
-      LAUNCH_HOT(kTagMStepFwd, (mstep_fwd_kernel<2>), grid, kRdBlock, st, A);
+      if (gx == 0) continue;
+      const dim3 grid(gx, tc);
+      A.trace = trace_region(kTagMStepFwd, grid.x * grid.y, kFwdBlock);
+      LAUNCH_HOT(kTagMStepFwd, (mstep_fwd_kernel<kFwdBlock>), grid, kFwdBlock, st, A);
+      HIP_OK(hipGetLastError());
+    }
+  }
+
+  // run dedup of the ragged batch (ids, split) into `slot`; max_wgs: persistent workgroups per
+  // launch (0: one per item)
+  void launch_dedup(const int64_t* ids, const int64_t* split, int slot, uint32_t max_wgs, hipStream_t st) {
+    for (uint32_t t0 = 0; t0 < T; t0 += kMaxStepTables) {
+      const uint32_t tc = std::min<uint32_t>(kMaxStepTables, T - t0);
+      MDedupArgs A{};
+      A.st = ConstStatics(d_st + t0);
+      A.ids = ids + split[t0];
+      A.slot = uint32_t(slot);
+      A.T = tc;
+      uint32_t blocks = 0;
+      for (uint32_t k = 0; k < tc; ++k) {
+        const uint32_t t = t0 + k;
+        A.id_off[k] = uint32_t(split[t] - split[t0]);
+        A.blk_start[k] = blocks;
+        blocks += uint32_t((split[t + 1] - split[t] + kRdBlock - 1) / kRdBlock);
+      }
+      A.id_off[tc] = uint32_t(split[t0 + tc] - split[t0]);
+      A.blk_start[tc] = blocks;
+      if (!blocks) continue;
+      const uint32_t grid = max_wgs ? std::min(blocks, max_wgs) : blocks;
+      A.trace = trace_region(kTagDedup, grid, kRdBlock);
+      LAUNCH_HOT(kTagDedup, mstep_dedup_kernel, grid, kRdBlock, st, A);
       HIP_OK(hipGetLastError());
     }
   }
@@ -278,6 +321,8 @@ struct MultiStep {
         const Table& tb = *mt->tables[t];
         const uint32_t n = p.grads ? n_slot[slot_cur][t] : 0u;
         bt.build_next = (build_next && n_slot[slot_cur ^ 1][t]) ? 1u : 0u;
+        bt.n = n;
+        bt.n_next = n_slot[slot_cur ^ 1][t];
         uint32_t blocks = bt.build_next ? h_st[t].nblk_build : 0u;
         if (n) {
           bt.apply = 1;
@@ -291,6 +336,7 @@ struct MultiStep {
           bt.a.filter_mode = 1;
           bt.a.global_step = 0;
           bt.light_max = p.exact_order ? 0xffffffffu : uint32_t(kStepLightMax);
+          bt.hints = (has_hints[slot_cur] && fwd_epoch[slot_cur][t] == tb.mut_epoch) ? 1u : 0u;
           const uint32_t groups_per_wg = 256u / h_st[t].g;
           const uint32_t cap_items = DedupWs::max_items(n);
           bt.nblk_items = p.exact_order ? 0u
@@ -307,11 +353,14 @@ struct MultiStep {
         gx = std::max(gx, blocks);
       }
       if (gx == 0) continue;
+      A.trace = trace_region(kTagMStepBwd, gx * tc, 256);
       LAUNCH_HOT(kTagMStepBwd, mstep_bwd_kernel, dim3(gx, tc), 256, st, A);
       HIP_OK(hipGetLastError());
       if (any_apply) {
         mstep_slow_kernel<<<tc, 64, 0, st>>>(A);
         HIP_OK(hipGetLastError());
+        for (uint32_t k = 0; k < tc; ++k)
+          if (A.tab[k].apply) ++mt->tables[t0 + k]->mut_epoch;
       }
     }
   }
@@ -320,10 +369,36 @@ struct MultiStep {
   void dedup_now(const int64_t* ids, const int64_t* split, int slot, hipStream_t st) {
     if (stage[slot] == 1) clear_slots(1u << slot, st);
     for (uint32_t t = 0; t < T; ++t) n_slot[slot][t] = uint32_t(split[t + 1] - split[t]);
-    launch_fwd(nullptr, nullptr, nullptr, ids, split, slot, st);
+    has_hints[slot] = false;
+    launch_dedup(ids, split, slot, 0, st);
     BwdPlan none;
     launch_bwd(none, slot ^ 1, true, st);
     stage[slot] = 2;
+  }
+
+  // ---- streams: the dedup of the next batch runs on a stream of its own beside the step's launches
+  hipStream_t side = nullptr;
+  hipEvent_t ev_now = nullptr;            // main stream, at the start of a forward call
+  hipEvent_t ev_dedup[2] = {nullptr, nullptr};   // side: the slot's dedup has finished
+  bool dedup_on_side[2] = {false, false};
+  uint32_t dedup_wgs = 128;               // persistent workgroups of the side-stream dedup
+  bool use_side = false;                  // MHTE_MSTEP_SIDE=1 (measured slower: the two queues
+                                          // compete for the dispatcher)
+
+  void make_streams() {
+    HIP_OK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&ev_now, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) HIP_OK(hipEventCreateWithFlags(&ev_dedup[i], hipEventDisableTiming));
+    if (const char* e = getenv("MHTE_MSTEP_DEDUP_WGS")) dedup_wgs = std::max(1, atoi(e));
+    if (const char* e = getenv("MHTE_MSTEP_SIDE")) use_side = atoi(e) != 0;
+  }
+
+  // main stream waits for the side-stream dedup of `slot` (if that is where it ran)
+  void join_dedup(int slot, hipStream_t st) {
+    if (dedup_on_side[slot]) {
+      HIP_OK(hipStreamWaitEvent(st, ev_dedup[slot], 0));
+      dedup_on_side[slot] = false;
+    }
   }
 
   void forward(const int64_t* id, const int64_t* split, int64_t n_split, float* emb, int64_t emb_len,
@@ -348,16 +423,42 @@ struct MultiStep {
         throw Error(MHTE_FAILED_PRECONDITION,
                     "multi step forward: this batch was not deduplicated ahead by the previous forward");
       cur = nxt;
-    } else {
-      dedup_now(id, split, cur, st);
     }
     const int nxt = cur ^ 1;
-    if (id_next) {
-      if (stage[nxt] == 1) clear_slots(1u << nxt, st);
+    auto dedup_next = [&](hipStream_t ds, uint32_t wgs) {
+      if (stage[nxt] == 1) clear_slots(1u << nxt, ds);
       for (uint32_t t = 0; t < T; ++t) n_slot[nxt][t] = uint32_t(split_next[t + 1] - split_next[t]);
+      has_hints[nxt] = false;
+      launch_dedup(id_next, split_next, nxt, wgs, ds);
+      stage[nxt] = 1;
+    };
+    if (id_next && use_side) {
+      // The next batch's dedup on the side stream, beside this step's lookup and update.  It
+      // starts after everything the caller has enqueued so far: the ids may have just been
+      // produced, and the launches that last read or wrote the slot are among it.
+      HIP_OK(hipEventRecord(ev_now, st));
+      HIP_OK(hipStreamWaitEvent(side, ev_now, 0));
+      dedup_next(side, dedup_wgs);
+      HIP_OK(hipEventRecord(ev_dedup[nxt], side));
+      dedup_on_side[nxt] = true;
     }
-    launch_fwd(id, split, emb, id_next, split_next, nxt, st);
-    if (id_next) stage[nxt] = 1;
+    if (prefetched) {
+      if (stage[cur] == 1) {  // (forward, forward: the batch was never numbered)
+        join_dedup(cur, st);
+        BwdPlan none;
+        launch_bwd(none, cur ^ 1, true, st);
+        stage[cur] = 2;
+      }
+    } else {
+      join_dedup(cur, st);   // (a dedup still running into this slot is overwritten in order)
+      dedup_now(id, split, cur, st);
+    }
+    // the lookup reads the ids from the slot's numbering (distinct ids + occurrence runs), not
+    // from `id`: the caller's promise (prefetched) is that they are the same batch
+    launch_fwd(emb, cur, st);
+    for (uint32_t t = 0; t < T; ++t) fwd_epoch[cur][t] = mt->tables[t]->mut_epoch;
+    has_hints[cur] = true;
+    if (id_next && !use_side) dedup_next(st, 0);  // in stream order, behind the lookup
   }
 
   void backward(const float* grads, int64_t grads_len, const float* lrs, int64_t n_lr,
@@ -387,6 +488,7 @@ struct MultiStep {
     sync_views(mt, st);
     sync_static(st);
     if (stage[cur] == 1) {  // (forward, forward, backward: the batch was never numbered)
+      join_dedup(cur, st);
       BwdPlan none;
       launch_bwd(none, cur ^ 1, true, st);
       stage[cur] = 2;
@@ -398,8 +500,10 @@ struct MultiStep {
     p.exact_order = exact_order;
     const int nxt = cur ^ 1;
     const bool build_next = stage[nxt] == 1;
+    if (build_next) join_dedup(nxt, st);
     launch_bwd(p, cur, build_next, st);
     stage[cur] = 0;
+    has_hints[cur] = false;
     if (build_next) stage[nxt] = 2;
   }
 };
@@ -512,6 +616,8 @@ static void fused_optimize_segments(mhte_multi_table* t, const int64_t* ids,
     LAUNCH_HOT(kTagUpsert, seg_upsert_kernel, dim3(gx, ns), 256, st, A);
     seg_slow_kernel<<<T, 64, 0, st>>>(A);
     HIP_OK(hipGetLastError());
+    for (int k = 0; k < T; ++k)
+      if (per_table[size_t(k)]) ++t->tables[k]->mut_epoch;
   }
 }
 

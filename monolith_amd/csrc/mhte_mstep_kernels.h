@@ -42,6 +42,9 @@ struct MStepStatic {
   uint32_t* pending;       // [n_max + 1]
   float* part[2];          // per slot: partial rows of multi-item lists
   uint32_t* arrive[2];     // per slot: arrival counters, kept zeroed
+  uint32_t* urow[2];       // per slot [n_max]: row handle of unique index u as the forward launch
+                           // found it (kNoRow: not in the table), and where its slot is
+  unsigned long long* uloc[2];  //          (bucket * 4 + slot): the backward launch need not probe
   int64_t n_max;           // capacity of the dense arrays (largest batch of the table)
   uint32_t g;              // lanes per id: 8 / 16 / 32 / 64 >= dim / 4
   uint32_t oneseg;         // the table has one segment (scalar descriptor loads, seg_of)
@@ -51,18 +54,17 @@ struct MStepStatic {
 typedef const MHTE_CONST MStepStatic* ConstStatics;
 
 struct MFwdTab {
-  uint32_t id_off, n;          // this batch: ids[id_off, id_off + n)
-  uint32_t next_off, n_next;   // next batch (n_next = 0: none)
+  uint32_t n;                  // ids of this batch (its dedup is in slot cur); 0: no lookup
+  uint32_t nblk_s;             // workgroups of the lookup role
   uint32_t emb_off;            // floats
 };
 struct MFwdArgs {
   ConstViews views;
   ConstStatics st;
-  const int64_t* ids;
-  const int64_t* ids_next;
   float* out;
-  uint32_t cur;                // slot of the batch being trained; the next one dedups into cur ^ 1
-  uint32_t pad;
+  uint32_t cur;                // slot that holds the (numbered) batch being looked up
+  uint32_t item_split;         // wavefronts per heavy work item (>= 1)
+  unsigned long long* trace;   // per-wavefront timeline (mhte_trace_begin) or nullptr
   MFwdTab tab[kMaxStepTables];
 };
 
@@ -72,6 +74,11 @@ struct MBwdTab {
   uint32_t nblk_items, nblk_ids;
   uint32_t build_next;         // 1: slot cur ^ 1 holds a deduplicated batch to number
   uint32_t light_max;
+  uint32_t hints;              // 1: urow / uloc of slot cur are what the forward launch left and
+                               // nothing has touched the table since
+  uint32_t n;                  // ids of the batch in slot cur
+  uint32_t n_next;             // ids of the batch in slot cur ^ 1
+  uint32_t pad;
   ApplyArgs a;
 };
 struct MBwdArgs {
@@ -80,6 +87,7 @@ struct MBwdArgs {
   const float* grads;
   uint32_t cur;
   uint32_t pad;
+  unsigned long long* trace;
   MBwdTab tab[kMaxStepTables];
 };
 static_assert(sizeof(MFwdArgs) <= 4096 && sizeof(MBwdArgs) <= 4096, "kernel arguments exceed 4 KB");
@@ -102,7 +110,6 @@ __global__ __launch_bounds__(256) void mstep_clear_kernel(ConstStatics st, uint3
     if (i <= d.cap_mask + 1u) {
       d.hkey[i] = kEmptyKey;
       d.hcnt[i] = 0;
-      d.hblk[i] = 0ull;
       d.hpos[i] = 0;
     }
     if (i < 4) d.ctr[i] = 0;
@@ -110,52 +117,274 @@ __global__ __launch_bounds__(256) void mstep_clear_kernel(ConstStatics st, uint3
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward: per table   run dedup of the NEXT batch | lookup of this batch
-// (the displacement pass of the previous update has its own launch here, mstep_slow_kernel: with
-// T tables in a launch a 3 us launch is noise, and the lookups need no gate)
+// run dedup of the NEXT batch of every table, on its own (side) stream beside the step's launches.
+// What paces this role is not bandwidth but device-scope atomics (two per distinct id and dedup
+// workgroup: the slot claim and the count bump; ~36 G/s on MI355X, scripts/mstep_probe.py), so it
+// gets a fixed, small number of persistent workgroups — the memory-bound lookup / apply launches
+// keep the rest of the chip — and walks the (table, 1024 positions) items in grid-stride order.
 // ---------------------------------------------------------------------------------------------
-template <int G, int UNR>
-__device__ __forceinline__ void mstep_lookup_loop(const TableView& tv, const int64_t* ids, int64_t n,
-                                                  float* out, int count_hits, uint32_t bid,
-                                                  uint32_t nblk_l) {
-  const int64_t ngroups = (n + UNR - 1) / UNR;
+struct MDedupArgs {
+  ConstStatics st;
+  const int64_t* ids;
+  uint32_t slot;
+  uint32_t T;
+  unsigned long long* trace;
+  uint32_t id_off[kMaxStepTables + 1];      // table t: ids[id_off[t], id_off[t + 1])
+  uint32_t blk_start[kMaxStepTables + 1];   // first item of table t
+};
+
+__global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void mstep_dedup_kernel(
+    MDedupArgs A) {
+  __shared__ __attribute__((aligned(16))) RdLds L;
+  WaveTrace wt(A.trace);
+  const uint32_t total = A.blk_start[A.T];
 #pragma unroll 1
-  for (int64_t g = (int64_t(bid) * kRdBlock + threadIdx.x) / G; g < ngroups;
-       g += int64_t(nblk_l) * kRdBlock / G)
-    lookup_role_u<G, 4, UNR, true>(tv, ids, n, nullptr, out, count_hits, g);
+  for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
+    uint32_t t = 0;
+    while (t + 1 < A.T && A.blk_start[t + 1] <= w) ++t;  // (uniform; T <= 32)
+    const MStepStatic& s = deref_const(A.st + t);
+    RunView d = s.rv[A.slot & 1u];
+    d.ids = A.ids + A.id_off[t];
+    d.n = A.id_off[t + 1] - A.id_off[t];
+    d.nblk = A.blk_start[t + 1] - A.blk_start[t];
+    rd_dedup_role(d, w - A.blk_start[t], L, wt);
+    __syncthreads();  // (the LDS is reused by the next item)
+  }
+  wt.end(3u);
 }
 
-template <int UNR>
-__global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void mstep_fwd_kernel(
-    MFwdArgs A) {
-  __shared__ __attribute__((aligned(16))) RdLds L;
+// ---------------------------------------------------------------------------------------------
+// forward: per table   run dedup of the NEXT batch | lookup of this batch
+//
+// The batch being looked up was deduplicated and numbered a step ahead, so the lookup probes each
+// DISTINCT id once (U ~ 12 k of B = 65 536 under Zipf(1.2)) and scatters its row to the id's
+// occurrences through the run format — the reference's lookup(unique) + MonolithFillWithOffsetMap
+// (RT/ops/unique_mapping_ops.cc:204-268) as one role: stores are fire and forget, so a wavefront
+// has one dependent chain (dense arrays -> buckets -> row) per DISTINCT id instead of per
+// occurrence.  What the probe found (row handle, bucket slot) is left for the backward launch,
+// which then reaches the row of a resident id without reading a bucket.
+// (The displacement pass of the previous update has its own launch, mstep_slow_kernel: with T
+// tables in a launch a 3 us launch is noise, and the lookups need no gate.)
+// ---------------------------------------------------------------------------------------------
+#ifndef MHTE_SCATTER_UNR
+#define MHTE_SCATTER_UNR 2
+#endif
+#ifdef MHTE_SCATTER_PLAIN_STORES
+#define MHTE_SCATTER_STORE(P, V) (V).store(P)
+#else
+#define MHTE_SCATTER_STORE(P, V) store_stream<VEC>(P, V)
+#endif
+template <int G, int BLOCK, int UNR>
+__device__ __forceinline__ void mstep_scatter_role(const TableView& tv, const RunView& d,
+                                                   float* __restrict__ out,
+                                                   uint32_t* __restrict__ urow,
+                                                   unsigned long long* __restrict__ uloc,
+                                                   int64_t n_max, int count_hits, uint32_t bid,
+                                                   uint32_t nblk, uint32_t item_split,
+                                                   WaveTrace& wt) {
+  constexpr int VEC = 4;
+  constexpr int NG = BLOCK / G;
+  constexpr int GPW = 64 / G;  // groups per wavefront
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (G - 1);
+  const int gbase = lane & ~(G - 1);
+  const int grp = threadIdx.x / G;
+  const uint32_t dim = tv.dim;
+  const uint32_t e = uint32_t(j) * VEC;
+  const bool ev = e < dim;
+  const uint32_t n_unique = d.ctr[0];
+  const uint32_t n_items = d.ctr[2];
+  const int64_t nu = min(n_max, int64_t(n_unique));
+  uint64_t hits = 0;
+  // ---------------------------------------------------------------- distinct ids, UNR per group
+  // (a wavefront's throughput is ids per trip / the trip's dependent round trips, so UNR ids per
+  // lane group are in flight together: their probes, then their rows)
+  constexpr int PER = (kStepLightMax + G - 1) / G;
+  const int64_t stride = int64_t(nblk) * NG * UNR;
+#pragma unroll 1
+  for (int64_t g0 = int64_t(bid) * NG * UNR; g0 < nu; g0 += stride) {  // workgroup-uniform
+    int64_t id[UNR];
+    uint32_t cnt[UNR], hp[UNR], gs[UNR];
+    bool valid[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t g = g0 + int64_t(grp) * UNR + u;
+      valid[u] = g < nu;
+      const int64_t gi = valid[u] ? g : 0;  // (loads from a safe index, masked afterwards)
+      id[u] = d.uids[gi];
+      cnt[u] = d.ucnt[gi];
+      hp[u] = d.upos[gi];
+      gs[u] = d.uslot[gi];
+    }
+    if (wt.rec && g0 == int64_t(bid) * NG * UNR) {  // (traced runs: when the first trip's ids arrive)
+      asm volatile("" ::"v"(cnt[0]));
+      wt.mark(1);
+    }
+    int64_t kk[UNR];
+    uint32_t row[UNR], x[UNR][PER];
+    uint64_t i1[UNR], i2[UNR];
+    bool flat[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (!valid[u]) cnt[u] = 0;
+      const uint64_t hv = hash_key(id[u]);
+      i1[u] = index_hash(tv.hp, hv);
+      i2[u] = alt_index(tv.hp, partial_key(hv), i1[u]);
+      const GBucket* b = global_bucket(tv.buckets + ((j & 4) ? i2[u] : i1[u]));
+      kk[u] = b->key[j & 3];
+      row[u] = b->row[j & 3];
+      flat[u] = cnt[u] > 1 && cnt[u] <= uint32_t(kStepLightMax);
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const uint32_t idx = uint32_t(j) + uint32_t(q) * G;
+        x[u][q] = (flat[u] && idx < cnt[u]) ? d.hlist[size_t(gs[u]) * kLightMax + idx] : 0xffffffffu;
+      }
+    }
+    if (wt.rec && g0 == int64_t(bid) * NG * UNR) {  // (... its bucket lines and position lists)
+      asm volatile("" ::"v"(row[0]), "v"(x[0][0]));
+      wt.mark(2);
+    }
+    Vec<VEC> v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const bool use = valid[u] && j < 8 && id[u] != kEmptyKey;
+      const uint64_t m = group_mask_of<G>(__ballot(use && kk[u] == id[u]), gbase);
+      bool found = m != 0;
+      const int src = found ? (__ffsll(static_cast<long long>(m)) - 1) : 0;
+      uint32_t r = __shfl(use ? row[u] : kNoRow, gbase + src);
+      const bool special = valid[u] && id[u] == kEmptyKey;
+      if (special) {
+        found = tv.ctr->special_state == 1;
+        r = tv.ctr->special_row;
+      }
+      found = found && valid[u];
+      if (valid[u] && j == 0) {  // (the side slot's key is left to the update's own path)
+        const int64_t g = g0 + int64_t(grp) * UNR + u;
+        urow[g] = (found && !special) ? r : kNoRow;
+        uloc[g] = (((src & 4) ? i2[u] : i1[u]) << 2) | uint64_t(src & 3);
+      }
+      if (count_hits && found && j == 0) hits += cnt[u];  // (per occurrence, as the direct lookup counts)
+      const bool light = valid[u] && cnt[u] <= uint32_t(kStepLightMax);
+      vec_zero(v[u]);
+      if (found && light && ev) v[u].load(row_ptr(tv, r) + e);
+    }
+    if (wt.rec && g0 == int64_t(bid) * NG * UNR) {  // (... its rows)
+      asm volatile("" ::"v"(v[0].v[0]));
+      wt.mark(3);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (cnt[u] == 1) {
+        if (ev) MHTE_SCATTER_STORE(out + int64_t(hp[u]) * dim + e, v[u]);
+      } else if (flat[u]) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+#pragma unroll 4
+          for (int t2 = 0; t2 < G; ++t2) {
+            const uint32_t p = __shfl(x[u][q], gbase + t2);
+            if (p != 0xffffffffu && ev) MHTE_SCATTER_STORE(out + int64_t(p) * dim + e, v[u]);
+          }
+        }
+      }
+    }
+  }
+  wt.mark(0);
+  // ---------------------------------------------------------------- heavy lists: one work item
+  // (~256 occurrences of one id, a power-of-two range of dedup workgroups) per WAVEFRONT; run
+  // starts by wave scan, no LDS, no barrier
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll 1
+  // (item_split wavefronts share an item, each taking every item_split-th pass of 64 occurrences:
+  // items are cut for the update launch, where a bigger item amortises its fixed round trips)
+  for (uint32_t unit = bid * (BLOCK / 64) + wave; unit < n_items * item_split;
+       unit += nblk * (BLOCK / 64)) {
+    const uint32_t w = unit / item_split, sub = unit % item_split;
+    const ItemHdr hd = d.item_hdr[w];
+    const uint32_t rval = d.item_runs[size_t(w) * 64 + lane];
+    const uint32_t b0 = hd.meta & 0xffu, nbk = (hd.meta >> 8) & 0xffu;
+    const uint32_t val = (uint32_t(lane) < nbk) ? rval : 0u;
+    uint32_t incl = run_cnt(val);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    const uint32_t excl = incl - run_cnt(val);
+    const uint32_t E = __shfl(incl, 63);
+    // the id's row (every group fetches the same lines: one request)
+    const uint64_t hv = hash_key(hd.id);
+    const uint64_t i1 = index_hash(tv.hp, hv);
+    const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
+    const GBucket* b = global_bucket(tv.buckets + ((j & 4) ? i2 : i1));
+    const int64_t kk = b->key[j & 3];
+    const uint32_t row = b->row[j & 3];
+    const bool use = j < 8 && hd.id != kEmptyKey;
+    const uint64_t m = group_mask_of<G>(__ballot(use && kk == hd.id), gbase);
+    bool found = m != 0;
+    const int src = found ? (__ffsll(static_cast<long long>(m)) - 1) : 0;
+    uint32_t r = __shfl(use ? row : kNoRow, gbase + src);
+    if (hd.id == kEmptyKey) {
+      found = tv.ctr->special_state == 1;
+      r = tv.ctr->special_row;
+    }
+    Vec<VEC> v;
+    vec_zero(v);
+    if (found && ev) v.load(row_ptr(tv, r) + e);
+#pragma unroll 1
+    for (uint32_t qb = sub * 64; qb < E; qb += 64 * item_split) {
+      const uint32_t q = qb + uint32_t(lane);
+      const bool has = q < E;
+      const uint32_t qq = has ? q : 0u;
+      uint32_t lo = 0, hi = 63;  // run lo with excl[lo] <= q < incl[lo]
+#pragma unroll
+      for (int it2 = 0; it2 < 6; ++it2) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        const bool le = uint32_t(__shfl(excl, int(mid))) <= qq;
+        lo = le ? mid : lo;
+        hi = le ? hi : mid - 1;
+      }
+      const uint32_t vr = __shfl(val, int(lo));
+      const uint32_t er = __shfl(excl, int(lo));
+      const uint32_t base = (b0 + lo) * kRdBlock;
+      uint32_t p = base + run_first(vr);
+      if (has && run_cnt(vr) != 1) p = base + uint32_t(d.seg[base + run_off(vr) + (qq - er)]);
+#pragma unroll 4
+      for (int t = 0; t < G; ++t) {
+        const int idx = t * GPW + (lane / G);
+        const uint32_t pt = __shfl(p, idx);
+        if (qb + uint32_t(idx) < E && ev) MHTE_SCATTER_STORE(out + int64_t(pt) * dim + e, v);
+      }
+    }
+  }
+  wt.mark(4);
+  if (count_hits) {
+    unsigned long long tot = hits;  // (leader lanes hold partial counts)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
+    if (lane == 0 && tot) atomicAdd(&tv.ctr->hits, tot);
+  }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void mstep_fwd_kernel(MFwdArgs A) {
   const uint32_t t = blockIdx.y;
   const MFwdTab ft = A.tab[t];
+  const uint32_t bid = blockIdx.x;
+  if (ft.n == 0 || bid >= ft.nblk_s) return;
   const MStepStatic& s = deref_const(A.st + t);
-  WaveTrace wt(nullptr);
-  uint32_t bid = blockIdx.x;
-  const uint32_t nblk_d = (ft.n_next + kRdBlock - 1) / kRdBlock;
-  if (bid < nblk_d) {
-    RunView d = s.rv[(A.cur ^ 1u) & 1u];
-    d.ids = A.ids_next + ft.next_off;
-    d.n = ft.n_next;
-    d.nblk = nblk_d;
-    rd_dedup_role(d, bid, L, wt);
-    return;
-  }
-  bid -= nblk_d;
-  if (ft.n == 0 || gridDim.x <= nblk_d) return;
-  const uint32_t nblk_l = gridDim.x - nblk_d;
+  WaveTrace wt(A.trace);
   const TableView& tv = deref_const(A.views + t);
-  const int64_t* ids = A.ids + ft.id_off;
+  const uint32_t cur = A.cur & 1u;
+  const RunView d = s.rv[cur];
   float* out = A.out + size_t(ft.emb_off);
   const int ch = int(s.count_hits);
   switch (s.g) {
-    case 8: mstep_lookup_loop<8, UNR>(tv, ids, ft.n, out, ch, bid, nblk_l); break;
-    case 16: mstep_lookup_loop<16, UNR>(tv, ids, ft.n, out, ch, bid, nblk_l); break;
-    case 32: mstep_lookup_loop<32, UNR>(tv, ids, ft.n, out, ch, bid, nblk_l); break;
-    default: mstep_lookup_loop<64, UNR>(tv, ids, ft.n, out, ch, bid, nblk_l); break;
+    case 8: mstep_scatter_role<8, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
+    case 16: mstep_scatter_role<16, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
+    case 32: mstep_scatter_role<32, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
+    default: mstep_scatter_role<64, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
   }
+  wt.end(5u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -166,31 +395,37 @@ __device__ __forceinline__ void mstep_apply_switch(uint32_t g, const TableView& 
                                                    const ApplyCtl& c, const ApplyArgs& a,
                                                    uint32_t bid, WaveTrace& wt, ApplyLds& L) {
   switch (g) {
-    case 8: rd_apply_role<8, 4, ONESEG>(tv, d, c, a, bid, wt, L); break;
-    case 16: rd_apply_role<16, 4, ONESEG>(tv, d, c, a, bid, wt, L); break;
-    case 32: rd_apply_role<32, 4, ONESEG>(tv, d, c, a, bid, wt, L); break;
-    default: rd_apply_role<64, 4, ONESEG>(tv, d, c, a, bid, wt, L); break;
+    case 8: rd_apply_role<8, 4, ONESEG, true>(tv, d, c, a, bid, wt, L); break;
+    case 16: rd_apply_role<16, 4, ONESEG, true>(tv, d, c, a, bid, wt, L); break;
+    case 32: rd_apply_role<32, 4, ONESEG, true>(tv, d, c, a, bid, wt, L); break;
+    default: rd_apply_role<64, 4, ONESEG, true>(tv, d, c, a, bid, wt, L); break;
   }
 }
 
-__global__ __launch_bounds__(256, kBwdBlocksPerCu) void mstep_bwd_kernel(MBwdArgs A) {
+#ifndef MHTE_MBWD_OCC
+#define MHTE_MBWD_OCC kBwdBlocksPerCu
+#endif
+__global__ __launch_bounds__(256, MHTE_MBWD_OCC) void mstep_bwd_kernel(MBwdArgs A) {
   __shared__ ApplyLds L;
   const uint32_t t = blockIdx.y;
   const MBwdTab& bt = A.tab[t];
   const MStepStatic& s = deref_const(A.st + t);
-  WaveTrace wt(nullptr);
+  WaveTrace wt(A.trace);
   uint32_t bid = blockIdx.x;
   const uint32_t cur = A.cur & 1u;
   const uint32_t nblk_build = bt.build_next ? s.nblk_build : 0u;
   if (bid < nblk_build) {
-    const RunView nxt = s.rv[cur ^ 1u];
+    RunView nxt = s.rv[cur ^ 1u];
+    nxt.nblk = (bt.n_next + kRdBlock - 1) / kRdBlock;
     rd_build_role(nxt, uint32_t(kStepLightMax), bid, nblk_build);
+    wt.end(6u);
     return;
   }
   bid -= nblk_build;
   if (!bt.apply || bid >= bt.nblk_items + bt.nblk_ids) return;
   const TableView& tv = deref_const(A.views + t);
-  const RunView d = s.rv[cur];
+  RunView d = s.rv[cur];
+  d.nblk = (bt.n + kRdBlock - 1) / kRdBlock;
   ApplyCtl c;
   c.grads = A.grads + size_t(bt.grad_off);
   c.grad_u = s.grad_u;
@@ -202,8 +437,11 @@ __global__ __launch_bounds__(256, kBwdBlocksPerCu) void mstep_bwd_kernel(MBwdArg
   c.nblk_items = bt.nblk_items;
   c.nblk_ids = bt.nblk_ids;
   c.spec_row = nullptr;
+  c.urow = bt.hints ? s.urow[cur] : nullptr;
+  c.uloc = bt.hints ? s.uloc[cur] : nullptr;
   if (s.oneseg) mstep_apply_switch<true>(s.g, tv, d, c, bt.a, bid, wt, L);
   else mstep_apply_switch<false>(s.g, tv, d, c, bt.a, bid, wt, L);
+  wt.end(bid < bt.nblk_items ? 7u : 8u);
 }
 
 // displacement pass of every table's update, one wavefront per table (usually nothing to do)

@@ -83,7 +83,7 @@ struct RunView {
   // global scratch hash, capacity cap_mask + 1 (+1 side slot); all-empty between uses
   int64_t* hkey;
   uint32_t* hcnt;               // occurrences of the slot's id in the batch
-  unsigned long long* hblk;     // mask of the workgroups that hold a run of it
+  unsigned long long* hblk;     // (unused since r2: one atomic less per run; kept for layout)
   uint32_t* hpos;               // position of an occurrence (the only one when hcnt == 1)
   uint32_t* hlist;              // [slots][kLightMax] the positions of a light list (<= kLightMax
                                 //     occurrences), runs in arrival order; never scanned or reset
@@ -91,7 +91,7 @@ struct RunView {
   // per batch
   uint32_t* uslot;              // [n] dense copies made by the build role: scratch slot,
   uint32_t* ucnt;               //     occurrences,
-  unsigned long long* ublk;     //     workgroup mask,
+  unsigned long long* ublk;     //     (unused since r2),
   uint32_t* upos;               //     a position (the only one when ucnt == 1) of unique index u
   int64_t* btab_key;            // [nblk][kRdStride] dumped LDS tables
   uint32_t* btab_val;           // [nblk][kRdStride] run_pack
@@ -112,7 +112,6 @@ __global__ __launch_bounds__(256) void rd_clear_kernel(RunView d) {
   if (i <= d.cap_mask + 1u) {
     d.hkey[i] = kEmptyKey;
     d.hcnt[i] = 0;
-    d.hblk[i] = 0ull;
     d.hpos[i] = 0;
   }
   if (i < 4) d.ctr[i] = 0;
@@ -276,8 +275,10 @@ __device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, Rd
                                                  static_cast<unsigned long long>(id)));
       }
     }
+    // (which workgroups hold a run of the id is not recorded: device-scope atomics are the scarce
+    // resource of this role — ~36 G/s on MI355X, scripts/mstep_probe.py — and the few heavy ids
+    // find their runs by probing every workgroup's directory, rd_find_run_opt)
     lbase = atomicAdd(&d.hcnt[gs], L.cnt[ls]);
-    atomicOr(&d.hblk[gs], 1ull << bid);      // (no return value: fire and forget)
     d.hpos[gs] = p;                          // read only when the id turns out to occur once
   }
   // ---- the LDS table is the workgroup's run directory
@@ -324,6 +325,25 @@ __device__ __forceinline__ uint32_t rd_find_run(const RunView& d, uint32_t b, in
   return v;
 }
 
+// the same for an id that may have no run in workgroup b: 0 when the probe sequence ends at an empty
+// entry (run_pack of a present run is never 0: its count is >= 1)
+__device__ __forceinline__ uint32_t rd_find_run_opt(const RunView& d, uint32_t b, int64_t id) {
+  const int64_t* kt = d.btab_key + size_t(b) * kRdStride;
+  const uint32_t* vt = d.btab_val + size_t(b) * kRdStride;
+  if (id == kEmptyKey) return run_cnt(vt[kRdLds]) ? vt[kRdLds] : 0u;
+  uint32_t ls = rd_home(id);
+  int64_t k = kt[ls];
+  uint32_t v = vt[ls];
+  int left = kRdLds;
+  while (k != id) {
+    if (k == kEmptyKey || --left == 0) return 0u;
+    ls = (ls + 1u) & (kRdLds - 1);
+    k = kt[ls];
+    v = vt[ls];
+  }
+  return v;
+}
+
 // workgroups per item for a list of c occurrences: power of two, ~kItemTarget entries expected
 // A list that fits one item (<= 2 * target entries) stays whole; a longer one is cut into items of
 // target / 2 .. target expected entries: its items are followed by a hand-off (partial rows, arrival
@@ -358,7 +378,7 @@ __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_m
     const uint32_t base = bb + (t >> 6) * (64u * Q);
     int64_t key[Q];
     uint32_t cnt[Q], pos[Q];
-    unsigned long long blk[Q], occ[Q];
+    unsigned long long occ[Q];
     uint32_t total = 0;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
@@ -366,7 +386,6 @@ __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_m
       const bool in = sl < nslots;
       key[q] = in ? d.hkey[sl] : kEmptyKey;
       cnt[q] = in ? d.hcnt[sl] : 0u;
-      blk[q] = in ? d.hblk[sl] : 0ull;
       pos[q] = in ? d.hpos[sl] : 0u;
     }
 #pragma unroll
@@ -376,7 +395,6 @@ __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_m
       if (o) {  // clean-after-use: the scratch is all-empty again after this launch
         d.hkey[sl] = kEmptyKey;
         d.hcnt[sl] = 0;
-        d.hblk[sl] = 0ull;
         if (sl == d.cap_mask + 1u) key[q] = kEmptyKey;  // the side slot stands for that id itself
       }
       occ[q] = __ballot(o);
@@ -403,7 +421,6 @@ __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_m
         d.uids[kq[q]] = key[q];
         d.uslot[kq[q]] = base + q * 64 + lane;
         d.ucnt[kq[q]] = cnt[q];
-        d.ublk[kq[q]] = blk[q];
         d.upos[kq[q]] = pos[q];
       }
     }
@@ -416,8 +433,9 @@ __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_m
         const uint32_t hu = __shfl(kq[q], src);
         const uint32_t c = __shfl(cnt[q], src);
         const int64_t id = __shfl(key[q], src);
-        const unsigned long long bm = __shfl(blk[q], src);
-        const bool has = (bm >> lane) & 1ull;
+        // lane b looks the id up in dedup workgroup b's run directory (0: no run there)
+        const uint32_t val = (uint32_t(lane) < d.nblk) ? rd_find_run_opt(d, uint32_t(lane), id) : 0u;
+        const unsigned long long bm = __ballot(val != 0u);
         const uint32_t nbk = rd_item_blocks(c, d.item_target);
         const uint32_t b0 = uint32_t(lane) & ~(nbk - 1u);
         const unsigned long long rmask = (nbk == 64 ? ~0ull : ((1ull << nbk) - 1ull)) << b0;
@@ -425,8 +443,7 @@ __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_m
         const unsigned long long lm = __ballot(leader);
         const uint32_t nitems = __popcll(lm);
         uint32_t w0 = 0;
-        if (lane == 0) w0 = atomicAdd(&d.ctr[2], nitems);  // in flight beside the run probes
-        const uint32_t val = has ? rd_find_run(d, uint32_t(lane), id) : 0u;
+        if (lane == 0) w0 = atomicAdd(&d.ctr[2], nitems);
         w0 = __shfl(w0, 0);
         // item index of this lane's range = rank of its leader among the leaders
         const uint32_t k = __popcll(lm & ((1ull << b0) - 1ull));
@@ -467,6 +484,10 @@ struct ApplyCtl {
   uint32_t nblk_ids;
   const uint32_t* spec_row;  // [n] row handle reserved for unique index u by the forward launch
                              // (rd_prealloc_role; kNoRow: the id was in the table), or nullptr
+  // (multi-table step, HINT) what the forward launch's lookup found for unique index u: row handle
+  // (kNoRow: absent) and bucket * 4 + slot; nullptr: probe as usual
+  const uint32_t* urow;
+  const unsigned long long* uloc;
 };
 
 // row of a found id, fetched while the gradient chain is in flight
@@ -751,7 +772,7 @@ struct ApplyLds {
   uint32_t last;
 };
 
-template <int G, int VEC, bool ONESEG>
+template <int G, int VEC, bool ONESEG, bool HINT = false>
 __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView& d,
                                               const ApplyCtl& c, const ApplyArgs& a, uint32_t bid,
                                               WaveTrace& wt, ApplyLds& L) {
@@ -789,11 +810,20 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       uint32_t cnt = inb ? d.ucnt[g] : 0u;
       const uint32_t hp = inb ? d.upos[g] : 0u;
       const uint32_t gs = inb ? d.uslot[g] : 0u;
+      // (HINT) the forward launch already resolved the id: its row handle and bucket slot arrive
+      // with the rest of the trip, no bucket line is read for an id that was resident
+      uint32_t hrow = kNoRow;
+      unsigned long long hloc = 0;
+      if (HINT && c.urow) {
+        hrow = inb ? c.urow[g] : kNoRow;
+        hloc = inb ? c.uloc[g] : 0ull;
+      }
       nu = min(c.n_max, int64_t(n_unique));
       bool valid = g < nu;
       if (!valid) cnt = 0;
+      const bool hinted = HINT && valid && hrow != kNoRow;
       // round trip 2: table probe | gradient of a lone occurrence | run tables of a short list
-      Probe<G> pr = probe_issue<G>(tv, id, valid, j);
+      Probe<G> pr = probe_issue<G>(tv, id, valid && !hinted, j);
       if (it == 0) wt.mark(0);
       if (cnt > c.light_max) valid = false;  // heavy list: the item workgroups own it
       const bool single = valid && cnt == 1;
@@ -819,21 +849,28 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       if (tv.flt_slots) {
         bool contained = group_mask_of<G>(__ballot(valid && id != kEmptyKey && j < 8 && pr.k == id), gbase) != 0;
         if (valid && id == kEmptyKey) contained = tv.ctr->special_state == 1;
+        if (hinted) contained = true;
         uint32_t first = 0;
         if (valid && j == 0) first = filter_consult(tv, id, cnt, 2, contained);
         if (__shfl(first, gbase) != 0u) valid = false;
       }
       // round trip 3: slot claim + row handle of a new id | the row of a found one | (below) the
       // gradients of a list — all in flight together
-      const UpsertFlight<G> uf = upsert_issue<G>(tv, pr.b, id, valid, pr.k, lane, reserved);
-      if (lane == 0) sh_need[wave] = uint32_t(__popcll(uf.specm));
-      lds_barrier();  // (the trip count is the same for the four wavefronts)
+      const UpsertFlight<G> uf = upsert_issue<G>(tv, pr.b, id, valid && !hinted, pr.k, lane, reserved);
+      // (HINT: the multi-table launch.  Few ids are new — the forward launch found the rest — and
+      // every table has its own counter, so a wavefront that needs rows bumps the counter itself:
+      // no workgroup barrier in the trip, the four wavefronts run free)
+      if (!HINT) {
+        if (lane == 0) sh_need[wave] = uint32_t(__popcll(uf.specm));
+        lds_barrier();  // (the trip count is the same for the four wavefronts)
+      }
       RowRegs<VEC> rr;
       vec_zero(rr.w);
       vec_zero(rr.s1);
-      const bool pre = valid && uf.found;
+      const bool pre = valid && (uf.found || hinted);
       if (__any(pre)) {
-        const uint32_t frow = __shfl(pr.row, gbase + (uf.owner < 0 ? 0 : uf.owner));
+        uint32_t frow = __shfl(pr.row, gbase + (uf.owner < 0 ? 0 : uf.owner));
+        if (hinted) frow = hrow;
         if (pre) row_prefetch<VEC, ONESEG>(tv, row_ptr(tv, frow), e, rr);
       }
       if (__any(flat)) {
@@ -858,7 +895,13 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       // wavefront needs next anyway
       unsigned long long rows0;  // (not initialised on purpose: see lbase in rd_dedup_role)
       bool bumped = false;
-      if (threadIdx.x == 0) {
+      if (HINT) {
+        const unsigned long long tot = __popcll(uf.specm);
+        if (tot && lane == 0) {
+          rows0 = atomicAdd(&tv.ctr->alloc, (tot << 32) | tot);
+          bumped = true;
+        }
+      } else if (threadIdx.x == 0) {
         const unsigned long long tot = sh_need[0] + sh_need[1] + sh_need[2] + sh_need[3];
         if (tot) {
           rows0 = atomicAdd(&tv.ctr->alloc, (tot << 32) | tot);
@@ -873,8 +916,15 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       }
       if (flat) sum_list_lds<VEC>(c.grads, dim, e, ev, sh_pos, cnt, acc);
       if (big) {
-        // strictly sequential sum of a long list (MHTE_EXACT_ORDER): run after run
-        unsigned long long rest = d.ublk[g];
+        // strictly sequential sum of a long list (MHTE_EXACT_ORDER): run after run.  Which dedup
+        // workgroups hold a run: the group's lanes probe G directories per round.
+        unsigned long long rest = 0ull;
+#pragma unroll 1
+        for (uint32_t b1 = 0; b1 < d.nblk; b1 += G) {
+          const uint32_t bq = b1 + uint32_t(j);
+          const uint32_t vq = (bq < d.nblk) ? rd_find_run_opt(d, bq, id) : 0u;
+          rest |= group_mask_of<G>(__ballot(vq != 0u), gbase) << b1;
+        }
 #pragma unroll 1
         while (rest) {
           const uint32_t b = uint32_t(__ffsll(static_cast<long long>(rest)) - 1);
@@ -897,12 +947,24 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
           }
         }
       }
-      if (bumped) sh_rowbase = uint32_t(rows0);  // (only thread 0, only when rows were needed)
-      lds_barrier();
-      uint32_t base_row = sh_rowbase;
-      for (int w2 = 0; w2 < wave; ++w2) base_row += sh_need[w2];
-      const SlotResult sr =
-          upsert_complete<G>(tv, pr.b, id, valid, pr.row, lane, a.ts, uf, base_row, reserved);
+      uint32_t base_row;
+      if (HINT) {
+        uint32_t br = bumped ? uint32_t(rows0) : 0u;  // (lane 0 of a wavefront that needed rows)
+        base_row = __shfl(br, 0);
+      } else {
+        if (bumped) sh_rowbase = uint32_t(rows0);  // (only thread 0, only when rows were needed)
+        lds_barrier();
+        base_row = sh_rowbase;
+        for (int w2 = 0; w2 < wave; ++w2) base_row += sh_need[w2];
+      }
+      SlotResult sr =
+          upsert_complete<G>(tv, pr.b, id, valid && !hinted, pr.row, lane, a.ts, uf, base_row, reserved);
+      if (hinted) {  // resident id: nothing to claim; the timestamp goes to the slot the lookup found
+        sr.r = hrow;
+        sr.is_new = false;
+        sr.deferred = false;
+        if (valid && j == 0) global_bucket(tv.buckets + (hloc >> 2))->ts[hloc & 3ull] = a.ts;
+      }
       float* rp = nullptr;
       if (valid && !sr.deferred) {
         rp = row_ptr(tv, sr.r);
@@ -916,7 +978,8 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         optimize_row_pre<VEC, ONESEG>(tv, rp, sr.is_new, e, acc, a, rr);
       }
       if (it == 0) wt.mark(4);
-      lds_barrier();  // sh_pos / sh_need are reused
+      if (HINT) lds_wave_sync();  // (sh_pos is the group's own)
+      else lds_barrier();         // sh_pos / sh_need are reused
     }
     return;
   }
