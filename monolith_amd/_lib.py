@@ -129,14 +129,17 @@ def lib():
     # /opt/rocm's copies into the process as well and the second HSA runtime then finds no device.
     # Import torch first so libmhte.so binds to the runtime that owns the tensors and streams.
     import torch  # noqa: F401  pylint: disable=unused-import,import-outside-toplevel
-    if _stale():
+    # MHTE_LIBRARY (another build, A/B runs) and MHTE_NO_REBUILD=1 (use the .so as it is) are the
+    # explicit opt-outs; otherwise a library older than its sources is rebuilt, and a failed
+    # rebuild is an error — never a silent fall back to the stale binary
+    if not _OVERRIDE and os.environ.get("MHTE_NO_REBUILD") != "1" and _stale():
       try:
         build_library()
       except Exception as e:  # pylint: disable=broad-except
-        if not os.path.exists(_SO):
-          raise MhteError(MHTE_UNAVAILABLE,
-                          "libmhte.so is missing and could not be built (%s); the MI355X engine "
-                          "has no fallback path" % e)
+        raise MhteError(MHTE_UNAVAILABLE,
+                        "libmhte.so is %s and could not be rebuilt (%s); the MI355X engine has no "
+                        "fallback path (MHTE_NO_REBUILD=1 loads an existing library as it is)" %
+                        ("older than its sources" if os.path.exists(_SO) else "missing", e))
     L = C.CDLL(_OVERRIDE or _SO)
     for name in EXPORTS:
       if not hasattr(L, name):

@@ -26,6 +26,8 @@
 
 #include "../../include/monolith_amd_hash_table.h"
 #include <unistd.h>
+#include <dirent.h>
+#include <ctype.h>
 
 #include "mhte_ckpt.h"
 #include "mhte_pool_kernels.h"
@@ -1881,16 +1883,48 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
 }
 
 static void restore_multi_table(mhte_multi_table* t, const std::string& basename, hipStream_t st) {
-  // the shard count is in the file names: <basename>-00000-of-<total>
+  // The shard set is what the directory holds under <basename>-%05d-of-%05d (the reference globs
+  // <basename>-* and validates the set, ValidateShardedFiles,
+  // multi_hash_table_save_restore_ops.cc:323-349): one consistent total, every data shard and every
+  // .meta sidecar present.  Leftovers of an earlier save with another shard count are an error, not
+  // something to restore silently.
   int total = 0;
-  for (int cand = 1; cand <= 4096 && !total; ++cand) {
-    FILE* f = fopen(ckpt::shard_name(basename, "", 0, cand).c_str(), "rb");
-    if (f) {
-      fclose(f);
-      total = cand;
+  {
+    const size_t slash = basename.find_last_of('/');
+    const std::string dir = slash == std::string::npos ? "." : basename.substr(0, slash == 0 ? 1 : slash);
+    const std::string stem = slash == std::string::npos ? basename : basename.substr(slash + 1);
+    std::vector<std::pair<int, int>> data, meta;  // (index, total)
+    DIR* dp = opendir(dir.c_str());
+    if (!dp) throw Error(MHTE_NOT_FOUND, "no checkpoint shards found for " + basename);
+    while (dirent* de = readdir(dp)) {
+      const std::string fn = de->d_name;
+      for (int is_meta = 0; is_meta < 2; ++is_meta) {
+        const std::string pre = stem + (is_meta ? ".meta-" : "-");
+        if (fn.size() != pre.size() + 14 || fn.compare(0, pre.size(), pre) != 0) continue;
+        const std::string tail = fn.substr(pre.size());  // ddddd-of-ddddd
+        if (tail.compare(5, 4, "-of-") != 0) continue;
+        bool digits = true;
+        for (int k = 0; k < 14; ++k)
+          if (k < 5 || k >= 9) digits = digits && isdigit(static_cast<unsigned char>(tail[k]));
+        if (!digits) continue;
+        (is_meta ? meta : data).emplace_back(atoi(tail.substr(0, 5).c_str()), atoi(tail.substr(9).c_str()));
+      }
     }
+    closedir(dp);
+    if (data.empty()) throw Error(MHTE_NOT_FOUND, "no checkpoint shards found for " + basename);
+    total = data[0].second;
+    auto complete = [&](std::vector<std::pair<int, int>>& v, const char* what) {
+      std::sort(v.begin(), v.end());
+      bool ok = int(v.size()) == total;
+      for (int i = 0; ok && i < total; ++i) ok = v[size_t(i)].first == i && v[size_t(i)].second == total;
+      if (!ok)
+        throw Error(MHTE_INVALID_ARGUMENT,
+                    std::string("checkpoint ") + basename + ": the " + what + " files are not one "
+                    "complete set of -%05d-of-%05d shards (stale files of another save?)");
+    };
+    complete(data, "data");
+    complete(meta, ".meta");
   }
-  if (!total) throw Error(MHTE_NOT_FOUND, "no checkpoint shards found for " + basename);
   // one thread per shard file: decoding (the long part) runs in parallel, a table is held only
   // while a decoded batch is upserted
   HIP_OK(hipStreamSynchronize(st));

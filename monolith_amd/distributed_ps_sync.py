@@ -200,6 +200,10 @@ class HipBackend(LocalBackend):
         self.owner_prepare(ids)
       self.table.table_step_backward(self.idx, sl.ws_o, None, sl.o_uids[:m], sl.o_nu, grads,
                                      sl.o_grad_u, self.lrs, update_time, global_step)
+      # the displacement pass of this update reads the slot's o_uids / o_grad_u: run it now, in
+      # stream order, so that the side stream's next owner_prepare into this slot (it waits for the
+      # event recorded after apply_gradients) cannot overtake it
+      self.table.table_finish_pending(self.idx)
       sl.owner_n = -1
     else:
       self.table.table_optimize_n(self.idx, ids, None, grads, self.lrs, update_time, global_step,
@@ -276,8 +280,8 @@ class ShardedEmbedding:
     """ids int64 [B] on this rank -> rows fp32 [B, D]."""
     D, be = self.dim, self.backend
     dev = ids.device
-    key = (ids.data_ptr(), ids.numel())
-    if self._pre is not None and self._pre[0] == key:
+    key = self._batch_key(ids)
+    if self._pre is not None and self._same_batch(self._pre[0], key):
       _, disp, ev = self._pre
       if ev is not None:
         torch.cuda.current_stream().wait_event(ev)
@@ -316,8 +320,17 @@ class ShardedEmbedding:
     if next_ids is not None and self._pre is None:
       self._prefetch(next_ids, self._slot)
 
+  @staticmethod
+  def _batch_key(ids):
+    # the tensor object and its version: a buffer refilled in place is a different batch
+    return (ids, getattr(ids, "_version", 0), ids.data_ptr(), ids.numel())
+
+  @staticmethod
+  def _same_batch(a, b):
+    return a[0] is b[0] and a[1] == b[1] and a[2] == b[2] and a[3] == b[3]
+
   def _prefetch(self, ids: torch.Tensor, slot: int):
-    key = (ids.data_ptr(), ids.numel())
+    key = self._batch_key(ids)
     if not ids.is_cuda or not self.prefetch_on_side_stream:
       # (same stream: the dispatch simply runs behind this step's forward)
       self._pre = (key, self._dispatch(ids, slot), None)

@@ -122,15 +122,19 @@ class SparseStep:
       self._joined = True
       self._mode = "plain"
       return self.emb
-    key = (ids.data_ptr(), ids.numel())
+    key = self._batch_key(ids)
     pipelined = (self.fusable and self.fused_backward and not self.ordered_unique and
                  self.batch <= MAX_PIPELINED_BATCH)
     other = 1 - self._cur
-    have = pipelined and self._key[other] == key   # deduplicated ahead by the previous step
+    have = pipelined and self._same_batch(self._key[other], key)   # deduplicated ahead by the previous step
     if have or (pipelined and next_ids is not None):
       if have:
         self._cur = other
       else:  # first step of a pipeline: dedup in stream order
+        # The previous backward may have left ids for the displacement pass, which reads the
+        # unique ids and summed gradients of THIS slot's last batch: it must run before the
+        # slot's buffers are rewritten (a restarted pipeline lost those updates).
+        self.table.table_finish_pending(self.idx)
         self._ws[self._cur].step_dedup(ids, self._uids[self._cur], self._nu[self._cur])
         self._key[self._cur] = key
       nxt = 1 - self._cur
@@ -139,7 +143,7 @@ class SparseStep:
         self.table.table_step_forward(self.idx, ids, self.emb, self._ws[nxt], next_ids,
                                       self._uids[nxt], self._nu[nxt],
                                       ws_cur=self._ws[self._cur] if self.reserve_ahead else None)
-        self._key[nxt] = (next_ids.data_ptr(), next_ids.numel())
+        self._key[nxt] = self._batch_key(next_ids)
       else:
         self.table.table_step_forward(self.idx, ids, self.emb,
                                       ws_cur=self._ws[self._cur] if self.reserve_ahead else None)
@@ -160,6 +164,17 @@ class SparseStep:
     self._mode = "plain"
     self.table.table_lookup_n(self.idx, ids, None, self.emb, n_max=self.batch)
     return self.emb
+
+  @staticmethod
+  def _batch_key(ids):
+    """Identity of a batch handed over as ``next_ids``: the tensor object and its version counter,
+    so a buffer refilled in place (or a freed tensor's address reused by the allocator) is not taken
+    for the batch that was deduplicated ahead."""
+    return (ids, ids._version, ids.data_ptr(), ids.numel())  # pylint: disable=protected-access
+
+  @staticmethod
+  def _same_batch(a, b):
+    return (a is not None and a[0] is b[0] and a[1] == b[1] and a[2] == b[2] and a[3] == b[3])
 
   def _join(self):
     if not self._joined:

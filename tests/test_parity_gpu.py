@@ -1281,3 +1281,71 @@ def test_full_batch_zipf_step_properties_d64_adagrad():
   miss = mt.lookup({"emb": ids_t(absent)})["emb"]
   assert not miss.any().item()
   assert mt.size("emb") == len(seen)
+
+
+# =============================================================================== ADVICE r1 regressions
+def test_pipelined_step_restart_flushes_deferred_ids():
+  """A pipeline that ends (next_ids=None) on a nearly full table leaves ids for the displacement
+  pass; the pipeline is then restarted with other batches, in the same slot and through an id
+  buffer refilled in place.  The deferred updates must land (they read the slot's buffers, which the
+  restart rewrites) and a refilled buffer must not be taken for the batch deduplicated ahead."""
+  cap, dim, n = 1 << 13, 8, 2400
+  mt = make({"a": adagrad_cfg(dim, 0.1, 0.1, initial_capacity=cap, max_load_factor=0.97)})
+  ot = O.Table(O.segment(dim, O.OPT_ADAGRAD, p=(0.1, 0.0)), cap)
+  step = SparseStep(mt, "a", n, exact_order=True)
+  rng = np.random.default_rng(31)
+
+  def batch():
+    ids = rng.integers(1, 2**60, n)
+    ids[n // 2:] = ids[:n - n // 2]
+    return ids
+
+  seen = set()
+  t = [0]
+
+  def train(dev_ids, host_ids, nxt):
+    g = S.grad_batch(t[0], n, dim)
+    emb = step.forward(dev_ids, next_ids=nxt)
+    np.testing.assert_array_equal(emb.cpu().numpy(), ot.lookup(host_ids)[0])
+    step.backward(val_t(g), S.update_time(t[0]))
+    _oracle_step(ot, host_ids, g, dim, 0.1, S.update_time(t[0]))
+    seen.update(host_ids.tolist())
+    t[0] += 1
+
+  b = [batch() for _ in range(6)]
+  d = [ids_t(x) for x in b]
+  train(d[0], b[0], d[1])
+  train(d[1], b[1], None)          # pipeline ends: deferred ids of this update are outstanding
+  train(d[2], b[2], d[3])          # restart: dedups into the slot the deferred pass still reads
+  buf = d[3]                       # deduplicated ahead ...
+  buf.copy_(d[4])                  # ... then refilled in place with another batch
+  train(buf, b[4], None)
+  train(d[5], b[5], None)
+  st = mt.stats("a")
+  assert st.dropped == 0 and st.hashpower == 11 and st.size > 0.5 * cap
+  allids = np.fromiter(seen, dtype=np.int64)
+  np.testing.assert_array_equal(mt.lookup({"a": ids_t(allids)})["a"].cpu().numpy(),
+                                ot.lookup(allids)[0])
+  assert mt.size("a") == ot.size()
+
+
+def test_restore_rejects_a_stale_shard_set(tmp_path):
+  """Two saves under one basename with different shard counts leave two sets of files; the
+  reference validates the set it globs (ValidateShardedFiles), so restore must fail instead of
+  silently taking the smaller, older set."""
+  mt = make({"t": sgd_cfg(4)})
+  mt.assign({"t": (ids_t(np.arange(1, 2001)), torch.ones(2000, 4).cuda())})
+  base = str(tmp_path / "ck")
+  mt.save(base, nshards=2)
+  mt.assign({"t": (ids_t(np.arange(2001, 3001)), torch.ones(1000, 4).cuda())})
+  mt.save(base, nshards=3)
+  mt2 = make({"t": sgd_cfg(4)})
+  with pytest.raises(_lib.MhteError):
+    mt2.restore(base)
+  for f in os.listdir(tmp_path):
+    if f.endswith("-of-00002"):
+      os.remove(os.path.join(tmp_path, f))
+  mt2.restore(base)
+  assert mt2.size("t") == 3000
+  with pytest.raises(_lib.MhteError):
+    mt2.restore(str(tmp_path / "absent"))
