@@ -42,7 +42,7 @@ enum {
 
 const char* mhte_last_error(void);
 /* ABI version of this header; mhte_abi_version() must return the same value. */
-#define MHTE_ABI_VERSION 5
+#define MHTE_ABI_VERSION 7
 int32_t mhte_abi_version(void);
 
 /* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
@@ -55,7 +55,11 @@ enum {                                                                     /* op
   MHTE_OPT_BATCH_SOFTMAX = 10, /* dim_size 1; uses the ops' global_step argument */
   MHTE_OPT_GROUP_ADAGRAD = 11  /* AdaGradWithGroupLasso: one step needs the whole segment */
 };
-enum { MHTE_INIT_ZEROS = 0, MHTE_INIT_ONES = 1, MHTE_INIT_CONSTANT = 2 }; /* initializer_config.proto */
+enum { MHTE_INIT_ZEROS = 0, MHTE_INIT_ONES = 1, MHTE_INIT_CONSTANT = 2, /* initializer_config.proto */
+       MHTE_INIT_RANDOM_UNIFORM = 3 /* uniform in [init_value, init_value2): a counter-based draw per
+                                       element; the reference's thread-local mt19937
+                                       (initializer/random_uniform_initializer.cc:31-37) is not
+                                       reproducible, so parity is distributional */ };
 
 /* EntryConfig.Segment (embedding_hash_table.proto:23-43) */
 typedef struct {
@@ -73,7 +77,8 @@ typedef struct {
                            GROUP_ADAGRAD: {initial_accumulator_value, beta,
                                      l2_regularization_strength, weight_decay_factor} */
   int32_t init_type;    /* MHTE_INIT_* */
-  float init_value;     /* ConstantsInitializerConfig.constant */
+  float init_value;     /* ConstantsInitializerConfig.constant; RandomUniform: minval */
+  float init_value2;    /* RandomUniformInitializerConfig.maxval */
 } mhte_segment_config;
 
 /* EmbeddingHashTableConfig (embedding_hash_table.proto:70-95) + SlotExpireTimeConfig (:54-64) */
@@ -96,9 +101,18 @@ typedef struct {
   int32_t n_slot_occurrence;
   const int64_t* occurrence_slots;      /* host */
   const int32_t* occurrence_thresholds; /* host */
+  /* EmbeddingHashTableConfig.enable_feature_eviction / feature_evict_every_n_hours (:84-87): the
+     reference's bridge runs a thread per table that wakes every 10 s and evicts once that many
+     hours have passed (RT/ops/embedding_hash_table_tf_bridge.cc:73-104).  A scan that rewrites
+     buckets has to be ordered with the table's other work, so here the same check rides on the
+     update entry points (Optimize / FusedOptimize / the step's backward) and the scan is enqueued on
+     their stream. */
+  int32_t enable_feature_eviction;
+  int32_t feature_evict_every_n_hours;  /* <= 0 -> 240 */
 } mhte_table_config;
 
 typedef struct mhte_multi_table mhte_multi_table;
+typedef struct mhte_hash_filter mhte_hash_filter;   /* the admission filter resource, below */
 
 /* CreateMonolithMultiHashTable (RT/ops/multi_hash_table_op.cc:44-112).  `configs` may be in any
  * order; tables are stored sorted by name.  device = HIP device ordinal. */
@@ -106,6 +120,22 @@ mhte_status mhte_multi_table_create(const mhte_table_config* configs, int32_t n_
                                     int32_t device, const char* shared_name,
                                     mhte_multi_table** out);
 void mhte_multi_table_destroy(mhte_multi_table* t);
+/* CreateMonolithMultiHashTable taking its `config` input as is: the serialized
+ * MultiEmbeddingHashTableConfig (RT/hash_table/embedding_hash_table.proto:93-96; names / configs of
+ * different length -> InvalidArgument as RT/ops/multi_hash_table_op.cc:50-53).  `filter` (may be NULL)
+ * is the filter_handle input; its occurrence thresholds (mhte_hash_filter_create_from_proto) become
+ * the tables'.  reserve_rows / max_load_factor: the MI355X extensions of mhte_table_config, applied to
+ * every table (0: defaults).  learning_rates_out (optional, host float[cap]) receives the configs' own
+ * per-segment learning rates in table order (the ops take the live values as an input). */
+mhte_status mhte_multi_table_create_from_proto(const void* config, int64_t config_len,
+                                               mhte_hash_filter* filter, uint64_t reserve_rows,
+                                               float max_load_factor, int32_t device,
+                                               const char* shared_name, float* learning_rates_out,
+                                               int32_t learning_rates_cap, mhte_multi_table** out);
+/* ReadMonolithMultiHashTable / IsHashTableInitialized (RT/ops/multi_hash_table_op.cc:137-166): the
+ * live table created under `shared_name`, or NULL / 0. */
+mhte_multi_table* mhte_multi_table_find(const char* shared_name);
+int32_t mhte_multi_table_is_initialized(const char* shared_name);
 int32_t mhte_num_tables(const mhte_multi_table* t);
 const char* mhte_table_name(const mhte_multi_table* t, int32_t i);
 int32_t mhte_table_dim(const mhte_multi_table* t, int32_t i);        /* dim_size() */
@@ -178,6 +208,23 @@ mhte_status mhte_fused_optimize(mhte_multi_table* t, const int64_t* ids,
                                 int64_t n_learning_rates, int64_t req_time, int64_t global_step,
                                 int32_t num_of_shards, int32_t flags, void* stream);
 
+/* MonolithMultiHashTableLookupEntry (RT/ops/multi_hash_table_lookup_op.cc:91-118,214-223): the
+ * serialized EntryDump (embedding_hash_table.proto:45-50) of every id — what Save writes for it —
+ * and an empty string for an id the table does not hold (cuckoo_embedding_hash_table.cc:174-182).
+ * Strings are host data in TF: entries [host, cap bytes] receives them back to back,
+ * entry_offsets [host, n + 1] where each starts.  *needed = total bytes; cap too small ->
+ * MHTE_INVALID_ARGUMENT with *needed set.  Synchronises. */
+mhte_status mhte_lookup_entry(mhte_multi_table* t, const int64_t* id, const int64_t* id_split,
+                              int64_t n_split, char* entries, int64_t cap, int64_t* entry_offsets,
+                              int64_t* needed, void* stream);
+/* MonolithMultiHashTableFeatureStat (RT/ops/multi_hash_table_save_restore_ops.cc:424-497,522-530):
+ * entries per table name summed over the .meta sidecars of a checkpoint.  names [host, names_cap
+ * bytes]: the names, each NUL-terminated, sorted; counts [host, cap]. */
+mhte_status mhte_feature_stat(const char* basename, char* names, int64_t names_cap, uint64_t* counts,
+                              int32_t cap, int32_t* n_out);
+/* Test hook for the eviction cadence: moves the library's clock forward by `seconds`. */
+void mhte_advance_clock_for_testing(double seconds);
+
 /* ---- introspection / maintenance ----------------------------------------------------------- */
 /* Size() (RT/hash_table/embedding_hash_table_interface.h); synchronises the stream. */
 mhte_status mhte_table_size(mhte_multi_table* t, int32_t table, int64_t* size, void* stream);
@@ -246,9 +293,14 @@ mhte_status mhte_reduce_rows(const int64_t* indices, const float* values, int64_
  * :182-185,300-321); AssignAdd consults the filter without the Contains guard, as the reference's
  * multi-table path does (:230-232).  One filter split; the sliding window over several splits
  * (sliding_hash_filter.cc) is not built, `split_num` is accepted for signature parity. */
-typedef struct mhte_hash_filter mhte_hash_filter;
 mhte_status mhte_hash_filter_create(uint64_t capacity, int32_t split_num, int32_t device,
                                     mhte_hash_filter** out);
+/* the same with the filter op's `config` attr: a serialized SlotOccurrenceThresholdConfig
+ * (embedding_hash_table.proto:100-110).  Tables created from a proto with this filter attached take
+ * their occurrence thresholds from it. */
+mhte_status mhte_hash_filter_create_from_proto(uint64_t capacity, int32_t split_num,
+                                               const void* config, int64_t config_len,
+                                               int32_t device, mhte_hash_filter** out);
 void mhte_hash_filter_destroy(mhte_hash_filter* f);
 mhte_status mhte_multi_table_set_filter(mhte_multi_table* t, mhte_hash_filter* f /* NULL detaches */);
 /* Filter::get: the seen count of ids (0..15), out [dev u32, n] */

@@ -9,7 +9,7 @@ _SO = os.path.join(_DIR, "libmhte.so")
 _SRC = os.path.join(_DIR, "csrc", "mhte.hip")
 _DEPS = [_SRC] + [os.path.join(_DIR, "csrc", h) for h in
                   ("mhte_kernels.h", "mhte_core.h", "mhte_step_kernels.h", "mhte_pool_kernels.h",
-                   "mhte_ckpt.h", "mhte_mstep_kernels.h", "mhte_mstep_host.h")] + [os.path.join(_DIR, "..", "include", "monolith_amd_hash_table.h")]
+                   "mhte_ckpt.h", "mhte_mstep_kernels.h", "mhte_mstep_host.h", "mhte_proto_config.h")] + [os.path.join(_DIR, "..", "include", "monolith_amd_hash_table.h")]
 # A/B measurements: MHTE_LIBRARY=<other build of libmhte.so> (same ABI) is loaded instead
 _OVERRIDE = os.environ.get("MHTE_LIBRARY")
 
@@ -25,12 +25,12 @@ MHTE_IDS_UNIQUE = 1
 MHTE_SUM_DUPLICATES = 2
 MHTE_EXACT_ORDER = 1       # flags of mhte_table_sum_optimize_n
 MHTE_DEFER_SLOWPATH = 2
-ABI_VERSION = 5            # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
+ABI_VERSION = 7            # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 OPT_MOMENTUM, OPT_ADADELTA, OPT_RMSPROP, OPT_RMSPROPV2, OPT_ADAM, OPT_AMSGRAD = 3, 4, 5, 6, 7, 8
 OPT_MOVING_AVERAGE, OPT_BATCH_SOFTMAX, OPT_GROUP_ADAGRAD = 9, 10, 11
-INIT_ZEROS, INIT_ONES, INIT_CONSTANT = 0, 1, 2
+INIT_ZEROS, INIT_ONES, INIT_CONSTANT, INIT_RANDOM_UNIFORM = 0, 1, 2, 3
 
 
 class MhteError(RuntimeError):
@@ -52,7 +52,7 @@ class ResourceExhaustedError(MhteError):
 
 class SegmentConfig(C.Structure):
   _fields_ = [("dim_size", C.c_int32), ("opt_type", C.c_int32), ("opt_params", C.c_float * 8),
-              ("init_type", C.c_int32), ("init_value", C.c_float)]
+              ("init_type", C.c_int32), ("init_value", C.c_float), ("init_value2", C.c_float)]
 
 
 class TableConfig(C.Structure):
@@ -63,7 +63,8 @@ class TableConfig(C.Structure):
               ("expire_slots", C.POINTER(C.c_int64)), ("expire_days", C.POINTER(C.c_int32)),
               ("default_occurrence_threshold", C.c_int32), ("n_slot_occurrence", C.c_int32),
               ("occurrence_slots", C.POINTER(C.c_int64)),
-              ("occurrence_thresholds", C.POINTER(C.c_int32))]
+              ("occurrence_thresholds", C.POINTER(C.c_int32)),
+              ("enable_feature_eviction", C.c_int32), ("feature_evict_every_n_hours", C.c_int32)]
 
 
 class TableStats(C.Structure):
@@ -116,6 +117,9 @@ EXPORTS = [
     "mhte_fused_gather_embeddings_by_input_gradient", "mhte_reduce_rows",
     "mhte_multi_step_create", "mhte_multi_step_destroy", "mhte_multi_step_forward",
     "mhte_multi_step_backward", "mhte_multi_step_unique_counts",
+    "mhte_multi_table_create_from_proto", "mhte_multi_table_find", "mhte_multi_table_is_initialized",
+    "mhte_hash_filter_create_from_proto", "mhte_lookup_entry", "mhte_feature_stat",
+    "mhte_advance_clock_for_testing",
 ]
 
 _lib = None
@@ -150,6 +154,11 @@ def lib():
     L.mhte_multi_table_destroy.restype = None
     L.mhte_dedup_ws_destroy.restype = None
     L.mhte_hash_filter_destroy.restype = None
+    L.mhte_multi_table_find.restype = C.c_void_p
+    L.mhte_multi_table_find.argtypes = [C.c_char_p]
+    L.mhte_multi_table_is_initialized.argtypes = [C.c_char_p]
+    L.mhte_advance_clock_for_testing.restype = None
+    L.mhte_advance_clock_for_testing.argtypes = [C.c_double]
     L.mhte_multi_step_destroy.restype = None
     L.mhte_multi_step_destroy.argtypes = [C.c_void_p]
     L.mhte_hash_filter_destroy.argtypes = [C.c_void_p]

@@ -30,6 +30,8 @@
 #include <ctype.h>
 
 #include "mhte_ckpt.h"
+#include "mhte_proto_config.h"
+#include <map>
 #include "mhte_pool_kernels.h"
 #include "mhte_step_kernels.h"
 #include "mhte_mstep_kernels.h"
@@ -369,6 +371,14 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
     }                                                                \
   } while (0)
 
+// ------------------------------------------------------------------------------------------ clock
+// seconds on a monotonic clock (+ the test hook's offset): the eviction cadence
+static std::atomic<double> g_clock_offset{0.0};
+static double lib_now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() +
+         g_clock_offset.load();
+}
+
 // ------------------------------------------------------------------------------------------ table
 // global_step of the API call being served on this thread (every entry point is synchronous on
 // its caller's thread); read by Table::upsert for the one optimizer that uses it (batch softmax)
@@ -444,7 +454,7 @@ struct Table {
       if (s.dim_size <= 0) throw Error(MHTE_INVALID_ARGUMENT, "segment dim_size must be > 0");
       if (s.opt_type < MHTE_OPT_SGD || s.opt_type >= kOptCount)
         throw Error(MHTE_INVALID_ARGUMENT, "unknown optimizer type " + std::to_string(s.opt_type));
-      if (s.init_type < MHTE_INIT_ZEROS || s.init_type > MHTE_INIT_CONSTANT)
+      if (s.init_type < MHTE_INIT_ZEROS || s.init_type > MHTE_INIT_RANDOM_UNIFORM)
         throw Error(MHTE_INVALID_ARGUMENT, "unknown initializer type");
       if (s.opt_type == MHTE_OPT_BATCH_SOFTMAX && s.dim_size != 1)  // batch_softmax_optimizer.cc:29
         throw Error(MHTE_INVALID_ARGUMENT, "a batch softmax segment has dim_size 1");
@@ -463,6 +473,7 @@ struct Table {
       for (int k = 0; k < 8; ++k) d.p[k] = segs[i].opt_params[k];
       d.init = segs[i].init_type;
       d.init_value = segs[i].init_value;
+      d.init_value2 = segs[i].init_value2;
       if ((d.dim % 4) || (d.w_off % 4) || (d.st_off % 4)) vec_ok = false;
       w += d.dim;
       st += uint32_t(opt_state_floats(d.opt, d.dim));
@@ -490,6 +501,9 @@ struct Table {
       HIP_OK(hipMemcpy(d_occ_slots.p, occ_slots.data(), occ_slots.size() * 8, hipMemcpyHostToDevice));
       HIP_OK(hipMemcpy(d_occ_thr.p, occ_thr.data(), occ_thr.size() * 4, hipMemcpyHostToDevice));
     }
+    evict_enabled = c.enable_feature_eviction != 0;
+    evict_every_s = (c.feature_evict_every_n_hours > 0 ? c.feature_evict_every_n_hours : 240) * 3600.0;
+    last_evict = last_evict_check = lib_now();
     hp = reserve_calc(c.initial_capacity ? c.initial_capacity : 1);
     if (hp > 34) throw Error(MHTE_INVALID_ARGUMENT, "initial_capacity too large");
     alloc_buckets(hp, &buckets, nullptr);
@@ -974,6 +988,26 @@ struct Table {
     max_update_ts = std::max(max_update_ts, update_time);
   }
 
+  // Feature eviction cadence (tf_bridge.cc:73-104: a thread per table wakes every 10 s and runs
+  // Evict(max_update_ts) once feature_evict_every_n_hours have passed since the last one).  Called by
+  // the update entry points with their stream: the scan is ordered with the table's other work.
+  bool evict_enabled = false;
+  double evict_every_s = 240 * 3600.0;
+  double last_evict = 0, last_evict_check = 0;
+  uint64_t evict_runs = 0;
+  void maybe_evict(hipStream_t st) {
+    if (!evict_enabled) return;
+    const double now = lib_now();
+    if (now - last_evict_check < 10.0) return;
+    last_evict_check = now;
+    if (now - last_evict < evict_every_s) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return;
+    evict(-1, st);
+    last_evict = now;
+    ++evict_runs;
+  }
+
   void evict(int64_t max_ts, hipStream_t st) {
     finish_pending(st);
     ++mut_epoch;
@@ -1003,10 +1037,19 @@ struct mhte_multi_table {
 struct mhte_dedup_ws {
   mhte::DedupWs ws;
 };
+// live tables by shared_name (the TF ResourceMgr's role for ReadMonolithMultiHashTable /
+// IsHashTableInitialized)
+static std::mutex g_registry_mu;
+static std::map<std::string, mhte_multi_table*> g_registry;
 struct mhte_hash_filter {
   int device = 0;
   uint32_t* slots = nullptr;
   uint64_t total = 0;
+  // SlotOccurrenceThresholdConfig given with the filter (mhte_hash_filter_create_from_proto)
+  bool has_occ = false;
+  int32_t occ_default = 0;
+  std::vector<int64_t> occ_slots;
+  std::vector<int32_t> occ_thr;
   ~mhte_hash_filter() {
     if (slots) {
       (void)hipSetDevice(device);
@@ -1081,6 +1124,7 @@ static void ragged_upsert(mhte_multi_table* t, const int64_t* id, const int64_t*
     tb.note_update_time(update_time);
     tb.upsert<OP>(id + id_split[i], num_ids, nullptr, value + value_offset, lrs, update_time, flags,
                   nullptr, S(stream));
+    if (OP == kOpOptimize) tb.maybe_evict(S(stream));
     value_offset += value_size;
   }
 }
@@ -1132,10 +1176,32 @@ mhte_status mhte_multi_table_create(const mhte_table_config* configs, int32_t n_
     }
     HIP_OK(hipDeviceSynchronize());
     *out = mt.release();
+    if (!(*out)->shared_name.empty()) {
+      std::lock_guard<std::mutex> g(g_registry_mu);
+      g_registry[(*out)->shared_name] = *out;
+    }
   });
 }
 
-void mhte_multi_table_destroy(mhte_multi_table* t) { delete t; }
+void mhte_multi_table_destroy(mhte_multi_table* t) {
+  if (t) {
+    std::lock_guard<std::mutex> g(g_registry_mu);
+    auto it = g_registry.find(t->shared_name);
+    if (it != g_registry.end() && it->second == t) g_registry.erase(it);
+  }
+  delete t;
+}
+
+mhte_multi_table* mhte_multi_table_find(const char* shared_name) {
+  if (!shared_name) return nullptr;
+  std::lock_guard<std::mutex> g(g_registry_mu);
+  auto it = g_registry.find(shared_name);
+  return it == g_registry.end() ? nullptr : it->second;
+}
+int32_t mhte_multi_table_is_initialized(const char* shared_name) {
+  return mhte_multi_table_find(shared_name) ? 1 : 0;
+}
+void mhte_advance_clock_for_testing(double seconds) { g_clock_offset.store(g_clock_offset.load() + seconds); }
 int32_t mhte_num_tables(const mhte_multi_table* t) { return t ? int32_t(t->tables.size()) : 0; }
 const char* mhte_table_name(const mhte_multi_table* t, int32_t i) {
   return (t && i >= 0 && i < int32_t(t->tables.size())) ? t->tables[i]->name.c_str() : "";
@@ -1354,6 +1420,7 @@ mhte_status mhte_fused_optimize(mhte_multi_table* t, const int64_t* ids,
         tb.note_update_time(req_time);
         tb.upsert<kOpOptimize>(ids + id_offsets[idx], n, nullptr, id_grads + grad_offsets[idx], lrs,
                                req_time, flags, nullptr, S(stream));
+        if (s == num_of_shards - 1) tb.maybe_evict(S(stream));
       }
     }
   });
@@ -1830,7 +1897,8 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
       std::vector<float> init(rf, 0.f);
       for (uint32_t k = 0; k < tb.nseg; ++k) {
         const SegDesc& d = tb.view.seg[k];
-        const float w0 = init_weight(d);
+        // (a dump always carries `num`: the initial weight only stands in until it is overwritten)
+        const float w0 = d.init == kInitRandomUniform ? 0.f : init_weight(d, nullptr);
         const int nv = opt_vectors(d.opt);
         for (int e = 0; e < d.dim; ++e) {
           init[size_t(d.w_off + e)] = w0;
@@ -1882,12 +1950,12 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
   }
 }
 
-static void restore_multi_table(mhte_multi_table* t, const std::string& basename, hipStream_t st) {
-  // The shard set is what the directory holds under <basename>-%05d-of-%05d (the reference globs
-  // <basename>-* and validates the set, ValidateShardedFiles,
-  // multi_hash_table_save_restore_ops.cc:323-349): one consistent total, every data shard and every
-  // .meta sidecar present.  Leftovers of an earlier save with another shard count are an error, not
-  // something to restore silently.
+// The shard set of a checkpoint: what the directory holds under <basename>-%05d-of-%05d (the
+// reference globs <basename>-* and validates the set, ValidateShardedFiles,
+// multi_hash_table_save_restore_ops.cc:323-349): one consistent total, every data shard and every
+// .meta sidecar present.  Leftovers of an earlier save with another shard count are an error, not
+// something to restore silently.
+static int discover_shards(const std::string& basename) {
   int total = 0;
   {
     const size_t slash = basename.find_last_of('/');
@@ -1925,6 +1993,11 @@ static void restore_multi_table(mhte_multi_table* t, const std::string& basename
     complete(data, "data");
     complete(meta, ".meta");
   }
+  return total;
+}
+
+static void restore_multi_table(mhte_multi_table* t, const std::string& basename, hipStream_t st) {
+  const int total = discover_shards(basename);
   // one thread per shard file: decoding (the long part) runs in parallel, a table is held only
   // while a decoded batch is upserted
   HIP_OK(hipStreamSynchronize(st));
@@ -2104,6 +2177,7 @@ mhte_status mhte_table_optimize_n(mhte_multi_table* t, int32_t table, const int6
     tb.note_update_time(update_time);
     tb.upsert<kOpOptimize>(id, n_max, n_dev, value, learning_rate, update_time, flags, nullptr,
                            S(stream));
+    tb.maybe_evict(S(stream));
   });
 }
 
@@ -2131,6 +2205,7 @@ mhte_status mhte_table_sum_optimize_n(mhte_multi_table* t, int32_t table, mhte_d
       tb.sum_optimize(ws->ws, unique_ids, n_max, n_unique_dev, grads, list_start, list_end,
                       seg_pos, n, grad_unique, learning_rate, update_time,
                       (flags & MHTE_EXACT_ORDER) != 0, (flags & MHTE_DEFER_SLOWPATH) != 0, st);
+      if (!(flags & MHTE_DEFER_SLOWPATH)) tb.maybe_evict(st);
       return;
     }
     // wide rows: segment sum, then the ordinary upsert over the unique ids (needs the CSR form of
@@ -2299,6 +2374,11 @@ mhte_status mhte_table_step_backward(mhte_multi_table* t, int32_t table, mhte_de
     tb.step_backward(ws->ws, ws_next ? &ws_next->ws : nullptr, unique_ids, n_max, n_unique_dev,
                      grads, n, grad_unique, learning_rate, update_time,
                      (flags & MHTE_EXACT_ORDER) != 0, S(stream));
+    if (tb.evict_enabled && lib_now() - tb.last_evict >= tb.evict_every_s) {
+      // (the scan must not overtake the displacement pass this update left for the next forward)
+      tb.finish_pending(S(stream));
+      tb.maybe_evict(S(stream));
+    }
   });
 }
 
@@ -2379,6 +2459,213 @@ mhte_status mhte_table_set_count_hits(mhte_multi_table* t, int32_t table, int32_
     std::lock_guard<std::mutex> g(tb.mu);
     tb.count_hits = enable != 0;
     ++tb.view_version;
+  });
+}
+
+// ---- boundary completion: proto configs, entry lookup, feature stat -------------------------------
+mhte_status mhte_hash_filter_create_from_proto(uint64_t capacity, int32_t split_num,
+                                               const void* config, int64_t config_len,
+                                               int32_t device, mhte_hash_filter** out) {
+  mhte_status st = mhte_hash_filter_create(capacity, split_num, device, out);
+  if (st != MHTE_OK) return st;
+  return guard([&] {
+    try {
+      mhte_hash_filter* f = *out;
+      if (config && config_len > 0) {
+        pcfg::parse_occurrence(config, size_t(config_len), &f->occ_default, &f->occ_slots, &f->occ_thr);
+        f->has_occ = true;
+      }
+    } catch (const ckpt::ProtoError& e) {
+      mhte_hash_filter_destroy(*out);
+      *out = nullptr;
+      throw Error(MHTE_INVALID_ARGUMENT, e.what());
+    }
+  });
+}
+
+mhte_status mhte_multi_table_create_from_proto(const void* config, int64_t config_len,
+                                               mhte_hash_filter* filter, uint64_t reserve_rows,
+                                               float max_load_factor, int32_t device,
+                                               const char* shared_name, float* learning_rates_out,
+                                               int32_t learning_rates_cap, mhte_multi_table** out) {
+  std::vector<pcfg::TableCfg> tabs;
+  mhte_status st = guard([&] {
+    if (!config || config_len <= 0 || !out) throw Error(MHTE_INVALID_ARGUMENT, "create: bad arguments");
+    try {
+      tabs = pcfg::parse_multi(config, size_t(config_len));
+    } catch (const ckpt::ProtoError& e) {
+      throw Error(MHTE_INVALID_ARGUMENT, std::string("Unable to parse config: ") + e.what());
+    }
+    if (tabs.empty()) throw Error(MHTE_INVALID_ARGUMENT, "config holds no table");
+  });
+  if (st != MHTE_OK) return st;
+  std::vector<std::vector<mhte_segment_config>> segs(tabs.size());
+  std::vector<mhte_table_config> cfgs(tabs.size());
+  for (size_t i = 0; i < tabs.size(); ++i) {
+    const pcfg::TableCfg& t = tabs[i];
+    for (const auto& s : t.segs) segs[i].push_back(s.c);
+    mhte_table_config& c = cfgs[i];
+    memset(&c, 0, sizeof(c));
+    c.name = t.name.c_str();
+    c.n_segments = int32_t(segs[i].size());
+    c.segments = segs[i].data();
+    c.initial_capacity = t.initial_capacity;
+    c.reserve_rows = reserve_rows;
+    c.max_load_factor = max_load_factor;
+    c.default_expire_days = t.default_expire;
+    c.n_slot_expire = int32_t(t.expire_slots.size());
+    c.expire_slots = t.expire_slots.data();
+    c.expire_days = t.expire_days.data();
+    if (filter && filter->has_occ) {
+      c.default_occurrence_threshold = filter->occ_default;
+      c.n_slot_occurrence = int32_t(filter->occ_slots.size());
+      c.occurrence_slots = filter->occ_slots.data();
+      c.occurrence_thresholds = filter->occ_thr.data();
+    }
+    c.enable_feature_eviction = t.enable_eviction ? 1 : 0;
+    c.feature_evict_every_n_hours = t.evict_every_n_hours;
+  }
+  st = mhte_multi_table_create(cfgs.data(), int32_t(cfgs.size()), device, shared_name, out);
+  if (st != MHTE_OK) return st;
+  if (filter) {
+    st = mhte_multi_table_set_filter(*out, filter);
+    if (st != MHTE_OK) {
+      mhte_multi_table_destroy(*out);
+      *out = nullptr;
+      return st;
+    }
+  }
+  if (learning_rates_out) {  // sorted-name order, like the tables
+    int32_t k = 0;
+    for (auto& tb : (*out)->tables)
+      for (const auto& t : tabs)
+        if (t.name == tb->name)
+          for (const auto& s : t.segs)
+            if (k < learning_rates_cap) learning_rates_out[k++] = s.learning_rate;
+  }
+  return MHTE_OK;
+}
+
+namespace mhte {
+// one thread per id: probe, then found flag, timestamp and the whole row (weights | optimizer ctx)
+__global__ __launch_bounds__(256) void entry_fetch_kernel(TableView tv, const int64_t* __restrict__ ids,
+                                                          int64_t n, int32_t* __restrict__ found,
+                                                          uint32_t* __restrict__ ts,
+                                                          float* __restrict__ rows) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t id = ids[i];
+  uint32_t r = kNoRow, t = 0;
+  if (id == kEmptyKey) {
+    if (tv.ctr->special_state == 1) {
+      r = tv.ctr->special_row;
+      t = tv.ctr->special_ts;
+    }
+  } else {
+    const uint64_t hv = hash_key(id);
+    const uint64_t i1 = index_hash(tv.hp, hv);
+    const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
+    for (int s = 0; s < kSlots; ++s) {
+      if (tv.buckets[i1].key[s] == id) { r = tv.buckets[i1].row[s]; t = tv.buckets[i1].ts[s]; }
+      if (tv.buckets[i2].key[s] == id) { r = tv.buckets[i2].row[s]; t = tv.buckets[i2].ts[s]; }
+    }
+  }
+  found[i] = r != kNoRow;
+  ts[i] = t;
+  if (r != kNoRow) {
+    const float* rp = row_ptr(tv, r);
+    for (uint32_t e = 0; e < tv.row_floats; ++e) rows[i * tv.row_floats + e] = rp[e];
+  }
+}
+}  // namespace mhte
+
+mhte_status mhte_lookup_entry(mhte_multi_table* t, const int64_t* id, const int64_t* id_split,
+                              int64_t n_split, char* entries, int64_t cap, int64_t* entry_offsets,
+                              int64_t* needed, void* stream) {
+  return guard([&] {
+    check_handle(t);
+    if (!id_split || n_split != int64_t(t->tables.size()) + 1)  // multi_hash_table_lookup_op.cc:101-103
+      throw Error(MHTE_INVALID_ARGUMENT, "id_split must be " + std::to_string(t->tables.size() + 1) +
+                                             ". Current: " + std::to_string(n_split));
+    if (!entry_offsets || !needed) throw Error(MHTE_INVALID_ARGUMENT, "lookup_entry: null argument");
+    HIP_OK(hipSetDevice(t->device));
+    hipStream_t st = S(stream);
+    std::string all, rec;
+    std::vector<int64_t> offs;
+    offs.push_back(0);
+    for (size_t k = 0; k < t->tables.size(); ++k) {
+      Table& tb = *t->tables[k];
+      const int64_t n = id_split[k + 1] - id_split[k];
+      if (n < 0) throw Error(MHTE_INVALID_ARGUMENT, "id_split not monotonic");
+      if (n == 0) continue;
+      std::lock_guard<std::mutex> g(tb.mu);
+      tb.finish_pending(st);
+      DevBuf<int32_t> d_found;
+      DevBuf<uint32_t> d_ts;
+      DevBuf<float> d_rows;
+      d_found.reserve(n);
+      d_ts.reserve(n);
+      d_rows.reserve(size_t(n) * tb.row_floats);
+      entry_fetch_kernel<<<dim3(uint32_t((n + 255) / 256)), 256, 0, st>>>(
+          tb.view, id + id_split[k], n, d_found.p, d_ts.p, d_rows.p);
+      HIP_OK(hipGetLastError());
+      std::vector<int64_t> h_ids(n);
+      std::vector<int32_t> h_found(n);
+      std::vector<uint32_t> h_ts(n);
+      std::vector<float> h_rows(size_t(n) * tb.row_floats);
+      HIP_OK(hipMemcpyAsync(h_ids.data(), id + id_split[k], n * 8, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipMemcpyAsync(h_found.data(), d_found.p, n * 4, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipMemcpyAsync(h_ts.data(), d_ts.p, n * 4, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipMemcpyAsync(h_rows.data(), d_rows.p, h_rows.size() * 4, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipStreamSynchronize(st));
+      const std::vector<ckpt::SegLayout> segs = seg_layout(tb);
+      for (int64_t i = 0; i < n; ++i) {
+        if (h_found[size_t(i)]) {
+          ckpt::encode_entry(rec, h_ids[size_t(i)], h_rows.data() + size_t(i) * tb.row_floats, segs,
+                             int(tb.dim), h_ts[size_t(i)]);
+          all += rec;
+        }
+        offs.push_back(int64_t(all.size()));
+      }
+    }
+    *needed = int64_t(all.size());
+    memcpy(entry_offsets, offs.data(), offs.size() * sizeof(int64_t));
+    if (int64_t(all.size()) > cap || (!entries && !all.empty()))
+      throw Error(MHTE_INVALID_ARGUMENT, "lookup_entry: entries buffer too small: need " +
+                                             std::to_string(all.size()));
+    if (!all.empty()) memcpy(entries, all.data(), all.size());
+  });
+}
+
+mhte_status mhte_feature_stat(const char* basename, char* names, int64_t names_cap, uint64_t* counts,
+                              int32_t cap, int32_t* n_out) {
+  return guard([&] {
+    if (!basename || !*basename || !n_out) throw Error(MHTE_INVALID_ARGUMENT, "feature_stat: bad arguments");
+    const int total = discover_shards(basename);
+    std::map<std::string, uint64_t> stat;
+    for (int sh = 0; sh < total; ++sh) {
+      ckpt::RecordReader meta(ckpt::shard_name(basename, ".meta", sh, total), false);
+      std::string rec, name;
+      try {
+        while (meta.read(&rec)) {
+          uint64_t num = 0;
+          ckpt::decode_meta(reinterpret_cast<const uint8_t*>(rec.data()), rec.size(), &name, &num);
+          stat[name] += num;
+        }
+      } catch (const std::exception& e) {
+        throw Error(MHTE_INTERNAL, std::string("DataLoss: Read table metadata failed! ") + e.what());
+      }
+    }
+    *n_out = int32_t(stat.size());
+    int64_t off = 0;
+    int32_t k = 0;
+    for (auto& kv : stat) {
+      if (k >= cap || off + int64_t(kv.first.size()) + 1 > names_cap)
+        throw Error(MHTE_INVALID_ARGUMENT, "feature_stat: output buffers too small");
+      memcpy(names + off, kv.first.c_str(), kv.first.size() + 1);
+      off += int64_t(kv.first.size()) + 1;
+      counts[k++] = kv.second;
+    }
   });
 }
 

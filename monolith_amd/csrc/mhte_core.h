@@ -44,7 +44,7 @@ enum OptType : int32_t {
   kOptMovingAverage = 9, kOptBatchSoftmax = 10, kOptGroupAdagrad = 11,
   kOptCount = 12
 };
-enum InitType : int32_t { kInitZeros = 0, kInitOnes = 1, kInitConstant = 2 };
+enum InitType : int32_t { kInitZeros = 0, kInitOnes = 1, kInitConstant = 2, kInitRandomUniform = 3 };
 
 // One 64-byte line per bucket: 4 keys, 4 row handles, 4 uint32 timestamps.  The reference's
 // PACKED bucket is 4 x (int64 key + {u32 EntryAddress,u32 ts}) + 4 partial + 4 occupied = 72 B
@@ -70,7 +70,8 @@ struct SegDesc {
                     // rmsprop / rmspropv2: {momentum, weight_decay_factor, config learning_rate}
                     // adam / amsgrad: {beta1, beta2, epsilon, weight_decay_factor, use_nesterov}
   int32_t init;     // InitType
-  float init_value; // constants initializer value
+  float init_value; // constants initializer value; random uniform: minval
+  float init_value2; // random uniform: maxval
 };
 
 // fmix64 (murmur3 finaliser).  Stands in for absl::Hash<int64_t> (cuckoohash_map.hpp:64-70), which
@@ -411,7 +412,17 @@ MHTE_HD void adam_step(float& w, float& m, float& v, float* vhat, float grad, fl
   v = new_v;
 }
 
-MHTE_HD float init_weight(const SegDesc& s) {
+// Initial value of the weight stored at `where` (initializer/{zeros,ones,constants,random_uniform}
+// _initializer.cc).  RandomUniform: the reference draws from a thread-local mt19937
+// (random_uniform_initializer.cc:31-37), i.e. values depend on which thread inserted what and are
+// not reproducible; here the draw is a counter-based hash of the element's address — uniform in
+// [minval, maxval), independent between elements, nothing to seed or to synchronise.
+MHTE_HD float init_weight(const SegDesc& s, const float* where) {
+  if (s.init == kInitRandomUniform) {
+    const uint64_t h = hash_key(static_cast<int64_t>(reinterpret_cast<uintptr_t>(where)) ^ 0x5851f42d4c957f2dLL);
+    const float u = static_cast<float>(h >> 40) * (1.0f / 16777216.0f);  // 24 bits -> [0, 1)
+    return s.init_value + (s.init_value2 - s.init_value) * u;
+  }
   return s.init == kInitOnes ? 1.f : (s.init == kInitConstant ? s.init_value : 0.f);
 }
 

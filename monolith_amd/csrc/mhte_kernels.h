@@ -473,13 +473,12 @@ __device__ __forceinline__ void group_adagrad_segment(const TableView& tv, float
   float* sc = rp + sd.st_off;
   float gss = is_new ? sd.p[0] : sc[0];
   if (is_new) {
-    const float w0 = init_weight(sd);
     for (uint32_t t = t0; t < t1; ++t) {
       const uint32_t e = uint32_t(j) * VEC + t * G * VEC;
       if (e >= lo && e < hi) {
         Vec<VEC> w;
 #pragma unroll
-        for (int c = 0; c < VEC; ++c) w.v[c] = w0;
+        for (int c = 0; c < VEC; ++c) w.v[c] = init_weight(sd, rp + e + c);
         w.store(rp + e);
       }
     }
@@ -616,10 +615,9 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
     const bool bsm = !BASIC && sd.opt == kOptBatchSoftmax;  // the slot holds the id's last global step
     long long last_step = 0;
     if (is_new || OP == kOpReinit) {
-      const float w0 = init_weight(sd);
 #pragma unroll
       for (int c = 0; c < VEC; ++c) {
-        w.v[c] = w0;
+        w.v[c] = init_weight(sd, rp + e + c);
         s1.v[c] = opt_state_init(sd, 0);
         s2.v[c] = opt_state_init(sd, 1);
         s3.v[c] = opt_state_init(sd, 2);
@@ -2275,10 +2273,9 @@ __device__ __forceinline__ void optimize_row_reg(const TableView& tv, float* rp,
   const bool has1 = sd.opt == kOptAdagrad || sd.opt == kOptFtrl;
   const bool has2 = sd.opt == kOptFtrl;
   if (is_new) {
-    const float w0 = init_weight(sd);
 #pragma unroll
     for (int c = 0; c < VEC; ++c) {
-      w.v[c] = w0;
+      w.v[c] = init_weight(sd, rp + e + c);
       s1.v[c] = sd.p[0];
       s2.v[c] = 0.f;
     }

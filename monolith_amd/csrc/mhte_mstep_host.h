@@ -502,6 +502,8 @@ struct MultiStep {
     const bool build_next = stage[nxt] == 1;
     if (build_next) join_dedup(nxt, st);
     launch_bwd(p, cur, build_next, st);
+    for (uint32_t t = 0; t < T; ++t)
+      if (n_slot[cur][t]) mt->tables[t]->maybe_evict(st);  // (cadence of the reference's bridge)
     stage[cur] = 0;
     has_hints[cur] = false;
     if (build_next) stage[nxt] = 2;
@@ -619,6 +621,8 @@ static void fused_optimize_segments(mhte_multi_table* t, const int64_t* ids,
     for (int k = 0; k < T; ++k)
       if (per_table[size_t(k)]) ++t->tables[k]->mut_epoch;
   }
+  for (int k = 0; k < T; ++k)
+    if (per_table[size_t(k)]) t->tables[k]->maybe_evict(st);
 }
 
 }  // namespace mhte

@@ -525,10 +525,9 @@ __device__ __forceinline__ void optimize_row_pre(const TableView& tv, float* rp,
   Vec<VEC> s2;
   vec_zero(s2);
   if (is_new) {
-    const float w0 = init_weight(sd);
 #pragma unroll
     for (int c = 0; c < VEC; ++c) {
-      r.w.v[c] = w0;
+      r.w.v[c] = init_weight(sd, rp + e + c);
       r.s1.v[c] = sd.p[0];
     }
   } else if (has2) {

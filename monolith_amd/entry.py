@@ -203,6 +203,17 @@ class ConstantsInitializer(Initializer):
     self.value = float(constant)
 
 
+class RandomUniformInitializer(Initializer):
+  """reference entry.py:426-440 (proto defaults minval -0.05, maxval 0.05,
+  initializer_config.proto).  Draws are counter-based per element on the device; the reference's
+  generator is thread-local and unseeded, so only the distribution is comparable."""
+  init_type = _lib.INIT_RANDOM_UNIFORM
+
+  def __init__(self, minval: float = -0.05, maxval: float = 0.05):
+    self.value = float(minval)
+    self.value2 = float(maxval)
+
+
 class Fp32Compressor:
   """reference entry.py:505-511 — training rows are fp32; the serving-side compressors are out of
   scope."""

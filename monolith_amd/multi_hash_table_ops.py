@@ -61,6 +61,7 @@ def _lower_config(name: str, cfg: entry.HashTableConfigInstance, keep: list):
       segs[i].opt_params[k] = v
     segs[i].init_type = s.initializer.init_type
     segs[i].init_value = s.initializer.value
+    segs[i].init_value2 = getattr(s.initializer, "value2", 0.0)
   c = _lib.TableConfig()
   bname = name.encode()
   c.name = bname
@@ -83,6 +84,8 @@ def _lower_config(name: str, cfg: entry.HashTableConfigInstance, keep: list):
   c.n_slot_occurrence = int(oslots.size)
   c.occurrence_slots = _i64p(oslots)
   c.occurrence_thresholds = _i32p(othr)
+  c.enable_feature_eviction = 1 if tc.enable_feature_eviction else 0
+  c.feature_evict_every_n_hours = int(tc.feature_evict_every_n_hours)
   keep.extend([segs, bname, slots, days, oslots, othr])
   return c
 
@@ -92,14 +95,21 @@ class HashFilter:
   ``filter_handle`` input of CreateMonolithMultiHashTable): a counting admission filter in HBM,
   shared by the tables of the MultiHashTable it is attached to."""
 
-  def __init__(self, capacity: int = 300000000, split_num: int = 7, device: Optional[int] = None):
+  def __init__(self, capacity: int = 300000000, split_num: int = 7, device: Optional[int] = None,
+               config: Optional[bytes] = None):
+    """``config``: serialized SlotOccurrenceThresholdConfig, the hash filter op's attr."""
     if not torch.cuda.is_available():
       raise _lib.MhteError(_lib.MHTE_UNAVAILABLE, "HashFilter needs a HIP device")
     self._lib = _lib.lib()
     self._device = torch.cuda.current_device() if device is None else int(device)
     h = C.c_void_p()
-    check(self._lib.mhte_hash_filter_create(C.c_uint64(int(capacity)), C.c_int32(int(split_num)),
-                                            C.c_int32(self._device), C.byref(h)))
+    if config is None:
+      check(self._lib.mhte_hash_filter_create(C.c_uint64(int(capacity)), C.c_int32(int(split_num)),
+                                              C.c_int32(self._device), C.byref(h)))
+    else:
+      check(self._lib.mhte_hash_filter_create_from_proto(
+          C.c_uint64(int(capacity)), C.c_int32(int(split_num)), config, C.c_int64(len(config)),
+          C.c_int32(self._device), C.byref(h)))
     self._h = h
 
   def get(self, ids: torch.Tensor) -> torch.Tensor:
@@ -162,16 +172,8 @@ class MultiHashTable:
     MultiHashTable._names_in_use.add(self._shared_name)
     self._slice_sizes = tuple(
         self._lib.mhte_table_slice_size(self._h, i) for i in range(len(self._table_names)))
-    # Feature eviction (tf_bridge.cc:73-104: a thread per table wakes every 10 s and evicts once
-    # `feature_evict_every_n_hours` have passed).  A scan that rewrites buckets must be ordered with
-    # the table's other work, which on the GPU means: on the caller's stream.  So the check rides on
-    # the update calls instead of a thread; same cadence, no race.
-    self._evict_clock = time.time
-    self._evict_every_s = {
-        n: configs[n].table_config.feature_evict_every_n_hours * 3600.0
-        for n in self._table_names if configs[n].table_config.enable_feature_eviction}
-    self._last_evict = {n: self._evict_clock() for n in self._evict_every_s}
-    self._last_evict_check = self._evict_clock()
+    # Feature eviction (tf_bridge.cc:73-104) lives behind the boundary: the library checks the
+    # cadence on its update entry points and enqueues the scan on their stream.
 
   @classmethod
   def from_configs(cls, configs: Dict[str, entry.HashTableConfigInstance], *args, **kwargs):
@@ -318,22 +320,9 @@ class MultiHashTable:
     return out
 
   def maybe_evict(self, force_check: bool = False) -> List[str]:
-    """Runs the TTL eviction scan of every table whose ``feature_evict_every_n_hours`` have passed
-    (on the current stream); called by the update paths, at most every 10 s.  Returns the names of
-    the tables scanned."""
-    if not self._evict_every_s:
-      return []
-    now = self._evict_clock()
-    if not force_check and now - self._last_evict_check < 10.0:
-      return []
-    self._last_evict_check = now
-    done = []
-    for n, period in self._evict_every_s.items():
-      if now - self._last_evict[n] >= period:
-        self.evict(n)
-        self._last_evict[n] = now
-        done.append(n)
-    return done
+    """Kept for callers of the round-1 API: the eviction cadence is checked inside the library now
+    (every update entry point, at most every 10 s; mhte_table_config.enable_feature_eviction)."""
+    return []
 
   def raw_apply_gradients(self, ragged_id: Ragged, flat_grad: torch.Tensor, global_step: int = 0,
                           req_time: int = 0, ids_unique: bool = False) -> "MultiHashTable":
@@ -386,6 +375,77 @@ class MultiHashTable:
       if v is not None:
         tensors.append(self._dev(v, torch.float32).reshape(-1))
     return torch.cat(tensors) if tensors else torch.empty(0, dtype=torch.float32, device=dev)
+
+  # ------------------------------------------------------------------ boundary completion
+  @classmethod
+  def from_serialized_config(cls, config: bytes, name_suffix: str = "", device: Optional[int] = None,
+                             hash_filter: Optional["HashFilter"] = None, reserve_rows: int = 0,
+                             max_load_factor: float = 0.0) -> "MultiHashTable":
+    """CreateMonolithMultiHashTable with its ``config`` input as the reference passes it: a
+    serialized MultiEmbeddingHashTableConfig (mhte_multi_table_create_from_proto)."""
+    self = cls.__new__(cls)
+    self._lib = _lib.lib()
+    self._device = torch.cuda.current_device() if device is None else int(device)
+    self._shared_name = "_".join([MultiHashTable.NAME_PREFIX, name_suffix])
+    if self._shared_name in MultiHashTable._names_in_use:
+      raise ValueError("shared_name {} has already been used.".format(self._shared_name))
+    lrs = np.zeros(256, dtype=np.float32)
+    h = C.c_void_p()
+    check(self._lib.mhte_multi_table_create_from_proto(
+        config, C.c_int64(len(config)), hash_filter._h if hash_filter is not None else C.c_void_p(0),  # pylint: disable=protected-access
+        C.c_uint64(int(reserve_rows)), C.c_float(float(max_load_factor)), C.c_int32(self._device),
+        self._shared_name.encode(), _f32p(lrs), C.c_int32(lrs.size), C.byref(h)))
+    self._h = h
+    self._hash_filter = hash_filter
+    MultiHashTable._names_in_use.add(self._shared_name)
+    T = self._lib.mhte_num_tables(self._h)
+    self._table_names = tuple(self._lib.mhte_table_name(self._h, i).decode() for i in range(T))
+    self._dims = tuple(self._lib.mhte_table_dim(self._h, i) for i in range(T))
+    self._slice_sizes = tuple(self._lib.mhte_table_slice_size(self._h, i) for i in range(T))
+    self._learning_rate = np.ascontiguousarray(lrs[:sum(self._slice_sizes)])
+    self._configs = None
+    return self
+
+  @staticmethod
+  def is_initialized(shared_name: str) -> bool:
+    """IsHashTableInitialized (multi_hash_table_op.cc:145-166)."""
+    return bool(_lib.lib().mhte_multi_table_is_initialized(shared_name.encode()))
+
+  def lookup_entry(self, slot_to_id: Dict[str, torch.Tensor]) -> Dict[str, List[bytes]]:
+    """MonolithMultiHashTableLookupEntry: the serialized EntryDump of every id (b"" when absent)."""
+    ragged_id = self.get_ragged_id(slot_to_id)
+    n = int(ragged_id.row_splits[-1])
+    offs = np.zeros(n + 1, dtype=np.int64)
+    need = C.c_int64(0)
+    cap = max(1, n) * 64
+    while True:
+      buf = C.create_string_buffer(cap)
+      rc = self._lib.mhte_lookup_entry(self._h, vp(ragged_id.values), _i64p(ragged_id.row_splits),
+                                       C.c_int64(ragged_id.row_splits.size), buf, C.c_int64(cap),
+                                       _i64p(offs), C.byref(need), _stream())
+      if rc == _lib.MHTE_INVALID_ARGUMENT and need.value > cap:
+        cap = int(need.value)
+        continue
+      check(rc)
+      break
+    raw = buf.raw
+    out, k = {}, 0
+    for name, m in zip(self._table_names, ragged_id.row_lengths()):
+      out[name] = [raw[offs[k + i]:offs[k + i + 1]] for i in range(int(m))]
+      k += int(m)
+    return {k_: v for k_, v in out.items() if k_ in slot_to_id}
+
+  @staticmethod
+  def feature_stat(basename: str) -> Dict[str, int]:
+    """MonolithMultiHashTableFeatureStat: entries per table name in a checkpoint's .meta files."""
+    L = _lib.lib()
+    names = C.create_string_buffer(1 << 16)
+    counts = (C.c_uint64 * 1024)()
+    n = C.c_int32(0)
+    check(L.mhte_feature_stat(basename.encode("utf-8"), names, C.c_int64(len(names)), counts,
+                              C.c_int32(1024), C.byref(n)))
+    parts = names.raw.split(b"\0")[:n.value]
+    return {p.decode(): int(counts[i]) for i, p in enumerate(parts)}
 
   # ------------------------------------------------------------------ introspection / maintenance
   def _index(self, name: str) -> int:

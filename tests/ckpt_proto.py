@@ -69,13 +69,72 @@ def _build():
                     ("last_update_ts_sec", 4, F.TYPE_INT64, OPT, None, False)])
   msg("MultiHashTableMetadata", [("table_name", 1, F.TYPE_STRING, OPT, None, False),
                                  ("num_entries", 2, F.TYPE_UINT64, OPT, None, False)])
+  # ---- configuration messages (embedding_hash_table.proto:23-43,54-96,100-110; optimizer.proto;
+  # initializer/initializer_config.proto), for the C ABI's proto-config reader
+  i32 = lambda name, num: (name, num, F.TYPE_INT32, OPT, None, False)
+  i64 = lambda name, num: (name, num, F.TYPE_INT64, OPT, None, False)
+  u32 = lambda name, num: (name, num, F.TYPE_UINT32, OPT, None, False)
+  bl = lambda name, num: (name, num, F.TYPE_BOOL, OPT, None, False)
+  msg("AdagradOptimizerConfig", [i32("dim_size", 1), sc("learning_rate", 2), sc("initial_accumulator_value", 3),
+                                 i32("hessian_compression_times", 4), sc("weight_decay_factor", 5),
+                                 i64("warmup_steps", 6)])
+  msg("SgdOptimizerConfig", [i32("dim_size", 1), sc("learning_rate", 2), i64("warmup_steps", 6)])
+  msg("FtrlOptimizerConfig", [i32("dim_size", 1), sc("learning_rate", 2), sc("beta", 3),
+                              sc("initial_accumulator_value", 4), sc("l1_regularization_strength", 5),
+                              sc("l2_regularization_strength", 6), i64("warmup_steps", 7)])
+  msg("AdamOptimizerConfig", [i32("dim_size", 1), sc("learning_rate", 2), sc("beta1", 3), sc("beta2", 4),
+                              bl("use_beta1_warmup", 5), sc("weight_decay_factor", 6), bl("use_nesterov", 7),
+                              sc("epsilon", 8), i64("warmup_steps", 9)])
+  msg("MomentumOptimizerConfig", [i32("dim_size", 1), sc("learning_rate", 2), sc("weight_decay_factor", 3),
+                                  bl("use_nesterov", 4), sc("momentum", 5), i64("warmup_steps", 6)])
+  msg("DcOptimizerConfig", [i32("dim_size", 1), sc("lambda_", 2)])
+  msg("OptimizerConfig", [("adagrad", 1, F.TYPE_MESSAGE, OPT, "AdagradOptimizerConfig", True),
+                          ("sgd", 2, F.TYPE_MESSAGE, OPT, "SgdOptimizerConfig", True),
+                          ("ftrl", 3, F.TYPE_MESSAGE, OPT, "FtrlOptimizerConfig", True),
+                          ("adam", 7, F.TYPE_MESSAGE, OPT, "AdamOptimizerConfig", True),
+                          ("momentum", 9, F.TYPE_MESSAGE, OPT, "MomentumOptimizerConfig", True),
+                          ("dc", 13, F.TYPE_MESSAGE, OPT, "DcOptimizerConfig", True),
+                          ("stochastic_rounding_float16", 4, F.TYPE_BOOL, OPT, None, False)], oneof="type")
+  msg("ZerosInitializerConfig", [i32("dim_size", 1)])
+  msg("OnesInitializerConfig", [i32("dim_size", 1)])
+  msg("ConstantsInitializerConfig", [i32("dim_size", 1), sc("constant", 2)])
+  msg("RandomUniformInitializerConfig", [i32("dim_size", 1), sc("minval", 2), sc("maxval", 3)])
+  msg("InitializerConfig", [("zeros", 1, F.TYPE_MESSAGE, OPT, "ZerosInitializerConfig", True),
+                            ("random_uniform", 2, F.TYPE_MESSAGE, OPT, "RandomUniformInitializerConfig", True),
+                            ("ones", 3, F.TYPE_MESSAGE, OPT, "OnesInitializerConfig", True),
+                            ("constants", 15, F.TYPE_MESSAGE, OPT, "ConstantsInitializerConfig", True)],
+      oneof="type")
+  msg("Segment", [("init_config", 1, F.TYPE_MESSAGE, OPT, "InitializerConfig", False),
+                  ("opt_config", 2, F.TYPE_MESSAGE, OPT, "OptimizerConfig", False),
+                  i32("dim_size", 7)])
+  msg("EntryConfig", [("segments", 1, F.TYPE_MESSAGE, REP, "Segment", False), i32("entry_type", 2)])
+  msg("SlotExpireTime", [u32("slot", 1), u32("expire_time", 2)])
+  msg("SlotExpireTimeConfig", [("slot_expire_times", 1, F.TYPE_MESSAGE, REP, "SlotExpireTime", False),
+                               u32("default_expire_time", 2)])
+  msg("CuckooEmbeddingHashTableConfig", [])
+  msg("EmbeddingHashTableConfig", [("entry_config", 1, F.TYPE_MESSAGE, OPT, "EntryConfig", False),
+                                   ("initial_capacity", 2, F.TYPE_UINT64, OPT, None, False),
+                                   ("slot_expire_time_config", 3, F.TYPE_MESSAGE, OPT, "SlotExpireTimeConfig", False),
+                                   ("cuckoo", 5, F.TYPE_MESSAGE, OPT, "CuckooEmbeddingHashTableConfig", False),
+                                   i32("entry_type", 6), bl("enable_feature_eviction", 7),
+                                   i32("feature_evict_every_n_hours", 8), bl("skip_zero_embedding", 10)])
+  msg("MultiEmbeddingHashTableConfig", [("names", 1, F.TYPE_STRING, REP, None, False),
+                                        ("configs", 2, F.TYPE_MESSAGE, REP, "EmbeddingHashTableConfig", False)])
+  msg("SlotOccurrenceThreshold", [u32("slot", 1), u32("occurrence_threshold", 2)])
+  msg("SlotOccurrenceThresholdConfig",
+      [("slot_occurrence_thresholds", 1, F.TYPE_MESSAGE, REP, "SlotOccurrenceThreshold", False),
+       u32("default_occurrence_threshold", 2)])
   pool = descriptor_pool.DescriptorPool()
   pool.Add(fd)
   get = lambda n: message_factory.GetMessageClass(pool.FindMessageTypeByName("monolith.hash_table." + n))
-  return get("EntryDump"), get("MultiHashTableMetadata")
+  return get
 
 
-EntryDump, MultiHashTableMetadata = _build()
+_get = _build()
+EntryDump, MultiHashTableMetadata = _get("EntryDump"), _get("MultiHashTableMetadata")
+MultiEmbeddingHashTableConfig = _get("MultiEmbeddingHashTableConfig")
+EmbeddingHashTableConfig = _get("EmbeddingHashTableConfig")
+SlotOccurrenceThresholdConfig = _get("SlotOccurrenceThresholdConfig")
 
 
 # ---------------------------------------------------------------------------------- crc32c / TFRecord

@@ -48,6 +48,30 @@ def test_header_is_plain_c():
   assert r.returncode == 0, r.stderr
 
 
+def build_c_client(out_dir):
+  """gcc (C99, no hipcc, no C++) compiles tests/c_client.c against the public header and links
+  libmhte.so: the boundary is usable from plain C."""
+  so = _lib.build_library()
+  exe = os.path.join(str(out_dir), "mhte_c_client")
+  r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                      "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                      os.path.join(ROOT, "tests", "c_client.c"), "-o", exe,
+                      "-L" + os.path.dirname(so), "-lmhte", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+                      "-Wl,-rpath," + os.path.dirname(so), "-Wl,-rpath,/opt/rocm/lib"],
+                     capture_output=True, text=True)
+  assert r.returncode == 0, r.stderr
+  return exe
+
+
+def test_c_client_compiles_and_links(tmp_path):
+  exe = build_c_client(tmp_path)
+  assert os.path.exists(exe)
+  out = subprocess.run(["nm", "-u", exe], capture_output=True, text=True).stdout
+  for sym in ("mhte_multi_table_create", "mhte_lookup", "mhte_optimize", "mhte_multi_table_save",
+              "mhte_multi_table_restore", "mhte_lookup_entry", "mhte_feature_stat"):
+    assert sym in out, sym
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only check")
 def test_no_gpu_means_loud_failure():
   L = _lib.lib()

@@ -1,0 +1,189 @@
+"""GPU tests (-m gpu) of the boundary pieces a TF shim needs beyond the hot path: the serialized
+config protos of the create ops, LookupEntry, FeatureStat, the resource registry, the RandomUniform
+initializer, and the compiled plain-C client of tests/c_client.c."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle as O  # noqa: E402
+from monolith_amd import _lib, entry  # noqa: E402
+from monolith_amd.multi_hash_table_ops import HashFilter, MultiHashTable  # noqa: E402
+from tests import ckpt_proto as P  # noqa: E402
+from tests.test_abi import build_c_client  # noqa: E402
+
+_counter = [0]
+
+
+def _name():
+  _counter[0] += 1
+  return "bd%d" % _counter[0]
+
+
+def ids_t(x):
+  return torch.as_tensor(np.asarray(x, dtype=np.int64)).cuda()
+
+
+def val_t(x):
+  return torch.as_tensor(np.asarray(x, dtype=np.float32)).cuda()
+
+
+def _multi_config():
+  m = P.MultiEmbeddingHashTableConfig()
+  # given out of order on purpose: tables are kept sorted by name
+  for name in ("vec", "bias", "emb"):
+    m.names.append(name)
+    c = m.configs.add()
+    c.cuckoo.SetInParent()
+    if name == "bias":        # SGD lr 1 (test_utils.generate_test_hash_table_config)
+      s = c.entry_config.segments.add()
+      s.dim_size = 2
+      s.init_config.ones.dim_size = 2
+      s.opt_config.sgd.learning_rate = 1.0
+      c.initial_capacity = 64
+    elif name == "emb":       # adagrad_optimizer_test.cc:32-60 KAT
+      s = c.entry_config.segments.add()
+      s.dim_size = 2
+      s.init_config.zeros.dim_size = 2
+      s.opt_config.adagrad.initial_accumulator_value = 1.0
+      s.opt_config.adagrad.learning_rate = 0.1
+      c.slot_expire_time_config.default_expire_time = 14
+      e = c.slot_expire_time_config.slot_expire_times.add()
+      e.slot, e.expire_time = 1, 5
+      c.enable_feature_eviction = True
+      c.feature_evict_every_n_hours = 2
+    else:                     # FTRL bias + Adam vector, constants / random-uniform init
+      s = c.entry_config.segments.add()
+      s.dim_size = 4
+      s.init_config.constants.constant = 0.25
+      s.opt_config.ftrl.learning_rate = 0.05
+      s.opt_config.ftrl.beta = 1.0
+      s.opt_config.ftrl.l1_regularization_strength = 0.001
+      s = c.entry_config.segments.add()
+      s.dim_size = 8
+      s.init_config.random_uniform.minval = -0.5
+      s.init_config.random_uniform.maxval = 0.5
+      s.opt_config.adam.learning_rate = 0.02
+      s.opt_config.adam.use_nesterov = True
+  return m
+
+
+def test_create_from_serialized_config_and_kats():
+  m = _multi_config()
+  mt = MultiHashTable.from_serialized_config(m.SerializeToString(), name_suffix=_name())
+  assert mt.table_names == ("bias", "emb", "vec")
+  assert mt.get_table_dim_sizes() == (2, 2, 12)
+  np.testing.assert_allclose(mt.learning_rate, [1.0, 0.1, 0.05, 0.02])
+  assert MultiHashTable.is_initialized(mt.shared_name) and not MultiHashTable.is_initialized("nope")
+  # absent ids read as zeros whatever the initializer; SGD lr 1 on a ones-initialised row
+  assert not mt.lookup({"bias": ids_t([5])})["bias"].any().item()
+  mt.apply_gradients({"bias": (ids_t([5]), val_t([[0.5, 2.0]]))})
+  np.testing.assert_array_equal(mt.lookup({"bias": ids_t([5])})["bias"].cpu().numpy(), [[0.5, -1.0]])
+  # Adagrad KAT: init_acc 1, lr .1, g {1,2} -> {-0.07071068, -0.08944272}
+  mt.apply_gradients({"emb": (ids_t([9]), val_t([[1.0, 2.0]]))})
+  np.testing.assert_allclose(mt.lookup({"emb": ids_t([9])})["emb"].cpu().numpy(),
+                             [[-0.07071068, -0.08944272]], rtol=0, atol=1e-7)
+  # the two-segment table against the oracle (constants-initialised FTRL; the Adam part starts
+  # from a random-uniform draw, so only its FTRL half is compared)
+  ot = O.Table([O.segment(4, O.OPT_FTRL, p=(0.1, 1.0, 0.001, 0.0), init=O.INIT_CONSTANT, init_value=0.25),
+                O.segment(8, O.OPT_ADAM, p=(0.9, 0.99, 0.01, 0.0, 1.0))], 1)
+  g = np.linspace(-1, 1, 12, dtype=np.float32)[None, :]
+  mt.apply_gradients({"vec": (ids_t([77]), val_t(g))})
+  ot.optimize(np.array([77], np.int64), g, [0.05, 0.02], 0)
+  got = mt.lookup({"vec": ids_t([77])})["vec"].cpu().numpy()
+  np.testing.assert_array_equal(got[:, :4], ot.lookup(np.array([77], np.int64))[0][:, :4])
+  # eviction config came through: ttl 5 days for slot 1
+  st = mt.stats("emb")
+  assert st.size == 1
+
+
+def test_serialized_config_errors():
+  m = _multi_config()
+  m.names.append("extra")                                # names / configs of different length
+  with pytest.raises(_lib.InvalidArgumentError):
+    MultiHashTable.from_serialized_config(m.SerializeToString(), name_suffix=_name())
+  m = P.MultiEmbeddingHashTableConfig()
+  m.names.append("t")
+  s = m.configs.add().entry_config.segments.add()
+  s.dim_size = 4
+  s.opt_config.dc.lambda_ = 0.1                          # not implemented (out of scope)
+  with pytest.raises(_lib.InvalidArgumentError):
+    MultiHashTable.from_serialized_config(m.SerializeToString(), name_suffix=_name())
+  with pytest.raises(_lib.InvalidArgumentError):
+    MultiHashTable.from_serialized_config(b"\xff\xff\xff", name_suffix=_name())
+
+
+def test_filter_config_proto_sets_occurrence_thresholds():
+  oc = P.SlotOccurrenceThresholdConfig()
+  oc.default_occurrence_threshold = 2
+  e = oc.slot_occurrence_thresholds.add()
+  e.slot, e.occurrence_threshold = 3, 0
+  flt = HashFilter(capacity=1000, split_num=1, config=oc.SerializeToString())
+  m = P.MultiEmbeddingHashTableConfig()
+  m.names.append("t")
+  s = m.configs.add().entry_config.segments.add()
+  s.dim_size = 1
+  s.opt_config.sgd.learning_rate = 1.0
+  mt = MultiHashTable.from_serialized_config(m.SerializeToString(), name_suffix=_name(), hash_filter=flt)
+  a, b = 11, (3 << 48) | 11
+  g = val_t([[1.0], [1.0]])
+  mt.apply_gradients({"t": (ids_t([a, b]), g)})          # a: first sighting, dropped; b: slot 3 -> thr 0
+  assert mt.contains("t", ids_t([a, b])).cpu().tolist() == [False, True]
+  mt.apply_gradients({"t": (ids_t([a, b]), g)})
+  mt.apply_gradients({"t": (ids_t([a, b]), g)})          # third sighting of a: admitted
+  assert mt.contains("t", ids_t([a, b])).cpu().tolist() == [True, True]
+
+
+def test_random_uniform_initializer_distribution():
+  cfg = entry.make_table_config([entry.CombineAsSegment(
+      16, entry.RandomUniformInitializer(-0.05, 0.05), entry.SgdOptimizer(0.0))])
+  mt = MultiHashTable.from_configs({"t": cfg}, name_suffix=_name())
+  n = 20000
+  ids = np.arange(1, n + 1, dtype=np.int64)
+  assert not mt.lookup({"t": ids_t(ids)})["t"].any().item()      # lookups do not insert
+  mt.apply_gradients({"t": (ids_t(ids), torch.zeros(n, 16).cuda())}, ids_unique=True)  # lr 0: w = init
+  w = mt.lookup({"t": ids_t(ids)})["t"].cpu().numpy()
+  assert w.min() >= -0.05 and w.max() < 0.05
+  assert abs(w.mean()) < 2e-4 and abs(w.std() - 0.1 / np.sqrt(12)) < 3e-4
+  assert np.unique(w).size > 0.98 * w.size                        # independent draws
+  h, _ = np.histogram(w, bins=10, range=(-0.05, 0.05))
+  assert h.min() > 0.09 * w.size and h.max() < 0.11 * w.size
+
+
+def test_lookup_entry_and_feature_stat(tmp_path):
+  cfgs = {"a": entry.make_table_config([entry.CombineAsSegment(
+              3, entry.ZerosInitializer(), entry.AdagradOptimizer(0.1, 1.0))]),
+          "b": entry.make_table_config([entry.CombineAsSegment(
+              2, entry.ZerosInitializer(), entry.SgdOptimizer(1.0))])}
+  mt = MultiHashTable.from_configs(cfgs, name_suffix=_name())
+  mt.apply_gradients({"a": (ids_t([1, 2]), val_t([[1, 2, 3], [4, 5, 6]])),
+                      "b": (ids_t([3]), val_t([[1, 1]]))}, req_time=1234)
+  out = mt.lookup_entry({"a": ids_t([2, 99, 1]), "b": ids_t([3, 4])})
+  assert [len(x) > 0 for x in out["a"]] == [True, False, True] and out["b"][1] == b""
+  e = P.EntryDump.FromString(out["a"][0])
+  rows = mt.lookup({"a": ids_t([2])})["a"].cpu().numpy()[0]
+  assert e.id == 2 and e.last_update_ts_sec == 1234
+  np.testing.assert_array_equal(np.array(e.num, np.float32), rows)
+  np.testing.assert_allclose(list(e.opt.dump[0].adagrad.norm), [1 + 16, 1 + 25, 1 + 36])
+  e = P.EntryDump.FromString(out["b"][0])
+  assert e.id == 3 and list(e.num) == [-1.0, -1.0] and e.opt.dump[0].HasField("sgd")
+  # what LookupEntry returns is what Save writes
+  base = str(tmp_path / "fs" / "ck")
+  mt.save(base, nshards=2)
+  recs = []
+  for sh in range(2):
+    recs += P.unframe(P.read_tf_snappy(open("%s-%05d-of-00002" % (base, sh), "rb").read()))
+  assert sorted(recs) == sorted([out["a"][0], out["a"][2], out["b"][0]])
+  assert MultiHashTable.feature_stat(base) == {"a": 2, "b": 1}
+  with pytest.raises(_lib.MhteError):
+    MultiHashTable.feature_stat(str(tmp_path / "none"))
+
+
+def test_plain_c_client_runs(tmp_path):
+  exe = build_c_client(tmp_path)
+  r = subprocess.run([exe, str(tmp_path / "c_ckpt")], capture_output=True, text=True, timeout=120)
+  assert r.returncode == 0 and "c_client ok" in r.stdout, r.stdout + r.stderr

@@ -1058,18 +1058,15 @@ def test_feature_eviction_cadence_and_ttl():
       [entry.CombineAsSegment(1, entry.ZerosInitializer(), entry.SgdOptimizer(1.0))],
       entry.CuckooHashTableConfig(feature_evict_every_n_hours=2), slot_expire_time_config=ttl)
   mt = make({"t": cfg})
-  clock = [1000.0]
-  mt._evict_clock = lambda: clock[0]  # pylint: disable=protected-access
-  mt._last_evict = {"t": 1000.0}  # pylint: disable=protected-access
-  mt._last_evict_check = 1000.0  # pylint: disable=protected-access
+  adv = _lib.lib().mhte_advance_clock_for_testing   # (the cadence lives in the library)
   t0 = 1_600_000_000
   fids = [(1 << 48) | 123, (2 << 48) | 456, 789]
   mt.assign_add({"t": (ids_t(fids), val_t([[1.0], [2.0], [3.0]]))}, req_time=t0)
   g = val_t([[0.0]])
-  clock[0] += 3600           # one hour: nothing is due
+  adv(3600.0)                # one hour: nothing is due
   mt.apply_gradients({"t": (ids_t([55]), g)}, req_time=t0 + 5 * day + 60)
   assert mt.size("t") == 4
-  clock[0] += 3600 + 11      # two hours passed: the scan runs on the next update call
+  adv(3600.0 + 11)           # two hours passed: the scan runs on the next update call
   mt.apply_gradients({"t": (ids_t([55]), g)}, req_time=t0 + 5 * day + 61)
   assert mt.contains("t", ids_t(fids + [55])).cpu().tolist() == [False, True, True, True]
   assert mt.stats("t").evicted == 1
