@@ -91,7 +91,8 @@ typedef struct {
   uint64_t reserve_rows;         /* MI355X extension: rows of HBM slab to allocate up front (0 = grow
                                     on demand in 2^20-row slabs) */
   float max_load_factor;         /* MI355X extension: proactive doubling threshold, 0 -> 0.5 */
-  int64_t default_expire_days;   /* SlotExpireTimeConfig.default_expire_time, 0 -> 36500 */
+  int64_t default_expire_days;   /* SlotExpireTimeConfig.default_expire_time; 0 (unset) -> 36500, the
+                                    proto default; negative -> a TTL of 0 days */
   int32_t n_slot_expire;
   const int64_t* expire_slots;   /* host */
   const int32_t* expire_days;    /* host */
@@ -285,14 +286,23 @@ mhte_status mhte_reduce_rows(const int64_t* indices, const float* values, int64_
                              int64_t batch, int32_t mode, int32_t indices_sorted, float* out,
                              void* stream);
 
-/* Admission filter (RT/hash_filter/hash_filter.h:33-214, the `filter_handle` input of
- * CreateMonolithMultiHashTable, RT/ops/multi_hash_table_op.cc:104-112): a counting filter with 4-bit
- * saturating counts shared by the tables of a MultiHashTable.  While attached, Optimize / Assign
- * (and the training step's apply) drop an id that is not in the table yet and has been seen fewer
- * times than its feature slot's occurrence threshold (RT/ops/embedding_hash_table_tf_bridge.cc
- * :182-185,300-321); AssignAdd consults the filter without the Contains guard, as the reference's
- * multi-table path does (:230-232).  One filter split; the sliding window over several splits
- * (sliding_hash_filter.cc) is not built, `split_num` is accepted for signature parity. */
+/* Admission filter: the reference's SlidingHashFilter (RT/hash_filter/sliding_hash_filter.{h,cc};
+ * created by HashFilterOp, RT/ops/hash_filter_op.cc:47-81; the `filter_handle` input of
+ * CreateMonolithMultiHashTable, RT/ops/multi_hash_table_op.cc:104-112), in HBM, shared by the tables of
+ * a MultiHashTable: max(split_num, 5) counting filters (4-bit saturating counts, HashFilter,
+ * RT/hash_filter/hash_filter.h:33-214) of capacity / (split_num - 1) elements each as a sliding window —
+ * counts are taken forward in the head split, an id's older count is looked up backward, the window
+ * moves on when the head split is full.  While attached, Optimize / Assign (and the training step's
+ * apply) drop an id that is not in the table yet and has been seen fewer times than its feature slot's
+ * occurrence threshold (RT/ops/embedding_hash_table_tf_bridge.cc:182-185,300-321); AssignAdd consults
+ * the filter without the Contains guard, as the reference's multi-table path does (:230-232).  The
+ * window moves between launches, not inside one.
+ * mhte_hash_filter_save / _restore: MonolithHashFilterSave / Restore (RT/ops/hash_filter_save_op.cc,
+ * hash_filter_restore_op.cc): one TFRecord file per split, <basename>-%05d-of-%05d, a
+ * HashFilterSplitMetaDump then HashFilterSplitDataDump records (embedding_hash_table.proto:112-137);
+ * restore checks the geometry like SlidingHashFilter::RestoreMetaDump.  (Slot positions depend on the
+ * hash function — the reference's absl::Hash is unpinned — so files are interchangeable between
+ * instances of this engine, not with the reference.)  Both synchronise. */
 mhte_status mhte_hash_filter_create(uint64_t capacity, int32_t split_num, int32_t device,
                                     mhte_hash_filter** out);
 /* the same with the filter op's `config` attr: a serialized SlotOccurrenceThresholdConfig
@@ -303,6 +313,8 @@ mhte_status mhte_hash_filter_create_from_proto(uint64_t capacity, int32_t split_
                                                int32_t device, mhte_hash_filter** out);
 void mhte_hash_filter_destroy(mhte_hash_filter* f);
 mhte_status mhte_multi_table_set_filter(mhte_multi_table* t, mhte_hash_filter* f /* NULL detaches */);
+mhte_status mhte_hash_filter_save(mhte_hash_filter* f, const char* basename, void* stream);
+mhte_status mhte_hash_filter_restore(mhte_hash_filter* f, const char* basename, void* stream);
 /* Filter::get: the seen count of ids (0..15), out [dev u32, n] */
 mhte_status mhte_hash_filter_get(mhte_hash_filter* f, const int64_t* id, int64_t n, uint32_t* out,
                                  void* stream);

@@ -420,6 +420,15 @@ struct Table {
   bool has_group_opt = false;       // a segment uses GroupAdaGrad (picks the kernel instantiation)
   uint32_t* flt_slots = nullptr;    // owned by the mhte_hash_filter attached to the MultiHashTable
   uint64_t flt_total = 0;
+  uint32_t* flt_state = nullptr;
+  uint32_t flt_nsplit = 0, flt_stride = 0, flt_cap = 0;
+  // after a launch that consulted the filter: move the sliding window on if the head split filled
+  // up (filter_advance_kernel) and clear the split that becomes the look-ahead one
+  void filter_maintain(hipStream_t st) {
+    if (!flt_slots) return;
+    filter_advance_kernel<<<1, 64, 0, st>>>(view);
+    filter_clear_kernel<<<256, 256, 0, st>>>(view);
+  }
   // in-op grouping scratch (ids not declared unique)
   DedupWs dd;
   DevBuf<int64_t> g_uids;
@@ -481,7 +490,9 @@ struct Table {
     row_floats = st;
     if (row_floats % 4) vec_ok = false;
     max_load = (c.max_load_factor > 0.f && c.max_load_factor <= 1.f) ? c.max_load_factor : 0.5;
-    default_expire_days = c.default_expire_days > 0 ? c.default_expire_days : 36500;
+    // (0 = unset -> the proto default; a TTL of zero days — everything expires at the next save /
+    // scan, hash_table_ops_test.py:381-395 — is written as a negative value)
+    default_expire_days = c.default_expire_days > 0 ? c.default_expire_days : (c.default_expire_days < 0 ? 0 : 36500);
     if (c.n_slot_expire > 0) {
       expire_slots.assign(c.expire_slots, c.expire_slots + c.n_slot_expire);
       expire_days.assign(c.expire_days, c.expire_days + c.n_slot_expire);
@@ -564,6 +575,10 @@ struct Table {
     view.trace = nullptr;
     view.flt_slots = flt_slots;
     view.flt_total = flt_total;
+    view.flt_state = flt_state;
+    view.flt_nsplit = flt_nsplit;
+    view.flt_stride = flt_stride;
+    view.flt_cap = flt_cap;
     view.occ_default = occ_default;
     view.occ_n = int32_t(occ_slots.size());
     view.occ_slots = d_occ_slots.p;
@@ -719,6 +734,7 @@ struct Table {
     } else {
       slowpath_kernel<1, OP><<<1, 64, 0, st>>>(view, ids, values, seg_off, seg_pos, a, status, pend, skp);
     }
+    if (a.filter_mode) filter_maintain(st);
     HIP_OK(hipGetLastError());
   }
 
@@ -804,6 +820,7 @@ struct Table {
     pend_grad = grad_u;
     pend_args = a;
     pend_vec = sh.VEC;
+    filter_maintain(st);
     if (!defer_slowpath) finish_pending(st);
   }
 
@@ -953,6 +970,7 @@ struct Table {
       if (ws_next) ws_next->r_clean_cap = 0;
       HIP_OK(le);
     }
+    filter_maintain(st);
     // the displacement pass rides in the next step_forward (or runs on its own if anything else
     // touches the table first)
     pend_valid = true;
@@ -1043,8 +1061,21 @@ static std::mutex g_registry_mu;
 static std::map<std::string, mhte_multi_table*> g_registry;
 struct mhte_hash_filter {
   int device = 0;
-  uint32_t* slots = nullptr;
-  uint64_t total = 0;
+  uint32_t* slots = nullptr;       // [nsplit][stride]
+  uint32_t* state = nullptr;       // FilterState
+  uint64_t total = 0;              // hash range of a split = split_capacity * 1.2
+  uint64_t capacity = 0;           // the filter's (constructor argument)
+  uint32_t nsplit = 0, stride = 0, split_cap = 0, split_num_arg = 0;
+  mhte::TableView view() const {   // (a view that only carries the filter: the filter's own kernels)
+    mhte::TableView v{};
+    v.flt_slots = slots;
+    v.flt_total = total;
+    v.flt_state = state;
+    v.flt_nsplit = nsplit;
+    v.flt_stride = stride;
+    v.flt_cap = split_cap;
+    return v;
+  }
   // SlotOccurrenceThresholdConfig given with the filter (mhte_hash_filter_create_from_proto)
   bool has_occ = false;
   int32_t occ_default = 0;
@@ -1055,6 +1086,7 @@ struct mhte_hash_filter {
       (void)hipSetDevice(device);
       (void)hipFree(slots);
     }
+    if (state) (void)hipFree(state);
   }
 };
 
@@ -1639,13 +1671,28 @@ mhte_status mhte_hash_filter_create(uint64_t capacity, int32_t split_num, int32_
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
       throw Error(MHTE_UNAVAILABLE, "no such HIP device");
     HIP_OK(hipSetDevice(device));
-    (void)split_num;  // (one split: the sliding window of SlidingHashFilter is not built)
-    if (capacity < 300) capacity = 300;  // sliding_hash_filter.cc:31
+    // SlidingHashFilter(capacity, split_num), sliding_hash_filter.cc:29-42
+    if (capacity < 300) capacity = 300;
+    if (split_num < 5) split_num = 5;
+    if (split_num > kFilterMaxSplits)
+      throw Error(MHTE_INVALID_ARGUMENT, "hash filter: split_num must be <= " + std::to_string(kFilterMaxSplits));
     std::unique_ptr<mhte_hash_filter> f(new mhte_hash_filter);
     f->device = device;
-    f->total = uint64_t(double(capacity) * 1.5);  // HashFilter(capacity, fill_rate = 1.5)
-    HIP_OK(hipMalloc(&f->slots, f->total * sizeof(uint32_t)));
-    HIP_OK(hipMemset(f->slots, 0, f->total * sizeof(uint32_t)));
+    f->capacity = capacity;
+    f->split_num_arg = uint32_t(split_num);
+    f->nsplit = uint32_t(split_num);
+    const uint64_t split_capacity = capacity / uint64_t(split_num - kFilterForward + 1);  // get_split_capacity
+    f->split_cap = uint32_t(std::min<uint64_t>(split_capacity, 0xffffffffu));
+    f->total = uint64_t(double(split_capacity) * 1.2);   // HashFilter(split_capacity, fill_rate = 1.2)
+    if (f->total < 1) f->total = 1;
+    if (f->total + kFilterMaxStep > 0xffffffffull)
+      throw Error(MHTE_INVALID_ARGUMENT, "hash filter: split too large");
+    f->stride = uint32_t(f->total + kFilterMaxStep);
+    const size_t words = size_t(f->nsplit) * f->stride;
+    HIP_OK(hipMalloc(&f->slots, words * sizeof(uint32_t)));
+    HIP_OK(hipMemset(f->slots, 0, words * sizeof(uint32_t)));
+    HIP_OK(hipMalloc(&f->state, sizeof(FilterState)));
+    HIP_OK(hipMemset(f->state, 0, sizeof(FilterState)));
     *out = f.release();
   });
 }
@@ -1660,6 +1707,10 @@ mhte_status mhte_multi_table_set_filter(mhte_multi_table* t, mhte_hash_filter* f
       std::lock_guard<std::mutex> g(tb->mu);
       tb->flt_slots = f ? f->slots : nullptr;
       tb->flt_total = f ? f->total : 0;
+      tb->flt_state = f ? f->state : nullptr;
+      tb->flt_nsplit = f ? f->nsplit : 0;
+      tb->flt_stride = f ? f->stride : 0;
+      tb->flt_cap = f ? f->split_cap : 0;
       tb->refresh_view();
     }
   });
@@ -1672,8 +1723,149 @@ mhte_status mhte_hash_filter_get(mhte_hash_filter* f, const int64_t* id, int64_t
     if (!f || !id || !out) throw Error(MHTE_INVALID_ARGUMENT, "null argument");
     if (n <= 0) return;
     HIP_OK(hipSetDevice(f->device));
-    filter_get_kernel<<<dim3(uint32_t((n + 255) / 256)), 256, 0, S(stream)>>>(f->slots, f->total, id, n, out);
+    filter_get_kernel<<<dim3(uint32_t((n + 255) / 256)), 256, 0, S(stream)>>>(f->view(), id, n, out);
     HIP_OK(hipGetLastError());
+  });
+}
+
+// MonolithHashFilterSave / Restore (RT/ops/hash_filter_save_op.cc:35-112, hash_filter_restore_op.cc):
+// one TFRecord file per split, <basename>-%05d-of-%05d: a HashFilterSplitMetaDump (with the sliding
+// window's SlidingHashFilterMetaDump inside), then HashFilterSplitDataDump records of <= 10 000 slot
+// words (hash_filter.cc:27-57; embedding_hash_table.proto:112-137).
+namespace mhte {
+namespace {
+void put_key(std::string& o, uint32_t field, uint32_t wt) { ckpt::put_varint(o, (uint64_t(field) << 3) | wt); }
+void put_u(std::string& o, uint32_t field, uint64_t v) { put_key(o, field, 0); ckpt::put_varint(o, v); }
+}  // namespace
+}  // namespace mhte
+
+mhte_status mhte_hash_filter_save(mhte_hash_filter* f, const char* basename, void* stream) {
+  return guard([&] {
+    if (!f || !basename || !*basename) throw Error(MHTE_INVALID_ARGUMENT, "filter save: bad arguments");
+    HIP_OK(hipSetDevice(f->device));
+    hipStream_t st = S(stream);
+    FilterState hs;
+    HIP_OK(hipMemcpyAsync(&hs, f->state, sizeof(hs), hipMemcpyDeviceToHost, st));
+    std::vector<uint32_t> words(size_t(f->nsplit) * f->stride);
+    HIP_OK(hipMemcpyAsync(words.data(), f->slots, words.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    std::string sl;   // SlidingHashFilterMetaDump
+    put_u(sl, 1, f->split_num_arg);
+    put_u(sl, 2, kFilterForward);
+    put_u(sl, 3, f->nsplit - kFilterForward);
+    put_u(sl, 4, kFilterProbe);
+    put_u(sl, 5, hs.head);
+    put_u(sl, 6, hs.head_increment);
+    put_u(sl, 7, hs.failure_count);
+    for (uint32_t sp = 0; sp < f->nsplit; ++sp) {
+      const std::string fn = ckpt::shard_name(basename, "", int(sp), int(f->nsplit));
+      const std::string tmp = fn + "-tmp-" + std::to_string(uint64_t(getpid()));
+      {
+        ckpt::RecordWriter w(tmp, false);
+        std::string meta;   // HashFilterSplitMetaDump
+        put_u(meta, 1, 0);
+        put_u(meta, 2, f->total);
+        put_u(meta, 3, hs.num_elements[sp]);
+        put_key(meta, 4, 1);
+        const double fill = 1.2;
+        meta.append(reinterpret_cast<const char*>(&fill), 8);
+        put_key(meta, 5, 2);
+        ckpt::put_varint(meta, sl.size());
+        meta += sl;
+        w.write(meta);
+        const uint32_t* split = words.data() + size_t(sp) * f->stride;
+        std::string rec;
+        for (uint32_t s0 = 0; s0 < f->stride; s0 += 10000) {
+          rec.clear();
+          put_u(rec, 1, s0);
+          const uint32_t s1 = std::min<uint32_t>(f->stride, s0 + 10000);
+          for (uint32_t i = s0; i < s1; ++i) put_u(rec, 2, split[i]);   // (proto2 repeated: unpacked)
+          w.write(rec);
+        }
+        w.close();
+      }
+      if (rename(tmp.c_str(), fn.c_str()) != 0)
+        throw Error(MHTE_INTERNAL, "filter save: cannot rename into " + fn);
+    }
+  });
+}
+
+mhte_status mhte_hash_filter_restore(mhte_hash_filter* f, const char* basename, void* stream) {
+  return guard([&] {
+    if (!f || !basename || !*basename) throw Error(MHTE_INVALID_ARGUMENT, "filter restore: bad arguments");
+    HIP_OK(hipSetDevice(f->device));
+    hipStream_t st = S(stream);
+    FilterState hs;
+    memset(&hs, 0, sizeof(hs));
+    std::vector<uint32_t> words(size_t(f->nsplit) * f->stride, 0u);
+    try {
+      for (uint32_t sp = 0; sp < f->nsplit; ++sp) {
+        ckpt::RecordReader r(ckpt::shard_name(basename, "", int(sp), int(f->nsplit)), false);
+        std::string rec;
+        if (!r.read(&rec)) throw Error(MHTE_INTERNAL, "filter restore: empty split file");
+        {
+          pcfg::Msg m(reinterpret_cast<const uint8_t*>(rec.data()), rec.size());
+          pcfg::Field fl;
+          uint64_t total = 0;
+          while (m.next(&fl)) {
+            if (fl.num == 2) total = fl.v;
+            if (fl.num == 3) hs.num_elements[sp] = uint32_t(fl.v);
+            if (fl.num == 5 && fl.wt == 2) {
+              pcfg::Msg sm(fl.p, fl.n);
+              pcfg::Field g;
+              while (sm.next(&g)) {
+                // SlidingHashFilter::RestoreMetaDump validates the geometry (:181-197)
+                auto same = [&](uint64_t want, const char* what) {
+                  if (g.v != want)
+                    throw Error(MHTE_RESOURCE_EXHAUSTED,
+                                std::string(what) + ": " + std::to_string(want) + " does't match with : " +
+                                    std::to_string(g.v) + " read from hash filter checkpoint file.");
+                };
+                if (g.num == 1) same(f->split_num_arg, "split_num");
+                if (g.num == 2) same(kFilterForward, "max_forward_step");
+                if (g.num == 3) same(f->nsplit - kFilterForward, "max_backward_step");
+                if (g.num == 4) same(kFilterProbe, "max_step");
+                if (g.num == 5) hs.head = uint32_t(g.v);
+                if (g.num == 6) hs.head_increment = uint32_t(g.v);
+                if (g.num == 7) hs.failure_count = g.v;
+              }
+            }
+          }
+          if (total != f->total)
+            throw Error(MHTE_RESOURCE_EXHAUSTED, "filter restore: split size " + std::to_string(total) +
+                                                     " does not match this filter's " + std::to_string(f->total));
+        }
+        uint32_t* split = words.data() + size_t(sp) * f->stride;
+        while (r.read(&rec)) {
+          pcfg::Msg m(reinterpret_cast<const uint8_t*>(rec.data()), rec.size());
+          pcfg::Field fl;
+          uint64_t off = 0, i = 0;
+          while (m.next(&fl)) {
+            if (fl.num == 1) off = fl.v;
+            if (fl.num == 2 && fl.wt == 0) {
+              if (off + i < f->stride) split[off + i] = uint32_t(fl.v);
+              ++i;
+            }
+            if (fl.num == 2 && fl.wt == 2) {  // (a packed writer)
+              const uint8_t* q = fl.p;
+              const uint8_t* qe = fl.p + fl.n;
+              uint64_t v;
+              while (q < qe && ckpt::get_varint(q, qe, &v)) {
+                if (off + i < f->stride) split[off + i] = uint32_t(v);
+                ++i;
+              }
+            }
+          }
+        }
+      }
+    } catch (const Error&) {
+      throw;
+    } catch (const std::exception& e) {
+      throw Error(MHTE_NOT_FOUND, std::string("filter restore: ") + e.what());
+    }
+    HIP_OK(hipMemcpyAsync(f->slots, words.data(), words.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(f->state, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));
   });
 }
 
@@ -2512,7 +2704,7 @@ mhte_status mhte_multi_table_create_from_proto(const void* config, int64_t confi
     c.initial_capacity = t.initial_capacity;
     c.reserve_rows = reserve_rows;
     c.max_load_factor = max_load_factor;
-    c.default_expire_days = t.default_expire;
+    c.default_expire_days = t.default_expire == 0 ? -1 : t.default_expire;
     c.n_slot_expire = int32_t(t.expire_slots.size());
     c.expire_slots = t.expire_slots.data();
     c.expire_days = t.expire_days.data();

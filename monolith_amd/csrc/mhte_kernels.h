@@ -44,8 +44,12 @@ struct TableView {
   uint32_t nseg;
   SegDesc seg[kMaxSegments];
   // admission (hash filter, runtime/hash_filter/hash_filter.h): null = no filter attached
-  uint32_t* flt_slots;            // signature << 4 | count (0 = empty)
-  uint64_t flt_total;             // number of filter slots
+  uint32_t* flt_slots;            // [flt_nsplit][flt_stride] signature << 4 | count (0 = empty)
+  uint64_t flt_total;             // hash range of one split (its slots + kFilterMaxStep of overrun)
+  uint32_t* flt_state;            // FilterState: head, head_increment, ..., elements per split
+  uint32_t flt_nsplit;            // splits of the sliding window (>= 5)
+  uint32_t flt_stride;            // words per split = flt_total + kFilterMaxStep
+  uint32_t flt_cap;               // elements a split takes before the window moves on
   int32_t occ_default;            // SlotOccurrenceThresholdConfig.default_occurrence_threshold
   int32_t occ_n;
   const int64_t* occ_slots;       // device: per-feature-slot overrides
@@ -174,18 +178,41 @@ struct Vec<1> {
 };
 
 // =============================================================================================
-// Admission filter (runtime/hash_filter/hash_filter.h:33-214; bridge call sites
-// ops/embedding_hash_table_tf_bridge.cc:182-185,208-211,230-232,300-321): a counting filter with
-// 4-bit saturating counts; an id that is not in the table yet is dropped while the number of times
-// it has been seen is below its feature slot's occurrence threshold.
-//   slot word = signature << 4 | count; signature = (fid >> 17 | fid << 15) (hash_filter.h:149),
-//   28 bits here (the reference's HashFilter<uint16_t> keeps 12), open addressing, <= 64 probes;
-//   no free slot within 64 probes counts as "seen max_count times" (:100-107), i.e. admitted.
+// Admission filter: the reference's SlidingHashFilter (runtime/hash_filter/sliding_hash_filter.cc,
+// .h; one split = HashFilter<uint16_t>, hash_filter.h:33-214; created by HashFilterOp,
+// ops/hash_filter_op.cc:47-81; bridge call sites ops/embedding_hash_table_tf_bridge.cc
+// :182-185,208-211,230-232,300-321).  An id that is not in the table yet is dropped while the
+// number of times it has been seen is below its feature slot's occurrence threshold.
+//   * `nsplit` (>= 5) counting filters of capacity / (nsplit - 1) elements each, fill rate 1.2,
+//     4-bit saturating counts; slot word = signature << 4 | count, signature = (fid >> 17 | fid << 15)
+//     (28 bits here, the reference's uint16 keeps 12); linear probing, 16 probes
+//     (SlidingHashFilter::MAX_STEP), no wrap: the split has 64 words of overrun like the reference's
+//     map_ (total_size + MAX_STEP).
+//   * add (:56-91): look FORWARD from `head` over 2 splits for a usable slot (the id's, or an empty
+//     one); the id's own -> count there.  An empty one -> look BACKWARD over up to
+//     min(head_increment, nsplit - 2) older splits for the id's last count and start the new slot
+//     from it.  No usable slot -> failure, counts as "seen max_count times".
+//   * the window moves on (head advances, the split two ahead is cleared) when the head split is full.
+//     The reference checks after every add; here the check runs between launches
+//     (filter_advance_kernel) — inside one launch all adds see one window, as they would under any
+//     one of the reference's thread interleavings in which the split fills at the batch's end.
 // Physical placement uses the engine's fixed hash (the reference's absl::Hash is unpinned), so
 // parity is semantic: counts and admission decisions.
 // =============================================================================================
 constexpr uint32_t kFilterMaxCount = 15;   // count_bit = 4, filter.h:56-57
-constexpr int kFilterMaxStep = 64;         // hash_filter.h:190
+constexpr int kFilterMaxStep = 64;         // words of overrun behind a split (hash_filter.h:190)
+constexpr int kFilterProbe = 16;           // SlidingHashFilter::MAX_STEP
+constexpr int kFilterForward = 2;          // max_forward_step_
+constexpr int kFilterMaxSplits = 64;
+
+struct FilterState {           // device words behind TableView::flt_state
+  uint32_t head;
+  uint32_t head_increment;
+  uint32_t clear_req;          // split to clear + 1 (set by filter_advance_kernel)
+  uint32_t pad;
+  unsigned long long failure_count;
+  uint32_t num_elements[kFilterMaxSplits];
+};
 
 __device__ __forceinline__ int32_t occurrence_threshold(const TableView& tv, int64_t id) {
   const int64_t slot = (id >> 48) & 0x7fff;  // slot_id_v2
@@ -193,6 +220,34 @@ __device__ __forceinline__ int32_t occurrence_threshold(const TableView& tv, int
   for (int i = 0; i < tv.occ_n; ++i)
     if (tv.occ_slots[i] == slot) thr = tv.occ_thr[i];
   return thr;
+}
+
+__device__ __forceinline__ uint32_t filter_sign(int64_t id) {
+  const uint64_t fid = uint64_t(id);
+  return uint32_t((fid >> 17) | (fid << 15)) & 0x0fffffffu;
+}
+__device__ __forceinline__ uint64_t filter_home(int64_t id, uint64_t total) {
+  return hash_key(id ^ 0x5bd1e995) % total;
+}
+
+// HashFilter::find (hash_filter.h:118-134) on one split: the first of kFilterProbe slots that is
+// empty or carries `sign`; with `nonempty` only a slot that carries it.  Returns the slot index or
+// -1; *v = the word seen there.
+__device__ __forceinline__ long long filter_find(uint32_t* split, uint64_t home, uint32_t sign,
+                                                 bool nonempty, uint32_t* v) {
+  for (int t = 0; t < kFilterProbe; ++t) {
+    const uint32_t w = __hip_atomic_load(&split[home + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w == 0u) {
+      if (nonempty) return -1;   // (the id would have been put here or before)
+      *v = 0u;
+      return static_cast<long long>(home + t);
+    }
+    if ((w >> 4) == sign) {
+      *v = w;
+      return static_cast<long long>(home + t);
+    }
+  }
+  return -1;
 }
 
 // The decision for ONE id whose k occurrences arrive in order (one lane calls it).
@@ -211,61 +266,131 @@ __device__ __forceinline__ uint32_t filter_consult(const TableView& tv, int64_t 
   if (thr_i <= 0 || k == 0) return 0u;              // ShouldBeFiltered: threshold <= 0 disables
   if (contained && mode != 3) return 0u;
   const uint32_t thr = uint32_t(thr_i);
-  const uint64_t fid = uint64_t(id);
-  const uint32_t sign = uint32_t((fid >> 17) | (fid << 15)) & 0x0fffffffu;
-  uint64_t pos = hash_key(id ^ 0x5bd1e995) % tv.flt_total;
-  for (int step = 0; step < kFilterMaxStep; ++step) {
-    uint32_t v = __hip_atomic_load(&tv.flt_slots[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {
-      if (v != 0u && (v >> 4) != sign) break;       // another id's slot: next probe
-      const uint32_t c0 = v & kFilterMaxCount;      // (0 for an empty slot)
-      uint32_t first, adds;
-      if (mode == 2) {
-        first = (c0 < thr) ? k : 0u;
-        adds = k;
-      } else if (mode == 3) {
-        first = (c0 >= thr) ? 0u : min(k, thr - c0);
-        adds = k;
-      } else {
-        first = (c0 >= thr) ? 0u : (thr - c0);
-        adds = min(k, first + 1u);                  // the admitted occurrence is the last to ask
-        first = min(first, k);
-      }
-      const uint32_t c1 = min(kFilterMaxCount, c0 + min(adds, kFilterMaxCount));
-      const uint32_t nv = (sign << 4) | c1;
-      const uint32_t old = atomicCAS(&tv.flt_slots[pos], v, nv);
-      if (old == v) return first;
-      v = old;
+  const uint32_t sign = filter_sign(id);
+  const uint64_t home = filter_home(id, tv.flt_total);
+  FilterState* fs = reinterpret_cast<FilterState*>(tv.flt_state);
+  const uint32_t S = tv.flt_nsplit;
+  const uint32_t head = fs->head, hinc = fs->head_increment;
+  // first / adds for a count c0 seen before this batch's occurrences
+  auto decide = [&](uint32_t c0, uint32_t* first, uint32_t* adds) {
+    if (mode == 2) {
+      *first = (c0 < thr) ? k : 0u;
+      *adds = k;
+    } else if (mode == 3) {
+      *first = (c0 >= thr) ? 0u : min(k, thr - c0);
+      *adds = k;
+    } else {
+      *first = (c0 >= thr) ? 0u : (thr - c0);
+      *adds = min(k, *first + 1u);                  // the admitted occurrence is the last to ask
+      *first = min(*first, k);
     }
-    pos = (pos + 1 == tv.flt_total) ? 0 : pos + 1;
+  };
+  for (int attempt = 0; attempt < 64; ++attempt) {
+    // ---- look forward: a slot in the head split or the one after it
+    long long pos = -1;
+    uint32_t sp = head, v = 0;
+    for (int f = 0; f < kFilterForward && pos < 0; ++f) {
+      sp = (head + uint32_t(f)) % S;
+      pos = filter_find(tv.flt_slots + size_t(sp) * tv.flt_stride, home, sign, false, &v);
+    }
+    if (pos < 0) {                                  // :64-67: failure, "seen max_count times"
+      atomicAdd(&fs->failure_count, 1ull);
+      uint32_t first, adds;
+      decide(kFilterMaxCount, &first, &adds);
+      return first;
+    }
+    uint32_t* slot = tv.flt_slots + size_t(sp) * tv.flt_stride + pos;
+    if (v != 0u) {                                  // the id's slot: count there
+      for (;;) {
+        uint32_t first, adds;
+        decide(v & kFilterMaxCount, &first, &adds);
+        const uint32_t c1 = min(kFilterMaxCount, (v & kFilterMaxCount) + min(adds, kFilterMaxCount));
+        const uint32_t old = atomicCAS(slot, v, (sign << 4) | c1);
+        if (old == v) return first;
+        v = old;                                    // (same signature: another lane counted)
+      }
+    }
+    // ---- an empty slot: the id's last count from the older splits, then start the new slot
+    uint32_t old_count = 0;
+    {
+      const uint32_t nb = min(hinc, S - uint32_t(kFilterForward));
+      uint32_t sb = head;
+      for (uint32_t i = 0; i < nb; ++i) {
+        sb = (sb == 0u) ? S - 1u : sb - 1u;
+        uint32_t w = 0;
+        if (filter_find(tv.flt_slots + size_t(sb) * tv.flt_stride, home, sign, true, &w) >= 0) {
+          old_count = w & kFilterMaxCount;
+          break;
+        }
+      }
+    }
+    uint32_t first, adds;
+    decide(old_count, &first, &adds);
+    const uint32_t c1 = min(kFilterMaxCount, old_count + min(adds, kFilterMaxCount));
+    if (atomicCAS(slot, 0u, (sign << 4) | c1) == 0u) {
+      atomicAdd(&fs->num_elements[sp], 1u);
+      return first;
+    }
+    // the slot went to another id meanwhile: look again
   }
-  return 0u;  // no slot: add() returns max_count -> admitted
+  return 0u;
 }
 
-__global__ __launch_bounds__(256) void filter_get_kernel(const uint32_t* __restrict__ slots,
-                                                         uint64_t total,
-                                                         const int64_t* __restrict__ ids, int64_t n,
-                                                         uint32_t* __restrict__ out) {
+// SlidingHashFilter::get (:93-114)
+__global__ __launch_bounds__(256) void filter_get_kernel(TableView tv, const int64_t* __restrict__ ids,
+                                                         int64_t n, uint32_t* __restrict__ out) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int64_t id = ids[i];
-  const uint64_t fid = uint64_t(id);
-  const uint32_t sign = uint32_t((fid >> 17) | (fid << 15)) & 0x0fffffffu;
-  uint64_t pos = hash_key(id ^ 0x5bd1e995) % total;
-  uint32_t c = kFilterMaxCount;  // no slot within the probe limit: get() returns max_count
-  for (int step = 0; step < kFilterMaxStep; ++step) {
-    const uint32_t v = slots[pos];
+  const uint32_t sign = filter_sign(id);
+  const uint64_t home = filter_home(id, tv.flt_total);
+  const FilterState* fs = reinterpret_cast<const FilterState*>(tv.flt_state);
+  const uint32_t S = tv.flt_nsplit, head = fs->head;
+  long long pos = -1;
+  uint32_t v = 0;
+  for (int f = 0; f < kFilterForward && pos < 0; ++f)
+    pos = filter_find(tv.flt_slots + size_t((head + uint32_t(f)) % S) * tv.flt_stride, home, sign, false, &v);
+  uint32_t c = kFilterMaxCount;                     // no usable slot: max_count
+  if (pos >= 0) {
+    c = v & kFilterMaxCount;
     if (v == 0u) {
-      c = 0;
-      break;
+      const uint32_t nb = min(fs->head_increment, S - uint32_t(kFilterForward));
+      uint32_t sb = head;
+      for (uint32_t k = 0; k < nb; ++k) {
+        sb = (sb == 0u) ? S - 1u : sb - 1u;
+        uint32_t w = 0;
+        if (filter_find(tv.flt_slots + size_t(sb) * tv.flt_stride, home, sign, true, &w) >= 0) {
+          c = w & kFilterMaxCount;
+          break;
+        }
+      }
     }
-    if ((v >> 4) == sign) {
-      c = v & kFilterMaxCount;
-      break;
-    }
-    pos = (pos + 1 == total) ? 0 : pos + 1;
   }
   out[i] = c;
+}
+
+// Between launches: the window moves on when the head split is full (:85-89); the split that
+// becomes the look-ahead one is cleared by filter_clear_kernel, launched right behind.
+__global__ void filter_advance_kernel(TableView tv) {
+  FilterState* fs = reinterpret_cast<FilterState*>(tv.flt_state);
+  if (threadIdx.x != 0) return;
+  fs->clear_req = 0;
+  if (fs->num_elements[fs->head] + 1u >= tv.flt_cap) {      // HashFilter::full(): >= capacity - 1
+    fs->head = (fs->head + 1u) % tv.flt_nsplit;
+    fs->head_increment += 1u;
+    const uint32_t c = (fs->head + uint32_t(kFilterForward) - 1u) % tv.flt_nsplit;
+    fs->num_elements[c] = 0;
+    fs->clear_req = c + 1u;
+  }
+}
+__global__ __launch_bounds__(256) void filter_clear_kernel(TableView tv) {
+  const FilterState* fs = reinterpret_cast<const FilterState*>(tv.flt_state);
+  const uint32_t req = fs->clear_req;
+  if (req == 0u) return;
+  uint32_t* split = tv.flt_slots + size_t(req - 1u) * tv.flt_stride;
+  for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < tv.flt_stride;
+       i += uint64_t(gridDim.x) * blockDim.x)
+    split[i] = 0u;
 }
 
 // =============================================================================================

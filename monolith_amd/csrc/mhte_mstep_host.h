@@ -361,6 +361,11 @@ struct MultiStep {
         HIP_OK(hipGetLastError());
         for (uint32_t k = 0; k < tc; ++k)
           if (A.tab[k].apply) ++mt->tables[t0 + k]->mut_epoch;
+        for (uint32_t k = 0; k < tc; ++k)
+          if (A.tab[k].apply && mt->tables[t0 + k]->flt_slots) {
+            mt->tables[t0 + k]->filter_maintain(st);   // (one filter for all tables: once is enough)
+            break;
+          }
       }
     }
   }

@@ -71,7 +71,7 @@ def _lower_config(name: str, cfg: entry.HashTableConfigInstance, keep: list):
   c.reserve_rows = int(tc.reserve_rows)
   c.max_load_factor = float(tc.max_load_factor)
   se = tc.slot_expire_time_config
-  c.default_expire_days = int(se.default_expire_time)
+  c.default_expire_days = int(se.default_expire_time) if int(se.default_expire_time) != 0 else -1
   slots = np.ascontiguousarray(list(se.slot_expire_times.keys()), dtype=np.int64)
   days = np.ascontiguousarray(list(se.slot_expire_times.values()), dtype=np.int32)
   c.n_slot_expire = int(slots.size)
@@ -119,6 +119,20 @@ class HashFilter:
     check(self._lib.mhte_hash_filter_get(self._h, vp(ids), C.c_int64(ids.numel()), vp(out),
                                          _stream()))
     return out
+
+  def save(self, basename: str) -> "HashFilter":
+    """hash_filter_ops.save_hash_filter (MonolithHashFilterSave): one file per split."""
+    import os
+    d = os.path.dirname(basename)
+    if d:
+      os.makedirs(d, exist_ok=True)
+    check(self._lib.mhte_hash_filter_save(self._h, basename.encode("utf-8"), _stream()))
+    return self
+
+  def restore(self, basename: str) -> "HashFilter":
+    """hash_filter_ops.restore_hash_filter (MonolithHashFilterRestore)."""
+    check(self._lib.mhte_hash_filter_restore(self._h, basename.encode("utf-8"), _stream()))
+    return self
 
   def close(self):
     if getattr(self, "_h", None):

@@ -187,3 +187,152 @@ def test_plain_c_client_runs(tmp_path):
   exe = build_c_client(tmp_path)
   r = subprocess.run([exe, str(tmp_path / "c_ckpt")], capture_output=True, text=True, timeout=120)
   assert r.returncode == 0 and "c_client ok" in r.stdout, r.stdout + r.stderr
+
+
+# =============================================================================== sliding hash filter
+class SlidingModel:
+  """sliding_hash_filter.cc:56-114 + HashFilter::find / HashFilterIterator::add (hash_filter.h:39-66,
+  118-134) restated with the engine's documented slot hash (fmix64(id ^ 0x5bd1e995) % total) and
+  28-bit signature, so that placement — which split an id lands in when the head split's 16 probe
+  positions are taken, hence when the window moves — is the device's: the checker of the device
+  filter.  The one deliberate difference is written out: the window moves between launches."""
+  PROBE, FORWARD = 16, 2
+
+  def __init__(self, capacity, split_num):
+    capacity = max(capacity, 300)
+    self.S = max(split_num, 5)
+    self.cap = capacity // (self.S - self.FORWARD + 1)
+    self.total = max(1, int(float(self.cap) * 1.2))
+    self.splits = [np.zeros(self.total + 64, dtype=np.uint32) for _ in range(self.S)]
+    self.nelem = [0] * self.S
+    self.head, self.hinc = 0, 0
+
+  def _home(self, fid):
+    return int(O.lib().mo_hash(int(np.int64(fid) ^ np.int64(0x5bd1e995)))) % self.total
+
+  @staticmethod
+  def _sign(fid):
+    u = int(fid) & 0xFFFFFFFFFFFFFFFF
+    return ((u >> 17) | (u << 15)) & 0x0FFFFFFF
+
+  def _find(self, sp, fid, nonempty):
+    home, sign = self._home(fid), self._sign(fid)
+    a = self.splits[sp]
+    for t in range(self.PROBE):
+      w = int(a[home + t])
+      if w == 0:
+        return None if nonempty else home + t
+      if (w >> 4) == sign:
+        return home + t
+    return None
+
+  def _forward(self, fid):
+    for f in range(self.FORWARD):
+      sp = (self.head + f) % self.S
+      pos = self._find(sp, fid, False)
+      if pos is not None:
+        return sp, pos
+    return None, None
+
+  def _back(self, fid):
+    i = self.head
+    for _ in range(min(self.hinc, self.S - self.FORWARD)):
+      i = (i - 1) % self.S
+      pos = self._find(i, fid, True)
+      if pos is not None:
+        return int(self.splits[i][pos]) & 15
+    return None
+
+  def add(self, fid, count):
+    sp, pos = self._forward(fid)
+    if sp is None:
+      return 15
+    w = int(self.splits[sp][pos])
+    if w:
+      self.splits[sp][pos] = (w & ~15) | min(15, (w & 15) + min(count, 15))
+      return w & 15
+    old = self._back(fid) or 0
+    self.splits[sp][pos] = (self._sign(fid) << 4) | min(15, old + min(count, 15))
+    self.nelem[sp] += 1
+    return old
+
+  def advance_if_full(self):       # (the device checks between launches)
+    if self.nelem[self.head] + 1 >= self.cap:
+      self.head = (self.head + 1) % self.S
+      self.hinc += 1
+      c = (self.head + self.FORWARD - 1) % self.S
+      self.splits[c][:] = 0
+      self.nelem[c] = 0
+
+  def get(self, fid):
+    sp, pos = self._forward(fid)
+    if sp is None:
+      return 15
+    w = int(self.splits[sp][pos])
+    if w:
+      return w & 15
+    return self._back(fid) or 0
+
+
+def _filter_table(flt, thr):
+  cfg = entry.make_table_config(
+      [entry.CombineAsSegment(1, entry.ZerosInitializer(), entry.SgdOptimizer(1.0))],
+      slot_occurrence_threshold_config=entry.SlotOccurrenceThresholdConfig(default_occurrence_threshold=thr))
+  return MultiHashTable.from_configs({"t": cfg}, name_suffix=_name(), hash_filter=flt)
+
+
+def test_sliding_hash_filter_window_against_model(tmp_path):
+  """Ids seen again and again while the window moves on (capacity 300 -> 5 splits of 75): counts
+  carry over from older splits, fall out of the window after nsplit - 2 moves, and the table admits
+  an id exactly when the model's count reaches the threshold.  Then save -> restore into a fresh
+  filter -> the same counts, and the two keep agreeing."""
+  thr = 3
+  flt = HashFilter(capacity=300, split_num=5)
+  mt = _filter_table(flt, thr)
+  model = SlidingModel(300, 5)
+  rng = np.random.default_rng(9)
+  universe = (rng.integers(1, 2**40, 900).astype(np.int64) | (1 << 48))
+  admitted = set()
+  g1 = val_t([[1.0]])
+
+  def step(fid):
+    mt.apply_gradients({"t": (ids_t([fid]), g1)})
+    if fid not in admitted:                      # (tf_bridge.cc:315-321: the filter is asked only
+      if model.add(fid, 1) >= thr:               #  about ids the table does not hold)
+        admitted.add(fid)
+      model.advance_if_full()
+
+  seq = []
+  for k in range(1000):
+    # a slowly drifting working set: old ids return for a while, then never again
+    lo = k // 2
+    seq.append(int(universe[lo + int(rng.integers(0, 60))]))
+  for i, fid in enumerate(seq):
+    step(fid)
+    if i % 100 == 99 or i == len(seq) - 1:
+      probe = np.unique(np.array(seq[:i + 1], dtype=np.int64))
+      got = flt.get(ids_t(probe)).cpu().numpy()
+      np.testing.assert_array_equal(got, [model.get(int(x)) for x in probe], err_msg="step %d" % i)
+      present = mt.contains("t", ids_t(probe)).cpu().numpy()
+      np.testing.assert_array_equal(present, [int(x) in admitted for x in probe])
+  assert model.hinc > model.S                     # the window went round more than once
+  base = str(tmp_path / "flt" / "filter")
+  flt.save(base)
+  assert sorted(os.listdir(tmp_path / "flt")) == ["filter-%05d-of-00005" % i for i in range(5)]
+  flt2 = HashFilter(capacity=300, split_num=5)
+  flt2.restore(base)
+  probe = np.unique(np.array(seq, dtype=np.int64))
+  np.testing.assert_array_equal(flt2.get(ids_t(probe)).cpu().numpy(), flt.get(ids_t(probe)).cpu().numpy())
+  mt2 = _filter_table(flt2, thr)
+  for fid in seq[-50:] + [int(x) for x in universe[400:430]]:
+    mt.apply_gradients({"t": (ids_t([fid]), g1)})
+    if fid not in admitted:
+      mt2.apply_gradients({"t": (ids_t([fid]), g1)})
+  probe2 = np.unique(np.concatenate([probe, universe[400:430]]))
+  mask = np.array([int(x) not in admitted for x in probe2])
+  np.testing.assert_array_equal(flt2.get(ids_t(probe2)).cpu().numpy()[mask],
+                                flt.get(ids_t(probe2)).cpu().numpy()[mask])
+  with pytest.raises(_lib.MhteError):             # geometry is validated (RestoreMetaDump)
+    HashFilter(capacity=300, split_num=7).restore(base)
+  with pytest.raises(_lib.MhteError):
+    HashFilter(capacity=300, split_num=5).restore(str(tmp_path / "flt" / "absent"))

@@ -1419,3 +1419,65 @@ def test_two_doublings_of_a_2p24_slot_table_mid_pipeline():
   np.testing.assert_array_equal(
       got, np.repeat(((sample | (3 << 48)) % 97).astype(np.float32)[:, None], dim, 1))
   assert mt.size("a") == filled[0] + probe.size
+
+
+# =============================================================================== TTL / expire-on-save KATs
+def _ttl_table(dim, expire_time, lr=1.0):
+  """test_utils / hash_table_ops_test.py test_hash_table(dim_size, expire_time): SGD lr 1."""
+  return make({"t": entry.make_table_config(
+      [entry.CombineAsSegment(dim, entry.ZerosInitializer(), entry.SgdOptimizer(lr))],
+      slot_expire_time_config=entry.SlotExpireTimeConfig(default_expire_time=expire_time))})
+
+
+@pytest.mark.parametrize("how", ["assign_add", "apply_gradients"])
+def test_save_restore_with_feature_eviction(how, tmp_path):
+  """hash_table_ops_test.py:294-379: rows older than the TTL relative to the table's max update time
+  are dropped by Save; [[0],[2],[3]] after assign_add, [[0],[-2],[-3]] after apply_gradients."""
+  t = _ttl_table(1, 1)
+  max_ts = 10000000
+  sec = 24 * 3600
+  for i, ts in ((1, max_ts - sec - 1), (2, max_ts - sec + 1), (3, max_ts)):
+    if how == "assign_add":
+      t.assign_add({"t": (ids_t([i]), val_t([[float(i)]]))}, req_time=ts)
+    else:
+      t.apply_gradients({"t": (ids_t([i]), val_t([[float(i)]]))}, req_time=ts)
+  base = str(tmp_path / how / "table")
+  t.save(base)
+  t2 = make({"t": sgd_cfg(1)})
+  t2.restore(base)
+  sign = 1.0 if how == "assign_add" else -1.0
+  assert t2.lookup({"t": ids_t([1, 2, 3])})["t"].cpu().tolist() == [[0.0], [sign * 2], [sign * 3]]
+
+
+@pytest.mark.parametrize("ttl,expect", [(0, [[0.0], [0.0]]), (3600, [[1.0], [2.0]])])
+def test_entry_ttl_zero_and_not_zero(ttl, expect, tmp_path):
+  """hash_table_ops_test.py:381-411 (ids -1 and 1, default req_time 0)."""
+  t = _ttl_table(1, ttl)
+  t.assign_add({"t": (ids_t([-1, 1]), val_t([[1.0], [2.0]]))})
+  base = str(tmp_path / "ttl" / "table")
+  t.save(base)
+  t2 = _ttl_table(1, 36500)
+  t2.restore(base)
+  assert t2.lookup({"t": ids_t([-1, 1])})["t"].cpu().tolist() == expect
+
+
+def test_entry_ttl_by_slots(tmp_path):
+  """hash_table_ops_test.py:413-466: slot 1 expires at once (TTL 0), slot 2 after a day; the
+  restored table saves and restores again to the same rows."""
+  ttl = entry.SlotExpireTimeConfig(default_expire_time=3600, slot_expire_times={1: 0, 2: 1})
+  cfg = lambda: {"t": entry.make_table_config(
+      [entry.CombineAsSegment(1, entry.ZerosInitializer(), entry.SgdOptimizer(1.0))],
+      slot_expire_time_config=ttl)}
+  id_1, id_2 = 1 << 48, 2 << 48
+  t = make(cfg())
+  t.assign_add({"t": (ids_t([id_1, id_2]), val_t([[1.0], [2.0]]))}, req_time=100)
+  base = str(tmp_path / "slots" / "table")
+  t.save(base)
+  t2 = make(cfg())
+  t2.restore(base)
+  assert t2.lookup({"t": ids_t([id_1, id_2])})["t"].cpu().tolist() == [[0.0], [2.0]]
+  base2 = str(tmp_path / "slots" / "table_new")
+  t2.save(base2)
+  t3 = _ttl_table(1, 36500)
+  t3.restore(base2)
+  assert t3.lookup({"t": ids_t([id_1, id_2])})["t"].cpu().tolist() == [[0.0], [2.0]]
