@@ -42,7 +42,7 @@ enum {
 
 const char* mhte_last_error(void);
 /* ABI version of this header; mhte_abi_version() must return the same value. */
-#define MHTE_ABI_VERSION 7
+#define MHTE_ABI_VERSION 8
 int32_t mhte_abi_version(void);
 
 /* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
@@ -285,6 +285,48 @@ mhte_status mhte_fused_gather_embeddings_by_input_gradient(float* fused_grad, in
 mhte_status mhte_reduce_rows(const int64_t* indices, const float* values, int64_t n, int32_t dim,
                              int64_t batch, int32_t mode, int32_t indices_sorted, float* out,
                              void* stream);
+
+/* MonolithEmbeddingToLayout / MonolithEmbeddingToLayoutGrad (RT/ops/fused_embedding_to_layout.cc
+ * :1037-1066; CUDA kernels RT/ops/fused_embedding_to_layout.cu.cc:96-199,337-...; GatherEmb /
+ * ScatterGrad RT/ops/fused_embedding_to_layout.h:204-346): pools the looked-up embeddings of every
+ * feature into the dense model's input tensors, and scatters the tensors' gradients back.
+ *   embeddings[M]      HOST array of M device pointers: matrix m is [rows_m, emb_row_floats[m]],
+ *                      emb_len[m] floats in all (the op's embeddings_list, one per shard x sub-table)
+ *   fid_offset         [dev u64, n_fid] (matrix index << 32 | row) of every fid occurrence (:50-54)
+ *   feature_offset     [dev i32, n_feature] first fid of every feature instance
+ *   nfl_offset         [dev u32, n_nfl] first feature instance of every named feature list; bit 31:
+ *                      the feature is shared by all rows of the batch (:56-60)
+ *   slices             HOST: the slices of all layouts, layouts in sorted-name order (the op sorts
+ *                      them, fused_embedding_to_layout.cc:283), slices in configuration order —
+ *                      SliceConfig / OutConfig / FeatureConfig of idl/matrix/proto/example.proto
+ *                      :176-221 flattened: feature_idx = the feature's index among the sorted feature
+ *                      names (:273-279); pooling 0 SUM, 1 MEAN, 3 FIRSTN (max_sequence_length rows);
+ *                      out_type 0 CONCAT, 1 STACK, 2 ADDN, 3 NONE; out_index / out_offset /
+ *                      out_row_floats place the slice in its output tensor [batch, out_row_floats]
+ *   outputs            HOST array of device pointers, zero-filled first (rows without fids stay 0)
+ * SUM / MEAN walk a feature's fids in order (the reference's loop: bit-identical sums); the slices
+ * of an ADDN layout are added in configuration order (the reference's CPU order; its CUDA path uses
+ * float atomics).  The gradient op zero-fills embeddings_grad and adds with float atomics, as the
+ * reference's CUDA path does.  <= 64 matrices, <= 32 outputs per call. */
+typedef struct {
+  int32_t feature_idx, start, dim;
+  int32_t pooling, max_sequence_length;
+  int32_t out_type, out_index, out_offset, out_row_floats;
+} mhte_layout_slice;
+mhte_status mhte_embedding_to_layout(const float* const* embeddings, const int32_t* emb_row_floats,
+                                     const int64_t* emb_len, int32_t n_emb, const uint64_t* fid_offset,
+                                     int64_t n_fid, const int32_t* feature_offset, int64_t n_feature,
+                                     const uint32_t* nfl_offset, int32_t n_nfl, int32_t batch_size,
+                                     const mhte_layout_slice* slices, int32_t n_slices,
+                                     float* const* outputs, const int64_t* output_len, int32_t n_outputs,
+                                     void* stream);
+mhte_status mhte_embedding_to_layout_grad(float* const* embeddings_grad, const int32_t* emb_row_floats,
+                                          const int64_t* emb_len, int32_t n_emb, const uint64_t* fid_offset,
+                                          int64_t n_fid, const int32_t* feature_offset, int64_t n_feature,
+                                          const uint32_t* nfl_offset, int32_t n_nfl, int32_t batch_size,
+                                          const mhte_layout_slice* slices, int32_t n_slices,
+                                          const float* const* tensors_grad, const int64_t* tensor_len,
+                                          int32_t n_tensors, void* stream);
 
 /* Admission filter: the reference's SlidingHashFilter (RT/hash_filter/sliding_hash_filter.{h,cc};
  * created by HashFilterOp, RT/ops/hash_filter_op.cc:47-81; the `filter_handle` input of

@@ -9,7 +9,8 @@ _SO = os.path.join(_DIR, "libmhte.so")
 _SRC = os.path.join(_DIR, "csrc", "mhte.hip")
 _DEPS = [_SRC] + [os.path.join(_DIR, "csrc", h) for h in
                   ("mhte_kernels.h", "mhte_core.h", "mhte_step_kernels.h", "mhte_pool_kernels.h",
-                   "mhte_ckpt.h", "mhte_mstep_kernels.h", "mhte_mstep_host.h", "mhte_proto_config.h")] + [os.path.join(_DIR, "..", "include", "monolith_amd_hash_table.h")]
+                   "mhte_ckpt.h", "mhte_mstep_kernels.h", "mhte_mstep_host.h", "mhte_proto_config.h",
+                   "mhte_layout_kernels.h")] + [os.path.join(_DIR, "..", "include", "monolith_amd_hash_table.h")]
 # A/B measurements: MHTE_LIBRARY=<other build of libmhte.so> (same ABI) is loaded instead
 _OVERRIDE = os.environ.get("MHTE_LIBRARY")
 
@@ -25,7 +26,7 @@ MHTE_IDS_UNIQUE = 1
 MHTE_SUM_DUPLICATES = 2
 MHTE_EXACT_ORDER = 1       # flags of mhte_table_sum_optimize_n
 MHTE_DEFER_SLOWPATH = 2
-ABI_VERSION = 7            # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
+ABI_VERSION = 8            # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 OPT_MOMENTUM, OPT_ADADELTA, OPT_RMSPROP, OPT_RMSPROPV2, OPT_ADAM, OPT_AMSGRAD = 3, 4, 5, 6, 7, 8
@@ -65,6 +66,12 @@ class TableConfig(C.Structure):
               ("occurrence_slots", C.POINTER(C.c_int64)),
               ("occurrence_thresholds", C.POINTER(C.c_int32)),
               ("enable_feature_eviction", C.c_int32), ("feature_evict_every_n_hours", C.c_int32)]
+
+
+class LayoutSlice(C.Structure):
+  _fields_ = [("feature_idx", C.c_int32), ("start", C.c_int32), ("dim", C.c_int32),
+              ("pooling", C.c_int32), ("max_sequence_length", C.c_int32), ("out_type", C.c_int32),
+              ("out_index", C.c_int32), ("out_offset", C.c_int32), ("out_row_floats", C.c_int32)]
 
 
 class TableStats(C.Structure):
@@ -120,6 +127,7 @@ EXPORTS = [
     "mhte_multi_table_create_from_proto", "mhte_multi_table_find", "mhte_multi_table_is_initialized",
     "mhte_hash_filter_create_from_proto", "mhte_lookup_entry", "mhte_feature_stat",
     "mhte_advance_clock_for_testing", "mhte_hash_filter_save", "mhte_hash_filter_restore",
+    "mhte_embedding_to_layout", "mhte_embedding_to_layout_grad",
 ]
 
 _lib = None

@@ -33,6 +33,7 @@
 #include "mhte_proto_config.h"
 #include <map>
 #include "mhte_pool_kernels.h"
+#include "mhte_layout_kernels.h"
 #include "mhte_step_kernels.h"
 #include "mhte_mstep_kernels.h"
 
@@ -2651,6 +2652,123 @@ mhte_status mhte_table_set_count_hits(mhte_multi_table* t, int32_t table, int32_
     std::lock_guard<std::mutex> g(tb.mu);
     tb.count_hits = enable != 0;
     ++tb.view_version;
+  });
+}
+
+// ---- fused_embedding_to_layout ------------------------------------------------------------------
+extern "C++" {
+namespace mhte {
+static void layout_launch(bool forward, const float* const* embeddings, const int32_t* emb_stride,
+                          const int64_t* emb_count, int32_t n_emb, const unsigned long long* fid_offset,
+                          int64_t n_fid, const int32_t* feature_offset, int64_t n_feature,
+                          const uint32_t* nfl_offset, int32_t n_nfl, int32_t batch,
+                          const mhte_layout_slice* slices, int32_t n_slices, float* const* outputs,
+                          const int64_t* output_len, int32_t n_outputs, hipStream_t st) {
+  if (n_emb < 0 || n_emb > kMaxLayoutEmb || n_outputs < 0 || n_outputs > kMaxLayoutOut)
+    throw Error(MHTE_INVALID_ARGUMENT, "layout: at most " + std::to_string(kMaxLayoutEmb) +
+                                           " embedding matrices and " + std::to_string(kMaxLayoutOut) + " outputs");
+  if (batch < 0 || n_slices < 0 || n_fid > INT32_MAX || n_feature > INT32_MAX)
+    throw Error(MHTE_INVALID_ARGUMENT, "layout: bad sizes");
+  if (forward) {  // SetZeroFunctor: rows without fids stay zero
+    for (int32_t i = 0; i < n_outputs; ++i)
+      if (output_len[i] > 0) HIP_OK(hipMemsetAsync(outputs[i], 0, size_t(output_len[i]) * 4, st));
+  } else {
+    for (int32_t i = 0; i < n_emb; ++i)
+      if (emb_count[i] > 0)
+        HIP_OK(hipMemsetAsync(const_cast<float*>(embeddings[i]), 0, size_t(emb_count[i]) * 4, st));
+  }
+  if (batch == 0 || n_slices == 0) return;
+  LayoutArgs A{};
+  for (int32_t i = 0; i < n_emb; ++i) {
+    A.emb[i] = embeddings[i];
+    A.emb_stride[i] = uint32_t(emb_stride[i]);
+    A.emb_count[i] = uint32_t(emb_count[i]);
+  }
+  for (int32_t i = 0; i < n_outputs; ++i) A.out[i] = outputs[i];
+  A.fid_offset = fid_offset;
+  A.feature_offset = feature_offset;
+  A.nfl_offset = nfl_offset;
+  A.n_fid = int32_t(n_fid);
+  A.n_feature = int32_t(n_feature);
+  A.n_nfl = n_nfl;
+  A.batch = batch;
+  A.n_emb = n_emb;
+  int32_t k = 0;
+  while (k < n_slices) {
+    // one launch per kMaxLayoutTasks slices; an ADDN layout's slices stay together
+    int32_t nt = 0, nu = 0;
+    while (k < n_slices) {
+      int32_t span = 1;
+      if (slices[k].out_type == 2)
+        while (k + span < n_slices && slices[k + span].out_type == 2 &&
+               slices[k + span].out_index == slices[k].out_index) ++span;
+      if (span > kMaxLayoutTasks) throw Error(MHTE_INVALID_ARGUMENT, "layout: an ADDN layout has too many slices");
+      if (nt + span > kMaxLayoutTasks) break;
+      for (int32_t q = 0; q < span; ++q) {
+        const mhte_layout_slice& sc = slices[k + q];
+        if (sc.out_index < 0 || sc.out_index >= n_outputs || sc.dim <= 0 || sc.out_row_floats <= 0 ||
+            int64_t(sc.out_offset) + int64_t(sc.dim) * (sc.pooling == 3 ? std::max(1, sc.max_sequence_length) : 1) >
+                sc.out_row_floats ||
+            int64_t(batch) * sc.out_row_floats > output_len[sc.out_index])
+          throw Error(MHTE_INVALID_ARGUMENT, "layout: slice " + std::to_string(k + q) + " does not fit its output");
+        if (sc.out_type == 2 && sc.pooling == 3)   // CHECK in the op's constructor
+          throw Error(MHTE_INVALID_ARGUMENT, "layout: FIRSTN pooling cannot be added (ADDN)");
+        if (sc.out_type == 2 && sc.dim != slices[k].dim)
+          throw Error(MHTE_INVALID_ARGUMENT, "layout: slices of an ADDN layout differ in width");
+        LayoutTask& t = A.task[nt + q];
+        t.nfl_idx = sc.feature_idx;
+        t.start = sc.start;
+        t.dim = sc.dim;
+        t.pooling = sc.pooling;
+        t.max_seq = sc.max_sequence_length;
+        t.out_index = sc.out_index;
+        t.out_offset = sc.out_offset;
+        t.out_stride = sc.out_row_floats;
+      }
+      A.unit[nu].first = uint16_t(nt);
+      A.unit[nu].count = uint16_t(span);
+      A.unit[nu].addn = slices[k].out_type == 2 ? 1 : 0;
+      ++nu;
+      nt += span;
+      k += span;
+    }
+    A.n_units = nu;
+    const dim3 grid(uint32_t((int64_t(batch) * 16 + 255) / 256), uint32_t(nu));
+    if (forward) layout_kernel<true><<<grid, 256, 0, st>>>(A);
+    else layout_kernel<false><<<grid, 256, 0, st>>>(A);
+    HIP_OK(hipGetLastError());
+  }
+}
+}  // namespace mhte
+}  // extern "C++"
+
+mhte_status mhte_embedding_to_layout(const float* const* embeddings, const int32_t* emb_row_floats,
+                                     const int64_t* emb_len, int32_t n_emb, const uint64_t* fid_offset,
+                                     int64_t n_fid, const int32_t* feature_offset, int64_t n_feature,
+                                     const uint32_t* nfl_offset, int32_t n_nfl, int32_t batch_size,
+                                     const mhte_layout_slice* slices, int32_t n_slices,
+                                     float* const* outputs, const int64_t* output_len, int32_t n_outputs,
+                                     void* stream) {
+  return guard([&] {
+    layout_launch(true, embeddings, emb_row_floats, emb_len, n_emb,
+                  reinterpret_cast<const unsigned long long*>(fid_offset), n_fid, feature_offset, n_feature,
+                  nfl_offset, n_nfl, batch_size, slices, n_slices, outputs, output_len, n_outputs, S(stream));
+  });
+}
+
+mhte_status mhte_embedding_to_layout_grad(float* const* embeddings_grad, const int32_t* emb_row_floats,
+                                          const int64_t* emb_len, int32_t n_emb, const uint64_t* fid_offset,
+                                          int64_t n_fid, const int32_t* feature_offset, int64_t n_feature,
+                                          const uint32_t* nfl_offset, int32_t n_nfl, int32_t batch_size,
+                                          const mhte_layout_slice* slices, int32_t n_slices,
+                                          const float* const* tensors_grad, const int64_t* tensor_len,
+                                          int32_t n_tensors, void* stream) {
+  return guard([&] {
+    layout_launch(false, const_cast<const float* const*>(embeddings_grad), emb_row_floats, emb_len, n_emb,
+                  reinterpret_cast<const unsigned long long*>(fid_offset), n_fid, feature_offset, n_feature,
+                  nfl_offset, n_nfl, batch_size, slices, n_slices,
+                  (float* const*)tensors_grad,
+                  tensor_len, n_tensors, S(stream));
   });
 }
 

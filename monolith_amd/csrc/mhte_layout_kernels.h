@@ -1,0 +1,139 @@
+// fused_embedding_to_layout forward / backward: the pooling that turns looked-up embeddings into
+// the dense model's input tensors.  Reference:
+//   runtime/ops/fused_embedding_to_layout.h:50-76 (fid / nfl offset encodings, GetFeatureInfo),
+//   :204-261 GatherEmb, :286-346 ScatterGrad; the CUDA kernels that call them,
+//   runtime/ops/fused_embedding_to_layout.cu.cc:96-199 (ForwardBatchKernel), :337-... (backward);
+//   op inputs / outputs runtime/ops/fused_embedding_to_layout.cc:1037-1066; configuration messages
+//   idl/matrix/proto/example.proto:176-221.  Included by mhte.hip.
+//
+// One lane group of 16 takes one (unit, batch row); lanes stride over the slice's elements, the
+// feature's fids are walked in order — the reference's loop, so SUM / MEAN are its sequential sums
+// bit for bit.  A unit is one slice of a layout, or a whole ADDN layout: its slices are added in
+// configuration order by the same group (the reference's GPU path adds them with float atomics in
+// whatever order the blocks arrive, its CPU path in this order).
+// HBM-streaming copy / add work: nothing here has a GEMM shape.
+#ifndef MHTE_LAYOUT_KERNELS_H_
+#define MHTE_LAYOUT_KERNELS_H_
+
+#include "mhte_kernels.h"
+
+namespace mhte {
+
+constexpr int kMaxLayoutTasks = 48;   // slices per launch (more: several launches)
+constexpr int kMaxLayoutEmb = 64;     // embedding matrices (shard x sub-table)
+constexpr int kMaxLayoutOut = 32;     // output tensors
+
+enum LayoutPooling : int32_t { kPoolSum = 0, kPoolMean = 1, kPoolFirstN = 3 };  // example.proto:176-180
+
+struct LayoutTask {
+  int32_t nfl_idx;       // SliceConfig.feature_idx
+  int32_t start, dim;    // slice [start, start + dim) of the feature's embedding
+  int32_t pooling;
+  int32_t max_seq;       // FIRSTN: rows kept
+  int32_t out_index;     // which output tensor
+  int32_t out_offset;    // float offset of the slice inside an output row
+  int32_t out_stride;    // floats per output row
+};
+struct LayoutUnit {
+  uint16_t first, count; // tasks [first, first + count); count > 1 only for an ADDN layout
+  uint16_t addn, pad;
+};
+struct LayoutArgs {
+  const float* emb[kMaxLayoutEmb];      // forward: embeddings; backward: gradient buffers (written)
+  uint32_t emb_stride[kMaxLayoutEmb];   // floats per row (PtrWrapper.offset)
+  uint32_t emb_count[kMaxLayoutEmb];    // floats in the matrix (PtrWrapper.count)
+  float* out[kMaxLayoutOut];            // forward: outputs; backward: output gradients (read)
+  const unsigned long long* fid_offset;
+  const int32_t* feature_offset;
+  const uint32_t* nfl_offset;
+  int32_t n_fid, n_feature, n_nfl, batch, n_emb, n_units;
+  LayoutTask task[kMaxLayoutTasks];
+  LayoutUnit unit[kMaxLayoutTasks];
+};
+static_assert(sizeof(LayoutArgs) <= 4096, "kernel arguments exceed 4 KB");
+
+// GetFeatureInfo + the feature's fid range for batch row b (fused_embedding_to_layout.h:56-76,
+// :214-221); false: the named feature list is absent or the row has no fids
+__device__ __forceinline__ bool layout_fid_range(const LayoutArgs& A, int32_t nfl_idx, int32_t b,
+                                                 int32_t* f0, int32_t* f1) {
+  if (nfl_idx < 0 || nfl_idx >= A.n_nfl) return false;
+  const uint32_t enc = A.nfl_offset[nfl_idx];
+  const bool shared = enc >> 31;
+  const int32_t off = int32_t(enc & 0x7fffffffu);
+  const int32_t off_next = nfl_idx < A.n_nfl - 1 ? int32_t(A.nfl_offset[nfl_idx + 1] & 0x7fffffffu)
+                                                 : A.n_feature;
+  if (off_next - off <= 0) return false;          // "nfl exits"
+  const int32_t f = off + (shared ? 0 : b);
+  if (f >= A.n_feature) return false;
+  *f0 = A.feature_offset[f];
+  *f1 = f < A.n_feature - 1 ? A.feature_offset[f + 1] : A.n_fid;
+  return *f1 > *f0;
+}
+
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void layout_kernel(LayoutArgs A) {
+  constexpr int G = 16;
+  const int j = threadIdx.x & (G - 1);
+  const int32_t b = int32_t((int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G);
+  if (b >= A.batch) return;
+  const LayoutUnit u = A.unit[blockIdx.y];
+  // elements of an ADDN layout's row, summed over its slices in order (forward)
+  for (int32_t e0 = 0; e0 < A.task[u.first].dim || e0 == 0; e0 += G) {
+    const int32_t e = e0 + j;
+    float acc = 0.f;
+    bool any = false;
+    for (uint32_t k = u.first; k < uint32_t(u.first) + u.count; ++k) {
+      const LayoutTask t = A.task[k];
+      int32_t f0 = 0, f1 = 0;
+      if (e >= t.dim || !layout_fid_range(A, t.nfl_idx, b, &f0, &f1)) continue;
+      const int32_t fid_num = f1 - f0;
+      float* orow = A.out[t.out_index] + int64_t(b) * t.out_stride + t.out_offset;
+      float pooled = 0.f;
+      int32_t seq = 0;
+      for (int32_t q = f0; q < f1; ++q) {
+        const unsigned long long fo = A.fid_offset[q];
+        const uint32_t i1 = uint32_t(fo >> 32), i2 = uint32_t(fo);
+        if (i1 >= uint32_t(A.n_emb)) continue;
+        const uint64_t at = uint64_t(i2) * A.emb_stride[i1] + uint32_t(t.start) + uint32_t(e);
+        if (at >= A.emb_count[i1]) continue;      // (CUSTOM_CHECK in the reference)
+        if (FORWARD) {
+          const float x = A.emb[i1][at];
+          if (t.pooling == kPoolFirstN) {
+            if (seq < t.max_seq) orow[int64_t(seq) * t.dim + e] = x;
+            ++seq;
+          } else if (t.pooling == kPoolMean) {
+            pooled = (q == f0) ? x / float(fid_num) : pooled + x / float(fid_num);
+          } else {
+            pooled = (q == f0) ? x : pooled + x;
+          }
+        } else {
+          float* dst = const_cast<float*>(A.emb[i1]) + at;
+          if (t.pooling == kPoolFirstN) {
+            if (seq < t.max_seq) atomicAdd(dst, orow[int64_t(seq) * t.dim + e]);
+            ++seq;
+          } else if (t.pooling == kPoolMean) {
+            atomicAdd(dst, orow[e] / float(fid_num));
+          } else {
+            atomicAdd(dst, orow[e]);
+          }
+        }
+      }
+      if (FORWARD && t.pooling != kPoolFirstN) {
+        if (u.addn) {
+          acc = any ? acc + pooled : pooled;
+          any = true;
+        } else {
+          orow[e] = pooled;
+        }
+      }
+    }
+    if (FORWARD && u.addn && any) {
+      const LayoutTask t = A.task[u.first];
+      A.out[t.out_index][int64_t(b) * t.out_stride + t.out_offset + e] = acc;
+    }
+    // (all slices of a unit have its first slice's width; FIRSTN units are single slices)
+  }
+}
+
+}  // namespace mhte
+#endif  // MHTE_LAYOUT_KERNELS_H_

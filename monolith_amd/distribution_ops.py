@@ -315,3 +315,127 @@ def reduce_sqrtn(id_indices, id_values, id_length, indices_sorted: bool = True):
   """distribution_ops.reduce_sqrtn (ReduceSquareNorm, reduce_op.cc:91-125): sqrt of the sum of
   squares."""
   return _reduce(id_indices, id_values, id_length, 2, indices_sorted)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused_embedding_to_layout (reference distribution_ops.fused_embedding_to_layout and its gradient;
+# configuration messages of idl/matrix/proto/example.proto:176-221 as plain Python objects)
+# ---------------------------------------------------------------------------------------------
+class PoolingType:
+  SUM, MEAN, FIRSTN = 0, 1, 3
+
+
+class OutType:
+  CONCAT, STACK, ADDN, NONE = 0, 1, 2, 3
+
+
+class SliceConfig:
+  def __init__(self, feature_name: str, start: int, end: int):
+    self.feature_name, self.start, self.end = feature_name, int(start), int(end)
+
+
+class OutConfig:
+  """slice_configs in order; shape: list of per-tensor dims (first dim -1 = batch): one tensor for
+  CONCAT / STACK / ADDN, one per slice for NONE."""
+
+  def __init__(self, slice_configs: List[SliceConfig], out_type: int, shape: List[List[int]]):
+    self.slice_configs, self.out_type, self.shape = list(slice_configs), out_type, [list(s) for s in shape]
+
+
+class FeatureConfig:
+  def __init__(self, table: str, pooling_type: int = PoolingType.SUM, slice_dims=(),
+               max_sequence_length: int = 0):
+    self.table, self.pooling_type = table, pooling_type
+    self.slice_dims, self.max_sequence_length = list(slice_dims), int(max_sequence_length)
+
+
+class FeatureConfigs:
+  def __init__(self, feature_configs, out_configs):
+    self.feature_configs, self.out_configs = dict(feature_configs), dict(out_configs)
+
+
+def _layout_plan(cfgs: FeatureConfigs, batch_size: int):
+  """-> (slices ctypes array, output shapes in op order).  Mirrors the op's constructor
+  (runtime/ops/fused_embedding_to_layout.cc:240-284): features are indexed by sorted name, layouts
+  are emitted in sorted-name order, a slice takes its feature's pooling type."""
+  feature_names = sorted(cfgs.feature_configs)
+  slices, shapes = [], []
+  for ln in sorted(cfgs.out_configs):
+    oc = cfgs.out_configs[ln]
+    base = len(shapes)
+    for sh in oc.shape:
+      shapes.append([batch_size if (i == 0 and d == -1) else d for i, d in enumerate(sh)])
+    offset = 0
+    for i, sc in enumerate(oc.slice_configs):
+      fc = cfgs.feature_configs[sc.feature_name]
+      dim = sc.end - sc.start
+      s = _lib.LayoutSlice()
+      s.feature_idx = feature_names.index(sc.feature_name)
+      s.start, s.dim = sc.start, dim
+      s.pooling, s.max_sequence_length = fc.pooling_type, fc.max_sequence_length
+      s.out_type = oc.out_type
+      if len(oc.shape) == 1:
+        s.out_index = base
+        row = int(np.prod(shapes[base][1:]))
+        if oc.out_type == OutType.CONCAT:
+          s.out_offset = offset
+          offset += dim
+        elif oc.out_type == OutType.STACK:
+          s.out_offset = i * dim
+        else:
+          s.out_offset = 0
+        s.out_row_floats = row
+      else:                          # NONE: one tensor per slice
+        s.out_index = base + i
+        s.out_offset = 0
+        s.out_row_floats = int(np.prod(shapes[base + i][1:]))
+      slices.append(s)
+  return (_lib.LayoutSlice * len(slices))(*slices), shapes
+
+
+def _layout_common(embeddings_list, fid_offset, feature_offset, nfl_offset):
+  dev = embeddings_list[0].device
+  embs = [e.to(device=dev, dtype=torch.float32).contiguous() for e in embeddings_list]
+  stride = (C.c_int32 * len(embs))(*[int(e.shape[1]) if e.dim() == 2 else 1 for e in embs])
+  count = (C.c_int64 * len(embs))(*[e.numel() for e in embs])
+  fo = fid_offset.to(device=dev).contiguous()
+  assert fo.dtype in (torch.int64, torch.uint64)
+  fe = feature_offset.to(device=dev, dtype=torch.int32).contiguous()
+  nf = nfl_offset.to(device=dev).contiguous()
+  assert nf.dtype in (torch.int32, torch.uint32)
+  return dev, embs, stride, count, fo, fe, nf
+
+
+def fused_embedding_to_layout(embeddings_list: List[torch.Tensor], fid_offset: torch.Tensor,
+                              feature_offset: torch.Tensor, nfl_offset: torch.Tensor, batch_size: int,
+                              feature_cfgs: FeatureConfigs) -> List[torch.Tensor]:
+  """MonolithEmbeddingToLayout: the layouts' tensors, layouts in sorted-name order."""
+  dev, embs, stride, count, fo, fe, nf = _layout_common(embeddings_list, fid_offset, feature_offset,
+                                                        nfl_offset)
+  slices, shapes = _layout_plan(feature_cfgs, int(batch_size))
+  outs = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes]
+  lens = (C.c_int64 * len(outs))(*[o.numel() for o in outs])
+  check(_lib.lib().mhte_embedding_to_layout(
+      _ptr_array(embs), stride, count, C.c_int32(len(embs)), vp(fo), C.c_int64(fo.numel()), vp(fe),
+      C.c_int64(fe.numel()), vp(nf), C.c_int32(nf.numel()), C.c_int32(int(batch_size)), slices,
+      C.c_int32(len(slices)), _ptr_array(outs), lens, C.c_int32(len(outs)), _stream()))
+  return outs
+
+
+def fused_embedding_to_layout_grad(embeddings_list: List[torch.Tensor], fid_offset: torch.Tensor,
+                                   feature_offset: torch.Tensor, nfl_offset: torch.Tensor,
+                                   batch_size: int, tensors_grad: List[torch.Tensor],
+                                   feature_cfgs: FeatureConfigs) -> List[torch.Tensor]:
+  """MonolithEmbeddingToLayoutGrad: gradients of ``embeddings_list`` (same shapes)."""
+  dev, embs, stride, count, fo, fe, nf = _layout_common(embeddings_list, fid_offset, feature_offset,
+                                                        nfl_offset)
+  slices, shapes = _layout_plan(feature_cfgs, int(batch_size))
+  assert len(tensors_grad) == len(shapes)
+  tg = [g.to(device=dev, dtype=torch.float32).contiguous() for g in tensors_grad]
+  grads = [torch.empty_like(e) for e in embs]
+  lens = (C.c_int64 * len(tg))(*[g.numel() for g in tg])
+  check(_lib.lib().mhte_embedding_to_layout_grad(
+      _ptr_array(grads), stride, count, C.c_int32(len(embs)), vp(fo), C.c_int64(fo.numel()), vp(fe),
+      C.c_int64(fe.numel()), vp(nf), C.c_int32(nf.numel()), C.c_int32(int(batch_size)), slices,
+      C.c_int32(len(slices)), _ptr_array(tg), lens, C.c_int32(len(tg)), _stream()))
+  return grads

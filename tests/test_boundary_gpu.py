@@ -336,3 +336,132 @@ def test_sliding_hash_filter_window_against_model(tmp_path):
     HashFilter(capacity=300, split_num=7).restore(base)
   with pytest.raises(_lib.MhteError):
     HashFilter(capacity=300, split_num=5).restore(str(tmp_path / "flt" / "absent"))
+
+
+# =============================================================================== fused_embedding_to_layout
+def _layout_model(embs, fid_offset, feature_offset, nfl_offset, batch, cfgs, tensors_grad=None):
+  """GatherEmb / ScatterGrad (runtime/ops/fused_embedding_to_layout.h:204-346) and the op's layout
+  placement restated in numpy, the way the reference's own test computes its expectation
+  (fused_embedding_to_layout_test.py:430-530, 690-710): the checker.  Forward when tensors_grad is
+  None, else the gradients of `embs`."""
+  from monolith_amd.distribution_ops import OutType, PoolingType
+  names = sorted(cfgs.feature_configs)
+  n_feature, n_fid, n_nfl = len(feature_offset), len(fid_offset), len(nfl_offset)
+  outs, grads = [], [np.zeros_like(e) for e in embs]
+  k = 0
+  for ln in sorted(cfgs.out_configs):
+    oc = cfgs.out_configs[ln]
+    base = len(outs)
+    for sh in oc.shape:
+      outs.append(np.zeros([batch if d == -1 else d for d in sh], np.float32))
+    off = 0
+    for i, sc in enumerate(oc.slice_configs):
+      fc = cfgs.feature_configs[sc.feature_name]
+      dim = sc.end - sc.start
+      nfl = names.index(sc.feature_name)
+      enc = int(nfl_offset[nfl])
+      shared, noff = enc >> 31, enc & 0x7fffffff
+      nxt = (int(nfl_offset[nfl + 1]) & 0x7fffffff) if nfl < n_nfl - 1 else n_feature
+      t_idx = base if len(oc.shape) == 1 else base + i
+      tgt = outs[t_idx] if tensors_grad is None else tensors_grad[t_idx]
+      for b in range(batch):
+        if nxt - noff <= 0:
+          continue
+        f = noff + (0 if shared else b)
+        f0 = int(feature_offset[f])
+        f1 = int(feature_offset[f + 1]) if f < n_feature - 1 else n_fid
+        rows = []
+        for q in range(f0, f1):
+          i1, i2 = int(fid_offset[q]) >> 32, int(fid_offset[q]) & 0xffffffff
+          rows.append((i1, i2))
+        if not rows:
+          continue
+        if oc.out_type == OutType.CONCAT:
+          view = tgt[b, off:off + dim]
+        elif oc.out_type == OutType.STACK:
+          view = tgt[b, i, :]
+        elif oc.out_type == OutType.ADDN:
+          view = tgt[b, :]
+        else:
+          view = tgt[b]
+        if tensors_grad is None:
+          if fc.pooling_type == PoolingType.FIRSTN:
+            for s_, (i1, i2) in enumerate(rows[:fc.max_sequence_length]):
+              view[s_, :] = embs[i1][i2, sc.start:sc.end]
+            continue
+          acc = None
+          for (i1, i2) in rows:
+            x = embs[i1][i2, sc.start:sc.end]
+            if fc.pooling_type == PoolingType.MEAN:
+              x = x / np.float32(len(rows))
+            acc = x.copy() if acc is None else acc + x
+          if oc.out_type == OutType.ADDN:
+            view += acc if k_first_addn.get((t_idx, b)) else 0
+            if not k_first_addn.get((t_idx, b)):
+              view[:] = acc
+              k_first_addn[(t_idx, b)] = True
+          else:
+            view[:] = acc
+        else:
+          for s_, (i1, i2) in enumerate(rows):
+            if fc.pooling_type == PoolingType.FIRSTN:
+              if s_ < fc.max_sequence_length:
+                grads[i1][i2, sc.start:sc.end] += view[s_, :]
+            elif fc.pooling_type == PoolingType.MEAN:
+              grads[i1][i2, sc.start:sc.end] += view / np.float32(len(rows))
+            else:
+              grads[i1][i2, sc.start:sc.end] += view
+      if oc.out_type == OutType.CONCAT:
+        off += dim
+      k += 1
+  return outs if tensors_grad is None else grads
+
+
+k_first_addn = {}
+
+
+@pytest.mark.parametrize("batch,seed", [(1, 0), (7, 1), (300, 2)])
+def test_fused_embedding_to_layout_forward_and_grad(batch, seed):
+  from monolith_amd import distribution_ops as D
+  rng = np.random.default_rng(seed)
+  P_, OT = D.PoolingType, D.OutType
+  feats = {"f_a": D.FeatureConfig("t0", P_.SUM, [1, 8]), "f_b": D.FeatureConfig("t1", P_.MEAN, [1, 8]),
+           "f_c": D.FeatureConfig("t2", P_.FIRSTN, [1, 4], max_sequence_length=3),
+           "f_d": D.FeatureConfig("t0", P_.SUM, [1, 8]), "f_e": D.FeatureConfig("t1", P_.SUM, [1, 8])}
+  S_ = D.SliceConfig
+  outs = {
+      "bias": D.OutConfig([S_("f_a", 0, 1), S_("f_b", 0, 1), S_("f_d", 0, 1), S_("f_e", 0, 1)], OT.ADDN, [[-1, 1]]),
+      "vec": D.OutConfig([S_("f_a", 1, 9), S_("f_b", 1, 9), S_("f_d", 1, 9)], OT.CONCAT, [[-1, 24]]),
+      "ffm": D.OutConfig([S_("f_b", 1, 9), S_("f_a", 1, 9)], OT.STACK, [[-1, 2, 8]]),
+      "seq": D.OutConfig([S_("f_c", 1, 5)], OT.NONE, [[-1, 3, 4]]),
+      "two": D.OutConfig([S_("f_a", 1, 9), S_("f_b", 0, 1)], OT.NONE, [[-1, 8], [-1, 1]]),
+  }
+  cfgs = D.FeatureConfigs(feats, outs)
+  embs = [rng.standard_normal((50, 9)).astype(np.float32), rng.standard_normal((40, 9)).astype(np.float32),
+          rng.standard_normal((30, 5)).astype(np.float32)]
+  mat_of = {"f_a": 0, "f_b": 1, "f_c": 2, "f_d": 0, "f_e": 1}
+  fid_offset, feature_offset, nfl_offset = [], [], []
+  for name in sorted(feats):
+    shared = name == "f_d"                       # one feature instance for the whole batch
+    absent = name == "f_e"                       # a named feature list with no instances at all
+    nfl_offset.append(len(feature_offset) | ((1 << 31) if shared else 0))
+    for b in range(0 if absent else (1 if shared else batch)):
+      feature_offset.append(len(fid_offset))
+      for _ in range(int(rng.integers(0, 6))):   # 0..5 fids; 0: the row keeps zeros
+        m = mat_of[name]
+        fid_offset.append((m << 32) | int(rng.integers(0, embs[m].shape[0])))
+  fo = torch.tensor(np.array(fid_offset, dtype=np.uint64).view(np.int64)).cuda()
+  fe = torch.tensor(np.array(feature_offset, dtype=np.int32)).cuda()
+  nf = torch.tensor(np.array(nfl_offset, dtype=np.uint32).view(np.int32)).cuda()
+  dev_embs = [torch.tensor(e).cuda() for e in embs]
+  got = D.fused_embedding_to_layout(dev_embs, fo, fe, nf, batch, cfgs)
+  k_first_addn.clear()
+  exp = _layout_model(embs, fid_offset, feature_offset, nfl_offset, batch, cfgs)
+  assert len(got) == len(exp) == 6
+  for g, e in zip(got, exp):
+    np.testing.assert_array_equal(g.cpu().numpy(), e)      # sequential sums: bit for bit
+  tg = [rng.standard_normal(e.shape).astype(np.float32) for e in exp]
+  gg = D.fused_embedding_to_layout_grad(dev_embs, fo, fe, nf, batch, [torch.tensor(t).cuda() for t in tg], cfgs)
+  ge = _layout_model(embs, fid_offset, feature_offset, nfl_offset, batch, cfgs, tensors_grad=tg)
+  for g, e in zip(gg, ge):                                  # float atomics: arrival order
+    np.testing.assert_allclose(g.cpu().numpy(), e, rtol=1e-5, atol=1e-5)
