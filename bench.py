@@ -51,6 +51,12 @@ def parse():
                  help="gradient buffers rotated by the timed loop (17 x 16.8 MB > the 256 MiB "
                       "Infinity Cache: gradients are read from HBM, not from the LLC)")
   p.add_argument("--no-parity-check", action="store_true")
+  p.add_argument("--dense", action="store_true",
+                 help="dlrm26: the dense leg too — embeddings -> fused_embedding_to_layout (concat) -> "
+                      "bf16 MLP 1024-512-256-1 on MFMA (hipBLASLt through torch) forward + backward + "
+                      "SGD, layout gradient -> sparse update; the next batch's dedup runs on a side "
+                      "stream beside the GEMMs")
+  p.add_argument("--mlp", default="1024,512,256", help="hidden widths of the dense model")
   p.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"])
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--cpu-steps", type=int, default=150)
@@ -209,15 +215,64 @@ def main_dlrm(args):
   NG = 2
   grad_pool = [torch.from_numpy(grad_host(g)).to(dev) for g in range(NG)]
   out = torch.empty(gsz, dtype=torch.float32, device=dev)
+  if args.dense:
+    os.environ.setdefault("MHTE_MSTEP_SIDE", "1")   # dedup of the next batch beside the GEMMs
   step = MultiSparseStep(mt, B, exact_order=args.exact_order)
   applied = []
   evictions = [0]
 
+  # ---- dense leg: layout (concat of the T features' rows) -> MLP -> layout gradient -------------
+  dense = None
+  if args.dense:
+    from monolith_amd import distribution_ops as DO
+    feats = {n: DO.FeatureConfig(n, DO.PoolingType.SUM, [dims[i]]) for i, n in enumerate(names)}
+    kin = (sum(dims) + 127) // 128 * 128     # GEMM K padded to a multiple of 128 (zero columns)
+    concat = DO.OutConfig([DO.SliceConfig(n, 0, dims[i]) for i, n in enumerate(names)], DO.OutType.CONCAT,
+                          [[-1, kin]])
+    lcfg = DO.FeatureConfigs(feats, {"concat": concat})
+    # one id per feature and sample: fid (t, b) is row b of matrix t (the per-occurrence rows of the
+    # step's forward), feature instance t * B + b, named feature list t
+    fo = (torch.arange(T, dtype=torch.int64, device=dev).repeat_interleave(B) << 32) | \
+         torch.arange(B, dtype=torch.int64, device=dev).repeat(T)
+    fe = torch.arange(T * B, dtype=torch.int32, device=dev)
+    nf = (torch.arange(T, dtype=torch.int32, device=dev) * B)
+    widths = [kin] + [int(w) for w in args.mlp.split(",")] + [1]
+    layers = []
+    for a, b_ in zip(widths[:-1], widths[1:]):
+      layers += [torch.nn.Linear(a, b_), torch.nn.ReLU()]
+    mlp = torch.nn.Sequential(*layers[:-1]).to(dev)
+    opt = torch.optim.SGD(mlp.parameters(), lr=1e-3)
+    eoff = np.concatenate([[0], np.cumsum([B * d for d in dims])])
+    dense = {"flops_per_step": 6 * B * sum(a * b_ for a, b_ in zip(widths[:-1], widths[1:])), "widths": widths}
+
+    gflat = torch.empty(gsz, dtype=torch.float32, device=dev)
+    gviews = [gflat[eoff[i]:eoff[i + 1]].view(B, dims[i]) for i in range(T)]
+
+    def mlp_step(x):
+      with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = mlp(x)
+      loss = y.float().mean()
+      opt.zero_grad(set_to_none=True)
+      loss.backward()
+      opt.step()
+
+    def dense_step(emb_flat):
+      embs = [emb_flat[eoff[i]:eoff[i + 1]].view(B, dims[i]) for i in range(T)]
+      x = DO.fused_embedding_to_layout(embs, fo, fe, nf, B, lcfg, one_fid_unique_rows=True)[0]
+      x.requires_grad_(True)
+      mlp_step(x)
+      DO.fused_embedding_to_layout_grad(embs, fo, fe, nf, B, [x.grad], lcfg, one_fid_unique_rows=True,
+                                        out=gviews)
+      return gflat
+
   def run(lo, hi):
     for s in range(lo, hi):
       step.forward(rag[s], rag[s + 1], out=out)
-      step.backward(grad_pool[s % NG], S.update_time(s))
-      applied.append((s, s % NG, S.update_time(s)))
+      if dense is not None:
+        step.backward(dense_step(out), S.update_time(s))
+      else:
+        step.backward(grad_pool[s % NG], S.update_time(s))
+        applied.append((s, s % NG, S.update_time(s)))
       if args.evict_every and (s + 1) % args.evict_every == 0:
         for n in names:
           mt.evict(n)
@@ -238,8 +293,11 @@ def main_dlrm(args):
     step.forward(rag[s], rag[s + 1], out=out)
     if s % 10 == 0:
       uniq.append(step.unique_counts())
-    step.backward(grad_pool[s % NG], S.update_time(s))
-    applied.append((s, s % NG, S.update_time(s)))
+    if dense is not None:
+      step.backward(dense_step(out), S.update_time(s))
+    else:
+      step.backward(grad_pool[s % NG], S.update_time(s))
+      applied.append((s, s % NG, S.update_time(s)))
   torch.cuda.synchronize()
   for name, us in _lib.profile_read():
     a = acc.setdefault(name, [0, 0.0])
@@ -271,7 +329,37 @@ def main_dlrm(args):
 
   # ---- parity of the benched state against the oracle's replay, three tables (one per dim) ----
   parity = None
-  if not args.no_parity_check:
+  if dense is not None:
+    # the dense leg alone, timed with events on its stream: MFMA roofline of the GEMMs
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+      dense_step(out)
+    e1.record()
+    torch.cuda.synchronize()
+    d_us = e0.elapsed_time(e1) * 1e3 / 10
+    xin = torch.randn(B, kin, device=dev, requires_grad=True)
+    for _ in range(3):
+      xin.grad = None
+      mlp_step(xin)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+      xin.grad = None
+      mlp_step(xin)
+    e1.record()
+    torch.cuda.synchronize()
+    m_us = e0.elapsed_time(e1) * 1e3 / 10
+    dense.update({"dense_leg_us": round(d_us, 1), "mlp_us": round(m_us, 1),
+                  "layout_fwd_bwd_us": round(d_us - m_us, 1),
+                  "roofline": {"bound": "mfma", "achieved": round(dense["flops_per_step"] / m_us / 1e6, 1),
+                               "peak": 2500.0, "unit": "TFLOP/s",
+                               "frac": round(dense["flops_per_step"] / m_us / 1e6 / 2500.0, 4)},
+                  "note": "mlp_us: bf16 MLP forward + backward + SGD (hipBLASLt GEMMs through torch "
+                          "autocast, incl. its casts and elementwise kernels); flops = 6 * batch * "
+                          "sum(in * out); dense_leg_us adds the layout kernels either side"})
+  if not args.no_parity_check and dense is None:
     try:
       t0p = time.time()
       parity = {}
@@ -338,8 +426,10 @@ def main_dlrm(args):
       "config": {
           "workload": "configs[4] shape on 1 MI355X: %d feature tables, dims 16/32/64, fused Adagrad, "
                       "Zipf(1.2) over %d ids per feature, batch %d ids per feature and step, online "
-                      "insert, TTL eviction scan every %d steps; sparse path only (no dense model)" %
-                      (T, V, B, args.evict_every),
+                      "insert, TTL eviction scan every %d steps; %s" %
+                      (T, V, B, args.evict_every,
+                       "end to end with the dense model (layout + bf16 MLP)" if dense is not None else
+                       "sparse path only (no dense model)"),
           "tables": T, "dims": dims, "batch_per_table": B, "universe_per_table": V,
           "resident_rows_start": int(sum(size0)), "resident_rows_end": int(sum(size1)),
           "unique_ids_per_batch_mean": float(U.mean()), "eviction_scans_in_timed_region": evictions[0],
@@ -347,6 +437,7 @@ def main_dlrm(args):
           "launch": "eager",
       },
       "roofline": roofline, "stages": stages, "cpu_baseline": cpu, "parity_check": parity,
+      "dense": dense,
   }
   if cpu and cpu.get("value"):
     out_json["vs_cpu_baseline"] = round(value / cpu["value"], 2)

@@ -42,7 +42,7 @@ enum {
 
 const char* mhte_last_error(void);
 /* ABI version of this header; mhte_abi_version() must return the same value. */
-#define MHTE_ABI_VERSION 8
+#define MHTE_ABI_VERSION 9
 int32_t mhte_abi_version(void);
 
 /* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
@@ -307,7 +307,12 @@ mhte_status mhte_reduce_rows(const int64_t* indices, const float* values, int64_
  * SUM / MEAN walk a feature's fids in order (the reference's loop: bit-identical sums); the slices
  * of an ADDN layout are added in configuration order (the reference's CPU order; its CUDA path uses
  * float atomics).  The gradient op zero-fills embeddings_grad and adds with float atomics, as the
- * reference's CUDA path does.  <= 64 matrices, <= 32 outputs per call. */
+ * reference's CUDA path does.  <= 64 matrices, <= 32 outputs per call.
+ * flags: MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS — the caller states that every feature instance has exactly
+ * one fid and no embedding row is referenced twice (the per-occurrence rows of a lookup feeding a
+ * one-id-per-feature model): slices on float4 boundaries then move as float4 copies and the gradient
+ * is a plain store instead of a float atomic per element. */
+enum { MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS = 1 };
 typedef struct {
   int32_t feature_idx, start, dim;
   int32_t pooling, max_sequence_length;
@@ -319,14 +324,14 @@ mhte_status mhte_embedding_to_layout(const float* const* embeddings, const int32
                                      const uint32_t* nfl_offset, int32_t n_nfl, int32_t batch_size,
                                      const mhte_layout_slice* slices, int32_t n_slices,
                                      float* const* outputs, const int64_t* output_len, int32_t n_outputs,
-                                     void* stream);
+                                     int32_t flags, void* stream);
 mhte_status mhte_embedding_to_layout_grad(float* const* embeddings_grad, const int32_t* emb_row_floats,
                                           const int64_t* emb_len, int32_t n_emb, const uint64_t* fid_offset,
                                           int64_t n_fid, const int32_t* feature_offset, int64_t n_feature,
                                           const uint32_t* nfl_offset, int32_t n_nfl, int32_t batch_size,
                                           const mhte_layout_slice* slices, int32_t n_slices,
                                           const float* const* tensors_grad, const int64_t* tensor_len,
-                                          int32_t n_tensors, void* stream);
+                                          int32_t n_tensors, int32_t flags, void* stream);
 
 /* Admission filter: the reference's SlidingHashFilter (RT/hash_filter/sliding_hash_filter.{h,cc};
  * created by HashFilterOp, RT/ops/hash_filter_op.cc:47-81; the `filter_handle` input of

@@ -26,7 +26,8 @@ MHTE_IDS_UNIQUE = 1
 MHTE_SUM_DUPLICATES = 2
 MHTE_EXACT_ORDER = 1       # flags of mhte_table_sum_optimize_n
 MHTE_DEFER_SLOWPATH = 2
-ABI_VERSION = 8            # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
+MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS = 1
+ABI_VERSION = 9            # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 OPT_MOMENTUM, OPT_ADADELTA, OPT_RMSPROP, OPT_RMSPROPV2, OPT_ADAM, OPT_AMSGRAD = 3, 4, 5, 6, 7, 8

@@ -2663,7 +2663,7 @@ static void layout_launch(bool forward, const float* const* embeddings, const in
                           int64_t n_fid, const int32_t* feature_offset, int64_t n_feature,
                           const uint32_t* nfl_offset, int32_t n_nfl, int32_t batch,
                           const mhte_layout_slice* slices, int32_t n_slices, float* const* outputs,
-                          const int64_t* output_len, int32_t n_outputs, hipStream_t st) {
+                          const int64_t* output_len, int32_t n_outputs, int32_t flags, hipStream_t st) {
   if (n_emb < 0 || n_emb > kMaxLayoutEmb || n_outputs < 0 || n_outputs > kMaxLayoutOut)
     throw Error(MHTE_INVALID_ARGUMENT, "layout: at most " + std::to_string(kMaxLayoutEmb) +
                                            " embedding matrices and " + std::to_string(kMaxLayoutOut) + " outputs");
@@ -2734,8 +2734,23 @@ static void layout_launch(bool forward, const float* const* embeddings, const in
     }
     A.n_units = nu;
     const dim3 grid(uint32_t((int64_t(batch) * 16 + 255) / 256), uint32_t(nu));
-    if (forward) layout_kernel<true><<<grid, 256, 0, st>>>(A);
-    else layout_kernel<false><<<grid, 256, 0, st>>>(A);
+    // one fid per feature instance (asserted by the caller), copies of float4-aligned slices: the
+    // vector copy form, plain stores for the gradient
+    bool fast = (flags & MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS) != 0 && n_fid == n_feature;
+    for (int32_t q = 0; fast && q < nt; ++q) {
+      const LayoutTask& t = A.task[q];
+      fast = t.pooling != kPoolFirstN && ((t.start | t.dim | t.out_offset | t.out_stride) & 3) == 0 &&
+             aligned16(A.out[t.out_index]);
+    }
+    for (int32_t q = 0; fast && q < nu; ++q) fast = A.unit[q].count == 1;
+    for (int32_t i = 0; fast && i < n_emb; ++i) fast = (A.emb_stride[i] & 3u) == 0 && aligned16(A.emb[i]);
+    if (fast) {
+      if (forward) layout_copy_kernel<true><<<grid, 256, 0, st>>>(A);
+      else layout_copy_kernel<false><<<grid, 256, 0, st>>>(A);
+    } else {
+      if (forward) layout_kernel<true><<<grid, 256, 0, st>>>(A);
+      else layout_kernel<false><<<grid, 256, 0, st>>>(A);
+    }
     HIP_OK(hipGetLastError());
   }
 }
@@ -2748,11 +2763,12 @@ mhte_status mhte_embedding_to_layout(const float* const* embeddings, const int32
                                      const uint32_t* nfl_offset, int32_t n_nfl, int32_t batch_size,
                                      const mhte_layout_slice* slices, int32_t n_slices,
                                      float* const* outputs, const int64_t* output_len, int32_t n_outputs,
-                                     void* stream) {
+                                     int32_t flags, void* stream) {
   return guard([&] {
     layout_launch(true, embeddings, emb_row_floats, emb_len, n_emb,
                   reinterpret_cast<const unsigned long long*>(fid_offset), n_fid, feature_offset, n_feature,
-                  nfl_offset, n_nfl, batch_size, slices, n_slices, outputs, output_len, n_outputs, S(stream));
+                  nfl_offset, n_nfl, batch_size, slices, n_slices, outputs, output_len, n_outputs, flags,
+                  S(stream));
   });
 }
 
@@ -2762,13 +2778,13 @@ mhte_status mhte_embedding_to_layout_grad(float* const* embeddings_grad, const i
                                           const uint32_t* nfl_offset, int32_t n_nfl, int32_t batch_size,
                                           const mhte_layout_slice* slices, int32_t n_slices,
                                           const float* const* tensors_grad, const int64_t* tensor_len,
-                                          int32_t n_tensors, void* stream) {
+                                          int32_t n_tensors, int32_t flags, void* stream) {
   return guard([&] {
     layout_launch(false, const_cast<const float* const*>(embeddings_grad), emb_row_floats, emb_len, n_emb,
                   reinterpret_cast<const unsigned long long*>(fid_offset), n_fid, feature_offset, n_feature,
                   nfl_offset, n_nfl, batch_size, slices, n_slices,
                   (float* const*)tensors_grad,
-                  tensor_len, n_tensors, S(stream));
+                  tensor_len, n_tensors, flags, S(stream));
   });
 }
 

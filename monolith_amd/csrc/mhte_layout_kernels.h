@@ -70,6 +70,38 @@ __device__ __forceinline__ bool layout_fid_range(const LayoutArgs& A, int32_t nf
   return *f1 > *f0;
 }
 
+// Fast form for the common shape of a recommendation batch after a per-occurrence lookup: every
+// feature instance has exactly ONE fid, SUM / MEAN pooling (a copy), every slice boundary, row
+// stride and output offset a multiple of 4 floats, and (gradient) no embedding row referenced twice
+// — the host checks what it can and the caller asserts the rest (MHTE_LAYOUT_UNIQUE_ROWS).  A lane
+// moves float4s; the gradient is a plain store instead of a float atomic per element.
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void layout_copy_kernel(LayoutArgs A) {
+  constexpr int G = 16;
+  const int j = threadIdx.x & (G - 1);
+  const int32_t b = int32_t((int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G);
+  if (b >= A.batch) return;
+  const LayoutUnit u = A.unit[blockIdx.y];
+  const LayoutTask t = A.task[u.first];
+  int32_t f0 = 0, f1 = 0;
+  if (!layout_fid_range(A, t.nfl_idx, b, &f0, &f1)) return;
+  const unsigned long long fo = A.fid_offset[f0];
+  const uint32_t i1 = uint32_t(fo >> 32), i2 = uint32_t(fo);
+  if (i1 >= uint32_t(A.n_emb)) return;
+  float* orow = A.out[t.out_index] + int64_t(b) * t.out_stride + t.out_offset;
+  float* erow = const_cast<float*>(A.emb[i1]) + uint64_t(i2) * A.emb_stride[i1] + uint32_t(t.start);
+  for (int32_t e = j * 4; e < t.dim; e += G * 4) {
+    Vec<4> v;
+    if (FORWARD) {
+      v.load(erow + e);
+      v.store(orow + e);
+    } else {
+      v.load(orow + e);
+      v.store(erow + e);
+    }
+  }
+}
+
 template <bool FORWARD>
 __global__ __launch_bounds__(256) void layout_kernel(LayoutArgs A) {
   constexpr int G = 16;

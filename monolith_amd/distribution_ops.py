@@ -408,8 +408,10 @@ def _layout_common(embeddings_list, fid_offset, feature_offset, nfl_offset):
 
 def fused_embedding_to_layout(embeddings_list: List[torch.Tensor], fid_offset: torch.Tensor,
                               feature_offset: torch.Tensor, nfl_offset: torch.Tensor, batch_size: int,
-                              feature_cfgs: FeatureConfigs) -> List[torch.Tensor]:
-  """MonolithEmbeddingToLayout: the layouts' tensors, layouts in sorted-name order."""
+                              feature_cfgs: FeatureConfigs,
+                              one_fid_unique_rows: bool = False) -> List[torch.Tensor]:
+  """MonolithEmbeddingToLayout: the layouts' tensors, layouts in sorted-name order.
+  ``one_fid_unique_rows``: MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS (float4 copies)."""
   dev, embs, stride, count, fo, fe, nf = _layout_common(embeddings_list, fid_offset, feature_offset,
                                                         nfl_offset)
   slices, shapes = _layout_plan(feature_cfgs, int(batch_size))
@@ -418,24 +420,28 @@ def fused_embedding_to_layout(embeddings_list: List[torch.Tensor], fid_offset: t
   check(_lib.lib().mhte_embedding_to_layout(
       _ptr_array(embs), stride, count, C.c_int32(len(embs)), vp(fo), C.c_int64(fo.numel()), vp(fe),
       C.c_int64(fe.numel()), vp(nf), C.c_int32(nf.numel()), C.c_int32(int(batch_size)), slices,
-      C.c_int32(len(slices)), _ptr_array(outs), lens, C.c_int32(len(outs)), _stream()))
+      C.c_int32(len(slices)), _ptr_array(outs), lens, C.c_int32(len(outs)),
+      C.c_int32(_lib.MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS if one_fid_unique_rows else 0), _stream()))
   return outs
 
 
 def fused_embedding_to_layout_grad(embeddings_list: List[torch.Tensor], fid_offset: torch.Tensor,
                                    feature_offset: torch.Tensor, nfl_offset: torch.Tensor,
                                    batch_size: int, tensors_grad: List[torch.Tensor],
-                                   feature_cfgs: FeatureConfigs) -> List[torch.Tensor]:
-  """MonolithEmbeddingToLayoutGrad: gradients of ``embeddings_list`` (same shapes)."""
+                                   feature_cfgs: FeatureConfigs, one_fid_unique_rows: bool = False,
+                                   out: List[torch.Tensor] = None) -> List[torch.Tensor]:
+  """MonolithEmbeddingToLayoutGrad: gradients of ``embeddings_list`` (same shapes; ``out``: buffers
+  to write them into, e.g. views of one flat gradient)."""
   dev, embs, stride, count, fo, fe, nf = _layout_common(embeddings_list, fid_offset, feature_offset,
                                                         nfl_offset)
   slices, shapes = _layout_plan(feature_cfgs, int(batch_size))
   assert len(tensors_grad) == len(shapes)
   tg = [g.to(device=dev, dtype=torch.float32).contiguous() for g in tensors_grad]
-  grads = [torch.empty_like(e) for e in embs]
+  grads = out if out is not None else [torch.empty_like(e) for e in embs]
   lens = (C.c_int64 * len(tg))(*[g.numel() for g in tg])
   check(_lib.lib().mhte_embedding_to_layout_grad(
       _ptr_array(grads), stride, count, C.c_int32(len(embs)), vp(fo), C.c_int64(fo.numel()), vp(fe),
       C.c_int64(fe.numel()), vp(nf), C.c_int32(nf.numel()), C.c_int32(int(batch_size)), slices,
-      C.c_int32(len(slices)), _ptr_array(tg), lens, C.c_int32(len(tg)), _stream()))
+      C.c_int32(len(slices)), _ptr_array(tg), lens, C.c_int32(len(tg)),
+      C.c_int32(_lib.MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS if one_fid_unique_rows else 0), _stream()))
   return grads

@@ -465,3 +465,28 @@ def test_fused_embedding_to_layout_forward_and_grad(batch, seed):
   ge = _layout_model(embs, fid_offset, feature_offset, nfl_offset, batch, cfgs, tensors_grad=tg)
   for g, e in zip(gg, ge):                                  # float atomics: arrival order
     np.testing.assert_allclose(g.cpu().numpy(), e, rtol=1e-5, atol=1e-5)
+
+
+def test_fused_embedding_to_layout_copy_form():
+  """MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS: one fid per feature instance, unique rows, float4-aligned
+  slices — the vector copy form (plain stores in the gradient) equals the general form."""
+  from monolith_amd import distribution_ops as D
+  rng = np.random.default_rng(4)
+  B, dims = 257, [16, 32, 64]
+  names = ["a", "b", "c"]
+  feats = {n: D.FeatureConfig(n, D.PoolingType.SUM, [d]) for n, d in zip(names, dims)}
+  cfgs = D.FeatureConfigs(feats, {"x": D.OutConfig([D.SliceConfig(n, 0, d) for n, d in zip(names, dims)],
+                                                     D.OutType.CONCAT, [[-1, sum(dims)]])})
+  embs = [torch.tensor(rng.standard_normal((B, d)).astype(np.float32)).cuda() for d in dims]
+  T = len(dims)
+  fo = (torch.arange(T, dtype=torch.int64).repeat_interleave(B) << 32 | torch.arange(B).repeat(T)).cuda()
+  fe = torch.arange(T * B, dtype=torch.int32).cuda()
+  nf = (torch.arange(T, dtype=torch.int32) * B).cuda()
+  a = D.fused_embedding_to_layout(embs, fo, fe, nf, B, cfgs)[0]
+  b = D.fused_embedding_to_layout(embs, fo, fe, nf, B, cfgs, one_fid_unique_rows=True)[0]
+  assert torch.equal(a, b) and torch.equal(a, torch.cat(embs, dim=1))
+  g = torch.tensor(rng.standard_normal((B, sum(dims))).astype(np.float32)).cuda()
+  ga = D.fused_embedding_to_layout_grad(embs, fo, fe, nf, B, [g], cfgs)
+  gb = D.fused_embedding_to_layout_grad(embs, fo, fe, nf, B, [g], cfgs, one_fid_unique_rows=True)
+  for x, y, w in zip(ga, gb, torch.split(g, dims, dim=1)):
+    assert torch.equal(x, y) and torch.equal(x, w)
