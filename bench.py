@@ -61,6 +61,8 @@ def parse():
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--cpu-steps", type=int, default=150)
   p.add_argument("--exact-order", action="store_true")
+  p.add_argument("--ids-per-peer", type=int, default=0,
+                 help="sharded step: id slots per (peer, table) block (0: library default)")
   p.add_argument("--force-sharded", action="store_true",
                  help="N=1 through the id-sharded code path (one-rank process group): the floor of "
                       "the multi-GPU step without any link traffic; a measurement, not the bench line")
@@ -532,7 +534,7 @@ def main():
   # contiguous batch sequence: the last step of a mode deduplicates the first batch of the next
   # mode ahead, exactly as it does inside a mode.
   reps = min(K, 100)
-  n_batches = (2 * (W + K) + 2 * reps + 8) if not sharded else (K + W + 1)
+  n_batches = (2 * (W + K) + 2 * reps + 8) if not sharded else (K + W + 24)
   ids_host = np.stack([S.id_batch(s * world + rank, B, V, "zipf") for s in range(n_batches)])
   ids_all = torch.from_numpy(ids_host).to(dev)
   NG = max(1, args.grad_pool)
@@ -548,6 +550,7 @@ def main():
 
   results = {}
   steps_of = {}
+  stages, shard_info = {}, None
   graph_err = None
   if not sharded:
     # Steady-state pipeline (fused_step.py): while batch s is looked up and updated, the dedup of
@@ -618,22 +621,64 @@ def main():
         cur += gc * (len(graphs) + 1)
     P0 = cur
   else:
-    from monolith_amd.distributed_ps_sync import HipBackend, ShardedEmbedding
-    se = ShardedEmbedding(HipBackend(mt, "emb"))
+    # the id-sharded step, enqueued from C++ (csrc/mhte_shard_host.h): kernels + RCCL send / recv
+    # groups on this stream; world == 1: the exchange is the identity
+    from monolith_amd.distributed_ps_sync import ShardedMultiStep
+    from monolith_amd.multi_hash_table_ops import Ragged
+    se = ShardedMultiStep(mt, B, ids_per_peer_table=args.ids_per_peer)
+    splits1 = np.array([0, B], dtype=np.int64)
+    rag = [Ragged(ids_all[s], splits1) for s in range(n_batches)]
+    emb_out = torch.empty(B * D, dtype=torch.float32, device=dev)
+
+    host_us = []   # MHTE_BENCH_STEP_TIMES=1: host time of every step's two calls (stall hunting)
+    trace_host = os.environ.get("MHTE_BENCH_STEP_TIMES") == "1"
 
     def run_sharded(lo, hi):
       for s in range(lo, hi):
-        se.lookup(ids_all[s], next_ids=ids_all[s + 1])
-        se.apply_gradients(grad_pool[s % NG], S.update_time(s))
+        t_a = time.perf_counter() if trace_host else 0.0
+        se.forward(rag[s], rag[s + 1], out=emb_out)
+        t_b = time.perf_counter() if trace_host else 0.0
+        se.backward(grad_pool[s % NG].view(-1), S.update_time(s))
+        if trace_host:
+          host_us.append((s, (t_b - t_a) * 1e6, (time.perf_counter() - t_b) * 1e6))
         applied.append((s, s % NG, S.update_time(s)))
 
+    import gc
     run_sharded(0, W)
+    gc.collect()
+    gc_was = gc.isenabled()
+    if os.environ.get("MHTE_BENCH_KEEP_GC") != "1":
+      gc.disable()   # (a generation-2 pass of the interpreter is ~40 ms: 200 us on every step of 200)
     barrier()
     t = time.perf_counter()
     run_sharded(W, W + K)
     barrier()
     results["eager"] = time.perf_counter() - t
+    if gc_was:
+      gc.enable()
     steps_of["eager"] = K
+    se.check()
+    shard_info = se.info()
+    if trace_host:
+      top = sorted(host_us, key=lambda x: -(x[1] + x[2]))[:6]
+      print("slowest steps (step, forward us, backward us): %s" % [(a, round(b), round(c)) for a, b, c in top],
+            file=sys.stderr)
+    if world == 1 and not args.no_stage_timing:   # kernel-exact time of every launch of a step
+      acc = {}
+      nprof = min(20, n_batches - (W + K) - 1)
+      for s in range(W + K, W + K + nprof):
+        _lib.profile_arm(64)
+        run_sharded(s, s + 1)
+        torch.cuda.synchronize()
+        for name, us in _lib.profile_read():
+          a = acc.setdefault(name, [0, 0.0])
+          a[0] += 1
+          a[1] += us
+      if nprof > 0:
+        stages = {"per_step": {k: {"launches": round(v[0] / nprof, 2), "us": round(v[1] / nprof, 2)}
+                               for k, v in acc.items()},
+                  "note": "kernel-exact HIP-event time of the tagged launches of the sharded step "
+                          "(+ 1 untagged displacement launch per peer)"}
   full = {k: v for k, v in results.items() if steps_of[k] == K}   # modes timed over exactly K steps
   launch = min(full, key=full.get) if args.launch == "auto" else (
       args.launch if args.launch in full else "eager")
@@ -648,7 +693,7 @@ def main():
   # stream (mhte_profile_arm -> hipExtLaunchKernelGGL), the interval rocprofv3 --kernel-trace
   # reports.  Pass 1: the pipelined step as timed above (2 launches per step).  Pass 2: the
   # same work as separate launches, which attributes time to lookup / backward / dedup.
-  roofline, stages, uniq_avg = None, {}, None
+  roofline, uniq_avg = None, None
   if not sharded and not args.no_stage_timing:
     step.quiesce()
     acc = {}
@@ -725,7 +770,7 @@ def main():
   # ---- parity of the benched state: the rows of >= 10 000 ids of the timed stream, read back
   # after everything above, against the oracle's replay of the same update sequence
   parity = None
-  if not sharded and rank == 0 and not args.no_parity_check:
+  if world == 1 and rank == 0 and not args.no_parity_check:
     if not applied_ok:
       parity = {"skipped": "update log invalid after a failed graph capture"}
     else:
@@ -808,7 +853,9 @@ def main():
             "table_bytes_per_gpu": int(st1.bytes_buckets + st1.bytes_rows),
             "unique_ids_per_batch": uniq_avg, "launch": launch,
             "parallelism": "1 GPU" if not sharded else
-                           "fid mod %d sharding, 4 all-to-all/step (%s)" % (world, args.dist_backend),
+                           "fid mod %d sharding, 3 fixed-capacity exchanges/step (%s)" %
+                           (world, shard_info["transport"]),
+            "shard_step": shard_info,
             "prefill_s": round(prefill_s, 2),
         },
         "timing_ms_per_step": {k: round(v / steps_of[k] * 1e3, 5) for k, v in results.items()},

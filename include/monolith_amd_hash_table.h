@@ -42,7 +42,7 @@ enum {
 
 const char* mhte_last_error(void);
 /* ABI version of this header; mhte_abi_version() must return the same value. */
-#define MHTE_ABI_VERSION 9
+#define MHTE_ABI_VERSION 10
 int32_t mhte_abi_version(void);
 
 /* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
@@ -559,6 +559,62 @@ mhte_status mhte_multi_step_backward(mhte_multi_step* s, const float* value, int
                                      int64_t update_time, int64_t global_step, int32_t flags,
                                      void* stream);
 mhte_status mhte_multi_step_unique_counts(mhte_multi_step* s, int64_t* counts, void* stream);
+
+/* Id-sharded training step over ALL tables, one process per GPU: the reference's sync-training
+ * exchange (NT/distributed_ps_sync.py:95-287 lookup, :289-490 apply_gradients; shard =
+ * floormod(id, world), NT/distributed_ps.py:289; packing RT/ops/fused_reorder_by_indices.cc:75-123)
+ * driven from C++ with RCCL send / recv groups on the caller's stream.  Rank r's mhte_multi_table
+ * holds the ids it owns of every table.  Per step a rank deduplicates its ragged batch, packs the
+ * distinct ids into one fixed-capacity block per peer that carries its own per-table counts (no
+ * size exchange, no device-to-host copy), and the ranks trade: id blocks -> owners look the rows up
+ * (no insert) -> row blocks back -> scatter to the occurrences; gradients: per-id sums in
+ * occurrence order -> row-shaped blocks to the owners -> every owner applies the peers' blocks one
+ * after the other in rank order (the reference's default of one optimizer application per
+ * sender).  Three exchanges per step, all tables in each.
+ *   ids_per_peer_table  id slots per (peer, table) block; 0 = max_batch when world == 1, else
+ *                       1.5 * max_batch / world + 256.  A step in which one table sends more
+ *                       distinct ids than that to one peer hands those ids zero rows, drops their
+ *                       gradients and makes the next call (or mhte_shard_step_check) return
+ *                       MHTE_RESOURCE_EXHAUSTED.
+ *   unique_id           128 bytes from mhte_shard_unique_id on one rank, distributed by the
+ *                       launcher: the step creates its RCCL communicator (collective: every rank
+ *                       calls create).  NULL with world == 1: no communicator, the exchange is the
+ *                       identity.  NULL with world > 1: the ranks live in this process on one device
+ *                       and are driven together through mhte_shard_group_* (device copies stand in
+ *                       for the links; tests).
+ * forward / backward arguments are those of mhte_multi_step_* for this rank's batch; `prefetched`
+ * and the next batch must agree across the ranks (the calls are collective).  Tables with an
+ * occurrence filter or whole-segment optimizers are rejected.  global_step reaches the optimizers. */
+typedef struct mhte_shard_step mhte_shard_step;
+mhte_status mhte_shard_unique_id(void* out128);
+mhte_status mhte_shard_step_create(mhte_multi_table* t, int64_t max_batch_per_table, int32_t rank,
+                                   int32_t world, int64_t ids_per_peer_table, const void* unique_id,
+                                   mhte_shard_step** out);
+void mhte_shard_step_destroy(mhte_shard_step* s);
+mhte_status mhte_shard_step_forward(mhte_shard_step* s, const int64_t* id, const int64_t* id_split,
+                                    int64_t n_split, float* embedding, int64_t embedding_len,
+                                    const int64_t* id_next, const int64_t* id_split_next,
+                                    int64_t n_split_next, int32_t prefetched, void* stream);
+mhte_status mhte_shard_step_backward(mhte_shard_step* s, const float* value, int64_t value_len,
+                                     const float* learning_rate, int64_t n_learning_rate,
+                                     int64_t update_time, int64_t global_step, void* stream);
+/* waits for the stream, then reports a block overflow of the steps enqueued so far */
+mhte_status mhte_shard_step_check(mhte_shard_step* s, void* stream);
+/* info[0] = id slots per (peer, table), [1] = bytes of one id block, [2] = bytes of one row block,
+ * [3] = transport: 0 identity, 1 RCCL, 2 in-process group */
+mhte_status mhte_shard_step_info(mhte_shard_step* s, int64_t info[4]);
+/* all `n` ranks of a world living in this process (created with unique_id NULL, world n): the same
+ * step, with arrays of per-rank arguments */
+mhte_status mhte_shard_group_forward(mhte_shard_step** steps, int32_t n, const int64_t* const* id,
+                                     const int64_t* const* id_split, int64_t n_split,
+                                     float* const* embedding, const int64_t* embedding_len,
+                                     const int64_t* const* id_next,
+                                     const int64_t* const* id_split_next, int64_t n_split_next,
+                                     int32_t prefetched, void* stream);
+mhte_status mhte_shard_group_backward(mhte_shard_step** steps, int32_t n, const float* const* value,
+                                      const int64_t* value_len, const float* learning_rate,
+                                      int64_t n_learning_rate, int64_t update_time,
+                                      int64_t global_step, void* stream);
 
 /* 1 when table i's row fits the single-launch backward (dim <= 256 floats, or <= 64 when segment
  * boundaries are not multiples of 4 floats); otherwise mhte_table_sum_optimize_n runs segment sum +

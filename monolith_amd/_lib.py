@@ -27,7 +27,7 @@ MHTE_SUM_DUPLICATES = 2
 MHTE_EXACT_ORDER = 1       # flags of mhte_table_sum_optimize_n
 MHTE_DEFER_SLOWPATH = 2
 MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS = 1
-ABI_VERSION = 9            # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
+ABI_VERSION = 10           # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 OPT_MOMENTUM, OPT_ADADELTA, OPT_RMSPROP, OPT_RMSPROPV2, OPT_ADAM, OPT_AMSGRAD = 3, 4, 5, 6, 7, 8
@@ -125,6 +125,9 @@ EXPORTS = [
     "mhte_fused_gather_embeddings_by_input_gradient", "mhte_reduce_rows",
     "mhte_multi_step_create", "mhte_multi_step_destroy", "mhte_multi_step_forward",
     "mhte_multi_step_backward", "mhte_multi_step_unique_counts",
+    "mhte_shard_unique_id", "mhte_shard_step_create", "mhte_shard_step_destroy",
+    "mhte_shard_step_forward", "mhte_shard_step_backward", "mhte_shard_step_check",
+    "mhte_shard_step_info", "mhte_shard_group_forward", "mhte_shard_group_backward",
     "mhte_multi_table_create_from_proto", "mhte_multi_table_find", "mhte_multi_table_is_initialized",
     "mhte_hash_filter_create_from_proto", "mhte_lookup_entry", "mhte_feature_stat",
     "mhte_advance_clock_for_testing", "mhte_hash_filter_save", "mhte_hash_filter_restore",
@@ -170,6 +173,8 @@ def lib():
     L.mhte_advance_clock_for_testing.argtypes = [C.c_double]
     L.mhte_multi_step_destroy.restype = None
     L.mhte_multi_step_destroy.argtypes = [C.c_void_p]
+    L.mhte_shard_step_destroy.restype = None
+    L.mhte_shard_step_destroy.argtypes = [C.c_void_p]
     L.mhte_hash_filter_destroy.argtypes = [C.c_void_p]
     L.mhte_multi_table_destroy.argtypes = [C.c_void_p]
     L.mhte_dedup_ws_destroy.argtypes = [C.c_void_p]
@@ -208,7 +213,8 @@ def vp(x):
 
 PROFILE_TAGS = {1: "lookup_kernel", 2: "sum_apply_kernel", 6: "slowpath_kernel", 7: "dd_kernels",
                 8: "upsert_kernel", 9: "step_fwd_kernel", 10: "step_bwd_kernel",
-                11: "mstep_fwd_kernel", 12: "mstep_bwd_kernel"}
+                11: "mstep_fwd_kernel", 12: "mstep_bwd_kernel", 13: "shard_build_kernel",
+                14: "shard_lookup_kernel", 15: "shard_scatter_kernel", 16: "shard_upsert_kernel"}
 TRACE_WORDS = 8
 TRACE_ROLES = {3: "run_dedup", 4: "displacement", 5: "lookup", 6: "work_list", 7: "apply_items",
                8: "apply_ids", 9: "reserve_rows"}

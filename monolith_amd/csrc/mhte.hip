@@ -36,6 +36,7 @@
 #include "mhte_layout_kernels.h"
 #include "mhte_step_kernels.h"
 #include "mhte_mstep_kernels.h"
+#include "mhte_shard_kernels.h"
 
 namespace mhte {
 
@@ -90,7 +91,8 @@ static inline uint32_t ceil_log2(uint64_t n) {
 enum ProfTag : int32_t {
   kTagLookup = 1, kTagSumApply = 2,
   kTagSlowpath = 6, kTagDedup = 7, kTagUpsert = 8, kTagStepFwd = 9, kTagStepBwd = 10,
-  kTagMStepFwd = 11, kTagMStepBwd = 12
+  kTagMStepFwd = 11, kTagMStepBwd = 12,
+  kTagShardBuild = 13, kTagShardLookup = 14, kTagShardGather = 15, kTagShardUpsert = 16
 };
 
 // Per-wavefront timeline of the step kernels (mhte_trace_begin / mhte_trace_end): each traced
@@ -1165,9 +1167,13 @@ static void ragged_upsert(mhte_multi_table* t, const int64_t* id, const int64_t*
 }  // namespace mhte
 
 #include "mhte_mstep_host.h"
+#include "mhte_shard_host.h"
 
 struct mhte_multi_step {
   mhte::MultiStep ms;
+};
+struct mhte_shard_step {
+  mhte::ShardStep ss;
 };
 
 using namespace mhte;
@@ -3054,6 +3060,137 @@ mhte_status mhte_multi_step_unique_counts(mhte_multi_step* s, int64_t* counts, v
                               hipMemcpyDeviceToHost, S(stream)));
     HIP_OK(hipStreamSynchronize(S(stream)));
     for (uint32_t t = 0; t < ms.T; ++t) counts[t] = h[t];
+  });
+}
+
+// ---- id-sharded multi-table step (mhte_shard_host.h) -------------------------------------------------
+mhte_status mhte_shard_unique_id(void* out128) {
+  return guard([&] {
+    if (!out128) throw Error(MHTE_INVALID_ARGUMENT, "null out");
+    Rccl& R = Rccl::get();
+    ncclUniqueId id;
+    R.ok(R.GetUniqueId(&id), "GetUniqueId");
+    static_assert(sizeof(id) == 128, "ncclUniqueId");
+    memcpy(out128, &id, sizeof(id));
+  });
+}
+
+static std::vector<std::unique_lock<std::mutex>> lock_tables(mhte_shard_step** steps, int32_t n) {
+  std::vector<std::unique_lock<std::mutex>> locks;
+  for (int32_t r = 0; r < n; ++r)
+    for (auto& tb : steps[r]->ss.mt->tables) locks.emplace_back(tb->mu);
+  return locks;
+}
+
+mhte_status mhte_shard_step_create(mhte_multi_table* t, int64_t max_batch_per_table, int32_t rank,
+                                   int32_t world, int64_t ids_per_peer_table, const void* unique_id,
+                                   mhte_shard_step** out) {
+  return guard([&] {
+    check_handle(t);
+    if (!out) throw Error(MHTE_INVALID_ARGUMENT, "null out");
+    HIP_OK(hipSetDevice(t->device));
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (auto& tb : t->tables) locks.emplace_back(tb->mu);
+    std::unique_ptr<mhte_shard_step> s(new mhte_shard_step);
+    s->ss.init(t, max_batch_per_table, rank, world, ids_per_peer_table, unique_id);
+    *out = s.release();
+  });
+}
+void mhte_shard_step_destroy(mhte_shard_step* s) { delete s; }
+
+mhte_status mhte_shard_step_forward(mhte_shard_step* s, const int64_t* id, const int64_t* id_split,
+                                    int64_t n_split, float* embedding, int64_t embedding_len,
+                                    const int64_t* id_next, const int64_t* id_split_next,
+                                    int64_t n_split_next, int32_t prefetched, void* stream) {
+  return guard([&] {
+    if (!s) throw Error(MHTE_INVALID_ARGUMENT, "null shard step");
+    HIP_OK(hipSetDevice(s->ss.device));
+    auto locks = lock_tables(&s, 1);
+    ShardFwd a;
+    a.id = id;
+    a.split = id_split;
+    a.emb = embedding;
+    a.emb_len = embedding_len;
+    a.id_next = id_next;
+    a.split_next = id_split_next;
+    ShardStep* S = &s->ss;
+    shard_forward(&S, 1, &a, n_split, n_split_next, prefetched, mhte::S(stream));
+  });
+}
+
+mhte_status mhte_shard_step_backward(mhte_shard_step* s, const float* value, int64_t value_len,
+                                     const float* learning_rate, int64_t n_learning_rate,
+                                     int64_t update_time, int64_t global_step, void* stream) {
+  return guard([&] {
+    if (!s) throw Error(MHTE_INVALID_ARGUMENT, "null shard step");
+    HIP_OK(hipSetDevice(s->ss.device));
+    auto locks = lock_tables(&s, 1);
+    ShardStep* S = &s->ss;
+    shard_backward(&S, 1, &value, &value_len, learning_rate, n_learning_rate, update_time, global_step,
+                   mhte::S(stream));
+  });
+}
+
+mhte_status mhte_shard_step_check(mhte_shard_step* s, void* stream) {
+  return guard([&] {
+    if (!s) throw Error(MHTE_INVALID_ARGUMENT, "null shard step");
+    HIP_OK(hipSetDevice(s->ss.device));
+    HIP_OK(hipStreamSynchronize(mhte::S(stream)));
+    s->ss.check_flags();
+  });
+}
+
+mhte_status mhte_shard_step_info(mhte_shard_step* s, int64_t info[4]) {
+  return guard([&] {
+    if (!s || !info) throw Error(MHTE_INVALID_ARGUMENT, "null argument");
+    info[0] = s->ss.cap;
+    info[1] = int64_t(s->ss.x_block(kXIds));
+    info[2] = int64_t(s->ss.x_block(kXRows));
+    info[3] = s->ss.alias ? 0 : (s->ss.comm ? 1 : 2);
+  });
+}
+
+mhte_status mhte_shard_group_forward(mhte_shard_step** steps, int32_t n, const int64_t* const* id,
+                                     const int64_t* const* id_split, int64_t n_split,
+                                     float* const* embedding, const int64_t* embedding_len,
+                                     const int64_t* const* id_next,
+                                     const int64_t* const* id_split_next, int64_t n_split_next,
+                                     int32_t prefetched, void* stream) {
+  return guard([&] {
+    if (!steps || n < 1 || n > kMaxShards || !id || !id_split || !embedding || !embedding_len)
+      throw Error(MHTE_INVALID_ARGUMENT, "shard group forward: bad arguments");
+    for (int32_t r = 0; r < n; ++r)
+      if (!steps[r]) throw Error(MHTE_INVALID_ARGUMENT, "null shard step");
+    auto locks = lock_tables(steps, n);
+    std::vector<ShardStep*> S(size_t(n), nullptr);
+    std::vector<ShardFwd> a(size_t(n), ShardFwd{});
+    for (int32_t r = 0; r < n; ++r) {
+      S[size_t(r)] = &steps[r]->ss;
+      a[size_t(r)].id = id[r];
+      a[size_t(r)].split = id_split[r];
+      a[size_t(r)].emb = embedding[r];
+      a[size_t(r)].emb_len = embedding_len[r];
+      a[size_t(r)].id_next = id_next ? id_next[r] : nullptr;
+      a[size_t(r)].split_next = id_split_next ? id_split_next[r] : nullptr;
+    }
+    shard_forward(S.data(), n, a.data(), n_split, n_split_next, prefetched, mhte::S(stream));
+  });
+}
+
+mhte_status mhte_shard_group_backward(mhte_shard_step** steps, int32_t n, const float* const* value,
+                                      const int64_t* value_len, const float* learning_rate,
+                                      int64_t n_learning_rate, int64_t update_time,
+                                      int64_t global_step, void* stream) {
+  return guard([&] {
+    if (!steps || n < 1 || n > kMaxShards || !value || !value_len)
+      throw Error(MHTE_INVALID_ARGUMENT, "shard group backward: bad arguments");
+    for (int32_t r = 0; r < n; ++r)
+      if (!steps[r]) throw Error(MHTE_INVALID_ARGUMENT, "null shard step");
+    auto locks = lock_tables(steps, n);
+    std::vector<ShardStep*> S(size_t(n), nullptr);
+    for (int32_t r = 0; r < n; ++r) S[size_t(r)] = &steps[r]->ss;
+    shard_backward(S.data(), n, value, value_len, learning_rate, n_learning_rate, update_time,
+                   global_step, mhte::S(stream));
   });
 }
 

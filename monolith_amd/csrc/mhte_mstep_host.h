@@ -156,6 +156,9 @@ struct MultiStep {
     }
     if (const char* e = getenv("MHTE_MSTEP_OVERSUB")) ovs = std::max(1, atoi(e));
     if (const char* e = getenv("MHTE_MSTEP_SCATTER_OVS")) scatter_ovs = std::max(1, atoi(e));
+    // (with a few tables in a launch the heavy items are the launch's longest chain again: cut them
+    // as the single-table step does)
+    item_target = T >= 4 ? 4 * kItemTarget : kItemTarget;
     if (const char* e = getenv("MHTE_MSTEP_ITEM_TARGET")) item_target = std::max<int>(int(kItemTarget), atoi(e));
     h_st.assign(T, MStepStatic{});
     Arena sizing;

@@ -1,0 +1,544 @@
+// Host side of the id-sharded multi-table step (kernels + wire format: mhte_shard_kernels.h).
+// Included by mhte.hip after mhte_mstep_host.h.
+//
+// One process per GPU; rank r owns {id : floormod(id, N) == r} of EVERY table of the model
+// (NT/distributed_ps.py:289) as a complete local mhte_multi_table.  A step on a rank:
+//
+//   forward   owner lookup of the received id blocks            1 launch
+//             exchange rows  (owner -> sender)                  RCCL group of N send/recv pairs
+//             scatter rows to the occurrences                   1 launch
+//             run dedup of the NEXT batch (depends on ids only, 1 launch
+//             NT/distributed_ps_sync.py:199-203)
+//   backward  per-id gradient sums into the row slots |         1 launch
+//               numbering + owner packing of the next batch
+//             exchange gradients (sender -> owner)              RCCL group
+//             exchange the next batch's id blocks               RCCL group
+//             per peer, in rank order: upsert, displacement     2 launches each
+//   (a batch that was not prepared ahead costs two more launches in its forward)
+//
+// Everything the host decides is a function of the configured capacities: no count crosses to the
+// host, so there is no D2H copy and no stream synchronisation in the step.  RCCL is called directly
+// (ncclSend / ncclRecv in one group on the caller's stream), loaded at run time from the librccl
+// the process already has.  With world == 1 and no communicator the exchange is the identity: send
+// and receive buffers are the same memory.
+#ifndef MHTE_SHARD_HOST_H_
+#define MHTE_SHARD_HOST_H_
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace mhte {
+
+// ---- RCCL, bound at run time ------------------------------------------------------------------------
+struct Rccl {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+
+  static Rccl& get() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+      std::vector<std::string> names;
+      if (const char* e = getenv("MHTE_RCCL_LIBRARY")) names.push_back(e);
+      for (const char* n : {"librccl.so.1", "librccl.so"}) names.push_back(n);
+      // a copy the process already holds (PyTorch ships its own) first: one RCCL per process
+      for (auto& n : names)
+        if (!r.h) r.h = dlopen(n.c_str(), RTLD_NOW | RTLD_NOLOAD);
+      for (auto& n : names)
+        if (!r.h) r.h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
+      if (!r.h) return;
+      auto sym = [&](const char* s) { return dlsym(r.h, s); };
+      r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+      r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+      r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+      r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+      r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+      r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+      r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+      r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    if (!r.h || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.GroupStart || !r.GroupEnd ||
+        !r.Send || !r.Recv)
+      throw Error(MHTE_UNAVAILABLE, "RCCL (librccl.so) could not be loaded: set MHTE_RCCL_LIBRARY");
+    return r;
+  }
+  void ok(ncclResult_t e, const char* what) const {
+    if (e != ncclSuccess)
+      throw Error(MHTE_INTERNAL, std::string("RCCL ") + what + ": " +
+                                     (GetErrorString ? GetErrorString(e) : "error"));
+  }
+};
+
+enum ShardExchange : int { kXIds = 0, kXRows = 1, kXGrads = 2 };
+
+struct ShardFwd {
+  const int64_t* id = nullptr;
+  const int64_t* split = nullptr;
+  float* emb = nullptr;
+  int64_t emb_len = 0;
+  const int64_t* id_next = nullptr;
+  const int64_t* split_next = nullptr;
+};
+
+struct ShardStep {
+  MultiStep ms;                 // sender side: run dedup + numbering of this rank's batches
+  mhte_multi_table* mt = nullptr;
+  int device = 0;
+  int rank = 0, world = 1;
+  uint32_t T = 0;
+  ShardGeom geo{};
+  std::vector<ShardTab> tab;
+  int64_t max_batch = 0;
+  uint32_t cap = 0;             // id slots per (peer, table)
+  // device memory
+  int64_t* ids_send[2] = {nullptr, nullptr};   // per slot [world][ids_block]
+  int64_t* ids_recv[2] = {nullptr, nullptr};
+  uint32_t* slot_off[2] = {nullptr, nullptr};  // per slot [T][max_batch]
+  float* own_rows = nullptr;    // owner side: looked-up rows out / gradients in  [world][rows_block]
+  float* snd_rows = nullptr;    // sender side: rows back / gradient sums out
+  uint32_t* h_flags = nullptr;  // pinned, device-visible
+  uint32_t* d_flags = nullptr;
+  bool alias = false;           // world == 1 without a communicator
+  ncclComm_t comm = nullptr;
+  bool hdr_dirty[2] = {false, false};   // the slot's send headers hold counts
+  bool disp[2] = {false, false};        // the slot's batch has been dispatched (ids exchanged)
+  bool ahead = false;                   // slot cur ^ 1 holds the batch the last forward was given as next
+
+  ~ShardStep() {
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    if (comm) (void)Rccl::get().CommDestroy(comm);
+    for (int s = 0; s < 2; ++s) {
+      if (ids_send[s]) (void)hipFree(ids_send[s]);
+      if (ids_recv[s] && !alias) (void)hipFree(ids_recv[s]);
+      if (slot_off[s]) (void)hipFree(slot_off[s]);
+    }
+    if (own_rows) (void)hipFree(own_rows);
+    if (snd_rows && !alias) (void)hipFree(snd_rows);
+    if (h_flags) (void)hipHostFree(h_flags);
+  }
+
+  void init(mhte_multi_table* m, int64_t mb, int rank_, int world_, int64_t ids_per_peer_table,
+            const void* unique_id) {
+    mt = m;
+    device = m->device;
+    rank = rank_;
+    world = world_;
+    max_batch = mb;
+    T = uint32_t(m->tables.size());
+    if (world < 1 || world > kMaxShards || rank < 0 || rank >= world)
+      throw Error(MHTE_INVALID_ARGUMENT, "shard step: rank / world out of range (world <= " +
+                                             std::to_string(kMaxShards) + ")");
+    if (T > uint32_t(kMaxStepTables))
+      throw Error(MHTE_INVALID_ARGUMENT, "shard step: at most " + std::to_string(kMaxStepTables) + " tables");
+    if (!seg_kernels_ok(m))
+      throw Error(MHTE_INVALID_ARGUMENT, "shard step: every table needs rows of whole float4s and "
+                                         "per-element optimizers");
+    for (auto& tb : m->tables)
+      if (tb->flt_slots)
+        throw Error(MHTE_INVALID_ARGUMENT, "shard step: table " + tb->name + " has an occurrence "
+                                           "filter (not supported on the sharded path)");
+    ms.init(m, mb);
+    int64_t c = ids_per_peer_table > 0 ? ids_per_peer_table
+                                       : (world == 1 ? mb : (mb + world - 1) / world * 3 / 2 + 256);
+    c = std::min<int64_t>(c, mb);
+    cap = uint32_t((c + 3) & ~int64_t(3));
+    geo.world = uint32_t(world);
+    geo.T = T;
+    const uint32_t hdr = (T + 7u) & ~7u;
+    tab.resize(T);
+    uint64_t idw = hdr, rw = 0;
+    for (uint32_t t = 0; t < T; ++t) {
+      tab[t].cap = cap;
+      tab[t].dim = m->tables[t]->dim;
+      tab[t].id_off = uint32_t(idw);
+      tab[t].row_off = uint32_t(rw);
+      idw += cap;
+      rw += uint64_t(cap) * tab[t].dim;
+    }
+    if (rw * uint64_t(world) >= 0xffffffffull || idw * uint64_t(world) >= 0xffffffffull)
+      throw Error(MHTE_INVALID_ARGUMENT, "shard step: peer blocks exceed 2^32 floats; lower "
+                                         "ids_per_peer_table");
+    geo.ids_block = uint32_t((idw + 1) & ~uint64_t(1));
+    geo.rows_block = uint32_t(rw);
+    alias = world == 1 && unique_id == nullptr;
+    const size_t ib = size_t(geo.ids_block) * world * sizeof(int64_t);
+    const size_t rb = size_t(geo.rows_block) * world * sizeof(float);
+    for (int s = 0; s < 2; ++s) {
+      HIP_OK(hipMalloc(&ids_send[s], ib));
+      HIP_OK(hipMemset(ids_send[s], 0, ib));
+      if (alias) {
+        ids_recv[s] = ids_send[s];
+      } else {
+        HIP_OK(hipMalloc(&ids_recv[s], ib));
+        HIP_OK(hipMemset(ids_recv[s], 0, ib));
+      }
+      HIP_OK(hipMalloc(&slot_off[s], size_t(T) * size_t(mb) * sizeof(uint32_t)));
+    }
+    HIP_OK(hipMalloc(&own_rows, rb + 64));
+    if (alias) snd_rows = own_rows;
+    else HIP_OK(hipMalloc(&snd_rows, rb + 64));
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&h_flags), 64, hipHostMallocMapped));
+    memset(h_flags, 0, 64);
+    HIP_OK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_flags), h_flags, 0));
+    if (unique_id) {
+      Rccl& R = Rccl::get();
+      ncclUniqueId id;
+      memcpy(&id, unique_id, sizeof(id));
+      R.ok(R.CommInitRank(&comm, world, id, rank), "CommInitRank");
+    }
+    HIP_OK(hipDeviceSynchronize());
+  }
+
+  bool local_group_member() const { return world > 1 && comm == nullptr; }
+
+  void check_flags() {
+    const uint32_t f = *reinterpret_cast<volatile uint32_t*>(h_flags);
+    if (f) {
+      *reinterpret_cast<volatile uint32_t*>(h_flags) = 0;
+      throw Error(MHTE_RESOURCE_EXHAUSTED,
+                  "shard step: a table sent more than ids_per_peer_table = " + std::to_string(cap) +
+                      " distinct ids to one peer in a step; their rows were zeros and their gradients "
+                      "dropped.  Create the step with a larger capacity");
+    }
+  }
+
+  void prepare(hipStream_t st) {
+    check_flags();
+    for (auto& tb : mt->tables) tb->finish_pending(st);
+    sync_views(mt, st);
+    ms.sync_static(st);
+  }
+
+  void fill_tabs(ShardTab* dst) const {
+    for (uint32_t t = 0; t < T; ++t) dst[t] = tab[t];
+  }
+
+  // ---- sender: run dedup of (ids, split) into `slot` (stage 1)
+  void dedup(const int64_t* ids, const int64_t* split, int slot, hipStream_t st) {
+    if (ms.stage[slot] == 1) ms.clear_slots(1u << slot, st);
+    for (uint32_t t = 0; t < T; ++t) ms.n_slot[slot][t] = uint32_t(split[t + 1] - split[t]);
+    ms.has_hints[slot] = false;
+    ms.launch_dedup(ids, split, slot, 0, st);
+    ms.stage[slot] = 1;
+    disp[slot] = false;
+  }
+
+  void gather_tabs(ShardGatherTab* gt, int slot, uint32_t* gx_out) const {
+    uint32_t active = 0;
+    for (uint32_t t = 0; t < T; ++t) active += ms.n_slot[slot][t] ? 1u : 0u;
+    const uint32_t budget = uint32_t(kBwdBlocksPerCu * ms.num_cus);
+    const uint32_t share = std::max<uint32_t>(32, budget * (active > 1 ? ms.ovs : 1u) / std::max(1u, active));
+    int64_t off = 0;
+    uint32_t gx = 0;
+    for (uint32_t t = 0; t < T; ++t) {
+      ShardGatherTab& g = gt[t];
+      const uint32_t n = ms.n_slot[slot][t];
+      g.n = n;
+      g.io_off = uint32_t(off);
+      off += int64_t(n) * tab[t].dim;
+      g.nblk_items = g.nblk_ids = 0;
+      if (!n) continue;
+      const uint32_t groups_per_wg = 256u / ms.h_st[t].g;
+      g.nblk_items = std::min<uint32_t>(DedupWs::max_items(n),
+                                        std::min<uint32_t>(uint32_t(ms.num_cus) * 10 / 8,
+                                                           std::max<uint32_t>(8, share / 4)));
+      const uint32_t need = (n + groups_per_wg - 1) / groups_per_wg;
+      g.nblk_ids = std::max<uint32_t>(1, std::min(need, share));
+      gx = std::max(gx, g.nblk_items + g.nblk_ids);
+    }
+    if (uint64_t(off) > 0xffffffffull)
+      throw Error(MHTE_INVALID_ARGUMENT, "shard step: flat buffer exceeds 2^32 floats");
+    *gx_out = gx;
+  }
+
+  // ---- sender: [gradient sums of the batch in sum_slot -> row slots] | [numbering + owner packing
+  // of the batch deduplicated into build_slot]; either may be absent (-1)
+  void build_and_sum(int build_slot, int sum_slot, const float* grads, hipStream_t st) {
+    ShardBuildArgs A{};
+    A.st = ConstStatics(ms.d_st);
+    A.geo = geo;
+    A.flags = d_flags;
+    A.n_max = uint32_t(max_batch);
+    fill_tabs(A.tab);
+    uint32_t gx_sum = 0, gx_build = 0;
+    if (sum_slot >= 0) {
+      A.grads = grads;
+      A.rows_out = snd_rows;
+      A.slot_off = slot_off[sum_slot];
+      A.slot = uint32_t(sum_slot);
+      gather_tabs(A.gt, sum_slot, &gx_sum);
+    }
+    if (build_slot >= 0) {
+      if (hdr_dirty[build_slot])   // (a batch that was packed and never trained)
+        HIP_OK(hipMemset2DAsync(ids_send[build_slot], size_t(geo.ids_block) * 8, 0, size_t(T) * 8,
+                                size_t(world), st));
+      A.send_ids = ids_send[build_slot];
+      A.slot_off_build = slot_off[build_slot];
+      A.build_slot = uint32_t(build_slot);
+      for (uint32_t t = 0; t < T; ++t) {
+        A.n_build[t] = ms.n_slot[build_slot][t];
+        if (A.n_build[t]) gx_build = std::max(gx_build, ms.h_st[t].nblk_build);
+      }
+      hdr_dirty[build_slot] = true;
+      ms.stage[build_slot] = 2;
+      disp[build_slot] = true;
+    }
+    uint32_t gx = 0;
+    for (uint32_t t = 0; t < T; ++t)
+      gx = std::max(gx, (A.n_build[t] ? ms.h_st[t].nblk_build : 0u) + A.gt[t].nblk_items + A.gt[t].nblk_ids);
+    (void)gx_sum;
+    (void)gx_build;
+    if (!gx) return;
+    LAUNCH_HOT(kTagShardBuild, shard_build_kernel, dim3(gx, T), 256, st, A);
+    HIP_OK(hipGetLastError());
+  }
+
+  void scatter(float* out, int slot, hipStream_t st) {
+    ShardGatherArgs A{};
+    A.st = ConstStatics(ms.d_st);
+    A.in = snd_rows;
+    A.out = out;
+    A.slot_off = slot_off[slot];
+    A.slot = uint32_t(slot);
+    A.n_max = uint32_t(max_batch);
+    fill_tabs(A.tab);
+    uint32_t gx = 0;
+    gather_tabs(A.gt, slot, &gx);
+    if (!gx) return;
+    LAUNCH_HOT(kTagShardGather, shard_scatter_kernel, dim3(gx, T), 256, st, A);
+    HIP_OK(hipGetLastError());
+  }
+
+  void owner_args(ShardOwnerArgs& A, int slot) const {
+    A.views = ConstViews(mt->d_views.p);
+    A.geo = geo;
+    A.recv_ids = ids_recv[slot];
+    A.rows = own_rows;
+    A.flags = d_flags;
+    fill_tabs(A.tab);
+    for (uint32_t t = 0; t < T; ++t) {
+      A.g[t] = uint8_t(group_lanes(mt->tables[t]->dim));
+      A.count_hits[t] = mt->tables[t]->count_hits ? 1 : 0;
+    }
+  }
+
+  void owner_lookup(int slot, hipStream_t st) {
+    ShardOwnerArgs A{};
+    owner_args(A, slot);
+    uint32_t gx = 1;
+    for (uint32_t t = 0; t < T; ++t)
+      gx = std::max(gx, uint32_t((uint64_t((cap + 1) / 2) * A.g[t] + 511) / 512));
+    // (grid-stride inside: enough workgroups to fill the chip a few times over, not one per slot)
+    const uint32_t fill = std::max<uint32_t>(8, uint32_t(ms.num_cus) * 16 / (uint32_t(world) * T));
+    gx = std::min(gx, fill);
+    LAUNCH_HOT(kTagShardLookup, shard_lookup_kernel, dim3(gx, uint32_t(world) * T), 512, st, A);
+    HIP_OK(hipGetLastError());
+  }
+
+  void owner_apply(int slot, const float* lrs, int64_t update_time, int64_t global_step, hipStream_t st) {
+    for (uint32_t t = 0; t < T; ++t) {
+      Table& tb = *mt->tables[t];
+      tb.note_update_time(update_time);
+      tb.ensure_capacity(uint64_t(cap) * uint64_t(world), st);
+      tb.pending.reserve(2 * size_t(cap) + 2);
+    }
+    sync_views(mt, st);
+    ShardOwnerArgs A{};
+    owner_args(A, slot);
+    int64_t lr_off = 0;
+    uint32_t gx = 1;
+    for (uint32_t t = 0; t < T; ++t) {
+      Table& tb = *mt->tables[t];
+      A.pending[t] = tb.pending.p;
+      ApplyArgs& a = A.a[t];
+      for (int i = 0; i < kMaxSegments; ++i) a.lr[i] = (i < int(tb.nseg)) ? lrs[lr_off + i] : 0.f;
+      lr_off += tb.nseg;
+      a.ts = static_cast<uint32_t>(update_time);
+      a.sum_dups = 0;
+      a.filter_mode = 0;
+      a.global_step = global_step;
+      gx = std::max(gx, (cap + 256u / A.g[t] - 1) / (256u / A.g[t]));
+    }
+    const uint32_t fill = std::max<uint32_t>(8, uint32_t(ms.num_cus) * 16 / T);
+    gx = std::min(gx, fill);
+    A.clear_ids = ids_send[slot];
+    for (int p = 0; p < world; ++p) {
+      A.peer = uint32_t(p);
+      A.zero_headers = p == world - 1 ? 1u : 0u;
+      LAUNCH_HOT(kTagShardUpsert, shard_upsert_kernel, dim3(gx, T), 256, st, A);
+      shard_slow_kernel<<<T, 64, 0, st>>>(A);
+      HIP_OK(hipGetLastError());
+    }
+    hdr_dirty[slot] = false;
+    for (uint32_t t = 0; t < T; ++t) {
+      ++mt->tables[t]->mut_epoch;
+      mt->tables[t]->maybe_evict(st);
+    }
+  }
+
+  const void* x_src(int kind, int slot) const {
+    return kind == kXIds ? static_cast<const void*>(ids_send[slot])
+                         : kind == kXRows ? static_cast<const void*>(own_rows) : snd_rows;
+  }
+  void* x_dst(int kind, int slot) const {
+    return kind == kXIds ? static_cast<void*>(ids_recv[slot])
+                         : kind == kXRows ? static_cast<void*>(snd_rows) : own_rows;
+  }
+  size_t x_block(int kind) const {
+    return kind == kXIds ? size_t(geo.ids_block) * sizeof(int64_t) : size_t(geo.rows_block) * sizeof(float);
+  }
+
+  // block p of the source goes to peer p, block p of the destination comes from peer p
+  void exchange_rccl(int kind, int slot, hipStream_t st) {
+    Rccl& R = Rccl::get();
+    const char* src = static_cast<const char*>(x_src(kind, slot));
+    char* dst = static_cast<char*>(x_dst(kind, slot));
+    const size_t b = x_block(kind);
+    R.ok(R.GroupStart(), "GroupStart");
+    for (int p = 0; p < world; ++p) {
+      R.ok(R.Send(src + size_t(p) * b, b, ncclInt8, p, comm, st), "Send");
+      R.ok(R.Recv(dst + size_t(p) * b, b, ncclInt8, p, comm, st), "Recv");
+    }
+    R.ok(R.GroupEnd(), "GroupEnd");
+  }
+};
+
+// the ranks of one process (all of them: a test, or one process driving several tables on one GPU)
+static void shard_exchange(ShardStep** S, int n, int kind, int slot, hipStream_t st) {
+  if (n == 1) {
+    if (S[0]->alias) return;
+    S[0]->exchange_rccl(kind, slot, st);
+    return;
+  }
+  for (int r = 0; r < n; ++r)
+    for (int p = 0; p < n; ++p) {
+      const size_t b = S[r]->x_block(kind);
+      HIP_OK(hipMemcpyAsync(static_cast<char*>(S[p]->x_dst(kind, slot)) + size_t(r) * b,
+                            static_cast<const char*>(S[r]->x_src(kind, slot)) + size_t(p) * b, b,
+                            hipMemcpyDeviceToDevice, st));
+    }
+}
+
+static void shard_check_group(ShardStep** S, int n) {
+  if (n < 1 || !S) throw Error(MHTE_INVALID_ARGUMENT, "shard step: no steps");
+  if (n == 1) {
+    if (S[0]->local_group_member())
+      throw Error(MHTE_FAILED_PRECONDITION, "shard step: created without a communicator for world > 1: "
+                                            "drive all its ranks together (mhte_shard_group_*)");
+    return;
+  }
+  for (int r = 0; r < n; ++r) {
+    if (!S[r] || S[r]->world != n || S[r]->rank != r || S[r]->comm || S[r]->device != S[0]->device ||
+        S[r]->T != S[0]->T || S[r]->cap != S[0]->cap || S[r]->geo.ids_block != S[0]->geo.ids_block ||
+        S[r]->geo.rows_block != S[0]->geo.rows_block || S[r]->ms.cur != S[0]->ms.cur)
+      throw Error(MHTE_INVALID_ARGUMENT, "shard group: steps must be ranks 0..n-1 of one world, same "
+                                         "device, tables and capacities, driven in lockstep");
+  }
+}
+
+static void shard_forward(ShardStep** S, int n, const ShardFwd* a, int64_t n_split, int64_t n_split_next,
+                          int prefetched, hipStream_t st) {
+  shard_check_group(S, n);
+  const bool has_next = a[0].id_next != nullptr;
+  for (int r = 0; r < n; ++r) {
+    ShardStep& s = *S[r];
+    MultiStep& ms = s.ms;
+    if ((a[r].id_next != nullptr) != has_next)
+      throw Error(MHTE_INVALID_ARGUMENT, "shard group: every rank or none passes a next batch");
+    ms.check_ragged(a[r].split, n_split, "id");
+    if (has_next) ms.check_ragged(a[r].split_next, n_split_next, "id_next");
+    if (!a[r].id || !a[r].emb) throw Error(MHTE_INVALID_ARGUMENT, "shard step forward: null argument");
+    if (!aligned16(a[r].emb)) throw Error(MHTE_INVALID_ARGUMENT, "shard step: embedding must be 16-byte aligned");
+    int64_t need = 0;
+    for (uint32_t t = 0; t < s.T; ++t)
+      need += (a[r].split[t + 1] - a[r].split[t]) * int64_t(s.tab[t].dim);
+    if (need > a[r].emb_len)
+      throw Error(MHTE_INVALID_ARGUMENT, "embedding buffer too short: need " + std::to_string(need));
+    if (prefetched) {
+      const int nxt = ms.cur ^ 1;
+      bool same = s.ahead && ms.stage[nxt] >= 1;
+      for (uint32_t t = 0; same && t < s.T; ++t)
+        same = ms.n_slot[nxt][t] == uint32_t(a[r].split[t + 1] - a[r].split[t]);
+      if (!same)
+        throw Error(MHTE_FAILED_PRECONDITION,
+                    "shard step forward: this batch was not deduplicated ahead by the previous forward");
+    }
+  }
+  for (int r = 0; r < n; ++r) {
+    ShardStep& s = *S[r];
+    HIP_OK(hipSetDevice(s.device));
+    s.prepare(st);
+    if (prefetched) {
+      s.ms.cur ^= 1;
+    } else {
+      const int other = s.ms.cur ^ 1;   // a batch prepared ahead is dropped
+      if (s.ms.stage[other] == 2) s.ms.stage[other] = 0;
+      s.disp[other] = false;
+      s.dedup(a[r].id, a[r].split, s.ms.cur, st);
+    }
+    s.ahead = false;
+  }
+  const int cur = S[0]->ms.cur;
+  if (S[0]->ms.stage[cur] == 1) {   // not numbered by a backward call: number + pack + send now
+    for (int r = 0; r < n; ++r) S[r]->build_and_sum(cur, -1, nullptr, st);
+    shard_exchange(S, n, kXIds, cur, st);
+  }
+  for (int r = 0; r < n; ++r) S[r]->owner_lookup(cur, st);
+  shard_exchange(S, n, kXRows, cur, st);
+  for (int r = 0; r < n; ++r) S[r]->scatter(a[r].emb, cur, st);
+  if (has_next)
+    for (int r = 0; r < n; ++r) {
+      S[r]->dedup(a[r].id_next, a[r].split_next, cur ^ 1, st);
+      S[r]->ahead = true;
+    }
+}
+
+static void shard_backward(ShardStep** S, int n, const float* const* grads, const int64_t* grads_len,
+                           const float* lrs, int64_t n_lr, int64_t update_time, int64_t global_step,
+                           hipStream_t st) {
+  shard_check_group(S, n);
+  for (int r = 0; r < n; ++r) {
+    ShardStep& s = *S[r];
+    MultiStep& ms = s.ms;
+    if (!s.disp[ms.cur] || ms.stage[ms.cur] != 2)
+      throw Error(MHTE_FAILED_PRECONDITION, "shard step backward: no forward batch outstanding");
+    if (!grads[r] || !lrs) throw Error(MHTE_INVALID_ARGUMENT, "shard step backward: null argument");
+    if (!aligned16(grads[r])) throw Error(MHTE_INVALID_ARGUMENT, "shard step: gradients must be 16-byte aligned");
+    int64_t need = 0, need_lr = 0;
+    for (uint32_t t = 0; t < s.T; ++t) {
+      need += int64_t(ms.n_slot[ms.cur][t]) * int64_t(s.tab[t].dim);
+      need_lr += s.mt->tables[t]->nseg;
+    }
+    if (need > grads_len[r])
+      throw Error(MHTE_INVALID_ARGUMENT, "The length of tensor `value` is too short. Currently value" +
+                                             std::to_string(grads_len[r]));
+    if (need_lr > n_lr)
+      throw Error(MHTE_INVALID_ARGUMENT,
+                  "The length of tensor `learning_rate` is too short. Currently value" + std::to_string(n_lr));
+  }
+  const int cur = S[0]->ms.cur;
+  const bool build_next = S[0]->ahead && S[0]->ms.stage[cur ^ 1] == 1;
+  for (int r = 0; r < n; ++r) {
+    HIP_OK(hipSetDevice(S[r]->device));
+    S[r]->prepare(st);
+    S[r]->build_and_sum(build_next ? (cur ^ 1) : -1, cur, grads[r], st);
+  }
+  shard_exchange(S, n, kXGrads, cur, st);
+  if (build_next) shard_exchange(S, n, kXIds, cur ^ 1, st);
+  for (int r = 0; r < n; ++r) {
+    S[r]->owner_apply(cur, lrs, update_time, global_step, st);
+    S[r]->ms.stage[cur] = 0;
+    S[r]->disp[cur] = false;
+  }
+}
+
+}  // namespace mhte
+#endif  // MHTE_SHARD_HOST_H_

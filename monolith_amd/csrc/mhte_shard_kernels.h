@@ -1,0 +1,290 @@
+// Kernels of the id-sharded multi-table step (host: mhte_shard_host.h): every table of the model in
+// ONE exchange per direction, as the reference's sync-training path moves them
+// (NT/distributed_ps_sync.py:95-287 lookup, :289-490 apply_gradients; shard = floormod(id, N),
+// NT/distributed_ps.py:289; packing RT/ops/fused_reorder_by_indices.cc:75-123).
+//
+// Wire format.  Rank r keeps, for every peer p, one fixed-capacity block in each direction:
+//   id block    int64[hdr + sum_t cap_t]   word t (< T) = number of ids of table t in the block (the
+//                                          exchange carries its own counts: no size all-to-all, no
+//                                          D2H), then per table cap_t id slots at id_off[t]
+//   row block   float[sum_t cap_t * dim_t] per table cap_t rows at row_off[t]; slot s of the id
+//                                          block's table t <-> row s — lookups come back and
+//                                          gradients leave in the same slots
+// Buffers hold N blocks back to back, peer-major, so an exchange is N fixed-size send / recv pairs.
+//
+//   owner   shard_lookup   the received id blocks' rows (no insert) into the row blocks
+//   sender  shard_scatter  rows back -> every occurrence (rd_gather_role)
+//   sender  shard_build    numbering of the NEXT batch's distinct ids, each also packed into its
+//                          owner's id block (PackCtl in rd_build_role: slot_off[u] = float offset of
+//                          u's row slot in the row buffers)  |  per-id gradient sums of this batch
+//                          (same order as the single-GPU step) -> row slots
+//   owner   shard_upsert   one peer's block: probe / insert / optimizer per id (ids of a block are
+//                          distinct), then shard_slow: the displacement pass; the peers are
+//                          applied one after the other in rank order — the reference's N separate
+//                          optimizer applications
+#ifndef MHTE_SHARD_KERNELS_H_
+#define MHTE_SHARD_KERNELS_H_
+
+namespace mhte {
+
+struct ShardTab {
+  uint32_t cap;       // id / row slots per peer block
+  uint32_t id_off;    // int64 words from the start of a block (header included)
+  uint32_t row_off;   // floats from the start of a row block
+  uint32_t dim;
+};
+
+struct ShardGeom {
+  uint32_t world;
+  uint32_t T;
+  uint32_t ids_block;    // int64 words per peer block
+  uint32_t rows_block;   // floats per peer block
+};
+
+enum : uint32_t { kShardOverflow = 1u, kShardBadHeader = 2u };
+
+// ---- owner: lookup of the received blocks ---------------------------------------------------------
+struct ShardOwnerArgs {
+  ConstViews views;
+  ShardGeom geo;
+  const int64_t* recv_ids;    // [world][ids_block]
+  float* rows;                // lookup: out [world][rows_block]; upsert: gradients in
+  uint32_t* flags;
+  uint32_t peer;              // upsert / slow: the block being applied
+  uint32_t zero_headers;      // slow: 1 = clear the headers of `clear_ids` when done
+  int64_t* clear_ids;
+  uint32_t* pending[kMaxStepTables];
+  ShardTab tab[kMaxStepTables];
+  uint8_t g[kMaxStepTables];
+  uint8_t count_hits[kMaxStepTables];
+  ApplyArgs a[kMaxStepTables];
+};
+static_assert(sizeof(ShardOwnerArgs) <= 4096, "kernel arguments exceed 4 KB");
+
+__device__ __forceinline__ uint32_t shard_block_count(const ShardOwnerArgs& A, uint32_t p, uint32_t t) {
+  const uint64_t c = uint64_t(A.recv_ids[size_t(p) * A.geo.ids_block + t]);
+  if (c > A.tab[t].cap) {
+    // the sender saw the same count and dropped the surplus ids' rows; flagged on both sides
+    if (threadIdx.x == 0) atomicOr(A.flags, uint32_t(kShardOverflow));
+    return A.tab[t].cap;
+  }
+  return uint32_t(c);
+}
+
+// grid (x, world * T): y = peer * T + table
+__global__ __launch_bounds__(512) void shard_lookup_kernel(ShardOwnerArgs A) {
+  const uint32_t p = blockIdx.y / A.geo.T, t = blockIdx.y % A.geo.T;
+  const uint32_t n = shard_block_count(A, p, t);
+  if (n == 0) return;
+  const ShardTab tb = A.tab[t];
+  const TableView& tv = deref_const(A.views + t);
+  const int64_t* ids = A.recv_ids + size_t(p) * A.geo.ids_block + tb.id_off;
+  float* out = A.rows + size_t(p) * A.geo.rows_block + tb.row_off;
+  const int ch = A.count_hits[t];
+  switch (A.g[t]) {
+    case 8: seg_lookup_loop<8>(tv, ids, n, out, ch); break;
+    case 16: seg_lookup_loop<16>(tv, ids, n, out, ch); break;
+    case 32: seg_lookup_loop<32>(tv, ids, n, out, ch); break;
+    default: seg_lookup_loop<64>(tv, ids, n, out, ch); break;
+  }
+}
+
+// displacement pass of one peer's block for table t, by one wavefront (lane 0 alone touches q, path
+// and the buckets; the waits order its stores before the wavefront's next loads)
+__device__ __forceinline__ void shard_slow_role(const ShardOwnerArgs& A, uint32_t t, BfsSlot* q,
+                                                CuckooRecord* path, int lane) {
+  const TableView& tv = deref_const(A.views + t);
+  const uint32_t np = tv.ctr->n_pending;
+  if (!np) return;
+  const ShardTab tb = A.tab[t];
+  const int64_t* ids = A.recv_ids + size_t(A.peer) * A.geo.ids_block + tb.id_off;
+  const float* values = A.rows + size_t(A.peer) * A.geo.rows_block + tb.row_off;
+  const uint32_t* pending = A.pending[t];
+  const ApplyArgs& a = A.a[t];
+  for (uint32_t i = 0; i < np; ++i) {
+    const uint32_t g = pending[2 * i];
+    const int64_t id = ids[g];
+    uint32_t r;
+    if (lane == 0) r = static_cast<uint32_t>(atomicAdd(&tv.ctr->alloc, (1ull << 32) | 1ull));
+    const long long pos = wave_insert_slot(tv.buckets, tv.hp, id, q, path, lane);
+    if (lane == 0) {
+      if (pos >= 0) {
+        Bucket* b = tv.buckets + (pos >> 2);
+        b->row[pos & 3] = r;
+        b->ts[pos & 3] = a.ts;
+      } else {
+        atomicAdd(&tv.ctr->alloc, ~((1ull << 32) - 1ull));
+        atomicOr(&tv.ctr->error, 1u);
+        atomicAdd(&tv.ctr->n_dropped, 1u);
+      }
+    }
+    r = __shfl(r, 0);
+    if (pos >= 0)
+      apply_row<64, 4, kOpOptimize, false, false>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
+                                                  1u, int64_t(g), a);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
+  if (lane == 0) tv.ctr->n_pending = 0;
+}
+
+// grid (x, T): the block of peer A.peer.  Ids whose two buckets are full go to the table's pending
+// list, finished by shard_slow_kernel.  (A launch of its own, not the last workgroup of this one: on
+// the 8-XCD part the other workgroups' bucket and pending-list stores sit in their XCDs' L2s until
+// the kernel ends — making them visible earlier is an L2 write-back per workgroup, measured 295 us
+// against 5 us for the extra launch.)
+__global__ __launch_bounds__(256) void shard_upsert_kernel(ShardOwnerArgs A) {
+  const uint32_t p = A.peer, t = blockIdx.y;
+  const uint32_t n = shard_block_count(A, p, t);
+  if (n == 0) return;
+  const ShardTab tb = A.tab[t];
+  const TableView& tv = deref_const(A.views + t);
+  const int64_t* ids = A.recv_ids + size_t(p) * A.geo.ids_block + tb.id_off;
+  const float* values = A.rows + size_t(p) * A.geo.rows_block + tb.row_off;
+  uint32_t* pend = A.pending[t];
+  switch (A.g[t]) {   // pending entry = (position in the block's table segment, unused)
+    case 8: seg_upsert_loop<8>(tv, ids, n, values, A.a[t], pend, 0u, 0u); break;
+    case 16: seg_upsert_loop<16>(tv, ids, n, values, A.a[t], pend, 0u, 0u); break;
+    case 32: seg_upsert_loop<32>(tv, ids, n, values, A.a[t], pend, 0u, 0u); break;
+    default: seg_upsert_loop<64>(tv, ids, n, values, A.a[t], pend, 0u, 0u); break;
+  }
+}
+
+// displacement pass of one peer's block, one wavefront per table; the last one of a step also
+// clears the headers of the step's send blocks (the next numbering into them counts from zero)
+__global__ __launch_bounds__(64) void shard_slow_kernel(ShardOwnerArgs A) {
+  __shared__ BfsSlot q[kMaxCuckooCount];
+  __shared__ CuckooRecord path[kMaxBfsPathLen];
+  const uint32_t t = blockIdx.x;
+  const int lane = threadIdx.x;
+  shard_slow_role(A, t, q, path, lane);
+  if (A.zero_headers && uint32_t(lane) < A.geo.world)
+    A.clear_ids[size_t(lane) * A.geo.ids_block + t] = 0;
+}
+
+// ---- sender: rows -> occurrences, occurrence gradients -> row slots ---------------------------------
+struct ShardGatherTab {
+  uint32_t nblk_items;
+  uint32_t nblk_ids;
+  uint32_t io_off;      // floats: SCATTER the table's embeddings in `flat`, SUM its gradients
+  uint32_t n;           // occurrences of the batch (0: nothing to do)
+};
+struct ShardGatherArgs {
+  ConstStatics st;
+  const float* in;      // SCATTER: row buffer; SUM: flat gradients
+  float* out;           // SCATTER: flat embeddings; SUM: row buffer
+  const uint32_t* slot_off;   // [T][n_max]
+  uint32_t slot;
+  uint32_t n_max;
+  ShardTab tab[kMaxStepTables];
+  ShardGatherTab gt[kMaxStepTables];
+};
+static_assert(sizeof(ShardGatherArgs) <= 4096, "kernel arguments exceed 4 KB");
+
+__device__ __forceinline__ void shard_gather_ctl(GatherCtl& c, const MStepStatic& s, uint32_t cur,
+                                                 const uint32_t* slot_off, uint32_t n_max, uint32_t t,
+                                                 uint32_t dim, const ShardGatherTab& gt) {
+  c.index = slot_off + size_t(t) * n_max;
+  c.part = s.part[cur];
+  c.arrive = s.arrive[cur];
+  c.n_max = s.n_max;
+  c.dim = dim;
+  c.nblk_items = gt.nblk_items;
+  c.nblk_ids = gt.nblk_ids;
+  c.index_is_offset = 1;
+}
+
+template <bool SCATTER>
+__device__ __forceinline__ void shard_gather_switch(uint32_t g, const RunView& d, const GatherCtl& c,
+                                                    uint32_t bid, char* raw) {
+  switch (g) {
+    case 8: rd_gather_role<8, 4, SCATTER>(d, c, bid, *reinterpret_cast<GatherLds<8, 4>*>(raw)); break;
+    case 16: rd_gather_role<16, 4, SCATTER>(d, c, bid, *reinterpret_cast<GatherLds<16, 4>*>(raw)); break;
+    case 32: rd_gather_role<32, 4, SCATTER>(d, c, bid, *reinterpret_cast<GatherLds<32, 4>*>(raw)); break;
+    default: rd_gather_role<64, 4, SCATTER>(d, c, bid, *reinterpret_cast<GatherLds<64, 4>*>(raw)); break;
+  }
+}
+static_assert(sizeof(GatherLds<8, 4>) >= sizeof(GatherLds<16, 4>) &&
+                  sizeof(GatherLds<8, 4>) >= sizeof(GatherLds<32, 4>) &&
+                  sizeof(GatherLds<8, 4>) >= sizeof(GatherLds<64, 4>),
+              "LDS of the gather role");
+
+// rows back -> every occurrence of the batch in `slot`
+__global__ __launch_bounds__(256) void shard_scatter_kernel(ShardGatherArgs A) {
+  __shared__ __attribute__((aligned(16))) char raw[sizeof(GatherLds<8, 4>)];
+  const uint32_t t = blockIdx.y;
+  const ShardGatherTab gt = A.gt[t];
+  if (gt.n == 0 || blockIdx.x >= gt.nblk_items + gt.nblk_ids) return;
+  const MStepStatic& s = deref_const(A.st + t);
+  const uint32_t cur = A.slot & 1u;
+  RunView d = s.rv[cur];
+  d.nblk = (gt.n + kRdBlock - 1) / kRdBlock;
+  GatherCtl c;
+  c.in = A.in;
+  c.out = A.out + size_t(gt.io_off);
+  shard_gather_ctl(c, s, cur, A.slot_off, A.n_max, t, A.tab[t].dim, gt);
+  shard_gather_switch<true>(s.g, d, c, blockIdx.x, raw);
+}
+
+// backward launch of the sender side, per table:
+//   numbering + owner packing of the batch deduplicated into build_slot | gradient sums of the
+//   batch in slot -> row slots
+// (either half may be absent: n_build[t] == 0, gt[t].n == 0)
+struct ShardBuildArgs {
+  ConstStatics st;
+  ShardGeom geo;
+  int64_t* send_ids;              // blocks of build_slot; headers zero on entry
+  uint32_t* slot_off_build;       // [T][n_max] of build_slot
+  uint32_t* flags;
+  const float* grads;             // flat gradients of the batch in `slot`
+  float* rows_out;                // sender-side row buffer
+  const uint32_t* slot_off;       // [T][n_max] of `slot`
+  uint32_t build_slot;
+  uint32_t slot;
+  uint32_t n_max;
+  uint32_t pad;
+  ShardTab tab[kMaxStepTables];
+  uint32_t n_build[kMaxStepTables];
+  ShardGatherTab gt[kMaxStepTables];
+};
+static_assert(sizeof(ShardBuildArgs) <= 4096, "kernel arguments exceed 4 KB");
+
+__global__ __launch_bounds__(256) void shard_build_kernel(ShardBuildArgs A) {
+  __shared__ __attribute__((aligned(16))) char raw[sizeof(GatherLds<8, 4>)];
+  const uint32_t t = blockIdx.y;
+  const MStepStatic& s = deref_const(A.st + t);
+  uint32_t bid = blockIdx.x;
+  const uint32_t nb = A.n_build[t] ? s.nblk_build : 0u;
+  if (bid < nb) {
+    RunView nxt = s.rv[A.build_slot & 1u];
+    nxt.nblk = (A.n_build[t] + kRdBlock - 1) / kRdBlock;
+    const ShardTab tb = A.tab[t];
+    PackCtl pc;
+    pc.send_ids = A.send_ids;
+    pc.slot_off = A.slot_off_build + size_t(t) * A.n_max;
+    pc.flags = A.flags;
+    pc.world = A.geo.world;
+    pc.ids_block = A.geo.ids_block;
+    pc.rows_block = A.geo.rows_block;
+    pc.hdr_word = t;
+    pc.cap = tb.cap;
+    pc.id_off = tb.id_off;
+    pc.row_off = tb.row_off;
+    pc.dim = tb.dim;
+    rd_build_role<true>(nxt, uint32_t(kStepLightMax), bid, nb, &pc);
+    return;
+  }
+  bid -= nb;
+  const ShardGatherTab gt = A.gt[t];
+  if (gt.n == 0 || bid >= gt.nblk_items + gt.nblk_ids) return;
+  const uint32_t cur = A.slot & 1u;
+  RunView d = s.rv[cur];
+  d.nblk = (gt.n + kRdBlock - 1) / kRdBlock;
+  GatherCtl c;
+  c.in = A.grads + size_t(gt.io_off);
+  c.out = A.rows_out;
+  shard_gather_ctl(c, s, cur, A.slot_off, A.n_max, t, A.tab[t].dim, gt);
+  shard_gather_switch<false>(s.g, d, c, bid, raw);
+}
+
+}  // namespace mhte
+#endif  // MHTE_SHARD_KERNELS_H_

@@ -365,11 +365,31 @@ __device__ __forceinline__ uint32_t rd_item_blocks(uint32_t c, uint32_t target) 
 // ---------------------------------------------------------------------------------------------
 constexpr int kBuildSlotsPerLane = 4;
 
+// Optional second output of the numbering (the id-sharded step, mhte_shard_kernels.h): every
+// distinct id also gets a slot in the block of its owner floormod(id, world) — FusedReorderByIndices'
+// shard-major packing (RT/ops/fused_reorder_by_indices.cc:75-123) — through one LDS histogram per
+// workgroup trip and one global add per (trip, owner) on the block's header word.
+constexpr int kMaxShards = 64;
+__device__ __forceinline__ uint32_t shard_of_id(int64_t id, uint32_t nshards) {
+  const int64_t m = id % int64_t(nshards);
+  return uint32_t(m < 0 ? m + int64_t(nshards) : m);
+}
+struct PackCtl {
+  int64_t* send_ids;     // [world][ids_block]
+  uint32_t* slot_off;    // [n_max] of this table: float offset of unique index u's row slot
+  uint32_t* flags;
+  uint32_t world, ids_block, rows_block;
+  uint32_t hdr_word;     // the table's count word in a block's header
+  uint32_t cap, id_off, row_off, dim;
+};
+
+template <bool PACK = false>
 __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_max, uint32_t bid,
-                                              uint32_t nblocks) {
+                                              uint32_t nblocks, const PackCtl* pc = nullptr) {
   constexpr int Q = kBuildSlotsPerLane;
   __shared__ uint32_t sh_tot[4];
   __shared__ uint32_t sh_base;
+  __shared__ uint32_t sh_pc[PACK ? kMaxShards : 1], sh_pb[PACK ? kMaxShards : 1];
   const uint32_t t = threadIdx.x;
   const int lane = t & 63;
   const uint32_t nslots = d.cap_mask + 2u;  // + the side slot of kEmptyKey
@@ -380,6 +400,10 @@ __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_m
     uint32_t cnt[Q], pos[Q];
     unsigned long long occ[Q];
     uint32_t total = 0;
+    if (PACK) {
+      if (t < pc->world) sh_pc[t] = 0;
+      lds_barrier();
+    }
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const uint32_t sl = base + q * 64 + lane;
@@ -400,6 +424,17 @@ __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_m
       occ[q] = __ballot(o);
       total += uint32_t(__popcll(occ[q]));
     }
+    uint32_t pown[Q], prank[Q];
+    if (PACK) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        pown[q] = prank[q] = 0;
+        if ((occ[q] >> lane) & 1ull) {
+          pown[q] = shard_of_id(key[q], pc->world);
+          prank[q] = atomicAdd(&sh_pc[pown[q]], 1u);
+        }
+      }
+    }
     // one counter bump per WORKGROUP and trip (hundreds of wavefronts bumping one address would
     // queue behind each other for longer than the whole launch should take)
     if (lane == 0) sh_tot[t >> 6] = total;
@@ -407,6 +442,13 @@ __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_m
     if (t == 0) {
       const uint32_t all = sh_tot[0] + sh_tot[1] + sh_tot[2] + sh_tot[3];
       sh_base = all ? atomicAdd(&d.ctr[0], all) : 0u;
+    }
+    if (PACK && t < pc->world) {
+      const uint32_t c = sh_pc[t];
+      sh_pb[t] = c ? uint32_t(atomicAdd(reinterpret_cast<unsigned long long*>(
+                                            pc->send_ids + size_t(t) * pc->ids_block + pc->hdr_word),
+                                        static_cast<unsigned long long>(c)))
+                   : 0u;
     }
     lds_barrier();
     uint32_t k0 = sh_base;
@@ -422,6 +464,16 @@ __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_m
         d.uslot[kq[q]] = base + q * 64 + lane;
         d.ucnt[kq[q]] = cnt[q];
         d.upos[kq[q]] = pos[q];
+        if (PACK) {
+          const uint32_t sl = sh_pb[pown[q]] + prank[q];
+          if (sl < pc->cap) {
+            pc->send_ids[size_t(pown[q]) * pc->ids_block + pc->id_off + sl] = key[q];
+            pc->slot_off[kq[q]] = pown[q] * pc->rows_block + pc->row_off + sl * pc->dim;
+          } else {   // no room in the owner's block: zero row back, gradient dropped, flagged
+            pc->slot_off[kq[q]] = 0xffffffffu;
+            atomicOr(pc->flags, 1u);
+          }
+        }
       }
     }
 #pragma unroll
@@ -1356,10 +1408,27 @@ struct GatherCtl {
   uint32_t dim;
   uint32_t nblk_items;
   uint32_t nblk_ids;
+  uint32_t index_is_offset;  // index[u] is a float offset into the rows (0xffffffff: no row — the
+                             // id found no room in its peer block) instead of a row number
 };
 
+// LDS of the gather role, for NG = 256 / G lane groups; the caller declares it
+template <int G, int VEC>
+struct GatherLds {
+  uint32_t pos[256 / G][kStepLightMax];
+  uint32_t rstart[65];
+  uint32_t rval[64];
+  float sum[256 / G][G * VEC];
+  uint32_t last;
+};
+
+__device__ __forceinline__ int64_t gather_row_off(const GatherCtl& c, uint32_t ix) {
+  return c.index_is_offset ? int64_t(ix) : int64_t(ix) * c.dim;
+}
+
 template <int G, int VEC, bool SCATTER>
-__global__ __launch_bounds__(256) void rd_gather_kernel(RunView d, GatherCtl c) {
+__device__ __forceinline__ void rd_gather_role(const RunView& d, const GatherCtl& c, uint32_t bid,
+                                               GatherLds<G, VEC>& L) {
   constexpr int WIN = G < 8 ? G : 8;
   constexpr int NG = 256 / G;
   const int lane = threadIdx.x & 63;
@@ -1370,10 +1439,9 @@ __global__ __launch_bounds__(256) void rd_gather_kernel(RunView d, GatherCtl c) 
   const int64_t n_max = c.n_max;
   const uint32_t e = uint32_t(j) * VEC;
   const bool ev = e < dim;
-  const uint32_t bid = blockIdx.x;
 
   if (bid >= c.nblk_items) {
-    __shared__ uint32_t sh_pos[NG][kStepLightMax];
+    auto& sh_pos = L.pos;
     const int64_t stride = int64_t(c.nblk_ids) * NG;
     const int64_t k = bid - c.nblk_items;
     int64_t nu = n_max;
@@ -1386,8 +1454,9 @@ __global__ __launch_bounds__(256) void rd_gather_kernel(RunView d, GatherCtl c) 
       const uint32_t gs = inb ? d.uslot[g] : 0u;
       const uint32_t ix = inb ? (c.index ? c.index[g] : uint32_t(g)) : 0u;
       if (it == 0) nu = min(n_max, int64_t(d.ctr[0]));
-      const bool valid = g < nu && cnt <= uint32_t(kStepLightMax);
-      if (!valid) cnt = 0;
+      const bool inrange = g < nu && cnt <= uint32_t(kStepLightMax);
+      if (!inrange) cnt = 0;
+      const bool valid = inrange && ix != 0xffffffffu;  // (no row: zeros out, gradient dropped)
       constexpr int PER = (kStepLightMax + G - 1) / G;
       uint32_t x[PER];
 #pragma unroll
@@ -1398,7 +1467,7 @@ __global__ __launch_bounds__(256) void rd_gather_kernel(RunView d, GatherCtl c) 
       if (SCATTER) {
         Vec<VEC> row;
         vec_zero(row);
-        if (valid && ev) row.load(c.in + int64_t(ix) * dim + e);
+        if (valid && ev) row.load(c.in + gather_row_off(c, ix) + e);
         if (cnt == 1) {
           if (ev) row.store(c.out + int64_t(hp) * dim + e);
         } else if (cnt > 1) {
@@ -1440,17 +1509,17 @@ __global__ __launch_bounds__(256) void rd_gather_kernel(RunView d, GatherCtl c) 
           if (cnt > 1) sum_list_lds<VEC>(c.in, dim, e, ev, sh_pos[grp], cnt, acc);
           lds_wave_sync();
         }
-        if (valid && ev) acc.store(c.out + int64_t(ix) * dim + e);
+        if (valid && ev) acc.store(c.out + gather_row_off(c, ix) + e);
       }
     }
     return;
   }
 
   // ---- item workgroups
-  __shared__ uint32_t sh_rstart[65];
-  __shared__ uint32_t sh_rval[64];
-  __shared__ float sh_sum[NG][G * VEC];
-  __shared__ uint32_t sh_last;
+  auto& sh_rstart = L.rstart;
+  auto& sh_rval = L.rval;
+  auto& sh_sum = L.sum;
+  uint32_t& sh_last = L.last;
 #pragma unroll 1
   for (uint32_t w = bid;; w += c.nblk_items) {
     const uint32_t nitems_all = d.ctr[2];
@@ -1480,7 +1549,7 @@ __global__ __launch_bounds__(256) void rd_gather_kernel(RunView d, GatherCtl c) 
     Vec<VEC> acc, row;
     vec_zero(acc);
     vec_zero(row);
-    if (SCATTER && ev) row.load(c.in + int64_t(ix) * dim + e);
+    if (SCATTER && ev && ix != 0xffffffffu) row.load(c.in + gather_row_off(c, ix) + e);
 #pragma unroll 1
     for (uint32_t qb = uint32_t(grp) * WIN; qb < E; qb += NG * WIN) {
       uint32_t p = 0;
@@ -1573,10 +1642,16 @@ __global__ __launch_bounds__(256) void rd_gather_kernel(RunView d, GatherCtl c) 
           }
         }
       }
-      if (fin && threadIdx.x < G && ev) tot.store(c.out + int64_t(ix) * dim + e);
+      if (fin && threadIdx.x < G && ev && ix != 0xffffffffu) tot.store(c.out + gather_row_off(c, ix) + e);
     }
     lds_barrier();
   }
+}
+
+template <int G, int VEC, bool SCATTER>
+__global__ __launch_bounds__(256) void rd_gather_kernel(RunView d, GatherCtl c) {
+  __shared__ GatherLds<G, VEC> L;
+  rd_gather_role<G, VEC, SCATTER>(d, c, blockIdx.x, L);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1590,12 +1665,6 @@ __global__ __launch_bounds__(256) void rd_gather_kernel(RunView d, GatherCtl c) 
 //                    every consumer goes through send_pos, nothing depends on it.
 // n comes from device memory (the build role's unique count).
 // ---------------------------------------------------------------------------------------------
-constexpr int kMaxShards = 64;
-
-__device__ __forceinline__ uint32_t shard_of_id(int64_t id, uint32_t nshards) {
-  const int64_t m = id % int64_t(nshards);
-  return uint32_t(m < 0 ? m + int64_t(nshards) : m);
-}
 
 __global__ __launch_bounds__(1024) void rd_shard_count_kernel(const int64_t* __restrict__ ids,
                                                               const uint32_t* __restrict__ n_dev,

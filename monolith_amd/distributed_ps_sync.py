@@ -348,3 +348,210 @@ class ShardedEmbedding:
       if isinstance(t, torch.Tensor) and t.is_cuda:
         t.record_stream(main)
     self._pre = (key, disp, ev)
+
+
+# =================================================================================================
+# The multi-table sharded step, driven from C++ (csrc/mhte_shard_host.h)
+# =================================================================================================
+def _rccl_env():
+  """Point the library at the RCCL this process already has (PyTorch ships its own copy)."""
+  import os
+  if "MHTE_RCCL_LIBRARY" not in os.environ:
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if os.path.exists(cand):
+      os.environ["MHTE_RCCL_LIBRARY"] = cand
+
+
+def shard_unique_id() -> bytes:
+  """128-byte RCCL unique id (mhte_shard_unique_id); one rank makes it, the launcher hands it to
+  all."""
+  from monolith_amd import _lib
+  _rccl_env()
+  buf = C.create_string_buffer(128)
+  _lib.check(_lib.lib().mhte_shard_unique_id(buf))
+  return buf.raw
+
+
+class ShardedMultiStep:
+  """All tables of the model, sharded by id over the ranks, one exchange per direction for all of
+  them (native_training/distributed_ps_sync.py:95-287, :289-490) — mhte_shard_step_*: the whole
+  step is enqueued from C++ (kernels + RCCL send / recv groups), no count ever reaches the host.
+
+  ``table`` is this rank's MultiHashTable (the ids it owns).  ``group``: a torch.distributed group
+  (backend nccl = RCCL) used ONCE, to hand the RCCL unique id of rank 0 to the others; the step's
+  exchanges run on a communicator of the library's own.  Without a group (world 1) the exchange is
+  the identity.  Same call protocol as ``MultiSparseStep``: ``forward(ragged, next_ragged)``
+  returns the flat per-occurrence embedding and dispatches the next batch's ids ahead;
+  ``backward(flat_grad, update_time)``."""
+
+  def __init__(self, table, batch_per_table: int, group: Optional["dist.ProcessGroup"] = None,
+               ids_per_peer_table: int = 0, use_rccl: Optional[bool] = None):
+    from monolith_amd import _lib
+    self._libmod = _lib
+    self._lib = table._lib  # pylint: disable=protected-access
+    self.table = table
+    self.batch = int(batch_per_table)
+    self._dims = table.get_table_dim_sizes()
+    if group is not None or (dist.is_available() and dist.is_initialized()):
+      self.world = dist.get_world_size(group)
+      self.rank = dist.get_rank(group)
+    else:
+      self.world, self.rank = 1, 0
+    if use_rccl is None:
+      use_rccl = self.world > 1
+    uid = None
+    if use_rccl:
+      _rccl_env()
+      if self.world > 1:
+        box = [shard_unique_id() if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                                   group=group)
+        uid = box[0]
+      else:
+        uid = shard_unique_id()
+    h = C.c_void_p()
+    _lib.check(self._lib.mhte_shard_step_create(
+        table.handle, C.c_int64(self.batch), C.c_int32(self.rank), C.c_int32(self.world),
+        C.c_int64(int(ids_per_peer_table)), uid, C.byref(h)))
+    self._h = h
+    self._ahead = None
+    self._keep = None
+
+  def close(self):
+    if getattr(self, "_h", None):
+      torch.cuda.synchronize()
+      self._lib.mhte_shard_step_destroy(self._h)
+      self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def info(self):
+    out = (C.c_int64 * 4)()
+    self._libmod.check(self._lib.mhte_shard_step_info(self._h, out))
+    return {"ids_per_peer_table": out[0], "id_block_bytes": out[1], "row_block_bytes": out[2],
+            "transport": ("identity", "rccl", "group")[out[3]]}
+
+  @staticmethod
+  def _key(r):
+    return (r.values, r.values._version, r.row_splits.tobytes())  # pylint: disable=protected-access
+
+  @staticmethod
+  def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+  def forward(self, ragged, next_ragged=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _lib = self._libmod
+    lens = ragged.row_lengths()
+    total = int(sum(int(l) * d for l, d in zip(lens, self._dims)))
+    if out is None:
+      out = torch.empty(total, dtype=torch.float32, device=ragged.values.device)
+    a = self._ahead
+    pre = (a is not None and a[0] is ragged.values and a[1] == ragged.values._version and  # pylint: disable=protected-access
+           a[2] == ragged.row_splits.tobytes())
+    sp = np.ascontiguousarray(ragged.row_splits, dtype=np.int64)
+    if next_ragged is not None:
+      nsp = np.ascontiguousarray(next_ragged.row_splits, dtype=np.int64)
+      nv, nsp_p, nsp_n = _lib.vp(next_ragged.values), nsp.ctypes.data_as(C.POINTER(C.c_int64)), nsp.size
+    else:
+      nv, nsp_p, nsp_n = C.c_void_p(0), None, 0
+    _lib.check(self._lib.mhte_shard_step_forward(
+        self._h, _lib.vp(ragged.values), sp.ctypes.data_as(C.POINTER(C.c_int64)), C.c_int64(sp.size),
+        _lib.vp(out), C.c_int64(out.numel()), nv, nsp_p, C.c_int64(nsp_n),
+        C.c_int32(1 if pre else 0), self._stream()))
+    self._ahead = self._key(next_ragged) if next_ragged is not None else None
+    self._keep = (ragged, next_ragged, out)
+    return out
+
+  def backward(self, flat_grad: torch.Tensor, update_time: int, global_step: int = 0):
+    _lib = self._libmod
+    lrs = np.ascontiguousarray(self.table.learning_rate, dtype=np.float32)
+    _lib.check(self._lib.mhte_shard_step_backward(
+        self._h, _lib.vp(flat_grad), C.c_int64(flat_grad.numel()),
+        lrs.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(lrs.size), C.c_int64(int(update_time)),
+        C.c_int64(int(global_step)), self._stream()))
+
+  def check(self):
+    """Wait for the stream; raises ResourceExhausted if a peer block overflowed."""
+    self._libmod.check(self._lib.mhte_shard_step_check(self._h, self._stream()))
+
+
+class ShardedStepGroup:
+  """All ranks of a world inside ONE process on one GPU (mhte_shard_group_*): device copies stand
+  in for the links.  For tests of the N-rank protocol on a single MI355X."""
+
+  def __init__(self, tables, batch_per_table: int, ids_per_peer_table: int = 0):
+    from monolith_amd import _lib
+    self._libmod = _lib
+    self.tables = list(tables)
+    self.world = len(self.tables)
+    self._lib = self.tables[0]._lib  # pylint: disable=protected-access
+    self._dims = self.tables[0].get_table_dim_sizes()
+    self._hs = []
+    for r, t in enumerate(self.tables):
+      h = C.c_void_p()
+      _lib.check(self._lib.mhte_shard_step_create(
+          t.handle, C.c_int64(int(batch_per_table)), C.c_int32(r), C.c_int32(self.world),
+          C.c_int64(int(ids_per_peer_table)), None, C.byref(h)))
+      self._hs.append(h)
+    self._arr = (C.c_void_p * self.world)(*[h.value for h in self._hs])
+    self._keep = None
+
+  def close(self):
+    if getattr(self, "_hs", None):
+      torch.cuda.synchronize()
+      for h in self._hs:
+        self._lib.mhte_shard_step_destroy(h)
+      self._hs = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def forward(self, raggeds, next_raggeds=None, prefetched=False):
+    """raggeds: one Ragged per rank -> list of flat embeddings."""
+    _lib, N = self._libmod, self.world
+    I64P = C.POINTER(C.c_int64)
+    outs, sps = [], []
+    for r in raggeds:
+      lens = r.row_lengths()
+      outs.append(torch.empty(int(sum(int(l) * d for l, d in zip(lens, self._dims))),
+                              dtype=torch.float32, device=r.values.device))
+      sps.append(np.ascontiguousarray(r.row_splits, dtype=np.int64))
+    ids = (C.c_void_p * N)(*[r.values.data_ptr() for r in raggeds])
+    spl = (I64P * N)(*[s.ctypes.data_as(I64P) for s in sps])
+    emb = (C.c_void_p * N)(*[o.data_ptr() for o in outs])
+    elen = (C.c_int64 * N)(*[o.numel() for o in outs])
+    if next_raggeds is not None:
+      nsps = [np.ascontiguousarray(r.row_splits, dtype=np.int64) for r in next_raggeds]
+      nids = (C.c_void_p * N)(*[r.values.data_ptr() for r in next_raggeds])
+      nspl = (I64P * N)(*[s.ctypes.data_as(I64P) for s in nsps])
+      n_next = nsps[0].size
+    else:
+      nsps, nids, nspl, n_next = None, None, None, 0
+    _lib.check(self._lib.mhte_shard_group_forward(
+        self._arr, C.c_int32(N), ids, spl, C.c_int64(sps[0].size), emb, elen, nids, nspl,
+        C.c_int64(n_next), C.c_int32(1 if prefetched else 0),
+        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    self._keep = (raggeds, next_raggeds, outs, sps, nsps)
+    return outs
+
+  def backward(self, flat_grads, update_time: int, global_step: int = 0):
+    _lib, N = self._libmod, self.world
+    lrs = np.ascontiguousarray(self.tables[0].learning_rate, dtype=np.float32)
+    val = (C.c_void_p * N)(*[g.data_ptr() for g in flat_grads])
+    vlen = (C.c_int64 * N)(*[g.numel() for g in flat_grads])
+    _lib.check(self._lib.mhte_shard_group_backward(
+        self._arr, C.c_int32(N), val, vlen, lrs.ctypes.data_as(C.POINTER(C.c_float)),
+        C.c_int64(lrs.size), C.c_int64(int(update_time)), C.c_int64(int(global_step)),
+        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+  def check(self):
+    for h in self._hs:
+      self._libmod.check(self._lib.mhte_shard_step_check(
+          h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))

@@ -1,0 +1,185 @@
+"""GPU parity (-m gpu) of the id-sharded multi-table step (csrc/mhte_shard_host.h, C ABI
+mhte_shard_step_* / mhte_shard_group_*):
+  * world 1 (identity exchange) against the single-GPU multi-table step, bit for bit;
+  * N ranks in one process on one GPU (device copies as links) against the CPU oracle: every
+    rank's embeddings, and every owner's rows after the peers' gradient blocks were applied in
+    rank order (the reference's one optimizer application per sender,
+    native_training/distributed_ps_sync.py:357-479);
+  * world 1 over a real RCCL communicator (send / recv to self): the dlopen'ed RCCL path;
+  * a peer block that overflows is reported, its ids read zeros.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle as O  # noqa: E402,F401
+from monolith_amd import _lib, synthetic as S  # noqa: E402
+from monolith_amd.distributed_ps_sync import ShardedMultiStep, ShardedStepGroup  # noqa: E402
+from monolith_amd.fused_step import MultiSparseStep  # noqa: E402
+from test_multi_step_gpu import (ATOL, RTOL, dlrm_specs, make, oracle_backward, ragged_of,  # noqa: E402
+                                 val_t)
+
+
+def batch_of(specs, seed, n, universe, dist="zipf", skip=()):
+  out = {}
+  for s in specs:
+    if s.name in skip:
+      continue
+    out[s.name] = S.id_batch(seed * 131 + s.slot, n, universe, dist, feature_slot=s.slot)
+  return out
+
+
+def grads_of(step, rank, spec, n):
+  rng = np.random.default_rng(1000 * step + 17 * rank + spec.slot)
+  return (rng.standard_normal((n, spec.dim)) * 0.1).astype(np.float32)
+
+
+def test_world1_identity_matches_multi_step():
+  specs = dlrm_specs(7, initial_capacity=1 << 12)
+  by_name = sorted(specs, key=lambda s: s.name)
+  B, steps = 6000, 6
+  batches = [batch_of(specs, s, B, 9000) for s in range(steps + 1)]
+  mt_a, mt_b = make(specs), make(specs)
+  ref = MultiSparseStep(mt_a, B)
+  shd = ShardedMultiStep(mt_b, B)
+  assert shd.info()["transport"] == "identity"
+  rag_a = [ragged_of(specs, mt_a, b) for b in batches]
+  rag_b = [ragged_of(specs, mt_b, b) for b in batches]
+  for s in range(steps):
+    ea = ref.forward(rag_a[s], rag_a[s + 1])
+    eb = shd.forward(rag_b[s], rag_b[s + 1] if s % 3 != 2 else None)   # (every third: not ahead)
+    assert torch.equal(ea, eb), "forward step %d" % s
+    g = val_t(np.concatenate([grads_of(s, 0, sp, B).ravel() for sp in by_name]))
+    ref.backward(g, S.update_time(s))
+    shd.backward(g, S.update_time(s))
+  shd.check()
+  allids = {sp.name: np.unique(np.concatenate([b[sp.name] for b in batches])) for sp in specs}
+  ra, rb = ragged_of(specs, mt_a, allids), ragged_of(specs, mt_b, allids)
+  assert torch.equal(mt_a.raw_lookup(ra), mt_b.raw_lookup(rb))
+  ref.close()
+  shd.close()
+
+
+@pytest.mark.parametrize("dist,world", [("uniform", 3), ("zipf", 2), ("zipf", 5)])
+def test_group_against_oracle(dist, world):
+  specs = dlrm_specs(8, initial_capacity=1 << 10)
+  by_name = sorted(specs, key=lambda s: s.name)
+  B, steps = 3000, 5
+  universe = 200000 if dist == "uniform" else 7000
+  exact = dist == "uniform"   # every id occurs <= 32 times in a batch: sums in occurrence order
+  mts = [make(specs) for _ in range(world)]
+  grp = ShardedStepGroup(mts, B)
+  ots = {s.name: s.oracle_table() for s in specs}
+
+  def rank_batch(step, r):
+    skip = ("f03",) if (r == 1 and step % 2 == 0) else ()      # ragged: an empty table on one rank
+    n = B if not (r == 0 and step == 2) else 1                 # and a one-id batch
+    return batch_of(specs, 100 * step + r, n, universe, dist, skip)
+
+  batches = [[rank_batch(s, r) for r in range(world)] for s in range(steps + 1)]
+  rag = [[ragged_of(specs, mts[r], batches[s][r]) for r in range(world)] for s in range(steps + 1)]
+  pre = False
+  for s in range(steps):
+    ahead = s % 2 == 0
+    embs = grp.forward(rag[s], rag[s + 1] if ahead else None, prefetched=pre)
+    pre = ahead
+    flat = []
+    for r in range(world):
+      views = mts[r].get_embeddings(rag[s][r], embs[r])
+      for sp in by_name:
+        ids = batches[s][r].get(sp.name)
+        if ids is None:
+          continue
+        exp = ots[sp.name].lookup(ids)[0]
+        got = views[sp.name].cpu().numpy()
+        if exact:
+          np.testing.assert_array_equal(got, exp, err_msg="rank %d %s step %d" % (r, sp.name, s))
+        else:
+          np.testing.assert_allclose(got, exp, rtol=RTOL, atol=ATOL)
+    # the owners apply the senders' blocks in rank order; owners hold disjoint ids, so one oracle
+    # table per feature stands for all of them
+    for r in range(world):
+      fg = []
+      for sp in by_name:
+        ids = batches[s][r].get(sp.name)
+        if ids is None:
+          continue
+        g = grads_of(s, r, sp, ids.size)
+        fg.append(g.ravel())
+        uk, gu = oracle_backward(ots[sp.name], sp, ids, g)
+        ots[sp.name].optimize(uk, gu, sp.lrs(), S.update_time(s))
+      flat.append(val_t(np.concatenate(fg)))
+    grp.backward(flat, S.update_time(s))
+  grp.check()
+  # every owner holds exactly its ids, with the oracle's rows
+  for sp in by_name:
+    seen = np.unique(np.concatenate([b[sp.name] for st in batches[:steps] for b in st if sp.name in b]))
+    for r in range(world):
+      mine = seen[seen % world == r]
+      got = mts[r].lookup({sp.name: torch.as_tensor(mine).cuda()})[sp.name].cpu().numpy()
+      exp = ots[sp.name].lookup(mine)[0]
+      if exact:
+        np.testing.assert_array_equal(got, exp, err_msg="owner %d %s" % (r, sp.name))
+      else:
+        np.testing.assert_allclose(got, exp, rtol=RTOL, atol=ATOL)
+    sizes = [int(mts[r].size(sp.name)) for r in range(world)]
+    assert sum(sizes) == seen.size, (sp.name, sizes, seen.size)
+  grp.close()
+
+
+def test_world1_over_rccl():
+  specs = dlrm_specs(4, initial_capacity=1 << 10)
+  by_name = sorted(specs, key=lambda s: s.name)
+  B, steps = 2000, 4
+  batches = [batch_of(specs, 7 + s, B, 5000) for s in range(steps + 1)]
+  mt_a, mt_b = make(specs), make(specs)
+  ref = ShardedMultiStep(mt_a, B)
+  rc = ShardedMultiStep(mt_b, B, use_rccl=True)
+  assert rc.info()["transport"] == "rccl"
+  rag_a = [ragged_of(specs, mt_a, b) for b in batches]
+  rag_b = [ragged_of(specs, mt_b, b) for b in batches]
+  for s in range(steps):
+    ea = ref.forward(rag_a[s], rag_a[s + 1])
+    eb = rc.forward(rag_b[s], rag_b[s + 1])
+    assert torch.equal(ea, eb), "forward step %d" % s
+    g = val_t(np.concatenate([grads_of(s, 0, sp, B).ravel() for sp in by_name]))
+    ref.backward(g, S.update_time(s))
+    rc.backward(g, S.update_time(s))
+  rc.check()
+  ref.close()
+  rc.close()
+
+
+def test_block_overflow_is_reported():
+  specs = dlrm_specs(2, initial_capacity=1 << 10)
+  B = 512
+  mts = [make(specs) for _ in range(2)]
+  grp = ShardedStepGroup(mts, B, ids_per_peer_table=16)
+  b = [batch_of(specs, 3 + r, B, 100000, "uniform") for r in range(2)]
+  rag = [ragged_of(specs, mts[r], b[r]) for r in range(2)]
+  embs = grp.forward(rag)
+  with pytest.raises(_lib.MhteError) as ei:
+    grp.check()
+  assert ei.value.code == _lib.MHTE_RESOURCE_EXHAUSTED
+  assert all(float(e.abs().max()) == 0.0 for e in embs)   # (empty tables: zeros either way)
+  grp.close()
+
+
+def test_argument_errors():
+  specs = dlrm_specs(2, initial_capacity=1 << 10)
+  mt = make(specs)
+  with pytest.raises(_lib.MhteError):
+    ShardedStepGroup([mt], 0)
+  grp = ShardedStepGroup([mt, make(specs)], 64)
+  one = ShardedMultiStep.__new__(ShardedMultiStep)
+  # a rank of a world > 1 without a communicator cannot step on its own
+  one._libmod, one._lib, one.table, one._dims = _lib, mt._lib, mt, mt.get_table_dim_sizes()  # pylint: disable=protected-access
+  one._h, one._ahead, one._keep = grp._hs[0], None, None  # pylint: disable=protected-access
+  b = batch_of(specs, 1, 64, 1000)
+  with pytest.raises(_lib.MhteError) as ei:
+    one.forward(ragged_of(specs, mt, b))
+  assert ei.value.code == _lib.MHTE_FAILED_PRECONDITION
+  one._h = None  # pylint: disable=protected-access
+  grp.close()
