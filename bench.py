@@ -93,6 +93,19 @@ def algorithmic_bytes(B, U, D, S):
   return lookup + update, per_kernel
 
 
+def sharded_algorithmic_bytes(B, U, D, S):
+  """Per launch of the id-sharded step (csrc/mhte_shard_kernels.h), world 1, one table: the rows of
+  the U distinct ids cross a peer block in each direction on top of SURVEY 8d's per-step bytes."""
+  P = PROBE_BYTES
+  return {
+      "shard_lookup_kernel": 8 * U + P * U + 4 * D * U + 4 * D * U,      # ids, probes, rows -> block
+      "shard_scatter_kernel": 4 * U + 4 * D * U + 4 * D * B,             # slots, block -> occurrences
+      "shard_build_kernel": 4 * D * B + 4 * U + 4 * D * U + 8 * U,       # gradient sums -> block; ids -> block
+      "shard_upsert_kernel": 8 * U + 4 * D * U + P * U + (8 * D + 8 * S) * U + 4 * U,
+      "dd_kernels": 8 * B,
+  }
+
+
 def pmc_traffic(kernel):
   """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json,
   written by scripts/pmc_traffic.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
@@ -219,7 +232,13 @@ def main_dlrm(args):
   out = torch.empty(gsz, dtype=torch.float32, device=dev)
   if args.dense:
     os.environ.setdefault("MHTE_MSTEP_SIDE", "1")   # dedup of the next batch beside the GEMMs
-  step = MultiSparseStep(mt, B, exact_order=args.exact_order)
+  sharded = bool(args.force_sharded)
+  if sharded:
+    # every table through the id-sharded step with one rank: the floor of the multi-GPU step
+    from monolith_amd.distributed_ps_sync import ShardedMultiStep
+    step = ShardedMultiStep(mt, B, ids_per_peer_table=args.ids_per_peer)
+  else:
+    step = MultiSparseStep(mt, B, exact_order=args.exact_order)
   applied = []
   evictions = [0]
 
@@ -280,17 +299,21 @@ def main_dlrm(args):
           mt.evict(n)
         evictions[0] += 1
 
+  import gc
   run(0, W)
   torch.cuda.synchronize()
   evictions[0] = 0
+  gc.collect()
+  gc.disable()   # (a generation-2 pass of the interpreter inside the timed region is ~40 ms)
   t = time.perf_counter()
   run(W, W + K)
   torch.cuda.synchronize()
   elapsed = time.perf_counter() - t
+  gc.enable()
 
   # ---- per-kernel timing: HIP events with the kernels' own begin/end (mhte_profile_arm) ----
   acc, uniq = {}, []
-  _lib.profile_arm(2 * reps)
+  _lib.profile_arm(8 * reps)
   for s in range(W + K, W + K + reps):
     step.forward(rag[s], rag[s + 1], out=out)
     if s % 10 == 0:
@@ -312,6 +335,12 @@ def main_dlrm(args):
     alg_fwd += pk["lookup_kernel"]
     alg_bwd += pk["sum_apply_kernel"]
   alg = {"mstep_fwd_kernel": alg_fwd, "mstep_bwd_kernel": alg_bwd}
+  if sharded:
+    alg = {}
+    for i in range(T):
+      for k, v in sharded_algorithmic_bytes(B, float(U[i]), dims[i], dims[i]).items():
+        alg[k] = alg.get(k, 0) + v
+    alg.pop("dd_kernels")
   stages = {}
   for name, (cnt, tot) in sorted(acc.items()):
     stages[name] = {"avg_us": round(tot / cnt, 2), "launches_per_step": round(cnt / reps, 2)}
@@ -430,8 +459,10 @@ def main_dlrm(args):
                       "Zipf(1.2) over %d ids per feature, batch %d ids per feature and step, online "
                       "insert, TTL eviction scan every %d steps; %s" %
                       (T, V, B, args.evict_every,
-                       "end to end with the dense model (layout + bf16 MLP)" if dense is not None else
-                       "sparse path only (no dense model)"),
+                       ("end to end with the dense model (layout + bf16 MLP)" if dense is not None else
+                        "sparse path only (no dense model)") +
+                       ("; through the id-sharded step with one rank (%s)" % step.info()["transport"]
+                        if sharded else "")),
           "tables": T, "dims": dims, "batch_per_table": B, "universe_per_table": V,
           "resident_rows_start": int(sum(size0)), "resident_rows_end": int(sum(size1)),
           "unique_ids_per_batch_mean": float(U.mean()), "eviction_scans_in_timed_region": evictions[0],
@@ -464,7 +495,7 @@ def main():
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
   sharded = world > 1 or args.force_sharded
-  if sharded:
+  if world > 1:   # (one rank needs no rendezvous: the sharded step's exchange is the identity)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
@@ -550,7 +581,7 @@ def main():
 
   results = {}
   steps_of = {}
-  stages, shard_info = {}, None
+  stages, shard_info, shard_roofline, uniq_avg = {}, None, None, None
   graph_err = None
   if not sharded:
     # Steady-state pipeline (fused_step.py): while batch s is looked up and updated, the dedup of
@@ -568,12 +599,16 @@ def main():
         applied.append((s, s % NG, S.update_time(s)))
 
     def timed(name, c, w, k):
+      import gc
       run_eager(c, c + w)
+      gc.collect()
+      gc.disable()   # (a generation-2 pass of the interpreter inside the timed region is ~40 ms)
       barrier()
       t = time.perf_counter()
       run_eager(c + w, c + w + k)
       barrier()
       results[name] = time.perf_counter() - t
+      gc.enable()
       steps_of[name] = k
       return c + w + k
 
@@ -654,6 +689,7 @@ def main():
     run_sharded(W, W + K)
     barrier()
     results["eager"] = time.perf_counter() - t
+    elapsed_local = results["eager"]
     if gc_was:
       gc.enable()
     steps_of["eager"] = K
@@ -675,10 +711,27 @@ def main():
           a[0] += 1
           a[1] += us
       if nprof > 0:
-        stages = {"per_step": {k: {"launches": round(v[0] / nprof, 2), "us": round(v[1] / nprof, 2)}
-                               for k, v in acc.items()},
-                  "note": "kernel-exact HIP-event time of the tagged launches of the sharded step "
+        uniq_avg = float(np.mean([np.unique(ids_host[s]).size for s in range(W + K, W + K + nprof)]))
+        salg = sharded_algorithmic_bytes(B, uniq_avg, D, S_state)
+        stages = {"note": "kernel-exact HIP-event time of the tagged launches of the sharded step "
                           "(+ 1 untagged displacement launch per peer)"}
+        for k, v in acc.items():
+          us = v[1] / v[0]
+          stages[k] = {"launches_per_step": round(v[0] / nprof, 2), "avg_us": round(us, 2)}
+          if k in salg:
+            stages[k]["alg_bytes"] = int(salg[k])
+            stages[k]["GBps"] = round(salg[k] / us / 1e3, 1)
+        dom = max((k for k in acc if k in salg and k != "dd_kernels"), key=lambda k: stages[k]["avg_us"])
+        a_gbps = salg[dom] / stages[dom]["avg_us"] / 1e3
+        step_bytes, _ = algorithmic_bytes(B, uniq_avg, D, S_state)
+        shard_roofline = {
+            "bound": "hbm", "kernel": dom, "achieved": round(a_gbps, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(a_gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+            "alg_bytes_per_launch": int(salg[dom]), "avg_launch_us": stages[dom]["avg_us"],
+            "timing": "hipExtLaunchKernelGGL start/stop events on the launch stream, %d launches" % nprof,
+            "step_alg_bytes": int(step_bytes),
+            "step_GBps": round(step_bytes / (elapsed_local / K) / 1e9, 1),
+            "step_frac": round(step_bytes / (elapsed_local / K) / 1e9 / HBM_PEAK_GBPS, 4)}
   full = {k: v for k, v in results.items() if steps_of[k] == K}   # modes timed over exactly K steps
   launch = min(full, key=full.get) if args.launch == "auto" else (
       args.launch if args.launch in full else "eager")
@@ -693,7 +746,7 @@ def main():
   # stream (mhte_profile_arm -> hipExtLaunchKernelGGL), the interval rocprofv3 --kernel-trace
   # reports.  Pass 1: the pipelined step as timed above (2 launches per step).  Pass 2: the
   # same work as separate launches, which attributes time to lookup / backward / dedup.
-  roofline, uniq_avg = None, None
+  roofline = shard_roofline
   if not sharded and not args.no_stage_timing:
     step.quiesce()
     acc = {}
@@ -870,6 +923,8 @@ def main():
       out["graph_error"] = graph_err
     print(json.dumps(out))
   if sharded:
+    se.close()
+  if world > 1:
     dist.destroy_process_group()
 
 

@@ -600,6 +600,8 @@ mhte_status mhte_shard_step_backward(mhte_shard_step* s, const float* value, int
                                      int64_t update_time, int64_t global_step, void* stream);
 /* waits for the stream, then reports a block overflow of the steps enqueued so far */
 mhte_status mhte_shard_step_check(mhte_shard_step* s, void* stream);
+/* distinct ids per table of this rank's forward batch (host int64[T]); synchronises */
+mhte_status mhte_shard_step_unique_counts(mhte_shard_step* s, int64_t* counts, void* stream);
 /* info[0] = id slots per (peer, table), [1] = bytes of one id block, [2] = bytes of one row block,
  * [3] = transport: 0 identity, 1 RCCL, 2 in-process group */
 mhte_status mhte_shard_step_info(mhte_shard_step* s, int64_t info[4]);

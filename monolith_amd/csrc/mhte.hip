@@ -3140,6 +3140,23 @@ mhte_status mhte_shard_step_check(mhte_shard_step* s, void* stream) {
   });
 }
 
+mhte_status mhte_shard_step_unique_counts(mhte_shard_step* s, int64_t* counts, void* stream) {
+  return guard([&] {
+    if (!s || !counts) throw Error(MHTE_INVALID_ARGUMENT, "null argument");
+    MultiStep& ms = s->ss.ms;
+    HIP_OK(hipSetDevice(ms.device));
+    if (ms.stage[ms.cur] != 2)
+      throw Error(MHTE_FAILED_PRECONDITION, "shard step: the current batch has not been numbered");
+    std::vector<uint32_t> h(ms.T, 0);
+    for (uint32_t t = 0; t < ms.T; ++t)
+      if (ms.n_slot[ms.cur][t])
+        HIP_OK(hipMemcpyAsync(&h[t], ms.h_st[t].rv[ms.cur].n_unique, sizeof(uint32_t),
+                              hipMemcpyDeviceToHost, mhte::S(stream)));
+    HIP_OK(hipStreamSynchronize(mhte::S(stream)));
+    for (uint32_t t = 0; t < ms.T; ++t) counts[t] = h[t];
+  });
+}
+
 mhte_status mhte_shard_step_info(mhte_shard_step* s, int64_t info[4]) {
   return guard([&] {
     if (!s || !info) throw Error(MHTE_INVALID_ARGUMENT, "null argument");

@@ -474,6 +474,13 @@ class ShardedMultiStep:
         lrs.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(lrs.size), C.c_int64(int(update_time)),
         C.c_int64(int(global_step)), self._stream()))
 
+  def unique_counts(self) -> np.ndarray:
+    """Distinct ids per table of the batch last given to ``forward`` (synchronises)."""
+    out = np.zeros(len(self._dims), dtype=np.int64)
+    self._libmod.check(self._lib.mhte_shard_step_unique_counts(
+        self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), self._stream()))
+    return out
+
   def check(self):
     """Wait for the stream; raises ResourceExhausted if a peer block overflowed."""
     self._libmod.check(self._lib.mhte_shard_step_check(self._h, self._stream()))
