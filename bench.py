@@ -856,24 +856,40 @@ def main():
       cores = os.cpu_count() or 1
       opt = O.OPT_ADAGRAD if args.opt == "adagrad" else O.OPT_SGD
       avx = O.ref_available(True)
-      ps = O.RefPs(cores, D, opt, 0.1, 0.0, 0.0, 1, avx=avx)
       lr = 0.001 if args.opt == "adagrad" else 0.01
-      cw, ck = 10, args.cpu_steps
+      cw = 10
       grads_h = [S.grad_batch(s, B, D) for s in range(4)]
-      times = []
-      for s in range(cw + ck):
-        ids = S.id_batch(s, B, V, "zipf")
-        t = time.perf_counter()
-        ps.step(ids, grads_h[s % 4], lr, S.update_time(s), want_emb=True)
-        times.append(time.perf_counter() - t)
-      med = float(np.median(times[cw:]))
-      cpu = {"value": round(2 * B / med, 1), "unit": "lookups+updates/s", "cores": cores,
+
+      def cpu_variant(shared, ck):
+        ps = O.RefPs(cores, D, opt, 0.1, 0.0, 0.0, 1, avx=avx, shared=shared)
+        times, phases = [], []
+        for s in range(cw + ck):
+          ids = S.id_batch(s, B, V, "zipf")
+          t = time.perf_counter()
+          ps.step(ids, grads_h[s % 4], lr, S.update_time(s), want_emb=True)
+          times.append(time.perf_counter() - t)
+          phases.append(ps.breakdown())
+        med = float(np.median(times[cw:]))
+        return {"value": round(2 * B / med, 1), "median_step_ms": round(med * 1e3, 3), "steps": ck,
+                "rows_at_end": ps.size(),
+                "phase_ms_median": {k: round(float(np.median([p_[k] for p_ in phases[cw:]])) * 1e3, 3)
+                                    for k in O.RefPs.PHASES}}
+
+      v1 = cpu_variant(False, args.cpu_steps)
+      v2 = cpu_variant(True, max(20, args.cpu_steps // 2))
+      cpu = {"value": v1["value"], "unit": "lookups+updates/s", "cores": cores,
              "kind": "reference",
              "sample": "%d steps (after %d warm-up) of the same Zipf(1.2) stream, batch %d, dim %d, "
-                       "%s; table grown on demand from empty (%d rows at end); PS-style %d "
-                       "single-threaded shards of the reference cuckoohash_map + %s Adagrad, "
-                       "median step %.2f ms" % (ck, cw, B, D, args.opt, ps.size(), cores,
-                                                "AVX2" if avx else "scalar", med * 1e3)}
+                       "%s; table grown on demand from empty (%d rows at end); variant (i) PS-style: "
+                       "%d single-threaded shards of the reference cuckoohash_map + %s Adagrad, "
+                       "median step %.2f ms" % (args.cpu_steps, cw, B, D, args.opt, v1["rows_at_end"],
+                                                cores, "AVX2" if avx else "scalar",
+                                                v1["median_step_ms"]),
+             "variants": {"i_ps_shards": v1, "ii_shared_table": v2},
+             "note": "phases: single-threaded worker-side dedup (std::unordered_map) and shard "
+                     "partition, then %d threads: lookup, scatter to occurrences, duplicate-gradient "
+                     "sum, optimize.  (ii) = ONE reference map shared by the threads, contiguous "
+                     "chunks of the distinct ids (the fused ops' Shard() loop)" % cores}
     except Exception as e:  # pylint: disable=broad-except
       cpu = {"value": None, "unit": "lookups+updates/s", "cores": os.cpu_count(), "kind": "reference",
              "sample": "failed: %r" % (e,)}

@@ -280,6 +280,11 @@ def ref_lib(avx=False):
     L.ref_table_new.restype = C.c_void_p
     L.ref_table_new.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64]
     L.ref_ps_new.restype = C.c_void_p
+    L.ref_ps_new_shared.restype = C.c_void_p
+    L.ref_ps_new_shared.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                    C.c_uint64]
+    L.ref_ps_breakdown.restype = None
+    L.ref_ps_breakdown.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.ref_ps_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                              C.c_uint64]
     for name in ("ref_size", "ref_hashpower", "ref_lookup", "ref_dump", "ref_ps_size",
@@ -377,12 +382,22 @@ def ref_adagrad(num, norm, grad, lr, wd, avx=False):
 class RefPs:
   """CPU baseline: P single-threaded reference-map shards + worker-side dedup."""
 
+  PHASES = ("dedup", "partition", "lookup", "scatter", "grad_sum", "optimize")
+
   def __init__(self, P, dim, opt, init_acc=0.1, wd=0.0, init_value=0.0, initial_capacity=1,
-               avx=True):
+               avx=True, shared=False):
+    """shared=False: variant (i), P single-threaded shards (fid mod P); shared=True: variant (ii),
+    one table, P threads over contiguous chunks of the distinct ids."""
     self.L = ref_lib(avx)
     self.P, self.dim = P, dim
-    self.h = C.c_void_p(self.L.ref_ps_new(P, dim, opt, init_acc, wd, init_value,
-                                          initial_capacity))
+    new = self.L.ref_ps_new_shared if shared else self.L.ref_ps_new
+    self.h = C.c_void_p(new(P, dim, opt, init_acc, wd, init_value, initial_capacity))
+
+  def breakdown(self):
+    """Seconds the last step spent in each phase (PHASES)."""
+    out = (C.c_double * 6)()
+    self.L.ref_ps_breakdown(self.h, out)
+    return dict(zip(self.PHASES, [float(x) for x in out]))
 
   def __del__(self):
     try:

@@ -266,11 +266,15 @@ int ref_built_with_avx(void) {
 }  // extern "C"
 
 // --------------------------------------------------------------------------------------------
-// CPU-baseline step runner ("PS-style", BASELINE.md §2 variant (i)): P single-threaded table
-// shards (shard = fid mod P, distributed_ps.py:289,497), worker-side dedup in first-occurrence
-// order (unique_mapping_ops.cc:82-114), per-shard BatchLookup, scatter to duplicates
-// (:225-242), duplicate-gradient sum in occurrence order (:307-324), per-shard BatchOptimize.
-// No TF / grpc cost is included, which favours the reference.
+// CPU-baseline step runner, both variants of SURVEY.md 8d:
+//   (i)  "PS-style": P single-threaded table shards (shard = fid mod P, distributed_ps.py:289,497)
+//   (ii) "shared table": ONE table, P threads over contiguous chunks of the distinct ids — the
+//        Shard() loop of the fused ops (multi_hash_table_lookup_op.cc:191-196); the reference map
+//        is concurrent (per-bucket spinlocks), the ids of a step are distinct
+// around the same worker-side dedup in first-occurrence order (unique_mapping_ops.cc:82-114),
+// BatchLookup, scatter to duplicates (:225-242), duplicate-gradient sum in occurrence order
+// (:307-324), BatchOptimize.  No TF / grpc cost is included, which favours the reference.
+// ref_ps_breakdown reports the seconds the last step spent in each phase.
 // --------------------------------------------------------------------------------------------
 namespace {
 
@@ -331,6 +335,8 @@ class Pool {
 
 struct RefPs {
   int P, dim;
+  bool shared = false;     // variant (ii): ONE table, P threads over contiguous id chunks
+  double phase_s[6] = {0, 0, 0, 0, 0, 0};  // last step: dedup, partition, lookup, scatter, grad sum, optimize
   std::vector<std::unique_ptr<RefTable>> shards;
   std::unique_ptr<Pool> pool;
   // per-step scratch
@@ -358,6 +364,24 @@ void* ref_ps_new(int P, int dim, int opt, float init_acc, float wd, float init_v
   ps->shard_u.resize(P);
   return ps;
 }
+// variant (ii)
+void* ref_ps_new_shared(int P, int dim, int opt, float init_acc, float wd, float init_value,
+                        uint64_t initial_capacity) {
+  RefPs* ps = new RefPs;
+  ps->P = P;
+  ps->dim = dim;
+  ps->shared = true;
+  ps->shards.emplace_back(new RefTable(dim, opt, init_acc, wd, init_value, initial_capacity));
+  // (Row() reads the block list while other threads append to it: never let it reallocate)
+  ps->shards[0]->blocks.reserve(size_t(1) << 20);
+  ps->pool.reset(new Pool(P));
+  ps->shard_u.resize(P);
+  return ps;
+}
+void ref_ps_breakdown(void* h, double* out6) {
+  RefPs* ps = static_cast<RefPs*>(h);
+  for (int i = 0; i < 6; ++i) out6[i] = ps->phase_s[i];
+}
 void ref_ps_free(void* h) { delete static_cast<RefPs*>(h); }
 int64_t ref_ps_size(void* h) {
   RefPs* ps = static_cast<RefPs*>(h);
@@ -372,6 +396,13 @@ int64_t ref_ps_step(void* h, const int64_t* ids, int64_t n, const float* grads, 
                     int64_t update_time, float* emb_out) {
   RefPs* ps = static_cast<RefPs*>(h);
   const int P = ps->P, D = ps->dim;
+  using Clock = std::chrono::steady_clock;
+  auto t_prev = Clock::now();
+  auto lap = [&](int i) {
+    auto now = Clock::now();
+    ps->phase_s[i] = std::chrono::duration<double>(now - t_prev).count();
+    t_prev = now;
+  };
   // worker-side dedup, first-occurrence order
   ps->uniq.clear();
   ps->inverse.resize(n);
@@ -391,16 +422,23 @@ int64_t ref_ps_step(void* h, const int64_t* ids, int64_t n, const float* grads, 
     }
   }
   const int64_t U = ps->uniq.size();
+  lap(0);
   for (auto& v : ps->shard_u) v.clear();
-  for (int64_t u = 0; u < U; ++u) {
-    int64_t id = ps->uniq[u];
-    int s = static_cast<int>(((id % P) + P) % P);  // floormod, distributed_ps.py:289
-    ps->shard_u[s].push_back(static_cast<int32_t>(u));
+  if (ps->shared) {
+    for (int s = 0; s < P; ++s)
+      for (int64_t u = U * s / P; u < U * (s + 1) / P; ++u) ps->shard_u[s].push_back(static_cast<int32_t>(u));
+  } else {
+    for (int64_t u = 0; u < U; ++u) {
+      int64_t id = ps->uniq[u];
+      int s = static_cast<int>(((id % P) + P) % P);  // floormod, distributed_ps.py:289
+      ps->shard_u[s].push_back(static_cast<int32_t>(u));
+    }
   }
   ps->emb_u.resize(U * D);
+  lap(1);
   // per-shard BatchLookup
   ps->pool->Run([&](int s) {
-    RefTable* t = ps->shards[s].get();
+    RefTable* t = ps->shards[ps->shared ? 0 : s].get();
     for (int32_t u : ps->shard_u[s]) {
       float* dst = ps->emb_u.data() + int64_t(u) * D;
       bool hit = t->m.find_fn(ps->uniq[u], [&](const Entry& e) {
@@ -409,6 +447,7 @@ int64_t ref_ps_step(void* h, const int64_t* ids, int64_t n, const float* grads, 
       if (!hit) std::memset(dst, 0, sizeof(float) * D);
     }
   });
+  lap(2);
   // fill_with_offset_map: scatter unique rows to every occurrence (parallel over occurrence
   // ranges; the reference op is single-threaded, so this favours the reference)
   if (emb_out) {
@@ -420,6 +459,7 @@ int64_t ref_ps_step(void* h, const int64_t* ids, int64_t n, const float* grads, 
       }
     });
   }
+  lap(3);
   // fill_with_offset_map_gradient: sum duplicates in occurrence order.  Occurrence lists
   // (CSR) are built once; threads own disjoint unique ranges, each list summed in order.
   ps->grad_u.assign(U * D, 0.f);
@@ -441,9 +481,10 @@ int64_t ref_ps_step(void* h, const int64_t* ids, int64_t n, const float* grads, 
       }
     }
   });
+  lap(4);
   // per-shard BatchOptimize
   ps->pool->Run([&](int s) {
-    RefTable* t = ps->shards[s].get();
+    RefTable* t = ps->shards[ps->shared ? 0 : s].get();
     for (int32_t u : ps->shard_u[s]) {
       const float* g = ps->grad_u.data() + int64_t(u) * D;
       t->UpsertEntry(ps->uniq[u], [&](Entry& e) {
@@ -452,6 +493,7 @@ int64_t ref_ps_step(void* h, const int64_t* ids, int64_t n, const float* grads, 
       });
     }
   });
+  lap(5);
   return U;
 }
 
@@ -459,7 +501,7 @@ int64_t ref_ps_lookup(void* h, const int64_t* ids, int64_t n, float* out) {
   RefPs* ps = static_cast<RefPs*>(h);
   int64_t found = 0;
   for (int64_t i = 0; i < n; ++i) {
-    int s = static_cast<int>(((ids[i] % ps->P) + ps->P) % ps->P);
+    int s = ps->shared ? 0 : static_cast<int>(((ids[i] % ps->P) + ps->P) % ps->P);
     found += ref_lookup(ps->shards[s].get(), ids + i, 1, out + i * ps->dim);
   }
   return found;

@@ -1,7 +1,8 @@
 #!/bin/bash
 # One GPU-box visit: parity tests, bench line, rocprofv3 kernel trace of a short bench.
 # Usage (from the repo root on the GPU box): bash scripts/gpu_round.sh <tag> [what...]
-#   what: tests smoke bench prof tl trace pmc calib next (default: tests bench prof)
+#   what: tests smoke bench prof tl trace pmc calib next cfg1 dlrm dlrmdense dlrmprof shard shardprof
+#   (default: tests bench prof)
 set -u
 TAG=${1:-r01}; shift || true
 WHAT=${*:-tests bench prof}
@@ -19,7 +20,7 @@ bench)
   timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
   cat $OUT/bench.json; tail -5 $OUT/bench.err ;;
 prof)
-  rm -rf /tmp/prof && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof -o trace -- \
+  rm -rf /tmp/prof && timeout -k 5 600 rocprofv3 --kernel-trace --stats -d /tmp/prof -o trace -- \
     python bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err
   echo "prof rc=$?"; find /tmp/prof -type f | head -20
   for f in $(find /tmp/prof -name '*kernel_stats*.csv'); do cp $f $OUT/; done
@@ -54,6 +55,33 @@ calib)
     echo "calib $c rc=$?"
     for f in $(find /tmp/cal_$c -name '*counter_collection*.csv'); do python scripts/pmc_csv.py $f > $OUT/calib_${c}.md; head -8 $OUT/calib_${c}.md; done
   done ;;
+cfg1)
+  # BASELINE.json configs[1]: 100 M ids, dim 32, SGD, one table on one GPU
+  timeout 600 python bench.py --universe 100000000 --dim 32 --opt sgd > $OUT/bench_configs1.json 2> $OUT/bench_configs1.err
+  echo "cfg1 rc=$?"; cut -c1-600 $OUT/bench_configs1.json ;;
+dlrm)
+  timeout 900 python bench.py --config dlrm26 > $OUT/bench_dlrm26.json 2> $OUT/bench_dlrm26.err
+  echo "dlrm rc=$?"; cut -c1-1500 $OUT/bench_dlrm26.json ;;
+dlrmdense)
+  timeout 900 python bench.py --config dlrm26 --dense --no-cpu-baseline > $OUT/bench_dlrm26_dense.json 2> $OUT/bench_dlrm26_dense.err
+  echo "dlrmdense rc=$?"; cut -c1-600 $OUT/bench_dlrm26_dense.json; python -c "import json,sys; print(json.load(open('$OUT/bench_dlrm26_dense.json'))['dense'])" ;;
+dlrmprof)
+  rm -rf /tmp/dprof && timeout -k 5 600 rocprofv3 --kernel-trace --stats -d /tmp/dprof -o trace -- \
+    python bench.py --config dlrm26 --steps 50 --warmup 10 --no-cpu-baseline --no-parity-check > $OUT/prof_dlrm26_bench.json 2> $OUT/prof_dlrm26.err
+  echo "dlrmprof rc=$?"
+  db=$(find /tmp/dprof -name '*.db' | head -1)
+  if [ -n "$db" ]; then python scripts/rocpd_stats.py $db $OUT/kernel_stats_dlrm26.md | head -14; fi ;;
+shard)
+  timeout -k 5 600 python bench.py --force-sharded --no-cpu-baseline > $OUT/bench_sharded_n1.json 2> $OUT/bench_sharded_n1.err
+  echo "shard rc=$?"; cut -c1-400 $OUT/bench_sharded_n1.json
+  timeout -k 5 600 python bench.py --config dlrm26 --force-sharded --no-cpu-baseline > $OUT/bench_sharded_n1_dlrm26.json 2> $OUT/bench_sharded_n1_dlrm26.err
+  echo "shard dlrm rc=$?"; cut -c1-400 $OUT/bench_sharded_n1_dlrm26.json ;;
+shardprof)
+  rm -rf /tmp/sprof && timeout -k 5 300 rocprofv3 --kernel-trace --stats -d /tmp/sprof -o trace -- \
+    python bench.py --force-sharded --steps 100 --warmup 10 --no-cpu-baseline --no-parity-check > $OUT/prof_sharded_n1_bench.json 2> $OUT/prof_sharded_n1.err
+  echo "shardprof rc=$?"
+  db=$(find /tmp/sprof -name '*.db' | head -1)
+  if [ -n "$db" ]; then python scripts/rocpd_stats.py $db $OUT/kernel_stats_sharded_n1.md | head -14; fi ;;
 next)
   # the rows next to the hot path: checkpoint, eviction, filter, gather, reductions, optimizers
   NEXT_ROWS_MD=$OUT/next_rows.md timeout 900 python scripts/next_rows_bench.py > $OUT/next_rows.jsonl 2> $OUT/next_rows.err
