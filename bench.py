@@ -60,6 +60,8 @@ def parse():
   p.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"])
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--cpu-steps", type=int, default=150)
+  p.add_argument("--cpu-child", default="", help=argparse.SUPPRESS)   # "i" | "ii": one CPU-baseline
+                                                                      # variant in a process of its own
   p.add_argument("--exact-order", action="store_true")
   p.add_argument("--ids-per-peer", type=int, default=0,
                  help="sharded step: id slots per (peer, table) block (0: library default)")
@@ -477,8 +479,36 @@ def main_dlrm(args):
   print(json.dumps(out_json))
 
 
+def cpu_child(args):
+  """One CPU-baseline variant on this box's host cores; prints one JSON line."""
+  import oracle as O
+  from monolith_amd import synthetic as S
+  B, D, V = args.batch, args.dim, int(args.universe)
+  cores = os.cpu_count() or 1
+  opt = O.OPT_ADAGRAD if args.opt == "adagrad" else O.OPT_SGD
+  avx = O.ref_available(True)
+  lr = 0.001 if args.opt == "adagrad" else 0.01
+  cw, ck = 10, args.cpu_steps
+  grads_h = [S.grad_batch(s, B, D) for s in range(4)]
+  ps = O.RefPs(cores, D, opt, 0.1, 0.0, 0.0, 1, avx=avx, shared=args.cpu_child == "ii")
+  times, phases = [], []
+  for s in range(cw + ck):
+    ids = S.id_batch(s, B, V, "zipf")
+    t = time.perf_counter()
+    ps.step(ids, grads_h[s % 4], lr, S.update_time(s), want_emb=True)
+    times.append(time.perf_counter() - t)
+    phases.append(ps.breakdown())
+  med = float(np.median(times[cw:]))
+  print(json.dumps({"value": round(2 * B / med, 1), "median_step_ms": round(med * 1e3, 3), "steps": ck,
+                    "rows_at_end": ps.size(), "cores": cores, "avx": bool(avx),
+                    "phase_ms_median": {k: round(float(np.median([p_[k] for p_ in phases[cw:]])) * 1e3, 3)
+                                        for k in O.RefPs.PHASES}}))
+
+
 def main():
   args = parse()
+  if args.cpu_child:
+    return cpu_child(args)
   if args.config == "dlrm26":
     return main_dlrm(args)
   import torch
@@ -861,30 +891,27 @@ def main():
       grads_h = [S.grad_batch(s, B, D) for s in range(4)]
 
       def cpu_variant(shared, ck):
-        ps = O.RefPs(cores, D, opt, 0.1, 0.0, 0.0, 1, avx=avx, shared=shared)
-        times, phases = [], []
-        for s in range(cw + ck):
-          ids = S.id_batch(s, B, V, "zipf")
-          t = time.perf_counter()
-          ps.step(ids, grads_h[s % 4], lr, S.update_time(s), want_emb=True)
-          times.append(time.perf_counter() - t)
-          phases.append(ps.breakdown())
-        med = float(np.median(times[cw:]))
-        return {"value": round(2 * B / med, 1), "median_step_ms": round(med * 1e3, 3), "steps": ck,
-                "rows_at_end": ps.size(),
-                "phase_ms_median": {k: round(float(np.median([p_[k] for p_ in phases[cw:]])) * 1e3, 3)
-                                    for k in O.RefPs.PHASES}}
+        # in a process of its own: the reference map with 256 threads on ONE table (variant ii) has
+        # been seen to crash on this box; a baseline must not take the GPU measurement with it
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", "ii" if shared else "i",
+               "--cpu-steps", str(ck), "--batch", str(B), "--dim", str(D), "--opt", args.opt,
+               "--universe", str(args.universe)]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        if r.returncode != 0:
+          return {"value": None, "failed": "rc %d: %s" % (r.returncode, r.stderr.decode()[-200:])}
+        return json.loads(r.stdout.decode().strip().splitlines()[-1])
 
       v1 = cpu_variant(False, args.cpu_steps)
       v2 = cpu_variant(True, max(20, args.cpu_steps // 2))
       cpu = {"value": v1["value"], "unit": "lookups+updates/s", "cores": cores,
              "kind": "reference",
              "sample": "%d steps (after %d warm-up) of the same Zipf(1.2) stream, batch %d, dim %d, "
-                       "%s; table grown on demand from empty (%d rows at end); variant (i) PS-style: "
+                       "%s; table grown on demand from empty (%s rows at end); variant (i) PS-style: "
                        "%d single-threaded shards of the reference cuckoohash_map + %s Adagrad, "
-                       "median step %.2f ms" % (args.cpu_steps, cw, B, D, args.opt, v1["rows_at_end"],
-                                                cores, "AVX2" if avx else "scalar",
-                                                v1["median_step_ms"]),
+                       "median step %s ms" % (args.cpu_steps, cw, B, D, args.opt, v1.get("rows_at_end"),
+                                              cores, "AVX2" if avx else "scalar",
+                                              v1.get("median_step_ms")),
              "variants": {"i_ps_shards": v1, "ii_shared_table": v2},
              "note": "phases: single-threaded worker-side dedup (std::unordered_map) and shard "
                      "partition, then %d threads: lookup, scatter to occurrences, duplicate-gradient "

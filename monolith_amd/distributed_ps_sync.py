@@ -327,7 +327,9 @@ class ShardedEmbedding:
 
   @staticmethod
   def _same_batch(a, b):
-    return a[0] is b[0] and a[1] == b[1] and a[2] == b[2] and a[3] == b[3]
+    # same memory, unmodified since (the key keeps the tensor alive); not the Python object: a
+    # slice of a resident id array is a new view object every time
+    return a[1] == b[1] and a[2] == b[2] and a[3] == b[3]
 
   def _prefetch(self, ids: torch.Tensor, slot: int):
     key = self._batch_key(ids)
@@ -450,8 +452,9 @@ class ShardedMultiStep:
     if out is None:
       out = torch.empty(total, dtype=torch.float32, device=ragged.values.device)
     a = self._ahead
-    pre = (a is not None and a[0] is ragged.values and a[1] == ragged.values._version and  # pylint: disable=protected-access
-           a[2] == ragged.row_splits.tobytes())
+    v = ragged.values
+    pre = (a is not None and a[0].data_ptr() == v.data_ptr() and a[0].numel() == v.numel() and
+           a[1] == v._version and a[2] == ragged.row_splits.tobytes())  # pylint: disable=protected-access
     sp = np.ascontiguousarray(ragged.row_splits, dtype=np.int64)
     if next_ragged is not None:
       nsp = np.ascontiguousarray(next_ragged.row_splits, dtype=np.int64)

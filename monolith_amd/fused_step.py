@@ -167,14 +167,17 @@ class SparseStep:
 
   @staticmethod
   def _batch_key(ids):
-    """Identity of a batch handed over as ``next_ids``: the tensor object and its version counter,
-    so a buffer refilled in place (or a freed tensor's address reused by the allocator) is not taken
-    for the batch that was deduplicated ahead."""
+    """Identity of a batch handed over as ``next_ids``: its memory (address, length) and version
+    counter.  The key keeps the tensor referenced, so the address cannot be handed to another
+    allocation meanwhile, and a buffer refilled in place bumps the version (views share their
+    base's counter) — either way the batch deduplicated ahead is not taken for a different one
+    (ADVICE r1).  Not the Python object: ``ids_all[s]`` makes a new view object on every call."""
     return (ids, ids._version, ids.data_ptr(), ids.numel())  # pylint: disable=protected-access
 
   @staticmethod
   def _same_batch(a, b):
-    return (a is not None and a[0] is b[0] and a[1] == b[1] and a[2] == b[2] and a[3] == b[3])
+    return (a is not None and a[1] == b[1] and a[2] == b[2] and a[3] == b[3] and
+            a[0].device == b[0].device)
 
   def _join(self):
     if not self._joined:
@@ -272,8 +275,9 @@ class MultiSparseStep:
     if out is None:
       out = torch.empty(total, dtype=torch.float32, device=ragged.values.device)
     a = self._ahead
-    pre = (a is not None and a[0] is ragged.values and a[1] == ragged.values._version and  # pylint: disable=protected-access
-           a[2] == ragged.row_splits.tobytes())
+    v = ragged.values
+    pre = (a is not None and a[0].data_ptr() == v.data_ptr() and a[0].numel() == v.numel() and
+           a[1] == v._version and a[2] == ragged.row_splits.tobytes())  # pylint: disable=protected-access
     sp = np.ascontiguousarray(ragged.row_splits, dtype=np.int64)
     if next_ragged is not None:
       nsp = np.ascontiguousarray(next_ragged.row_splits, dtype=np.int64)

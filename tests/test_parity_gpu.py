@@ -1336,6 +1336,29 @@ def test_pipelined_step_restart_flushes_deferred_ids():
   assert mt.size("a") == ot.size()
 
 
+def test_pipeline_picks_up_slices_of_a_resident_id_array():
+  """bench.py trains `ids_all[s]` with `next_ids=ids_all[s + 1]`: every slice is a NEW view object
+  of the same memory.  The batch deduplicated ahead must be recognised by memory + version, not
+  by Python identity — otherwise every step deduplicates twice (the r2 regression: 34 -> 59 us
+  per step, invisible to the parity tests).  Exactly two launches per step."""
+  n, dim = 4096, 16
+  mt = make({"a": adagrad_cfg(dim, 0.1, 0.1, initial_capacity=1 << 15)})
+  step = SparseStep(mt, "a", n)
+  ids_all = ids_t(np.stack([S.id_batch(s, n, 50000, "zipf") for s in range(8)]))
+  g = val_t(S.grad_batch(0, n, dim))
+  for s in range(3):
+    step.forward(ids_all[s], next_ids=ids_all[s + 1])
+    step.backward(g, S.update_time(s))
+  torch.cuda.synchronize()
+  _lib.profile_arm(32)
+  for s in range(3, 6):
+    step.forward(ids_all[s], next_ids=ids_all[s + 1])
+    step.backward(g, S.update_time(s))
+  torch.cuda.synchronize()
+  tags = [t for t, _ in _lib.profile_read()]
+  assert tags == ["step_fwd_kernel", "step_bwd_kernel"] * 3, tags
+
+
 def test_restore_rejects_a_stale_shard_set(tmp_path):
   """Two saves under one basename with different shard counts leave two sets of files; the
   reference validates the set it globs (ValidateShardedFiles), so restore must fail instead of
