@@ -76,6 +76,73 @@ struct DevBuf {
   }
 };
 
+// pinned host staging (device <-> host copies at link speed, not through a pageable bounce buffer)
+template <class T>
+struct HostBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  ~HostBuf() { if (p) (void)hipHostFree(p); }
+  void reserve(size_t n) {
+    if (n <= cap) return;
+    if (p) {
+      HIP_OK(hipHostFree(p));
+      p = nullptr;
+    }
+    size_t want = std::max<size_t>(n, cap * 2);
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), hipHostMallocDefault));
+    cap = want;
+  }
+};
+
+// fn(lo, hi, k) over [0, n) cut into `parts` contiguous ranges, on that many host threads (the
+// caller's included); the first exception is rethrown
+template <typename F>
+static void parallel_ranges(size_t n, int parts, F&& fn) {
+  parts = int(std::max<size_t>(1, std::min<size_t>(size_t(parts), n)));
+  std::vector<std::exception_ptr> err;
+  err.resize(size_t(parts));
+  auto run = [&](int k) {
+    try {
+      fn(n * size_t(k) / size_t(parts), n * size_t(k + 1) / size_t(parts), k);
+    } catch (...) {
+      err[size_t(k)] = std::current_exception();
+    }
+  };
+  std::vector<std::thread> th;
+  for (int k = 1; k < parts; ++k) th.emplace_back(run, k);
+  run(0);
+  for (auto& x : th) x.join();
+  for (auto& e : err)
+    if (e) std::rethrow_exception(e);
+}
+
+// staging of one checkpoint shard job (device scan output, pinned host copies, codec buffers): kept
+// by the table between saves / restores — pinning and unpinning a gigabyte per call costs more than
+// the copy it speeds up
+struct CkptStage {
+  DevBuf<uint32_t> bc;
+  DevBuf<uint64_t> bo;
+  DevBuf<int64_t> d_ids, d_pos;
+  DevBuf<uint32_t> d_ts;
+  DevBuf<float> d_rows;
+  HostBuf<int64_t> h_ids;
+  HostBuf<uint32_t> h_ts;
+  HostBuf<float> h_rows;
+  std::vector<std::string> parts;
+  std::string arena;
+};
+
+// host threads per checkpoint shard for the EntryDump codec (MHTE_CKPT_THREADS; shards run beside
+// each other on up to 16 threads of their own)
+static int ckpt_codec_threads() {
+  static const int n = [] {
+    if (const char* e = getenv("MHTE_CKPT_THREADS")) return std::max(1, atoi(e));
+    const unsigned hw = std::thread::hardware_concurrency();
+    return int(std::max(1u, std::min(16u, hw / 8u)));
+  }();
+  return n;
+}
+
 static inline uint32_t ceil_log2(uint64_t n) {
   uint32_t l = 0;
   while ((uint64_t(1) << l) < n) ++l;
@@ -1038,7 +1105,9 @@ struct Table {
     ttl.slots = d_expire_slots.p;
     ttl.days = d_expire_days.p;
     const uint64_t nslots = (uint64_t(1) << hp) * kSlots;
-    evict_kernel<<<dim3(uint32_t((nslots + 255) / 256)), 256, 0, st>>>(
+    // persistent: 8 workgroups per CU (one atomic pair per workgroup at the end)
+    const uint64_t need = (nslots + 255) / 256;
+    evict_kernel<<<dim3(uint32_t(std::min<uint64_t>(need, 2048))), 256, 0, st>>>(
         view, max_ts < 0 ? max_update_ts : max_ts, ttl);
     HIP_OK(hipGetLastError());
   }
@@ -1050,6 +1119,20 @@ struct Table {
 struct mhte_multi_table {
   int device = 0;
   std::string shared_name;
+  // checkpoint staging, one per concurrent shard job, reused across calls
+  std::mutex stage_mu;
+  std::vector<std::unique_ptr<mhte::CkptStage>> stages;
+  std::unique_ptr<mhte::CkptStage> take_stage() {
+    std::lock_guard<std::mutex> g(stage_mu);
+    if (stages.empty()) return std::unique_ptr<mhte::CkptStage>(new mhte::CkptStage);
+    std::unique_ptr<mhte::CkptStage> s = std::move(stages.back());
+    stages.pop_back();
+    return s;
+  }
+  void give_stage(std::unique_ptr<mhte::CkptStage> s) {
+    std::lock_guard<std::mutex> g(stage_mu);
+    stages.push_back(std::move(s));
+  }
   std::vector<std::unique_ptr<mhte::Table>> tables;  // sorted by name
   // device copies of the tables' views, read by the multi-table launches (mhte_mstep_host.h)
   mhte::DevBuf<mhte::TableView> d_views;
@@ -1906,34 +1989,45 @@ static int64_t ttl_days_of(const Table& tb, int64_t id) {
 // chunks; rows expired relative to the table's max_update_ts are dropped
 // (multi_hash_table_save_restore_ops.cc:203-211).  Returns the number of entries written.
 static uint64_t save_table_shard(Table& tb, int shard, int total, ckpt::RecordWriter& w,
-                                 hipStream_t st) {
+                                 CkptStage& sg, hipStream_t st) {
   const uint64_t nb = uint64_t(1) << tb.hp;
   const uint64_t Q = nb / uint64_t(total), R = nb % uint64_t(total);
   const uint64_t begin = uint64_t(shard) * Q + std::min<uint64_t>(shard, R);
   const uint64_t end = begin + Q + (uint64_t(shard) < R ? 1 : 0);
   const std::vector<ckpt::SegLayout> segs = seg_layout(tb);
   const uint32_t rf = tb.row_floats;
-  const uint64_t kChunkSlots = uint64_t(1) << 22;
-  DevBuf<uint32_t> bc;
-  DevBuf<uint64_t> bo;
-  DevBuf<int64_t> d_ids, d_pos;
-  DevBuf<uint32_t> d_ts;
-  DevBuf<float> d_rows;
-  std::vector<int64_t> h_ids;
-  std::vector<uint32_t> h_ts;
-  std::vector<float> h_rows;
+  const uint64_t kChunkSlots = uint64_t(1) << 21;
+  DevBuf<uint32_t>& bc = sg.bc;
+  DevBuf<uint64_t>& bo = sg.bo;
+  DevBuf<int64_t>&d_ids = sg.d_ids, &d_pos = sg.d_pos;
+  DevBuf<uint32_t>& d_ts = sg.d_ts;
+  DevBuf<float>& d_rows = sg.d_rows;
+  HostBuf<int64_t>& h_ids = sg.h_ids;
+  HostBuf<uint32_t>& h_ts = sg.h_ts;
+  HostBuf<float>& h_rows = sg.h_rows;
   std::string rec;
   uint64_t written = 0;
+  auto expired = [&](int64_t id, uint32_t ts) {
+    return tb.max_update_ts - int64_t(ts) >= ttl_days_of(tb, id) * int64_t(86400);
+  };
   auto emit = [&](int64_t id, const float* row, uint32_t ts) {
-    if (tb.max_update_ts - int64_t(ts) >= ttl_days_of(tb, id) * int64_t(86400)) return;
+    if (expired(id, ts)) return;
     ckpt::encode_entry(rec, id, row, segs, int(tb.dim), ts);
     w.write(rec);
     ++written;
   };
+  const int P = ckpt_codec_threads();
+  std::vector<std::string>& parts = sg.parts;
+  if (parts.size() < size_t(P)) parts.resize(size_t(P));
+  std::vector<uint64_t> part_n(static_cast<size_t>(P), 0);
+  const bool trace = getenv("MHTE_CKPT_TRACE") != nullptr;   // phase seconds of this shard to stderr
+  double t_scan = 0, t_enc = 0, t_write = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (uint64_t s0 = begin * kSlots; s0 < end * kSlots; s0 += kChunkSlots) {
     const uint64_t s1 = std::min(end * kSlots, s0 + kChunkSlots);
     const uint32_t nblocks = uint32_t((s1 - s0 + 1023) / 1024);
     uint64_t acc = 0;
+    const double t0 = now();
     {
     // the table is held for the device scan + copy of a chunk only; the (much longer) encoding of
     // the chunk runs beside the other shards' threads
@@ -1958,16 +2052,46 @@ static uint64_t save_table_shard(Table& tb, int shard, int total, ckpt::RecordWr
     HIP_OK(hipMemcpyAsync(bo.p, ho.data(), sizeof(uint64_t) * nblocks, hipMemcpyHostToDevice, st));
     dump_emit_kernel<<<nblocks, 256, 0, st>>>(tb.view, s0, s1, bo.p, d_ids.p, d_pos.p, d_ts.p, d_rows.p);
     HIP_OK(hipGetLastError());
-    h_ids.resize(acc);
-    h_ts.resize(acc);
-    h_rows.resize(acc * rf);
-    HIP_OK(hipMemcpyAsync(h_ids.data(), d_ids.p, acc * 8, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(h_ts.data(), d_ts.p, acc * 4, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(h_rows.data(), d_rows.p, acc * rf * 4, hipMemcpyDeviceToHost, st));
+    h_ids.reserve(acc);
+    h_ts.reserve(acc);
+    h_rows.reserve(acc * rf);
+    HIP_OK(hipMemcpyAsync(h_ids.p, d_ids.p, acc * 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(h_ts.p, d_ts.p, acc * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(h_rows.p, d_rows.p, acc * rf * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     }
-    for (uint64_t i = 0; i < acc; ++i) emit(h_ids[i], h_rows.data() + i * rf, h_ts[i]);
+    const double t1 = now();
+    // EntryDump + TFRecord framing of the chunk's rows on P threads (contiguous ranges, so the
+    // file keeps the dump order), then the framed bytes go through the writer in range order
+    parallel_ranges(size_t(acc), P, [&](size_t lo, size_t hi, int k) {
+      std::string& out = parts[size_t(k)];
+      std::string r;
+      out.clear();
+      uint64_t n = 0;
+      for (size_t i = lo; i < hi; ++i) {
+        if (expired(h_ids.p[i], h_ts.p[i])) continue;
+        ckpt::encode_entry(r, h_ids.p[i], h_rows.p + i * rf, segs, int(tb.dim), h_ts.p[i]);
+        ckpt::RecordWriter::frame(out, r);
+        ++n;
+      }
+      part_n[size_t(k)] = n;
+    });
+    const double t2 = now();
+    for (int k = 0; k < P; ++k) {
+      if (parts[size_t(k)].empty()) continue;
+      w.write_framed(parts[size_t(k)]);
+      written += part_n[size_t(k)];
+      parts[size_t(k)].clear();
+      part_n[size_t(k)] = 0;
+    }
+    t_scan += t1 - t0;
+    t_enc += t2 - t1;
+    t_write += now() - t2;
   }
+  if (trace)
+    fprintf(stderr, "[mhte ckpt] save %s shard %d/%d: %llu rows, scan+copy %.3f s, encode(%d thr) %.3f s, "
+                    "write %.3f s\n", tb.name.c_str(), shard, total, (unsigned long long)written, t_scan, P,
+            t_enc, t_write);
   if (shard == 0 && tb.h_ctr->special_state == 1) {
     std::lock_guard<std::mutex> g(tb.mu);
     // the one key that lives in the side slot (kEmptyKey itself): last entry of shard 0
@@ -2013,8 +2137,12 @@ static void save_multi_table(mhte_multi_table* t, const std::string& basename, i
   HIP_OK(hipStreamSynchronize(st));
   std::vector<std::exception_ptr> err;
   err.resize(size_t(nshards));
+  const bool trace = getenv("MHTE_CKPT_TRACE") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = now();
   auto shard_job = [&](int sh) {
     hipStream_t s2 = nullptr;
+    const double tj0 = now();
     try {
       HIP_OK(hipSetDevice(t->device));
       HIP_OK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
@@ -2025,13 +2153,25 @@ static void save_multi_table(mhte_multi_table* t, const std::string& basename, i
       {
         ckpt::RecordWriter w(tmp, true), mw(mtmp, false);
         std::string meta;
-        for (auto& tb : t->tables) {
-          const uint64_t n = save_table_shard(*tb, sh, nshards, w, s2);
-          ckpt::encode_meta(meta, tb->name, n);
-          mw.write(meta);
+        const double tj1 = now();
+        std::unique_ptr<CkptStage> sg = t->take_stage();
+        try {
+          for (auto& tb : t->tables) {
+            const uint64_t n = save_table_shard(*tb, sh, nshards, w, *sg, s2);
+            ckpt::encode_meta(meta, tb->name, n);
+            mw.write(meta);
+          }
+        } catch (...) {
+          t->give_stage(std::move(sg));
+          throw;
         }
+        t->give_stage(std::move(sg));
+        const double tj2 = now();
         w.close();
         mw.close();
+        if (trace)
+          fprintf(stderr, "[mhte ckpt] save shard %d: started +%.3f s, setup %.3f s, tables %.3f s, close %.3f s\n",
+                  sh, tj0 - t_begin, tj1 - tj0, tj2 - tj1, now() - tj2);
       }
       if (rename(tmp.c_str(), fn.c_str()) != 0 || rename(mtmp.c_str(), mfn.c_str()) != 0)
         throw Error(MHTE_INTERNAL, "checkpoint: cannot rename into " + fn);
@@ -2041,33 +2181,30 @@ static void save_multi_table(mhte_multi_table* t, const std::string& basename, i
     if (s2) (void)hipStreamDestroy(s2);
   };
   run_shard_jobs(nshards, shard_job);
+  if (trace) fprintf(stderr, "[mhte ckpt] save: all shards done +%.3f s\n", now() - t_begin);
   for (auto& e : err)
     if (e) std::rethrow_exception(e);
 }
 
 // rows of one restore batch -> table (upsert of whole rows with their own timestamps)
-static void restore_batch(Table& tb, const std::vector<int64_t>& ids, const std::vector<float>& rows,
-                          const std::vector<uint32_t>& ts, hipStream_t st) {
-  const int64_t n = int64_t(ids.size());
+static void restore_batch(Table& tb, CkptStage& sg, const int64_t* ids, const float* rows,
+                          const uint32_t* ts, int64_t n, hipStream_t st) {
   if (n == 0) return;
   tb.finish_pending(st);
   ++tb.mut_epoch;
   tb.ensure_capacity(uint64_t(n), st);
-  DevBuf<int64_t> d_ids;
-  DevBuf<uint32_t> d_ts;
-  DevBuf<float> d_rows;
-  d_ids.reserve(n);
-  d_ts.reserve(n);
-  d_rows.reserve(size_t(n) * tb.row_floats);
-  HIP_OK(hipMemcpyAsync(d_ids.p, ids.data(), n * 8, hipMemcpyHostToDevice, st));
-  HIP_OK(hipMemcpyAsync(d_ts.p, ts.data(), n * 4, hipMemcpyHostToDevice, st));
-  HIP_OK(hipMemcpyAsync(d_rows.p, rows.data(), size_t(n) * tb.row_floats * 4, hipMemcpyHostToDevice, st));
+  sg.d_ids.reserve(size_t(n));
+  sg.d_ts.reserve(size_t(n));
+  sg.d_rows.reserve(size_t(n) * tb.row_floats);
+  HIP_OK(hipMemcpyAsync(sg.d_ids.p, ids, n * 8, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(sg.d_ts.p, ts, n * 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(sg.d_rows.p, rows, size_t(n) * tb.row_floats * 4, hipMemcpyHostToDevice, st));
   tb.pending.reserve(size_t(n) + 1);
   const dim3 grid(uint32_t((n * 16 + 255) / 256));
-  restore_rows_kernel<16><<<grid, 256, 0, st>>>(tb.view, d_ids.p, n, d_rows.p, d_ts.p, tb.pending.p);
-  restore_slowpath_kernel<<<1, 64, 0, st>>>(tb.view, d_ids.p, d_rows.p, d_ts.p, tb.pending.p);
+  restore_rows_kernel<16><<<grid, 256, 0, st>>>(tb.view, sg.d_ids.p, n, sg.d_rows.p, sg.d_ts.p, tb.pending.p);
+  restore_slowpath_kernel<<<1, 64, 0, st>>>(tb.view, sg.d_ids.p, sg.d_rows.p, sg.d_ts.p, tb.pending.p);
   HIP_OK(hipGetLastError());
-  HIP_OK(hipStreamSynchronize(st));  // the staging buffers go out of scope
+  HIP_OK(hipStreamSynchronize(st));  // the staging buffers are rewritten by the next batch
 }
 
 static void restore_shard(mhte_multi_table* t, const std::string& basename, int sh, int total,
@@ -2075,7 +2212,30 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
   {
     ckpt::RecordReader data(ckpt::shard_name(basename, "", sh, total), true);
     ckpt::RecordReader meta(ckpt::shard_name(basename, ".meta", sh, total), false);
-    std::string mrec, rec, name;
+    std::string mrec, name;
+    // the data file is read in stretches of ~64 MiB into the stage's arena; `refs[cur..)` are the
+    // records of the current stretch not yet consumed (a stretch may span two tables)
+    std::unique_ptr<CkptStage> sgp = t->take_stage();
+    struct Return {
+      mhte_multi_table* t;
+      std::unique_ptr<CkptStage>& s;
+      ~Return() { t->give_stage(std::move(s)); }
+    } give_back{t, sgp};
+    CkptStage& sg = *sgp;
+    std::vector<ckpt::RecordReader::RecRef> refs;
+    size_t cur = 0;
+    const size_t kStretch = size_t(64) << 20;
+    // up to `want` records of the stream -> (first, count) in refs; 0 at the end of the file
+    auto take = [&](uint64_t want, size_t* first) -> size_t {
+      if (cur == refs.size()) {
+        cur = 0;
+        if (!data.read_batch(sg.arena, kStretch, refs)) return 0;
+      }
+      const size_t k = size_t(std::min<uint64_t>(want, refs.size() - cur));
+      *first = cur;
+      cur += k;
+      return k;
+    };
     while (meta.read(&mrec)) {
       uint64_t num = 0;
       ckpt::decode_meta(reinterpret_cast<const uint8_t*>(mrec.data()), mrec.size(), &name, &num);
@@ -2083,8 +2243,12 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
       for (size_t i = 0; i < t->tables.size(); ++i)
         if (t->tables[i]->name == name) idx = int(i);
       if (idx < 0) {  // table in the checkpoint but not in this MultiHashTable: skipped (:352-361)
-        for (uint64_t i = 0; i < num; ++i)
-          if (!data.read(&rec)) throw Error(MHTE_INTERNAL, "checkpoint shard ends early");
+        for (uint64_t left = num; left;) {
+          size_t first;
+          const size_t k = take(left, &first);
+          if (!k) throw Error(MHTE_INTERNAL, "checkpoint shard ends early");
+          left -= k;
+        }
         continue;
       }
       Table& tb = *t->tables[size_t(idx)];
@@ -2110,42 +2274,74 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
         if (d.opt == kOptGroupAdagrad) init[size_t(d.st_off)] = d.p[0];  // group_adagrad_optimizer.cc:45-48
       }
       const size_t kBatch = size_t(1) << 18;
-      std::vector<int64_t> ids;
-      std::vector<uint32_t> ts;
-      std::vector<float> rows;
+      HostBuf<int64_t>& ids = sg.h_ids;
+      HostBuf<uint32_t>& ts = sg.h_ts;
+      HostBuf<float>& rows = sg.h_rows;
+      ids.reserve(kBatch);
+      ts.reserve(kBatch);
+      rows.reserve(kBatch * rf);
       std::vector<int64_t> sorted;
-      int64_t max_ts = 0;
-      // ids inside one batch must be distinct for the upsert: a checkpoint holds each id once per
-      // table, but two shards of a foreign writer could repeat one — later entries win by flushing
-      auto flush = [&] {
-        sorted = ids;
+      const int P = ckpt_codec_threads();
+      std::vector<int64_t> part_max(static_cast<size_t>(P), 0);
+      const bool trace = getenv("MHTE_CKPT_TRACE") != nullptr;
+      double t_read = 0, t_dec = 0, t_up = 0;
+      auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+      for (uint64_t done = 0; done < num;) {
+        // the file is read in order (one reader per shard); a batch's records are verified (data
+        // crc) and decoded in place, on P threads
+        const double t0 = now();
+        size_t first = 0;
+        const size_t nb = take(std::min<uint64_t>(kBatch, num - done), &first);
+        if (!nb) throw Error(MHTE_INTERNAL, "checkpoint shard ends early");
+        const double t1 = now();
+        const char* base = sg.arena.data();
+        parallel_ranges(nb, P, [&](size_t lo, size_t hi, int k) {
+          int64_t mx = 0;
+          for (size_t i = lo; i < hi; ++i) {
+            const ckpt::RecordReader::RecRef& r = refs[first + i];
+            data.verify(base + r.off, r.len, r.crc);
+            float* row = rows.p + i * rf;
+            memcpy(row, init.data(), sizeof(float) * rf);
+            int64_t id;
+            uint32_t tsv;
+            ckpt::decode_entry(reinterpret_cast<const uint8_t*>(base + r.off), r.len, segs, int(tb.dim),
+                               &id, row, &tsv);
+            ids.p[i] = id;
+            ts.p[i] = tsv;
+            mx = std::max<int64_t>(mx, int64_t(tsv));
+          }
+          part_max[size_t(k)] = mx;
+        });
+        int64_t max_ts = 0;
+        for (int k = 0; k < P; ++k) {
+          max_ts = std::max(max_ts, part_max[size_t(k)]);
+          part_max[size_t(k)] = 0;
+        }
+        const double t2 = now();
+        // ids inside one batch must be distinct for the upsert: a checkpoint holds each id once
+        // per table, but two shards of a foreign writer could repeat one — later entries win by
+        // flushing batch after batch
+        sorted.assign(ids.p, ids.p + nb);
         std::sort(sorted.begin(), sorted.end());
         if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
           throw Error(MHTE_INVALID_ARGUMENT, "checkpoint repeats an id inside table " + name);
         {
           std::lock_guard<std::mutex> g(tb.mu);
           tb.max_update_ts = std::max<int64_t>(tb.max_update_ts, max_ts);
-          restore_batch(tb, ids, rows, ts, st);
+          restore_batch(tb, sg, ids.p, rows.p, ts.p, int64_t(nb), st);
         }
-        ids.clear();
-        ts.clear();
-        rows.clear();
-      };
-      for (uint64_t i = 0; i < num; ++i) {
-        if (!data.read(&rec)) throw Error(MHTE_INTERNAL, "checkpoint shard ends early");
-        int64_t id;
-        uint32_t tsv;
-        rows.insert(rows.end(), init.begin(), init.end());
-        ckpt::decode_entry(reinterpret_cast<const uint8_t*>(rec.data()), rec.size(), segs,
-                           int(tb.dim), &id, rows.data() + rows.size() - rf, &tsv);
-        ids.push_back(id);
-        ts.push_back(tsv);
-        max_ts = std::max<int64_t>(max_ts, int64_t(tsv));
-        if (ids.size() == kBatch) flush();
+        done += nb;
+        t_read += t1 - t0;
+        t_dec += t2 - t1;
+        t_up += now() - t2;
       }
-      flush();
+      if (trace)
+        fprintf(stderr, "[mhte ckpt] restore %s shard %d/%d: %llu rows, read %.3f s, verify+decode(%d thr) "
+                        "%.3f s, sort+upsert %.3f s\n", name.c_str(), sh, total, (unsigned long long)num,
+                t_read, P, t_dec, t_up);
     }
-    if (data.read(&rec)) throw Error(MHTE_INTERNAL, "Couldn't read all of checkpoint shard");
+    size_t first = 0;
+    if (take(1, &first)) throw Error(MHTE_INTERNAL, "Couldn't read all of checkpoint shard");
   }
 }
 

@@ -520,6 +520,22 @@ class RecordWriter {
     emit(rec.data(), rec.size());
     emit(ftr, 4);
   }
+  // the framing of write(), appended to a buffer (any thread); write_framed() then passes whole
+  // buffers of framed records through the file's byte stream
+  static void frame(std::string& out, const std::string& rec) {
+    char hdr[12];
+    const uint64_t len = rec.size();
+    for (int i = 0; i < 8; ++i) hdr[i] = char(len >> (8 * i));
+    const uint32_t c1 = masked_crc(hdr, 8);
+    for (int i = 0; i < 4; ++i) hdr[8 + i] = char(c1 >> (8 * i));
+    const uint32_t c2 = masked_crc(rec.data(), rec.size());
+    char ftr[4];
+    for (int i = 0; i < 4; ++i) ftr[i] = char(c2 >> (8 * i));
+    out.append(hdr, 12);
+    out.append(rec);
+    out.append(ftr, 4);
+  }
+  void write_framed(const std::string& bytes) { emit(bytes.data(), bytes.size()); }
   void close() {
     if (!fp_) return;
     if (snappy_) flush_block();
@@ -621,6 +637,80 @@ class RecordReader {
       throw std::runtime_error("corrupted record data in " + path_);
     return true;
   }
+  // read() without the data checksum's verification: *crc receives the stored (masked) value for
+  // verify(), which any thread may run
+  bool read_raw(std::string* rec, uint32_t* crc) {
+    char hdr[12];
+    const size_t got = fetch(hdr, 12);
+    if (got == 0) return false;
+    if (got != 12) throw std::runtime_error("truncated record header in " + path_);
+    uint64_t len = 0;
+    for (int i = 0; i < 8; ++i) len |= uint64_t(uint8_t(hdr[i])) << (8 * i);
+    uint32_t c1 = 0;
+    for (int i = 0; i < 4; ++i) c1 |= uint32_t(uint8_t(hdr[8 + i])) << (8 * i);
+    if (c1 != masked_crc(hdr, 8)) throw std::runtime_error("corrupted record length in " + path_);
+    rec->resize(len);
+    if (fetch(&(*rec)[0], len) != len) throw std::runtime_error("truncated record in " + path_);
+    char ftr[4];
+    if (fetch(ftr, 4) != 4) throw std::runtime_error("truncated record in " + path_);
+    uint32_t c2 = 0;
+    for (int i = 0; i < 4; ++i) c2 |= uint32_t(uint8_t(ftr[i])) << (8 * i);
+    *crc = c2;
+    return true;
+  }
+  void verify(const std::string& rec, uint32_t crc) const {
+    if (crc != masked_crc(rec.data(), rec.size()))
+      throw std::runtime_error("corrupted record data in " + path_);
+  }
+  void verify(const char* data, size_t n, uint32_t crc) const {
+    if (crc != masked_crc(data, n)) throw std::runtime_error("corrupted record data in " + path_);
+  }
+
+  // Batch form: the next stretch of the file's byte stream (about target_bytes of it) lands in
+  // `arena` as ONE contiguous buffer and `refs` lists the whole records inside it (data offset,
+  // length, stored data checksum — unverified: verify() on any thread).  A record cut by the end of
+  // the stretch is carried into the next call.  No per-record allocation or copy: the decoders
+  // read the arena in place.  false at a clean end of file.
+  struct RecRef {
+    size_t off;
+    uint32_t len;
+    uint32_t crc;
+  };
+  bool read_batch(std::string& arena, size_t target_bytes, std::vector<RecRef>& refs) {
+    refs.clear();
+    arena.clear();
+    arena.append(carry_);
+    carry_.clear();
+    if (pos_ < buf_.size()) arena.append(buf_, pos_, std::string::npos);  // (after read() calls)
+    buf_.clear();
+    pos_ = 0;
+    bool eof = false;
+    size_t pos = 0;
+    for (;;) {
+      while (!eof && arena.size() < target_bytes) eof = !append_block(arena);
+      while (arena.size() - pos >= 12) {
+        const char* h = arena.data() + pos;
+        uint64_t len = 0;
+        for (int i = 0; i < 8; ++i) len |= uint64_t(uint8_t(h[i])) << (8 * i);
+        uint32_t c1 = 0;
+        for (int i = 0; i < 4; ++i) c1 |= uint32_t(uint8_t(h[8 + i])) << (8 * i);
+        if (c1 != masked_crc(h, 8)) throw std::runtime_error("corrupted record length in " + path_);
+        if (len > 0xffffffffull) throw std::runtime_error("oversized record in " + path_);
+        if (arena.size() - pos < 16 + len) break;
+        uint32_t c2 = 0;
+        for (int i = 0; i < 4; ++i) c2 |= uint32_t(uint8_t(h[12 + len + i])) << (8 * i);
+        refs.push_back(RecRef{pos + 12, uint32_t(len), c2});
+        pos += 16 + len;
+      }
+      if (!refs.empty() || eof) break;
+      target_bytes = arena.size() + kSnappyBlock;  // (one record longer than the stretch)
+    }
+    if (pos < arena.size()) {
+      if (eof) throw std::runtime_error("truncated record in " + path_);
+      carry_.assign(arena, pos, std::string::npos);
+    }
+    return !refs.empty();
+  }
 
  private:
   size_t fetch(char* dst, size_t n) {
@@ -636,6 +726,26 @@ class RecordReader {
       done += take;
     }
     return done;
+  }
+  // the next piece of the byte stream appended to `out` (a snappy block / 1 MiB of a plain file)
+  bool append_block(std::string& out) {
+    if (!snappy_) {
+      const size_t base = out.size(), want = size_t(1) << 20;
+      out.resize(base + want);
+      const size_t got = fread(&out[base], 1, want, fp_);
+      out.resize(base + got);
+      return got != 0;
+    }
+    uint8_t be[4];
+    const size_t got = fread(be, 1, 4, fp_);
+    if (got == 0) return false;
+    if (got != 4) throw std::runtime_error("truncated snappy block header in " + path_);
+    const uint32_t cl = (uint32_t(be[0]) << 24) | (uint32_t(be[1]) << 16) | (uint32_t(be[2]) << 8) | be[3];
+    comp_.resize(cl);
+    if (fread(&comp_[0], 1, cl, fp_) != cl) throw std::runtime_error("truncated snappy block in " + path_);
+    if (!snappy_uncompress(reinterpret_cast<const uint8_t*>(comp_.data()), cl, out))
+      throw std::runtime_error("corrupted snappy block in " + path_);
+    return true;
   }
   bool next_block() {
     uint8_t be[4];
@@ -653,7 +763,7 @@ class RecordReader {
   }
   FILE* fp_ = nullptr;
   bool snappy_;
-  std::string path_, buf_, comp_;
+  std::string path_, buf_, comp_, carry_;
   size_t pos_ = 0;
 };
 

@@ -1419,32 +1419,48 @@ struct TtlConfig {
   const int32_t* days;   // device
 };
 
+// Persistent workgroups, grid-stride over the slots (4 threads per 64-B bucket: coalesced), the
+// eviction count kept in registers and added to the table's counters ONCE per workgroup: with every
+// row expired a per-wavefront add is 2 atomics x nslots / 64 on two addresses — they queue behind
+// each other for milliseconds (r1: 6.1 ms for 4 M rows against 45 us when nothing expires).
 __global__ __launch_bounds__(256) void evict_kernel(TableView tv, int64_t max_update_time,
                                                     TtlConfig ttl) {
-  const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  __shared__ uint32_t wsum[4];
   const uint64_t nslots = (uint64_t(1) << tv.hp) * kSlots;
-  bool ev = false;
-  if (t < nslots) {
-    Bucket* b = tv.buckets + (t >> 2);
-    const int s = t & 3;
-    const int64_t key = b->key[s];
-    if (key != kEmptyKey) {
-      const int64_t slot = (key >> 48) & 0x7fff;
-      int64_t days = ttl.default_days;
-      for (int i = 0; i < ttl.n; ++i)
-        if (ttl.slots[i] == slot) days = ttl.days[i];
-      if (max_update_time - int64_t(b->ts[s]) >= days * int64_t(86400)) {
-        b->key[s] = kEmptyKey;
-        b->row[s] = kNoRow;
-        ev = true;
+  const int64_t def_secs = ttl.default_days * int64_t(86400);
+  uint32_t mine = 0;   // (lane 0 of each wavefront: evictions of the wavefront)
+#pragma unroll 1
+  for (uint64_t t0 = uint64_t(blockIdx.x) * 256; t0 < nslots; t0 += uint64_t(gridDim.x) * 256) {
+    const uint64_t t = t0 + threadIdx.x;
+    bool ev = false;
+    if (t < nslots) {
+      Bucket* b = tv.buckets + (t >> 2);
+      const int s = t & 3;
+      const int64_t key = b->key[s];
+      if (key != kEmptyKey) {
+        int64_t secs = def_secs;
+        if (ttl.n) {
+          const int64_t slot = (key >> 48) & 0x7fff;
+          for (int i = 0; i < ttl.n; ++i)
+            if (ttl.slots[i] == slot) secs = int64_t(ttl.days[i]) * int64_t(86400);
+        }
+        if (max_update_time - int64_t(b->ts[s]) >= secs) {
+          b->key[s] = kEmptyKey;
+          b->row[s] = kNoRow;
+          ev = true;
+        }
       }
     }
+    mine += uint32_t(__popcll(__ballot(ev)));
   }
-  const uint64_t em = __ballot(ev);
-  if (em && (threadIdx.x & 63) == 0) {
-    const unsigned long long c = __popcll(em);
-    atomicAdd(&tv.ctr->alloc, ~(c << 32) + 1ull);  // live keys -= c
-    atomicAdd(&tv.ctr->n_evicted, (unsigned int)c);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long c = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (c) {
+      atomicAdd(&tv.ctr->alloc, ~(c << 32) + 1ull);  // live keys -= c
+      atomicAdd(&tv.ctr->n_evicted, (unsigned int)c);
+    }
   }
 }
 
