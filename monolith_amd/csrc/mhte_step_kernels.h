@@ -49,7 +49,10 @@ constexpr int kStepLightMax = 32;
 constexpr int kMaxLongRuns = 16;
 constexpr uint32_t kItemTarget = 256;   // entries per heavy work item (expected)
 constexpr uint32_t kSpecSlackRows = 32; // row handles an update may strand (upsert_issue), per op
-constexpr int kBwdBlocksPerCu = 5;      // 256-thread workgroups of step_bwd resident per CU (<= 96 VGPRs)
+#ifndef MHTE_BWD_OCC
+#define MHTE_BWD_OCC 5
+#endif
+constexpr int kBwdBlocksPerCu = MHTE_BWD_OCC;  // 256-thread workgroups of step_bwd resident per CU (5: <= 96 VGPRs)
 
 // Workgroup barrier for LDS traffic only.  __syncthreads() also drains every outstanding global
 // store and atomic of the wavefront (s_waitcnt vmcnt(0)), which costs a full memory round trip per

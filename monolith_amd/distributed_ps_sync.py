@@ -374,6 +374,32 @@ def shard_unique_id() -> bytes:
   return buf.raw
 
 
+def shard_block_geometry(dims, batch_per_table: int, world: int, ids_per_peer_table: int = 0):
+  """The wire format of the sharded multi-table step (csrc/mhte_shard_kernels.h), as ShardStep::init
+  lays it out: every rank keeps one fixed-capacity block per peer and direction,
+
+    id block    int64[hdr + T * cap]      word t < T: number of ids of table t, then cap id slots
+                                          per table at id_off[t]
+    row block   float32[sum_t cap * dim]  cap rows per table at row_off[t]; id slot s <-> row s
+
+  -> dict(cap, hdr, id_off[T], row_off[T], ids_block (int64 words), rows_block (floats)).
+  ``ShardedMultiStep.info()`` reports the same block sizes from the library."""
+  T = len(dims)
+  mb = int(batch_per_table)
+  c = int(ids_per_peer_table) if ids_per_peer_table > 0 else (
+      mb if world == 1 else (mb + world - 1) // world * 3 // 2 + 256)
+  cap = (min(c, mb) + 3) & ~3
+  hdr = (T + 7) & ~7
+  id_off = [hdr + t * cap for t in range(T)]
+  row_off, rw = [], 0
+  for d in dims:
+    row_off.append(rw)
+    rw += cap * int(d)
+  idw = hdr + T * cap
+  return {"cap": cap, "hdr": hdr, "id_off": id_off, "row_off": row_off,
+          "ids_block": (idw + 1) & ~1, "rows_block": rw}
+
+
 class ShardedMultiStep:
   """All tables of the model, sharded by id over the ranks, one exchange per direction for all of
   them (native_training/distributed_ps_sync.py:95-287, :289-490) — mhte_shard_step_*: the whole

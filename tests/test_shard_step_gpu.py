@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 
 import oracle as O  # noqa: E402,F401
 from monolith_amd import _lib, synthetic as S  # noqa: E402
-from monolith_amd.distributed_ps_sync import ShardedMultiStep, ShardedStepGroup  # noqa: E402
+from monolith_amd.distributed_ps_sync import (ShardedMultiStep, ShardedStepGroup,  # noqa: E402
+                                              shard_block_geometry)
 from monolith_amd.fused_step import MultiSparseStep  # noqa: E402
 from test_multi_step_gpu import (ATOL, RTOL, dlrm_specs, make, oracle_backward, ragged_of,  # noqa: E402
                                  val_t)
@@ -29,6 +30,13 @@ def batch_of(specs, seed, n, universe, dist="zipf", skip=()):
       continue
     out[s.name] = S.id_batch(seed * 131 + s.slot, n, universe, dist, feature_slot=s.slot)
   return out
+
+
+def _info_of(grp):
+  import ctypes as C
+  out = (C.c_int64 * 4)()
+  _lib.check(grp._lib.mhte_shard_step_info(grp._hs[0], out))  # pylint: disable=protected-access
+  return list(out)
 
 
 def grads_of(step, rank, spec, n):
@@ -45,6 +53,8 @@ def test_world1_identity_matches_multi_step():
   ref = MultiSparseStep(mt_a, B)
   shd = ShardedMultiStep(mt_b, B)
   assert shd.info()["transport"] == "identity"
+  geo = shard_block_geometry(mt_b.get_table_dim_sizes(), B, 1)
+  assert (shd.info()["id_block_bytes"], shd.info()["row_block_bytes"]) == (8 * geo["ids_block"], 4 * geo["rows_block"])
   rag_a = [ragged_of(specs, mt_a, b) for b in batches]
   rag_b = [ragged_of(specs, mt_b, b) for b in batches]
   for s in range(steps):
@@ -71,6 +81,9 @@ def test_group_against_oracle(dist, world):
   exact = dist == "uniform"   # every id occurs <= 32 times in a batch: sums in occurrence order
   mts = [make(specs) for _ in range(world)]
   grp = ShardedStepGroup(mts, B)
+  geo = shard_block_geometry(mts[0].get_table_dim_sizes(), B, world)
+  info = _info_of(grp)
+  assert (info[0], info[1], info[2]) == (geo["cap"], 8 * geo["ids_block"], 4 * geo["rows_block"])
   ots = {s.name: s.oracle_table() for s in specs}
 
   def rank_batch(step, r):
