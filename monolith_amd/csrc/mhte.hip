@@ -1855,7 +1855,7 @@ mhte_status mhte_hash_filter_save(mhte_hash_filter* f, const char* basename, voi
         std::string meta;   // HashFilterSplitMetaDump
         put_u(meta, 1, 0);
         put_u(meta, 2, f->total);
-        put_u(meta, 3, hs.num_elements[sp]);
+        put_u(meta, 3, filter_split_elements(hs, uint32_t(sp)));
         put_key(meta, 4, 1);
         const double fill = 1.2;
         meta.append(reinterpret_cast<const char*>(&fill), 8);
@@ -1899,7 +1899,7 @@ mhte_status mhte_hash_filter_restore(mhte_hash_filter* f, const char* basename, 
           uint64_t total = 0;
           while (m.next(&fl)) {
             if (fl.num == 2) total = fl.v;
-            if (fl.num == 3) hs.num_elements[sp] = uint32_t(fl.v);
+            if (fl.num == 3) hs.num_elements[sp][0] = uint32_t(fl.v);
             if (fl.num == 5 && fl.wt == 2) {
               pcfg::Msg sm(fl.p, fl.n);
               pcfg::Field g;

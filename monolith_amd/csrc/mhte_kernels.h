@@ -204,6 +204,7 @@ constexpr int kFilterMaxStep = 64;         // words of overrun behind a split (h
 constexpr int kFilterProbe = 16;           // SlidingHashFilter::MAX_STEP
 constexpr int kFilterForward = 2;          // max_forward_step_
 constexpr int kFilterMaxSplits = 64;
+constexpr int kFilterWays = 32;
 
 struct FilterState {           // device words behind TableView::flt_state
   uint32_t head;
@@ -211,8 +212,15 @@ struct FilterState {           // device words behind TableView::flt_state
   uint32_t clear_req;          // split to clear + 1 (set by filter_advance_kernel)
   uint32_t pad;
   unsigned long long failure_count;
-  uint32_t num_elements[kFilterMaxSplits];
+  // elements per split, kept as kFilterWays partial counts (an id adds to way home % kFilterWays):
+  // a step that starts 40 000 slots would otherwise queue 40 000 adds on ONE word
+  uint32_t num_elements[kFilterMaxSplits][kFilterWays];
 };
+__device__ __host__ inline uint32_t filter_split_elements(const FilterState& fs, uint32_t sp) {
+  uint32_t n = 0;
+  for (int w = 0; w < kFilterWays; ++w) n += fs.num_elements[sp][w];
+  return n;
+}
 
 __device__ __forceinline__ int32_t occurrence_threshold(const TableView& tv, int64_t id) {
   const int64_t slot = (id >> 48) & 0x7fff;  // slot_id_v2
@@ -328,7 +336,7 @@ __device__ __forceinline__ uint32_t filter_consult(const TableView& tv, int64_t 
     decide(old_count, &first, &adds);
     const uint32_t c1 = min(kFilterMaxCount, old_count + min(adds, kFilterMaxCount));
     if (atomicCAS(slot, 0u, (sign << 4) | c1) == 0u) {
-      atomicAdd(&fs->num_elements[sp], 1u);
+      atomicAdd(&fs->num_elements[sp][home & uint64_t(kFilterWays - 1)], 1u);
       return first;
     }
     // the slot went to another id meanwhile: look again
@@ -375,11 +383,11 @@ __global__ void filter_advance_kernel(TableView tv) {
   FilterState* fs = reinterpret_cast<FilterState*>(tv.flt_state);
   if (threadIdx.x != 0) return;
   fs->clear_req = 0;
-  if (fs->num_elements[fs->head] + 1u >= tv.flt_cap) {      // HashFilter::full(): >= capacity - 1
+  if (filter_split_elements(*fs, fs->head) + 1u >= tv.flt_cap) {   // HashFilter::full(): >= capacity - 1
     fs->head = (fs->head + 1u) % tv.flt_nsplit;
     fs->head_increment += 1u;
     const uint32_t c = (fs->head + uint32_t(kFilterForward) - 1u) % tv.flt_nsplit;
-    fs->num_elements[c] = 0;
+    for (int w = 0; w < kFilterWays; ++w) fs->num_elements[c][w] = 0;
     fs->clear_req = c + 1u;
   }
 }

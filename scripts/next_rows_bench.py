@@ -255,7 +255,10 @@ def bench_optimizers():
 def main():
   torch.cuda.set_device(0)
   which = sys.argv[1:] or ["optimizers", "gather", "reduce", "evict", "filter", "checkpoint"]
+  import gc
   for w in which:
+    gc.collect()
+    gc.disable()   # (a generation-2 pass of the interpreter is ~40 ms: it would land in a 60-step window)
     {"optimizers": bench_optimizers, "gather": bench_gather, "reduce": bench_reduce,
      "evict": bench_evict, "filter": bench_filter_step, "checkpoint": bench_checkpoint}[w]()
   md = ["| Measurement | time | algorithmic bytes | GB/s | of 8 TB/s | notes |", "|---|---|---|---|---|---|"]
