@@ -352,8 +352,11 @@ def main_dlrm(args):
   dom = max((k for k in stages if k in alg), key=lambda k: stages[k]["avg_us"])
   a_gbps = alg[dom] / stages[dom]["avg_us"] / 1e3
   step_bytes = alg_fwd + alg_bwd
+  # (the committed PMC passes are of the default 26 x 65 536 shape)
+  traffic, traffic_src = pmc_traffic(dom) if (T == 26 and B == 65536 and not sharded) else (None, None)
   roofline = {"bound": "hbm", "kernel": dom, "achieved": round(a_gbps, 1), "peak": HBM_PEAK_GBPS,
-              "unit": "GB/s", "frac": round(a_gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+              "unit": "GB/s", "frac": round(a_gbps / HBM_PEAK_GBPS, 4), "traffic": traffic,
+              "traffic_source": traffic_src,
               "alg_bytes_per_launch": int(alg[dom]), "avg_launch_us": stages[dom]["avg_us"],
               "timing": "hipExtLaunchKernelGGL start/stop events on the launch stream, %d launches" % reps,
               "step_alg_bytes": int(step_bytes),

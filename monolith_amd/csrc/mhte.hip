@@ -302,8 +302,9 @@ struct DedupWs {
 
   // --- run dedup of the pipelined step (mhte_step_kernels.h); own scratch, independent of the
   // list-building dedup above
-  DevBuf<int64_t> r_hkey, r_btab_key;
-  DevBuf<uint32_t> r_hcnt, r_hpos, r_hlist, r_uslot, r_ucnt, r_upos, r_btab_val, r_item_runs, r_ctr;
+  DevBuf<RdSlot> r_hs;
+  DevBuf<int64_t> r_btab_key;
+  DevBuf<uint32_t> r_hlist, r_uslot, r_ucnt, r_upos, r_btab_val, r_item_runs, r_ctr;
   DevBuf<unsigned long long> r_hblk, r_ublk;
   DevBuf<uint16_t> r_seg;
   DevBuf<ItemHdr> r_item_hdr;
@@ -329,12 +330,9 @@ struct DedupWs {
       throw Error(MHTE_INVALID_ARGUMENT, "step: batch must have 1.." +
                                              std::to_string(kRdMaxBlocks * kRdBlock) + " ids");
     const uint32_t C = 1u << std::max<uint32_t>(10, ceil_log2(uint64_t(2) * n));
-    const int64_t* old_key = r_hkey.p;
+    const RdSlot* old_key = r_hs.p;
     const uint32_t* old_ctr = r_ctr.p;
-    r_hkey.reserve(size_t(C) + 2);
-    r_hcnt.reserve(size_t(C) + 2);
-    r_hblk.reserve(size_t(C) + 2);
-    r_hpos.reserve(size_t(C) + 2);
+    r_hs.reserve(size_t(C) + 2);
     r_hlist.reserve((size_t(C) + 2) * kLightMax);
     r_ctr.reserve(4);
     const uint32_t nblk = uint32_t((n + kRdBlock - 1) / kRdBlock);
@@ -348,12 +346,12 @@ struct DedupWs {
     r_item_hdr.reserve(max_items(n));
     r_item_runs.reserve(size_t(max_items(n)) * 64);
     RunView d{};
-    d.hkey = r_hkey.p; d.hcnt = r_hcnt.p; d.hblk = r_hblk.p; d.hpos = r_hpos.p; d.hlist = r_hlist.p; d.cap_mask = C - 1;
+    d.hs = r_hs.p; d.hblk = nullptr; d.hlist = r_hlist.p; d.cap_mask = C - 1;
     d.uslot = r_uslot.p; d.ucnt = r_ucnt.p; d.ublk = r_ublk.p; d.upos = r_upos.p; d.btab_key = r_btab_key.p; d.btab_val = r_btab_val.p; d.seg = r_seg.p;
     d.item_hdr = r_item_hdr.p; d.item_runs = r_item_runs.p; d.ctr = r_ctr.p;
     d.ids = ids; d.n = uint32_t(n); d.nblk = nblk; d.uids = uids; d.n_unique = n_unique_dev;
     d.item_target = item_target();
-    if (r_hkey.p != old_key || r_ctr.p != old_ctr || C > r_clean_cap || r_stage == 1) {
+    if (r_hs.p != old_key || r_ctr.p != old_ctr || C > r_clean_cap || r_stage == 1) {
       rd_clear_kernel<<<(C + 2 + 255) / 256, 256, 0, st>>>(d);
       r_clean_cap = C;
     }

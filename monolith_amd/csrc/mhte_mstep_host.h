@@ -97,10 +97,8 @@ struct MultiStep {
     const uint32_t items = DedupWs::max_items(n);
     for (int sl = 0; sl < 2; ++sl) {
       RunView d{};
-      d.hkey = A.take<int64_t>(size_t(C) + 2);
-      d.hcnt = A.take<uint32_t>(size_t(C) + 2);
-      d.hblk = A.take<unsigned long long>(size_t(C) + 2);
-      d.hpos = A.take<uint32_t>(size_t(C) + 2);
+      d.hs = A.take<RdSlot>(size_t(C) + 2);
+      d.hblk = nullptr;
       d.hlist = A.take<uint32_t>((size_t(C) + 2) * kLightMax);
       d.cap_mask = C - 1;
       d.uslot = A.take<uint32_t>(size_t(n) + 1);

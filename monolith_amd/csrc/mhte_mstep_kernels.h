@@ -108,9 +108,7 @@ __global__ __launch_bounds__(256) void mstep_clear_kernel(ConstStatics st, uint3
     const RunView d = s.rv[sl];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i <= d.cap_mask + 1u) {
-      d.hkey[i] = kEmptyKey;
-      d.hcnt[i] = 0;
-      d.hpos[i] = 0;
+      d.hs[i] = RdSlot{kEmptyKey, 0ull};
     }
     if (i < 4) d.ctr[i] = 0;
   }

@@ -82,12 +82,21 @@ struct ItemHdr {   // one heavy work item: workgroups [b0, b0 + nbk) of list u
   uint32_t meta;   // b0 | nbk << 8 | k << 16 | nitems << 24   (nbk 1..64, k < nitems <= 64)
 };
 
+// One slot of the global scratch hash: key, count and a position share 16 bytes, so a run's CAS,
+// count bump and position store touch ONE line (three arrays cost three lines per run and two
+// partial-line write-backs per slot at reset: PMC, profiles/r02), and the build role's scan / reset
+// is one 16-byte load / store per slot.
+struct __attribute__((aligned(16))) RdSlot {
+  int64_t key;
+  unsigned long long cp;        // low half: occurrences of the slot's id in the batch; high half:
+                                // the sum of one position per run — THE position when the id
+                                // occurs once (one 64-bit add per run sets both)
+};
+
 struct RunView {
   // global scratch hash, capacity cap_mask + 1 (+1 side slot); all-empty between uses
-  int64_t* hkey;
-  uint32_t* hcnt;               // occurrences of the slot's id in the batch
+  RdSlot* hs;
   unsigned long long* hblk;     // (unused since r2: one atomic less per run; kept for layout)
-  uint32_t* hpos;               // position of an occurrence (the only one when hcnt == 1)
   uint32_t* hlist;              // [slots][kLightMax] the positions of a light list (<= kLightMax
                                 //     occurrences), runs in arrival order; never scanned or reset
   uint32_t cap_mask;
@@ -113,9 +122,7 @@ struct RunView {
 __global__ __launch_bounds__(256) void rd_clear_kernel(RunView d) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= d.cap_mask + 1u) {
-    d.hkey[i] = kEmptyKey;
-    d.hcnt[i] = 0;
-    d.hpos[i] = 0;
+    d.hs[i] = RdSlot{kEmptyKey, 0ull};
   }
   if (i < 4) d.ctr[i] = 0;
 }
@@ -187,11 +194,11 @@ __device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, Rd
   if (speaker) {
     if (id == kEmptyKey) {
       gs = d.cap_mask + 1u;
-      cas_old = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hkey[gs]),
+      cas_old = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hs[gs].key),
                                                static_cast<unsigned long long>(kEmptyKey), 0ull));
     } else {
       gs = uint32_t(hash_key(id)) & d.cap_mask;
-      cas_old = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hkey[gs]),
+      cas_old = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hs[gs].key),
                                                static_cast<unsigned long long>(kEmptyKey),
                                                static_cast<unsigned long long>(id)));
     }
@@ -273,7 +280,7 @@ __device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, Rd
     if (id != kEmptyKey) {
       while (cas_old != kEmptyKey && cas_old != id) {
         gs = (gs + 1u) & d.cap_mask;
-        cas_old = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hkey[gs]),
+        cas_old = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hs[gs].key),
                                                  static_cast<unsigned long long>(kEmptyKey),
                                                  static_cast<unsigned long long>(id)));
       }
@@ -281,8 +288,8 @@ __device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, Rd
     // (which workgroups hold a run of the id is not recorded: device-scope atomics are the scarce
     // resource of this role — ~36 G/s on MI355X, scripts/mstep_probe.py — and the few heavy ids
     // find their runs by probing every workgroup's directory, rd_find_run_opt)
-    lbase = atomicAdd(&d.hcnt[gs], L.cnt[ls]);
-    d.hpos[gs] = p;                          // read only when the id turns out to occur once
+    lbase = uint32_t(atomicAdd(&d.hs[gs].cp, (static_cast<unsigned long long>(p) << 32) |
+                                                 static_cast<unsigned long long>(L.cnt[ls])));
   }
   // ---- the LDS table is the workgroup's run directory
   for (uint32_t i = t; i < uint32_t(kRdStride); i += kRdBlock) {
@@ -411,17 +418,17 @@ __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_m
     for (int q = 0; q < Q; ++q) {
       const uint32_t sl = base + q * 64 + lane;
       const bool in = sl < nslots;
-      key[q] = in ? d.hkey[sl] : kEmptyKey;
-      cnt[q] = in ? d.hcnt[sl] : 0u;
-      pos[q] = in ? d.hpos[sl] : 0u;
+      const RdSlot sv = d.hs[in ? sl : 0u];   // (one 16-byte load from a safe index, masked below)
+      key[q] = in ? sv.key : kEmptyKey;
+      cnt[q] = in ? uint32_t(sv.cp) : 0u;
+      pos[q] = in ? uint32_t(sv.cp >> 32) : 0u;
     }
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const uint32_t sl = base + q * 64 + lane;
       const bool o = key[q] != kEmptyKey;
       if (o) {  // clean-after-use: the scratch is all-empty again after this launch
-        d.hkey[sl] = kEmptyKey;
-        d.hcnt[sl] = 0;
+        d.hs[sl] = RdSlot{kEmptyKey, 0ull};   // (one 16-byte store)
         if (sl == d.cap_mask + 1u) key[q] = kEmptyKey;  // the side slot stands for that id itself
       }
       occ[q] = __ballot(o);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit: parity tests, bench line, rocprofv3 kernel trace of a short bench.
 # Usage (from the repo root on the GPU box): bash scripts/gpu_round.sh <tag> [what...]
-#   what: tests smoke bench prof tl trace pmc calib next cfg1 dlrm dlrmdense dlrmprof shard shardprof
+#   what: tests smoke bench prof tl trace pmc calib next cfg1 dlrm dlrmdense dlrmprof dlrmpmc shard shardprof
 #   (default: tests bench prof)
 set -u
 TAG=${1:-r01}; shift || true
@@ -71,6 +71,13 @@ dlrmprof)
   echo "dlrmprof rc=$?"
   db=$(find /tmp/dprof -name '*.db' | head -1)
   if [ -n "$db" ]; then python scripts/rocpd_stats.py $db $OUT/kernel_stats_dlrm26.md | head -14; fi ;;
+dlrmpmc)
+  for c in "FETCH_SIZE" "WRITE_SIZE"; do
+    rm -rf /tmp/dpmc_$c && timeout -k 5 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/dpmc_$c -o pmc -- \
+      python bench.py --config dlrm26 --steps 30 --warmup 10 --no-cpu-baseline --no-parity-check > $OUT/pmc_dlrm_$c.json 2> $OUT/pmc_dlrm_$c.err
+    echo "dlrmpmc $c rc=$?"
+    for f in $(find /tmp/dpmc_$c -name '*counter_collection*.csv'); do python scripts/pmc_csv.py $f > $OUT/pmc_dlrm_${c}.md; grep mstep $OUT/pmc_dlrm_${c}.md; done
+  done ;;
 shard)
   timeout -k 5 600 python bench.py --force-sharded --no-cpu-baseline > $OUT/bench_sharded_n1.json 2> $OUT/bench_sharded_n1.err
   echo "shard rc=$?"; cut -c1-400 $OUT/bench_sharded_n1.json

@@ -87,7 +87,38 @@ def main():
     kernels[name] = {"fetch_size_bytes": round(f[1]), "write_size_bytes": round(w[1]),
                      "dispatches": f[0], "read_bytes_corrected": round(rd),
                      "write_bytes_corrected": round(wr), "hbm_bytes_per_launch": round(rd + wr)}
-  out = {"source": tag, "method": method, "workload": cfgb.get("workload"), "kernels": kernels}
+  # ---- the multi-table step (configs[4]'s shape), when the visit has its PMC passes too
+  dl_f, dl_w = table(os.path.join(d, "pmc_dlrm_FETCH_SIZE.md")), table(os.path.join(d, "pmc_dlrm_WRITE_SIZE.md"))
+  dl_bench = os.path.join(d, "bench_dlrm26.json")
+  workload_dlrm = None
+  if dl_f and dl_w and os.path.exists(dl_bench):
+    db = json.loads(open(dl_bench).read().strip().splitlines()[-1])
+    dims, Bt, Ut = db["config"]["dims"], db["config"]["batch_per_table"], db["config"]["unique_ids_per_batch_mean"]
+    workload_dlrm = db["config"]["workload"]
+
+    def cls(nbytes):  # counter per byte of a random access of that width (64-B lines vs >= 128-B rows)
+      return c_buckets if nbytes <= 64 else c_rows
+
+    mix = {"lookup": [0.0, 0.0], "update": [0.0, 0.0]}   # [algorithmic read bytes, counter value expected]
+    for D_ in dims:
+      rowb, gradb = 8 * D_, 4 * D_                       # Adagrad row (w + accumulator), gradient row
+      look = [(8 * Ut, 0.5), (128 * Ut, c_buckets), (4 * D_ * Ut, cls(4 * D_))]
+      upd = [(24 * Ut, 0.5), (gradb * Bt, cls(gradb)), (rowb * Ut, cls(rowb))]   # hints: no bucket read
+      for k, parts in (("lookup", look), ("update", upd)):
+        for nbytes, c in parts:
+          mix[k][0] += nbytes
+          mix[k][1] += nbytes * c
+    for name, r in (("mstep_fwd_kernel", "lookup"), ("mstep_bwd_kernel", "update")):
+      f, w = find(dl_f, name), find(dl_w, name)
+      if not f or not w:
+        continue
+      rd = f[1] * mix[r][0] / mix[r][1]
+      wr = w[1] / c_write
+      kernels[name] = {"fetch_size_bytes": round(f[1]), "write_size_bytes": round(w[1]),
+                       "dispatches": f[0], "read_bytes_corrected": round(rd),
+                       "write_bytes_corrected": round(wr), "hbm_bytes_per_launch": round(rd + wr)}
+  out = {"source": tag, "method": method, "workload": cfgb.get("workload"),
+         "workload_multi_table": workload_dlrm, "kernels": kernels}
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   with open(os.path.join(root, "profiles", "pmc_traffic.json"), "w") as fp:
     json.dump(out, fp, indent=1)
