@@ -305,7 +305,6 @@ struct DedupWs {
   DevBuf<RdSlot> r_hs;
   DevBuf<int64_t> r_btab_key;
   DevBuf<uint32_t> r_hlist, r_uslot, r_ucnt, r_upos, r_btab_val, r_item_runs, r_ctr;
-  DevBuf<unsigned long long> r_hblk, r_ublk;
   DevBuf<uint16_t> r_seg;
   DevBuf<ItemHdr> r_item_hdr;
   DevBuf<uint32_t> r_cursor;   // shard packing cursors
@@ -338,7 +337,6 @@ struct DedupWs {
     const uint32_t nblk = uint32_t((n + kRdBlock - 1) / kRdBlock);
     r_uslot.reserve(size_t(n) + 1);
     r_ucnt.reserve(size_t(n) + 1);
-    r_ublk.reserve(size_t(n) + 1);
     r_upos.reserve(size_t(n) + 1);
     r_btab_key.reserve(size_t(nblk) * kRdStride);
     r_btab_val.reserve(size_t(nblk) * kRdStride);
@@ -346,8 +344,8 @@ struct DedupWs {
     r_item_hdr.reserve(max_items(n));
     r_item_runs.reserve(size_t(max_items(n)) * 64);
     RunView d{};
-    d.hs = r_hs.p; d.hblk = nullptr; d.hlist = r_hlist.p; d.cap_mask = C - 1;
-    d.uslot = r_uslot.p; d.ucnt = r_ucnt.p; d.ublk = r_ublk.p; d.upos = r_upos.p; d.btab_key = r_btab_key.p; d.btab_val = r_btab_val.p; d.seg = r_seg.p;
+    d.hs = r_hs.p; d.hlist = r_hlist.p; d.cap_mask = C - 1;
+    d.uslot = r_uslot.p; d.ucnt = r_ucnt.p; d.upos = r_upos.p; d.btab_key = r_btab_key.p; d.btab_val = r_btab_val.p; d.seg = r_seg.p;
     d.item_hdr = r_item_hdr.p; d.item_runs = r_item_runs.p; d.ctr = r_ctr.p;
     d.ids = ids; d.n = uint32_t(n); d.nblk = nblk; d.uids = uids; d.n_unique = n_unique_dev;
     d.item_target = item_target();

@@ -98,12 +98,10 @@ struct MultiStep {
     for (int sl = 0; sl < 2; ++sl) {
       RunView d{};
       d.hs = A.take<RdSlot>(size_t(C) + 2);
-      d.hblk = nullptr;
       d.hlist = A.take<uint32_t>((size_t(C) + 2) * kLightMax);
       d.cap_mask = C - 1;
       d.uslot = A.take<uint32_t>(size_t(n) + 1);
       d.ucnt = A.take<uint32_t>(size_t(n) + 1);
-      d.ublk = A.take<unsigned long long>(size_t(n) + 1);
       d.upos = A.take<uint32_t>(size_t(n) + 1);
       d.btab_key = A.take<int64_t>(size_t(nblk) * kRdStride);
       d.btab_val = A.take<uint32_t>(size_t(nblk) * kRdStride);

@@ -152,7 +152,8 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward: per table   run dedup of the NEXT batch | lookup of this batch
+// forward: per table, lookup of this batch (the run dedup of the NEXT batch is its own launch,
+// mstep_dedup_kernel: 1024-thread workgroups do not share a launch with these 256-thread ones)
 //
 // The batch being looked up was deduplicated and numbered a step ahead, so the lookup probes each
 // DISTINCT id once (U ~ 12 k of B = 65 536 under Zipf(1.2)) and scatters its row to the id's

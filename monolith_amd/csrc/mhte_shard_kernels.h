@@ -41,7 +41,7 @@ struct ShardGeom {
   uint32_t rows_block;   // floats per peer block
 };
 
-enum : uint32_t { kShardOverflow = 1u, kShardBadHeader = 2u };
+enum : uint32_t { kShardOverflow = 1u };
 
 // ---- owner: lookup of the received blocks ---------------------------------------------------------
 struct ShardOwnerArgs {

@@ -96,14 +96,12 @@ struct __attribute__((aligned(16))) RdSlot {
 struct RunView {
   // global scratch hash, capacity cap_mask + 1 (+1 side slot); all-empty between uses
   RdSlot* hs;
-  unsigned long long* hblk;     // (unused since r2: one atomic less per run; kept for layout)
   uint32_t* hlist;              // [slots][kLightMax] the positions of a light list (<= kLightMax
                                 //     occurrences), runs in arrival order; never scanned or reset
   uint32_t cap_mask;
   // per batch
   uint32_t* uslot;              // [n] dense copies made by the build role: scratch slot,
   uint32_t* ucnt;               //     occurrences,
-  unsigned long long* ublk;     //     (unused since r2),
   uint32_t* upos;               //     a position (the only one when ucnt == 1) of unique index u
   int64_t* btab_key;            // [nblk][kRdStride] dumped LDS tables
   uint32_t* btab_val;           // [nblk][kRdStride] run_pack
