@@ -7,10 +7,9 @@ import subprocess
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_DIR, "libmhte.so")
 _SRC = os.path.join(_DIR, "csrc", "mhte.hip")
-_DEPS = [_SRC] + [os.path.join(_DIR, "csrc", h) for h in
-                  ("mhte_kernels.h", "mhte_core.h", "mhte_step_kernels.h", "mhte_pool_kernels.h",
-                   "mhte_ckpt.h", "mhte_mstep_kernels.h", "mhte_mstep_host.h", "mhte_proto_config.h",
-                   "mhte_layout_kernels.h")] + [os.path.join(_DIR, "..", "include", "monolith_amd_hash_table.h")]
+# every header under csrc/ (a new one must not leave a stale library looking current)
+_DEPS = [_SRC] + sorted(os.path.join(_DIR, "csrc", h) for h in os.listdir(os.path.join(_DIR, "csrc"))
+                        if h.endswith(".h")) + [os.path.join(_DIR, "..", "include", "monolith_amd_hash_table.h")]
 # A/B measurements: MHTE_LIBRARY=<other build of libmhte.so> (same ABI) is loaded instead
 _OVERRIDE = os.environ.get("MHTE_LIBRARY")
 
