@@ -53,7 +53,10 @@ class Spec:
            "ftrl": lambda: entry.FtrlOptimizer(lr, 0.1, 1.0, l1_regularization=0.001,
                                                    l2_regularization=0.001)}[opt]()
       parts.append(entry.CombineAsSegment(d, entry.ZerosInitializer(), o))
-    return entry.make_table_config(parts, entry.CuckooHashTableConfig(**self.kw))
+    ttl = getattr(self, "ttl_days", None)
+    return entry.make_table_config(
+        parts, entry.CuckooHashTableConfig(**self.kw),
+        slot_expire_time_config=None if ttl is None else entry.SlotExpireTimeConfig(default_expire_time=ttl))
 
   def oracle_table(self):
     segs = []
@@ -64,7 +67,10 @@ class Spec:
         segs.append(O.segment(d, O.OPT_ADAGRAD, p=(0.1, 0.0)))
       else:
         segs.append(O.segment(d, O.OPT_FTRL, p=(0.1, 1.0, 0.001, 0.001)))
-    return O.Table(segs if len(segs) > 1 else segs[0], int(self.kw.get("initial_capacity", 1)))
+    t = O.Table(segs if len(segs) > 1 else segs[0], int(self.kw.get("initial_capacity", 1)))
+    if getattr(self, "ttl_days", None) is not None:
+      t.set_ttl(self.ttl_days)
+    return t
 
   def lrs(self):
     return [lr for _, _, lr in self.segs]
@@ -319,6 +325,59 @@ def test_multi_step_displacement_and_doubling():
     assert st.dropped == 0 and st.hashpower == 11 and st.size > 0.5 * (1 << 13)
   for sp in grow:
     assert mt.stats(sp.name).hashpower >= 11
+
+
+def test_hints_do_not_survive_a_table_change_between_forward_and_backward():
+  """The forward leaves (row handle, bucket slot) hints for the backward.  An eviction scan, an
+  assign that displaces entries or a doubling between the two calls makes them stale
+  (Table::mut_epoch): the backward must probe again.  Here half of the looked-up ids expire and are
+  evicted, and a burst of assigns doubles the table, after the forward and before the backward."""
+  specs = dlrm_specs(4, initial_capacity=1 << 11)
+  for sp in specs:
+    sp.ttl_days = 1
+  by_name = sorted(specs, key=lambda s: s.name)
+  mt = make(specs)
+  ots = {s.name: s.oracle_table() for s in specs}
+  B = 1500
+  step = MultiSparseStep(mt, B, exact_order=True)
+  rng = np.random.default_rng(11)
+  day = 86400
+  t0 = S.update_time(0)
+
+  def ids_of(sp, lo, hi):
+    return (rng.integers(lo, hi, B).astype(np.int64)) | (sp.slot << 48)
+
+  # step 0 at time t0: ids in [1, 1000); step 1 two days later looks up the same range
+  for s_, now in ((0, t0), (1, t0 + 2 * day)):
+    batch = {sp.name: ids_of(sp, 1, 1000) for sp in specs}
+    rag = ragged_of(specs, mt, batch)
+    emb = step.forward(rag, None)
+    views = mt.get_embeddings(rag, emb)
+    for sp in by_name:
+      np.testing.assert_array_equal(views[sp.name].cpu().numpy(), ots[sp.name].lookup(batch[sp.name])[0])
+    if s_ == 1:
+      # between forward and backward: everything last touched at t0 expires (TTL 1 day) ...
+      for sp in by_name:
+        mt.evict(sp.name, now)
+        ots[sp.name].evict(now)
+        # ... and 6 000 fresh ids double the table
+        fresh = (np.arange(5000, 11000, dtype=np.int64)) | (sp.slot << 48)
+        vals = np.full((fresh.size, sp.dim), 0.5, np.float32)
+        mt.assign({sp.name: (ids_t(fresh), val_t(vals))}, req_time=now)
+        ots[sp.name].assign(fresh, vals, now)
+    flat = []
+    for sp in by_name:
+      g = seeded_grads(s_, sp, B)
+      flat.append(g.ravel())
+      uk, gu = oracle_backward(ots[sp.name], sp, batch[sp.name], g)
+      ots[sp.name].optimize(uk, gu, sp.lrs(), now)
+    step.backward(val_t(np.concatenate(flat)), now)
+  for sp in by_name:
+    allids = np.concatenate([np.arange(1, 1000, dtype=np.int64), np.arange(5000, 11000, dtype=np.int64)]) | (sp.slot << 48)
+    got = mt.lookup({sp.name: ids_t(allids)})[sp.name].cpu().numpy()
+    np.testing.assert_array_equal(got, ots[sp.name].lookup(allids)[0], err_msg=sp.name)
+    assert mt.size(sp.name) == ots[sp.name].size()
+    assert mt.stats(sp.name).evicted > 0
 
 
 def test_multi_step_errors():
