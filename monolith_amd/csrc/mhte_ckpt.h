@@ -24,6 +24,10 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <stdexcept>
@@ -610,11 +614,29 @@ class RecordWriter {
 class RecordReader {
  public:
   RecordReader(const std::string& path, bool snappy) : snappy_(snappy), path_(path) {
+    if (snappy) {
+      // the block stream is decoded straight out of a read-only mapping: no copy into a staging
+      // buffer in front of the decoder (falls back to stdio when the file cannot be mapped)
+      const int fd = open(path.c_str(), O_RDONLY);
+      if (fd < 0) throw std::runtime_error("cannot open " + path);
+      struct stat sb;
+      if (fstat(fd, &sb) == 0 && sb.st_size > 0) {
+        void* m = mmap(nullptr, size_t(sb.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+          map_ = static_cast<const uint8_t*>(m);
+          map_size_ = size_t(sb.st_size);
+          (void)madvise(m, map_size_, MADV_SEQUENTIAL);
+        }
+      }
+      close(fd);
+      if (map_) return;
+    }
     fp_ = fopen(path.c_str(), "rb");
     if (!fp_) throw std::runtime_error("cannot open " + path);
   }
   ~RecordReader() {
     if (fp_) fclose(fp_);
+    if (map_) munmap(const_cast<uint8_t*>(map_), map_size_);
   }
   // false at a clean end of file; throws on corruption (errors::DataLoss in the reference)
   bool read(std::string* rec) {
@@ -736,32 +758,49 @@ class RecordReader {
       out.resize(base + got);
       return got != 0;
     }
+    const uint8_t* blk;
+    uint32_t cl;
+    if (!next_compressed(&blk, &cl)) return false;
+    if (!snappy_uncompress(blk, cl, out)) throw std::runtime_error("corrupted snappy block in " + path_);
+    return true;
+  }
+  // the next [4-byte big-endian length | block] of the file: *blk points into the mapping (or comp_)
+  bool next_compressed(const uint8_t** blk, uint32_t* len) {
     uint8_t be[4];
-    const size_t got = fread(be, 1, 4, fp_);
-    if (got == 0) return false;
-    if (got != 4) throw std::runtime_error("truncated snappy block header in " + path_);
+    if (map_) {
+      if (map_pos_ == map_size_) return false;
+      if (map_size_ - map_pos_ < 4) throw std::runtime_error("truncated snappy block header in " + path_);
+      memcpy(be, map_ + map_pos_, 4);
+    } else {
+      const size_t got = fread(be, 1, 4, fp_);
+      if (got == 0) return false;
+      if (got != 4) throw std::runtime_error("truncated snappy block header in " + path_);
+    }
     const uint32_t cl = (uint32_t(be[0]) << 24) | (uint32_t(be[1]) << 16) | (uint32_t(be[2]) << 8) | be[3];
-    comp_.resize(cl);
-    if (fread(&comp_[0], 1, cl, fp_) != cl) throw std::runtime_error("truncated snappy block in " + path_);
-    if (!snappy_uncompress(reinterpret_cast<const uint8_t*>(comp_.data()), cl, out))
-      throw std::runtime_error("corrupted snappy block in " + path_);
+    if (map_) {
+      if (map_size_ - map_pos_ - 4 < cl) throw std::runtime_error("truncated snappy block in " + path_);
+      *blk = map_ + map_pos_ + 4;
+      map_pos_ += size_t(4) + cl;
+    } else {
+      comp_.resize(cl);
+      if (fread(&comp_[0], 1, cl, fp_) != cl) throw std::runtime_error("truncated snappy block in " + path_);
+      *blk = reinterpret_cast<const uint8_t*>(comp_.data());
+    }
+    *len = cl;
     return true;
   }
   bool next_block() {
-    uint8_t be[4];
-    const size_t got = fread(be, 1, 4, fp_);
-    if (got == 0) return false;
-    if (got != 4) throw std::runtime_error("truncated snappy block header in " + path_);
-    const uint32_t cl = (uint32_t(be[0]) << 24) | (uint32_t(be[1]) << 16) | (uint32_t(be[2]) << 8) | be[3];
-    comp_.resize(cl);
-    if (fread(&comp_[0], 1, cl, fp_) != cl) throw std::runtime_error("truncated snappy block in " + path_);
+    const uint8_t* blk;
+    uint32_t cl;
+    if (!next_compressed(&blk, &cl)) return false;
     buf_.clear();
     pos_ = 0;
-    if (!snappy_uncompress(reinterpret_cast<const uint8_t*>(comp_.data()), cl, buf_))
-      throw std::runtime_error("corrupted snappy block in " + path_);
+    if (!snappy_uncompress(blk, cl, buf_)) throw std::runtime_error("corrupted snappy block in " + path_);
     return true;
   }
   FILE* fp_ = nullptr;
+  const uint8_t* map_ = nullptr;   // snappy files: the whole file, read-only
+  size_t map_size_ = 0, map_pos_ = 0;
   bool snappy_;
   std::string path_, buf_, comp_, carry_;
   size_t pos_ = 0;
