@@ -691,12 +691,36 @@ def main():
   else:
     # the id-sharded step, enqueued from C++ (csrc/mhte_shard_host.h): kernels + RCCL send / recv
     # groups on this stream; world == 1: the exchange is the identity
-    from monolith_amd.distributed_ps_sync import ShardedMultiStep
+    from monolith_amd.distributed_ps_sync import HipBackend, ShardedEmbedding, ShardedMultiStep
     from monolith_amd.multi_hash_table_ops import Ragged
-    se = ShardedMultiStep(mt, B, ids_per_peer_table=args.ids_per_peer)
     splits1 = np.array([0, B], dtype=np.int64)
     rag = [Ragged(ids_all[s], splits1) for s in range(n_batches)]
     emb_out = torch.empty(B * D, dtype=torch.float32, device=dev)
+    if world > 1 and args.dist_backend == "gloo":
+      # ranks sharing one GPU (the 1-GPU box): RCCL cannot put two ranks on a device, so the N > 1
+      # control flow of this file is exercised through round 1's torch.distributed form of the step,
+      # its exchanges staged through host memory by gloo — not a scaling number
+      class _GlooStep:
+        def __init__(self):
+          self.se = ShardedEmbedding(HipBackend(mt, "emb"))
+
+        def forward(self, r, nxt, out=None):
+          out.copy_(self.se.lookup(r.values, next_ids=nxt.values).view(-1))
+
+        def backward(self, g, t):
+          self.se.apply_gradients(g.view(B, D), t)
+
+        def check(self):
+          torch.cuda.synchronize()
+
+        def info(self):
+          return {"transport": "torch.distributed gloo (host staged)"}
+
+        def close(self):
+          pass
+      se = _GlooStep()
+    else:
+      se = ShardedMultiStep(mt, B, ids_per_peer_table=args.ids_per_peer)
 
     host_us = []   # MHTE_BENCH_STEP_TIMES=1: host time of every step's two calls (stall hunting)
     trace_host = os.environ.get("MHTE_BENCH_STEP_TIMES") == "1"
