@@ -1,0 +1,109 @@
+"""CPU suite: the hand-written proto-wire reader behind mhte_multi_table_create_from_proto
+(csrc/mhte_proto_config.h) decodes the serialized MultiEmbeddingHashTableConfig BEFORE it needs a
+device, so its error behaviour is testable here: a config the reader rejects returns
+InvalidArgument with the reason; one it accepts gets as far as "no HIP device" (the engine has no
+CPU path).  The configs are built with the protobuf runtime on restated descriptors
+(tests/ckpt_proto.py), i.e. by an independent encoder.  Reference:
+runtime/ops/multi_hash_table_op.cc:60-112 (ParseFromString + config checks)."""
+import ctypes as C
+
+import pytest
+import torch
+
+from monolith_amd import _lib
+from tests import ckpt_proto as P
+
+pytestmark = pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only: with a device the create succeeds")
+
+
+def _create(blob):
+  L = _lib.lib()
+  h = C.c_void_p()
+  lrs = (C.c_float * 64)()
+  st = L.mhte_multi_table_create_from_proto(blob, C.c_int64(len(blob)), None, C.c_uint64(0),
+                                            C.c_float(0.0), C.c_int32(0), b"cpu_test", lrs,
+                                            C.c_int32(64), C.byref(h))
+  return st, L.mhte_last_error().decode()
+
+
+def _empty_submessage(field):
+  """wire bytes of `field { }` (length-delimited, empty)"""
+  tag, out = (field << 3) | 2, bytearray()
+  while tag >= 0x80:
+    out.append((tag & 0x7f) | 0x80)
+    tag >>= 7
+  out.append(tag)
+  out.append(0)
+  return bytes(out)
+
+
+def _one_table(mutate):
+  m = P.MultiEmbeddingHashTableConfig()
+  m.names.append("t")
+  c = m.configs.add()
+  c.cuckoo.SetInParent()
+  s = c.entry_config.segments.add()
+  s.dim_size = 4
+  s.init_config.zeros.dim_size = 4
+  s.opt_config.adagrad.learning_rate = 0.1
+  s.opt_config.adagrad.initial_accumulator_value = 0.1
+  mutate(m, c, s)
+  return m.SerializeToString()
+
+
+def test_a_valid_config_gets_as_far_as_the_missing_device():
+  st, msg = _create(_one_table(lambda m, c, s: None))
+  assert st == _lib.MHTE_UNAVAILABLE, (st, msg)
+  assert "HIP" in msg or "device" in msg
+
+
+def test_every_supported_optimizer_and_initializer_parses():
+  # OptimizerConfig's oneof field numbers (optimizer.proto): written as raw wire bytes (tag, empty
+  # message) so that arms the restated descriptors do not carry are covered too
+  arms = {"adagrad": 1, "sgd": 2, "ftrl": 3, "adadelta": 6, "adam": 7, "amsgrad": 8, "momentum": 9,
+          "moving_average": 10, "rmsprop": 11, "rmspropv2": 12, "batch_softmax": 15, "group_adagrad": 16}
+  for arm, num in arms.items():
+    def mut(m, c, s, arm=arm, num=num):
+      s.opt_config.Clear()
+      s.opt_config.MergeFromString(_empty_submessage(num))
+      if arm == "batch_softmax":
+        s.dim_size = 1
+        s.init_config.zeros.dim_size = 1
+    st, msg = _create(_one_table(mut))
+    assert st == _lib.MHTE_UNAVAILABLE, (arm, st, msg)
+  for init in ("zeros", "ones", "constants", "random_uniform"):
+    def mut(m, c, s, init=init):
+      s.init_config.Clear()
+      getattr(s.init_config, init).SetInParent()
+    st, msg = _create(_one_table(mut))
+    assert st == _lib.MHTE_UNAVAILABLE, (init, st, msg)
+  # arms that are not built: dc (13) and group_ftrl (14)
+  for num in (13, 14):
+    def mut(m, c, s, num=num):
+      s.opt_config.Clear()
+      s.opt_config.MergeFromString(_empty_submessage(num))
+    st, msg = _create(_one_table(mut))
+    assert st == _lib.MHTE_INVALID_ARGUMENT and "not implemented" in msg, (num, st, msg)
+
+
+@pytest.mark.parametrize("case", ["garbage", "truncated", "names_mismatch", "no_tables", "dc_optimizer",
+                                  "no_segments"])
+def test_rejected_configs_say_why(case):
+  if case == "garbage":
+    blob = b"\xff\xff\xff\xff\x07"
+  elif case == "truncated":
+    blob = _one_table(lambda m, c, s: None)[:-3]
+  elif case == "names_mismatch":
+    blob = _one_table(lambda m, c, s: m.names.append("extra"))
+  elif case == "no_tables":
+    blob = P.MultiEmbeddingHashTableConfig().SerializeToString() or b"\x0a\x00"[:0] or b" "
+  elif case == "dc_optimizer":
+    def mut(m, c, s):
+      s.opt_config.Clear()
+      s.opt_config.dc.lambda_ = 0.1
+    blob = _one_table(mut)
+  else:
+    blob = _one_table(lambda m, c, s: c.entry_config.ClearField("segments"))
+  st, msg = _create(blob)
+  assert st == _lib.MHTE_INVALID_ARGUMENT, (case, st, msg)
+  assert msg, case
