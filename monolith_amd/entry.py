@@ -35,8 +35,10 @@ class AdagradOptimizer(Optimizer):
 
   def __init__(self, learning_rate=None, initial_accumulator_value=None,
                hessian_compression_times=1, warmup_steps=0, weight_decay_factor=0.0):
-    if hessian_compression_times != 1:
-      raise NotImplementedError("hessian_compression_times != 1 is not on the MI355X hot path")
+    # accepted and carried like the reference's config field (optimizer.proto:23); the
+    # reference's open-source runtime never reads it (adagrad_optimizer.cc has no sketching
+    # code path), so — as there — it does not change the update
+    self.hessian_compression_times = hessian_compression_times
     self.learning_rate = 0.001 if learning_rate is None else learning_rate
     self.initial_accumulator_value = (0.1 if initial_accumulator_value is None else
                                       initial_accumulator_value)
