@@ -19,6 +19,7 @@
 #include <atomic>
 #include <exception>
 #include <mutex>
+#include <future>
 #include <thread>
 #include <stdexcept>
 #include <string>
@@ -129,7 +130,7 @@ struct CkptStage {
   HostBuf<uint32_t> h_ts;
   HostBuf<float> h_rows;
   std::vector<std::string> parts;
-  std::string arena;
+  std::string arena[2];   // restore: the stretch being decoded and the one being read ahead
 };
 
 // host threads per checkpoint shard for the EntryDump codec (MHTE_CKPT_THREADS; shards run beside
@@ -2218,16 +2219,49 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
       ~Return() { t->give_stage(std::move(s)); }
     } give_back{t, sgp};
     CkptStage& sg = *sgp;
-    std::vector<ckpt::RecordReader::RecRef> refs;
+    // Two stretches: while the records of one are verified, decoded and upserted, a helper thread
+    // reads and unpacks the next one (the reader is only ever used by that one thread at a time).
+    std::vector<ckpt::RecordReader::RecRef> refs_buf[2];
+    int use = 0;                      // stretch in use: sg.arena[use], refs_buf[use]
     size_t cur = 0;
     const size_t kStretch = size_t(64) << 20;
-    // up to `want` records of the stream -> (first, count) in refs; 0 at the end of the file
-    auto take = [&](uint64_t want, size_t* first) -> size_t {
-      if (cur == refs.size()) {
-        cur = 0;
-        if (!data.read_batch(sg.arena, kStretch, refs)) return 0;
+    std::future<bool> ahead;          // the read into the other stretch
+    auto read_into = [&](int b) {
+      ahead = std::async(std::launch::async,
+                         [&, b] { return data.read_batch(sg.arena[b], kStretch, refs_buf[b]); });
+    };
+    struct Drain {                    // never leave the helper running into freed buffers
+      std::future<bool>& f;
+      ~Drain() {
+        if (f.valid()) {
+          try {
+            (void)f.get();
+          } catch (...) {
+          }
+        }
       }
-      const size_t k = size_t(std::min<uint64_t>(want, refs.size() - cur));
+    } drain{ahead};
+    read_into(0);
+    bool started = false, at_end = false;
+    size_t avail = 0;   // records of the stretch in use (this thread's view: the helper may be
+                        // filling the other stretch's vectors right now)
+    // up to `want` records of the stream -> (first, count) in refs_buf[use]; 0 at the end of the file
+    auto take = [&](uint64_t want, size_t* first) -> size_t {
+      if (cur == avail) {
+        if (at_end) return 0;
+        const int nxt = started ? (use ^ 1) : 0;
+        const bool got = ahead.get();          // (rethrows the reader's errors)
+        started = true;
+        use = nxt;
+        cur = 0;
+        avail = got ? refs_buf[use].size() : 0;
+        if (!got) {
+          at_end = true;
+          return 0;
+        }
+        read_into(use ^ 1);
+      }
+      const size_t k = size_t(std::min<uint64_t>(want, avail - cur));
       *first = cur;
       cur += k;
       return k;
@@ -2290,7 +2324,8 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
         const size_t nb = take(std::min<uint64_t>(kBatch, num - done), &first);
         if (!nb) throw Error(MHTE_INTERNAL, "checkpoint shard ends early");
         const double t1 = now();
-        const char* base = sg.arena.data();
+        const char* base = sg.arena[use].data();
+        const std::vector<ckpt::RecordReader::RecRef>& refs = refs_buf[use];
         parallel_ranges(nb, P, [&](size_t lo, size_t hi, int k) {
           int64_t mx = 0;
           for (size_t i = lo; i < hi; ++i) {
