@@ -582,6 +582,10 @@ mhte_status mhte_multi_step_unique_counts(mhte_multi_step* s, int64_t* counts, v
  *                       identity.  NULL with world > 1: the ranks live in this process on one device
  *                       and are driven together through mhte_shard_group_* (device copies stand in
  *                       for the links; tests).
+ * MHTE_SHARD_EXACT=1 in the environment at creation: the row / gradient exchanges move only the
+ * occupied part of every (peer, table) segment; the counts are the id blocks' headers, copied to
+ * pinned host memory behind the id exchange (a step ahead of their use for a batch that was
+ * prepared ahead).  Default: whole fixed-size blocks, nothing known to the host.
  * forward / backward arguments are those of mhte_multi_step_* for this rank's batch; `prefetched`
  * and the next batch must agree across the ranks (the calls are collective).  Tables with an
  * occurrence filter or whole-segment optimizers are rejected.  global_step reaches the optimizers. */

@@ -107,6 +107,15 @@ struct ShardStep {
   uint32_t* d_flags = nullptr;
   bool alias = false;           // world == 1 without a communicator
   ncclComm_t comm = nullptr;
+  // MHTE_SHARD_EXACT=1: the row / gradient exchanges move only the occupied part of every (peer,
+  // table) segment.  The counts are the id blocks' headers, copied to pinned host memory right
+  // after the id exchange — a step ahead of their first use when the batch was prepared ahead, so
+  // waiting for the copy costs nothing then.  Default off: the fixed-size form needs no host
+  // knowledge at all; which one wins on real links is a measurement for an N > 1 box.
+  bool exact = false;
+  int64_t* h_cnt[2] = {nullptr, nullptr};   // per slot [2 (sent | received)][world][hdr]
+  hipEvent_t ev_cnt[2] = {nullptr, nullptr};
+  uint32_t hdr_words = 0;
   bool hdr_dirty[2] = {false, false};   // the slot's send headers hold counts
   bool disp[2] = {false, false};        // the slot's batch has been dispatched (ids exchanged)
   bool ahead = false;                   // slot cur ^ 1 holds the batch the last forward was given as next
@@ -123,6 +132,10 @@ struct ShardStep {
     if (own_rows) (void)hipFree(own_rows);
     if (snd_rows && !alias) (void)hipFree(snd_rows);
     if (h_flags) (void)hipHostFree(h_flags);
+    for (int s = 0; s < 2; ++s) {
+      if (h_cnt[s]) (void)hipHostFree(h_cnt[s]);
+      if (ev_cnt[s]) (void)hipEventDestroy(ev_cnt[s]);
+    }
   }
 
   void init(mhte_multi_table* m, int64_t mb, int rank_, int world_, int64_t ids_per_peer_table,
@@ -153,6 +166,7 @@ struct ShardStep {
     geo.world = uint32_t(world);
     geo.T = T;
     const uint32_t hdr = (T + 7u) & ~7u;
+    hdr_words = hdr;
     tab.resize(T);
     uint64_t idw = hdr, rw = 0;
     for (uint32_t t = 0; t < T; ++t) {
@@ -188,6 +202,14 @@ struct ShardStep {
     HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&h_flags), 64, hipHostMallocMapped));
     memset(h_flags, 0, 64);
     HIP_OK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_flags), h_flags, 0));
+    if (const char* e = getenv("MHTE_SHARD_EXACT")) exact = atoi(e) != 0 && !alias;
+    if (exact)
+      for (int s = 0; s < 2; ++s) {
+        HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&h_cnt[s]), size_t(2) * world * hdr * sizeof(int64_t),
+                             hipHostMallocDefault));
+        memset(h_cnt[s], 0, size_t(2) * world * hdr * sizeof(int64_t));
+        HIP_OK(hipEventCreateWithFlags(&ev_cnt[s], hipEventDisableTiming));
+      }
     if (unique_id) {
       Rccl& R = Rccl::get();
       ncclUniqueId id;
@@ -396,18 +418,52 @@ struct ShardStep {
     return kind == kXIds ? size_t(geo.ids_block) * sizeof(int64_t) : size_t(geo.rows_block) * sizeof(float);
   }
 
+  // after the id exchange of `slot`: its headers (ids sent to / received from every peer, per table)
+  // on their way to the host
+  void fetch_counts(int slot, hipStream_t st) {
+    if (!exact) return;
+    const size_t w = size_t(hdr_words) * sizeof(int64_t);
+    HIP_OK(hipMemcpy2DAsync(h_cnt[slot], w, ids_send[slot], size_t(geo.ids_block) * 8, w, size_t(world),
+                            hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpy2DAsync(h_cnt[slot] + size_t(world) * hdr_words, w, ids_recv[slot],
+                            size_t(geo.ids_block) * 8, w, size_t(world), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipEventRecord(ev_cnt[slot], st));
+  }
+  // rows of table t in the block exchanged with peer p: `sent` = ids this rank sent to p (its rows
+  // come back / its gradient sums leave), else ids p sent here
+  uint32_t seg_rows(int slot, bool sent, int p, uint32_t t) const {
+    const int64_t c = h_cnt[slot][(sent ? 0 : size_t(world) * hdr_words) + size_t(p) * hdr_words + t];
+    return uint32_t(std::min<int64_t>(std::max<int64_t>(c, 0), int64_t(cap)));
+  }
+
   // block p of the source goes to peer p, block p of the destination comes from peer p
   void exchange_rccl(int kind, int slot, hipStream_t st) {
     Rccl& R = Rccl::get();
     const char* src = static_cast<const char*>(x_src(kind, slot));
     char* dst = static_cast<char*>(x_dst(kind, slot));
     const size_t b = x_block(kind);
+    if (exact && kind != kXIds) {
+      HIP_OK(hipEventSynchronize(ev_cnt[slot]));   // (long done unless the batch was not prepared ahead)
+      const bool out_sent = kind == kXGrads;       // gradients: what I sent ids for; rows: what I was asked
+      R.ok(R.GroupStart(), "GroupStart");
+      for (int p = 0; p < world; ++p)
+        for (uint32_t t = 0; t < T; ++t) {
+          const size_t off = size_t(p) * b + size_t(tab[t].row_off) * sizeof(float);
+          const size_t ns = size_t(seg_rows(slot, out_sent, p, t)) * tab[t].dim * sizeof(float);
+          const size_t nr = size_t(seg_rows(slot, !out_sent, p, t)) * tab[t].dim * sizeof(float);
+          if (ns) R.ok(R.Send(src + off, ns, ncclInt8, p, comm, st), "Send");
+          if (nr) R.ok(R.Recv(dst + off, nr, ncclInt8, p, comm, st), "Recv");
+        }
+      R.ok(R.GroupEnd(), "GroupEnd");
+      return;
+    }
     R.ok(R.GroupStart(), "GroupStart");
     for (int p = 0; p < world; ++p) {
       R.ok(R.Send(src + size_t(p) * b, b, ncclInt8, p, comm, st), "Send");
       R.ok(R.Recv(dst + size_t(p) * b, b, ncclInt8, p, comm, st), "Recv");
     }
     R.ok(R.GroupEnd(), "GroupEnd");
+    if (kind == kXIds) fetch_counts(slot, st);
   }
 };
 
@@ -418,13 +474,27 @@ static void shard_exchange(ShardStep** S, int n, int kind, int slot, hipStream_t
     S[0]->exchange_rccl(kind, slot, st);
     return;
   }
+  const bool exact = S[0]->exact && kind != kXIds;
+  if (exact)
+    for (int r = 0; r < n; ++r) HIP_OK(hipEventSynchronize(S[r]->ev_cnt[slot]));
   for (int r = 0; r < n; ++r)
     for (int p = 0; p < n; ++p) {
       const size_t b = S[r]->x_block(kind);
-      HIP_OK(hipMemcpyAsync(static_cast<char*>(S[p]->x_dst(kind, slot)) + size_t(r) * b,
-                            static_cast<const char*>(S[r]->x_src(kind, slot)) + size_t(p) * b, b,
-                            hipMemcpyDeviceToDevice, st));
+      char* dst = static_cast<char*>(S[p]->x_dst(kind, slot)) + size_t(r) * b;
+      const char* src = static_cast<const char*>(S[r]->x_src(kind, slot)) + size_t(p) * b;
+      if (!exact) {
+        HIP_OK(hipMemcpyAsync(dst, src, b, hipMemcpyDeviceToDevice, st));
+        continue;
+      }
+      // what rank r sends to p: gradients of the ids r sent to p / rows of the ids p sent to r
+      for (uint32_t t = 0; t < S[r]->T; ++t) {
+        const size_t off = size_t(S[r]->tab[t].row_off) * sizeof(float);
+        const size_t nb = size_t(S[r]->seg_rows(slot, kind == kXGrads, p, t)) * S[r]->tab[t].dim * sizeof(float);
+        if (nb) HIP_OK(hipMemcpyAsync(dst + off, src + off, nb, hipMemcpyDeviceToDevice, st));
+      }
     }
+  if (kind == kXIds)
+    for (int r = 0; r < n; ++r) S[r]->fetch_counts(slot, st);
 }
 
 static void shard_check_group(ShardStep** S, int n) {

@@ -165,6 +165,16 @@ def test_world1_over_rccl():
   rc.close()
 
 
+def test_exact_size_exchange(monkeypatch):
+  """MHTE_SHARD_EXACT=1: rows and gradients cross only for the occupied part of every (peer, table)
+  segment, the counts copied to the host behind the id exchange — same results, through the group
+  transport and through RCCL send / recv to self."""
+  monkeypatch.setenv("MHTE_SHARD_EXACT", "1")
+  test_group_against_oracle("zipf", 3)
+  test_group_against_oracle("uniform", 2)
+  test_world1_over_rccl()
+
+
 def test_block_overflow_is_reported():
   specs = dlrm_specs(2, initial_capacity=1 << 10)
   B = 512
