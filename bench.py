@@ -45,6 +45,10 @@ def parse():
                       "batch ids per table and step, online insert + TTL eviction scans, all tables in "
                       "one launch pair per step (a measurement kept under profiles/, not the bench line)")
   p.add_argument("--tables", type=int, default=26, help="dlrm26: number of feature tables")
+  p.add_argument("--steps-per-second", type=int, default=2000,
+                 help="dlrm26: update_time (seconds) advances once per this many steps — a ~0.43 ms "
+                      "step is ~2 300 steps per wall-clock second; 1 = a new second every step (the "
+                      "timestamp of every touched id changes every step)")
   p.add_argument("--evict-every", type=int, default=100,
                  help="dlrm26: TTL eviction scan of every table each N steps (0: never)")
   p.add_argument("--grad-pool", type=int, default=17,
@@ -206,7 +210,8 @@ def main_dlrm(args):
       sp[i + 1:] = m
       _lib.check(mt._lib.mhte_assign(mt.handle, _lib.vp(fid), sp.ctypes.data_as(_lib.C.POINTER(_lib.C.c_int64)),
                                      _lib.C.c_int64(T + 1), _lib.vp(zeros), _lib.C.c_int64(m * dims[i]),
-                                     _lib.C.c_int64(S.update_time(0)), _lib.C.c_int32(_lib.MHTE_IDS_UNIQUE), None))
+                                     _lib.C.c_int64(S.update_time(0) - 3600),   # (last touched an hour ago)
+                                     _lib.C.c_int32(_lib.MHTE_IDS_UNIQUE), None))
     torch.cuda.synchronize()
     del zeros
   torch.cuda.empty_cache()
@@ -243,6 +248,10 @@ def main_dlrm(args):
     step = MultiSparseStep(mt, B, exact_order=args.exact_order)
   applied = []
   evictions = [0]
+  sps = max(1, int(args.steps_per_second))
+
+  def ut(step):   # update_time of a step: wall-clock seconds
+    return S.update_time(step // sps)
 
   # ---- dense leg: layout (concat of the T features' rows) -> MLP -> layout gradient -------------
   dense = None
@@ -292,10 +301,10 @@ def main_dlrm(args):
     for s in range(lo, hi):
       step.forward(rag[s], rag[s + 1], out=out)
       if dense is not None:
-        step.backward(dense_step(out), S.update_time(s))
+        step.backward(dense_step(out), ut(s))
       else:
-        step.backward(grad_pool[s % NG], S.update_time(s))
-        applied.append((s, s % NG, S.update_time(s)))
+        step.backward(grad_pool[s % NG], ut(s))
+        applied.append((s, s % NG, ut(s)))
       if args.evict_every and (s + 1) % args.evict_every == 0:
         for n in names:
           mt.evict(n)
@@ -321,10 +330,10 @@ def main_dlrm(args):
     if s % 10 == 0:
       uniq.append(step.unique_counts())
     if dense is not None:
-      step.backward(dense_step(out), S.update_time(s))
+      step.backward(dense_step(out), ut(s))
     else:
-      step.backward(grad_pool[s % NG], S.update_time(s))
-      applied.append((s, s % NG, S.update_time(s)))
+      step.backward(grad_pool[s % NG], ut(s))
+      applied.append((s, s % NG, ut(s)))
   torch.cuda.synchronize()
   for name, us in _lib.profile_read():
     a = acc.setdefault(name, [0, 0.0])
@@ -435,7 +444,7 @@ def main_dlrm(args):
         times = []
         for s in range(5 + 30):
           tt = time.perf_counter()
-          ps.step(ids_host[s, i * B:(i + 1) * B], gh, lr, S.update_time(s), want_emb=True)
+          ps.step(ids_host[s, i * B:(i + 1) * B], gh, lr, ut(s), want_emb=True)
           times.append(time.perf_counter() - tt)
         per_dim[d] = float(np.median(times[5:]))
       t_step = sum(per_dim[d] for d in dims)
@@ -472,6 +481,7 @@ def main_dlrm(args):
           "resident_rows_start": int(sum(size0)), "resident_rows_end": int(sum(size1)),
           "unique_ids_per_batch_mean": float(U.mean()), "eviction_scans_in_timed_region": evictions[0],
           "gradient_bytes_rotated": int(NG * gsz * 4), "prefill_s": round(prefill_s, 2),
+          "update_time": "one second per %d steps" % sps,
           "launch": "eager",
       },
       "roofline": roofline, "stages": stages, "cpu_baseline": cpu, "parity_check": parity,

@@ -120,6 +120,7 @@ struct MultiStep {
       s.arrive[sl] = A.take<uint32_t>(size_t(n) + 2);
       s.urow[sl] = A.take<uint32_t>(size_t(n) + 2);
       s.uloc[sl] = A.take<unsigned long long>(size_t(n) + 2);
+      s.uts[sl] = A.take<uint32_t>(size_t(n) + 2);
     }
     s.grad_u = A.take<float>(size_t(n) * tb.dim + 16);
     s.pending = A.take<uint32_t>(size_t(n) + 2);

@@ -45,6 +45,8 @@ struct MStepStatic {
   uint32_t* urow[2];       // per slot [n_max]: row handle of unique index u as the forward launch
                            // found it (kNoRow: not in the table), and where its slot is
   unsigned long long* uloc[2];  //          (bucket * 4 + slot): the backward launch need not probe
+  uint32_t* uts[2];        // per slot [n_max]: the timestamp the forward launch saw in that slot — the
+                           // backward skips its timestamp store when the step's is the same value
   int64_t n_max;           // capacity of the dense arrays (largest batch of the table)
   uint32_t g;              // lanes per id: 8 / 16 / 32 / 64 >= dim / 4
   uint32_t oneseg;         // the table has one segment (scalar descriptor loads, seg_of)
@@ -178,6 +180,7 @@ __device__ __forceinline__ void mstep_scatter_role(const TableView& tv, const Ru
                                                    float* __restrict__ out,
                                                    uint32_t* __restrict__ urow,
                                                    unsigned long long* __restrict__ uloc,
+                                                   uint32_t* __restrict__ uts,
                                                    int64_t n_max, int count_hits, uint32_t bid,
                                                    uint32_t nblk, uint32_t item_split,
                                                    WaveTrace& wt) {
@@ -220,7 +223,7 @@ __device__ __forceinline__ void mstep_scatter_role(const TableView& tv, const Ru
       wt.mark(1);
     }
     int64_t kk[UNR];
-    uint32_t row[UNR], x[UNR][PER];
+    uint32_t row[UNR], tsv[UNR], x[UNR][PER];
     uint64_t i1[UNR], i2[UNR];
     bool flat[UNR];
 #pragma unroll
@@ -232,6 +235,7 @@ __device__ __forceinline__ void mstep_scatter_role(const TableView& tv, const Ru
       const GBucket* b = global_bucket(tv.buckets + ((j & 4) ? i2[u] : i1[u]));
       kk[u] = b->key[j & 3];
       row[u] = b->row[j & 3];
+      tsv[u] = b->ts[j & 3];   // (same 64-byte line)
       flat[u] = cnt[u] > 1 && cnt[u] <= uint32_t(kStepLightMax);
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
@@ -251,6 +255,7 @@ __device__ __forceinline__ void mstep_scatter_role(const TableView& tv, const Ru
       bool found = m != 0;
       const int src = found ? (__ffsll(static_cast<long long>(m)) - 1) : 0;
       uint32_t r = __shfl(use ? row[u] : kNoRow, gbase + src);
+      const uint32_t ots = __shfl(tsv[u], gbase + src);
       const bool special = valid[u] && id[u] == kEmptyKey;
       if (special) {
         found = tv.ctr->special_state == 1;
@@ -261,6 +266,7 @@ __device__ __forceinline__ void mstep_scatter_role(const TableView& tv, const Ru
         const int64_t g = g0 + int64_t(grp) * UNR + u;
         urow[g] = (found && !special) ? r : kNoRow;
         uloc[g] = (((src & 4) ? i2[u] : i1[u]) << 2) | uint64_t(src & 3);
+        uts[g] = ots;
       }
       if (count_hits && found && j == 0) hits += cnt[u];  // (per occurrence, as the direct lookup counts)
       const bool light = valid[u] && cnt[u] <= uint32_t(kStepLightMax);
@@ -378,10 +384,10 @@ __global__ __launch_bounds__(BLOCK) void mstep_fwd_kernel(MFwdArgs A) {
   float* out = A.out + size_t(ft.emb_off);
   const int ch = int(s.count_hits);
   switch (s.g) {
-    case 8: mstep_scatter_role<8, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
-    case 16: mstep_scatter_role<16, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
-    case 32: mstep_scatter_role<32, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
-    default: mstep_scatter_role<64, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
+    case 8: mstep_scatter_role<8, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
+    case 16: mstep_scatter_role<16, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
+    case 32: mstep_scatter_role<32, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
+    default: mstep_scatter_role<64, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
   }
   wt.end(5u);
 }
@@ -438,6 +444,7 @@ __global__ __launch_bounds__(256, MHTE_MBWD_OCC) void mstep_bwd_kernel(MBwdArgs 
   c.spec_row = nullptr;
   c.urow = bt.hints ? s.urow[cur] : nullptr;
   c.uloc = bt.hints ? s.uloc[cur] : nullptr;
+  c.uts = bt.hints ? s.uts[cur] : nullptr;
   if (s.oneseg) mstep_apply_switch<true>(s.g, tv, d, c, bt.a, bid, wt, L);
   else mstep_apply_switch<false>(s.g, tv, d, c, bt.a, bid, wt, L);
   wt.end(bid < bt.nblk_items ? 7u : 8u);
