@@ -706,7 +706,25 @@ def main():
     splits1 = np.array([0, B], dtype=np.int64)
     rag = [Ragged(ids_all[s], splits1) for s in range(n_batches)]
     emb_out = torch.empty(B * D, dtype=torch.float32, device=dev)
-    if world > 1 and args.dist_backend == "gloo":
+    impl = os.environ.get("MHTE_BENCH_SHARDED_IMPL", "")   # "torch": round 1's torch.distributed form
+    se = None
+    if world > 1 and args.dist_backend != "gloo" and impl != "torch":
+      # the C++ step over RCCL; if RCCL cannot be bound on any rank (a symmetric failure, before the
+      # collective communicator set-up), every rank takes the torch.distributed form instead
+      err = None
+      try:
+        from monolith_amd.distributed_ps_sync import shard_unique_id
+        shard_unique_id()
+      except Exception as e:  # pylint: disable=broad-except
+        err = e
+      flag = torch.tensor([1 if err is not None else 0], device=dev)
+      dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+      if int(flag.item()):
+        if rank == 0:
+          print("RCCL could not be bound by the library (%r): torch.distributed form of the step" % (err,),
+                file=sys.stderr)
+        impl = "torch"
+    if world > 1 and (args.dist_backend == "gloo" or impl == "torch"):
       # ranks sharing one GPU (the 1-GPU box): RCCL cannot put two ranks on a device, so the N > 1
       # control flow of this file is exercised through round 1's torch.distributed form of the step,
       # its exchanges staged through host memory by gloo — not a scaling number
@@ -724,12 +742,12 @@ def main():
           torch.cuda.synchronize()
 
         def info(self):
-          return {"transport": "torch.distributed gloo (host staged)"}
+          return {"transport": "torch.distributed %s (round 1's Python form of the step)" % args.dist_backend}
 
         def close(self):
           pass
       se = _GlooStep()
-    else:
+    if se is None:
       se = ShardedMultiStep(mt, B, ids_per_peer_table=args.ids_per_peer)
 
     host_us = []   # MHTE_BENCH_STEP_TIMES=1: host time of every step's two calls (stall hunting)
