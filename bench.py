@@ -784,7 +784,8 @@ def main():
       top = sorted(host_us, key=lambda x: -(x[1] + x[2]))[:6]
       print("slowest steps (step, forward us, backward us): %s" % [(a, round(b), round(c)) for a, b, c in top],
             file=sys.stderr)
-    if world == 1 and not args.no_stage_timing:   # kernel-exact time of every launch of a step
+    if not args.no_stage_timing:   # kernel-exact time of every tagged launch of a step (every rank
+                                   # runs the same extra steps: they are collective; rank 0 reports its own)
       acc = {}
       nprof = min(20, n_batches - (W + K) - 1)
       for s in range(W + K, W + K + nprof):
@@ -806,10 +807,11 @@ def main():
           if k in salg:
             stages[k]["alg_bytes"] = int(salg[k])
             stages[k]["GBps"] = round(salg[k] / us / 1e3, 1)
-        dom = max((k for k in acc if k in salg and k != "dd_kernels"), key=lambda k: stages[k]["avg_us"])
-        a_gbps = salg[dom] / stages[dom]["avg_us"] / 1e3
+        cands = [k for k in acc if k in salg and k != "dd_kernels"]
+        dom = max(cands, key=lambda k: stages[k]["avg_us"]) if cands else None
+        a_gbps = salg[dom] / stages[dom]["avg_us"] / 1e3 if dom else 0.0
         step_bytes, _ = algorithmic_bytes(B, uniq_avg, D, S_state)
-        shard_roofline = {
+        shard_roofline = None if dom is None else {
             "bound": "hbm", "kernel": dom, "achieved": round(a_gbps, 1), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(a_gbps / HBM_PEAK_GBPS, 4), "traffic": None,
             "alg_bytes_per_launch": int(salg[dom]), "avg_launch_us": stages[dom]["avg_us"],
