@@ -586,7 +586,8 @@ __global__ __launch_bounds__(64) void seg_slow_kernel(SegUpsertArgs A) {
   for (uint32_t i = 0; i < np; ++i) {
     const uint32_t gp = pending[2 * i], seg = pending[2 * i + 1];
     const int64_t id = A.ids[gp];
-    uint32_t r;
+    uint32_t r;  // (only lane 0's value is read, after the search: not merged with a constant on purpose,
+                 // slowpath_role)
     if (lane == 0) r = static_cast<uint32_t>(atomicAdd(&tv.ctr->alloc, (1ull << 32) | 1ull));
     const long long pos = wave_insert_slot(tv.buckets, tv.hp, id, q, path, lane);
     if (lane == 0) {

@@ -104,7 +104,8 @@ __device__ __forceinline__ void shard_slow_role(const ShardOwnerArgs& A, uint32_
   for (uint32_t i = 0; i < np; ++i) {
     const uint32_t g = pending[2 * i];
     const int64_t id = ids[g];
-    uint32_t r;
+    uint32_t r;  // (only lane 0's value is read, after the search: not merged with a constant on purpose,
+                 // slowpath_role)
     if (lane == 0) r = static_cast<uint32_t>(atomicAdd(&tv.ctr->alloc, (1ull << 32) | 1ull));
     const long long pos = wave_insert_slot(tv.buckets, tv.hp, id, q, path, lane);
     if (lane == 0) {
