@@ -608,7 +608,9 @@ def main():
   # contiguous batch sequence: the last step of a mode deduplicates the first batch of the next
   # mode ahead, exactly as it does inside a mode.
   reps = min(K, 100)
-  n_batches = (2 * (W + K) + 2 * reps + 8) if not sharded else (K + W + 24)
+  gchunk = 10                               # steps per captured graph
+  Wg = -(-W // gchunk) * gchunk             # the graph mode's warm-up: W rounded up to whole chunks
+  n_batches = ((W + K) + (Wg + K) + 2 * reps + 12) if not sharded else (K + W + 24)
   ids_host = np.stack([S.id_batch(s * world + rank, B, V, "zipf") for s in range(n_batches)])
   ids_all = torch.from_numpy(ids_host).to(dev)
   NG = max(1, args.grad_pool)
@@ -660,8 +662,9 @@ def main():
     # ---- hipGraph replay: the launch-bound loop captured in chunks of `gc` pipelined steps
     # (2 launches per step on one queue).  Each chunk graph reads its batches straight from the
     # resident id array, so nothing is copied or skipped inside the timed region.
-    gc = 10
-    if args.launch in ("auto", "graph") and K % gc == 0 and W % gc == 0:
+    # The warm-up is rounded UP to whole chunks (extra untimed steps); exactly K steps are timed.
+    gc = gchunk
+    if args.launch in ("auto", "graph") and K % gc == 0:
       graphs = []
       try:
         # one eager step first: leaves batch cur+1 deduplicated ahead and a displacement pass
@@ -670,19 +673,19 @@ def main():
         cur += 1
         step.quiesce()
         G0 = cur
-        for c0 in range(G0, G0 + W + K, gc):
+        for c0 in range(G0, G0 + Wg + K, gc):
           g = torch.cuda.CUDAGraph()
           with torch.cuda.graph(g):
             run_eager(c0, c0 + gc)
           graphs.append(g)
-        cur = G0 + W + K
+        cur = G0 + Wg + K
         torch.cuda.synchronize()
         # capture executed nothing: replay from batch G0
-        for g in graphs[:W // gc]:
+        for g in graphs[:Wg // gc]:
           g.replay()
         barrier()
         t = time.perf_counter()
-        for g in graphs[W // gc:]:
+        for g in graphs[Wg // gc:]:
           g.replay()
         barrier()
         results["graph"] = time.perf_counter() - t
@@ -1007,6 +1010,9 @@ def main():
             "row_bytes": 4 * (D + S_state), "hashpower": int(st1.hashpower),
             "table_bytes_per_gpu": int(st1.bytes_buckets + st1.bytes_rows),
             "unique_ids_per_batch": uniq_avg, "launch": launch,
+            "launch_note": ("hipGraph replay, %d steps per graph; %d untimed warm-up steps replayed "
+                            "(--warmup rounded up to whole graphs), exactly %d steps timed" %
+                            (gchunk, Wg, K)) if launch == "graph" else None,
             "parallelism": "1 GPU" if not sharded else
                            "fid mod %d sharding, 3 fixed-capacity exchanges/step (%s)" %
                            (world, shard_info["transport"]),
