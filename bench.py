@@ -99,6 +99,16 @@ def algorithmic_bytes(B, U, D, S):
   return lookup + update, per_kernel
 
 
+def peer_unique_max(ids_host, world):
+  """Largest number of distinct ids one batch of `ids_host` [steps, B] sends to one owner
+  (owner = id mod world, NT/distributed_ps.py:289)."""
+  mx = 0
+  for row in ids_host:
+    u = np.unique(row)
+    mx = max(mx, int(np.bincount(np.mod(u, world).astype(np.int64), minlength=world).max()))
+  return mx
+
+
 def sharded_algorithmic_bytes(B, U, D, S):
   """Per launch of the id-sharded step (csrc/mhte_shard_kernels.h), world 1, one table: the rows of
   the U distinct ids cross a peer block in each direction on top of SURVEY 8d's per-step bytes."""
@@ -751,7 +761,18 @@ def main():
           pass
       se = _GlooStep()
     if se is None:
-      se = ShardedMultiStep(mt, B, ids_per_peer_table=args.ids_per_peer)
+      ipp = args.ids_per_peer
+      if world > 1 and not ipp:
+        # A (peer, table) block moves at its full configured size, so the capacity is sized from the
+        # id stream the way an operator sizes it from the traffic: 1.25 x the most distinct ids any
+        # rank sends one peer in a step of this run (the library default assumes no duplicates —
+        # several times that on Zipf ids).  Every rank must use the same value.  Going over it is
+        # not silent: the step raises ResourceExhausted (check() below).
+        mx = peer_unique_max(ids_host, world)
+        tt = torch.tensor([mx], dtype=torch.int64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ipp = min(B, (int(tt.item()) * 5 // 4 + 63) // 64 * 64)
+      se = ShardedMultiStep(mt, B, ids_per_peer_table=ipp)
 
     host_us = []   # MHTE_BENCH_STEP_TIMES=1: host time of every step's two calls (stall hunting)
     trace_host = os.environ.get("MHTE_BENCH_STEP_TIMES") == "1"

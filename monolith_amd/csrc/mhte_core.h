@@ -377,11 +377,14 @@ MHTE_HD void rmsprop_step(float& w, float& n, float grad, double lr, float mom, 
   n = new_n;
 }
 
-// adam_optimizer.cc:56-86 / amsgrad_optimizer.cc; lr_eff = lr * sqrt(1 - beta2_power) / (1 - beta1_power)
+// adam_optimizer.cc:56-86 / amsgrad_optimizer.cc; lr_eff = lr * sqrt(1 - beta2_power) / (1 - beta1_power).
+// The reference's `sqrt` is unqualified after <cmath> alone, i.e. ::sqrt(double) (:64,74,76;
+// amsgrad_optimizer.cc:66,77,79): lr_eff and every element's quotient are formed in double and
+// rounded to float once, at the assignment.  Followed bit for bit (f64 sqrt / div are IEEE here).
 MHTE_HD float adam_lr(float lr, float b1p, float b2p) {
-  float a = sqrtf(1 - b2p);
-  float b = lr * a;
-  return b / (1 - b1p);
+  const double a = sqrt(static_cast<double>(1 - b2p));
+  const double b = static_cast<double>(lr) * a;
+  return static_cast<float>(b / static_cast<double>(1 - b1p));
 }
 MHTE_HD void adam_step(float& w, float& m, float& v, float* vhat, float grad, float lr_eff,
                        float beta1, float beta2, float eps, float wd, bool nesterov) {
@@ -397,7 +400,7 @@ MHTE_HD void adam_step(float& w, float& m, float& v, float* vhat, float grad, fl
     vv = (*vhat > new_v) ? *vhat : new_v;
     *vhat = vv;
   }
-  float den = sqrtf(vv) + eps;
+  const double den = sqrt(static_cast<double>(vv)) + static_cast<double>(eps);
   float numr;
   if (nesterov) {
     float a = g * (1 - beta1);
@@ -406,8 +409,8 @@ MHTE_HD void adam_step(float& w, float& m, float& v, float* vhat, float grad, fl
   } else {
     numr = new_m * lr_eff;
   }
-  float q = numr / den;
-  w = w - q;
+  const double q = static_cast<double>(numr) / den;
+  w = static_cast<float>(static_cast<double>(w) - q);
   m = new_m;
   v = new_v;
 }

@@ -560,14 +560,18 @@ static void mo_rmsprop(float* num, float* n, const float* grad, int64_t len, flo
   }
 }
 /* optimizer/adam_optimizer.cc:56-86, amsgrad_optimizer.cc (vhat != NULL);
- * p = {beta1, beta2, epsilon, weight_decay_factor, use_nesterov}; ctx = m | v | [vhat |] powers */
+ * p = {beta1, beta2, epsilon, weight_decay_factor, use_nesterov}; ctx = m | v | [vhat |] powers.
+ * The reference calls `sqrt` UNQUALIFIED (adam_optimizer.cc:64,74,76; amsgrad_optimizer.cc:66,77,79)
+ * after <cmath> only: that is ::sqrt(double) (libstdc++'s <cmath> puts the float overload in std::
+ * alone), so the effective learning rate and the quotient of every element are formed in double and
+ * rounded to float once, at the assignment — restated so here. */
 static void mo_adam(float* num, float* ctx, const float* grad, int64_t len, float lr0,
                     const float* p, int amsgrad) {
   float* m = ctx;
   float* v = m + len;
   float* vhat = amsgrad ? v + len : NULL;
   float* pw = (amsgrad ? vhat : v) + len;
-  float lr = lr0 * sqrtf(1 - pw[1]) / (1 - pw[0]);
+  float lr = (float)((double)lr0 * sqrt((double)(1 - pw[1])) / (double)(1 - pw[0]));
   for (int64_t i = 0; i < len; ++i) {
     float cur_grad = grad[i] + p[3] * num[i];
     float new_m = m[i] + (cur_grad - m[i]) * (1 - p[0]);
@@ -579,9 +583,11 @@ static void mo_adam(float* num, float* ctx, const float* grad, int64_t len, floa
     }
     float new_w = num[i];
     if (p[4] != 0.f) {
-      new_w -= ((cur_grad * (1 - p[0]) + p[0] * new_m) * lr) / (sqrtf(den_v) + p[2]);
+      float numr = (cur_grad * (1 - p[0]) + p[0] * new_m) * lr;
+      new_w = (float)((double)new_w - (double)numr / (sqrt((double)den_v) + (double)p[2]));
     } else {
-      new_w -= (new_m * lr) / (sqrtf(den_v) + p[2]);
+      float numr = new_m * lr;
+      new_w = (float)((double)new_w - (double)numr / (sqrt((double)den_v) + (double)p[2]));
     }
     num[i] = new_w;
     m[i] = new_m;
