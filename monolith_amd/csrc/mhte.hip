@@ -126,11 +126,15 @@ struct CkptStage {
   DevBuf<int64_t> d_ids, d_pos;
   DevBuf<uint32_t> d_ts;
   DevBuf<float> d_rows;
-  HostBuf<int64_t> h_ids;
-  HostBuf<uint32_t> h_ts;
-  HostBuf<float> h_rows;
-  std::vector<std::string> parts;
-  std::string arena[2];   // restore: the stretch being decoded and the one being read ahead
+  // two sets of everything a save chunk passes from stage to stage (scan -> encode -> write run
+  // beside each other, ckpt::run_pipeline3); restore decodes into set 0
+  HostBuf<int64_t> h_ids[2];
+  HostBuf<uint32_t> h_ts[2];
+  HostBuf<float> h_rows[2];
+  uint64_t h_n[2] = {0, 0};                 // rows of the chunk in the set
+  std::vector<std::string> parts[2];        // framed records of the chunk, one string per codec thread
+  std::vector<uint64_t> part_n[2];
+  ckpt::ByteArena arena[2];   // restore: the stretch being decoded and the one being read ahead
 };
 
 // host threads per checkpoint shard for the EntryDump codec (MHTE_CKPT_THREADS; shards run beside
@@ -1993,15 +1997,15 @@ static uint64_t save_table_shard(Table& tb, int shard, int total, ckpt::RecordWr
   const uint64_t end = begin + Q + (uint64_t(shard) < R ? 1 : 0);
   const std::vector<ckpt::SegLayout> segs = seg_layout(tb);
   const uint32_t rf = tb.row_floats;
-  const uint64_t kChunkSlots = uint64_t(1) << 21;
+  // chunk = what one pipeline stage holds at a time: small enough that a shard has several of them
+  // in flight (scan | encode | write beside each other) and that the two pinned staging sets stay
+  // in the hundreds of megabytes, large enough that the per-chunk synchronisations do not show
+  const uint64_t kChunkSlots = uint64_t(1) << 18;
   DevBuf<uint32_t>& bc = sg.bc;
   DevBuf<uint64_t>& bo = sg.bo;
   DevBuf<int64_t>&d_ids = sg.d_ids, &d_pos = sg.d_pos;
   DevBuf<uint32_t>& d_ts = sg.d_ts;
   DevBuf<float>& d_rows = sg.d_rows;
-  HostBuf<int64_t>& h_ids = sg.h_ids;
-  HostBuf<uint32_t>& h_ts = sg.h_ts;
-  HostBuf<float>& h_rows = sg.h_rows;
   std::string rec;
   uint64_t written = 0;
   auto expired = [&](int64_t id, uint32_t ts) {
@@ -2014,20 +2018,26 @@ static uint64_t save_table_shard(Table& tb, int shard, int total, ckpt::RecordWr
     ++written;
   };
   const int P = ckpt_codec_threads();
-  std::vector<std::string>& parts = sg.parts;
-  if (parts.size() < size_t(P)) parts.resize(size_t(P));
-  std::vector<uint64_t> part_n(static_cast<size_t>(P), 0);
+  for (int b = 0; b < 2; ++b) {
+    if (sg.parts[b].size() < size_t(P)) sg.parts[b].resize(size_t(P));
+    sg.part_n[b].assign(size_t(P), 0);
+    sg.h_n[b] = 0;
+  }
   const bool trace = getenv("MHTE_CKPT_TRACE") != nullptr;   // phase seconds of this shard to stderr
-  double t_scan = 0, t_enc = 0, t_write = 0;
+  double t_scan = 0, t_enc = 0, t_write = 0;                 // (each written by its stage's thread only)
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  for (uint64_t s0 = begin * kSlots; s0 < end * kSlots; s0 += kChunkSlots) {
-    const uint64_t s1 = std::min(end * kSlots, s0 + kChunkSlots);
+  const uint64_t slot_begin = begin * kSlots, slot_end = end * kSlots;
+  const size_t n_chunks = size_t((slot_end - slot_begin + kChunkSlots - 1) / kChunkSlots);
+  // stage A (this thread: it owns the HIP stream): device scan of the chunk's slots + copy of the
+  // rows it found into pinned set b.  The table is held for that only; the (longer) encoding and
+  // writing of the chunk run beside the next chunk's scan and the other shards' threads.
+  auto scan = [&](size_t c, int b) {
+    const double t0 = now();
+    const uint64_t s0 = slot_begin + uint64_t(c) * kChunkSlots;
+    const uint64_t s1 = std::min(slot_end, s0 + kChunkSlots);
     const uint32_t nblocks = uint32_t((s1 - s0 + 1023) / 1024);
     uint64_t acc = 0;
-    const double t0 = now();
-    {
-    // the table is held for the device scan + copy of a chunk only; the (much longer) encoding of
-    // the chunk runs beside the other shards' threads
+    sg.h_n[b] = 0;
     std::lock_guard<std::mutex> g(tb.mu);
     bc.reserve(nblocks);
     bo.reserve(nblocks);
@@ -2041,54 +2051,70 @@ static uint64_t save_table_shard(Table& tb, int shard, int total, ckpt::RecordWr
       ho[i] = acc;
       acc += hc[i];
     }
-    if (acc == 0) continue;
-    d_ids.reserve(acc);
-    d_pos.reserve(acc);
-    d_ts.reserve(acc);
-    d_rows.reserve(acc * rf);
-    HIP_OK(hipMemcpyAsync(bo.p, ho.data(), sizeof(uint64_t) * nblocks, hipMemcpyHostToDevice, st));
-    dump_emit_kernel<<<nblocks, 256, 0, st>>>(tb.view, s0, s1, bo.p, d_ids.p, d_pos.p, d_ts.p, d_rows.p);
-    HIP_OK(hipGetLastError());
-    h_ids.reserve(acc);
-    h_ts.reserve(acc);
-    h_rows.reserve(acc * rf);
-    HIP_OK(hipMemcpyAsync(h_ids.p, d_ids.p, acc * 8, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(h_ts.p, d_ts.p, acc * 4, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(h_rows.p, d_rows.p, acc * rf * 4, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
+    if (acc != 0) {
+      d_ids.reserve(acc);
+      d_pos.reserve(acc);
+      d_ts.reserve(acc);
+      d_rows.reserve(acc * rf);
+      HIP_OK(hipMemcpyAsync(bo.p, ho.data(), sizeof(uint64_t) * nblocks, hipMemcpyHostToDevice, st));
+      dump_emit_kernel<<<nblocks, 256, 0, st>>>(tb.view, s0, s1, bo.p, d_ids.p, d_pos.p, d_ts.p, d_rows.p);
+      HIP_OK(hipGetLastError());
+      sg.h_ids[b].reserve(acc);
+      sg.h_ts[b].reserve(acc);
+      sg.h_rows[b].reserve(acc * rf);
+      HIP_OK(hipMemcpyAsync(sg.h_ids[b].p, d_ids.p, acc * 8, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipMemcpyAsync(sg.h_ts[b].p, d_ts.p, acc * 4, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipMemcpyAsync(sg.h_rows[b].p, d_rows.p, acc * rf * 4, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipStreamSynchronize(st));
+      sg.h_n[b] = acc;
     }
-    const double t1 = now();
-    // EntryDump + TFRecord framing of the chunk's rows on P threads (contiguous ranges, so the
-    // file keeps the dump order), then the framed bytes go through the writer in range order
-    parallel_ranges(size_t(acc), P, [&](size_t lo, size_t hi, int k) {
-      std::string& out = parts[size_t(k)];
-      std::string r;
-      out.clear();
-      uint64_t n = 0;
-      for (size_t i = lo; i < hi; ++i) {
-        if (expired(h_ids.p[i], h_ts.p[i])) continue;
-        ckpt::encode_entry(r, h_ids.p[i], h_rows.p + i * rf, segs, int(tb.dim), h_ts.p[i]);
-        ckpt::RecordWriter::frame(out, r);
-        ++n;
-      }
-      part_n[size_t(k)] = n;
-    });
-    const double t2 = now();
+    t_scan += now() - t0;
+  };
+  // stage B: EntryDump + TFRecord framing of the chunk's rows on P threads (contiguous ranges, so
+  // the file keeps the dump order) into set b's strings
+  auto encode = [&](size_t, int b) {
+    const double t0 = now();
+    const uint64_t acc = sg.h_n[b];
+    const int64_t* ids = sg.h_ids[b].p;
+    const uint32_t* tsv = sg.h_ts[b].p;
+    const float* rows = sg.h_rows[b].p;
+    std::vector<std::string>& parts = sg.parts[b];
+    std::vector<uint64_t>& part_n = sg.part_n[b];
     for (int k = 0; k < P; ++k) {
-      if (parts[size_t(k)].empty()) continue;
-      w.write_framed(parts[size_t(k)]);
-      written += part_n[size_t(k)];
       parts[size_t(k)].clear();
       part_n[size_t(k)] = 0;
     }
-    t_scan += t1 - t0;
-    t_enc += t2 - t1;
-    t_write += now() - t2;
-  }
+    if (acc)
+      parallel_ranges(size_t(acc), P, [&](size_t lo, size_t hi, int k) {
+        std::string& out = parts[size_t(k)];
+        std::string r;
+        uint64_t n = 0;
+        for (size_t i = lo; i < hi; ++i) {
+          if (expired(ids[i], tsv[i])) continue;
+          ckpt::encode_entry(r, ids[i], rows + i * rf, segs, int(tb.dim), tsv[i]);
+          ckpt::RecordWriter::frame(out, r);
+          ++n;
+        }
+        part_n[size_t(k)] = n;
+      });
+    t_enc += now() - t0;
+  };
+  // stage C: the framed bytes through the writer, in range order
+  auto write_out = [&](size_t, int b) {
+    const double t0 = now();
+    for (int k = 0; k < P; ++k) {
+      if (sg.parts[b][size_t(k)].empty()) continue;
+      w.write_framed(sg.parts[b][size_t(k)]);
+      written += sg.part_n[b][size_t(k)];
+    }
+    t_write += now() - t0;
+  };
+  const double t_pipe0 = now();
+  ckpt::run_pipeline3(n_chunks, scan, encode, write_out);
   if (trace)
-    fprintf(stderr, "[mhte ckpt] save %s shard %d/%d: %llu rows, scan+copy %.3f s, encode(%d thr) %.3f s, "
-                    "write %.3f s\n", tb.name.c_str(), shard, total, (unsigned long long)written, t_scan, P,
-            t_enc, t_write);
+    fprintf(stderr, "[mhte ckpt] save %s shard %d/%d: %llu rows in %zu chunks, %.3f s (stage seconds, "
+                    "overlapped: scan+copy %.3f, encode(%d thr) %.3f, write %.3f)\n", tb.name.c_str(), shard,
+            total, (unsigned long long)written, n_chunks, now() - t_pipe0, t_scan, P, t_enc, t_write);
   if (shard == 0 && tb.h_ctr->special_state == 1) {
     std::lock_guard<std::mutex> g(tb.mu);
     // the one key that lives in the side slot (kEmptyKey itself): last entry of shard 0
@@ -2210,7 +2236,7 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
     ckpt::RecordReader data(ckpt::shard_name(basename, "", sh, total), true);
     ckpt::RecordReader meta(ckpt::shard_name(basename, ".meta", sh, total), false);
     std::string mrec, name;
-    // the data file is read in stretches of ~64 MiB into the stage's arena; `refs[cur..)` are the
+    // the data file is read in stretches of ~32 MiB into the stage's arena; `refs[cur..)` are the
     // records of the current stretch not yet consumed (a stretch may span two tables)
     std::unique_ptr<CkptStage> sgp = t->take_stage();
     struct Return {
@@ -2224,11 +2250,19 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
     std::vector<ckpt::RecordReader::RecRef> refs_buf[2];
     int use = 0;                      // stretch in use: sg.arena[use], refs_buf[use]
     size_t cur = 0;
-    const size_t kStretch = size_t(64) << 20;
+    // (a stretch's arena is first touched by the block decoders: the smaller it is, the fewer fresh
+    // pages a restore into a new table faults in, and the warmer it is when the record decoders
+    // read it; 32 MiB is still ~50 000 rows of 512 B per upsert)
+    const size_t kStretch = size_t(32) << 20;
+    // the snappy blocks of a stretch are unpacked side by side on a few threads of the reader's own
+    const int kUnpackThreads = std::min(8, ckpt_codec_threads());
+    const ckpt::ParallelFor unpack = [kUnpackThreads](size_t n, const std::function<void(size_t, size_t)>& fn) {
+      parallel_ranges(n, kUnpackThreads, [&](size_t lo, size_t hi, int) { fn(lo, hi); });
+    };
     std::future<bool> ahead;          // the read into the other stretch
     auto read_into = [&](int b) {
       ahead = std::async(std::launch::async,
-                         [&, b] { return data.read_batch(sg.arena[b], kStretch, refs_buf[b]); });
+                         [&, b] { return data.read_batch(sg.arena[b], kStretch, refs_buf[b], unpack); });
     };
     struct Drain {                    // never leave the helper running into freed buffers
       std::future<bool>& f;
@@ -2304,9 +2338,9 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
         if (d.opt == kOptGroupAdagrad) init[size_t(d.st_off)] = d.p[0];  // group_adagrad_optimizer.cc:45-48
       }
       const size_t kBatch = size_t(1) << 18;
-      HostBuf<int64_t>& ids = sg.h_ids;
-      HostBuf<uint32_t>& ts = sg.h_ts;
-      HostBuf<float>& rows = sg.h_rows;
+      HostBuf<int64_t>& ids = sg.h_ids[0];
+      HostBuf<uint32_t>& ts = sg.h_ts[0];
+      HostBuf<float>& rows = sg.h_rows[0];
       ids.reserve(kBatch);
       ts.reserve(kBatch);
       rows.reserve(kBatch * rf);

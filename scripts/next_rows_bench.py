@@ -94,8 +94,9 @@ def bench_checkpoint():
     row_bytes = 4 * 2 * dim + 16
     emit("checkpoint save (2M rows, dim 64 + Adagrad state, 4 shards, TFRecord + snappy + EntryDump)",
          ts, n * row_bytes, rows=n, rows_per_s=round(n / ts), file_bytes=disk,
-         bound="per shard: device scan + copy (under the table lock), EntryDump + crc32c on 16 host "
-               "threads, one writer thread; first save pins its staging buffers")
+         bound="per shard, in chunks of 2^18 slots, three stages beside each other: device scan + copy "
+               "(under the table lock) | EntryDump + crc32c on 16 host threads | one writer thread; "
+               "first save pins its staging buffers")
     mt2 = make_table(entry.AdagradOptimizer(0.01, 0.1), dim, rows + (1 << 19), "ckpt2")
     t = time.perf_counter()
     mt2.restore(base)
@@ -103,8 +104,9 @@ def bench_checkpoint():
     tr = time.perf_counter() - t
     assert mt2.size("emb") == n
     emit("checkpoint restore (same files into an empty table)", tr, n * row_bytes, rows=n,
-         rows_per_s=round(n / tr), bound="one reader thread per shard (fread + snappy block copy), "
-                                         "verify + decode on 16 threads, upsert")
+         rows_per_s=round(n / tr), bound="per shard: a reader thread ahead by one 32 MiB stretch "
+                                         "(snappy blocks unpacked on 8 threads), verify + decode on "
+                                         "16 threads, upsert")
     mt2.close()
     # the same table in 16 shard files (shards are written / read by threads of their own)
     for f in os.listdir(tmp):

@@ -7,9 +7,15 @@
 //   decode <hexfile> <dim> <nseg> {<kind> <dim>}...                 -> id ts row...
 //   write <path> <snappy 0|1> <n> <len>  -> n records of len bytes, record i filled with byte i
 //   read <path> <snappy 0|1>             -> "<count> <xor of all bytes> <sum of lengths>"
+//   pipeline <chunks> <failing stage 0-2 | -1> <failing chunk>  -> run_pipeline3 over buffers that
+//                                           check the hand-over order: "ok <chunks written>" / ERROR
+//   readbatch <path> <snappy 0|1> <stretch bytes> <threads>  -> the same through read_batch (the
+//                                           restore path: stretches, blocks unpacked on <threads>)
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../monolith_amd/csrc/mhte_ckpt.h"
@@ -93,6 +99,73 @@ int main(int argc, char** argv) {
         for (unsigned char c : rec) x ^= c;
       }
       printf("%llu %u %llu\n", cnt, x, total);
+    } else if (cmd == "pipeline") {
+      const size_t n = size_t(atoll(argv[2]));
+      const int fail_stage = atoi(argv[3]);
+      const size_t fail_chunk = size_t(atoll(argv[4]));
+      // what a slot holds: chunk + 1 once its producer has filled it, 0 once its consumer is done
+      long ab[2] = {0, 0}, bc[2] = {0, 0};
+      size_t written = 0;
+      unsigned seed = 12345;
+      auto jitter = [&seed](int stage) {   // (only stage A draws: one thread)
+        seed = seed * 1664525u + 1013904223u;
+        if (stage == 0 && (seed >> 28) == 0) std::this_thread::sleep_for(std::chrono::microseconds(200));
+      };
+      auto boom = [&](int stage, size_t c) {
+        if (stage == fail_stage && c == fail_chunk) throw std::runtime_error("stage failed as asked");
+      };
+      run_pipeline3(
+          n,
+          [&](size_t c, int slot) {
+            boom(0, c);
+            jitter(0);
+            if (ab[slot] != 0) throw std::runtime_error("A overwrote a buffer B had not taken");
+            ab[slot] = long(c) + 1;
+          },
+          [&](size_t c, int slot) {
+            boom(1, c);
+            if (ab[slot] != long(c) + 1) throw std::runtime_error("B saw the wrong chunk");
+            if (bc[slot] != 0) throw std::runtime_error("B overwrote a buffer C had not taken");
+            if (c % 3 == 0) std::this_thread::sleep_for(std::chrono::microseconds(150));
+            bc[slot] = long(c) + 1;
+            ab[slot] = 0;
+          },
+          [&](size_t c, int slot) {
+            boom(2, c);
+            if (bc[slot] != long(c) + 1) throw std::runtime_error("C saw the wrong chunk");
+            if (c % 5 == 0) std::this_thread::sleep_for(std::chrono::microseconds(300));
+            if (written != c) throw std::runtime_error("C out of order");
+            ++written;
+            bc[slot] = 0;
+          });
+      printf("ok %zu\n", written);
+    } else if (cmd == "readbatch") {
+      RecordReader r(argv[2], atoi(argv[3]) != 0);
+      const size_t stretch = size_t(atoll(argv[4]));
+      const int threads = atoi(argv[5]);
+      ParallelFor par;
+      if (threads > 1)
+        par = [threads](size_t n, const std::function<void(size_t, size_t)>& fn) {
+          std::vector<std::thread> th;
+          const size_t parts = std::min<size_t>(size_t(threads), n);
+          for (size_t k = 0; k < parts; ++k)
+            th.emplace_back([&, k] { fn(n * k / parts, n * (k + 1) / parts); });
+          for (auto& t : th) t.join();
+        };
+      ByteArena arena;
+      std::vector<RecordReader::RecRef> refs;
+      unsigned long long cnt = 0, total = 0, batches = 0;
+      unsigned x = 0;
+      while (r.read_batch(arena, stretch, refs, par)) {
+        ++batches;
+        for (const auto& ref : refs) {
+          r.verify(arena.data() + ref.off, ref.len, ref.crc);
+          ++cnt;
+          total += ref.len;
+          for (uint32_t i = 0; i < ref.len; ++i) x ^= (unsigned char)arena.data()[ref.off + i];
+        }
+      }
+      printf("%llu %u %llu %llu\n", cnt, x, total, batches);
     } else {
       return 2;
     }

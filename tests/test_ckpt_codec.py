@@ -27,7 +27,7 @@ STATE = {SGD: (0, 0), ADAGRAD: (1, 0), FTRL: (2, 0), MOMENTUM: (1, 0), ADADELTA:
 @pytest.fixture(scope="module")
 def driver(tmp_path_factory):
   exe = str(tmp_path_factory.mktemp("ckpt") / "ckpt_driver")
-  subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe,
+  subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe,
                          os.path.join(ROOT, "tests", "ckpt_host_driver.cc")])
   return exe
 
@@ -199,6 +199,14 @@ def test_record_files_roundtrip_and_match_python_reader(driver, tmp_path, snappy
     assert len(path2.read_bytes()) < len(raw2) // 4   # copies were emitted
   cnt2, x2, total2 = (int(v) for v in run(driver, "read", path2, snappy).split())
   assert (cnt2, x2, total2) == (cnt, x, total)
+  # the restore path's reader: stretches of whole records, snappy blocks unpacked side by side; the
+  # stretch size decides where records are cut and carried over, the thread count nothing
+  for f in (path, path2):
+    for stretch, threads in ((1 << 20, 1), (1 << 20, 4), (300000, 3), (1000, 2), (64 << 20, 8)):
+      c, xx, tot, batches = (int(v) for v in run(driver, "readbatch", f, snappy, stretch, threads).split())
+      assert (c, xx, tot) == (cnt, x, total), (f, stretch, threads)
+      if stretch == 1000 and snappy:   # (a plain file is read a MiB at a time at least)
+        assert batches > 3
 
 
 def test_corruption_is_reported(driver, tmp_path):
@@ -209,3 +217,24 @@ def test_corruption_is_reported(driver, tmp_path):
   path.write_bytes(bytes(b))
   r = subprocess.run([driver, "read", str(path), "1"], capture_output=True, text=True)
   assert r.returncode == 1 and "ERROR" in r.stdout
+  r = subprocess.run([driver, "readbatch", str(path), "1", "4096", "2"], capture_output=True, text=True)
+  assert r.returncode == 1 and "ERROR" in r.stdout
+  # a block whose varint promises more bytes than its elements deliver
+  b = bytearray(path.read_bytes())
+  b[40] ^= 0x55          # (undo)
+  b[4] ^= 0x01           # uncompressed length of the first block
+  path.write_bytes(bytes(b))
+  for cmd in (["read", str(path), "1"], ["readbatch", str(path), "1", "4096", "2"]):
+    r = subprocess.run([driver] + cmd, capture_output=True, text=True)
+    assert r.returncode == 1 and "ERROR" in r.stdout
+
+
+def test_save_pipeline_hands_chunks_over_in_order(driver):
+  """run_pipeline3 (the save path's scan | encode | write): two buffer sets between neighbouring
+  stages, every stage in chunk order; a failing stage stops the others and its error comes out."""
+  for n in (0, 1, 2, 3, 64):
+    assert run(driver, "pipeline", n, -1, 0) == "ok %d" % n
+  for stage in (0, 1, 2):
+    for chunk in (0, 1, 7, 31):
+      r = subprocess.run([driver, "pipeline", "32", str(stage), str(chunk)], capture_output=True, text=True)
+      assert r.returncode == 1 and "stage failed as asked" in r.stdout, (stage, chunk, r.stdout)
