@@ -2236,7 +2236,7 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
     ckpt::RecordReader data(ckpt::shard_name(basename, "", sh, total), true);
     ckpt::RecordReader meta(ckpt::shard_name(basename, ".meta", sh, total), false);
     std::string mrec, name;
-    // the data file is read in stretches of ~32 MiB into the stage's arena; `refs[cur..)` are the
+    // the data file is read in stretches of ~64 MiB into the stage's arena; `refs[cur..)` are the
     // records of the current stretch not yet consumed (a stretch may span two tables)
     std::unique_ptr<CkptStage> sgp = t->take_stage();
     struct Return {
@@ -2250,12 +2250,9 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
     std::vector<ckpt::RecordReader::RecRef> refs_buf[2];
     int use = 0;                      // stretch in use: sg.arena[use], refs_buf[use]
     size_t cur = 0;
-    // (a stretch's arena is first touched by the block decoders: the smaller it is, the fewer fresh
-    // pages a restore into a new table faults in, and the warmer it is when the record decoders
-    // read it; 32 MiB is still ~50 000 rows of 512 B per upsert)
-    const size_t kStretch = size_t(32) << 20;
+    const size_t kStretch = size_t(64) << 20;
     // the snappy blocks of a stretch are unpacked side by side on a few threads of the reader's own
-    const int kUnpackThreads = std::min(8, ckpt_codec_threads());
+    const int kUnpackThreads = std::min(4, ckpt_codec_threads());
     const ckpt::ParallelFor unpack = [kUnpackThreads](size_t n, const std::function<void(size_t, size_t)>& fn) {
       parallel_ranges(n, kUnpackThreads, [&](size_t lo, size_t hi, int) { fn(lo, hi); });
     };
@@ -2338,19 +2335,19 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
         if (d.opt == kOptGroupAdagrad) init[size_t(d.st_off)] = d.p[0];  // group_adagrad_optimizer.cc:45-48
       }
       const size_t kBatch = size_t(1) << 18;
-      HostBuf<int64_t>& ids = sg.h_ids[0];
-      HostBuf<uint32_t>& ts = sg.h_ts[0];
-      HostBuf<float>& rows = sg.h_rows[0];
-      ids.reserve(kBatch);
-      ts.reserve(kBatch);
-      rows.reserve(kBatch * rf);
-      std::vector<int64_t> sorted;
       const int P = ckpt_codec_threads();
       std::vector<int64_t> part_max(static_cast<size_t>(P), 0);
       const bool trace = getenv("MHTE_CKPT_TRACE") != nullptr;
-      double t_read = 0, t_dec = 0, t_up = 0;
+      double t_read = 0, t_dec = 0, t_up = 0;   // (read / decode: this thread; upsert: the helper)
       auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-      for (uint64_t done = 0; done < num;) {
+      // Two stages beside each other over the table's batches (ckpt::run_pipeline3, two staging
+      // sets): this thread takes the next records of the stream and verifies + decodes them on P
+      // threads into pinned set b; a helper checks the batch for repeated ids and upserts it.
+      uint64_t done = 0;
+      size_t set_n[2] = {0, 0};
+      int64_t set_max_ts[2] = {0, 0};
+      auto decode = [&](size_t, int b) -> bool {
+        if (done >= num) return false;
         // the file is read in order (one reader per shard); a batch's records are verified (data
         // crc) and decoded in place, on P threads
         const double t0 = now();
@@ -2358,6 +2355,12 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
         const size_t nb = take(std::min<uint64_t>(kBatch, num - done), &first);
         if (!nb) throw Error(MHTE_INTERNAL, "checkpoint shard ends early");
         const double t1 = now();
+        HostBuf<int64_t>& ids = sg.h_ids[b];
+        HostBuf<uint32_t>& ts = sg.h_ts[b];
+        HostBuf<float>& rows = sg.h_rows[b];
+        ids.reserve(nb);
+        ts.reserve(nb);
+        rows.reserve(nb * rf);
         const char* base = sg.arena[use].data();
         const std::vector<ckpt::RecordReader::RecRef>& refs = refs_buf[use];
         parallel_ranges(nb, P, [&](size_t lo, size_t hi, int k) {
@@ -2382,28 +2385,46 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
           max_ts = std::max(max_ts, part_max[size_t(k)]);
           part_max[size_t(k)] = 0;
         }
-        const double t2 = now();
+        set_n[b] = nb;
+        set_max_ts[b] = max_ts;
+        done += nb;
+        t_read += t1 - t0;
+        t_dec += now() - t1;
+        return true;
+      };
+      std::vector<uint32_t> seen;   // open-addressing set of the batch's ids: index + 1, 0 = free
+      auto upsert = [&](size_t, int b) {
+        const double t0 = now();
+        HIP_OK(hipSetDevice(t->device));   // (a thread of the pipeline's own)
+        const size_t nb = set_n[b];
+        const int64_t* ids = sg.h_ids[b].p;
         // ids inside one batch must be distinct for the upsert: a checkpoint holds each id once
         // per table, but two shards of a foreign writer could repeat one — later entries win by
         // flushing batch after batch
-        sorted.assign(ids.p, ids.p + nb);
-        std::sort(sorted.begin(), sorted.end());
-        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
-          throw Error(MHTE_INVALID_ARGUMENT, "checkpoint repeats an id inside table " + name);
+        size_t cap = 1024;
+        while (cap < 2 * nb) cap <<= 1;
+        seen.assign(cap, 0u);
+        for (size_t i = 0; i < nb; ++i) {
+          size_t h = size_t(hash_key(ids[i])) & (cap - 1);
+          while (seen[h]) {
+            if (ids[seen[h] - 1] == ids[i])
+              throw Error(MHTE_INVALID_ARGUMENT, "checkpoint repeats an id inside table " + name);
+            h = (h + 1) & (cap - 1);
+          }
+          seen[h] = uint32_t(i + 1);
+        }
         {
           std::lock_guard<std::mutex> g(tb.mu);
-          tb.max_update_ts = std::max<int64_t>(tb.max_update_ts, max_ts);
-          restore_batch(tb, sg, ids.p, rows.p, ts.p, int64_t(nb), st);
+          tb.max_update_ts = std::max<int64_t>(tb.max_update_ts, set_max_ts[b]);
+          restore_batch(tb, sg, ids, sg.h_rows[b].p, sg.h_ts[b].p, int64_t(nb), st);
         }
-        done += nb;
-        t_read += t1 - t0;
-        t_dec += t2 - t1;
-        t_up += now() - t2;
-      }
+        t_up += now() - t0;
+      };
+      ckpt::run_pipeline3(size_t(-1), decode, upsert, [](size_t, int) {});
       if (trace)
         fprintf(stderr, "[mhte ckpt] restore %s shard %d/%d: %llu rows, read %.3f s, verify+decode(%d thr) "
-                        "%.3f s, sort+upsert %.3f s\n", name.c_str(), sh, total, (unsigned long long)num,
-                t_read, P, t_dec, t_up);
+                        "%.3f s | dup check + upsert %.3f s (beside each other)\n", name.c_str(), sh, total,
+                (unsigned long long)num, t_read, P, t_dec, t_up);
     }
     size_t first = 0;
     if (take(1, &first)) throw Error(MHTE_INTERNAL, "Couldn't read all of checkpoint shard");

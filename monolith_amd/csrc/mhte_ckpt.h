@@ -38,6 +38,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <thread>
+#include <type_traits>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -952,40 +953,50 @@ class RecordReader {
   size_t pos_ = 0;
 };
 
-// Three stages over chunks 0 .. n-1 — the save path's scan | encode | write.  Every stage takes the
-// chunks in order on a thread of its own (stage A on the caller's); neighbouring stages hand over
-// through TWO buffer sets (slot = chunk & 1), so
+// Three stages over chunks 0 .. n-1 — the save path's scan | encode | write, the restore path's
+// decode | upsert.  Every stage takes the chunks in order on a thread of its own (stage A on the
+// caller's); neighbouring stages hand over through TWO buffer sets (slot = chunk & 1), so
 //     A(c) starts after B(c-2),   B(c) after A(c) and C(c-2),   C(c) after B(c),
-// and while one chunk is written the next is encoded and the one after it scanned.  The first
-// exception of any stage stops the others at their next chunk and is rethrown here, after both
-// helper threads have ended (nothing keeps running into the caller's buffers).
+// and while one chunk is written the next is encoded and the one after it scanned.  Stage A may
+// return bool: false says "the stream ended, there is no chunk c" (n is then only an upper bound).
+// The first exception of any stage stops the others at their next chunk and is rethrown here,
+// after both helper threads have ended (nothing keeps running into the caller's buffers).
 template <class FA, class FB, class FC>
 inline void run_pipeline3(size_t n, FA&& stage_a, FB&& stage_b, FC&& stage_c) {
   if (n == 0) return;
   std::mutex mu;
   std::condition_variable cv;
   size_t done_a = 0, done_b = 0, done_c = 0;   // chunks each stage has finished
+  size_t total = n;                            // (lowered by a stage A that reports the end)
   std::exception_ptr err;
   auto fail = [&] {
     std::lock_guard<std::mutex> g(mu);
     if (!err) err = std::current_exception();
     cv.notify_all();
   };
-  // false: another stage failed
-  auto wait_for = [&](const std::function<bool()>& ready) {
+  // waits until chunk c may be taken; false: there is no chunk c, or another stage failed
+  auto wait_for = [&](size_t c, const std::function<bool()>& ready) {
     std::unique_lock<std::mutex> g(mu);
-    cv.wait(g, [&] { return err || ready(); });
-    return !err;
+    cv.wait(g, [&] { return err || c >= total || ready(); });
+    return !err && c < total;
   };
   auto finished = [&](size_t& counter) {
     std::lock_guard<std::mutex> g(mu);
     ++counter;
     cv.notify_all();
   };
+  auto call_a = [&](size_t c, int slot) -> bool {
+    if constexpr (std::is_void<decltype(stage_a(c, slot))>::value) {
+      stage_a(c, slot);
+      return true;
+    } else {
+      return stage_a(c, slot);
+    }
+  };
   auto run_b = [&] {
     try {
-      for (size_t c = 0; c < n; ++c) {
-        if (!wait_for([&] { return done_a > c && done_c + 2 > c; })) return;
+      for (size_t c = 0;; ++c) {
+        if (!wait_for(c, [&] { return done_a > c && done_c + 2 > c; })) return;
         stage_b(c, int(c & 1));
         finished(done_b);
       }
@@ -995,8 +1006,8 @@ inline void run_pipeline3(size_t n, FA&& stage_a, FB&& stage_b, FC&& stage_c) {
   };
   auto run_c = [&] {
     try {
-      for (size_t c = 0; c < n; ++c) {
-        if (!wait_for([&] { return done_b > c; })) return;
+      for (size_t c = 0;; ++c) {
+        if (!wait_for(c, [&] { return done_b > c; })) return;
         stage_c(c, int(c & 1));
         finished(done_c);
       }
@@ -1008,9 +1019,14 @@ inline void run_pipeline3(size_t n, FA&& stage_a, FB&& stage_b, FC&& stage_c) {
   try {
     tb = std::thread(run_b);
     tc = std::thread(run_c);
-    for (size_t c = 0; c < n; ++c) {
-      if (!wait_for([&] { return done_b + 2 > c; })) break;
-      stage_a(c, int(c & 1));
+    for (size_t c = 0;; ++c) {
+      if (!wait_for(c, [&] { return done_b + 2 > c; })) break;
+      if (!call_a(c, int(c & 1))) {
+        std::lock_guard<std::mutex> g(mu);
+        total = c;
+        cv.notify_all();
+        break;
+      }
       finished(done_a);
     }
   } catch (...) {   // (a stage A failure, or a helper thread that could not be started)

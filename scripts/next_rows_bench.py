@@ -104,9 +104,9 @@ def bench_checkpoint():
     tr = time.perf_counter() - t
     assert mt2.size("emb") == n
     emit("checkpoint restore (same files into an empty table)", tr, n * row_bytes, rows=n,
-         rows_per_s=round(n / tr), bound="per shard: a reader thread ahead by one 32 MiB stretch "
-                                         "(snappy blocks unpacked on 8 threads), verify + decode on "
-                                         "16 threads, upsert")
+         rows_per_s=round(n / tr), bound="per shard: a reader thread ahead by one 64 MiB stretch "
+                                         "(snappy blocks unpacked on 4 threads) | verify + decode on "
+                                         "16 threads | duplicate check + upsert, beside each other")
     mt2.close()
     # the same table in 16 shard files (shards are written / read by threads of their own)
     for f in os.listdir(tmp):

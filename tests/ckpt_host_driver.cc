@@ -7,8 +7,9 @@
 //   decode <hexfile> <dim> <nseg> {<kind> <dim>}...                 -> id ts row...
 //   write <path> <snappy 0|1> <n> <len>  -> n records of len bytes, record i filled with byte i
 //   read <path> <snappy 0|1>             -> "<count> <xor of all bytes> <sum of lengths>"
-//   pipeline <chunks> <failing stage 0-2 | -1> <failing chunk>  -> run_pipeline3 over buffers that
-//                                           check the hand-over order: "ok <chunks written>" / ERROR
+//   pipeline <chunks> <failing stage 0-2 | -1> <failing chunk> [<end>]  -> run_pipeline3 over buffers
+//                                           that check the hand-over order: "ok <chunks written>" /
+//                                           ERROR; <end>: stage A reports the end at that chunk
 //   readbatch <path> <snappy 0|1> <stretch bytes> <threads>  -> the same through read_batch (the
 //                                           restore path: stretches, blocks unpacked on <threads>)
 #include <cstdio>
@@ -103,6 +104,7 @@ int main(int argc, char** argv) {
       const size_t n = size_t(atoll(argv[2]));
       const int fail_stage = atoi(argv[3]);
       const size_t fail_chunk = size_t(atoll(argv[4]));
+      const size_t end_at = argc > 5 ? size_t(atoll(argv[5])) : size_t(-1);
       // what a slot holds: chunk + 1 once its producer has filled it, 0 once its consumer is done
       long ab[2] = {0, 0}, bc[2] = {0, 0};
       size_t written = 0;
@@ -116,11 +118,13 @@ int main(int argc, char** argv) {
       };
       run_pipeline3(
           n,
-          [&](size_t c, int slot) {
+          [&](size_t c, int slot) -> bool {
             boom(0, c);
             jitter(0);
+            if (c == end_at) return false;
             if (ab[slot] != 0) throw std::runtime_error("A overwrote a buffer B had not taken");
             ab[slot] = long(c) + 1;
+            return true;
           },
           [&](size_t c, int slot) {
             boom(1, c);

@@ -234,6 +234,8 @@ def test_save_pipeline_hands_chunks_over_in_order(driver):
   stages, every stage in chunk order; a failing stage stops the others and its error comes out."""
   for n in (0, 1, 2, 3, 64):
     assert run(driver, "pipeline", n, -1, 0) == "ok %d" % n
+  for end in (0, 1, 2, 9, 40):        # a stage A that says where the stream ends (n: an upper bound)
+    assert run(driver, "pipeline", 1000000, -1, 0, end) == "ok %d" % end
   for stage in (0, 1, 2):
     for chunk in (0, 1, 7, 31):
       r = subprocess.run([driver, "pipeline", "32", str(stage), str(chunk)], capture_output=True, text=True)
