@@ -290,12 +290,12 @@ struct ShardStep {
     A.flags = d_flags;
     A.n_max = uint32_t(max_batch);
     fill_tabs(A.tab);
-    uint32_t gx_sum = 0, gx_build = 0;
     if (sum_slot >= 0) {
       A.grads = grads;
       A.rows_out = snd_rows;
       A.slot_off = slot_off[sum_slot];
       A.slot = uint32_t(sum_slot);
+      uint32_t gx_sum = 0;   // (the grid below is the per-table maximum of build + sum blocks)
       gather_tabs(A.gt, sum_slot, &gx_sum);
     }
     if (build_slot >= 0) {
@@ -305,10 +305,7 @@ struct ShardStep {
       A.send_ids = ids_send[build_slot];
       A.slot_off_build = slot_off[build_slot];
       A.build_slot = uint32_t(build_slot);
-      for (uint32_t t = 0; t < T; ++t) {
-        A.n_build[t] = ms.n_slot[build_slot][t];
-        if (A.n_build[t]) gx_build = std::max(gx_build, ms.h_st[t].nblk_build);
-      }
+      for (uint32_t t = 0; t < T; ++t) A.n_build[t] = ms.n_slot[build_slot][t];
       hdr_dirty[build_slot] = true;
       ms.stage[build_slot] = 2;
       disp[build_slot] = true;
@@ -316,8 +313,6 @@ struct ShardStep {
     uint32_t gx = 0;
     for (uint32_t t = 0; t < T; ++t)
       gx = std::max(gx, (A.n_build[t] ? ms.h_st[t].nblk_build : 0u) + A.gt[t].nblk_items + A.gt[t].nblk_ids);
-    (void)gx_sum;
-    (void)gx_build;
     if (!gx) return;
     LAUNCH_HOT(kTagShardBuild, shard_build_kernel, dim3(gx, T), 256, st, A);
     HIP_OK(hipGetLastError());
