@@ -26,7 +26,9 @@
 #include <string.h>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <errno.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 
 #include <stdlib.h>
@@ -615,12 +617,17 @@ constexpr size_t kSnappyBlock = 262144;  // RecordWriterOptions' snappy input bu
 
 class RecordWriter {
  public:
-  RecordWriter(const std::string& path, bool snappy) : snappy_(snappy) {
-    fp_ = fopen(path.c_str(), "wb");
-    if (!fp_) throw std::runtime_error("cannot create " + path);
+  RecordWriter(const std::string& path, bool snappy) : snappy_(snappy), path_(path) {
+    fd_ = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+    if (fd_ < 0) throw std::runtime_error("cannot create " + path);
   }
-  ~RecordWriter() {
-    if (fp_) fclose(fp_);
+  ~RecordWriter() {   // (without close(): what was collected goes out, errors are not reported)
+    if (fd_ < 0) return;
+    try {
+      flush_out();
+    } catch (...) {
+    }
+    ::close(fd_);
   }
   void write(const std::string& rec) {
     char hdr[12];
@@ -652,74 +659,154 @@ class RecordWriter {
   }
   void write_framed(const std::string& bytes) { emit(bytes.data(), bytes.size()); }
   void close() {
-    if (!fp_) return;
+    if (fd_ < 0) return;
     if (snappy_) flush_block();
-    if (fclose(fp_) != 0) {
-      fp_ = nullptr;
-      throw std::runtime_error("checkpoint write failed (close)");
-    }
-    fp_ = nullptr;
+    flush_out();
+    const int fd = fd_;
+    fd_ = -1;
+    if (::close(fd) != 0) throw std::runtime_error("checkpoint write failed (close) " + path_);
   }
 
  private:
+  // Output goes to the descriptor directly.  Small pieces (record files without compression, block
+  // headers) collect in out_; the payload of whole snappy blocks is handed to writev() from where
+  // it lies — the caller's buffer — so a gigabyte stream is copied once, into the page cache.
+  void write_all(const struct iovec* iov_in, int cnt) {
+    std::vector<struct iovec> iov(iov_in, iov_in + cnt);
+    size_t at = 0;
+    while (at < iov.size()) {
+      const int batch = int(std::min<size_t>(iov.size() - at, 512));
+      const ssize_t w = ::writev(fd_, iov.data() + at, batch);
+      if (w < 0) {
+        if (errno == EINTR) continue;
+        throw std::runtime_error("checkpoint write failed: " + path_);
+      }
+      size_t left = size_t(w);
+      while (left && at < iov.size()) {   // (a short write: resume inside the vector)
+        if (left >= iov[at].iov_len) {
+          left -= iov[at].iov_len;
+          ++at;
+        } else {
+          iov[at].iov_base = static_cast<char*>(iov[at].iov_base) + left;
+          iov[at].iov_len -= left;
+          left = 0;
+        }
+      }
+      while (at < iov.size() && iov[at].iov_len == 0) ++at;
+    }
+  }
+  void flush_out() {
+    if (out_.empty()) return;
+    struct iovec v;
+    v.iov_base = &out_[0];
+    v.iov_len = out_.size();
+    write_all(&v, 1);
+    out_.clear();
+  }
   void emit(const char* p, size_t n) {
     if (!snappy_) {
-      if (n && fwrite(p, 1, n, fp_) != n) throw std::runtime_error("checkpoint write failed");
+      if (n >= (size_t(1) << 16)) {   // (large pieces skip the collecting buffer)
+        flush_out();
+        struct iovec v;
+        v.iov_base = const_cast<char*>(p);
+        v.iov_len = n;
+        write_all(&v, 1);
+        return;
+      }
+      out_.append(p, n);
+      if (out_.size() >= (size_t(1) << 20)) flush_out();
       return;
     }
-    while (n) {
+    // top up a partly filled block first
+    if (!buf_.empty()) {
       const size_t take = std::min(n, kSnappyBlock - buf_.size());
       buf_.append(p, take);
       p += take;
       n -= take;
       if (buf_.size() == kSnappyBlock) flush_block();
     }
+    // whole blocks straight from the caller's memory
+    if (n >= kSnappyBlock) {
+      const size_t blocks = n / kSnappyBlock;
+      write_blocks(p, blocks);
+      p += blocks * kSnappyBlock;
+      n -= blocks * kSnappyBlock;
+    }
+    if (n) buf_.append(p, n);
   }
-  // one raw snappy block made of literal elements (snappy_compress_literals' bytes, written
-  // straight from the buffer)
-  void flush_block() {
-    if (buf_.empty()) return;
-    const size_t n = buf_.size();
-    auto tag_of = [](size_t len, char* t) -> size_t {
-      const size_t l1 = len - 1;
-      if (l1 < 60) {
-        t[0] = char(l1 << 2);
-        return 1;
-      }
-      if (l1 < 256) {
-        t[0] = char(60 << 2);
-        t[1] = char(l1);
-        return 2;
-      }
-      t[0] = char(61 << 2);
-      t[1] = char(l1 & 0xff);
-      t[2] = char(l1 >> 8);
-      return 3;
-    };
+  static size_t literal_tag(size_t len, char* t) {
+    const size_t l1 = len - 1;
+    if (l1 < 60) {
+      t[0] = char(l1 << 2);
+      return 1;
+    }
+    if (l1 < 256) {
+      t[0] = char(60 << 2);
+      t[1] = char(l1);
+      return 2;
+    }
+    t[0] = char(61 << 2);
+    t[1] = char(l1 & 0xff);
+    t[2] = char(l1 >> 8);
+    return 3;
+  }
+  // [4-byte big-endian packed length | varint n | literal elements of <= 64 KiB] for n bytes at p,
+  // as iovecs: the small parts are appended to `meta` (reserved by the caller: no reallocation)
+  void block_iov(const char* p, size_t n, std::string& meta, std::vector<struct iovec>& iov) {
     char t[3];
     size_t cl = size_t(varint_len(n));
-    for (size_t i = 0; i < n; i += 65536) {
-      const size_t len = std::min<size_t>(n - i, 65536);
-      cl += tag_of(len, t) + len;
-    }
+    for (size_t i = 0; i < n; i += 65536) cl += literal_tag(std::min<size_t>(n - i, 65536), t) + std::min<size_t>(n - i, 65536);
     char head[4 + 10];
     head[0] = char(cl >> 24);
     head[1] = char(cl >> 16);
     head[2] = char(cl >> 8);
     head[3] = char(cl);
     char* e = put_varint_raw(head + 4, n);
-    bool ok = fwrite(head, 1, size_t(e - head), fp_) == size_t(e - head);
-    for (size_t i = 0; i < n && ok; i += 65536) {
+    auto small = [&](const char* q, size_t m) {
+      struct iovec v;
+      v.iov_base = &meta[0] + meta.size();
+      v.iov_len = m;
+      meta.append(q, m);
+      iov.push_back(v);
+    };
+    small(head, size_t(e - head));
+    for (size_t i = 0; i < n; i += 65536) {
       const size_t len = std::min<size_t>(n - i, 65536);
-      const size_t tl = tag_of(len, t);
-      ok = fwrite(t, 1, tl, fp_) == tl && fwrite(buf_.data() + i, 1, len, fp_) == len;
+      small(t, literal_tag(len, t));
+      struct iovec v;
+      v.iov_base = const_cast<char*>(p + i);
+      v.iov_len = len;
+      iov.push_back(v);
     }
-    if (!ok) throw std::runtime_error("checkpoint write failed");
+  }
+  void write_blocks(const char* p, size_t blocks) {
+    flush_out();
+    std::string meta;
+    std::vector<struct iovec> iov;
+    const size_t kPer = 32;   // blocks per writev round (8 MiB)
+    for (size_t b0 = 0; b0 < blocks; b0 += kPer) {
+      const size_t nb = std::min(kPer, blocks - b0);
+      meta.clear();
+      meta.reserve(nb * 32);
+      iov.clear();
+      for (size_t b = 0; b < nb; ++b) block_iov(p + (b0 + b) * kSnappyBlock, kSnappyBlock, meta, iov);
+      write_all(iov.data(), int(iov.size()));
+    }
+  }
+  // one raw snappy block made of literal elements (snappy_compress_literals' bytes) from buf_
+  void flush_block() {
+    if (buf_.empty()) return;
+    flush_out();
+    std::string meta;
+    meta.reserve(64);
+    std::vector<struct iovec> iov;
+    block_iov(buf_.data(), buf_.size(), meta, iov);
+    write_all(iov.data(), int(iov.size()));
     buf_.clear();
   }
-  FILE* fp_ = nullptr;
+  int fd_ = -1;
   bool snappy_;
-  std::string buf_;
+  std::string path_, buf_, out_;
 };
 
 class RecordReader {
