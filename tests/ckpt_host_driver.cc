@@ -6,6 +6,9 @@
 //   entry <id> <ts> <dim> <nseg> {<kind> <dim>}... <row floats...>  -> EntryDump bytes, hex
 //   decode <hexfile> <dim> <nseg> {<kind> <dim>}...                 -> id ts row...
 //   write <path> <snappy 0|1> <n> <len>  -> n records of len bytes, record i filled with byte i
+//   writeparts <path> <snappy 0|1> <parts> <n> <len>  -> the save path's pattern: <parts> buffers of n
+//                                           framed records each (record j of part p filled with byte
+//                                           p + j, len + j % 7 bytes) through write_framed
 //   read <path> <snappy 0|1>             -> "<count> <xor of all bytes> <sum of lengths>"
 //   pipeline <chunks> <failing stage 0-2 | -1> <failing chunk> [<end>]  -> run_pipeline3 over buffers
 //                                           that check the hand-over order: "ok <chunks written>" /
@@ -88,6 +91,15 @@ int main(int argc, char** argv) {
       RecordWriter w(argv[2], atoi(argv[3]) != 0);
       const int n = atoi(argv[4]), len = atoi(argv[5]);
       for (int i = 0; i < n; ++i) w.write(std::string(size_t(len + i % 7), char(i)));
+      w.close();
+    } else if (cmd == "writeparts") {
+      RecordWriter w(argv[2], atoi(argv[3]) != 0);
+      const int parts = atoi(argv[4]), n = atoi(argv[5]), len = atoi(argv[6]);
+      for (int p = 0; p < parts; ++p) {
+        std::string part;
+        for (int j = 0; j < n; ++j) RecordWriter::frame(part, std::string(size_t(len + j % 7), char(p + j)));
+        w.write_framed(part);
+      }
       w.close();
     } else if (cmd == "read") {
       RecordReader r(argv[2], atoi(argv[3]) != 0);

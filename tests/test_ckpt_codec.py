@@ -209,6 +209,54 @@ def test_record_files_roundtrip_and_match_python_reader(driver, tmp_path, snappy
         assert batches > 3
 
 
+def _literal_only_stream(raw: bytes) -> bytes:
+  """What the engine's writer emits for a record stream (mhte_ckpt.h RecordWriter): blocks of
+  <= 256 KiB, each [4-byte big-endian packed length | varint length | literal elements <= 64 KiB]."""
+  def varint(v):
+    out = bytearray()
+    while v >= 0x80:
+      out.append((v & 0x7f) | 0x80)
+      v >>= 7
+    out.append(v)
+    return bytes(out)
+  out = bytearray()
+  for b0 in range(0, len(raw), 262144):
+    blk = raw[b0:b0 + 262144]
+    body = bytearray(varint(len(blk)))
+    for i in range(0, len(blk), 65536):
+      lit = blk[i:i + 65536]
+      l1 = len(lit) - 1
+      if l1 < 60:
+        body.append(l1 << 2)
+      elif l1 < 256:
+        body += bytes([60 << 2, l1])
+      else:
+        body += bytes([61 << 2, l1 & 0xff, l1 >> 8])
+      body += lit
+    out += len(body).to_bytes(4, "big") + body
+  return bytes(out)
+
+
+@pytest.mark.parametrize("n,ln", [(1, 5), (397, 660), (3000, 300), (900, 1171), (2, 300000)])
+def test_writer_output_is_the_literal_only_block_stream(driver, tmp_path, n, ln):
+  """Byte for byte: the writer hands whole blocks to writev() from the caller's buffer and tops
+  up partial ones through its own — the file must not depend on how the bytes arrived."""
+  path = tmp_path / "w"
+  run(driver, "write", path, 1, n, ln)
+  recs = [bytes([i & 0xff]) * (ln + i % 7) for i in range(n)]
+  raw = b"".join(P.frame(r) for r in recs)
+  assert path.read_bytes() == _literal_only_stream(raw)
+  run(driver, "write", path, 0, n, ln)
+  assert path.read_bytes() == raw
+  # the save path's pattern: a few large buffers of framed records
+  parts = 5
+  raw = b"".join(P.frame(bytes([(p + j) & 0xff]) * (ln + j % 7)) for p in range(parts) for j in range(n))
+  run(driver, "writeparts", path, 1, parts, n, ln)
+  assert path.read_bytes() == _literal_only_stream(raw)
+  run(driver, "writeparts", path, 0, parts, n, ln)
+  assert path.read_bytes() == raw
+
+
 def test_corruption_is_reported(driver, tmp_path):
   path = tmp_path / "c"
   run(driver, "write", path, 1, 50, 100)
