@@ -99,6 +99,20 @@ def algorithmic_bytes(B, U, D, S):
   return lookup + update, per_kernel
 
 
+def emit_line(obj):
+  """The bench's ONE JSON line, as the last thing on stdout.  Native libraries write to the C stdio
+  buffer (RCCL prints its version block there when a communicator is made), which a piped stdout
+  only receives at exit — after everything Python printed.  Flushing it first keeps the JSON line
+  last."""
+  import ctypes
+  try:
+    ctypes.CDLL(None).fflush(None)
+  except OSError:
+    pass
+  sys.stdout.write(json.dumps(obj) + "\n")
+  sys.stdout.flush()
+
+
 def peer_unique_max(ids_host, world):
   """Largest number of distinct ids one batch of `ids_host` [steps, B] sends to one owner
   (owner = id mod world, NT/distributed_ps.py:289)."""
@@ -499,7 +513,7 @@ def main_dlrm(args):
   }
   if cpu and cpu.get("value"):
     out_json["vs_cpu_baseline"] = round(value / cpu["value"], 2)
-  print(json.dumps(out_json))
+  emit_line(out_json)
 
 
 def cpu_child(args):
@@ -1050,11 +1064,13 @@ def main():
       out["vs_cpu_baseline"] = round(value / cpu["value"], 2)
     if graph_err:
       out["graph_error"] = graph_err
-    print(json.dumps(out))
+  # communicators go first: whatever their teardown prints must not follow the JSON line
   if sharded:
     se.close()
   if world > 1:
     dist.destroy_process_group()
+  if rank == 0:
+    emit_line(out)
 
 
 if __name__ == "__main__":
