@@ -104,12 +104,17 @@ def emit_line(obj):
   buffer (RCCL prints its version block there when a communicator is made), which a piped stdout
   only receives at exit — after everything Python printed.  Flushing it first keeps the JSON line
   last."""
+  flush_native_stdout()
+  sys.stdout.write(json.dumps(obj) + "\n")
+  sys.stdout.flush()
+
+
+def flush_native_stdout():
   import ctypes
   try:
     ctypes.CDLL(None).fflush(None)
   except OSError:
     pass
-  sys.stdout.write(json.dumps(obj) + "\n")
   sys.stdout.flush()
 
 
@@ -1064,11 +1069,16 @@ def main():
       out["vs_cpu_baseline"] = round(value / cpu["value"], 2)
     if graph_err:
       out["graph_error"] = graph_err
-  # communicators go first: whatever their teardown prints must not follow the JSON line
+  # communicators go first: whatever their teardown prints must not follow the JSON line; the
+  # other ranks empty their C stdio buffers (RCCL's version block) before rank 0 gets that far
+  flush_native_stdout()
+  if world > 1:
+    barrier()
   if sharded:
     se.close()
   if world > 1:
     dist.destroy_process_group()
+  flush_native_stdout()
   if rank == 0:
     emit_line(out)
 
