@@ -307,3 +307,36 @@ def test_group_adagrad_list_kat():
   np.testing.assert_allclose(t.lookup(one)[0][0], [-0.008639, -0.000864], rtol=0, atol=1e-6)
   t.optimize(one, np.array([[1.0, 5.0]], np.float32), [0.01], 0)
   np.testing.assert_allclose(t.lookup(one)[0][0], [-0.009096, -0.004778], rtol=0, atol=1e-6)
+
+
+@needs_ref
+def test_eviction_interleaved_with_inserts_matches_reference_map():
+  """TTL eviction (cuckoohash_map.hpp:775-799 through cuckoo_embedding_hash_table.cc:251-264) between
+  rounds of inserts: the slots an eviction frees are the ones later inserts take (last empty slot of
+  the first bucket, :1398-1418), so physical placement after several evict / refill rounds pins the
+  restatement's erase and its interaction with doubling."""
+  rng = np.random.default_rng(4242)
+  dim = 4
+  t = O.Table(O.segment(dim, O.OPT_SGD), 1)
+  r = O.RefTable(dim, O.OPT_SGD, 0.1, 0.0, 0.0, 1)
+  day = 86400
+  ttl = {1: 1, 2: 3}                      # feature slot -> days; everything else: 7 days
+  t.set_ttl(7, ttl)
+  r.set_ttl(7, ttl)
+  now = 1_700_000_000
+  sig = rng.integers(0, 2**40, 40000)
+  slots = rng.integers(1, 5, sig.size)    # feature slots 1..4 (bit 63 clear)
+  universe = (slots.astype(np.int64) << 48) | sig.astype(np.int64)
+  for rnd in range(6):
+    ids = rng.choice(universe, 6000)
+    v = rng.standard_normal((ids.size, dim)).astype(np.float32)
+    t.optimize(ids, v, [0.05], now)
+    r.optimize(ids, v, 0.05, now)
+    now += day * (1 + rnd % 3)            # 1, 2, 3 days later: slot-1 rows always expire, slot-2 sometimes
+    t.evict(now)
+    r.evict(now)
+    assert t.size() == r.size() and t.hashpower() == r.hashpower(), rnd
+    a, b = t.dump(), r.dump()
+    for x, y in zip(a, b):
+      np.testing.assert_array_equal(x, y)
+  assert 0 < t.size() < 24000             # (something was evicted, something stayed)
