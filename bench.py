@@ -74,9 +74,16 @@ def parse():
                       "the multi-GPU step without any link traffic; a measurement, not the bench line")
   p.add_argument("--reserve-ahead", action="store_true",
                  help="forward launch reserves the row handles of the update (SparseStep.reserve_ahead)")
-  p.add_argument("--dist-backend", default="nccl",
-                 help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo stages through "
-                      "host memory and lets several ranks share one GPU: a functional check only)")
+  p.add_argument("--dist-backend", default="auto", choices=["auto", "nccl", "gloo", "ipc"],
+                 help="torch.distributed backend of the launcher's side channel for --gpus > 1 (rendezvous, "
+                      "barriers, the max-over-ranks reduction): auto = nccl (RCCL) with one device per "
+                      "rank, gloo when ranks share a device (RCCL cannot place two ranks on one GPU); "
+                      "ipc = gloo + --transport ipc")
+  p.add_argument("--transport", default="auto", choices=["auto", "ipc", "rccl", "torch"],
+                 help="the sharded step's exchanges: ipc = direct peer stores into hipIpc-mapped windows "
+                      "(device-sized, works across xGMI and between ranks sharing a GPU); rccl = "
+                      "ncclSend / ncclRecv groups; auto = ipc if every rank's self test passes, else "
+                      "rccl; torch = round 1's torch.distributed form of the step (functional check)")
   p.add_argument("--trace-out", default="",
                  help="write a per-wavefront timeline (.npz) of three pipelined steps")
   p.add_argument("--no-stage-timing", action="store_true",
@@ -116,6 +123,28 @@ def flush_native_stdout():
   except OSError:
     pass
   sys.stdout.flush()
+
+
+def spawn_ranks(n):
+  """`python bench.py --gpus N` without a launcher: run the N ranks under torch.distributed.run
+  (one process per rank, rendezvous on 127.0.0.1) and pass their output through — rank 0's JSON line
+  stays the last line of stdout.  On a box with fewer than N GPUs the ranks share devices and the
+  exchanges go through the peer-store transport."""
+  import socket
+  import subprocess
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  port = s.getsockname()[1]
+  s.close()
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  env = dict(os.environ)
+  env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  env.setdefault("OMP_NUM_THREADS", "8")
+  flush_native_stdout()
+  rc = subprocess.call(cmd, env=env)
+  if rc:
+    raise SystemExit(rc)
 
 
 def peer_unique_max(ids_host, world):
@@ -558,15 +587,23 @@ def main():
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-  if args.gpus != world:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit("--gpus %d needs: python -m torch.distributed.run --nproc-per-node %d "
-                       "bench.py --gpus %d" % (args.gpus, args.gpus, args.gpus))
+  if args.gpus != world and world == 1 and args.gpus > 1:
+    return spawn_ranks(args.gpus)   # `python bench.py --gpus N`: launch the N ranks ourselves
   assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
-  local_rank %= torch.cuda.device_count()
+  ndev = torch.cuda.device_count()
+  shared_device = world > ndev        # several ranks per GPU (the 1-GPU box)
+  local_rank %= ndev
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
   sharded = world > 1 or args.force_sharded
+  if args.dist_backend == "ipc":
+    args.dist_backend, args.transport = "gloo", "ipc"
+  if args.dist_backend == "auto":
+    args.dist_backend = "gloo" if shared_device else "nccl"
+  if shared_device and args.transport == "auto":
+    args.transport = "ipc"            # (RCCL refuses two ranks on one device)
+  if shared_device:
+    args.resident_rows = args.resident_rows / -(-world // ndev)   # the ranks of a device share its HBM
   if world > 1:   # (one rank needs no rendezvous: the sharded step's exchange is the identity)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
@@ -739,8 +776,10 @@ def main():
     rag = [Ragged(ids_all[s], splits1) for s in range(n_batches)]
     emb_out = torch.empty(B * D, dtype=torch.float32, device=dev)
     impl = os.environ.get("MHTE_BENCH_SHARDED_IMPL", "")   # "torch": round 1's torch.distributed form
+    if args.transport == "torch":
+      impl = "torch"
     se = None
-    if world > 1 and args.dist_backend != "gloo" and impl != "torch":
+    if world > 1 and args.transport == "rccl" and impl != "torch":
       # the C++ step over RCCL; if RCCL cannot be bound on any rank (a symmetric failure, before the
       # collective communicator set-up), every rank takes the torch.distributed form instead
       err = None
@@ -749,14 +788,14 @@ def main():
         shard_unique_id()
       except Exception as e:  # pylint: disable=broad-except
         err = e
-      flag = torch.tensor([1 if err is not None else 0], device=dev)
+      flag = torch.tensor([1 if err is not None else 0], device=dev if args.dist_backend == "nccl" else "cpu")
       dist.all_reduce(flag, op=dist.ReduceOp.MAX)
       if int(flag.item()):
         if rank == 0:
           print("RCCL could not be bound by the library (%r): torch.distributed form of the step" % (err,),
                 file=sys.stderr)
         impl = "torch"
-    if world > 1 and (args.dist_backend == "gloo" or impl == "torch"):
+    if world > 1 and impl == "torch":
       # ranks sharing one GPU (the 1-GPU box): RCCL cannot put two ranks on a device, so the N > 1
       # control flow of this file is exercised through round 1's torch.distributed form of the step,
       # its exchanges staged through host memory by gloo — not a scaling number
@@ -780,18 +819,11 @@ def main():
           pass
       se = _GlooStep()
     if se is None:
-      ipp = args.ids_per_peer
-      if world > 1 and not ipp:
-        # A (peer, table) block moves at its full configured size, so the capacity is sized from the
-        # id stream the way an operator sizes it from the traffic: 1.25 x the most distinct ids any
-        # rank sends one peer in a step of this run (the library default assumes no duplicates —
-        # several times that on Zipf ids).  Every rank must use the same value.  Going over it is
-        # not silent: the step raises ResourceExhausted (check() below).
-        mx = peer_unique_max(ids_host, world)
-        tt = torch.tensor([mx], dtype=torch.int64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ipp = min(B, (int(tt.item()) * 5 // 4 + 63) // 64 * 64)
-      se = ShardedMultiStep(mt, B, ids_per_peer_table=ipp)
+      # Blocks hold the whole batch by default (no step can overflow one, no id is dropped); the
+      # peer-store transport and RCCL's exact form move only their occupied part.  --ids-per-peer is
+      # an explicit smaller capacity (fixed-size RCCL blocks).
+      se = ShardedMultiStep(mt, B, ids_per_peer_table=args.ids_per_peer,
+                            transport=args.transport if (world > 1 or args.transport == "ipc") else "auto")
 
     host_us = []   # MHTE_BENCH_STEP_TIMES=1: host time of every step's two calls (stall hunting)
     trace_host = os.environ.get("MHTE_BENCH_STEP_TIMES") == "1"
@@ -955,7 +987,7 @@ def main():
   # ---- parity of the benched state: the rows of >= 10 000 ids of the timed stream, read back
   # after everything above, against the oracle's replay of the same update sequence
   parity = None
-  if world == 1 and rank == 0 and not args.no_parity_check:
+  if rank == 0 and not args.no_parity_check:
     if not applied_ok:
       parity = {"skipped": "update log invalid after a failed graph capture"}
     else:
@@ -971,7 +1003,17 @@ def main():
             gcache[g] = S.grad_batch(g, B, D)
           return gcache[g]
 
-        exp = oracle_subset_rows(probe, D, args.opt, lr, applied, lambda b: ids_host[b], grads_of)
+        log, ids_of = applied, (lambda b: ids_host[b])
+        if world > 1:
+          # rank 0's shard after the run: the ids it owns, updated by EVERY rank's batches — one
+          # optimizer application per sender, in rank order (distributed_ps_sync.py:357-479)
+          probe = probe[np.mod(probe, world) == 0]
+          if probe.size > 12000:
+            probe = probe[:: probe.size // 12000 + 1]
+          log = [((b, r), g, t) for (b, g, t) in applied for r in range(world)]
+          ids_of = lambda br: (ids_host[br[0]] if br[1] == 0 else  # noqa: E731
+                               S.id_batch(br[0] * world + br[1], B, V, "zipf"))
+        exp = oracle_subset_rows(probe, D, args.opt, lr, log, ids_of, grads_of)
         got = mt.lookup({"emb": torch.from_numpy(probe).to(dev)})["emb"].cpu().numpy()
         parity = parity_numbers(got, exp)
         parity.update({"updates_replayed": len(applied), "seconds": round(time.time() - t0p, 1),
@@ -1054,8 +1096,9 @@ def main():
                             "(--warmup rounded up to whole graphs), exactly %d steps timed" %
                             (gchunk, Wg, K)) if launch == "graph" else None,
             "parallelism": "1 GPU" if not sharded else
-                           "fid mod %d sharding, 3 fixed-capacity exchanges/step (%s)" %
-                           (world, shard_info["transport"]),
+                           "fid mod %d sharding, 3 exchanges/step for all tables (%s)%s" %
+                           (world, shard_info["transport"],
+                            "; %d ranks share each GPU" % -(-world // ndev) if shared_device else ""),
             "shard_step": shard_info,
             "prefill_s": round(prefill_s, 2),
         },

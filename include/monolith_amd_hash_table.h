@@ -42,7 +42,7 @@ enum {
 
 const char* mhte_last_error(void);
 /* ABI version of this header; mhte_abi_version() must return the same value. */
-#define MHTE_ABI_VERSION 10
+#define MHTE_ABI_VERSION 11
 int32_t mhte_abi_version(void);
 
 /* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
@@ -563,29 +563,47 @@ mhte_status mhte_multi_step_unique_counts(mhte_multi_step* s, int64_t* counts, v
 /* Id-sharded training step over ALL tables, one process per GPU: the reference's sync-training
  * exchange (NT/distributed_ps_sync.py:95-287 lookup, :289-490 apply_gradients; shard =
  * floormod(id, world), NT/distributed_ps.py:289; packing RT/ops/fused_reorder_by_indices.cc:75-123)
- * driven from C++ with RCCL send / recv groups on the caller's stream.  Rank r's mhte_multi_table
+ * driven from C++ (RCCL send / recv groups, or direct peer stores) on the caller's stream.  Rank r's mhte_multi_table
  * holds the ids it owns of every table.  Per step a rank deduplicates its ragged batch, packs the
- * distinct ids into one fixed-capacity block per peer that carries its own per-table counts (no
- * size exchange, no device-to-host copy), and the ranks trade: id blocks -> owners look the rows up
+ * distinct ids into one block per peer that carries its own per-table counts (no size exchange),
+ * and the ranks trade: id blocks -> owners look the rows up
  * (no insert) -> row blocks back -> scatter to the occurrences; gradients: per-id sums in
  * occurrence order -> row-shaped blocks to the owners -> every owner applies the peers' blocks one
  * after the other in rank order (the reference's default of one optimizer application per
  * sender).  Three exchanges per step, all tables in each.
- *   ids_per_peer_table  id slots per (peer, table) block; 0 = max_batch when world == 1, else
- *                       1.5 * max_batch / world + 256.  A step in which one table sends more
- *                       distinct ids than that to one peer hands those ids zero rows, drops their
- *                       gradients and makes the next call (or mhte_shard_step_check) return
- *                       MHTE_RESOURCE_EXHAUSTED.
+ *   ids_per_peer_table  id slots per (peer, table) block; 0 (default) = max_batch: a block can hold
+ *                       the whole batch, so no step can overflow one and no id is ever dropped —
+ *                       the reference's all-to-all is variable-sized.  A smaller value is an explicit
+ *                       choice of fixed-size blocks that cross the links whole: a step in which one
+ *                       table sends more distinct ids than that to one peer hands those ids zero
+ *                       rows, drops their gradients and makes the next call (or
+ *                       mhte_shard_step_check, which must then be called before the step's results
+ *                       are used) return MHTE_RESOURCE_EXHAUSTED.
  *   unique_id           128 bytes from mhte_shard_unique_id on one rank, distributed by the
  *                       launcher: the step creates its RCCL communicator (collective: every rank
  *                       calls create).  NULL with world == 1: no communicator, the exchange is the
  *                       identity.  NULL with world > 1: the ranks live in this process on one device
  *                       and are driven together through mhte_shard_group_* (device copies stand in
  *                       for the links; tests).
- * MHTE_SHARD_EXACT=1 in the environment at creation: the row / gradient exchanges move only the
- * occupied part of every (peer, table) segment; the counts are the id blocks' headers, copied to
- * pinned host memory behind the id exchange (a step ahead of their use for a batch that was
- * prepared ahead).  Default: whole fixed-size blocks, nothing known to the host.
+ * RCCL transport: with the default capacity the row / gradient exchanges move only the occupied
+ * part of every (peer, table) segment; the counts are the id blocks' headers, copied to pinned host
+ * memory behind the id exchange (a step ahead of their use for a batch that was prepared ahead).
+ * With an explicit ids_per_peer_table: whole fixed-size blocks, nothing known to the host.
+ * MHTE_SHARD_EXACT=0 / 1 in the environment at creation overrides the choice.
+ *
+ * Peer-store transport (mhte_shard_step_create_ipc): every rank maps every other rank's receive
+ * WINDOW (hipIpcGetMemHandle / hipIpcOpenMemHandle — across xGMI between devices, or between
+ * processes sharing one device) and an exchange is one copy kernel per rank that stores the
+ * occupied part of every (peer, table) segment straight into the peers' windows, sized ON THE
+ * DEVICE from the id blocks' headers: exact-size exchanges with no count on the host, no size
+ * exchange and no staging copy.  Flow control is two words per (channel, peer) in the windows
+ * (ready-to-receive credit, block-arrived sequence number); a consumer launch is preceded by a
+ * one-wavefront wait for exactly the peers it needs, so an owner applies a peer's gradient block as
+ * soon as that block has landed.  Waits are bounded (MHTE_SHARD_TIMEOUT_MS, default 30 000): a peer
+ * that never arrives makes mhte_shard_step_check / the next call return MHTE_UNAVAILABLE instead of
+ * hanging the queue.  Creation is three calls: create_ipc (allocates the window), ipc_handle (128
+ * bytes for the launcher to gather from every rank), ipc_connect (all ranks' handles, rank-major);
+ * ipc_selftest is a data-less round trip with every peer (collective, synchronises).
  * forward / backward arguments are those of mhte_multi_step_* for this rank's batch; `prefetched`
  * and the next batch must agree across the ranks (the calls are collective).  Tables with an
  * occurrence filter or whole-segment optimizers are rejected.  global_step reaches the optimizers. */
@@ -595,6 +613,12 @@ mhte_status mhte_shard_step_create(mhte_multi_table* t, int64_t max_batch_per_ta
                                    int32_t world, int64_t ids_per_peer_table, const void* unique_id,
                                    mhte_shard_step** out);
 void mhte_shard_step_destroy(mhte_shard_step* s);
+mhte_status mhte_shard_step_create_ipc(mhte_multi_table* t, int64_t max_batch_per_table, int32_t rank,
+                                       int32_t world, int64_t ids_per_peer_table,
+                                       mhte_shard_step** out);
+mhte_status mhte_shard_step_ipc_handle(mhte_shard_step* s, void* out128);
+mhte_status mhte_shard_step_ipc_connect(mhte_shard_step* s, const void* handles, int32_t n_handles);
+mhte_status mhte_shard_step_ipc_selftest(mhte_shard_step* s, void* stream);
 mhte_status mhte_shard_step_forward(mhte_shard_step* s, const int64_t* id, const int64_t* id_split,
                                     int64_t n_split, float* embedding, int64_t embedding_len,
                                     const int64_t* id_next, const int64_t* id_split_next,
@@ -607,7 +631,8 @@ mhte_status mhte_shard_step_check(mhte_shard_step* s, void* stream);
 /* distinct ids per table of this rank's forward batch (host int64[T]); synchronises */
 mhte_status mhte_shard_step_unique_counts(mhte_shard_step* s, int64_t* counts, void* stream);
 /* info[0] = id slots per (peer, table), [1] = bytes of one id block, [2] = bytes of one row block,
- * [3] = transport: 0 identity, 1 RCCL, 2 in-process group */
+ * [3] = transport: 0 identity, 1 RCCL, 2 in-process group, 3 peer stores into fine-grained windows,
+ * 4 peer stores into plain device memory (MHTE_SHARD_WINDOW=coarse) */
 mhte_status mhte_shard_step_info(mhte_shard_step* s, int64_t info[4]);
 /* all `n` ranks of a world living in this process (created with unique_id NULL, world n): the same
  * step, with arrays of per-rank arguments */

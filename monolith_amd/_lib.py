@@ -26,7 +26,7 @@ MHTE_SUM_DUPLICATES = 2
 MHTE_EXACT_ORDER = 1       # flags of mhte_table_sum_optimize_n
 MHTE_DEFER_SLOWPATH = 2
 MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS = 1
-ABI_VERSION = 10           # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
+ABI_VERSION = 11           # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 OPT_MOMENTUM, OPT_ADADELTA, OPT_RMSPROP, OPT_RMSPROPV2, OPT_ADAM, OPT_AMSGRAD = 3, 4, 5, 6, 7, 8
@@ -125,7 +125,8 @@ EXPORTS = [
     "mhte_multi_step_create", "mhte_multi_step_destroy", "mhte_multi_step_forward",
     "mhte_multi_step_backward", "mhte_multi_step_unique_counts",
     "mhte_shard_unique_id", "mhte_shard_step_create", "mhte_shard_step_destroy",
-    "mhte_shard_step_forward", "mhte_shard_step_backward", "mhte_shard_step_check",
+    "mhte_shard_step_create_ipc", "mhte_shard_step_ipc_handle", "mhte_shard_step_ipc_connect",
+    "mhte_shard_step_ipc_selftest", "mhte_shard_step_forward", "mhte_shard_step_backward", "mhte_shard_step_check",
     "mhte_shard_step_info", "mhte_shard_step_unique_counts", "mhte_shard_group_forward", "mhte_shard_group_backward",
     "mhte_multi_table_create_from_proto", "mhte_multi_table_find", "mhte_multi_table_is_initialized",
     "mhte_hash_filter_create_from_proto", "mhte_lookup_entry", "mhte_feature_stat",
@@ -213,7 +214,8 @@ def vp(x):
 PROFILE_TAGS = {1: "lookup_kernel", 2: "sum_apply_kernel", 6: "slowpath_kernel", 7: "dd_kernels",
                 8: "upsert_kernel", 9: "step_fwd_kernel", 10: "step_bwd_kernel",
                 11: "mstep_fwd_kernel", 12: "mstep_bwd_kernel", 13: "shard_build_kernel",
-                14: "shard_lookup_kernel", 15: "shard_scatter_kernel", 16: "shard_upsert_kernel"}
+                14: "shard_lookup_kernel", 15: "shard_scatter_kernel", 16: "shard_upsert_kernel",
+                17: "shard_push_kernel", 18: "shard_wait_kernel"}
 TRACE_WORDS = 8
 TRACE_ROLES = {3: "run_dedup", 4: "displacement", 5: "lookup", 6: "work_list", 7: "apply_items",
                8: "apply_ids", 9: "reserve_rows"}

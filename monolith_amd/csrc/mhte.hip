@@ -164,7 +164,8 @@ enum ProfTag : int32_t {
   kTagLookup = 1, kTagSumApply = 2,
   kTagSlowpath = 6, kTagDedup = 7, kTagUpsert = 8, kTagStepFwd = 9, kTagStepBwd = 10,
   kTagMStepFwd = 11, kTagMStepBwd = 12,
-  kTagShardBuild = 13, kTagShardLookup = 14, kTagShardGather = 15, kTagShardUpsert = 16
+  kTagShardBuild = 13, kTagShardLookup = 14, kTagShardGather = 15, kTagShardUpsert = 16,
+  kTagShardPush = 17, kTagShardWait = 18
 };
 
 // Per-wavefront timeline of the step kernels (mhte_trace_begin / mhte_trace_end): each traced
@@ -3380,6 +3381,47 @@ mhte_status mhte_shard_step_create(mhte_multi_table* t, int64_t max_batch_per_ta
 }
 void mhte_shard_step_destroy(mhte_shard_step* s) { delete s; }
 
+mhte_status mhte_shard_step_create_ipc(mhte_multi_table* t, int64_t max_batch_per_table, int32_t rank,
+                                       int32_t world, int64_t ids_per_peer_table,
+                                       mhte_shard_step** out) {
+  return guard([&] {
+    check_handle(t);
+    if (!out) throw Error(MHTE_INVALID_ARGUMENT, "null out");
+    HIP_OK(hipSetDevice(t->device));
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (auto& tb : t->tables) locks.emplace_back(tb->mu);
+    std::unique_ptr<mhte_shard_step> s(new mhte_shard_step);
+    s->ss.init(t, max_batch_per_table, rank, world, ids_per_peer_table, nullptr, true);
+    *out = s.release();
+  });
+}
+
+mhte_status mhte_shard_step_ipc_handle(mhte_shard_step* s, void* out128) {
+  return guard([&] {
+    if (!s || !out128) throw Error(MHTE_INVALID_ARGUMENT, "null argument");
+    HIP_OK(hipSetDevice(s->ss.device));
+    s->ss.ipc_handle(out128);
+  });
+}
+
+mhte_status mhte_shard_step_ipc_connect(mhte_shard_step* s, const void* handles, int32_t n_handles) {
+  return guard([&] {
+    if (!s || !handles) throw Error(MHTE_INVALID_ARGUMENT, "null argument");
+    if (n_handles != s->ss.world)
+      throw Error(MHTE_INVALID_ARGUMENT, "shard step connect: one handle per rank of the world");
+    HIP_OK(hipSetDevice(s->ss.device));
+    s->ss.ipc_connect(handles);
+  });
+}
+
+mhte_status mhte_shard_step_ipc_selftest(mhte_shard_step* s, void* stream) {
+  return guard([&] {
+    if (!s) throw Error(MHTE_INVALID_ARGUMENT, "null shard step");
+    HIP_OK(hipSetDevice(s->ss.device));
+    s->ss.ipc_selftest(mhte::S(stream));
+  });
+}
+
 mhte_status mhte_shard_step_forward(mhte_shard_step* s, const int64_t* id, const int64_t* id_split,
                                     int64_t n_split, float* embedding, int64_t embedding_len,
                                     const int64_t* id_next, const int64_t* id_split_next,
@@ -3445,7 +3487,7 @@ mhte_status mhte_shard_step_info(mhte_shard_step* s, int64_t info[4]) {
     info[0] = s->ss.cap;
     info[1] = int64_t(s->ss.x_block(kXIds));
     info[2] = int64_t(s->ss.x_block(kXRows));
-    info[3] = s->ss.alias ? 0 : (s->ss.comm ? 1 : 2);
+    info[3] = s->ss.alias ? 0 : s->ss.ipc ? (s->ss.win_fine ? 3 : 4) : (s->ss.comm ? 1 : 2);
   });
 }
 

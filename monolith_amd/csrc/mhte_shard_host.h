@@ -101,8 +101,15 @@ struct ShardStep {
   int64_t* ids_send[2] = {nullptr, nullptr};   // per slot [world][ids_block]
   int64_t* ids_recv[2] = {nullptr, nullptr};
   uint32_t* slot_off[2] = {nullptr, nullptr};  // per slot [T][max_batch]
-  float* own_rows = nullptr;    // owner side: looked-up rows out / gradients in  [world][rows_block]
-  float* snd_rows = nullptr;    // sender side: rows back / gradient sums out
+  // row buffers, each [world][rows_block]: owner side own_rows (looked-up rows out) and own_grads
+  // (gradient sums in), sender side snd_rows (rows back) and snd_grads (gradient sums out).  RCCL /
+  // group / identity: own_grads == own_rows, snd_grads == snd_rows (the two directions of a block
+  // never overlap in time).  Peer-store transport: snd_rows and own_grads are what PEERS write, so
+  // they live in this rank's window; own_rows and snd_grads stay private.
+  float* own_rows = nullptr;
+  float* own_grads = nullptr;
+  float* snd_rows = nullptr;
+  float* snd_grads = nullptr;
   uint32_t* h_flags = nullptr;  // pinned, device-visible
   uint32_t* d_flags = nullptr;
   bool alias = false;           // world == 1 without a communicator
@@ -119,18 +126,35 @@ struct ShardStep {
   bool hdr_dirty[2] = {false, false};   // the slot's send headers hold counts
   bool disp[2] = {false, false};        // the slot's batch has been dispatched (ids exchanged)
   bool ahead = false;                   // slot cur ^ 1 holds the batch the last forward was given as next
+  // ---- peer-store transport (mhte_shard_step_create_ipc; kernels: shard_push / shard_wait)
+  bool ipc = false;
+  bool ipc_connected = false;
+  bool win_fine = false;                // the window is fine-grained device memory
+  char* win = nullptr;                  // my window
+  size_t win_bytes = 0;
+  size_t win_off_ids[2] = {0, 0}, win_off_rows = 0, win_off_grads = 0;
+  char* peer_win[kMaxShards] = {};      // every rank's window as mapped in this process
+  uint32_t* push_done = nullptr;        // [world] last-workgroup counters of the push kernel
+  uint32_t seq_sent[kIpcChannels] = {};               // exchanges pushed per channel
+  uint32_t seq_waited[kIpcChannels][kMaxShards] = {}; // ... and waited for, per peer
+  uint64_t timeout_ticks = 0;
 
   ~ShardStep() {
     (void)hipSetDevice(device);
     (void)hipDeviceSynchronize();
     if (comm) (void)Rccl::get().CommDestroy(comm);
+    for (int p = 0; p < world && p < kMaxShards; ++p)
+      if (peer_win[p] && p != rank) (void)hipIpcCloseMemHandle(peer_win[p]);
     for (int s = 0; s < 2; ++s) {
       if (ids_send[s]) (void)hipFree(ids_send[s]);
-      if (ids_recv[s] && !alias) (void)hipFree(ids_recv[s]);
+      if (ids_recv[s] && !alias && !ipc) (void)hipFree(ids_recv[s]);
       if (slot_off[s]) (void)hipFree(slot_off[s]);
     }
     if (own_rows) (void)hipFree(own_rows);
-    if (snd_rows && !alias) (void)hipFree(snd_rows);
+    if (snd_rows && !alias && !ipc) (void)hipFree(snd_rows);
+    if (ipc && snd_grads) (void)hipFree(snd_grads);
+    if (win) (void)hipFree(win);
+    if (push_done) (void)hipFree(push_done);
     if (h_flags) (void)hipHostFree(h_flags);
     for (int s = 0; s < 2; ++s) {
       if (h_cnt[s]) (void)hipHostFree(h_cnt[s]);
@@ -139,8 +163,9 @@ struct ShardStep {
   }
 
   void init(mhte_multi_table* m, int64_t mb, int rank_, int world_, int64_t ids_per_peer_table,
-            const void* unique_id) {
+            const void* unique_id, bool ipc_ = false) {
     mt = m;
+    ipc = ipc_;
     device = m->device;
     rank = rank_;
     world = world_;
@@ -159,8 +184,10 @@ struct ShardStep {
         throw Error(MHTE_INVALID_ARGUMENT, "shard step: table " + tb->name + " has an occurrence "
                                            "filter (not supported on the sharded path)");
     ms.init(m, mb);
-    int64_t c = ids_per_peer_table > 0 ? ids_per_peer_table
-                                       : (world == 1 ? mb : (mb + world - 1) / world * 3 / 2 + 256);
+    // default: a (peer, table) block can hold the whole batch, so no step can overflow one (the
+    // reference's all-to-all is variable-sized and never drops an id).  A smaller capacity is the
+    // caller's explicit choice (fixed-size RCCL blocks that cross the links whole).
+    int64_t c = ids_per_peer_table > 0 ? ids_per_peer_table : mb;
     c = std::min<int64_t>(c, mb);
     cap = uint32_t((c + 3) & ~int64_t(3));
     geo.world = uint32_t(world);
@@ -182,14 +209,17 @@ struct ShardStep {
                                          "ids_per_peer_table");
     geo.ids_block = uint32_t((idw + 1) & ~uint64_t(1));
     geo.rows_block = uint32_t(rw);
-    alias = world == 1 && unique_id == nullptr;
+    alias = world == 1 && unique_id == nullptr && !ipc;
     const size_t ib = size_t(geo.ids_block) * world * sizeof(int64_t);
     const size_t rb = size_t(geo.rows_block) * world * sizeof(float);
+    if (ipc) alloc_window(ib, rb);
     for (int s = 0; s < 2; ++s) {
       HIP_OK(hipMalloc(&ids_send[s], ib));
       HIP_OK(hipMemset(ids_send[s], 0, ib));
       if (alias) {
         ids_recv[s] = ids_send[s];
+      } else if (ipc) {
+        ids_recv[s] = reinterpret_cast<int64_t*>(win + win_off_ids[s]);
       } else {
         HIP_OK(hipMalloc(&ids_recv[s], ib));
         HIP_OK(hipMemset(ids_recv[s], 0, ib));
@@ -197,12 +227,24 @@ struct ShardStep {
       HIP_OK(hipMalloc(&slot_off[s], size_t(T) * size_t(mb) * sizeof(uint32_t)));
     }
     HIP_OK(hipMalloc(&own_rows, rb + 64));
-    if (alias) snd_rows = own_rows;
-    else HIP_OK(hipMalloc(&snd_rows, rb + 64));
+    if (ipc) {
+      snd_rows = reinterpret_cast<float*>(win + win_off_rows);
+      own_grads = reinterpret_cast<float*>(win + win_off_grads);
+      HIP_OK(hipMalloc(&snd_grads, rb + 64));
+    } else {
+      if (alias) snd_rows = own_rows;
+      else HIP_OK(hipMalloc(&snd_rows, rb + 64));
+      own_grads = own_rows;
+      snd_grads = snd_rows;
+    }
     HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&h_flags), 64, hipHostMallocMapped));
     memset(h_flags, 0, 64);
     HIP_OK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_flags), h_flags, 0));
-    if (const char* e = getenv("MHTE_SHARD_EXACT")) exact = atoi(e) != 0 && !alias;
+    // RCCL with whole-batch blocks: exact-size exchanges unless the caller insists (a fixed-size
+    // exchange of blocks that can hold the whole batch would move world x the batch per direction)
+    exact = unique_id != nullptr && world > 1 && ids_per_peer_table <= 0;
+    if (const char* e = getenv("MHTE_SHARD_EXACT")) exact = atoi(e) != 0;
+    exact = exact && !alias && !ipc;
     if (exact)
       for (int s = 0; s < 2; ++s) {
         HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&h_cnt[s]), size_t(2) * world * hdr * sizeof(int64_t),
@@ -219,10 +261,171 @@ struct ShardStep {
     HIP_OK(hipDeviceSynchronize());
   }
 
-  bool local_group_member() const { return world > 1 && comm == nullptr; }
+  bool local_group_member() const { return world > 1 && comm == nullptr && !ipc; }
+
+  // ---- peer-store transport: the window -------------------------------------------------------------
+  void alloc_window(size_t ib, size_t rb) {
+    auto up = [](size_t x) { return (x + 4095) & ~size_t(4095); };
+    size_t off = up(kIpcFlagBytes);
+    for (int s = 0; s < 2; ++s) {
+      win_off_ids[s] = off;
+      off += up(ib);
+    }
+    win_off_rows = off;
+    off += up(rb + 64);
+    win_off_grads = off;
+    off += up(rb + 64);
+    win_bytes = off;
+    // fine-grained device memory: written by other agents / processes while this one reads it
+    // (MHTE_SHARD_WINDOW=coarse: plain hipMalloc, for A/B runs)
+    const char* e = getenv("MHTE_SHARD_WINDOW");
+    const bool want_fine = !(e && std::string(e) == "coarse");
+    void* w = nullptr;
+    if (want_fine && hipExtMallocWithFlags(&w, win_bytes, hipDeviceMallocFinegrained) == hipSuccess) {
+      win_fine = true;
+    } else {
+      (void)hipGetLastError();
+      HIP_OK(hipMalloc(&w, win_bytes));
+    }
+    win = static_cast<char*>(w);
+    HIP_OK(hipMemset(win, 0, win_bytes));
+    HIP_OK(hipMalloc(&push_done, sizeof(uint32_t) * kMaxShards));
+    HIP_OK(hipMemset(push_done, 0, sizeof(uint32_t) * kMaxShards));
+    double ms = 30000.0;
+    if (const char* t = getenv("MHTE_SHARD_TIMEOUT_MS")) ms = std::max(1.0, atof(t));
+    timeout_ticks = uint64_t(ms * 1e5);   // wall_clock64: 100 MHz
+    peer_win[rank] = win;
+  }
+
+  struct IpcBlob {               // what mhte_shard_step_ipc_handle hands the launcher (128 bytes)
+    hipIpcMemHandle_t h;         // 64
+    uint64_t win_bytes;
+    uint32_t magic, rank, world, T, cap, ids_block, rows_block;
+    int32_t pid;
+    char pad[128 - 64 - 8 - 7 * 4 - 4];
+  };
+  static_assert(sizeof(IpcBlob) == 128, "ipc handle blob");
+  static constexpr uint32_t kIpcMagic = 0x6d687431u;
+
+  void ipc_handle(void* out128) {
+    if (!ipc) throw Error(MHTE_FAILED_PRECONDITION, "shard step: not created with the peer-store transport");
+    IpcBlob b{};
+    HIP_OK(hipIpcGetMemHandle(&b.h, win));
+    b.win_bytes = win_bytes;
+    b.magic = kIpcMagic;
+    b.rank = uint32_t(rank);
+    b.world = uint32_t(world);
+    b.T = T;
+    b.cap = cap;
+    b.ids_block = geo.ids_block;
+    b.rows_block = geo.rows_block;
+    b.pid = int32_t(getpid());
+    memcpy(out128, &b, sizeof(b));
+  }
+
+  // handles: world x 128 bytes, rank-major (every rank's mhte_shard_step_ipc_handle output)
+  void ipc_connect(const void* handles) {
+    if (!ipc) throw Error(MHTE_FAILED_PRECONDITION, "shard step: not created with the peer-store transport");
+    if (ipc_connected) throw Error(MHTE_FAILED_PRECONDITION, "shard step: already connected");
+    const char* hb = static_cast<const char*>(handles);
+    for (int p = 0; p < world; ++p) {
+      IpcBlob b;
+      memcpy(&b, hb + size_t(p) * sizeof(IpcBlob), sizeof(b));
+      if (b.magic != kIpcMagic || b.rank != uint32_t(p) || b.world != uint32_t(world))
+        throw Error(MHTE_INVALID_ARGUMENT, "shard step connect: handle " + std::to_string(p) +
+                                               " is not rank " + std::to_string(p) + " of this world");
+      if (b.T != T || b.cap != cap || b.ids_block != geo.ids_block || b.rows_block != geo.rows_block ||
+          b.win_bytes != win_bytes)
+        throw Error(MHTE_INVALID_ARGUMENT, "shard step connect: rank " + std::to_string(p) +
+                                               " was created with other tables or capacities");
+      if (p == rank) continue;
+      void* m = nullptr;
+      hipError_t e = hipIpcOpenMemHandle(&m, b.h, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        throw Error(MHTE_UNAVAILABLE, std::string("shard step connect: hipIpcOpenMemHandle of rank ") +
+                                          std::to_string(p) + "'s window: " + hipGetErrorString(e));
+      }
+      peer_win[p] = static_cast<char*>(m);
+    }
+    ipc_connected = true;
+  }
+
+  static uint32_t chan_of(int kind, int slot) {
+    return kind == kXIds ? uint32_t(slot ? kChIds1 : kChIds0) : kind == kXRows ? uint32_t(kChRows) : uint32_t(kChGrads);
+  }
+
+  void push(uint32_t chan, const void* src, const int64_t* counts, size_t dst_off, bool ids, hipStream_t st) {
+    if (!ipc_connected) throw Error(MHTE_FAILED_PRECONDITION, "shard step: mhte_shard_step_ipc_connect first");
+    ShardPushArgs A{};
+    for (int p = 0; p < world; ++p) A.win[p] = peer_win[p];
+    A.src = static_cast<const char*>(src);
+    A.counts = counts;
+    A.dst_off = dst_off;
+    A.done = push_done;
+    A.flags = d_flags;
+    A.timeout_ticks = timeout_ticks;
+    A.geo = geo;
+    A.rank = uint32_t(rank);
+    A.chan = chan;
+    A.seq = ++seq_sent[chan];
+    A.ids = ids ? 1u : 0u;
+    fill_tabs(A.tab);
+    // enough workgroups per peer to keep a link (or the local HBM) busy, few enough that a waiting
+    // launch never fills the chip (another process may share the device)
+    const size_t blk = ids ? size_t(geo.ids_block) * 8 : size_t(geo.rows_block) * 4;
+    uint32_t gx = src ? uint32_t(std::min<size_t>(std::max<size_t>(1, blk / (256 * 16 * 4)),
+                                                  std::max<size_t>(1, size_t(ms.num_cus) * 2 / size_t(world))))
+                      : 1u;
+    LAUNCH_HOT(kTagShardPush, shard_push_kernel, dim3(gx, uint32_t(world)), 256, st, A);
+    HIP_OK(hipGetLastError());
+  }
+
+  void exchange_ipc(int kind, int slot, hipStream_t st) {
+    const uint32_t ch = chan_of(kind, slot);
+    if (kind == kXIds)
+      push(ch, ids_send[slot], ids_send[slot], win_off_ids[slot], true, st);
+    else if (kind == kXRows)   // rows of the ids every peer sent me: sized by the received headers
+      push(ch, own_rows, ids_recv[slot], win_off_rows, false, st);
+    else                       // gradient sums of the ids I sent every peer
+      push(ch, snd_grads, ids_send[slot], win_off_grads, false, st);
+  }
+
+  // before a consumer of what peers [lo, hi) sent on (kind, slot): hold the stream until it landed
+  void wait_arrived(int kind, int slot, int lo, int hi, hipStream_t st) {
+    if (!ipc) return;
+    const uint32_t ch = chan_of(kind, slot);
+    int a = hi, b = lo;
+    for (int p = lo; p < hi; ++p)
+      if (seq_waited[ch][p] != seq_sent[ch]) {
+        a = std::min(a, p);
+        b = std::max(b, p + 1);
+      }
+    if (a >= b) return;
+    LAUNCH_HOT(kTagShardWait, shard_wait_kernel, 1, 64, st, win, ch, seq_sent[ch], uint32_t(a), uint32_t(b),
+               d_flags, timeout_ticks);
+    HIP_OK(hipGetLastError());
+    for (int p = a; p < b; ++p) seq_waited[ch][p] = seq_sent[ch];
+  }
+
+  // a data-less round trip with every peer: proves the windows are mapped and the flags travel
+  void ipc_selftest(hipStream_t st) {
+    push(kChTest, nullptr, ids_send[0], 0, false, st);
+    LAUNCH_HOT(kTagShardWait, shard_wait_kernel, 1, 64, st, win, uint32_t(kChTest), seq_sent[kChTest], 0u,
+               uint32_t(world), d_flags, timeout_ticks);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(st));
+    check_flags();
+  }
 
   void check_flags() {
     const uint32_t f = *reinterpret_cast<volatile uint32_t*>(h_flags);
+    if (f & kShardPeerTimeout) {
+      *reinterpret_cast<volatile uint32_t*>(h_flags) = 0;
+      throw Error(MHTE_UNAVAILABLE, "shard step: a peer did not take part in an exchange within "
+                                    "MHTE_SHARD_TIMEOUT_MS (its process is gone, or the ranks' calls "
+                                    "are out of step); the step's results are not valid");
+    }
     if (f) {
       *reinterpret_cast<volatile uint32_t*>(h_flags) = 0;
       throw Error(MHTE_RESOURCE_EXHAUSTED,
@@ -292,7 +495,7 @@ struct ShardStep {
     fill_tabs(A.tab);
     if (sum_slot >= 0) {
       A.grads = grads;
-      A.rows_out = snd_rows;
+      A.rows_out = snd_grads;
       A.slot_off = slot_off[sum_slot];
       A.slot = uint32_t(sum_slot);
       uint32_t gx_sum = 0;   // (the grid below is the per-table maximum of build + sum blocks)
@@ -319,6 +522,7 @@ struct ShardStep {
   }
 
   void scatter(float* out, int slot, hipStream_t st) {
+    wait_arrived(kXRows, slot, 0, world, st);
     ShardGatherArgs A{};
     A.st = ConstStatics(ms.d_st);
     A.in = snd_rows;
@@ -334,11 +538,11 @@ struct ShardStep {
     HIP_OK(hipGetLastError());
   }
 
-  void owner_args(ShardOwnerArgs& A, int slot) const {
+  void owner_args(ShardOwnerArgs& A, int slot, bool apply) const {
     A.views = ConstViews(mt->d_views.p);
     A.geo = geo;
     A.recv_ids = ids_recv[slot];
-    A.rows = own_rows;
+    A.rows = apply ? own_grads : own_rows;
     A.flags = d_flags;
     fill_tabs(A.tab);
     for (uint32_t t = 0; t < T; ++t) {
@@ -348,8 +552,9 @@ struct ShardStep {
   }
 
   void owner_lookup(int slot, hipStream_t st) {
+    wait_arrived(kXIds, slot, 0, world, st);
     ShardOwnerArgs A{};
-    owner_args(A, slot);
+    owner_args(A, slot, false);
     uint32_t gx = 1;
     for (uint32_t t = 0; t < T; ++t)
       gx = std::max(gx, uint32_t((uint64_t((cap + 1) / 2) * A.g[t] + 511) / 512));
@@ -368,8 +573,9 @@ struct ShardStep {
       tb.pending.reserve(2 * size_t(cap) + 2);
     }
     sync_views(mt, st);
+    wait_arrived(kXIds, slot, 0, world, st);
     ShardOwnerArgs A{};
-    owner_args(A, slot);
+    owner_args(A, slot, true);
     int64_t lr_off = 0;
     uint32_t gx = 1;
     for (uint32_t t = 0; t < T; ++t) {
@@ -388,6 +594,7 @@ struct ShardStep {
     gx = std::min(gx, fill);
     A.clear_ids = ids_send[slot];
     for (int p = 0; p < world; ++p) {
+      wait_arrived(kXGrads, slot, p, p + 1, st);   // (a peer's block is applied as soon as it has landed)
       A.peer = uint32_t(p);
       A.zero_headers = p == world - 1 ? 1u : 0u;
       LAUNCH_HOT(kTagShardUpsert, shard_upsert_kernel, dim3(gx, T), 256, st, A);
@@ -403,11 +610,11 @@ struct ShardStep {
 
   const void* x_src(int kind, int slot) const {
     return kind == kXIds ? static_cast<const void*>(ids_send[slot])
-                         : kind == kXRows ? static_cast<const void*>(own_rows) : snd_rows;
+                         : kind == kXRows ? static_cast<const void*>(own_rows) : snd_grads;
   }
   void* x_dst(int kind, int slot) const {
     return kind == kXIds ? static_cast<void*>(ids_recv[slot])
-                         : kind == kXRows ? static_cast<void*>(snd_rows) : own_rows;
+                         : kind == kXRows ? static_cast<void*>(snd_rows) : own_grads;
   }
   size_t x_block(int kind) const {
     return kind == kXIds ? size_t(geo.ids_block) * sizeof(int64_t) : size_t(geo.rows_block) * sizeof(float);
@@ -466,7 +673,8 @@ struct ShardStep {
 static void shard_exchange(ShardStep** S, int n, int kind, int slot, hipStream_t st) {
   if (n == 1) {
     if (S[0]->alias) return;
-    S[0]->exchange_rccl(kind, slot, st);
+    if (S[0]->ipc) S[0]->exchange_ipc(kind, slot, st);
+    else S[0]->exchange_rccl(kind, slot, st);
     return;
   }
   const bool exact = S[0]->exact && kind != kXIds;

@@ -287,5 +287,137 @@ __global__ __launch_bounds__(256) void shard_build_kernel(ShardBuildArgs A) {
   shard_gather_switch<false>(s.g, d, c, bid, raw);
 }
 
+// ---- peer-store transport: one process per GPU, every rank maps every other rank's WINDOW ----------
+// (hipIpcGetMemHandle / hipIpcOpenMemHandle; works over xGMI between devices and between two
+// processes on one device alike.)  A window holds what peers write into a rank:
+//   flags      credit[kIpcChannels][kMaxShards]   written by peer p: "p is ready to RECEIVE exchange n
+//                                                  of this channel" (its buffer of the channel is free)
+//              arrived[kIpcChannels][kMaxShards]  written by peer p: "p's block of exchange n landed"
+//   ids_recv[2], snd_rows (rows coming back), own_grads (gradient sums coming in)
+// Channels: the two id slots, rows, gradients, and a data-less one for the creation self test.  Every
+// exchange of a channel has a sequence number the ranks count in lockstep (the calls are collective).
+//
+// shard_push_kernel (grid (x, world), y = peer): post my credit to the peer, wait for the peer's
+// credit, copy the OCCUPIED part of every (peer, table) segment straight into the peer's window — the
+// counts are the id blocks' headers, read on the device: exact-size exchanges and still nothing
+// reaches the host — then the last workgroup of the peer publishes `arrived`.  shard_wait_kernel (one
+// wavefront) holds the stream until the blocks of the wanted peers have landed; consumers are
+// separate launches behind it.  Waits are bounded (wall clock): a peer that never shows up sets
+// kShardPeerTimeout in the host-mapped flag word instead of hanging the queue.
+enum : uint32_t { kShardPeerTimeout = 2u };
+constexpr int kIpcChannels = 5;
+enum IpcChannel : uint32_t { kChIds0 = 0, kChIds1 = 1, kChRows = 2, kChGrads = 3, kChTest = 4 };
+constexpr size_t kIpcFlagBytes = size_t(2) * kIpcChannels * kMaxShards * sizeof(uint32_t);
+
+__device__ __forceinline__ uint32_t* ipc_credit(char* win, uint32_t chan, uint32_t from) {
+  return reinterpret_cast<uint32_t*>(win) + size_t(chan) * kMaxShards + from;
+}
+__device__ __forceinline__ uint32_t* ipc_arrived(char* win, uint32_t chan, uint32_t from) {
+  return reinterpret_cast<uint32_t*>(win) + size_t(kIpcChannels + chan) * kMaxShards + from;
+}
+__device__ __forceinline__ uint32_t ld_sys(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// sequence numbers wrap after 2^32 exchanges: compared as signed differences
+__device__ __forceinline__ bool ipc_spin(const uint32_t* flag, uint32_t seq, uint64_t timeout_ticks) {
+  if (int32_t(ld_sys(flag) - seq) >= 0) return true;
+  const uint64_t t0 = wall_clock64();
+  for (;;) {
+    for (int i = 0; i < 64; ++i) {
+      if (int32_t(ld_sys(flag) - seq) >= 0) return true;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (wall_clock64() - t0 > timeout_ticks) return false;
+  }
+}
+
+struct ShardPushArgs {
+  char* win[kMaxShards];      // every rank's window as mapped here (win[rank] = my own)
+  const char* src;            // [world][block] of this rank's send buffer; nullptr: no data (test)
+  const int64_t* counts;      // [world][ids_block]: the headers that size the segments
+  uint64_t dst_off;           // byte offset of the destination buffer inside a window
+  uint32_t* done;             // [world] device counters, zero between launches
+  uint32_t* flags;            // host-mapped error word
+  uint64_t timeout_ticks;
+  ShardGeom geo;
+  uint32_t rank;
+  uint32_t chan;
+  uint32_t seq;
+  uint32_t ids;               // 1: id blocks (header + int64 slots), 0: row blocks (floats)
+  ShardTab tab[kMaxStepTables];
+};
+static_assert(sizeof(ShardPushArgs) <= 4096, "kernel arguments exceed 4 KB");
+
+__device__ __forceinline__ void ipc_copy16(char* dst, const char* src, uint32_t n16, uint32_t first,
+                                           uint32_t stride) {
+  const uint4* s = reinterpret_cast<const uint4*>(src);
+  uint4* d = reinterpret_cast<uint4*>(dst);
+  for (uint32_t i = first; i < n16; i += stride) {
+    const uint4 v = s[i];
+    __builtin_nontemporal_store(v.x, &d[i].x);
+    __builtin_nontemporal_store(v.y, &d[i].y);
+    __builtin_nontemporal_store(v.z, &d[i].z);
+    __builtin_nontemporal_store(v.w, &d[i].w);
+  }
+}
+
+__global__ __launch_bounds__(256) void shard_push_kernel(ShardPushArgs A) {
+  __shared__ uint32_t ok;
+  const uint32_t p = blockIdx.y;
+  char* mine = A.win[A.rank];
+  char* peer = A.win[p];
+  if (threadIdx.x == 0) {
+    if (blockIdx.x == 0) st_sys(ipc_credit(peer, A.chan, A.rank), A.seq);
+    ok = ipc_spin(ipc_credit(mine, A.chan, p), A.seq, A.timeout_ticks) ? 1u : 0u;
+    if (!ok) atomicOr(A.flags, uint32_t(kShardPeerTimeout));
+  }
+  __syncthreads();
+  if (ok && A.src) {
+    const size_t blk = A.ids ? size_t(A.geo.ids_block) * 8 : size_t(A.geo.rows_block) * 4;
+    const char* src = A.src + size_t(p) * blk;
+    char* dst = peer + A.dst_off + size_t(A.rank) * blk;
+    const int64_t* hdr = A.counts + size_t(p) * A.geo.ids_block;
+    const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if (A.ids) {
+      const uint32_t hdr16 = (((A.geo.T + 7u) & ~7u) * 8u) / 16u;
+      ipc_copy16(dst, src, hdr16, first, stride);
+    }
+    for (uint32_t t = 0; t < A.geo.T; ++t) {
+      const ShardTab tb = A.tab[t];
+      const uint64_t c = uint64_t(hdr[t]);
+      const uint32_t n = c > tb.cap ? tb.cap : uint32_t(c);
+      if (!n) continue;
+      if (A.ids)
+        ipc_copy16(dst + size_t(tb.id_off) * 8, src + size_t(tb.id_off) * 8, (n + 1u) / 2u, first, stride);
+      else
+        ipc_copy16(dst + size_t(tb.row_off) * 4, src + size_t(tb.row_off) * 4, n * (tb.dim / 4u), first,
+                   stride);
+    }
+  }
+  // every thread's stores are performed system-wide before its workgroup counts itself; the last
+  // workgroup of the peer publishes the block
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t prev = __hip_atomic_fetch_add(A.done + p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == gridDim.x - 1) {
+      __hip_atomic_store(A.done + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      if (ok) st_sys(ipc_arrived(peer, A.chan, A.rank), A.seq);
+    }
+  }
+}
+
+// lanes [lo, hi): hold the stream until those peers' blocks of exchange `seq` have landed
+__global__ __launch_bounds__(64) void shard_wait_kernel(char* mine, uint32_t chan, uint32_t seq, uint32_t lo,
+                                                        uint32_t hi, uint32_t* flags, uint64_t timeout_ticks) {
+  for (uint32_t p = lo + threadIdx.x; p < hi; p += 64)
+    if (!ipc_spin(ipc_arrived(mine, chan, p), seq, timeout_ticks)) atomicOr(flags, uint32_t(kShardPeerTimeout));
+  __threadfence_system();
+}
+
 }  // namespace mhte
 #endif  // MHTE_SHARD_KERNELS_H_

@@ -386,8 +386,7 @@ def shard_block_geometry(dims, batch_per_table: int, world: int, ids_per_peer_ta
   ``ShardedMultiStep.info()`` reports the same block sizes from the library."""
   T = len(dims)
   mb = int(batch_per_table)
-  c = int(ids_per_peer_table) if ids_per_peer_table > 0 else (
-      mb if world == 1 else (mb + world - 1) // world * 3 // 2 + 256)
+  c = int(ids_per_peer_table) if ids_per_peer_table > 0 else mb   # default: the whole batch fits
   cap = (min(c, mb) + 3) & ~3
   hdr = (T + 7) & ~7
   id_off = [hdr + t * cap for t in range(T)]
@@ -403,17 +402,25 @@ def shard_block_geometry(dims, batch_per_table: int, world: int, ids_per_peer_ta
 class ShardedMultiStep:
   """All tables of the model, sharded by id over the ranks, one exchange per direction for all of
   them (native_training/distributed_ps_sync.py:95-287, :289-490) — mhte_shard_step_*: the whole
-  step is enqueued from C++ (kernels + RCCL send / recv groups), no count ever reaches the host.
+  step is enqueued from C++.
 
   ``table`` is this rank's MultiHashTable (the ids it owns).  ``group``: a torch.distributed group
-  (backend nccl = RCCL) used ONCE, to hand the RCCL unique id of rank 0 to the others; the step's
-  exchanges run on a communicator of the library's own.  Without a group (world 1) the exchange is
-  the identity.  Same call protocol as ``MultiSparseStep``: ``forward(ragged, next_ragged)``
-  returns the flat per-occurrence embedding and dispatches the next batch's ids ahead;
-  ``backward(flat_grad, update_time)``."""
+  used ONCE, at creation, as the launcher's side channel (any backend: gloo when several ranks
+  share one device).  ``transport``:
+
+    "ipc"   peer stores: every rank maps the others' receive windows (hipIpc*), an exchange is one
+            copy kernel storing the occupied part of every (peer, table) segment into the peers'
+            windows, sized on the device — works across xGMI and between processes on one GPU;
+    "rccl"  ncclSend / ncclRecv groups on a communicator of the library's own (rank 0's unique id
+            is handed out through ``group``); needs one device per rank;
+    "auto"  world 1: identity; else "ipc" if every rank's self test passes, else "rccl".
+
+  Same call protocol as ``MultiSparseStep``: ``forward(ragged, next_ragged)`` returns the flat
+  per-occurrence embedding and dispatches the next batch's ids ahead; ``backward(flat_grad,
+  update_time)``."""
 
   def __init__(self, table, batch_per_table: int, group: Optional["dist.ProcessGroup"] = None,
-               ids_per_peer_table: int = 0, use_rccl: Optional[bool] = None):
+               ids_per_peer_table: int = 0, use_rccl: Optional[bool] = None, transport: str = "auto"):
     from monolith_amd import _lib
     self._libmod = _lib
     self._lib = table._lib  # pylint: disable=protected-access
@@ -425,8 +432,20 @@ class ShardedMultiStep:
       self.rank = dist.get_rank(group)
     else:
       self.world, self.rank = 1, 0
-    if use_rccl is None:
-      use_rccl = self.world > 1
+    if transport not in ("auto", "ipc", "rccl", "identity"):
+      raise ValueError("transport must be auto | ipc | rccl | identity")
+    if use_rccl:
+      transport = "rccl"
+    self._group = group
+    self._h = None
+    if transport == "ipc" or (transport == "auto" and self.world > 1):
+      err = self._create_ipc(ids_per_peer_table)
+      if err is None:
+        return
+      if transport == "ipc":
+        raise err
+      transport = "rccl"
+    use_rccl = transport == "rccl"
     uid = None
     if use_rccl:
       _rccl_env()
@@ -445,15 +464,70 @@ class ShardedMultiStep:
     self._ahead = None
     self._keep = None
 
-  def close(self):
+  def _all_true(self, ok: bool) -> bool:
+    if self.world == 1:
+      return ok
+    box = [None] * self.world
+    dist.all_gather_object(box, bool(ok), group=self._group)
+    return all(box)
+
+  def _create_ipc(self, ids_per_peer_table):
+    """The peer-store transport: create -> gather every rank's window handle -> connect -> self test.
+    Collective.  Returns None, or the error after EVERY rank has given the transport up."""
+    _lib = self._libmod
+    h = C.c_void_p()
+    err = None
+    blob = C.create_string_buffer(128)
+    try:
+      _lib.check(self._lib.mhte_shard_step_create_ipc(
+          self.table.handle, C.c_int64(self.batch), C.c_int32(self.rank), C.c_int32(self.world),
+          C.c_int64(int(ids_per_peer_table)), C.byref(h)))
+      _lib.check(self._lib.mhte_shard_step_ipc_handle(h, blob))
+    except _lib.MhteError as e:
+      err = e
+    blobs = [None] * self.world
+    if self.world > 1:
+      dist.all_gather_object(blobs, blob.raw if err is None else None, group=self._group)
+    else:
+      blobs[0] = blob.raw if err is None else None
+    if err is None and all(b is not None for b in blobs):
+      try:
+        _lib.check(self._lib.mhte_shard_step_ipc_connect(h, b"".join(blobs), C.c_int32(self.world)))
+      except _lib.MhteError as e:
+        err = e
+    elif err is None:
+      err = _lib.MhteError(_lib.MHTE_UNAVAILABLE, "a peer could not create its window")
+    if self._all_true(err is None):
+      try:   # (every rank connected: the round trip is collective)
+        _lib.check(self._lib.mhte_shard_step_ipc_selftest(h, self._stream()))
+      except _lib.MhteError as e:
+        err = e
+    elif err is None:
+      err = _lib.MhteError(_lib.MHTE_UNAVAILABLE, "a peer could not map the windows")
+    if not self._all_true(err is None):
+      if h:
+        torch.cuda.synchronize()
+        self._lib.mhte_shard_step_destroy(h)
+      return err or _lib.MhteError(_lib.MHTE_UNAVAILABLE, "a peer failed the peer-store self test")
+    self._h = h
+    self._ahead = None
+    self._keep = None
+    return None
+
+  def close(self, collective: bool = True):
+    """Destroys the step.  With peers (world > 1) an explicit close is collective: every rank drains
+    its stream and meets the others before any window is unmapped — a peer may still be storing
+    into it."""
     if getattr(self, "_h", None):
       torch.cuda.synchronize()
+      if collective and self.world > 1 and dist.is_available() and dist.is_initialized():
+        dist.barrier(group=self._group)
       self._lib.mhte_shard_step_destroy(self._h)
       self._h = None
 
   def __del__(self):
     try:
-      self.close()
+      self.close(collective=False)
     except Exception:  # pylint: disable=broad-except
       pass
 
@@ -461,7 +535,7 @@ class ShardedMultiStep:
     out = (C.c_int64 * 4)()
     self._libmod.check(self._lib.mhte_shard_step_info(self._h, out))
     return {"ids_per_peer_table": out[0], "id_block_bytes": out[1], "row_block_bytes": out[2],
-            "transport": ("identity", "rccl", "group")[out[3]]}
+            "transport": ("identity", "rccl", "group", "ipc", "ipc (coarse window)")[out[3]]}
 
   @staticmethod
   def _key(r):

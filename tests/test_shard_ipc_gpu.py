@@ -1,0 +1,107 @@
+"""GPU parity (-m gpu) of the MULTI-PROCESS id-sharded step: `world` processes (sharing cuda:0 on a
+1-GPU box) drive the C++ product path mhte_shard_step_forward / _backward over the peer-store
+transport — hipIpc-mapped receive windows, device-sized direct stores, credit / arrival flags
+(csrc/mhte_shard_host.h, shard_push_kernel / shard_wait_kernel) — and every rank checks itself
+against the CPU oracle's single-process replay (tests/shard_ipc_worker.py).  RCCL cannot place two
+ranks on one device; this transport runs the same on xGMI peers.
+Reference: native_training/distributed_ps_sync.py:95-287 (lookup), :289-490 (apply_gradients).
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def run_world(world, dist_kind, steps, tmp_path, extra_env=None):
+  port = _free_port()
+  env = dict(os.environ)
+  env.setdefault("MHTE_SHARD_TIMEOUT_MS", "20000")
+  env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  env.update(extra_env or {})
+  outs = [str(tmp_path / ("rank%d.json" % r)) for r in range(world)]
+  procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_ipc_worker.py"), str(r), str(world),
+                             str(port), dist_kind, str(steps), outs[r]], env=env,
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+  logs = []
+  try:
+    for p in procs:
+      try:
+        logs.append(p.communicate(timeout=420)[0].decode("utf-8", "replace"))
+      except subprocess.TimeoutExpired:
+        logs.append("timeout")
+  finally:
+    for p in procs:   # (exactly the processes started above)
+      if p.poll() is None:
+        p.kill()
+  results = []
+  for r in range(world):
+    assert os.path.exists(outs[r]), "rank %d wrote no result; log:\n%s" % (r, logs[r][-3000:])
+    with open(outs[r]) as f:
+      results.append(json.load(f))
+  for r, res in enumerate(results):
+    assert res["ok"], "rank %d: %s\nlog:\n%s" % (r, res.get("error"), logs[r][-2000:])
+  return results
+
+
+@pytest.mark.parametrize("dist_kind,world", [("uniform", 2), ("zipf", 2), ("uniform", 3)])
+def test_processes_against_oracle(dist_kind, world, tmp_path):
+  res = run_world(world, dist_kind, 6, tmp_path)
+  assert len({r["pid"] for r in res}) == world            # really separate processes
+  assert all(r["transport"].startswith("ipc") for r in res)
+  # the owners' shards are disjoint and complete (each rank checked its own rows against the oracle)
+  for name in res[0]["sizes"]:
+    assert sum(r["sizes"][name] for r in res) > 0
+
+
+def test_coarse_window(tmp_path):
+  """MHTE_SHARD_WINDOW=coarse: the windows as plain device memory (the A/B form)."""
+  res = run_world(2, "uniform", 4, tmp_path, {"MHTE_SHARD_WINDOW": "coarse"})
+  assert all(r["transport"] == "ipc (coarse window)" for r in res)
+
+
+def test_missing_peer_times_out_instead_of_hanging(tmp_path):
+  """A rank whose peer maps the windows and then never takes part gets MHTE_UNAVAILABLE (14) from the
+  bounded waits; its queue drains."""
+  res = run_world(2, "timeout", 0, tmp_path, {"MHTE_SHARD_TIMEOUT_MS": "1500"})
+  assert res[0]["code"] == 14
+
+
+def test_unconnected_step_is_refused():
+  import ctypes as C
+  sys.path.insert(0, HERE)
+  from monolith_amd import _lib
+  from test_multi_step_gpu import dlrm_specs, make
+  mt = make(dlrm_specs(2, initial_capacity=1 << 10))
+  L, h = mt._lib, C.c_void_p()  # pylint: disable=protected-access
+  # world 1 over the transport: the rank's own window, a round trip with itself
+  _lib.check(L.mhte_shard_step_create_ipc(mt.handle, C.c_int64(64), C.c_int32(0), C.c_int32(1), C.c_int64(0),
+                                          C.byref(h)))
+  b = C.create_string_buffer(128)
+  _lib.check(L.mhte_shard_step_ipc_handle(h, b))
+  with pytest.raises(_lib.MhteError):   # not rank-major handles of this world
+    _lib.check(L.mhte_shard_step_ipc_connect(h, b.raw, C.c_int32(2)))
+  _lib.check(L.mhte_shard_step_ipc_connect(h, b.raw, C.c_int32(1)))
+  _lib.check(L.mhte_shard_step_ipc_selftest(h, None))
+  L.mhte_shard_step_destroy(h)
+  h0 = C.c_void_p()
+  _lib.check(L.mhte_shard_step_create_ipc(mt.handle, C.c_int64(64), C.c_int32(0), C.c_int32(2), C.c_int64(0),
+                                          C.byref(h0)))
+  with pytest.raises(_lib.MhteError) as ei:
+    _lib.check(L.mhte_shard_step_ipc_selftest(h0, None))
+  assert ei.value.code == _lib.MHTE_FAILED_PRECONDITION
+  L.mhte_shard_step_destroy(h0)
