@@ -382,6 +382,21 @@ mhte_status mhte_multi_table_save(mhte_multi_table* t, const char* basename, int
                                   void* stream);
 mhte_status mhte_multi_table_restore(mhte_multi_table* t, const char* basename, void* stream);
 
+/* MonolithHashTableSave / MonolithHashTableRestore for ONE table (RT/ops/hash_table_save_op.cc:72-200,
+ * RT/ops/hash_table_restore_op.cc:63-160): the single-table layout the reference's exported models
+ * carry (model_export/testdata/saved_model/ps_N/.../assets/MonolithHashTable_*):
+ *   <basename>-%05d-of-%05d   UNCOMPRESSED TFRecord stream of EntryDump, one file per shard, no .meta
+ * Save: nshards < 0 = min(4, max(1, size / 1e6)); each shard a contiguous bucket range, expired
+ * rows left out, written under a temporary name and renamed.  Restore validates the shard set
+ * (RT/ops/file_utils.cc:34-78), CLEARS the table (restore_op.cc:88), then upserts every record of
+ * every shard (whole row + the entry's own timestamp; an entry without last_update_ts_sec gets 0).
+ * mhte_table_clear: EmbeddingHashTableInterface::Clear (cuckoo_embedding_hash_table.cc:322-326).
+ * All three synchronise the stream. */
+mhte_status mhte_table_save(mhte_multi_table* t, int32_t table, const char* basename, int32_t nshards,
+                            void* stream);
+mhte_status mhte_table_restore(mhte_multi_table* t, int32_t table, const char* basename, void* stream);
+mhte_status mhte_table_clear(mhte_multi_table* t, int32_t table, void* stream);
+
 /* ---- caller-side dedup / packing ops on the device ------------------------------------------ */
 typedef struct mhte_dedup_ws mhte_dedup_ws;
 mhte_status mhte_dedup_ws_create(int32_t device, mhte_dedup_ws** out);

@@ -671,6 +671,21 @@ struct Table {
     }
   }
 
+  // EmbeddingHashTableInterface::Clear (cuckoo_embedding_hash_table.cc:322-326: clear_with_callback +
+  // DeallocateAll): no entries, the bucket array keeps its size, row handles start over; the
+  // table's max_update_ts stands (it lives in the bridge, tf_bridge.cc:385-398)
+  void clear(hipStream_t st) {
+    finish_pending(st);
+    ++mut_epoch;
+    const uint64_t nb = uint64_t(1) << hp;
+    clear_buckets_kernel<<<dim3(uint32_t((nb + 255) / 256)), 256, 0, st>>>(buckets, nb);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemsetAsync(ctr, 0, sizeof(Counters), st));
+    HIP_OK(hipStreamSynchronize(st));
+    memset(h_ctr, 0, sizeof(Counters));
+    keys_upper = rows_upper = 0;
+  }
+
   void double_table(hipStream_t st) {
     ++mut_epoch;
     if (hp >= 34) throw Error(MHTE_RESOURCE_EXHAUSTED, "table " + name + ": hashpower limit");
@@ -1764,6 +1779,9 @@ mhte_status mhte_hash_filter_create(uint64_t capacity, int32_t split_num, int32_
       throw Error(MHTE_UNAVAILABLE, "no such HIP device");
     HIP_OK(hipSetDevice(device));
     // SlidingHashFilter(capacity, split_num), sliding_hash_filter.cc:29-42
+    // (the dump's split_num is the constructor ARGUMENT, unclamped — split_num_, :30,160,192 — so a
+    // reference-written dump of a filter created with split_num < 5 validates here and vice versa)
+    const int32_t split_num_as_given = split_num;
     if (capacity < 300) capacity = 300;
     if (split_num < 5) split_num = 5;
     if (split_num > kFilterMaxSplits)
@@ -1771,7 +1789,7 @@ mhte_status mhte_hash_filter_create(uint64_t capacity, int32_t split_num, int32_
     std::unique_ptr<mhte_hash_filter> f(new mhte_hash_filter);
     f->device = device;
     f->capacity = capacity;
-    f->split_num_arg = uint32_t(split_num);
+    f->split_num_arg = uint32_t(split_num_as_given);
     f->nsplit = uint32_t(split_num);
     const uint64_t split_capacity = capacity / uint64_t(split_num - kFilterForward + 1);  // get_split_capacity
     f->split_cap = uint32_t(std::min<uint64_t>(split_capacity, 0xffffffffu));
@@ -1855,7 +1873,8 @@ mhte_status mhte_hash_filter_save(mhte_hash_filter* f, const char* basename, voi
       {
         ckpt::RecordWriter w(tmp, false);
         std::string meta;   // HashFilterSplitMetaDump
-        put_u(meta, 1, 0);
+        put_u(meta, 1, 0);   // failure_count of the split (hash_filter.h:103: a statistic of exhausted
+                             // probe sequences; the engine keeps the sliding filter's total only)
         put_u(meta, 2, f->total);
         put_u(meta, 3, filter_split_elements(hs, uint32_t(sp)));
         put_key(meta, 4, 1);
@@ -1992,7 +2011,17 @@ static int64_t ttl_days_of(const Table& tb, int64_t id) {
 // (multi_hash_table_save_restore_ops.cc:203-211).  Returns the number of entries written.
 static uint64_t save_table_shard(Table& tb, int shard, int total, ckpt::RecordWriter& w,
                                  CkptStage& sg, hipStream_t st) {
-  const uint64_t nb = uint64_t(1) << tb.hp;
+  // the shard's bucket range is a function of the hashpower: a doubling between two chunks (a
+  // concurrent update: the table is released between chunks) would leave the rest of the range
+  // stale — rows missed or written twice.  The geometry is snapshotted under the lock and checked
+  // by every chunk's scan; a change fails the save (the reference holds LockAll for the whole save,
+  // hash_table_save_op.cc:106-108).
+  uint32_t hp0;
+  {
+    std::lock_guard<std::mutex> g(tb.mu);
+    hp0 = tb.hp;
+  }
+  const uint64_t nb = uint64_t(1) << hp0;
   const uint64_t Q = nb / uint64_t(total), R = nb % uint64_t(total);
   const uint64_t begin = uint64_t(shard) * Q + std::min<uint64_t>(shard, R);
   const uint64_t end = begin + Q + (uint64_t(shard) < R ? 1 : 0);
@@ -2040,6 +2069,9 @@ static uint64_t save_table_shard(Table& tb, int shard, int total, ckpt::RecordWr
     uint64_t acc = 0;
     sg.h_n[b] = 0;
     std::lock_guard<std::mutex> g(tb.mu);
+    if (tb.hp != hp0)
+      throw Error(MHTE_FAILED_PRECONDITION, "table " + tb.name + " was resized by a concurrent update while "
+                                            "it was being saved; save again");
     bc.reserve(nblocks);
     bo.reserve(nblocks);
     dump_count_kernel<<<nblocks, 256, 0, st>>>(tb.view, s0, s1, bc.p);
@@ -2231,11 +2263,16 @@ static void restore_batch(Table& tb, CkptStage& sg, const int64_t* ids, const fl
   HIP_OK(hipStreamSynchronize(st));  // the staging buffers are rewritten by the next batch
 }
 
+// legacy_table >= 0: the single-table layout of MonolithHashTableSave (hash_table_save_op.cc:147-160) —
+// an UNCOMPRESSED TFRecord stream of EntryDump, no .meta sidecar: every record of the file belongs to
+// that table (hash_table_restore_op.cc:118-150)
 static void restore_shard(mhte_multi_table* t, const std::string& basename, int sh, int total,
-                          hipStream_t st) {
+                          hipStream_t st, int legacy_table = -1) {
   {
-    ckpt::RecordReader data(ckpt::shard_name(basename, "", sh, total), true);
-    ckpt::RecordReader meta(ckpt::shard_name(basename, ".meta", sh, total), false);
+    const bool legacy = legacy_table >= 0;
+    ckpt::RecordReader data(ckpt::shard_name(basename, "", sh, total), !legacy);
+    std::unique_ptr<ckpt::RecordReader> meta;
+    if (!legacy) meta.reset(new ckpt::RecordReader(ckpt::shard_name(basename, ".meta", sh, total), false));
     std::string mrec, name;
     // the data file is read in stretches of ~64 MiB into the stage's arena; `refs[cur..)` are the
     // records of the current stretch not yet consumed (a stretch may span two tables)
@@ -2298,12 +2335,22 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
       cur += k;
       return k;
     };
-    while (meta.read(&mrec)) {
+    bool legacy_done = false;
+    for (;;) {
       uint64_t num = 0;
-      ckpt::decode_meta(reinterpret_cast<const uint8_t*>(mrec.data()), mrec.size(), &name, &num);
       int idx = -1;
-      for (size_t i = 0; i < t->tables.size(); ++i)
-        if (t->tables[i]->name == name) idx = int(i);
+      if (legacy) {
+        if (legacy_done) break;
+        legacy_done = true;
+        idx = legacy_table;
+        name = t->tables[size_t(idx)]->name;
+        num = ~uint64_t(0);   // until the end of the file
+      } else {
+        if (!meta->read(&mrec)) break;
+        ckpt::decode_meta(reinterpret_cast<const uint8_t*>(mrec.data()), mrec.size(), &name, &num);
+        for (size_t i = 0; i < t->tables.size(); ++i)
+          if (t->tables[i]->name == name) idx = int(i);
+      }
       if (idx < 0) {  // table in the checkpoint but not in this MultiHashTable: skipped (:352-361)
         for (uint64_t left = num; left;) {
           size_t first;
@@ -2354,7 +2401,10 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
         const double t0 = now();
         size_t first = 0;
         const size_t nb = take(std::min<uint64_t>(kBatch, num - done), &first);
-        if (!nb) throw Error(MHTE_INTERNAL, "checkpoint shard ends early");
+        if (!nb) {
+          if (legacy) return false;
+          throw Error(MHTE_INTERNAL, "checkpoint shard ends early");
+        }
         const double t1 = now();
         HostBuf<int64_t>& ids = sg.h_ids[b];
         HostBuf<uint32_t>& ts = sg.h_ts[b];
@@ -2437,7 +2487,7 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
 // multi_hash_table_save_restore_ops.cc:323-349): one consistent total, every data shard and every
 // .meta sidecar present.  Leftovers of an earlier save with another shard count are an error, not
 // something to restore silently.
-static int discover_shards(const std::string& basename) {
+static int discover_shards(const std::string& basename, bool want_meta = true) {
   int total = 0;
   {
     const size_t slash = basename.find_last_of('/');
@@ -2473,7 +2523,7 @@ static int discover_shards(const std::string& basename) {
                     "complete set of -%05d-of-%05d shards (stale files of another save?)");
     };
     complete(data, "data");
-    complete(meta, ".meta");
+    if (want_meta) complete(meta, ".meta");
   }
   return total;
 }
@@ -2491,6 +2541,81 @@ static void restore_multi_table(mhte_multi_table* t, const std::string& basename
       HIP_OK(hipSetDevice(t->device));
       HIP_OK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
       restore_shard(t, basename, sh, total, s2);
+    } catch (...) {
+      err[size_t(sh)] = std::current_exception();
+    }
+    if (s2) (void)hipStreamDestroy(s2);
+  };
+  run_shard_jobs(total, shard_job);
+  for (auto& e : err)
+    if (e) std::rethrow_exception(e);
+}
+
+// MonolithHashTableSave for ONE table (hash_table_save_op.cc:98-173): per shard an uncompressed
+// TFRecord file of EntryDump over a contiguous bucket range, written under a temporary name and
+// renamed; rows expired relative to the table's max_update_ts are left out (:149-155).
+static void save_table_legacy(mhte_multi_table* t, int idx, const std::string& basename, int nshards,
+                              hipStream_t st) {
+  Table& tbl = *t->tables[size_t(idx)];
+  int64_t total = 0;
+  {
+    std::lock_guard<std::mutex> g(tbl.mu);
+    tbl.sync_counters(st);
+    total = int64_t(tbl.h_ctr->alloc >> 32) + (tbl.h_ctr->special_state == 1 ? 1 : 0);
+  }
+  if (nshards < 0) nshards = int(std::min<int64_t>(4, std::max<int64_t>(1, total / 1000000)));   // PickNshards :122-127
+  if (nshards < 1) nshards = 1;
+  HIP_OK(hipStreamSynchronize(st));
+  std::vector<std::exception_ptr> err;
+  err.resize(size_t(nshards));
+  auto shard_job = [&](int sh) {
+    hipStream_t s2 = nullptr;
+    try {
+      HIP_OK(hipSetDevice(t->device));
+      HIP_OK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+      const std::string fn = ckpt::shard_name(basename, "", sh, nshards);
+      const std::string tmp = fn + "-tmp-" + std::to_string(uint64_t(getpid())) + "-" + std::to_string(sh);
+      {
+        ckpt::RecordWriter w(tmp, false);
+        std::unique_ptr<CkptStage> sg = t->take_stage();
+        try {
+          (void)save_table_shard(tbl, sh, nshards, w, *sg, s2);
+        } catch (...) {
+          t->give_stage(std::move(sg));
+          throw;
+        }
+        t->give_stage(std::move(sg));
+        w.close();
+      }
+      if (rename(tmp.c_str(), fn.c_str()) != 0) throw Error(MHTE_INTERNAL, "checkpoint: cannot rename into " + fn);
+    } catch (...) {
+      err[size_t(sh)] = std::current_exception();
+    }
+    if (s2) (void)hipStreamDestroy(s2);
+  };
+  run_shard_jobs(nshards, shard_job);
+  for (auto& e : err)
+    if (e) std::rethrow_exception(e);
+}
+
+// MonolithHashTableRestore for ONE table (hash_table_restore_op.cc:67-100): the shard set is
+// validated (ValidateShardedFiles), the table is CLEARED, then every shard's records are upserted.
+static void restore_table_legacy(mhte_multi_table* t, int idx, const std::string& basename, hipStream_t st) {
+  const int total = discover_shards(basename, false);
+  Table& tbl = *t->tables[size_t(idx)];
+  {
+    std::lock_guard<std::mutex> g(tbl.mu);
+    tbl.clear(st);
+  }
+  HIP_OK(hipStreamSynchronize(st));
+  std::vector<std::exception_ptr> err;
+  err.resize(size_t(total));
+  auto shard_job = [&](int sh) {
+    hipStream_t s2 = nullptr;
+    try {
+      HIP_OK(hipSetDevice(t->device));
+      HIP_OK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+      restore_shard(t, basename, sh, total, s2, idx);
     } catch (...) {
       err[size_t(sh)] = std::current_exception();
     }
@@ -2532,6 +2657,50 @@ mhte_status mhte_multi_table_restore(mhte_multi_table* t, const char* basename, 
     } catch (const std::exception& e) {
       throw Error(MHTE_INTERNAL, std::string("DataLoss: ") + e.what());
     }
+  });
+}
+
+mhte_status mhte_table_save(mhte_multi_table* t, int32_t table, const char* basename, int32_t nshards,
+                            void* stream) {
+  return guard([&] {
+    check_handle(t);
+    if (table < 0 || size_t(table) >= t->tables.size()) throw Error(MHTE_INVALID_ARGUMENT, "table index out of range");
+    if (!basename || !*basename) throw Error(MHTE_INVALID_ARGUMENT, "save: empty basename");
+    HIP_OK(hipSetDevice(t->device));
+    try {
+      save_table_legacy(t, table, basename, nshards, S(stream));
+    } catch (const Error&) {
+      throw;
+    } catch (const std::exception& e) {
+      throw Error(MHTE_INTERNAL, e.what());
+    }
+  });
+}
+
+mhte_status mhte_table_restore(mhte_multi_table* t, int32_t table, const char* basename, void* stream) {
+  return guard([&] {
+    check_handle(t);
+    if (table < 0 || size_t(table) >= t->tables.size()) throw Error(MHTE_INVALID_ARGUMENT, "table index out of range");
+    if (!basename || !*basename) throw Error(MHTE_INVALID_ARGUMENT, "restore: empty basename");
+    HIP_OK(hipSetDevice(t->device));
+    try {
+      restore_table_legacy(t, table, basename, S(stream));
+    } catch (const Error&) {
+      throw;
+    } catch (const std::exception& e) {
+      throw Error(MHTE_INTERNAL, std::string("DataLoss: ") + e.what());
+    }
+  });
+}
+
+mhte_status mhte_table_clear(mhte_multi_table* t, int32_t table, void* stream) {
+  return guard([&] {
+    check_handle(t);
+    if (table < 0 || size_t(table) >= t->tables.size()) throw Error(MHTE_INVALID_ARGUMENT, "table index out of range");
+    HIP_OK(hipSetDevice(t->device));
+    Table& tb = *t->tables[size_t(table)];
+    std::lock_guard<std::mutex> g(tb.mu);
+    tb.clear(S(stream));
   });
 }
 

@@ -968,9 +968,11 @@ class RecordReader {
     };
     std::vector<Blk> blks;
     size_t total = 0;
+    bool got_block = false;   // (a stretch of empty blocks is not the end of the file)
     while (total < want) {
       Blk b;
       if (!next_compressed(&b.p, &b.cl)) break;
+      got_block = true;
       uint64_t ulen;
       if (!snappy_block_length(b.p, b.cl, &ulen) || ulen > (uint64_t(1) << 32))
         throw std::runtime_error("corrupted snappy block in " + path_);
@@ -984,7 +986,7 @@ class RecordReader {
       }
       blks.push_back(b);
     }
-    if (total == 0 && blks.empty()) return false;
+    if (!got_block) return false;
     if (blks.empty()) return true;
     char* dst = out.grow(total);
     std::vector<uint8_t> bad(blks.size(), 0);

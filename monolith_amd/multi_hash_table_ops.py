@@ -510,6 +510,30 @@ class MultiHashTable:
     check(self._lib.mhte_multi_table_restore(self._h, basename.encode("utf-8"), _stream()))
     return self
 
+  def save_table(self, name: str, basename: str, nshards: int = -1) -> "MultiHashTable":
+    """HashTable.save of ONE table (NT/hash_table_ops.py:313-320, MonolithHashTableSave): the
+    single-table layout — ``<basename>-%05d-of-%05d`` uncompressed TFRecord files of EntryDump, no
+    ``.meta`` (what the reference's exported saved_models carry in ``assets/``)."""
+    import os
+    d = os.path.dirname(basename)
+    if d:
+      os.makedirs(d, exist_ok=True)
+    check(self._lib.mhte_table_save(self._h, C.c_int32(self._index(name)), basename.encode("utf-8"),
+                                    C.c_int32(int(nshards)), _stream()))
+    return self
+
+  def restore_table(self, name: str, basename: str) -> "MultiHashTable":
+    """HashTable.restore of ONE table (NT/hash_table_ops.py:322-325, MonolithHashTableRestore):
+    validates the shard set, CLEARS the table, then upserts every record of every shard."""
+    check(self._lib.mhte_table_restore(self._h, C.c_int32(self._index(name)), basename.encode("utf-8"),
+                                       _stream()))
+    return self
+
+  def clear_table(self, name: str) -> "MultiHashTable":
+    """EmbeddingHashTableInterface::Clear: no entries, capacity kept."""
+    check(self._lib.mhte_table_clear(self._h, C.c_int32(self._index(name)), _stream()))
+    return self
+
   def evict(self, name: str, max_update_time: int = -1) -> "MultiHashTable":
     check(self._lib.mhte_table_evict(self._h, C.c_int32(self._index(name)),
                                      C.c_int64(int(max_update_time)), _stream()))

@@ -87,6 +87,45 @@ int main(int argc, char** argv) {
       printf("%lld %u", (long long)id, ts);
       for (float x : row) printf(" %.9g", x);
       printf("\n");
+    } else if (cmd == "recode") {
+      // recode <in> <out> <batch 0|1> <dim> <nseg> {<kind> <dim>}...: an UNCOMPRESSED TFRecord file of
+      // EntryDump (the single-table layout, hash_table_save_op.cc:147-160) read record by record
+      // (batch 0) or through read_batch (batch 1: the restore path), every record decoded into a row
+      // and encoded again, written through RecordWriter -> prints "<records> <ids xor> <max ts>"
+      const bool batch = atoi(argv[4]) != 0;
+      const int dim = atoi(argv[5]), nseg = atoi(argv[6]);
+      int rf;
+      std::vector<SegLayout> segs = segs_from(argv + 7, nseg, dim, &rf);
+      RecordReader r(argv[2], false);
+      RecordWriter w(argv[3], false);
+      unsigned long long cnt = 0, x = 0;
+      unsigned max_ts = 0;
+      std::string out;
+      auto one = [&](const uint8_t* p, size_t n) {
+        std::vector<float> row(rf, 0.f);
+        int64_t id;
+        uint32_t ts;
+        decode_entry(p, n, segs, dim, &id, row.data(), &ts);
+        encode_entry(out, id, row.data(), segs, dim, ts);
+        w.write(out);
+        ++cnt;
+        x ^= (unsigned long long)id;
+        if (ts > max_ts) max_ts = ts;
+      };
+      if (!batch) {
+        std::string rec;
+        while (r.read(&rec)) one(reinterpret_cast<const uint8_t*>(rec.data()), rec.size());
+      } else {
+        ByteArena arena;
+        std::vector<RecordReader::RecRef> refs;
+        while (r.read_batch(arena, 1024, refs))
+          for (const auto& ref : refs) {
+            r.verify(arena.data() + ref.off, ref.len, ref.crc);
+            one(reinterpret_cast<const uint8_t*>(arena.data() + ref.off), ref.len);
+          }
+      }
+      w.close();
+      printf("%llu %llu %u\n", cnt, x, max_ts);
     } else if (cmd == "write") {
       RecordWriter w(argv[2], atoi(argv[3]) != 0);
       const int n = atoi(argv[4]), len = atoi(argv[5]);

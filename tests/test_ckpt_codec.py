@@ -288,3 +288,49 @@ def test_save_pipeline_hands_chunks_over_in_order(driver):
     for chunk in (0, 1, 7, 31):
       r = subprocess.run([driver, "pipeline", "32", str(stage), str(chunk)], capture_output=True, text=True)
       assert r.returncode == 1 and "stage failed as asked" in r.stdout, (stage, chunk, r.stdout)
+
+
+# ---- the reference's own TF-written files (tests/golden/tf_written, made by make_tf_written.py from
+# model_export/testdata/saved_model/ps_N/.../assets/MonolithHashTable_*: MonolithHashTableSave's
+# single-table layout, uncompressed TFRecord of EntryDump, hash_table_save_op.cc:147-160)
+def _tf_written():
+  import json
+  d = os.path.join(ROOT, "tests", "golden", "tf_written")
+  with open(os.path.join(d, "manifest.json")) as f:
+    return d, json.load(f)
+
+
+KIND_OF = {"sgd": SGD, "ftrl": FTRL, "adagrad": ADAGRAD}
+
+
+@pytest.mark.parametrize("batch", [0, 1])
+def test_tf_written_files_decode_and_reencode_byte_identically(driver, tmp_path, batch):
+  """Every record TensorFlow wrote (150 across the four table layouts) goes through the C++ codec
+  (framing check, crc, decode_entry into a row, encode_entry, framing) and comes out as the same
+  bytes: the record codec and the TFRecord framing are pinned to files the reference holds."""
+  d, manifest = _tf_written()
+  total = 0
+  for m in manifest:
+    segs = []
+    for kind, dim in m["segments"]:
+      segs += [KIND_OF[kind], dim]
+    files = [m["all_records_file"]] + ["%s-%05d-of-%05d" % (m["basename"], i, 4) for i in range(4)]
+    for fn in files:
+      src = os.path.join(d, fn)
+      out = str(tmp_path / ("re_%d_%s" % (batch, fn)))
+      got = run(driver, "recode", src, out, batch, m["dim"], len(m["segments"]), *segs).split()
+      raw = open(src, "rb").read()
+      assert open(out, "rb").read() == raw, fn
+      # the protobuf runtime agrees on what was in there
+      recs = P.unframe(raw)
+      ids = 0
+      for r in recs:
+        e = P.EntryDump()
+        e.ParseFromString(r)
+        ids ^= e.id & 0xFFFFFFFFFFFFFFFF
+        assert len(e.num) == m["dim"] and e.HasField("last_update_ts_sec")
+      assert (int(got[0]), int(got[1])) == (len(recs), ids), fn
+      if fn == m["all_records_file"]:
+        assert len(recs) == m["all_records"]
+        total += len(recs)
+  assert total == 150
