@@ -296,7 +296,6 @@ class MultiSparseStep:
   def backward(self, flat_grad: torch.Tensor, update_time: int, global_step: int = 0):
     C = _lib.C
     lrs = np.ascontiguousarray(self.table.learning_rate, dtype=np.float32)
-    self.table.maybe_evict()
     _lib.check(self._lib.mhte_multi_step_backward(
         self._h, _lib.vp(flat_grad), C.c_int64(flat_grad.numel()),
         lrs.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(lrs.size), C.c_int64(int(update_time)),

@@ -334,13 +334,21 @@ class MultiHashTable:
     return out
 
   def maybe_evict(self, force_check: bool = False) -> List[str]:
-    """Kept for callers of the round-1 API: the eviction cadence is checked inside the library now
-    (every update entry point, at most every 10 s; mhte_table_config.enable_feature_eviction)."""
-    return []
+    """Deprecated (round-1 API).  The eviction cadence is checked inside the library now (every
+    update entry point, at most every 10 s; mhte_table_config.enable_feature_eviction), so a plain
+    call has nothing to do.  ``force_check=True`` still means "scan now": every table is scanned
+    against its TTLs (mhte_table_evict) and the names are returned."""
+    import warnings
+    warnings.warn("MultiHashTable.maybe_evict is deprecated: the library runs the eviction cadence "
+                  "itself; use evict(name) for an immediate scan", DeprecationWarning, stacklevel=2)
+    if not force_check:
+      return []
+    for name in self._table_names:
+      self.evict(name)
+    return list(self._table_names)
 
   def raw_apply_gradients(self, ragged_id: Ragged, flat_grad: torch.Tensor, global_step: int = 0,
                           req_time: int = 0, ids_unique: bool = False) -> "MultiHashTable":
-    self.maybe_evict()
     flat_grad = self._dev(flat_grad, torch.float32)
     check(self._lib.mhte_optimize(self._h, vp(ragged_id.values), _i64p(ragged_id.row_splits),
                                   C.c_int64(ragged_id.row_splits.size), vp(flat_grad),
@@ -403,7 +411,7 @@ class MultiHashTable:
     self._shared_name = "_".join([MultiHashTable.NAME_PREFIX, name_suffix])
     if self._shared_name in MultiHashTable._names_in_use:
       raise ValueError("shared_name {} has already been used.".format(self._shared_name))
-    lrs = np.zeros(256, dtype=np.float32)
+    lrs = np.zeros(1 << 16, dtype=np.float32)   # (one float per segment of the model; checked below)
     h = C.c_void_p()
     check(self._lib.mhte_multi_table_create_from_proto(
         config, C.c_int64(len(config)), hash_filter._h if hash_filter is not None else C.c_void_p(0),  # pylint: disable=protected-access
@@ -416,6 +424,13 @@ class MultiHashTable:
     self._table_names = tuple(self._lib.mhte_table_name(self._h, i).decode() for i in range(T))
     self._dims = tuple(self._lib.mhte_table_dim(self._h, i) for i in range(T))
     self._slice_sizes = tuple(self._lib.mhte_table_slice_size(self._h, i) for i in range(T))
+    if sum(self._slice_sizes) > lrs.size:
+      self._lib.mhte_multi_table_destroy(self._h)
+      self._h = None
+      MultiHashTable._names_in_use.discard(self._shared_name)
+      raise _lib.InvalidArgumentError(
+          _lib.MHTE_INVALID_ARGUMENT, "config has %d segments: more than the %d learning rates this "
+          "binding reads back" % (sum(self._slice_sizes), lrs.size))
     self._learning_rate = np.ascontiguousarray(lrs[:sum(self._slice_sizes)])
     self._configs = None
     return self
@@ -627,7 +642,6 @@ class MultiHashTable:
     """mhte_table_step_backward: gradient sum + upsert + optimizer of the batch ``ws`` holds
     (+ the heavy work list of the batch ``ws_next`` holds)."""
     i = name_or_idx if isinstance(name_or_idx, int) else self._index(name_or_idx)
-    self.maybe_evict()
     lrs = np.ascontiguousarray(lrs, dtype=np.float32)
     n = grads.shape[0]
     check(self._lib.mhte_table_step_backward(
