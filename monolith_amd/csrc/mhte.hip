@@ -2449,25 +2449,34 @@ static void restore_shard(mhte_multi_table* t, const std::string& basename, int 
         HIP_OK(hipSetDevice(t->device));   // (a thread of the pipeline's own)
         const size_t nb = set_n[b];
         const int64_t* ids = sg.h_ids[b].p;
-        // ids inside one batch must be distinct for the upsert: a checkpoint holds each id once
-        // per table, but two shards of a foreign writer could repeat one — later entries win by
-        // flushing batch after batch
+        // ids inside one upsert launch must be distinct.  A checkpoint holds each id once per table,
+        // but a foreign writer (or concatenated files) may repeat one: the reference upserts entry
+        // after entry, so the LATER record wins (cuckoo_embedding_hash_table.cc:303-318).  The batch
+        // is therefore applied as maximal runs of distinct ids, one launch per run, in file order.
         size_t cap = 1024;
         while (cap < 2 * nb) cap <<= 1;
-        seen.assign(cap, 0u);
-        for (size_t i = 0; i < nb; ++i) {
-          size_t h = size_t(hash_key(ids[i])) & (cap - 1);
-          while (seen[h]) {
-            if (ids[seen[h] - 1] == ids[i])
-              throw Error(MHTE_INVALID_ARGUMENT, "checkpoint repeats an id inside table " + name);
-            h = (h + 1) & (cap - 1);
+        size_t start = 0;
+        while (start < nb) {
+          seen.assign(cap, 0u);
+          size_t end = start;
+          for (; end < nb; ++end) {
+            size_t h = size_t(hash_key(ids[end])) & (cap - 1);
+            bool dup = false;
+            while (seen[h]) {
+              if (ids[seen[h] - 1] == ids[end]) {
+                dup = true;
+                break;
+              }
+              h = (h + 1) & (cap - 1);
+            }
+            if (dup) break;
+            seen[h] = uint32_t(end + 1);
           }
-          seen[h] = uint32_t(i + 1);
-        }
-        {
           std::lock_guard<std::mutex> g(tb.mu);
           tb.max_update_ts = std::max<int64_t>(tb.max_update_ts, set_max_ts[b]);
-          restore_batch(tb, sg, ids, sg.h_rows[b].p, sg.h_ts[b].p, int64_t(nb), st);
+          restore_batch(tb, sg, ids + start, sg.h_rows[b].p + start * rf, sg.h_ts[b].p + start,
+                        int64_t(end - start), st);
+          start = end;
         }
         t_up += now() - t0;
       };

@@ -134,7 +134,7 @@ struct ShardStep {
   size_t win_bytes = 0;
   size_t win_off_ids[2] = {0, 0}, win_off_rows = 0, win_off_grads = 0;
   char* peer_win[kMaxShards] = {};      // every rank's window as mapped in this process
-  uint32_t* push_done = nullptr;        // [world] last-workgroup counters of the push kernel
+  uint32_t sig_pending = 0;             // channels pushed since the last sync launch (bit per channel)
   uint32_t seq_sent[kIpcChannels] = {};               // exchanges pushed per channel
   uint32_t seq_waited[kIpcChannels][kMaxShards] = {}; // ... and waited for, per peer
   uint64_t timeout_ticks = 0;
@@ -154,7 +154,6 @@ struct ShardStep {
     if (snd_rows && !alias && !ipc) (void)hipFree(snd_rows);
     if (ipc && snd_grads) (void)hipFree(snd_grads);
     if (win) (void)hipFree(win);
-    if (push_done) (void)hipFree(push_done);
     if (h_flags) (void)hipHostFree(h_flags);
     for (int s = 0; s < 2; ++s) {
       if (h_cnt[s]) (void)hipHostFree(h_cnt[s]);
@@ -289,8 +288,6 @@ struct ShardStep {
     }
     win = static_cast<char*>(w);
     HIP_OK(hipMemset(win, 0, win_bytes));
-    HIP_OK(hipMalloc(&push_done, sizeof(uint32_t) * kMaxShards));
-    HIP_OK(hipMemset(push_done, 0, sizeof(uint32_t) * kMaxShards));
     double ms = 30000.0;
     if (const char* t = getenv("MHTE_SHARD_TIMEOUT_MS")) ms = std::max(1.0, atof(t));
     timeout_ticks = uint64_t(ms * 1e5);   // wall_clock64: 100 MHz
@@ -362,7 +359,6 @@ struct ShardStep {
     A.src = static_cast<const char*>(src);
     A.counts = counts;
     A.dst_off = dst_off;
-    A.done = push_done;
     A.flags = d_flags;
     A.timeout_ticks = timeout_ticks;
     A.geo = geo;
@@ -379,6 +375,37 @@ struct ShardStep {
                       : 1u;
     LAUNCH_HOT(kTagShardPush, shard_push_kernel, dim3(gx, uint32_t(world)), 256, st, A);
     HIP_OK(hipGetLastError());
+    sig_pending |= 1u << chan;
+  }
+
+  // one launch: publish the arrival of every push since the last sync, then (wait_chan <
+  // kIpcChannels) hold the stream until peers [lo, hi) have published `wait_chan`'s latest exchange
+  void sync(uint32_t wait_chan, int lo, int hi, hipStream_t st) {
+    if (!sig_pending && wait_chan >= uint32_t(kIpcChannels)) return;
+    ShardSyncArgs A{};
+    for (int p = 0; p < world; ++p) A.win[p] = peer_win[p];
+    A.flags = d_flags;
+    A.timeout_ticks = timeout_ticks;
+    A.rank = uint32_t(rank);
+    A.world = uint32_t(world);
+    for (uint32_t c = 0; c < uint32_t(kIpcChannels); ++c)
+      if (sig_pending & (1u << c)) {
+        A.sig_chan[A.n_sig] = c;
+        A.sig_seq[A.n_sig++] = seq_sent[c];
+      }
+    sig_pending = 0;
+    A.wait_chan = wait_chan;
+    if (wait_chan < uint32_t(kIpcChannels)) {
+      A.wait_seq = seq_sent[wait_chan];
+      A.lo = uint32_t(lo);
+      A.hi = uint32_t(hi);
+    }
+    LAUNCH_HOT(kTagShardWait, shard_sync_kernel, 1, 64, st, A);
+    HIP_OK(hipGetLastError());
+  }
+  // at the end of an API call: nothing this rank owes its peers stays unpublished
+  void flush_signals(hipStream_t st) {
+    if (ipc && sig_pending) sync(uint32_t(kIpcChannels), 0, 0, st);
   }
 
   void exchange_ipc(int kind, int slot, hipStream_t st) {
@@ -402,18 +429,14 @@ struct ShardStep {
         b = std::max(b, p + 1);
       }
     if (a >= b) return;
-    LAUNCH_HOT(kTagShardWait, shard_wait_kernel, 1, 64, st, win, ch, seq_sent[ch], uint32_t(a), uint32_t(b),
-               d_flags, timeout_ticks);
-    HIP_OK(hipGetLastError());
+    sync(ch, a, b, st);
     for (int p = a; p < b; ++p) seq_waited[ch][p] = seq_sent[ch];
   }
 
   // a data-less round trip with every peer: proves the windows are mapped and the flags travel
   void ipc_selftest(hipStream_t st) {
     push(kChTest, nullptr, ids_send[0], 0, false, st);
-    LAUNCH_HOT(kTagShardWait, shard_wait_kernel, 1, 64, st, win, uint32_t(kChTest), seq_sent[kChTest], 0u,
-               uint32_t(world), d_flags, timeout_ticks);
-    HIP_OK(hipGetLastError());
+    sync(uint32_t(kChTest), 0, world, st);
     HIP_OK(hipStreamSynchronize(st));
     check_flags();
   }
@@ -772,6 +795,7 @@ static void shard_forward(ShardStep** S, int n, const ShardFwd* a, int64_t n_spl
       S[r]->dedup(a[r].id_next, a[r].split_next, cur ^ 1, st);
       S[r]->ahead = true;
     }
+  for (int r = 0; r < n; ++r) S[r]->flush_signals(st);
 }
 
 static void shard_backward(ShardStep** S, int n, const float* const* grads, const int64_t* grads_len,
@@ -810,6 +834,7 @@ static void shard_backward(ShardStep** S, int n, const float* const* grads, cons
     S[r]->owner_apply(cur, lrs, update_time, global_step, st);
     S[r]->ms.stage[cur] = 0;
     S[r]->disp[cur] = false;
+    S[r]->flush_signals(st);
   }
 }
 

@@ -300,10 +300,13 @@ __global__ __launch_bounds__(256) void shard_build_kernel(ShardBuildArgs A) {
 // shard_push_kernel (grid (x, world), y = peer): post my credit to the peer, wait for the peer's
 // credit, copy the OCCUPIED part of every (peer, table) segment straight into the peer's window — the
 // counts are the id blocks' headers, read on the device: exact-size exchanges and still nothing
-// reaches the host — then the last workgroup of the peer publishes `arrived`.  shard_wait_kernel (one
-// wavefront) holds the stream until the blocks of the wanted peers have landed; consumers are
-// separate launches behind it.  Waits are bounded (wall clock): a peer that never shows up sets
-// kShardPeerTimeout in the host-mapped flag word instead of hanging the queue.
+// reaches the host.  The stores are made visible by the END of the launch (measured: a system-scope
+// fence per workgroup is an L2 write-back each, 45 us for a 3 MB push; none at all: 4 us), so
+// `arrived` is published by the next launch on the stream: shard_sync_kernel (one wavefront) first
+// posts the arrival of every push since the last sync, then holds the stream until the blocks of
+// the wanted peers have landed; consumers are separate launches behind it.  Every rank posts what
+// it owes before it waits, so the waits cannot cross.  Waits are bounded (wall clock): a peer that
+// never shows up sets kShardPeerTimeout in the host-mapped flag word instead of hanging the queue.
 enum : uint32_t { kShardPeerTimeout = 2u };
 constexpr int kIpcChannels = 5;
 enum IpcChannel : uint32_t { kChIds0 = 0, kChIds1 = 1, kChRows = 2, kChGrads = 3, kChTest = 4 };
@@ -339,7 +342,6 @@ struct ShardPushArgs {
   const char* src;            // [world][block] of this rank's send buffer; nullptr: no data (test)
   const int64_t* counts;      // [world][ids_block]: the headers that size the segments
   uint64_t dst_off;           // byte offset of the destination buffer inside a window
-  uint32_t* done;             // [world] device counters, zero between launches
   uint32_t* flags;            // host-mapped error word
   uint64_t timeout_ticks;
   ShardGeom geo;
@@ -375,47 +377,50 @@ __global__ __launch_bounds__(256) void shard_push_kernel(ShardPushArgs A) {
     if (!ok) atomicOr(A.flags, uint32_t(kShardPeerTimeout));
   }
   __syncthreads();
-  if (ok && A.src) {
-    const size_t blk = A.ids ? size_t(A.geo.ids_block) * 8 : size_t(A.geo.rows_block) * 4;
-    const char* src = A.src + size_t(p) * blk;
-    char* dst = peer + A.dst_off + size_t(A.rank) * blk;
-    const int64_t* hdr = A.counts + size_t(p) * A.geo.ids_block;
-    const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    if (A.ids) {
-      const uint32_t hdr16 = (((A.geo.T + 7u) & ~7u) * 8u) / 16u;
-      ipc_copy16(dst, src, hdr16, first, stride);
-    }
-    for (uint32_t t = 0; t < A.geo.T; ++t) {
-      const ShardTab tb = A.tab[t];
-      const uint64_t c = uint64_t(hdr[t]);
-      const uint32_t n = c > tb.cap ? tb.cap : uint32_t(c);
-      if (!n) continue;
-      if (A.ids)
-        ipc_copy16(dst + size_t(tb.id_off) * 8, src + size_t(tb.id_off) * 8, (n + 1u) / 2u, first, stride);
-      else
-        ipc_copy16(dst + size_t(tb.row_off) * 4, src + size_t(tb.row_off) * 4, n * (tb.dim / 4u), first,
-                   stride);
-    }
+  if (!ok || !A.src) return;
+  const size_t blk = A.ids ? size_t(A.geo.ids_block) * 8 : size_t(A.geo.rows_block) * 4;
+  const char* src = A.src + size_t(p) * blk;
+  char* dst = peer + A.dst_off + size_t(A.rank) * blk;
+  const int64_t* hdr = A.counts + size_t(p) * A.geo.ids_block;
+  const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  if (A.ids) {
+    const uint32_t hdr16 = (((A.geo.T + 7u) & ~7u) * 8u) / 16u;
+    ipc_copy16(dst, src, hdr16, first, stride);
   }
-  // every thread's stores are performed system-wide before its workgroup counts itself; the last
-  // workgroup of the peer publishes the block
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t prev = __hip_atomic_fetch_add(A.done + p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == gridDim.x - 1) {
-      __hip_atomic_store(A.done + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence_system();
-      if (ok) st_sys(ipc_arrived(peer, A.chan, A.rank), A.seq);
-    }
+  for (uint32_t t = 0; t < A.geo.T; ++t) {
+    const ShardTab tb = A.tab[t];
+    const uint64_t c = uint64_t(hdr[t]);
+    const uint32_t n = c > tb.cap ? tb.cap : uint32_t(c);
+    if (!n) continue;
+    if (A.ids)
+      ipc_copy16(dst + size_t(tb.id_off) * 8, src + size_t(tb.id_off) * 8, (n + 1u) / 2u, first, stride);
+    else
+      ipc_copy16(dst + size_t(tb.row_off) * 4, src + size_t(tb.row_off) * 4, n * (tb.dim / 4u), first, stride);
   }
 }
 
-// lanes [lo, hi): hold the stream until those peers' blocks of exchange `seq` have landed
-__global__ __launch_bounds__(64) void shard_wait_kernel(char* mine, uint32_t chan, uint32_t seq, uint32_t lo,
-                                                        uint32_t hi, uint32_t* flags, uint64_t timeout_ticks) {
-  for (uint32_t p = lo + threadIdx.x; p < hi; p += 64)
-    if (!ipc_spin(ipc_arrived(mine, chan, p), seq, timeout_ticks)) atomicOr(flags, uint32_t(kShardPeerTimeout));
+// one wavefront: (1) the pushes completed before this launch are published to every peer, (2) the
+// stream is held until peers [lo, hi) have published exchange `wait_seq` of `wait_chan`
+struct ShardSyncArgs {
+  char* win[kMaxShards];
+  uint32_t* flags;
+  uint64_t timeout_ticks;
+  uint32_t rank, world;
+  uint32_t n_sig;
+  uint32_t sig_chan[kIpcChannels], sig_seq[kIpcChannels];
+  uint32_t wait_chan;         // kIpcChannels: nothing to wait for
+  uint32_t wait_seq, lo, hi;
+};
+
+__global__ __launch_bounds__(64) void shard_sync_kernel(ShardSyncArgs A) {
+  for (uint32_t k = 0; k < A.n_sig; ++k)
+    for (uint32_t p = threadIdx.x; p < A.world; p += 64)
+      st_sys(ipc_arrived(A.win[p], A.sig_chan[k], A.rank), A.sig_seq[k]);
+  if (A.wait_chan >= uint32_t(kIpcChannels)) return;
+  char* mine = A.win[A.rank];
+  for (uint32_t p = A.lo + threadIdx.x; p < A.hi; p += 64)
+    if (!ipc_spin(ipc_arrived(mine, A.wait_chan, p), A.wait_seq, A.timeout_ticks))
+      atomicOr(A.flags, uint32_t(kShardPeerTimeout));
   __threadfence_system();
 }
 
