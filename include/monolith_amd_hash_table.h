@@ -360,6 +360,10 @@ mhte_status mhte_hash_filter_create_from_proto(uint64_t capacity, int32_t split_
                                                int32_t device, mhte_hash_filter** out);
 void mhte_hash_filter_destroy(mhte_hash_filter* f);
 mhte_status mhte_multi_table_set_filter(mhte_multi_table* t, mhte_hash_filter* f /* NULL detaches */);
+/* Filter::estimated_total_element / failure_count / split_num (RT/hash_filter/filter.h:31-36):
+ * out[0] = head, [1] = head_increment, [2] = failure_count (adds that found no usable slot),
+ * [3] = number of splits S, [4 .. 4+S) = elements per split; cap >= 4 + S.  Synchronises. */
+mhte_status mhte_hash_filter_stats(mhte_hash_filter* f, int64_t* out, int32_t cap, void* stream);
 mhte_status mhte_hash_filter_save(mhte_hash_filter* f, const char* basename, void* stream);
 mhte_status mhte_hash_filter_restore(mhte_hash_filter* f, const char* basename, void* stream);
 /* Filter::get: the seen count of ids (0..15), out [dev u32, n] */

@@ -1849,6 +1849,23 @@ void put_u(std::string& o, uint32_t field, uint64_t v) { put_key(o, field, 0); c
 }  // namespace
 }  // namespace mhte
 
+mhte_status mhte_hash_filter_stats(mhte_hash_filter* f, int64_t* out, int32_t cap, void* stream) {
+  return guard([&] {
+    if (!f || !out) throw Error(MHTE_INVALID_ARGUMENT, "filter stats: bad arguments");
+    if (cap < 4 + int32_t(f->nsplit)) throw Error(MHTE_INVALID_ARGUMENT, "filter stats: out holds 4 + split count words");
+    HIP_OK(hipSetDevice(f->device));
+    hipStream_t st = S(stream);
+    FilterState hs;
+    HIP_OK(hipMemcpyAsync(&hs, f->state, sizeof(hs), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    out[0] = hs.head;
+    out[1] = hs.head_increment;
+    out[2] = int64_t(hs.failure_count);
+    out[3] = f->nsplit;
+    for (uint32_t sp = 0; sp < f->nsplit; ++sp) out[4 + sp] = filter_split_elements(hs, sp);
+  });
+}
+
 mhte_status mhte_hash_filter_save(mhte_hash_filter* f, const char* basename, void* stream) {
   return guard([&] {
     if (!f || !basename || !*basename) throw Error(MHTE_INVALID_ARGUMENT, "filter save: bad arguments");

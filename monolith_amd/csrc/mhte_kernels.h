@@ -185,7 +185,7 @@ struct Vec<1> {
 // number of times it has been seen is below its feature slot's occurrence threshold.
 //   * `nsplit` (>= 5) counting filters of capacity / (nsplit - 1) elements each, fill rate 1.2,
 //     4-bit saturating counts; slot word = signature << 4 | count, signature = (fid >> 17 | fid << 15)
-//     (28 bits here, the reference's uint16 keeps 12); linear probing, 16 probes
+//     & 0xfff (the reference's uint16 word, kept in 32 bits here); linear probing, 16 probes
 //     (SlidingHashFilter::MAX_STEP), no wrap: the split has 64 words of overrun like the reference's
 //     map_ (total_size + MAX_STEP).
 //   * add (:56-91): look FORWARD from `head` over 2 splits for a usable slot (the id's, or an empty
@@ -196,8 +196,9 @@ struct Vec<1> {
 //     The reference checks after every add; here the check runs between launches
 //     (filter_advance_kernel) — inside one launch all adds see one window, as they would under any
 //     one of the reference's thread interleavings in which the split fills at the batch's end.
-// Physical placement uses the engine's fixed hash (the reference's absl::Hash is unpinned), so
-// parity is semantic: counts and admission decisions.
+// Physical placement uses the engine's fixed hash (the reference's absl::Hash is seeded per process).
+// Checked against the reference's own sources compiled with that hash (oracle/_ref, through the
+// restatement oracle/mhte_filter_oracle.c): counts, admission decisions, the split words.
 // =============================================================================================
 constexpr uint32_t kFilterMaxCount = 15;   // count_bit = 4, filter.h:56-57
 constexpr int kFilterMaxStep = 64;         // words of overrun behind a split (hash_filter.h:190)
@@ -230,9 +231,14 @@ __device__ __forceinline__ int32_t occurrence_threshold(const TableView& tv, int
   return thr;
 }
 
+// HashFilter<uint16_t>::signature (hash_filter.h:151): 12 bits — sign_mask = 0xffff >> count_bit.
+// A slot word is the reference's uint16 value (signature << 4 | count) in a 32-bit word (the CAS
+// unit), so a dump is readable by the reference ((uint16_t)data, hash_filter.cc:75) and two ids
+// alias exactly when they would there: the reference's own test expects 0.9 % of the counts to be
+// off at its load (sliding_hash_filter_test.cc:95-99).
 __device__ __forceinline__ uint32_t filter_sign(int64_t id) {
   const uint64_t fid = uint64_t(id);
-  return uint32_t((fid >> 17) | (fid << 15)) & 0x0fffffffu;
+  return uint32_t((fid >> 17) | (fid << 15)) & 0x0fffu;
 }
 __device__ __forceinline__ uint64_t filter_home(int64_t id, uint64_t total) {
   return hash_key(id ^ 0x5bd1e995) % total;

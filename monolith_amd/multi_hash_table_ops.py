@@ -120,6 +120,22 @@ class HashFilter:
                                          _stream()))
     return out
 
+  def _stats(self):
+    out = (C.c_int64 * (4 + 64))()
+    check(self._lib.mhte_hash_filter_stats(self._h, out, C.c_int32(4 + 64), _stream()))
+    return out
+
+  def num_elements(self) -> List[int]:
+    """elements per split (HashFilter::estimated_total_element of each)."""
+    s = self._stats()
+    return [int(s[4 + i]) for i in range(int(s[3]))]
+
+  def estimated_total_element(self) -> int:
+    return sum(self.num_elements())
+
+  def failure_count(self) -> int:
+    return int(self._stats()[2])
+
   def save(self, basename: str) -> "HashFilter":
     """hash_filter_ops.save_hash_filter (MonolithHashFilterSave): one file per split."""
     import os

@@ -3,8 +3,9 @@
 ctypes bindings for
   * ``liboracle.so``               — the plain-C restatement of the reference hot path
                                      (oracle/mhte_oracle.c), and
-  * ``_ref/libmonolith_ref*.so``   — the reference's own cuckoohash_map.hpp / avx_utils.h compiled
-                                     in place from /root/reference by oracle/Makefile.
+  * ``_ref/libmonolith_ref*.so``   — the reference's own cuckoohash_map.hpp / avx_utils.h, and
+                                     (``_filter``) its hash_filter sources, compiled in place from
+                                     /root/reference by oracle/Makefile.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
 this package; ``monolith_amd`` never does.
@@ -28,7 +29,8 @@ def build(force=False):
   # (make compares time stamps: an edited restatement is rebuilt, an up-to-date one is left alone)
   subprocess.check_call(["make", "-s", "-C", _DIR] + (["-B"] if force else []) + ["liboracle.so"])
   if os.path.isdir("/root/reference") and (
-      force or not os.path.exists(os.path.join(_DIR, "_ref", "libmonolith_ref.so"))):
+      force or not all(os.path.exists(os.path.join(_DIR, "_ref", n)) for n in
+                       ("libmonolith_ref.so", "libmonolith_ref_avx.so", "libmonolith_ref_filter.so"))):
     subprocess.check_call(["make", "-s", "-C", _DIR, "ref"])
 
 
@@ -422,3 +424,153 @@ class RefPs:
     hits = self.L.ref_ps_lookup(self.h, _p(ids, C.c_int64), C.c_int64(ids.size),
                                 _p(out, C.c_float))
     return out, int(hits)
+
+
+# ---------------------------------------------------------------- occurrence filter
+class SlidingFilter:
+  """The restatement of SlidingHashFilter / HashFilter<uint16_t> (oracle/mhte_filter_oracle.c): the
+  checker of the device filter.  ``defer_advance``: the window moves only in ``advance_if_full()``
+  (the device checks between launches)."""
+
+  def __init__(self, capacity, split_num, defer_advance=False):
+    L = lib()
+    L.mo_filter_new.restype = C.c_void_p
+    L.mo_filter_new.argtypes = [C.c_uint64, C.c_int]
+    L.mo_filter_estimated_total_element.restype = C.c_uint64
+    L.mo_filter_split_words.restype = C.c_uint64
+    self._L = L
+    self._h = C.c_void_p(L.mo_filter_new(int(capacity), int(split_num)))
+    if defer_advance:
+      L.mo_filter_set_defer_advance(self._h, 1)
+
+  def __del__(self):
+    try:
+      if self._h:
+        self._L.mo_filter_free(self._h)
+        self._h = None
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def add(self, fid, count=1):
+    return int(self._L.mo_filter_add(self._h, C.c_uint64(int(fid) & 0xFFFFFFFFFFFFFFFF), C.c_uint32(int(count))))
+
+  def get(self, fid):
+    return int(self._L.mo_filter_get(self._h, C.c_uint64(int(fid) & 0xFFFFFFFFFFFFFFFF)))
+
+  def should_be_filtered(self, fid, count, threshold):
+    return bool(self._L.mo_filter_should_be_filtered(self._h, C.c_int64(int(fid)), C.c_int64(int(count)),
+                                                     C.c_int64(int(threshold))))
+
+  def advance_if_full(self):
+    self._L.mo_filter_advance_if_full(self._h)
+
+  def estimated_total_element(self):
+    return int(self._L.mo_filter_estimated_total_element(self._h))
+
+  def state(self):
+    """-> dict(head, head_increment, failure_count, num_elements[nsplit])"""
+    out = (C.c_uint64 * (4 + 64))()
+    self._L.mo_filter_state(self._h, out)
+    n = int(out[3])
+    return {"head": int(out[0]), "head_increment": int(out[1]), "failure_count": int(out[2]),
+            "num_elements": [int(out[4 + i]) for i in range(n)]}
+
+  def split_words(self, split):
+    n = int(self._L.mo_filter_split_words(self._h, C.c_int(split), None, C.c_uint64(0)))
+    out = np.zeros(n, dtype=np.uint32)
+    self._L.mo_filter_split_words(self._h, C.c_int(split), out.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                  C.c_uint64(n))
+    return out
+
+
+_ref_filter = None
+
+
+def ref_filter_available():
+  return os.path.exists(os.path.join(_DIR, "_ref", "libmonolith_ref_filter.so"))
+
+
+def ref_filter_lib():
+  global _ref_filter
+  if _ref_filter is None:
+    build()
+    L = C.CDLL(os.path.join(_DIR, "_ref", "libmonolith_ref_filter.so"))
+    L.rf_create.restype = C.c_void_p
+    L.rf_create.argtypes = [C.c_uint64, C.c_int]
+    L.rf_destroy.argtypes = [C.c_void_p]
+    L.rf_add.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
+    L.rf_add.restype = C.c_uint32
+    L.rf_get.argtypes = [C.c_void_p, C.c_uint64]
+    L.rf_get.restype = C.c_uint32
+    L.rf_should_be_filtered.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+    for n in ("rf_estimated_total_element", "rf_failure_count", "rf_split_num"):
+      getattr(L, n).restype = C.c_uint64
+      getattr(L, n).argtypes = [C.c_void_p]
+    L.rf_save_split.restype = C.c_int64
+    L.rf_save_split.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_int64]
+    L.rf_restore_split.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_int64]
+    L.rf_add_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.rf_get_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    _ref_filter = L
+  return _ref_filter
+
+
+class RefSlidingFilter:
+  """The reference's own SlidingHashFilter (sliding_hash_filter.cc + hash_filter.{h,cc} compiled in
+  place, oracle/ref_filter_driver.cc), absl::Hash replaced by the engine's fixed slot hash."""
+  META = ("failure_count", "total_size", "num_elements", "fill_rate_e6", "split_num", "max_forward_step",
+          "max_backward_step", "max_step", "head", "head_increment", "sliding_failure_count")
+
+  def __init__(self, capacity, split_num):
+    self._L = ref_filter_lib()
+    self._h = C.c_void_p(self._L.rf_create(int(capacity), int(split_num)))
+
+  def __del__(self):
+    try:
+      if self._h:
+        self._L.rf_destroy(self._h)
+        self._h = None
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def add(self, fid, count=1):
+    return int(self._L.rf_add(self._h, int(fid) & 0xFFFFFFFFFFFFFFFF, int(count)))
+
+  def get(self, fid):
+    return int(self._L.rf_get(self._h, int(fid) & 0xFFFFFFFFFFFFFFFF))
+
+  def add_many(self, fids, counts):
+    fids = np.ascontiguousarray(fids, dtype=np.uint64)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    out = np.zeros(fids.size, dtype=np.uint32)
+    self._L.rf_add_many(self._h, fids.ctypes.data, counts.ctypes.data, fids.size, out.ctypes.data)
+    return out
+
+  def get_many(self, fids):
+    fids = np.ascontiguousarray(fids, dtype=np.uint64)
+    out = np.zeros(fids.size, dtype=np.uint32)
+    self._L.rf_get_many(self._h, fids.ctypes.data, fids.size, out.ctypes.data)
+    return out
+
+  def should_be_filtered(self, fid, count, threshold):
+    return bool(self._L.rf_should_be_filtered(self._h, int(fid), int(count), int(threshold)))
+
+  def estimated_total_element(self):
+    return int(self._L.rf_estimated_total_element(self._h))
+
+  def failure_count(self):
+    return int(self._L.rf_failure_count(self._h))
+
+  def save_split(self, split):
+    """-> (meta dict, words uint32[total_size + 64]) — Filter::Save of one split"""
+    meta = (C.c_uint64 * 11)()
+    n = int(self._L.rf_save_split(self._h, split, meta, None, 0))
+    words = np.zeros(n, dtype=np.uint32)
+    self._L.rf_save_split(self._h, split, meta, words.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+    return dict(zip(self.META, [int(x) for x in meta])), words
+
+  def restore_split(self, split, meta, words):
+    m = (C.c_uint64 * 11)(*[int(meta[k]) for k in self.META])
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    return int(self._L.rf_restore_split(self._h, split, m, words.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                        words.size)) == 0

@@ -69,6 +69,17 @@ def _build():
                     ("last_update_ts_sec", 4, F.TYPE_INT64, OPT, None, False)])
   msg("MultiHashTableMetadata", [("table_name", 1, F.TYPE_STRING, OPT, None, False),
                                  ("num_entries", 2, F.TYPE_UINT64, OPT, None, False)])
+  # hash filter dumps (embedding_hash_table.proto:112-137)
+  u32f = lambda name, num: (name, num, F.TYPE_UINT32, OPT, None, False)
+  u64f = lambda name, num: (name, num, F.TYPE_UINT64, OPT, None, False)
+  msg("SlidingHashFilterMetaDump", [u32f("split_num", 1), u32f("max_forward_step", 2), u32f("max_backward_step", 3),
+                                    u32f("max_step", 4), u32f("head", 5), u32f("head_increment", 6),
+                                    u64f("failure_count", 7)])
+  msg("HashFilterSplitMetaDump", [u64f("failure_count", 1), u64f("total_size", 2), u64f("num_elements", 3),
+                                  ("fill_rate", 4, F.TYPE_DOUBLE, OPT, None, False),
+                                  ("sliding_hash_filter_meta", 5, F.TYPE_MESSAGE, OPT, "SlidingHashFilterMetaDump",
+                                   False)])
+  msg("HashFilterSplitDataDump", [u32f("offset", 1), ("data", 2, F.TYPE_UINT32, REP, None, False)])
   # ---- configuration messages (embedding_hash_table.proto:23-43,54-96,100-110; optimizer.proto;
   # initializer/initializer_config.proto), for the C ABI's proto-config reader
   i32 = lambda name, num: (name, num, F.TYPE_INT32, OPT, None, False)
@@ -132,6 +143,21 @@ def _build():
 
 _get = _build()
 EntryDump, MultiHashTableMetadata = _get("EntryDump"), _get("MultiHashTableMetadata")
+HashFilterSplitMetaDump, HashFilterSplitDataDump = _get("HashFilterSplitMetaDump"), _get("HashFilterSplitDataDump")
+
+
+def read_filter_split(path):
+  """One split file of MonolithHashFilterSave (hash_filter.cc:29-58): the first record is the
+  HashFilterSplitMetaDump, the rest HashFilterSplitDataDump of <= 10 000 words each -> (meta, words)."""
+  import numpy as np
+  recs = unframe(open(path, "rb").read())
+  meta = HashFilterSplitMetaDump.FromString(recs[0])
+  words = np.zeros(int(meta.total_size) + 64, dtype=np.uint32)
+  for r in recs[1:]:
+    d = HashFilterSplitDataDump.FromString(r)
+    assert len(d.data) <= 10000
+    words[d.offset:d.offset + len(d.data)] = np.array(d.data, dtype=np.uint32)
+  return meta, words
 MultiEmbeddingHashTableConfig = _get("MultiEmbeddingHashTableConfig")
 EmbeddingHashTableConfig = _get("EmbeddingHashTableConfig")
 SlotOccurrenceThresholdConfig = _get("SlotOccurrenceThresholdConfig")

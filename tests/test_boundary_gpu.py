@@ -190,88 +190,11 @@ def test_plain_c_client_runs(tmp_path):
 
 
 # =============================================================================== sliding hash filter
-class SlidingModel:
-  """sliding_hash_filter.cc:56-114 + HashFilter::find / HashFilterIterator::add (hash_filter.h:39-66,
-  118-134) restated with the engine's documented slot hash (fmix64(id ^ 0x5bd1e995) % total) and
-  28-bit signature, so that placement — which split an id lands in when the head split's 16 probe
-  positions are taken, hence when the window moves — is the device's: the checker of the device
-  filter.  The one deliberate difference is written out: the window moves between launches."""
-  PROBE, FORWARD = 16, 2
-
-  def __init__(self, capacity, split_num):
-    capacity = max(capacity, 300)
-    self.S = max(split_num, 5)
-    self.cap = capacity // (self.S - self.FORWARD + 1)
-    self.total = max(1, int(float(self.cap) * 1.2))
-    self.splits = [np.zeros(self.total + 64, dtype=np.uint32) for _ in range(self.S)]
-    self.nelem = [0] * self.S
-    self.head, self.hinc = 0, 0
-
-  def _home(self, fid):
-    return int(O.lib().mo_hash(int(np.int64(fid) ^ np.int64(0x5bd1e995)))) % self.total
-
-  @staticmethod
-  def _sign(fid):
-    u = int(fid) & 0xFFFFFFFFFFFFFFFF
-    return ((u >> 17) | (u << 15)) & 0x0FFFFFFF
-
-  def _find(self, sp, fid, nonempty):
-    home, sign = self._home(fid), self._sign(fid)
-    a = self.splits[sp]
-    for t in range(self.PROBE):
-      w = int(a[home + t])
-      if w == 0:
-        return None if nonempty else home + t
-      if (w >> 4) == sign:
-        return home + t
-    return None
-
-  def _forward(self, fid):
-    for f in range(self.FORWARD):
-      sp = (self.head + f) % self.S
-      pos = self._find(sp, fid, False)
-      if pos is not None:
-        return sp, pos
-    return None, None
-
-  def _back(self, fid):
-    i = self.head
-    for _ in range(min(self.hinc, self.S - self.FORWARD)):
-      i = (i - 1) % self.S
-      pos = self._find(i, fid, True)
-      if pos is not None:
-        return int(self.splits[i][pos]) & 15
-    return None
-
-  def add(self, fid, count):
-    sp, pos = self._forward(fid)
-    if sp is None:
-      return 15
-    w = int(self.splits[sp][pos])
-    if w:
-      self.splits[sp][pos] = (w & ~15) | min(15, (w & 15) + min(count, 15))
-      return w & 15
-    old = self._back(fid) or 0
-    self.splits[sp][pos] = (self._sign(fid) << 4) | min(15, old + min(count, 15))
-    self.nelem[sp] += 1
-    return old
-
-  def advance_if_full(self):       # (the device checks between launches)
-    if self.nelem[self.head] + 1 >= self.cap:
-      self.head = (self.head + 1) % self.S
-      self.hinc += 1
-      c = (self.head + self.FORWARD - 1) % self.S
-      self.splits[c][:] = 0
-      self.nelem[c] = 0
-
-  def get(self, fid):
-    sp, pos = self._forward(fid)
-    if sp is None:
-      return 15
-    w = int(self.splits[sp][pos])
-    if w:
-      return w & 15
-    return self._back(fid) or 0
+# The checker is oracle.SlidingFilter (oracle/mhte_filter_oracle.c): the restatement of
+# sliding_hash_filter.cc / hash_filter.h that tests/test_filter_oracle.py pins, add by add and word by
+# word, to those very sources compiled in place.  defer_advance: the window moves between launches.
+def SlidingModel(capacity, split_num):
+  return O.SlidingFilter(capacity, split_num, defer_advance=True)
 
 
 def _filter_table(flt, thr):
@@ -315,10 +238,32 @@ def test_sliding_hash_filter_window_against_model(tmp_path):
       np.testing.assert_array_equal(got, [model.get(int(x)) for x in probe], err_msg="step %d" % i)
       present = mt.contains("t", ids_t(probe)).cpu().numpy()
       np.testing.assert_array_equal(present, [int(x) in admitted for x in probe])
-  assert model.hinc > model.S                     # the window went round more than once
+  st = model.state()
+  assert st["head_increment"] > len(st["num_elements"])   # the window went round more than once
   base = str(tmp_path / "flt" / "filter")
   flt.save(base)
   assert sorted(os.listdir(tmp_path / "flt")) == ["filter-%05d-of-00005" % i for i in range(5)]
+  # the files hold the reference's messages, and the device's words ARE the reference's uint16
+  # words: every split, slot for slot, equals the restatement's (which test_filter_oracle.py pins to
+  # the compiled reference) — independent TFRecord + protobuf-runtime reader
+  ref = O.RefSlidingFilter(300, 5) if O.ref_filter_available() else None
+  for sp in range(5):
+    meta, words = P.read_filter_split("%s-%05d-of-00005" % (base, sp))
+    np.testing.assert_array_equal(words, model.split_words(sp), err_msg="split %d" % sp)
+    sl = meta.sliding_hash_filter_meta
+    assert (meta.total_size, meta.num_elements, meta.fill_rate) == (90, st["num_elements"][sp], 1.2)
+    assert (sl.split_num, sl.max_forward_step, sl.max_backward_step, sl.max_step, sl.head, sl.head_increment) == (
+        5, 2, 3, 16, st["head"], st["head_increment"])
+    if ref is not None:   # ... and the reference's own Restore takes them
+      assert ref.restore_split(sp, {"failure_count": meta.failure_count, "total_size": meta.total_size,
+                                    "num_elements": meta.num_elements, "fill_rate_e6": 1200000,
+                                    "split_num": sl.split_num, "max_forward_step": sl.max_forward_step,
+                                    "max_backward_step": sl.max_backward_step, "max_step": sl.max_step,
+                                    "head": sl.head, "head_increment": sl.head_increment,
+                                    "sliding_failure_count": sl.failure_count}, words)
+  if ref is not None:
+    probe = np.unique(np.array(seq, dtype=np.int64))
+    np.testing.assert_array_equal(ref.get_many(probe.astype(np.uint64)), flt.get(ids_t(probe)).cpu().numpy())
   flt2 = HashFilter(capacity=300, split_num=5)
   flt2.restore(base)
   probe = np.unique(np.array(seq, dtype=np.int64))
@@ -338,86 +283,147 @@ def test_sliding_hash_filter_window_against_model(tmp_path):
     HashFilter(capacity=300, split_num=5).restore(str(tmp_path / "flt" / "absent"))
 
 
+def _device_add(mt, ids_with_multiplicity):
+  """add(fid, k) for every distinct fid occurring k times: an update of a table whose threshold (100)
+  no 4-bit count reaches, so every occurrence is dropped and counted (tf_bridge.cc:300-321)."""
+  n = len(ids_with_multiplicity)
+  mt.apply_gradients({"t": (ids_t(ids_with_multiplicity), torch.zeros((n, 1), device="cuda"))})
+
+
+def test_sliding_hash_filter_reference_kats():
+  """sliding_hash_filter_test.cc:27-41 (test_simple), :43-62 (test_count), :101-111
+  (SkipZeroThresholdFeatures) on the device filter."""
+  for key_num in (1, 3, 100):
+    flt = HashFilter(capacity=key_num, split_num=10)
+    mt = _filter_table(flt, 100)
+    for i in range(17):
+      assert int(flt.get(ids_t([1]))[0]) == min(i, 15)
+      _device_add(mt, [1])
+    assert int(flt.get(ids_t([1]))[0]) == 15
+  flt = HashFilter(capacity=1000000, split_num=10)
+  mt = _filter_table(flt, 100)
+  big = 10000002961562801052 - (1 << 64)
+  for c in (1, 20, 1):
+    _device_add(mt, [big] * c)
+  assert int(flt.get(ids_t([big]))[0]) == 15
+  meta_total = sum(int(x) for x in flt.num_elements())
+  assert meta_total == 1
+  # threshold 0 never consults the filter, threshold 1 drops the first sighting
+  flt = HashFilter(capacity=1000000, split_num=10)
+  cfg0 = entry.make_table_config(
+      [entry.CombineAsSegment(1, entry.ZerosInitializer(), entry.SgdOptimizer(1.0))],
+      slot_occurrence_threshold_config=entry.SlotOccurrenceThresholdConfig(default_occurrence_threshold=0))
+  mt0 = MultiHashTable.from_configs({"t": cfg0}, name_suffix=_name(), hash_filter=flt)
+  mt1 = _filter_table(flt, 1)
+  zero_thr = ids_t([0, 1, 2, 3, 4])
+  normal = ids_t([0, 2, 4, 6, 8])
+  g = torch.ones((5, 1), device="cuda")
+  mt0.apply_gradients({"t": (zero_thr, g)})
+  mt1.apply_gradients({"t": (normal, g)})
+  assert mt0.contains("t", zero_thr).cpu().numpy().all()             # not filtered
+  assert not mt1.contains("t", normal).cpu().numpy().any()           # filtered: seen 0 < 1 times before
+  assert sum(int(x) for x in flt.num_elements()) == 5                # only the normal fids were counted
+
+
+def test_sliding_hash_filter_conflict_rate_kat():
+  """sliding_hash_filter_test.cc:64-99 compare_to_unordered_map(1 000 000 keys, capacity 1 000 000,
+  10 splits): the reference expects 0.908 % (+- half) of the filter's counts to differ from an exact
+  map — aliasing of 12-bit signatures over 16 probe positions — and fewer than keys / 10 000 probe
+  failures.  The device filter must land in the same band, and agree with the restatement fed the
+  same launches (the window moves between launches on both)."""
+  cap, keys, per = 1000000, 1000000, 25000
+  flt = HashFilter(capacity=cap, split_num=10)
+  mt = _filter_table(flt, 100)
+  model = O.SlidingFilter(cap, 10, defer_advance=True)
+  rng = np.random.default_rng(cap)
+  counter = {}
+  for b in range(keys // per):
+    draw = rng.integers(0, 2**31 - 1, per)
+    uniq, mult = np.unique(draw, return_counts=True)
+    ok = np.array([counter.get(int(u), 0) + 2 * int(m) <= 14 for u, m in zip(uniq, mult)])
+    uniq, mult = uniq[ok], mult[ok]
+    for u, m in zip(uniq.tolist(), mult.tolist()):
+      counter[u] = counter.get(u, 0) + 2 * m
+      model.add(u, 2 * m)
+    model.advance_if_full()
+    _device_add(mt, np.repeat(uniq, 2 * mult))
+  keys_arr = np.fromiter(counter.keys(), dtype=np.int64, count=len(counter))
+  want = np.fromiter(counter.values(), dtype=np.int64, count=len(counter))
+  got = flt.get(ids_t(keys_arr)).cpu().numpy()
+  rate = float((got != want).mean())
+  assert abs(rate - 0.00908) <= 0.00908 / 2, rate
+  mod = np.array([model.get(int(k)) for k in keys_arr.tolist()])
+  assert float((got != mod).mean()) <= 1e-4, float((got != mod).mean())
+  assert flt.failure_count() < len(counter) / 10000
+
+
 # =============================================================================== fused_embedding_to_layout
+# The checkers live in oracle/layout.py: layout_model / layout_grad_model (the op's algorithm over
+# its own offset encoding) and the reference test's input generation + truth procedure
+# (fused_embedding_to_layout_test.py:176-530, :553-790); tests/test_layout_oracle.py pins the former
+# to the latter on the CPU.
+from oracle import layout as OL  # noqa: E402
+
+
+def _to_oracle_cfgs(cfgs):
+  return OL.FeatureConfigs(
+      {n: OL.FeatureConfig(f.table, f.pooling_type, list(f.slice_dims), f.max_sequence_length)
+       for n, f in cfgs.feature_configs.items()},
+      {n: OL.OutConfig([OL.SliceConfig(s_.feature_name, s_.start, s_.end) for s_ in o.slice_configs], o.out_type,
+                       [list(x) for x in o.shape]) for n, o in cfgs.out_configs.items()})
+
+
+def _to_product_cfgs(ocfgs):
+  from monolith_amd import distribution_ops as D
+  return D.FeatureConfigs(
+      {n: D.FeatureConfig(f.table, f.pooling_type, list(f.slice_dims), f.max_sequence_length)
+       for n, f in ocfgs.feature_configs.items()},
+      {n: D.OutConfig([D.SliceConfig(s_.feature_name, s_.start, s_.end) for s_ in o.slice_configs], o.out_type,
+                      [list(x) for x in o.shape]) for n, o in ocfgs.out_configs.items()})
+
+
 def _layout_model(embs, fid_offset, feature_offset, nfl_offset, batch, cfgs, tensors_grad=None):
-  """GatherEmb / ScatterGrad (runtime/ops/fused_embedding_to_layout.h:204-346) and the op's layout
-  placement restated in numpy, the way the reference's own test computes its expectation
-  (fused_embedding_to_layout_test.py:430-530, 690-710): the checker.  Forward when tensors_grad is
-  None, else the gradients of `embs`."""
-  from monolith_amd.distribution_ops import OutType, PoolingType
-  names = sorted(cfgs.feature_configs)
-  n_feature, n_fid, n_nfl = len(feature_offset), len(fid_offset), len(nfl_offset)
-  outs, grads = [], [np.zeros_like(e) for e in embs]
-  k = 0
-  for ln in sorted(cfgs.out_configs):
-    oc = cfgs.out_configs[ln]
-    base = len(outs)
-    for sh in oc.shape:
-      outs.append(np.zeros([batch if d == -1 else d for d in sh], np.float32))
-    off = 0
-    for i, sc in enumerate(oc.slice_configs):
-      fc = cfgs.feature_configs[sc.feature_name]
-      dim = sc.end - sc.start
-      nfl = names.index(sc.feature_name)
-      enc = int(nfl_offset[nfl])
-      shared, noff = enc >> 31, enc & 0x7fffffff
-      nxt = (int(nfl_offset[nfl + 1]) & 0x7fffffff) if nfl < n_nfl - 1 else n_feature
-      t_idx = base if len(oc.shape) == 1 else base + i
-      tgt = outs[t_idx] if tensors_grad is None else tensors_grad[t_idx]
-      for b in range(batch):
-        if nxt - noff <= 0:
-          continue
-        f = noff + (0 if shared else b)
-        f0 = int(feature_offset[f])
-        f1 = int(feature_offset[f + 1]) if f < n_feature - 1 else n_fid
-        rows = []
-        for q in range(f0, f1):
-          i1, i2 = int(fid_offset[q]) >> 32, int(fid_offset[q]) & 0xffffffff
-          rows.append((i1, i2))
-        if not rows:
-          continue
-        if oc.out_type == OutType.CONCAT:
-          view = tgt[b, off:off + dim]
-        elif oc.out_type == OutType.STACK:
-          view = tgt[b, i, :]
-        elif oc.out_type == OutType.ADDN:
-          view = tgt[b, :]
-        else:
-          view = tgt[b]
-        if tensors_grad is None:
-          if fc.pooling_type == PoolingType.FIRSTN:
-            for s_, (i1, i2) in enumerate(rows[:fc.max_sequence_length]):
-              view[s_, :] = embs[i1][i2, sc.start:sc.end]
-            continue
-          acc = None
-          for (i1, i2) in rows:
-            x = embs[i1][i2, sc.start:sc.end]
-            if fc.pooling_type == PoolingType.MEAN:
-              x = x / np.float32(len(rows))
-            acc = x.copy() if acc is None else acc + x
-          if oc.out_type == OutType.ADDN:
-            view += acc if k_first_addn.get((t_idx, b)) else 0
-            if not k_first_addn.get((t_idx, b)):
-              view[:] = acc
-              k_first_addn[(t_idx, b)] = True
-          else:
-            view[:] = acc
-        else:
-          for s_, (i1, i2) in enumerate(rows):
-            if fc.pooling_type == PoolingType.FIRSTN:
-              if s_ < fc.max_sequence_length:
-                grads[i1][i2, sc.start:sc.end] += view[s_, :]
-            elif fc.pooling_type == PoolingType.MEAN:
-              grads[i1][i2, sc.start:sc.end] += view / np.float32(len(rows))
-            else:
-              grads[i1][i2, sc.start:sc.end] += view
-      if oc.out_type == OutType.CONCAT:
-        off += dim
-      k += 1
-  return outs if tensors_grad is None else grads
+  oc = _to_oracle_cfgs(cfgs)
+  if tensors_grad is None:
+    return OL.layout_model(embs, fid_offset, feature_offset, nfl_offset, batch, oc)
+  return OL.layout_grad_model(embs, fid_offset, feature_offset, nfl_offset, batch, oc, tensors_grad)
 
 
-k_first_addn = {}
+def _dev_case(c):
+  fo = torch.tensor(c["fid_offset"].view(np.int64)).cuda()
+  fe = torch.tensor(c["feature_offset"]).cuda()
+  nf = torch.tensor(c["nfl_offset"].view(np.int32)).cuda()
+  return [torch.tensor(e).cuda() for e in c["embs"]], fo, fe, nf
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_fused_embedding_to_layout_reference_test_forward(seed):
+  """The reference's own forward test (fused_embedding_to_layout_test.py:176-530: 199 slots, 5 shards,
+  batch 256, shared lists for even slots, SUM / MEAN / FIRSTN, ADDN / CONCAT / STACK / NONE): the
+  device against the test's truth procedure at the test's tolerance, and bit for bit against the
+  op's restatement."""
+  from monolith_amd import distribution_ops as D
+  c = OL.reference_forward_case(seed)
+  embs, fo, fe, nf = _dev_case(c)
+  got = D.fused_embedding_to_layout(embs, fo, fe, nf, c["batch"], _to_product_cfgs(c["cfgs"]))
+  model = OL.layout_model(c["embs"], c["fid_offset"], c["feature_offset"], c["nfl_offset"], c["batch"], c["cfgs"])
+  assert len(got) == len(c["expected"]) == len(model)
+  for g, e, m in zip(got, c["expected"], model):
+    g = g.cpu().numpy()
+    assert np.allclose(e, g, rtol=1e-4, atol=1e-7)          # (:523)
+    np.testing.assert_array_equal(g, m)
+
+
+def test_fused_embedding_to_layout_reference_test_grad():
+  """The reference's gradient test (:553-790: 29 slots, 3 shards, batch 256, every output gradient 1):
+  the gradient of a fid's row is how often it was pooled (1 / len for MEAN, first 3 for FIRSTN)."""
+  from monolith_amd import distribution_ops as D
+  c = OL.reference_grad_case(0)
+  embs, fo, fe, nf = _dev_case(c)
+  tg = [torch.tensor(t).cuda() for t in c["tensors_grad"]]
+  got = D.fused_embedding_to_layout_grad(embs, fo, fe, nf, c["batch"], tg, _to_product_cfgs(c["cfgs"]))
+  for g, e in zip(got, c["expected_grads"]):
+    np.testing.assert_allclose(g.cpu().numpy(), e, rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("batch,seed", [(1, 0), (7, 1), (300, 2)])
@@ -455,7 +461,6 @@ def test_fused_embedding_to_layout_forward_and_grad(batch, seed):
   nf = torch.tensor(np.array(nfl_offset, dtype=np.uint32).view(np.int32)).cuda()
   dev_embs = [torch.tensor(e).cuda() for e in embs]
   got = D.fused_embedding_to_layout(dev_embs, fo, fe, nf, batch, cfgs)
-  k_first_addn.clear()
   exp = _layout_model(embs, fid_offset, feature_offset, nfl_offset, batch, cfgs)
   assert len(got) == len(exp) == 6
   for g, e in zip(got, exp):

@@ -1,11 +1,11 @@
 """CPU suite, world_size 2 over gloo: the wire protocol of the C++ sharded multi-table step
-(csrc/mhte_shard_host.h / mhte_shard_kernels.h) restated in numpy and run between two processes —
-fixed-capacity peer blocks whose headers carry the per-table counts (no size exchange), one
-exchange per direction for ALL tables, row slot s <-> id slot s, owners applying the senders'
-blocks in rank order — against a single-process run of the reference semantics on the oracle.  The
-block geometry comes from the product (``shard_block_geometry``, which the GPU tests pin to the
-library's own numbers); the HIP kernels themselves are checked against the same oracle semantics
-in tests/test_shard_step_gpu.py (N ranks in one process on the GPU box)."""
+(oracle/shard_protocol.py: whole-batch peer blocks whose headers carry the per-table counts, one
+exchange per direction for ALL tables, row slot s <-> id slot s, owners applying the senders' blocks
+in rank order) run between two processes against a single-process run of the reference semantics
+on the oracle.  The block geometry is the product's (``shard_block_geometry`` == the oracle's
+``block_geometry``; the GPU tests pin it to the library's own numbers).  The C++ step itself is
+checked against the same semantics by separate PROCESSES on the GPU (tests/test_shard_ipc_gpu.py)
+and by N ranks in one process (tests/test_shard_step_gpu.py)."""
 import os
 import socket
 import sys
@@ -37,21 +37,8 @@ def _batch(rank, step, t):
 
 
 def _unique_sum(O, ids, g, d):
-  if ids.size == 0:
-    return np.zeros(0, np.int64), np.zeros((0, d), np.float32), np.zeros(0, np.int64)
-  uk, _, vo, vos, _ = O.unique_key_with_value_and_offset(ids, [0, ids.size], [d])
-  gu = O.fill_with_offset_map_gradient(np.arange(uk.size), [0, uk.size], g.ravel(), vo, vos,
-                                       [d]).reshape(-1, d)
-  index = {int(k): i for i, k in enumerate(uk)}
-  inv = np.array([index[int(x)] for x in ids], dtype=np.int64)
-  return uk, gu, inv
-
-
-def _exchange(blocks):
-  """blocks [world, n] -> block p goes to peer p, row p of the result came from peer p."""
-  out = torch.empty_like(blocks)
-  dist.all_to_all_single(out, blocks)
-  return out
+  from oracle import shard_protocol as SP
+  return SP.unique_sum(O, ids, g, d)
 
 
 def _worker(rank, world, port, out_dir):
@@ -59,59 +46,24 @@ def _worker(rank, world, port, out_dir):
   os.environ["MASTER_PORT"] = str(port)
   dist.init_process_group("gloo", rank=rank, world_size=world)
   import oracle as O
+  from oracle import shard_protocol as SP
   from monolith_amd.distributed_ps_sync import shard_block_geometry
-  geo = shard_block_geometry(DIMS, BATCH, world)
-  T, cap = len(DIMS), geo["cap"]
+  geo = SP.block_geometry(DIMS, BATCH, world)
+  assert geo == shard_block_geometry(DIMS, BATCH, world)   # the product lays its blocks out the same way
+  T = len(DIMS)
   mine = _tables()                       # the ids this rank owns
+
+  def exchange(blocks):
+    """blocks [world, n] -> block p goes to peer p, row p of the result came from peer p."""
+    inp = torch.from_numpy(np.ascontiguousarray(blocks))
+    out = torch.empty_like(inp)
+    dist.all_to_all_single(out, inp)
+    return out.numpy()
+
   embs = []
   for step in range(STEPS):
     batches = [_batch(rank, step, t) for t in range(T)]
-    # ---- sender: dedup, pack the distinct ids into the owners' blocks (counts in the header)
-    ids_send = np.zeros((world, geo["ids_block"]), np.int64)
-    slot_of, uniq = [], []
-    for t, (ids, g) in enumerate(batches):
-      uk, gu, inv = _unique_sum(O, ids, g, DIMS[t])
-      owner = np.mod(uk, world)
-      slot = np.zeros(uk.size, np.int64)
-      for u in range(uk.size):
-        p = int(owner[u])
-        s = int(ids_send[p, t])
-        assert s < cap
-        ids_send[p, t] = s + 1
-        ids_send[p, geo["id_off"][t] + s] = uk[u]
-        slot[u] = p * geo["rows_block"] + geo["row_off"][t] + s * DIMS[t]
-      slot_of.append(slot)
-      uniq.append((uk, gu, inv))
-    ids_recv = _exchange(torch.from_numpy(ids_send)).numpy()          # exchange 1: id blocks
-    # ---- owner: rows of the received ids (no insert) into the row blocks
-    rows_own = np.zeros((world, geo["rows_block"]), np.float32)
-    for p in range(world):
-      for t in range(T):
-        n = int(ids_recv[p, t])
-        if n:
-          e, _ = mine[t].lookup(ids_recv[p, geo["id_off"][t]:geo["id_off"][t] + n])
-          rows_own[p, geo["row_off"][t]:geo["row_off"][t] + n * DIMS[t]] = e.ravel()
-    rows_back = _exchange(torch.from_numpy(rows_own)).numpy().ravel()  # exchange 2: rows
-    # ---- sender: rows -> occurrences
-    for t, (ids, g) in enumerate(batches):
-      uk, gu, inv = uniq[t]
-      d = DIMS[t]
-      ur = np.stack([rows_back[o:o + d] for o in slot_of[t]]) if uk.size else np.zeros((0, d), np.float32)
-      embs.append(ur[inv] if ids.size else np.zeros((0, d), np.float32))
-    # ---- sender: per-id gradient sums into the row slots; owner: peers applied in rank order
-    grad_send = np.zeros(world * geo["rows_block"], np.float32)
-    for t in range(T):
-      uk, gu, inv = uniq[t]
-      for u in range(uk.size):
-        grad_send[slot_of[t][u]:slot_of[t][u] + DIMS[t]] = gu[u]
-    grad_recv = _exchange(torch.from_numpy(grad_send.reshape(world, -1))).numpy()   # exchange 3
-    for p in range(world):
-      for t in range(T):
-        n = int(ids_recv[p, t])
-        if n:
-          ids_p = ids_recv[p, geo["id_off"][t]:geo["id_off"][t] + n]
-          g_p = grad_recv[p, geo["row_off"][t]:geo["row_off"][t] + n * DIMS[t]].reshape(n, DIMS[t])
-          mine[t].optimize(ids_p, g_p, [LRS[t]], 1_700_000_000 + step)
+    embs += SP.rank_step(O, mine, DIMS, LRS, geo, world, batches, 1_700_000_000 + step, exchange)
   np.savez(os.path.join(out_dir, "rank%d.npz" % rank), *embs,
            **{"dump%d" % t: np.concatenate([np.sort(mine[t].dump()[0])]) for t in range(T)},
            **{"rows%d" % t: mine[t].lookup(np.sort(mine[t].dump()[0]))[0] for t in range(T)})
