@@ -3148,27 +3148,83 @@ static void layout_launch(bool forward, const float* const* embeddings, const in
                           const uint32_t* nfl_offset, int32_t n_nfl, int32_t batch,
                           const mhte_layout_slice* slices, int32_t n_slices, float* const* outputs,
                           const int64_t* output_len, int32_t n_outputs, int32_t flags, hipStream_t st) {
-  if (n_emb < 0 || n_emb > kMaxLayoutEmb || n_outputs < 0 || n_outputs > kMaxLayoutOut)
-    throw Error(MHTE_INVALID_ARGUMENT, "layout: at most " + std::to_string(kMaxLayoutEmb) +
-                                           " embedding matrices and " + std::to_string(kMaxLayoutOut) + " outputs");
+  if (n_emb < 0 || n_outputs < 0 || n_emb > (1 << 20) || n_outputs > (1 << 20))
+    throw Error(MHTE_INVALID_ARGUMENT, "layout: bad matrix / output count");
   if (batch < 0 || n_slices < 0 || n_fid > INT32_MAX || n_feature > INT32_MAX)
     throw Error(MHTE_INVALID_ARGUMENT, "layout: bad sizes");
-  if (forward) {  // SetZeroFunctor: rows without fids stay zero
-    for (int32_t i = 0; i < n_outputs; ++i)
-      if (output_len[i] > 0) HIP_OK(hipMemsetAsync(outputs[i], 0, size_t(output_len[i]) * 4, st));
+  // Few matrices and outputs (a model's tables: the training path) travel in the kernel arguments.
+  // More of them (one matrix per (table, shard, feature) as the reference's parameter-server path
+  // hands them over: ~1000 in its own test) go through pointer tables uploaded for the call.
+  const bool ext = n_emb > kMaxLayoutEmb || n_outputs > kMaxLayoutOut;
+  struct Blob {
+    char* d = nullptr;
+    hipStream_t st;
+    ~Blob() {
+      if (d && hipFreeAsync(d, st) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(d);
+      }
+    }
+  } blob;
+  blob.st = st;
+  LayoutArgs A{};
+  if (ext) {
+    const size_t o_emb = 0, o_out = o_emb + size_t(n_emb) * 8, o_len = o_out + size_t(n_outputs) * 8,
+                 o_str = o_len + size_t(std::max(n_emb, n_outputs)) * 8, o_cnt = o_str + size_t(n_emb) * 4,
+                 total = o_cnt + size_t(n_emb) * 4;
+    std::vector<char> h(total, 0);
+    memcpy(h.data() + o_emb, embeddings, size_t(n_emb) * 8);
+    memcpy(h.data() + o_out, outputs, size_t(n_outputs) * 8);
+    uint64_t* len = reinterpret_cast<uint64_t*>(h.data() + o_len);
+    uint32_t* str = reinterpret_cast<uint32_t*>(h.data() + o_str);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(h.data() + o_cnt);
+    uint64_t longest = 0;
+    if (forward) for (int32_t i = 0; i < n_outputs; ++i) longest = std::max(longest, len[i] = uint64_t(std::max<int64_t>(0, output_len[i])));
+    else for (int32_t i = 0; i < n_emb; ++i) longest = std::max(longest, len[i] = uint64_t(std::max<int64_t>(0, emb_count[i])));
+    for (int32_t i = 0; i < n_emb; ++i) {
+      str[i] = uint32_t(emb_stride[i]);
+      cnt[i] = uint32_t(emb_count[i]);
+    }
+    void* d = nullptr;
+    if (hipMallocAsync(&d, total, st) != hipSuccess) {
+      (void)hipGetLastError();
+      HIP_OK(hipMalloc(&d, total));
+    }
+    blob.d = static_cast<char*>(d);
+    HIP_OK(hipMemcpyAsync(blob.d, h.data(), total, hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));   // (h is a pageable temporary)
+    A.x_emb = reinterpret_cast<const float* const*>(blob.d + o_emb);
+    A.x_out = reinterpret_cast<float* const*>(blob.d + o_out);
+    A.x_stride = reinterpret_cast<const uint32_t*>(blob.d + o_str);
+    A.x_count = reinterpret_cast<const uint32_t*>(blob.d + o_cnt);
+    const int32_t nz = forward ? n_outputs : n_emb;   // SetZeroFunctor: rows without fids stay zero
+    if (nz > 0 && longest > 0) {
+      const uint32_t gx = uint32_t(std::min<uint64_t>(64, (longest + 1023) / 1024));
+      layout_zero_kernel<<<dim3(gx, uint32_t(nz)), 256, 0, st>>>(
+          reinterpret_cast<float* const*>(blob.d + (forward ? o_out : o_emb)),
+          reinterpret_cast<const uint64_t*>(blob.d + o_len));
+      HIP_OK(hipGetLastError());
+    }
   } else {
-    for (int32_t i = 0; i < n_emb; ++i)
-      if (emb_count[i] > 0)
-        HIP_OK(hipMemsetAsync(const_cast<float*>(embeddings[i]), 0, size_t(emb_count[i]) * 4, st));
+    if (forward) {  // SetZeroFunctor: rows without fids stay zero
+      for (int32_t i = 0; i < n_outputs; ++i)
+        if (output_len[i] > 0) HIP_OK(hipMemsetAsync(outputs[i], 0, size_t(output_len[i]) * 4, st));
+    } else {
+      for (int32_t i = 0; i < n_emb; ++i)
+        if (emb_count[i] > 0)
+          HIP_OK(hipMemsetAsync(const_cast<float*>(embeddings[i]), 0, size_t(emb_count[i]) * 4, st));
+    }
   }
   if (batch == 0 || n_slices == 0) return;
-  LayoutArgs A{};
-  for (int32_t i = 0; i < n_emb; ++i) {
-    A.emb[i] = embeddings[i];
-    A.emb_stride[i] = uint32_t(emb_stride[i]);
-    A.emb_count[i] = uint32_t(emb_count[i]);
+  if (!ext) {
+    for (int32_t i = 0; i < n_emb; ++i) {
+      A.emb[i] = embeddings[i];
+      A.emb_stride[i] = uint32_t(emb_stride[i]);
+      A.emb_count[i] = uint32_t(emb_count[i]);
+    }
+    for (int32_t i = 0; i < n_outputs; ++i) A.out[i] = outputs[i];
   }
-  for (int32_t i = 0; i < n_outputs; ++i) A.out[i] = outputs[i];
   A.fid_offset = fid_offset;
   A.feature_offset = feature_offset;
   A.nfl_offset = nfl_offset;
@@ -3178,16 +3234,26 @@ static void layout_launch(bool forward, const float* const* embeddings, const in
   A.batch = batch;
   A.n_emb = n_emb;
   int32_t k = 0;
+  bool addn_open = false;   // the previous launch ended inside an ADDN layout: its next slices add on
   while (k < n_slices) {
-    // one launch per kMaxLayoutTasks slices; an ADDN layout's slices stay together
+    // one launch per kMaxLayoutTasks slices.  An ADDN layout's slices are added in configuration
+    // order by one lane group; a layout with more slices than a launch holds continues in the next
+    // launch, which starts from the sums the previous one stored (same order, same roundings).
     int32_t nt = 0, nu = 0;
     while (k < n_slices) {
       int32_t span = 1;
       if (slices[k].out_type == 2)
         while (k + span < n_slices && slices[k + span].out_type == 2 &&
                slices[k + span].out_index == slices[k].out_index) ++span;
-      if (span > kMaxLayoutTasks) throw Error(MHTE_INVALID_ARGUMENT, "layout: an ADDN layout has too many slices");
-      if (nt + span > kMaxLayoutTasks) break;
+      const bool cont = addn_open;
+      if (span > kMaxLayoutTasks) {
+        if (nt > 0) break;             // (a long ADDN layout starts its own launch)
+        span = kMaxLayoutTasks;
+        addn_open = true;
+      } else {
+        if (nt + span > kMaxLayoutTasks) break;
+        addn_open = false;
+      }
       for (int32_t q = 0; q < span; ++q) {
         const mhte_layout_slice& sc = slices[k + q];
         if (sc.out_index < 0 || sc.out_index >= n_outputs || sc.dim <= 0 || sc.out_row_floats <= 0 ||
@@ -3211,7 +3277,7 @@ static void layout_launch(bool forward, const float* const* embeddings, const in
       }
       A.unit[nu].first = uint16_t(nt);
       A.unit[nu].count = uint16_t(span);
-      A.unit[nu].addn = slices[k].out_type == 2 ? 1 : 0;
+      A.unit[nu].addn = slices[k].out_type == 2 ? (cont ? 2 : 1) : 0;
       ++nu;
       nt += span;
       k += span;
@@ -3224,10 +3290,10 @@ static void layout_launch(bool forward, const float* const* embeddings, const in
     for (int32_t q = 0; fast && q < nt; ++q) {
       const LayoutTask& t = A.task[q];
       fast = t.pooling != kPoolFirstN && ((t.start | t.dim | t.out_offset | t.out_stride) & 3) == 0 &&
-             aligned16(A.out[t.out_index]);
+             aligned16(outputs[t.out_index]);
     }
     for (int32_t q = 0; fast && q < nu; ++q) fast = A.unit[q].count == 1;
-    for (int32_t i = 0; fast && i < n_emb; ++i) fast = (A.emb_stride[i] & 3u) == 0 && aligned16(A.emb[i]);
+    for (int32_t i = 0; fast && i < n_emb; ++i) fast = (emb_stride[i] & 3) == 0 && aligned16(embeddings[i]);
     if (fast) {
       if (forward) layout_copy_kernel<true><<<grid, 256, 0, st>>>(A);
       else layout_copy_kernel<false><<<grid, 256, 0, st>>>(A);

@@ -20,8 +20,9 @@
 namespace mhte {
 
 constexpr int kMaxLayoutTasks = 48;   // slices per launch (more: several launches)
-constexpr int kMaxLayoutEmb = 64;     // embedding matrices (shard x sub-table)
-constexpr int kMaxLayoutOut = 32;     // output tensors
+constexpr int kMaxLayoutEmb = 64;     // embedding matrices (shard x sub-table) carried in the kernel
+constexpr int kMaxLayoutOut = 32;     // arguments, output tensors likewise; more (the reference's own
+                                      // test has ~1000 and 153): pointer tables in device memory
 
 enum LayoutPooling : int32_t { kPoolSum = 0, kPoolMean = 1, kPoolFirstN = 3 };  // example.proto:176-180
 
@@ -36,7 +37,7 @@ struct LayoutTask {
 };
 struct LayoutUnit {
   uint16_t first, count; // tasks [first, first + count); count > 1 only for an ADDN layout
-  uint16_t addn, pad;
+  uint16_t addn, pad;    // addn: 1 an ADDN layout, 2 its continuation in a following launch
 };
 struct LayoutArgs {
   const float* emb[kMaxLayoutEmb];      // forward: embeddings; backward: gradient buffers (written)
@@ -47,10 +48,37 @@ struct LayoutArgs {
   const int32_t* feature_offset;
   const uint32_t* nfl_offset;
   int32_t n_fid, n_feature, n_nfl, batch, n_emb, n_units;
+  // when the model has more matrices / outputs than the inline arrays hold: the same four tables in
+  // device memory (x_emb != nullptr), uploaded by the host for the call
+  const float* const* x_emb;
+  const uint32_t* x_stride;
+  const uint32_t* x_count;
+  float* const* x_out;
   LayoutTask task[kMaxLayoutTasks];
   LayoutUnit unit[kMaxLayoutTasks];
 };
 static_assert(sizeof(LayoutArgs) <= 4096, "kernel arguments exceed 4 KB");
+
+__device__ __forceinline__ const float* layout_emb(const LayoutArgs& A, uint32_t i) {
+  return A.x_emb ? A.x_emb[i] : A.emb[i];
+}
+__device__ __forceinline__ uint32_t layout_stride(const LayoutArgs& A, uint32_t i) {
+  return A.x_emb ? A.x_stride[i] : A.emb_stride[i];
+}
+__device__ __forceinline__ uint32_t layout_count(const LayoutArgs& A, uint32_t i) {
+  return A.x_emb ? A.x_count[i] : A.emb_count[i];
+}
+__device__ __forceinline__ float* layout_out(const LayoutArgs& A, int32_t i) {
+  return A.x_emb ? A.x_out[i] : A.out[i];
+}
+
+// zero fill of a table of buffers (the op's SetZeroFunctor over every output / gradient buffer)
+__global__ __launch_bounds__(256) void layout_zero_kernel(float* const* buf, const uint64_t* len) {
+  float* p = buf[blockIdx.y];
+  const uint64_t n = len[blockIdx.y];
+  for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x)
+    p[i] = 0.f;
+}
 
 // GetFeatureInfo + the feature's fid range for batch row b (fused_embedding_to_layout.h:56-76,
 // :214-221); false: the named feature list is absent or the row has no fids
@@ -88,8 +116,8 @@ __global__ __launch_bounds__(256) void layout_copy_kernel(LayoutArgs A) {
   const unsigned long long fo = A.fid_offset[f0];
   const uint32_t i1 = uint32_t(fo >> 32), i2 = uint32_t(fo);
   if (i1 >= uint32_t(A.n_emb)) return;
-  float* orow = A.out[t.out_index] + int64_t(b) * t.out_stride + t.out_offset;
-  float* erow = const_cast<float*>(A.emb[i1]) + uint64_t(i2) * A.emb_stride[i1] + uint32_t(t.start);
+  float* orow = layout_out(A, t.out_index) + int64_t(b) * t.out_stride + t.out_offset;
+  float* erow = const_cast<float*>(layout_emb(A, i1)) + uint64_t(i2) * layout_stride(A, i1) + uint32_t(t.start);
   for (int32_t e = j * 4; e < t.dim; e += G * 4) {
     Vec<4> v;
     if (FORWARD) {
@@ -114,22 +142,27 @@ __global__ __launch_bounds__(256) void layout_kernel(LayoutArgs A) {
     const int32_t e = e0 + j;
     float acc = 0.f;
     bool any = false;
+    if (FORWARD && u.addn == 2 && e < A.task[u.first].dim) {   // continues the previous launch's sums
+      const LayoutTask t0 = A.task[u.first];
+      acc = layout_out(A, t0.out_index)[int64_t(b) * t0.out_stride + t0.out_offset + e];
+      any = true;
+    }
     for (uint32_t k = u.first; k < uint32_t(u.first) + u.count; ++k) {
       const LayoutTask t = A.task[k];
       int32_t f0 = 0, f1 = 0;
       if (e >= t.dim || !layout_fid_range(A, t.nfl_idx, b, &f0, &f1)) continue;
       const int32_t fid_num = f1 - f0;
-      float* orow = A.out[t.out_index] + int64_t(b) * t.out_stride + t.out_offset;
+      float* orow = layout_out(A, t.out_index) + int64_t(b) * t.out_stride + t.out_offset;
       float pooled = 0.f;
       int32_t seq = 0;
       for (int32_t q = f0; q < f1; ++q) {
         const unsigned long long fo = A.fid_offset[q];
         const uint32_t i1 = uint32_t(fo >> 32), i2 = uint32_t(fo);
         if (i1 >= uint32_t(A.n_emb)) continue;
-        const uint64_t at = uint64_t(i2) * A.emb_stride[i1] + uint32_t(t.start) + uint32_t(e);
-        if (at >= A.emb_count[i1]) continue;      // (CUSTOM_CHECK in the reference)
+        const uint64_t at = uint64_t(i2) * layout_stride(A, i1) + uint32_t(t.start) + uint32_t(e);
+        if (at >= layout_count(A, i1)) continue;      // (CUSTOM_CHECK in the reference)
         if (FORWARD) {
-          const float x = A.emb[i1][at];
+          const float x = layout_emb(A, i1)[at];
           if (t.pooling == kPoolFirstN) {
             if (seq < t.max_seq) orow[int64_t(seq) * t.dim + e] = x;
             ++seq;
@@ -139,7 +172,7 @@ __global__ __launch_bounds__(256) void layout_kernel(LayoutArgs A) {
             pooled = (q == f0) ? x : pooled + x;
           }
         } else {
-          float* dst = const_cast<float*>(A.emb[i1]) + at;
+          float* dst = const_cast<float*>(layout_emb(A, i1)) + at;
           if (t.pooling == kPoolFirstN) {
             if (seq < t.max_seq) atomicAdd(dst, orow[int64_t(seq) * t.dim + e]);
             ++seq;
@@ -161,7 +194,7 @@ __global__ __launch_bounds__(256) void layout_kernel(LayoutArgs A) {
     }
     if (FORWARD && u.addn && any) {
       const LayoutTask t = A.task[u.first];
-      A.out[t.out_index][int64_t(b) * t.out_stride + t.out_offset + e] = acc;
+      layout_out(A, t.out_index)[int64_t(b) * t.out_stride + t.out_offset + e] = acc;
     }
     // (all slices of a unit have its first slice's width; FIRSTN units are single slices)
   }
