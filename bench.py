@@ -45,6 +45,7 @@ def parse():
                       "batch ids per table and step, online insert + TTL eviction scans, all tables in "
                       "one launch pair per step (a measurement kept under profiles/, not the bench line)")
   p.add_argument("--tables", type=int, default=26, help="dlrm26: number of feature tables")
+  p.add_argument("--dims", default="16,32,64", help="dlrm26: table dims, cycled over the tables")
   p.add_argument("--steps-per-second", type=int, default=2000,
                  help="dlrm26: update_time (seconds) advances once per this many steps — a ~0.43 ms "
                       "step is ~2 300 steps per wall-clock second; 1 = a new second every step (the "
@@ -237,7 +238,8 @@ def main_dlrm(args):
   K, W = args.steps, args.warmup
   V = int(args.universe) // T                      # ids per feature
   resident = min(int(args.resident_rows) // T, V)  # prefilled rows per table
-  dims = [(16, 32, 64)[i % 3] for i in range(T)]
+  dcyc = [int(x) for x in args.dims.split(",")]
+  dims = [dcyc[i % len(dcyc)] for i in range(T)]
   names = ["f%02d" % (i + 1) for i in range(T)]    # sorted order == slot order
   reps = min(K, 50)
   n_steps = W + K + reps + 4

@@ -358,6 +358,16 @@ mhte_status mhte_hash_filter_create(uint64_t capacity, int32_t split_num, int32_
 mhte_status mhte_hash_filter_create_from_proto(uint64_t capacity, int32_t split_num,
                                                const void* config, int64_t config_len,
                                                int32_t device, mhte_hash_filter** out);
+/* MonolithProbabilisticFilter (RT/ops/hash_filter_op.cc:81-110, RT/hash_filter/probabilistic_filter.cc):
+ * no counts are kept — an id the table does not hold is admitted with probability count / threshold
+ * per consultation (equal_probability != 0: 1 - (1 - p)^count, p = 1 - 0.05^(1/threshold)); an id the
+ * table holds is never filtered.  The reference draws from a time-seeded thread-local xorshift, so
+ * parity is the admission rate; here a counter-based generator keyed by (seed, id, update launch,
+ * occurrence) — seed 0: taken from the clock.  config: serialized SlotOccurrenceThresholdConfig
+ * (may be NULL).  get returns 15, save / restore are no-ops (split_num() == 0), as in the reference. */
+mhte_status mhte_hash_filter_create_probabilistic(int32_t equal_probability, uint64_t seed,
+                                                  const void* config, int64_t config_len,
+                                                  int32_t device, mhte_hash_filter** out);
 void mhte_hash_filter_destroy(mhte_hash_filter* f);
 mhte_status mhte_multi_table_set_filter(mhte_multi_table* t, mhte_hash_filter* f /* NULL detaches */);
 /* Filter::estimated_total_element / failure_count / split_num (RT/hash_filter/filter.h:31-36):

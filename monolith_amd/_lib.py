@@ -120,7 +120,7 @@ EXPORTS = [
     "mhte_trace_begin", "mhte_trace_end", "mhte_step_dedup", "mhte_shard_partition",
     "mhte_step_scatter", "mhte_step_sum", "mhte_multi_table_save", "mhte_multi_table_restore", "mhte_table_save", "mhte_table_restore", "mhte_table_clear",
     "mhte_hash_filter_create", "mhte_hash_filter_destroy", "mhte_multi_table_set_filter",
-    "mhte_hash_filter_get", "mhte_hash_filter_stats", "mhte_fused_gather_embeddings_by_input",
+    "mhte_hash_filter_get", "mhte_hash_filter_stats", "mhte_hash_filter_create_probabilistic", "mhte_fused_gather_embeddings_by_input",
     "mhte_fused_gather_embeddings_by_input_gradient", "mhte_reduce_rows",
     "mhte_multi_step_create", "mhte_multi_step_destroy", "mhte_multi_step_forward",
     "mhte_multi_step_backward", "mhte_multi_step_unique_counts",

@@ -1869,6 +1869,7 @@ mhte_status mhte_hash_filter_stats(mhte_hash_filter* f, int64_t* out, int32_t ca
 mhte_status mhte_hash_filter_save(mhte_hash_filter* f, const char* basename, void* stream) {
   return guard([&] {
     if (!f || !basename || !*basename) throw Error(MHTE_INVALID_ARGUMENT, "filter save: bad arguments");
+    if (f->nsplit == 0) return;   // probabilistic: split_num() == 0, the save op writes no file
     HIP_OK(hipSetDevice(f->device));
     hipStream_t st = S(stream);
     FilterState hs;
@@ -1921,6 +1922,7 @@ mhte_status mhte_hash_filter_save(mhte_hash_filter* f, const char* basename, voi
 mhte_status mhte_hash_filter_restore(mhte_hash_filter* f, const char* basename, void* stream) {
   return guard([&] {
     if (!f || !basename || !*basename) throw Error(MHTE_INVALID_ARGUMENT, "filter restore: bad arguments");
+    if (f->nsplit == 0) return;   // probabilistic: stateless
     HIP_OK(hipSetDevice(f->device));
     hipStream_t st = S(stream);
     FilterState hs;
@@ -3356,6 +3358,43 @@ mhte_status mhte_hash_filter_create_from_proto(uint64_t capacity, int32_t split_
       *out = nullptr;
       throw Error(MHTE_INVALID_ARGUMENT, e.what());
     }
+  });
+}
+
+// MonolithProbabilisticFilter (ops/hash_filter_op.cc:81-110; probabilistic_filter.{h,cc}): no table
+// of counts — admission is a draw per consultation (csrc/mhte_kernels.h prob_consult)
+mhte_status mhte_hash_filter_create_probabilistic(int32_t equal_probability, uint64_t seed, const void* config,
+                                                  int64_t config_len, int32_t device, mhte_hash_filter** out) {
+  return guard([&] {
+    if (!out) throw Error(MHTE_INVALID_ARGUMENT, "null out");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+      throw Error(MHTE_UNAVAILABLE, "no such HIP device");
+    HIP_OK(hipSetDevice(device));
+    std::unique_ptr<mhte_hash_filter> f(new mhte_hash_filter);
+    f->device = device;
+    f->nsplit = 0;                                    // the marker of the probabilistic kind
+    f->total = equal_probability ? 1 : 0;
+    f->stride = 0;
+    HIP_OK(hipMalloc(&f->slots, 64 * sizeof(uint32_t)));   // (never read: "a filter is attached")
+    HIP_OK(hipMemset(f->slots, 0, 64 * sizeof(uint32_t)));
+    HIP_OK(hipMalloc(&f->state, sizeof(FilterState)));
+    FilterState hs;
+    memset(&hs, 0, sizeof(hs));
+    if (seed == 0)   // (the reference seeds with time(0), xorshift.h:29-31)
+      seed = uint64_t(std::chrono::steady_clock::now().time_since_epoch().count()) | 1ull;
+    hs.failure_count = seed;
+    HIP_OK(hipMemcpy(f->state, &hs, sizeof(hs), hipMemcpyHostToDevice));
+    if (config && config_len > 0) {
+      try {
+        pcfg::parse_occurrence(config, size_t(config_len), &f->occ_default, &f->occ_slots, &f->occ_thr);
+      } catch (const ckpt::ProtoError& e) {
+        throw Error(MHTE_INVALID_ARGUMENT, e.what());
+      }
+      f->has_occ = true;
+    }
+    HIP_OK(hipDeviceSynchronize());
+    *out = f.release();
   });
 }
 

@@ -274,9 +274,49 @@ __device__ __forceinline__ long long filter_find(uint32_t* split, uint64_t home,
 //          consults the filter; returns the first admitted index (later ones are admitted too, as
 //          the count only grows).
 // `contained`: the id is in the table already (modes 1, 2: filter untouched, everything admitted).
+// ProbabilisticFilter (runtime/hash_filter/probabilistic_filter.{h,cc}; op MonolithProbabilisticFilter,
+// ops/hash_filter_op.cc:81-110): stateless — an id that is NOT in the table is admitted with
+// probability count / threshold per consultation (:24-28: Rand32 * threshold < UINT32_MAX * count) or,
+// equal_probability, 1 - (1 - p)^count with p = 1 - 0.05^(1 / threshold) (:30-38); an id the table
+// holds is never filtered (:43).  The reference draws from a thread-local xorshift seeded with
+// time(0): there is no reproducible sequence to match, so the device draws from a counter-based
+// generator — fmix64 of (seed, id, launch number, occurrence) — and parity is the admission RATE.
+// A probabilistic filter is a view with flt_nsplit == 0: flt_total = 1 for equal_probability,
+// FilterState::failure_count holds the seed, head_increment the launch number.
+__device__ __forceinline__ uint32_t prob_rand32(const FilterState* fs, int64_t id, uint32_t occurrence) {
+  uint64_t h = fs->failure_count ^ (uint64_t(id) * 0x9E3779B97F4A7C15ull) ^
+               (uint64_t(fs->head_increment) << 32) ^ uint64_t(occurrence);
+  h ^= h >> 33;
+  h *= 0xff51afd7ed558ccdULL;
+  h ^= h >> 33;
+  h *= 0xc4ceb9fe1a85ec53ULL;
+  h ^= h >> 33;
+  return uint32_t(h >> 16);
+}
+__device__ __forceinline__ bool prob_admit(uint32_t r, uint32_t count, uint32_t thr, bool equal) {
+  if (!equal) return uint64_t(r) * uint64_t(thr) < uint64_t(0xffffffffu) * uint64_t(count);
+  const float p = 1.f - powf(0.05f, 1.f / float(thr));
+  return float(r) < float(0xffffffffu) * (1.f - powf(1.f - p, float(count)));
+}
+__device__ __forceinline__ uint32_t prob_consult(const TableView& tv, int64_t id, uint32_t k, int mode,
+                                                 bool contained, uint32_t thr) {
+  if (contained) return 0u;                          // `table && !table->Contains(fid)` (:43)
+  const FilterState* fs = reinterpret_cast<const FilterState*>(tv.flt_state);
+  const bool equal = tv.flt_total == 1;
+  if (mode == 2) return prob_admit(prob_rand32(fs, id, 0u), k, thr, equal) ? 0u : k;
+  // one draw per occurrence while the id is absent; the first admitted one inserts it
+  for (uint32_t i = 0; i < k; ++i)
+    if (prob_admit(prob_rand32(fs, id, i), 1u, thr, equal)) return i;
+  return k;
+}
+
 __device__ __forceinline__ uint32_t filter_consult(const TableView& tv, int64_t id, uint32_t k,
                                                    int mode, bool contained) {
   const int32_t thr_i = occurrence_threshold(tv, id);
+  if (tv.flt_nsplit == 0u) {                         // probabilistic: a threshold of 0 admits (0 < count)
+    if (k == 0) return 0u;
+    return prob_consult(tv, id, k, mode, contained, uint32_t(thr_i < 0 ? 0 : thr_i));
+  }
   if (thr_i <= 0 || k == 0) return 0u;              // ShouldBeFiltered: threshold <= 0 disables
   if (contained && mode != 3) return 0u;
   const uint32_t thr = uint32_t(thr_i);
@@ -359,6 +399,10 @@ __global__ __launch_bounds__(256) void filter_get_kernel(TableView tv, const int
   const uint32_t sign = filter_sign(id);
   const uint64_t home = filter_home(id, tv.flt_total);
   const FilterState* fs = reinterpret_cast<const FilterState*>(tv.flt_state);
+  if (tv.flt_nsplit == 0u) {                          // ProbabilisticFilter::get: max_count (:31-33)
+    out[i] = kFilterMaxCount;
+    return;
+  }
   const uint32_t S = tv.flt_nsplit, head = fs->head;
   long long pos = -1;
   uint32_t v = 0;
@@ -389,6 +433,10 @@ __global__ void filter_advance_kernel(TableView tv) {
   FilterState* fs = reinterpret_cast<FilterState*>(tv.flt_state);
   if (threadIdx.x != 0) return;
   fs->clear_req = 0;
+  if (tv.flt_nsplit == 0u) {     // probabilistic: a new launch number for the next update's draws
+    fs->head_increment += 1u;
+    return;
+  }
   if (filter_split_elements(*fs, fs->head) + 1u >= tv.flt_cap) {   // HashFilter::full(): >= capacity - 1
     fs->head = (fs->head + 1u) % tv.flt_nsplit;
     fs->head_increment += 1u;

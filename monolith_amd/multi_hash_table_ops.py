@@ -163,6 +163,23 @@ class HashFilter:
       pass
 
 
+class ProbabilisticFilter(HashFilter):
+  """hash_filter_ops.create_probabilistic_filter (MonolithProbabilisticFilter): stateless admission
+  with probability count / threshold (``equal_probability``: 1 - (1 - p)^count)."""
+
+  def __init__(self, equal_probability: bool = False, device: Optional[int] = None,
+               config: Optional[bytes] = None, seed: int = 0):  # pylint: disable=super-init-not-called
+    if not torch.cuda.is_available():
+      raise _lib.MhteError(_lib.MHTE_UNAVAILABLE, "ProbabilisticFilter needs a HIP device")
+    self._lib = _lib.lib()
+    self._device = torch.cuda.current_device() if device is None else int(device)
+    h = C.c_void_p()
+    check(self._lib.mhte_hash_filter_create_probabilistic(
+        C.c_int32(1 if equal_probability else 0), C.c_uint64(int(seed)), config,
+        C.c_int64(len(config) if config else 0), C.c_int32(self._device), C.byref(h)))
+    self._h = h
+
+
 class MultiHashTable:
   """The GPU-resident equivalent of the reference's ``MultiHashTable`` resource
   (runtime/ops/multi_hash_table.h:29-72): T embedding tables ordered by sorted name."""

@@ -363,6 +363,68 @@ def test_sliding_hash_filter_conflict_rate_kat():
   assert flt.failure_count() < len(counter) / 10000
 
 
+def _prob_table(flt, thr):
+  cfg = entry.make_table_config(
+      [entry.CombineAsSegment(1, entry.ZerosInitializer(), entry.SgdOptimizer(1.0))],
+      slot_occurrence_threshold_config=entry.SlotOccurrenceThresholdConfig(default_occurrence_threshold=thr))
+  return MultiHashTable.from_configs({"t": cfg}, name_suffix=_name(), hash_filter=flt)
+
+
+@pytest.mark.parametrize("equal", [False, True])
+def test_probabilistic_filter_admission_rate(equal):
+  """ProbabilisticFilter (probabilistic_filter.cc:24-52; the reference's RNG is seeded with the clock, so
+  its own tests check RATES at threshold 7: probabilistic_filter_test.cc:28-50 unequal, :52-76 equal,
+  :78-118 ShouldBeFiltered against a table): an absent id is admitted with probability
+  count / threshold per consultation — or 1 - 0.05^(count / threshold) — ids the table holds are never
+  filtered, a threshold of 0 admits everything, get() is max_count, the draws are a function of the
+  seed."""
+  from monolith_amd.multi_hash_table_ops import ProbabilisticFilter
+  thr, n = 7, 40000
+  flt = ProbabilisticFilter(equal_probability=equal, seed=1234)
+  mt = _prob_table(flt, thr)
+  rng = np.random.default_rng(5)
+  ids = np.unique(rng.integers(1, 2**40, n).astype(np.int64) | (1 << 48))
+  n = ids.size
+  g = torch.ones((n, 1), device="cuda")
+  p1 = (1.0 - 0.05 ** (1.0 / thr)) if equal else 1.0 / thr
+  mt.apply_gradients({"t": (ids_t(ids), g)})
+  in1 = mt.contains("t", ids_t(ids)).cpu().numpy().astype(bool)
+  assert abs(in1.mean() - p1) < 4 * np.sqrt(p1 * (1 - p1) / n), (in1.mean(), p1)
+  # a second sighting: the admitted ids are updated (never filtered), the others draw again
+  mt.apply_gradients({"t": (ids_t(ids), g)})
+  in2 = mt.contains("t", ids_t(ids)).cpu().numpy().astype(bool)
+  assert in2[in1].all()
+  p2 = 1 - (1 - p1) ** 2
+  assert abs(in2.mean() - p2) < 4 * np.sqrt(p2 * (1 - p2) / n), (in2.mean(), p2)
+  rows = mt.lookup({"t": ids_t(ids[in1][:100])})["t"].cpu().numpy()
+  np.testing.assert_array_equal(rows, np.full((min(100, int(in1.sum())), 1), -2.0, np.float32))   # two SGD steps of lr 1
+  assert (flt.get(ids_t(ids[:10])).cpu().numpy() == 15).all()
+  # k occurrences in one deduplicated update: one consultation with count k (tf_bridge.cc:300-310)
+  from monolith_amd.fused_step import SparseStep
+  flt3 = ProbabilisticFilter(equal_probability=equal, seed=99)
+  mt3 = _prob_table(flt3, thr)
+  fresh = np.unique(rng.integers(1, 2**40, 20000).astype(np.int64) | (2 << 48))
+  batch = np.repeat(fresh, 2)
+  step = SparseStep(mt3, "t", batch.size)
+  step.forward(ids_t(batch))
+  step.backward(torch.ones((batch.size, 1), device="cuda"), 1_700_000_000)
+  pk = (1.0 - 0.05 ** (2.0 / thr)) if equal else 2.0 / thr
+  got = mt3.contains("t", ids_t(fresh)).cpu().numpy().mean()
+  assert abs(got - pk) < 4 * np.sqrt(pk * (1 - pk) / fresh.size), (got, pk)
+  # same seed, same launches -> same draws; another seed -> another set
+  a, b, c = (ProbabilisticFilter(equal_probability=equal, seed=s_) for s_ in (7, 7, 8))
+  sets = []
+  for f in (a, b, c):
+    t = _prob_table(f, thr)
+    t.apply_gradients({"t": (ids_t(ids[:5000]), g[:5000])})
+    sets.append(t.contains("t", ids_t(ids[:5000])).cpu().numpy())
+  assert np.array_equal(sets[0], sets[1]) and not np.array_equal(sets[0], sets[2])
+  # threshold 0: everything is admitted
+  mt0 = _prob_table(ProbabilisticFilter(equal_probability=False, seed=3), 0)
+  mt0.apply_gradients({"t": (ids_t(ids[:1000]), g[:1000])})
+  assert mt0.contains("t", ids_t(ids[:1000])).cpu().numpy().all()
+
+
 # =============================================================================== fused_embedding_to_layout
 # The checkers live in oracle/layout.py: layout_model / layout_grad_model (the op's algorithm over
 # its own offset encoding) and the reference test's input generation + truth procedure
