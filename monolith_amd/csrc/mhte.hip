@@ -1681,6 +1681,52 @@ mhte_status mhte_table_dump(mhte_multi_table* t, int32_t table, int64_t cap, int
 // ---- post-exchange gather + pooling -------------------------------------------------------------
 extern "C++" {
 namespace mhte {
+// scratch of the deterministic (list-based) forms of the pooling ops: one per device, serialised
+struct AuxWs {
+  std::mutex mu;
+  DedupWs dd;
+  DevBuf<int64_t> keys, uids;
+  DevBuf<uint32_t> inverse, seg_off, seg_pos, nu;
+  static AuxWs& of(int device) {
+    static std::mutex m;
+    static std::map<int, std::unique_ptr<AuxWs>> all;
+    std::lock_guard<std::mutex> g(m);
+    auto& p = all[device];
+    if (!p) {
+      p.reset(new AuxWs);
+      p->dd.device = device;
+    }
+    return *p;
+  }
+  // the scratch is reused by the next call in stream order; a call on ANOTHER stream first waits for
+  // the launches of the previous one
+  hipStream_t last = nullptr;
+  bool used = false;
+  void enter(hipStream_t st) {
+    if (used && last != st) HIP_OK(hipStreamSynchronize(last));
+    last = st;
+    used = true;
+  }
+  // distinct keys + their positions in ascending order -> uids / seg_off / seg_pos / nu
+  void group(const int64_t* k, int64_t n, hipStream_t st) {
+    uids.reserve(size_t(n) + 1);
+    inverse.reserve(size_t(n) + 1);
+    seg_off.reserve(size_t(n) + 2);
+    seg_pos.reserve(size_t(n) + 1);
+    nu.reserve(4);
+    dd.unique(k, n, uids.p, inverse.p, seg_off.p, seg_pos.p, nu.p, st);
+  }
+};
+static bool pool_atomics() {   // MHTE_POOL_ATOMICS=1: the float-atomic forms (A/B runs)
+  static const bool on = getenv("MHTE_POOL_ATOMICS") != nullptr && atoi(getenv("MHTE_POOL_ATOMICS")) != 0;
+  return on;
+}
+static int current_device() {
+  int d = 0;
+  HIP_OK(hipGetDevice(&d));
+  return d;
+}
+
 template <bool GATHER>
 static void fused_gather(float* fused, int32_t n_inputs, const int32_t* const* offsets,
                          const int64_t* n, const int32_t* dims, float* const* rows, float scale,
@@ -1704,6 +1750,19 @@ static void fused_gather(float* fused, int32_t n_inputs, const int32_t* const* o
     for (int32_t k = 0; k < in.n_inputs; ++k)
       if (!aligned16(in.rows[k])) in.aligned = 0;
     if (acc == 0) continue;
+    if (!GATHER && !pool_atomics()) {
+      // the gradient without atomics: rows that share an offset are grouped and added in row order
+      AuxWs& ws = AuxWs::of(current_device());
+      std::lock_guard<std::mutex> g(ws.mu);
+      ws.enter(st);
+      ws.keys.reserve(size_t(acc));
+      gather_keys_kernel<<<dim3(uint32_t((acc + 255) / 256)), 256, 0, st>>>(in, ws.keys.p);
+      ws.group(ws.keys.p, acc, st);
+      gather_grad_lists_kernel<<<dim3(uint32_t((acc * 8 + 255) / 256)), 256, 0, st>>>(
+          fused, in, scale, ws.uids.p, ws.nu.p, ws.seg_off.p, ws.seg_pos.p);
+      HIP_OK(hipGetLastError());
+      continue;
+    }
     const dim3 grid(uint32_t((acc * 8 + 255) / 256));
     fused_gather_kernel<GATHER><<<grid, 256, 0, st>>>(fused, in, scale);
     HIP_OK(hipGetLastError());
@@ -1750,6 +1809,26 @@ mhte_status mhte_reduce_rows(const int64_t* indices, const float* values, int64_
         reduce_rows_sorted_kernel<4><<<grid, 256, 0, st>>>(indices, values, n, dim, batch, mode, out);
       else
         reduce_rows_sorted_kernel<1><<<grid, 256, 0, st>>>(indices, values, n, dim, batch, mode, out);
+    } else if (!pool_atomics()) {
+      // indices in any order, no atomics: rows of one output are grouped and added in index order —
+      // the reference's sequential loop, bit for bit.  An output no index names is 0 (sum, square
+      // norm) or 0 * (1 / 0) = NaN (mean), as there.
+      if (mode == 1) HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out), 0x7fc00000, size_t(batch) * dim, st));
+      else HIP_OK(hipMemsetAsync(out, 0, size_t(batch) * dim * sizeof(float), st));
+      if (n) {
+        AuxWs& ws = AuxWs::of(current_device());
+        std::lock_guard<std::mutex> g(ws.mu);
+        ws.enter(st);
+        ws.group(indices, n, st);
+        const dim3 grid(uint32_t((n * 16 + 255) / 256));
+        if (dim % 4 == 0 && aligned16(values) && aligned16(out))
+          reduce_rows_lists_kernel<4><<<grid, 256, 0, st>>>(ws.uids.p, ws.nu.p, ws.seg_off.p, ws.seg_pos.p, values,
+                                                            dim, batch, mode, out);
+        else
+          reduce_rows_lists_kernel<1><<<grid, 256, 0, st>>>(ws.uids.p, ws.nu.p, ws.seg_off.p, ws.seg_pos.p, values,
+                                                            dim, batch, mode, out);
+        HIP_OK(hipGetLastError());
+      }
     } else {
       HIP_OK(hipMemsetAsync(out, 0, size_t(batch) * dim * sizeof(float), st));
       uint32_t* cnt = nullptr;
@@ -2868,7 +2947,6 @@ mhte_status mhte_table_sum_optimize_n(mhte_multi_table* t, int32_t table, mhte_d
                                       float* grad_unique, const float* learning_rate,
                                       int64_t n_learning_rate, int64_t update_time,
                                       int64_t global_step, int32_t flags, void* stream) {
-  (void)global_step;
   return guard([&] {
     Table& tb = table_at(t, table);
     if (!ws) throw Error(MHTE_INVALID_ARGUMENT, "null workspace");
@@ -2880,6 +2958,26 @@ mhte_status mhte_table_sum_optimize_n(mhte_multi_table* t, int32_t table, mhte_d
     std::lock_guard<std::mutex> g(tb.mu);
     tb.note_update_time(update_time);
     hipStream_t st = S(stream);
+    if (tb.flt_slots) {
+      // an occurrence filter is attached: the admission decision needs every id's occurrence COUNT
+      // (one consultation with count k, tf_bridge.cc:300-310) — the update kernel that walks the
+      // occurrence lists, sums them in order and consults the filter (sum_apply_kernel does not)
+      if (list_end != list_start + 1)
+        throw Error(MHTE_INVALID_ARGUMENT, "a table with an occurrence filter needs the ordered mhte_unique "
+                                           "(CSR occurrence lists)");
+      tb.finish_pending(st);
+      if (n <= 0 || n_max <= 0) return;
+      ApplyArgs a;
+      for (int i = 0; i < kMaxSegments; ++i) a.lr[i] = i < int(tb.nseg) ? learning_rate[i] : 0.f;
+      a.ts = static_cast<uint32_t>(update_time);
+      a.sum_dups = 1;
+      a.filter_mode = 1;
+      a.global_step = global_step;
+      tb.ensure_capacity(uint64_t(n_max), st);
+      tb.launch_upsert<kOpOptimize>(unique_ids, n_max, n_unique_dev, grads, list_start, seg_pos, a, nullptr, st);
+      tb.maybe_evict(st);
+      return;
+    }
     if (tb.fusable()) {
       tb.sum_optimize(ws->ws, unique_ids, n_max, n_unique_dev, grads, list_start, list_end,
                       seg_pos, n, grad_unique, learning_rate, update_time,

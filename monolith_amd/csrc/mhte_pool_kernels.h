@@ -150,5 +150,99 @@ __global__ __launch_bounds__(256) void reduce_rows_finish_kernel(float* __restri
   if (mode == 2) out[t] = sqrtf(out[t]);
 }
 
+// ---- deterministic forms (no float atomics): the rows that share a destination are found with the
+// list-building dedup (DedupWs::unique: distinct keys in first-occurrence order, each key's positions
+// in ascending order) and ONE lane group per destination adds them in position order — for the
+// reductions that is the reference's sequential loop (reduce_op.cc:46-49,77-81,110-116), bit for bit,
+// for indices in any order.
+template <int VEC>
+__global__ __launch_bounds__(256) void reduce_rows_lists_kernel(const int64_t* __restrict__ keys,
+                                                                const uint32_t* __restrict__ n_keys,
+                                                                const uint32_t* __restrict__ seg_off,
+                                                                const uint32_t* __restrict__ seg_pos,
+                                                                const float* __restrict__ values,
+                                                                int32_t dim, int64_t batch, int32_t mode,
+                                                                float* __restrict__ out) {
+  constexpr int G = 16;
+  const int j = threadIdx.x & (G - 1);
+  const int64_t u = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  if (u >= int64_t(*n_keys)) return;
+  const int64_t b = keys[u];
+  if (b < 0 || b >= batch) return;
+  const uint32_t s0 = seg_off[u], s1 = seg_off[u + 1];
+  const float mult = 1.0f / static_cast<float>(s1 - s0);
+  for (int k = j * VEC; k < dim; k += G * VEC) {
+    Vec<VEC> acc;
+    vec_zero(acc);
+    for (uint32_t i = s0; i < s1; i += 4) {   // 4 rows in flight, added in order
+      Vec<VEC> v[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) vec_zero(v[t]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (i + t < s1) v[t].load(values + int64_t(seg_pos[i + t]) * dim + k);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (i + t < s1) {
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) {
+            const float x = v[t].v[c];
+            acc.v[c] = acc.v[c] + (mode == 2 ? x * x : x);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      if (mode == 1) acc.v[c] = acc.v[c] * mult;
+      if (mode == 2) acc.v[c] = sqrtf(acc.v[c]);
+    }
+    acc.store(out + b * int64_t(dim) + k);
+  }
+}
+
+// gradient of FusedGatherEmbeddingsByInput without atomics: key of global row r = its float offset
+__global__ __launch_bounds__(256) void gather_keys_kernel(GatherInputs in, int64_t* __restrict__ keys) {
+  const int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= in.start[in.n_inputs]) return;
+  int i = 0;
+  while (in.start[i + 1] <= r) ++i;
+  keys[r] = in.offsets[i][r - in.start[i]];
+}
+// one lane group per distinct offset: its rows (of whichever inputs) added in row order, scaled as the
+// reference scales every addend (map_id_to_embedding.cu.cc:98-107), then added to fused_grad (plain
+// read-modify-write: one group owns the destination; launches of further input chunks follow in
+// stream order)
+__global__ __launch_bounds__(256) void gather_grad_lists_kernel(float* __restrict__ fused, GatherInputs in,
+                                                                float scale,
+                                                                const int64_t* __restrict__ keys,
+                                                                const uint32_t* __restrict__ n_keys,
+                                                                const uint32_t* __restrict__ seg_off,
+                                                                const uint32_t* __restrict__ seg_pos) {
+  constexpr int G = 8;
+  const int j = threadIdx.x & (G - 1);
+  const int64_t u = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  if (u >= int64_t(*n_keys)) return;
+  const int64_t off = keys[u];
+  const uint32_t s0 = seg_off[u], s1 = seg_off[u + 1];
+  int32_t dim = 0;
+  {
+    const int64_t r = seg_pos[s0];
+    int i = 0;
+    while (in.start[i + 1] <= r) ++i;
+    dim = in.dim[i];
+  }
+  for (int k = j; k < dim; k += G) {
+    float acc = 0.f;
+    for (uint32_t q = s0; q < s1; ++q) {
+      const int64_t r = seg_pos[q];
+      int i = 0;
+      while (in.start[i + 1] <= r) ++i;
+      if (k < in.dim[i]) acc += in.rows[i][(r - in.start[i]) * in.dim[i] + k] * scale;
+    }
+    fused[off + k] += acc;
+  }
+}
+
 }  // namespace mhte
 #endif  // MHTE_POOL_KERNELS_H_

@@ -59,6 +59,10 @@ class SparseStep:
     self.fusable = bool(table._lib.mhte_table_fused_backward_ok(table.handle, self.idx))  # pylint: disable=protected-access
     if not self.fusable:
       self.ordered_unique = True  # wide rows: segment sum + optimize on CSR lists
+    # an occurrence filter: the UNPIPELINED update walks CSR occurrence lists (the admission decision
+    # needs each id's count), so its dedup is the ordered one; the pipelined step consults the filter
+    # itself and keeps its run dedup
+    self._plain_ordered = self.ordered_unique or getattr(table, "_hash_filter", None) is not None
     self.batch = batch
     self.exact_order = exact_order
     dev = torch.device("cuda:%d" % table._device)  # pylint: disable=protected-access
@@ -72,7 +76,7 @@ class SparseStep:
                             torch.empty(n + 1, dtype=torch.int32, device=dev),
                             torch.empty(n, dtype=torch.int32, device=dev),
                             torch.zeros(1, dtype=torch.int32, device=dev), None,
-                            None if self.ordered_unique else
+                            None if self._plain_ordered else
                             torch.empty(n + 1, dtype=torch.int32, device=dev))
     # pipelined path: two slots — the batch being trained and the batch deduplicated ahead of it
     self._ws = [DedupWorkspace(dev.index), DedupWorkspace(dev.index)]
@@ -100,7 +104,7 @@ class SparseStep:
     return self._u0
 
   def _unique(self, ids):
-    if self.ordered_unique:
+    if self._plain_ordered:
       self._ws0.unique(ids, want_host_count=False, out=self._u0)
     else:
       self._ws0.unique_unordered(ids, want_host_count=False, out=self._u0)

@@ -204,7 +204,7 @@ def bench_gather():
        2 * 4 * total + 4 * n_inputs * rows_each)
   grads = [torch.randn((rows_each, d), dtype=torch.float32, device=DEV) for d in dims]
   t = gpu_time(lambda: D.fused_gather_embeddings_by_input_gradient(total, grads, offs, dims))
-  emit("fused_gather_embeddings_by_input_gradient (same shapes; zero-fill + float atomics)", t,
+  emit("fused_gather_embeddings_by_input_gradient (same shapes; zero-fill + grouped in-order sums; MHTE_POOL_ATOMICS=1: float atomics)", t,
        3 * 4 * total + 4 * n_inputs * rows_each)
 
 
@@ -222,7 +222,7 @@ def bench_reduce():
   perm = torch.randperm(n, device=DEV)
   idx_u, vals_u = idx_t[perm].contiguous(), vals[perm].contiguous()
   t = gpu_time(lambda: D.reduce_sum(idx_u, vals_u, batch, indices_sorted=False))
-  emit("reduce_sum, unsorted indices (float atomics)", t, alg + batch * dim * 4)
+  emit("reduce_sum, unsorted indices (grouped in-order sums; MHTE_POOL_ATOMICS=1: float atomics)", t, alg + batch * dim * 4)
 
 
 def bench_optimizers():

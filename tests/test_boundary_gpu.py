@@ -363,6 +363,29 @@ def test_sliding_hash_filter_conflict_rate_kat():
   assert flt.failure_count() < len(counter) / 10000
 
 
+def test_unpipelined_fused_backward_consults_the_filter():
+  """mhte_table_sum_optimize_n (SparseStep without a next batch) on a table with an occurrence
+  filter: the update must ask the filter with each id's occurrence count (tf_bridge.cc:300-310:
+  ShouldBeFiltered(id, count) = add(id, count) < threshold, add returning the count BEFORE it) — round 2's
+  sum_apply_kernel path updated such a table without asking."""
+  from monolith_amd.fused_step import SparseStep
+  flt = HashFilter(capacity=100000, split_num=5)
+  mt = _filter_table(flt, 3)
+  ids = np.unique(np.random.default_rng(2).integers(1, 2**40, 3000).astype(np.int64) | (1 << 48))
+  batch = np.repeat(ids, 2)                       # every id twice per batch
+  step = SparseStep(mt, "t", batch.size)
+  g = torch.ones((batch.size, 1), device="cuda")
+  seen_before = [0, 2, 4]
+  for k, before in enumerate(seen_before):
+    step.forward(ids_t(batch))
+    step.backward(g, 1_700_000_000 + k)
+    present = mt.contains("t", ids_t(ids)).cpu().numpy().astype(bool)
+    assert present.all() == (before >= 3) and present.any() == (before >= 3), (k, present.mean())
+  assert (flt.get(ids_t(ids)).cpu().numpy() == 6).all()      # three consultations of count 2; admitted ids are no longer counted
+  rows = mt.lookup({"t": ids_t(ids[:50])})["t"].cpu().numpy()
+  np.testing.assert_array_equal(rows, np.full((50, 1), -2.0, np.float32))   # one update: 2 gradients of 1, lr 1
+
+
 def _prob_table(flt, thr):
   cfg = entry.make_table_config(
       [entry.CombineAsSegment(1, entry.ZerosInitializer(), entry.SgdOptimizer(1.0))],

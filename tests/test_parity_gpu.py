@@ -907,8 +907,8 @@ def test_fused_gather_embeddings_by_input_golden():
 @pytest.mark.parametrize("sorted_", [True, False])
 def test_reduce_sum_mean_sqrtn(sorted_):
   """distribution_ops_test.py:306-352 goldens, then a ragged batch against the reference's
-  sequential accumulation (reduce_op.cc:29-125): bit-exact with sorted indices, 1e-6 with the
-  atomic path."""
+  sequential accumulation (reduce_op.cc:29-125): bit-exact for sorted indices AND for indices in
+  any order (rows of one output are grouped and added in index order: no atomics)."""
   idx = torch.tensor([[0], [0], [1]], dtype=torch.int64).cuda()
   np.testing.assert_array_equal(
       D.reduce_mean(idx, val_t([[4, 4], [2, 2], [1, 1]]), [2], sorted_).cpu().numpy(), [[3, 3], [1, 1]])
@@ -937,10 +937,39 @@ def test_reduce_sum_mean_sqrtn(sorted_):
       if mode == 2:
         exp = np.sqrt(exp)
     got = fn(torch.from_numpy(ind[:, None]).cuda(), val_t(vals), [batch], sorted_).cpu().numpy()
-    if sorted_:
-      np.testing.assert_array_equal(got, exp)        # incl. the NaN row of an empty mean
-    else:
-      np.testing.assert_allclose(got, exp, rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(got, exp)          # incl. the NaN row of an empty mean
+
+
+def test_fused_gather_gradient_is_sequential_and_repeatable():
+  """The gradient of FusedGatherEmbeddingsByInput without float atomics: rows that share an offset are
+  added in row order (each scaled first, map_id_to_embedding.cu.cc:98-107) — equal to a sequential
+  fp32 loop bit for bit, and the same bits on every run (the reference's GpuAtomicAdd adds in arrival
+  order)."""
+  rng = np.random.default_rng(21)
+  dims, n_rows = [8, 16, 4], [30000, 20000, 5000]
+  slots = [400, 300, 50]                     # distinct rows per input: heavy duplication
+  base, offs_h, grads_h = 0, [], []
+  for d, n, k in zip(dims, n_rows, slots):
+    offs_h.append((base + rng.integers(0, k, n) * d).astype(np.int32))
+    grads_h.append(rng.standard_normal((n, d)).astype(np.float32))
+    base += k * d
+  exp = np.zeros(base, np.float32)
+  sc = np.float32(0.37)
+  for o, g, d in zip(offs_h, grads_h, dims):
+    acc = {}
+    for j in range(o.size):
+      a = acc.get(int(o[j]))
+      t = g[j] * sc
+      acc[int(o[j])] = t if a is None else a + t
+    for off, v in acc.items():
+      exp[off:off + d] = np.float32(0) + v
+  offs = [torch.from_numpy(o).cuda() for o in offs_h]
+  grads = [val_t(g) for g in grads_h]
+  outs = [D.fused_gather_embeddings_by_input_gradient(base, grads, offs, dims, scale=float(sc)).cpu().numpy()
+          for _ in range(3)]
+  # (a sum starts from 0: 0 + first addend)
+  np.testing.assert_array_equal(outs[0], exp)
+  assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
 # =============================================================================== admission + eviction
