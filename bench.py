@@ -62,6 +62,12 @@ def parse():
                       "SGD, layout gradient -> sparse update; the next batch's dedup runs on a side "
                       "stream beside the GEMMs")
   p.add_argument("--mlp", default="1024,512,256", help="hidden widths of the dense model")
+  p.add_argument("--mlp-split", type=int, default=32,
+                 help="dense model: weight gradients as a batched GEMM over this many slices of the "
+                      "batch (0: torch.nn.Linear under autocast, one GEMM per gradient)")
+  p.add_argument("--overlap", action="store_true",
+                 help="sharded step: the next batch's dedup / numbering / id dispatch on the step's own "
+                      "stream beside the dense leg (mhte_shard_step_set_overlap)")
   p.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"])
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--cpu-steps", type=int, default=150)
@@ -303,7 +309,10 @@ def main_dlrm(args):
   if sharded:
     # every table through the id-sharded step with one rank: the floor of the multi-GPU step
     from monolith_amd.distributed_ps_sync import ShardedMultiStep
-    step = ShardedMultiStep(mt, B, ids_per_peer_table=args.ids_per_peer)
+    step = ShardedMultiStep(mt, B, ids_per_peer_table=args.ids_per_peer,
+                            transport="ipc" if args.transport == "ipc" else "auto")
+    if args.overlap:
+      step.set_overlap(True)
   else:
     step = MultiSparseStep(mt, B, exact_order=args.exact_order)
   applied = []
@@ -329,10 +338,59 @@ def main_dlrm(args):
     fe = torch.arange(T * B, dtype=torch.int32, device=dev)
     nf = (torch.arange(T, dtype=torch.int32, device=dev) * B)
     widths = [kin] + [int(w) for w in args.mlp.split(",")] + [1]
-    layers = []
-    for a, b_ in zip(widths[:-1], widths[1:]):
-      layers += [torch.nn.Linear(a, b_), torch.nn.ReLU()]
-    mlp = torch.nn.Sequential(*layers[:-1]).to(dev)
+
+    class SplitKLinearFn(torch.autograd.Function):
+      """y = x w^T + b in bf16 on MFMA (hipBLASLt through torch).  The weight gradient dW = dy^T x has a
+      small output (out x in) and a 65 536-long reduction: as ONE GEMM hipBLASLt launches 25-97
+      workgroups on 256 CUs (rocprofv3: 248-357 us per layer, 0.15 of the bf16 peak).  Split along the
+      batch into `split` partial products (a batched GEMM: split x (out/256) x (in/256) tiles) and
+      summed in fp32, the same arithmetic fills the chip."""
+
+      @staticmethod
+      def forward(ctx, x, w, b, split):
+        ctx.save_for_backward(x, w)
+        ctx.split = split
+        return torch.addmm(b, x, w.t())
+
+      @staticmethod
+      def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ w
+        M, S = x.shape[0], ctx.split
+        if S > 1 and M % S == 0:
+          dw = torch.bmm(dy.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1)).float().sum(0)
+        else:
+          dw = (dy.t() @ x).float()
+        return dx, dw, dy.float().sum(0), None
+
+    class Mlp(torch.nn.Module):
+      def __init__(self, split):
+        super().__init__()
+        self.split = split
+        self.w = torch.nn.ParameterList()
+        self.b = torch.nn.ParameterList()
+        for a, b_ in zip(widths[:-1], widths[1:]):
+          lin = torch.nn.Linear(a, b_)
+          self.w.append(lin.weight)
+          self.b.append(lin.bias)
+
+      def forward(self, x):
+        h = x.to(torch.bfloat16)
+        for i, (w, b) in enumerate(zip(self.w, self.b)):
+          h = SplitKLinearFn.apply(h, w.to(torch.bfloat16), b.to(torch.bfloat16),
+                                   self.split if w.shape[0] > 1 else 1)
+          if i + 1 < len(self.w):
+            h = torch.relu(h)
+        return h
+
+    if args.mlp_split > 0:
+      mlp = Mlp(args.mlp_split).to(dev)
+    else:
+      layers = []
+      for a, b_ in zip(widths[:-1], widths[1:]):
+        layers += [torch.nn.Linear(a, b_), torch.nn.ReLU()]
+      mlp = torch.nn.Sequential(*layers[:-1]).to(dev)
     opt = torch.optim.SGD(mlp.parameters(), lr=1e-3)
     eoff = np.concatenate([[0], np.cumsum([B * d for d in dims])])
     dense = {"flops_per_step": 6 * B * sum(a * b_ for a, b_ in zip(widths[:-1], widths[1:])), "widths": widths}
@@ -341,8 +399,11 @@ def main_dlrm(args):
     gviews = [gflat[eoff[i]:eoff[i + 1]].view(B, dims[i]) for i in range(T)]
 
     def mlp_step(x):
-      with torch.autocast("cuda", dtype=torch.bfloat16):
+      if args.mlp_split > 0:
         y = mlp(x)
+      else:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+          y = mlp(x)
       loss = y.float().mean()
       opt.zero_grad(set_to_none=True)
       loss.backward()
@@ -543,6 +604,8 @@ def main_dlrm(args):
           "gradient_bytes_rotated": int(NG * gsz * 4), "prefill_s": round(prefill_s, 2),
           "update_time": "one second per %d steps" % sps,
           "launch": "eager",
+          "overlap": bool(args.overlap and sharded),
+          "shard_step": step.info() if sharded else None,
       },
       "roofline": roofline, "stages": stages, "cpu_baseline": cpu, "parity_check": parity,
       "dense": dense,

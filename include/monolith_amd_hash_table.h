@@ -655,6 +655,15 @@ mhte_status mhte_shard_step_forward(mhte_shard_step* s, const int64_t* id, const
 mhte_status mhte_shard_step_backward(mhte_shard_step* s, const float* value, int64_t value_len,
                                      const float* learning_rate, int64_t n_learning_rate,
                                      int64_t update_time, int64_t global_step, void* stream);
+/* mode 1 (or MHTE_SHARD_OVERLAP=1 at creation): what the NEXT batch needs and the tables do not — its
+ * run dedup, the numbering + owner packing of its distinct ids, the id exchange (peer-store
+ * transport) — is enqueued by mhte_shard_step_forward on a stream of the step's own and runs beside
+ * whatever the caller enqueues between forward and backward (layout -> dense model -> layout
+ * gradient); backward then carries the gradient sums only.  Results are the same as mode 0 (nothing
+ * stale is read: the reference pipelines the same stages with its prefetch queues,
+ * NT/distributed_ps_sync.py:199-203,270-275).  The caller's next-batch ids must stay valid until the
+ * following forward call. */
+mhte_status mhte_shard_step_set_overlap(mhte_shard_step* s, int32_t mode);
 /* waits for the stream, then reports a block overflow of the steps enqueued so far */
 mhte_status mhte_shard_step_check(mhte_shard_step* s, void* stream);
 /* distinct ids per table of this rank's forward batch (host int64[T]); synchronises */

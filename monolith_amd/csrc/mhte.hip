@@ -3853,11 +3853,22 @@ mhte_status mhte_shard_step_backward(mhte_shard_step* s, const float* value, int
   });
 }
 
+mhte_status mhte_shard_step_set_overlap(mhte_shard_step* s, int32_t mode) {
+  return guard([&] {
+    if (!s) throw Error(MHTE_INVALID_ARGUMENT, "null shard step");
+    HIP_OK(hipSetDevice(s->ss.device));
+    auto locks = lock_tables(&s, 1);
+    if (s->ss.aux_pending) HIP_OK(hipStreamSynchronize(s->ss.aux));
+    s->ss.set_overlap(mode);
+  });
+}
+
 mhte_status mhte_shard_step_check(mhte_shard_step* s, void* stream) {
   return guard([&] {
     if (!s) throw Error(MHTE_INVALID_ARGUMENT, "null shard step");
     HIP_OK(hipSetDevice(s->ss.device));
     HIP_OK(hipStreamSynchronize(mhte::S(stream)));
+    if (s->ss.aux) HIP_OK(hipStreamSynchronize(s->ss.aux));
     s->ss.check_flags();
   });
 }

@@ -134,7 +134,19 @@ struct ShardStep {
   size_t win_bytes = 0;
   size_t win_off_ids[2] = {0, 0}, win_off_rows = 0, win_off_grads = 0;
   char* peer_win[kMaxShards] = {};      // every rank's window as mapped in this process
-  uint32_t sig_pending = 0;             // channels pushed since the last sync launch (bit per channel)
+  uint32_t sig_pending[2] = {0, 0};     // channels pushed since the last sync launch (bit per channel),
+                                        // per stream: [0] the caller's, [1] the step's own (overlap)
+  // ---- overlap with the dense model (MHTE_SHARD_OVERLAP=1 / mhte_shard_step_set_overlap): what the
+  // next batch needs and the tables do not — its run dedup, the numbering + owner packing of its
+  // distinct ids, the id exchange — runs on a stream of the step's own, beside whatever the caller
+  // enqueues between forward and backward (layout -> MLP -> layout gradient); the backward launch
+  // then carries the gradient sums only.  The reference pipelines the same stages with its
+  // prefetch queues (NT/distributed_ps_sync.py:199-203, 270-275).
+  int overlap = 0;
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_in = nullptr, ev_aux = nullptr;
+  bool aux_pending = false;             // work on `aux` the caller's stream has not waited for yet
+  bool ids_exchanged[2] = {false, false};   // the slot's id blocks have been exchanged
   uint32_t seq_sent[kIpcChannels] = {};               // exchanges pushed per channel
   uint32_t seq_waited[kIpcChannels][kMaxShards] = {}; // ... and waited for, per peer
   uint64_t timeout_ticks = 0;
@@ -143,6 +155,9 @@ struct ShardStep {
     (void)hipSetDevice(device);
     (void)hipDeviceSynchronize();
     if (comm) (void)Rccl::get().CommDestroy(comm);
+    if (aux) (void)hipStreamDestroy(aux);
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_aux) (void)hipEventDestroy(ev_aux);
     for (int p = 0; p < world && p < kMaxShards; ++p)
       if (peer_win[p] && p != rank) (void)hipIpcCloseMemHandle(peer_win[p]);
     for (int s = 0; s < 2; ++s) {
@@ -251,6 +266,7 @@ struct ShardStep {
         memset(h_cnt[s], 0, size_t(2) * world * hdr * sizeof(int64_t));
         HIP_OK(hipEventCreateWithFlags(&ev_cnt[s], hipEventDisableTiming));
       }
+    if (const char* e = getenv("MHTE_SHARD_OVERLAP")) set_overlap(atoi(e));
     if (unique_id) {
       Rccl& R = Rccl::get();
       ncclUniqueId id;
@@ -261,6 +277,45 @@ struct ShardStep {
   }
 
   bool local_group_member() const { return world > 1 && comm == nullptr && !ipc; }
+
+  void set_overlap(int mode) {
+    overlap = mode != 0 ? 1 : 0;
+    if (overlap && !aux) {
+      // (lowest priority: the dense model's GEMMs on the caller's stream go first where both want a CU)
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      if (hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, least) != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_OK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+      }
+      HIP_OK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&ev_aux, hipEventDisableTiming));
+    }
+  }
+  // the caller's stream waits for what was enqueued on the step's own
+  void join_aux(hipStream_t st) {
+    if (!aux_pending) return;
+    HIP_OK(hipStreamWaitEvent(st, ev_aux, 0));
+    aux_pending = false;
+  }
+  // the next batch on the step's own stream: dedup, numbering + packing, id exchange where the
+  // transport allows it there (peer stores; RCCL keeps one stream per communicator)
+  void prepare_next_on_aux(const int64_t* ids, const int64_t* split, int slot, hipStream_t st) {
+    HIP_OK(hipEventRecord(ev_in, st));       // the ids are ready, the slot's last users are done
+    HIP_OK(hipStreamWaitEvent(aux, ev_in, 0));
+    dedup(ids, split, slot, aux);
+    build_and_sum(slot, -1, nullptr, aux);
+    ids_exchanged[slot] = false;
+    if (alias) {
+      ids_exchanged[slot] = true;
+    } else if (ipc) {
+      exchange_ipc(kXIds, slot, aux);
+      flush_signals(aux);
+      ids_exchanged[slot] = true;
+    }
+    HIP_OK(hipEventRecord(ev_aux, aux));
+    aux_pending = true;
+  }
 
   // ---- peer-store transport: the window -------------------------------------------------------------
   void alloc_window(size_t ib, size_t rb) {
@@ -375,13 +430,14 @@ struct ShardStep {
                       : 1u;
     LAUNCH_HOT(kTagShardPush, shard_push_kernel, dim3(gx, uint32_t(world)), 256, st, A);
     HIP_OK(hipGetLastError());
-    sig_pending |= 1u << chan;
+    sig_pending[st == aux && aux ? 1 : 0] |= 1u << chan;
   }
 
   // one launch: publish the arrival of every push since the last sync, then (wait_chan <
   // kIpcChannels) hold the stream until peers [lo, hi) have published `wait_chan`'s latest exchange
   void sync(uint32_t wait_chan, int lo, int hi, hipStream_t st) {
-    if (!sig_pending && wait_chan >= uint32_t(kIpcChannels)) return;
+    uint32_t& pend = sig_pending[st == aux && aux ? 1 : 0];   // (a push is published on ITS stream)
+    if (!pend && wait_chan >= uint32_t(kIpcChannels)) return;
     ShardSyncArgs A{};
     for (int p = 0; p < world; ++p) A.win[p] = peer_win[p];
     A.flags = d_flags;
@@ -389,11 +445,11 @@ struct ShardStep {
     A.rank = uint32_t(rank);
     A.world = uint32_t(world);
     for (uint32_t c = 0; c < uint32_t(kIpcChannels); ++c)
-      if (sig_pending & (1u << c)) {
+      if (pend & (1u << c)) {
         A.sig_chan[A.n_sig] = c;
         A.sig_seq[A.n_sig++] = seq_sent[c];
       }
-    sig_pending = 0;
+    pend = 0;
     A.wait_chan = wait_chan;
     if (wait_chan < uint32_t(kIpcChannels)) {
       A.wait_seq = seq_sent[wait_chan];
@@ -405,7 +461,7 @@ struct ShardStep {
   }
   // at the end of an API call: nothing this rank owes its peers stays unpublished
   void flush_signals(hipStream_t st) {
-    if (ipc && sig_pending) sync(uint32_t(kIpcChannels), 0, 0, st);
+    if (ipc && sig_pending[st == aux && aux ? 1 : 0]) sync(uint32_t(kIpcChannels), 0, 0, st);
   }
 
   void exchange_ipc(int kind, int slot, hipStream_t st) {
@@ -460,6 +516,12 @@ struct ShardStep {
 
   void prepare(hipStream_t st) {
     check_flags();
+    if (aux_pending)   // (descriptors are about to be re-uploaded: nothing of ours may still read them)
+      for (uint32_t t = 0; t < T; ++t)
+        if (ms.st_version[t] != mt->tables[t]->view_version) {
+          HIP_OK(hipStreamSynchronize(aux));
+          break;
+        }
     for (auto& tb : mt->tables) tb->finish_pending(st);
     sync_views(mt, st);
     ms.sync_static(st);
@@ -477,6 +539,7 @@ struct ShardStep {
     ms.launch_dedup(ids, split, slot, 0, st);
     ms.stage[slot] = 1;
     disp[slot] = false;
+    ids_exchanged[slot] = false;
   }
 
   void gather_tabs(ShardGatherTab* gt, int slot, uint32_t* gx_out) const {
@@ -771,6 +834,7 @@ static void shard_forward(ShardStep** S, int n, const ShardFwd* a, int64_t n_spl
   for (int r = 0; r < n; ++r) {
     ShardStep& s = *S[r];
     HIP_OK(hipSetDevice(s.device));
+    s.join_aux(st);
     s.prepare(st);
     if (prefetched) {
       s.ms.cur ^= 1;
@@ -786,13 +850,18 @@ static void shard_forward(ShardStep** S, int n, const ShardFwd* a, int64_t n_spl
   if (S[0]->ms.stage[cur] == 1) {   // not numbered by a backward call: number + pack + send now
     for (int r = 0; r < n; ++r) S[r]->build_and_sum(cur, -1, nullptr, st);
     shard_exchange(S, n, kXIds, cur, st);
+    for (int r = 0; r < n; ++r) S[r]->ids_exchanged[cur] = true;
+  } else if (!S[0]->ids_exchanged[cur]) {   // numbered on the step's own stream, not sent there
+    shard_exchange(S, n, kXIds, cur, st);
+    for (int r = 0; r < n; ++r) S[r]->ids_exchanged[cur] = true;
   }
   for (int r = 0; r < n; ++r) S[r]->owner_lookup(cur, st);
   shard_exchange(S, n, kXRows, cur, st);
   for (int r = 0; r < n; ++r) S[r]->scatter(a[r].emb, cur, st);
   if (has_next)
     for (int r = 0; r < n; ++r) {
-      S[r]->dedup(a[r].id_next, a[r].split_next, cur ^ 1, st);
+      if (S[r]->overlap && n == 1) S[r]->prepare_next_on_aux(a[r].id_next, a[r].split_next, cur ^ 1, st);
+      else S[r]->dedup(a[r].id_next, a[r].split_next, cur ^ 1, st);
       S[r]->ahead = true;
     }
   for (int r = 0; r < n; ++r) S[r]->flush_signals(st);
@@ -829,7 +898,10 @@ static void shard_backward(ShardStep** S, int n, const float* const* grads, cons
     S[r]->build_and_sum(build_next ? (cur ^ 1) : -1, cur, grads[r], st);
   }
   shard_exchange(S, n, kXGrads, cur, st);
-  if (build_next) shard_exchange(S, n, kXIds, cur ^ 1, st);
+  if (build_next) {
+    shard_exchange(S, n, kXIds, cur ^ 1, st);
+    for (int r = 0; r < n; ++r) S[r]->ids_exchanged[cur ^ 1] = true;
+  }
   for (int r = 0; r < n; ++r) {
     S[r]->owner_apply(cur, lrs, update_time, global_step, st);
     S[r]->ms.stage[cur] = 0;

@@ -531,6 +531,12 @@ class ShardedMultiStep:
     except Exception:  # pylint: disable=broad-except
       pass
 
+  def set_overlap(self, on: bool = True):
+    """The next batch's dedup / numbering / id dispatch on a stream of the step's own, beside the
+    dense model the caller runs between ``forward`` and ``backward`` (mhte_shard_step_set_overlap)."""
+    self._libmod.check(self._lib.mhte_shard_step_set_overlap(self._h, C.c_int32(1 if on else 0)))
+    return self
+
   def info(self):
     out = (C.c_int64 * 4)()
     self._libmod.check(self._lib.mhte_shard_step_info(self._h, out))

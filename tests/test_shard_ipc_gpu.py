@@ -68,6 +68,15 @@ def test_processes_against_oracle(dist_kind, world, tmp_path):
     assert sum(r["sizes"][name] for r in res) > 0
 
 
+def test_processes_with_overlap(tmp_path):
+  """MHTE_SHARD_OVERLAP=1: the next batch's dedup, numbering, packing and id exchange on the step's own
+  stream (pushes and their publication from two streams of every process) — same results."""
+  res = run_world(2, "uniform", 6, tmp_path, {"MHTE_SHARD_OVERLAP": "1"})
+  assert all(r["ok"] for r in res)
+  res = run_world(3, "zipf", 5, tmp_path, {"MHTE_SHARD_OVERLAP": "1"})
+  assert all(r["ok"] for r in res)
+
+
 def test_coarse_window(tmp_path):
   """MHTE_SHARD_WINDOW=coarse: the windows as plain device memory (the A/B form)."""
   res = run_world(2, "uniform", 4, tmp_path, {"MHTE_SHARD_WINDOW": "coarse"})

@@ -44,7 +44,8 @@ def grads_of(step, rank, spec, n):
   return (rng.standard_normal((n, spec.dim)) * 0.1).astype(np.float32)
 
 
-def test_world1_identity_matches_multi_step():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_world1_identity_matches_multi_step(overlap):
   specs = dlrm_specs(7, initial_capacity=1 << 12)
   by_name = sorted(specs, key=lambda s: s.name)
   B, steps = 6000, 6
@@ -52,6 +53,9 @@ def test_world1_identity_matches_multi_step():
   mt_a, mt_b = make(specs), make(specs)
   ref = MultiSparseStep(mt_a, B)
   shd = ShardedMultiStep(mt_b, B)
+  if overlap:     # the next batch prepared on the step's own stream beside a stand-in for the dense model
+    shd.set_overlap(True)
+    busy = torch.randn(2048, 2048, device="cuda")
   assert shd.info()["transport"] == "identity"
   geo = shard_block_geometry(mt_b.get_table_dim_sizes(), B, 1)
   assert (shd.info()["id_block_bytes"], shd.info()["row_block_bytes"]) == (8 * geo["ids_block"], 4 * geo["rows_block"])
@@ -62,6 +66,8 @@ def test_world1_identity_matches_multi_step():
     eb = shd.forward(rag_b[s], rag_b[s + 1] if s % 3 != 2 else None)   # (every third: not ahead)
     assert torch.equal(ea, eb), "forward step %d" % s
     g = val_t(np.concatenate([grads_of(s, 0, sp, B).ravel() for sp in by_name]))
+    if overlap:
+      busy = busy @ busy * 1e-3
     ref.backward(g, S.update_time(s))
     shd.backward(g, S.update_time(s))
   shd.check()
@@ -173,6 +179,14 @@ def test_exact_size_exchange(monkeypatch):
   test_group_against_oracle("zipf", 3)
   test_group_against_oracle("uniform", 2)
   test_world1_over_rccl()
+
+
+def test_overlap_over_rccl(monkeypatch):
+  """MHTE_SHARD_OVERLAP=1 with the RCCL transport: dedup and numbering run on the step's own stream,
+  the id exchange stays on the communicator's stream (sent by the next forward)."""
+  monkeypatch.setenv("MHTE_SHARD_OVERLAP", "1")
+  test_world1_over_rccl()
+  test_group_against_oracle("uniform", 2)      # (in-process groups ignore the mode)
 
 
 def test_block_overflow_is_reported():
