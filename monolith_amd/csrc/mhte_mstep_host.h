@@ -261,6 +261,71 @@ struct MultiStep {
     }
   }
 
+  // lookup of the batch in `slot` + run dedup of (ids_next, split_next) into `slot_next`, ONE launch
+  // (T <= kMaxStepTables; mstep_fwd_dedup_kernel)
+  uint32_t fused_dedup_wgs = 0;   // persistent dedup workgroups of the fused launch (0: per CU count)
+  uint32_t fused_lookup_wgs = 0;  // lookup workgroups of the fused launch over all tables (0: resident share)
+  void launch_fwd_dedup(float* out, int slot, const int64_t* ids_next, const int64_t* split_next,
+                        int slot_next, hipStream_t st) {
+    MFwdArgs A{};
+    A.views = ConstViews(mt->d_views.p);
+    A.st = ConstStatics(d_st);
+    A.out = out;
+    A.cur = uint32_t(slot);
+    A.item_split = std::max<uint32_t>(1, item_target / kItemTarget);
+    MDedupArgs D{};
+    D.st = ConstStatics(d_st);
+    D.ids = ids_next + split_next[0];
+    D.slot = uint32_t(slot_next);
+    D.T = T;
+    MFwdFuse F{};
+    uint32_t active = 0, dblocks = 0;
+    for (uint32_t t = 0; t < T; ++t) active += n_slot[slot][t] ? 1u : 0u;
+    int64_t emb_off = 0;
+    uint32_t lin = 0;
+    // lookup workgroups of 1024 threads: two resident per CU; the dedup's persistent ones take
+    // their share of the slots, the rest goes to the tables in proportion
+    const uint32_t slots = uint32_t(2 * num_cus);
+    for (uint32_t t = 0; t < T; ++t) {
+      D.id_off[t] = uint32_t(split_next[t] - split_next[0]);
+      D.blk_start[t] = dblocks;
+      dblocks += uint32_t((split_next[t + 1] - split_next[t] + kRdBlock - 1) / kRdBlock);
+    }
+    D.id_off[T] = uint32_t(split_next[T] - split_next[0]);
+    D.blk_start[T] = dblocks;
+    F.nd = std::min<uint32_t>(dblocks, fused_dedup_wgs ? fused_dedup_wgs : uint32_t(num_cus) / 2);
+    uint32_t room = std::max<uint32_t>(slots > F.nd ? slots - F.nd : 8u, 8u) * scatter_ovs;
+    if (fused_lookup_wgs) room = fused_lookup_wgs;
+    for (uint32_t t = 0; t < T; ++t) {
+      MFwdTab& ft = A.tab[t];
+      const Table& tb = *mt->tables[t];
+      ft.n = n_slot[slot][t];
+      if (uint64_t(emb_off) > 0xffffffffull)
+        throw Error(MHTE_INVALID_ARGUMENT, "multi step: embedding buffer exceeds 2^32 floats");
+      ft.emb_off = uint32_t(emb_off);
+      emb_off += int64_t(ft.n) * tb.dim;
+      F.fwd_start[t] = lin;
+      if (ft.n) {
+        const uint32_t groups_per_wg = uint32_t(kRdBlock) / h_st[t].g;
+        const uint32_t one_trip = (ft.n + groups_per_wg - 1) / groups_per_wg;
+        const uint32_t share = std::max<uint32_t>(2, room / std::max(1u, active));
+        ft.nblk_s = std::max<uint32_t>(1, std::min(one_trip, share));
+        lin += ft.nblk_s;
+      }
+    }
+    F.fwd_start[T] = lin;
+    const uint32_t grid = F.nd + lin;
+    if (!grid) return;
+    // (the dedup workgroups FIRST: spread evenly among the lookups' they measured 162-502 us against
+    // 161 us — MHTE_MSTEP_FUSE_INTERLEAVE=1 keeps the other mapping for A/B runs)
+    static const bool interleave = getenv("MHTE_MSTEP_FUSE_INTERLEAVE") != nullptr;
+    F.period = (interleave && F.nd) ? std::max<uint32_t>(1, grid / F.nd) : 1u;
+    A.trace = trace_region(kTagMStepFwd, grid, kRdBlock);
+    D.trace = A.trace;
+    LAUNCH_HOT(kTagMStepFwd, mstep_fwd_dedup_kernel, grid, kRdBlock, st, A, D, F);
+    HIP_OK(hipGetLastError());
+  }
+
   // run dedup of the ragged batch (ids, split) into `slot`; max_wgs: persistent workgroups per
   // launch (0: one per item)
   void launch_dedup(const int64_t* ids, const int64_t* split, int slot, uint32_t max_wgs, hipStream_t st) {
@@ -389,6 +454,8 @@ struct MultiStep {
   uint32_t dedup_wgs = 128;               // persistent workgroups of the side-stream dedup
   bool use_side = false;                  // MHTE_MSTEP_SIDE=1 (measured slower: the two queues
                                           // compete for the dispatcher)
+  bool fuse_fwd = true;                   // lookup + next batch's dedup in one launch
+                                          // (MHTE_MSTEP_FUSE_FWD=0: two launches)
 
   void make_streams() {
     HIP_OK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
@@ -396,6 +463,9 @@ struct MultiStep {
     for (int i = 0; i < 2; ++i) HIP_OK(hipEventCreateWithFlags(&ev_dedup[i], hipEventDisableTiming));
     if (const char* e = getenv("MHTE_MSTEP_DEDUP_WGS")) dedup_wgs = std::max(1, atoi(e));
     if (const char* e = getenv("MHTE_MSTEP_SIDE")) use_side = atoi(e) != 0;
+    if (const char* e = getenv("MHTE_MSTEP_FUSE_FWD")) fuse_fwd = atoi(e) != 0;
+    if (const char* e = getenv("MHTE_MSTEP_FUSE_DEDUP_WGS")) fused_dedup_wgs = uint32_t(std::max(1, atoi(e)));
+    if (const char* e = getenv("MHTE_MSTEP_FUSE_LOOKUP_WGS")) fused_lookup_wgs = uint32_t(std::max(1, atoi(e)));
   }
 
   // main stream waits for the side-stream dedup of `slot` (if that is where it ran)
@@ -460,6 +530,17 @@ struct MultiStep {
     }
     // the lookup reads the ids from the slot's numbering (distinct ids + occurrence runs), not
     // from `id`: the caller's promise (prefetched) is that they are the same batch
+    if (id_next && !use_side && fuse_fwd && T <= uint32_t(kMaxStepTables)) {
+      // lookup of this batch and the run dedup of the next one in ONE launch
+      if (stage[nxt] == 1) clear_slots(1u << nxt, st);
+      for (uint32_t t = 0; t < T; ++t) n_slot[nxt][t] = uint32_t(split_next[t + 1] - split_next[t]);
+      has_hints[nxt] = false;
+      launch_fwd_dedup(emb, cur, id_next, split_next, nxt, st);
+      stage[nxt] = 1;
+      for (uint32_t t = 0; t < T; ++t) fwd_epoch[cur][t] = mt->tables[t]->mut_epoch;
+      has_hints[cur] = true;
+      return;
+    }
     launch_fwd(emb, cur, st);
     for (uint32_t t = 0; t < T; ++t) fwd_epoch[cur][t] = mt->tables[t]->mut_epoch;
     has_hints[cur] = true;

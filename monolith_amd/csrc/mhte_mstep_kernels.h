@@ -393,6 +393,69 @@ __global__ __launch_bounds__(BLOCK) void mstep_fwd_kernel(MFwdArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward + the run dedup of the NEXT batch in ONE launch (as the single-table step_fwd does): the
+// lookup / scatter is bound by HBM bandwidth, the dedup by device-scope atomics — side by side they
+// take about as long as the longer one (measured: 97 + 103 us as two launches at 26 x 65 536 ids).
+// 1024-thread workgroups: the first `nd` are the dedup's persistent workgroups, the rest belong to
+// the tables' lookups (fwd_start[t] .. fwd_start[t + 1]).
+// ---------------------------------------------------------------------------------------------
+struct MFwdFuse {
+  uint32_t nd;                                // dedup workgroups (persistent: item w, w + nd, ...)
+  uint32_t period;                            // workgroup b is dedup workgroup b / period when
+                                              // b % period == 0 and b / period < nd: the two roles'
+                                              // workgroups start interleaved, not one role first
+  uint32_t fwd_start[kMaxStepTables + 1];     // first lookup workgroup of table t
+};
+#ifndef MHTE_FUSED_SCATTER_UNR
+#define MHTE_FUSED_SCATTER_UNR 1
+#endif
+// (8 waves per SIMD = two 1024-thread workgroups per CU: at 76 VGPRs only one fits and the lookups
+// wait for the persistent dedup workgroups to leave — measured 12.7 ms with 256 of them)
+__global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void mstep_fwd_dedup_kernel(
+    MFwdArgs A, MDedupArgs D, MFwdFuse F) {
+  __shared__ __attribute__((aligned(16))) RdLds L;
+  WaveTrace wt(A.trace);
+  const uint32_t bq = blockIdx.x / F.period;
+  if (blockIdx.x % F.period == 0 && bq < F.nd) {
+    const uint32_t total = D.blk_start[D.T];
+#pragma unroll 1
+    for (uint32_t w = bq; w < total; w += F.nd) {
+      uint32_t t = 0;
+      while (t + 1 < D.T && D.blk_start[t + 1] <= w) ++t;
+      const MStepStatic& s = deref_const(D.st + t);
+      RunView d = s.rv[D.slot & 1u];
+      d.ids = D.ids + D.id_off[t];
+      d.n = D.id_off[t + 1] - D.id_off[t];
+      d.nblk = D.blk_start[t + 1] - D.blk_start[t];
+      rd_dedup_role(d, w - D.blk_start[t], L, wt);
+      __syncthreads();
+    }
+    wt.end(3u);
+    return;
+  }
+  const uint32_t lin = blockIdx.x - min(F.nd, (blockIdx.x + F.period - 1) / F.period);   // dedup workgroups before it
+  uint32_t t = 0;
+  while (t + 1 < D.T && F.fwd_start[t + 1] <= lin) ++t;
+  const MFwdTab ft = A.tab[t];
+  const uint32_t bid = lin - F.fwd_start[t];
+  if (ft.n == 0 || bid >= ft.nblk_s) return;
+  const MStepStatic& s = deref_const(A.st + t);
+  const TableView& tv = deref_const(A.views + t);
+  const uint32_t cur = A.cur & 1u;
+  const RunView d = s.rv[cur];
+  float* out = A.out + size_t(ft.emb_off);
+  const int ch = int(s.count_hits);
+  constexpr int U = MHTE_FUSED_SCATTER_UNR;
+  switch (s.g) {
+    case 8: mstep_scatter_role<8, kRdBlock, U>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
+    case 16: mstep_scatter_role<16, kRdBlock, U>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
+    case 32: mstep_scatter_role<32, kRdBlock, U>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
+    default: mstep_scatter_role<64, kRdBlock, U>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
+  }
+  wt.end(5u);
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward: per table   numbering + heavy work list of the NEXT batch | apply of this batch
 // ---------------------------------------------------------------------------------------------
 template <bool ONESEG>
