@@ -741,7 +741,10 @@ def main():
   reps = min(K, 100)
   gchunk = 10                               # steps per captured graph
   Wg = -(-W // gchunk) * gchunk             # the graph mode's warm-up: W rounded up to whole chunks
-  n_batches = ((W + K) + (Wg + K) + 2 * reps + 12) if not sharded else (K + W + 24)
+  # a short --steps window (the driver's 20 steps are 0.7 ms of GPU work) is reported next to a
+  # 200-step window of the same mode: `reference_window` in the JSON line
+  REFW = 200 if (K < 200 and not sharded) else 0
+  n_batches = ((W + K) + (Wg + K) + 2 * reps + 12 + REFW) if not sharded else (K + W + 24)
   ids_host = np.stack([S.id_batch(s * world + rank, B, V, "zipf") for s in range(n_batches)])
   ids_all = torch.from_numpy(ids_host).to(dev)
   NG = max(1, args.grad_pool)
@@ -831,6 +834,8 @@ def main():
         step = SparseStep(mt, "emb", B, exact_order=args.exact_order,
                       reserve_ahead=args.reserve_ahead)
         cur += gc * (len(graphs) + 1)
+    if REFW:
+      cur = timed("eager_ref_window", cur, 0, REFW)
     P0 = cur
   else:
     # the id-sharded step, enqueued from C++ (csrc/mhte_shard_host.h): kernels + RCCL send / recv
@@ -959,7 +964,7 @@ def main():
             "step_alg_bytes": int(step_bytes),
             "step_GBps": round(step_bytes / (elapsed_local / K) / 1e9, 1),
             "step_frac": round(step_bytes / (elapsed_local / K) / 1e9 / HBM_PEAK_GBPS, 4)}
-  full = {k: v for k, v in results.items() if steps_of[k] == K}   # modes timed over exactly K steps
+  full = {k: v for k, v in results.items() if steps_of[k] == K and k != "eager_ref_window"}   # modes timed over exactly K steps
   launch = min(full, key=full.get) if args.launch == "auto" else (
       args.launch if args.launch in full else "eager")
   elapsed = results[launch]
@@ -1167,7 +1172,13 @@ def main():
             "shard_step": shard_info,
             "prefill_s": round(prefill_s, 2),
         },
-        "timing_ms_per_step": {k: round(v / steps_of[k] * 1e3, 5) for k, v in results.items()},
+        "timing_ms_per_step": {k: round(v / steps_of[k] * 1e3, 5) for k, v in results.items()
+                               if k != "eager_ref_window"},
+        "reference_window": None if "eager_ref_window" not in results else {
+            "steps": steps_of["eager_ref_window"], "launch": "eager",
+            "ms_per_step": round(results["eager_ref_window"] / steps_of["eager_ref_window"] * 1e3, 5),
+            "note": "the same step timed over a longer window (a %d-step window is %.2f ms of work)"
+                    % (K, elapsed * 1e3)},
         "roofline": roofline,
         "stages": stages,
         "cpu_baseline": cpu,

@@ -1909,8 +1909,9 @@ mhte_status mhte_multi_table_set_filter(mhte_multi_table* t, mhte_hash_filter* f
 mhte_status mhte_hash_filter_get(mhte_hash_filter* f, const int64_t* id, int64_t n, uint32_t* out,
                                  void* stream) {
   return guard([&] {
-    if (!f || !id || !out) throw Error(MHTE_INVALID_ARGUMENT, "null argument");
+    if (!f) throw Error(MHTE_INVALID_ARGUMENT, "null argument");
     if (n <= 0) return;
+    if (!id || !out) throw Error(MHTE_INVALID_ARGUMENT, "null argument");
     HIP_OK(hipSetDevice(f->device));
     filter_get_kernel<<<dim3(uint32_t((n + 255) / 256)), 256, 0, S(stream)>>>(f->view(), id, n, out);
     HIP_OK(hipGetLastError());

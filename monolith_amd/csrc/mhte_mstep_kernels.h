@@ -603,9 +603,20 @@ __device__ __forceinline__ void seg_upsert_loop(const TableView& tv, const int64
 #pragma unroll 1
   for (uint32_t g0 = blockIdx.x * ngroups_wg; g0 < n; g0 += gridDim.x * ngroups_wg) {  // wave-uniform
     const uint32_t g = g0 + threadIdx.x / G;
-    const bool valid = g < n;
+    bool valid = g < n;
     const int64_t id = valid ? ids[g] : 0;
     Probe<G> pr = probe_issue<G>(tv, id, valid, j);
+    // occurrence filter: the ids of a segment are distinct (one sender's, or one shard's), so an id
+    // the table does not hold asks with count 1 — what the reference's fused optimize does per
+    // (sender, id) (tf_bridge.cc:300-321 behind multi_hash_table_update_op.cc:270-306)
+    if (tv.flt_slots && a.filter_mode) {
+      const int gbase = lane & ~(G - 1);
+      bool contained = group_mask_of<G>(__ballot(valid && id != kEmptyKey && j < 8 && pr.k == id), gbase) != 0;
+      if (valid && id == kEmptyKey) contained = tv.ctr->special_state == 1;
+      uint32_t first = 0;
+      if (valid && j == 0) first = filter_consult(tv, id, 1u, 1, contained);
+      if (__shfl(first, gbase) != 0u) valid = false;
+    }
     const SlotResult sr = upsert_resolve<G>(tv, (Bucket*)pr.b, id, valid, pr.k, pr.row, lane, a.ts);
     if (sr.deferred && j == 0) {
       const uint32_t slot = atomicAdd(&tv.ctr->n_pending, 1u);

@@ -193,10 +193,6 @@ struct ShardStep {
     if (!seg_kernels_ok(m))
       throw Error(MHTE_INVALID_ARGUMENT, "shard step: every table needs rows of whole float4s and "
                                          "per-element optimizers");
-    for (auto& tb : m->tables)
-      if (tb->flt_slots)
-        throw Error(MHTE_INVALID_ARGUMENT, "shard step: table " + tb->name + " has an occurrence "
-                                           "filter (not supported on the sharded path)");
     ms.init(m, mb);
     // default: a (peer, table) block can hold the whole batch, so no step can overflow one (the
     // reference's all-to-all is variable-sized and never drops an id).  A smaller capacity is the
@@ -672,7 +668,7 @@ struct ShardStep {
       lr_off += tb.nseg;
       a.ts = static_cast<uint32_t>(update_time);
       a.sum_dups = 0;
-      a.filter_mode = 0;
+      a.filter_mode = tb.flt_slots ? 1 : 0;   // an owner asks its filter about every id it does not hold
       a.global_step = global_step;
       gx = std::max(gx, (cap + 256u / A.g[t] - 1) / (256u / A.g[t]));
     }
@@ -686,6 +682,11 @@ struct ShardStep {
       LAUNCH_HOT(kTagShardUpsert, shard_upsert_kernel, dim3(gx, T), 256, st, A);
       shard_slow_kernel<<<T, 64, 0, st>>>(A);
       HIP_OK(hipGetLastError());
+      for (uint32_t t = 0; t < T; ++t)   // the filter's window moves between senders (one filter for all tables)
+        if (mt->tables[t]->flt_slots) {
+          mt->tables[t]->filter_maintain(st);
+          break;
+        }
     }
     hdr_dirty[slot] = false;
     for (uint32_t t = 0; t < T; ++t) {

@@ -189,6 +189,105 @@ def test_overlap_over_rccl(monkeypatch):
   test_group_against_oracle("uniform", 2)      # (in-process groups ignore the mode)
 
 
+def test_sharded_step_with_occurrence_filters():
+  """Tables with an occurrence filter through the sharded step (round 2 rejected them): every OWNER
+  asks its own filter about the ids of a sender's block it does not hold, with count 1 per (sender,
+  id) — the reference's fused optimize behind the all-to-all (tf_bridge.cc:300-321 per id of
+  multi_hash_table_update_op.cc:270-306) — senders in rank order, the window moving between them.
+  Checked against oracle tables + the filter restatement (oracle.SlidingFilter) per owner."""
+  from monolith_amd import entry
+  from monolith_amd.multi_hash_table_ops import HashFilter, MultiHashTable
+  world, B, steps, thr = 2, 1500, 6, 2
+  dims = {"a": 16, "b": 32}
+  mts, flts, ots, models = [], [], [], []
+  for r in range(world):
+    flt = HashFilter(capacity=4000, split_num=5)
+    cfgs = {n: entry.make_table_config(
+        [entry.CombineAsSegment(d, entry.ZerosInitializer(), entry.AdagradOptimizer(0.05, 0.1))],
+        slot_occurrence_threshold_config=entry.SlotOccurrenceThresholdConfig(default_occurrence_threshold=thr))
+            for n, d in dims.items()}
+    mts.append(MultiHashTable.from_configs(cfgs, name_suffix="shflt%d" % r, hash_filter=flt))
+    flts.append(flt)
+    ots.append({n: O.Table(O.segment(d, O.OPT_ADAGRAD, p=(0.1, 0.0)), 1) for n, d in dims.items()})
+    models.append(O.SlidingFilter(4000, 5, defer_advance=True))
+  grp = ShardedStepGroup(mts, B)
+  names = sorted(dims)
+  dropped = [0]
+
+  def ids_of(s, r, k):
+    # A small universe: ids come back, pass their threshold, get trained.  Every id has its own 12-bit
+    # filter signature (fid bits 17..28, hash_filter.h:151), so no two ids share a count: which of two
+    # aliasing ids of ONE launch crosses the threshold first is not defined (nor in the reference,
+    # whose filter is not thread safe) and would make the expectation order-dependent.
+    idx = S.id_batch(50 * s + 7 * r + k, B, 1800, "uniform") % 1800 + 1800 * k
+    return ((idx + 1) << 17) | (idx % 7) | (np.int64(k + 1) << 48)
+
+  def rag_of(s, r):
+    return mts[r].get_ragged_id({n: torch.as_tensor(ids_of(s, r, k)).cuda() for k, n in enumerate(names)})
+
+  for s in range(steps):
+    embs = grp.forward([rag_of(s, r) for r in range(world)], [rag_of(s + 1, r) for r in range(world)],
+                       prefetched=s > 0)
+    for r in range(world):
+      views = mts[r].get_embeddings(rag_of(s, r), embs[r])
+      for k, n in enumerate(names):
+        ids = ids_of(s, r, k)
+        exp = np.zeros((ids.size, dims[n]), np.float32)
+        for o in range(world):
+          m = np.mod(ids, world) == o
+          exp[m] = ots[o][n].lookup(ids[m])[0]
+        np.testing.assert_array_equal(views[n].cpu().numpy(), exp, err_msg="rank %d %s step %d" % (r, n, s))
+    flat = []
+    grads = {}
+    for r in range(world):
+      fg = []
+      for k, n in enumerate(names):
+        g = (np.random.default_rng(1000 * s + 10 * r + k).standard_normal((B, dims[n])) * 0.1).astype(np.float32)
+        grads[(r, n)] = g
+        fg.append(g.ravel())
+      flat.append(val_t(np.concatenate(fg)))
+    grp.backward(flat, S.update_time(s))
+    # the owners' semantics: senders in rank order, one consultation per (sender, distinct id)
+    for o in range(world):
+      for r in range(world):
+        for k, n in enumerate(names):
+          ids = ids_of(s, r, k)
+          uk, _, vo, vos, _ = O.unique_key_with_value_and_offset(ids, [0, ids.size], [dims[n]])
+          gu = O.fill_with_offset_map_gradient(np.arange(uk.size), [0, uk.size], grads[(r, n)].ravel(), vo, vos,
+                                               [dims[n]]).reshape(-1, dims[n])
+          mine = np.mod(uk, world) == o
+          keep = []
+          for i in np.nonzero(mine)[0]:
+            fid = int(uk[i])
+            if ots[o][n].contains(fid) or models[o].add(fid, 1) >= thr:
+              keep.append(i)
+            else:
+              dropped[0] += 1
+          if keep:
+            ots[o][n].optimize(uk[keep], gu[keep], [0.05], S.update_time(s))
+        models[o].advance_if_full()
+  grp.check()
+  assert dropped[0] > 1000            # the filters did filter
+  for o in range(world):
+    for k, n in enumerate(names):
+      seen = np.unique(np.concatenate([ids_of(s, r, k) for s in range(steps) for r in range(world)]))
+      mine = seen[np.mod(seen, world) == o]
+      want = np.array([ots[o][n].contains(int(x)) for x in mine])
+      got = mts[o].contains(n, torch.as_tensor(mine).cuda()).cpu().numpy().astype(bool)
+      np.testing.assert_array_equal(got, want)
+      assert want.sum() > 0
+      held = mine[want]
+      np.testing.assert_array_equal(mts[o].lookup({n: torch.as_tensor(held).cuda()})[n].cpu().numpy(),
+                                    ots[o][n].lookup(held)[0])
+    probe = np.unique(np.concatenate([ids_of(s, r, 0) for s in range(steps) for r in range(world)]))
+    probe = probe[np.mod(probe, world) == o]
+    absent = np.array([not ots[o][names[0]].contains(int(x)) for x in probe])
+    if absent.any():
+      np.testing.assert_array_equal(flts[o].get(torch.as_tensor(probe[absent]).cuda()).cpu().numpy(),
+                                    [models[o].get(int(x)) for x in probe[absent]])
+  grp.close()
+
+
 def test_block_overflow_is_reported():
   specs = dlrm_specs(2, initial_capacity=1 << 10)
   B = 512
