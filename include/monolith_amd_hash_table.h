@@ -688,9 +688,11 @@ mhte_status mhte_shard_group_backward(mhte_shard_step** steps, int32_t n, const 
                                       int64_t n_learning_rate, int64_t update_time,
                                       int64_t global_step, void* stream);
 
-/* 1 when table i's row fits the single-launch backward (dim <= 256 floats, or <= 64 when segment
- * boundaries are not multiples of 4 floats); otherwise mhte_table_sum_optimize_n runs segment sum +
- * optimize and needs the ordered mhte_unique. */
+/* != 0 when table i fits the fused training step (row of <= 256 floats, or <= 64 when segment
+ * boundaries are not multiples of 4 floats; no whole-segment optimizer): 1 = SGD / Adagrad / FTRL, 2 =
+ * any per-element optimizer (Momentum, Adadelta, RMSProp, Adam, AMSGrad, MovingAverage, BatchSoftmax:
+ * the step kernels' FULL instantiations).  0, and 2 for the unpipelined mhte_table_sum_optimize_n:
+ * segment sum + optimize, which needs the ordered mhte_unique. */
 int32_t mhte_table_fused_backward_ok(const mhte_multi_table* t, int32_t i);
 
 /* MonolithUniqueKeyWithValueAndOffset (RT/ops/unique_mapping_ops.cc:51-155), one table at a time:

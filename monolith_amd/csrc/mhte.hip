@@ -860,11 +860,18 @@ struct Table {
   // ---------------------------------------------------------------- fused backward
   // duplicate-gradient sum + upsert + optimizer apply of the unique ids of ws's most recent
   // unique() in one launch (sum_apply_kernel); falls back to segment-sum + upsert for wide rows.
+  // the fused step kernels take every per-element optimizer (their FULL instantiations beyond SGD /
+  // Adagrad / FTRL); the whole-segment GroupAdaGrad stays on the op-level kernels
   bool fusable() const {
     for (uint32_t i = 0; i < nseg; ++i)
-      if (view.seg[i].opt > kOptFtrl) return false;  // the step kernels take sgd / adagrad / ftrl
+      if (view.seg[i].opt == kOptGroupAdagrad) return false;
     Shape sh = pick_shape(dim, vec_ok);
     return dim <= uint32_t(sh.G * sh.VEC);
+  }
+  bool basic_opts() const {   // SGD / Adagrad / FTRL only: the BASIC kernel instantiations
+    for (uint32_t i = 0; i < nseg; ++i)
+      if (view.seg[i].opt > kOptFtrl) return false;
+    return true;
   }
   void sum_optimize(DedupWs& ws, const int64_t* uids, int64_t n_max, const uint32_t* n_dev,
                     const float* grads, const uint32_t* lst_start, const uint32_t* lst_end,
@@ -965,9 +972,17 @@ struct Table {
     const dim3 grid(others + nblk_l);
     TableView v = view;
     v.trace = trace_region(kTagStepFwd, grid.x, kRdBlock);
+    const bool basic = basic_opts();   // (the displacement role's update code)
 #define CALLU(G_, V_, U_)                                                                        \
-  LAUNCH_HOT(kTagStepFwd, (step_fwd_kernel<G_, V_, U_>), grid, kRdBlock, st, nxt, v, ids, n, out, \
-             count_hits ? 1 : 0, sp, nblk_l, pre)
+  do {                                                                                           \
+    if (basic) {                                                                                 \
+      LAUNCH_HOT(kTagStepFwd, (step_fwd_kernel<G_, V_, U_, true>), grid, kRdBlock, st, nxt, v, ids, n, out, \
+                 count_hits ? 1 : 0, sp, nblk_l, pre);                                           \
+    } else {                                                                                     \
+      LAUNCH_HOT(kTagStepFwd, (step_fwd_kernel<G_, V_, U_, false>), grid, kRdBlock, st, nxt, v, ids, n, out, \
+                 count_hits ? 1 : 0, sp, nblk_l, pre);                                           \
+    }                                                                                            \
+  } while (0)
 #define CALL(G_, V_)                              \
   do {                                            \
     if (unr == 2) { CALLU(G_, V_, 2); }           \
@@ -981,7 +996,8 @@ struct Table {
 
   void step_backward(DedupWs& ws, DedupWs* ws_next, const int64_t* uids, int64_t n_max,
                      const uint32_t* n_dev, const float* grads, int64_t n, float* grad_u,
-                     const float* lrs, int64_t update_time, bool exact_order, hipStream_t st) {
+                     const float* lrs, int64_t update_time, bool exact_order, hipStream_t st,
+                     int64_t global_step = 0) {
     finish_pending(st);
     if (n <= 0 || n_max <= 0) throw Error(MHTE_INVALID_ARGUMENT, "step_backward: empty batch");
     if (ws.r_stage == 0 || int64_t(ws.rv.n) != n || ws.rv.uids != uids || ws.rv.n_unique != n_dev)
@@ -993,7 +1009,7 @@ struct Table {
     a.ts = static_cast<uint32_t>(update_time);
     a.sum_dups = 1;
     a.filter_mode = 1;
-    a.global_step = 0;  // (the fused kernels take SGD / Adagrad / FTRL only)
+    a.global_step = global_step;  // (batch softmax)
     ++mut_epoch;
     const bool prealloc = ws.r_prealloc;  // (rows reserved — and room ensured — by step_forward)
     ws.r_prealloc = false;
@@ -1039,9 +1055,12 @@ struct Table {
     TableView v = view;
     v.trace = trace_region(kTagStepBwd, grid.x, 256);
     const RunView cur = ws.rv;
+    const bool basic = basic_opts();
 #define CALL(G_, V_) \
   do {                                                                                               \
-    if (nseg == 1) {                                                                                 \
+    if (!basic) {                                                                                    \
+      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, false, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a); \
+    } else if (nseg == 1) {                                                                          \
       LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a);  \
     } else {                                                                                         \
       LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, false>), grid, 256, st, nxt, nblk_build, v, cur, c, a); \
@@ -2949,6 +2968,7 @@ mhte_status mhte_table_sum_optimize_n(mhte_multi_table* t, int32_t table, mhte_d
                                       int64_t n_learning_rate, int64_t update_time,
                                       int64_t global_step, int32_t flags, void* stream) {
   return guard([&] {
+    mhte::t_global_step = global_step;  // (batch softmax, through the op-level update of wide / non-basic tables)
     Table& tb = table_at(t, table);
     if (!ws) throw Error(MHTE_INVALID_ARGUMENT, "null workspace");
     if (!learning_rate || n_learning_rate < int64_t(tb.nseg))
@@ -2979,7 +2999,7 @@ mhte_status mhte_table_sum_optimize_n(mhte_multi_table* t, int32_t table, mhte_d
       tb.maybe_evict(st);
       return;
     }
-    if (tb.fusable()) {
+    if (tb.fusable() && tb.basic_opts()) {   // (sum_apply_kernel is compiled for SGD / Adagrad / FTRL)
       tb.sum_optimize(ws->ws, unique_ids, n_max, n_unique_dev, grads, list_start, list_end,
                       seg_pos, n, grad_unique, learning_rate, update_time,
                       (flags & MHTE_EXACT_ORDER) != 0, (flags & MHTE_DEFER_SLOWPATH) != 0, st);
@@ -2990,7 +3010,8 @@ mhte_status mhte_table_sum_optimize_n(mhte_multi_table* t, int32_t table, mhte_d
     // the ordered dedup: list_end == list_start + 1)
     if (list_end != list_start + 1)
       throw Error(MHTE_INVALID_ARGUMENT,
-                  "rows wider than 256 floats need the ordered mhte_unique (CSR occurrence lists)");
+                  "rows wider than 256 floats and optimizers beyond SGD / Adagrad / FTRL need the ordered "
+                  "mhte_unique (CSR occurrence lists) here; the pipelined step takes them as they are");
     mhte_status s2 = mhte_segment_sum(ws, grads, inverse, list_start, seg_pos, n_unique_dev, n,
                                       int32_t(tb.dim), grad_unique,
                                       (flags & MHTE_EXACT_ORDER) ? 1 : 0, stream);
@@ -3134,7 +3155,6 @@ mhte_status mhte_table_step_backward(mhte_multi_table* t, int32_t table, mhte_de
                                      const float* learning_rate, int64_t n_learning_rate,
                                      int64_t update_time, int64_t global_step, int32_t flags,
                                      void* stream) {
-  (void)global_step;
   return guard([&] {
     Table& tb = table_at(t, table);
     if (!ws || ws == ws_next)
@@ -3145,13 +3165,14 @@ mhte_status mhte_table_step_backward(mhte_multi_table* t, int32_t table, mhte_de
     if (!n_unique_dev || !grad_unique || !unique_ids || !grads)
       throw Error(MHTE_INVALID_ARGUMENT, "step_backward: null argument");
     if (!tb.fusable())
-      throw Error(MHTE_INVALID_ARGUMENT, "step_backward: row too wide for the fused step");
+      throw Error(MHTE_INVALID_ARGUMENT, "step_backward: row too wide (or a whole-segment optimizer) "
+                                         "for the fused step");
     HIP_OK(hipSetDevice(t->device));
     std::lock_guard<std::mutex> g(tb.mu);
     tb.note_update_time(update_time);
     tb.step_backward(ws->ws, ws_next ? &ws_next->ws : nullptr, unique_ids, n_max, n_unique_dev,
                      grads, n, grad_unique, learning_rate, update_time,
-                     (flags & MHTE_EXACT_ORDER) != 0, S(stream));
+                     (flags & MHTE_EXACT_ORDER) != 0, S(stream), global_step);
     if (tb.evict_enabled && lib_now() - tb.last_evict >= tb.evict_every_s) {
       // (the scan must not overtake the displacement pass this update left for the next forward)
       tb.finish_pending(S(stream));
@@ -3170,7 +3191,8 @@ mhte_status mhte_table_finish_pending(mhte_multi_table* t, int32_t table, void* 
 }
 
 int32_t mhte_table_fused_backward_ok(const mhte_multi_table* t, int32_t i) {
-  return (t && i >= 0 && i < int32_t(t->tables.size()) && t->tables[i]->fusable()) ? 1 : 0;
+  if (!(t && i >= 0 && i < int32_t(t->tables.size()) && t->tables[i]->fusable())) return 0;
+  return t->tables[i]->basic_opts() ? 1 : 2;
 }
 
 mhte_status mhte_value_offsets(const uint32_t* seg_off, const uint32_t* seg_pos,
@@ -3717,14 +3739,13 @@ mhte_status mhte_multi_step_backward(mhte_multi_step* s, const float* value, int
                                      const float* learning_rate, int64_t n_learning_rate,
                                      int64_t update_time, int64_t global_step, int32_t flags,
                                      void* stream) {
-  (void)global_step;
   return guard([&] {
     if (!s) throw Error(MHTE_INVALID_ARGUMENT, "null multi step");
     HIP_OK(hipSetDevice(s->ms.device));
     std::vector<std::unique_lock<std::mutex>> locks;
     for (auto& tb : s->ms.mt->tables) locks.emplace_back(tb->mu);
     s->ms.backward(value, value_len, learning_rate, n_learning_rate, update_time,
-                   (flags & MHTE_EXACT_ORDER) != 0, S(stream));
+                   (flags & MHTE_EXACT_ORDER) != 0, S(stream), global_step);
   });
 }
 

@@ -1257,7 +1257,8 @@ __device__ __forceinline__ long long wave_insert_slot(Bucket* buckets, uint32_t 
 // GATED: other workgroups of the same launch wait for n_pending == 0 before they touch the table
 // (lookup_role's gate): the pass ends with an agent-scope release (its bucket and row stores are
 // written back from this XCD's L2) followed by an agent-scope store of the 0.
-template <int VEC, int OP, bool SOLO, bool GATED = false>
+// BASIC (gated launches = the fused step kernels): the update code of SGD / Adagrad / FTRL only.
+template <int VEC, int OP, bool SOLO, bool GATED = false, bool BASIC = GATED>
 __device__ __forceinline__ void slowpath_role(const TableView& tv, const int64_t* __restrict__ ids,
                                               const float* __restrict__ values,
                                               const uint32_t* __restrict__ seg_off,
@@ -1297,8 +1298,8 @@ __device__ __forceinline__ void slowpath_role(const TableView& tv, const int64_t
       // (skip: first occurrence the admission filter let through, upsert_kernel)
       const uint32_t q0 = (skip && seg_off) ? skip[g] : (seg_off ? seg_off[g] : 0u);
       const uint32_t q1 = seg_off ? seg_off[g + 1] : 1u;
-      apply_row<64, VEC, OP, GATED>(tv, row_ptr(tv, r), true, lane, values, seg_off ? seg_pos : nullptr,
-                             q0, q1, g, a);
+      apply_row<64, VEC, OP, BASIC, (GATED ? false : true)>(tv, row_ptr(tv, r), true, lane, values,
+                                                            seg_off ? seg_pos : nullptr, q0, q1, g, a);
       if (OP == kOpReinit && lane == 0) {
         if (seg_off) {
           for (uint32_t t = q0; t < q1; ++t) status[seg_pos[t]] = (t == q0) ? 0 : 1;
@@ -2500,6 +2501,98 @@ __device__ __forceinline__ void optimize_row_reg(const TableView& tv, float* rp,
   w.store(rp + e);
   if (has1) s1.store(st1);
   if (has2) s2.store(st2);
+}
+
+// The same for a table that uses ANY per-element optimizer (Momentum, Adadelta, RMSProp v1 / v2, Adam,
+// AMSGrad, MovingAverage, BatchSoftmax beside SGD / Adagrad / FTRL; not the whole-segment GroupAdaGrad):
+// the fused step kernels' FULL instantiations.  Kept apart from optimize_row_reg so that the kernels
+// of SGD / Adagrad / FTRL tables keep their register budget (the twelve-way switch costs ~20 VGPRs).
+// Arithmetic: the one source of apply_row (optimizer steps of mhte_core.h), one Optimize() call.
+template <int VEC>
+__device__ __forceinline__ void optimize_row_reg_full(const TableView& tv, float* rp, bool is_new,
+                                                      uint32_t e, const Vec<VEC>& g, const ApplyArgs& a) {
+  if (e >= tv.dim) return;
+  uint32_t k = 0;
+  const SegDesc sd = seg_of<false>(tv, e, k);
+  const uint32_t le = e - sd.w_off;
+  const float lr = a.lr[k];
+  const int nv = opt_vectors(sd.opt);
+  const bool scal = opt_scalars(sd.opt) != 0;
+  const bool bsm = sd.opt == kOptBatchSoftmax;
+  Vec<VEC> w, s1, s2, s3;
+  float* st1 = rp + sd.st_off + le;
+  float* st2 = st1 + sd.dim;
+  float* st3 = st2 + sd.dim;
+  float* sc = rp + sd.st_off + nv * sd.dim;
+  float c1 = 0.f, c2 = 0.f;
+  long long last_step = 0;
+  if (is_new) {
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      w.v[c] = init_weight(sd, rp + e + c);
+      s1.v[c] = opt_state_init(sd, 0);
+      s2.v[c] = opt_state_init(sd, 1);
+      s3.v[c] = opt_state_init(sd, 2);
+    }
+    c1 = sd.p[0];
+    c2 = sd.p[1];
+  } else {
+    w.load(rp + e);
+    if (nv > 0) s1.load(st1);
+    if (nv > 1) s2.load(st2);
+    if (nv > 2) s3.load(st3);
+    if (scal) {
+      c1 = sc[0];
+      c2 = sc[1];
+    }
+    if (bsm)
+      last_step = static_cast<long long>(
+          (static_cast<unsigned long long>(__float_as_uint(sc[1])) << 32) | __float_as_uint(sc[0]));
+  }
+  const float lr_eff = scal ? adam_lr(lr, c1, c2) : lr;
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) {
+    switch (sd.opt) {
+      case kOptSgd: w.v[c] = sgd_step(w.v[c], g.v[c], lr); break;
+      case kOptAdagrad: adagrad_step(w.v[c], s1.v[c], g.v[c], lr, sd.p[1]); break;
+      case kOptFtrl: ftrl_step(w.v[c], s1.v[c], s2.v[c], g.v[c], lr, sd.p[1], sd.p[2], sd.p[3]); break;
+      case kOptMomentum: momentum_step(w.v[c], s1.v[c], g.v[c], lr, sd.p[0], sd.p[1], sd.p[2] != 0.f); break;
+      case kOptAdadelta: adadelta_step(w.v[c], s1.v[c], s2.v[c], g.v[c], lr, sd.p[0], sd.p[1], sd.p[2]); break;
+      case kOptRmsprop: rmsprop_step(w.v[c], s1.v[c], g.v[c], double(sd.p[2]), sd.p[0], sd.p[1], false); break;
+      case kOptRmspropV2: rmsprop_step(w.v[c], s1.v[c], g.v[c], double(lr), sd.p[0], sd.p[1], true); break;
+      case kOptAdam:
+        adam_step(w.v[c], s1.v[c], s2.v[c], nullptr, g.v[c], lr_eff, sd.p[0], sd.p[1], sd.p[2], sd.p[3],
+                  sd.p[4] != 0.f);
+        break;
+      case kOptMovingAverage: w.v[c] = moving_average_step(w.v[c], g.v[c], sd.p[0]); break;
+      case kOptBatchSoftmax: batch_softmax_step(w.v[c], last_step, lr, a.global_step); break;
+      default:  // kOptAmsgrad
+        adam_step(w.v[c], s1.v[c], s2.v[c], &s3.v[c], g.v[c], lr_eff, sd.p[0], sd.p[1], sd.p[2], sd.p[3],
+                  sd.p[4] != 0.f);
+        break;
+    }
+  }
+  if (scal) {
+    c1 = c1 * sd.p[0];
+    c2 = c2 * sd.p[1];
+  }
+  w.store(rp + e);
+  if (nv > 0) s1.store(st1);
+  if (nv > 1) s2.store(st2);
+  if (nv > 2) s3.store(st3);
+  if (scal && le == 0) {
+    sc[0] = c1;
+    sc[1] = c2;
+    sc[2] = 0.f;
+    sc[3] = 0.f;
+  }
+  if (bsm && le == 0) {
+    const unsigned long long gs = static_cast<unsigned long long>(last_step);
+    sc[0] = __uint_as_float(uint32_t(gs));
+    sc[1] = __uint_as_float(uint32_t(gs >> 32));
+    sc[2] = 0.f;
+    sc[3] = 0.f;
+  }
 }
 
 // probe + insert + apply for the id of unique index u, gradient vector in registers.  Wave-uniform

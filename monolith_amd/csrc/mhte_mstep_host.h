@@ -354,6 +354,7 @@ struct MultiStep {
   }
 
   struct BwdPlan {
+    int64_t global_step = 0;
     const float* grads = nullptr;
     const int64_t* split = nullptr;   // of the batch in slot `cur` (nullptr: build only)
     const float* lrs = nullptr;
@@ -379,13 +380,16 @@ struct MultiStep {
       A.grads = p.grads;
       A.cur = uint32_t(slot_cur);
       uint32_t gx = 0;
-      bool any_apply = false;
+      bool any_apply = false, any_full = false, any_basic = false;
       for (uint32_t k = 0; k < tc; ++k) {
         const uint32_t t = t0 + k;
         MBwdTab& bt = A.tab[k];
         const Table& tb = *mt->tables[t];
         const uint32_t n = p.grads ? n_slot[slot_cur][t] : 0u;
         bt.build_next = (build_next && n_slot[slot_cur ^ 1][t]) ? 1u : 0u;
+        bt.full = tb.basic_opts() ? 0u : 1u;
+        any_full = any_full || bt.full;
+        any_basic = any_basic || !bt.full;
         bt.n = n;
         bt.n_next = n_slot[slot_cur ^ 1][t];
         uint32_t blocks = bt.build_next ? h_st[t].nblk_build : 0u;
@@ -399,7 +403,7 @@ struct MultiStep {
           bt.a.ts = static_cast<uint32_t>(p.update_time);
           bt.a.sum_dups = 1;
           bt.a.filter_mode = 1;
-          bt.a.global_step = 0;
+          bt.a.global_step = p.global_step;
           bt.light_max = p.exact_order ? 0xffffffffu : uint32_t(kStepLightMax);
           bt.hints = (has_hints[slot_cur] && fwd_epoch[slot_cur][t] == tb.mut_epoch) ? 1u : 0u;
           const uint32_t groups_per_wg = 256u / h_st[t].g;
@@ -419,7 +423,10 @@ struct MultiStep {
       }
       if (gx == 0) continue;
       A.trace = trace_region(kTagMStepBwd, gx * tc, 256);
-      LAUNCH_HOT(kTagMStepBwd, mstep_bwd_kernel, dim3(gx, tc), 256, st, A);
+      // one launch per optimizer family present (the BASIC instantiation keeps the register budget
+      // of SGD / Adagrad / FTRL tables; a workgroup of the other family's table leaves at once)
+      if (any_basic) LAUNCH_HOT(kTagMStepBwd, mstep_bwd_kernel<false>, dim3(gx, tc), 256, st, A);
+      if (any_full) LAUNCH_HOT(kTagMStepBwd, mstep_bwd_kernel<true>, dim3(gx, tc), 256, st, A);
       HIP_OK(hipGetLastError());
       if (any_apply) {
         mstep_slow_kernel<<<tc, 64, 0, st>>>(A);
@@ -548,7 +555,7 @@ struct MultiStep {
   }
 
   void backward(const float* grads, int64_t grads_len, const float* lrs, int64_t n_lr,
-                int64_t update_time, bool exact_order, hipStream_t st) {
+                int64_t update_time, bool exact_order, hipStream_t st, int64_t global_step = 0) {
     if (stage[cur] == 0)
       throw Error(MHTE_FAILED_PRECONDITION, "multi step backward: no forward batch outstanding");
     if (!grads || !lrs) throw Error(MHTE_INVALID_ARGUMENT, "multi step backward: null argument");
@@ -584,6 +591,7 @@ struct MultiStep {
     p.lrs = lrs;
     p.update_time = update_time;
     p.exact_order = exact_order;
+    p.global_step = global_step;
     const int nxt = cur ^ 1;
     const bool build_next = stage[nxt] == 1;
     if (build_next) join_dedup(nxt, st);

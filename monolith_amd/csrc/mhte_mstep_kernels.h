@@ -80,7 +80,8 @@ struct MBwdTab {
                                // nothing has touched the table since
   uint32_t n;                  // ids of the batch in slot cur
   uint32_t n_next;             // ids of the batch in slot cur ^ 1
-  uint32_t pad;
+  uint32_t full;               // 1: the table uses optimizers beyond SGD / Adagrad / FTRL (the
+                               // mstep_bwd_kernel<true> launch serves it, <false> the others)
   ApplyArgs a;
 };
 struct MBwdArgs {
@@ -458,25 +459,27 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
 // ---------------------------------------------------------------------------------------------
 // backward: per table   numbering + heavy work list of the NEXT batch | apply of this batch
 // ---------------------------------------------------------------------------------------------
-template <bool ONESEG>
+template <bool ONESEG, bool FULL>
 __device__ __forceinline__ void mstep_apply_switch(uint32_t g, const TableView& tv, const RunView& d,
                                                    const ApplyCtl& c, const ApplyArgs& a,
                                                    uint32_t bid, WaveTrace& wt, ApplyLds& L) {
   switch (g) {
-    case 8: rd_apply_role<8, 4, ONESEG, true>(tv, d, c, a, bid, wt, L); break;
-    case 16: rd_apply_role<16, 4, ONESEG, true>(tv, d, c, a, bid, wt, L); break;
-    case 32: rd_apply_role<32, 4, ONESEG, true>(tv, d, c, a, bid, wt, L); break;
-    default: rd_apply_role<64, 4, ONESEG, true>(tv, d, c, a, bid, wt, L); break;
+    case 8: rd_apply_role<8, 4, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L); break;
+    case 16: rd_apply_role<16, 4, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L); break;
+    case 32: rd_apply_role<32, 4, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L); break;
+    default: rd_apply_role<64, 4, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L); break;
   }
 }
 
 #ifndef MHTE_MBWD_OCC
 #define MHTE_MBWD_OCC kBwdBlocksPerCu
 #endif
+template <bool FULL>
 __global__ __launch_bounds__(256, MHTE_MBWD_OCC) void mstep_bwd_kernel(MBwdArgs A) {
   __shared__ ApplyLds L;
   const uint32_t t = blockIdx.y;
   const MBwdTab& bt = A.tab[t];
+  if ((bt.full != 0u) != FULL) return;   // the other family's launch serves this table
   const MStepStatic& s = deref_const(A.st + t);
   WaveTrace wt(A.trace);
   uint32_t bid = blockIdx.x;
@@ -508,8 +511,9 @@ __global__ __launch_bounds__(256, MHTE_MBWD_OCC) void mstep_bwd_kernel(MBwdArgs 
   c.urow = bt.hints ? s.urow[cur] : nullptr;
   c.uloc = bt.hints ? s.uloc[cur] : nullptr;
   c.uts = bt.hints ? s.uts[cur] : nullptr;
-  if (s.oneseg) mstep_apply_switch<true>(s.g, tv, d, c, bt.a, bid, wt, L);
-  else mstep_apply_switch<false>(s.g, tv, d, c, bt.a, bid, wt, L);
+  if (FULL) mstep_apply_switch<false, true>(s.g, tv, d, c, bt.a, bid, wt, L);
+  else if (s.oneseg) mstep_apply_switch<true, false>(s.g, tv, d, c, bt.a, bid, wt, L);
+  else mstep_apply_switch<false, false>(s.g, tv, d, c, bt.a, bid, wt, L);
   wt.end(bid < bt.nblk_items ? 7u : 8u);
 }
 

@@ -832,7 +832,9 @@ struct ApplyLds {
   uint32_t last;
 };
 
-template <int G, int VEC, bool ONESEG, bool HINT = false>
+// FULL: the table uses per-element optimizers beyond SGD / Adagrad / FTRL (optimize_row_reg_full; no
+// row prefetch: the state layout is the optimizer's); the host picks the instantiation.
+template <int G, int VEC, bool ONESEG, bool HINT = false, bool FULL = false>
 __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView& d,
                                               const ApplyCtl& c, const ApplyArgs& a, uint32_t bid,
                                               WaveTrace& wt, ApplyLds& L) {
@@ -933,7 +935,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       if (__any(pre)) {
         uint32_t frow = __shfl(pr.row, gbase + (uf.owner < 0 ? 0 : uf.owner));
         if (hinted) frow = hrow;
-        if (pre) row_prefetch<VEC, ONESEG>(tv, row_ptr(tv, frow), e, rr);
+        if (pre && !FULL) row_prefetch<VEC, ONESEG>(tv, row_ptr(tv, frow), e, rr);
       }
       if (__any(flat)) {
         uint32_t xr[PER];
@@ -1033,14 +1035,15 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       float* rp = nullptr;
       if (valid && !sr.deferred) {
         rp = row_ptr(tv, sr.r);
-        if (!sr.is_new && !pre) row_prefetch<VEC, ONESEG>(tv, rp, e, rr);  // (the side slot's row)
+        if (!FULL && !sr.is_new && !pre) row_prefetch<VEC, ONESEG>(tv, rp, e, rr);  // (the side slot's row)
       }
       if (it == 0) wt.mark(3);
       if (sr.deferred) {
         if (ev) acc.store(c.grad_u + g * int64_t(dim) + e);
         if (j == 0) c.pending[atomicAdd(&tv.ctr->n_pending, 1u)] = uint32_t(g);
       } else if (valid) {
-        optimize_row_pre<VEC, ONESEG>(tv, rp, sr.is_new, e, acc, a, rr);
+        if (FULL) optimize_row_reg_full<VEC>(tv, rp, sr.is_new, e, acc, a);
+        else optimize_row_pre<VEC, ONESEG>(tv, rp, sr.is_new, e, acc, a, rr);
       }
       if (it == 0) wt.mark(4);
       if (HINT) lds_wave_sync();  // (sh_pos is the group's own)
@@ -1218,7 +1221,8 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         if (ev) tot.store(c.grad_u + int64_t(hd.u) * dim + e);
         if (j == 0) c.pending[atomicAdd(&tv.ctr->n_pending, 1u)] = hd.u;
       } else if (valid) {
-        optimize_row_reg<VEC, ONESEG>(tv, row_ptr(tv, sr.r), sr.is_new, e, tot, a);
+        if (FULL) optimize_row_reg_full<VEC>(tv, row_ptr(tv, sr.r), sr.is_new, e, tot, a);
+        else optimize_row_reg<VEC, ONESEG>(tv, row_ptr(tv, sr.r), sr.is_new, e, tot, a);
       }
     }
     wt.mark(4);
@@ -1320,7 +1324,9 @@ __device__ __forceinline__ void rd_prealloc_role(const TableView& tv, const PreA
 //            the lookup workgroups gate on it) | lookup of this batch
 // (<= 80 SGPRs: with more, the hardware admits 7 wavefronts per SIMD and only ONE of these
 // 16-wavefront workgroups per CU instead of two — MI355X_MICROARCH.md, residency)
-template <int G, int VEC, int UNR>
+// BASIC: the table's optimizers are SGD / Adagrad / FTRL (the displacement role is compiled for those
+// three: 17 spilled VGPRs with all twelve); BASIC = false: any per-element optimizer.
+template <int G, int VEC, int UNR, bool BASIC = true>
 __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void step_fwd_kernel(RunView nxt, TableView tv,
                                                             const int64_t* __restrict__ ids,
                                                             int64_t n, float* __restrict__ out,
@@ -1342,8 +1348,8 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
       if (threadIdx.x < 64) {
         BfsSlot* q = reinterpret_cast<BfsSlot*>(&L);
         CuckooRecord* path = reinterpret_cast<CuckooRecord*>(q + kMaxCuckooCount);
-        slowpath_role<VEC, kOpOptimize, false, true>(tv, sp.uids, sp.grad_u, nullptr, nullptr, sp.a,
-                                                     nullptr, sp.pending, q, path);
+        slowpath_role<VEC, kOpOptimize, false, true, BASIC>(tv, sp.uids, sp.grad_u, nullptr, nullptr, sp.a,
+                                                            nullptr, sp.pending, q, path);
       }
       wt.end(4u);
       return;
@@ -1382,7 +1388,7 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
 
 // step_bwd:  heavy work list of the NEXT batch | apply of this batch
 // ONESEG: the table has one segment (the host picks the instantiation: see seg_of)
-template <int G, int VEC, bool ONESEG>
+template <int G, int VEC, bool ONESEG, bool FULL = false>
 __global__ __launch_bounds__(256, kBwdBlocksPerCu) void step_bwd_kernel(RunView nxt, uint32_t nblk_build,
                                                        TableView tv, RunView cur, ApplyCtl c,
                                                        ApplyArgs a) {
@@ -1394,7 +1400,7 @@ __global__ __launch_bounds__(256, kBwdBlocksPerCu) void step_bwd_kernel(RunView 
   }
   const uint32_t bid = blockIdx.x - nblk_build;
   __shared__ ApplyLds L;
-  rd_apply_role<G, VEC, ONESEG>(tv, cur, c, a, bid, wt, L);
+  rd_apply_role<G, VEC, ONESEG, false, FULL>(tv, cur, c, a, bid, wt, L);
   wt.end(bid < c.nblk_items ? 7u : 8u);
 }
 

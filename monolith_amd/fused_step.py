@@ -56,13 +56,18 @@ class SparseStep:
     self.name = table_name
     self.idx = table._index(table_name)  # pylint: disable=protected-access
     self.dim = table.get_table_dim_sizes()[self.idx]
-    self.fusable = bool(table._lib.mhte_table_fused_backward_ok(table.handle, self.idx))  # pylint: disable=protected-access
+    ok = int(table._lib.mhte_table_fused_backward_ok(table.handle, self.idx))  # pylint: disable=protected-access
+    self.fusable = ok != 0          # 1: SGD / Adagrad / FTRL, 2: any per-element optimizer
+    self._full_opts = ok == 2
     if not self.fusable:
       self.ordered_unique = True  # wide rows: segment sum + optimize on CSR lists
     # an occurrence filter: the UNPIPELINED update walks CSR occurrence lists (the admission decision
     # needs each id's count), so its dedup is the ordered one; the pipelined step consults the filter
     # itself and keeps its run dedup
-    self._plain_ordered = self.ordered_unique or getattr(table, "_hash_filter", None) is not None
+    # (likewise optimizers beyond SGD / Adagrad / FTRL: the unpipelined one-launch backward is
+    # compiled for those three; the others take segment sum + update on CSR lists there)
+    self._plain_ordered = (self.ordered_unique or getattr(table, "_hash_filter", None) is not None or
+                           self._full_opts)
     self.batch = batch
     self.exact_order = exact_order
     dev = torch.device("cuda:%d" % table._device)  # pylint: disable=protected-access

@@ -812,7 +812,8 @@ def test_remaining_optimizers_kat_and_oracle(name, tmp_path):
   segs = [entry.CombineAsSegment(d1, entry.ConstantsInitializer(0.25), _OPT_ENTRY[name]()),
           entry.CombineAsSegment(d2, entry.ZerosInitializer(), entry.AdagradOptimizer(0.05, 0.1))]
   mt2 = make({"t": entry.make_table_config(segs)})
-  assert not mt2._lib.mhte_table_fused_backward_ok(mt2.handle, 0)  # pylint: disable=protected-access
+  # (2 = fits the fused step through its FULL instantiations; 0 = the whole-segment GroupAdaGrad)
+  assert mt2._lib.mhte_table_fused_backward_ok(mt2.handle, 0) == (0 if name == "group_adagrad" else 2)  # pylint: disable=protected-access
   ot = O.Table([O.segment(d1, oopt, p=p, init=O.INIT_CONSTANT, init_value=0.25),
                 O.segment(d2, O.OPT_ADAGRAD, p=(0.1, 0.0))], 1)
   rng = np.random.default_rng(len(name))
@@ -834,6 +835,83 @@ def test_remaining_optimizers_kat_and_oracle(name, tmp_path):
     m_.apply_gradients({"t": (ids_t(ids), val_t(gr))}, req_time=200)
   np.testing.assert_array_equal(mt2.lookup({"t": ids_t(probe)})["t"].cpu().numpy(),
                                 mt3.lookup({"t": ids_t(probe)})["t"].cpu().numpy())
+
+
+@pytest.mark.parametrize("name", sorted(n for n in _OPT_ENTRY if n != "group_adagrad") + ["batch_softmax"])
+@pytest.mark.parametrize("how", ["pipelined", "plain", "multi"])
+def test_remaining_optimizers_on_the_fused_step(name, how):
+  """Round 2 sent tables with these optimizers down the unpipelined op-level path; now the training
+  step takes them (FULL instantiations of step_fwd / step_bwd / mstep_bwd): the pipelined two-launch
+  step, the unpipelined step, and the multi-table step with a MIX of optimizer families (two backward
+  launches, one per family) — duplicate gradients summed in occurrence order, ONE optimizer step per
+  distinct id, bit-exact against the oracle with MHTE_EXACT_ORDER."""
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from test_oracle import OPT_KATS
+  from monolith_amd.fused_step import MultiSparseStep
+  if name == "batch_softmax":
+    oopt, p, lr, mk, d1 = O.OPT_BATCH_SOFTMAX, (), 0.1, (lambda: entry.BatchSoftmaxOptimizer(0.1)), 1
+    # (a one-float segment: the row is not whole float4s, so it rides the VEC = 1 kernels)
+  else:
+    _, oopt, p, lr, _, _, _, _ = [k for k in OPT_KATS if k[0] == name][0]
+    mk, d1 = _OPT_ENTRY[name], 16
+  d2 = 16
+  segs = [entry.CombineAsSegment(d1, entry.ConstantsInitializer(0.25), mk()),
+          entry.CombineAsSegment(d2, entry.ZerosInitializer(), entry.AdagradOptimizer(0.05, 0.1))]
+  osegs = [O.segment(d1, oopt, p=p, init=O.INIT_CONSTANT, init_value=0.25), O.segment(d2, O.OPT_ADAGRAD, p=(0.1, 0.0))]
+  dim, B, steps = d1 + d2, 4096, 5
+  rng = np.random.default_rng(len(name) + len(how))
+  batches = [(rng.zipf(1.3, B) % 900).astype(np.int64) | (1 << 48) for _ in range(steps + 1)]
+  grads = [rng.standard_normal((B, dim)).astype(np.float32) * 0.1 for _ in range(steps)]
+  gstep = 1000
+
+  def oracle_step(ot, ids, g, lrs, t, gs):
+    uk, _, vo, vos, _ = O.unique_key_with_value_and_offset(ids, [0, ids.size], [g.shape[1]])
+    gu = O.fill_with_offset_map_gradient(np.arange(uk.size), [0, uk.size], g.ravel(), vo, vos,
+                                         [g.shape[1]]).reshape(-1, g.shape[1])
+    ot.optimize(uk, gu, lrs, t, global_step=gs)
+
+  if how == "multi":
+    if d1 % 4:
+      pytest.skip("the multi-table step takes rows of whole float4s")
+    cfgs = {"a_full": entry.make_table_config(segs),
+            "b_basic": entry.make_table_config([entry.CombineAsSegment(32, entry.ZerosInitializer(),
+                                                                       entry.AdagradOptimizer(0.01, 0.1))]),
+            "c_full": entry.make_table_config([entry.CombineAsSegment(16, entry.ZerosInitializer(), mk())])}
+    mt = make(cfgs)
+    ots = {"a_full": O.Table(osegs, 1), "b_basic": O.Table(O.segment(32, O.OPT_ADAGRAD, p=(0.1, 0.0)), 1),
+           "c_full": O.Table(O.segment(16, oopt, p=p), 1)}
+    lrs = {"a_full": [lr, 0.05], "b_basic": [0.01], "c_full": [lr]}
+    dims = {"a_full": dim, "b_basic": 32, "c_full": 16}
+    names = sorted(cfgs)
+    step = MultiSparseStep(mt, B, exact_order=True)
+    rag = [mt.get_ragged_id({n: ids_t(batches[s] + k) for k, n in enumerate(names)}) for s in range(steps + 1)]
+    for s in range(steps):
+      emb = step.forward(rag[s], rag[s + 1])
+      views = mt.get_embeddings(rag[s], emb)
+      flat = []
+      for k, n in enumerate(names):
+        ids = batches[s] + k
+        np.testing.assert_array_equal(views[n].cpu().numpy(), ots[n].lookup(ids)[0], err_msg="%s step %d" % (n, s))
+        g = (np.random.default_rng(100 * s + k).standard_normal((B, dims[n])) * 0.1).astype(np.float32)
+        flat.append(g.ravel())
+        oracle_step(ots[n], ids, g, lrs[n], 100 + s, gstep + 3 * s)
+      step.backward(val_t(np.concatenate(flat)), 100 + s, global_step=gstep + 3 * s)
+    for k, n in enumerate(names):
+      probe = np.unique(np.concatenate([b + k for b in batches[:steps]]))
+      np.testing.assert_array_equal(mt.lookup({n: ids_t(probe)})[n].cpu().numpy(), ots[n].lookup(probe)[0])
+    return
+  mt = make({"t": entry.make_table_config(segs)})
+  ot = O.Table(osegs, 1)
+  step = SparseStep(mt, "t", B, exact_order=True)
+  dev_ids = [ids_t(b) for b in batches]
+  for s in range(steps):
+    emb = step.forward(dev_ids[s], next_ids=dev_ids[s + 1] if how == "pipelined" else None)
+    np.testing.assert_array_equal(emb.cpu().numpy(), ot.lookup(batches[s])[0], err_msg="step %d" % s)
+    step.backward(val_t(grads[s]), 100 + s, global_step=gstep + 3 * s)
+    oracle_step(ot, batches[s], grads[s], [lr, 0.05], 100 + s, gstep + 3 * s)
+  probe = np.unique(np.concatenate(batches[:steps]))
+  np.testing.assert_array_equal(mt.lookup({"t": ids_t(probe)})["t"].cpu().numpy(), ot.lookup(probe)[0])
+  assert mt.size("t") == ot.size()
 
 
 def test_batch_softmax_optimizer(tmp_path):
