@@ -667,6 +667,12 @@ mhte_status mhte_shard_step_backward(mhte_shard_step* s, const float* value, int
  * NT/distributed_ps_sync.py:199-203,270-275).  The caller's next-batch ids must stay valid until the
  * following forward call. */
 mhte_status mhte_shard_step_set_overlap(mhte_shard_step* s, int32_t mode);
+/* bits 16 (or MHTE_SHARD_GRAD_FP16=1 at creation): the gradient exchange carries fp16 — the sender
+ * rounds its per-id sums to nearest even, the owner widens them before its update — half the link
+ * bytes of exchange 3.  A numerics change the reference offers as an option (`grad_flat` cast to
+ * tf.float16 around the gradient all-to-all, NT/distributed_ps_sync.py:47,334-337); every rank of the
+ * world must make the same choice, before its first backward.  bits 32: fp32 (default). */
+mhte_status mhte_shard_step_set_grad_bits(mhte_shard_step* s, int32_t bits);
 /* waits for the stream, then reports a block overflow of the steps enqueued so far */
 mhte_status mhte_shard_step_check(mhte_shard_step* s, void* stream);
 /* distinct ids per table of this rank's forward batch (host int64[T]); synchronises */

@@ -126,7 +126,7 @@ EXPORTS = [
     "mhte_multi_step_backward", "mhte_multi_step_unique_counts",
     "mhte_shard_unique_id", "mhte_shard_step_create", "mhte_shard_step_destroy",
     "mhte_shard_step_create_ipc", "mhte_shard_step_ipc_handle", "mhte_shard_step_ipc_connect",
-    "mhte_shard_step_ipc_selftest", "mhte_shard_step_set_overlap", "mhte_shard_step_forward", "mhte_shard_step_backward", "mhte_shard_step_check",
+    "mhte_shard_step_ipc_selftest", "mhte_shard_step_set_overlap", "mhte_shard_step_set_grad_bits", "mhte_shard_step_forward", "mhte_shard_step_backward", "mhte_shard_step_check",
     "mhte_shard_step_info", "mhte_shard_step_unique_counts", "mhte_shard_group_forward", "mhte_shard_group_backward",
     "mhte_multi_table_create_from_proto", "mhte_multi_table_find", "mhte_multi_table_is_initialized",
     "mhte_hash_filter_create_from_proto", "mhte_lookup_entry", "mhte_feature_stat",

@@ -9,6 +9,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC mhte.hip
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <hip/hip_fp16.h>
 
 #include <algorithm>
 #include <chrono>
@@ -3882,6 +3883,16 @@ mhte_status mhte_shard_step_set_overlap(mhte_shard_step* s, int32_t mode) {
     auto locks = lock_tables(&s, 1);
     if (s->ss.aux_pending) HIP_OK(hipStreamSynchronize(s->ss.aux));
     s->ss.set_overlap(mode);
+  });
+}
+
+mhte_status mhte_shard_step_set_grad_bits(mhte_shard_step* s, int32_t bits) {
+  return guard([&] {
+    if (!s) throw Error(MHTE_INVALID_ARGUMENT, "null shard step");
+    HIP_OK(hipSetDevice(s->ss.device));
+    auto locks = lock_tables(&s, 1);
+    HIP_OK(hipDeviceSynchronize());
+    s->ss.set_grad_bits(bits);
   });
 }
 

@@ -142,6 +142,13 @@ struct ShardStep {
   // enqueues between forward and backward (layout -> MLP -> layout gradient); the backward launch
   // then carries the gradient sums only.  The reference pipelines the same stages with its
   // prefetch queues (NT/distributed_ps_sync.py:199-203, 270-275).
+  // ---- the fp16 gradient wire (MHTE_SHARD_GRAD_FP16=1 / mhte_shard_step_set_grad_bits(16)): the
+  // gradient exchange moves half the bytes; a NUMERICS change the reference offers as an option
+  // (NT/distributed_ps_sync.py:47,334-337), every rank must choose the same
+  int grad_bits = 32;
+  unsigned short* snd_grads16 = nullptr;   // sender: fp16 of snd_grads, [world][rows_block]
+  unsigned short* own_grads16 = nullptr;   // owner: what arrives (peer stores: the window's gradient region)
+  float* own_grads32 = nullptr;            // peer stores only: the fp32 the owner's update reads
   int overlap = 0;
   hipStream_t aux = nullptr;
   hipEvent_t ev_in = nullptr, ev_aux = nullptr;
@@ -168,6 +175,9 @@ struct ShardStep {
     if (own_rows) (void)hipFree(own_rows);
     if (snd_rows && !alias && !ipc) (void)hipFree(snd_rows);
     if (ipc && snd_grads) (void)hipFree(snd_grads);
+    if (snd_grads16) (void)hipFree(snd_grads16);
+    if (own_grads16 && !ipc) (void)hipFree(own_grads16);
+    if (own_grads32) (void)hipFree(own_grads32);
     if (win) (void)hipFree(win);
     if (h_flags) (void)hipHostFree(h_flags);
     for (int s = 0; s < 2; ++s) {
@@ -263,6 +273,7 @@ struct ShardStep {
         HIP_OK(hipEventCreateWithFlags(&ev_cnt[s], hipEventDisableTiming));
       }
     if (const char* e = getenv("MHTE_SHARD_OVERLAP")) set_overlap(atoi(e));
+    if (const char* e = getenv("MHTE_SHARD_GRAD_FP16")) set_grad_bits(atoi(e) != 0 ? 16 : 32);
     if (unique_id) {
       Rccl& R = Rccl::get();
       ncclUniqueId id;
@@ -273,6 +284,41 @@ struct ShardStep {
   }
 
   bool local_group_member() const { return world > 1 && comm == nullptr && !ipc; }
+
+  void set_grad_bits(int bits) {
+    if (bits != 16 && bits != 32) throw Error(MHTE_INVALID_ARGUMENT, "shard step: gradient wire is 32 or 16 bits");
+    if (bits == 16 && alias)
+      throw Error(MHTE_INVALID_ARGUMENT, "shard step: the identity exchange (world 1) has no wire to narrow");
+    if (bits == 16 && !snd_grads16) {
+      const size_t hb = size_t(geo.rows_block) * world * 2 + 64;
+      HIP_OK(hipMalloc(reinterpret_cast<void**>(&snd_grads16), hb));
+      if (ipc) {
+        own_grads16 = reinterpret_cast<unsigned short*>(win + win_off_grads);
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&own_grads32), size_t(geo.rows_block) * world * 4 + 64));
+      } else {
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&own_grads16), hb));
+      }
+    }
+    grad_bits = bits;
+  }
+  // the fp32 buffer the owner's update reads
+  float* apply_grads() const { return (grad_bits == 16 && ipc) ? own_grads32 : own_grads; }
+  template <bool NARROW>
+  void cvt(const int64_t* counts, const void* src, void* dst, int peer_lo, int peer_n, hipStream_t st) {
+    ShardCvtArgs A{};
+    A.counts = counts;
+    A.src = src;
+    A.dst = dst;
+    A.geo = geo;
+    A.peer_lo = uint32_t(peer_lo);
+    A.peer_n = uint32_t(peer_n);
+    fill_tabs(A.tab);
+    uint32_t gx = 1;
+    for (uint32_t t = 0; t < T; ++t) gx = std::max(gx, (cap * tab[t].dim / 4u + 1023u) / 1024u);
+    gx = std::min<uint32_t>(gx, std::max<uint32_t>(4, uint32_t(ms.num_cus) * 4 / (uint32_t(peer_n) * T)));
+    shard_cvt_kernel<NARROW><<<dim3(gx, uint32_t(peer_n) * T), 256, 0, st>>>(A);
+    HIP_OK(hipGetLastError());
+  }
 
   void set_overlap(int mode) {
     overlap = mode != 0 ? 1 : 0;
@@ -403,7 +449,8 @@ struct ShardStep {
     return kind == kXIds ? uint32_t(slot ? kChIds1 : kChIds0) : kind == kXRows ? uint32_t(kChRows) : uint32_t(kChGrads);
   }
 
-  void push(uint32_t chan, const void* src, const int64_t* counts, size_t dst_off, bool ids, hipStream_t st) {
+  void push(uint32_t chan, const void* src, const int64_t* counts, size_t dst_off, bool ids, hipStream_t st,
+            bool half = false) {
     if (!ipc_connected) throw Error(MHTE_FAILED_PRECONDITION, "shard step: mhte_shard_step_ipc_connect first");
     ShardPushArgs A{};
     for (int p = 0; p < world; ++p) A.win[p] = peer_win[p];
@@ -417,6 +464,7 @@ struct ShardStep {
     A.chan = chan;
     A.seq = ++seq_sent[chan];
     A.ids = ids ? 1u : 0u;
+    A.half = half ? 1u : 0u;
     fill_tabs(A.tab);
     // enough workgroups per peer to keep a link (or the local HBM) busy, few enough that a waiting
     // launch never fills the chip (another process may share the device)
@@ -466,7 +514,9 @@ struct ShardStep {
       push(ch, ids_send[slot], ids_send[slot], win_off_ids[slot], true, st);
     else if (kind == kXRows)   // rows of the ids every peer sent me: sized by the received headers
       push(ch, own_rows, ids_recv[slot], win_off_rows, false, st);
-    else                       // gradient sums of the ids I sent every peer
+    else if (grad_bits == 16)  // gradient sums of the ids I sent every peer, as fp16
+      push(ch, snd_grads16, ids_send[slot], win_off_grads, false, st, true);
+    else
       push(ch, snd_grads, ids_send[slot], win_off_grads, false, st);
   }
 
@@ -624,7 +674,7 @@ struct ShardStep {
     A.views = ConstViews(mt->d_views.p);
     A.geo = geo;
     A.recv_ids = ids_recv[slot];
-    A.rows = apply ? own_grads : own_rows;
+    A.rows = apply ? apply_grads() : own_rows;
     A.flags = d_flags;
     fill_tabs(A.tab);
     for (uint32_t t = 0; t < T; ++t) {
@@ -677,6 +727,7 @@ struct ShardStep {
     A.clear_ids = ids_send[slot];
     for (int p = 0; p < world; ++p) {
       wait_arrived(kXGrads, slot, p, p + 1, st);   // (a peer's block is applied as soon as it has landed)
+      if (grad_bits == 16) cvt<false>(ids_recv[slot], own_grads16, apply_grads(), p, 1, st);
       A.peer = uint32_t(p);
       A.zero_headers = p == world - 1 ? 1u : 0u;
       LAUNCH_HOT(kTagShardUpsert, shard_upsert_kernel, dim3(gx, T), 256, st, A);
@@ -697,14 +748,20 @@ struct ShardStep {
 
   const void* x_src(int kind, int slot) const {
     return kind == kXIds ? static_cast<const void*>(ids_send[slot])
-                         : kind == kXRows ? static_cast<const void*>(own_rows) : snd_grads;
+                         : kind == kXRows ? static_cast<const void*>(own_rows)
+                                          : (grad_bits == 16 ? static_cast<const void*>(snd_grads16) : snd_grads);
   }
   void* x_dst(int kind, int slot) const {
     return kind == kXIds ? static_cast<void*>(ids_recv[slot])
-                         : kind == kXRows ? static_cast<void*>(snd_rows) : own_grads;
+                         : kind == kXRows ? static_cast<void*>(snd_rows)
+                                          : (grad_bits == 16 ? static_cast<void*>(own_grads16) : own_grads);
   }
   size_t x_block(int kind) const {
-    return kind == kXIds ? size_t(geo.ids_block) * sizeof(int64_t) : size_t(geo.rows_block) * sizeof(float);
+    return kind == kXIds ? size_t(geo.ids_block) * sizeof(int64_t)
+                         : size_t(geo.rows_block) * x_elem(kind);
+  }
+  size_t x_elem(int kind) const {   // bytes per element of a row block on the wire
+    return (kind == kXGrads && grad_bits == 16) ? 2 : sizeof(float);
   }
 
   // after the id exchange of `slot`: its headers (ids sent to / received from every peer, per table)
@@ -737,9 +794,10 @@ struct ShardStep {
       R.ok(R.GroupStart(), "GroupStart");
       for (int p = 0; p < world; ++p)
         for (uint32_t t = 0; t < T; ++t) {
-          const size_t off = size_t(p) * b + size_t(tab[t].row_off) * sizeof(float);
-          const size_t ns = size_t(seg_rows(slot, out_sent, p, t)) * tab[t].dim * sizeof(float);
-          const size_t nr = size_t(seg_rows(slot, !out_sent, p, t)) * tab[t].dim * sizeof(float);
+          const size_t es = x_elem(kind);
+          const size_t off = size_t(p) * b + size_t(tab[t].row_off) * es;
+          const size_t ns = size_t(seg_rows(slot, out_sent, p, t)) * tab[t].dim * es;
+          const size_t nr = size_t(seg_rows(slot, !out_sent, p, t)) * tab[t].dim * es;
           if (ns) R.ok(R.Send(src + off, ns, ncclInt8, p, comm, st), "Send");
           if (nr) R.ok(R.Recv(dst + off, nr, ncclInt8, p, comm, st), "Recv");
         }
@@ -778,8 +836,8 @@ static void shard_exchange(ShardStep** S, int n, int kind, int slot, hipStream_t
       }
       // what rank r sends to p: gradients of the ids r sent to p / rows of the ids p sent to r
       for (uint32_t t = 0; t < S[r]->T; ++t) {
-        const size_t off = size_t(S[r]->tab[t].row_off) * sizeof(float);
-        const size_t nb = size_t(S[r]->seg_rows(slot, kind == kXGrads, p, t)) * S[r]->tab[t].dim * sizeof(float);
+        const size_t off = size_t(S[r]->tab[t].row_off) * S[r]->x_elem(kind);
+        const size_t nb = size_t(S[r]->seg_rows(slot, kind == kXGrads, p, t)) * S[r]->tab[t].dim * S[r]->x_elem(kind);
         if (nb) HIP_OK(hipMemcpyAsync(dst + off, src + off, nb, hipMemcpyDeviceToDevice, st));
       }
     }
@@ -897,6 +955,8 @@ static void shard_backward(ShardStep** S, int n, const float* const* grads, cons
     HIP_OK(hipSetDevice(S[r]->device));
     S[r]->prepare(st);
     S[r]->build_and_sum(build_next ? (cur ^ 1) : -1, cur, grads[r], st);
+    if (S[r]->grad_bits == 16)   // the sums leave as fp16
+      S[r]->cvt<true>(S[r]->ids_send[cur], S[r]->snd_grads, S[r]->snd_grads16, 0, S[r]->world, st);
   }
   shard_exchange(S, n, kXGrads, cur, st);
   if (build_next) {

@@ -349,6 +349,8 @@ struct ShardPushArgs {
   uint32_t chan;
   uint32_t seq;
   uint32_t ids;               // 1: id blocks (header + int64 slots), 0: row blocks (floats)
+  uint32_t half;              // row blocks of 16-bit elements (the fp16 gradient wire): dense
+                              // [world][rows_block] arrays of 16-bit words on both sides
   ShardTab tab[kMaxStepTables];
 };
 static_assert(sizeof(ShardPushArgs) <= 4096, "kernel arguments exceed 4 KB");
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(256) void shard_push_kernel(ShardPushArgs A) {
   }
   __syncthreads();
   if (!ok || !A.src) return;
-  const size_t blk = A.ids ? size_t(A.geo.ids_block) * 8 : size_t(A.geo.rows_block) * 4;
+  const size_t blk = A.ids ? size_t(A.geo.ids_block) * 8 : size_t(A.geo.rows_block) * (A.half ? 2 : 4);
   const char* src = A.src + size_t(p) * blk;
   char* dst = peer + A.dst_off + size_t(A.rank) * blk;
   const int64_t* hdr = A.counts + size_t(p) * A.geo.ids_block;
@@ -394,8 +396,53 @@ __global__ __launch_bounds__(256) void shard_push_kernel(ShardPushArgs A) {
     if (!n) continue;
     if (A.ids)
       ipc_copy16(dst + size_t(tb.id_off) * 8, src + size_t(tb.id_off) * 8, (n + 1u) / 2u, first, stride);
+    else if (A.half)
+      ipc_copy16(dst + size_t(tb.row_off) * 2, src + size_t(tb.row_off) * 2, (n * tb.dim * 2u + 15u) / 16u, first,
+                 stride);
     else
       ipc_copy16(dst + size_t(tb.row_off) * 4, src + size_t(tb.row_off) * 4, n * (tb.dim / 4u), first, stride);
+  }
+}
+
+// The fp16 gradient wire (the reference's optional cast of the gradient all-to-all,
+// NT/distributed_ps_sync.py:47,334-337: `grad_flat` goes out as tf.float16 and is cast back by the
+// owner): NARROW = sender, fp32 sums -> fp16 (round to nearest even) before the exchange; !NARROW =
+// owner, back to fp32 before the update.  The occupied part of every (peer, table) segment, sized by
+// the id blocks' headers.  grid (x, world * T).
+struct ShardCvtArgs {
+  const int64_t* counts;      // [world][ids_block]
+  const void* src;            // [world][rows_block] fp32 (NARROW) / 16-bit words at the same element offsets
+  void* dst;
+  ShardGeom geo;
+  uint32_t peer_lo, peer_n;   // peers [peer_lo, peer_lo + peer_n)
+  ShardTab tab[kMaxStepTables];
+};
+template <bool NARROW>
+__global__ __launch_bounds__(256) void shard_cvt_kernel(ShardCvtArgs A) {
+  const uint32_t p = A.peer_lo + blockIdx.y / A.geo.T, t = blockIdx.y % A.geo.T;
+  const ShardTab tb = A.tab[t];
+  const uint64_t c = uint64_t(A.counts[size_t(p) * A.geo.ids_block + t]);
+  const uint32_t n = c > tb.cap ? tb.cap : uint32_t(c);
+  const size_t base = size_t(p) * A.geo.rows_block + tb.row_off;   // element offset
+  const uint32_t total = n * tb.dim / 4u;                          // 4 elements per thread and trip
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    if (NARROW) {
+      const float4 v = reinterpret_cast<const float4*>(static_cast<const float*>(A.src) + base)[i];
+      ushort4 h;
+      h.x = __half_as_ushort(__float2half_rn(v.x));
+      h.y = __half_as_ushort(__float2half_rn(v.y));
+      h.z = __half_as_ushort(__float2half_rn(v.z));
+      h.w = __half_as_ushort(__float2half_rn(v.w));
+      reinterpret_cast<ushort4*>(static_cast<unsigned short*>(A.dst) + base)[i] = h;
+    } else {
+      const ushort4 h = reinterpret_cast<const ushort4*>(static_cast<const unsigned short*>(A.src) + base)[i];
+      float4 v;
+      v.x = __half2float(__ushort_as_half(h.x));
+      v.y = __half2float(__ushort_as_half(h.y));
+      v.z = __half2float(__ushort_as_half(h.z));
+      v.w = __half2float(__ushort_as_half(h.w));
+      reinterpret_cast<float4*>(static_cast<float*>(A.dst) + base)[i] = v;
+    }
   }
 }
 

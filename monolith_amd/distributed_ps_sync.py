@@ -537,6 +537,12 @@ class ShardedMultiStep:
     self._libmod.check(self._lib.mhte_shard_step_set_overlap(self._h, C.c_int32(1 if on else 0)))
     return self
 
+  def set_grad_fp16(self, on: bool = True):
+    """The gradient exchange in fp16 (mhte_shard_step_set_grad_bits; the reference's optional cast of
+    the gradient all-to-all): a numerics change, every rank must choose the same."""
+    self._libmod.check(self._lib.mhte_shard_step_set_grad_bits(self._h, C.c_int32(16 if on else 32)))
+    return self
+
   def info(self):
     out = (C.c_int64 * 4)()
     self._libmod.check(self._lib.mhte_shard_step_info(self._h, out))

@@ -188,6 +188,33 @@ def bench_filter_step():
       flt.close()
 
 
+def bench_step_optimizers():
+  """The pipelined two-launch training step on tables whose optimizer is not SGD / Adagrad / FTRL
+  (round 2: such tables took the unpipelined op-level path)."""
+  B, dim, K = 65536, 64, 80
+  V = int(1e8)
+  ids_all = [torch.from_numpy(S.id_batch(s, B, V)).to(DEV) for s in range(K + 12)]
+  grad = torch.from_numpy(S.grad_batch(0, B, dim)).to(DEV)
+  for name, opt in (("adagrad", entry.AdagradOptimizer(0.001, 0.1)), ("momentum", entry.MomentumOptimizer(0.01)),
+                    ("adam", entry.AdamOptimizer(0.01)), ("amsgrad", entry.AdamOptimizer(0.01, amsgrad=True))):
+    mt = make_table(opt, dim, (K + 20) * B, "sopt_" + name)
+    step = SparseStep(mt, "emb", B)
+
+    def run(lo, hi):
+      for s in range(lo, hi):
+        step.forward(ids_all[s], next_ids=ids_all[s + 1])
+        step.backward(grad, S.update_time(s), global_step=s)
+    run(0, 10)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    run(10, 10 + K)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / K
+    emit("pipelined training step, %s (dim 64, Zipf batch of 65 536, empty table at start)" % name, dt, None,
+         lookups_updates_per_s=round(2 * B / dt))
+    mt.close()
+
+
 def bench_gather():
   n_inputs, rows_each, dims = 16, 65536, [16, 32, 64, 32] * 4
   total = sum(rows_each * d for d in dims)
@@ -261,7 +288,8 @@ def main():
   for w in which:
     gc.collect()
     gc.disable()   # (a generation-2 pass of the interpreter is ~40 ms: it would land in a 60-step window)
-    {"optimizers": bench_optimizers, "gather": bench_gather, "reduce": bench_reduce,
+    {"optimizers": bench_optimizers, "step_optimizers": bench_step_optimizers, "gather": bench_gather,
+     "reduce": bench_reduce,
      "evict": bench_evict, "filter": bench_filter_step, "checkpoint": bench_checkpoint}[w]()
   md = ["| Measurement | time | algorithmic bytes | GB/s | of 8 TB/s | notes |", "|---|---|---|---|---|---|"]
   for r in LINES:

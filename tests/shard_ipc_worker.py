@@ -112,6 +112,8 @@ def main():
           g = grads_of(s, r, sp, ids.size)
           fg.append(g.ravel())
           uk, gu = oracle_backward(ots[sp.name], sp, ids, g)
+          if os.environ.get("MHTE_SHARD_GRAD_FP16") == "1":   # the sums cross the wire as fp16
+            gu = gu.astype(np.float16).astype(np.float32)
           ots[sp.name].optimize(uk, gu, sp.lrs(), S.update_time(s))
         if r == rank:
           mine = val_t(np.concatenate(fg))

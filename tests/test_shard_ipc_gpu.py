@@ -77,6 +77,16 @@ def test_processes_with_overlap(tmp_path):
   assert all(r["ok"] for r in res)
 
 
+def test_processes_fp16_gradient_wire(tmp_path):
+  """MHTE_SHARD_GRAD_FP16=1 between processes: the push narrows nothing itself — the sender's sums are
+  rounded to fp16 by a launch of their own, stored into the peers' windows as 16-bit words and widened by
+  the owner per peer — bit-exact against the oracle fed the same rounding."""
+  res = run_world(2, "uniform", 5, tmp_path, {"MHTE_SHARD_GRAD_FP16": "1"})
+  assert all(r["ok"] for r in res)
+  res = run_world(2, "uniform", 5, tmp_path, {"MHTE_SHARD_GRAD_FP16": "1", "MHTE_SHARD_OVERLAP": "1"})
+  assert all(r["ok"] for r in res)
+
+
 def test_coarse_window(tmp_path):
   """MHTE_SHARD_WINDOW=coarse: the windows as plain device memory (the A/B form)."""
   res = run_world(2, "uniform", 4, tmp_path, {"MHTE_SHARD_WINDOW": "coarse"})

@@ -79,7 +79,7 @@ def test_world1_identity_matches_multi_step(overlap):
 
 
 @pytest.mark.parametrize("dist,world", [("uniform", 3), ("zipf", 2), ("zipf", 5)])
-def test_group_against_oracle(dist, world):
+def test_group_against_oracle(dist, world, grad_fp16=False):
   specs = dlrm_specs(8, initial_capacity=1 << 10)
   by_name = sorted(specs, key=lambda s: s.name)
   B, steps = 3000, 5
@@ -128,6 +128,8 @@ def test_group_against_oracle(dist, world):
         g = grads_of(s, r, sp, ids.size)
         fg.append(g.ravel())
         uk, gu = oracle_backward(ots[sp.name], sp, ids, g)
+        if grad_fp16:   # the sender's sums cross the wire as fp16 (round to nearest even)
+          gu = gu.astype(np.float16).astype(np.float32)
         ots[sp.name].optimize(uk, gu, sp.lrs(), S.update_time(s))
       flat.append(val_t(np.concatenate(fg)))
     grp.backward(flat, S.update_time(s))
@@ -286,6 +288,17 @@ def test_sharded_step_with_occurrence_filters():
       np.testing.assert_array_equal(flts[o].get(torch.as_tensor(probe[absent]).cuda()).cpu().numpy(),
                                     [models[o].get(int(x)) for x in probe[absent]])
   grp.close()
+
+
+def test_fp16_gradient_wire(monkeypatch):
+  """MHTE_SHARD_GRAD_FP16=1 (the reference's optional fp16 cast of the gradient all-to-all,
+  distributed_ps_sync.py:47,334-337): the owners see every sender's per-id sums rounded to fp16 —
+  bit-exact against the oracle fed the same rounding; through device copies, RCCL's exact-size form
+  (send / recv to self) and the fixed-size form."""
+  monkeypatch.setenv("MHTE_SHARD_GRAD_FP16", "1")
+  test_group_against_oracle("uniform", 3, grad_fp16=True)
+  monkeypatch.setenv("MHTE_SHARD_EXACT", "1")
+  test_group_against_oracle("uniform", 2, grad_fp16=True)
 
 
 def test_block_overflow_is_reported():
