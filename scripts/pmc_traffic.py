@@ -108,7 +108,12 @@ def main():
         for nbytes, c in parts:
           mix[k][0] += nbytes
           mix[k][1] += nbytes * c
-    for name, r in (("mstep_fwd_kernel", "lookup"), ("mstep_bwd_kernel", "update")):
+    # (round 3: the lookup and the next batch's run dedup are one launch; the dedup's own reads are
+    # the ids, streamed, and its scratch, which lives in L2 — the ids are added to the lookup's mix)
+    for D_ in dims:
+      mix["lookup"][0] += 8 * Bt
+      mix["lookup"][1] += 8 * Bt * 0.5
+    for name, r in (("mstep_fwd_dedup_kernel", "lookup"), ("mstep_bwd_kernel", "update")):
       f, w = find(dl_f, name), find(dl_w, name)
       if not f or not w:
         continue
