@@ -1318,6 +1318,164 @@ __device__ __forceinline__ void slowpath_role(const TableView& tv, const int64_t
     if (lane == 0) tv.ctr->n_pending = 0;
   }
 }
+// ---------------------------------------------------------------------------------------------
+// The displacement pass with W wavefronts of ONE workgroup working on W pending ids at a time
+// (the multi-table step: a table defers 1-5 ids per step and a displacement is ~10 dependent round
+// trips, so one wavefront per table was 24-59 us of a 390 us step).  Per round of W ids:
+//   A  every wavefront searches a slot for its id WITHOUT writing — the home buckets' empty slot
+//      (try_find_insert_bucket, cuckoohash_map.hpp:1398-1418), else the BFS path (:1725-1762) — and
+//      publishes the buckets it will write (the path's, <= kMaxBfsPathLen) in LDS;
+//   B  a wavefront none of whose buckets is on the list of a LOWER wavefront of the round moves its
+//      path and writes its key: the buckets written in one sub-round are pairwise disjoint, and what
+//      a path's validity depends on is the content of its own buckets, which nobody has touched
+//      since the search.  The others search again after the barrier (the lowest unfinished
+//      wavefront is always clear: every sub-round finishes at least one id).
+// All wavefronts of a workgroup share one CU's L1, so the barrier (which drains the stores) is all
+// the visibility the rounds need.  The result is a valid cuckoo placement of the same key set; which
+// of several valid placements depends on the round structure, as the reference's does on its
+// threads' interleaving.  Row handles come from the table's counter as they do in the serial pass.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+struct SlowParLds {
+  BfsSlot q[W][kMaxCuckooCount];
+  CuckooRecord path[W][kMaxBfsPathLen];
+  unsigned long long wb[W][8];   // buckets wavefront w is going to write (sub-round)
+  int nwb[W];                    // 0: nothing to place in this sub-round
+  int again[2];
+};
+
+// phase A for one id: 0 = no slot (table over its load limit), 1 = slot found.  path[0..depth] is
+// the displacement path (depth 0: path[0] is an empty slot, of a home bucket or at the end of a
+// search whose first hop has since become free)
+__device__ __forceinline__ int wave_plan_slot(const Bucket* buckets, uint32_t hp, int64_t key,
+                                              BfsSlot* q, CuckooRecord* path, int lane, int* depth_out) {
+  const uint64_t hv = hash_key(key);
+  const uint64_t i1 = index_hash(hp, hv);
+  const uint64_t i2 = alt_index(hp, partial_key(hv), i1);
+  int found = -1;
+  if (lane < 8) {
+    const int64_t k = buckets[lane < 4 ? i1 : i2].key[lane & 3];
+    found = (k == kEmptyKey) ? 1 : 0;
+  }
+  const uint64_t fm = __ballot(found == 1) & 0xffull;
+  if (fm) {   // last empty slot of b1, else of b2
+    const int s = (fm & 0xfull) ? 63 - __builtin_clzll(fm & 0xfull) : (63 - __builtin_clzll(fm)) - 4;
+    if (lane == 0) {
+      path[0].bucket = (fm & 0xfull) ? i1 : i2;
+      path[0].slot = s;
+    }
+    *depth_out = 0;
+    return 1;
+  }
+  BfsSlot x = slot_search_wave(buckets, hp, i1, i2, q, lane);
+  if (x.depth == -1) return 0;
+  int depth = 0;
+  if (lane == 0) {  // cuckoopath_search's path reconstruction, :1508-1561
+    const int d0 = x.depth;
+    for (int i = x.depth; i >= 0; --i) {
+      path[i].slot = x.pathcode % kSlots;
+      x.pathcode = static_cast<uint16_t>(x.pathcode / kSlots);
+    }
+    path[0].bucket = (x.pathcode == 0) ? i1 : i2;
+    depth = d0;
+    const Bucket& b = buckets[path[0].bucket];
+    if (!slot_occupied(b, path[0].slot)) {
+      depth = 0;
+    } else {
+      path[0].hash = hash_key(b.key[path[0].slot]);
+      path[0].partial = partial_key(path[0].hash);
+      for (int i = 1; i <= d0; ++i) {
+        path[i].bucket = alt_index(hp, path[i - 1].partial, path[i - 1].bucket);
+        const Bucket& bi = buckets[path[i].bucket];
+        if (!slot_occupied(bi, path[i].slot)) {
+          depth = i;
+          break;
+        }
+        path[i].hash = hash_key(bi.key[path[i].slot]);
+        path[i].partial = partial_key(path[i].hash);
+      }
+    }
+  }
+  *depth_out = __shfl(depth, 0);
+  return 1;
+}
+
+template <int VEC, int OP, int W, bool BASIC>
+__device__ __forceinline__ void slowpath_par_role(const TableView& tv, const int64_t* __restrict__ ids,
+                                                  const float* __restrict__ values, const ApplyArgs& a,
+                                                  const uint32_t* __restrict__ pending,
+                                                  SlowParLds<W>& L) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t np = tv.ctr->n_pending;
+  if (np == 0) return;   // (uniform: every thread reads the same word)
+  if (threadIdx.x < 2) L.again[threadIdx.x] = 0;
+  uint32_t k = 0;        // sub-round counter (parity of the `again` word in use)
+  for (uint32_t base = 0; base < np; base += W) {
+    const uint32_t i = base + uint32_t(w);
+    const bool active = i < np;
+    const uint32_t g = active ? pending[i] : 0u;
+    const int64_t id = active ? ids[g] : 0;
+    uint32_t r;   // (lane 0's value; left uninitialised on the other path: see slowpath_role)
+    if (active && lane == 0) r = static_cast<uint32_t>(atomicAdd(&tv.ctr->alloc, (1ull << 32) | 1ull));
+    int state = active ? 0 : 2;   // 0 to place, 1 placed, 2 nothing to do / failed
+    int attempts = 0;
+    for (;; ++k) {
+      int depth = 0, have = 0;
+      if (state == 0) {
+        have = (++attempts <= 64) ? wave_plan_slot(tv.buckets, tv.hp, id, L.q[w], L.path[w], lane, &depth) : 0;
+        if (!have) {   // no path of length <= 5: the key is not inserted (reported at the next call)
+          state = 2;
+          if (lane == 0) {
+            atomicAdd(&tv.ctr->alloc, ~((1ull << 32) - 1ull));
+            atomicOr(&tv.ctr->error, 1u);
+            atomicAdd(&tv.ctr->n_dropped, 1u);
+          }
+        }
+      }
+      if (lane == 0) {
+        L.nwb[w] = have ? depth + 1 : 0;
+        for (int e = 0; e <= depth && have; ++e) L.wb[w][e] = L.path[w][e].bucket;
+      }
+      __syncthreads();
+      if (state == 0) {
+        // lane -> (lower wavefront, entry of its list) against this wavefront's buckets
+        const int ow = lane >> 3, oe = lane & 7;
+        bool hit = false;
+        if (ow < w && ow < W && oe < L.nwb[ow]) {
+          const unsigned long long ob = L.wb[ow][oe];
+          for (int e = 0; e <= depth; ++e) hit |= (L.wb[w][e] == ob);
+        }
+        const bool clear = __ballot(hit) == 0ull;
+        int ok = 0;
+        if (clear && lane == 0) {
+          CuckooRecord* path = L.path[w];
+          if (cuckoopath_move(tv.buckets, path, depth)) {
+            Bucket* b = tv.buckets + path[0].bucket;
+            b->row[path[0].slot] = r;
+            b->ts[path[0].slot] = a.ts;
+            b->key[path[0].slot] = id;
+            ok = 1;
+          }
+        }
+        ok = __shfl(ok, 0);
+        if (ok) state = 1;
+        else if (lane == 0) L.again[k & 1u] = 1;
+      }
+      __syncthreads();
+      const int more = L.again[k & 1u];
+      if (threadIdx.x == 0) L.again[(k + 1u) & 1u] = 0;
+      if (!more) { ++k; break; }
+    }
+    if (state == 1) {
+      r = __shfl(r, 0);
+      apply_row<64, VEC, OP, BASIC, true>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u, 1u, g, a);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) tv.ctr->n_pending = 0;
+}
+
 template <int VEC, int OP>
 __global__ __launch_bounds__(64) void slowpath_kernel(TableView tv, const int64_t* __restrict__ ids,
                                                       const float* __restrict__ values,
@@ -2462,6 +2620,41 @@ __device__ __forceinline__ void load_agent(const float* p, Vec<VEC>& v) {
     v.v[c] = __hip_atomic_load(p + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Store of an updated row's vector in the fused step kernels.  (Measured and dropped: write-through
+// `global_store_dwordx4 ... sc1` stores here, so that the rows leave the XCD's L2 while the launch
+// runs instead of being drained at its end — step and mstep times unchanged within noise, r03e.)
+template <int VEC>
+__device__ __forceinline__ void row_store(float* p, const Vec<VEC>& v) {
+  v.store(p);
+}
+
+// Rare paths of the fused step kernels (a NEW id's initializer, FTRL's constants): what they compute
+// from the table descriptor is loop-invariant, so the compiler hoists it in front of the trip loop
+// and — at 96 VGPRs — spills it there: scratch stores at every loop entry for values most trips
+// never read.  A descriptor whose fields pass through an empty volatile asm stays in the branch.
+__device__ __forceinline__ float opaque_f(float x) {
+#ifndef MHTE_NO_ANTIHOIST
+  asm volatile("" : "+v"(x));
+#endif
+  return x;
+}
+// a wave-uniform 32-bit value as a store operand, copied to its VGPR where it is used
+__device__ __forceinline__ uint32_t vgpr_copy_of_uniform(uint32_t u) {
+#ifndef MHTE_NO_ANTIHOIST
+  uint32_t v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(__builtin_amdgcn_readfirstlane(u)));
+  return v;
+#else
+  return u;
+#endif
+}
+__device__ __forceinline__ SegDesc seg_for_init(const SegDesc& sd) {
+  SegDesc si = sd;
+  si.init_value = opaque_f(sd.init_value);
+  si.init_value2 = opaque_f(sd.init_value2);
+  return si;
+}
+
 // one optimizer step on the lane's element vector, gradient in registers (kOpOptimize only)
 template <int VEC, bool ONESEG = false>
 __device__ __forceinline__ void optimize_row_reg(const TableView& tv, float* rp, bool is_new,
@@ -2477,9 +2670,10 @@ __device__ __forceinline__ void optimize_row_reg(const TableView& tv, float* rp,
   const bool has1 = sd.opt == kOptAdagrad || sd.opt == kOptFtrl;
   const bool has2 = sd.opt == kOptFtrl;
   if (is_new) {
+    const SegDesc si = seg_for_init(sd);
 #pragma unroll
     for (int c = 0; c < VEC; ++c) {
-      w.v[c] = init_weight(sd, rp + e + c);
+      w.v[c] = init_weight(si, rp + e + c);
       s1.v[c] = sd.p[0];
       s2.v[c] = 0.f;
     }
@@ -2488,19 +2682,22 @@ __device__ __forceinline__ void optimize_row_reg(const TableView& tv, float* rp,
     if (has1) s1.load(st1);
     if (has2) s2.load(st2);
   }
+  if (sd.opt == kOptSgd) {
+    const float slr = opaque_f(lr);
 #pragma unroll
-  for (int c = 0; c < VEC; ++c) {
-    if (sd.opt == kOptSgd) {
-      w.v[c] = sgd_step(w.v[c], g.v[c], lr);
-    } else if (sd.opt == kOptAdagrad) {
-      adagrad_step(w.v[c], s1.v[c], g.v[c], lr, sd.p[1]);
-    } else {
-      ftrl_step(w.v[c], s1.v[c], s2.v[c], g.v[c], lr, sd.p[1], sd.p[2], sd.p[3]);
-    }
+    for (int c = 0; c < VEC; ++c) w.v[c] = sgd_step(w.v[c], g.v[c], slr);
+  } else if (sd.opt == kOptAdagrad) {
+    const float alr = opaque_f(lr), wd = opaque_f(sd.p[1]);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) adagrad_step(w.v[c], s1.v[c], g.v[c], alr, wd);
+  } else {
+    const float flr = opaque_f(lr), beta = opaque_f(sd.p[1]), l1 = opaque_f(sd.p[2]), l2 = opaque_f(sd.p[3]);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) ftrl_step(w.v[c], s1.v[c], s2.v[c], g.v[c], flr, beta, l1, l2);
   }
-  w.store(rp + e);
-  if (has1) s1.store(st1);
-  if (has2) s2.store(st2);
+  row_store<VEC>(rp + e, w);
+  if (has1) row_store<VEC>(st1, s1);
+  if (has2) row_store<VEC>(st2, s2);
 }
 
 // The same for a table that uses ANY per-element optimizer (Momentum, Adadelta, RMSProp v1 / v2, Adam,
@@ -2576,10 +2773,10 @@ __device__ __forceinline__ void optimize_row_reg_full(const TableView& tv, float
     c1 = c1 * sd.p[0];
     c2 = c2 * sd.p[1];
   }
-  w.store(rp + e);
-  if (nv > 0) s1.store(st1);
-  if (nv > 1) s2.store(st2);
-  if (nv > 2) s3.store(st3);
+  row_store<VEC>(rp + e, w);
+  if (nv > 0) row_store<VEC>(st1, s1);
+  if (nv > 1) row_store<VEC>(st2, s2);
+  if (nv > 2) row_store<VEC>(st3, s3);
   if (scal && le == 0) {
     sc[0] = c1;
     sc[1] = c2;

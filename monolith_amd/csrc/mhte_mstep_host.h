@@ -429,7 +429,7 @@ struct MultiStep {
       if (any_full) LAUNCH_HOT(kTagMStepBwd, mstep_bwd_kernel<true>, dim3(gx, tc), 256, st, A);
       HIP_OK(hipGetLastError());
       if (any_apply) {
-        mstep_slow_kernel<<<tc, 64, 0, st>>>(A);
+        mstep_slow_kernel<<<tc, 64 * kSlowWaves, 0, st>>>(A);
         HIP_OK(hipGetLastError());
         for (uint32_t k = 0; k < tc; ++k)
           if (A.tab[k].apply) ++mt->tables[t0 + k]->mut_epoch;

@@ -517,17 +517,18 @@ __global__ __launch_bounds__(256, MHTE_MBWD_OCC) void mstep_bwd_kernel(MBwdArgs 
   wt.end(bid < bt.nblk_items ? 7u : 8u);
 }
 
-// displacement pass of every table's update, one wavefront per table (usually nothing to do)
-__global__ __launch_bounds__(64) void mstep_slow_kernel(MBwdArgs A) {
-  __shared__ BfsSlot q[kMaxCuckooCount];
-  __shared__ CuckooRecord path[kMaxBfsPathLen];
+// displacement pass of every table's update: one workgroup per table, kSlowWaves deferred ids at a
+// time (slowpath_par_role; a table defers 1-5 ids per step at load 0.3)
+constexpr int kSlowWaves = 4;
+__global__ __launch_bounds__(64 * kSlowWaves) void mstep_slow_kernel(MBwdArgs A) {
+  __shared__ SlowParLds<kSlowWaves> L;
   const uint32_t t = blockIdx.x;
   const MBwdTab& bt = A.tab[t];
   if (!bt.apply) return;
   const MStepStatic& s = deref_const(A.st + t);
   const TableView& tv = deref_const(A.views + t);
-  slowpath_role<4, kOpOptimize, true>(tv, s.rv[A.cur & 1u].uids, s.grad_u, nullptr, nullptr, bt.a,
-                                      nullptr, s.pending, q, path);
+  slowpath_par_role<4, kOpOptimize, kSlowWaves, false>(tv, s.rv[A.cur & 1u].uids, s.grad_u, bt.a,
+                                                       s.pending, L);
 }
 
 // ---------------------------------------------------------------------------------------------

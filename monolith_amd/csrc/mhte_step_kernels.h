@@ -586,27 +586,41 @@ __device__ __forceinline__ void optimize_row_pre(const TableView& tv, float* rp,
   Vec<VEC> s2;
   vec_zero(s2);
   if (is_new) {
+    const SegDesc si = seg_for_init(sd);
 #pragma unroll
     for (int c = 0; c < VEC; ++c) {
-      r.w.v[c] = init_weight(sd, rp + e + c);
+      r.w.v[c] = init_weight(si, rp + e + c);
       r.s1.v[c] = sd.p[0];
     }
   } else if (has2) {
     s2.load(st2);
   }
+  if (sd.opt == kOptSgd) {
+    const float slr = opaque_f(lr);
 #pragma unroll
-  for (int c = 0; c < VEC; ++c) {
-    if (sd.opt == kOptSgd) {
-      r.w.v[c] = sgd_step(r.w.v[c], g.v[c], lr);
-    } else if (sd.opt == kOptAdagrad) {
-      adagrad_step(r.w.v[c], r.s1.v[c], g.v[c], lr, sd.p[1]);
-    } else {
-      ftrl_step(r.w.v[c], r.s1.v[c], s2.v[c], g.v[c], lr, sd.p[1], sd.p[2], sd.p[3]);
-    }
+    for (int c = 0; c < VEC; ++c) r.w.v[c] = sgd_step(r.w.v[c], g.v[c], slr);
+  } else if (sd.opt == kOptAdagrad) {
+    const float alr = opaque_f(lr), wd = opaque_f(sd.p[1]);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) adagrad_step(r.w.v[c], r.s1.v[c], g.v[c], alr, wd);
+  } else {
+    const float flr = opaque_f(lr), beta = opaque_f(sd.p[1]), l1 = opaque_f(sd.p[2]), l2 = opaque_f(sd.p[3]);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) ftrl_step(r.w.v[c], r.s1.v[c], s2.v[c], g.v[c], flr, beta, l1, l2);
   }
-  r.w.store(rp + e);
-  if (has1) r.s1.store(st1);
-  if (has2) s2.store(st2);
+  row_store<VEC>(rp + e, r.w);
+  if (has1) row_store<VEC>(st1, r.s1);
+  if (has2) row_store<VEC>(st2, s2);
+}
+
+// an id whose two buckets are full goes to the displacement pass's list (rare: the counter's address
+// is formed here, not in front of the trip loop — see opaque_f)
+__device__ __forceinline__ void defer_id(const TableView& tv, uint32_t* pending, uint32_t u) {
+  auto* ctr = tv.ctr;
+#ifndef MHTE_NO_ANTIHOIST
+  asm volatile("" : "+v"(ctr));
+#endif
+  pending[atomicAdd(&ctr->n_pending, 1u)] = u;
 }
 
 // Probe state of one id per G-lane group, split in two so the caller can put work between the
@@ -802,15 +816,21 @@ __device__ __forceinline__ SlotResult upsert_complete(const TableView& tv, GBuck
     r = found_row;
   }
   if (f.special) {
+    auto* ctr = tv.ctr;   // (kept inside the branch: see opaque_f)
+#ifndef MHTE_NO_ANTIHOIST
+    asm volatile("" : "+v"(ctr));
+#endif
     if (is_new) {
-      if (j == 0) tv.ctr->special_row = r;
+      if (j == 0) ctr->special_row = r;
     } else {
-      r = tv.ctr->special_row;  // written by an earlier kernel
+      r = ctr->special_row;  // written by an earlier kernel
     }
-    if (j == 0) tv.ctr->special_ts = ts;
+    if (j == 0) ctr->special_ts = vgpr_copy_of_uniform(ts);
   } else if (valid && !deferred && j == owner) {
     if (is_new) b->row[s] = r;
-    b->ts[s] = ts;  // SetTimestamp(update_time), cuckoo_embedding_hash_table.cc:242-246
+    // (the uniform's VGPR copy, made in front of the trip loop, was spilled there and reloaded here
+    // behind a wait for every load in flight: the copy is made in place instead — see opaque_f)
+    b->ts[s] = vgpr_copy_of_uniform(ts);  // SetTimestamp(update_time), cuckoo_embedding_hash_table.cc:242-246
   }
   SlotResult out;
   out.r = r;
@@ -849,20 +869,43 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
   const bool ev = e < dim;
 
   if (bid >= c.nblk_items) {
+    const int j0 = j, gbase0 = gbase;
     // ------------------------------------------------------------------ id-major groups
     // Group `grp` of workgroup k takes the unique indices u = it * stride + grp * nblk_ids + k:
     // consecutive indices (the claim order puts the hot ids first) land in different workgroups.
     // A group lives inside one wavefront, so its LDS hand-offs need no workgroup barrier.
-    uint32_t* const sh_pos = L.pos + grp * kStepLightMax;  // this group's slice
     uint32_t* const sh_need = L.need;
     uint32_t& sh_rowbase = L.rowbase;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t stride = int64_t(c.nblk_ids) * NG;
-    const int64_t k = bid - c.nblk_items;
-    int64_t nu = c.n_max;  // refined below, once the count has arrived with the first trip's loads
+    // (32-bit index arithmetic: n_max is a batch size; the 64-bit form kept a hoisted per-lane offset
+    // in a register pair that was spilled at the loop entry and reloaded — with a wait for every
+    // load in flight — in front of each trip's first loads)
+    const uint32_t stride = c.nblk_ids * uint32_t(NG);
+    const uint32_t k = bid - c.nblk_items;
+    uint32_t nu = c.n_max;  // refined below, once the count has arrived with the first trip's loads
 #pragma unroll 1
-    for (int64_t it = 0; it * stride < nu; ++it) {
-      const int64_t g = it * stride + int64_t(grp) * c.nblk_ids + k;
+    for (uint32_t it = 0; uint64_t(it) * stride < nu; ++it) {
+#ifndef MHTE_NO_ANTIHOIST
+      // (a group makes one or two trips: addresses of the form base + e hoisted out of the loop are
+      // not worth the registers — the compiler spilled them, 52 B per lane stored at every loop
+      // entry = 9 MB of scratch writes per launch.  An element offset it cannot see through keeps
+      // them inside the trip.)
+      int j = j0, gbase = gbase0;
+      asm volatile("" : "+v"(j), "+v"(gbase));
+      const uint32_t e = uint32_t(j) * VEC;
+#endif
+#ifndef MHTE_NO_ANTIHOIST
+      // (the same for the unique index and the group's LDS slice: without this, loop strength
+      // reduction keeps one 64-bit pointer per dense array alive across the loop)
+      uint32_t grp_ = uint32_t(grp);
+      asm volatile("" : "+v"(grp_));
+      uint32_t* const sh_pos = L.pos + grp_ * kStepLightMax;  // this group's slice
+      uint32_t g = it * stride + grp_ * c.nblk_ids + k;
+      asm volatile("" : "+v"(g));
+#else
+      uint32_t* const sh_pos = L.pos + grp * kStepLightMax;  // this group's slice
+      const uint32_t g = it * stride + uint32_t(grp) * c.nblk_ids + k;
+#endif
       // round trip 1: everything about unique index g (the build role's dense arrays; an index past
       // the count reads stale entries of the preallocated arrays and is dropped)
       const bool inb = g < c.n_max;
@@ -882,7 +925,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         hloc = inb ? c.uloc[g] : 0ull;
         huts = inb ? c.uts[g] : 0u;
       }
-      nu = min(c.n_max, int64_t(n_unique));
+      nu = min(uint32_t(c.n_max), n_unique);
       bool valid = g < nu;
       if (!valid) cnt = 0;
       const bool hinted = HINT && valid && hrow != kNoRow;
@@ -1030,7 +1073,8 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         // (a 4-byte store into a line this launch otherwise never touches costs a 128-byte fetch and
         // a write-back: 21 of mstep_bwd's 200 us at 26 x 65 536 ids.  update_time has the
         // resolution of a second; an id updated again within the second already carries it.)
-        if (valid && j == 0 && huts != a.ts) global_bucket(tv.buckets + (hloc >> 2))->ts[hloc & 3ull] = a.ts;
+        if (valid && j == 0 && huts != a.ts)
+          global_bucket(tv.buckets + (hloc >> 2))->ts[hloc & 3ull] = vgpr_copy_of_uniform(a.ts);
       }
       float* rp = nullptr;
       if (valid && !sr.deferred) {
@@ -1040,7 +1084,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       if (it == 0) wt.mark(3);
       if (sr.deferred) {
         if (ev) acc.store(c.grad_u + g * int64_t(dim) + e);
-        if (j == 0) c.pending[atomicAdd(&tv.ctr->n_pending, 1u)] = uint32_t(g);
+        if (j == 0) defer_id(tv, c.pending, uint32_t(g));
       } else if (valid) {
         if (FULL) optimize_row_reg_full<VEC>(tv, rp, sr.is_new, e, acc, a);
         else optimize_row_pre<VEC, ONESEG>(tv, rp, sr.is_new, e, acc, a, rr);
@@ -1218,8 +1262,12 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       const SlotResult sr =
           upsert_resolve<G>(tv, (Bucket*)pr.b, hd.id, valid, pr.k, pr.row, lane, a.ts, reserved);
       if (sr.deferred) {
-        if (ev) tot.store(c.grad_u + int64_t(hd.u) * dim + e);
-        if (j == 0) c.pending[atomicAdd(&tv.ctr->n_pending, 1u)] = hd.u;
+        uint32_t ed = e;   // (rare path: its address arithmetic stays here, see opaque_f)
+#ifndef MHTE_NO_ANTIHOIST
+        asm volatile("" : "+v"(ed));
+#endif
+        if (ev) tot.store(c.grad_u + int64_t(hd.u) * dim + ed);
+        if (j == 0) defer_id(tv, c.pending, hd.u);
       } else if (valid) {
         if (FULL) optimize_row_reg_full<VEC>(tv, row_ptr(tv, sr.r), sr.is_new, e, tot, a);
         else optimize_row_reg<VEC, ONESEG>(tv, row_ptr(tv, sr.r), sr.is_new, e, tot, a);

@@ -323,6 +323,16 @@ def test_multi_step_displacement_and_doubling():
   for sp in hi:
     st = mt.stats(sp.name)
     assert st.dropped == 0 and st.hashpower == 11 and st.size > 0.5 * (1 << 13)
+    # the displacement pass works on several deferred ids at a time (slowpath_par_role): every key
+    # sits in one of ITS two buckets, once
+    ids, pos, _, _ = mt.dump(sp.name, with_rows=False)
+    ids, pos = ids.cpu().numpy(), pos.cpu().numpy()
+    L = O.lib()
+    assert ids.size == st.size == np.unique(ids).size
+    for k, p_ in zip(ids, pos):
+      hv = L.mo_hash(int(k))
+      i1 = hv & ((1 << 11) - 1)
+      assert (int(p_) >> 2) in (i1, L.mo_alt_index(11, L.mo_partial(hv), i1)), (sp.name, k, p_)
   for sp in grow:
     assert mt.stats(sp.name).hashpower >= 11
 
