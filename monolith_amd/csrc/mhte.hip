@@ -766,7 +766,7 @@ struct Table {
       TableView v = view;
       v.trace = trace_region(kTagLookup, g, 512);
 #define LK(G_)                                                                                   \
-  LAUNCH_HOT(kTagLookup, (lookup_kernel_u<G_, 4, 2, true, 512>), g, 512, st, v, ids, n, n_dev, out, \
+  LAUNCH_HOT(kTagLookup, (lookup_kernel_u<G_, 4, 2, 1, 512>), g, 512, st, v, ids, n, n_dev, out, \
              count_hits ? 1 : 0)
       switch (sh.G) {
         case 8: LK(8); break;

@@ -531,7 +531,27 @@ __device__ __forceinline__ void store_stream(float* p, const Vec<VEC>& v) {
 #pragma unroll
   for (int c = 0; c < VEC; ++c) __builtin_nontemporal_store(v.v[c], p + c);
 }
-template <int G, int VEC, int UNR, bool NT>
+// Output rows of the per-occurrence lookup (B rows, written once, read by the next consumer from
+// HBM): write-through (sc1) 16-byte stores — the rows leave the XCD's L2 while the launch runs
+// instead of sitting there dirty until its end, when the next launch's start waits for them to drain
+// (21.7 MB per launch at the bench's shape: step_fwd 13.9 -> 13.4 us, same-box A/B r03f).  NOT for
+// the multi-table forward's scatter (one id's row to many positions): there the same store form
+// costs 160 -> 204 us.
+template <int VEC>
+__device__ __forceinline__ void store_out_rows(float* p, const Vec<VEC>& v) {
+  if constexpr (VEC == 4) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 t;
+    t.x = v.v[0]; t.y = v.v[1]; t.z = v.v[2]; t.w = v.v[3];
+    // (s_nop: the data registers must not be overwritten before the store has read them,
+    // cdna_hip_programming.md 5.7)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"((MHTE_GLOBAL float*)p), "v"(t) : "memory");
+  } else {
+    store_stream<VEC>(p, v);
+  }
+}
+// NT: 0 plain stores, 1 streaming (nontemporal), 2 write-through (store_out_rows)
+template <int G, int VEC, int UNR, int NT>
 __device__ __forceinline__ void lookup_role_u(const TableView& tv, const int64_t* __restrict__ ids,
                                               int64_t n, const uint32_t* __restrict__ n_dev,
                                               float* __restrict__ out, int count_hits,
@@ -600,14 +620,16 @@ __device__ __forceinline__ void lookup_role_u(const TableView& tv, const int64_t
     for (int u = 0; u < UNR; ++u) {
       if (valid[u]) {
         float* op = out + (g0 + u) * int64_t(tv.dim) + e;
-        if (NT) store_stream<VEC>(op, v[u]); else v[u].store(op);
+        if (NT == 2) store_out_rows<VEC>(op, v[u]);
+        else if (NT == 1) store_stream<VEC>(op, v[u]);
+        else v[u].store(op);
       }
     }
   }
   if (count_hits && hits && lane == __ffsll(static_cast<long long>(__ballot(1))) - 1)
     atomicAdd(&tv.ctr->hits, (unsigned long long)hits);
 }
-template <int G, int VEC, int UNR, bool NT, int BLOCK>
+template <int G, int VEC, int UNR, int NT, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void lookup_kernel_u(TableView tv,
                                                          const int64_t* __restrict__ ids, int64_t n,
                                                          const uint32_t* __restrict__ n_dev,

@@ -557,7 +557,7 @@ __device__ __forceinline__ void seg_lookup_loop(const TableView& tv, const int64
 #pragma unroll 1
   for (int64_t g = (int64_t(blockIdx.x) * 512 + threadIdx.x) / G; g < ngroups;
        g += int64_t(gridDim.x) * 512 / G)
-    lookup_role_u<G, 4, 2, true>(tv, ids, n, nullptr, out, count_hits, g);
+    lookup_role_u<G, 4, 2, 1>(tv, ids, n, nullptr, out, count_hits, g);
 }
 
 __global__ __launch_bounds__(512) void seg_lookup_kernel(SegLookupArgs A) {

@@ -1430,7 +1430,7 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
 #pragma unroll 1
   for (int64_t g = (int64_t(bid) * kRdBlock + threadIdx.x) / G; g < ngroups;
        g += int64_t(nblk_l) * kRdBlock / G)
-    lookup_role_u<G, VEC, UNR, true>(tv, ids, n, nullptr, out, count_hits, g);
+    lookup_role_u<G, VEC, UNR, 2>(tv, ids, n, nullptr, out, count_hits, g);
   wt.end(5u);
 }
 
