@@ -3357,6 +3357,101 @@ static void layout_launch(bool forward, const float* const* embeddings, const in
   A.n_nfl = n_nfl;
   A.batch = batch;
   A.n_emb = n_emb;
+  auto check_slice = [&](int32_t i, int32_t first_of_addn) {
+    const mhte_layout_slice& sc = slices[i];
+    if (sc.out_index < 0 || sc.out_index >= n_outputs || sc.dim <= 0 || sc.out_row_floats <= 0 ||
+        int64_t(sc.out_offset) + int64_t(sc.dim) * (sc.pooling == 3 ? std::max(1, sc.max_sequence_length) : 1) >
+            sc.out_row_floats ||
+        int64_t(batch) * sc.out_row_floats > output_len[sc.out_index])
+      throw Error(MHTE_INVALID_ARGUMENT, "layout: slice " + std::to_string(i) + " does not fit its output");
+    if (sc.out_type == 2 && sc.pooling == 3)   // CHECK in the op's constructor
+      throw Error(MHTE_INVALID_ARGUMENT, "layout: FIRSTN pooling cannot be added (ADDN)");
+    if (sc.out_type == 2 && sc.dim != slices[first_of_addn].dim)
+      throw Error(MHTE_INVALID_ARGUMENT, "layout: slices of an ADDN layout differ in width");
+  };
+  auto task_of = [&](const mhte_layout_slice& sc) {
+    LayoutTask t{};
+    t.nfl_idx = sc.feature_idx;
+    t.start = sc.start;
+    t.dim = sc.dim;
+    t.pooling = sc.pooling;
+    t.max_seq = sc.max_sequence_length;
+    t.out_index = sc.out_index;
+    t.out_offset = sc.out_offset;
+    t.out_stride = sc.out_row_floats;
+    return t;
+  };
+  // ---- the gradient without float atomics (general form; MHTE_POOL_ATOMICS=1 keeps the atomic one)
+  bool copy_form = (flags & MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS) != 0 && n_fid == n_feature;
+  if (!forward && !copy_form && !pool_atomics() && n_fid > 0) {
+    std::vector<LayoutTask> tasks(static_cast<size_t>(n_slices));
+    std::vector<uint32_t> t_off(size_t(n_nfl) + 1, 0), t_idx;
+    for (int32_t i = 0, first = 0; i < n_slices; ++i) {
+      if (i == 0 || slices[i].out_type != 2 || slices[i - 1].out_type != 2 ||
+          slices[i].out_index != slices[i - 1].out_index)
+        first = i;
+      check_slice(i, first);
+      tasks[size_t(i)] = task_of(slices[i]);
+      if (slices[i].feature_idx >= 0 && slices[i].feature_idx < n_nfl) ++t_off[size_t(slices[i].feature_idx) + 1];
+    }
+    for (int32_t i = 0; i < n_nfl; ++i) t_off[size_t(i) + 1] += t_off[size_t(i)];
+    t_idx.resize(t_off[size_t(n_nfl)]);
+    {
+      std::vector<uint32_t> cur(t_off.begin(), t_off.end() - 1);
+      for (int32_t i = 0; i < n_slices; ++i)
+        if (slices[i].feature_idx >= 0 && slices[i].feature_idx < n_nfl)
+          t_idx[cur[size_t(slices[i].feature_idx)]++] = uint32_t(i);
+    }
+    const size_t o_task = 0, o_off = o_task + tasks.size() * sizeof(LayoutTask),
+                 o_idx = o_off + t_off.size() * 4, o_qf = (o_idx + t_idx.size() * 4 + 15) & ~size_t(15),
+                 o_qseq = o_qf + size_t(n_fid) * 4, o_fnfl = o_qseq + size_t(n_fid) * 4,
+                 total = o_fnfl + size_t(std::max<int64_t>(1, n_feature)) * 4;
+    struct Tmp {   // (freed in stream order behind the kernels that read it)
+      char* d = nullptr;
+      hipStream_t st;
+      ~Tmp() {
+        if (d && hipFreeAsync(d, st) != hipSuccess) {
+          (void)hipGetLastError();
+          (void)hipStreamSynchronize(st);
+          (void)hipFree(d);
+        }
+      }
+    } tmp;
+    tmp.st = st;
+    void* d = nullptr;
+    if (hipMallocAsync(&d, total, st) != hipSuccess) {
+      (void)hipGetLastError();
+      HIP_OK(hipMalloc(&d, total));
+    }
+    tmp.d = static_cast<char*>(d);
+    std::vector<char> h(o_qf, 0);
+    memcpy(h.data() + o_task, tasks.data(), tasks.size() * sizeof(LayoutTask));
+    memcpy(h.data() + o_off, t_off.data(), t_off.size() * 4);
+    if (!t_idx.empty()) memcpy(h.data() + o_idx, t_idx.data(), t_idx.size() * 4);
+    HIP_OK(hipMemcpyAsync(tmp.d, h.data(), o_qf, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemsetAsync(tmp.d + o_qf, 0xff, total - o_qf, st));   // qf = -1, fnfl = ~0
+    HIP_OK(hipStreamSynchronize(st));   // (h is a pageable temporary)
+    AuxWs& ws = AuxWs::of(current_device());
+    std::lock_guard<std::mutex> g(ws.mu);
+    ws.enter(st);
+    ws.group(reinterpret_cast<const int64_t*>(fid_offset), n_fid, st);
+    LayoutLists X{};
+    X.tasks = reinterpret_cast<const LayoutTask*>(tmp.d + o_task);
+    X.nfl_task_off = reinterpret_cast<const uint32_t*>(tmp.d + o_off);
+    X.nfl_tasks = reinterpret_cast<const uint32_t*>(tmp.d + o_idx);
+    X.qf = reinterpret_cast<int32_t*>(tmp.d + o_qf);
+    X.qseq = reinterpret_cast<uint32_t*>(tmp.d + o_qseq);
+    X.fnfl = reinterpret_cast<uint32_t*>(tmp.d + o_fnfl);
+    X.ukeys = ws.uids.p;
+    X.nu = ws.nu.p;
+    X.seg_off = ws.seg_off.p;
+    X.seg_pos = ws.seg_pos.p;
+    const int64_t inst = int64_t(n_nfl) * batch;
+    if (inst > 0) layout_qmap_kernel<<<dim3(uint32_t((inst + 255) / 256)), 256, 0, st>>>(A, X);
+    layout_grad_lists_kernel<<<dim3(uint32_t((n_fid * 16 + 255) / 256)), 256, 0, st>>>(A, X);
+    HIP_OK(hipGetLastError());
+    return;
+  }
   int32_t k = 0;
   bool addn_open = false;   // the previous launch ended inside an ADDN layout: its next slices add on
   while (k < n_slices) {
@@ -3379,25 +3474,8 @@ static void layout_launch(bool forward, const float* const* embeddings, const in
         addn_open = false;
       }
       for (int32_t q = 0; q < span; ++q) {
-        const mhte_layout_slice& sc = slices[k + q];
-        if (sc.out_index < 0 || sc.out_index >= n_outputs || sc.dim <= 0 || sc.out_row_floats <= 0 ||
-            int64_t(sc.out_offset) + int64_t(sc.dim) * (sc.pooling == 3 ? std::max(1, sc.max_sequence_length) : 1) >
-                sc.out_row_floats ||
-            int64_t(batch) * sc.out_row_floats > output_len[sc.out_index])
-          throw Error(MHTE_INVALID_ARGUMENT, "layout: slice " + std::to_string(k + q) + " does not fit its output");
-        if (sc.out_type == 2 && sc.pooling == 3)   // CHECK in the op's constructor
-          throw Error(MHTE_INVALID_ARGUMENT, "layout: FIRSTN pooling cannot be added (ADDN)");
-        if (sc.out_type == 2 && sc.dim != slices[k].dim)
-          throw Error(MHTE_INVALID_ARGUMENT, "layout: slices of an ADDN layout differ in width");
-        LayoutTask& t = A.task[nt + q];
-        t.nfl_idx = sc.feature_idx;
-        t.start = sc.start;
-        t.dim = sc.dim;
-        t.pooling = sc.pooling;
-        t.max_seq = sc.max_sequence_length;
-        t.out_index = sc.out_index;
-        t.out_offset = sc.out_offset;
-        t.out_stride = sc.out_row_floats;
+        check_slice(k + q, k);
+        A.task[nt + q] = task_of(slices[k + q]);
       }
       A.unit[nu].first = uint16_t(nt);
       A.unit[nu].count = uint16_t(span);

@@ -200,5 +200,128 @@ __global__ __launch_bounds__(256) void layout_kernel(LayoutArgs A) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The gradient WITHOUT float atomics (the general form: pooled features, a row referenced by several
+// batch rows): one lane group per DISTINCT embedding row adds everything that row receives, in the
+// order the reference's CPU kernel adds it — slices in configuration order, for each slice the batch
+// rows ascending, inside a batch row the fids in list order (ScatterGrad inside the op's slice /
+// batch loops, fused_embedding_to_layout.h:286-346, .cc:600-700) — so the result is that sequential
+// fp32 sum bit for bit, and the same bits on every run.  (The reference's GPU kernel uses float
+// atomics, .cu.cc:337-420; layout_kernel<false> above is that form, kept behind MHTE_POOL_ATOMICS.)
+//   host: distinct (matrix, row) keys of fid_offset with their positions ascending (DedupWs::unique)
+//   layout_qmap_kernel: position q -> its feature instance and its rank among the instance's valid
+//                       fids (FIRSTN); feature instance -> its named feature list
+//   layout_grad_lists_kernel: per distinct key, the slices of the features on its list in ascending
+//                       slice order; per slice the list is walked once per element stride
+// ---------------------------------------------------------------------------------------------
+struct LayoutLists {
+  const LayoutTask* tasks;          // every slice of the call, configuration order
+  const uint32_t* nfl_task_off;     // [n_nfl + 1] slices of a named feature list ...
+  const uint32_t* nfl_tasks;        //   ... ascending
+  int32_t* qf;                      // [n_fid] feature instance of position q (-1: none)
+  uint32_t* qseq;                   // [n_fid] valid fids before q in its instance
+  uint32_t* fnfl;                   // [n_feature] named feature list of an instance (~0u: none)
+  const int64_t* ukeys;             // distinct fid_offset values,
+  const uint32_t* nu;               //   their number,
+  const uint32_t* seg_off;          //   and positions: seg_pos[seg_off[u] .. seg_off[u + 1]) ascending
+  const uint32_t* seg_pos;
+};
+
+static_assert(sizeof(LayoutArgs) + sizeof(LayoutLists) <= 4096, "kernel arguments exceed 4 KB");
+
+// one thread per (named feature list, instance): the instances a batch row reaches (GetFeatureInfo:
+// off + b, or off for a shared list) and their fids
+__global__ __launch_bounds__(256) void layout_qmap_kernel(LayoutArgs A, LayoutLists X) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int32_t nfl = int32_t(i / A.batch), b = int32_t(i % A.batch);
+  if (nfl >= A.n_nfl) return;
+  const uint32_t enc = A.nfl_offset[nfl];
+  const bool shared = enc >> 31;
+  const int32_t off = int32_t(enc & 0x7fffffffu);
+  const int32_t off_next = nfl < A.n_nfl - 1 ? int32_t(A.nfl_offset[nfl + 1] & 0x7fffffffu) : A.n_feature;
+  if (off_next - off <= 0 || (shared && b != 0)) return;
+  const int32_t f = off + b;
+  if (f >= A.n_feature || f >= off_next) return;   // (an instance of the NEXT list belongs to that list)
+  X.fnfl[f] = uint32_t(nfl);
+  const int32_t f0 = A.feature_offset[f];
+  const int32_t f1 = f < A.n_feature - 1 ? A.feature_offset[f + 1] : A.n_fid;
+  uint32_t seq = 0;
+  for (int32_t q = f0; q < f1; ++q) {
+    X.qf[q] = f;
+    X.qseq[q] = seq;
+    if (uint32_t(A.fid_offset[q] >> 32) < uint32_t(A.n_emb)) ++seq;
+  }
+}
+
+__global__ __launch_bounds__(256) void layout_grad_lists_kernel(LayoutArgs A, LayoutLists X) {
+  constexpr int G = 16;
+  const int j = threadIdx.x & (G - 1);
+  const int64_t u = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  if (u >= int64_t(X.nu[0])) return;
+  const unsigned long long key = static_cast<unsigned long long>(X.ukeys[u]);
+  const uint32_t i1 = uint32_t(key >> 32), i2 = uint32_t(key);
+  if (i1 >= uint32_t(A.n_emb)) return;
+  const uint32_t l0 = X.seg_off[u], l1 = X.seg_off[u + 1];
+  float* const mat = const_cast<float*>(layout_emb(A, i1));
+  const uint64_t rbase = uint64_t(i2) * layout_stride(A, i1);
+  const uint64_t cnt = layout_count(A, i1);
+  int32_t last_k = -1;
+  for (;;) {
+    // the next slice: the smallest index > last_k among the slices of the features on the list
+    int32_t best = INT32_MAX;
+    for (uint32_t p = l0 + uint32_t(j); p < l1; p += G) {
+      const int32_t f = X.qf[X.seg_pos[p]];
+      if (f < 0) continue;
+      const uint32_t nfl = X.fnfl[f];
+      if (nfl >= uint32_t(A.n_nfl)) continue;
+      for (uint32_t c = X.nfl_task_off[nfl]; c < X.nfl_task_off[nfl + 1]; ++c) {
+        const int32_t k = int32_t(X.nfl_tasks[c]);
+        if (k > last_k) {
+          best = min(best, k);
+          break;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = G / 2; o; o >>= 1) best = min(best, __shfl_xor(best, o, G));
+    if (best == INT32_MAX) break;
+    last_k = best;
+    const LayoutTask t = X.tasks[best];
+    const float* og = layout_out(A, t.out_index);
+    const uint32_t enc = A.nfl_offset[t.nfl_idx];
+    const bool shared = enc >> 31;
+    const int32_t off = int32_t(enc & 0x7fffffffu);
+    const int32_t nb = shared ? A.batch : 1;
+    for (int32_t e = j; e < t.dim; e += G) {
+      const uint64_t at = rbase + uint32_t(t.start) + uint32_t(e);
+      if (at >= cnt) continue;                         // (CUSTOM_CHECK in the reference)
+      // (L2-served load: the previous slice's store to an overlapping element came from another lane)
+      float acc = __hip_atomic_load(mat + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int32_t bb = 0; bb < nb; ++bb) {
+        for (uint32_t p = l0; p < l1; ++p) {
+          const uint32_t q = X.seg_pos[p];
+          const int32_t f = X.qf[q];
+          if (f < 0 || X.fnfl[f] != uint32_t(t.nfl_idx)) continue;
+          const int32_t b = shared ? bb : f - off;
+          if (b < 0 || b >= A.batch) continue;
+          const float* orow = og + int64_t(b) * t.out_stride + t.out_offset;
+          if (t.pooling == kPoolFirstN) {
+            const uint32_t seq = X.qseq[q];
+            if (seq < uint32_t(t.max_seq)) acc = acc + orow[int64_t(seq) * t.dim + e];
+          } else if (t.pooling == kPoolMean) {
+            const int32_t f0 = A.feature_offset[f];
+            const int32_t f1 = f < A.n_feature - 1 ? A.feature_offset[f + 1] : A.n_fid;
+            acc = acc + orow[e] / float(f1 - f0);
+          } else {
+            acc = acc + orow[e];
+          }
+        }
+      }
+      mat[at] = acc;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this slice's stores before the next one's loads)
+  }
+}
+
 }  // namespace mhte
 #endif  // MHTE_LAYOUT_KERNELS_H_

@@ -355,10 +355,15 @@ def layout_model(embs, fid_offset, feature_offset, nfl_offset, batch, cfgs):
   return outs
 
 
-def layout_grad_model(embs, fid_offset, feature_offset, nfl_offset, batch, cfgs, tensors_grad):
-  """Gradient: ScatterGrad (fused_embedding_to_layout.h:264-346) -> gradients of `embs` (fp64
-  accumulation: the device sums in arrival order, compared with a tolerance)."""
-  grads = [np.zeros(e.shape, np.float64) for e in embs]
+def layout_grad_model(embs, fid_offset, feature_offset, nfl_offset, batch, cfgs, tensors_grad,
+                      acc_dtype=np.float64):
+  """Gradient: ScatterGrad (fused_embedding_to_layout.h:264-346) -> gradients of `embs`.
+  acc_dtype = float64: the sums' value (the reference's GPU kernel and the product's
+  MHTE_POOL_ATOMICS form add in arrival order: compared with a tolerance); float32: every add in
+  fp32 in the op's traversal order — slices in configuration order, batch rows ascending, fids in
+  list order — which is what the reference's CPU kernel computes and what the product's grouped
+  (atomic-free) form reproduces bit for bit."""
+  grads = [np.zeros(e.shape, acc_dtype) for e in embs]
   for t_idx, sc, oc, i, off, b, rows in _walk(fid_offset, feature_offset, nfl_offset, batch, cfgs):
     fc = cfgs.feature_configs[sc.feature_name]
     view = _view(tensors_grad[t_idx], oc, i, off, sc.end - sc.start, b)

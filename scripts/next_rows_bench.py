@@ -252,6 +252,44 @@ def bench_reduce():
   emit("reduce_sum, unsorted indices (grouped in-order sums; MHTE_POOL_ATOMICS=1: float atomics)", t, alg + batch * dim * 4)
 
 
+def bench_layout():
+  """fused_embedding_to_layout, the GENERAL form: 8 pooled features (1-4 fids per batch row, Zipf row
+  choice: hot rows are referenced from hundreds of batch rows), dim 32 + bias, CONCAT + ADDN."""
+  rng = np.random.default_rng(3)
+  batch, nfeat, rows, dim = 65536, 8, 1 << 18, 33
+  P_, OT, S_ = D.PoolingType, D.OutType, D.SliceConfig
+  names = ["f%02d" % i for i in range(nfeat)]
+  feats = {n: D.FeatureConfig("t%d" % i, P_.SUM if i % 2 == 0 else P_.MEAN, [1, dim - 1]) for i, n in enumerate(names)}
+  outs = {"bias": D.OutConfig([S_(n, 0, 1) for n in names], OT.ADDN, [[-1, 1]]),
+          "vec": D.OutConfig([S_(n, 1, dim) for n in names], OT.CONCAT, [[-1, nfeat * (dim - 1)]])}
+  cfgs = D.FeatureConfigs(feats, outs)
+  fid_offset, feature_offset, nfl_offset = [], [], []
+  pos = 0
+  for i, n in enumerate(names):
+    nfl_offset.append(len(feature_offset))
+    cnt = rng.integers(1, 5, batch)
+    starts = pos + np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    feature_offset.extend(starts.tolist())
+    r = (rng.zipf(1.2, int(cnt.sum())) - 1) % rows
+    fid_offset.append((np.uint64(i) << np.uint64(32)) | r.astype(np.uint64))
+    pos += int(cnt.sum())
+  fo_np = np.concatenate(fid_offset)
+  fo = torch.tensor(fo_np.view(np.int64)).to(DEV)
+  fe = torch.tensor(np.array(feature_offset, dtype=np.int32)).to(DEV)
+  nf = torch.tensor(np.array(nfl_offset, dtype=np.uint32).view(np.int32)).to(DEV)
+  embs = [torch.randn((rows, dim), dtype=torch.float32, device=DEV) for _ in names]
+  n_fid = int(fo_np.size)
+  t = gpu_time(lambda: D.fused_embedding_to_layout(embs, fo, fe, nf, batch, cfgs), reps=10)
+  out_bytes = batch * (1 + nfeat * (dim - 1)) * 4
+  emit("fused_embedding_to_layout, general form (8 pooled features, %d fids, batch 65 536, dim 33)" % n_fid, t,
+       n_fid * (8 + dim * 4) + out_bytes)
+  outs_t = D.fused_embedding_to_layout(embs, fo, fe, nf, batch, cfgs)
+  tg = [torch.randn_like(o) for o in outs_t]
+  t = gpu_time(lambda: D.fused_embedding_to_layout_grad(embs, fo, fe, nf, batch, tg, cfgs), reps=10)
+  emit("fused_embedding_to_layout gradient, general form (zero-fill + grouped in-order sums; MHTE_POOL_ATOMICS=1: float atomics)", t,
+       n_fid * (8 + dim * 4) + out_bytes + nfeat * rows * dim * 4, distinct_rows=int(np.unique(fo_np).size))
+
+
 def bench_optimizers():
   B, dim = 65536, 64
   opts = [
@@ -289,7 +327,7 @@ def main():
     gc.collect()
     gc.disable()   # (a generation-2 pass of the interpreter is ~40 ms: it would land in a 60-step window)
     {"optimizers": bench_optimizers, "step_optimizers": bench_step_optimizers, "gather": bench_gather,
-     "reduce": bench_reduce,
+     "reduce": bench_reduce, "layout": bench_layout,
      "evict": bench_evict, "filter": bench_filter_step, "checkpoint": bench_checkpoint}[w]()
   md = ["| Measurement | time | algorithmic bytes | GB/s | of 8 TB/s | notes |", "|---|---|---|---|---|---|"]
   for r in LINES:

@@ -473,11 +473,18 @@ def _to_product_cfgs(ocfgs):
                       [list(x) for x in o.shape]) for n, o in ocfgs.out_configs.items()})
 
 
-def _layout_model(embs, fid_offset, feature_offset, nfl_offset, batch, cfgs, tensors_grad=None):
+def _layout_model(embs, fid_offset, feature_offset, nfl_offset, batch, cfgs, tensors_grad=None,
+                  acc_dtype=np.float64):
   oc = _to_oracle_cfgs(cfgs)
   if tensors_grad is None:
     return OL.layout_model(embs, fid_offset, feature_offset, nfl_offset, batch, oc)
-  return OL.layout_grad_model(embs, fid_offset, feature_offset, nfl_offset, batch, oc, tensors_grad)
+  return OL.layout_grad_model(embs, fid_offset, feature_offset, nfl_offset, batch, oc, tensors_grad,
+                              acc_dtype=acc_dtype)
+
+
+# the gradient's general form adds without float atomics, in the op's traversal order, unless the
+# process was started with MHTE_POOL_ATOMICS=1 (then: arrival order, tolerance only)
+_LAYOUT_GRAD_EXACT = os.environ.get("MHTE_POOL_ATOMICS", "0") in ("", "0")
 
 
 def _dev_case(c):
@@ -515,6 +522,13 @@ def test_fused_embedding_to_layout_reference_test_grad():
   got = D.fused_embedding_to_layout_grad(embs, fo, fe, nf, c["batch"], tg, _to_product_cfgs(c["cfgs"]))
   for g, e in zip(got, c["expected_grads"]):
     np.testing.assert_allclose(g.cpu().numpy(), e, rtol=1e-4, atol=1e-6)
+  if _LAYOUT_GRAD_EXACT:   # ... and the op's own sequential fp32 sums bit for bit, on every run
+    seq = OL.layout_grad_model(c["embs"], c["fid_offset"], c["feature_offset"], c["nfl_offset"], c["batch"],
+                               c["cfgs"], c["tensors_grad"], acc_dtype=np.float32)
+    again = D.fused_embedding_to_layout_grad(embs, fo, fe, nf, c["batch"], tg, _to_product_cfgs(c["cfgs"]))
+    for g, g2, m in zip(got, again, seq):
+      np.testing.assert_array_equal(g.cpu().numpy(), m)
+      np.testing.assert_array_equal(g.cpu().numpy(), g2.cpu().numpy())
 
 
 @pytest.mark.parametrize("batch,seed", [(1, 0), (7, 1), (300, 2)])
@@ -559,8 +573,15 @@ def test_fused_embedding_to_layout_forward_and_grad(batch, seed):
   tg = [rng.standard_normal(e.shape).astype(np.float32) for e in exp]
   gg = D.fused_embedding_to_layout_grad(dev_embs, fo, fe, nf, batch, [torch.tensor(t).cuda() for t in tg], cfgs)
   ge = _layout_model(embs, fid_offset, feature_offset, nfl_offset, batch, cfgs, tensors_grad=tg)
-  for g, e in zip(gg, ge):                                  # float atomics: arrival order
+  for g, e in zip(gg, ge):
     np.testing.assert_allclose(g.cpu().numpy(), e, rtol=1e-5, atol=1e-5)
+  if _LAYOUT_GRAD_EXACT:
+    # rows of matrix 0 are reached from f_a and from the SHARED list f_d, through overlapping slices
+    # of four layouts: slices in configuration order, batch rows ascending, fids in list order
+    gs = _layout_model(embs, fid_offset, feature_offset, nfl_offset, batch, cfgs, tensors_grad=tg,
+                       acc_dtype=np.float32)
+    for g, e in zip(gg, gs):
+      np.testing.assert_array_equal(g.cpu().numpy(), e)
 
 
 def test_fused_embedding_to_layout_copy_form():

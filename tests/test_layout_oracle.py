@@ -34,6 +34,13 @@ def test_layout_grad_model_reproduces_the_reference_tests_truth():
     np.testing.assert_allclose(g, e, rtol=1e-4, atol=1e-7)
     touched += int((e != 0).sum())
   assert touched > 10000
+  # the sequential fp32 form (what the product's atomic-free gradient must equal bit for bit) is the
+  # same walk with fp32 adds: it meets the reference test's truth at the test's tolerance too
+  seq = L.layout_grad_model(c["embs"], c["fid_offset"], c["feature_offset"], c["nfl_offset"], c["batch"],
+                            c["cfgs"], c["tensors_grad"], acc_dtype=np.float32)
+  for g, e in zip(seq, c["expected_grads"]):
+    assert g.dtype == np.float32
+    np.testing.assert_allclose(g, e, rtol=1e-4, atol=1e-6)
 
 
 def test_small_case_by_hand():
