@@ -3405,7 +3405,9 @@ static void layout_launch(bool forward, const float* const* embeddings, const in
     const size_t o_task = 0, o_off = o_task + tasks.size() * sizeof(LayoutTask),
                  o_idx = o_off + t_off.size() * 4, o_qf = (o_idx + t_idx.size() * 4 + 15) & ~size_t(15),
                  o_qseq = o_qf + size_t(n_fid) * 4, o_fnfl = o_qseq + size_t(n_fid) * 4,
-                 total = o_fnfl + size_t(std::max<int64_t>(1, n_feature)) * 4;
+                 o_kflag = o_fnfl + size_t(std::max<int64_t>(1, n_feature)) * 4,   // (zeroed from here)
+                 o_nheavy = o_kflag + size_t(n_fid) * 4, o_heavy = o_nheavy + 16,
+                 o_cpos = o_heavy + size_t(n_fid) * 4, total = o_cpos + size_t(n_fid) * 4;
     struct Tmp {   // (freed in stream order behind the kernels that read it)
       char* d = nullptr;
       hipStream_t st;
@@ -3429,7 +3431,8 @@ static void layout_launch(bool forward, const float* const* embeddings, const in
     memcpy(h.data() + o_off, t_off.data(), t_off.size() * 4);
     if (!t_idx.empty()) memcpy(h.data() + o_idx, t_idx.data(), t_idx.size() * 4);
     HIP_OK(hipMemcpyAsync(tmp.d, h.data(), o_qf, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemsetAsync(tmp.d + o_qf, 0xff, total - o_qf, st));   // qf = -1, fnfl = ~0
+    HIP_OK(hipMemsetAsync(tmp.d + o_qf, 0xff, o_kflag - o_qf, st));   // qf = -1, fnfl = ~0
+    HIP_OK(hipMemsetAsync(tmp.d + o_kflag, 0, o_heavy - o_kflag, st));   // kflag, n_heavy
     HIP_OK(hipStreamSynchronize(st));   // (h is a pageable temporary)
     AuxWs& ws = AuxWs::of(current_device());
     std::lock_guard<std::mutex> g(ws.mu);
@@ -3446,9 +3449,22 @@ static void layout_launch(bool forward, const float* const* embeddings, const in
     X.nu = ws.nu.p;
     X.seg_off = ws.seg_off.p;
     X.seg_pos = ws.seg_pos.p;
+    X.inverse = ws.inverse.p;
+    X.kflag = reinterpret_cast<uint32_t*>(tmp.d + o_kflag);
+    X.n_heavy = reinterpret_cast<uint32_t*>(tmp.d + o_nheavy);
+    X.heavy = reinterpret_cast<uint32_t*>(tmp.d + o_heavy);
+    X.cpos = reinterpret_cast<uint32_t*>(tmp.d + o_cpos);
     const int64_t inst = int64_t(n_nfl) * batch;
     if (inst > 0) layout_qmap_kernel<<<dim3(uint32_t((inst + 255) / 256)), 256, 0, st>>>(A, X);
+    layout_heavy_select_kernel<<<dim3(uint32_t((n_fid + 255) / 256)), 256, 0, st>>>(A, X);
     layout_grad_lists_kernel<<<dim3(uint32_t((n_fid * 16 + 255) / 256)), 256, 0, st>>>(A, X);
+    // (heavy rows: persistent workgroups over the list the select kernel made; rows are disjoint
+    // from the light ones, so the two launches' order does not matter)
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, current_device()) != hipSuccess || cus <= 0)
+      cus = 256;
+    layout_grad_heavy_kernel<<<dim3(uint32_t(std::min<int64_t>(2 * cus, n_fid / kLayoutLight + 64))),
+                               1024, 0, st>>>(A, X);
     HIP_OK(hipGetLastError());
     return;
   }

@@ -225,7 +225,26 @@ struct LayoutLists {
   const uint32_t* nu;               //   their number,
   const uint32_t* seg_off;          //   and positions: seg_pos[seg_off[u] .. seg_off[u + 1]) ascending
   const uint32_t* seg_pos;
+  const uint32_t* inverse;          // [n_fid] distinct-key index of position q
+  uint32_t* kflag;                  // [n_fid] per distinct key: 1 = a SHARED list reaches it
+  uint32_t* heavy;                  // [n_fid] distinct-key indices of the heavy keys, n_heavy[0] of them
+  uint32_t* n_heavy;
+  uint32_t* cpos;                   // [n_fid] scratch of the heavy form (a key's slice of it: its list)
 };
+
+// A row that receives more than kLayoutLight contributions for one slice is HEAVY: a Zipf head row
+// is pooled into tens of thousands of batch rows, a row of a SHARED list into every batch row, and
+// one lane group walking that in order would be the launch's long pole (64 ms against 4 ms with
+// atomics, scripts/next_rows_bench.py layout).  A heavy row gets a workgroup: the contribution
+// sequence of a slice — still in the op's order — is cut into kLayoutHeavyGroups contiguous ranges,
+// each summed in order by one lane group, and the partial sums are added to the row in range order.  The result
+// depends on the inputs only (same bits on every run); against the strictly sequential sum it
+// differs by fp32 re-association, as the training step's heavy lists do.
+constexpr uint32_t kLayoutLight = 1024;
+__device__ __forceinline__ bool layout_key_heavy(const LayoutArgs& A, const LayoutLists& X, int64_t u) {
+  const uint64_t len = X.seg_off[u + 1] - X.seg_off[u];
+  return len > kLayoutLight || (X.kflag[u] && len * uint64_t(A.batch) > kLayoutLight);
+}
 
 static_assert(sizeof(LayoutArgs) + sizeof(LayoutLists) <= 4096, "kernel arguments exceed 4 KB");
 
@@ -250,8 +269,39 @@ __global__ __launch_bounds__(256) void layout_qmap_kernel(LayoutArgs A, LayoutLi
     X.qf[q] = f;
     X.qseq[q] = seq;
     if (uint32_t(A.fid_offset[q] >> 32) < uint32_t(A.n_emb)) ++seq;
+    if (shared) X.kflag[X.inverse[q]] = 1u;   // (racing stores of the same value)
   }
 }
+
+__global__ __launch_bounds__(256) void layout_heavy_select_kernel(LayoutArgs A, LayoutLists X) {
+  const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u >= int64_t(X.nu[0])) return;
+  if (uint32_t(static_cast<unsigned long long>(X.ukeys[u]) >> 32) >= uint32_t(A.n_emb)) return;
+  if (layout_key_heavy(A, X, u)) X.heavy[atomicAdd(X.n_heavy, 1u)] = uint32_t(u);
+}
+
+// one contribution of slice t to element e of its row from list position q and batch row b, loaded
+// unconditionally from a valid address (the callers keep several of these dependent chains —
+// position -> feature instance -> gradient row — in flight and add the results in order afterwards);
+// *ok = false: FIRSTN beyond max_sequence_length, nothing is added
+__device__ __forceinline__ float layout_contribution(const LayoutArgs& A, const LayoutLists& X,
+                                                    const LayoutTask& t, const float* og, uint32_t q,
+                                                    int32_t f, int32_t b, int32_t e, bool* ok) {
+  const float* orow = og + int64_t(b) * t.out_stride + t.out_offset;
+  if (t.pooling == kPoolFirstN) {
+    const uint32_t seq = X.qseq[q];
+    *ok = seq < uint32_t(t.max_seq);
+    return orow[int64_t(*ok ? seq : 0u) * t.dim + e];
+  }
+  *ok = true;
+  if (t.pooling == kPoolMean) {
+    const int32_t f0 = A.feature_offset[f];
+    const int32_t f1 = f < A.n_feature - 1 ? A.feature_offset[f + 1] : A.n_fid;
+    return orow[e] / float(f1 - f0);
+  }
+  return orow[e];
+}
+constexpr int kLayoutUnroll = 8;
 
 __global__ __launch_bounds__(256) void layout_grad_lists_kernel(LayoutArgs A, LayoutLists X) {
   constexpr int G = 16;
@@ -260,7 +310,7 @@ __global__ __launch_bounds__(256) void layout_grad_lists_kernel(LayoutArgs A, La
   if (u >= int64_t(X.nu[0])) return;
   const unsigned long long key = static_cast<unsigned long long>(X.ukeys[u]);
   const uint32_t i1 = uint32_t(key >> 32), i2 = uint32_t(key);
-  if (i1 >= uint32_t(A.n_emb)) return;
+  if (i1 >= uint32_t(A.n_emb) || layout_key_heavy(A, X, u)) return;
   const uint32_t l0 = X.seg_off[u], l1 = X.seg_off[u + 1];
   float* const mat = const_cast<float*>(layout_emb(A, i1));
   const uint64_t rbase = uint64_t(i2) * layout_stride(A, i1);
@@ -298,28 +348,156 @@ __global__ __launch_bounds__(256) void layout_grad_lists_kernel(LayoutArgs A, La
       // (L2-served load: the previous slice's store to an overlapping element came from another lane)
       float acc = __hip_atomic_load(mat + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (int32_t bb = 0; bb < nb; ++bb) {
-        for (uint32_t p = l0; p < l1; ++p) {
-          const uint32_t q = X.seg_pos[p];
-          const int32_t f = X.qf[q];
-          if (f < 0 || X.fnfl[f] != uint32_t(t.nfl_idx)) continue;
-          const int32_t b = shared ? bb : f - off;
-          if (b < 0 || b >= A.batch) continue;
-          const float* orow = og + int64_t(b) * t.out_stride + t.out_offset;
-          if (t.pooling == kPoolFirstN) {
-            const uint32_t seq = X.qseq[q];
-            if (seq < uint32_t(t.max_seq)) acc = acc + orow[int64_t(seq) * t.dim + e];
-          } else if (t.pooling == kPoolMean) {
-            const int32_t f0 = A.feature_offset[f];
-            const int32_t f1 = f < A.n_feature - 1 ? A.feature_offset[f + 1] : A.n_fid;
-            acc = acc + orow[e] / float(f1 - f0);
-          } else {
-            acc = acc + orow[e];
+        for (uint32_t p0 = l0; p0 < l1; p0 += kLayoutUnroll) {
+          float x[kLayoutUnroll];
+          bool ok[kLayoutUnroll];
+#pragma unroll
+          for (int r = 0; r < kLayoutUnroll; ++r) {   // (unconditional loads from clamped positions)
+            const uint32_t p = min(p0 + uint32_t(r), l1 - 1u);
+            const uint32_t q = X.seg_pos[p];
+            const int32_t f = X.qf[q];
+            const int32_t fc = max(f, 0);
+            const int32_t b = shared ? bb : fc - off;
+            const bool in = p0 + uint32_t(r) < l1 && f >= 0 && X.fnfl[fc] == uint32_t(t.nfl_idx) && b >= 0 &&
+                            b < A.batch;
+            bool o2;
+            x[r] = layout_contribution(A, X, t, og, q, fc, in ? b : 0, e, &o2);
+            ok[r] = in && o2;
           }
+#pragma unroll
+          for (int r = 0; r < kLayoutUnroll; ++r)
+            if (ok[r]) acc = acc + x[r];
         }
       }
       mat[at] = acc;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this slice's stores before the next one's loads)
+  }
+}
+
+// the heavy rows: one workgroup per row, see kLayoutLight
+constexpr int kLayoutHeavyGroups = 64;   // lane groups of that workgroup = ranges of a slice's sum
+__global__ __launch_bounds__(1024) void layout_grad_heavy_kernel(LayoutArgs A, LayoutLists X) {
+  constexpr int G = 16, NG = kLayoutHeavyGroups, NT = G * NG, NW = NT / 64;
+  __shared__ int32_t s_best;
+  __shared__ uint32_t s_wcnt[NW];
+  __shared__ float s_part[NG][G];
+  __shared__ uint32_t s_has[NG];
+  const int tid = threadIdx.x, j = tid & (G - 1), g = tid >> 4, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t nh = X.n_heavy[0];
+  for (uint32_t w = blockIdx.x; w < nh; w += gridDim.x) {
+    const uint32_t u = X.heavy[w];
+    const unsigned long long key = static_cast<unsigned long long>(X.ukeys[u]);
+    const uint32_t i1 = uint32_t(key >> 32), i2 = uint32_t(key);
+    const uint32_t l0 = X.seg_off[u], l1 = X.seg_off[u + 1];
+    float* const mat = const_cast<float*>(layout_emb(A, i1));
+    const uint64_t rbase = uint64_t(i2) * layout_stride(A, i1);
+    const uint64_t cnt = layout_count(A, i1);
+    int32_t last_k = -1;
+    for (;;) {
+      // ---- the next slice
+      if (tid == 0) s_best = INT32_MAX;
+      __syncthreads();
+      int32_t best = INT32_MAX;
+      for (uint32_t p = l0 + uint32_t(tid); p < l1; p += NT) {
+        const int32_t f = X.qf[X.seg_pos[p]];
+        if (f < 0) continue;
+        const uint32_t nfl = X.fnfl[f];
+        if (nfl >= uint32_t(A.n_nfl)) continue;
+        for (uint32_t c = X.nfl_task_off[nfl]; c < X.nfl_task_off[nfl + 1]; ++c) {
+          const int32_t k = int32_t(X.nfl_tasks[c]);
+          if (k > last_k) {
+            best = min(best, k);
+            break;
+          }
+        }
+      }
+      if (best != INT32_MAX) atomicMin(&s_best, best);
+      __syncthreads();
+      best = s_best;
+      if (best == INT32_MAX) break;
+      last_k = best;
+      const LayoutTask t = X.tasks[best];
+      const float* og = layout_out(A, t.out_index);
+      const uint32_t enc = A.nfl_offset[t.nfl_idx];
+      const bool shared = enc >> 31;
+      const int32_t off = int32_t(enc & 0x7fffffffu);
+      // ---- the slice's entries of the list, in list order -> cpos[l0 .. l0 + m)
+      uint32_t m = 0;
+      for (uint32_t tile = l0; tile < l1; tile += NT) {
+        const uint32_t p = tile + uint32_t(tid);
+        bool match = false;
+        uint32_t q = 0;
+        if (p < l1) {
+          q = X.seg_pos[p];
+          const int32_t f = X.qf[q];
+          if (f >= 0 && X.fnfl[f] == uint32_t(t.nfl_idx)) {
+            const int32_t b = shared ? 0 : f - off;
+            match = b >= 0 && b < A.batch;
+          }
+        }
+        const unsigned long long mask = __ballot(match);
+        if (lane == 0) s_wcnt[wave] = uint32_t(__popcll(mask));
+        __syncthreads();
+        uint32_t base = m;
+        for (int w2 = 0; w2 < wave; ++w2) base += s_wcnt[w2];
+        if (match) X.cpos[l0 + base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)))] = q;
+        for (int w2 = 0; w2 < NW; ++w2) m += s_wcnt[w2];
+        __syncthreads();
+      }
+      // (cpos is read back below by other lanes of this workgroup: L2-served loads after the drain)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const uint64_t total = uint64_t(m) * uint64_t(shared ? A.batch : 1);
+      const uint64_t per = (total + NG - 1) / NG;
+      const uint64_t lo = min(total, per * uint64_t(g)), hi = min(total, lo + per);
+      for (int32_t e0 = 0; e0 < t.dim; e0 += G) {
+        const int32_t e = e0 + j;
+        const uint64_t at = rbase + uint32_t(t.start) + uint32_t(e);
+        const bool active = e < t.dim && at < cnt;
+        float acc = 0.f;
+        bool has = false;
+        if (active) {
+          for (uint64_t s0 = lo; s0 < hi; s0 += kLayoutUnroll) {
+            float x[kLayoutUnroll];
+            bool ok[kLayoutUnroll];
+#pragma unroll
+            for (int r = 0; r < kLayoutUnroll; ++r) {   // (unconditional loads from clamped indices)
+              const uint64_t s_ = min(s0 + uint64_t(r), hi - 1u);
+              const uint32_t i = uint32_t(shared ? s_ % m : s_);
+              const uint32_t q = __hip_atomic_load(X.cpos + l0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const int32_t f = X.qf[q];
+              const int32_t b = shared ? int32_t(s_ / m) : f - off;
+              bool o2;
+              x[r] = layout_contribution(A, X, t, og, q, f, b, e, &o2);
+              ok[r] = o2 && s0 + uint64_t(r) < hi;
+            }
+#pragma unroll
+            for (int r = 0; r < kLayoutUnroll; ++r)
+              if (ok[r]) {
+                acc = has ? acc + x[r] : x[r];
+                has = true;
+              }
+          }
+        }
+        s_part[g][j] = acc;
+        // (has is the same for the lanes of a group that are active; lane 0 of a group is active
+        // whenever any lane is: e0 + 0 < t.dim, and the bound check only cuts a row's tail)
+        if (j == 0) s_has[g] = (active && has) ? 1u : 0u;
+        __syncthreads();
+        if (g == 0 && active) {
+          float a = __hip_atomic_load(mat + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int gg = 0; gg < NG; ++gg)
+            if (s_has[gg]) a = a + s_part[gg][j];
+          mat[at] = a;
+        }
+        __syncthreads();
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this slice's stores before the next one's loads)
+      __syncthreads();
+    }
+    __syncthreads();
   }
 }
 

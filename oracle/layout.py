@@ -376,3 +376,76 @@ def layout_grad_model(embs, fid_offset, feature_offset, nfl_offset, batch, cfgs,
       else:
         grads[i1][i2, sc.start:sc.end] += view
   return grads
+
+
+# the product's atomic-free gradient (csrc/mhte_layout_kernels.h: kLayoutLight, kLayoutHeavyGroups)
+LAYOUT_LIGHT = 1024
+LAYOUT_HEAVY_GROUPS = 64
+
+
+def layout_grad_model_grouped(embs, fid_offset, feature_offset, nfl_offset, batch, cfgs, tensors_grad,
+                              light=LAYOUT_LIGHT, groups=LAYOUT_HEAVY_GROUPS):
+  """The gradient as the product's grouped form computes it, fp32 add for fp32 add: per embedding
+  row and slice (slices in configuration order) the contributions in the op's order (batch rows
+  ascending, fids in list order).  A LIGHT row adds them one after the other onto the row — which is
+  layout_grad_model(acc_dtype=float32).  A HEAVY row (more than `light` positions of fid_offset name
+  it, or a shared list reaches it and positions x batch exceeds `light`) cuts a slice's sequence into
+  `groups` contiguous ranges, sums each range in order and adds the range sums to the row in range
+  order.  -> (gradients, number of heavy rows)"""
+  names = sorted(cfgs.feature_configs)
+  n_feature, n_nfl = len(feature_offset), len(nfl_offset)
+  fo = [int(x) for x in fid_offset]
+  length = {}
+  for v in fo:
+    k = (v >> 32, v & 0xffffffff)
+    length[k] = length.get(k, 0) + 1
+  shared_rows = set()
+  for nfl in range(n_nfl):
+    enc = int(nfl_offset[nfl])
+    if not enc >> 31:
+      continue
+    noff = enc & 0x7fffffff
+    nxt = (int(nfl_offset[nfl + 1]) & 0x7fffffff) if nfl < n_nfl - 1 else n_feature
+    if nxt - noff <= 0 or noff >= n_feature:
+      continue
+    f0 = int(feature_offset[noff])
+    f1 = int(feature_offset[noff + 1]) if noff < n_feature - 1 else len(fo)
+    for q in range(f0, f1):
+      shared_rows.add((fo[q] >> 32, fo[q] & 0xffffffff))
+  heavy = {k for k, n in length.items() if n > light or (k in shared_rows and n * batch > light)}
+  # (row, slice ordinal) -> contributions in order; None = FIRSTN beyond max_sequence_length
+  seqs, order = {}, {}
+  for t_idx, sc, oc, i, off, b, rows in _walk(fid_offset, feature_offset, nfl_offset, batch, cfgs):
+    fc = cfgs.feature_configs[sc.feature_name]
+    view = _view(tensors_grad[t_idx], oc, i, off, sc.end - sc.start, b)
+    tid = order.setdefault((id(oc), i), len(order))
+    for s_, (i1, i2) in enumerate(rows):
+      if i1 >= len(embs):
+        continue
+      if fc.pooling_type == FIRSTN:
+        x = view[s_, :].astype(np.float32) if s_ < fc.max_sequence_length else None
+      elif fc.pooling_type == MEAN:
+        x = (view / np.float32(len(rows))).astype(np.float32)
+      else:
+        x = np.asarray(view, np.float32)
+      seqs.setdefault((i1, i2), {}).setdefault((tid, sc.start, sc.end), []).append(x)
+  grads = [np.zeros(e.shape, np.float32) for e in embs]
+  for (i1, i2), per_task in seqs.items():
+    for (tid, s0, s1), xs in sorted(per_task.items()):
+      acc = grads[i1][i2, s0:s1].copy()
+      if (i1, i2) not in heavy:
+        for x in xs:
+          if x is not None:
+            acc = acc + x
+      else:
+        per = (len(xs) + groups - 1) // groups
+        for g in range(groups):
+          part = None
+          for x in xs[g * per:(g + 1) * per]:
+            if x is not None:
+              part = x.copy() if part is None else part + x
+          if part is not None:
+            acc = acc + part
+      grads[i1][i2, s0:s1] = acc
+  return grads, len(heavy & set(seqs))
+

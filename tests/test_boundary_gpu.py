@@ -578,10 +578,69 @@ def test_fused_embedding_to_layout_forward_and_grad(batch, seed):
   if _LAYOUT_GRAD_EXACT:
     # rows of matrix 0 are reached from f_a and from the SHARED list f_d, through overlapping slices
     # of four layouts: slices in configuration order, batch rows ascending, fids in list order
-    gs = _layout_model(embs, fid_offset, feature_offset, nfl_offset, batch, cfgs, tensors_grad=tg,
-                       acc_dtype=np.float32)
+    # (at batch 300 the shared list's rows are heavy: the workgroup form, restated exactly too)
+    oc = _to_oracle_cfgs(cfgs)
+    gs, n_heavy = OL.layout_grad_model_grouped(embs, fid_offset, feature_offset, nfl_offset, batch, oc, tg)
     for g, e in zip(gg, gs):
       np.testing.assert_array_equal(g.cpu().numpy(), e)
+    if n_heavy == 0:   # light rows only: the op's strictly sequential fp32 sums
+      seq = OL.layout_grad_model(embs, fid_offset, feature_offset, nfl_offset, batch, oc, tg, acc_dtype=np.float32)
+      for e, s_ in zip(gs, seq):
+        np.testing.assert_array_equal(e, s_)
+    else:
+      assert batch == 300
+
+
+def test_fused_embedding_to_layout_grad_heavy_rows():
+  """Rows that receive more contributions than one lane group should walk (a hot row pooled into
+  thousands of batch rows; every row of a SHARED list at batch > 1024): the workgroup form — a
+  slice's sequence in 64 contiguous ranges, range sums added in range order — against its
+  restatement bit for bit, the same bits on a second run, and the sequential sum within fp32
+  re-association."""
+  if not _LAYOUT_GRAD_EXACT:
+    pytest.skip("MHTE_POOL_ATOMICS=1")
+  from monolith_amd import distribution_ops as D
+  rng = np.random.default_rng(11)
+  batch = 1500
+  P_, OT, S_ = D.PoolingType, D.OutType, D.SliceConfig
+  feats = {"f_a": D.FeatureConfig("t0", P_.SUM, [1, 8]), "f_b": D.FeatureConfig("t0", P_.MEAN, [1, 8]),
+           "f_s": D.FeatureConfig("t1", P_.SUM, [1, 8]),
+           "f_n": D.FeatureConfig("t1", P_.FIRSTN, [1, 4], max_sequence_length=2)}
+  outs = {"bias": D.OutConfig([S_("f_a", 0, 1), S_("f_b", 0, 1), S_("f_s", 0, 1)], OT.ADDN, [[-1, 1]]),
+          "vec": D.OutConfig([S_("f_a", 1, 9), S_("f_b", 1, 9), S_("f_s", 1, 9)], OT.CONCAT, [[-1, 24]]),
+          "seq": D.OutConfig([S_("f_n", 1, 5)], OT.NONE, [[-1, 2, 4]])}
+  cfgs = D.FeatureConfigs(feats, outs)
+  embs = [rng.standard_normal((64, 9)).astype(np.float32), rng.standard_normal((32, 9)).astype(np.float32)]
+  mat_of = {"f_a": 0, "f_b": 0, "f_s": 1, "f_n": 1}
+  fid_offset, feature_offset, nfl_offset = [], [], []
+  for name in sorted(feats):
+    shared = name == "f_s"
+    nfl_offset.append(len(feature_offset) | ((1 << 31) if shared else 0))
+    for b in range(1 if shared else batch):
+      feature_offset.append(len(fid_offset))
+      m = mat_of[name]
+      for _ in range(3 if shared else int(rng.integers(0, 4))):
+        # rows 0 and 1 of matrix 0 are hot (f_a AND f_b reach them: two features, overlapping slices)
+        row = int(rng.integers(0, 2)) if (m == 0 and rng.random() < 0.7) else int(rng.integers(0, embs[m].shape[0]))
+        fid_offset.append((m << 32) | row)
+  fo = torch.tensor(np.array(fid_offset, dtype=np.uint64).view(np.int64)).cuda()
+  fe = torch.tensor(np.array(feature_offset, dtype=np.int32)).cuda()
+  nf = torch.tensor(np.array(nfl_offset, dtype=np.uint32).view(np.int32)).cuda()
+  dev_embs = [torch.tensor(e).cuda() for e in embs]
+  shapes = [[batch, 1], [batch, 2, 4], [batch, 24]]            # layouts in sorted-name order
+  tg = [rng.standard_normal(sh).astype(np.float32) for sh in shapes]
+  dev_tg = [torch.tensor(t).cuda() for t in tg]
+  got = [g.cpu().numpy() for g in D.fused_embedding_to_layout_grad(dev_embs, fo, fe, nf, batch, dev_tg, cfgs)]
+  again = [g.cpu().numpy() for g in D.fused_embedding_to_layout_grad(dev_embs, fo, fe, nf, batch, dev_tg, cfgs)]
+  oc = _to_oracle_cfgs(cfgs)
+  exp, n_heavy = OL.layout_grad_model_grouped(embs, fid_offset, feature_offset, nfl_offset, batch, oc, tg)
+  assert n_heavy >= 5           # the two hot rows, and the shared list's rows (3 fids x 1500 batch rows)
+  seq = OL.layout_grad_model(embs, fid_offset, feature_offset, nfl_offset, batch, oc, tg, acc_dtype=np.float32)
+  for g, g2, e, s_ in zip(got, again, exp, seq):
+    np.testing.assert_array_equal(g, e)
+    np.testing.assert_array_equal(g, g2)
+    np.testing.assert_allclose(g, s_, rtol=2e-5, atol=2e-4)
+  assert any(not np.array_equal(e, s_) for e, s_ in zip(exp, seq))   # (the ranges do re-associate)
 
 
 def test_fused_embedding_to_layout_copy_form():
