@@ -306,8 +306,13 @@ mhte_status mhte_reduce_rows(const int64_t* indices, const float* values, int64_
  *   outputs            HOST array of device pointers, zero-filled first (rows without fids stay 0)
  * SUM / MEAN walk a feature's fids in order (the reference's loop: bit-identical sums); the slices
  * of an ADDN layout are added in configuration order (the reference's CPU order; its CUDA path uses
- * float atomics).  The gradient op zero-fills embeddings_grad and adds with float atomics, as the
- * reference's CUDA path does.  <= 64 matrices, <= 32 outputs per call.
+ * float atomics).  The gradient op zero-fills embeddings_grad and adds, per embedding row, in the
+ * order the reference's CPU kernel does (slices in configuration order, batch rows ascending, fids
+ * in list order): its sequential fp32 sums bit for bit, no float atomics; a row with more than 1 024
+ * contributions to one slice sums 64 contiguous ranges of that sequence and adds the range sums in
+ * order (same bits on every run; fp32 re-association against the sequential sum).
+ * MHTE_POOL_ATOMICS=1 in the environment selects the reference's CUDA form (float atomics, arrival
+ * order).  Any number of matrices and outputs (beyond 64 / 32 their pointers are uploaded per call).
  * flags: MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS — the caller states that every feature instance has exactly
  * one fid and no embedding row is referenced twice (the per-occurrence rows of a lookup feeding a
  * one-id-per-feature model): slices on float4 boundaries then move as float4 copies and the gradient
