@@ -1059,7 +1059,9 @@ struct Table {
     const bool basic = basic_opts();
 #define CALL(G_, V_) \
   do {                                                                                               \
-    if (!basic) {                                                                                    \
+    if (!basic && nseg == 1) {                                                                       \
+      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, true, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a); \
+    } else if (!basic) {                                                                             \
       LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, false, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a); \
     } else if (nseg == 1) {                                                                          \
       LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a);  \

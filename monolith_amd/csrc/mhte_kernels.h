@@ -2727,12 +2727,12 @@ __device__ __forceinline__ void optimize_row_reg(const TableView& tv, float* rp,
 // the fused step kernels' FULL instantiations.  Kept apart from optimize_row_reg so that the kernels
 // of SGD / Adagrad / FTRL tables keep their register budget (the twelve-way switch costs ~20 VGPRs).
 // Arithmetic: the one source of apply_row (optimizer steps of mhte_core.h), one Optimize() call.
-template <int VEC>
+template <int VEC, bool ONESEG = false>
 __device__ __forceinline__ void optimize_row_reg_full(const TableView& tv, float* rp, bool is_new,
                                                       uint32_t e, const Vec<VEC>& g, const ApplyArgs& a) {
   if (e >= tv.dim) return;
   uint32_t k = 0;
-  const SegDesc sd = seg_of<false>(tv, e, k);
+  const SegDesc sd = seg_of<ONESEG>(tv, e, k);
   const uint32_t le = e - sd.w_off;
   const float lr = a.lr[k];
   const int nv = opt_vectors(sd.opt);
@@ -2746,15 +2746,20 @@ __device__ __forceinline__ void optimize_row_reg_full(const TableView& tv, float
   float c1 = 0.f, c2 = 0.f;
   long long last_step = 0;
   if (is_new) {
+    SegDesc si = seg_for_init(sd);
+    if (ONESEG) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) si.p[i] = opaque_f(sd.p[i]);
+    }
 #pragma unroll
     for (int c = 0; c < VEC; ++c) {
-      w.v[c] = init_weight(sd, rp + e + c);
-      s1.v[c] = opt_state_init(sd, 0);
-      s2.v[c] = opt_state_init(sd, 1);
-      s3.v[c] = opt_state_init(sd, 2);
+      w.v[c] = init_weight(si, rp + e + c);
+      s1.v[c] = opt_state_init(si, 0);
+      s2.v[c] = opt_state_init(si, 1);
+      s3.v[c] = opt_state_init(si, 2);
     }
-    c1 = sd.p[0];
-    c2 = sd.p[1];
+    c1 = si.p[0];
+    c2 = si.p[1];
   } else {
     w.load(rp + e);
     if (nv > 0) s1.load(st1);
@@ -2768,32 +2773,38 @@ __device__ __forceinline__ void optimize_row_reg_full(const TableView& tv, float
       last_step = static_cast<long long>(
           (static_cast<unsigned long long>(__float_as_uint(sc[1])) << 32) | __float_as_uint(sc[0]));
   }
-  const float lr_eff = scal ? adam_lr(lr, c1, c2) : lr;
+  // (ONESEG: the descriptor is uniform, and what the eleven update rules derive from it — VGPR copies
+  // of the hyper-parameters, their double forms, 1 - beta — would be hoisted in front of the caller's
+  // trip loop and spilled there: 100 B per lane at every loop entry, reloaded inside the rules.
+  // Copies the compiler cannot see through keep all of that in the trip; see opaque_f.)
+  float hp[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) hp[i] = ONESEG ? opaque_f(sd.p[i]) : sd.p[i];
+  const float lrv = ONESEG ? opaque_f(lr) : lr;
+  const float lr_eff = scal ? adam_lr(lrv, c1, c2) : lrv;
 #pragma unroll
   for (int c = 0; c < VEC; ++c) {
     switch (sd.opt) {
-      case kOptSgd: w.v[c] = sgd_step(w.v[c], g.v[c], lr); break;
-      case kOptAdagrad: adagrad_step(w.v[c], s1.v[c], g.v[c], lr, sd.p[1]); break;
-      case kOptFtrl: ftrl_step(w.v[c], s1.v[c], s2.v[c], g.v[c], lr, sd.p[1], sd.p[2], sd.p[3]); break;
-      case kOptMomentum: momentum_step(w.v[c], s1.v[c], g.v[c], lr, sd.p[0], sd.p[1], sd.p[2] != 0.f); break;
-      case kOptAdadelta: adadelta_step(w.v[c], s1.v[c], s2.v[c], g.v[c], lr, sd.p[0], sd.p[1], sd.p[2]); break;
-      case kOptRmsprop: rmsprop_step(w.v[c], s1.v[c], g.v[c], double(sd.p[2]), sd.p[0], sd.p[1], false); break;
-      case kOptRmspropV2: rmsprop_step(w.v[c], s1.v[c], g.v[c], double(lr), sd.p[0], sd.p[1], true); break;
+      case kOptSgd: w.v[c] = sgd_step(w.v[c], g.v[c], lrv); break;
+      case kOptAdagrad: adagrad_step(w.v[c], s1.v[c], g.v[c], lrv, hp[1]); break;
+      case kOptFtrl: ftrl_step(w.v[c], s1.v[c], s2.v[c], g.v[c], lrv, hp[1], hp[2], hp[3]); break;
+      case kOptMomentum: momentum_step(w.v[c], s1.v[c], g.v[c], lrv, hp[0], hp[1], hp[2] != 0.f); break;
+      case kOptAdadelta: adadelta_step(w.v[c], s1.v[c], s2.v[c], g.v[c], lrv, hp[0], hp[1], hp[2]); break;
+      case kOptRmsprop: rmsprop_step(w.v[c], s1.v[c], g.v[c], double(hp[2]), hp[0], hp[1], false); break;
+      case kOptRmspropV2: rmsprop_step(w.v[c], s1.v[c], g.v[c], double(lrv), hp[0], hp[1], true); break;
       case kOptAdam:
-        adam_step(w.v[c], s1.v[c], s2.v[c], nullptr, g.v[c], lr_eff, sd.p[0], sd.p[1], sd.p[2], sd.p[3],
-                  sd.p[4] != 0.f);
+        adam_step(w.v[c], s1.v[c], s2.v[c], nullptr, g.v[c], lr_eff, hp[0], hp[1], hp[2], hp[3], hp[4] != 0.f);
         break;
-      case kOptMovingAverage: w.v[c] = moving_average_step(w.v[c], g.v[c], sd.p[0]); break;
-      case kOptBatchSoftmax: batch_softmax_step(w.v[c], last_step, lr, a.global_step); break;
+      case kOptMovingAverage: w.v[c] = moving_average_step(w.v[c], g.v[c], hp[0]); break;
+      case kOptBatchSoftmax: batch_softmax_step(w.v[c], last_step, lrv, a.global_step); break;
       default:  // kOptAmsgrad
-        adam_step(w.v[c], s1.v[c], s2.v[c], &s3.v[c], g.v[c], lr_eff, sd.p[0], sd.p[1], sd.p[2], sd.p[3],
-                  sd.p[4] != 0.f);
+        adam_step(w.v[c], s1.v[c], s2.v[c], &s3.v[c], g.v[c], lr_eff, hp[0], hp[1], hp[2], hp[3], hp[4] != 0.f);
         break;
     }
   }
   if (scal) {
-    c1 = c1 * sd.p[0];
-    c2 = c2 * sd.p[1];
+    c1 = c1 * hp[0];
+    c2 = c2 * hp[1];
   }
   row_store<VEC>(rp + e, w);
   if (nv > 0) row_store<VEC>(st1, s1);

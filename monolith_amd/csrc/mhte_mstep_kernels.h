@@ -511,7 +511,8 @@ __global__ __launch_bounds__(256, MHTE_MBWD_OCC) void mstep_bwd_kernel(MBwdArgs 
   c.urow = bt.hints ? s.urow[cur] : nullptr;
   c.uloc = bt.hints ? s.uloc[cur] : nullptr;
   c.uts = bt.hints ? s.uts[cur] : nullptr;
-  if (FULL) mstep_apply_switch<false, true>(s.g, tv, d, c, bt.a, bid, wt, L);
+  if (FULL && s.oneseg) mstep_apply_switch<true, true>(s.g, tv, d, c, bt.a, bid, wt, L);
+  else if (FULL) mstep_apply_switch<false, true>(s.g, tv, d, c, bt.a, bid, wt, L);
   else if (s.oneseg) mstep_apply_switch<true, false>(s.g, tv, d, c, bt.a, bid, wt, L);
   else mstep_apply_switch<false, false>(s.g, tv, d, c, bt.a, bid, wt, L);
   wt.end(bid < bt.nblk_items ? 7u : 8u);

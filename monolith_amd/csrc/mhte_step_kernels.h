@@ -1086,7 +1086,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         if (ev) acc.store(c.grad_u + g * int64_t(dim) + e);
         if (j == 0) defer_id(tv, c.pending, uint32_t(g));
       } else if (valid) {
-        if (FULL) optimize_row_reg_full<VEC>(tv, rp, sr.is_new, e, acc, a);
+        if (FULL) optimize_row_reg_full<VEC, ONESEG>(tv, rp, sr.is_new, e, acc, a);
         else optimize_row_pre<VEC, ONESEG>(tv, rp, sr.is_new, e, acc, a, rr);
       }
       if (it == 0) wt.mark(4);
@@ -1269,7 +1269,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         if (ev) tot.store(c.grad_u + int64_t(hd.u) * dim + ed);
         if (j == 0) defer_id(tv, c.pending, hd.u);
       } else if (valid) {
-        if (FULL) optimize_row_reg_full<VEC>(tv, row_ptr(tv, sr.r), sr.is_new, e, tot, a);
+        if (FULL) optimize_row_reg_full<VEC, ONESEG>(tv, row_ptr(tv, sr.r), sr.is_new, e, tot, a);
         else optimize_row_reg<VEC, ONESEG>(tv, row_ptr(tv, sr.r), sr.is_new, e, tot, a);
       }
     }
