@@ -42,7 +42,7 @@ enum {
 
 const char* mhte_last_error(void);
 /* ABI version of this header; mhte_abi_version() must return the same value. */
-#define MHTE_ABI_VERSION 11
+#define MHTE_ABI_VERSION 12
 int32_t mhte_abi_version(void);
 
 /* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
@@ -53,7 +53,15 @@ enum {                                                                     /* op
   MHTE_OPT_MOMENTUM = 3, MHTE_OPT_ADADELTA = 4, MHTE_OPT_RMSPROP = 5, MHTE_OPT_RMSPROPV2 = 6,
   MHTE_OPT_ADAM = 7, MHTE_OPT_AMSGRAD = 8, MHTE_OPT_MOVING_AVERAGE = 9,
   MHTE_OPT_BATCH_SOFTMAX = 10, /* dim_size 1; uses the ops' global_step argument */
-  MHTE_OPT_GROUP_ADAGRAD = 11  /* AdaGradWithGroupLasso: one step needs the whole segment */
+  MHTE_OPT_GROUP_ADAGRAD = 11, /* AdaGradWithGroupLasso: one step needs the whole segment */
+  /* OR-ed into opt_type: OptimizerConfig.stochastic_rounding_float16 (optimizer.proto:228) — the
+     StochasticRoundingFloat16OptimizerDecorator (optimizer/stochastic_rounding.h:27-59): after every
+     Optimize() each weight of the segment becomes one of its two binary16 neighbours, the upper one
+     with probability (w - down) / (up - down).  The rounding function is the reference's, value for
+     value; its draws there come from a thread-local generator consumed in call order, here from a
+     counter-based hash of (element address, unrounded value, update_time, occurrence).  Not with
+     GROUP_ADAGRAD (INVALID_ARGUMENT). */
+  MHTE_OPT_FLAG_STOCHASTIC_ROUNDING_FP16 = 0x100
 };
 enum { MHTE_INIT_ZEROS = 0, MHTE_INIT_ONES = 1, MHTE_INIT_CONSTANT = 2, /* initializer_config.proto */
        MHTE_INIT_RANDOM_UNIFORM = 3 /* uniform in [init_value, init_value2): a counter-based draw per

@@ -26,11 +26,12 @@ MHTE_SUM_DUPLICATES = 2
 MHTE_EXACT_ORDER = 1       # flags of mhte_table_sum_optimize_n
 MHTE_DEFER_SLOWPATH = 2
 MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS = 1
-ABI_VERSION = 11           # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
+ABI_VERSION = 12           # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 OPT_MOMENTUM, OPT_ADADELTA, OPT_RMSPROP, OPT_RMSPROPV2, OPT_ADAM, OPT_AMSGRAD = 3, 4, 5, 6, 7, 8
 OPT_MOVING_AVERAGE, OPT_BATCH_SOFTMAX, OPT_GROUP_ADAGRAD = 9, 10, 11
+OPT_FLAG_STOCHASTIC_ROUNDING_FP16 = 0x100   # OR-ed into opt_type
 INIT_ZEROS, INIT_ONES, INIT_CONSTANT, INIT_RANDOM_UNIFORM = 0, 1, 2, 3
 
 

@@ -534,13 +534,16 @@ struct Table {
     dim = 0;
     for (auto& s : segs) {
       if (s.dim_size <= 0) throw Error(MHTE_INVALID_ARGUMENT, "segment dim_size must be > 0");
-      if (s.opt_type < MHTE_OPT_SGD || s.opt_type >= kOptCount)
+      const int32_t base_opt = s.opt_type & ~int32_t(MHTE_OPT_FLAG_STOCHASTIC_ROUNDING_FP16);
+      if (base_opt < MHTE_OPT_SGD || base_opt >= kOptCount)
         throw Error(MHTE_INVALID_ARGUMENT, "unknown optimizer type " + std::to_string(s.opt_type));
+      if (base_opt != s.opt_type && base_opt == MHTE_OPT_GROUP_ADAGRAD)
+        throw Error(MHTE_INVALID_ARGUMENT, "stochastic_rounding_float16 on a group_adagrad segment is not implemented");
       if (s.init_type < MHTE_INIT_ZEROS || s.init_type > MHTE_INIT_RANDOM_UNIFORM)
         throw Error(MHTE_INVALID_ARGUMENT, "unknown initializer type");
-      if (s.opt_type == MHTE_OPT_BATCH_SOFTMAX && s.dim_size != 1)  // batch_softmax_optimizer.cc:29
+      if (base_opt == MHTE_OPT_BATCH_SOFTMAX && s.dim_size != 1)  // batch_softmax_optimizer.cc:29
         throw Error(MHTE_INVALID_ARGUMENT, "a batch softmax segment has dim_size 1");
-      if (s.opt_type == MHTE_OPT_GROUP_ADAGRAD) has_group_opt = true;
+      if (base_opt == MHTE_OPT_GROUP_ADAGRAD) has_group_opt = true;
       dim += s.dim_size;
     }
     // row = float num[dim] | ctx(seg0) | ctx(seg1) ... (entry_accessor.cc:113-114)
@@ -551,7 +554,8 @@ struct Table {
       d.dim = segs[i].dim_size;
       d.w_off = w;
       d.st_off = st;
-      d.opt = segs[i].opt_type;
+      d.opt = segs[i].opt_type & ~int32_t(MHTE_OPT_FLAG_STOCHASTIC_ROUNDING_FP16);
+      d.sr16 = (segs[i].opt_type & MHTE_OPT_FLAG_STOCHASTIC_ROUNDING_FP16) ? 1 : 0;
       for (int k = 0; k < 8; ++k) d.p[k] = segs[i].opt_params[k];
       d.init = segs[i].init_type;
       d.init_value = segs[i].init_value;
@@ -871,7 +875,7 @@ struct Table {
   }
   bool basic_opts() const {   // SGD / Adagrad / FTRL only: the BASIC kernel instantiations
     for (uint32_t i = 0; i < nseg; ++i)
-      if (view.seg[i].opt > kOptFtrl) return false;
+      if (view.seg[i].opt > kOptFtrl || view.seg[i].sr16) return false;   // (rounding: FULL forms only)
     return true;
   }
   void sum_optimize(DedupWs& ws, const int64_t* uids, int64_t n_max, const uint32_t* n_dev,

@@ -72,6 +72,7 @@ struct SegDesc {
   int32_t init;     // InitType
   float init_value; // constants initializer value; random uniform: minval
   float init_value2; // random uniform: maxval
+  int32_t sr16;     // OptimizerConfig.stochastic_rounding_float16 (optimizer.proto:228)
 };
 
 // fmix64 (murmur3 finaliser).  Stands in for absl::Hash<int64_t> (cuckoohash_map.hpp:64-70), which
@@ -420,6 +421,89 @@ MHTE_HD void adam_step(float& w, float& m, float& v, float* vhat, float grad, fl
 // (random_uniform_initializer.cc:31-37), i.e. values depend on which thread inserted what and are
 // not reproducible; here the draw is a counter-based hash of the element's address — uniform in
 // [minval, maxval), independent between elements, nothing to seed or to synchronise.
+// ---- fp16 stochastic rounding (the StochasticRoundingFloat16OptimizerDecorator,
+// optimizer/stochastic_rounding.h:27-59, OptimizerConfig.stochastic_rounding_float16): after every
+// Optimize() the weights — not the optimizer's state — become one of their two binary16 neighbours,
+// the upper one with probability (vf - down) / (up - down).  stochastic_round is the reference's
+// function value for value (pinned through oracle/mhte_oracle.c to the reference's own, compiled in
+// place).  Its draws come from a thread-local multiply-with-carry generator consumed in call order
+// there — no sequence an engine with another execution order could reproduce — so the draw here is
+// a counter-based hash of (the element's address, the unrounded value, update_time, the occurrence):
+// a function of the table's state, the same on every run, unbiased over the updates of an element.
+MHTE_HD uint32_t sr_float_bits(float f) {
+  union { float f; uint32_t u; } c;
+  c.f = f;
+  return c.u;
+}
+MHTE_HD float sr_bits_float(uint32_t u) {
+  union { float f; uint32_t u; } c;
+  c.u = u;
+  return c.f;
+}
+// float -> binary16 with a directed rounding (half.hpp float2half<round_toward_infinity /
+// round_toward_neg_infinity>), returned as the float it stands for
+MHTE_HD float half_neighbour(float f, bool toward_pos_inf) {
+  const uint32_t x = sr_float_bits(f);
+  const uint32_t sign = x >> 31, exp = (x >> 23) & 0xffu, man = x & 0x7fffffu;
+  if (exp == 0xffu) return f;
+  const bool mag_up = toward_pos_inf ? !sign : (sign != 0);
+  const int e = int(exp) - 127;
+  uint32_t h, rem;
+  if (exp == 0) {
+    h = 0;
+    rem = man;
+  } else if (e >= 16) {
+    h = mag_up ? 0x7c00u : 0x7bffu;
+    rem = 0;
+  } else if (e >= -14) {
+    h = (uint32_t(e + 15) << 10) | (man >> 13);
+    rem = man & 0x1fffu;
+  } else {
+    const uint32_t full = 0x800000u | man;
+    const int sh = 13 + (-14 - e);
+    if (sh >= 32) {
+      h = 0;
+      rem = 1;
+    } else {
+      h = full >> sh;
+      rem = full & ((1u << sh) - 1u);
+    }
+  }
+  if (rem && mag_up) h += 1;
+  // binary16 bits -> float
+  const uint32_t hexp = (h >> 10) & 0x1fu, hman = h & 0x3ffu;
+  uint32_t o;
+  if (hexp == 0x1fu) {
+    o = 0x7f800000u | (hman << 13);
+  } else if (hexp) {
+    o = ((hexp + 112u) << 23) | (hman << 13);
+  } else if (hman) {
+    int sft = 0;
+    uint32_t m = hman;
+    while (!(m & 0x400u)) {
+      m <<= 1;
+      ++sft;
+    }
+    o = (uint32_t(113 - sft) << 23) | ((m & 0x3ffu) << 13);
+  } else {
+    o = 0;
+  }
+  return sr_bits_float((sign << 31) | o);
+}
+MHTE_HD float stochastic_round(float vf, float p) {   // stochastic_rounding.h:27-40
+  const float up = half_neighbour(vf, true), down = half_neighbour(vf, false);
+  const float num = vf - down, den = up - down;
+  const float frac = num / den;   // (0 / 0 = NaN for a representable vf: the comparison is false)
+  return (p <= frac) ? up : down;
+}
+MHTE_HD float sr_draw(const float* where, float v, uint32_t ts, uint32_t occurrence) {
+  const uint64_t h = hash_key(static_cast<int64_t>(reinterpret_cast<uintptr_t>(where)) ^
+                              static_cast<int64_t>(uint64_t(sr_float_bits(v)) << 32) ^
+                              static_cast<int64_t>(uint64_t(ts) * 0x9E3779B97F4A7C15ull) ^
+                              static_cast<int64_t>(occurrence));
+  return static_cast<float>(h >> 40) * (1.0f / 16777216.0f);   // 24 bits -> [0, 1)
+}
+
 MHTE_HD float init_weight(const SegDesc& s, const float* where) {
   if (s.init == kInitRandomUniform) {
     const uint64_t h = hash_key(static_cast<int64_t>(reinterpret_cast<uintptr_t>(where)) ^ 0x5851f42d4c957f2dLL);

@@ -913,6 +913,11 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
           c1 = c1 * sd.p[0];
           c2 = c2 * sd.p[1];
         }
+        if (OP == kOpOptimize && !BASIC && sd.sr16) {   // the fp16 stochastic-rounding decorator
+#pragma unroll
+          for (int c = 0; c < VEC; ++c)
+            w.v[c] = stochastic_round(w.v[c], sr_draw(rp + e + c, w.v[c], a.ts, t));
+        }
       }
     }
     w.store(rp + e);
@@ -2805,6 +2810,10 @@ __device__ __forceinline__ void optimize_row_reg_full(const TableView& tv, float
   if (scal) {
     c1 = c1 * hp[0];
     c2 = c2 * hp[1];
+  }
+  if (sd.sr16) {   // the fp16 stochastic-rounding decorator (one Optimize() per step here)
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) w.v[c] = stochastic_round(w.v[c], sr_draw(rp + e + c, w.v[c], a.ts, 0u));
   }
   row_store<VEC>(rp + e, w);
   if (nv > 0) row_store<VEC>(st1, s1);

@@ -155,10 +155,10 @@ inline const OptSpec* opt_spec(uint32_t oneof_field) {
 inline void parse_optimizer(const uint8_t* b, size_t n, Segment* s) {
   Msg m(b, n);
   Field f;
-  bool have = false;
+  bool have = false, sr16 = false;
   while (m.next(&f)) {
-    if (f.num == 4 && f.wt == 0) {  // stochastic_rounding_float16
-      if (f.v) throw ckpt::ProtoError("config: stochastic_rounding_float16 is not supported by the MI355X engine");
+    if (f.num == 4 && f.wt == 0) {  // stochastic_rounding_float16 (optimizer.proto:228)
+      sr16 = f.v != 0;
       continue;
     }
     if (f.wt != 2) continue;
@@ -183,6 +183,7 @@ inline void parse_optimizer(const uint8_t* b, size_t n, Segment* s) {
     }
   }
   if (!have) throw ckpt::ProtoError("config: segment without an optimizer");
+  if (sr16) s->c.opt_type |= MHTE_OPT_FLAG_STOCHASTIC_ROUNDING_FP16;
 }
 
 inline void parse_initializer(const uint8_t* b, size_t n, Segment* s) {

@@ -20,6 +20,24 @@ class Optimizer:
     return ()
 
 
+class StochasticRoundingFloat16OptimizerWrapper(Optimizer):
+  """reference entry.py:42-50: sets OptimizerConfig.stochastic_rounding_float16 on the wrapped
+  optimizer's config — the segment's weights are stochastically rounded to binary16 values after
+  every update (MHTE_OPT_FLAG_STOCHASTIC_ROUNDING_FP16)."""
+
+  def __init__(self, optimizer: Optimizer):
+    if isinstance(optimizer, StochasticRoundingFloat16OptimizerWrapper) or optimizer.opt_type is None:
+      raise ValueError("StochasticRoundingFloat16OptimizerWrapper wraps a concrete optimizer")
+    self._optimizer = optimizer
+    self.opt_type = optimizer.opt_type | _lib.OPT_FLAG_STOCHASTIC_ROUNDING_FP16
+
+  def params(self):
+    return self._optimizer.params()
+
+  def __getattr__(self, name):   # learning_rate, warmup_steps, ... of the wrapped optimizer
+    return getattr(self.__dict__["_optimizer"], name)
+
+
 class SgdOptimizer(Optimizer):
   """reference entry.py:54-74; proto default learning_rate 0.01 (optimizer.proto:50-54)."""
   opt_type = _lib.OPT_SGD

@@ -963,3 +963,77 @@ int64_t mo_fused_reorder_by_indices(const int64_t* input, const int64_t* input_s
   imap_free(&m);
   return uniq;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * fp16 stochastic rounding (runtime/hash_table/optimizer/stochastic_rounding.h:27-40): the two
+ * binary16 neighbours of vf — float2half<round_toward_infinity> / <round_toward_neg_infinity> of
+ * third_party/half_sourceforge_net/half.hpp, converted back — and the upper one iff
+ * p <= (vf - down) / (up - down) in fp32 (0 / 0 for an exactly representable vf is NaN: the lower,
+ * equal, neighbour).  Pinned value for value to the reference's own function compiled in place
+ * (oracle/ref_sr_driver.cc, tests/test_stochastic_rounding.py).
+ * ------------------------------------------------------------------------------------------- */
+static uint16_t mo_float_to_half_dir(float f, int toward_pos_inf) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = x >> 31, exp = (x >> 23) & 0xffu, man = x & 0x7fffffu;
+  const uint16_t hs = (uint16_t)(sign << 15);
+  if (exp == 0xffu) return (uint16_t)(hs | (man ? 0x7e00u : 0x7c00u));
+  /* inexact results move the MAGNITUDE up when rounding away from zero on this side */
+  const int mag_up = toward_pos_inf ? !sign : (int)sign;
+  const int e = (int)exp - 127;
+  uint32_t h, rem;
+  if (exp == 0) {                 /* float zero / subnormal: far below the smallest half */
+    h = 0;
+    rem = man;
+  } else if (e >= 16) {           /* beyond the largest finite half (65504) */
+    return (uint16_t)(hs | (mag_up ? 0x7c00u : 0x7bffu));
+  } else if (e >= -14) {          /* normal half */
+    h = ((uint32_t)(e + 15) << 10) | (man >> 13);
+    rem = man & 0x1fffu;
+  } else {                        /* subnormal half: units of 2^-24 */
+    const uint32_t full = 0x800000u | man;
+    const int sh = 13 + (-14 - e);
+    if (sh >= 32) {
+      h = 0;
+      rem = 1;
+    } else {
+      h = full >> sh;
+      rem = full & ((1u << sh) - 1u);
+    }
+  }
+  if (rem && mag_up) h += 1;      /* (a carry out of the mantissa is the next exponent, up to inf) */
+  return (uint16_t)(hs | h);
+}
+
+static float mo_half_to_float(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h >> 15) << 31, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+  uint32_t x;
+  if (exp == 0x1fu) {
+    x = sign | 0x7f800000u | (man << 13);
+  } else if (exp) {
+    x = sign | ((exp + 112u) << 23) | (man << 13);
+  } else if (man) {               /* subnormal: man * 2^-24 */
+    int e = -1;
+    uint32_t m = man;
+    while (!(m & 0x400u)) {
+      m <<= 1;
+      ++e;
+    }
+    x = sign | ((uint32_t)(112 - e) << 23) | ((m & 0x3ffu) << 13);
+  } else {
+    x = sign;
+  }
+  float f;
+  memcpy(&f, &x, 4);
+  return f;
+}
+
+float mo_half_up(float vf) { return mo_half_to_float(mo_float_to_half_dir(vf, 1)); }
+float mo_half_down(float vf) { return mo_half_to_float(mo_float_to_half_dir(vf, 0)); }
+
+float mo_stochastic_round(float vf, float p) {
+  const float up = mo_half_up(vf), down = mo_half_down(vf);
+  const float num = vf - down, den = up - down;
+  const float frac = num / den;
+  return (p <= frac) ? up : down;
+}

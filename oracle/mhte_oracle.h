@@ -39,6 +39,9 @@ typedef struct {
 
 typedef struct mo_table mo_table;
 
+float mo_half_up(float vf);     /* nearest binary16 value >= vf (as float) */
+float mo_half_down(float vf);   /* nearest binary16 value <= vf */
+float mo_stochastic_round(float vf, float p);  /* stochastic_rounding.h:27-40 */
 uint64_t mo_hash(int64_t key);                       /* engine's fixed hash (fmix64) */
 uint8_t mo_partial(uint64_t hash);                   /* cuckoohash_map.hpp:860-869 */
 uint64_t mo_alt_index(int hp, uint8_t partial, uint64_t index); /* :882-888 */

@@ -99,12 +99,16 @@ def _build():
   msg("MomentumOptimizerConfig", [i32("dim_size", 1), sc("learning_rate", 2), sc("weight_decay_factor", 3),
                                   bl("use_nesterov", 4), sc("momentum", 5), i64("warmup_steps", 6)])
   msg("DcOptimizerConfig", [i32("dim_size", 1), sc("lambda_", 2)])
+  msg("GroupAdaGradOptimizerConfig", [i32("dim_size", 1), sc("learning_rate", 2), sc("beta", 3),
+                                      sc("initial_accumulator_value", 4), sc("l2_regularization_strength", 5),
+                                      sc("weight_decay_factor", 6), i64("warmup_steps", 7)])
   msg("OptimizerConfig", [("adagrad", 1, F.TYPE_MESSAGE, OPT, "AdagradOptimizerConfig", True),
                           ("sgd", 2, F.TYPE_MESSAGE, OPT, "SgdOptimizerConfig", True),
                           ("ftrl", 3, F.TYPE_MESSAGE, OPT, "FtrlOptimizerConfig", True),
                           ("adam", 7, F.TYPE_MESSAGE, OPT, "AdamOptimizerConfig", True),
                           ("momentum", 9, F.TYPE_MESSAGE, OPT, "MomentumOptimizerConfig", True),
                           ("dc", 13, F.TYPE_MESSAGE, OPT, "DcOptimizerConfig", True),
+                          ("group_adagrad", 16, F.TYPE_MESSAGE, OPT, "GroupAdaGradOptimizerConfig", True),
                           ("stochastic_rounding_float16", 4, F.TYPE_BOOL, OPT, None, False)], oneof="type")
   msg("ZerosInitializerConfig", [i32("dim_size", 1)])
   msg("OnesInitializerConfig", [i32("dim_size", 1)])

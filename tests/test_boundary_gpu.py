@@ -101,6 +101,38 @@ def test_create_from_serialized_config_and_kats():
   assert st.size == 1
 
 
+def test_serialized_config_stochastic_rounding_float16():
+  """OptimizerConfig.stochastic_rounding_float16 (optimizer.proto:228) in the serialized config: the
+  segment's weights are binary16 values after an update, the other segment's are not rounded; on a
+  group_adagrad segment the flag is refused."""
+  m = P.MultiEmbeddingHashTableConfig()
+  m.names.append("t")
+  c = m.configs.add()
+  s = c.entry_config.segments.add()
+  s.dim_size = 8
+  s.opt_config.adagrad.learning_rate = 0.05
+  s.opt_config.stochastic_rounding_float16 = True
+  s = c.entry_config.segments.add()
+  s.dim_size = 8
+  s.opt_config.adagrad.learning_rate = 0.05
+  mt = MultiHashTable.from_serialized_config(m.SerializeToString(), name_suffix=_name())
+  rng = np.random.default_rng(4)
+  ids = np.arange(1, 257, dtype=np.int64)
+  for _ in range(2):
+    mt.apply_gradients({"t": (ids_t(ids), val_t(rng.standard_normal((ids.size, 16)).astype(np.float32)))})
+  w = mt.lookup({"t": ids_t(ids)})["t"].cpu().numpy()
+  assert (w[:, :8].astype(np.float16).astype(np.float32) == w[:, :8]).all() and w[:, :8].any()
+  assert (w[:, 8:].astype(np.float16).astype(np.float32) != w[:, 8:]).mean() > 0.9
+  m = P.MultiEmbeddingHashTableConfig()
+  m.names.append("g")
+  s = m.configs.add().entry_config.segments.add()
+  s.dim_size = 4
+  s.opt_config.group_adagrad.learning_rate = 0.05
+  s.opt_config.stochastic_rounding_float16 = True
+  with pytest.raises(_lib.InvalidArgumentError):
+    MultiHashTable.from_serialized_config(m.SerializeToString(), name_suffix=_name())
+
+
 def test_serialized_config_errors():
   m = _multi_config()
   m.names.append("extra")                                # names / configs of different length

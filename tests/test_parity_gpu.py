@@ -914,6 +914,92 @@ def test_remaining_optimizers_on_the_fused_step(name, how):
   assert mt.size("t") == ot.size()
 
 
+def _half_neighbours(x):
+  """(down, up): the two binary16 values around each fp32 x, as fp32 (|x| well inside the range)"""
+  h = x.astype(np.float16)
+  hf = h.astype(np.float32)
+  up = np.where(hf >= x, hf, np.nextafter(h, np.float16(np.inf)).astype(np.float32))
+  dn = np.where(hf <= x, hf, np.nextafter(h, np.float16(-np.inf)).astype(np.float32))
+  return dn, up
+
+
+@pytest.mark.parametrize("name", ["sgd", "adagrad", "adam"])
+@pytest.mark.parametrize("how", ["op", "pipelined", "plain"])
+def test_stochastic_rounding_float16(name, how):
+  """OptimizerConfig.stochastic_rounding_float16 (the StochasticRoundingFloat16OptimizerDecorator,
+  optimizer/stochastic_rounding.h): after every update the weights of the flagged segment are one of
+  the two binary16 neighbours of what the optimizer computed, its state and the other segment are
+  what the oracle computes bit for bit, and the rounding is unbiased (the upper neighbour is taken
+  with probability (w - down) / (up - down): a z-score over > 30 000 inexact elements).  The rounding function
+  itself is pinned to the reference's on the CPU (tests/test_stochastic_rounding.py); its draws are
+  the engine's own (the reference's come from a thread-local generator in call order)."""
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from test_oracle import OPT_KATS
+  if name == "sgd":
+    oopt, p, lr, mk = O.OPT_SGD, (), 0.05, (lambda: entry.SgdOptimizer(0.05))
+  elif name == "adagrad":
+    oopt, p, lr, mk = O.OPT_ADAGRAD, (0.1, 0.01), 0.05, (lambda: entry.AdagradOptimizer(0.05, 0.1, weight_decay_factor=0.01))
+  else:
+    _, oopt, p, lr, _, _, _, _ = [k for k in OPT_KATS if k[0] == name][0]
+    mk = _OPT_ENTRY[name]
+  d1 = d2 = 16
+  segs = [entry.CombineAsSegment(d1, entry.ConstantsInitializer(0.25),
+                                 entry.StochasticRoundingFloat16OptimizerWrapper(mk())),
+          entry.CombineAsSegment(d2, entry.ZerosInitializer(), entry.AdagradOptimizer(0.05, 0.1))]
+  osegs = [O.segment(d1, oopt, p=p, init=O.INIT_CONSTANT, init_value=0.25), O.segment(d2, O.OPT_ADAGRAD, p=(0.1, 0.0))]
+  dim, B, steps = d1 + d2, 4096, 4
+  rng = np.random.default_rng(5 + len(name) + len(how))
+  mt = make({"t": entry.make_table_config(segs)})
+  assert mt._lib.mhte_table_fused_backward_ok(mt.handle, 0) == 2    # (the FULL kernel family)
+  ot = O.Table(osegs, 1)
+  lrs = [lr, 0.05]
+  step = SparseStep(mt, "t", B, exact_order=True) if how != "op" else None
+  batches = [(rng.zipf(1.3, B) % 1500).astype(np.int64) | (1 << 48) for _ in range(steps + 1)]
+  dev_ids = [ids_t(b) for b in batches]
+  num = den = 0.0
+  n_inexact = 0
+  for s in range(steps):
+    ids = batches[s]
+    g = (rng.standard_normal((B, dim)) * 0.1).astype(np.float32)
+    uk = np.unique(ids)
+    # the oracle continues from the device's (rounded) weights: Assign overwrites weights only
+    have = uk[np.array([ot.contains(int(k)) for k in uk], bool)] if ot.size() else uk[:0]
+    if have.size:
+      ot.assign(have, mt.lookup({"t": ids_t(have)})["t"].cpu().numpy(), 50)
+    uo, _, vo, vos, _ = O.unique_key_with_value_and_offset(ids, [0, ids.size], [dim])
+    gu = O.fill_with_offset_map_gradient(np.arange(uo.size), [0, uo.size], g.ravel(), vo, vos, [dim]).reshape(-1, dim)
+    ot.optimize(uo, gu, lrs, 100 + s)
+    if how == "op":
+      mt.table_optimize_n("t", ids_t(uo), None, val_t(gu), np.array(lrs, np.float32), 100 + s, 0)
+    else:
+      step.forward(dev_ids[s], next_ids=dev_ids[s + 1] if how == "pipelined" else None)
+      step.backward(val_t(g), 100 + s)
+    got = mt.lookup({"t": ids_t(uk)})["t"].cpu().numpy()
+    exp = ot.lookup(uk)[0]
+    np.testing.assert_array_equal(got[:, d1:], exp[:, d1:])            # the unflagged segment
+    dn, up = _half_neighbours(exp[:, :d1])
+    w = got[:, :d1]
+    assert ((w == dn) | (w == up)).all(), "step %d" % s
+    assert (w.astype(np.float16).astype(np.float32) == w).all()
+    inexact = up > dn
+    frac = (exp[:, :d1] - dn)[inexact] / (up - dn)[inexact]
+    num += float(((w == up)[inexact].astype(np.float64) - frac).sum())
+    den += float((frac * (1 - frac)).sum())
+    n_inexact += int(inexact.sum())
+  # optimizer state of the flagged segment: untouched by the rounding.  (Adam's row keeps its two
+  # powers in a float4 here and in two floats in the oracle: its state is checked through the steps
+  # above — a state that had drifted would take the next step's weights off the neighbour pair.)
+  di, _, _, drows = mt.dump("t")
+  oi, _, _, orows = ot.dump()
+  do, oo = np.argsort(di.cpu().numpy()), np.argsort(oi)
+  np.testing.assert_array_equal(di.cpu().numpy()[do], oi[oo])
+  if drows.shape[1] == orows.shape[1]:
+    np.testing.assert_array_equal(drows.cpu().numpy()[do][:, dim:], orows[oo][:, dim:])
+  else:
+    assert name == "adam"
+  assert n_inexact > 30000 and abs(num) / np.sqrt(den) < 5.0, (num, den, n_inexact)
+
+
 def test_batch_softmax_optimizer(tmp_path):
   """BatchSoftmaxOptimizer (batch_softmax_optimizer.cc:52-63): the reference's KAT, then several
   steps with duplicates and a growing global_step bit-exact against the oracle (a one-float

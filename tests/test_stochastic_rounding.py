@@ -1,0 +1,118 @@
+"""CPU suite: fp16 stochastic rounding (OptimizerConfig.stochastic_rounding_float16).
+
+  * the reference's stochastic_round(vf, p) compiled in place (oracle/_ref/libmonolith_ref_sr.so:
+    optimizer/stochastic_rounding.h + third_party half.hpp) pins the C restatement
+    (oracle/mhte_oracle.c mo_stochastic_round) and the engine's own function (csrc/mhte_core.h,
+    compiled for the host) value for value: normals at every scale, binary16 subnormals, values
+    beyond 65504, signed zeros, infinities, raw random bit patterns;
+  * the reference's decorator around a plain optimizer: every weight leaves as one of the two
+    binary16 neighbours of the inner optimizer's result, and — its generator being a thread-local
+    multiply-with-carry seeded {0, 1} — exactly the one the header's rand() sequence picks;
+  * the Python mirror of entry.py's wrapper sets the flag the C ABI reads.
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "libmonolith_ref_sr.so")
+needs_ref = pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not built (no reference tree)")
+
+
+def _cases():
+  rng = np.random.default_rng(7)
+  special = np.array([0.0, -0.0, 1.0, -1.0, 65504.0, -65504.0, 65505.0, 65519.99, 65520.0, 7e4, -7e4, 1e10, -1e10,
+                      2.0**-14, 2.0**-15, 2.0**-24, 2.0**-25, 5.96e-8, 6e-8, 1e-8, -1e-8, 2.0**-149, 0.1, 3e-5,
+                      np.inf, -np.inf], np.float32)
+  x = np.concatenate([special,
+                      (rng.standard_normal(60000) * np.exp(rng.uniform(-20, 12, 60000))).astype(np.float32),
+                      rng.integers(0, 2**32, 60000, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+  x = x[~np.isnan(x)]
+  p = rng.random(x.size).astype(np.float32)
+  p[:special.size] = np.resize(np.array([0.0, 0.5, 0.999999], np.float32), special.size)
+  return x, p
+
+
+def _lib(path, name):
+  lib = C.CDLL(path)
+  f = getattr(lib, name)
+  f.restype, f.argtypes = C.c_float, [C.c_float, C.c_float]
+  return lib, f
+
+
+@needs_ref
+def test_restatement_equals_the_reference_function():
+  x, p = _cases()
+  _, ref = _lib(REF, "ref_stochastic_round")
+  _, mine = _lib(os.path.join(ROOT, "oracle", "liboracle.so"), "mo_stochastic_round")
+  a = np.array([ref(float(v), float(q)) for v, q in zip(x, p)], np.float32)
+  b = np.array([mine(float(v), float(q)) for v, q in zip(x, p)], np.float32)
+  np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+  # both neighbours occur, and the result is always one of them
+  lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+  for fn in (lib.mo_half_up, lib.mo_half_down):
+    fn.restype, fn.argtypes = C.c_float, [C.c_float]
+  fin = np.isfinite(x) & (np.abs(x) < 65504)
+  up = np.array([lib.mo_half_up(float(v)) for v in x[fin]], np.float32)
+  dn = np.array([lib.mo_half_down(float(v)) for v in x[fin]], np.float32)
+  assert (dn <= x[fin]).all() and (x[fin] <= up).all()
+  assert ((b[fin] == up) | (b[fin] == dn)).all() and (b[fin] == up).any() and (b[fin] == dn).any()
+  assert (up.astype(np.float16).astype(np.float32) == up).all()      # representable in binary16
+
+
+def test_engine_function_equals_the_restatement(tmp_path):
+  """csrc/mhte_core.h (the source the kernels compile) on the host against oracle/"""
+  exe = str(tmp_path / "sr_host")
+  subprocess.check_call(["g++", "-O2", "-std=c++17", "-DMHTE_HOST_ONLY", "-ffp-contract=off",
+                         "-I" + os.path.join(ROOT, "monolith_amd", "csrc"),
+                         os.path.join(ROOT, "tests", "sr_host_driver.cc"), "-o", exe])
+  x, p = _cases()
+  path = str(tmp_path / "cases.bin")
+  with open(path, "wb") as f:
+    f.write(struct.pack("<i", x.size))
+    f.write(np.stack([x, p], 1).astype(np.float32).tobytes())
+  out = subprocess.run([exe, path], capture_output=True, text=True, check=True).stdout
+  got = np.array([int(t, 16) for t in out.split()], np.uint32)
+  _, mine = _lib(os.path.join(ROOT, "oracle", "liboracle.so"), "mo_stochastic_round")
+  want = np.array([mine(float(v), float(q)) for v, q in zip(x, p)], np.float32).view(np.uint32)
+  np.testing.assert_array_equal(got, want)
+
+
+@needs_ref
+def test_reference_decorator_rounds_the_weights_with_its_generator():
+  lib = C.CDLL(REF)
+  lib.ref_sr_decorated_sgd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float]
+  rng = np.random.default_rng(3)
+  n = 4096
+  w = rng.standard_normal(n).astype(np.float32)
+  g = rng.standard_normal(n).astype(np.float32)
+  lr = np.float32(0.01)
+  inner = (w - lr * g).astype(np.float32)
+  out = w.copy()
+  lib.ref_sr_decorated_sgd(out.ctypes.data, g.ctypes.data, n, float(lr))
+  # the header's generator (stochastic_rounding.h:90-108, .cc:21: thread-local state {0, 1}) on a
+  # fresh thread state -- this process has not called the decorator before
+  r0, r1, ps = 0, 1, []
+  for _ in range(n):
+    r0 = (36969 * (r0 & 65535) + (r0 >> 16)) & 0xffffffff
+    r1 = (18000 * (r1 & 65535) + (r1 >> 16)) & 0xffffffff
+    ps.append(np.float32((((r0 & 65535) << 16) + r1) & 0xffffffff) / np.float32(4294967296))
+  _, mine = _lib(os.path.join(ROOT, "oracle", "liboracle.so"), "mo_stochastic_round")
+  want = np.array([mine(float(v), float(q)) for v, q in zip(inner, ps)], np.float32)
+  np.testing.assert_array_equal(out.view(np.uint32), want.view(np.uint32))
+  assert (out.astype(np.float16).astype(np.float32) == out).all()
+
+
+def test_python_wrapper_sets_the_flag():
+  from monolith_amd import _lib as L, entry
+  opt = entry.StochasticRoundingFloat16OptimizerWrapper(entry.AdagradOptimizer(0.05, 0.1))
+  assert opt.opt_type == (L.OPT_ADAGRAD | L.OPT_FLAG_STOCHASTIC_ROUNDING_FP16)
+  assert tuple(opt.params()) == (0.1, 0.0) and opt.learning_rate == 0.05
+  with pytest.raises(ValueError):
+    entry.StochasticRoundingFloat16OptimizerWrapper(opt)
