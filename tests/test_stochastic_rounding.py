@@ -110,7 +110,11 @@ def test_reference_decorator_rounds_the_weights_with_its_generator():
 
 
 def test_python_wrapper_sets_the_flag():
+  import re
   from monolith_amd import _lib as L, entry
+  hdr = open(os.path.join(ROOT, "include", "monolith_amd_hash_table.h")).read()
+  assert int(re.search(r"MHTE_OPT_FLAG_STOCHASTIC_ROUNDING_FP16 = (0x[0-9a-fA-F]+)", hdr).group(1), 16) == \
+      L.OPT_FLAG_STOCHASTIC_ROUNDING_FP16
   opt = entry.StochasticRoundingFloat16OptimizerWrapper(entry.AdagradOptimizer(0.05, 0.1))
   assert opt.opt_type == (L.OPT_ADAGRAD | L.OPT_FLAG_STOCHASTIC_ROUNDING_FP16)
   assert tuple(opt.params()) == (0.1, 0.0) and opt.learning_rate == 0.05
