@@ -47,9 +47,12 @@ def unique_sum(O, ids, g, d):
   return uk, gu, inv
 
 
-def rank_step(O, tables, dims, lrs, geo, world, batches, update_time, exchange):
+def rank_step(O, tables, dims, lrs, geo, world, batches, update_time, exchange, grad_bits=32):
   """One training step of one rank.  tables: this rank's oracle tables (the ids it owns); batches:
-  [(ids, grads)] per table -> per-table per-occurrence embeddings of this rank's batch."""
+  [(ids, grads)] per table -> per-table per-occurrence embeddings of this rank's batch.
+  grad_bits = 16: the optional fp16 gradient wire (mhte_shard_step_set_grad_bits; the reference's
+  distributed_ps_sync.py:424-436): the SENDER rounds its per-id sums to binary16 — after summing in
+  fp32 — the block crosses as 2-byte values, the owner widens them and applies."""
   T, cap = len(dims), geo["cap"]
   ids_send = np.zeros((world, geo["ids_block"]), np.int64)
   slot_of, uniq = [], []
@@ -86,7 +89,10 @@ def rank_step(O, tables, dims, lrs, geo, world, batches, update_time, exchange):
     uk, gu, inv = uniq[t]
     for u in range(uk.size):
       grad_send[slot_of[t][u]:slot_of[t][u] + dims[t]] = gu[u]
-  grad_recv = exchange(grad_send.reshape(world, -1))                 # exchange 3: gradients
+  if grad_bits == 16:
+    grad_recv = exchange(grad_send.astype(np.float16).reshape(world, -1)).astype(np.float32)
+  else:
+    grad_recv = exchange(grad_send.reshape(world, -1))               # exchange 3: gradients
   for p in range(world):                                             # owner: peers in rank order
     for t in range(T):
       n = int(ids_recv[p, t])

@@ -41,7 +41,7 @@ def _unique_sum(O, ids, g, d):
   return SP.unique_sum(O, ids, g, d)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, grad_bits=32):
   os.environ["MASTER_ADDR"] = "127.0.0.1"
   os.environ["MASTER_PORT"] = str(port)
   dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -63,20 +63,27 @@ def _worker(rank, world, port, out_dir):
   embs = []
   for step in range(STEPS):
     batches = [_batch(rank, step, t) for t in range(T)]
-    embs += SP.rank_step(O, mine, DIMS, LRS, geo, world, batches, 1_700_000_000 + step, exchange)
+    embs += SP.rank_step(O, mine, DIMS, LRS, geo, world, batches, 1_700_000_000 + step, exchange,
+                         grad_bits=grad_bits)
   np.savez(os.path.join(out_dir, "rank%d.npz" % rank), *embs,
            **{"dump%d" % t: np.concatenate([np.sort(mine[t].dump()[0])]) for t in range(T)},
            **{"rows%d" % t: mine[t].lookup(np.sort(mine[t].dump()[0]))[0] for t in range(T)})
   dist.destroy_process_group()
 
 
-def test_two_ranks_over_gloo_match_the_single_process_reference(tmp_path):
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("grad_bits", [32, 16])
+def test_two_ranks_over_gloo_match_the_single_process_reference(tmp_path, grad_bits):
+  """grad_bits = 16: the fp16 gradient wire — the block really crosses gloo as 2-byte values, and the
+  single-process reference rounds each sender's per-id sums the same way before applying them."""
   import oracle as O
   world = 2
   with socket.socket() as s:
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
-  mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+  mp.spawn(_worker, args=(world, port, str(tmp_path), grad_bits), nprocs=world, join=True)
   # the reference semantics in one process: one table per feature (owners hold disjoint ids)
   ref = _tables()
   T = len(DIMS)
@@ -90,6 +97,8 @@ def test_two_ranks_over_gloo_match_the_single_process_reference(tmp_path):
       for t in range(T):
         ids, g = _batch(r, step, t)
         uk, gu, _ = _unique_sum(O, ids, g, DIMS[t])
+        if grad_bits == 16:
+          gu = gu.astype(np.float16).astype(np.float32)
         if uk.size:
           ref[t].optimize(uk, gu, [LRS[t]], 1_700_000_000 + step)
   got = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
