@@ -48,8 +48,9 @@ int32_t mhte_abi_version(void);
 /* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
 enum {                                                                     /* optimizer.proto:210-229 */
   MHTE_OPT_SGD = 0, MHTE_OPT_ADAGRAD = 1, MHTE_OPT_FTRL = 2,
-  /* the following run in the op-level kernels (mhte_optimize & co, mhte_table_optimize_n); a table
-     that uses one of them is not mhte_table_fused_backward_ok */
+  /* every per-element optimizer below rides the fused training-step kernels too (the single-table,
+     multi-table and sharded steps: their FULL instantiations); only GROUP_ADAGRAD — one step needs
+     the whole segment — stays on the op-level kernels (mhte_optimize & co) */
   MHTE_OPT_MOMENTUM = 3, MHTE_OPT_ADADELTA = 4, MHTE_OPT_RMSPROP = 5, MHTE_OPT_RMSPROPV2 = 6,
   MHTE_OPT_ADAM = 7, MHTE_OPT_AMSGRAD = 8, MHTE_OPT_MOVING_AVERAGE = 9,
   MHTE_OPT_BATCH_SOFTMAX = 10, /* dim_size 1; uses the ops' global_step argument */
@@ -73,7 +74,13 @@ enum { MHTE_INIT_ZEROS = 0, MHTE_INIT_ONES = 1, MHTE_INIT_CONSTANT = 2, /* initi
 typedef struct {
   int32_t dim_size;
   int32_t opt_type;     /* MHTE_OPT_* */
-  float opt_params[8];  /* ADAGRAD:  {initial_accumulator_value, weight_decay_factor}
+  float opt_params[8];  /* ADAGRAD:  {initial_accumulator_value, weight_decay_factor, avx_form}
+                                     avx_form != 0 (extension): the update of the reference as its
+                                     .bazelrc:63-68 builds it, avx_utils.h:96-119 — fused
+                                     multiply-adds and, inside blocks of 8 elements, the weight
+                                     step taken with the raw gradient (:112); default 0: the
+                                     baseline loop (:29-38).  They differ when
+                                     weight_decay_factor != 0
                            FTRL:     {initial_accumulator_value, beta, l1, l2}
                            MOMENTUM: {momentum, weight_decay_factor, use_nesterov}
                            ADADELTA: {averaging_ratio, epsilon, weight_decay_factor}

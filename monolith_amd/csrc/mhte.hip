@@ -425,6 +425,15 @@ static Shape pick_shape(uint32_t dim, bool vec_ok) {
 }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// MHTE_DEV_FAST (development builds, scripts/dev_build.sh): only the dim-64 float4 shape is
+// instantiated, which cuts the compile from minutes to well under one; every other shape throws.
+#ifdef MHTE_DEV_FAST
+#define DISPATCH_G_VEC(shape, CALL)                                                            \
+  do {                                                                                         \
+    if ((shape).VEC == 4 && (shape).G == 16) { CALL(16, 4); }                                  \
+    else throw Error(MHTE_INTERNAL, "MHTE_DEV_FAST build: only G = 16, VEC = 4");         \
+  } while (0)
+#else
 #define DISPATCH_G_VEC(shape, CALL)                                  \
   do {                                                               \
     if ((shape).VEC == 4) {                                          \
@@ -443,6 +452,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
       }                                                              \
     }                                                                \
   } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------ clock
 // seconds on a monotonic clock (+ the test hook's offset): the eviction cadence
@@ -2099,6 +2109,16 @@ mhte_status mhte_hash_filter_restore(mhte_hash_filter* f, const char* basename, 
     } catch (const std::exception& e) {
       throw Error(MHTE_NOT_FOUND, std::string("filter restore: ") + e.what());
     }
+    // A slot word is the reference's uint16: signature << 4 | count (hash_filter.h:33-60).  Dumps
+    // written by this engine before ABI 12 carried 28-bit signatures in the same 32-bit words,
+    // untagged: restored as they are, no id would ever match its slot again (counts lost, admitted
+    // ids filtered anew) — refuse them by name instead.
+    for (uint32_t wv : words)
+      if (wv > 0xffffu)
+        throw Error(MHTE_INVALID_ARGUMENT,
+                    "filter restore: slot words wider than 16 bits — a dump written before ABI 12 "
+                    "(28-bit signatures); not convertible (the 12-bit signature is a different hash "
+                    "slice), re-create the filter");
     HIP_OK(hipMemcpyAsync(f->slots, words.data(), words.size() * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(f->state, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
     HIP_OK(hipStreamSynchronize(st));

@@ -63,7 +63,7 @@ struct SegDesc {
   int32_t w_off;    // float offset of this segment's weights inside the row
   int32_t st_off;   // float offset of this segment's optimizer ctx inside the row
   int32_t opt;      // OptType
-  float p[8];       // adagrad:  {initial_accumulator_value, weight_decay_factor}
+  float p[8];       // adagrad:  {initial_accumulator_value, weight_decay_factor, avx form (adagrad_step_avx)}
                     // ftrl:     {initial_accumulator_value, beta, l1, l2}
                     // momentum: {momentum, weight_decay_factor, use_nesterov}
                     // adadelta: {averaging_ratio, epsilon, weight_decay_factor}
@@ -253,6 +253,25 @@ MHTE_HD void adagrad_step(float& w, float& n, float grad, float lr, float wd) { 
   float eff = lr / sqrtf(n);
   float d = eff * g;
   w = w - d;
+}
+
+// The reference's AVX2 form of AdagradOptimize (avx_utils.h:96-119: what its .bazelrc:63-68 build
+// runs), opt-in per segment (p[2] != 0; entry.AdagradOptimizer(avx_semantics=True)): fused
+// multiply-adds, and inside the segment's blocks of 8 elements the weight step is taken with the RAW
+// gradient (:112) — a different update from the baseline loop whenever weight_decay_factor != 0.  The
+// len % 8 tail runs the baseline formula as that build contracts it.  Explicit fma: exempt from the
+// contraction pragma above, bit-identical to the reference's AVX build (tests/test_oracle.py).
+MHTE_HD void adagrad_step_avx(float& w, float& n, float grad, float lr, float wd, bool in_block) {
+  const float ug = __builtin_fmaf(wd, w, grad);
+  n = __builtin_fmaf(ug, ug, n);
+  const float eff = lr / sqrtf(n);
+  w = __builtin_fmaf(-eff, in_block ? grad : ug, w);
+}
+// elem: element index inside the segment of seg_dim elements
+MHTE_HD void adagrad_any(float& w, float& n, float grad, float lr, float wd, float avx_flag,
+                         uint32_t elem, uint32_t seg_dim) {
+  if (avx_flag != 0.f) adagrad_step_avx(w, n, grad, lr, wd, elem < (seg_dim & ~7u));
+  else adagrad_step(w, n, grad, lr, wd);
 }
 
 // ftrl_optimizer.cc:56-75, including its `std::signbit(z) * l1` term (1*l1 for negative z, else 0)

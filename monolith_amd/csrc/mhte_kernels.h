@@ -12,6 +12,14 @@
 
 #include "mhte_core.h"
 
+// Development builds (-DMHTE_DEV_FAST, scripts/dev_build.sh) instantiate the device-side lane-group
+// switches for G = 16 only (dim 64): the other cases do nothing.
+#ifdef MHTE_DEV_FAST
+#define MHTE_OTHER_G(...) ((void)0)
+#else
+#define MHTE_OTHER_G(...) __VA_ARGS__
+#endif
+
 namespace mhte {
 
 struct Counters {
@@ -395,14 +403,14 @@ __global__ __launch_bounds__(256) void filter_get_kernel(TableView tv, const int
                                                          int64_t n, uint32_t* __restrict__ out) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (tv.flt_nsplit == 0u) {                          // ProbabilisticFilter::get: max_count (:31-33)
+    out[i] = kFilterMaxCount;                         // (first: such a filter has flt_total == 0, and
+    return;                                           // filter_home takes the hash modulo it)
+  }
   const int64_t id = ids[i];
   const uint32_t sign = filter_sign(id);
   const uint64_t home = filter_home(id, tv.flt_total);
   const FilterState* fs = reinterpret_cast<const FilterState*>(tv.flt_state);
-  if (tv.flt_nsplit == 0u) {                          // ProbabilisticFilter::get: max_count (:31-33)
-    out[i] = kFilterMaxCount;
-    return;
-  }
   const uint32_t S = tv.flt_nsplit, head = fs->head;
   long long pos = -1;
   uint32_t v = 0;
@@ -875,12 +883,12 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
           } else {
             if (BASIC) {
               if (sd.opt == kOptSgd) w.v[c] = sgd_step(w.v[c], v.v[c], lr);
-              else if (sd.opt == kOptAdagrad) adagrad_step(w.v[c], s1.v[c], v.v[c], lr, sd.p[1]);
+              else if (sd.opt == kOptAdagrad) adagrad_any(w.v[c], s1.v[c], v.v[c], lr, sd.p[1], sd.p[2], le + c, sd.dim);
               else ftrl_step(w.v[c], s1.v[c], s2.v[c], v.v[c], lr, sd.p[1], sd.p[2], sd.p[3]);
             } else
             switch (sd.opt) {
               case kOptSgd: w.v[c] = sgd_step(w.v[c], v.v[c], lr); break;
-              case kOptAdagrad: adagrad_step(w.v[c], s1.v[c], v.v[c], lr, sd.p[1]); break;
+              case kOptAdagrad: adagrad_any(w.v[c], s1.v[c], v.v[c], lr, sd.p[1], sd.p[2], le + c, sd.dim); break;
               case kOptFtrl:
                 ftrl_step(w.v[c], s1.v[c], s2.v[c], v.v[c], lr, sd.p[1], sd.p[2], sd.p[3]);
                 break;
@@ -2714,9 +2722,9 @@ __device__ __forceinline__ void optimize_row_reg(const TableView& tv, float* rp,
 #pragma unroll
     for (int c = 0; c < VEC; ++c) w.v[c] = sgd_step(w.v[c], g.v[c], slr);
   } else if (sd.opt == kOptAdagrad) {
-    const float alr = opaque_f(lr), wd = opaque_f(sd.p[1]);
+    const float alr = opaque_f(lr), wd = opaque_f(sd.p[1]), avx = opaque_f(sd.p[2]);
 #pragma unroll
-    for (int c = 0; c < VEC; ++c) adagrad_step(w.v[c], s1.v[c], g.v[c], alr, wd);
+    for (int c = 0; c < VEC; ++c) adagrad_any(w.v[c], s1.v[c], g.v[c], alr, wd, avx, le + c, sd.dim);
   } else {
     const float flr = opaque_f(lr), beta = opaque_f(sd.p[1]), l1 = opaque_f(sd.p[2]), l2 = opaque_f(sd.p[3]);
 #pragma unroll
@@ -2791,7 +2799,7 @@ __device__ __forceinline__ void optimize_row_reg_full(const TableView& tv, float
   for (int c = 0; c < VEC; ++c) {
     switch (sd.opt) {
       case kOptSgd: w.v[c] = sgd_step(w.v[c], g.v[c], lrv); break;
-      case kOptAdagrad: adagrad_step(w.v[c], s1.v[c], g.v[c], lrv, hp[1]); break;
+      case kOptAdagrad: adagrad_any(w.v[c], s1.v[c], g.v[c], lrv, hp[1], hp[2], le + c, sd.dim); break;
       case kOptFtrl: ftrl_step(w.v[c], s1.v[c], s2.v[c], g.v[c], lrv, hp[1], hp[2], hp[3]); break;
       case kOptMomentum: momentum_step(w.v[c], s1.v[c], g.v[c], lrv, hp[0], hp[1], hp[2] != 0.f); break;
       case kOptAdadelta: adadelta_step(w.v[c], s1.v[c], s2.v[c], g.v[c], lrv, hp[0], hp[1], hp[2]); break;

@@ -385,10 +385,10 @@ __global__ __launch_bounds__(BLOCK) void mstep_fwd_kernel(MFwdArgs A) {
   float* out = A.out + size_t(ft.emb_off);
   const int ch = int(s.count_hits);
   switch (s.g) {
-    case 8: mstep_scatter_role<8, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
+    case 8: MHTE_OTHER_G(mstep_scatter_role<8, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt)); break;
     case 16: mstep_scatter_role<16, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
-    case 32: mstep_scatter_role<32, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
-    default: mstep_scatter_role<64, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
+    case 32: MHTE_OTHER_G(mstep_scatter_role<32, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt)); break;
+    default: MHTE_OTHER_G(mstep_scatter_role<64, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt)); break;
   }
   wt.end(5u);
 }
@@ -448,10 +448,10 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
   const int ch = int(s.count_hits);
   constexpr int U = MHTE_FUSED_SCATTER_UNR;
   switch (s.g) {
-    case 8: mstep_scatter_role<8, kRdBlock, U>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
+    case 8: MHTE_OTHER_G(mstep_scatter_role<8, kRdBlock, U>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt)); break;
     case 16: mstep_scatter_role<16, kRdBlock, U>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
-    case 32: mstep_scatter_role<32, kRdBlock, U>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
-    default: mstep_scatter_role<64, kRdBlock, U>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
+    case 32: MHTE_OTHER_G(mstep_scatter_role<32, kRdBlock, U>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt)); break;
+    default: MHTE_OTHER_G(mstep_scatter_role<64, kRdBlock, U>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt)); break;
   }
   wt.end(5u);
 }
@@ -464,10 +464,10 @@ __device__ __forceinline__ void mstep_apply_switch(uint32_t g, const TableView& 
                                                    const ApplyCtl& c, const ApplyArgs& a,
                                                    uint32_t bid, WaveTrace& wt, ApplyLds& L) {
   switch (g) {
-    case 8: rd_apply_role<8, 4, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L); break;
+    case 8: MHTE_OTHER_G(rd_apply_role<8, 4, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L)); break;
     case 16: rd_apply_role<16, 4, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L); break;
-    case 32: rd_apply_role<32, 4, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L); break;
-    default: rd_apply_role<64, 4, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L); break;
+    case 32: MHTE_OTHER_G(rd_apply_role<32, 4, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L)); break;
+    default: MHTE_OTHER_G(rd_apply_role<64, 4, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L)); break;
   }
 }
 
@@ -571,10 +571,10 @@ __global__ __launch_bounds__(512) void seg_lookup_kernel(SegLookupArgs A) {
   float* out = A.out + size_t(A.emb_off[y]);
   const int ch = A.count_hits[t];
   switch (A.g[t]) {
-    case 8: seg_lookup_loop<8>(tv, ids, n, out, ch); break;
+    case 8: MHTE_OTHER_G(seg_lookup_loop<8>(tv, ids, n, out, ch)); break;
     case 16: seg_lookup_loop<16>(tv, ids, n, out, ch); break;
-    case 32: seg_lookup_loop<32>(tv, ids, n, out, ch); break;
-    default: seg_lookup_loop<64>(tv, ids, n, out, ch); break;
+    case 32: MHTE_OTHER_G(seg_lookup_loop<32>(tv, ids, n, out, ch)); break;
+    default: MHTE_OTHER_G(seg_lookup_loop<64>(tv, ids, n, out, ch)); break;
   }
 }
 
@@ -645,10 +645,10 @@ __global__ __launch_bounds__(256) void seg_upsert_kernel(SegUpsertArgs A) {
   const float* values = A.grads + size_t(A.grad_off[y]);
   uint32_t* pend = A.pending[t];
   switch (A.g[t]) {
-    case 8: seg_upsert_loop<8>(tv, ids, n, values, A.a[t], pend, A.id_off[y], y); break;
+    case 8: MHTE_OTHER_G(seg_upsert_loop<8>(tv, ids, n, values, A.a[t], pend, A.id_off[y], y)); break;
     case 16: seg_upsert_loop<16>(tv, ids, n, values, A.a[t], pend, A.id_off[y], y); break;
-    case 32: seg_upsert_loop<32>(tv, ids, n, values, A.a[t], pend, A.id_off[y], y); break;
-    default: seg_upsert_loop<64>(tv, ids, n, values, A.a[t], pend, A.id_off[y], y); break;
+    case 32: MHTE_OTHER_G(seg_upsert_loop<32>(tv, ids, n, values, A.a[t], pend, A.id_off[y], y)); break;
+    default: MHTE_OTHER_G(seg_upsert_loop<64>(tv, ids, n, values, A.a[t], pend, A.id_off[y], y)); break;
   }
 }
 

@@ -273,7 +273,9 @@ struct ShardStep {
         HIP_OK(hipEventCreateWithFlags(&ev_cnt[s], hipEventDisableTiming));
       }
     if (const char* e = getenv("MHTE_SHARD_OVERLAP")) set_overlap(atoi(e));
-    if (const char* e = getenv("MHTE_SHARD_GRAD_FP16")) set_grad_bits(atoi(e) != 0 ? 16 : 32);
+    // (a job-wide setting: the world-1 identity step has no wire to narrow and ignores it)
+    if (const char* e = getenv("MHTE_SHARD_GRAD_FP16"))
+      if (!alias) set_grad_bits(atoi(e) != 0 ? 16 : 32);
     if (unique_id) {
       Rccl& R = Rccl::get();
       ncclUniqueId id;
@@ -396,7 +398,8 @@ struct ShardStep {
     uint64_t win_bytes;
     uint32_t magic, rank, world, T, cap, ids_block, rows_block;
     int32_t pid;
-    char pad[128 - 64 - 8 - 7 * 4 - 4];
+    uint32_t grad_bits, overlap;  // the wire format and the pipeline mode: every rank the same
+    char pad[128 - 64 - 8 - 7 * 4 - 4 - 8];
   };
   static_assert(sizeof(IpcBlob) == 128, "ipc handle blob");
   static constexpr uint32_t kIpcMagic = 0x6d687431u;
@@ -414,6 +417,8 @@ struct ShardStep {
     b.ids_block = geo.ids_block;
     b.rows_block = geo.rows_block;
     b.pid = int32_t(getpid());
+    b.grad_bits = uint32_t(grad_bits);   // (set_grad_bits / set_overlap come BEFORE the handle is taken)
+    b.overlap = uint32_t(overlap);
     memcpy(out128, &b, sizeof(b));
   }
 
@@ -432,6 +437,14 @@ struct ShardStep {
           b.win_bytes != win_bytes)
         throw Error(MHTE_INVALID_ARGUMENT, "shard step connect: rank " + std::to_string(p) +
                                                " was created with other tables or capacities");
+      // (fp16 against fp32 gradient blocks would corrupt silently; overlap on one side only ends in a
+      // peer timeout)
+      if (b.grad_bits != uint32_t(grad_bits) || b.overlap != uint32_t(overlap))
+        throw Error(MHTE_INVALID_ARGUMENT,
+                    "shard step connect: rank " + std::to_string(p) + " runs gradient wire " +
+                        std::to_string(b.grad_bits) + " bits / overlap " + std::to_string(b.overlap) +
+                        ", this rank " + std::to_string(grad_bits) + " / " + std::to_string(overlap) +
+                        " (mhte_shard_step_set_grad_bits / _set_overlap on every rank, before the handles are taken)");
       if (p == rank) continue;
       void* m = nullptr;
       hipError_t e = hipIpcOpenMemHandle(&m, b.h, hipIpcMemLazyEnablePeerAccess);

@@ -82,10 +82,10 @@ __global__ __launch_bounds__(512) void shard_lookup_kernel(ShardOwnerArgs A) {
   float* out = A.rows + size_t(p) * A.geo.rows_block + tb.row_off;
   const int ch = A.count_hits[t];
   switch (A.g[t]) {
-    case 8: seg_lookup_loop<8>(tv, ids, n, out, ch); break;
+    case 8: MHTE_OTHER_G(seg_lookup_loop<8>(tv, ids, n, out, ch)); break;
     case 16: seg_lookup_loop<16>(tv, ids, n, out, ch); break;
-    case 32: seg_lookup_loop<32>(tv, ids, n, out, ch); break;
-    default: seg_lookup_loop<64>(tv, ids, n, out, ch); break;
+    case 32: MHTE_OTHER_G(seg_lookup_loop<32>(tv, ids, n, out, ch)); break;
+    default: MHTE_OTHER_G(seg_lookup_loop<64>(tv, ids, n, out, ch)); break;
   }
 }
 
@@ -143,10 +143,10 @@ __global__ __launch_bounds__(256) void shard_upsert_kernel(ShardOwnerArgs A) {
   const float* values = A.rows + size_t(p) * A.geo.rows_block + tb.row_off;
   uint32_t* pend = A.pending[t];
   switch (A.g[t]) {   // pending entry = (position in the block's table segment, unused)
-    case 8: seg_upsert_loop<8>(tv, ids, n, values, A.a[t], pend, 0u, 0u); break;
+    case 8: MHTE_OTHER_G(seg_upsert_loop<8>(tv, ids, n, values, A.a[t], pend, 0u, 0u)); break;
     case 16: seg_upsert_loop<16>(tv, ids, n, values, A.a[t], pend, 0u, 0u); break;
-    case 32: seg_upsert_loop<32>(tv, ids, n, values, A.a[t], pend, 0u, 0u); break;
-    default: seg_upsert_loop<64>(tv, ids, n, values, A.a[t], pend, 0u, 0u); break;
+    case 32: MHTE_OTHER_G(seg_upsert_loop<32>(tv, ids, n, values, A.a[t], pend, 0u, 0u)); break;
+    default: MHTE_OTHER_G(seg_upsert_loop<64>(tv, ids, n, values, A.a[t], pend, 0u, 0u)); break;
   }
 }
 
@@ -198,10 +198,10 @@ template <bool SCATTER>
 __device__ __forceinline__ void shard_gather_switch(uint32_t g, const RunView& d, const GatherCtl& c,
                                                     uint32_t bid, char* raw) {
   switch (g) {
-    case 8: rd_gather_role<8, 4, SCATTER>(d, c, bid, *reinterpret_cast<GatherLds<8, 4>*>(raw)); break;
+    case 8: MHTE_OTHER_G(rd_gather_role<8, 4, SCATTER>(d, c, bid, *reinterpret_cast<GatherLds<8, 4>*>(raw))); break;
     case 16: rd_gather_role<16, 4, SCATTER>(d, c, bid, *reinterpret_cast<GatherLds<16, 4>*>(raw)); break;
-    case 32: rd_gather_role<32, 4, SCATTER>(d, c, bid, *reinterpret_cast<GatherLds<32, 4>*>(raw)); break;
-    default: rd_gather_role<64, 4, SCATTER>(d, c, bid, *reinterpret_cast<GatherLds<64, 4>*>(raw)); break;
+    case 32: MHTE_OTHER_G(rd_gather_role<32, 4, SCATTER>(d, c, bid, *reinterpret_cast<GatherLds<32, 4>*>(raw))); break;
+    default: MHTE_OTHER_G(rd_gather_role<64, 4, SCATTER>(d, c, bid, *reinterpret_cast<GatherLds<64, 4>*>(raw))); break;
   }
 }
 static_assert(sizeof(GatherLds<8, 4>) >= sizeof(GatherLds<16, 4>) &&

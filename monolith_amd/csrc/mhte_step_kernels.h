@@ -600,9 +600,9 @@ __device__ __forceinline__ void optimize_row_pre(const TableView& tv, float* rp,
 #pragma unroll
     for (int c = 0; c < VEC; ++c) r.w.v[c] = sgd_step(r.w.v[c], g.v[c], slr);
   } else if (sd.opt == kOptAdagrad) {
-    const float alr = opaque_f(lr), wd = opaque_f(sd.p[1]);
+    const float alr = opaque_f(lr), wd = opaque_f(sd.p[1]), avx = opaque_f(sd.p[2]);
 #pragma unroll
-    for (int c = 0; c < VEC; ++c) adagrad_step(r.w.v[c], r.s1.v[c], g.v[c], alr, wd);
+    for (int c = 0; c < VEC; ++c) adagrad_any(r.w.v[c], r.s1.v[c], g.v[c], alr, wd, avx, le + c, sd.dim);
   } else {
     const float flr = opaque_f(lr), beta = opaque_f(sd.p[1]), l1 = opaque_f(sd.p[2]), l2 = opaque_f(sd.p[3]);
 #pragma unroll

@@ -52,7 +52,13 @@ class AdagradOptimizer(Optimizer):
   opt_type = _lib.OPT_ADAGRAD
 
   def __init__(self, learning_rate=None, initial_accumulator_value=None,
-               hessian_compression_times=1, warmup_steps=0, weight_decay_factor=0.0):
+               hessian_compression_times=1, warmup_steps=0, weight_decay_factor=0.0,
+               avx_semantics=False):
+    # avx_semantics (an extension; not a field of the reference's config): the update of the
+    # reference AS ITS .bazelrc:63-68 BUILDS IT — avx_utils.h:96-119, fused multiply-adds and, in
+    # every block of 8 elements, the weight step taken with the raw gradient (differs from the
+    # baseline loop whenever weight_decay_factor != 0) — bit for bit; default: the baseline loop
+    self.avx_semantics = bool(avx_semantics)
     # accepted and carried like the reference's config field (optimizer.proto:23); the
     # reference's open-source runtime never reads it (adagrad_optimizer.cc has no sketching
     # code path), so — as there — it does not change the update
@@ -64,7 +70,7 @@ class AdagradOptimizer(Optimizer):
     self.warmup_steps = warmup_steps
 
   def params(self):
-    return (self.initial_accumulator_value, self.weight_decay_factor)
+    return (self.initial_accumulator_value, self.weight_decay_factor, 1.0 if self.avx_semantics else 0.0)
 
 
 class FtrlOptimizer(Optimizer):

@@ -30,7 +30,8 @@ def build(force=False):
   subprocess.check_call(["make", "-s", "-C", _DIR] + (["-B"] if force else []) + ["liboracle.so"])
   if os.path.isdir("/root/reference") and (
       force or not all(os.path.exists(os.path.join(_DIR, "_ref", n)) for n in
-                       ("libmonolith_ref.so", "libmonolith_ref_avx.so", "libmonolith_ref_filter.so"))):
+                       ("libmonolith_ref.so", "libmonolith_ref_avx.so", "libmonolith_ref_filter.so",
+                        "libmonolith_ref_opt.so", "libmonolith_ref_opt_avx.so"))):
     subprocess.check_call(["make", "-s", "-C", _DIR, "ref"])
 
 
@@ -175,6 +176,15 @@ def adagrad(num, norm, grad, lr, wd):
   num, norm, grad = _f32(num).copy(), _f32(norm).copy(), _f32(grad)
   lib().mo_adagrad(_p(num, C.c_float), _p(norm, C.c_float), _p(grad, C.c_float),
                    C.c_int64(num.size), C.c_float(lr), C.c_float(wd))
+  return num, norm
+
+
+def adagrad_avx(num, norm, grad, lr, wd):
+  """avx_utils.h:96-119 restated (blocks of 8 with fused multiply-adds, raw gradient in the weight
+  step; the tail as the baseline)."""
+  num, norm, grad = _f32(num).copy(), _f32(norm).copy(), _f32(grad)
+  lib().mo_adagrad_avx(_p(num, C.c_float), _p(norm, C.c_float), _p(grad, C.c_float),
+                       C.c_int64(num.size), C.c_float(lr), C.c_float(wd))
   return num, norm
 
 
@@ -481,6 +491,81 @@ class SlidingFilter:
     self._L.mo_filter_split_words(self._h, C.c_int(split), out.ctypes.data_as(C.POINTER(C.c_uint32)),
                                   C.c_uint64(n))
     return out
+
+_ref_opt = {}
+
+
+def ref_opt_available(avx=False):
+  return os.path.exists(os.path.join(_DIR, "_ref", "libmonolith_ref_opt%s.so" % ("_avx" if avx else "")))
+
+
+def ref_opt_lib(avx=False):
+  if avx not in _ref_opt:
+    build()
+    L = C.CDLL(os.path.join(_DIR, "_ref", "libmonolith_ref_opt%s.so" % ("_avx" if avx else "")))
+    L.ref_opt_new.restype = C.c_void_p
+    L.ref_opt_new.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.ref_opt_free.argtypes = [C.c_void_p]
+    L.ref_opt_ctx_bytes.restype = C.c_int64
+    L.ref_opt_ctx_bytes.argtypes = [C.c_void_p]
+    L.ref_opt_slice_size.argtypes = [C.c_void_p]
+    L.ref_opt_init.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.ref_opt_optimize.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                   C.POINTER(C.c_float), C.c_float, C.c_int64]
+    L.ref_opt_save_restore.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ref_dc_sgd.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
+                             C.c_float, C.c_float]
+    _ref_opt[avx] = L
+  return _ref_opt[avx]
+
+
+class RefOptimizer:
+  """ONE optimizer object of the reference, made by its own factory (New*Optimizer, the
+  optimizer/*_optimizer.cc files compiled in place: oracle/ref_opt_driver.cc) — Init() and Optimize()
+  on a weight vector and an optimizer context held here.  `p` is the oracle's parameter layout for
+  the optimizer (mhte_oracle.h, mo_segment.p)."""
+
+  def __init__(self, opt, dim, p=(), avx=False):
+    self.L = ref_opt_lib(avx)
+    pp = (C.c_float * 8)(*([float(x) for x in p] + [0.0] * (8 - len(p))))
+    self.h = C.c_void_p(self.L.ref_opt_new(int(opt), int(dim), pp))
+    assert self.h, "reference factory refused the optimizer"
+    self.dim = dim
+    nb = int(self.L.ref_opt_ctx_bytes(self.h))
+    self.ctx = np.zeros(max(1, (nb + 3) // 4), np.float32)
+    self.ctx_floats = nb // 4
+    self.num = np.zeros(dim, np.float32)
+    self.L.ref_opt_init(self.h, _p(self.ctx, C.c_float))
+
+  def __del__(self):
+    try:
+      if self.h:
+        self.L.ref_opt_free(self.h)
+        self.h = None
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def optimize(self, grad, lr, global_step=0):
+    g = _f32(grad)
+    assert g.size == self.dim
+    rc = self.L.ref_opt_optimize(self.h, _p(self.ctx, C.c_float), _p(self.num, C.c_float), _p(g, C.c_float),
+                                 C.c_float(lr), C.c_int64(global_step))
+    assert rc == 0
+    return self.num.copy(), self.ctx[:self.ctx_floats].copy()
+
+  def save_restore(self):
+    out = np.zeros_like(self.ctx)
+    assert self.L.ref_opt_save_restore(self.h, _p(self.ctx, C.c_float), _p(out, C.c_float)) == 0
+    return out[:self.ctx_floats].copy()
+
+
+def ref_dc_sgd(num, grad, latest, lr, lambda_):
+  """DcOptimizer (dc_optimizer.cc:28-43) around the reference's SGD: one OptimizeWithLatestValue."""
+  L = ref_opt_lib()
+  num, grad, latest = _f32(num).copy(), _f32(grad), _f32(latest)
+  assert L.ref_dc_sgd(_p(num, C.c_float), _p(grad, C.c_float), _p(latest, C.c_float), C.c_int(num.size),
+                      C.c_float(lr), C.c_float(lambda_)) == 0
+  return num
 
 
 _ref_filter = None

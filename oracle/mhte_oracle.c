@@ -492,6 +492,30 @@ void mo_adagrad(float* num, float* norm, const float* grad, int64_t len, float l
     num[i] -= effective_lr * g;
   }
 }
+/* optimizer/avx_utils.h:96-119 (Avx256AdagradOptimize) — what AdagradOptimize IS in the reference as
+ * its .bazelrc:63-68 builds it: blocks of 8 elements with fused multiply-adds, the weight step taken
+ * with the RAW gradient (:112, not grad + wd * w); the len % 8 tail falls back to the baseline loop
+ * (:115-117) as that build compiles it.  Opt-in (segment p[2] != 0). */
+void mo_adagrad_avx(float* num, float* norm, const float* grad, int64_t len, float lr, float wd) {
+  int64_t i = 0;
+  for (; i + 8 <= len; i += 8) {
+    for (int k = 0; k < 8; ++k) {
+      float ug = fmaf(wd, num[i + k], grad[i + k]);
+      float nn = fmaf(ug, ug, norm[i + k]);
+      norm[i + k] = nn;
+      float eff = lr / sqrtf(nn);
+      num[i + k] = fmaf(-eff, grad[i + k], num[i + k]);
+    }
+  }
+  /* the tail: BaselineAdagradOptimize's formula (the weight step uses g = grad + wd * w), with the
+   * multiply-adds the -mfma build contracts (gcc and clang both fuse each of its three statements) */
+  for (; i < len; ++i) {
+    float g = fmaf(wd, num[i], grad[i]);
+    norm[i] = fmaf(g, g, norm[i]);
+    float eff = lr / sqrtf(norm[i]);
+    num[i] = fmaf(-eff, g, num[i]);
+  }
+}
 /* optimizer/ftrl_optimizer.cc:56-75 (including the std::signbit quirk) */
 static void mo_ftrl(float* num, float* norm, float* zero, const float* grad, int64_t len,
                     float lr, float beta, float l1, float l2) {
@@ -661,7 +685,8 @@ void mo_optimize(mo_table* t, const int64_t* ids, int64_t n, const float* grads,
       if (sg->opt == MO_OPT_SGD) {
         mo_sgd(row + w, g + w, sg->dim, lrs[k]);
       } else if (sg->opt == MO_OPT_ADAGRAD) {
-        mo_adagrad(row + w, st, g + w, sg->dim, lrs[k], sg->p[1]);
+        if (sg->p[2] != 0.f) mo_adagrad_avx(row + w, st, g + w, sg->dim, lrs[k], sg->p[1]);
+        else mo_adagrad(row + w, st, g + w, sg->dim, lrs[k], sg->p[1]);
       } else if (sg->opt == MO_OPT_FTRL) {
         mo_ftrl(row + w, st, st + sg->dim, g + w, sg->dim, lrs[k], sg->p[1], sg->p[2], sg->p[3]);
       } else if (sg->opt == MO_OPT_MOMENTUM) {

@@ -32,6 +32,7 @@ typedef struct {
   int32_t dim;
   int32_t opt;       /* MO_OPT_* */
   float p[8];        /* adagrad: p[0]=initial_accumulator_value p[1]=weight_decay_factor
+                                 p[2]!=0: the reference's AVX form (avx_utils.h:96-119)
                         ftrl:    p[0]=initial_accumulator_value p[1]=beta p[2]=l1 p[3]=l2 */
   int32_t init;      /* MO_INIT_* */
   float init_value;  /* constant initializer value */
@@ -75,6 +76,8 @@ int64_t mo_dump(const mo_table* t, int64_t cap, int64_t* ids, int64_t* positions
 /* ---- optimizer arithmetic on raw buffers (optimizer/test_utils.h style) ---- */
 void mo_sgd(float* num, const float* grad, int64_t len, float lr);
 void mo_adagrad(float* num, float* norm, const float* grad, int64_t len, float lr, float wd);
+/* avx_utils.h:96-119: the AVX2/FMA form (blocks of 8 fused, raw gradient in the weight step) */
+void mo_adagrad_avx(float* num, float* norm, const float* grad, int64_t len, float lr, float wd);
 
 /* ---- caller-side dedup / packing ops ---- */
 /* ops/unique_mapping_ops.cc:51-155.  key_split has T+1 entries; dims has T entries.

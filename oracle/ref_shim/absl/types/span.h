@@ -10,6 +10,8 @@ class Span {
  public:
   Span() : p_(nullptr), n_(0) {}
   Span(T* p, size_t n) : p_(p), n_(n) {}
+  template <typename C, typename = decltype(((C*)nullptr)->data()), typename = decltype(((C*)nullptr)->size())>
+  Span(C& c) : p_(c.data()), n_(c.size()) {}   // a container (dc_optimizer.cc:41 passes a std::vector)
   template <typename U>
   Span(const Span<U>& o) : p_(o.data()), n_(o.size()) {}   // Span<float> -> Span<const float>
   T* data() const { return p_; }

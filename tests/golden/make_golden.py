@@ -82,9 +82,36 @@ def adagrad_fixture():
   print("adagrad kat ok")
 
 
+def adagrad_avx_fixture():
+  """The reference AS BUILT (.bazelrc:63-68: -mavx2 -mfma, AdagradOptimizer::Optimize ->
+  avx_utils.h:96-119) on ONE id of dim 64 and ONE of dim 27 (three fused blocks + a tail of 3),
+  wd = 0.1: 12 Optimize() calls through the reference's own NewAdagradOptimizer object compiled in
+  place (oracle/ref_opt_driver.cc).  Weights and accumulators after every call."""
+  out = {}
+  for dim in (64, 27):
+    rng = np.random.default_rng(100 + dim)
+    r = O.RefOptimizer(O.OPT_ADAGRAD, dim, (0.1, 0.1), avx=True)
+    g = (rng.standard_normal((12, dim)) * 0.5).astype(np.float32)
+    nums, norms = [], []
+    for s in range(12):
+      n, c = r.optimize(g[s], 0.05)
+      nums.append(n)
+      norms.append(c)
+    out["grad_d%d" % dim] = g
+    out["num_d%d" % dim] = np.stack(nums)
+    out["norm_d%d" % dim] = np.stack(norms)
+  np.savez_compressed(os.path.join(OUT, "adagrad_avx_kat.npz"), lr=np.float32(0.05), init_acc=np.float32(0.1),
+                      wd=np.float32(0.1), **out)
+  print("adagrad avx kat ok")
+
+
 if __name__ == "__main__":
+  if len(sys.argv) > 1 and sys.argv[1] == "adagrad_avx":   # (only this fixture)
+    adagrad_avx_fixture()
+    sys.exit(0)
   table_fixture("sgd_d8_uniform", 8, O.OPT_SGD, 6, 4096, 20000, "uniform", 0.01)
   table_fixture("adagrad_d16_zipf", 16, O.OPT_ADAGRAD, 8, 8192, 10**6, "zipf", 0.001)
   table_fixture("adagrad_d64_zipf", 64, O.OPT_ADAGRAD, 4, 8192, 10**9, "zipf", 0.001)
   placement_fixture()
   adagrad_fixture()
+  adagrad_avx_fixture()

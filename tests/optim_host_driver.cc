@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < dim; ++i) {
       switch (opt) {
         case mhte::kOptSgd: w[i] = mhte::sgd_step(w[i], gt[i], lr); break;
-        case mhte::kOptAdagrad: mhte::adagrad_step(w[i], s1[i], gt[i], lr, p[1]); break;
+        case mhte::kOptAdagrad: mhte::adagrad_any(w[i], s1[i], gt[i], lr, p[1], p[2], uint32_t(i), uint32_t(dim)); break;
         case mhte::kOptFtrl: mhte::ftrl_step(w[i], s1[i], s2[i], gt[i], lr, p[1], p[2], p[3]); break;
         case mhte::kOptMomentum: mhte::momentum_step(w[i], s1[i], gt[i], lr, p[0], p[1], p[2] != 0.f); break;
         case mhte::kOptAdadelta: mhte::adadelta_step(w[i], s1[i], s2[i], gt[i], lr, p[0], p[1], p[2]); break;

@@ -20,6 +20,8 @@ CASES = [
     ("sgd", 0, O.OPT_SGD, (), 0.01),
     ("adagrad", 1, O.OPT_ADAGRAD, (0.1, 0.0), 0.05),
     ("adagrad_wd", 1, O.OPT_ADAGRAD, (0.1, 0.01), 0.05),
+    # the reference's AVX2 form (avx_utils.h:96-119), opt-in: three fused blocks of 8 + the tail
+    ("adagrad_avx_form_wd", 1, O.OPT_ADAGRAD, (0.1, 0.1, 1.0), 0.05),
     ("ftrl", 2, O.OPT_FTRL, (0.1, 1.0, 0.001, 0.01), 0.05),
     ("momentum", 3, O.OPT_MOMENTUM, (0.9, 0.01, 0.0), 0.01),
     ("momentum_nesterov", 3, O.OPT_MOMENTUM, (0.9, 0.0, 1.0), 0.01),
@@ -51,7 +53,7 @@ def test_engine_opt_ids_are_the_oracles():
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_optimizer_arithmetic_host_equals_oracle(case, driver, tmp_path):
   _, eng, orc, p, lr = case
-  dim, steps = 24, 25
+  dim, steps = (27 if len(p) > 2 and case[0].startswith("adagrad_avx") else 24), 25
   rng = np.random.default_rng(1234 + eng)
   g = (rng.standard_normal((steps, dim)) * np.float32(0.3)).astype(np.float32)
   pp = np.zeros(8, np.float32)

@@ -340,3 +340,138 @@ def test_eviction_interleaved_with_inserts_matches_reference_map():
     for x, y in zip(a, b):
       np.testing.assert_array_equal(x, y)
   assert 0 < t.size() < 24000             # (something was evicted, something stayed)
+
+
+# ---- every per-row optimizer against the reference's OWN sources compiled in place ----------------
+# (oracle/ref_opt_driver.cc #includes runtime/hash_table/optimizer/*_optimizer.cc; the factory
+# functions, Init() and Optimize() that run are the reference's.)  25 random Optimize() calls per
+# configuration; weights AND optimizer context compared bit for bit after every call.
+needs_ref_opt = pytest.mark.skipif(not O.ref_opt_available(), reason="oracle/_ref (optimizers) not built here")
+REF_OPT_CASES = [
+    ("sgd", O.OPT_SGD, ()),
+    ("adagrad", O.OPT_ADAGRAD, (0.1, 0.0)),
+    ("adagrad_wd", O.OPT_ADAGRAD, (1.0, 0.1)),
+    ("ftrl", O.OPT_FTRL, (0.1, 0.0, 0.0, 0.0)),
+    ("ftrl_l1_l2_beta", O.OPT_FTRL, (0.1, 1.0, 0.001, 0.01)),
+    ("momentum", O.OPT_MOMENTUM, (0.9, 0.0, 0.0)),
+    ("momentum_nesterov_wd", O.OPT_MOMENTUM, (0.9, 0.01, 1.0)),
+    ("adadelta", O.OPT_ADADELTA, (0.9, 0.01, 0.0)),
+    ("adadelta_wd", O.OPT_ADADELTA, (0.95, 1e-6, 0.02)),
+    ("rmsprop", O.OPT_RMSPROP, (0.9, 0.0, 0.01)),
+    ("rmsprop_wd", O.OPT_RMSPROP, (0.8, 0.05, 0.003)),
+    ("rmspropv2", O.OPT_RMSPROPV2, (0.9, 0.0, 0.01)),
+    ("rmspropv2_wd", O.OPT_RMSPROPV2, (0.8, 0.05, 0.003)),
+    ("adam", O.OPT_ADAM, (0.9, 0.99, 0.01, 0.0, 0.0)),
+    ("adam_nesterov_wd", O.OPT_ADAM, (0.9, 0.999, 1e-8, 0.01, 1.0)),
+    ("amsgrad", O.OPT_AMSGRAD, (0.9, 0.99, 0.01, 0.0, 0.0)),
+    ("amsgrad_nesterov_wd", O.OPT_AMSGRAD, (0.9, 0.999, 1e-8, 0.01, 1.0)),
+    ("moving_average", O.OPT_MOVING_AVERAGE, (0.9,)),
+    ("group_adagrad", O.OPT_GROUP_ADAGRAD, (0.1, 1.0, 0.001, 0.0)),
+    ("group_adagrad_wd_l2", O.OPT_GROUP_ADAGRAD, (0.0, 1.0, 1.0, 0.05)),
+    ("batch_softmax", O.OPT_BATCH_SOFTMAX, ()),
+]
+
+
+def _oracle_row(t, dim):
+  _, _, _, rows = t.dump()
+  return rows[0, :dim].copy(), rows[0, dim:].copy()
+
+
+@needs_ref_opt
+@pytest.mark.parametrize("case", REF_OPT_CASES, ids=[c[0] for c in REF_OPT_CASES])
+def test_optimizer_restatement_bit_exact_vs_compiled_reference(case):
+  name, opt, p = case
+  for seed, dim in ((1, 1), (2, 8), (3, 19)):
+    if opt == O.OPT_BATCH_SOFTMAX and dim != 1:
+      continue   # (dim_size 1 by definition, batch_softmax_optimizer.cc:28)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    t = O.Table([O.segment(dim, opt, p=p)], 1)
+    r = O.RefOptimizer(opt, dim, p)
+    one = np.array([7], np.int64)
+    for step in range(25):
+      g = (rng.standard_normal(dim) * (10.0 ** rng.integers(-3, 2))).astype(np.float32)
+      lr = float(np.float32(10.0 ** rng.uniform(-3, -0.5)))
+      gs = 3 * step + 1
+      t.optimize(one, g[None, :], [lr], 0, global_step=gs)
+      num_ref, ctx_ref = r.optimize(g, lr, global_step=gs)
+      num, ctx = _oracle_row(t, dim)
+      assert np.array_equal(num.view(np.uint32), num_ref.view(np.uint32)), (name, dim, step, num, num_ref)
+      assert np.array_equal(ctx.view(np.uint32)[:ctx_ref.size], ctx_ref.view(np.uint32)), (name, dim, step)
+
+
+@needs_ref_opt
+def test_reference_as_built_avx_fma_flavour_stays_within_the_parity_bar():
+  """The reference as its .bazelrc builds it (-mavx2 -mfma: avx_utils.h's vector Adagrad, contracted
+  multiply-adds elsewhere) against the scalar arithmetic the engine follows: within north_star's
+  1e-5 on the weights after 25 steps for every optimizer at wd = 0 (Adagrad with wd != 0 is a
+  different FORMULA on the AVX path, avx_utils.h:112 — opt-in in the engine, tested on its own)."""
+  if not O.ref_opt_available(avx=True):
+    pytest.skip("avx flavour not built")
+  for name, opt, p in REF_OPT_CASES:
+    if name in ("adagrad_wd",):
+      continue
+    dim = 1 if opt == O.OPT_BATCH_SOFTMAX else 16
+    rng = np.random.Generator(np.random.PCG64(11))
+    a, b = O.RefOptimizer(opt, dim, p), O.RefOptimizer(opt, dim, p, avx=True)
+    for step in range(25):
+      g = (rng.standard_normal(dim) * 0.01).astype(np.float32)
+      na, _ = a.optimize(g, 0.01, global_step=step + 1)
+      nb, _ = b.optimize(g, 0.01, global_step=step + 1)
+    np.testing.assert_allclose(na, nb, rtol=1e-5, atol=1e-5, err_msg=name)
+
+
+@needs_ref_opt
+def test_adagrad_avx_semantics_differ_with_weight_decay():
+  """avx_utils.h:96-119 subtracts eff_lr * grad (not eff_lr * (grad + wd w)) — what the reference
+  ships (.bazelrc:63-68); the oracle's opt-in restatement of THAT formula against the AVX build."""
+  dim = 64
+  rng = np.random.Generator(np.random.PCG64(5))
+  a = O.RefOptimizer(O.OPT_ADAGRAD, dim, (0.1, 0.1))
+  b = O.RefOptimizer(O.OPT_ADAGRAD, dim, (0.1, 0.1), avx=True)
+  num = np.zeros(dim, np.float32)
+  norm = np.full(dim, 0.1, np.float32)
+  for step in range(10):
+    g = rng.standard_normal(dim).astype(np.float32)
+    na, _ = a.optimize(g, 0.05)
+    nb, cb = b.optimize(g, 0.05)
+    num, norm = O.adagrad_avx(num, norm, g, 0.05, 0.1)
+    np.testing.assert_array_equal(num, nb)      # bit for bit: the restatement fuses where the AVX code does
+    np.testing.assert_array_equal(norm, cb)
+  assert np.abs(na - nb).max() > 1e-3   # the two formulas really are different updates
+  # through the table (segment p[2] != 0), dim 19 = two fused blocks of 8 + a baseline tail of 3
+  t = O.Table([O.segment(19, O.OPT_ADAGRAD, p=(0.1, 0.1, 1.0))], 1)
+  r = O.RefOptimizer(O.OPT_ADAGRAD, 19, (0.1, 0.1), avx=True)
+  one = np.array([3], np.int64)
+  for step in range(10):
+    g = rng.standard_normal(19).astype(np.float32)
+    t.optimize(one, g[None, :], [0.05], 0)
+    nr, cr = r.optimize(g, 0.05)
+    num, ctx = _oracle_row(t, 19)
+    np.testing.assert_array_equal(num, nr)
+    np.testing.assert_array_equal(ctx, cr)
+
+
+@needs_ref_opt
+def test_dc_decorator_compiled_reference_matches_closed_form():
+  """dc_optimizer.cc:28-43: g' = g + lambda g^2 (w - w_latest), then the base optimizer."""
+  rng = np.random.Generator(np.random.PCG64(9))
+  w = rng.standard_normal(8).astype(np.float32)
+  g = rng.standard_normal(8).astype(np.float32)
+  lv = rng.standard_normal(8).astype(np.float32)
+  got = O.ref_dc_sgd(w, g, lv, 0.1, 0.5)
+  lam, lr = np.float32(0.5), np.float32(0.1)
+  gc = g + lam * g * g * (w - lv)
+  np.testing.assert_array_equal(got, w - lr * gc)
+
+
+def test_adagrad_avx_restatement_matches_the_committed_as_built_fixture():
+  """tests/golden/adagrad_avx_kat.npz (the reference's NewAdagradOptimizer compiled -mavx2 -mfma,
+  make_golden.py adagrad_avx_fixture): pins mo_adagrad_avx where oracle/_ref is absent."""
+  z = np.load(os.path.join(GOLD, "adagrad_avx_kat.npz"))
+  for dim in (64, 27):
+    num = np.zeros(dim, np.float32)
+    norm = np.full(dim, z["init_acc"], np.float32)
+    for s in range(z["grad_d%d" % dim].shape[0]):
+      num, norm = O.adagrad_avx(num, norm, z["grad_d%d" % dim][s], float(z["lr"]), float(z["wd"]))
+      np.testing.assert_array_equal(num, z["num_d%d" % dim][s])
+      np.testing.assert_array_equal(norm, z["norm_d%d" % dim][s])

@@ -914,6 +914,51 @@ def test_remaining_optimizers_on_the_fused_step(name, how):
   assert mt.size("t") == ot.size()
 
 
+@pytest.mark.parametrize("how", ["op", "pipelined", "plain"])
+@pytest.mark.parametrize("dim", [64, 27])
+def test_adagrad_avx_form_matches_the_reference_as_built(how, dim):
+  """entry.AdagradOptimizer(avx_semantics=True): the reference's AVX2 AdagradOptimize
+  (avx_utils.h:96-119 — what its .bazelrc:63-68 build runs), which with weight_decay_factor != 0 is a
+  different update from the baseline loop.  Against tests/golden/adagrad_avx_kat.npz (the reference's
+  own NewAdagradOptimizer object compiled -mavx2 -mfma, 12 Optimize() calls at wd = 0.1) BIT FOR
+  BIT, through the op-level kernel and the fused training step (dim 64: float4 rows; dim 27: three
+  fused blocks + a baseline tail on the one-float-per-lane kernels); and against the oracle on a
+  Zipf batch with duplicates."""
+  z = np.load(os.path.join(GOLD, "adagrad_avx_kat.npz"))
+  opt = lambda: entry.AdagradOptimizer(0.05, 0.1, weight_decay_factor=0.1, avx_semantics=True)  # noqa: E731
+  mt = make({"t": entry.make_table_config([entry.CombineAsSegment(dim, entry.ZerosInitializer(), opt())])})
+  one = np.array([77], np.int64)
+  g = z["grad_d%d" % dim]
+  step = SparseStep(mt, "t", 1, exact_order=True) if how != "op" else None
+  for s in range(g.shape[0]):
+    if how == "op":
+      mt.apply_gradients({"t": (ids_t(one), val_t(g[s:s + 1]))}, req_time=10 + s)
+    else:
+      step.forward(ids_t(one), next_ids=ids_t(one) if how == "pipelined" else None)
+      step.backward(val_t(g[s:s + 1]), 10 + s)
+    got = mt.lookup({"t": ids_t(one)})["t"].cpu().numpy()[0]
+    np.testing.assert_array_equal(got, z["num_d%d" % dim][s], err_msg="call %d" % s)
+  # a batch with duplicates against the oracle's restatement of the same form
+  mt2 = make({"t": entry.make_table_config([entry.CombineAsSegment(dim, entry.ZerosInitializer(), opt())])})
+  ot = O.Table([O.segment(dim, O.OPT_ADAGRAD, p=(0.1, 0.1, 1.0))], 1)
+  rng = np.random.default_rng(dim)
+  B = 2048
+  st2 = SparseStep(mt2, "t", B, exact_order=True) if how != "op" else None
+  batches = [(rng.zipf(1.3, B) % 500).astype(np.int64) for _ in range(4)]
+  for s in range(3):
+    gr = (rng.standard_normal((B, dim)) * 0.3).astype(np.float32)
+    uk, _, vo, vos, _ = O.unique_key_with_value_and_offset(batches[s], [0, B], [dim])
+    gu = O.fill_with_offset_map_gradient(np.arange(uk.size), [0, uk.size], gr.ravel(), vo, vos, [dim]).reshape(-1, dim)
+    ot.optimize(uk, gu, [0.05], 50 + s)
+    if how == "op":
+      mt2.apply_gradients({"t": (ids_t(uk), val_t(gu))}, req_time=50 + s)
+    else:
+      st2.forward(ids_t(batches[s]), next_ids=ids_t(batches[s + 1]) if how == "pipelined" else None)
+      st2.backward(val_t(gr), 50 + s)
+  probe = np.unique(np.concatenate(batches[:3]))
+  np.testing.assert_array_equal(mt2.lookup({"t": ids_t(probe)})["t"].cpu().numpy(), ot.lookup(probe)[0])
+
+
 def _half_neighbours(x):
   """(down, up): the two binary16 values around each fp32 x, as fp32 (|x| well inside the range)"""
   h = x.astype(np.float16)

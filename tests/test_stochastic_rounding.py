@@ -117,6 +117,6 @@ def test_python_wrapper_sets_the_flag():
       L.OPT_FLAG_STOCHASTIC_ROUNDING_FP16
   opt = entry.StochasticRoundingFloat16OptimizerWrapper(entry.AdagradOptimizer(0.05, 0.1))
   assert opt.opt_type == (L.OPT_ADAGRAD | L.OPT_FLAG_STOCHASTIC_ROUNDING_FP16)
-  assert tuple(opt.params()) == (0.1, 0.0) and opt.learning_rate == 0.05
+  assert tuple(opt.params()) == (0.1, 0.0, 0.0) and opt.learning_rate == 0.05   # (init_acc, wd, avx form)
   with pytest.raises(ValueError):
     entry.StochasticRoundingFloat16OptimizerWrapper(opt)
