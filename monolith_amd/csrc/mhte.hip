@@ -214,6 +214,22 @@ static thread_local Prof g_prof;
     }                                                                                          \
   } while (0)
 
+// tables alive in this process, by their device counter block: a dedup workspace that holds row
+// reservations (ProbeOut.spec) gives their keys back when its batch is dropped — unless the table
+// went first
+static std::mutex g_ctr_mu;
+static std::vector<const void*> g_live_ctrs;
+static void register_counters(const void* p, bool live) {
+  std::lock_guard<std::mutex> g(g_ctr_mu);
+  auto it = std::find(g_live_ctrs.begin(), g_live_ctrs.end(), p);
+  if (live && it == g_live_ctrs.end()) g_live_ctrs.push_back(p);
+  if (!live && it != g_live_ctrs.end()) g_live_ctrs.erase(it);
+}
+static bool table_counters_alive(const void* p) {
+  std::lock_guard<std::mutex> g(g_ctr_mu);
+  return std::find(g_live_ctrs.begin(), g_live_ctrs.end(), p) != g_live_ctrs.end();
+}
+
 // ------------------------------------------------------------------------------------------ dedup ws
 struct DedupWs {
   int device = 0;
@@ -315,8 +331,27 @@ struct DedupWs {
   DevBuf<uint16_t> r_seg;
   DevBuf<ItemHdr> r_item_hdr;
   DevBuf<uint32_t> r_cursor;   // shard packing cursors
-  DevBuf<uint32_t> r_spec;     // row handles reserved for the batch's unique ids (rd_prealloc_role)
-  bool r_prealloc = false;     // r_spec holds the reservations of the deduplicated batch
+  bool r_prealloc = false;     // r_urec holds row reservations for the numbered batch
+  DevBuf<URec> r_urec;         // ProbeOut of the numbered batch: per unique index, what the update
+                               // needs in one load — incl. the row handle / slot of an id the table
+                               // held when the batch was numbered, or a row reserved for it
+  bool r_hints = false;        // r_urec describes the numbered batch
+  Counters* r_res_ctr = nullptr;   // the table whose rows the records reserve
+  void probe_out_reserve(int64_t n) {
+    const URec* old = r_urec.p;
+    r_urec.reserve(size_t(n) + 1);
+    // (the update reads records past the unique count before it knows the count: never-written
+    // memory must at least be well-formed)
+    if (r_urec.p != old) HIP_OK(hipMemset(r_urec.p, 0, r_urec.cap * sizeof(URec)));
+  }
+  // reservations of a numbered batch that is dropped instead of applied: the keys go back
+  void drop_reservations(hipStream_t st) {
+    if (r_prealloc && r_stage == 2 && r_res_ctr && table_counters_alive(r_res_ctr))
+      rd_unreserve_kernel<<<32, 256, 0, st>>>(r_urec.p, rv.n_unique, rv.n, r_res_ctr);
+    r_prealloc = false;
+    r_hints = false;
+    r_res_ctr = nullptr;
+  }
   uint32_t r_clean_cap = 0;  // run scratch [0, r_clean_cap] is all-empty
   int r_stage = 0;           // 0 idle, 1 dedup enqueued, 2 work list enqueued (ready for apply)
   RunView rv{};
@@ -335,6 +370,7 @@ struct DedupWs {
     if (n <= 0 || n > int64_t(kRdMaxBlocks) * kRdBlock)
       throw Error(MHTE_INVALID_ARGUMENT, "step: batch must have 1.." +
                                              std::to_string(kRdMaxBlocks * kRdBlock) + " ids");
+    drop_reservations(st);
     const uint32_t C = 1u << std::max<uint32_t>(10, ceil_log2(uint64_t(2) * n));
     const RdSlot* old_key = r_hs.p;
     const uint32_t* old_ctr = r_ctr.p;
@@ -362,7 +398,6 @@ struct DedupWs {
     }
     rv = d;
     r_stage = 1;
-    r_prealloc = false;
     return d;
   }
   // workgroups of the build role: one trip of 256 slots per wavefront, at most 128 workgroups
@@ -524,7 +559,10 @@ struct Table {
     if (buckets) (void)hipFree(buckets);
     for (float* c : chunks) (void)hipFree(c);
     if (d_chunks) (void)hipFree(d_chunks);
-    if (ctr) (void)hipFree(ctr);
+    if (ctr) {
+      register_counters(ctr, false);
+      (void)hipFree(ctr);
+    }
     if (h_ctr) (void)hipHostFree(h_ctr);
   }
 
@@ -620,6 +658,7 @@ struct Table {
     HIP_OK(hipMemset(d_chunks, 0, sizeof(float*) * max_chunks));
     HIP_OK(hipMalloc(&ctr, sizeof(Counters)));
     HIP_OK(hipMemset(ctr, 0, sizeof(Counters)));
+    register_counters(ctr, true);
     HIP_OK(hipHostMalloc(&h_ctr, sizeof(Counters), hipHostMallocDefault));
     memset(h_ctr, 0, sizeof(Counters));
     add_chunk();
@@ -719,14 +758,22 @@ struct Table {
   // Called before every mutating op with the number of ids it may insert.
   // true if ensure_capacity(n) would have to grow the table (a displacement pass still
   // outstanding must be finished first: growing re-hashes)
+  // keys in the buckets by the (synchronised) counters: row reservations of a batch that was numbered
+  // and probed but not applied yet are counted in `alloc` ahead of their insert
+  int64_t live_keys() const { return int64_t(h_ctr->alloc >> 32) - int64_t(h_ctr->reserved); }
   bool would_grow(uint64_t n) const {
     const uint64_t row_cap = uint64_t(chunks.size()) << chunk_shift;
     return double(keys_upper + n) > max_load * double(uint64_t(kSlots) << hp) ||
            rows_upper + n + kSpecSlackRows > row_cap;
   }
-  void ensure_capacity(uint64_t n, hipStream_t st) {
-    keys_upper += n;
-    rows_upper += n + kSpecSlackRows;
+  // what: kCapBoth — room for n more keys and rows; kCapRows / kCapKeys — one half of it.  The
+  // pipelined step reserves the next batch's ROWS a launch ahead (the build role's probe) and makes
+  // room in the BUCKETS when that batch is applied, as before: a doubling a batch early would lower
+  // the load factor the caller asked for.
+  enum { kCapBoth = 0, kCapRows = 1, kCapKeys = 2 };
+  void ensure_capacity(uint64_t n, hipStream_t st, int what = kCapBoth) {
+    if (what != kCapRows) keys_upper += n;
+    if (what != kCapKeys) rows_upper += n + kSpecSlackRows;
     const uint64_t row_cap = uint64_t(chunks.size()) << chunk_shift;
     const bool need_keys = double(keys_upper) > max_load * double(uint64_t(kSlots) << hp);
     const bool need_rows = rows_upper > row_cap;
@@ -741,8 +788,9 @@ struct Table {
                     "reserve capacity (initial_capacity / reserve_rows) before capturing");
     }
     sync_counters(st);
-    keys_upper = (h_ctr->alloc >> 32) + n;
-    rows_upper = (h_ctr->alloc & 0xffffffffull) + n + kSpecSlackRows;
+    // (keys counted ahead for row reservations are the batch's own inserts: n covers them)
+    keys_upper = uint64_t(live_keys()) + (what != kCapRows ? n : 0);
+    rows_upper = (h_ctr->alloc & 0xffffffffull) + (what != kCapKeys ? n + kSpecSlackRows : 0);
     if ((h_ctr->alloc >> 32) == 0) {
       // nothing to migrate: jump straight to the needed hashpower
       uint32_t want = hp;
@@ -944,19 +992,10 @@ struct Table {
     if (n <= 0) throw Error(MHTE_INVALID_ARGUMENT, "step_forward: empty batch");
     Shape sh = pick_shape(dim, vec_ok && aligned16(out));
     PreArgs pre{};
-    if (ws_cur && ws_cur->r_stage == 2 && !flt_slots && int64_t(ws_cur->rv.n) == n) {
-      // (with an admission filter an id the table lacks may not be inserted at all: the update
-      // keeps its own allocation then)
-      if (would_grow(uint64_t(n))) finish_pending(st);
-      ensure_capacity(uint64_t(n), st);
-      ws_cur->r_spec.reserve(size_t(n) + 1);
-      pre.uids = ws_cur->rv.uids;
-      pre.ctr = ws_cur->rv.ctr;
-      pre.spec_row = ws_cur->r_spec.p;
-      pre.n_max = uint32_t(n);
-      pre.nblk = std::min<uint32_t>(16, uint32_t((n + kRdBlock - 1) / kRdBlock));
-      ws_cur->r_prealloc = true;
-    }
+    // (ws_cur: the forward launch used to reserve the update's row handles here, rd_prealloc_role —
+    // superseded: the build role's table probe reserves them a launch earlier, off this launch's
+    // critical path; the argument is accepted and ignored)
+    (void)ws_cur;
     SlowArgs sp{};
     sp.enabled = pend_valid ? 1 : 0;
     if (pend_valid) {
@@ -1018,7 +1057,27 @@ struct Table {
     if (ws.r_stage == 0 || int64_t(ws.rv.n) != n || ws.rv.uids != uids || ws.rv.n_unique != n_dev)
       throw Error(MHTE_FAILED_PRECONDITION,
                   "step_backward: workspace does not hold the run dedup of this batch");
-    ws.build_work_list(st);  // (first step of a pipeline; later ones were built a step ahead)
+    // first step of a pipeline (later ones were numbered — and probed — a step ahead, inside the
+    // previous update's launch)
+    if (ws.r_stage == 1 || !ws.r_hints) {
+      // (r_stage 2 without hints: numbered on its own, mhte_step_dedup — the probe alone)
+      ws.probe_out_reserve(n);
+      const bool reserve = flt_slots == nullptr && !ws.r_prealloc;
+      if (reserve) ensure_capacity(uint64_t(std::min<int64_t>(n_max, n)), st, kCapRows);
+      ProbeOut po{ws.r_urec.p, reserve ? 1u : 0u};
+      if (ws.r_stage == 1)
+        rd_build_probe_kernel<<<DedupWs::build_blocks(ws.rv), 256, 0, st>>>(ws.rv, uint32_t(kStepLightMax), view, po);
+      else
+        rd_probe_kernel<<<uint32_t(std::min<int64_t>(256, (n + 255) / 256)), 256, 0, st>>>(
+            ws.rv, view, po, uint32_t(n), exact_order ? 0xffffffffu : uint32_t(kStepLightMax));
+      HIP_OK(hipGetLastError());
+      ws.r_stage = 2;
+      ws.r_hints = true;
+      if (reserve) {
+        ws.r_prealloc = true;
+        ws.r_res_ctr = view.ctr;
+      }
+    }
     ApplyArgs a;
     for (int i = 0; i < kMaxSegments; ++i) a.lr[i] = (lrs && i < int(nseg)) ? lrs[i] : 0.f;
     a.ts = static_cast<uint32_t>(update_time);
@@ -1028,7 +1087,8 @@ struct Table {
     ++mut_epoch;
     const bool prealloc = ws.r_prealloc;  // (rows reserved — and room ensured — by step_forward)
     ws.r_prealloc = false;
-    if (!prealloc) ensure_capacity(uint64_t(std::min<int64_t>(n_max, n)), st);
+    // (prealloc: the rows were reserved — and their room made — when the batch was numbered)
+    ensure_capacity(uint64_t(std::min<int64_t>(n_max, n)), st, prealloc ? kCapKeys : kCapBoth);
     Shape sh = pick_shape(dim, vec_ok && aligned16(grads) && aligned16(grad_u));
     pending.reserve(size_t(n_max) + 1);
     const uint32_t cap_items = DedupWs::max_items(n);
@@ -1050,7 +1110,15 @@ struct Table {
     c.arrive = ws.arrive.p;
     c.n_max = n_max;
     c.light_max = exact_order ? 0xffffffffu : uint32_t(kStepLightMax);
-    c.spec_row = prealloc ? ws.r_spec.p : nullptr;
+    c.spec_row = nullptr;
+    c.urow = nullptr;
+    c.uloc = nullptr;
+    c.uts = nullptr;
+    c.urec = ws.r_urec.p;
+    c.trusted = 0;   // (an update, a displacement pass, a doubling may lie between probe and use: the
+                     // kernel checks every hint against the slot's key)
+    ws.r_hints = false;
+    ws.r_res_ctr = nullptr;
     // fixed grids with grid-stride loops: item workgroups first (longest chain), sized for the
     // work a Zipf batch has; more ids / items than workgroups just means more trips
     const uint32_t groups_per_wg = uint32_t(256 / sh.G);
@@ -1062,9 +1130,17 @@ struct Table {
                               slots - c.nblk_items - 128));
     RunView nxt{};
     uint32_t nblk_build = 0;
+    ProbeOut po{};
+    bool reserve_next = false;
     if (ws_next && ws_next->r_stage == 1) {
       nxt = ws_next->rv;
       nblk_build = DedupWs::build_blocks(nxt);
+      // the next batch is numbered AND probed in this launch: hints and row reservations for its
+      // update (room for the rows it may reserve is made now)
+      ws_next->probe_out_reserve(int64_t(nxt.n));
+      reserve_next = flt_slots == nullptr;
+      if (reserve_next) ensure_capacity(uint64_t(nxt.n), st, kCapRows);
+      po = ProbeOut{ws_next->r_urec.p, reserve_next ? 1u : 0u};
     }
     const dim3 grid(nblk_build + c.nblk_items + c.nblk_ids);
     TableView v = view;
@@ -1074,20 +1150,25 @@ struct Table {
 #define CALL(G_, V_) \
   do {                                                                                               \
     if (!basic && nseg == 1) {                                                                       \
-      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, true, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a); \
+      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, true, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a, po); \
     } else if (!basic) {                                                                             \
-      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, false, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a); \
+      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, false, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a, po); \
     } else if (nseg == 1) {                                                                          \
-      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a);  \
+      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a, po);  \
     } else {                                                                                         \
-      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, false>), grid, 256, st, nxt, nblk_build, v, cur, c, a); \
+      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, false>), grid, 256, st, nxt, nblk_build, v, cur, c, a, po); \
     }                                                                                                \
   } while (0)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
     hipError_t le = hipGetLastError();
     ws.r_stage = 0;  // the apply leaves the scratch all-empty
-    if (nblk_build) ws_next->r_stage = 2;
+    if (nblk_build) {
+      ws_next->r_stage = 2;
+      ws_next->r_hints = true;
+      ws_next->r_prealloc = reserve_next;
+      ws_next->r_res_ctr = view.ctr;
+    }
     if (le != hipSuccess) {
       ws.r_clean_cap = 0;
       if (ws_next) ws_next->r_clean_cap = 0;
@@ -1607,7 +1688,7 @@ mhte_status mhte_table_size(mhte_multi_table* t, int32_t table, int64_t* size, v
     HIP_OK(hipSetDevice(t->device));
     std::lock_guard<std::mutex> g(tb.mu);
     tb.sync_counters(S(stream));
-    *size = int64_t(tb.h_ctr->alloc >> 32) + (tb.h_ctr->special_state ? 1 : 0);
+    *size = tb.live_keys() + (tb.h_ctr->special_state ? 1 : 0);
   });
 }
 
@@ -1663,7 +1744,7 @@ mhte_status mhte_table_get_stats(mhte_multi_table* t, int32_t table, mhte_table_
     HIP_OK(hipSetDevice(t->device));
     std::lock_guard<std::mutex> g(tb.mu);
     tb.sync_counters(S(stream));
-    out->size = int64_t(tb.h_ctr->alloc >> 32) + (tb.h_ctr->special_state ? 1 : 0);
+    out->size = tb.live_keys() + (tb.h_ctr->special_state ? 1 : 0);
     out->hashpower = int32_t(tb.hp);
     out->rows_allocated = int64_t(tb.h_ctr->alloc & 0xffffffffull);
     out->lookup_hits = int64_t(tb.h_ctr->hits);
@@ -2328,7 +2409,7 @@ static void save_multi_table(mhte_multi_table* t, const std::string& basename, i
   for (auto& tb : t->tables) {
     std::lock_guard<std::mutex> g(tb->mu);
     tb->sync_counters(st);
-    total += int64_t(tb->h_ctr->alloc >> 32) + (tb->h_ctr->special_state == 1 ? 1 : 0);
+    total += tb->live_keys() + (tb->h_ctr->special_state == 1 ? 1 : 0);
   }
   // PickNshards, multi_hash_table_save_restore_ops.cc:240-248
   if (nshards < 0) nshards = int(std::min<int64_t>(4, std::max<int64_t>(1, total / 1000000)));
@@ -2715,7 +2796,7 @@ static void save_table_legacy(mhte_multi_table* t, int idx, const std::string& b
   {
     std::lock_guard<std::mutex> g(tbl.mu);
     tbl.sync_counters(st);
-    total = int64_t(tbl.h_ctr->alloc >> 32) + (tbl.h_ctr->special_state == 1 ? 1 : 0);
+    total = tbl.live_keys() + (tbl.h_ctr->special_state == 1 ? 1 : 0);
   }
   if (nshards < 0) nshards = int(std::min<int64_t>(4, std::max<int64_t>(1, total / 1000000)));   // PickNshards :122-127
   if (nshards < 1) nshards = 1;
@@ -2869,7 +2950,16 @@ mhte_status mhte_dedup_ws_create(int32_t device, mhte_dedup_ws** out) {
     *out = w;
   });
 }
-void mhte_dedup_ws_destroy(mhte_dedup_ws* ws) { delete ws; }
+void mhte_dedup_ws_destroy(mhte_dedup_ws* ws) {
+  if (ws && ws->ws.r_prealloc && ws->ws.r_stage == 2 && ws->ws.r_res_ctr) {
+    // a numbered batch that was never applied: its row reservations' keys go back to the table
+    // (the table may already be gone: its counters then are freed memory — only while it lives)
+    (void)hipSetDevice(ws->ws.device);
+    ws->ws.drop_reservations(nullptr);
+    (void)hipDeviceSynchronize();
+  }
+  delete ws;
+}
 
 mhte_status mhte_unique(mhte_dedup_ws* ws, const int64_t* ids, int64_t n, int64_t* unique_ids,
                         uint32_t* inverse, uint32_t* seg_off, uint32_t* seg_pos,

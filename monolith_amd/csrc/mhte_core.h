@@ -196,6 +196,9 @@ MHTE_HD bool cuckoopath_move(Bucket* buckets, CuckooRecord* path, int depth) {
     tb.ts[to.slot] = fb.ts[from.slot];
     tb.key[to.slot] = fb.key[from.slot];
     fb.key[from.slot] = kEmptyKey;
+    fb.row[from.slot] = kNoRow;   // invariant: an empty slot carries no row handle (a claim publishes
+                                  // the key first and the handle after it — a reader that sees the
+                                  // new key beside a stale handle would take another id's row)
     --depth;
   }
   return true;

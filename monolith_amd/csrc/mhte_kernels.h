@@ -28,7 +28,8 @@ struct Counters {
   // device atomics cost ~12 ns each on MI355X, so the two counters share a single returning add.
   unsigned long long alloc;
   unsigned long long hits;     // lookup hits since last reset
-  unsigned int unused0;
+  unsigned int reserved;       // keys counted in `alloc` for row reservations that no update has consumed yet
+                               // (ProbeOut: the build role's table probe); live keys = alloc >> 32 minus this
   unsigned int n_pending;      // ids whose two buckets were full in the fast path
   unsigned int error;          // bit0: displacement failed (id dropped)
   unsigned int n_dropped;

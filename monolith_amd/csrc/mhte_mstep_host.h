@@ -39,6 +39,23 @@ static uint32_t group_lanes(uint32_t dim) {
   return g;
 }
 
+// Lane-group shape of a table in a launch (MHTE_SWITCH_GV): lanes per id | 1 when a lane moves one
+// float.  float4 lanes need rows of whole float4s (Table::vec_ok) AND the table's slices of the flat
+// buffers of the launch (float offsets off_a, off_b) on 16-byte boundaries; otherwise one float per
+// lane, which covers rows of up to 64 floats — the reference's standard layouts with a dim-1 bias
+// slice in front of the vector (NT/feature.py:117-120; distributed_ps_test.py:480-505: dims 17 / 33).
+static uint32_t shape_code(const Table& tb, uint64_t off_a = 0, uint64_t off_b = 0) {
+  const bool v4 = tb.vec_ok && off_a % 4 == 0 && off_b % 4 == 0;
+  const Shape sh = pick_shape(tb.dim, v4);
+  if (tb.dim > uint32_t(sh.G * sh.VEC))
+    throw Error(MHTE_INVALID_ARGUMENT,
+                "table " + tb.name + ": a row of " + std::to_string(tb.dim) + " floats that is not whole "
+                "float4s on a 16-byte boundary of the flat buffer (a table of odd dim in front of it?) "
+                "fits the fused step up to 64 floats");
+  return uint32_t(sh.G) | (sh.VEC == 1 ? 1u : 0u);
+}
+static uint32_t shape_lanes(uint32_t code) { return code & ~1u; }
+
 // bump allocator over one hipMalloc (first pass with base == nullptr sizes it)
 struct Arena {
   char* base = nullptr;
@@ -141,10 +158,11 @@ struct MultiStep {
                                              std::to_string(kRdMaxBlocks * kRdBlock));
     for (uint32_t t = 0; t < T; ++t) {
       const Table& tb = *m->tables[t];
-      if (!tb.fusable() || !tb.vec_ok)
+      if (!tb.fusable())
         throw Error(MHTE_INVALID_ARGUMENT,
-                    "multi step: table " + tb.name + " does not fit the fused step (SGD / Adagrad / "
-                    "FTRL segments on 4-float boundaries, dim <= 256)");
+                    "multi step: table " + tb.name + " does not fit the fused step (per-element "
+                    "optimizers — GroupAdaGrad needs the whole segment; rows of whole float4s up to "
+                    "256 floats, any other row layout up to 64)");
     }
     {
       int cus = 0;
@@ -243,10 +261,11 @@ struct MultiStep {
           throw Error(MHTE_INVALID_ARGUMENT, "multi step: embedding buffer exceeds 2^32 floats");
         ft.emb_off = uint32_t(emb_off);
         emb_off += int64_t(ft.n) * tb.dim;
+        ft.gv = shape_code(tb, uint64_t(ft.emb_off));
         if (ft.n) {
           // persistent workgroups: the launch's share of the resident slots (8 per CU) times the
           // oversubscription, split evenly over the tables; enough for one trip at most
-          const uint32_t groups_per_wg = uint32_t(kFwdBlock) / h_st[t].g;
+          const uint32_t groups_per_wg = uint32_t(kFwdBlock) / shape_lanes(ft.gv);
           const uint32_t one_trip = (ft.n + groups_per_wg - 1) / groups_per_wg;
           const uint32_t share = std::max<uint32_t>(8, uint32_t(8 * num_cus) * scatter_ovs / std::max(1u, active));
           ft.nblk_s = std::max<uint32_t>(1, std::min(one_trip, share));
@@ -305,8 +324,9 @@ struct MultiStep {
       ft.emb_off = uint32_t(emb_off);
       emb_off += int64_t(ft.n) * tb.dim;
       F.fwd_start[t] = lin;
+      ft.gv = shape_code(tb, uint64_t(ft.emb_off));
       if (ft.n) {
-        const uint32_t groups_per_wg = uint32_t(kRdBlock) / h_st[t].g;
+        const uint32_t groups_per_wg = uint32_t(kRdBlock) / shape_lanes(ft.gv);
         const uint32_t one_trip = (ft.n + groups_per_wg - 1) / groups_per_wg;
         const uint32_t share = std::max<uint32_t>(2, room / std::max(1u, active));
         ft.nblk_s = std::max<uint32_t>(1, std::min(one_trip, share));
@@ -406,7 +426,8 @@ struct MultiStep {
           bt.a.global_step = p.global_step;
           bt.light_max = p.exact_order ? 0xffffffffu : uint32_t(kStepLightMax);
           bt.hints = (has_hints[slot_cur] && fwd_epoch[slot_cur][t] == tb.mut_epoch) ? 1u : 0u;
-          const uint32_t groups_per_wg = 256u / h_st[t].g;
+          bt.gv = shape_code(tb, uint64_t(bt.grad_off));
+          const uint32_t groups_per_wg = 256u / shape_lanes(bt.gv);
           const uint32_t cap_items = DedupWs::max_items(n);
           bt.nblk_items = p.exact_order ? 0u
                                         : std::min<uint32_t>(cap_items, std::min<uint32_t>(
@@ -607,12 +628,13 @@ struct MultiStep {
 // =================================================================================================
 // One-launch fused ops
 // =================================================================================================
-// true when every table can take the segment kernels (float4 rows, no whole-segment optimizer)
+// true when every table can take the segment kernels (no whole-segment optimizer; rows of whole
+// float4s, or up to 64 floats of any layout)
 static bool seg_kernels_ok(const mhte_multi_table* t) {
   if (t->tables.size() > size_t(kMaxStepTables)) return false;
   for (auto& tb : t->tables) {
-    if (!tb->vec_ok || tb->has_group_opt) return false;
-    Shape sh = pick_shape(tb->dim, true);
+    if (tb->has_group_opt) return false;
+    Shape sh = pick_shape(tb->dim, tb->vec_ok);   // (other row layouts: one float per lane, up to 64)
     if (tb->dim > uint32_t(sh.G * sh.VEC)) return false;
   }
   return true;
@@ -638,12 +660,16 @@ static void fused_lookup_segments(mhte_multi_table* t, const int64_t* ids, const
       A.emb_off[y] = uint32_t(eo[s0 + y]);
     }
     for (int k = 0; k < T; ++k) {
-      A.g[k] = uint8_t(group_lanes(t->tables[k]->dim));
+      // (float4 lanes only if every segment of the table starts on a 16-byte boundary of `embeddings`)
+      uint64_t worst = 0;
+      for (int y = 0; y < ns; ++y)
+        if ((s0 + y) % T == k && (A.emb_off[y] % 4u)) worst = 1;
+      A.g[k] = uint8_t(shape_code(*t->tables[k], worst));
       A.count_hits[k] = t->tables[k]->count_hits ? 1 : 0;
     }
     for (int y = 0; y < ns; ++y) {
       const uint32_t n = A.id_off[y + 1] - A.id_off[y];
-      const uint32_t g = A.g[(s0 + y) % T];
+      const uint32_t g = shape_lanes(A.g[(s0 + y) % T]);
       gx = std::max(gx, uint32_t((uint64_t((n + 1) / 2) * g + 511) / 512));
     }
     if (gx == 0) continue;
@@ -686,7 +712,12 @@ static void fused_optimize_segments(mhte_multi_table* t, const int64_t* ids,
     int64_t lr_off = 0;
     for (int k = 0; k < T; ++k) {
       Table& tb = *t->tables[k];
-      A.g[k] = uint8_t(group_lanes(tb.dim));
+      {
+        uint64_t worst = 0;
+        for (int y = 0; y < ns; ++y)
+          if ((s0 + y) % T == k && (uint32_t(grad_offsets[s0 + y]) % 4u)) worst = 1;
+        A.g[k] = uint8_t(shape_code(tb, worst));
+      }
       A.pending[k] = tb.pending.p;
       ApplyArgs& a = A.a[k];
       for (int i = 0; i < kMaxSegments; ++i)
@@ -704,7 +735,7 @@ static void fused_optimize_segments(mhte_multi_table* t, const int64_t* ids,
       if (y == ns - 1) A.id_off[ns] = A.id_off[y] + n;
       else if (uint32_t(id_offsets[s0 + y + 1]) != A.id_off[y] + n)
         throw Error(MHTE_INVALID_ARGUMENT, "id_offsets do not follow fused_slot_size");
-      const uint32_t gl = A.g[(s0 + y) % T];
+      const uint32_t gl = shape_lanes(A.g[(s0 + y) % T]);
       gx = std::max(gx, (n + 256 / gl - 1) / (256 / gl));
     }
     if (gx == 0) continue;

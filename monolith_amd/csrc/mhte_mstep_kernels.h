@@ -35,6 +35,23 @@ constexpr int kMaxSegs = 160;        // [shard][table] segments per fused-op lau
 #define MHTE_CONST __attribute__((address_space(4)))
 typedef const MHTE_CONST TableView* ConstViews;
 
+// Lane-group shape of a table in a launch: lanes per id (8 / 16 / 32 / 64), | 1 when a lane moves ONE
+// float instead of a float4 — rows that are not whole float4s (a dim-1 FTRL bias slice in front of
+// the vector, NT/feature.py:117-120: dims 17 / 33 ...; dim <= 64 then) or whose slice of the flat
+// embedding / gradient buffer does not start on a 16-byte boundary.  CALL(G, VEC) is expanded for the
+// table's shape; -DMHTE_DEV_FAST keeps (16, 4) only.
+#define MHTE_SWITCH_GV(code, CALL)                     \
+  switch (code) {                                      \
+    case 8: MHTE_OTHER_G(CALL(8, 4)); break;           \
+    case 16: CALL(16, 4); break;                       \
+    case 32: MHTE_OTHER_G(CALL(32, 4)); break;         \
+    case 64: MHTE_OTHER_G(CALL(64, 4)); break;         \
+    case 9: MHTE_OTHER_G(CALL(8, 1)); break;           \
+    case 17: MHTE_OTHER_G(CALL(16, 1)); break;         \
+    case 33: MHTE_OTHER_G(CALL(32, 1)); break;         \
+    default: MHTE_OTHER_G(CALL(64, 1)); break;         \
+  }
+
 struct MStepStatic {
   RunView rv[2];           // run-dedup workspaces: slot s holds the batch deduplicated into it
                            // (ids / n / nblk are per launch: kernel arguments)
@@ -59,6 +76,7 @@ struct MFwdTab {
   uint32_t n;                  // ids of this batch (its dedup is in slot cur); 0: no lookup
   uint32_t nblk_s;             // workgroups of the lookup role
   uint32_t emb_off;            // floats
+  uint32_t gv;                 // lane-group shape of the table in this launch (MHTE_SWITCH_GV)
 };
 struct MFwdArgs {
   ConstViews views;
@@ -82,6 +100,7 @@ struct MBwdTab {
   uint32_t n_next;             // ids of the batch in slot cur ^ 1
   uint32_t full;               // 1: the table uses optimizers beyond SGD / Adagrad / FTRL (the
                                // mstep_bwd_kernel<true> launch serves it, <false> the others)
+  uint32_t gv;                 // lane-group shape of the table in this launch (MHTE_SWITCH_GV)
   ApplyArgs a;
 };
 struct MBwdArgs {
@@ -176,7 +195,7 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
 #else
 #define MHTE_SCATTER_STORE(P, V) store_stream<VEC>(P, V)
 #endif
-template <int G, int BLOCK, int UNR>
+template <int G, int BLOCK, int UNR, int VEC = 4>
 __device__ __forceinline__ void mstep_scatter_role(const TableView& tv, const RunView& d,
                                                    float* __restrict__ out,
                                                    uint32_t* __restrict__ urow,
@@ -185,7 +204,6 @@ __device__ __forceinline__ void mstep_scatter_role(const TableView& tv, const Ru
                                                    int64_t n_max, int count_hits, uint32_t bid,
                                                    uint32_t nblk, uint32_t item_split,
                                                    WaveTrace& wt) {
-  constexpr int VEC = 4;
   constexpr int NG = BLOCK / G;
   constexpr int GPW = 64 / G;  // groups per wavefront
   const int lane = threadIdx.x & 63;
@@ -384,12 +402,10 @@ __global__ __launch_bounds__(BLOCK) void mstep_fwd_kernel(MFwdArgs A) {
   const RunView d = s.rv[cur];
   float* out = A.out + size_t(ft.emb_off);
   const int ch = int(s.count_hits);
-  switch (s.g) {
-    case 8: MHTE_OTHER_G(mstep_scatter_role<8, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt)); break;
-    case 16: mstep_scatter_role<16, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
-    case 32: MHTE_OTHER_G(mstep_scatter_role<32, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt)); break;
-    default: MHTE_OTHER_G(mstep_scatter_role<64, BLOCK, MHTE_SCATTER_UNR>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt)); break;
-  }
+#define MHTE_FWD_CALL(G_, V_) \
+  mstep_scatter_role<G_, BLOCK, MHTE_SCATTER_UNR, V_>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt)
+  MHTE_SWITCH_GV(ft.gv, MHTE_FWD_CALL)
+#undef MHTE_FWD_CALL
   wt.end(5u);
 }
 
@@ -447,12 +463,10 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
   float* out = A.out + size_t(ft.emb_off);
   const int ch = int(s.count_hits);
   constexpr int U = MHTE_FUSED_SCATTER_UNR;
-  switch (s.g) {
-    case 8: MHTE_OTHER_G(mstep_scatter_role<8, kRdBlock, U>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt)); break;
-    case 16: mstep_scatter_role<16, kRdBlock, U>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt); break;
-    case 32: MHTE_OTHER_G(mstep_scatter_role<32, kRdBlock, U>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt)); break;
-    default: MHTE_OTHER_G(mstep_scatter_role<64, kRdBlock, U>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt)); break;
-  }
+#define MHTE_FWD_CALL(G_, V_) \
+  mstep_scatter_role<G_, kRdBlock, U, V_>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt)
+  MHTE_SWITCH_GV(ft.gv, MHTE_FWD_CALL)
+#undef MHTE_FWD_CALL
   wt.end(5u);
 }
 
@@ -460,15 +474,12 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
 // backward: per table   numbering + heavy work list of the NEXT batch | apply of this batch
 // ---------------------------------------------------------------------------------------------
 template <bool ONESEG, bool FULL>
-__device__ __forceinline__ void mstep_apply_switch(uint32_t g, const TableView& tv, const RunView& d,
+__device__ __forceinline__ void mstep_apply_switch(uint32_t gv, const TableView& tv, const RunView& d,
                                                    const ApplyCtl& c, const ApplyArgs& a,
                                                    uint32_t bid, WaveTrace& wt, ApplyLds& L) {
-  switch (g) {
-    case 8: MHTE_OTHER_G(rd_apply_role<8, 4, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L)); break;
-    case 16: rd_apply_role<16, 4, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L); break;
-    case 32: MHTE_OTHER_G(rd_apply_role<32, 4, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L)); break;
-    default: MHTE_OTHER_G(rd_apply_role<64, 4, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L)); break;
-  }
+#define MHTE_BWD_CALL(G_, V_) rd_apply_role<G_, V_, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L)
+  MHTE_SWITCH_GV(gv, MHTE_BWD_CALL)
+#undef MHTE_BWD_CALL
 }
 
 #ifndef MHTE_MBWD_OCC
@@ -511,10 +522,11 @@ __global__ __launch_bounds__(256, MHTE_MBWD_OCC) void mstep_bwd_kernel(MBwdArgs 
   c.urow = bt.hints ? s.urow[cur] : nullptr;
   c.uloc = bt.hints ? s.uloc[cur] : nullptr;
   c.uts = bt.hints ? s.uts[cur] : nullptr;
-  if (FULL && s.oneseg) mstep_apply_switch<true, true>(s.g, tv, d, c, bt.a, bid, wt, L);
-  else if (FULL) mstep_apply_switch<false, true>(s.g, tv, d, c, bt.a, bid, wt, L);
-  else if (s.oneseg) mstep_apply_switch<true, false>(s.g, tv, d, c, bt.a, bid, wt, L);
-  else mstep_apply_switch<false, false>(s.g, tv, d, c, bt.a, bid, wt, L);
+  c.trusted = 1;   // (the host hands the hints over only while Table::mut_epoch is unchanged)
+  if (FULL && s.oneseg) mstep_apply_switch<true, true>(bt.gv, tv, d, c, bt.a, bid, wt, L);
+  else if (FULL) mstep_apply_switch<false, true>(bt.gv, tv, d, c, bt.a, bid, wt, L);
+  else if (s.oneseg) mstep_apply_switch<true, false>(bt.gv, tv, d, c, bt.a, bid, wt, L);
+  else mstep_apply_switch<false, false>(bt.gv, tv, d, c, bt.a, bid, wt, L);
   wt.end(bid < bt.nblk_items ? 7u : 8u);
 }
 
@@ -528,8 +540,12 @@ __global__ __launch_bounds__(64 * kSlowWaves) void mstep_slow_kernel(MBwdArgs A)
   if (!bt.apply) return;
   const MStepStatic& s = deref_const(A.st + t);
   const TableView& tv = deref_const(A.views + t);
-  slowpath_par_role<4, kOpOptimize, kSlowWaves, false>(tv, s.rv[A.cur & 1u].uids, s.grad_u, bt.a,
-                                                       s.pending, L);
+  if (bt.gv & 1u)
+    slowpath_par_role<1, kOpOptimize, kSlowWaves, false>(tv, s.rv[A.cur & 1u].uids, s.grad_u, bt.a,
+                                                         s.pending, L);
+  else
+    slowpath_par_role<4, kOpOptimize, kSlowWaves, false>(tv, s.rv[A.cur & 1u].uids, s.grad_u, bt.a,
+                                                         s.pending, L);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -546,19 +562,19 @@ struct SegLookupArgs {
   uint32_t seg0;                      // first segment of this launch (its table = (seg0 + y) % T)
   uint32_t id_off[kMaxSegs + 1];
   uint32_t emb_off[kMaxSegs + 1];
-  uint8_t g[kMaxStepTables * 4];      // per table: lanes per id
+  uint8_t g[kMaxStepTables * 4];      // per table: lane-group shape (MHTE_SWITCH_GV)
   uint8_t count_hits[kMaxStepTables * 4];
 };
 static_assert(sizeof(SegLookupArgs) <= 4096, "kernel arguments exceed 4 KB");
 
-template <int G>
+template <int G, int VEC = 4>
 __device__ __forceinline__ void seg_lookup_loop(const TableView& tv, const int64_t* ids, int64_t n,
                                                 float* out, int count_hits) {
   const int64_t ngroups = (n + 1) / 2;
 #pragma unroll 1
   for (int64_t g = (int64_t(blockIdx.x) * 512 + threadIdx.x) / G; g < ngroups;
        g += int64_t(gridDim.x) * 512 / G)
-    lookup_role_u<G, 4, 2, 1>(tv, ids, n, nullptr, out, count_hits, g);
+    lookup_role_u<G, VEC, 2, 1>(tv, ids, n, nullptr, out, count_hits, g);
 }
 
 __global__ __launch_bounds__(512) void seg_lookup_kernel(SegLookupArgs A) {
@@ -570,12 +586,9 @@ __global__ __launch_bounds__(512) void seg_lookup_kernel(SegLookupArgs A) {
   const int64_t* ids = A.ids + A.id_off[y];
   float* out = A.out + size_t(A.emb_off[y]);
   const int ch = A.count_hits[t];
-  switch (A.g[t]) {
-    case 8: MHTE_OTHER_G(seg_lookup_loop<8>(tv, ids, n, out, ch)); break;
-    case 16: seg_lookup_loop<16>(tv, ids, n, out, ch); break;
-    case 32: MHTE_OTHER_G(seg_lookup_loop<32>(tv, ids, n, out, ch)); break;
-    default: MHTE_OTHER_G(seg_lookup_loop<64>(tv, ids, n, out, ch)); break;
-  }
+#define MHTE_SEGL_CALL(G_, V_) seg_lookup_loop<G_, V_>(tv, ids, n, out, ch)
+  MHTE_SWITCH_GV(A.g[t], MHTE_SEGL_CALL)
+#undef MHTE_SEGL_CALL
 }
 
 // FusedOptimize on ids that are distinct within every segment (they come out of
@@ -599,7 +612,7 @@ struct SegUpsertArgs {
 };
 static_assert(sizeof(SegUpsertArgs) <= 4096, "kernel arguments exceed 4 KB");
 
-template <int G>
+template <int G, int VEC = 4>
 __device__ __forceinline__ void seg_upsert_loop(const TableView& tv, const int64_t* ids, uint32_t n,
                                                 const float* values, const ApplyArgs& a,
                                                 uint32_t* pending, uint32_t id_base, uint32_t seg) {
@@ -630,8 +643,8 @@ __device__ __forceinline__ void seg_upsert_loop(const TableView& tv, const int64
       pending[2 * slot + 1] = seg;
     }
     if (valid && !sr.deferred)
-      apply_row<G, 4, kOpOptimize, false, false>(tv, row_ptr(tv, sr.r), sr.is_new, j, values, nullptr,
-                                                 0u, 1u, int64_t(g), a);
+      apply_row<G, VEC, kOpOptimize, false, false>(tv, row_ptr(tv, sr.r), sr.is_new, j, values, nullptr,
+                                                   0u, 1u, int64_t(g), a);
   }
 }
 
@@ -644,12 +657,9 @@ __global__ __launch_bounds__(256) void seg_upsert_kernel(SegUpsertArgs A) {
   const int64_t* ids = A.ids + A.id_off[y];
   const float* values = A.grads + size_t(A.grad_off[y]);
   uint32_t* pend = A.pending[t];
-  switch (A.g[t]) {
-    case 8: MHTE_OTHER_G(seg_upsert_loop<8>(tv, ids, n, values, A.a[t], pend, A.id_off[y], y)); break;
-    case 16: seg_upsert_loop<16>(tv, ids, n, values, A.a[t], pend, A.id_off[y], y); break;
-    case 32: MHTE_OTHER_G(seg_upsert_loop<32>(tv, ids, n, values, A.a[t], pend, A.id_off[y], y)); break;
-    default: MHTE_OTHER_G(seg_upsert_loop<64>(tv, ids, n, values, A.a[t], pend, A.id_off[y], y)); break;
-  }
+#define MHTE_SEGU_CALL(G_, V_) seg_upsert_loop<G_, V_>(tv, ids, n, values, A.a[t], pend, A.id_off[y], y)
+  MHTE_SWITCH_GV(A.g[t], MHTE_SEGU_CALL)
+#undef MHTE_SEGU_CALL
 }
 
 // displacement pass of a fused optimize: one wavefront per table
@@ -684,8 +694,12 @@ __global__ __launch_bounds__(64) void seg_slow_kernel(SegUpsertArgs A) {
     r = __shfl(r, 0);
     if (pos >= 0) {
       const float* values = A.grads + size_t(A.grad_off[seg]);
-      apply_row<64, 4, kOpOptimize, false, false>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
-                                                  1u, int64_t(gp - A.id_off[seg]), a);
+      if (A.g[t] & 1u)
+        apply_row<64, 1, kOpOptimize, false, false>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
+                                                    1u, int64_t(gp - A.id_off[seg]), a);
+      else
+        apply_row<64, 4, kOpOptimize, false, false>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
+                                                    1u, int64_t(gp - A.id_off[seg]), a);
     }
     __syncthreads();
   }

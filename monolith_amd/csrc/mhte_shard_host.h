@@ -201,8 +201,9 @@ struct ShardStep {
     if (T > uint32_t(kMaxStepTables))
       throw Error(MHTE_INVALID_ARGUMENT, "shard step: at most " + std::to_string(kMaxStepTables) + " tables");
     if (!seg_kernels_ok(m))
-      throw Error(MHTE_INVALID_ARGUMENT, "shard step: every table needs rows of whole float4s and "
-                                         "per-element optimizers");
+      throw Error(MHTE_INVALID_ARGUMENT, "shard step: every table needs per-element optimizers "
+                                         "(GroupAdaGrad takes the whole segment) and rows of whole "
+                                         "float4s up to 256 floats or of any layout up to 64");
     ms.init(m, mb);
     // default: a (peer, table) block can hold the whole batch, so no step can overflow one (the
     // reference's all-to-all is variable-sized and never drops an id).  A smaller capacity is the
@@ -615,8 +616,11 @@ struct ShardStep {
       g.io_off = uint32_t(off);
       off += int64_t(n) * tab[t].dim;
       g.nblk_items = g.nblk_ids = 0;
+      // (rows in the wire blocks sit at row_off + slot * dim: on 16-byte boundaries exactly when the
+      // row is whole float4s, which vec_ok says; the flat buffer's slice may still be off)
+      g.gv = shape_code(*ms.mt->tables[t], uint64_t(g.io_off));
       if (!n) continue;
-      const uint32_t groups_per_wg = 256u / ms.h_st[t].g;
+      const uint32_t groups_per_wg = 256u / shape_lanes(g.gv);
       g.nblk_items = std::min<uint32_t>(DedupWs::max_items(n),
                                         std::min<uint32_t>(uint32_t(ms.num_cus) * 10 / 8,
                                                            std::max<uint32_t>(8, share / 4)));
@@ -691,7 +695,7 @@ struct ShardStep {
     A.flags = d_flags;
     fill_tabs(A.tab);
     for (uint32_t t = 0; t < T; ++t) {
-      A.g[t] = uint8_t(group_lanes(mt->tables[t]->dim));
+      A.g[t] = uint8_t(shape_code(*mt->tables[t]));
       A.count_hits[t] = mt->tables[t]->count_hits ? 1 : 0;
     }
   }
@@ -702,7 +706,7 @@ struct ShardStep {
     owner_args(A, slot, false);
     uint32_t gx = 1;
     for (uint32_t t = 0; t < T; ++t)
-      gx = std::max(gx, uint32_t((uint64_t((cap + 1) / 2) * A.g[t] + 511) / 512));
+      gx = std::max(gx, uint32_t((uint64_t((cap + 1) / 2) * shape_lanes(A.g[t]) + 511) / 512));
     // (grid-stride inside: enough workgroups to fill the chip a few times over, not one per slot)
     const uint32_t fill = std::max<uint32_t>(8, uint32_t(ms.num_cus) * 16 / (uint32_t(world) * T));
     gx = std::min(gx, fill);
@@ -733,7 +737,7 @@ struct ShardStep {
       a.sum_dups = 0;
       a.filter_mode = tb.flt_slots ? 1 : 0;   // an owner asks its filter about every id it does not hold
       a.global_step = global_step;
-      gx = std::max(gx, (cap + 256u / A.g[t] - 1) / (256u / A.g[t]));
+      gx = std::max(gx, (cap + 256u / shape_lanes(A.g[t]) - 1) / (256u / shape_lanes(A.g[t])));
     }
     const uint32_t fill = std::max<uint32_t>(8, uint32_t(ms.num_cus) * 16 / T);
     gx = std::min(gx, fill);

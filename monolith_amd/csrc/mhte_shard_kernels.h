@@ -55,7 +55,7 @@ struct ShardOwnerArgs {
   int64_t* clear_ids;
   uint32_t* pending[kMaxStepTables];
   ShardTab tab[kMaxStepTables];
-  uint8_t g[kMaxStepTables];
+  uint8_t g[kMaxStepTables];          // lane-group shape per table (MHTE_SWITCH_GV)
   uint8_t count_hits[kMaxStepTables];
   ApplyArgs a[kMaxStepTables];
 };
@@ -81,12 +81,9 @@ __global__ __launch_bounds__(512) void shard_lookup_kernel(ShardOwnerArgs A) {
   const int64_t* ids = A.recv_ids + size_t(p) * A.geo.ids_block + tb.id_off;
   float* out = A.rows + size_t(p) * A.geo.rows_block + tb.row_off;
   const int ch = A.count_hits[t];
-  switch (A.g[t]) {
-    case 8: MHTE_OTHER_G(seg_lookup_loop<8>(tv, ids, n, out, ch)); break;
-    case 16: seg_lookup_loop<16>(tv, ids, n, out, ch); break;
-    case 32: MHTE_OTHER_G(seg_lookup_loop<32>(tv, ids, n, out, ch)); break;
-    default: MHTE_OTHER_G(seg_lookup_loop<64>(tv, ids, n, out, ch)); break;
-  }
+#define MHTE_SEGL_CALL(G_, V_) seg_lookup_loop<G_, V_>(tv, ids, n, out, ch)
+  MHTE_SWITCH_GV(A.g[t], MHTE_SEGL_CALL)
+#undef MHTE_SEGL_CALL
 }
 
 // displacement pass of one peer's block for table t, by one wavefront (lane 0 alone touches q, path
@@ -120,9 +117,14 @@ __device__ __forceinline__ void shard_slow_role(const ShardOwnerArgs& A, uint32_
       }
     }
     r = __shfl(r, 0);
-    if (pos >= 0)
-      apply_row<64, 4, kOpOptimize, false, false>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
-                                                  1u, int64_t(g), a);
+    if (pos >= 0) {
+      if (A.g[t] & 1u)
+        apply_row<64, 1, kOpOptimize, false, false>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
+                                                    1u, int64_t(g), a);
+      else
+        apply_row<64, 4, kOpOptimize, false, false>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
+                                                    1u, int64_t(g), a);
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
   if (lane == 0) tv.ctr->n_pending = 0;
@@ -142,12 +144,10 @@ __global__ __launch_bounds__(256) void shard_upsert_kernel(ShardOwnerArgs A) {
   const int64_t* ids = A.recv_ids + size_t(p) * A.geo.ids_block + tb.id_off;
   const float* values = A.rows + size_t(p) * A.geo.rows_block + tb.row_off;
   uint32_t* pend = A.pending[t];
-  switch (A.g[t]) {   // pending entry = (position in the block's table segment, unused)
-    case 8: MHTE_OTHER_G(seg_upsert_loop<8>(tv, ids, n, values, A.a[t], pend, 0u, 0u)); break;
-    case 16: seg_upsert_loop<16>(tv, ids, n, values, A.a[t], pend, 0u, 0u); break;
-    case 32: MHTE_OTHER_G(seg_upsert_loop<32>(tv, ids, n, values, A.a[t], pend, 0u, 0u)); break;
-    default: MHTE_OTHER_G(seg_upsert_loop<64>(tv, ids, n, values, A.a[t], pend, 0u, 0u)); break;
-  }
+  // (pending entry = (position in the block's table segment, unused))
+#define MHTE_SEGU_CALL(G_, V_) seg_upsert_loop<G_, V_>(tv, ids, n, values, A.a[t], pend, 0u, 0u)
+  MHTE_SWITCH_GV(A.g[t], MHTE_SEGU_CALL)
+#undef MHTE_SEGU_CALL
 }
 
 // displacement pass of one peer's block, one wavefront per table; the last one of a step also
@@ -168,6 +168,7 @@ struct ShardGatherTab {
   uint32_t nblk_ids;
   uint32_t io_off;      // floats: SCATTER the table's embeddings in `flat`, SUM its gradients
   uint32_t n;           // occurrences of the batch (0: nothing to do)
+  uint32_t gv;          // lane-group shape of the table in this launch (MHTE_SWITCH_GV)
 };
 struct ShardGatherArgs {
   ConstStatics st;
@@ -195,18 +196,18 @@ __device__ __forceinline__ void shard_gather_ctl(GatherCtl& c, const MStepStatic
 }
 
 template <bool SCATTER>
-__device__ __forceinline__ void shard_gather_switch(uint32_t g, const RunView& d, const GatherCtl& c,
+__device__ __forceinline__ void shard_gather_switch(uint32_t gv, const RunView& d, const GatherCtl& c,
                                                     uint32_t bid, char* raw) {
-  switch (g) {
-    case 8: MHTE_OTHER_G(rd_gather_role<8, 4, SCATTER>(d, c, bid, *reinterpret_cast<GatherLds<8, 4>*>(raw))); break;
-    case 16: rd_gather_role<16, 4, SCATTER>(d, c, bid, *reinterpret_cast<GatherLds<16, 4>*>(raw)); break;
-    case 32: MHTE_OTHER_G(rd_gather_role<32, 4, SCATTER>(d, c, bid, *reinterpret_cast<GatherLds<32, 4>*>(raw))); break;
-    default: MHTE_OTHER_G(rd_gather_role<64, 4, SCATTER>(d, c, bid, *reinterpret_cast<GatherLds<64, 4>*>(raw))); break;
-  }
+#define MHTE_GATHER_CALL(G_, V_) \
+  rd_gather_role<G_, V_, SCATTER>(d, c, bid, *reinterpret_cast<GatherLds<G_, V_>*>(raw))
+  MHTE_SWITCH_GV(gv, MHTE_GATHER_CALL)
+#undef MHTE_GATHER_CALL
 }
 static_assert(sizeof(GatherLds<8, 4>) >= sizeof(GatherLds<16, 4>) &&
                   sizeof(GatherLds<8, 4>) >= sizeof(GatherLds<32, 4>) &&
-                  sizeof(GatherLds<8, 4>) >= sizeof(GatherLds<64, 4>),
+                  sizeof(GatherLds<8, 4>) >= sizeof(GatherLds<64, 4>) &&
+                  sizeof(GatherLds<8, 4>) >= sizeof(GatherLds<8, 1>) &&
+                  sizeof(GatherLds<8, 4>) >= sizeof(GatherLds<64, 1>),
               "LDS of the gather role");
 
 // rows back -> every occurrence of the batch in `slot`
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void shard_scatter_kernel(ShardGatherArgs A) {
   c.in = A.in;
   c.out = A.out + size_t(gt.io_off);
   shard_gather_ctl(c, s, cur, A.slot_off, A.n_max, t, A.tab[t].dim, gt);
-  shard_gather_switch<true>(s.g, d, c, blockIdx.x, raw);
+  shard_gather_switch<true>(gt.gv, d, c, blockIdx.x, raw);
 }
 
 // backward launch of the sender side, per table:
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void shard_build_kernel(ShardBuildArgs A) {
   c.in = A.grads + size_t(gt.io_off);
   c.out = A.rows_out;
   shard_gather_ctl(c, s, cur, A.slot_off, A.n_max, t, A.tab[t].dim, gt);
-  shard_gather_switch<false>(s.g, d, c, bid, raw);
+  shard_gather_switch<false>(gt.gv, d, c, bid, raw);
 }
 
 // ---- peer-store transport: one process per GPU, every rank maps every other rank's WINDOW ----------
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) void shard_push_kernel(ShardPushArgs A) {
       ipc_copy16(dst + size_t(tb.row_off) * 2, src + size_t(tb.row_off) * 2, (n * tb.dim * 2u + 15u) / 16u, first,
                  stride);
     else
-      ipc_copy16(dst + size_t(tb.row_off) * 4, src + size_t(tb.row_off) * 4, n * (tb.dim / 4u), first, stride);
+      ipc_copy16(dst + size_t(tb.row_off) * 4, src + size_t(tb.row_off) * 4, (n * tb.dim + 3u) / 4u, first, stride);
   }
 }
 
@@ -424,7 +425,8 @@ __global__ __launch_bounds__(256) void shard_cvt_kernel(ShardCvtArgs A) {
   const uint64_t c = uint64_t(A.counts[size_t(p) * A.geo.ids_block + t]);
   const uint32_t n = c > tb.cap ? tb.cap : uint32_t(c);
   const size_t base = size_t(p) * A.geo.rows_block + tb.row_off;   // element offset
-  const uint32_t total = n * tb.dim / 4u;                          // 4 elements per thread and trip
+  const uint32_t total = (n * tb.dim + 3u) / 4u;                   // 4 elements per thread and trip (a table's
+                                                                   // region is whole float4s: cap is a multiple of 4)
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     if (NARROW) {
       const float4 v = reinterpret_cast<const float4*>(static_cast<const float*>(A.src) + base)[i];

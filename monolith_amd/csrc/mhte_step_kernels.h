@@ -76,10 +76,14 @@ __device__ __forceinline__ uint32_t run_cnt(uint32_t v) { return v & 0x7ffu; }
 __device__ __forceinline__ uint32_t run_off(uint32_t v) { return (v >> 11) & 0x3ffu; }
 __device__ __forceinline__ uint32_t run_first(uint32_t v) { return v >> 21; }
 
-struct ItemHdr {   // one heavy work item: workgroups [b0, b0 + nbk) of list u
+struct __attribute__((aligned(16))) ItemHdr {   // one heavy work item: workgroups [b0, b0 + nbk) of list u
   int64_t id;
   uint32_t u;      // unique index
   uint32_t meta;   // b0 | nbk << 8 | k << 16 | nitems << 24   (nbk 1..64, k < nitems <= 64)
+  // what the build role's table probe found for the id (ProbeOut; kNoRow / kNoRow / 0 without it)
+  uint32_t row;
+  uint32_t spec;
+  unsigned long long loc;
 };
 
 // One slot of the global scratch hash: key, count and a position share 16 bytes, so a run's CAS,
@@ -108,7 +112,8 @@ struct RunView {
   uint16_t* seg;                // [nblk * 1024] local positions grouped by run, ascending in a run
   ItemHdr* item_hdr;            // heavy work items
   uint32_t* item_runs;          // [items][64] run_pack of workgroup b0 + t (0: no run)
-  uint32_t* ctr;                // [0] unique counter, [1] build waves done, [2] number of items
+  uint32_t* ctr;                // [0] unique counter, [1] build waves done, [2] number of items,
+                                // [3] rows the build role's probe reserved for the batch (ProbeOut)
   const int64_t* ids;
   uint32_t n;
   uint32_t nblk;                // ceil(n / 1024) <= 64; 0 = nothing to do
@@ -156,7 +161,7 @@ __device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, Rd
   }
   if (t < kMaxLongRuns * 32) (&L.bm[0][0])[t] = 0;
   if (t == 0) L.nlong = 0;
-  if (bid == 0 && t < 3) d.ctr[t] = 0;  // counters of the build role, which runs after this launch
+  if (bid == 0 && t < 4) d.ctr[t] = 0;  // counters of the build role, which runs after this launch
   const uint32_t p = bid * kRdBlock + t;
   const bool valid = p < d.n;
   const int64_t id = valid ? d.ids[p] : 0;   // round trip 1
@@ -391,12 +396,82 @@ struct PackCtl {
   uint32_t cap, id_off, row_off, dim;
 };
 
-template <bool PACK = false>
+// Work items of ONE heavy id (a whole wavefront; lane b looks the id up in dedup workgroup b's run
+// directory): a power-of-two range of workgroups per item, the item's run descriptors next to it.
+// hrow / hspec / hloc: what a table probe of the id found (ProbeOut; kNoRow / kNoRow / 0 without).
+__device__ __forceinline__ void rd_emit_items(const RunView& d, int64_t id, uint32_t hu, uint32_t c,
+                                              uint32_t hrow, uint32_t hspec, unsigned long long hloc,
+                                              int lane) {
+  const uint32_t val = (uint32_t(lane) < d.nblk) ? rd_find_run_opt(d, uint32_t(lane), id) : 0u;
+  const unsigned long long bm = __ballot(val != 0u);
+  const uint32_t nbk = rd_item_blocks(c, d.item_target);
+  const uint32_t b0 = uint32_t(lane) & ~(nbk - 1u);
+  const unsigned long long rmask = (nbk == 64 ? ~0ull : ((1ull << nbk) - 1ull)) << b0;
+  const bool leader = (uint32_t(lane) == b0) && (bm & rmask) != 0ull;
+  const unsigned long long lm = __ballot(leader);
+  const uint32_t nitems = __popcll(lm);
+  uint32_t w0 = 0;
+  if (lane == 0) w0 = atomicAdd(&d.ctr[2], nitems);
+  w0 = __shfl(w0, 0);
+  // item index of this lane's range = rank of its leader among the leaders
+  const uint32_t k = __popcll(lm & ((1ull << b0) - 1ull));
+  if (leader) {
+    ItemHdr hd;
+    hd.id = id;
+    hd.u = hu;
+    hd.meta = b0 | (nbk << 8) | (k << 16) | (nitems << 24);
+    hd.row = hrow;
+    hd.spec = hspec;
+    hd.loc = hloc;
+    d.item_hdr[w0 + k] = hd;
+  }
+  if ((bm & rmask) != 0ull) d.item_runs[size_t(w0 + k) * 64 + (uint32_t(lane) - b0)] = val;
+}
+
+// Optional third output of the numbering (PROBE; the single-table training step): the table is
+// probed for every distinct id while its dense index is being assigned — a launch (and with the
+// pipelined step: a whole update) before the batch's own update needs the answer.
+//   found    -> urow = row handle, uloc = bucket * 4 + slot.  The update reaches the row without
+//               reading a bucket line; it VERIFIES the hint (the key at uloc must still be the id:
+//               displacement, doubling, eviction, clear / restore may have moved or removed the entry
+//               since) and probes as before when it does not hold.  Row handles are never recycled, so
+//               a hint that verifies is exact.
+//   missing  -> spec = a row handle reserved for the id now, ONE bump of the table's allocation
+//               counter per workgroup trip here instead of one per wavefront inside the update —
+//               that single address takes every allocation of a launch and same-address atomics are
+//               served one after the other (~18 ns each): on the update's critical path they were
+//               its longest wait.  An id that turns out to exist by then (the update running beside
+//               this probe inserted it) gives the key back (upsert_complete: lostm); the handle
+//               is stranded (kSpecSlackRows).
+// The probe may run BESIDE an update of the same table (step_bwd: apply of batch s | build of
+// batch s + 1).  A claim publishes the key first and the row handle after it, and an empty slot
+// carries kNoRow (cuckoopath_move, evict, split): a key seen beside kNoRow is an insert in flight —
+// treated as "not found, nothing reserved", the update's own probe will find it.
+constexpr unsigned long long kNoLoc = ~0ull;
+struct __attribute__((aligned(16))) URec {   // everything the update needs about unique index u: ONE 32-byte load
+  int64_t id;
+  uint32_t cnt;              // occurrences in the batch
+  uint32_t pos;              // a position (the only one when cnt == 1)
+  uint32_t slot;             // scratch slot: where the id's position list lives
+  uint32_t row;              // loc != kNoLoc: the id's row handle; else a row reserved for it (kNoRow: none)
+  unsigned long long loc;    // bucket * 4 + slot of a found id, or kNoLoc
+};
+struct ProbeOut {
+  URec* urec;                // [n_max]
+  uint32_t reserve;          // 0: hints only — a table with an admission filter may not insert a
+                             // missing id at all, its update allocates for itself
+};
+
+template <bool PACK = false, bool PROBE = false>
 __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_max, uint32_t bid,
-                                              uint32_t nblocks, const PackCtl* pc = nullptr) {
+                                              uint32_t nblocks, const PackCtl* pc = nullptr,
+                                              const TableView* tv = nullptr, ProbeOut po = ProbeOut{}) {
   constexpr int Q = kBuildSlotsPerLane;
   __shared__ uint32_t sh_tot[4];
   __shared__ uint32_t sh_base;
+  __shared__ uint32_t sh_mtot[PROBE ? 4 : 1];
+  __shared__ uint32_t sh_mbase;
+  __shared__ uint8_t sh_stage[PROBE ? 4 * 256 : 4];   // per wavefront: (q, lane) of the trip's r-th id
   __shared__ uint32_t sh_pc[PACK ? kMaxShards : 1], sh_pb[PACK ? kMaxShards : 1];
   const uint32_t t = threadIdx.x;
   const int lane = t & 63;
@@ -461,6 +536,8 @@ __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_m
     lds_barrier();
     uint32_t k0 = sh_base;
     for (uint32_t w2 = 0; w2 < (t >> 6); ++w2) k0 += sh_tot[w2];
+    const uint32_t kw0 = k0;   // dense index of this wavefront's first id of the trip
+    const uint32_t wg_max = max(max(sh_tot[0], sh_tot[1]), max(sh_tot[2], sh_tot[3]));
     lds_barrier();  // (sh_tot / sh_base are rewritten by the next trip)
     uint32_t kq[Q];
 #pragma unroll
@@ -484,37 +561,113 @@ __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_m
         }
       }
     }
+    if (!PROBE) {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      unsigned long long hm = occ[q] & __ballot(cnt[q] > light_max);
-      while (hm) {
-        const int src = __ffsll(static_cast<long long>(hm)) - 1;
-        hm &= hm - 1ull;
-        const uint32_t hu = __shfl(kq[q], src);
-        const uint32_t c = __shfl(cnt[q], src);
-        const int64_t id = __shfl(key[q], src);
-        // lane b looks the id up in dedup workgroup b's run directory (0: no run there)
-        const uint32_t val = (uint32_t(lane) < d.nblk) ? rd_find_run_opt(d, uint32_t(lane), id) : 0u;
-        const unsigned long long bm = __ballot(val != 0u);
-        const uint32_t nbk = rd_item_blocks(c, d.item_target);
-        const uint32_t b0 = uint32_t(lane) & ~(nbk - 1u);
-        const unsigned long long rmask = (nbk == 64 ? ~0ull : ((1ull << nbk) - 1ull)) << b0;
-        const bool leader = (uint32_t(lane) == b0) && (bm & rmask) != 0ull;
-        const unsigned long long lm = __ballot(leader);
-        const uint32_t nitems = __popcll(lm);
-        uint32_t w0 = 0;
-        if (lane == 0) w0 = atomicAdd(&d.ctr[2], nitems);
-        w0 = __shfl(w0, 0);
-        // item index of this lane's range = rank of its leader among the leaders
-        const uint32_t k = __popcll(lm & ((1ull << b0) - 1ull));
-        if (leader) {
-          ItemHdr hd;
-          hd.id = id;
-          hd.u = hu;
-          hd.meta = b0 | (nbk << 8) | (k << 16) | (nitems << 24);
-          d.item_hdr[w0 + k] = hd;
+      for (int q = 0; q < Q; ++q) {
+        unsigned long long hm = occ[q] & __ballot(cnt[q] > light_max);
+        while (hm) {
+          const int src = __ffsll(static_cast<long long>(hm)) - 1;
+          hm &= hm - 1ull;
+          rd_emit_items(d, __shfl(key[q], src), __shfl(kq[q], src), __shfl(cnt[q], src), kNoRow, kNoRow, 0ull,
+                        lane);
         }
-        if ((bm & rmask) != 0ull) d.item_runs[size_t(w0 + k) * 64 + (uint32_t(lane) - b0)] = val;
+      }
+    } else {
+      // ---- the trip's ids, one per lane in dense-index order (a wavefront's 256 slots hold ~25 ids at
+      // the scratch's load: one round), probed in the table; then the work items of the heavy ones
+      typedef long long i64x2 __attribute__((ext_vector_type(2)));
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      uint8_t* const stg = sh_stage + (t >> 6) * 256u;
+      uint32_t run = 0;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        if ((occ[q] >> lane) & 1ull) stg[run + uint32_t(__popcll(occ[q] & ((1ull << lane) - 1ull)))] = uint8_t(q * 64 + lane);
+        run += uint32_t(__popcll(occ[q]));
+      }
+      lds_wave_sync();
+#pragma unroll 1
+      for (uint32_t r0 = 0; r0 < wg_max; r0 += 64) {   // (workgroup-uniform bound: barriers inside)
+        const uint32_t r = r0 + uint32_t(lane);
+        const bool have = r < run;
+        const uint32_t src = have ? uint32_t(stg[r]) : 0u;
+        const int sl = int(src & 63u);
+        int64_t kid = 0;
+        uint32_t kc = 0, kp = 0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const int64_t kk = __shfl(key[q], sl);
+          const uint32_t cc = __shfl(cnt[q], sl), pp = __shfl(pos[q], sl);
+          if (int(src >> 6) == q) {
+            kid = kk;
+            kc = cc;
+            kp = pp;
+          }
+        }
+        const bool act = have && kid != kEmptyKey;   // (the side slot's key: the update's own path)
+        const int64_t pid = act ? kid : 0;           // (lanes without an id probe id 0's lines)
+        const uint64_t hv = hash_key(pid);
+        const uint64_t i1 = index_hash(tv->hp, hv);
+        const uint64_t i2 = alt_index(tv->hp, partial_key(hv), i1);
+        const GBucket* b1 = global_bucket(tv->buckets + i1);
+        const GBucket* b2 = global_bucket(tv->buckets + i2);
+        const i64x2 k0a = *(const MHTE_GLOBAL i64x2*)(&b1->key[0]);
+        const i64x2 k0b = *(const MHTE_GLOBAL i64x2*)(&b1->key[2]);
+        const i64x2 k1a = *(const MHTE_GLOBAL i64x2*)(&b2->key[0]);
+        const i64x2 k1b = *(const MHTE_GLOBAL i64x2*)(&b2->key[2]);
+        const u32x4 r0v = *(const MHTE_GLOBAL u32x4*)(&b1->row[0]);
+        const u32x4 r1v = *(const MHTE_GLOBAL u32x4*)(&b2->row[0]);
+        int fs = -1;
+        uint32_t fr = kNoRow;
+        if (k1b.y == pid) { fs = 7; fr = r1v.w; }
+        if (k1b.x == pid) { fs = 6; fr = r1v.z; }
+        if (k1a.y == pid) { fs = 5; fr = r1v.y; }
+        if (k1a.x == pid) { fs = 4; fr = r1v.x; }
+        if (k0b.y == pid) { fs = 3; fr = r0v.w; }
+        if (k0b.x == pid) { fs = 2; fr = r0v.z; }
+        if (k0a.y == pid) { fs = 1; fr = r0v.y; }
+        if (k0a.x == pid) { fs = 0; fr = r0v.x; }
+        const bool found = act && fs >= 0 && fr != kNoRow;   // (a key beside kNoRow: an insert in flight)
+        const bool miss = act && fs < 0;
+        uint32_t spec = kNoRow;
+        if (po.reserve) {   // rows for the ids the table lacks: one bump per workgroup and round
+          const unsigned long long mm = __ballot(miss);
+          if (lane == 0) sh_mtot[t >> 6] = uint32_t(__popcll(mm));
+          lds_barrier();
+          if (t == 0) {
+            const unsigned long long all = sh_mtot[0] + sh_mtot[1] + sh_mtot[2] + sh_mtot[3];
+            sh_mbase = all ? uint32_t(atomicAdd(&tv->ctr->alloc, (all << 32) | all)) : 0u;
+            if (all) {   // (the keys are counted now, inserted by the batch's update: Counters::reserved)
+              atomicAdd(&tv->ctr->reserved, uint32_t(all));
+              atomicAdd(&d.ctr[3], uint32_t(all));
+            }
+          }
+          lds_barrier();
+          uint32_t m0 = sh_mbase;
+          for (uint32_t w2 = 0; w2 < (t >> 6); ++w2) m0 += sh_mtot[w2];
+          lds_barrier();  // (sh_mtot / sh_mbase are rewritten by the next round)
+          if (miss) spec = m0 + uint32_t(__popcll(mm & ((1ull << lane) - 1ull)));
+        }
+        const unsigned long long floc = found ? (((fs & 4) ? i2 : i1) << 2) | uint64_t(fs & 3) : kNoLoc;
+        const uint32_t frow = found ? fr : spec;
+        if (have) {
+          URec rec;
+          rec.id = kid;
+          rec.cnt = kc;
+          rec.pos = kp;
+          rec.slot = base + (src >> 6) * 64u + (src & 63u);
+          rec.row = frow;
+          rec.loc = floc;
+          po.urec[kw0 + r] = rec;
+        }
+        unsigned long long hm = __ballot(have && kc > light_max);
+        while (hm) {
+          const int s2 = __ffsll(static_cast<long long>(hm)) - 1;
+          hm &= hm - 1ull;
+          const unsigned long long hl = __shfl(floc, s2);
+          rd_emit_items(d, __shfl(kid, s2), kw0 + r0 + uint32_t(s2), __shfl(kc, s2),
+                        hl != kNoLoc ? __shfl(frow, s2) : kNoRow, hl != kNoLoc ? kNoRow : __shfl(frow, s2),
+                        hl != kNoLoc ? hl : 0ull, lane);
+        }
       }
     }
   }
@@ -527,6 +680,100 @@ __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_m
 
 __global__ __launch_bounds__(256) void rd_build_kernel(RunView d, uint32_t light_max) {
   rd_build_role(d, light_max, blockIdx.x, gridDim.x);
+}
+// ... with the table probe (ProbeOut): the first batch of a pipeline, the unpipelined step
+__global__ __launch_bounds__(256) void rd_build_probe_kernel(RunView d, uint32_t light_max, TableView tv,
+                                                             ProbeOut po) {
+  rd_build_role<false, true>(d, light_max, blockIdx.x, gridDim.x, nullptr, &tv, po);
+}
+// the table probe on its own, for a batch that was numbered without it (mhte_step_dedup): one lane
+// per distinct id over the dense arrays
+// (light_max: ids with longer lists are applied by the item workgroups from their work-item headers,
+// which were written without a probe — no row is reserved for those here, they allocate their own)
+__global__ __launch_bounds__(256) void rd_probe_kernel(RunView d, TableView tv, ProbeOut po, uint32_t n_max,
+                                                       uint32_t light_max) {
+  typedef long long i64x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ uint32_t sh_mtot[4];
+  __shared__ uint32_t sh_mbase;
+  const uint32_t t = threadIdx.x;
+  const int lane = t & 63;
+  const uint32_t nu = min(n_max, d.ctr[0]);
+#pragma unroll 1
+  for (uint32_t u0 = blockIdx.x * 256u; u0 < nu; u0 += gridDim.x * 256u) {   // (workgroup-uniform)
+    const uint32_t u = u0 + t;
+    const bool have = u < nu;
+    const uint32_t us = have ? u : 0u;
+    const int64_t kid = d.uids[us];
+    const bool act = have && kid != kEmptyKey;
+    const int64_t pid = act ? kid : 0;
+    const uint64_t hv = hash_key(pid);
+    const uint64_t i1 = index_hash(tv.hp, hv);
+    const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
+    const GBucket* b1 = global_bucket(tv.buckets + i1);
+    const GBucket* b2 = global_bucket(tv.buckets + i2);
+    const i64x2 k0a = *(const MHTE_GLOBAL i64x2*)(&b1->key[0]);
+    const i64x2 k0b = *(const MHTE_GLOBAL i64x2*)(&b1->key[2]);
+    const i64x2 k1a = *(const MHTE_GLOBAL i64x2*)(&b2->key[0]);
+    const i64x2 k1b = *(const MHTE_GLOBAL i64x2*)(&b2->key[2]);
+    const u32x4 r0v = *(const MHTE_GLOBAL u32x4*)(&b1->row[0]);
+    const u32x4 r1v = *(const MHTE_GLOBAL u32x4*)(&b2->row[0]);
+    URec rec;
+    rec.id = kid;
+    rec.cnt = d.ucnt[us];
+    rec.pos = d.upos[us];
+    rec.slot = d.uslot[us];
+    int fs = -1;
+    uint32_t fr = kNoRow;
+    if (k1b.y == pid) { fs = 7; fr = r1v.w; }
+    if (k1b.x == pid) { fs = 6; fr = r1v.z; }
+    if (k1a.y == pid) { fs = 5; fr = r1v.y; }
+    if (k1a.x == pid) { fs = 4; fr = r1v.x; }
+    if (k0b.y == pid) { fs = 3; fr = r0v.w; }
+    if (k0b.x == pid) { fs = 2; fr = r0v.z; }
+    if (k0a.y == pid) { fs = 1; fr = r0v.y; }
+    if (k0a.x == pid) { fs = 0; fr = r0v.x; }
+    const bool found = act && fs >= 0 && fr != kNoRow;
+    const bool miss = act && fs < 0 && rec.cnt <= light_max;
+    uint32_t spec = kNoRow;
+    if (po.reserve) {
+      const unsigned long long mm = __ballot(miss);
+      if (lane == 0) sh_mtot[t >> 6] = uint32_t(__popcll(mm));
+      __syncthreads();
+      if (t == 0) {
+        const unsigned long long all = sh_mtot[0] + sh_mtot[1] + sh_mtot[2] + sh_mtot[3];
+        sh_mbase = all ? uint32_t(atomicAdd(&tv.ctr->alloc, (all << 32) | all)) : 0u;
+        if (all) {
+          atomicAdd(&tv.ctr->reserved, uint32_t(all));
+          atomicAdd(&d.ctr[3], uint32_t(all));
+        }
+      }
+      __syncthreads();
+      uint32_t m0 = sh_mbase;
+      for (uint32_t w2 = 0; w2 < (t >> 6); ++w2) m0 += sh_mtot[w2];
+      __syncthreads();
+      if (miss) spec = m0 + uint32_t(__popcll(mm & ((1ull << lane) - 1ull)));
+    }
+    rec.row = found ? fr : spec;
+    rec.loc = found ? (((fs & 4) ? i2 : i1) << 2) | uint64_t(fs & 3) : kNoLoc;
+    if (have) po.urec[u] = rec;
+  }
+}
+// keys of reservations that will never be used (a numbered batch that is dropped instead of applied)
+// go back to the table's live-key count; the row handles stay stranded (rows are not recycled)
+__global__ __launch_bounds__(256) void rd_unreserve_kernel(const URec* __restrict__ urec,
+                                                           const uint32_t* __restrict__ n_unique,
+                                                           uint32_t n_max, Counters* ctr) {
+  const uint32_t n = min(n_max, *n_unique);
+  uint32_t mine = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    mine += (urec[i].loc == kNoLoc && urec[i].row != kNoRow) ? 1u : 0u;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o);
+  if ((threadIdx.x & 63) == 0 && mine) {
+    atomicAdd(&ctr->alloc, ~((static_cast<unsigned long long>(mine) << 32) - 1ull));
+    atomicSub(&ctr->reserved, mine);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -542,13 +789,17 @@ struct ApplyCtl {
   uint32_t light_max;     // 0xffffffff: every list strictly sequential (MHTE_EXACT_ORDER)
   uint32_t nblk_items;    // workgroups [0, nblk_items) take work items, the rest ids
   uint32_t nblk_ids;
-  const uint32_t* spec_row;  // [n] row handle reserved for unique index u by the forward launch
-                             // (rd_prealloc_role; kNoRow: the id was in the table), or nullptr
+  const uint32_t* spec_row;  // [n] row handle reserved for unique index u (ProbeOut.spec of the build
+                             // role's probe; rd_prealloc_role; kNoRow: none), or nullptr
   // (multi-table step, HINT) what the forward launch's lookup found for unique index u: row handle
   // (kNoRow: absent) and bucket * 4 + slot; nullptr: probe as usual
   const uint32_t* urow;
   const unsigned long long* uloc;
-  const uint32_t* uts;          // timestamp the forward launch saw in the id's slot
+  const uint32_t* uts;          // timestamp the forward launch saw in the id's slot (or nullptr)
+  const URec* urec;             // (single-table step) the build role's packed record per unique index:
+                                // replaces the dense arrays, urow / uloc and spec_row in ONE load
+  uint32_t trusted;             // 1: nothing has touched the table since urow / uloc were written
+                                // (multi-table step, Table::mut_epoch): the hints need no check
 };
 
 // row of a found id, fetched while the gradient chain is in flight
@@ -844,8 +1095,6 @@ __device__ __forceinline__ SlotResult upsert_complete(const TableView& tv, GBuck
 // instantiation.  Sized for G = 8 (32 groups per workgroup).
 struct ApplyLds {
   uint32_t pos[(256 / 8) * kStepLightMax];  // [group][kStepLightMax] positions of a short list
-  uint32_t need[4];                         // rows each wavefront needs this trip
-  uint32_t rowbase;
   uint32_t rstart[65];                      // first flat entry of run t of the item
   uint32_t rval[64];
   float sum[256 * 4];                       // [group][G * VEC]
@@ -854,6 +1103,7 @@ struct ApplyLds {
 
 // FULL: the table uses per-element optimizers beyond SGD / Adagrad / FTRL (optimize_row_reg_full; no
 // row prefetch: the state layout is the optimizer's); the host picks the instantiation.
+// (HINT: kept for the call sites' sake — every launch takes hints when ApplyCtl carries them)
 template <int G, int VEC, bool ONESEG, bool HINT = false, bool FULL = false>
 __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView& d,
                                               const ApplyCtl& c, const ApplyArgs& a, uint32_t bid,
@@ -869,70 +1119,104 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
   const bool ev = e < dim;
 
   if (bid >= c.nblk_items) {
-    const int j0 = j, gbase0 = gbase;
     // ------------------------------------------------------------------ id-major groups
     // Group `grp` of workgroup k takes the unique indices u = it * stride + grp * nblk_ids + k:
     // consecutive indices (the claim order puts the hot ids first) land in different workgroups.
-    // A group lives inside one wavefront, so its LDS hand-offs need no workgroup barrier.
-    uint32_t* const sh_need = L.need;
-    uint32_t& sh_rowbase = L.rowbase;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // A group lives inside one wavefront and nothing in a trip is shared between wavefronts (row
+    // handles of new ids were reserved by the build role's probe, ProbeOut; the few that were not
+    // take one bump per wavefront): no workgroup barrier in the loop, the four wavefronts run free.
     // (32-bit index arithmetic: n_max is a batch size; the 64-bit form kept a hoisted per-lane offset
     // in a register pair that was spilled at the loop entry and reloaded — with a wait for every
     // load in flight — in front of each trip's first loads)
     const uint32_t stride = c.nblk_ids * uint32_t(NG);
     const uint32_t k = bid - c.nblk_items;
+    const uint32_t wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar)
     uint32_t nu = c.n_max;  // refined below, once the count has arrived with the first trip's loads
 #pragma unroll 1
     for (uint32_t it = 0; uint64_t(it) * stride < nu; ++it) {
-#ifndef MHTE_NO_ANTIHOIST
-      // (a group makes one or two trips: addresses of the form base + e hoisted out of the loop are
-      // not worth the registers — the compiler spilled them, 52 B per lane stored at every loop
-      // entry = 9 MB of scratch writes per launch.  An element offset it cannot see through keeps
-      // them inside the trip.)
-      int j = j0, gbase = gbase0;
-      asm volatile("" : "+v"(j), "+v"(gbase));
+      // (a group makes one or two trips: anything per lane that lives across the loop — the lane's
+      // index in its group, the group's index, element offsets, addresses of the form base + e — is
+      // not worth its registers: the compiler spilled them, and a spill reload waits for EVERY load
+      // the wavefront has in flight.  All of it is derived inside the trip from the lane id, which is
+      // recomputed from an operand the compiler cannot see through.)
+      uint32_t zero_ = 0;
+      asm volatile("" : "+v"(zero_));
+      const int lane = int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero_)));
+      const int j = lane & (G - 1);
+      const int gbase = lane & ~(G - 1);
       const uint32_t e = uint32_t(j) * VEC;
-#endif
-#ifndef MHTE_NO_ANTIHOIST
-      // (the same for the unique index and the group's LDS slice: without this, loop strength
-      // reduction keeps one 64-bit pointer per dense array alive across the loop)
-      uint32_t grp_ = uint32_t(grp);
-      asm volatile("" : "+v"(grp_));
+      const bool ev = e < dim;
+      const uint32_t grp_ = (uint32_t(wave_s) * 64u + uint32_t(lane)) / uint32_t(G);
       uint32_t* const sh_pos = L.pos + grp_ * kStepLightMax;  // this group's slice
-      uint32_t g = it * stride + grp_ * c.nblk_ids + k;
-      asm volatile("" : "+v"(g));
-#else
-      uint32_t* const sh_pos = L.pos + grp * kStepLightMax;  // this group's slice
-      const uint32_t g = it * stride + uint32_t(grp) * c.nblk_ids + k;
-#endif
+      const uint32_t g = it * stride + grp_ * c.nblk_ids + k;
       // round trip 1: everything about unique index g (the build role's dense arrays; an index past
       // the count reads stale entries of the preallocated arrays and is dropped)
       const bool inb = g < c.n_max;
       const uint32_t n_unique = d.ctr[0];  // (issued with the rest of the trip: not behind its wait)
-      const uint32_t reserved = (c.spec_row && inb) ? c.spec_row[g] : kNoRow;
-      const int64_t id = inb ? d.uids[g] : 0;
-      uint32_t cnt = inb ? d.ucnt[g] : 0u;
-      const uint32_t hp = inb ? d.upos[g] : 0u;
-      const uint32_t gs = inb ? d.uslot[g] : 0u;
-      // (HINT) the forward launch already resolved the id: its row handle and bucket slot arrive
-      // with the rest of the trip, no bucket line is read for an id that was resident
-      uint32_t hrow = kNoRow;
+      // the id was resolved a launch ago (single table: the build role's probe, URec — one
+      // unconditional 32-byte load from a safe index, masked afterwards: a load under a branch is
+      // waited for where the branch ends; multi-table step: the forward launch's lookup): its row
+      // handle and bucket slot arrive with the rest of the trip
+      int64_t id;
+      uint32_t cnt, hp, gs, reserved = kNoRow, hrow = kNoRow, huts = 0;
       unsigned long long hloc = 0;
-      uint32_t huts = 0;
-      if (HINT && c.urow) {
-        hrow = inb ? c.urow[g] : kNoRow;
-        hloc = inb ? c.uloc[g] : 0ull;
-        huts = inb ? c.uts[g] : 0u;
+      if (!HINT) {
+        const URec rec = c.urec[inb ? g : 0u];
+        id = rec.id;
+        cnt = inb ? rec.cnt : 0u;
+        hp = rec.pos;
+        gs = rec.slot;
+        const bool fnd = rec.loc != kNoLoc;
+        hrow = fnd ? rec.row : kNoRow;
+        hloc = fnd ? rec.loc : 0ull;
+        reserved = fnd ? kNoRow : rec.row;
+      } else {
+        reserved = (c.spec_row && inb) ? c.spec_row[g] : kNoRow;
+        id = inb ? d.uids[g] : 0;
+        cnt = inb ? d.ucnt[g] : 0u;
+        hp = inb ? d.upos[g] : 0u;
+        gs = inb ? d.uslot[g] : 0u;
+        if (c.urow) {
+          hrow = inb ? c.urow[g] : kNoRow;
+          hloc = inb ? c.uloc[g] : 0ull;
+          if (c.uts) huts = inb ? c.uts[g] : 0u;
+        }
+      }
+      // (every reservation of the batch is consumed by this launch — inserted, or its key given back:
+      // one thread takes them off the table's count of outstanding ones)
+      if (!HINT && it == 0 && k == 0 && threadIdx.x == 0) {
+        const uint32_t nres = d.ctr[3];
+        if (nres) atomicSub(&tv.ctr->reserved, nres);
       }
       nu = min(uint32_t(c.n_max), n_unique);
       bool valid = g < nu;
       if (!valid) cnt = 0;
-      const bool hinted = HINT && valid && hrow != kNoRow;
-      // round trip 2: table probe | gradient of a lone occurrence | run tables of a short list
-      Probe<G> pr = probe_issue<G>(tv, id, valid && !hinted, j);
-      if (it == 0) wt.mark(0);
       if (cnt > c.light_max) valid = false;  // heavy list: the item workgroups own it
+      bool hinted = valid && hrow != kNoRow;
+      // round trip 2: hinted id: the key in its slot (the hint's check) | its row;  other ids: the
+      // table probe;  both: gradient of a lone occurrence | position list of a short list
+      const bool ts_known = c.uts != nullptr && huts == a.ts;   // (multi-table step: the slot already
+                                                                // carries this second — no store, no check)
+      Probe<G> pr = probe_issue<G>(tv, id, valid && !hinted, j);
+      // (a group without a hint — or an index past the count, whose record is stale — checks bucket
+      // 0's first key: every lane loads, unconditionally, from an address that exists)
+      const unsigned long long sloc = hinted ? hloc : 0ull;
+      GBucket* const hb = global_bucket(tv.buckets + (sloc >> 2));
+      const int64_t vraw = HINT ? id : hb->key[sloc & 3ull];
+      RowRegs<VEC> rr;
+      vec_zero(rr.w);
+      vec_zero(rr.s1);
+      // the row of a hinted id.  Rows of the first slab — all of them in a table created with
+      // reserve_rows — are addressed without reading the slab table: row_ptr's load of the slab
+      // pointer sits under a branch, and the wait where that branch ends would hold the row loads
+      // back behind everything issued above (a whole round trip).  Later slabs: the slow way.
+      const bool slab0 = (hrow >> tv.chunk_shift) == 0u;
+      if (hinted && slab0 && !FULL)
+        row_prefetch<VEC, ONESEG>(tv, assume_global(tv.chunk0 + size_t(hrow) * tv.row_floats), e, rr);
+      if (__any(hinted && !slab0)) {
+        if (hinted && !slab0 && !FULL) row_prefetch<VEC, ONESEG>(tv, row_ptr(tv, hrow), e, rr);
+      }
+      if (it == 0) wt.mark(0);
       const bool single = valid && cnt == 1;
       const bool big = valid && cnt > uint32_t(kStepLightMax);  // (exact order only)
       const bool flat = valid && !single && !big;
@@ -950,6 +1234,21 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         x[q] = (flat && idx < cnt) ? d.hlist[size_t(gs) * kLightMax + idx] : 0xffffffffu;
       }
       if (it == 0) wt.mark(1);
+      // the hint holds when the slot still carries the id; otherwise (rare: the entry was moved by a
+      // displacement pass or a doubling, or evicted, since the probe) the group probes now
+      {
+        const bool hok = HINT || c.trusted || vraw == id;   // (every lane of the group read the same word)
+        if (__any(hinted && !hok)) {
+          const bool redo = hinted && !hok;
+          const Probe<G> p2 = probe_issue<G>(tv, id, redo, j);
+          if (redo) {
+            pr = p2;
+            hinted = false;
+            vec_zero(rr.w);
+            vec_zero(rr.s1);
+          }
+        }
+      }
       // admission filter (one consultation with the occurrence count: BatchOptimize with dedup,
       // tf_bridge.cc:300-310): an id that is not in the table yet and has not been seen often
       // enough is dropped — no insert, no update
@@ -960,24 +1259,14 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         uint32_t first = 0;
         if (valid && j == 0) first = filter_consult(tv, id, cnt, 2, contained);
         if (__shfl(first, gbase) != 0u) valid = false;
+        hinted = hinted && valid;
       }
-      // round trip 3: slot claim + row handle of a new id | the row of a found one | (below) the
-      // gradients of a list — all in flight together
+      // round trip 3 (ids without a hint): slot claim + row handle of a new id | the row of a found
+      // one | (below) the gradients of a list — all in flight together
       const UpsertFlight<G> uf = upsert_issue<G>(tv, pr.b, id, valid && !hinted, pr.k, lane, reserved);
-      // (HINT: the multi-table launch.  Few ids are new — the forward launch found the rest — and
-      // every table has its own counter, so a wavefront that needs rows bumps the counter itself:
-      // no workgroup barrier in the trip, the four wavefronts run free)
-      if (!HINT) {
-        if (lane == 0) sh_need[wave] = uint32_t(__popcll(uf.specm));
-        lds_barrier();  // (the trip count is the same for the four wavefronts)
-      }
-      RowRegs<VEC> rr;
-      vec_zero(rr.w);
-      vec_zero(rr.s1);
-      const bool pre = valid && (uf.found || hinted);
+      const bool pre = valid && !hinted && uf.found;
       if (__any(pre)) {
-        uint32_t frow = __shfl(pr.row, gbase + (uf.owner < 0 ? 0 : uf.owner));
-        if (hinted) frow = hrow;
+        const uint32_t frow = __shfl(pr.row, gbase + (uf.owner < 0 ? 0 : uf.owner));
         if (pre && !FULL) row_prefetch<VEC, ONESEG>(tv, row_ptr(tv, frow), e, rr);
       }
       if (__any(flat)) {
@@ -997,20 +1286,15 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         for (int q = 0; q < PER; ++q)
           if (x[q] != 0xffffffffu) sh_pos[xr[q]] = x[q];
       }
-      // the workgroup's allocation, placed behind the row loads: the compiler waits for a result
-      // produced under a branch where the branch ends, and here that wait is shared with loads this
-      // wavefront needs next anyway
+      // rows for new ids that have no reservation (the first step of a pipeline, an id the probe saw
+      // mid-insert and that was evicted since, the multi-table step): one bump per wavefront, placed
+      // behind the row loads — the compiler waits for a result produced under a branch where the
+      // branch ends, and here that wait is shared with loads this wavefront needs next anyway
       unsigned long long rows0;  // (not initialised on purpose: see lbase in rd_dedup_role)
       bool bumped = false;
-      if (HINT) {
+      {
         const unsigned long long tot = __popcll(uf.specm);
         if (tot && lane == 0) {
-          rows0 = atomicAdd(&tv.ctr->alloc, (tot << 32) | tot);
-          bumped = true;
-        }
-      } else if (threadIdx.x == 0) {
-        const unsigned long long tot = sh_need[0] + sh_need[1] + sh_need[2] + sh_need[3];
-        if (tot) {
           rows0 = atomicAdd(&tv.ctr->alloc, (tot << 32) | tot);
           bumped = true;
         }
@@ -1055,31 +1339,25 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         }
       }
       uint32_t base_row;
-      if (HINT) {
+      {
         uint32_t br = bumped ? uint32_t(rows0) : 0u;  // (lane 0 of a wavefront that needed rows)
         base_row = __shfl(br, 0);
-      } else {
-        if (bumped) sh_rowbase = uint32_t(rows0);  // (only thread 0, only when rows were needed)
-        lds_barrier();
-        base_row = sh_rowbase;
-        for (int w2 = 0; w2 < wave; ++w2) base_row += sh_need[w2];
       }
       SlotResult sr =
           upsert_complete<G>(tv, pr.b, id, valid && !hinted, pr.row, lane, a.ts, uf, base_row, reserved);
-      if (hinted) {  // resident id: nothing to claim; the timestamp goes to the slot the lookup found
+      if (hinted) {  // resident id: nothing to claim; the timestamp goes to the slot the probe found
         sr.r = hrow;
         sr.is_new = false;
         sr.deferred = false;
         // (a 4-byte store into a line this launch otherwise never touches costs a 128-byte fetch and
         // a write-back: 21 of mstep_bwd's 200 us at 26 x 65 536 ids.  update_time has the
         // resolution of a second; an id updated again within the second already carries it.)
-        if (valid && j == 0 && huts != a.ts)
-          global_bucket(tv.buckets + (hloc >> 2))->ts[hloc & 3ull] = vgpr_copy_of_uniform(a.ts);
+        if (valid && j == 0 && !ts_known) hb->ts[hloc & 3ull] = vgpr_copy_of_uniform(a.ts);
       }
       float* rp = nullptr;
       if (valid && !sr.deferred) {
         rp = row_ptr(tv, sr.r);
-        if (!FULL && !sr.is_new && !pre) row_prefetch<VEC, ONESEG>(tv, rp, e, rr);  // (the side slot's row)
+        if (!FULL && !sr.is_new && !pre && !hinted) row_prefetch<VEC, ONESEG>(tv, rp, e, rr);  // (the side slot's row)
       }
       if (it == 0) wt.mark(3);
       if (sr.deferred) {
@@ -1090,8 +1368,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         else optimize_row_pre<VEC, ONESEG>(tv, rp, sr.is_new, e, acc, a, rr);
       }
       if (it == 0) wt.mark(4);
-      if (HINT) lds_wave_sync();  // (sh_pos is the group's own)
-      else lds_barrier();         // sh_pos / sh_need are reused
+      lds_wave_sync();  // (sh_pos is the group's own)
     }
     return;
   }
@@ -1118,8 +1395,14 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
     const uint32_t b0 = hd.meta & 0xffu, nbk = (hd.meta >> 8) & 0xffu, kk = (hd.meta >> 16) & 0xffu,
                    nitems = hd.meta >> 24;
     // round trip 2: the table probe of the id (used by whoever applies: wave 0, group 0) | positions
-    Probe<G> pr = probe_issue<G>(tv, hd.id, threadIdx.x < G, j);
-    const uint32_t reserved = (c.spec_row && threadIdx.x < G) ? c.spec_row[hd.u] : kNoRow;
+    // (the build role's probe left the id's row handle and slot in the header: no bucket read for a
+    // resident id, only the hint's check — the key in its slot, fetched beside the positions)
+    const bool ihint = hd.row != kNoRow;   // block-uniform
+    GBucket* const hb = global_bucket(tv.buckets + (hd.loc >> 2));
+    int64_t vkey = hd.id;
+    if (ihint && !c.trusted && threadIdx.x == 0) vkey = hb->key[hd.loc & 3ull];
+    Probe<G> pr = probe_issue<G>(tv, hd.id, threadIdx.x < G && !ihint, j);
+    const uint32_t reserved = threadIdx.x < G ? hd.spec : kNoRow;
     if (threadIdx.x < 64) {
       const uint32_t val = (uint32_t(lane) < nbk) ? rval : 0u;
       uint32_t incl = run_cnt(val);
@@ -1252,15 +1535,25 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
     }
     if (apply && threadIdx.x < 64) {
       bool valid = threadIdx.x < G;
+      bool hok = ihint && __shfl(vkey == hd.id ? 1 : 0, 0) != 0;
+      if (ihint && !hok) pr = probe_issue<G>(tv, hd.id, valid, j);   // (rare: the entry moved or left)
       if (tv.flt_slots) {  // (as in the id-major groups; the list's length is its count)
         bool contained = group_mask_of<G>(__ballot(valid && hd.id != kEmptyKey && j < 8 && pr.k == hd.id), gbase) != 0;
         if (valid && hd.id == kEmptyKey) contained = tv.ctr->special_state == 1;
+        if (hok) contained = true;
         uint32_t first = 0;
         if (valid && j == 0) first = filter_consult(tv, hd.id, d.ucnt[hd.u], 2, contained);
         if (__shfl(first, gbase) != 0u) valid = false;
       }
-      const SlotResult sr =
-          upsert_resolve<G>(tv, (Bucket*)pr.b, hd.id, valid, pr.k, pr.row, lane, a.ts, reserved);
+      SlotResult sr;
+      if (hok) {
+        sr.r = hd.row;
+        sr.is_new = false;
+        sr.deferred = false;
+        if (valid && threadIdx.x == 0) hb->ts[hd.loc & 3ull] = vgpr_copy_of_uniform(a.ts);
+      } else {
+        sr = upsert_resolve<G>(tv, (Bucket*)pr.b, hd.id, valid, pr.k, pr.row, lane, a.ts, reserved);
+      }
       if (sr.deferred) {
         uint32_t ed = e;   // (rare path: its address arithmetic stays here, see opaque_f)
 #ifndef MHTE_NO_ANTIHOIST
@@ -1439,10 +1732,11 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
 template <int G, int VEC, bool ONESEG, bool FULL = false>
 __global__ __launch_bounds__(256, kBwdBlocksPerCu) void step_bwd_kernel(RunView nxt, uint32_t nblk_build,
                                                        TableView tv, RunView cur, ApplyCtl c,
-                                                       ApplyArgs a) {
+                                                       ApplyArgs a, ProbeOut po) {
   WaveTrace wt(tv.trace);
   if (blockIdx.x < nblk_build) {
-    rd_build_role(nxt, uint32_t(kStepLightMax), blockIdx.x, nblk_build);
+    // numbering of the next batch + its table probe (hints and row reservations for ITS update)
+    rd_build_role<false, true>(nxt, uint32_t(kStepLightMax), blockIdx.x, nblk_build, nullptr, &tv, po);
     wt.end(6u);
     return;
   }

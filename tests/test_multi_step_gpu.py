@@ -179,6 +179,41 @@ def seeded_grads(s_, sp, n):
   return rng.standard_normal((n, sp.dim), dtype=np.float32) * np.float32(0.01)
 
 
+# ============================================================== the reference's standard row layout
+def bias_slice_specs():
+  """NT/feature.py:117-120 (FeatureSlot(has_bias=True): a dim-1 FTRL bias slice in front of the
+  vector) as NT/distributed_ps_test.py:480-505 builds it: FTRL(1) + Adagrad(16) and FTRL(1) +
+  Adagrad(32) rows — dims 17 / 33, not whole float4s — beside a plain dim-64 table whose slice of the
+  flat buffers then does NOT start on a 16-byte boundary, and a dim-16 one that does."""
+  return [Spec("a_bias16", [(1, "ftrl", 0.05), (16, "adagrad", 0.01)], 1),
+          Spec("b_plain64", [(64, "adagrad", 0.01)], 2),
+          Spec("c_bias32", [(1, "ftrl", 0.05), (32, "adagrad", 0.01)], 3),
+          Spec("d_plain16", [(16, "adagrad", 0.01)], 4)]
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_multi_step_bias_slice_rows(exact):
+  """Rows with a dim-1 bias segment run through mhte_multi_step_* (round 3 rejected them): one float
+  per lane for those tables (and for a float4 table whose slice is pushed off its 16-byte boundary by
+  an odd-dim neighbour), float4 lanes for the rest, in the SAME launches; bit-exact vs the oracle."""
+  specs = bias_slice_specs()
+  B, steps = 4099, 4     # (odd batch: b_plain64's slice starts at 4099 * 17 floats)
+  batches = zipf_batches(specs, steps, B, 3000)
+  mt, ots, step = run_pipeline(specs, batches, seeded_grads, exact)
+  check_final(mt, ots, specs, batches, exact)
+  step.close()
+
+
+def test_multi_step_more_than_32_tables():
+  """kMaxStepTables = 32 is a per-launch budget (kernel arguments), not a model limit: 40 tables run
+  as two chunks per stage."""
+  specs = [Spec("t%02d" % i, [((16, 32)[i % 2], "adagrad", 0.01)], i + 1) for i in range(40)]
+  batches = zipf_batches(specs, 3, 1024, 500)
+  mt, ots, step = run_pipeline(specs, batches, seeded_grads, True)
+  check_final(mt, ots, specs, batches, True)
+  step.close()
+
+
 # =============================================================================== configs[4] shape
 @pytest.mark.parametrize("exact", [True, False])
 def test_multi_step_26_tables_matches_oracle(exact):
@@ -402,10 +437,15 @@ def test_multi_step_errors():
   step.forward(r)
   with pytest.raises(_lib.InvalidArgumentError):   # gradient too short
     step.backward(val_t(np.zeros(16)), 0)
-  wide = MultiHashTable.from_configs(
+  odd = MultiHashTable.from_configs(
       {"w": entry.make_table_config([entry.CombineAsSegment(
           6, entry.ZerosInitializer(), entry.SgdOptimizer(0.1))])}, name_suffix=_name())
-  with pytest.raises(_lib.InvalidArgumentError):   # rows not made of float4s
+  MultiSparseStep(odd, 10).close()    # rows not made of float4s: one float per lane (up to 64 floats)
+  wide = MultiHashTable.from_configs(
+      {"w": entry.make_table_config([entry.CombineAsSegment(1, entry.ZerosInitializer(), entry.FtrlOptimizer(0.1)),
+                                     entry.CombineAsSegment(68, entry.ZerosInitializer(), entry.SgdOptimizer(0.1))])},
+      name_suffix=_name())
+  with pytest.raises(_lib.InvalidArgumentError):   # ... a row of 69 floats that is not whole float4s does not fit
     MultiSparseStep(wide, 10)
 
 

@@ -68,6 +68,13 @@ def test_processes_against_oracle(dist_kind, world, tmp_path):
     assert sum(r["sizes"][name] for r in res) > 0
 
 
+def test_processes_bias_slice_rows(tmp_path):
+  """FTRL(1) + Adagrad(16 / 32) rows (NT/distributed_ps_test.py:480-505) between PROCESSES over the
+  peer-store transport: row slots of 17 / 33 floats on the wire, one float per lane on both sides."""
+  res = run_world(2, "zipf", 5, tmp_path, {"MHTE_TEST_SPECS": "bias"})
+  assert all(r["transport"].startswith("ipc") for r in res)
+
+
 def test_processes_with_overlap(tmp_path):
   """MHTE_SHARD_OVERLAP=1: the next batch's dedup, numbering, packing and id exchange on the step's own
   stream (pushes and their publication from two streams of every process) — same results."""
