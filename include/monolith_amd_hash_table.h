@@ -42,7 +42,7 @@ enum {
 
 const char* mhte_last_error(void);
 /* ABI version of this header; mhte_abi_version() must return the same value. */
-#define MHTE_ABI_VERSION 12
+#define MHTE_ABI_VERSION 13
 int32_t mhte_abi_version(void);
 
 /* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
@@ -701,6 +701,10 @@ mhte_status mhte_shard_step_unique_counts(mhte_shard_step* s, int64_t* counts, v
  * [3] = transport: 0 identity, 1 RCCL, 2 in-process group, 3 peer stores into fine-grained windows,
  * 4 peer stores into plain device memory (MHTE_SHARD_WINDOW=coarse) */
 mhte_status mhte_shard_step_info(mhte_shard_step* s, int64_t info[4]);
+/* out[0] = ncclCommCount, out[1] = ncclCommUserRank of the step's own RCCL communicator (0, 0 when the
+ * step has none: identity, peer stores, in-process group) — a launcher checks out[0] == world on
+ * every rank before it trusts a multi-GPU number */
+mhte_status mhte_shard_step_comm_ranks(mhte_shard_step* s, int32_t out[2]);
 /* all `n` ranks of a world living in this process (created with unique_id NULL, world n): the same
  * step, with arrays of per-rank arguments */
 mhte_status mhte_shard_group_forward(mhte_shard_step** steps, int32_t n, const int64_t* const* id,

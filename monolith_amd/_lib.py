@@ -26,7 +26,7 @@ MHTE_SUM_DUPLICATES = 2
 MHTE_EXACT_ORDER = 1       # flags of mhte_table_sum_optimize_n
 MHTE_DEFER_SLOWPATH = 2
 MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS = 1
-ABI_VERSION = 12           # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
+ABI_VERSION = 13           # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 OPT_MOMENTUM, OPT_ADADELTA, OPT_RMSPROP, OPT_RMSPROPV2, OPT_ADAM, OPT_AMSGRAD = 3, 4, 5, 6, 7, 8
@@ -86,9 +86,30 @@ def library_path():
   return _SO
 
 
+def _source_hash():
+  """sha256 over the library's sources (names and contents)."""
+  import hashlib
+  h = hashlib.sha256()
+  for d in sorted(_DEPS):
+    if os.path.exists(d):
+      h.update(os.path.basename(d).encode())
+      with open(d, "rb") as f:
+        h.update(f.read())
+  return h.hexdigest()
+
+
+_HASH_FILE = _SO + ".srchash"
+
+
 def _stale():
+  """The library is stale when it was built from other sources: by CONTENT (a sidecar keeps the hash
+  of the sources of the last build) — time stamps do not survive a checkout or the copy to a GPU box.
+  A library without a sidecar (built by hand) falls back to time stamps."""
   if not os.path.exists(_SO):
     return True
+  if os.path.exists(_HASH_FILE):
+    with open(_HASH_FILE) as f:
+      return f.read().strip() != _source_hash()
   t = os.path.getmtime(_SO)
   return any(os.path.exists(d) and os.path.getmtime(d) > t for d in _DEPS)
 
@@ -101,7 +122,11 @@ def build_library(force=False, verbose=False):
          "-fPIC", "-o", _SO, _SRC]
   if verbose:
     print(" ".join(cmd))
+  if os.path.exists(_HASH_FILE):
+    os.remove(_HASH_FILE)
   subprocess.check_call(cmd)
+  with open(_HASH_FILE, "w") as f:
+    f.write(_source_hash() + "\n")
   return _SO
 
 
@@ -128,7 +153,7 @@ EXPORTS = [
     "mhte_shard_unique_id", "mhte_shard_step_create", "mhte_shard_step_destroy",
     "mhte_shard_step_create_ipc", "mhte_shard_step_ipc_handle", "mhte_shard_step_ipc_connect",
     "mhte_shard_step_ipc_selftest", "mhte_shard_step_set_overlap", "mhte_shard_step_set_grad_bits", "mhte_shard_step_forward", "mhte_shard_step_backward", "mhte_shard_step_check",
-    "mhte_shard_step_info", "mhte_shard_step_unique_counts", "mhte_shard_group_forward", "mhte_shard_group_backward",
+    "mhte_shard_step_info", "mhte_shard_step_comm_ranks", "mhte_shard_step_unique_counts", "mhte_shard_group_forward", "mhte_shard_group_backward",
     "mhte_multi_table_create_from_proto", "mhte_multi_table_find", "mhte_multi_table_is_initialized",
     "mhte_hash_filter_create_from_proto", "mhte_lookup_entry", "mhte_feature_stat",
     "mhte_advance_clock_for_testing", "mhte_hash_filter_save", "mhte_hash_filter_restore",

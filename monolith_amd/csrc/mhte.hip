@@ -1815,15 +1815,26 @@ struct AuxWs {
     }
     return *p;
   }
-  // the scratch is reused by the next call in stream order; a call on ANOTHER stream first waits for
-  // the launches of the previous one
+  // the scratch is reused by the next call in stream order; a call on ANOTHER stream is ordered behind
+  // the launches of the previous one by an event the stream waits for — the host never does (these
+  // ops sit between the forward and the backward of every training step: a host wait here drains the
+  // caller's queue once per step)
   hipStream_t last = nullptr;
   bool used = false;
+  hipEvent_t done = nullptr;
   void enter(hipStream_t st) {
-    if (used && last != st) HIP_OK(hipStreamSynchronize(last));
+    if (!done) HIP_OK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    if (used && last != st) HIP_OK(hipStreamWaitEvent(st, done, 0));
     last = st;
     used = true;
   }
+  void leave(hipStream_t st) { HIP_OK(hipEventRecord(done, st)); }   // after the call's last launch
+  struct Use {   // enter now, leave when the caller's launches are enqueued
+    AuxWs& ws;
+    hipStream_t st;
+    Use(AuxWs& w, hipStream_t s) : ws(w), st(s) { ws.enter(st); }
+    ~Use() { (void)hipEventRecord(ws.done, st); }
+  };
   // distinct keys + their positions in ascending order -> uids / seg_off / seg_pos / nu
   void group(const int64_t* k, int64_t n, hipStream_t st) {
     uids.reserve(size_t(n) + 1);
@@ -1832,6 +1843,45 @@ struct AuxWs {
     seg_pos.reserve(size_t(n) + 1);
     nu.reserve(4);
     dd.unique(k, n, uids.p, inverse.p, seg_off.p, seg_pos.p, nu.p, st);
+  }
+};
+// Small host arrays a call uploads (task tables, pointer tables): staged through a ring of pinned
+// buffers, so the H2D copy is asynchronous and no call waits for its stream; a slot is reused after
+// its copy has completed (the host waits only when kSlots calls are still in flight).
+struct PinnedStage {
+  static constexpr int kSlots = 8;
+  std::mutex mu;
+  char* buf[kSlots] = {};
+  size_t cap[kSlots] = {};
+  hipEvent_t ev[kSlots] = {};
+  bool pending[kSlots] = {};
+  int next = 0;
+  static PinnedStage& of(int device) {
+    static std::mutex m;
+    static std::map<int, std::unique_ptr<PinnedStage>> all;
+    std::lock_guard<std::mutex> g(m);
+    auto& p = all[device];
+    if (!p) p.reset(new PinnedStage);
+    return *p;
+  }
+  void upload(void* dst_dev, const void* src, size_t n, hipStream_t st) {
+    if (!n) return;
+    std::lock_guard<std::mutex> g(mu);
+    const int i = next;
+    next = (next + 1) % kSlots;
+    if (!ev[i]) HIP_OK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    if (pending[i]) HIP_OK(hipEventSynchronize(ev[i]));
+    if (cap[i] < n) {
+      if (buf[i]) HIP_OK(hipHostFree(buf[i]));
+      buf[i] = nullptr;
+      const size_t want = std::max<size_t>(n, size_t(1) << 16);
+      HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&buf[i]), want, hipHostMallocDefault));
+      cap[i] = want;
+    }
+    memcpy(buf[i], src, n);
+    HIP_OK(hipMemcpyAsync(dst_dev, buf[i], n, hipMemcpyHostToDevice, st));
+    HIP_OK(hipEventRecord(ev[i], st));
+    pending[i] = true;
   }
 };
 static bool pool_atomics() {   // MHTE_POOL_ATOMICS=1: the float-atomic forms (A/B runs)
@@ -1871,7 +1921,7 @@ static void fused_gather(float* fused, int32_t n_inputs, const int32_t* const* o
       // the gradient without atomics: rows that share an offset are grouped and added in row order
       AuxWs& ws = AuxWs::of(current_device());
       std::lock_guard<std::mutex> g(ws.mu);
-      ws.enter(st);
+      AuxWs::Use use_(ws, st);
       ws.keys.reserve(size_t(acc));
       gather_keys_kernel<<<dim3(uint32_t((acc + 255) / 256)), 256, 0, st>>>(in, ws.keys.p);
       ws.group(ws.keys.p, acc, st);
@@ -1935,7 +1985,7 @@ mhte_status mhte_reduce_rows(const int64_t* indices, const float* values, int64_
       if (n) {
         AuxWs& ws = AuxWs::of(current_device());
         std::lock_guard<std::mutex> g(ws.mu);
-        ws.enter(st);
+        AuxWs::Use use_(ws, st);
         ws.group(indices, n, st);
         const dim3 grid(uint32_t((n * 16 + 255) / 256));
         if (dim % 4 == 0 && aligned16(values) && aligned16(out))
@@ -3432,8 +3482,7 @@ static void layout_launch(bool forward, const float* const* embeddings, const in
       HIP_OK(hipMalloc(&d, total));
     }
     blob.d = static_cast<char*>(d);
-    HIP_OK(hipMemcpyAsync(blob.d, h.data(), total, hipMemcpyHostToDevice, st));
-    HIP_OK(hipStreamSynchronize(st));   // (h is a pageable temporary)
+    PinnedStage::of(current_device()).upload(blob.d, h.data(), total, st);   // (no wait for the stream)
     A.x_emb = reinterpret_cast<const float* const*>(blob.d + o_emb);
     A.x_out = reinterpret_cast<float* const*>(blob.d + o_out);
     A.x_stride = reinterpret_cast<const uint32_t*>(blob.d + o_str);
@@ -3546,13 +3595,12 @@ static void layout_launch(bool forward, const float* const* embeddings, const in
     memcpy(h.data() + o_task, tasks.data(), tasks.size() * sizeof(LayoutTask));
     memcpy(h.data() + o_off, t_off.data(), t_off.size() * 4);
     if (!t_idx.empty()) memcpy(h.data() + o_idx, t_idx.data(), t_idx.size() * 4);
-    HIP_OK(hipMemcpyAsync(tmp.d, h.data(), o_qf, hipMemcpyHostToDevice, st));
+    PinnedStage::of(current_device()).upload(tmp.d, h.data(), o_qf, st);   // (no wait for the stream)
     HIP_OK(hipMemsetAsync(tmp.d + o_qf, 0xff, o_kflag - o_qf, st));   // qf = -1, fnfl = ~0
     HIP_OK(hipMemsetAsync(tmp.d + o_kflag, 0, o_heavy - o_kflag, st));   // kflag, n_heavy
-    HIP_OK(hipStreamSynchronize(st));   // (h is a pageable temporary)
     AuxWs& ws = AuxWs::of(current_device());
     std::lock_guard<std::mutex> g(ws.mu);
-    ws.enter(st);
+    AuxWs::Use use_(ws, st);
     ws.group(reinterpret_cast<const int64_t*>(fid_offset), n_fid, st);
     LayoutLists X{};
     X.tasks = reinterpret_cast<const LayoutTask*>(tmp.d + o_task);
@@ -4140,6 +4188,21 @@ mhte_status mhte_shard_step_info(mhte_shard_step* s, int64_t info[4]) {
     info[1] = int64_t(s->ss.x_block(kXIds));
     info[2] = int64_t(s->ss.x_block(kXRows));
     info[3] = s->ss.alias ? 0 : s->ss.ipc ? (s->ss.win_fine ? 3 : 4) : (s->ss.comm ? 1 : 2);
+  });
+}
+
+mhte_status mhte_shard_step_comm_ranks(mhte_shard_step* s, int32_t out[2]) {
+  return guard([&] {
+    if (!s || !out) throw Error(MHTE_INVALID_ARGUMENT, "null argument");
+    out[0] = out[1] = 0;
+    if (!s->ss.comm) return;   // (identity / peer stores / in-process group: no communicator)
+    Rccl& R = Rccl::get();
+    if (!R.CommCount || !R.CommUserRank) throw Error(MHTE_UNAVAILABLE, "this RCCL exports no ncclCommCount");
+    int n = 0, r = 0;
+    R.ok(R.CommCount(s->ss.comm, &n), "CommCount");
+    R.ok(R.CommUserRank(s->ss.comm, &r), "CommUserRank");
+    out[0] = n;
+    out[1] = r;
   });
 }
 

@@ -40,6 +40,8 @@ struct Rccl {
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;      // (optional: diagnostics)
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
 
   static Rccl& get() {
     static Rccl r;
@@ -63,6 +65,8 @@ struct Rccl {
       r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
       r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
       r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+      r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+      r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
     });
     if (!r.h || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.GroupStart || !r.GroupEnd ||
         !r.Send || !r.Recv)
@@ -117,8 +121,13 @@ struct ShardStep {
   // MHTE_SHARD_EXACT=1: the row / gradient exchanges move only the occupied part of every (peer,
   // table) segment.  The counts are the id blocks' headers, copied to pinned host memory right
   // after the id exchange — a step ahead of their first use when the batch was prepared ahead, so
-  // waiting for the copy costs nothing then.  Default off: the fixed-size form needs no host
-  // knowledge at all; which one wins on real links is a measurement for an N > 1 box.
+  // waiting for the copy costs nothing then.  In this mode the id blocks move exact-size as well
+  // (headers first, one host wait per id exchange).  Default off: the fixed-size form needs no host
+  // knowledge at all — at the price of whole blocks on the wire: with the default capacity (the
+  // whole batch per (peer, table): nothing can overflow) every rank keeps and moves
+  // O(world x T x batch) ids and rows per direction (26 tables x 65 536 ids x 8 ranks: ~110 MB of ids
+  // each way per step, GBs of row buffers) — give ids_per_peer_table or MHTE_SHARD_EXACT=1 at scale.
+  // Which form wins on real links is a measurement for an N > 1 box.
   bool exact = false;
   int64_t* h_cnt[2] = {nullptr, nullptr};   // per slot [2 (sent | received)][world][hdr]
   hipEvent_t ev_cnt[2] = {nullptr, nullptr};
@@ -821,6 +830,31 @@ struct ShardStep {
       R.ok(R.GroupEnd(), "GroupEnd");
       return;
     }
+    if (exact && kind == kXIds) {
+      // the id blocks exact-size too (whole-batch blocks are world x T x batch ids per rank: ~110 MB
+      // each way at 26 tables x 65 536 ids x 8 ranks): the headers cross first, their counts come to
+      // the host, then every (peer, table) segment moves at its occupied size
+      const size_t hb = size_t(hdr_words) * sizeof(int64_t);
+      R.ok(R.GroupStart(), "GroupStart");
+      for (int p = 0; p < world; ++p) {
+        R.ok(R.Send(src + size_t(p) * b, hb, ncclInt8, p, comm, st), "Send");
+        R.ok(R.Recv(dst + size_t(p) * b, hb, ncclInt8, p, comm, st), "Recv");
+      }
+      R.ok(R.GroupEnd(), "GroupEnd");
+      fetch_counts(slot, st);
+      HIP_OK(hipEventSynchronize(ev_cnt[slot]));
+      R.ok(R.GroupStart(), "GroupStart");
+      for (int p = 0; p < world; ++p)
+        for (uint32_t t = 0; t < T; ++t) {
+          const size_t off = size_t(p) * b + size_t(tab[t].id_off) * sizeof(int64_t);
+          const size_t ns = size_t(seg_rows(slot, true, p, t)) * sizeof(int64_t);
+          const size_t nr = size_t(seg_rows(slot, false, p, t)) * sizeof(int64_t);
+          if (ns) R.ok(R.Send(src + off, ns, ncclInt8, p, comm, st), "Send");
+          if (nr) R.ok(R.Recv(dst + off, nr, ncclInt8, p, comm, st), "Recv");
+        }
+      R.ok(R.GroupEnd(), "GroupEnd");
+      return;
+    }
     R.ok(R.GroupStart(), "GroupStart");
     for (int p = 0; p < world; ++p) {
       R.ok(R.Send(src + size_t(p) * b, b, ncclInt8, p, comm, st), "Send");
@@ -837,6 +871,32 @@ static void shard_exchange(ShardStep** S, int n, int kind, int slot, hipStream_t
     if (S[0]->alias) return;
     if (S[0]->ipc) S[0]->exchange_ipc(kind, slot, st);
     else S[0]->exchange_rccl(kind, slot, st);
+    return;
+  }
+  if (S[0]->exact && kind == kXIds) {
+    // (as exchange_rccl: headers, counts to the host, then the occupied part of every segment)
+    const size_t hb = size_t(S[0]->hdr_words) * sizeof(int64_t);
+    for (int r = 0; r < n; ++r)
+      for (int p = 0; p < n; ++p) {
+        const size_t b = S[r]->x_block(kind);
+        HIP_OK(hipMemcpyAsync(static_cast<char*>(S[p]->x_dst(kind, slot)) + size_t(r) * b,
+                              static_cast<const char*>(S[r]->x_src(kind, slot)) + size_t(p) * b, hb,
+                              hipMemcpyDeviceToDevice, st));
+      }
+    for (int r = 0; r < n; ++r) S[r]->fetch_counts(slot, st);
+    for (int r = 0; r < n; ++r) HIP_OK(hipEventSynchronize(S[r]->ev_cnt[slot]));
+    for (int r = 0; r < n; ++r)
+      for (int p = 0; p < n; ++p) {
+        const size_t b = S[r]->x_block(kind);
+        for (uint32_t t = 0; t < S[r]->T; ++t) {
+          const size_t off = size_t(S[r]->tab[t].id_off) * sizeof(int64_t);
+          const size_t nb = size_t(S[r]->seg_rows(slot, true, p, t)) * sizeof(int64_t);
+          if (nb)
+            HIP_OK(hipMemcpyAsync(static_cast<char*>(S[p]->x_dst(kind, slot)) + size_t(r) * b + off,
+                                  static_cast<const char*>(S[r]->x_src(kind, slot)) + size_t(p) * b + off, nb,
+                                  hipMemcpyDeviceToDevice, st));
+        }
+      }
     return;
   }
   const bool exact = S[0]->exact && kind != kXIds;

@@ -438,12 +438,14 @@ class ShardedMultiStep:
       transport = "rccl"
     self._group = group
     self._h = None
+    self.transport_note = None    # why the first choice of transport was not taken (auto)
     if transport == "ipc" or (transport == "auto" and self.world > 1):
       err = self._create_ipc(ids_per_peer_table)
       if err is None:
         return
       if transport == "ipc":
         raise err
+      self.transport_note = "peer stores unavailable (%s): RCCL send / recv" % (str(err)[:200],)
       transport = "rccl"
     use_rccl = transport == "rccl"
     uid = None
@@ -546,8 +548,19 @@ class ShardedMultiStep:
   def info(self):
     out = (C.c_int64 * 4)()
     self._libmod.check(self._lib.mhte_shard_step_info(self._h, out))
-    return {"ids_per_peer_table": out[0], "id_block_bytes": out[1], "row_block_bytes": out[2],
-            "transport": ("identity", "rccl", "group", "ipc", "ipc (coarse window)")[out[3]]}
+    d = {"ids_per_peer_table": out[0], "id_block_bytes": out[1], "row_block_bytes": out[2],
+         "transport": ("identity", "rccl", "group", "ipc", "ipc (coarse window)")[out[3]]}
+    if self.transport_note:
+      d["transport_note"] = self.transport_note
+    if out[3] == 1:
+      d["rccl_ranks"], d["rccl_rank"] = self.comm_ranks()
+    return d
+
+  def comm_ranks(self):
+    """(ncclCommCount, ncclCommUserRank) of the step's own RCCL communicator; (0, 0) without one."""
+    out = (C.c_int32 * 2)()
+    self._libmod.check(self._lib.mhte_shard_step_comm_ranks(self._h, out))
+    return int(out[0]), int(out[1])
 
   @staticmethod
   def _key(r):

@@ -7,10 +7,10 @@ per peer one id block whose header words carry the per-table counts (no size exc
 per direction for ALL tables, row slot s <-> id slot s, owners applying the senders' blocks in rank
 order (one optimizer application per sender).  `exchange(blocks[world, n]) -> [world, n]` is the
 transport (block p goes to peer p, row p of the result came from peer p): torch.distributed over
-gloo in tests/test_shard_protocol_gloo.py.
+gloo in tests/test_shard_protocol_oracle_gloo.py.
 
 What pins what: this restatement is checked against a single-process run of the reference semantics
-(tests/test_shard_protocol_gloo.py, world_size 2); the PRODUCT's C++ step is checked against the
+(tests/test_shard_protocol_oracle_gloo.py, world_size 2); the PRODUCT's C++ step is checked against the
 same single-process semantics by separate processes on the GPU (tests/test_shard_ipc_gpu.py) and by
 N ranks in one process (tests/test_shard_step_gpu.py); block_geometry() is compared with the
 product's shard_block_geometry and, on the GPU, with mhte_shard_step_info.

@@ -78,9 +78,12 @@ def main():
     universe = 200000 if dist_kind == "uniform" else 7000
     exact = dist_kind == "uniform"
     mt = make(specs)
-    step = ShardedMultiStep(mt, B, transport="ipc")
+    want = os.environ.get("MHTE_TEST_TRANSPORT", "ipc")    # "rccl": one DEVICE per rank (a multi-GPU node)
+    step = ShardedMultiStep(mt, B, transport=want)
     info = step.info()
-    assert info["transport"].startswith("ipc"), info
+    assert info["transport"].startswith(want), info
+    if want == "rccl":
+      assert step.comm_ranks() == (world, rank), (step.comm_ranks(), world, rank)
     assert info["ids_per_peer_table"] == B, info      # whole-batch blocks: nothing can overflow
     ots = {s.name: s.oracle_table() for s in specs}   # the oracle replays EVERY rank's stream
 

@@ -75,6 +75,33 @@ def test_processes_bias_slice_rows(tmp_path):
   assert all(r["transport"].startswith("ipc") for r in res)
 
 
+def _n_devices():
+  try:
+    import torch
+    return torch.cuda.device_count()
+  except Exception:  # pylint: disable=broad-except
+    return 0
+
+
+@pytest.mark.skipif(_n_devices() < 2, reason="needs two GPUs: one DEVICE per rank (runs on the driver's multi-GPU node)")
+@pytest.mark.parametrize("transport", ["ipc", "rccl"])
+@pytest.mark.parametrize("dist_kind", ["uniform", "zipf"])
+def test_two_devices_both_transports_against_oracle(transport, dist_kind, tmp_path):
+  """The first execution of the cross-DEVICE paths: two processes, rank r on cuda:r — peer stores
+  into the other device's hipIpc-mapped window over xGMI, and RCCL send / recv groups on the library's
+  own two-rank communicator (ncclCommCount == 2 asserted in the worker) — every rank's embeddings and
+  every owner's rows against the oracle's single-process replay, as the one-GPU process tests do."""
+  res = run_world(2, dist_kind, 5, tmp_path, {"MHTE_TEST_TRANSPORT": transport})
+  assert len({r["device"] for r in res}) == 2, [r["device"] for r in res]
+  assert all(r["transport"].startswith(transport) for r in res)
+
+
+@pytest.mark.skipif(_n_devices() < 4, reason="needs four GPUs")
+def test_four_devices_rccl_bias_rows(tmp_path):
+  res = run_world(4, "zipf", 4, tmp_path, {"MHTE_TEST_TRANSPORT": "rccl", "MHTE_TEST_SPECS": "bias"})
+  assert len({r["device"] for r in res}) == 4
+
+
 def test_processes_with_overlap(tmp_path):
   """MHTE_SHARD_OVERLAP=1: the next batch's dedup, numbering, packing and id exchange on the step's own
   stream (pushes and their publication from two streams of every process) — same results."""

@@ -1,11 +1,17 @@
-"""CPU suite, world_size 2 over gloo: the wire protocol of the C++ sharded multi-table step
-(oracle/shard_protocol.py: whole-batch peer blocks whose headers carry the per-table counts, one
-exchange per direction for ALL tables, row slot s <-> id slot s, owners applying the senders' blocks
-in rank order) run between two processes against a single-process run of the reference semantics
-on the oracle.  The block geometry is the product's (``shard_block_geometry`` == the oracle's
-``block_geometry``; the GPU tests pin it to the library's own numbers).  The C++ step itself is
-checked against the same semantics by separate PROCESSES on the GPU (tests/test_shard_ipc_gpu.py)
-and by N ranks in one process (tests/test_shard_step_gpu.py)."""
+"""CPU suite, world_size 2 over gloo — a test OF THE CHECKER, not of the product.
+
+oracle/shard_protocol.py restates the wire protocol of the C++ sharded multi-table step (whole-batch
+peer blocks whose headers carry the per-table counts, one exchange per direction for ALL tables, row
+slot s <-> id slot s, owners applying the senders' blocks in rank order).  Here that restatement runs
+between two processes against a single-process run of the reference semantics on the oracle: it pins
+the protocol model the GPU tests compare the product with, and that a two-process gloo rendezvous
+works on this image.  The only product symbol involved is ``shard_block_geometry`` (checked equal to
+the oracle's ``block_geometry``; the GPU tests pin it to the library's own numbers).
+
+The PRODUCT's step between processes is tests/test_shard_ipc_gpu.py (separate processes on the GPU,
+peer stores and — on a node with >= 2 devices — RCCL, against the oracle's replay) and
+tests/test_shard_step_gpu.py (N ranks in one process); the product's torch.distributed form of the
+step over gloo on CPU tensors is tests/test_sharded_gloo.py."""
 import os
 import socket
 import sys

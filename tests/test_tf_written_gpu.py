@@ -122,3 +122,58 @@ def test_restore_table_errors(tmp_path):
   with pytest.raises(_lib.MhteError) as ei:
     mt.restore_table("t", base)
   assert ei.value.code == _lib.MHTE_INVALID_ARGUMENT
+
+
+def test_tf_written_dim33_table_trains_through_the_sharded_and_multi_table_steps():
+  """A table the reference's TensorFlow wrote (dim 33 = bias FTRL(1) + vector SGD(32): its standard
+  row layout) is restored and then TRAINED: two updates through the id-sharded step (one rank) and
+  through the multi-table step must leave exactly the rows the op-level update (mhte_optimize on the
+  per-id gradient sums, duplicates added in occurrence order) leaves on a third restored copy — the
+  restored entries' FTRL state included.  Round 3 could restore these tables but had no fused / multi-GPU path for them."""
+  from monolith_amd.distributed_ps_sync import ShardedMultiStep
+  from monolith_amd.fused_step import MultiSparseStep
+  m = [x for x in MANIFEST if x["dim"] == 33][0]
+  base = os.path.join(GOLD, m["basename"])
+  recs = {}
+  for r in file_records(base):
+    e = P.EntryDump.FromString(r)
+    recs[e.id] = e
+  ids_all = np.array(sorted(recs), dtype=np.int64)
+  rng = np.random.default_rng(33)
+  B = 96
+  batches = [np.concatenate([rng.choice(ids_all, B - 16), rng.integers(1, 2**40, 16)]).astype(np.int64)
+             for _ in range(3)]
+  # (every id at most 32 times in a batch: its gradients are added in occurrence order on every path —
+  # bit-exact; longer lists are a fixed tree, equal to 1e-5)
+  assert max(np.unique(b, return_counts=True)[1].max() for b in batches) <= 32
+  grads = [(rng.standard_normal((B, 33)) * 0.1).astype(np.float32) for _ in range(2)]
+  results = []
+  for kind in ("sharded", "multi"):
+    mt = table_for(m)
+    mt.restore_table("t", base)
+    step = ShardedMultiStep(mt, B) if kind == "sharded" else MultiSparseStep(mt, B, exact_order=True)
+    rag = [mt.get_ragged_id({"t": torch.from_numpy(b).cuda()}) for b in batches]
+    for s in range(2):
+      emb = step.forward(rag[s], rag[s + 1])
+      got = mt.get_embeddings(rag[s], emb)["t"].cpu().numpy()
+      if s == 0:   # the restored rows (new ids: zeros)
+        exp0 = np.stack([np.array(recs[i].num, np.float32) if i in recs else np.zeros(33, np.float32)
+                         for i in batches[0].tolist()])
+        np.testing.assert_array_equal(got, exp0)
+      step.backward(torch.from_numpy(grads[s].ravel()).cuda(), 1000 + s)
+    step.close()
+    results.append((kind, mt.lookup({"t": torch.from_numpy(np.unique(np.concatenate(batches[:2]))).cuda()})["t"].cpu().numpy()))
+  # the two fused paths agree bit for bit with each other, and with the op-level path on a third copy
+  mt3 = table_for(m)
+  mt3.restore_table("t", base)
+  for s in range(2):
+    u, inv = np.unique(batches[s], return_inverse=True)
+    gu = np.zeros((u.size, 33), np.float32)
+    order = np.argsort(inv, kind="stable")
+    for p_ in order:          # duplicate gradients summed in occurrence order
+      gu[inv[p_]] = gu[inv[p_]] + grads[s][p_]
+    mt3.apply_gradients({"t": (torch.from_numpy(u).cuda(), torch.from_numpy(gu).cuda())}, req_time=1000 + s)
+  ref = mt3.lookup({"t": torch.from_numpy(np.unique(np.concatenate(batches[:2]))).cuda()})["t"].cpu().numpy()
+  for kind, rows in results:
+    np.testing.assert_array_equal(rows, ref, err_msg=kind)
+
