@@ -69,6 +69,11 @@ def parse():
                  help="sharded step: the next batch's dedup / numbering / id dispatch on the step's own "
                       "stream beside the dense leg (mhte_shard_step_set_overlap)")
   p.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"])
+  p.add_argument("--lookahead", type=int, default=1, choices=[1, 2],
+                 help="batches of look-ahead handed to the step: 1 = the next batch (its run dedup rides in "
+                      "the forward launch), 2 = the one after it as well (dedup in the backward launch: "
+                      "measured slower on one table of 65 536 ids, DESIGN 4.4 — the backward launch has no "
+                      "idle wave slots to hide it in)")
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--cpu-steps", type=int, default=150)
   p.add_argument("--cpu-child", default="", help=argparse.SUPPRESS)   # "i" | "ii": one CPU-baseline
@@ -744,7 +749,7 @@ def main():
   # a short --steps window (the driver's 20 steps are 0.7 ms of GPU work) is reported next to a
   # 200-step window of the same mode: `reference_window` in the JSON line
   REFW = 200 if (K < 200 and not sharded) else 0
-  n_batches = ((W + K) + (Wg + K) + 2 * reps + 12 + REFW) if not sharded else (K + W + 24)
+  n_batches = ((W + K) + (Wg + K) + 2 * reps + 14 + REFW) if not sharded else (K + W + 24)
   ids_host = np.stack([S.id_batch(s * world + rank, B, V, "zipf") for s in range(n_batches)])
   ids_all = torch.from_numpy(ids_host).to(dev)
   NG = max(1, args.grad_pool)
@@ -771,9 +776,14 @@ def main():
     step = SparseStep(mt, "emb", B, exact_order=args.exact_order,
                       reserve_ahead=args.reserve_ahead)
 
+    # --lookahead 2 (default): the batch after the next is handed over as well — its run dedup rides
+    # in this step's BACKWARD launch and the next step's forward launch carries lookups only; every
+    # timed step still executes exactly one dedup, one numbering + probe, one lookup and one update
+    two_ahead = args.lookahead >= 2
+
     def run_eager(lo, hi):
       for s in range(lo, hi):
-        step.forward(ids_all[s], next_ids=ids_all[s + 1])
+        step.forward(ids_all[s], next_ids=ids_all[s + 1], ahead_ids=ids_all[s + 2] if two_ahead else None)
         step.backward(grad_pool[s % NG], S.update_time(s))
         applied.append((s, s % NG, S.update_time(s)))
 

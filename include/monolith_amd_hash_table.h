@@ -571,6 +571,21 @@ mhte_status mhte_table_step_backward(mhte_multi_table* t, int32_t table, mhte_de
                                      const float* learning_rate, int64_t n_learning_rate,
                                      int64_t update_time, int64_t global_step, int32_t flags,
                                      void* stream);
+/* ... with TWO batches of look-ahead: the run dedup of the batch after the next (id_ahead, into
+ * ws_ahead, a third workspace) rides in this launch beside the update and the next batch's numbering.
+ * The forward launch of a step whose batch was deduplicated this way carries the lookups alone
+ * (mhte_table_step_forward with ws_next NULL): ~4 us less per step at 65 536 ids.  The reference's
+ * pipeline prefetches the same way, one stage queue per step of look-ahead
+ * (NT/distributed_ps_sync.py:199-203,270-275).  ws_ahead NULL: exactly mhte_table_step_backward. */
+mhte_status mhte_table_step_backward_ahead(mhte_multi_table* t, int32_t table, mhte_dedup_ws* ws,
+                                           mhte_dedup_ws* ws_next, const int64_t* unique_ids,
+                                           int64_t n_max, const uint32_t* n_unique_dev,
+                                           const float* grads, int64_t n, float* grad_unique,
+                                           const float* learning_rate, int64_t n_learning_rate,
+                                           int64_t update_time, int64_t global_step, int32_t flags,
+                                           mhte_dedup_ws* ws_ahead, const int64_t* id_ahead,
+                                           int64_t n_ahead, int64_t* unique_ids_ahead,
+                                           uint32_t* n_unique_dev_ahead, void* stream);
 
 /* Pipelined training step over ALL tables of a MultiHashTable: what a MonolithModel does per step
  * with MonolithMultiHashTableLookup (RT/ops/multi_hash_table_lookup_op.cc:33-89) and

@@ -142,7 +142,7 @@ EXPORTS = [
     "mhte_table_lookup_n", "mhte_table_optimize_n", "mhte_value_offsets",
     "mhte_fill_with_offset_map", "mhte_fill_with_offset_map_gradient", "mhte_table_set_count_hits",
     "mhte_table_sum_optimize_n", "mhte_unique_unordered", "mhte_table_fused_backward_ok", "mhte_table_finish_pending",
-    "mhte_table_step_forward", "mhte_table_step_backward", "mhte_profile_arm", "mhte_profile_read",
+    "mhte_table_step_forward", "mhte_table_step_backward", "mhte_table_step_backward_ahead", "mhte_profile_arm", "mhte_profile_read",
     "mhte_trace_begin", "mhte_trace_end", "mhte_step_dedup", "mhte_shard_partition",
     "mhte_step_scatter", "mhte_step_sum", "mhte_multi_table_save", "mhte_multi_table_restore", "mhte_table_save", "mhte_table_restore", "mhte_table_clear",
     "mhte_hash_filter_create", "mhte_hash_filter_destroy", "mhte_multi_table_set_filter",

@@ -1013,7 +1013,11 @@ struct Table {
     // role covers its groups in grid-stride trips
     const uint32_t others = nxt.nblk + uint32_t(sp.enabled) + pre.nblk;
     const uint32_t slots = uint32_t(2 * num_cus);
-    const uint32_t room = slots > others + 64 ? slots - others : 64u;
+    // (the displacement pass's workgroup leaves within a microsecond: it does not count against the
+    // lookups' residency — one workgroup fewer would put 1/512 of the batch on a second trip, the
+    // launch's tail)
+    const uint32_t held = nxt.nblk + pre.nblk;
+    const uint32_t room = slots > held + 64 ? slots - held : 64u;
     auto blocks_for = [&](int unr) {
       const int64_t groups = (n + unr - 1) / unr;
       return uint32_t((groups * sh.G + kRdBlock - 1) / kRdBlock);
@@ -1048,10 +1052,12 @@ struct Table {
     HIP_OK(hipGetLastError());
   }
 
+  // ahead: the run dedup of the batch TWO steps on (DedupWs::begin_run_dedup's RunView; nblk 0: none)
+  // rides in this launch
   void step_backward(DedupWs& ws, DedupWs* ws_next, const int64_t* uids, int64_t n_max,
                      const uint32_t* n_dev, const float* grads, int64_t n, float* grad_u,
                      const float* lrs, int64_t update_time, bool exact_order, hipStream_t st,
-                     int64_t global_step = 0) {
+                     int64_t global_step = 0, const RunView& ahead = RunView{}) {
     finish_pending(st);
     if (n <= 0 || n_max <= 0) throw Error(MHTE_INVALID_ARGUMENT, "step_backward: empty batch");
     if (ws.r_stage == 0 || int64_t(ws.rv.n) != n || ws.rv.uids != uids || ws.rv.n_unique != n_dev)
@@ -1135,6 +1141,10 @@ struct Table {
     if (ws_next && ws_next->r_stage == 1) {
       nxt = ws_next->rv;
       nblk_build = DedupWs::build_blocks(nxt);
+      // (with the run dedup of the batch two ahead in the launch, the build role gives up as many
+      // workgroups as the dedup takes — two trips each instead of one: every workgroup of the launch
+      // stays resident from the start; a late starter would be the launch's tail)
+      if (ahead.nblk && nblk_build > ahead.nblk) nblk_build = std::max<uint32_t>(nblk_build - ahead.nblk, nblk_build / 2);
       // the next batch is numbered AND probed in this launch: hints and row reservations for its
       // update (room for the rows it may reserve is made now)
       ws_next->probe_out_reserve(int64_t(nxt.n));
@@ -1142,7 +1152,20 @@ struct Table {
       if (reserve_next) ensure_capacity(uint64_t(nxt.n), st, kCapRows);
       po = ProbeOut{ws_next->r_urec.p, reserve_next ? 1u : 0u};
     }
-    const dim3 grid(nblk_build + c.nblk_items + c.nblk_ids);
+    DedupArgs da{};
+    if (ahead.nblk) {
+      da.hs = ahead.hs;
+      da.hlist = ahead.hlist;
+      da.btab_key = ahead.btab_key;
+      da.btab_val = ahead.btab_val;
+      da.seg = ahead.seg;
+      da.ctr = ahead.ctr;
+      da.ids = ahead.ids;
+      da.cap_mask = ahead.cap_mask;
+      da.n = ahead.n;
+      da.nblk = ahead.nblk;
+    }
+    const dim3 grid(da.nblk + nblk_build + c.nblk_items + c.nblk_ids);
     TableView v = view;
     v.trace = trace_region(kTagStepBwd, grid.x, 256);
     const RunView cur = ws.rv;
@@ -1150,13 +1173,13 @@ struct Table {
 #define CALL(G_, V_) \
   do {                                                                                               \
     if (!basic && nseg == 1) {                                                                       \
-      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, true, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a, po); \
+      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, true, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a, po, da); \
     } else if (!basic) {                                                                             \
-      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, false, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a, po); \
+      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, false, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a, po, da); \
     } else if (nseg == 1) {                                                                          \
-      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a, po);  \
+      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a, po, da);  \
     } else {                                                                                         \
-      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, false>), grid, 256, st, nxt, nblk_build, v, cur, c, a, po); \
+      LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, false>), grid, 256, st, nxt, nblk_build, v, cur, c, a, po, da); \
     }                                                                                                \
   } while (0)
     DISPATCH_G_VEC(sh, CALL);
@@ -3322,11 +3345,30 @@ mhte_status mhte_table_step_backward(mhte_multi_table* t, int32_t table, mhte_de
                                      const float* learning_rate, int64_t n_learning_rate,
                                      int64_t update_time, int64_t global_step, int32_t flags,
                                      void* stream) {
+  return mhte_table_step_backward_ahead(t, table, ws, ws_next, unique_ids, n_max, n_unique_dev, grads, n,
+                                        grad_unique, learning_rate, n_learning_rate, update_time,
+                                        global_step, flags, nullptr, nullptr, 0, nullptr, nullptr, stream);
+}
+
+mhte_status mhte_table_step_backward_ahead(mhte_multi_table* t, int32_t table, mhte_dedup_ws* ws,
+                                           mhte_dedup_ws* ws_next, const int64_t* unique_ids,
+                                           int64_t n_max, const uint32_t* n_unique_dev,
+                                           const float* grads, int64_t n, float* grad_unique,
+                                           const float* learning_rate, int64_t n_learning_rate,
+                                           int64_t update_time, int64_t global_step, int32_t flags,
+                                           mhte_dedup_ws* ws_ahead, const int64_t* id_ahead,
+                                           int64_t n_ahead, int64_t* unique_ids_ahead,
+                                           uint32_t* n_unique_dev_ahead, void* stream) {
   return guard([&] {
     Table& tb = table_at(t, table);
     if (!ws || ws == ws_next)
       throw Error(MHTE_INVALID_ARGUMENT, "step_backward needs the batch's workspace, distinct "
                                          "from the next batch's");
+    if (ws_ahead && (ws_ahead == ws || ws_ahead == ws_next))
+      throw Error(MHTE_INVALID_ARGUMENT, "step_backward: the workspace of the batch two ahead must be "
+                                         "a third one");
+    if (ws_ahead && (!id_ahead || !unique_ids_ahead || !n_unique_dev_ahead))
+      throw Error(MHTE_INVALID_ARGUMENT, "step_backward: null argument for the batch two ahead");
     if (!learning_rate || n_learning_rate < int64_t(tb.nseg))
       throw Error(MHTE_INVALID_ARGUMENT, "The length of tensor `learning_rate` is too short.");
     if (!n_unique_dev || !grad_unique || !unique_ids || !grads)
@@ -3337,9 +3379,12 @@ mhte_status mhte_table_step_backward(mhte_multi_table* t, int32_t table, mhte_de
     HIP_OK(hipSetDevice(t->device));
     std::lock_guard<std::mutex> g(tb.mu);
     tb.note_update_time(update_time);
+    RunView ahead{};
+    if (ws_ahead)
+      ahead = ws_ahead->ws.begin_run_dedup(id_ahead, n_ahead, unique_ids_ahead, n_unique_dev_ahead, S(stream));
     tb.step_backward(ws->ws, ws_next ? &ws_next->ws : nullptr, unique_ids, n_max, n_unique_dev,
                      grads, n, grad_unique, learning_rate, update_time,
-                     (flags & MHTE_EXACT_ORDER) != 0, S(stream), global_step);
+                     (flags & MHTE_EXACT_ORDER) != 0, S(stream), global_step, ahead);
     if (tb.evict_enabled && lib_now() - tb.last_evict >= tb.evict_every_s) {
       // (the scan must not overtake the displacement pass this update left for the next forward)
       tb.finish_pending(S(stream));

@@ -564,7 +564,7 @@ template <int G, int VEC, int UNR, int NT>
 __device__ __forceinline__ void lookup_role_u(const TableView& tv, const int64_t* __restrict__ ids,
                                               int64_t n, const uint32_t* __restrict__ n_dev,
                                               float* __restrict__ out, int count_hits,
-                                              int64_t group) {
+                                              int64_t group, const int64_t* pre = nullptr) {
   const int lane = threadIdx.x & 63;
   const int j = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
@@ -572,7 +572,8 @@ __device__ __forceinline__ void lookup_role_u(const TableView& tv, const int64_t
   const int64_t g0 = group * UNR;
   if (g0 >= n) return;
   // one 8-byte load per lane for the group's ids, then broadcast
-  const int64_t myid = (j < UNR && g0 + j < n) ? ids[g0 + j] : 0;
+  // (pre: the lane's id, fetched by the caller ahead of a wait of its own — step_fwd's gate)
+  const int64_t myid = pre ? *pre : ((j < UNR && g0 + j < n) ? ids[g0 + j] : 0);
   int64_t id[UNR];
   bool valid[UNR], match[UNR];
   uint32_t row[UNR];

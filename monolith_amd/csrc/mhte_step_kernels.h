@@ -318,6 +318,227 @@ __global__ __launch_bounds__(kRdBlock) void rd_dedup_kernel(RunView d) {
   rd_dedup_role(d, blockIdx.x, L, wt);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same run dedup for a 256-THREAD workgroup, four positions per thread — so that it can ride in
+// step_bwd (256-thread workgroups, five resident per CU): the dedup of batch s + 2 beside the
+// update of batch s, two batches of look-ahead, and the forward launch is left with the lookups
+// alone.  Same outputs, bit for bit the same format (scratch slots, position lists,
+// run directory, `seg`): the consumers do not know which role produced them.
+// LDS: five such workgroups must fit a CU's 160 KB beside nothing else, so the set's three
+// per-entry words (count, run offset, long-run slot) share ONE 32-bit word and `first` is read
+// back from `pos` when the table is dumped (it only matters for runs of one): 30.8 KB.
+//   word = count (bits 0-10, <= 1024) | offset << 11 (bits 11-21) | long-run slot << 22 (31: none)
+// ---------------------------------------------------------------------------------------------
+constexpr int kRd4Threads = 256;
+constexpr int kRd4PerThread = kRdBlock / kRd4Threads;   // 4
+struct __attribute__((aligned(16))) RdLds4 {
+  unsigned long long key[kRdStride];
+  uint32_t co[kRdStride + 3];
+  uint16_t pos[kRdBlock];
+  uint32_t bm[kMaxLongRuns][32];
+  uint32_t bmpre[kMaxLongRuns][32];
+  uint32_t wtot[4];
+  uint32_t nlong;
+};
+static_assert(sizeof(RdLds4) <= 31 * 1024, "five dedup workgroups (+ the other roles' statics) per CU");
+
+__device__ __forceinline__ void rd_dedup4_role(const RunView& d, uint32_t bid, RdLds4& L) {
+  // (four wavefronts that issue mostly LDS instructions, among sixteen that wait for memory: with
+  // the default priority they get a fifth of their SIMDs' issue slots and the role's chain outlasts
+  // the update's)
+  __builtin_amdgcn_s_setprio(3);
+  constexpr int Q = kRd4PerThread;
+  constexpr uint32_t kNoLong = 31u;
+  const uint32_t t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  for (uint32_t i = t; i < uint32_t(kRdStride); i += kRd4Threads) {
+    L.key[i] = static_cast<unsigned long long>(kEmptyKey);
+    L.co[i] = kNoLong << 22;
+  }
+  (&L.bm[0][0])[t] = 0;
+  (&L.bm[0][0])[t + 256] = 0;
+  if (t == 0) L.nlong = 0;
+  if (bid == 0 && t < 4) d.ctr[t] = 0;  // counters of the build role, which runs after this launch
+  int64_t id[Q];
+  bool valid[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const uint32_t p = bid * kRdBlock + uint32_t(q) * kRd4Threads + t;
+    valid[q] = p < d.n;
+    id[q] = d.ids[valid[q] ? p : 0u];   // round trip 1 (four coalesced loads, masked below)
+  }
+  lds_barrier();
+  uint32_t ls[Q], arr[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    ls[q] = 0;
+    arr[q] = 1;   // (not a speaker)
+    if (valid[q]) {
+      if (id[q] == kEmptyKey) {
+        ls[q] = kRdLds;
+      } else {
+        uint32_t h = rd_home(id[q]);
+        for (;;) {
+          unsigned long long k = L.key[h];
+          if (k == static_cast<unsigned long long>(kEmptyKey)) {
+            k = atomicCAS(&L.key[h], static_cast<unsigned long long>(kEmptyKey),
+                          static_cast<unsigned long long>(id[q]));
+            if (k == static_cast<unsigned long long>(kEmptyKey)) break;
+          }
+          if (k == static_cast<unsigned long long>(id[q])) break;
+          h = (h + 1u) & (kRdLds - 1);
+        }
+        ls[q] = h;
+      }
+      arr[q] = atomicAdd(&L.co[ls[q]], 1u) & 0x7ffu;
+    }
+  }
+  lds_barrier();
+  // ---- the run's first arrival speaks for the whole run in the global scratch: its CAS is in
+  // flight during the LDS work below
+  uint32_t gs[Q];
+  int64_t cas_old[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    gs[q] = 0;
+    cas_old[q] = kEmptyKey;
+    if (valid[q] && arr[q] == 0) {
+      if (id[q] == kEmptyKey) {
+        gs[q] = d.cap_mask + 1u;
+        cas_old[q] = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hs[gs[q]].key),
+                                                    static_cast<unsigned long long>(kEmptyKey), 0ull));
+      } else {
+        gs[q] = uint32_t(hash_key(id[q])) & d.cap_mask;
+        cas_old[q] = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hs[gs[q]].key),
+                                                    static_cast<unsigned long long>(kEmptyKey),
+                                                    static_cast<unsigned long long>(id[q])));
+      }
+      if ((L.co[ls[q]] & 0x7ffu) > uint32_t(kLongRun)) {
+        const uint32_t sl = atomicAdd(&L.nlong, 1u);
+        if (sl < uint32_t(kMaxLongRuns)) atomicAnd(&L.co[ls[q]], ~((kNoLong ^ sl) << 22));
+      }
+    }
+  }
+  // ---- run offsets: exclusive scan of the counts, eight entries per thread (+ the side entry)
+  {
+    uint32_t c8[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      c8[k] = L.co[8u * t + uint32_t(k)] & 0x7ffu;
+      sum += c8[k];
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) L.wtot[wave] = incl;
+    lds_barrier();
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) run += (i < wave) ? L.wtot[i] : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (run) atomicOr(&L.co[8u * t + uint32_t(k)], (run & 0x7ffu) << 11);   // (offsets <= 1024)
+      run += c8[k];
+    }
+    if (t == kRd4Threads - 1 && run) atomicOr(&L.co[kRdLds], (run & 0x7ffu) << 11);
+  }
+  lds_barrier();
+  uint32_t lsl[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    lsl[q] = kNoLong;
+    if (valid[q]) {
+      const uint32_t w = L.co[ls[q]];
+      const uint32_t tq = uint32_t(q) * kRd4Threads + t;
+      lsl[q] = (w >> 22) & 31u;
+      if (lsl[q] != kNoLong) atomicOr(&L.bm[lsl[q]][tq >> 5], 1u << (tq & 31u));
+      else L.pos[((w >> 11) & 0x7ffu) + arr[q]] = uint16_t(tq);  // grouped by run, arrival order
+    }
+  }
+  lds_barrier();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {  // exclusive prefix of the set-bit counts over each bitmap's 32 words
+    const uint32_t i = t + uint32_t(h) * 256u;
+    const uint32_t w = (&L.bm[0][0])[i];
+    uint32_t incl = __popc(w);
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const uint32_t v = __shfl_up(incl, o, 32);
+      if ((i & 31u) >= uint32_t(o)) incl += v;
+    }
+    (&L.bmpre[0][0])[i] = incl - __popc(w);
+  }
+  lds_barrier();
+  // ---- ascending order inside the run: rank = number of smaller positions in it
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    if (valid[q]) {
+      const uint32_t w = L.co[ls[q]];
+      const uint32_t c = w & 0x7ffu, o = (w >> 11) & 0x7ffu;
+      const uint32_t tq = uint32_t(q) * kRd4Threads + t;
+      uint32_t rank = 0;
+      if (lsl[q] != kNoLong) {
+        rank = L.bmpre[lsl[q]][tq >> 5] + __popc(L.bm[lsl[q]][tq >> 5] & ((1u << (tq & 31u)) - 1u));
+      } else if (c > 1) {
+        uint32_t i = 0;
+        for (; i + 8 <= c; i += 8) {
+          uint32_t x[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) x[k] = L.pos[o + i + k];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) rank += (x[k] < tq) ? 1u : 0u;
+        }
+        for (; i < c; ++i) rank += (uint32_t(L.pos[o + i]) < tq) ? 1u : 0u;
+      }
+      d.seg[bid * kRdBlock + o + rank] = uint16_t(tq);
+    }
+  }
+  // ---- now the CAS results: the home slot was free or already held the id (usual), else linear
+  // probing; the count bump returns where this run goes in the id's position list
+  uint32_t lbase[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    lbase[q] = 0;
+    if (valid[q] && arr[q] == 0) {
+      if (id[q] != kEmptyKey) {
+        while (cas_old[q] != kEmptyKey && cas_old[q] != id[q]) {
+          gs[q] = (gs[q] + 1u) & d.cap_mask;
+          cas_old[q] = static_cast<int64_t>(atomicCAS(reinterpret_cast<unsigned long long*>(&d.hs[gs[q]].key),
+                                                      static_cast<unsigned long long>(kEmptyKey),
+                                                      static_cast<unsigned long long>(id[q])));
+        }
+      }
+      const uint32_t p = bid * kRdBlock + uint32_t(q) * kRd4Threads + t;
+      lbase[q] = uint32_t(atomicAdd(&d.hs[gs[q]].cp, (static_cast<unsigned long long>(p) << 32) |
+                                                        static_cast<unsigned long long>(L.co[ls[q]] & 0x7ffu)));
+    }
+  }
+  // ---- the LDS table is the workgroup's run directory (first position: only read for runs of one,
+  // whose single position sits at pos[offset])
+  for (uint32_t i = t; i < uint32_t(kRdStride); i += kRd4Threads) {
+    const uint32_t w = L.co[i];
+    const uint32_t c = w & 0x7ffu, o = (w >> 11) & 0x7ffu;
+    d.btab_key[size_t(bid) * kRdStride + i] = static_cast<int64_t>(L.key[i]);
+    d.btab_val[size_t(bid) * kRdStride + i] = run_pack(c == 1 ? uint32_t(L.pos[o & 0x3ffu]) : 0u, o & 0x3ffu, c);
+  }
+  // ---- position list of a (so far) light id: this run's positions behind those already there
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    if (valid[q] && arr[q] == 0) {
+      const uint32_t w = L.co[ls[q]];
+      const uint32_t c = w & 0x7ffu, o = (w >> 11) & 0x7ffu;
+      if (lbase[q] + c <= uint32_t(kLightMax)) {
+        for (uint32_t i = 0; i < c; ++i)
+          d.hlist[size_t(gs[q]) * kLightMax + lbase[q] + i] = bid * kRdBlock + uint32_t(L.pos[o + i]);
+      }
+    }
+  }
+}
+
 // run descriptor of `id` in workgroup b's table (the id is known to have a run there).  Key and
 // descriptor of the home entry are fetched together: one round trip unless the LDS set had a
 // collision there.
@@ -1697,7 +1918,20 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
     }
     bid -= 1;
   }
-  // lookup workgroups: as many as are resident beside the other roles (nblk_l), grid-stride
+  // lookup workgroups: as many as are resident beside the other roles (nblk_l), grid-stride.
+  // The first trip's ids are fetched BEFORE the gate below: the gate's poll and this load share one
+  // round trip (with the run dedup out of this launch — two batches of look-ahead — the lookups'
+  // own chain ids -> buckets -> rows -> stores is what the launch lasts).
+  const int64_t ngroups = (n + UNR - 1) / UNR;
+  const uint32_t lbid = bid - min(bid, pre.nblk);
+  const int64_t g_first = (int64_t(lbid) * kRdBlock + threadIdx.x) / G;
+  int64_t id_first;
+  {
+    const int j = int(threadIdx.x & 63u) & (G - 1);
+    const int64_t p0 = g_first * UNR + j;
+    id_first = ids[(j < UNR && p0 < n) ? p0 : 0];   // (unconditional, from a safe index)
+    if (!(j < UNR && p0 < n)) id_first = 0;
+  }
   if (sp.enabled) {
     // A displacement pass for the previous update runs in another workgroup of this launch.  No
     // table word is read before it has finished: ONE lane polls n_pending (it drops to 0 only
@@ -1719,30 +1953,69 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
     return;
   }
   bid -= pre.nblk;
-  const int64_t ngroups = (n + UNR - 1) / UNR;
+  if (g_first < ngroups) lookup_role_u<G, VEC, UNR, 2>(tv, ids, n, nullptr, out, count_hits, g_first, &id_first);
 #pragma unroll 1
-  for (int64_t g = (int64_t(bid) * kRdBlock + threadIdx.x) / G; g < ngroups;
+  for (int64_t g = g_first + int64_t(nblk_l) * kRdBlock / G; g < ngroups;
        g += int64_t(nblk_l) * kRdBlock / G)
     lookup_role_u<G, VEC, UNR, 2>(tv, ids, n, nullptr, out, count_hits, g);
   wt.end(5u);
 }
 
-// step_bwd:  heavy work list of the NEXT batch | apply of this batch
+// what the dedup role needs of a workspace (the run dedup of batch s + 2 inside step_bwd: a compact
+// argument instead of a third RunView)
+struct DedupArgs {
+  RdSlot* hs;
+  uint32_t* hlist;
+  int64_t* btab_key;
+  uint32_t* btab_val;
+  uint16_t* seg;
+  uint32_t* ctr;
+  const int64_t* ids;
+  uint32_t cap_mask, n;
+  uint32_t nblk;        // workgroups of the role (0: none)
+};
+
+// step_bwd:  run dedup of the batch TWO ahead | numbering + table probe of the NEXT batch | apply of
+//            this batch
 // ONESEG: the table has one segment (the host picks the instantiation: see seg_of)
+union __attribute__((aligned(16))) StepBwdLds {
+  ApplyLds apply;
+  RdLds4 dedup;
+};
 template <int G, int VEC, bool ONESEG, bool FULL = false>
 __global__ __launch_bounds__(256, kBwdBlocksPerCu) void step_bwd_kernel(RunView nxt, uint32_t nblk_build,
                                                        TableView tv, RunView cur, ApplyCtl c,
-                                                       ApplyArgs a, ProbeOut po) {
+                                                       ApplyArgs a, ProbeOut po, DedupArgs da) {
+  __shared__ StepBwdLds L;
   WaveTrace wt(tv.trace);
-  if (blockIdx.x < nblk_build) {
+  uint32_t bid = blockIdx.x;
+  if (bid < da.nblk) {
+    // (first in the grid: its chain — ids, LDS set, scratch CAS, count bump, position lists — is as
+    // long as the update's, and it needs nothing the other roles produce)
+    RunView d{};
+    d.hs = da.hs;
+    d.hlist = da.hlist;
+    d.btab_key = da.btab_key;
+    d.btab_val = da.btab_val;
+    d.seg = da.seg;
+    d.ctr = da.ctr;
+    d.ids = da.ids;
+    d.cap_mask = da.cap_mask;
+    d.n = da.n;
+    d.nblk = da.nblk;
+    rd_dedup4_role(d, bid, L.dedup);
+    wt.end(3u);
+    return;
+  }
+  bid -= da.nblk;
+  if (bid < nblk_build) {
     // numbering of the next batch + its table probe (hints and row reservations for ITS update)
-    rd_build_role<false, true>(nxt, uint32_t(kStepLightMax), blockIdx.x, nblk_build, nullptr, &tv, po);
+    rd_build_role<false, true>(nxt, uint32_t(kStepLightMax), bid, nblk_build, nullptr, &tv, po);
     wt.end(6u);
     return;
   }
-  const uint32_t bid = blockIdx.x - nblk_build;
-  __shared__ ApplyLds L;
-  rd_apply_role<G, VEC, ONESEG, false, FULL>(tv, cur, c, a, bid, wt, L);
+  bid -= nblk_build;
+  rd_apply_role<G, VEC, ONESEG, false, FULL>(tv, cur, c, a, bid, wt, L.apply);
   wt.end(bid < c.nblk_items ? 7u : 8u);
 }
 

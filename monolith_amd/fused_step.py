@@ -18,13 +18,22 @@ done while batch s is looked up and updated: ``forward(ids, next_ids=...)``.  A 
 TWO launches on one queue (mhte_table_step_forward / _backward, csrc/mhte_step_kernels.h):
 
    forward   lookup(s)  | run dedup(s+1) | displacement pass of update s-1 (usually idle)
-             [| row handles for the ids update s will insert: ``reserve_ahead``, off by default —
-              it takes 1.2 us off the backward launch and puts 2.6 us on this one]
-   backward  gradient sum + upsert + optimizer(s) | heavy work list(s+1)
+   backward  gradient sum + upsert + optimizer(s) | numbering, heavy work list and table probe(s+1)
+             (the probe leaves every distinct id's row handle / slot, or a reserved row for an id the
+              table lacks: update s+1 reads no bucket and allocates nothing; ``reserve_ahead`` is
+              accepted and ignored — superseded)
 
 different workgroups of one kernel doing the jobs (a dependency between two HIP queues costs ~10 us
-on this part, a kernel boundary on one queue ~2 us).  Two dedup workspaces / result buffers
-alternate so the two batches never share scratch.  Batches of up to 65 536 ids.
+on this part, a kernel boundary on one queue ~2 us).  Batches of up to 65 536 ids.
+
+Two batches of look-ahead: ``forward(ids, next_ids=b1, ahead_ids=b2)``.  The run dedup's chain (ids,
+LDS set, scratch CAS, count bump, position lists) is what ends the forward launch; given the batch
+after the next as well, it moves into the BACKWARD launch, whose own chains are longer:
+
+   forward   lookup(s) | displacement pass of update s-1
+   backward  gradient sum + upsert + optimizer(s) | numbering + table probe(s+1) | run dedup(s+2)
+
+Three dedup workspaces / result buffers rotate so the batches in flight never share scratch.
 
 Without ``next_ids`` (and for rows too wide for the fused kernels) the step runs unpipelined: the
 list-building dedup (mhte_unique_unordered / mhte_unique) on a side stream beside the lookup, then
@@ -83,12 +92,15 @@ class SparseStep:
                             torch.zeros(1, dtype=torch.int32, device=dev), None,
                             None if self._plain_ordered else
                             torch.empty(n + 1, dtype=torch.int32, device=dev))
-    # pipelined path: two slots — the batch being trained and the batch deduplicated ahead of it
-    self._ws = [DedupWorkspace(dev.index), DedupWorkspace(dev.index)]
-    self._uids = [torch.empty(n, dtype=torch.int64, device=dev) for _ in range(2)]
-    self._nu = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
-    self._key = [None, None]    # (data_ptr, numel) of the ids whose run dedup the slot holds
+    # pipelined path: three slots — the batch being trained, the batch deduplicated ahead of it, and
+    # (two batches of look-ahead) the one after that
+    self._ws = [DedupWorkspace(dev.index) for _ in range(3)]
+    self._uids = [torch.empty(n, dtype=torch.int64, device=dev) for _ in range(3)]
+    self._nu = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(3)]
+    self._key = [None, None, None]    # (data_ptr, numel) of the ids whose run dedup the slot holds
     self._cur = 0
+    self._nxt = None
+    self._ahead = None          # the batch two steps on, handed to forward(): its dedup rides in backward
     self._mode = None           # "pipe" / "plain": how the current batch was deduplicated
     self._done = None           # event: the side-stream dedup of the current batch finished
     self._joined = True
@@ -114,13 +126,28 @@ class SparseStep:
     else:
       self._ws0.unique_unordered(ids, want_host_count=False, out=self._u0)
 
-  def forward(self, ids: torch.Tensor, next_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+  def _slot_of(self, key):
+    for i in range(3):
+      if self._same_batch(self._key[i], key):
+        return i
+    return None
+
+  def _free_slot(self, *busy):
+    for i in range(3):
+      if i not in busy:
+        return i
+    raise AssertionError("no free dedup slot")
+
+  def forward(self, ids: torch.Tensor, next_ids: Optional[torch.Tensor] = None,
+              ahead_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Rows for every occurrence.  ``direct`` (default): ONE probe+gather kernel over the B
     occurrences (duplicates of a Zipf head key are served from L2) — the same values as the
     reference's dedup -> lookup(unique) -> FillWithOffsetMap, without waiting for the dedup.
     ``direct=False`` keeps the reference's three-op shape.
     ``next_ids``: the following batch; its dedup is folded into this step's launches and picked
-    up by the next ``forward`` (which must receive that same tensor)."""
+    up by the next ``forward`` (which must receive that same tensor).
+    ``ahead_ids``: the batch after ``next_ids``; its run dedup rides in this step's BACKWARD launch,
+    so that the next step's forward launch carries lookups only."""
     assert ids.numel() == self.batch
     main = torch.cuda.current_stream()
     if not self.direct:
@@ -134,29 +161,42 @@ class SparseStep:
     key = self._batch_key(ids)
     pipelined = (self.fusable and self.fused_backward and not self.ordered_unique and
                  self.batch <= MAX_PIPELINED_BATCH)
-    other = 1 - self._cur
-    have = pipelined and self._same_batch(self._key[other], key)   # deduplicated ahead by the previous step
-    if have or (pipelined and next_ids is not None):
-      if have:
-        self._cur = other
+    at = self._slot_of(key) if pipelined else None      # deduplicated ahead by an earlier step?
+    if at is not None or (pipelined and next_ids is not None):
+      if at is not None:
+        self._cur = at
       else:  # first step of a pipeline: dedup in stream order
         # The previous backward may have left ids for the displacement pass, which reads the
         # unique ids and summed gradients of THIS slot's last batch: it must run before the
         # slot's buffers are rewritten (a restarted pipeline lost those updates).
         self.table.table_finish_pending(self.idx)
+        self._key = [None, None, None]     # (whatever was prepared ahead belongs to another stream of batches)
         self._ws[self._cur].step_dedup(ids, self._uids[self._cur], self._nu[self._cur])
         self._key[self._cur] = key
-      nxt = 1 - self._cur
+      self._nxt = None
       if next_ids is not None:
         assert next_ids.numel() == self.batch
-        self.table.table_step_forward(self.idx, ids, self.emb, self._ws[nxt], next_ids,
-                                      self._uids[nxt], self._nu[nxt],
-                                      ws_cur=self._ws[self._cur] if self.reserve_ahead else None)
-        self._key[nxt] = self._batch_key(next_ids)
+        nkey = self._batch_key(next_ids)
+        nxt = self._slot_of(nkey)
+        if nxt is None:
+          # not deduplicated yet (no look-ahead of two, or the pipeline's first steps): its run dedup
+          # rides in this forward launch
+          nxt = self._free_slot(self._cur)
+          self.table.table_step_forward(self.idx, ids, self.emb, self._ws[nxt], next_ids,
+                                        self._uids[nxt], self._nu[nxt])
+          self._key[nxt] = nkey
+        else:
+          self.table.table_step_forward(self.idx, ids, self.emb)     # lookups alone
+        self._nxt = nxt
       else:
-        self.table.table_step_forward(self.idx, ids, self.emb,
-                                      ws_cur=self._ws[self._cur] if self.reserve_ahead else None)
-        self._key[nxt] = None
+        self.table.table_step_forward(self.idx, ids, self.emb)
+      # slots that hold neither this batch nor the next are stale
+      for i in range(3):
+        if i != self._cur and i != self._nxt:
+          self._key[i] = None
+      self._ahead = ahead_ids if (next_ids is not None and ahead_ids is not None) else None
+      if self._ahead is not None:
+        assert self._ahead.numel() == self.batch
       self._mode = "pipe"
       self._joined = True
       return self.emb
@@ -196,11 +236,18 @@ class SparseStep:
   def backward(self, grads: torch.Tensor, update_time: int, global_step: int = 0):
     self._join()
     if self._mode == "pipe":
-      cur, nxt = self._cur, 1 - self._cur
-      ws_next = self._ws[nxt] if self._key[nxt] is not None else None
+      cur, nxt = self._cur, self._nxt
+      ws_next = self._ws[nxt] if nxt is not None else None
+      kw = {}
+      if self._ahead is not None and nxt is not None:
+        ah = self._free_slot(cur, nxt)
+        kw = dict(ws_ahead=self._ws[ah], ahead_ids=self._ahead, uids_ahead=self._uids[ah],
+                  n_unique_ahead=self._nu[ah])
+        self._key[ah] = self._batch_key(self._ahead)
       self.table.table_step_backward(self.idx, self._ws[cur], ws_next, self._uids[cur],
                                      self._nu[cur], grads, self.grad_u, self.lrs, update_time,
-                                     global_step, exact_order=self.exact_order)
+                                     global_step, exact_order=self.exact_order, **kw)
+      self._ahead = None
       self._key[cur] = None  # the slot's runs are consumed
     elif self.fused_backward:
       # one launch: per-id gradient sum + upsert + optimizer (mhte_table_sum_optimize_n)

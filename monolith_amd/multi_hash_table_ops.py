@@ -671,17 +671,23 @@ class MultiHashTable:
   def table_step_backward(self, name_or_idx, ws, ws_next, uids: torch.Tensor,
                           n_unique_dev: torch.Tensor, grads: torch.Tensor,
                           grad_unique: torch.Tensor, lrs: np.ndarray, update_time: int,
-                          global_step: int = 0, exact_order: bool = False):
-    """mhte_table_step_backward: gradient sum + upsert + optimizer of the batch ``ws`` holds
-    (+ the heavy work list of the batch ``ws_next`` holds)."""
+                          global_step: int = 0, exact_order: bool = False, ws_ahead=None,
+                          ahead_ids: Optional[torch.Tensor] = None,
+                          uids_ahead: Optional[torch.Tensor] = None,
+                          n_unique_ahead: Optional[torch.Tensor] = None):
+    """mhte_table_step_backward(_ahead): gradient sum + upsert + optimizer of the batch ``ws`` holds
+    (+ the numbering and table probe of the batch ``ws_next`` holds, + the run dedup of
+    ``ahead_ids`` — the batch two steps on — into ``ws_ahead``)."""
     i = name_or_idx if isinstance(name_or_idx, int) else self._index(name_or_idx)
     lrs = np.ascontiguousarray(lrs, dtype=np.float32)
     n = grads.shape[0]
-    check(self._lib.mhte_table_step_backward(
+    check(self._lib.mhte_table_step_backward_ahead(
         self._h, C.c_int32(i), ws._h,  # pylint: disable=protected-access
         ws_next._h if ws_next is not None else C.c_void_p(0),  # pylint: disable=protected-access
         vp(uids), C.c_int64(uids.numel()), vp(n_unique_dev), vp(grads), C.c_int64(n),
         vp(grad_unique), _f32p(lrs), C.c_int64(lrs.size), C.c_int64(int(update_time)),
         C.c_int64(int(global_step)), C.c_int32(_lib.MHTE_EXACT_ORDER if exact_order else 0),
-        _stream()))
+        ws_ahead._h if ws_ahead is not None else C.c_void_p(0),  # pylint: disable=protected-access
+        vp(ahead_ids), C.c_int64(ahead_ids.numel() if ahead_ids is not None else 0), vp(uids_ahead),
+        vp(n_unique_ahead), _stream()))
     return self

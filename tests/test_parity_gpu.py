@@ -695,6 +695,49 @@ def test_fused_backward_slow_path_at_high_load():
                                 ot.lookup(allids)[0])
 
 
+@pytest.mark.parametrize("exact", [True, False])
+def test_two_batches_of_lookahead_run_dedup_in_the_backward_launch(exact):
+  """forward(ids, next_ids, ahead_ids): the run dedup of the batch TWO steps on rides in the backward
+  launch (rd_dedup4_role: 256-thread workgroups, four positions per thread, the same scratch / run
+  format bit for bit), the forward launches carry lookups only, three workspaces rotate.  Same
+  results as one batch of look-ahead and as the oracle; Zipf batches with heavy lists, a batch size
+  that is not a multiple of 1024, the special key, a pipeline that is dropped and restarted."""
+  n, dim, steps = 33333, 32, 6
+  rng = np.random.default_rng(5)
+  batches = [S.id_batch(400 + s_, n, 10**6, "zipf") for s_ in range(steps + 2)]
+  batches[3][::3] = batches[3][2]                       # a list of n / 3 occurrences
+  batches[4][5::11] = np.iinfo(np.int64).min           # the key that lives in the side slot
+  dev = [ids_t(b) for b in batches]
+  grads = [S.grad_batch(s_, n, dim) for s_ in range(steps)]
+  rows = {}
+  for mode in ("one", "two", "two_restart"):
+    mt = make({"emb": adagrad_cfg(dim, 0.01, 0.1)})
+    step = SparseStep(mt, "emb", n, exact_order=exact)
+    for s_ in range(steps):
+      ahead = dev[s_ + 2] if mode != "one" else None
+      if mode == "two_restart" and s_ == 3:
+        step = SparseStep(mt, "emb", n, exact_order=exact)     # what was prepared ahead is dropped
+      emb = step.forward(dev[s_], next_ids=dev[s_ + 1], ahead_ids=ahead)
+      if s_ == 4:
+        first = emb.cpu().numpy().copy()
+      step.backward(val_t(grads[s_]), S.update_time(s_))
+      assert step.n_unique() == np.unique(batches[s_]).size
+    probe = np.unique(np.concatenate(batches[:steps]))
+    rows[mode] = (mt.lookup({"emb": ids_t(probe)})["emb"].cpu().numpy(), first, mt.size("emb"))
+    assert rows[mode][2] == probe.size
+  np.testing.assert_array_equal(rows["one"][0], rows["two"][0])
+  np.testing.assert_array_equal(rows["one"][1], rows["two"][1])
+  np.testing.assert_array_equal(rows["one"][0], rows["two_restart"][0])
+  ot = O.Table(O.segment(dim, O.OPT_ADAGRAD, p=(0.1, 0.0)), 1)
+  for s_ in range(steps):
+    _oracle_step(ot, batches[s_], grads[s_], dim, 0.01, S.update_time(s_))
+  exp = ot.lookup(probe)[0]
+  if exact:
+    np.testing.assert_array_equal(rows["two"][0], exp)
+  else:
+    np.testing.assert_allclose(rows["two"][0], exp, rtol=RTOL_TREE, atol=ATOL_SUM)
+
+
 def test_pipelined_step_slow_path_at_high_load():
   """Pipelined step at load factor ~0.97: many ids find both buckets full, so the displacement
   pass has work in every step.  It runs as one wavefront of the NEXT forward launch and the lookup

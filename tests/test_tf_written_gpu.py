@@ -140,8 +140,8 @@ def test_tf_written_dim33_table_trains_through_the_sharded_and_multi_table_steps
     recs[e.id] = e
   ids_all = np.array(sorted(recs), dtype=np.int64)
   rng = np.random.default_rng(33)
-  B = 96
-  batches = [np.concatenate([rng.choice(ids_all, B - 16), rng.integers(1, 2**40, 16)]).astype(np.int64)
+  B = 3 * ids_all.size + 16          # every restored id three times (shuffled) + 16 new ids
+  batches = [np.concatenate([rng.permutation(np.tile(ids_all, 3)), rng.integers(1, 2**40, 16)]).astype(np.int64)
              for _ in range(3)]
   # (every id at most 32 times in a batch: its gradients are added in occurrence order on every path —
   # bit-exact; longer lists are a fixed tree, equal to 1e-5)
