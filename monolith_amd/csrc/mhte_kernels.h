@@ -878,6 +878,13 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
           v = acc;
         }
         const float lr_eff = scal ? adam_lr(lr, c1, c2) : lr;
+        // (the AVX form of Adagrad is decided once per row, not per element: a branch per element
+        // took the segment kernels from 128 to 131 VGPRs = 4 -> 3 wavefronts per SIMD)
+        if (OP != kOpAssignAdd && sd.opt == kOptAdagrad && sd.p[2] != 0.f) {
+#pragma unroll
+          for (int c = 0; c < VEC; ++c)
+            adagrad_step_avx(w.v[c], s1.v[c], v.v[c], lr, sd.p[1], uint32_t(le + c) < (uint32_t(sd.dim) & ~7u));
+        } else
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
           if (OP == kOpAssignAdd) {
@@ -885,12 +892,12 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
           } else {
             if (BASIC) {
               if (sd.opt == kOptSgd) w.v[c] = sgd_step(w.v[c], v.v[c], lr);
-              else if (sd.opt == kOptAdagrad) adagrad_any(w.v[c], s1.v[c], v.v[c], lr, sd.p[1], sd.p[2], le + c, sd.dim);
+              else if (sd.opt == kOptAdagrad) adagrad_step(w.v[c], s1.v[c], v.v[c], lr, sd.p[1]);
               else ftrl_step(w.v[c], s1.v[c], s2.v[c], v.v[c], lr, sd.p[1], sd.p[2], sd.p[3]);
             } else
             switch (sd.opt) {
               case kOptSgd: w.v[c] = sgd_step(w.v[c], v.v[c], lr); break;
-              case kOptAdagrad: adagrad_any(w.v[c], s1.v[c], v.v[c], lr, sd.p[1], sd.p[2], le + c, sd.dim); break;
+              case kOptAdagrad: adagrad_step(w.v[c], s1.v[c], v.v[c], lr, sd.p[1]); break;
               case kOptFtrl:
                 ftrl_step(w.v[c], s1.v[c], s2.v[c], v.v[c], lr, sd.p[1], sd.p[2], sd.p[3]);
                 break;
@@ -978,6 +985,18 @@ struct SlotResult {
   bool deferred;
 };
 
+// a wave-uniform 32-bit value as a store operand, copied to its VGPR where it is used (a copy made
+// in front of a loop gets spilled there in the 96-VGPR kernels and reloaded — behind a wait for every
+// load in flight — at the store)
+__device__ __forceinline__ uint32_t vgpr_copy_of_uniform(uint32_t u) {
+#ifndef MHTE_NO_ANTIHOIST
+  uint32_t v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(__builtin_amdgcn_readfirstlane(u)));
+  return v;
+#else
+  return u;
+#endif
+}
 template <int G>
 __device__ __forceinline__ SlotResult upsert_resolve(const TableView& tv, Bucket* b_generic, int64_t id,
                                                      bool valid, int64_t k, uint32_t row, int lane,
@@ -1069,6 +1088,7 @@ __device__ __forceinline__ SlotResult upsert_resolve(const TableView& tv, Bucket
   } else if (valid && !deferred && j == owner) {
     if (is_new) b->row[s] = r;
     b->ts[s] = ts;  // SetTimestamp(update_time), cuckoo_embedding_hash_table.cc:242-246
+                    // (per lane: a restore passes every id's own timestamp)
   }
   SlotResult out;
   out.r = r;
@@ -2675,16 +2695,6 @@ __device__ __forceinline__ float opaque_f(float x) {
 #endif
   return x;
 }
-// a wave-uniform 32-bit value as a store operand, copied to its VGPR where it is used
-__device__ __forceinline__ uint32_t vgpr_copy_of_uniform(uint32_t u) {
-#ifndef MHTE_NO_ANTIHOIST
-  uint32_t v;
-  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(__builtin_amdgcn_readfirstlane(u)));
-  return v;
-#else
-  return u;
-#endif
-}
 __device__ __forceinline__ SegDesc seg_for_init(const SegDesc& sd) {
   SegDesc si = sd;
   si.init_value = opaque_f(sd.init_value);
@@ -2724,9 +2734,15 @@ __device__ __forceinline__ void optimize_row_reg(const TableView& tv, float* rp,
 #pragma unroll
     for (int c = 0; c < VEC; ++c) w.v[c] = sgd_step(w.v[c], g.v[c], slr);
   } else if (sd.opt == kOptAdagrad) {
-    const float alr = opaque_f(lr), wd = opaque_f(sd.p[1]), avx = opaque_f(sd.p[2]);
+    const float alr = opaque_f(lr), wd = opaque_f(sd.p[1]);
+    if (sd.p[2] != 0.f) {   // the reference's AVX2 form (adagrad_step_avx), opt-in
 #pragma unroll
-    for (int c = 0; c < VEC; ++c) adagrad_any(w.v[c], s1.v[c], g.v[c], alr, wd, avx, le + c, sd.dim);
+      for (int c = 0; c < VEC; ++c)
+        adagrad_step_avx(w.v[c], s1.v[c], g.v[c], alr, wd, uint32_t(le + c) < (uint32_t(sd.dim) & ~7u));
+    } else {
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) adagrad_step(w.v[c], s1.v[c], g.v[c], alr, wd);
+    }
   } else {
     const float flr = opaque_f(lr), beta = opaque_f(sd.p[1]), l1 = opaque_f(sd.p[2]), l2 = opaque_f(sd.p[3]);
 #pragma unroll

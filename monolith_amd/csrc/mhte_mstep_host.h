@@ -275,7 +275,12 @@ struct MultiStep {
       if (gx == 0) continue;
       const dim3 grid(gx, tc);
       A.trace = trace_region(kTagMStepFwd, grid.x * grid.y, kFwdBlock);
-      LAUNCH_HOT(kTagMStepFwd, (mstep_fwd_kernel<kFwdBlock>), grid, kFwdBlock, st, A);
+      // (one instance of the kernel per lane width among the tables: MHTE_SWITCH_G)
+      bool w4 = false, w1 = false;
+      for (uint32_t k = 0; k < tc; ++k)
+        if (A.tab[k].n) ((A.tab[k].gv & 1u) ? w1 : w4) = true;
+      if (w4) LAUNCH_HOT(kTagMStepFwd, (mstep_fwd_kernel<kFwdBlock, 4>), grid, kFwdBlock, st, A);
+      if (w1) LAUNCH_HOT(kTagMStepFwd, (mstep_fwd_kernel<kFwdBlock, 1>), grid, kFwdBlock, st, A);
       HIP_OK(hipGetLastError());
     }
   }
@@ -301,7 +306,7 @@ struct MultiStep {
     uint32_t active = 0, dblocks = 0;
     for (uint32_t t = 0; t < T; ++t) active += n_slot[slot][t] ? 1u : 0u;
     int64_t emb_off = 0;
-    uint32_t lin = 0;
+    uint32_t lin = 0, gx1 = 0;
     // lookup workgroups of 1024 threads: two resident per CU; the dedup's persistent ones take
     // their share of the slots, the rest goes to the tables in proportion
     const uint32_t slots = uint32_t(2 * num_cus);
@@ -325,7 +330,14 @@ struct MultiStep {
       emb_off += int64_t(ft.n) * tb.dim;
       F.fwd_start[t] = lin;
       ft.gv = shape_code(tb, uint64_t(ft.emb_off));
-      if (ft.n) {
+      if (ft.n && (ft.gv & 1u)) {
+        // one float per lane: looked up by mstep_fwd_kernel<.., 1> below (no blocks in the fused launch)
+        const uint32_t groups_per_wg = uint32_t(kFwdBlock) / shape_lanes(ft.gv);
+        const uint32_t one_trip = (ft.n + groups_per_wg - 1) / groups_per_wg;
+        const uint32_t share = std::max<uint32_t>(8, uint32_t(8 * num_cus) * scatter_ovs / std::max(1u, active));
+        ft.nblk_s = std::max<uint32_t>(1, std::min(one_trip, share));
+        gx1 = std::max(gx1, ft.nblk_s);
+      } else if (ft.n) {
         const uint32_t groups_per_wg = uint32_t(kRdBlock) / shape_lanes(ft.gv);
         const uint32_t one_trip = (ft.n + groups_per_wg - 1) / groups_per_wg;
         const uint32_t share = std::max<uint32_t>(2, room / std::max(1u, active));
@@ -335,6 +347,12 @@ struct MultiStep {
     }
     F.fwd_start[T] = lin;
     const uint32_t grid = F.nd + lin;
+    if (gx1) {
+      MFwdArgs A1 = A;
+      A1.trace = trace_region(kTagMStepFwd, gx1 * T, kFwdBlock);
+      LAUNCH_HOT(kTagMStepFwd, (mstep_fwd_kernel<kFwdBlock, 1>), dim3(gx1, T), kFwdBlock, st, A1);
+      HIP_OK(hipGetLastError());
+    }
     if (!grid) return;
     // (the dedup workgroups FIRST: spread evenly among the lookups' they measured 162-502 us against
     // 161 us — MHTE_MSTEP_FUSE_INTERLEAVE=1 keeps the other mapping for A/B runs)
@@ -400,7 +418,7 @@ struct MultiStep {
       A.grads = p.grads;
       A.cur = uint32_t(slot_cur);
       uint32_t gx = 0;
-      bool any_apply = false, any_full = false, any_basic = false;
+      bool any_apply = false;
       for (uint32_t k = 0; k < tc; ++k) {
         const uint32_t t = t0 + k;
         MBwdTab& bt = A.tab[k];
@@ -408,8 +426,6 @@ struct MultiStep {
         const uint32_t n = p.grads ? n_slot[slot_cur][t] : 0u;
         bt.build_next = (build_next && n_slot[slot_cur ^ 1][t]) ? 1u : 0u;
         bt.full = tb.basic_opts() ? 0u : 1u;
-        any_full = any_full || bt.full;
-        any_basic = any_basic || !bt.full;
         bt.n = n;
         bt.n_next = n_slot[slot_cur ^ 1][t];
         uint32_t blocks = bt.build_next ? h_st[t].nblk_build : 0u;
@@ -446,8 +462,14 @@ struct MultiStep {
       A.trace = trace_region(kTagMStepBwd, gx * tc, 256);
       // one launch per optimizer family present (the BASIC instantiation keeps the register budget
       // of SGD / Adagrad / FTRL tables; a workgroup of the other family's table leaves at once)
-      if (any_basic) LAUNCH_HOT(kTagMStepBwd, mstep_bwd_kernel<false>, dim3(gx, tc), 256, st, A);
-      if (any_full) LAUNCH_HOT(kTagMStepBwd, mstep_bwd_kernel<true>, dim3(gx, tc), 256, st, A);
+      // ... and per lane width (MHTE_SWITCH_G; a table with nothing to apply has shape code 0 = the
+      // float4 instance, which then runs its numbering)
+      bool fam[2][2] = {{false, false}, {false, false}};
+      for (uint32_t k = 0; k < tc; ++k) fam[A.tab[k].full ? 1 : 0][A.tab[k].gv & 1u] = true;
+      if (fam[0][0]) LAUNCH_HOT(kTagMStepBwd, (mstep_bwd_kernel<false, 4>), dim3(gx, tc), 256, st, A);
+      if (fam[0][1]) LAUNCH_HOT(kTagMStepBwd, (mstep_bwd_kernel<false, 1>), dim3(gx, tc), 256, st, A);
+      if (fam[1][0]) LAUNCH_HOT(kTagMStepBwd, (mstep_bwd_kernel<true, 4>), dim3(gx, tc), 256, st, A);
+      if (fam[1][1]) LAUNCH_HOT(kTagMStepBwd, (mstep_bwd_kernel<true, 1>), dim3(gx, tc), 256, st, A);
       HIP_OK(hipGetLastError());
       if (any_apply) {
         mstep_slow_kernel<<<tc, 64 * kSlowWaves, 0, st>>>(A);
@@ -673,7 +695,10 @@ static void fused_lookup_segments(mhte_multi_table* t, const int64_t* ids, const
       gx = std::max(gx, uint32_t((uint64_t((n + 1) / 2) * g + 511) / 512));
     }
     if (gx == 0) continue;
-    LAUNCH_HOT(kTagLookup, seg_lookup_kernel, dim3(gx, ns), 512, st, A);
+    bool w4 = false, w1 = false;
+    for (int k = 0; k < T; ++k) ((A.g[k] & 1u) ? w1 : w4) = true;
+    if (w4) LAUNCH_HOT(kTagLookup, seg_lookup_kernel<4>, dim3(gx, ns), 512, st, A);
+    if (w1) LAUNCH_HOT(kTagLookup, seg_lookup_kernel<1>, dim3(gx, ns), 512, st, A);
     HIP_OK(hipGetLastError());
   }
 }
@@ -740,7 +765,10 @@ static void fused_optimize_segments(mhte_multi_table* t, const int64_t* ids,
     }
     if (gx == 0) continue;
     gx = std::min<uint32_t>(gx, 1024);
-    LAUNCH_HOT(kTagUpsert, seg_upsert_kernel, dim3(gx, ns), 256, st, A);
+    bool w4 = false, w1 = false;
+    for (int k = 0; k < T; ++k) ((A.g[k] & 1u) ? w1 : w4) = true;
+    if (w4) LAUNCH_HOT(kTagUpsert, seg_upsert_kernel<4>, dim3(gx, ns), 256, st, A);
+    if (w1) LAUNCH_HOT(kTagUpsert, seg_upsert_kernel<1>, dim3(gx, ns), 256, st, A);
     seg_slow_kernel<<<T, 64, 0, st>>>(A);
     HIP_OK(hipGetLastError());
     for (int k = 0; k < T; ++k)

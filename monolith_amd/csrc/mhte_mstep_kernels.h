@@ -40,17 +40,30 @@ typedef const MHTE_CONST TableView* ConstViews;
 // the vector, NT/feature.py:117-120: dims 17 / 33 ...; dim <= 64 then) or whose slice of the flat
 // embedding / gradient buffer does not start on a 16-byte boundary.  CALL(G, VEC) is expanded for the
 // table's shape; -DMHTE_DEV_FAST keeps (16, 4) only.
-#define MHTE_SWITCH_GV(code, CALL)                     \
-  switch (code) {                                      \
-    case 8: MHTE_OTHER_G(CALL(8, 4)); break;           \
-    case 16: CALL(16, 4); break;                       \
-    case 32: MHTE_OTHER_G(CALL(32, 4)); break;         \
-    case 64: MHTE_OTHER_G(CALL(64, 4)); break;         \
-    case 9: MHTE_OTHER_G(CALL(8, 1)); break;           \
-    case 17: MHTE_OTHER_G(CALL(16, 1)); break;         \
-    case 33: MHTE_OTHER_G(CALL(32, 1)); break;         \
-    default: MHTE_OTHER_G(CALL(64, 1)); break;         \
+// One kernel INSTANCE per lane width (VW = 4 / 1): a launch serves the tables whose shape code has
+// that width, the other tables' workgroups leave at once and the host launches the other instance
+// only when the model has such tables.  (All eight shapes in one kernel made the register allocation
+// of the float4 paths worse: mstep_bwd 178 -> 192 us on 26 float4 tables.)
+#define MHTE_SWITCH_G(VW, code, CALL)                      \
+  if constexpr ((VW) == 4) {                               \
+    switch (code) {                                        \
+      case 8: MHTE_OTHER_G(CALL(8, 4)); break;             \
+      case 16: CALL(16, 4); break;                         \
+      case 32: MHTE_OTHER_G(CALL(32, 4)); break;           \
+      case 64: MHTE_OTHER_G(CALL(64, 4)); break;           \
+      default: break;                                      \
+    }                                                      \
+  } else {                                                 \
+    switch (code) {                                        \
+      case 9: MHTE_OTHER_G(CALL(8, 1)); break;             \
+      case 17: MHTE_OTHER_G(CALL(16, 1)); break;           \
+      case 33: MHTE_OTHER_G(CALL(32, 1)); break;           \
+      case 65: MHTE_OTHER_G(CALL(64, 1)); break;           \
+      default: break;                                      \
+    }                                                      \
   }
+// true when shape code `code` belongs to the instance of lane width VW
+#define MHTE_SHAPE_IS(VW, code) ((((code) & 1u) != 0u) == ((VW) == 1))
 
 struct MStepStatic {
   RunView rv[2];           // run-dedup workspaces: slot s holds the batch deduplicated into it
@@ -76,7 +89,7 @@ struct MFwdTab {
   uint32_t n;                  // ids of this batch (its dedup is in slot cur); 0: no lookup
   uint32_t nblk_s;             // workgroups of the lookup role
   uint32_t emb_off;            // floats
-  uint32_t gv;                 // lane-group shape of the table in this launch (MHTE_SWITCH_GV)
+  uint32_t gv;                 // lane-group shape of the table in this launch (MHTE_SWITCH_G)
 };
 struct MFwdArgs {
   ConstViews views;
@@ -100,7 +113,7 @@ struct MBwdTab {
   uint32_t n_next;             // ids of the batch in slot cur ^ 1
   uint32_t full;               // 1: the table uses optimizers beyond SGD / Adagrad / FTRL (the
                                // mstep_bwd_kernel<true> launch serves it, <false> the others)
-  uint32_t gv;                 // lane-group shape of the table in this launch (MHTE_SWITCH_GV)
+  uint32_t gv;                 // lane-group shape of the table in this launch (MHTE_SWITCH_G)
   ApplyArgs a;
 };
 struct MBwdArgs {
@@ -389,12 +402,12 @@ __device__ __forceinline__ void mstep_scatter_role(const TableView& tv, const Ru
   }
 }
 
-template <int BLOCK>
+template <int BLOCK, int VW = 4>
 __global__ __launch_bounds__(BLOCK) void mstep_fwd_kernel(MFwdArgs A) {
   const uint32_t t = blockIdx.y;
   const MFwdTab ft = A.tab[t];
   const uint32_t bid = blockIdx.x;
-  if (ft.n == 0 || bid >= ft.nblk_s) return;
+  if (ft.n == 0 || bid >= ft.nblk_s || !MHTE_SHAPE_IS(VW, ft.gv)) return;
   const MStepStatic& s = deref_const(A.st + t);
   WaveTrace wt(A.trace);
   const TableView& tv = deref_const(A.views + t);
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(BLOCK) void mstep_fwd_kernel(MFwdArgs A) {
   const int ch = int(s.count_hits);
 #define MHTE_FWD_CALL(G_, V_) \
   mstep_scatter_role<G_, BLOCK, MHTE_SCATTER_UNR, V_>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt)
-  MHTE_SWITCH_GV(ft.gv, MHTE_FWD_CALL)
+  MHTE_SWITCH_G(VW, ft.gv, MHTE_FWD_CALL)
 #undef MHTE_FWD_CALL
   wt.end(5u);
 }
@@ -455,7 +468,9 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
   while (t + 1 < D.T && F.fwd_start[t + 1] <= lin) ++t;
   const MFwdTab ft = A.tab[t];
   const uint32_t bid = lin - F.fwd_start[t];
-  if (ft.n == 0 || bid >= ft.nblk_s) return;
+  // (tables that move one float per lane are looked up by a launch of their own,
+  // mstep_fwd_kernel<.., 1>: this kernel must stay inside 64 VGPRs)
+  if (ft.n == 0 || bid >= ft.nblk_s || !MHTE_SHAPE_IS(4, ft.gv)) return;
   const MStepStatic& s = deref_const(A.st + t);
   const TableView& tv = deref_const(A.views + t);
   const uint32_t cur = A.cur & 1u;
@@ -465,7 +480,7 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
   constexpr int U = MHTE_FUSED_SCATTER_UNR;
 #define MHTE_FWD_CALL(G_, V_) \
   mstep_scatter_role<G_, kRdBlock, U, V_>(tv, d, out, s.urow[cur], s.uloc[cur], s.uts[cur], s.n_max, ch, bid, ft.nblk_s, A.item_split, wt)
-  MHTE_SWITCH_GV(ft.gv, MHTE_FWD_CALL)
+  MHTE_SWITCH_G(4, ft.gv, MHTE_FWD_CALL)
 #undef MHTE_FWD_CALL
   wt.end(5u);
 }
@@ -473,24 +488,24 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
 // ---------------------------------------------------------------------------------------------
 // backward: per table   numbering + heavy work list of the NEXT batch | apply of this batch
 // ---------------------------------------------------------------------------------------------
-template <bool ONESEG, bool FULL>
+template <bool ONESEG, bool FULL, int VW>
 __device__ __forceinline__ void mstep_apply_switch(uint32_t gv, const TableView& tv, const RunView& d,
                                                    const ApplyCtl& c, const ApplyArgs& a,
                                                    uint32_t bid, WaveTrace& wt, ApplyLds& L) {
 #define MHTE_BWD_CALL(G_, V_) rd_apply_role<G_, V_, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L)
-  MHTE_SWITCH_GV(gv, MHTE_BWD_CALL)
+  MHTE_SWITCH_G(VW, gv, MHTE_BWD_CALL)
 #undef MHTE_BWD_CALL
 }
 
 #ifndef MHTE_MBWD_OCC
 #define MHTE_MBWD_OCC kBwdBlocksPerCu
 #endif
-template <bool FULL>
+template <bool FULL, int VW = 4>
 __global__ __launch_bounds__(256, MHTE_MBWD_OCC) void mstep_bwd_kernel(MBwdArgs A) {
   __shared__ ApplyLds L;
   const uint32_t t = blockIdx.y;
   const MBwdTab& bt = A.tab[t];
-  if ((bt.full != 0u) != FULL) return;   // the other family's launch serves this table
+  if ((bt.full != 0u) != FULL || !MHTE_SHAPE_IS(VW, bt.gv)) return;   // another instance serves this table
   const MStepStatic& s = deref_const(A.st + t);
   WaveTrace wt(A.trace);
   uint32_t bid = blockIdx.x;
@@ -523,10 +538,10 @@ __global__ __launch_bounds__(256, MHTE_MBWD_OCC) void mstep_bwd_kernel(MBwdArgs 
   c.uloc = bt.hints ? s.uloc[cur] : nullptr;
   c.uts = bt.hints ? s.uts[cur] : nullptr;
   c.trusted = 1;   // (the host hands the hints over only while Table::mut_epoch is unchanged)
-  if (FULL && s.oneseg) mstep_apply_switch<true, true>(bt.gv, tv, d, c, bt.a, bid, wt, L);
-  else if (FULL) mstep_apply_switch<false, true>(bt.gv, tv, d, c, bt.a, bid, wt, L);
-  else if (s.oneseg) mstep_apply_switch<true, false>(bt.gv, tv, d, c, bt.a, bid, wt, L);
-  else mstep_apply_switch<false, false>(bt.gv, tv, d, c, bt.a, bid, wt, L);
+  if (FULL && s.oneseg) mstep_apply_switch<true, true, VW>(bt.gv, tv, d, c, bt.a, bid, wt, L);
+  else if (FULL) mstep_apply_switch<false, true, VW>(bt.gv, tv, d, c, bt.a, bid, wt, L);
+  else if (s.oneseg) mstep_apply_switch<true, false, VW>(bt.gv, tv, d, c, bt.a, bid, wt, L);
+  else mstep_apply_switch<false, false, VW>(bt.gv, tv, d, c, bt.a, bid, wt, L);
   wt.end(bid < bt.nblk_items ? 7u : 8u);
 }
 
@@ -562,7 +577,7 @@ struct SegLookupArgs {
   uint32_t seg0;                      // first segment of this launch (its table = (seg0 + y) % T)
   uint32_t id_off[kMaxSegs + 1];
   uint32_t emb_off[kMaxSegs + 1];
-  uint8_t g[kMaxStepTables * 4];      // per table: lane-group shape (MHTE_SWITCH_GV)
+  uint8_t g[kMaxStepTables * 4];      // per table: lane-group shape (MHTE_SWITCH_G)
   uint8_t count_hits[kMaxStepTables * 4];
 };
 static_assert(sizeof(SegLookupArgs) <= 4096, "kernel arguments exceed 4 KB");
@@ -577,17 +592,19 @@ __device__ __forceinline__ void seg_lookup_loop(const TableView& tv, const int64
     lookup_role_u<G, VEC, 2, 1>(tv, ids, n, nullptr, out, count_hits, g);
 }
 
+template <int VW>
 __global__ __launch_bounds__(512) void seg_lookup_kernel(SegLookupArgs A) {
   const uint32_t y = blockIdx.y;
   const uint32_t n = A.id_off[y + 1] - A.id_off[y];
   if (n == 0) return;
   const uint32_t t = (A.seg0 + y) % A.T;
+  if (!MHTE_SHAPE_IS(VW, A.g[t])) return;
   const TableView& tv = deref_const(A.views + t);
   const int64_t* ids = A.ids + A.id_off[y];
   float* out = A.out + size_t(A.emb_off[y]);
   const int ch = A.count_hits[t];
 #define MHTE_SEGL_CALL(G_, V_) seg_lookup_loop<G_, V_>(tv, ids, n, out, ch)
-  MHTE_SWITCH_GV(A.g[t], MHTE_SEGL_CALL)
+  MHTE_SWITCH_G(VW, A.g[t], MHTE_SEGL_CALL)
 #undef MHTE_SEGL_CALL
 }
 
@@ -648,17 +665,19 @@ __device__ __forceinline__ void seg_upsert_loop(const TableView& tv, const int64
   }
 }
 
+template <int VW>
 __global__ __launch_bounds__(256) void seg_upsert_kernel(SegUpsertArgs A) {
   const uint32_t y = blockIdx.y;
   const uint32_t n = A.id_off[y + 1] - A.id_off[y];
   if (n == 0) return;
   const uint32_t t = (A.seg0 + y) % A.T;
+  if (!MHTE_SHAPE_IS(VW, A.g[t])) return;
   const TableView& tv = deref_const(A.views + t);
   const int64_t* ids = A.ids + A.id_off[y];
   const float* values = A.grads + size_t(A.grad_off[y]);
   uint32_t* pend = A.pending[t];
 #define MHTE_SEGU_CALL(G_, V_) seg_upsert_loop<G_, V_>(tv, ids, n, values, A.a[t], pend, A.id_off[y], y)
-  MHTE_SWITCH_GV(A.g[t], MHTE_SEGU_CALL)
+  MHTE_SWITCH_G(VW, A.g[t], MHTE_SEGU_CALL)
 #undef MHTE_SEGU_CALL
 }
 

@@ -675,7 +675,11 @@ struct ShardStep {
     for (uint32_t t = 0; t < T; ++t)
       gx = std::max(gx, (A.n_build[t] ? ms.h_st[t].nblk_build : 0u) + A.gt[t].nblk_items + A.gt[t].nblk_ids);
     if (!gx) return;
-    LAUNCH_HOT(kTagShardBuild, shard_build_kernel, dim3(gx, T), 256, st, A);
+    // (one instance of the kernel per lane width among the tables: mhte_mstep_kernels.h MHTE_SWITCH_G)
+    bool w4 = false, w1 = false;
+    for (uint32_t t = 0; t < T; ++t) ((A.gt[t].gv & 1u) ? w1 : w4) = true;
+    if (w4) LAUNCH_HOT(kTagShardBuild, shard_build_kernel<4>, dim3(gx, T), 256, st, A);
+    if (w1) LAUNCH_HOT(kTagShardBuild, shard_build_kernel<1>, dim3(gx, T), 256, st, A);
     HIP_OK(hipGetLastError());
   }
 
@@ -692,7 +696,11 @@ struct ShardStep {
     uint32_t gx = 0;
     gather_tabs(A.gt, slot, &gx);
     if (!gx) return;
-    LAUNCH_HOT(kTagShardGather, shard_scatter_kernel, dim3(gx, T), 256, st, A);
+    bool w4 = false, w1 = false;
+    for (uint32_t t = 0; t < T; ++t)
+      if (A.gt[t].n) ((A.gt[t].gv & 1u) ? w1 : w4) = true;
+    if (w4) LAUNCH_HOT(kTagShardGather, shard_scatter_kernel<4>, dim3(gx, T), 256, st, A);
+    if (w1) LAUNCH_HOT(kTagShardGather, shard_scatter_kernel<1>, dim3(gx, T), 256, st, A);
     HIP_OK(hipGetLastError());
   }
 
@@ -719,7 +727,10 @@ struct ShardStep {
     // (grid-stride inside: enough workgroups to fill the chip a few times over, not one per slot)
     const uint32_t fill = std::max<uint32_t>(8, uint32_t(ms.num_cus) * 16 / (uint32_t(world) * T));
     gx = std::min(gx, fill);
-    LAUNCH_HOT(kTagShardLookup, shard_lookup_kernel, dim3(gx, uint32_t(world) * T), 512, st, A);
+    bool w4 = false, w1 = false;
+    for (uint32_t t = 0; t < T; ++t) ((A.g[t] & 1u) ? w1 : w4) = true;
+    if (w4) LAUNCH_HOT(kTagShardLookup, shard_lookup_kernel<4>, dim3(gx, uint32_t(world) * T), 512, st, A);
+    if (w1) LAUNCH_HOT(kTagShardLookup, shard_lookup_kernel<1>, dim3(gx, uint32_t(world) * T), 512, st, A);
     HIP_OK(hipGetLastError());
   }
 
@@ -751,12 +762,15 @@ struct ShardStep {
     const uint32_t fill = std::max<uint32_t>(8, uint32_t(ms.num_cus) * 16 / T);
     gx = std::min(gx, fill);
     A.clear_ids = ids_send[slot];
+    bool w4 = false, w1 = false;
+    for (uint32_t t = 0; t < T; ++t) ((A.g[t] & 1u) ? w1 : w4) = true;
     for (int p = 0; p < world; ++p) {
       wait_arrived(kXGrads, slot, p, p + 1, st);   // (a peer's block is applied as soon as it has landed)
       if (grad_bits == 16) cvt<false>(ids_recv[slot], own_grads16, apply_grads(), p, 1, st);
       A.peer = uint32_t(p);
       A.zero_headers = p == world - 1 ? 1u : 0u;
-      LAUNCH_HOT(kTagShardUpsert, shard_upsert_kernel, dim3(gx, T), 256, st, A);
+      if (w4) LAUNCH_HOT(kTagShardUpsert, shard_upsert_kernel<4>, dim3(gx, T), 256, st, A);
+      if (w1) LAUNCH_HOT(kTagShardUpsert, shard_upsert_kernel<1>, dim3(gx, T), 256, st, A);
       shard_slow_kernel<<<T, 64, 0, st>>>(A);
       HIP_OK(hipGetLastError());
       for (uint32_t t = 0; t < T; ++t)   // the filter's window moves between senders (one filter for all tables)

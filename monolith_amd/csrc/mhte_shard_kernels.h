@@ -55,7 +55,7 @@ struct ShardOwnerArgs {
   int64_t* clear_ids;
   uint32_t* pending[kMaxStepTables];
   ShardTab tab[kMaxStepTables];
-  uint8_t g[kMaxStepTables];          // lane-group shape per table (MHTE_SWITCH_GV)
+  uint8_t g[kMaxStepTables];          // lane-group shape per table (MHTE_SWITCH_G)
   uint8_t count_hits[kMaxStepTables];
   ApplyArgs a[kMaxStepTables];
 };
@@ -72,8 +72,10 @@ __device__ __forceinline__ uint32_t shard_block_count(const ShardOwnerArgs& A, u
 }
 
 // grid (x, world * T): y = peer * T + table
+template <int VW>
 __global__ __launch_bounds__(512) void shard_lookup_kernel(ShardOwnerArgs A) {
   const uint32_t p = blockIdx.y / A.geo.T, t = blockIdx.y % A.geo.T;
+  if (!MHTE_SHAPE_IS(VW, A.g[t])) return;
   const uint32_t n = shard_block_count(A, p, t);
   if (n == 0) return;
   const ShardTab tb = A.tab[t];
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(512) void shard_lookup_kernel(ShardOwnerArgs A) {
   float* out = A.rows + size_t(p) * A.geo.rows_block + tb.row_off;
   const int ch = A.count_hits[t];
 #define MHTE_SEGL_CALL(G_, V_) seg_lookup_loop<G_, V_>(tv, ids, n, out, ch)
-  MHTE_SWITCH_GV(A.g[t], MHTE_SEGL_CALL)
+  MHTE_SWITCH_G(VW, A.g[t], MHTE_SEGL_CALL)
 #undef MHTE_SEGL_CALL
 }
 
@@ -135,8 +137,10 @@ __device__ __forceinline__ void shard_slow_role(const ShardOwnerArgs& A, uint32_
 // the 8-XCD part the other workgroups' bucket and pending-list stores sit in their XCDs' L2s until
 // the kernel ends — making them visible earlier is an L2 write-back per workgroup, measured 295 us
 // against 5 us for the extra launch.)
+template <int VW>
 __global__ __launch_bounds__(256) void shard_upsert_kernel(ShardOwnerArgs A) {
   const uint32_t p = A.peer, t = blockIdx.y;
+  if (!MHTE_SHAPE_IS(VW, A.g[t])) return;
   const uint32_t n = shard_block_count(A, p, t);
   if (n == 0) return;
   const ShardTab tb = A.tab[t];
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256) void shard_upsert_kernel(ShardOwnerArgs A) {
   uint32_t* pend = A.pending[t];
   // (pending entry = (position in the block's table segment, unused))
 #define MHTE_SEGU_CALL(G_, V_) seg_upsert_loop<G_, V_>(tv, ids, n, values, A.a[t], pend, 0u, 0u)
-  MHTE_SWITCH_GV(A.g[t], MHTE_SEGU_CALL)
+  MHTE_SWITCH_G(VW, A.g[t], MHTE_SEGU_CALL)
 #undef MHTE_SEGU_CALL
 }
 
@@ -168,7 +172,7 @@ struct ShardGatherTab {
   uint32_t nblk_ids;
   uint32_t io_off;      // floats: SCATTER the table's embeddings in `flat`, SUM its gradients
   uint32_t n;           // occurrences of the batch (0: nothing to do)
-  uint32_t gv;          // lane-group shape of the table in this launch (MHTE_SWITCH_GV)
+  uint32_t gv;          // lane-group shape of the table in this launch (MHTE_SWITCH_G)
 };
 struct ShardGatherArgs {
   ConstStatics st;
@@ -195,12 +199,12 @@ __device__ __forceinline__ void shard_gather_ctl(GatherCtl& c, const MStepStatic
   c.index_is_offset = 1;
 }
 
-template <bool SCATTER>
+template <bool SCATTER, int VW>
 __device__ __forceinline__ void shard_gather_switch(uint32_t gv, const RunView& d, const GatherCtl& c,
                                                     uint32_t bid, char* raw) {
 #define MHTE_GATHER_CALL(G_, V_) \
   rd_gather_role<G_, V_, SCATTER>(d, c, bid, *reinterpret_cast<GatherLds<G_, V_>*>(raw))
-  MHTE_SWITCH_GV(gv, MHTE_GATHER_CALL)
+  MHTE_SWITCH_G(VW, gv, MHTE_GATHER_CALL)
 #undef MHTE_GATHER_CALL
 }
 static_assert(sizeof(GatherLds<8, 4>) >= sizeof(GatherLds<16, 4>) &&
@@ -211,11 +215,12 @@ static_assert(sizeof(GatherLds<8, 4>) >= sizeof(GatherLds<16, 4>) &&
               "LDS of the gather role");
 
 // rows back -> every occurrence of the batch in `slot`
+template <int VW>
 __global__ __launch_bounds__(256) void shard_scatter_kernel(ShardGatherArgs A) {
   __shared__ __attribute__((aligned(16))) char raw[sizeof(GatherLds<8, 4>)];
   const uint32_t t = blockIdx.y;
   const ShardGatherTab gt = A.gt[t];
-  if (gt.n == 0 || blockIdx.x >= gt.nblk_items + gt.nblk_ids) return;
+  if (gt.n == 0 || blockIdx.x >= gt.nblk_items + gt.nblk_ids || !MHTE_SHAPE_IS(VW, gt.gv)) return;
   const MStepStatic& s = deref_const(A.st + t);
   const uint32_t cur = A.slot & 1u;
   RunView d = s.rv[cur];
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256) void shard_scatter_kernel(ShardGatherArgs A) {
   c.in = A.in;
   c.out = A.out + size_t(gt.io_off);
   shard_gather_ctl(c, s, cur, A.slot_off, A.n_max, t, A.tab[t].dim, gt);
-  shard_gather_switch<true>(gt.gv, d, c, blockIdx.x, raw);
+  shard_gather_switch<true, VW>(gt.gv, d, c, blockIdx.x, raw);
 }
 
 // backward launch of the sender side, per table:
@@ -250,9 +255,12 @@ struct ShardBuildArgs {
 };
 static_assert(sizeof(ShardBuildArgs) <= 4096, "kernel arguments exceed 4 KB");
 
+// (a table is served — its numbering included — by the instance of its gradient rows' lane width)
+template <int VW>
 __global__ __launch_bounds__(256) void shard_build_kernel(ShardBuildArgs A) {
   __shared__ __attribute__((aligned(16))) char raw[sizeof(GatherLds<8, 4>)];
   const uint32_t t = blockIdx.y;
+  if (!MHTE_SHAPE_IS(VW, A.gt[t].gv)) return;
   const MStepStatic& s = deref_const(A.st + t);
   uint32_t bid = blockIdx.x;
   const uint32_t nb = A.n_build[t] ? s.nblk_build : 0u;
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(256) void shard_build_kernel(ShardBuildArgs A) {
   c.in = A.grads + size_t(gt.io_off);
   c.out = A.rows_out;
   shard_gather_ctl(c, s, cur, A.slot_off, A.n_max, t, A.tab[t].dim, gt);
-  shard_gather_switch<false>(gt.gv, d, c, bid, raw);
+  shard_gather_switch<false, VW>(gt.gv, d, c, bid, raw);
 }
 
 // ---- peer-store transport: one process per GPU, every rank maps every other rank's WINDOW ----------

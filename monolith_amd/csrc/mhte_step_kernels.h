@@ -1072,9 +1072,15 @@ __device__ __forceinline__ void optimize_row_pre(const TableView& tv, float* rp,
 #pragma unroll
     for (int c = 0; c < VEC; ++c) r.w.v[c] = sgd_step(r.w.v[c], g.v[c], slr);
   } else if (sd.opt == kOptAdagrad) {
-    const float alr = opaque_f(lr), wd = opaque_f(sd.p[1]), avx = opaque_f(sd.p[2]);
+    const float alr = opaque_f(lr), wd = opaque_f(sd.p[1]);
+    if (sd.p[2] != 0.f) {   // the reference's AVX2 form (adagrad_step_avx), opt-in
 #pragma unroll
-    for (int c = 0; c < VEC; ++c) adagrad_any(r.w.v[c], r.s1.v[c], g.v[c], alr, wd, avx, le + c, sd.dim);
+      for (int c = 0; c < VEC; ++c)
+        adagrad_step_avx(r.w.v[c], r.s1.v[c], g.v[c], alr, wd, uint32_t(le + c) < (uint32_t(sd.dim) & ~7u));
+    } else {
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) adagrad_step(r.w.v[c], r.s1.v[c], g.v[c], alr, wd);
+    }
   } else {
     const float flr = opaque_f(lr), beta = opaque_f(sd.p[1]), l1 = opaque_f(sd.p[2]), l2 = opaque_f(sd.p[3]);
 #pragma unroll
@@ -1421,9 +1427,13 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       Probe<G> pr = probe_issue<G>(tv, id, valid && !hinted, j);
       // (a group without a hint — or an index past the count, whose record is stale — checks bucket
       // 0's first key: every lane loads, unconditionally, from an address that exists)
-      const unsigned long long sloc = hinted ? hloc : 0ull;
-      GBucket* const hb = global_bucket(tv.buckets + (sloc >> 2));
-      const int64_t vraw = HINT ? id : hb->key[sloc & 3ull];
+      // (the bucket pointer is formed here and again at the timestamp store below: kept live across the
+      // gradient sums it cost the trip a spilled register pair — 8 bytes per lane stored on every trip)
+      int64_t vraw = id;
+      if (!HINT) {
+        const unsigned long long sloc = hinted ? hloc : 0ull;
+        vraw = global_bucket(tv.buckets + (sloc >> 2))->key[sloc & 3ull];
+      }
       RowRegs<VEC> rr;
       vec_zero(rr.w);
       vec_zero(rr.s1);
@@ -1511,12 +1521,13 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       // mid-insert and that was evicted since, the multi-table step): one bump per wavefront, placed
       // behind the row loads — the compiler waits for a result produced under a branch where the
       // branch ends, and here that wait is shared with loads this wavefront needs next anyway
-      unsigned long long rows0;  // (not initialised on purpose: see lbase in rd_dedup_role)
+      uint32_t rows0;  // (not initialised on purpose: see lbase in rd_dedup_role; the low half — the
+                       // first row handle — is all that is kept: the pair was a spilled register pair)
       bool bumped = false;
       {
         const unsigned long long tot = __popcll(uf.specm);
         if (tot && lane == 0) {
-          rows0 = atomicAdd(&tv.ctr->alloc, (tot << 32) | tot);
+          rows0 = uint32_t(atomicAdd(&tv.ctr->alloc, (tot << 32) | tot));
           bumped = true;
         }
       }
@@ -1561,7 +1572,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       }
       uint32_t base_row;
       {
-        uint32_t br = bumped ? uint32_t(rows0) : 0u;  // (lane 0 of a wavefront that needed rows)
+        uint32_t br = bumped ? rows0 : 0u;  // (lane 0 of a wavefront that needed rows)
         base_row = __shfl(br, 0);
       }
       SlotResult sr =
@@ -1573,7 +1584,8 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         // (a 4-byte store into a line this launch otherwise never touches costs a 128-byte fetch and
         // a write-back: 21 of mstep_bwd's 200 us at 26 x 65 536 ids.  update_time has the
         // resolution of a second; an id updated again within the second already carries it.)
-        if (valid && j == 0 && !ts_known) hb->ts[hloc & 3ull] = vgpr_copy_of_uniform(a.ts);
+        if (valid && j == 0 && !ts_known)
+          global_bucket(tv.buckets + (hloc >> 2))->ts[hloc & 3ull] = vgpr_copy_of_uniform(a.ts);
       }
       float* rp = nullptr;
       if (valid && !sr.deferred) {
@@ -1773,7 +1785,9 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         sr.deferred = false;
         if (valid && threadIdx.x == 0) hb->ts[hd.loc & 3ull] = vgpr_copy_of_uniform(a.ts);
       } else {
-        sr = upsert_resolve<G>(tv, (Bucket*)pr.b, hd.id, valid, pr.k, pr.row, lane, a.ts, reserved);
+        // (the uniform's VGPR copy is made here, not in front of the item loop: see vgpr_copy_of_uniform)
+        sr = upsert_resolve<G>(tv, (Bucket*)pr.b, hd.id, valid, pr.k, pr.row, lane, vgpr_copy_of_uniform(a.ts),
+                               reserved);
       }
       if (sr.deferred) {
         uint32_t ed = e;   // (rare path: its address arithmetic stays here, see opaque_f)
