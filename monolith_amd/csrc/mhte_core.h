@@ -270,6 +270,12 @@ MHTE_HD void adagrad_step_avx(float& w, float& n, float grad, float lr, float wd
   const float eff = lr / sqrtf(n);
   w = __builtin_fmaf(-eff, in_block ? grad : ug, w);
 }
+// (-DMHTE_NO_AVX_FORM compiles the opt-in out: A/B builds)
+#ifdef MHTE_NO_AVX_FORM
+#define MHTE_AVX_FORM(sd) false
+#else
+#define MHTE_AVX_FORM(sd) ((sd).p[2] != 0.f)
+#endif
 // elem: element index inside the segment of seg_dim elements
 MHTE_HD void adagrad_any(float& w, float& n, float grad, float lr, float wd, float avx_flag,
                          uint32_t elem, uint32_t seg_dim) {

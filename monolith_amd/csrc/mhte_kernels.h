@@ -880,7 +880,7 @@ __device__ __forceinline__ void apply_row(const TableView& tv, float* rp, bool i
         const float lr_eff = scal ? adam_lr(lr, c1, c2) : lr;
         // (the AVX form of Adagrad is decided once per row, not per element: a branch per element
         // took the segment kernels from 128 to 131 VGPRs = 4 -> 3 wavefronts per SIMD)
-        if (OP != kOpAssignAdd && sd.opt == kOptAdagrad && sd.p[2] != 0.f) {
+        if (OP != kOpAssignAdd && sd.opt == kOptAdagrad && MHTE_AVX_FORM(sd)) {
 #pragma unroll
           for (int c = 0; c < VEC; ++c)
             adagrad_step_avx(w.v[c], s1.v[c], v.v[c], lr, sd.p[1], uint32_t(le + c) < (uint32_t(sd.dim) & ~7u));
@@ -2735,7 +2735,7 @@ __device__ __forceinline__ void optimize_row_reg(const TableView& tv, float* rp,
     for (int c = 0; c < VEC; ++c) w.v[c] = sgd_step(w.v[c], g.v[c], slr);
   } else if (sd.opt == kOptAdagrad) {
     const float alr = opaque_f(lr), wd = opaque_f(sd.p[1]);
-    if (sd.p[2] != 0.f) {   // the reference's AVX2 form (adagrad_step_avx), opt-in
+    if (MHTE_AVX_FORM(sd)) {   // the reference's AVX2 form (adagrad_step_avx), opt-in
 #pragma unroll
       for (int c = 0; c < VEC; ++c)
         adagrad_step_avx(w.v[c], s1.v[c], g.v[c], alr, wd, uint32_t(le + c) < (uint32_t(sd.dim) & ~7u));

@@ -464,12 +464,20 @@ struct MultiStep {
       // of SGD / Adagrad / FTRL tables; a workgroup of the other family's table leaves at once)
       // ... and per lane width (MHTE_SWITCH_G; a table with nothing to apply has shape code 0 = the
       // float4 instance, which then runs its numbering)
-      bool fam[2][2] = {{false, false}, {false, false}};
-      for (uint32_t k = 0; k < tc; ++k) fam[A.tab[k].full ? 1 : 0][A.tab[k].gv & 1u] = true;
-      if (fam[0][0]) LAUNCH_HOT(kTagMStepBwd, (mstep_bwd_kernel<false, 4>), dim3(gx, tc), 256, st, A);
-      if (fam[0][1]) LAUNCH_HOT(kTagMStepBwd, (mstep_bwd_kernel<false, 1>), dim3(gx, tc), 256, st, A);
-      if (fam[1][0]) LAUNCH_HOT(kTagMStepBwd, (mstep_bwd_kernel<true, 4>), dim3(gx, tc), 256, st, A);
-      if (fam[1][1]) LAUNCH_HOT(kTagMStepBwd, (mstep_bwd_kernel<true, 1>), dim3(gx, tc), 256, st, A);
+      bool fam[2][2][2] = {};
+      for (uint32_t k = 0; k < tc; ++k)
+        fam[A.tab[k].full ? 1 : 0][A.tab[k].gv & 1u][h_st[t0 + k].oneseg ? 1 : 0] = true;
+#define MHTE_BWD_LAUNCH(F_, W_, O_)  \
+  if (fam[F_][W_ == 1][O_]) LAUNCH_HOT(kTagMStepBwd, (mstep_bwd_kernel<F_ != 0, W_, O_ != 0>), dim3(gx, tc), 256, st, A)
+      MHTE_BWD_LAUNCH(0, 4, 1);
+      MHTE_BWD_LAUNCH(0, 4, 0);
+      MHTE_BWD_LAUNCH(0, 1, 1);
+      MHTE_BWD_LAUNCH(0, 1, 0);
+      MHTE_BWD_LAUNCH(1, 4, 1);
+      MHTE_BWD_LAUNCH(1, 4, 0);
+      MHTE_BWD_LAUNCH(1, 1, 1);
+      MHTE_BWD_LAUNCH(1, 1, 0);
+#undef MHTE_BWD_LAUNCH
       HIP_OK(hipGetLastError());
       if (any_apply) {
         mstep_slow_kernel<<<tc, 64 * kSlowWaves, 0, st>>>(A);

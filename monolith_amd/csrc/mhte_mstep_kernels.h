@@ -500,13 +500,16 @@ __device__ __forceinline__ void mstep_apply_switch(uint32_t gv, const TableView&
 #ifndef MHTE_MBWD_OCC
 #define MHTE_MBWD_OCC kBwdBlocksPerCu
 #endif
-template <bool FULL, int VW = 4>
+// One instance per (optimizer family, lane width, one segment / several): a table is served by its
+// instance, the host launches the instances the model has tables for (one, for configs[4]).
+template <bool FULL, int VW, bool ONESEG>
 __global__ __launch_bounds__(256, MHTE_MBWD_OCC) void mstep_bwd_kernel(MBwdArgs A) {
   __shared__ ApplyLds L;
   const uint32_t t = blockIdx.y;
   const MBwdTab& bt = A.tab[t];
   if ((bt.full != 0u) != FULL || !MHTE_SHAPE_IS(VW, bt.gv)) return;   // another instance serves this table
   const MStepStatic& s = deref_const(A.st + t);
+  if ((s.oneseg != 0u) != ONESEG) return;
   WaveTrace wt(A.trace);
   uint32_t bid = blockIdx.x;
   const uint32_t cur = A.cur & 1u;
@@ -538,10 +541,7 @@ __global__ __launch_bounds__(256, MHTE_MBWD_OCC) void mstep_bwd_kernel(MBwdArgs 
   c.uloc = bt.hints ? s.uloc[cur] : nullptr;
   c.uts = bt.hints ? s.uts[cur] : nullptr;
   c.trusted = 1;   // (the host hands the hints over only while Table::mut_epoch is unchanged)
-  if (FULL && s.oneseg) mstep_apply_switch<true, true, VW>(bt.gv, tv, d, c, bt.a, bid, wt, L);
-  else if (FULL) mstep_apply_switch<false, true, VW>(bt.gv, tv, d, c, bt.a, bid, wt, L);
-  else if (s.oneseg) mstep_apply_switch<true, false, VW>(bt.gv, tv, d, c, bt.a, bid, wt, L);
-  else mstep_apply_switch<false, false, VW>(bt.gv, tv, d, c, bt.a, bid, wt, L);
+  mstep_apply_switch<ONESEG, FULL, VW>(bt.gv, tv, d, c, bt.a, bid, wt, L);
   wt.end(bid < bt.nblk_items ? 7u : 8u);
 }
 
@@ -665,8 +665,13 @@ __device__ __forceinline__ void seg_upsert_loop(const TableView& tv, const int64
   }
 }
 
+// (four workgroups per CU = 128 VGPRs, which the loop fits without a spill; left to itself the
+// compiler takes 132 and the owner's upsert of the sharded step runs 17 us instead of 13.8)
+#ifndef MHTE_SEGU_OCC
+#define MHTE_SEGU_OCC 4
+#endif
 template <int VW>
-__global__ __launch_bounds__(256) void seg_upsert_kernel(SegUpsertArgs A) {
+__global__ __launch_bounds__(256, MHTE_SEGU_OCC) void seg_upsert_kernel(SegUpsertArgs A) {
   const uint32_t y = blockIdx.y;
   const uint32_t n = A.id_off[y + 1] - A.id_off[y];
   if (n == 0) return;

@@ -138,7 +138,7 @@ __device__ __forceinline__ void shard_slow_role(const ShardOwnerArgs& A, uint32_
 // the kernel ends — making them visible earlier is an L2 write-back per workgroup, measured 295 us
 // against 5 us for the extra launch.)
 template <int VW>
-__global__ __launch_bounds__(256) void shard_upsert_kernel(ShardOwnerArgs A) {
+__global__ __launch_bounds__(256, MHTE_SEGU_OCC) void shard_upsert_kernel(ShardOwnerArgs A) {
   const uint32_t p = A.peer, t = blockIdx.y;
   if (!MHTE_SHAPE_IS(VW, A.g[t])) return;
   const uint32_t n = shard_block_count(A, p, t);

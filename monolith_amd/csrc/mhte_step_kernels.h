@@ -1073,7 +1073,7 @@ __device__ __forceinline__ void optimize_row_pre(const TableView& tv, float* rp,
     for (int c = 0; c < VEC; ++c) r.w.v[c] = sgd_step(r.w.v[c], g.v[c], slr);
   } else if (sd.opt == kOptAdagrad) {
     const float alr = opaque_f(lr), wd = opaque_f(sd.p[1]);
-    if (sd.p[2] != 0.f) {   // the reference's AVX2 form (adagrad_step_avx), opt-in
+    if (MHTE_AVX_FORM(sd)) {   // the reference's AVX2 form (adagrad_step_avx), opt-in
 #pragma unroll
       for (int c = 0; c < VEC; ++c)
         adagrad_step_avx(r.w.v[c], r.s1.v[c], g.v[c], alr, wd, uint32_t(le + c) < (uint32_t(sd.dim) & ~7u));
