@@ -84,8 +84,6 @@ def parse():
   p.add_argument("--force-sharded", action="store_true",
                  help="N=1 through the id-sharded code path (one-rank process group): the floor of "
                       "the multi-GPU step without any link traffic; a measurement, not the bench line")
-  p.add_argument("--reserve-ahead", action="store_true",
-                 help="forward launch reserves the row handles of the update (SparseStep.reserve_ahead)")
   p.add_argument("--dist-backend", default="auto", choices=["auto", "nccl", "gloo", "ipc"],
                  help="torch.distributed backend of the launcher's side channel for --gpus > 1 (rendezvous, "
                       "barriers, the max-over-ranks reduction): auto = nccl (RCCL) with one device per "
@@ -118,14 +116,28 @@ def algorithmic_bytes(B, U, D, S):
   return lookup + update, per_kernel
 
 
-def emit_line(obj):
-  """The bench's ONE JSON line, as the last thing on stdout.  Native libraries write to the C stdio
-  buffer (RCCL prints its version block there when a communicator is made), which a piped stdout
-  only receives at exit — after everything Python printed.  Flushing it first keeps the JSON line
-  last."""
+_JSON_FD = None
+
+
+def stdout_for_the_line_only():
+  """Everything else a rank writes to stdout goes to stderr from here on: native libraries print
+  there (RCCL's version block when a communicator is made, gloo's "[Gloo] Rank 0 is connected to …"
+  at the rendezvous), and the contract is ONE JSON line on stdout."""
+  global _JSON_FD
   flush_native_stdout()
-  sys.stdout.write(json.dumps(obj) + "\n")
-  sys.stdout.flush()
+  _JSON_FD = os.dup(1)
+  os.dup2(2, 1)
+
+
+def emit_line(obj):
+  """The bench's ONE JSON line, the only thing on stdout (stdout_for_the_line_only)."""
+  flush_native_stdout()
+  data = (json.dumps(obj) + "\n").encode()
+  if _JSON_FD is None:
+    sys.stdout.write(data.decode())
+    sys.stdout.flush()
+  else:
+    os.write(_JSON_FD, data)
 
 
 def flush_native_stdout():
@@ -660,6 +672,7 @@ def main():
   if args.gpus != world and world == 1 and args.gpus > 1:
     return spawn_ranks(args.gpus)   # `python bench.py --gpus N`: launch the N ranks ourselves
   assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+  stdout_for_the_line_only()
   ndev = torch.cuda.device_count()
   shared_device = world > ndev        # several ranks per GPU (the 1-GPU box)
   local_rank %= ndev
@@ -743,13 +756,17 @@ def main():
   # find every id resident and skip the insert path).  The modes run back to back over one
   # contiguous batch sequence: the last step of a mode deduplicates the first batch of the next
   # mode ahead, exactly as it does inside a mode.
-  reps = min(K, 100)
+  # launches of the per-kernel timing pass (HIP events): 100 whatever --steps is — the first launches
+  # after the queue has drained run slower (the driver's 20-step window averaged 17.9 us for a kernel
+  # that takes 15.5-16 us in steady state), so the pass also warms up before it arms the events
+  reps = 100
+  PROF_WARM = 8
   gchunk = 10                               # steps per captured graph
   Wg = -(-W // gchunk) * gchunk             # the graph mode's warm-up: W rounded up to whole chunks
   # a short --steps window (the driver's 20 steps are 0.7 ms of GPU work) is reported next to a
   # 200-step window of the same mode: `reference_window` in the JSON line
   REFW = 200 if (K < 200 and not sharded) else 0
-  n_batches = ((W + K) + (Wg + K) + 2 * reps + 14 + REFW) if not sharded else (K + W + 24)
+  n_batches = ((W + K) + (Wg + K) + 2 * reps + 14 + PROF_WARM + REFW) if not sharded else (K + W + 24)
   ids_host = np.stack([S.id_batch(s * world + rank, B, V, "zipf") for s in range(n_batches)])
   ids_all = torch.from_numpy(ids_host).to(dev)
   NG = max(1, args.grad_pool)
@@ -773,8 +790,7 @@ def main():
     # prefetch queue does.  Every timed step executes exactly one dedup, one lookup and one
     # update: the first timed batch was deduplicated by the last warm-up step, the last timed
     # step deduplicates the batch after it.
-    step = SparseStep(mt, "emb", B, exact_order=args.exact_order,
-                      reserve_ahead=args.reserve_ahead)
+    step = SparseStep(mt, "emb", B, exact_order=args.exact_order)
 
     # --lookahead 2 (default): the batch after the next is handed over as well — its run dedup rides
     # in this step's BACKWARD launch and the next step's forward launch carries lookups only; every
@@ -841,8 +857,7 @@ def main():
         torch.cuda.synchronize()
         # the aborted capture advanced the host-side pipeline state without executing anything:
         # start the following passes from a fresh pipeline
-        step = SparseStep(mt, "emb", B, exact_order=args.exact_order,
-                      reserve_ahead=args.reserve_ahead)
+        step = SparseStep(mt, "emb", B, exact_order=args.exact_order)
         cur += gc * (len(graphs) + 1)
     if REFW:
       cur = timed("eager_ref_window", cur, 0, REFW)
@@ -1051,6 +1066,8 @@ def main():
 
     run_eager(P0, P0 + 1)   # (first step after a mode switch may use the plain forward launch)
     step.quiesce()
+    run_eager(P0 + 1, P0 + 1 + PROF_WARM)   # untimed: clocks and caches as in the timed region
+    P0 += PROF_WARM
     _lib.profile_arm(2 * reps)
     run_eager(P0 + 1, P0 + 1 + reps)
     collect()
@@ -1106,7 +1123,9 @@ def main():
                 "traffic_source": traffic_src,
                 "alg_bytes_per_launch": int(alg[dom]),
                 "avg_launch_us": round(pipelined[dom], 2),
-                "timing": "hipExtLaunchKernelGGL start/stop events on the launch stream, %d launches" % reps,
+                "timing": "hipExtLaunchKernelGGL start/stop events on the launch stream, %d launches of the same "
+                          "step in a pass of their own behind the timed region (a graph replay cannot carry "
+                          "events), %d untimed steps first" % (reps, PROF_WARM),
                 "step_alg_bytes": int(step_bytes),
                 "step_GBps": round(step_bytes / (elapsed / K) / 1e9, 1),
                 "step_frac": round(step_bytes / (elapsed / K) / 1e9 / HBM_PEAK_GBPS, 4)}

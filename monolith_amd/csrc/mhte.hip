@@ -985,16 +985,14 @@ struct Table {
   //   step_forward   lookup of this batch | run dedup of the next batch
   //                  | displacement pass of the previous update (gated, usually idle)
   //   step_backward  apply of this batch | heavy work list of the next batch
-  // ws_cur: the workspace that holds THIS batch's deduplicated + built ids (or nullptr): the launch
-  // then also reserves the row handles its update will need (rd_prealloc_role)
+  // ws_cur: unused (kept for the C entry point's signature)
   void step_forward(const int64_t* ids, int64_t n, float* out, const RunView& nxt, DedupWs* ws_cur,
                     hipStream_t st) {
     if (n <= 0) throw Error(MHTE_INVALID_ARGUMENT, "step_forward: empty batch");
     Shape sh = pick_shape(dim, vec_ok && aligned16(out));
-    PreArgs pre{};
-    // (ws_cur: the forward launch used to reserve the update's row handles here, rd_prealloc_role —
-    // superseded: the build role's table probe reserves them a launch earlier, off this launch's
-    // critical path; the argument is accepted and ignored)
+    // (ws_cur: a round-1 form reserved the update's row handles in this launch; the build role's
+    // table probe reserves them a launch earlier, off this launch's critical path — the argument is
+    // accepted and ignored)
     (void)ws_cur;
     SlowArgs sp{};
     sp.enabled = pend_valid ? 1 : 0;
@@ -1011,12 +1009,12 @@ struct Table {
     }
     // every workgroup of the launch resident at once (two 1024-thread workgroups per CU); the lookup
     // role covers its groups in grid-stride trips
-    const uint32_t others = nxt.nblk + uint32_t(sp.enabled) + pre.nblk;
+    const uint32_t others = nxt.nblk + uint32_t(sp.enabled);
     const uint32_t slots = uint32_t(2 * num_cus);
     // (the displacement pass's workgroup leaves within a microsecond: it does not count against the
     // lookups' residency — one workgroup fewer would put 1/512 of the batch on a second trip, the
     // launch's tail)
-    const uint32_t held = nxt.nblk + pre.nblk;
+    const uint32_t held = nxt.nblk;
     const uint32_t room = slots > held + 64 ? slots - held : 64u;
     auto blocks_for = [&](int unr) {
       const int64_t groups = (n + unr - 1) / unr;
@@ -1035,10 +1033,10 @@ struct Table {
   do {                                                                                           \
     if (basic) {                                                                                 \
       LAUNCH_HOT(kTagStepFwd, (step_fwd_kernel<G_, V_, U_, true>), grid, kRdBlock, st, nxt, v, ids, n, out, \
-                 count_hits ? 1 : 0, sp, nblk_l, pre);                                           \
+                 count_hits ? 1 : 0, sp, nblk_l);                                                \
     } else {                                                                                     \
       LAUNCH_HOT(kTagStepFwd, (step_fwd_kernel<G_, V_, U_, false>), grid, kRdBlock, st, nxt, v, ids, n, out, \
-                 count_hits ? 1 : 0, sp, nblk_l, pre);                                           \
+                 count_hits ? 1 : 0, sp, nblk_l);                                                \
     }                                                                                            \
   } while (0)
 #define CALL(G_, V_)                              \
@@ -1116,7 +1114,6 @@ struct Table {
     c.arrive = ws.arrive.p;
     c.n_max = n_max;
     c.light_max = exact_order ? 0xffffffffu : uint32_t(kStepLightMax);
-    c.spec_row = nullptr;
     c.urow = nullptr;
     c.uloc = nullptr;
     c.uts = nullptr;

@@ -1051,7 +1051,7 @@ __device__ __forceinline__ SlotResult upsert_resolve(const TableView& tv, Bucket
   }
 
   // ---- row handles + live-key count for new ids: ONE atomic per wave ----
-  // (reserved != kNoRow: the row was allocated — and the key counted — ahead, rd_prealloc_role;
+  // (reserved != kNoRow: the row was allocated — and the key counted — ahead, by the build role (ProbeOut);
   // such a group needs nothing from the counter and returns its key if it did not insert)
   const bool has_res = reserved != kNoRow;
   const bool leader_new = is_new && j == 0 && !has_res;

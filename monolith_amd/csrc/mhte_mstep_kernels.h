@@ -536,7 +536,6 @@ __global__ __launch_bounds__(256, MHTE_MBWD_OCC) void mstep_bwd_kernel(MBwdArgs 
   c.light_max = bt.light_max;
   c.nblk_items = bt.nblk_items;
   c.nblk_ids = bt.nblk_ids;
-  c.spec_row = nullptr;
   c.urow = bt.hints ? s.urow[cur] : nullptr;
   c.uloc = bt.hints ? s.uloc[cur] : nullptr;
   c.uts = bt.hints ? s.uts[cur] : nullptr;

@@ -1010,15 +1010,13 @@ struct ApplyCtl {
   uint32_t light_max;     // 0xffffffff: every list strictly sequential (MHTE_EXACT_ORDER)
   uint32_t nblk_items;    // workgroups [0, nblk_items) take work items, the rest ids
   uint32_t nblk_ids;
-  const uint32_t* spec_row;  // [n] row handle reserved for unique index u (ProbeOut.spec of the build
-                             // role's probe; rd_prealloc_role; kNoRow: none), or nullptr
   // (multi-table step, HINT) what the forward launch's lookup found for unique index u: row handle
   // (kNoRow: absent) and bucket * 4 + slot; nullptr: probe as usual
   const uint32_t* urow;
   const unsigned long long* uloc;
   const uint32_t* uts;          // timestamp the forward launch saw in the id's slot (or nullptr)
   const URec* urec;             // (single-table step) the build role's packed record per unique index:
-                                // replaces the dense arrays, urow / uloc and spec_row in ONE load
+                                // replaces the dense arrays, urow / uloc in ONE load
   uint32_t trusted;             // 1: nothing has touched the table since urow / uloc were written
                                 // (multi-table step, Table::mut_epoch): the hints need no check
 };
@@ -1398,7 +1396,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         hloc = fnd ? rec.loc : 0ull;
         reserved = fnd ? kNoRow : rec.row;
       } else {
-        reserved = (c.spec_row && inb) ? c.spec_row[g] : kNoRow;
+        reserved = kNoRow;
         id = inb ? d.uids[g] : 0;
         cnt = inb ? d.ucnt[g] : 0u;
         hp = inb ? d.upos[g] : 0u;
@@ -1820,82 +1818,6 @@ struct SlowArgs {  // slowpath_role's arguments; enabled = 0: no displacement pa
 // ids per group of the forward lookup: 2 is the fastest shape (profiles/r01/f_lookup_sweep.jsonl); the host
 // picks 3 or 4 when that is what it takes to have every workgroup of the launch resident at once
 
-// Row handles for the ids of THIS batch that are not in the table yet, reserved one launch before
-// the update needs them.  Every allocation bumps ONE counter, and same-address atomics are served
-// one at a time (~18 ns each here): reserved per workgroup inside the update they were ~750 bumps
-// that paced step_bwd — its last allocation came back ~13 us after its first was issued.  Here a
-// lane takes one unique id (the dense numbering of the build role), probes its two buckets and
-// the workgroup reserves for all its misses with ONE bump: ~13 bumps per step.  Nothing inserts
-// between this launch and the update (the displacement pass of the previous update runs in front of
-// it, behind the same gate as the lookups), so a miss here is a miss there; an id evicted in
-// between simply finds no reservation and takes the update's own (per-workgroup) path.
-struct PreArgs {
-  const int64_t* uids;   // dense unique ids of this batch (build role)
-  const uint32_t* ctr;   // [0] their number
-  uint32_t* spec_row;    // out [n_max]
-  uint32_t n_max;
-  uint32_t nblk;         // workgroups of the role (0: off)
-};
-
-__device__ __forceinline__ void rd_prealloc_role(const TableView& tv, const PreArgs& p, uint32_t bid,
-                                                 WaveTrace& wt) {
-  __shared__ uint32_t sh_cnt[kRdBlock / 64];
-  __shared__ uint32_t sh_base;
-  const uint32_t t = threadIdx.x;
-  const int lane = t & 63;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  // (the count and the first trip's ids are fetched together: an index past the count reads a
-  // stale entry of the preallocated array and is dropped)
-  const uint32_t first = bid * kRdBlock + t;
-  int64_t id_next = p.uids[first < p.n_max ? first : 0u];
-  const uint32_t nu = min(p.n_max, p.ctr[0]);
-#pragma unroll 1
-  for (uint32_t u0 = bid * kRdBlock; u0 < nu; u0 += p.nblk * kRdBlock) {  // (workgroup-uniform)
-    const uint32_t u = u0 + t;
-    const bool in = u < nu;
-    const int64_t id = id_next;
-    {
-      const uint32_t un = u + p.nblk * kRdBlock;
-      id_next = p.uids[un < nu ? un : 0u];  // (the next trip's, in flight behind this one's probes)
-    }
-    const uint64_t hv = hash_key(id);
-    const uint64_t i1 = index_hash(tv.hp, hv);
-    const uint64_t i2 = alt_index(tv.hp, partial_key(hv), i1);
-    const GBucket* b1 = global_bucket(tv.buckets + i1);
-    const GBucket* b2 = global_bucket(tv.buckets + i2);
-    // (the eight keys as four 16-byte loads issued together, compared without short-circuit:
-    // `a || b` on loads lets the compiler fetch b only after a has come back and failed — eight
-    // round trips in a row)
-    typedef long long i64x2 __attribute__((ext_vector_type(2)));
-    const i64x2 a0 = *(const MHTE_GLOBAL i64x2*)(&b1->key[0]);
-    const i64x2 a1 = *(const MHTE_GLOBAL i64x2*)(&b1->key[2]);
-    const i64x2 c0 = *(const MHTE_GLOBAL i64x2*)(&b2->key[0]);
-    const i64x2 c1 = *(const MHTE_GLOBAL i64x2*)(&b2->key[2]);
-    const bool found = (a0.x == id) | (a0.y == id) | (a1.x == id) | (a1.y == id) | (c0.x == id) |
-                       (c0.y == id) | (c1.x == id) | (c1.y == id);
-    // (the one key that lives in the side slot is left to the update's own path)
-    const bool miss = in && id != kEmptyKey && !found;
-    const uint64_t mm = __ballot(miss);
-    wt.mark(0);
-    if (lane == 0) sh_cnt[w] = uint32_t(__popcll(mm));
-    lds_barrier();
-    wt.mark(1);
-    if (t == 0) {
-      unsigned long long tot = 0;
-      for (int i = 0; i < kRdBlock / 64; ++i) tot += sh_cnt[i];
-      sh_base = tot ? uint32_t(atomicAdd(&tv.ctr->alloc, (tot << 32) | tot)) : 0u;
-    }
-    lds_barrier();
-    wt.mark(2);
-    uint32_t base = sh_base;
-    for (int i = 0; i < w; ++i) base += sh_cnt[i];
-    base += uint32_t(__popcll(mm & ((1ull << lane) - 1ull)));
-    if (in) p.spec_row[u] = miss ? base : kNoRow;
-    wt.mark(3);
-    lds_barrier();  // (sh_cnt / sh_base are rewritten by the next trip)
-  }
-}
-
 // step_fwd:  run dedup of the NEXT batch | displacement pass of the previous update (one wavefront,
 //            the lookup workgroups gate on it) | lookup of this batch
 // (<= 80 SGPRs: with more, the hardware admits 7 wavefronts per SIMD and only ONE of these
@@ -1907,7 +1829,7 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
                                                             const int64_t* __restrict__ ids,
                                                             int64_t n, float* __restrict__ out,
                                                             int count_hits, SlowArgs sp,
-                                                            uint32_t nblk_l, PreArgs pre) {
+                                                            uint32_t nblk_l) {
   __shared__ __attribute__((aligned(16))) RdLds L;
   static_assert(sizeof(BfsSlot) * kMaxCuckooCount + sizeof(CuckooRecord) * kMaxBfsPathLen <=
                     sizeof(RdLds), "BFS scratch must fit the dedup's LDS");
@@ -1937,7 +1859,7 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
   // round trip (with the run dedup out of this launch — two batches of look-ahead — the lookups'
   // own chain ids -> buckets -> rows -> stores is what the launch lasts).
   const int64_t ngroups = (n + UNR - 1) / UNR;
-  const uint32_t lbid = bid - min(bid, pre.nblk);
+  const uint32_t lbid = bid;
   const int64_t g_first = (int64_t(lbid) * kRdBlock + threadIdx.x) / G;
   int64_t id_first;
   {
@@ -1961,12 +1883,6 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
     }
     __syncthreads();
   }
-  if (bid < pre.nblk) {  // (behind the gate: it reads the table)
-    rd_prealloc_role(tv, pre, bid, wt);
-    wt.end(9u);
-    return;
-  }
-  bid -= pre.nblk;
   if (g_first < ngroups) lookup_role_u<G, VEC, UNR, 2>(tv, ids, n, nullptr, out, count_hits, g_first, &id_first);
 #pragma unroll 1
   for (int64_t g = g_first + int64_t(nblk_l) * kRdBlock / G; g < ngroups;

@@ -20,8 +20,7 @@ TWO launches on one queue (mhte_table_step_forward / _backward, csrc/mhte_step_k
    forward   lookup(s)  | run dedup(s+1) | displacement pass of update s-1 (usually idle)
    backward  gradient sum + upsert + optimizer(s) | numbering, heavy work list and table probe(s+1)
              (the probe leaves every distinct id's row handle / slot, or a reserved row for an id the
-              table lacks: update s+1 reads no bucket and allocates nothing; ``reserve_ahead`` is
-              accepted and ignored — superseded)
+              table lacks: update s+1 reads no bucket and allocates nothing)
 
 different workgroups of one kernel doing the jobs (a dependency between two HIP queues costs ~10 us
 on this part, a kernel boundary on one queue ~2 us).  Batches of up to 65 536 ids.
@@ -54,9 +53,8 @@ class SparseStep:
 
   def __init__(self, table: MultiHashTable, table_name: str, batch: int,
                exact_order: bool = False, direct: bool = True, fused_backward: bool = True,
-               ordered_unique: bool = False, reserve_ahead: bool = False):
+               ordered_unique: bool = False):
     self.direct = direct
-    self.reserve_ahead = reserve_ahead
     self.fused_backward = fused_backward
     # the reference's first-occurrence numbering of the unique ids is only needed by the unfused
     # three-op forward (its gather indexes rows by that numbering) and by wide rows

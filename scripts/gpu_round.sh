@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit: parity tests, bench line, rocprofv3 kernel trace of a short bench.
 # Usage (from the repo root on the GPU box): bash scripts/gpu_round.sh <tag> [what...]
-#   what: tests smoke bench prof tl trace pmc calib next cfg1 dlrm dlrmdense dlrmprof dlrmpmc shard shardprof
+#   what: tests smoke bench drv prof tl trace pmc calib next cfg1 dlrm dlrmdense dlrmprof dlrmpmc shard shardprof ranks2
 #   (default: tests bench prof)
 set -u
 TAG=${1:-r01}; shift || true
@@ -89,6 +89,15 @@ shardprof)
   echo "shardprof rc=$?"
   db=$(find /tmp/sprof -name '*.db' | head -1)
   if [ -n "$db" ]; then python scripts/rocpd_stats.py $db $OUT/kernel_stats_sharded_n1.md | head -14; fi ;;
+drv)
+  # the line as the driver asks for it
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_driver_args.err
+  echo "drv rc=$?"; cut -c1-300 $OUT/bench_driver_args.json ;;
+ranks2)
+  # N = 2 as the driver launches it; on a 1-GPU box the two processes share the device (peer-store transport)
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
+    bench.py --gpus 2 --steps 200 --warmup 20 > $OUT/bench_2ranks.json 2> $OUT/bench_2ranks.err
+  echo "ranks2 rc=$?"; cut -c1-300 $OUT/bench_2ranks.json; tail -3 $OUT/bench_2ranks.err ;;
 next)
   # the rows next to the hot path: checkpoint, eviction, filter, gather, reductions, optimizers
   NEXT_ROWS_MD=$OUT/next_rows.md timeout 900 python scripts/next_rows_bench.py > $OUT/next_rows.jsonl 2> $OUT/next_rows.err
