@@ -214,20 +214,27 @@ static thread_local Prof g_prof;
     }                                                                                          \
   } while (0)
 
-// tables alive in this process, by their device counter block: a dedup workspace that holds row
-// reservations (ProbeOut.spec) gives their keys back when its batch is dropped — unless the table
-// went first
+// tables alive in this process, by their device counter block AND a serial number: a dedup
+// workspace that holds row reservations (ProbeOut.spec) gives their keys back when its batch is
+// dropped — unless the table went first.  (The address alone is not an identity: a table created
+// after another was closed gets the freed counter block back, and a workspace of the old table
+// would take its reservations off the NEW table's counts — seen as a size of keys - 2^32.)
 static std::mutex g_ctr_mu;
-static std::vector<const void*> g_live_ctrs;
-static void register_counters(const void* p, bool live) {
+static std::vector<std::pair<const void*, uint64_t>> g_live_ctrs;
+static uint64_t g_table_serial = 0;
+static uint64_t register_counters(const void* p) {
   std::lock_guard<std::mutex> g(g_ctr_mu);
-  auto it = std::find(g_live_ctrs.begin(), g_live_ctrs.end(), p);
-  if (live && it == g_live_ctrs.end()) g_live_ctrs.push_back(p);
-  if (!live && it != g_live_ctrs.end()) g_live_ctrs.erase(it);
+  g_live_ctrs.emplace_back(p, ++g_table_serial);
+  return g_table_serial;
 }
-static bool table_counters_alive(const void* p) {
+static void unregister_counters(const void* p, uint64_t serial) {
   std::lock_guard<std::mutex> g(g_ctr_mu);
-  return std::find(g_live_ctrs.begin(), g_live_ctrs.end(), p) != g_live_ctrs.end();
+  auto it = std::find(g_live_ctrs.begin(), g_live_ctrs.end(), std::make_pair(p, serial));
+  if (it != g_live_ctrs.end()) g_live_ctrs.erase(it);
+}
+static bool table_counters_alive(const void* p, uint64_t serial) {
+  std::lock_guard<std::mutex> g(g_ctr_mu);
+  return std::find(g_live_ctrs.begin(), g_live_ctrs.end(), std::make_pair(p, serial)) != g_live_ctrs.end();
 }
 
 // ------------------------------------------------------------------------------------------ dedup ws
@@ -336,7 +343,8 @@ struct DedupWs {
                                // needs in one load — incl. the row handle / slot of an id the table
                                // held when the batch was numbered, or a row reserved for it
   bool r_hints = false;        // r_urec describes the numbered batch
-  Counters* r_res_ctr = nullptr;   // the table whose rows the records reserve
+  Counters* r_res_ctr = nullptr;   // the table whose rows the records reserve ...
+  uint64_t r_res_serial = 0;       // ... and its serial number (register_counters)
   void probe_out_reserve(int64_t n) {
     const URec* old = r_urec.p;
     r_urec.reserve(size_t(n) + 1);
@@ -346,7 +354,7 @@ struct DedupWs {
   }
   // reservations of a numbered batch that is dropped instead of applied: the keys go back
   void drop_reservations(hipStream_t st) {
-    if (r_prealloc && r_stage == 2 && r_res_ctr && table_counters_alive(r_res_ctr))
+    if (r_prealloc && r_stage == 2 && r_res_ctr && table_counters_alive(r_res_ctr, r_res_serial))
       rd_unreserve_kernel<<<32, 256, 0, st>>>(r_urec.p, rv.n_unique, rv.n, r_res_ctr);
     r_prealloc = false;
     r_hints = false;
@@ -518,6 +526,7 @@ struct Table {
   uint32_t max_chunks = 0;
   uint32_t chunk_shift = 0;
   Counters* ctr = nullptr;
+  uint64_t ctr_serial = 0;      // identity of this table's counter block (register_counters)
   Counters* h_ctr = nullptr;  // pinned mirror
   uint64_t keys_upper = 0, rows_upper = 0;
   int64_t max_update_ts = 0;
@@ -560,7 +569,7 @@ struct Table {
     for (float* c : chunks) (void)hipFree(c);
     if (d_chunks) (void)hipFree(d_chunks);
     if (ctr) {
-      register_counters(ctr, false);
+      unregister_counters(ctr, ctr_serial);
       (void)hipFree(ctr);
     }
     if (h_ctr) (void)hipHostFree(h_ctr);
@@ -658,7 +667,7 @@ struct Table {
     HIP_OK(hipMemset(d_chunks, 0, sizeof(float*) * max_chunks));
     HIP_OK(hipMalloc(&ctr, sizeof(Counters)));
     HIP_OK(hipMemset(ctr, 0, sizeof(Counters)));
-    register_counters(ctr, true);
+    ctr_serial = register_counters(ctr);
     HIP_OK(hipHostMalloc(&h_ctr, sizeof(Counters), hipHostMallocDefault));
     memset(h_ctr, 0, sizeof(Counters));
     add_chunk();
@@ -1080,6 +1089,7 @@ struct Table {
       if (reserve) {
         ws.r_prealloc = true;
         ws.r_res_ctr = view.ctr;
+        ws.r_res_serial = ctr_serial;
       }
     }
     ApplyArgs a;
@@ -1188,6 +1198,7 @@ struct Table {
       ws_next->r_hints = true;
       ws_next->r_prealloc = reserve_next;
       ws_next->r_res_ctr = view.ctr;
+      ws_next->r_res_serial = ctr_serial;
     }
     if (le != hipSuccess) {
       ws.r_clean_cap = 0;

@@ -559,9 +559,34 @@ struct ShardStep {
   }
 
   // a data-less round trip with every peer: proves the windows are mapped and the flags travel
+  // Collective.  Three rounds of: credits (a data-less push: every peer's test region is free) ->
+  // pattern into every peer's window -> arrival published and awaited -> check of what the peers
+  // wrote here (shard_selftest_kernel).  A transport that loses, delays or caches the peers' stores
+  // fails HERE — and the caller falls back to RCCL — instead of training on stale rows.
   void ipc_selftest(hipStream_t st) {
-    push(kChTest, nullptr, ids_send[0], 0, false, st);
-    sync(uint32_t(kChTest), 0, world, st);
+    ShardSelftestArgs A{};
+    for (int p = 0; p < world; ++p) A.win[p] = peer_win[p];
+    A.off = win_off_grads;
+    A.blk = size_t(geo.rows_block) * 4;
+    A.flags = d_flags;
+    A.n16 = uint32_t(std::min<size_t>(4096, A.blk) / 16);
+    A.rank = uint32_t(rank);
+    if (const char* e = getenv("MHTE_SHARD_SELFTEST_CORRUPT")) A.corrupt = uint32_t(atoi(e));
+    for (uint32_t round = 0; round < 3; ++round) {
+      push(kChTest, nullptr, ids_send[0], 0, false, st);
+      A.round = round;
+      if (A.n16) {
+        A.check = 0;
+        shard_selftest_kernel<<<uint32_t(world), 256, 0, st>>>(A);
+        HIP_OK(hipGetLastError());
+      }
+      sync(uint32_t(kChTest), 0, world, st);
+      if (A.n16) {
+        A.check = 1;
+        shard_selftest_kernel<<<uint32_t(world), 256, 0, st>>>(A);
+        HIP_OK(hipGetLastError());
+      }
+    }
     HIP_OK(hipStreamSynchronize(st));
     check_flags();
   }
@@ -573,6 +598,12 @@ struct ShardStep {
       throw Error(MHTE_UNAVAILABLE, "shard step: a peer did not take part in an exchange within "
                                     "MHTE_SHARD_TIMEOUT_MS (its process is gone, or the ranks' calls "
                                     "are out of step); the step's results are not valid");
+    }
+    if (f & kShardSelftestBad) {
+      *reinterpret_cast<volatile uint32_t*>(h_flags) = 0;
+      throw Error(MHTE_UNAVAILABLE, "shard step: the peer-store self test read other data than a peer "
+                                    "wrote (stores into a mapped window are not arriving intact on this "
+                                    "system); use the RCCL transport");
     }
     if (f) {
       *reinterpret_cast<volatile uint32_t*>(h_flags) = 0;

@@ -456,6 +456,51 @@ __global__ __launch_bounds__(256) void shard_cvt_kernel(ShardCvtArgs A) {
   }
 }
 
+// Creation self test with DATA (ipc_selftest): round r, rank a -> peer b: a pattern of (r, a, b, word)
+// into the head of b's gradient block for sender a, with the push kernel's store form; b checks it
+// from its own window with plain loads in a launch of its own behind the sync — the path every real
+// exchange takes.  Several rounds over the SAME addresses with different patterns: a stale cached
+// copy of an earlier round, or stores that have not landed when `arrived` is seen, fail the check.
+enum : uint32_t { kShardSelftestBad = 4u };
+struct ShardSelftestArgs {
+  char* win[kMaxShards];
+  uint64_t off;               // byte offset of the gradient blocks inside a window
+  uint64_t blk;               // bytes between two senders' blocks
+  uint32_t* flags;
+  uint32_t n16;               // 16-byte words of the pattern
+  uint32_t rank, round, check;
+  uint32_t corrupt;           // test hook (MHTE_SHARD_SELFTEST_CORRUPT): the checker expects another round
+};
+__device__ __forceinline__ uint32_t selftest_word(uint32_t round, uint32_t from, uint32_t to, uint32_t i) {
+  uint32_t x = (round + 1u) * 0x9e3779b9u ^ (from * 0x85ebca6bu + to * 0xc2b2ae35u + i * 0x27d4eb2fu);
+  x ^= x >> 15;
+  x *= 0x2c1b3c6du;
+  x ^= x >> 12;
+  return x;
+}
+__global__ __launch_bounds__(256) void shard_selftest_kernel(ShardSelftestArgs A) {
+  const uint32_t p = blockIdx.x;   // the peer
+  if (!A.check) {
+    uint4* d = reinterpret_cast<uint4*>(A.win[p] + A.off + size_t(A.rank) * A.blk);
+    for (uint32_t i = threadIdx.x; i < A.n16; i += blockDim.x) {
+      __builtin_nontemporal_store(selftest_word(A.round, A.rank, p, 4 * i), &d[i].x);
+      __builtin_nontemporal_store(selftest_word(A.round, A.rank, p, 4 * i + 1), &d[i].y);
+      __builtin_nontemporal_store(selftest_word(A.round, A.rank, p, 4 * i + 2), &d[i].z);
+      __builtin_nontemporal_store(selftest_word(A.round, A.rank, p, 4 * i + 3), &d[i].w);
+    }
+    return;
+  }
+  const uint4* s = reinterpret_cast<const uint4*>(A.win[A.rank] + A.off + size_t(p) * A.blk);
+  const uint32_t r = A.round + A.corrupt;
+  bool bad = false;
+  for (uint32_t i = threadIdx.x; i < A.n16; i += blockDim.x) {
+    const uint4 v = s[i];
+    bad |= v.x != selftest_word(r, p, A.rank, 4 * i) || v.y != selftest_word(r, p, A.rank, 4 * i + 1) ||
+           v.z != selftest_word(r, p, A.rank, 4 * i + 2) || v.w != selftest_word(r, p, A.rank, 4 * i + 3);
+  }
+  if (__any(bad) && (threadIdx.x & 63u) == 0u) atomicOr(A.flags, uint32_t(kShardSelftestBad));
+}
+
 // one wavefront: (1) the pushes completed before this launch are published to every peer, (2) the
 // stream is held until peers [lo, hi) have published exchange `wait_seq` of `wait_chan`
 struct ShardSyncArgs {

@@ -1781,3 +1781,33 @@ def test_entry_ttl_by_slots(tmp_path):
   t3 = _ttl_table(1, 36500)
   t3.restore(base2)
   assert t3.lookup({"t": ids_t([id_1, id_2])})["t"].cpu().tolist() == [[0.0], [2.0]]
+
+
+def test_workspace_of_a_closed_table_does_not_touch_its_successor():
+  """A pipelined step leaves the NEXT batch numbered, with rows reserved in its table (the build
+  role's probe).  Dropping that workspace gives the reservations back — to ITS table only: a table
+  created after the first was closed may get the same device counter block, and must not be charged
+  (seen in scripts/next_rows_bench.py as a size of keys - 2^32)."""
+  import gc
+  n, dim = 4096, 16
+  a, b = S.id_batch(1, n, 10**6, "uniform"), S.id_batch(2, n, 10**6, "uniform")
+  for _ in range(3):   # (a few rounds: the allocator decides whether the address repeats)
+    mt1 = make({"emb": adagrad_cfg(dim, 0.01, 0.1)})
+    step1 = SparseStep(mt1, "emb", n)
+    step1.forward(ids_t(a), next_ids=ids_t(b))
+    step1.backward(val_t(S.grad_batch(0, n, dim)), S.update_time(0))   # batch b: numbered, rows reserved
+    assert mt1.size("emb") == np.unique(a).size
+    torch.cuda.synchronize()
+    mt1.close()
+    mt2 = make({"emb": adagrad_cfg(dim, 0.01, 0.1)})
+    del step1          # the old workspace goes after the new table exists
+    gc.collect()
+    assert mt2.size("emb") == 0
+    step2 = SparseStep(mt2, "emb", n)
+    step2.forward(ids_t(a), next_ids=ids_t(b))
+    step2.backward(val_t(S.grad_batch(0, n, dim)), S.update_time(0))
+    assert mt2.size("emb") == np.unique(a).size
+    del step2
+    gc.collect()
+    assert mt2.size("emb") == np.unique(a).size   # (its own dropped batch gave its reservations back)
+    mt2.close()

@@ -158,3 +158,35 @@ def test_unconnected_step_is_refused():
     _lib.check(L.mhte_shard_step_ipc_selftest(h0, None))
   assert ei.value.code == _lib.MHTE_FAILED_PRECONDITION
   L.mhte_shard_step_destroy(h0)
+
+
+def test_selftest_checks_the_data_not_only_the_flags(monkeypatch):
+  """The creation self test moves a pattern through every (sender, receiver) pair of windows, three
+  rounds over the same addresses, and checks it on the receiving side behind the sync — the path of a
+  real exchange.  With the checker told to expect another round's pattern (MHTE_SHARD_SELFTEST_CORRUPT)
+  it reports MHTE_UNAVAILABLE: what a transport whose stores arrive late or stale would get, and what
+  makes `transport="auto"` fall back to RCCL."""
+  import ctypes as C
+  sys.path.insert(0, HERE)
+  from monolith_amd import _lib
+  from test_multi_step_gpu import dlrm_specs, make
+  mt = make(dlrm_specs(2, initial_capacity=1 << 10))
+  L = mt._lib  # pylint: disable=protected-access
+
+  def connected():
+    h = C.c_void_p()
+    _lib.check(L.mhte_shard_step_create_ipc(mt.handle, C.c_int64(64), C.c_int32(0), C.c_int32(1), C.c_int64(0),
+                                            C.byref(h)))
+    b = C.create_string_buffer(128)
+    _lib.check(L.mhte_shard_step_ipc_handle(h, b))
+    _lib.check(L.mhte_shard_step_ipc_connect(h, b.raw, C.c_int32(1)))
+    return h
+
+  h = connected()
+  monkeypatch.setenv("MHTE_SHARD_SELFTEST_CORRUPT", "1")
+  with pytest.raises(_lib.MhteError) as ei:
+    _lib.check(L.mhte_shard_step_ipc_selftest(h, None))
+  assert ei.value.code == _lib.MHTE_UNAVAILABLE and "self test" in str(ei.value)
+  monkeypatch.delenv("MHTE_SHARD_SELFTEST_CORRUPT")
+  _lib.check(L.mhte_shard_step_ipc_selftest(h, None))   # the same step passes without the hook
+  L.mhte_shard_step_destroy(h)
