@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copies the artifacts of one full GPU visit (scripts/gpu_round.sh <tag> tests smoke bench drv prof pmc
-# calib trace dlrm dlrmprof dlrmpmc shard shardprof ranks2 cfg1 next) from gpurun_out/<tag>/ into
+# calib trace dlrm dlrmsps1 dlrmdense dlrmprof dlrmpmc shard shardprof ranks2 cfg1 next) from gpurun_out/<tag>/ into
 # profiles/<tag>/ under the names profiles/README.md lists, and regenerates profiles/pmc_traffic.json.
 set -u
 TAG=${1:?tag}; SRC=gpurun_out/$TAG; DST=profiles/$TAG
@@ -19,6 +19,8 @@ cpy calib_FETCH_SIZE.md pmc_calibration_FETCH_SIZE.md
 cpy calib_WRITE_SIZE.md pmc_calibration_WRITE_SIZE.md
 cpy trace_report.md wave_timeline.md
 cpy bench_dlrm26.json bench_dlrm26.json
+cpy bench_dlrm26_sps1.json bench_dlrm26_new_second_every_step.json
+cpy bench_dlrm26_dense.json bench_dlrm26_dense.json
 cpy prof_dlrm26_bench.json bench_dlrm26_under_rocprof.json
 cpy kernel_stats_dlrm26.md kernel_stats_dlrm26.md
 cpy bench_sharded_n1.json sharded_n1_identity_bench.json

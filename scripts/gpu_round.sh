@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit: parity tests, bench line, rocprofv3 kernel trace of a short bench.
 # Usage (from the repo root on the GPU box): bash scripts/gpu_round.sh <tag> [what...]
-#   what: tests smoke bench drv prof tl trace pmc calib next cfg1 dlrm dlrmdense dlrmprof dlrmpmc shard shardprof ranks2
+#   what: tests smoke bench drv prof tl trace pmc calib next cfg1 dlrm dlrmsps1 dlrmdense dlrmprof dlrmpmc shard shardprof ranks2
 #   (default: tests bench prof)
 set -u
 TAG=${1:-r01}; shift || true
@@ -62,6 +62,10 @@ cfg1)
 dlrm)
   timeout 900 python bench.py --config dlrm26 > $OUT/bench_dlrm26.json 2> $OUT/bench_dlrm26.err
   echo "dlrm rc=$?"; cut -c1-1500 $OUT/bench_dlrm26.json ;;
+dlrmsps1)
+  # a new update_time second on EVERY step: every touched id's timestamp store is due
+  timeout 900 python bench.py --config dlrm26 --steps-per-second 1 --no-cpu-baseline > $OUT/bench_dlrm26_sps1.json 2> $OUT/bench_dlrm26_sps1.err
+  echo "dlrmsps1 rc=$?"; cut -c1-300 $OUT/bench_dlrm26_sps1.json ;;
 dlrmdense)
   timeout 900 python bench.py --config dlrm26 --dense --no-cpu-baseline > $OUT/bench_dlrm26_dense.json 2> $OUT/bench_dlrm26_dense.err
   echo "dlrmdense rc=$?"; cut -c1-600 $OUT/bench_dlrm26_dense.json; python -c "import json,sys; print(json.load(open('$OUT/bench_dlrm26_dense.json'))['dense'])" ;;
