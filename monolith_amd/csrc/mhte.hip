@@ -747,6 +747,11 @@ struct Table {
     HIP_OK(hipStreamSynchronize(st));
     memset(h_ctr, 0, sizeof(Counters));
     keys_upper = rows_upper = 0;
+    // the row allocator starts over: a batch that was numbered and probed before (its records hold
+    // row handles and reservations of the old numbering) must not be applied with them, and must
+    // not give reservations "back" to the new counters — the table is a new one to such a workspace
+    unregister_counters(ctr, ctr_serial);
+    ctr_serial = register_counters(ctr);
   }
 
   void double_table(hipStream_t st) {
@@ -1070,6 +1075,15 @@ struct Table {
     if (ws.r_stage == 0 || int64_t(ws.rv.n) != n || ws.rv.uids != uids || ws.rv.n_unique != n_dev)
       throw Error(MHTE_FAILED_PRECONDITION,
                   "step_backward: workspace does not hold the run dedup of this batch");
+    // a probe of another table, or of this one before it was cleared (a restore between two steps):
+    // its row handles and reservations mean nothing here — probe again
+    if (ws.r_hints && (ws.r_res_ctr != view.ctr || ws.r_res_serial != ctr_serial)) {
+      ws.r_hints = false;
+      ws.r_prealloc = false;
+      ws.r_res_ctr = nullptr;
+      HIP_OK(hipMemsetAsync(ws.rv.ctr + 3, 0, sizeof(uint32_t), st));   // (its reservation count)
+      if (ws.r_stage == 2) rd_items_unhint_kernel<<<8, 256, 0, st>>>(ws.rv);
+    }
     // first step of a pipeline (later ones were numbered — and probed — a step ahead, inside the
     // previous update's launch)
     if (ws.r_stage == 1 || !ws.r_hints) {
@@ -1086,11 +1100,9 @@ struct Table {
       HIP_OK(hipGetLastError());
       ws.r_stage = 2;
       ws.r_hints = true;
-      if (reserve) {
-        ws.r_prealloc = true;
-        ws.r_res_ctr = view.ctr;
-        ws.r_res_serial = ctr_serial;
-      }
+      ws.r_res_ctr = view.ctr;
+      ws.r_res_serial = ctr_serial;
+      if (reserve) ws.r_prealloc = true;
     }
     ApplyArgs a;
     for (int i = 0; i < kMaxSegments; ++i) a.lr[i] = (lrs && i < int(nseg)) ? lrs[i] : 0.f;

@@ -980,6 +980,17 @@ __global__ __launch_bounds__(256) void rd_probe_kernel(RunView d, TableView tv, 
     if (have) po.urec[u] = rec;
   }
 }
+// a batch whose probe is void (its table was cleared — restored — after it was numbered): the heavy
+// work items forget what that probe left in their headers; rd_probe_kernel then probes the light ids
+// again and the items take the update's own probe / allocation path
+__global__ __launch_bounds__(256) void rd_items_unhint_kernel(RunView d) {
+  const uint32_t n = d.ctr[2];
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
+    d.item_hdr[w].row = kNoRow;
+    d.item_hdr[w].spec = kNoRow;
+    d.item_hdr[w].loc = 0ull;
+  }
+}
 // keys of reservations that will never be used (a numbered batch that is dropped instead of applied)
 // go back to the table's live-key count; the row handles stay stranded (rows are not recycled)
 __global__ __launch_bounds__(256) void rd_unreserve_kernel(const URec* __restrict__ urec,

@@ -1811,3 +1811,40 @@ def test_workspace_of_a_closed_table_does_not_touch_its_successor():
     gc.collect()
     assert mt2.size("emb") == np.unique(a).size   # (its own dropped batch gave its reservations back)
     mt2.close()
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_clear_between_numbering_and_update_voids_the_probe(exact):
+  """Clear() (what a restore starts with) resets the row allocator.  A batch that was numbered and
+  probed BEFORE it carries row handles of the old numbering — hints, and rows reserved for the ids the
+  table lacked; applied with them it would write into rows that the refilled table has handed to
+  other ids.  The step notices (the table's serial number moved) and probes again."""
+  n, dim = 20000, 16
+  b = [S.id_batch(60 + s_, n, 10**5, "zipf") for s_ in range(3)]
+  b[1][::3] = b[1][1]   # a heavy list: a work item whose header held a reservation
+  dev = [ids_t(x) for x in b]
+  mt = make({"emb": adagrad_cfg(dim, 0.01, 0.1)})
+  step = SparseStep(mt, "emb", n, exact_order=exact)
+  step.forward(dev[0], next_ids=dev[1])
+  step.backward(val_t(S.grad_batch(0, n, dim)), S.update_time(0))   # b[1]: numbered, probed, rows reserved
+  mt.clear_table("emb")
+  fill = np.arange(1, 30001, dtype=np.int64) * 7919 + (1 << 40)    # these get the first row handles now
+  vals = np.random.default_rng(3).standard_normal((fill.size, dim)).astype(np.float32)
+  mt.assign({"emb": (ids_t(fill), val_t(vals))}, req_time=5)
+  ot = O.Table(O.segment(dim, O.OPT_ADAGRAD, p=(0.1, 0.0)), 1)
+  ot.assign(fill, vals, 5)
+  emb = step.forward(dev[1], next_ids=dev[2])
+  np.testing.assert_array_equal(emb.cpu().numpy(), ot.lookup(b[1])[0])
+  g = S.grad_batch(1, n, dim)
+  step.backward(val_t(g), S.update_time(1))
+  _oracle_step(ot, b[1], g, dim, 0.01, S.update_time(1))
+  probe = np.unique(np.concatenate([fill, b[1]]))
+  got = mt.lookup({"emb": ids_t(probe)})["emb"].cpu().numpy()
+  exp = ot.lookup(probe)[0]
+  if exact:
+    np.testing.assert_array_equal(got, exp)
+  else:
+    np.testing.assert_allclose(got, exp, rtol=RTOL_TREE, atol=ATOL_TREE)
+  np.testing.assert_array_equal(got[np.isin(probe, fill) & ~np.isin(probe, b[1])],
+                                exp[np.isin(probe, fill) & ~np.isin(probe, b[1])])   # untouched rows: exact
+  assert mt.size("emb") == probe.size == ot.size()
