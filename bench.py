@@ -62,6 +62,9 @@ def parse():
                       "SGD, layout gradient -> sparse update; the next batch's dedup runs on a side "
                       "stream beside the GEMMs")
   p.add_argument("--mlp", default="1024,512,256", help="hidden widths of the dense model")
+  p.add_argument("--mlp-impl", default="mhte", choices=["mhte", "torch"],
+                 help="--dense: the tower through mhte_dense_mlp_* (this repo's bf16 MFMA GEMMs, default) or "
+                      "through torch / hipBLASLt (the A/B reference)")
   p.add_argument("--mlp-split", type=int, default=32,
                  help="dense model: weight gradients as a batched GEMM over this many slices of the "
                       "batch (0: torch.nn.Linear under autocast, one GEMM per gradient)")
@@ -401,21 +404,39 @@ def main_dlrm(args):
             h = torch.relu(h)
         return h
 
-    if args.mlp_split > 0:
+    dmlp = None
+    if args.mlp_impl == "mhte":
+      from monolith_amd.dense_mlp import DenseMlp
+      dmlp = DenseMlp(widths, max_batch=B)
+      for i, (a, b_) in enumerate(zip(widths[:-1], widths[1:])):
+        lin = torch.nn.Linear(a, b_)      # (the same initialisation as the torch form)
+        dmlp.set_params(i, lin.weight, lin.bias)
+      mlp = None
+    elif args.mlp_split > 0:
       mlp = Mlp(args.mlp_split).to(dev)
     else:
       layers = []
       for a, b_ in zip(widths[:-1], widths[1:]):
         layers += [torch.nn.Linear(a, b_), torch.nn.ReLU()]
       mlp = torch.nn.Sequential(*layers[:-1]).to(dev)
-    opt = torch.optim.SGD(mlp.parameters(), lr=1e-3)
+    opt = torch.optim.SGD(mlp.parameters(), lr=1e-3) if mlp is not None else None
     eoff = np.concatenate([[0], np.cumsum([B * d for d in dims])])
     dense = {"flops_per_step": 6 * B * sum(a * b_ for a, b_ in zip(widths[:-1], widths[1:])), "widths": widths}
 
     gflat = torch.empty(gsz, dtype=torch.float32, device=dev)
     gviews = [gflat[eoff[i]:eoff[i + 1]].view(B, dims[i]) for i in range(T)]
 
+    ybuf = torch.empty(B, dtype=torch.float32, device=dev)
+    dxbuf = torch.empty(B, kin, dtype=torch.float32, device=dev)
+    dy_mean = torch.full((B,), 1.0 / B, dtype=torch.float32, device=dev)   # loss = mean of the logits
+
     def mlp_step(x):
+      """forward + backward + SGD of the tower; -> gradient of the loss at x"""
+      if dmlp is not None:
+        dmlp.forward(x, out=ybuf)
+        return dmlp.backward(dy_mean, 1e-3, out=dxbuf)
+      x.requires_grad_(True)
+      x.grad = None
       if args.mlp_split > 0:
         y = mlp(x)
       else:
@@ -425,13 +446,13 @@ def main_dlrm(args):
       opt.zero_grad(set_to_none=True)
       loss.backward()
       opt.step()
+      return x.grad
 
     def dense_step(emb_flat):
       embs = [emb_flat[eoff[i]:eoff[i + 1]].view(B, dims[i]) for i in range(T)]
       x = DO.fused_embedding_to_layout(embs, fo, fe, nf, B, lcfg, one_fid_unique_rows=True)[0]
-      x.requires_grad_(True)
-      mlp_step(x)
-      DO.fused_embedding_to_layout_grad(embs, fo, fe, nf, B, [x.grad], lcfg, one_fid_unique_rows=True,
+      dx = mlp_step(x)
+      DO.fused_embedding_to_layout_grad(embs, fo, fe, nf, B, [dx], lcfg, one_fid_unique_rows=True,
                                         out=gviews)
       return gflat
 
@@ -522,14 +543,12 @@ def main_dlrm(args):
     e1.record()
     torch.cuda.synchronize()
     d_us = e0.elapsed_time(e1) * 1e3 / 10
-    xin = torch.randn(B, kin, device=dev, requires_grad=True)
+    xin = torch.randn(B, kin, device=dev)
     for _ in range(3):
-      xin.grad = None
       mlp_step(xin)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(10):
-      xin.grad = None
       mlp_step(xin)
     e1.record()
     torch.cuda.synchronize()
@@ -539,9 +558,11 @@ def main_dlrm(args):
                   "roofline": {"bound": "mfma", "achieved": round(dense["flops_per_step"] / m_us / 1e6, 1),
                                "peak": 2500.0, "unit": "TFLOP/s",
                                "frac": round(dense["flops_per_step"] / m_us / 1e6 / 2500.0, 4)},
-                  "note": "mlp_us: bf16 MLP forward + backward + SGD (hipBLASLt GEMMs through torch "
-                          "autocast, incl. its casts and elementwise kernels); flops = 6 * batch * "
-                          "sum(in * out); dense_leg_us adds the layout kernels either side"})
+                  "mlp_impl": ("mhte_dense_mlp_* (hand-written bf16 MFMA GEMMs, csrc/mhte_gemm_kernels.h)"
+                               if dmlp is not None else "torch / hipBLASLt"),
+                  "note": "mlp_us: bf16 MLP forward + backward + SGD incl. its casts, transposes and "
+                          "elementwise kernels; flops = 6 * batch * sum(in * out); dense_leg_us adds the "
+                          "layout kernels either side"})
   if not args.no_parity_check and dense is None:
     try:
       t0p = time.time()

@@ -42,7 +42,7 @@ enum {
 
 const char* mhte_last_error(void);
 /* ABI version of this header; mhte_abi_version() must return the same value. */
-#define MHTE_ABI_VERSION 13
+#define MHTE_ABI_VERSION 14
 int32_t mhte_abi_version(void);
 
 /* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
@@ -763,6 +763,30 @@ mhte_status mhte_fill_with_offset_map_gradient(const int64_t* pos, int64_t n, co
                                                int32_t offsets_vec4, float* backprop_grad,
                                                void* stream);
 
+/* ---- the dense tower downstream of the embedding path -------------------------------------------
+ * The ranking MLP that consumes fused_embedding_to_layout's output (native_training/layers/mlp.py:
+ * Dense + ReLU stack ending in one logit; its gradient feeds fused_embedding_to_layout_grad): bf16
+ * GEMMs on the matrix cores (csrc/mhte_gemm_kernels.h), fp32 master weights and accumulation, SGD
+ * inside backward.  widths[n]: input width, hidden widths, 1 (the last layer has ONE output); every
+ * width but the last and every batch are multiples of 128 (the GEMM tile).  Layer l in [0, n - 2]:
+ * weight [widths[l+1]][widths[l]] row-major (torch.nn.Linear's layout), bias [widths[l+1]].
+ *   forward   x [dev, batch x widths[0] fp32] -> y [dev, batch fp32]; keeps the activations
+ *   backward  dy [dev, batch fp32] (the loss gradient at the logit) -> SGD step with learning_rate on
+ *             every layer, dx [dev, batch x widths[0] fp32] when not NULL
+ * One stream at a time; forward and backward of a step on the same stream. */
+typedef struct mhte_dense_mlp mhte_dense_mlp;
+mhte_status mhte_dense_mlp_create(const int32_t* widths, int32_t n_widths, int64_t max_batch,
+                                  int32_t gpu_ordinal, mhte_dense_mlp** out);
+void mhte_dense_mlp_destroy(mhte_dense_mlp* m);
+mhte_status mhte_dense_mlp_set_params(mhte_dense_mlp* m, int32_t layer, const float* weight,
+                                      const float* bias, void* stream);
+mhte_status mhte_dense_mlp_get_params(mhte_dense_mlp* m, int32_t layer, float* weight, float* bias,
+                                      void* stream);
+mhte_status mhte_dense_mlp_forward(mhte_dense_mlp* m, const float* x, int64_t batch, float* y,
+                                   void* stream);
+mhte_status mhte_dense_mlp_backward(mhte_dense_mlp* m, const float* dy, float* dx,
+                                    float learning_rate, void* stream);
+
 /* ---- measurement aid (no reference counterpart) ---------------------------------------------
  * Kernel-exact timing of the hot kernels for bench.py's `roofline`: after mhte_profile_arm(n) the
  * next n launches of the step kernels made by the calling thread go through
@@ -770,7 +794,7 @@ mhte_status mhte_fill_with_offset_map_gradient(const int64_t* pos, int64_t n, co
  * on its queue (the interval rocprofv3 --kernel-trace reports).  mhte_profile_read disarms,
  * waits for the recorded launches and returns per launch the kernel tag and the duration in
  * microseconds.  Tags: 1 lookup_kernel, 2 sum_apply_kernel, 6 slowpath_kernel, 7 dd_* / rd_*
- * (dedup on its own), 8 upsert_kernel, 9 step_fwd_kernel, 10 step_bwd_kernel.
+ * (dedup on its own), 8 upsert_kernel, 9 step_fwd_kernel, 10 step_bwd_kernel, 19 gemm_nt_bf16_kernel.
  * Not for use inside a stream capture. */
 mhte_status mhte_profile_arm(int32_t n);
 mhte_status mhte_profile_read(int32_t cap, int32_t* kernel_tag, float* usec, int32_t* n_out);

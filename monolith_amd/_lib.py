@@ -26,7 +26,7 @@ MHTE_SUM_DUPLICATES = 2
 MHTE_EXACT_ORDER = 1       # flags of mhte_table_sum_optimize_n
 MHTE_DEFER_SLOWPATH = 2
 MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS = 1
-ABI_VERSION = 13           # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
+ABI_VERSION = 14           # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 OPT_MOMENTUM, OPT_ADADELTA, OPT_RMSPROP, OPT_RMSPROPV2, OPT_ADAM, OPT_AMSGRAD = 3, 4, 5, 6, 7, 8
@@ -158,6 +158,8 @@ EXPORTS = [
     "mhte_hash_filter_create_from_proto", "mhte_lookup_entry", "mhte_feature_stat",
     "mhte_advance_clock_for_testing", "mhte_hash_filter_save", "mhte_hash_filter_restore",
     "mhte_embedding_to_layout", "mhte_embedding_to_layout_grad",
+    "mhte_dense_mlp_create", "mhte_dense_mlp_destroy", "mhte_dense_mlp_set_params",
+    "mhte_dense_mlp_get_params", "mhte_dense_mlp_forward", "mhte_dense_mlp_backward",
 ]
 
 _lib = None
@@ -201,6 +203,8 @@ def lib():
     L.mhte_multi_step_destroy.argtypes = [C.c_void_p]
     L.mhte_shard_step_destroy.restype = None
     L.mhte_shard_step_destroy.argtypes = [C.c_void_p]
+    L.mhte_dense_mlp_destroy.restype = None
+    L.mhte_dense_mlp_destroy.argtypes = [C.c_void_p]
     L.mhte_hash_filter_destroy.argtypes = [C.c_void_p]
     L.mhte_multi_table_destroy.argtypes = [C.c_void_p]
     L.mhte_dedup_ws_destroy.argtypes = [C.c_void_p]
@@ -241,7 +245,7 @@ PROFILE_TAGS = {1: "lookup_kernel", 2: "sum_apply_kernel", 6: "slowpath_kernel",
                 8: "upsert_kernel", 9: "step_fwd_kernel", 10: "step_bwd_kernel",
                 11: "mstep_fwd_kernel", 12: "mstep_bwd_kernel", 13: "shard_build_kernel",
                 14: "shard_lookup_kernel", 15: "shard_scatter_kernel", 16: "shard_upsert_kernel",
-                17: "shard_push_kernel", 18: "shard_wait_kernel"}
+                17: "shard_push_kernel", 18: "shard_wait_kernel", 19: "gemm_nt_bf16_kernel"}
 TRACE_WORDS = 8
 TRACE_ROLES = {3: "run_dedup", 4: "displacement", 5: "lookup", 6: "work_list", 7: "apply_items",
                8: "apply_ids", 9: "reserve_rows"}

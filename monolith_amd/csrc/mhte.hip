@@ -39,6 +39,7 @@
 #include "mhte_step_kernels.h"
 #include "mhte_mstep_kernels.h"
 #include "mhte_shard_kernels.h"
+#include "mhte_gemm_kernels.h"
 
 namespace mhte {
 
@@ -166,7 +167,7 @@ enum ProfTag : int32_t {
   kTagSlowpath = 6, kTagDedup = 7, kTagUpsert = 8, kTagStepFwd = 9, kTagStepBwd = 10,
   kTagMStepFwd = 11, kTagMStepBwd = 12,
   kTagShardBuild = 13, kTagShardLookup = 14, kTagShardGather = 15, kTagShardUpsert = 16,
-  kTagShardPush = 17, kTagShardWait = 18
+  kTagShardPush = 17, kTagShardWait = 18, kTagGemm = 19
 };
 
 // Per-wavefront timeline of the step kernels (mhte_trace_begin / mhte_trace_end): each traced
@@ -1428,12 +1429,16 @@ static void ragged_upsert(mhte_multi_table* t, const int64_t* id, const int64_t*
 
 #include "mhte_mstep_host.h"
 #include "mhte_shard_host.h"
+#include "mhte_gemm_host.h"
 
 struct mhte_multi_step {
   mhte::MultiStep ms;
 };
 struct mhte_shard_step {
   mhte::ShardStep ss;
+};
+struct mhte_dense_mlp {
+  mhte::DenseMlp m;
 };
 
 using namespace mhte;
@@ -4338,6 +4343,59 @@ mhte_status mhte_profile_read(int32_t cap, int32_t* kernel_tag, float* usec, int
       if (kernel_tag) kernel_tag[i] = g_prof.tag[i];
       if (usec) usec[i] = ms * 1e3f;
     }
+  });
+}
+
+// ---- dense tower (mhte_gemm_host.h)
+mhte_status mhte_dense_mlp_create(const int32_t* widths, int32_t n_widths, int64_t max_batch,
+                                  int32_t gpu_ordinal, mhte_dense_mlp** out) {
+  return guard([&] {
+    if (!widths || !out) throw Error(MHTE_INVALID_ARGUMENT, "dense mlp: null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || gpu_ordinal < 0 || gpu_ordinal >= ndev)
+      throw Error(MHTE_UNAVAILABLE, "no such HIP device");
+    HIP_OK(hipSetDevice(gpu_ordinal));
+    std::unique_ptr<mhte_dense_mlp> m(new mhte_dense_mlp);
+    m->m.create(widths, n_widths, max_batch, gpu_ordinal);
+    *out = m.release();
+  });
+}
+void mhte_dense_mlp_destroy(mhte_dense_mlp* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->m.device);
+  (void)hipDeviceSynchronize();
+  delete m;
+}
+mhte_status mhte_dense_mlp_set_params(mhte_dense_mlp* m, int32_t layer, const float* weight,
+                                      const float* bias, void* stream) {
+  return guard([&] {
+    if (!m || !weight || !bias) throw Error(MHTE_INVALID_ARGUMENT, "dense mlp: null argument");
+    HIP_OK(hipSetDevice(m->m.device));
+    m->m.set_params(layer, weight, bias, S(stream));
+  });
+}
+mhte_status mhte_dense_mlp_get_params(mhte_dense_mlp* m, int32_t layer, float* weight, float* bias,
+                                      void* stream) {
+  return guard([&] {
+    if (!m || !weight || !bias) throw Error(MHTE_INVALID_ARGUMENT, "dense mlp: null argument");
+    HIP_OK(hipSetDevice(m->m.device));
+    m->m.get_params(layer, weight, bias, S(stream));
+  });
+}
+mhte_status mhte_dense_mlp_forward(mhte_dense_mlp* m, const float* x, int64_t batch, float* y,
+                                   void* stream) {
+  return guard([&] {
+    if (!m || !x || !y) throw Error(MHTE_INVALID_ARGUMENT, "dense mlp: null argument");
+    HIP_OK(hipSetDevice(m->m.device));
+    m->m.forward(x, batch, y, S(stream));
+  });
+}
+mhte_status mhte_dense_mlp_backward(mhte_dense_mlp* m, const float* dy, float* dx,
+                                    float learning_rate, void* stream) {
+  return guard([&] {
+    if (!m || !dy) throw Error(MHTE_INVALID_ARGUMENT, "dense mlp: null argument");
+    HIP_OK(hipSetDevice(m->m.device));
+    m->m.backward(dy, dx, learning_rate, S(stream));
   });
 }
 
