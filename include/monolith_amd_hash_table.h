@@ -667,13 +667,16 @@ mhte_status mhte_multi_step_unique_counts(mhte_multi_step* s, int64_t* counts, v
  * that never arrives makes mhte_shard_step_check / the next call return MHTE_UNAVAILABLE instead of
  * hanging the queue.  Creation is three calls: create_ipc (allocates the window), ipc_handle (128
  * bytes for the launcher to gather from every rank), ipc_connect (all ranks' handles, rank-major);
- * ipc_selftest is a data-less round trip with every peer (collective, synchronises).
+ * ipc_selftest moves a data pattern through every pair of windows, three rounds over the same
+ * addresses, checked on the receiving side (collective, synchronises; MHTE_UNAVAILABLE: use RCCL).
  * forward / backward arguments are those of mhte_multi_step_* for this rank's batch; `prefetched`
  * and the next batch must agree across the ranks (the calls are collective).  A table with an
  * occurrence filter is filtered on its OWNER: every id of a sender's block that the owner does not
  * hold asks the owner's filter with count 1 (ids of a block are distinct), as the reference's fused
- * optimize does per (sender, id); the filter's window moves between senders.  Tables with
- * whole-segment optimizers (GroupAdaGrad) are rejected.  global_step reaches the optimizers. */
+ * optimize does per (sender, id); the filter's window moves between senders.  Tables with the
+ * whole-segment optimizer (GroupAdaGrad) are accepted: the sender side does not look at the
+ * optimizer, the owner applies such a table's blocks with an instance of its own.  global_step
+ * reaches the optimizers. */
 typedef struct mhte_shard_step mhte_shard_step;
 mhte_status mhte_shard_unique_id(void* out128);
 mhte_status mhte_shard_step_create(mhte_multi_table* t, int64_t max_batch_per_table, int32_t rank,

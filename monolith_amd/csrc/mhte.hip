@@ -943,6 +943,9 @@ struct Table {
   bool fusable() const {
     for (uint32_t i = 0; i < nseg; ++i)
       if (view.seg[i].opt == kOptGroupAdagrad) return false;
+    return fusable_shape();
+  }
+  bool fusable_shape() const {   // the row fits one lane group
     Shape sh = pick_shape(dim, vec_ok);
     return dim <= uint32_t(sh.G * sh.VEC);
   }

@@ -54,7 +54,12 @@ static uint32_t shape_code(const Table& tb, uint64_t off_a = 0, uint64_t off_b =
                 "fits the fused step up to 64 floats");
   return uint32_t(sh.G) | (sh.VEC == 1 ? 1u : 0u);
 }
-static uint32_t shape_lanes(uint32_t code) { return code & ~1u; }
+static uint32_t shape_lanes(uint32_t code) { return code & ~3u; }
+// ... of the segment kernels (fused optimize, the sharded step's owner side): bit 1 = the table has
+// a whole-segment optimizer (GroupAdaGrad) — its own kernel instance (kShapeGroupBit)
+static uint32_t seg_shape_code(const Table& tb, uint64_t off_a = 0) {
+  return shape_code(tb, off_a) | (tb.has_group_opt ? uint32_t(kShapeGroupBit) : 0u);
+}
 
 // bump allocator over one hipMalloc (first pass with base == nullptr sizes it)
 struct Arena {
@@ -148,7 +153,9 @@ struct MultiStep {
     s.count_hits = tb.count_hits ? 1u : 0u;
   }
 
-  void init(mhte_multi_table* m, int64_t mb) {
+  // sender_roles_only: the id-sharded step uses this object for dedup / numbering / scatter / sums; the
+  // optimizers run on the owner (mhte_shard_host.h), so a whole-segment optimizer is no obstacle
+  void init(mhte_multi_table* m, int64_t mb, bool sender_roles_only = false) {
     mt = m;
     device = m->device;
     T = uint32_t(m->tables.size());
@@ -158,7 +165,7 @@ struct MultiStep {
                                              std::to_string(kRdMaxBlocks * kRdBlock));
     for (uint32_t t = 0; t < T; ++t) {
       const Table& tb = *m->tables[t];
-      if (!tb.fusable())
+      if (!tb.fusable() && !(sender_roles_only && tb.fusable_shape()))
         throw Error(MHTE_INVALID_ARGUMENT,
                     "multi step: table " + tb.name + " does not fit the fused step (per-element "
                     "optimizers — GroupAdaGrad needs the whole segment; rows of whole float4s up to "
@@ -658,12 +665,11 @@ struct MultiStep {
 // =================================================================================================
 // One-launch fused ops
 // =================================================================================================
-// true when every table can take the segment kernels (no whole-segment optimizer; rows of whole
-// float4s, or up to 64 floats of any layout)
+// true when every table can take the segment kernels (rows of whole float4s, or up to 64 floats of
+// any layout; tables with a whole-segment optimizer — GroupAdaGrad — go to their own instance)
 static bool seg_kernels_ok(const mhte_multi_table* t) {
   if (t->tables.size() > size_t(kMaxStepTables)) return false;
   for (auto& tb : t->tables) {
-    if (tb->has_group_opt) return false;
     Shape sh = pick_shape(tb->dim, tb->vec_ok);   // (other row layouts: one float per lane, up to 64)
     if (tb->dim > uint32_t(sh.G * sh.VEC)) return false;
   }
@@ -749,7 +755,7 @@ static void fused_optimize_segments(mhte_multi_table* t, const int64_t* ids,
         uint64_t worst = 0;
         for (int y = 0; y < ns; ++y)
           if ((s0 + y) % T == k && (uint32_t(grad_offsets[s0 + y]) % 4u)) worst = 1;
-        A.g[k] = uint8_t(shape_code(tb, worst));
+        A.g[k] = uint8_t(seg_shape_code(tb, worst));
       }
       A.pending[k] = tb.pending.p;
       ApplyArgs& a = A.a[k];
@@ -773,10 +779,12 @@ static void fused_optimize_segments(mhte_multi_table* t, const int64_t* ids,
     }
     if (gx == 0) continue;
     gx = std::min<uint32_t>(gx, 1024);
-    bool w4 = false, w1 = false;
-    for (int k = 0; k < T; ++k) ((A.g[k] & 1u) ? w1 : w4) = true;
-    if (w4) LAUNCH_HOT(kTagUpsert, seg_upsert_kernel<4>, dim3(gx, ns), 256, st, A);
-    if (w1) LAUNCH_HOT(kTagUpsert, seg_upsert_kernel<1>, dim3(gx, ns), 256, st, A);
+    bool inst[2][2] = {};   // [one float per lane][whole-segment optimizer]
+    for (int k = 0; k < T; ++k) inst[A.g[k] & 1u][(A.g[k] >> 1) & 1u] = true;
+    if (inst[0][0]) LAUNCH_HOT(kTagUpsert, (seg_upsert_kernel<4, false>), dim3(gx, ns), 256, st, A);
+    if (inst[1][0]) LAUNCH_HOT(kTagUpsert, (seg_upsert_kernel<1, false>), dim3(gx, ns), 256, st, A);
+    if (inst[0][1]) LAUNCH_HOT(kTagUpsert, (seg_upsert_kernel<4, true>), dim3(gx, ns), 256, st, A);
+    if (inst[1][1]) LAUNCH_HOT(kTagUpsert, (seg_upsert_kernel<1, true>), dim3(gx, ns), 256, st, A);
     seg_slow_kernel<<<T, 64, 0, st>>>(A);
     HIP_OK(hipGetLastError());
     for (int k = 0; k < T; ++k)

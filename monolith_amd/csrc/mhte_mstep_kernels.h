@@ -64,6 +64,9 @@ typedef const MHTE_CONST TableView* ConstViews;
   }
 // true when shape code `code` belongs to the instance of lane width VW
 #define MHTE_SHAPE_IS(VW, code) ((((code) & 1u) != 0u) == ((VW) == 1))
+// (segment kernels only) bit 1 of a shape code: the table has a whole-segment optimizer (GroupAdaGrad,
+// group_adagrad_segment) — served by the GROUP instance of seg_upsert_kernel / shard_upsert_kernel
+constexpr uint32_t kShapeGroupBit = 2u;
 
 struct MStepStatic {
   RunView rv[2];           // run-dedup workspaces: slot s holds the batch deduplicated into it
@@ -628,7 +631,7 @@ struct SegUpsertArgs {
 };
 static_assert(sizeof(SegUpsertArgs) <= 4096, "kernel arguments exceed 4 KB");
 
-template <int G, int VEC = 4>
+template <int G, int VEC = 4, bool GROUP = false>
 __device__ __forceinline__ void seg_upsert_loop(const TableView& tv, const int64_t* ids, uint32_t n,
                                                 const float* values, const ApplyArgs& a,
                                                 uint32_t* pending, uint32_t id_base, uint32_t seg) {
@@ -659,7 +662,7 @@ __device__ __forceinline__ void seg_upsert_loop(const TableView& tv, const int64
       pending[2 * slot + 1] = seg;
     }
     if (valid && !sr.deferred)
-      apply_row<G, VEC, kOpOptimize, false, false>(tv, row_ptr(tv, sr.r), sr.is_new, j, values, nullptr,
+      apply_row<G, VEC, kOpOptimize, false, GROUP>(tv, row_ptr(tv, sr.r), sr.is_new, j, values, nullptr,
                                                    0u, 1u, int64_t(g), a);
   }
 }
@@ -669,19 +672,19 @@ __device__ __forceinline__ void seg_upsert_loop(const TableView& tv, const int64
 #ifndef MHTE_SEGU_OCC
 #define MHTE_SEGU_OCC 4
 #endif
-template <int VW>
-__global__ __launch_bounds__(256, MHTE_SEGU_OCC) void seg_upsert_kernel(SegUpsertArgs A) {
+template <int VW, bool GROUP = false>
+__global__ __launch_bounds__(256, GROUP ? 1 : MHTE_SEGU_OCC) void seg_upsert_kernel(SegUpsertArgs A) {
   const uint32_t y = blockIdx.y;
   const uint32_t n = A.id_off[y + 1] - A.id_off[y];
   if (n == 0) return;
   const uint32_t t = (A.seg0 + y) % A.T;
-  if (!MHTE_SHAPE_IS(VW, A.g[t])) return;
+  if (!MHTE_SHAPE_IS(VW, A.g[t]) || ((A.g[t] & kShapeGroupBit) != 0u) != GROUP) return;
   const TableView& tv = deref_const(A.views + t);
   const int64_t* ids = A.ids + A.id_off[y];
   const float* values = A.grads + size_t(A.grad_off[y]);
   uint32_t* pend = A.pending[t];
-#define MHTE_SEGU_CALL(G_, V_) seg_upsert_loop<G_, V_>(tv, ids, n, values, A.a[t], pend, A.id_off[y], y)
-  MHTE_SWITCH_G(VW, A.g[t], MHTE_SEGU_CALL)
+#define MHTE_SEGU_CALL(G_, V_) seg_upsert_loop<G_, V_, GROUP>(tv, ids, n, values, A.a[t], pend, A.id_off[y], y)
+  MHTE_SWITCH_G(VW, A.g[t] & ~kShapeGroupBit, MHTE_SEGU_CALL)
 #undef MHTE_SEGU_CALL
 }
 
@@ -717,12 +720,18 @@ __global__ __launch_bounds__(64) void seg_slow_kernel(SegUpsertArgs A) {
     r = __shfl(r, 0);
     if (pos >= 0) {
       const float* values = A.grads + size_t(A.grad_off[seg]);
-      if (A.g[t] & 1u)
-        apply_row<64, 1, kOpOptimize, false, false>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
-                                                    1u, int64_t(gp - A.id_off[seg]), a);
-      else
-        apply_row<64, 4, kOpOptimize, false, false>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
-                                                    1u, int64_t(gp - A.id_off[seg]), a);
+      const bool grp = (A.g[t] & kShapeGroupBit) != 0u;   // (rare path: both forms in one kernel)
+      if (A.g[t] & 1u) {
+        if (grp) apply_row<64, 1, kOpOptimize, false, true>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
+                                                            1u, int64_t(gp - A.id_off[seg]), a);
+        else apply_row<64, 1, kOpOptimize, false, false>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
+                                                         1u, int64_t(gp - A.id_off[seg]), a);
+      } else {
+        if (grp) apply_row<64, 4, kOpOptimize, false, true>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
+                                                            1u, int64_t(gp - A.id_off[seg]), a);
+        else apply_row<64, 4, kOpOptimize, false, false>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
+                                                         1u, int64_t(gp - A.id_off[seg]), a);
+      }
     }
     __syncthreads();
   }

@@ -210,10 +210,11 @@ struct ShardStep {
     if (T > uint32_t(kMaxStepTables))
       throw Error(MHTE_INVALID_ARGUMENT, "shard step: at most " + std::to_string(kMaxStepTables) + " tables");
     if (!seg_kernels_ok(m))
-      throw Error(MHTE_INVALID_ARGUMENT, "shard step: every table needs per-element optimizers "
-                                         "(GroupAdaGrad takes the whole segment) and rows of whole "
-                                         "float4s up to 256 floats or of any layout up to 64");
-    ms.init(m, mb);
+      throw Error(MHTE_INVALID_ARGUMENT, "shard step: every table needs rows of whole float4s up to "
+                                         "256 floats or of any layout up to 64");
+    // (the sender side — dedup, numbering, scatter, gradient sums — does not look at the optimizer: a
+    // GroupAdaGrad table is fine here, its owner applies it with the whole-segment instance)
+    ms.init(m, mb, /*sender_roles_only=*/true);
     // default: a (peer, table) block can hold the whole batch, so no step can overflow one (the
     // reference's all-to-all is variable-sized and never drops an id).  A smaller capacity is the
     // caller's explicit choice (fixed-size RCCL blocks that cross the links whole).
@@ -743,7 +744,7 @@ struct ShardStep {
     A.flags = d_flags;
     fill_tabs(A.tab);
     for (uint32_t t = 0; t < T; ++t) {
-      A.g[t] = uint8_t(shape_code(*mt->tables[t]));
+      A.g[t] = uint8_t(seg_shape_code(*mt->tables[t]));
       A.count_hits[t] = mt->tables[t]->count_hits ? 1 : 0;
     }
   }
@@ -793,15 +794,17 @@ struct ShardStep {
     const uint32_t fill = std::max<uint32_t>(8, uint32_t(ms.num_cus) * 16 / T);
     gx = std::min(gx, fill);
     A.clear_ids = ids_send[slot];
-    bool w4 = false, w1 = false;
-    for (uint32_t t = 0; t < T; ++t) ((A.g[t] & 1u) ? w1 : w4) = true;
+    bool inst[2][2] = {};   // [one float per lane][whole-segment optimizer]
+    for (uint32_t t = 0; t < T; ++t) inst[A.g[t] & 1u][(A.g[t] >> 1) & 1u] = true;
     for (int p = 0; p < world; ++p) {
       wait_arrived(kXGrads, slot, p, p + 1, st);   // (a peer's block is applied as soon as it has landed)
       if (grad_bits == 16) cvt<false>(ids_recv[slot], own_grads16, apply_grads(), p, 1, st);
       A.peer = uint32_t(p);
       A.zero_headers = p == world - 1 ? 1u : 0u;
-      if (w4) LAUNCH_HOT(kTagShardUpsert, shard_upsert_kernel<4>, dim3(gx, T), 256, st, A);
-      if (w1) LAUNCH_HOT(kTagShardUpsert, shard_upsert_kernel<1>, dim3(gx, T), 256, st, A);
+      if (inst[0][0]) LAUNCH_HOT(kTagShardUpsert, (shard_upsert_kernel<4, false>), dim3(gx, T), 256, st, A);
+      if (inst[1][0]) LAUNCH_HOT(kTagShardUpsert, (shard_upsert_kernel<1, false>), dim3(gx, T), 256, st, A);
+      if (inst[0][1]) LAUNCH_HOT(kTagShardUpsert, (shard_upsert_kernel<4, true>), dim3(gx, T), 256, st, A);
+      if (inst[1][1]) LAUNCH_HOT(kTagShardUpsert, (shard_upsert_kernel<1, true>), dim3(gx, T), 256, st, A);
       shard_slow_kernel<<<T, 64, 0, st>>>(A);
       HIP_OK(hipGetLastError());
       for (uint32_t t = 0; t < T; ++t)   // the filter's window moves between senders (one filter for all tables)

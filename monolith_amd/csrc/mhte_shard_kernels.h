@@ -55,7 +55,7 @@ struct ShardOwnerArgs {
   int64_t* clear_ids;
   uint32_t* pending[kMaxStepTables];
   ShardTab tab[kMaxStepTables];
-  uint8_t g[kMaxStepTables];          // lane-group shape per table (MHTE_SWITCH_G)
+  uint8_t g[kMaxStepTables];          // lane-group shape per table (MHTE_SWITCH_G; | kShapeGroupBit)
   uint8_t count_hits[kMaxStepTables];
   ApplyArgs a[kMaxStepTables];
 };
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512) void shard_lookup_kernel(ShardOwnerArgs A) {
   float* out = A.rows + size_t(p) * A.geo.rows_block + tb.row_off;
   const int ch = A.count_hits[t];
 #define MHTE_SEGL_CALL(G_, V_) seg_lookup_loop<G_, V_>(tv, ids, n, out, ch)
-  MHTE_SWITCH_G(VW, A.g[t], MHTE_SEGL_CALL)
+  MHTE_SWITCH_G(VW, A.g[t] & ~kShapeGroupBit, MHTE_SEGL_CALL)
 #undef MHTE_SEGL_CALL
 }
 
@@ -120,12 +120,18 @@ __device__ __forceinline__ void shard_slow_role(const ShardOwnerArgs& A, uint32_
     }
     r = __shfl(r, 0);
     if (pos >= 0) {
-      if (A.g[t] & 1u)
-        apply_row<64, 1, kOpOptimize, false, false>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
-                                                    1u, int64_t(g), a);
-      else
-        apply_row<64, 4, kOpOptimize, false, false>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
-                                                    1u, int64_t(g), a);
+      const bool grp = (A.g[t] & kShapeGroupBit) != 0u;   // (rare path: both forms in one kernel)
+      if (A.g[t] & 1u) {
+        if (grp) apply_row<64, 1, kOpOptimize, false, true>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
+                                                            1u, int64_t(g), a);
+        else apply_row<64, 1, kOpOptimize, false, false>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
+                                                         1u, int64_t(g), a);
+      } else {
+        if (grp) apply_row<64, 4, kOpOptimize, false, true>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
+                                                            1u, int64_t(g), a);
+        else apply_row<64, 4, kOpOptimize, false, false>(tv, row_ptr(tv, r), true, lane, values, nullptr, 0u,
+                                                         1u, int64_t(g), a);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
@@ -137,10 +143,10 @@ __device__ __forceinline__ void shard_slow_role(const ShardOwnerArgs& A, uint32_
 // the 8-XCD part the other workgroups' bucket and pending-list stores sit in their XCDs' L2s until
 // the kernel ends — making them visible earlier is an L2 write-back per workgroup, measured 295 us
 // against 5 us for the extra launch.)
-template <int VW>
-__global__ __launch_bounds__(256, MHTE_SEGU_OCC) void shard_upsert_kernel(ShardOwnerArgs A) {
+template <int VW, bool GROUP = false>
+__global__ __launch_bounds__(256, GROUP ? 1 : MHTE_SEGU_OCC) void shard_upsert_kernel(ShardOwnerArgs A) {
   const uint32_t p = A.peer, t = blockIdx.y;
-  if (!MHTE_SHAPE_IS(VW, A.g[t])) return;
+  if (!MHTE_SHAPE_IS(VW, A.g[t]) || ((A.g[t] & kShapeGroupBit) != 0u) != GROUP) return;
   const uint32_t n = shard_block_count(A, p, t);
   if (n == 0) return;
   const ShardTab tb = A.tab[t];
@@ -149,8 +155,8 @@ __global__ __launch_bounds__(256, MHTE_SEGU_OCC) void shard_upsert_kernel(ShardO
   const float* values = A.rows + size_t(p) * A.geo.rows_block + tb.row_off;
   uint32_t* pend = A.pending[t];
   // (pending entry = (position in the block's table segment, unused))
-#define MHTE_SEGU_CALL(G_, V_) seg_upsert_loop<G_, V_>(tv, ids, n, values, A.a[t], pend, 0u, 0u)
-  MHTE_SWITCH_G(VW, A.g[t], MHTE_SEGU_CALL)
+#define MHTE_SEGU_CALL(G_, V_) seg_upsert_loop<G_, V_, GROUP>(tv, ids, n, values, A.a[t], pend, 0u, 0u)
+  MHTE_SWITCH_G(VW, A.g[t] & ~kShapeGroupBit, MHTE_SEGU_CALL)
 #undef MHTE_SEGU_CALL
 }
 

@@ -51,7 +51,10 @@ class Spec:
       o = {"sgd": lambda: entry.SgdOptimizer(lr),
            "adagrad": lambda: entry.AdagradOptimizer(lr, 0.1),
            "ftrl": lambda: entry.FtrlOptimizer(lr, 0.1, 1.0, l1_regularization=0.001,
-                                                   l2_regularization=0.001)}[opt]()
+                                                   l2_regularization=0.001),
+           # GroupAdaGrad: the one whole-segment optimizer (group_adagrad_optimizer.cc)
+           "group": lambda: entry.AdaGradWithGroupLassoOptimizer(lr, beta=1.0, initial_accumulator_value=0.1,
+                                                                 l2_regularization=0.001)}[opt]()
       parts.append(entry.CombineAsSegment(d, entry.ZerosInitializer(), o))
     ttl = getattr(self, "ttl_days", None)
     return entry.make_table_config(
@@ -65,6 +68,8 @@ class Spec:
         segs.append(O.segment(d, O.OPT_SGD))
       elif opt == "adagrad":
         segs.append(O.segment(d, O.OPT_ADAGRAD, p=(0.1, 0.0)))
+      elif opt == "group":
+        segs.append(O.segment(d, O.OPT_GROUP_ADAGRAD, p=(0.1, 1.0, 0.001, 0.0)))
       else:
         segs.append(O.segment(d, O.OPT_FTRL, p=(0.1, 1.0, 0.001, 0.001)))
     t = O.Table(segs if len(segs) > 1 else segs[0], int(self.kw.get("initial_capacity", 1)))
@@ -189,6 +194,16 @@ def bias_slice_specs():
           Spec("b_plain64", [(64, "adagrad", 0.01)], 2),
           Spec("c_bias32", [(1, "ftrl", 0.05), (32, "adagrad", 0.01)], 3),
           Spec("d_plain16", [(16, "adagrad", 0.01)], 4)]
+
+
+def group_opt_specs():
+  """Tables with the whole-segment optimizer GroupAdaGrad beside plain ones: a float4
+  row, a bias + group row of 17 floats (one float per lane), a row of two group segments."""
+  return [Spec("a_group16", [(16, "group", 0.02)], 1),
+          Spec("b_plain32", [(32, "adagrad", 0.01)], 2),
+          Spec("c_bias_group", [(1, "ftrl", 0.05), (16, "group", 0.02)], 3),
+          Spec("d_two_groups", [(8, "group", 0.02), (24, "group", 0.01)], 4),
+          Spec("e_plain64", [(64, "adagrad", 0.01)], 5)]
 
 
 @pytest.mark.parametrize("exact", [True, False])
@@ -451,13 +466,17 @@ def test_multi_step_errors():
 
 # =============================================================================== fused ops, one launch
 @pytest.mark.parametrize("shards,high_load", [(2, False), (8, False), (4, True)])
-def test_fused_ops_over_segments_match_per_table_ops(shards, high_load):
+def test_fused_ops_over_segments_match_per_table_ops(shards, high_load, with_group=False):
   """FusedLookup / FusedOptimize on [shard][table] segments (ids distinct inside a segment, as
   FusedReorderByIndices leaves them): the one-launch segment kernels against the oracle, which
   applies the segments one after the other like the reference's loop."""
   kw = dict(initial_capacity=1 << 12, max_load_factor=0.97) if high_load else dict(initial_capacity=1 << 14)
   specs = dlrm_specs(5, **kw)
   specs[3].segs = [(specs[3].dim, "adagrad", 0.02)]
+  if with_group:
+    specs = group_opt_specs()
+    for sp in specs:
+      sp.kw = kw
   mt = make(specs)
   by_name = sorted(specs, key=lambda s: s.name)
   T = len(by_name)
@@ -499,3 +518,11 @@ def test_fused_ops_over_segments_match_per_table_ops(shards, high_load):
     np.testing.assert_array_equal(mt.lookup({sp.name: ids_t(probe)})[sp.name].cpu().numpy(),
                                   ots[sp.name].lookup(probe)[0])
     assert mt.stats(sp.name).dropped == 0
+
+
+@pytest.mark.parametrize("shards,high_load", [(1, False), (3, True)])
+def test_fused_optimize_with_whole_segment_optimizer(shards, high_load):
+  """GroupAdaGrad tables in FusedOptimize's one-launch segment kernels (round 3: such a model took the
+  per-table op-level path): their own kernel instance (seg_upsert_kernel<VW, GROUP>), same launch
+  sequence, bit-exact vs the oracle — incl. the displacement pass at a high load factor."""
+  test_fused_ops_over_segments_match_per_table_ops(shards, high_load, with_group=True)

@@ -19,8 +19,8 @@ from monolith_amd import _lib, synthetic as S  # noqa: E402
 from monolith_amd.distributed_ps_sync import (ShardedMultiStep, ShardedStepGroup,  # noqa: E402
                                               shard_block_geometry)
 from monolith_amd.fused_step import MultiSparseStep  # noqa: E402
-from test_multi_step_gpu import (ATOL, RTOL, dlrm_specs, make, oracle_backward, ragged_of,  # noqa: E402
-                                 val_t)
+from test_multi_step_gpu import (ATOL, RTOL, dlrm_specs, group_opt_specs, make, oracle_backward,  # noqa: E402
+                                 ragged_of, val_t)
 
 
 def batch_of(specs, seed, n, universe, dist="zipf", skip=()):
@@ -345,3 +345,11 @@ def test_argument_errors():
   assert ei.value.code == _lib.MHTE_FAILED_PRECONDITION
   one._h = None  # pylint: disable=protected-access
   grp.close()
+
+
+@pytest.mark.parametrize("dist,world", [("uniform", 2), ("zipf", 3)])
+def test_group_whole_segment_optimizer_against_oracle(dist, world):
+  """GroupAdaGrad tables through the id-sharded step (round 3 refused them): the sender side is
+  optimizer-agnostic, the owner applies every peer's block with the whole-segment instance of its
+  upsert (shard_upsert_kernel<VW, GROUP>)."""
+  _group_against_oracle(group_opt_specs(), dist, world, False)
