@@ -206,7 +206,8 @@ mhte_status mhte_compute_fused_offsets(const mhte_multi_table* t, const int32_t*
  * embeddings [dev, total_embeddings from mhte_compute_fused_offsets];
  * embedding_splits [host, num_of_shards], id_offsets / embedding_offsets [host, N*T+1].
  * ONE launch over the N*T segments (the reference loops over the tables inside Shard() over the
- * shards, :150-196) when every table's row is made of float4s and <= 32 tables. */
+ * shards, :150-196) when the model has <= 32 tables whose rows are whole float4s (up to 256 floats)
+ * or of any layout up to 64 floats; otherwise table by table. */
 mhte_status mhte_fused_lookup(mhte_multi_table* t, const int64_t* ids,
                               const int32_t* fused_slot_size, int32_t num_of_shards,
                               int64_t req_time, float* embeddings, int64_t embeddings_len,
