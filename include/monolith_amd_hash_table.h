@@ -635,7 +635,8 @@ mhte_status mhte_multi_step_unique_counts(mhte_multi_step* s, int64_t* counts, v
  * (no insert) -> row blocks back -> scatter to the occurrences; gradients: per-id sums in
  * occurrence order -> row-shaped blocks to the owners -> every owner applies the peers' blocks one
  * after the other in rank order (the reference's default of one optimizer application per
- * sender).  Three exchanges per step, all tables in each.
+ * sender).  Three exchanges per step, all tables in each.  Any number of tables (tables x world <=
+ * 65535): the kernels of a stage take 32 tables per launch, the exchanges carry all of them.
  *   ids_per_peer_table  id slots per (peer, table) block; 0 (default) = max_batch: a block can hold
  *                       the whole batch, so no step can overflow one and no id is ever dropped —
  *                       the reference's all-to-all is variable-sized.  A smaller value is an explicit

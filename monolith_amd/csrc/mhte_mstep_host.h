@@ -667,13 +667,17 @@ struct MultiStep {
 // =================================================================================================
 // true when every table can take the segment kernels (rows of whole float4s, or up to 64 floats of
 // any layout; tables with a whole-segment optimizer — GroupAdaGrad — go to their own instance)
-static bool seg_kernels_ok(const mhte_multi_table* t) {
-  if (t->tables.size() > size_t(kMaxStepTables)) return false;
+static bool seg_shapes_ok(const mhte_multi_table* t) {
   for (auto& tb : t->tables) {
     Shape sh = pick_shape(tb->dim, tb->vec_ok);   // (other row layouts: one float per lane, up to 64)
     if (tb->dim > uint32_t(sh.G * sh.VEC)) return false;
   }
   return true;
+}
+// ... and the model fits one launch of the fused lookup / optimize ops (the id-sharded step chunks its
+// launches instead: mhte_shard_host.h)
+static bool seg_kernels_ok(const mhte_multi_table* t) {
+  return t->tables.size() <= size_t(kMaxStepTables) && seg_shapes_ok(t);
 }
 
 static void fused_lookup_segments(mhte_multi_table* t, const int64_t* ids, const int32_t* ko,

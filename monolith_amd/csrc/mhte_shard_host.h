@@ -99,6 +99,14 @@ struct ShardStep {
   uint32_t T = 0;
   ShardGeom geo{};
   std::vector<ShardTab> tab;
+  ShardTab* d_tab = nullptr;    // the same on the device (push / cvt kernels)
+  mutable std::vector<ShardGatherTab> gt_all;   // gather_tabs: all T tables of a launch group
+  struct OwnerChunk {           // owner_apply: the arguments of tables [c * kMaxStepTables, ...)
+    ShardOwnerArgs A;
+    uint32_t tc, gx;
+    bool inst[2][2];            // [one float per lane][whole-segment optimizer]
+  };
+  std::vector<OwnerChunk> apply_chunks;
   int64_t max_batch = 0;
   uint32_t cap = 0;             // id slots per (peer, table)
   // device memory
@@ -181,6 +189,7 @@ struct ShardStep {
       if (ids_recv[s] && !alias && !ipc) (void)hipFree(ids_recv[s]);
       if (slot_off[s]) (void)hipFree(slot_off[s]);
     }
+    if (d_tab) (void)hipFree(d_tab);
     if (own_rows) (void)hipFree(own_rows);
     if (snd_rows && !alias && !ipc) (void)hipFree(snd_rows);
     if (ipc && snd_grads) (void)hipFree(snd_grads);
@@ -207,9 +216,10 @@ struct ShardStep {
     if (world < 1 || world > kMaxShards || rank < 0 || rank >= world)
       throw Error(MHTE_INVALID_ARGUMENT, "shard step: rank / world out of range (world <= " +
                                              std::to_string(kMaxShards) + ")");
-    if (T > uint32_t(kMaxStepTables))
-      throw Error(MHTE_INVALID_ARGUMENT, "shard step: at most " + std::to_string(kMaxStepTables) + " tables");
-    if (!seg_kernels_ok(m))
+    // (any number of tables: the launches take kMaxStepTables of them each — table_chunks)
+    if (T < 1 || uint64_t(T) * uint64_t(world) > 65535ull)
+      throw Error(MHTE_INVALID_ARGUMENT, "shard step: tables x world must be 1..65535");
+    if (!seg_shapes_ok(m))
       throw Error(MHTE_INVALID_ARGUMENT, "shard step: every table needs rows of whole float4s up to "
                                          "256 floats or of any layout up to 64");
     // (the sender side — dedup, numbering, scatter, gradient sums — does not look at the optimizer: a
@@ -240,6 +250,8 @@ struct ShardStep {
                                          "ids_per_peer_table");
     geo.ids_block = uint32_t((idw + 1) & ~uint64_t(1));
     geo.rows_block = uint32_t(rw);
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&d_tab), sizeof(ShardTab) * T));
+    HIP_OK(hipMemcpy(d_tab, tab.data(), sizeof(ShardTab) * T, hipMemcpyHostToDevice));
     alias = world == 1 && unique_id == nullptr && !ipc;
     const size_t ib = size_t(geo.ids_block) * world * sizeof(int64_t);
     const size_t rb = size_t(geo.rows_block) * world * sizeof(float);
@@ -325,7 +337,7 @@ struct ShardStep {
     A.geo = geo;
     A.peer_lo = uint32_t(peer_lo);
     A.peer_n = uint32_t(peer_n);
-    fill_tabs(A.tab);
+    A.tab = d_tab;
     uint32_t gx = 1;
     for (uint32_t t = 0; t < T; ++t) gx = std::max(gx, (cap * tab[t].dim / 4u + 1023u) / 1024u);
     gx = std::min<uint32_t>(gx, std::max<uint32_t>(4, uint32_t(ms.num_cus) * 4 / (uint32_t(peer_n) * T)));
@@ -489,7 +501,7 @@ struct ShardStep {
     A.seq = ++seq_sent[chan];
     A.ids = ids ? 1u : 0u;
     A.half = half ? 1u : 0u;
-    fill_tabs(A.tab);
+    A.tab = d_tab;
     // enough workgroups per peer to keep a link (or the local HBM) busy, few enough that a waiting
     // launch never fills the chip (another process may share the device)
     const size_t blk = ids ? size_t(geo.ids_block) * 8 : size_t(geo.rows_block) * 4;
@@ -628,8 +640,10 @@ struct ShardStep {
     ms.sync_static(st);
   }
 
-  void fill_tabs(ShardTab* dst) const {
-    for (uint32_t t = 0; t < T; ++t) dst[t] = tab[t];
+  // tables [t0, t0 + tc) of one launch
+  uint32_t chunk_tables(uint32_t t0) const { return std::min<uint32_t>(uint32_t(kMaxStepTables), T - t0); }
+  void fill_tabs(ShardTab* dst, uint32_t t0, uint32_t tc) const {
+    for (uint32_t i = 0; i < tc; ++i) dst[i] = tab[t0 + i];
   }
 
   // ---- sender: run dedup of (ids, split) into `slot` (stage 1)
@@ -643,13 +657,14 @@ struct ShardStep {
     ids_exchanged[slot] = false;
   }
 
-  void gather_tabs(ShardGatherTab* gt, int slot, uint32_t* gx_out) const {
+  // -> gt_all[T]: the workgroup shares are of the whole model (every chunk's launches run together)
+  void gather_tabs(int slot) const {
+    ShardGatherTab* gt = (gt_all.assign(T, ShardGatherTab{}), gt_all.data());
     uint32_t active = 0;
     for (uint32_t t = 0; t < T; ++t) active += ms.n_slot[slot][t] ? 1u : 0u;
     const uint32_t budget = uint32_t(kBwdBlocksPerCu * ms.num_cus);
     const uint32_t share = std::max<uint32_t>(32, budget * (active > 1 ? ms.ovs : 1u) / std::max(1u, active));
     int64_t off = 0;
-    uint32_t gx = 0;
     for (uint32_t t = 0; t < T; ++t) {
       ShardGatherTab& g = gt[t];
       const uint32_t n = ms.n_slot[slot][t];
@@ -667,11 +682,9 @@ struct ShardStep {
                                                            std::max<uint32_t>(8, share / 4)));
       const uint32_t need = (n + groups_per_wg - 1) / groups_per_wg;
       g.nblk_ids = std::max<uint32_t>(1, std::min(need, share));
-      gx = std::max(gx, g.nblk_items + g.nblk_ids);
     }
     if (uint64_t(off) > 0xffffffffull)
       throw Error(MHTE_INVALID_ARGUMENT, "shard step: flat buffer exceeds 2^32 floats");
-    *gx_out = gx;
   }
 
   // ---- sender: [gradient sums of the batch in sum_slot -> row slots] | [numbering + owner packing
@@ -682,15 +695,14 @@ struct ShardStep {
     A.geo = geo;
     A.flags = d_flags;
     A.n_max = uint32_t(max_batch);
-    fill_tabs(A.tab);
+    gt_all.assign(T, ShardGatherTab{});
     if (sum_slot >= 0) {
       A.grads = grads;
       A.rows_out = snd_grads;
       A.slot_off = slot_off[sum_slot];
       A.slot = uint32_t(sum_slot);
-      uint32_t gx_sum = 0;   // (the grid below is the per-table maximum of build + sum blocks)
-      gather_tabs(A.gt, sum_slot, &gx_sum);
-    }
+      gather_tabs(sum_slot);
+    }   // (no sums: shape code 0, the numbering alone runs in the float4 instance)
     if (build_slot >= 0) {
       if (hdr_dirty[build_slot])   // (a batch that was packed and never trained)
         HIP_OK(hipMemset2DAsync(ids_send[build_slot], size_t(geo.ids_block) * 8, 0, size_t(T) * 8,
@@ -698,21 +710,29 @@ struct ShardStep {
       A.send_ids = ids_send[build_slot];
       A.slot_off_build = slot_off[build_slot];
       A.build_slot = uint32_t(build_slot);
-      for (uint32_t t = 0; t < T; ++t) A.n_build[t] = ms.n_slot[build_slot][t];
       hdr_dirty[build_slot] = true;
       ms.stage[build_slot] = 2;
       disp[build_slot] = true;
     }
-    uint32_t gx = 0;
-    for (uint32_t t = 0; t < T; ++t)
-      gx = std::max(gx, (A.n_build[t] ? ms.h_st[t].nblk_build : 0u) + A.gt[t].nblk_items + A.gt[t].nblk_ids);
-    if (!gx) return;
-    // (one instance of the kernel per lane width among the tables: mhte_mstep_kernels.h MHTE_SWITCH_G)
-    bool w4 = false, w1 = false;
-    for (uint32_t t = 0; t < T; ++t) ((A.gt[t].gv & 1u) ? w1 : w4) = true;
-    if (w4) LAUNCH_HOT(kTagShardBuild, shard_build_kernel<4>, dim3(gx, T), 256, st, A);
-    if (w1) LAUNCH_HOT(kTagShardBuild, shard_build_kernel<1>, dim3(gx, T), 256, st, A);
-    HIP_OK(hipGetLastError());
+    for (uint32_t t0 = 0; t0 < T; t0 += uint32_t(kMaxStepTables)) {
+      const uint32_t tc = chunk_tables(t0);
+      A.t0 = t0;
+      fill_tabs(A.tab, t0, tc);
+      uint32_t gx = 0;   // (the grid is the per-table maximum of build + sum blocks)
+      bool w4 = false, w1 = false;
+      for (uint32_t i = 0; i < tc; ++i) {
+        const uint32_t t = t0 + i;
+        A.gt[i] = gt_all[t];
+        A.n_build[i] = build_slot >= 0 ? ms.n_slot[build_slot][t] : 0u;
+        gx = std::max(gx, (A.n_build[i] ? ms.h_st[t].nblk_build : 0u) + A.gt[i].nblk_items + A.gt[i].nblk_ids);
+        // (one instance of the kernel per lane width among the tables: mhte_mstep_kernels.h MHTE_SWITCH_G)
+        ((A.gt[i].gv & 1u) ? w1 : w4) = true;
+      }
+      if (!gx) continue;
+      if (w4) LAUNCH_HOT(kTagShardBuild, shard_build_kernel<4>, dim3(gx, tc), 256, st, A);
+      if (w1) LAUNCH_HOT(kTagShardBuild, shard_build_kernel<1>, dim3(gx, tc), 256, st, A);
+      HIP_OK(hipGetLastError());
+    }
   }
 
   void scatter(float* out, int slot, hipStream_t st) {
@@ -724,46 +744,60 @@ struct ShardStep {
     A.slot_off = slot_off[slot];
     A.slot = uint32_t(slot);
     A.n_max = uint32_t(max_batch);
-    fill_tabs(A.tab);
-    uint32_t gx = 0;
-    gather_tabs(A.gt, slot, &gx);
-    if (!gx) return;
-    bool w4 = false, w1 = false;
-    for (uint32_t t = 0; t < T; ++t)
-      if (A.gt[t].n) ((A.gt[t].gv & 1u) ? w1 : w4) = true;
-    if (w4) LAUNCH_HOT(kTagShardGather, shard_scatter_kernel<4>, dim3(gx, T), 256, st, A);
-    if (w1) LAUNCH_HOT(kTagShardGather, shard_scatter_kernel<1>, dim3(gx, T), 256, st, A);
-    HIP_OK(hipGetLastError());
+    gather_tabs(slot);
+    for (uint32_t t0 = 0; t0 < T; t0 += uint32_t(kMaxStepTables)) {
+      const uint32_t tc = chunk_tables(t0);
+      A.t0 = t0;
+      A.tc = tc;
+      fill_tabs(A.tab, t0, tc);
+      uint32_t gx = 0;
+      bool w4 = false, w1 = false;
+      for (uint32_t i = 0; i < tc; ++i) {
+        A.gt[i] = gt_all[t0 + i];
+        gx = std::max(gx, A.gt[i].nblk_items + A.gt[i].nblk_ids);
+        if (A.gt[i].n) ((A.gt[i].gv & 1u) ? w1 : w4) = true;
+      }
+      if (!gx) continue;
+      if (w4) LAUNCH_HOT(kTagShardGather, shard_scatter_kernel<4>, dim3(gx, tc), 256, st, A);
+      if (w1) LAUNCH_HOT(kTagShardGather, shard_scatter_kernel<1>, dim3(gx, tc), 256, st, A);
+      HIP_OK(hipGetLastError());
+    }
   }
 
-  void owner_args(ShardOwnerArgs& A, int slot, bool apply) const {
+  // arguments of the owner-side launches for tables [t0, t0 + tc)
+  void owner_args(ShardOwnerArgs& A, int slot, bool apply, uint32_t t0, uint32_t tc) const {
     A.views = ConstViews(mt->d_views.p);
     A.geo = geo;
     A.recv_ids = ids_recv[slot];
     A.rows = apply ? apply_grads() : own_rows;
     A.flags = d_flags;
-    fill_tabs(A.tab);
-    for (uint32_t t = 0; t < T; ++t) {
-      A.g[t] = uint8_t(seg_shape_code(*mt->tables[t]));
-      A.count_hits[t] = mt->tables[t]->count_hits ? 1 : 0;
+    A.t0 = t0;
+    A.tc = tc;
+    fill_tabs(A.tab, t0, tc);
+    for (uint32_t i = 0; i < tc; ++i) {
+      A.g[i] = uint8_t(seg_shape_code(*mt->tables[t0 + i]));
+      A.count_hits[i] = mt->tables[t0 + i]->count_hits ? 1 : 0;
     }
   }
 
   void owner_lookup(int slot, hipStream_t st) {
     wait_arrived(kXIds, slot, 0, world, st);
-    ShardOwnerArgs A{};
-    owner_args(A, slot, false);
-    uint32_t gx = 1;
-    for (uint32_t t = 0; t < T; ++t)
-      gx = std::max(gx, uint32_t((uint64_t((cap + 1) / 2) * shape_lanes(A.g[t]) + 511) / 512));
-    // (grid-stride inside: enough workgroups to fill the chip a few times over, not one per slot)
-    const uint32_t fill = std::max<uint32_t>(8, uint32_t(ms.num_cus) * 16 / (uint32_t(world) * T));
-    gx = std::min(gx, fill);
-    bool w4 = false, w1 = false;
-    for (uint32_t t = 0; t < T; ++t) ((A.g[t] & 1u) ? w1 : w4) = true;
-    if (w4) LAUNCH_HOT(kTagShardLookup, shard_lookup_kernel<4>, dim3(gx, uint32_t(world) * T), 512, st, A);
-    if (w1) LAUNCH_HOT(kTagShardLookup, shard_lookup_kernel<1>, dim3(gx, uint32_t(world) * T), 512, st, A);
-    HIP_OK(hipGetLastError());
+    for (uint32_t t0 = 0; t0 < T; t0 += uint32_t(kMaxStepTables)) {
+      const uint32_t tc = chunk_tables(t0);
+      ShardOwnerArgs A{};
+      owner_args(A, slot, false, t0, tc);
+      uint32_t gx = 1;
+      for (uint32_t i = 0; i < tc; ++i)
+        gx = std::max(gx, uint32_t((uint64_t((cap + 1) / 2) * shape_lanes(A.g[i]) + 511) / 512));
+      // (grid-stride inside: enough workgroups to fill the chip a few times over, not one per slot)
+      const uint32_t fill = std::max<uint32_t>(8, uint32_t(ms.num_cus) * 16 / (uint32_t(world) * tc));
+      gx = std::min(gx, fill);
+      bool w4 = false, w1 = false;
+      for (uint32_t i = 0; i < tc; ++i) ((A.g[i] & 1u) ? w1 : w4) = true;
+      if (w4) LAUNCH_HOT(kTagShardLookup, shard_lookup_kernel<4>, dim3(gx, uint32_t(world) * tc), 512, st, A);
+      if (w1) LAUNCH_HOT(kTagShardLookup, shard_lookup_kernel<1>, dim3(gx, uint32_t(world) * tc), 512, st, A);
+      HIP_OK(hipGetLastError());
+    }
   }
 
   void owner_apply(int slot, const float* lrs, int64_t update_time, int64_t global_step, hipStream_t st) {
@@ -775,38 +809,50 @@ struct ShardStep {
     }
     sync_views(mt, st);
     wait_arrived(kXIds, slot, 0, world, st);
-    ShardOwnerArgs A{};
-    owner_args(A, slot, true);
+    // one set of arguments per kMaxStepTables tables; the same for every peer but `peer` / `zero_headers`
+    std::vector<OwnerChunk>& chunks = apply_chunks;
+    chunks.resize((T + uint32_t(kMaxStepTables) - 1) / uint32_t(kMaxStepTables));
     int64_t lr_off = 0;
-    uint32_t gx = 1;
-    for (uint32_t t = 0; t < T; ++t) {
-      Table& tb = *mt->tables[t];
-      A.pending[t] = tb.pending.p;
-      ApplyArgs& a = A.a[t];
-      for (int i = 0; i < kMaxSegments; ++i) a.lr[i] = (i < int(tb.nseg)) ? lrs[lr_off + i] : 0.f;
-      lr_off += tb.nseg;
-      a.ts = static_cast<uint32_t>(update_time);
-      a.sum_dups = 0;
-      a.filter_mode = tb.flt_slots ? 1 : 0;   // an owner asks its filter about every id it does not hold
-      a.global_step = global_step;
-      gx = std::max(gx, (cap + 256u / shape_lanes(A.g[t]) - 1) / (256u / shape_lanes(A.g[t])));
+    for (size_t c = 0; c < chunks.size(); ++c) {
+      OwnerChunk& k = chunks[c];
+      const uint32_t t0 = uint32_t(c) * uint32_t(kMaxStepTables);
+      k = OwnerChunk{};
+      k.tc = chunk_tables(t0);
+      ShardOwnerArgs& A = k.A;
+      owner_args(A, slot, true, t0, k.tc);
+      uint32_t gx = 1;
+      for (uint32_t i = 0; i < k.tc; ++i) {
+        Table& tb = *mt->tables[t0 + i];
+        A.pending[i] = tb.pending.p;
+        ApplyArgs& a = A.a[i];
+        for (int j = 0; j < kMaxSegments; ++j) a.lr[j] = (j < int(tb.nseg)) ? lrs[lr_off + j] : 0.f;
+        lr_off += tb.nseg;
+        a.ts = static_cast<uint32_t>(update_time);
+        a.sum_dups = 0;
+        a.filter_mode = tb.flt_slots ? 1 : 0;   // an owner asks its filter about every id it does not hold
+        a.global_step = global_step;
+        gx = std::max(gx, (cap + 256u / shape_lanes(A.g[i]) - 1) / (256u / shape_lanes(A.g[i])));
+        k.inst[A.g[i] & 1u][(A.g[i] >> 1) & 1u] = true;
+      }
+      const uint32_t fill = std::max<uint32_t>(8, uint32_t(ms.num_cus) * 16 / k.tc);
+      k.gx = std::min(gx, fill);
+      A.clear_ids = ids_send[slot];
     }
-    const uint32_t fill = std::max<uint32_t>(8, uint32_t(ms.num_cus) * 16 / T);
-    gx = std::min(gx, fill);
-    A.clear_ids = ids_send[slot];
-    bool inst[2][2] = {};   // [one float per lane][whole-segment optimizer]
-    for (uint32_t t = 0; t < T; ++t) inst[A.g[t] & 1u][(A.g[t] >> 1) & 1u] = true;
     for (int p = 0; p < world; ++p) {
       wait_arrived(kXGrads, slot, p, p + 1, st);   // (a peer's block is applied as soon as it has landed)
       if (grad_bits == 16) cvt<false>(ids_recv[slot], own_grads16, apply_grads(), p, 1, st);
-      A.peer = uint32_t(p);
-      A.zero_headers = p == world - 1 ? 1u : 0u;
-      if (inst[0][0]) LAUNCH_HOT(kTagShardUpsert, (shard_upsert_kernel<4, false>), dim3(gx, T), 256, st, A);
-      if (inst[1][0]) LAUNCH_HOT(kTagShardUpsert, (shard_upsert_kernel<1, false>), dim3(gx, T), 256, st, A);
-      if (inst[0][1]) LAUNCH_HOT(kTagShardUpsert, (shard_upsert_kernel<4, true>), dim3(gx, T), 256, st, A);
-      if (inst[1][1]) LAUNCH_HOT(kTagShardUpsert, (shard_upsert_kernel<1, true>), dim3(gx, T), 256, st, A);
-      shard_slow_kernel<<<T, 64, 0, st>>>(A);
-      HIP_OK(hipGetLastError());
+      for (OwnerChunk& k : chunks) {
+        ShardOwnerArgs& A = k.A;
+        const uint32_t gx = k.gx, tc = k.tc;
+        A.peer = uint32_t(p);
+        A.zero_headers = p == world - 1 ? 1u : 0u;
+        if (k.inst[0][0]) LAUNCH_HOT(kTagShardUpsert, (shard_upsert_kernel<4, false>), dim3(gx, tc), 256, st, A);
+        if (k.inst[1][0]) LAUNCH_HOT(kTagShardUpsert, (shard_upsert_kernel<1, false>), dim3(gx, tc), 256, st, A);
+        if (k.inst[0][1]) LAUNCH_HOT(kTagShardUpsert, (shard_upsert_kernel<4, true>), dim3(gx, tc), 256, st, A);
+        if (k.inst[1][1]) LAUNCH_HOT(kTagShardUpsert, (shard_upsert_kernel<1, true>), dim3(gx, tc), 256, st, A);
+        shard_slow_kernel<<<tc, 64, 0, st>>>(A);
+        HIP_OK(hipGetLastError());
+      }
       for (uint32_t t = 0; t < T; ++t)   // the filter's window moves between senders (one filter for all tables)
         if (mt->tables[t]->flt_slots) {
           mt->tables[t]->filter_maintain(st);

@@ -53,6 +53,10 @@ struct ShardOwnerArgs {
   uint32_t peer;              // upsert / slow: the block being applied
   uint32_t zero_headers;      // slow: 1 = clear the headers of `clear_ids` when done
   int64_t* clear_ids;
+  // a launch serves tables [t0, t0 + tc) of the model (the host chunks: kernel-argument budget); the
+  // arrays below are indexed by the table's position in the launch, `views`, the header words and
+  // the per-table device arrays by its index in the model
+  uint32_t t0, tc;
   uint32_t* pending[kMaxStepTables];
   ShardTab tab[kMaxStepTables];
   uint8_t g[kMaxStepTables];          // lane-group shape per table (MHTE_SWITCH_G; | kShapeGroupBit)
@@ -61,8 +65,9 @@ struct ShardOwnerArgs {
 };
 static_assert(sizeof(ShardOwnerArgs) <= 4096, "kernel arguments exceed 4 KB");
 
+// (t: position of the table in the launch)
 __device__ __forceinline__ uint32_t shard_block_count(const ShardOwnerArgs& A, uint32_t p, uint32_t t) {
-  const uint64_t c = uint64_t(A.recv_ids[size_t(p) * A.geo.ids_block + t]);
+  const uint64_t c = uint64_t(A.recv_ids[size_t(p) * A.geo.ids_block + A.t0 + t]);
   if (c > A.tab[t].cap) {
     // the sender saw the same count and dropped the surplus ids' rows; flagged on both sides
     if (threadIdx.x == 0) atomicOr(A.flags, uint32_t(kShardOverflow));
@@ -71,15 +76,15 @@ __device__ __forceinline__ uint32_t shard_block_count(const ShardOwnerArgs& A, u
   return uint32_t(c);
 }
 
-// grid (x, world * T): y = peer * T + table
+// grid (x, world * tc): y = peer * tc + table of the launch
 template <int VW>
 __global__ __launch_bounds__(512) void shard_lookup_kernel(ShardOwnerArgs A) {
-  const uint32_t p = blockIdx.y / A.geo.T, t = blockIdx.y % A.geo.T;
+  const uint32_t p = blockIdx.y / A.tc, t = blockIdx.y % A.tc;
   if (!MHTE_SHAPE_IS(VW, A.g[t])) return;
   const uint32_t n = shard_block_count(A, p, t);
   if (n == 0) return;
   const ShardTab tb = A.tab[t];
-  const TableView& tv = deref_const(A.views + t);
+  const TableView& tv = deref_const(A.views + (A.t0 + t));
   const int64_t* ids = A.recv_ids + size_t(p) * A.geo.ids_block + tb.id_off;
   float* out = A.rows + size_t(p) * A.geo.rows_block + tb.row_off;
   const int ch = A.count_hits[t];
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(512) void shard_lookup_kernel(ShardOwnerArgs A) {
 // and the buckets; the waits order its stores before the wavefront's next loads)
 __device__ __forceinline__ void shard_slow_role(const ShardOwnerArgs& A, uint32_t t, BfsSlot* q,
                                                 CuckooRecord* path, int lane) {
-  const TableView& tv = deref_const(A.views + t);
+  const TableView& tv = deref_const(A.views + (A.t0 + t));
   const uint32_t np = tv.ctr->n_pending;
   if (!np) return;
   const ShardTab tb = A.tab[t];
@@ -138,7 +143,7 @@ __device__ __forceinline__ void shard_slow_role(const ShardOwnerArgs& A, uint32_
   if (lane == 0) tv.ctr->n_pending = 0;
 }
 
-// grid (x, T): the block of peer A.peer.  Ids whose two buckets are full go to the table's pending
+// grid (x, tc): the block of peer A.peer.  Ids whose two buckets are full go to the table's pending
 // list, finished by shard_slow_kernel.  (A launch of its own, not the last workgroup of this one: on
 // the 8-XCD part the other workgroups' bucket and pending-list stores sit in their XCDs' L2s until
 // the kernel ends — making them visible earlier is an L2 write-back per workgroup, measured 295 us
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(256, GROUP ? 1 : MHTE_SEGU_OCC) void shard_upsert_k
   const uint32_t n = shard_block_count(A, p, t);
   if (n == 0) return;
   const ShardTab tb = A.tab[t];
-  const TableView& tv = deref_const(A.views + t);
+  const TableView& tv = deref_const(A.views + (A.t0 + t));
   const int64_t* ids = A.recv_ids + size_t(p) * A.geo.ids_block + tb.id_off;
   const float* values = A.rows + size_t(p) * A.geo.rows_block + tb.row_off;
   uint32_t* pend = A.pending[t];
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(64) void shard_slow_kernel(ShardOwnerArgs A) {
   const int lane = threadIdx.x;
   shard_slow_role(A, t, q, path, lane);
   if (A.zero_headers && uint32_t(lane) < A.geo.world)
-    A.clear_ids[size_t(lane) * A.geo.ids_block + t] = 0;
+    A.clear_ids[size_t(lane) * A.geo.ids_block + A.t0 + t] = 0;
 }
 
 // ---- sender: rows -> occurrences, occurrence gradients -> row slots ---------------------------------
@@ -187,6 +192,7 @@ struct ShardGatherArgs {
   const uint32_t* slot_off;   // [T][n_max]
   uint32_t slot;
   uint32_t n_max;
+  uint32_t t0, tc;      // tables [t0, t0 + tc) of the model (ShardOwnerArgs); tab / gt by position in the launch
   ShardTab tab[kMaxStepTables];
   ShardGatherTab gt[kMaxStepTables];
 };
@@ -224,8 +230,8 @@ static_assert(sizeof(GatherLds<8, 4>) >= sizeof(GatherLds<16, 4>) &&
 template <int VW>
 __global__ __launch_bounds__(256) void shard_scatter_kernel(ShardGatherArgs A) {
   __shared__ __attribute__((aligned(16))) char raw[sizeof(GatherLds<8, 4>)];
-  const uint32_t t = blockIdx.y;
-  const ShardGatherTab gt = A.gt[t];
+  const uint32_t tl = blockIdx.y, t = A.t0 + tl;
+  const ShardGatherTab gt = A.gt[tl];
   if (gt.n == 0 || blockIdx.x >= gt.nblk_items + gt.nblk_ids || !MHTE_SHAPE_IS(VW, gt.gv)) return;
   const MStepStatic& s = deref_const(A.st + t);
   const uint32_t cur = A.slot & 1u;
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(256) void shard_scatter_kernel(ShardGatherArgs A) {
   GatherCtl c;
   c.in = A.in;
   c.out = A.out + size_t(gt.io_off);
-  shard_gather_ctl(c, s, cur, A.slot_off, A.n_max, t, A.tab[t].dim, gt);
+  shard_gather_ctl(c, s, cur, A.slot_off, A.n_max, t, A.tab[tl].dim, gt);
   shard_gather_switch<true, VW>(gt.gv, d, c, blockIdx.x, raw);
 }
 
@@ -254,7 +260,7 @@ struct ShardBuildArgs {
   uint32_t build_slot;
   uint32_t slot;
   uint32_t n_max;
-  uint32_t pad;
+  uint32_t t0;                    // tables [t0, t0 + gridDim.y) of the model; tab / n_build / gt by position
   ShardTab tab[kMaxStepTables];
   uint32_t n_build[kMaxStepTables];
   ShardGatherTab gt[kMaxStepTables];
@@ -265,15 +271,15 @@ static_assert(sizeof(ShardBuildArgs) <= 4096, "kernel arguments exceed 4 KB");
 template <int VW>
 __global__ __launch_bounds__(256) void shard_build_kernel(ShardBuildArgs A) {
   __shared__ __attribute__((aligned(16))) char raw[sizeof(GatherLds<8, 4>)];
-  const uint32_t t = blockIdx.y;
-  if (!MHTE_SHAPE_IS(VW, A.gt[t].gv)) return;
+  const uint32_t tl = blockIdx.y, t = A.t0 + tl;
+  if (!MHTE_SHAPE_IS(VW, A.gt[tl].gv)) return;
   const MStepStatic& s = deref_const(A.st + t);
   uint32_t bid = blockIdx.x;
-  const uint32_t nb = A.n_build[t] ? s.nblk_build : 0u;
+  const uint32_t nb = A.n_build[tl] ? s.nblk_build : 0u;
   if (bid < nb) {
     RunView nxt = s.rv[A.build_slot & 1u];
-    nxt.nblk = (A.n_build[t] + kRdBlock - 1) / kRdBlock;
-    const ShardTab tb = A.tab[t];
+    nxt.nblk = (A.n_build[tl] + kRdBlock - 1) / kRdBlock;
+    const ShardTab tb = A.tab[tl];
     PackCtl pc;
     pc.send_ids = A.send_ids;
     pc.slot_off = A.slot_off_build + size_t(t) * A.n_max;
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(256) void shard_build_kernel(ShardBuildArgs A) {
     return;
   }
   bid -= nb;
-  const ShardGatherTab gt = A.gt[t];
+  const ShardGatherTab gt = A.gt[tl];
   if (gt.n == 0 || bid >= gt.nblk_items + gt.nblk_ids) return;
   const uint32_t cur = A.slot & 1u;
   RunView d = s.rv[cur];
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(256) void shard_build_kernel(ShardBuildArgs A) {
   GatherCtl c;
   c.in = A.grads + size_t(gt.io_off);
   c.out = A.rows_out;
-  shard_gather_ctl(c, s, cur, A.slot_off, A.n_max, t, A.tab[t].dim, gt);
+  shard_gather_ctl(c, s, cur, A.slot_off, A.n_max, t, A.tab[tl].dim, gt);
   shard_gather_switch<false, VW>(gt.gv, d, c, bid, raw);
 }
 
@@ -366,7 +372,7 @@ struct ShardPushArgs {
   uint32_t ids;               // 1: id blocks (header + int64 slots), 0: row blocks (floats)
   uint32_t half;              // row blocks of 16-bit elements (the fp16 gradient wire): dense
                               // [world][rows_block] arrays of 16-bit words on both sides
-  ShardTab tab[kMaxStepTables];
+  const ShardTab* tab;        // [T], device memory (the step's geometry: fixed at creation)
 };
 static_assert(sizeof(ShardPushArgs) <= 4096, "kernel arguments exceed 4 KB");
 
@@ -430,7 +436,7 @@ struct ShardCvtArgs {
   void* dst;
   ShardGeom geo;
   uint32_t peer_lo, peer_n;   // peers [peer_lo, peer_lo + peer_n)
-  ShardTab tab[kMaxStepTables];
+  const ShardTab* tab;        // [T], device memory
 };
 template <bool NARROW>
 __global__ __launch_bounds__(256) void shard_cvt_kernel(ShardCvtArgs A) {

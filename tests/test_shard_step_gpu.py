@@ -93,9 +93,8 @@ def test_group_bias_slice_rows_against_oracle(dist, world):
   _group_against_oracle(bias_slice_specs(), dist, world, False)
 
 
-def _group_against_oracle(specs, dist, world, grad_fp16):
+def _group_against_oracle(specs, dist, world, grad_fp16, B=3000, steps=5):
   by_name = sorted(specs, key=lambda s: s.name)
-  B, steps = 3000, 5
   universe = 200000 if dist == "uniform" else 7000
   exact = dist == "uniform"   # every id occurs <= 32 times in a batch: sums in occurrence order
   mts = [make(specs) for _ in range(world)]
@@ -353,3 +352,57 @@ def test_group_whole_segment_optimizer_against_oracle(dist, world):
   optimizer-agnostic, the owner applies every peer's block with the whole-segment instance of its
   upsert (shard_upsert_kernel<VW, GROUP>)."""
   _group_against_oracle(group_opt_specs(), dist, world, False)
+
+
+def many_table_specs(n=40):
+  """More tables than one launch takes (kMaxStepTables = 32), with every kind of row on BOTH sides of
+  the chunk boundary: float4 rows, a bias + vector row (one float per lane), a whole-segment
+  optimizer."""
+  from test_multi_step_gpu import Spec
+  specs = []
+  for i in range(n):
+    if i in (3, 34):
+      segs = [(1, "ftrl", 0.05), (16, "adagrad", 0.01)]
+    elif i in (6, 37):
+      segs = [(16, "group", 0.02)]
+    elif i == 38:
+      segs = [(1, "ftrl", 0.05), (16, "group", 0.02)]
+    else:
+      segs = [((16, 32, 64)[i % 3], "adagrad", 0.01)]
+    specs.append(Spec("t%02d" % i, segs, i + 1))
+  return specs
+
+
+@pytest.mark.parametrize("dist,world", [("uniform", 2), ("zipf", 3)])
+def test_group_more_than_32_tables_against_oracle(dist, world):
+  """Round 3's sharded step refused a model of more than 32 tables.  The limit is a per-launch budget
+  (kernel arguments): every stage launches per 32 tables (ShardOwnerArgs.t0 / tc), the exchanges
+  carry all of them in one block per peer."""
+  _group_against_oracle(many_table_specs(), dist, world, False, B=700, steps=4)
+
+
+def test_world1_identity_more_than_32_tables():
+  """40 tables, world 1 (identity exchange): bit for bit the single-GPU multi-table step."""
+  specs = [s for s in many_table_specs() if not any(o == "group" for _, o, _ in s.segs)]
+  assert len(specs) > 32
+  by_name = sorted(specs, key=lambda s: s.name)
+  B, steps = 900, 4
+  batches = [batch_of(specs, 7 + s, B, 20000) for s in range(steps + 1)]
+  mt_a, mt_b = make(specs), make(specs)
+  ref = MultiSparseStep(mt_a, B)
+  shd = ShardedMultiStep(mt_b, B)
+  rag_a = [ragged_of(specs, mt_a, b) for b in batches]
+  rag_b = [ragged_of(specs, mt_b, b) for b in batches]
+  for s in range(steps):
+    ea = ref.forward(rag_a[s], rag_a[s + 1])
+    eb = shd.forward(rag_b[s], rag_b[s + 1] if s % 2 == 0 else None)
+    assert torch.equal(ea, eb), "forward step %d" % s
+    g = val_t(np.concatenate([grads_of(s, 0, sp, B).ravel() for sp in by_name]))
+    ref.backward(g, S.update_time(s))
+    shd.backward(g, S.update_time(s))
+  shd.check()
+  allids = {sp.name: np.unique(np.concatenate([b[sp.name] for b in batches])) for sp in specs}
+  ra, rb = ragged_of(specs, mt_a, allids), ragged_of(specs, mt_b, allids)
+  assert torch.equal(mt_a.raw_lookup(ra), mt_b.raw_lookup(rb))
+  ref.close()
+  shd.close()
