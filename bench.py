@@ -78,6 +78,9 @@ def parse():
                       "measured slower on one table of 65 536 ids, DESIGN 4.4 — the backward launch has no "
                       "idle wave slots to hide it in)")
   p.add_argument("--no-cpu-baseline", action="store_true")
+  p.add_argument("--no-extra-windows", action="store_true",
+                 help="skip the eager_cpp (C-loop enqueue) and exact_order (bit-exact mode) windows that are "
+                      "reported under timing_ms_per_step beside the line's own")
   p.add_argument("--cpu-steps", type=int, default=150)
   p.add_argument("--cpu-child", default="", help=argparse.SUPPRESS)   # "i" | "ii": one CPU-baseline
                                                                       # variant in a process of its own
@@ -664,7 +667,15 @@ def cpu_child(args):
   lr = 0.001 if args.opt == "adagrad" else 0.01
   cw, ck = 20, args.cpu_steps    # (>= 20 warm-up steps, median of >= 100)
   grads_h = [S.grad_batch(s, B, D) for s in range(4)]
-  ps = O.RefPs(cores, D, opt, 0.1, 0.0, 0.0, 1, avx=avx, shared=args.cpu_child == "ii")
+  # Variant (ii) starts its ONE shared map at 2^18 slots (65 536 buckets = the reference map's
+  # kMaxNumLocks), not at the proto default of 1: below that size the reference's cuckoo_fast_double
+  # replaces the locks array at every doubling, and `old_buckets_.swap(buckets_)`
+  # (cuckoohash_map.hpp:1814-1815) lets a thread that slept through a doubling pass check_hashpower
+  # against a null bucket pointer — round 4's rc -11: 2 of 12 runs with 256 threads on the GPU box,
+  # all in the first step (oracle/stress/shared_map_stress.cc, profiles/r05/cpu_baseline_rc11.md).
+  # The per-thread shards of variant (i) have one thread per map and keep the default.
+  shared = args.cpu_child == "ii"
+  ps = O.RefPs(cores, D, opt, 0.1, 0.0, 0.0, (1 << 18) if shared else 1, avx=avx, shared=shared)
   times, phases = [], []
   for s in range(cw + ck):
     ids = S.id_batch(s, B, V, "zipf")
@@ -675,6 +686,7 @@ def cpu_child(args):
   med = float(np.median(times[cw:]))
   print(json.dumps({"value": round(2 * B / med, 1), "median_step_ms": round(med * 1e3, 3), "steps": ck,
                     "rows_at_end": ps.size(), "cores": cores, "avx": bool(avx),
+                    "initial_capacity": (1 << 18) if shared else 1,
                     "phase_ms_median": {k: round(float(np.median([p_[k] for p_ in phases[cw:]])) * 1e3, 3)
                                         for k in O.RefPs.PHASES}}))
 
@@ -787,7 +799,8 @@ def main():
   # a short --steps window (the driver's 20 steps are 0.7 ms of GPU work) is reported next to a
   # 200-step window of the same mode: `reference_window` in the JSON line
   REFW = 200 if (K < 200 and not sharded) else 0
-  n_batches = ((W + K) + (Wg + K) + 2 * reps + 14 + PROF_WARM + REFW) if not sharded else (K + W + 24)
+  n_batches = ((W + K) + (Wg + K) + 2 * reps + 14 + PROF_WARM + REFW +
+               (0 if args.no_extra_windows else (W + K + 1) + 2 * (Wg + K + 8))) if not sharded else (K + W + 24)
   ids_host = np.stack([S.id_batch(s * world + rank, B, V, "zipf") for s in range(n_batches)])
   ids_all = torch.from_numpy(ids_host).to(dev)
   NG = max(1, args.grad_pool)
@@ -803,6 +816,7 @@ def main():
 
   results = {}
   steps_of = {}
+  extra_windows = {}   # ms per step of the windows that are reported beside the line's own (eager_cpp, exact_order)
   stages, shard_info, shard_roofline, uniq_avg = {}, None, None, None
   graph_err = None
   if not sharded:
@@ -818,10 +832,18 @@ def main():
     # timed step still executes exactly one dedup, one numbering + probe, one lookup and one update
     two_ahead = args.lookahead >= 2
 
-    def run_eager(lo, hi):
+    def run_eager(lo, hi, st=None):
+      st = st or step
       for s in range(lo, hi):
-        step.forward(ids_all[s], next_ids=ids_all[s + 1], ahead_ids=ids_all[s + 2] if two_ahead else None)
-        step.backward(grad_pool[s % NG], S.update_time(s))
+        st.forward(ids_all[s], next_ids=ids_all[s + 1], ahead_ids=ids_all[s + 2] if two_ahead else None)
+        st.backward(grad_pool[s % NG], S.update_time(s))
+        applied.append((s, s % NG, S.update_time(s)))
+
+    def run_c_loop(lo, hi):
+      # the same steps enqueued by a plain C loop over mhte_table_step_forward / _backward
+      # (csrc/eager_loop.c): no interpreter and no hipGraph between the calls
+      step.c_loop(ids_all, lo, hi, grad_pool, S.update_time(0))
+      for s in range(lo, hi):
         applied.append((s, s % NG, S.update_time(s)))
 
     def timed(name, c, w, k):
@@ -892,6 +914,65 @@ def main():
         cur += gc * (len(graphs) + 1)
     if REFW and "graph_ref_window" not in results:   # (no graph mode: the long window enqueued step by step)
       cur = timed("eager_ref_window", cur, 0, REFW)
+    # ---- two more windows of K steps, reported under timing_ms_per_step, never the line's `value`:
+    # (a) eager_cpp: enqueued by a C loop over the C ABI — what a TF OpKernel pair pays per step without a
+    #     graph (the interpreter's share of `eager` gone);
+    # (b) exact_order: the bit-exact mode (every duplicate list summed strictly in occurrence order),
+    #     replayed from hipGraphs like the headline
+    if not two_ahead and not args.no_extra_windows:
+      try:
+        import gc as _gc
+        run_eager(cur, cur + 1)            # leaves batch cur + 1 deduplicated ahead
+        cur += 1
+        run_c_loop(cur, cur + W)
+        cur += W
+        _gc.collect()
+        _gc.disable()
+        barrier()
+        t = time.perf_counter()
+        run_c_loop(cur, cur + K)
+        barrier()
+        extra_windows["eager_cpp"] = (time.perf_counter() - t) / K * 1e3
+        _gc.enable()
+        cur += K
+      except Exception as e:  # pylint: disable=broad-except
+        extra_windows["eager_cpp_error"] = repr(e)[:200]
+        print("eager_cpp window failed: %r" % (e,), file=sys.stderr)
+      if not args.exact_order and "graph" in results and K % gchunk == 0:
+        try:
+          step_x = SparseStep(mt, "emb", B, exact_order=True)
+          run_eager(cur, cur + 4, step_x)   # (every workspace of the new pipeline allocates outside the capture)
+          cur += 4
+          step_x.quiesce()
+          gx = []
+          for c0 in range(cur, cur + Wg + K, gchunk):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+              run_eager(c0, c0 + gchunk, step_x)
+            gx.append(g)
+          cur += Wg + K
+          torch.cuda.synchronize()
+          for g in gx[:Wg // gchunk]:
+            g.replay()
+          barrier()
+          t = time.perf_counter()
+          for g in gx[Wg // gchunk:]:
+            g.replay()
+          barrier()
+          extra_windows["exact_order"] = (time.perf_counter() - t) / K * 1e3
+          del gx
+        except Exception as e:  # pylint: disable=broad-except
+          extra_windows["exact_order_error"] = repr(e)[:200]
+          applied_ok = False
+          print("exact-order window failed: %r" % (e,), file=sys.stderr)
+          for _ in range(2):   # (a failed capture leaves its error for the next launch check to find: absorb it)
+            try:
+              torch.cuda.synchronize()
+              torch.zeros(1, device=dev).add_(1)
+            except Exception:  # pylint: disable=broad-except
+              pass
+          step = SparseStep(mt, "emb", B, exact_order=args.exact_order)
+          cur += Wg + K + 8
     P0 = cur
   else:
     # the id-sharded step, enqueued from C++ (csrc/mhte_shard_host.h): kernels + RCCL send / recv
@@ -1215,8 +1296,8 @@ def main():
       grads_h = [S.grad_batch(s, B, D) for s in range(4)]
 
       def cpu_variant(shared, ck):
-        # in a process of its own: the reference map with 256 threads on ONE table (variant ii) has
-        # been seen to crash on this box; a baseline must not take the GPU measurement with it
+        # in a process of its own (a baseline must not take the GPU measurement with it).  Round 4 lost
+        # variant (ii) to an rc -11: root cause and cure in cpu_child
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", "ii" if shared else "i",
                "--cpu-steps", str(ck), "--batch", str(B), "--dim", str(D), "--opt", args.opt,
@@ -1319,8 +1400,14 @@ def main():
             "prefill_s": round(prefill_s, 2),
         },
         "value_window": value_window,
-        "timing_ms_per_step": {k: round(v / steps_of[k] * 1e3, 5) for k, v in results.items()
-                               if k not in REF_KEYS},
+        "timing_ms_per_step": dict(
+            {k: round(v / steps_of[k] * 1e3, 5) for k, v in results.items() if k not in REF_KEYS},
+            **{k: (round(v, 5) if isinstance(v, float) else v) for k, v in extra_windows.items()}),
+        "timing_note": "eager = two Python calls per step; graph = hipGraph replay (the line's value); eager_cpp = "
+                       "the same %d steps enqueued by a plain C loop over mhte_table_step_forward / _backward "
+                       "(csrc/eager_loop.c: what a TF OpKernel pair pays without a graph); exact_order = the "
+                       "bit-exact mode (MHTE_EXACT_ORDER: every duplicate list summed strictly in occurrence "
+                       "order), hipGraph replay" % K,
         "reference_window": None if not ref_key else {
             "steps": steps_of[ref_key], "launch": ref_key.split("_")[0],
             "ms_per_step": round(results[ref_key] / steps_of[ref_key] * 1e3, 5),

@@ -117,6 +117,7 @@ def _stale():
 def build_library(force=False, verbose=False):
   """hipcc --offload-arch=gfx950 cross-compiles without a GPU; output stays in-tree."""
   if not force and not _stale():
+    build_eager_loop()
     return _SO
   cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared",
          "-fPIC", "-o", _SO, _SRC]
@@ -127,7 +128,42 @@ def build_library(force=False, verbose=False):
   subprocess.check_call(cmd)
   with open(_HASH_FILE, "w") as f:
     f.write(_source_hash() + "\n")
+  build_eager_loop()
   return _SO
+
+
+# the plain-C step loop of bench.py's `eager_cpp` timing (csrc/eager_loop.c): gcc, the public header,
+# linked against libmhte.so beside it — a measurement aid, not part of the op surface
+_EAGER_SO = os.path.join(_DIR, "libmhte_eager.so")
+_EAGER_SRC = os.path.join(_DIR, "csrc", "eager_loop.c")
+
+
+def build_eager_loop(force=False):
+  if (not force and os.path.exists(_EAGER_SO) and
+      os.path.getmtime(_EAGER_SO) >= os.path.getmtime(_EAGER_SRC)):
+    return _EAGER_SO
+  subprocess.check_call(["gcc", "-O2", "-std=c99", "-Wall", "-shared", "-fPIC",
+                         "-I", os.path.join(_DIR, "..", "include"), _EAGER_SRC, "-o", _EAGER_SO,
+                         "-L", _DIR, "-lmhte", "-Wl,-rpath,$ORIGIN"])
+  return _EAGER_SO
+
+
+_eager = None
+
+
+def eager_lib():
+  """libmhte_eager.so (mhte_eager_step_loop), loaded after libmhte.so."""
+  global _eager
+  if _eager is None:
+    lib()
+    if _OVERRIDE:   # (libmhte_eager.so binds the in-tree libmhte.so: two copies of the engine in one process)
+      raise MhteError(MHTE_UNAVAILABLE, "libmhte_eager.so is not used with MHTE_LIBRARY")
+    if not os.path.exists(_EAGER_SO):
+      build_eager_loop()
+    E = C.CDLL(_EAGER_SO)
+    E.mhte_eager_step_loop.restype = C.c_int32
+    _eager = E
+  return _eager
 
 
 # every symbol include/monolith_amd_hash_table.h declares

@@ -103,7 +103,7 @@ struct ShardStep {
   mutable std::vector<ShardGatherTab> gt_all;   // gather_tabs: all T tables of a launch group
   struct OwnerChunk {           // owner_apply: the arguments of tables [c * kMaxStepTables, ...)
     ShardOwnerArgs A;
-    uint32_t tc, gx;
+    uint32_t tc, gx, gx_fill;
     bool inst[2][2];            // [one float per lane][whole-segment optimizer]
   };
   std::vector<OwnerChunk> apply_chunks;
@@ -122,6 +122,18 @@ struct ShardStep {
   float* own_grads = nullptr;
   float* snd_rows = nullptr;
   float* snd_grads = nullptr;
+  // ---- owner side, between a batch's lookup and its update (ShardX, mhte_shard_kernels.h)
+  OwnRec* orec = nullptr;       // [world][ids_block]
+  uint32_t* oslot = nullptr;    // [world][ids_block] (world > 1)
+  uint32_t* xs = nullptr;       // cross-peer scratch, [T][xcap + 1] slots (world > 1)
+  uint32_t xcap = 0, xstride = 0;
+  bool x_dirty = false;         // ids are registered in xs that no update has consumed
+  int own_slot = -1;            // the id slot the last owner lookup served
+  std::vector<uint64_t> own_epoch;   // Table::mut_epoch when that lookup ran
+  bool legacy_owner = false;    // MHTE_SHARD_PER_PEER=1 (A/B), or a table has an occurrence filter: the
+                                // peers' blocks are applied by one launch pair each, in rank order
+  uint32_t launches = 0;        // kernel launches + exchanges enqueued by the last forward + backward
+  uint32_t launches_fwd = 0;
   uint32_t* h_flags = nullptr;  // pinned, device-visible
   uint32_t* d_flags = nullptr;
   bool alias = false;           // world == 1 without a communicator
@@ -190,6 +202,9 @@ struct ShardStep {
       if (slot_off[s]) (void)hipFree(slot_off[s]);
     }
     if (d_tab) (void)hipFree(d_tab);
+    if (orec) (void)hipFree(orec);
+    if (oslot) (void)hipFree(oslot);
+    if (xs) (void)hipFree(xs);
     if (own_rows) (void)hipFree(own_rows);
     if (snd_rows && !alias && !ipc) (void)hipFree(snd_rows);
     if (ipc && snd_grads) (void)hipFree(snd_grads);
@@ -269,6 +284,21 @@ struct ShardStep {
       }
       HIP_OK(hipMalloc(&slot_off[s], size_t(T) * size_t(mb) * sizeof(uint32_t)));
     }
+    // what the owner keeps per received id between lookup and update; world > 1: the cross-peer scratch
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&orec), size_t(geo.ids_block) * world * sizeof(OwnRec)));
+    HIP_OK(hipMemset(orec, 0xff, size_t(geo.ids_block) * world * sizeof(OwnRec)));
+    own_epoch.assign(T, 0);
+    if (world > 1) {
+      HIP_OK(hipMalloc(reinterpret_cast<void**>(&oslot), size_t(geo.ids_block) * world * sizeof(uint32_t)));
+      HIP_OK(hipMemset(oslot, 0, size_t(geo.ids_block) * world * sizeof(uint32_t)));
+      xcap = 1u << std::max<uint32_t>(6, ceil_log2(uint64_t(2) * uint64_t(cap) * uint64_t(world)));
+      xstride = (kXKeyWords + uint32_t(world) + 3u) & ~3u;
+      const size_t words = size_t(T) * (size_t(xcap) + 1) * xstride;
+      HIP_OK(hipMalloc(reinterpret_cast<void**>(&xs), words * sizeof(uint32_t)));
+      clear_x(nullptr);
+    }
+    if (const char* e = getenv("MHTE_SHARD_PER_PEER")) legacy_owner = atoi(e) != 0;
+    if (const char* e = getenv("MHTE_SHARD_FUSE_SCATTER")) fuse_scatter = atoi(e) != 0;
     HIP_OK(hipMalloc(&own_rows, rb + 64));
     if (ipc) {
       snd_rows = reinterpret_cast<float*>(win + win_off_rows);
@@ -764,10 +794,101 @@ struct ShardStep {
     }
   }
 
+  void clear_x(hipStream_t st) {
+    if (!xs) return;
+    const uint64_t nslots = uint64_t(T) * (uint64_t(xcap) + 1);
+    shard_x_clear_kernel<<<uint32_t(std::min<uint64_t>((nslots + 255) / 256, 4096)), 256, 0, st>>>(xs, nslots, xstride);
+    HIP_OK(hipGetLastError());
+    x_dirty = false;
+  }
+  // a table with an occurrence filter keeps the per-peer form: its filter's window moves between senders
+  bool per_peer_owner() const {
+    if (legacy_owner) return true;
+    for (uint32_t t = 0; t < T; ++t)
+      if (mt->tables[t]->flt_slots) return true;
+    return false;
+  }
+
+  // rows back -> occurrences of the batch in `slot` AND the run dedup of (ids_next, split_next) into
+  // slot_next, ONE launch (shard_scatter_dedup_kernel; T <= kMaxStepTables).  Tables that move one float
+  // per lane are scattered by shard_scatter_kernel<1>.
+  bool fuse_scatter = true;     // MHTE_SHARD_FUSE_SCATTER=0: two launches (A/B)
+  void scatter_dedup(float* out, int slot, const int64_t* ids_next, const int64_t* split_next, int slot_next,
+                     hipStream_t st) {
+    wait_arrived(kXRows, slot, 0, world, st);
+    if (ms.stage[slot_next] == 1) ms.clear_slots(1u << slot_next, st);
+    for (uint32_t t = 0; t < T; ++t) ms.n_slot[slot_next][t] = uint32_t(split_next[t + 1] - split_next[t]);
+    ms.has_hints[slot_next] = false;
+    ShardGatherArgs A{};
+    A.st = ConstStatics(ms.d_st);
+    A.in = snd_rows;
+    A.out = out;
+    A.slot_off = slot_off[slot];
+    A.slot = uint32_t(slot);
+    A.n_max = uint32_t(max_batch);
+    A.t0 = 0;
+    A.tc = T;
+    gather_tabs(slot);
+    fill_tabs(A.tab, 0, T);
+    MDedupArgs D{};
+    D.st = ConstStatics(ms.d_st);
+    D.ids = ids_next + split_next[0];
+    D.slot = uint32_t(slot_next);
+    D.T = T;
+    MFwdFuse F{};
+    uint32_t dblocks = 0, active = 0, gx1 = 0, lin = 0;
+    for (uint32_t t = 0; t < T; ++t) {
+      A.gt[t] = gt_all[t];
+      D.id_off[t] = uint32_t(split_next[t] - split_next[0]);
+      D.blk_start[t] = dblocks;
+      dblocks += uint32_t((split_next[t + 1] - split_next[t] + kRdBlock - 1) / kRdBlock);
+      active += (A.gt[t].n && !(A.gt[t].gv & 1u)) ? 1u : 0u;
+    }
+    D.id_off[T] = uint32_t(split_next[T] - split_next[0]);
+    D.blk_start[T] = dblocks;
+    F.nd = std::min<uint32_t>(dblocks, ms.fused_dedup_wgs ? ms.fused_dedup_wgs : uint32_t(ms.num_cus) / 2);
+    F.period = 1;
+    const uint32_t slots = uint32_t(2 * ms.num_cus);
+    const uint32_t room = std::max<uint32_t>(slots > F.nd ? slots - F.nd : 8u, 8u) * ms.scatter_ovs;
+    for (uint32_t t = 0; t < T; ++t) {
+      F.fwd_start[t] = lin;
+      const ShardGatherTab& g = A.gt[t];
+      if (!g.n) continue;
+      if (g.gv & 1u) {
+        gx1 = std::max(gx1, g.nblk_items + g.nblk_ids);
+        continue;
+      }
+      const uint32_t ids_per_wg = uint32_t(kRdBlock) / shape_lanes(g.gv) * uint32_t(MHTE_SHARD_SCATTER_UNR);
+      const uint32_t one_trip = (g.n + ids_per_wg - 1) / ids_per_wg;
+      const uint32_t share = std::max<uint32_t>(2, room / std::max(1u, active));
+      lin += std::max<uint32_t>(1, std::min(one_trip, share));
+    }
+    F.fwd_start[T] = lin;
+    if (gx1) {
+      LAUNCH_HOT(kTagShardGather, shard_scatter_kernel<1>, dim3(gx1, T), 256, st, A);
+      ++launches;
+    }
+    if (F.nd + lin) {
+      LAUNCH_HOT(kTagShardGather, shard_scatter_dedup_kernel, F.nd + lin, kRdBlock, st, A, D, F,
+                 std::max<uint32_t>(1, ms.item_target / kItemTarget));
+      ++launches;
+    }
+    HIP_OK(hipGetLastError());
+    ms.stage[slot_next] = 1;
+    disp[slot_next] = false;
+    ids_exchanged[slot_next] = false;
+  }
+
   // arguments of the owner-side launches for tables [t0, t0 + tc)
   void owner_args(ShardOwnerArgs& A, int slot, bool apply, uint32_t t0, uint32_t tc) const {
     A.views = ConstViews(mt->d_views.p);
     A.geo = geo;
+    A.x.orec = orec;
+    A.x.oslot = oslot;
+    A.x.xs = xs;
+    A.x.xmask = xcap ? xcap - 1u : 0u;
+    A.x.xstride = xstride;
+    A.x.hints = 0;
     A.recv_ids = ids_recv[slot];
     A.rows = apply ? apply_grads() : own_rows;
     A.flags = d_flags;
@@ -782,10 +903,18 @@ struct ShardStep {
 
   void owner_lookup(int slot, hipStream_t st) {
     wait_arrived(kXIds, slot, 0, world, st);
+    const bool per_peer = per_peer_owner();
+    if (xs && !per_peer) {
+      if (x_dirty) clear_x(st);   // (a batch that was looked up and never trained left its ids registered)
+      x_dirty = true;
+    }
+    own_slot = slot;
+    for (uint32_t t = 0; t < T; ++t) own_epoch[t] = mt->tables[t]->mut_epoch;
     for (uint32_t t0 = 0; t0 < T; t0 += uint32_t(kMaxStepTables)) {
       const uint32_t tc = chunk_tables(t0);
       ShardOwnerArgs A{};
       owner_args(A, slot, false, t0, tc);
+      if (per_peer) A.x.xs = nullptr, A.x.oslot = nullptr;   // (no registration: nobody would consume it)
       uint32_t gx = 1;
       for (uint32_t i = 0; i < tc; ++i)
         gx = std::max(gx, uint32_t((uint64_t((cap + 1) / 2) * shape_lanes(A.g[i]) + 511) / 512));
@@ -796,6 +925,7 @@ struct ShardStep {
       for (uint32_t i = 0; i < tc; ++i) ((A.g[i] & 1u) ? w1 : w4) = true;
       if (w4) LAUNCH_HOT(kTagShardLookup, shard_lookup_kernel<4>, dim3(gx, uint32_t(world) * tc), 512, st, A);
       if (w1) LAUNCH_HOT(kTagShardLookup, shard_lookup_kernel<1>, dim3(gx, uint32_t(world) * tc), 512, st, A);
+      launches += (w4 ? 1u : 0u) + (w1 ? 1u : 0u);
       HIP_OK(hipGetLastError());
     }
   }
@@ -805,7 +935,7 @@ struct ShardStep {
       Table& tb = *mt->tables[t];
       tb.note_update_time(update_time);
       tb.ensure_capacity(uint64_t(cap) * uint64_t(world), st);
-      tb.pending.reserve(2 * size_t(cap) + 2);
+      tb.pending.reserve(2 * size_t(cap) * size_t(world) + 2);
     }
     sync_views(mt, st);
     wait_arrived(kXIds, slot, 0, world, st);
@@ -835,9 +965,39 @@ struct ShardStep {
         k.inst[A.g[i] & 1u][(A.g[i] >> 1) & 1u] = true;
       }
       const uint32_t fill = std::max<uint32_t>(8, uint32_t(ms.num_cus) * 16 / k.tc);
+      k.gx_fill = fill;
       k.gx = std::min(gx, fill);
       A.clear_ids = ids_send[slot];
     }
+    if (!per_peer_owner()) {
+      // ONE launch for every peer's block (+ the displacement pass): the groups of an id's lowest sender
+      // apply its entries in rank order (shard_apply_kernel)
+      wait_arrived(kXGrads, slot, 0, world, st);
+      if (grad_bits == 16) {
+        cvt<false>(ids_recv[slot], own_grads16, apply_grads(), 0, world, st);
+        ++launches;
+      }
+      for (size_t c = 0; c < chunks.size(); ++c) {
+        OwnerChunk& k = chunks[c];
+        ShardOwnerArgs& A = k.A;
+        const uint32_t t0 = uint32_t(c) * uint32_t(kMaxStepTables);
+        A.peer = 0;
+        A.zero_headers = 1u;
+        for (uint32_t i = 0; i < k.tc; ++i)
+          if (own_slot == slot && own_epoch[t0 + i] == mt->tables[t0 + i]->mut_epoch) A.x.hints |= 1u << i;
+        const uint32_t gx = std::max<uint32_t>(1u, std::min<uint32_t>(k.gx, std::max<uint32_t>(8, k.gx_fill / uint32_t(world))));
+        const dim3 grid(gx, uint32_t(world) * k.tc);
+        if (k.inst[0][0]) LAUNCH_HOT(kTagShardUpsert, (shard_apply_kernel<4, false>), grid, 256, st, A);
+        if (k.inst[1][0]) LAUNCH_HOT(kTagShardUpsert, (shard_apply_kernel<1, false>), grid, 256, st, A);
+        if (k.inst[0][1]) LAUNCH_HOT(kTagShardUpsert, (shard_apply_kernel<4, true>), grid, 256, st, A);
+        if (k.inst[1][1]) LAUNCH_HOT(kTagShardUpsert, (shard_apply_kernel<1, true>), grid, 256, st, A);
+        shard_slow_all_kernel<<<k.tc, 64, 0, st>>>(A);
+        HIP_OK(hipGetLastError());
+        launches += uint32_t(k.inst[0][0]) + uint32_t(k.inst[1][0]) + uint32_t(k.inst[0][1]) + uint32_t(k.inst[1][1]) + 1u;
+      }
+      x_dirty = false;
+      own_slot = -1;
+    } else
     for (int p = 0; p < world; ++p) {
       wait_arrived(kXGrads, slot, p, p + 1, st);   // (a peer's block is applied as soon as it has landed)
       if (grad_bits == 16) cvt<false>(ids_recv[slot], own_grads16, apply_grads(), p, 1, st);
@@ -852,6 +1012,7 @@ struct ShardStep {
         if (k.inst[1][1]) LAUNCH_HOT(kTagShardUpsert, (shard_upsert_kernel<1, true>), dim3(gx, tc), 256, st, A);
         shard_slow_kernel<<<tc, 64, 0, st>>>(A);
         HIP_OK(hipGetLastError());
+        launches += uint32_t(k.inst[0][0]) + uint32_t(k.inst[1][0]) + uint32_t(k.inst[0][1]) + uint32_t(k.inst[1][1]) + 1u;
       }
       for (uint32_t t = 0; t < T; ++t)   // the filter's window moves between senders (one filter for all tables)
         if (mt->tables[t]->flt_slots) {
@@ -1064,6 +1225,7 @@ static void shard_forward(ShardStep** S, int n, const ShardFwd* a, int64_t n_spl
   for (int r = 0; r < n; ++r) {
     ShardStep& s = *S[r];
     HIP_OK(hipSetDevice(s.device));
+    s.launches = 0;
     s.join_aux(st);
     s.prepare(st);
     if (prefetched) {
@@ -1087,14 +1249,22 @@ static void shard_forward(ShardStep** S, int n, const ShardFwd* a, int64_t n_spl
   }
   for (int r = 0; r < n; ++r) S[r]->owner_lookup(cur, st);
   shard_exchange(S, n, kXRows, cur, st);
-  for (int r = 0; r < n; ++r) S[r]->scatter(a[r].emb, cur, st);
-  if (has_next)
-    for (int r = 0; r < n; ++r) {
-      if (S[r]->overlap && n == 1) S[r]->prepare_next_on_aux(a[r].id_next, a[r].split_next, cur ^ 1, st);
-      else S[r]->dedup(a[r].id_next, a[r].split_next, cur ^ 1, st);
-      S[r]->ahead = true;
+  for (int r = 0; r < n; ++r) {
+    ShardStep& s = *S[r];
+    const bool on_aux = has_next && s.overlap && n == 1;
+    if (has_next && !on_aux && s.fuse_scatter && s.T <= uint32_t(kMaxStepTables)) {
+      s.scatter_dedup(a[r].emb, cur, a[r].id_next, a[r].split_next, cur ^ 1, st);
+    } else {
+      s.scatter(a[r].emb, cur, st);
+      if (on_aux) s.prepare_next_on_aux(a[r].id_next, a[r].split_next, cur ^ 1, st);
+      else if (has_next) s.dedup(a[r].id_next, a[r].split_next, cur ^ 1, st);
     }
-  for (int r = 0; r < n; ++r) S[r]->flush_signals(st);
+    if (has_next) s.ahead = true;
+  }
+  for (int r = 0; r < n; ++r) {
+    S[r]->flush_signals(st);
+    S[r]->launches_fwd = S[r]->launches;
+  }
 }
 
 static void shard_backward(ShardStep** S, int n, const float* const* grads, const int64_t* grads_len,

@@ -43,10 +43,53 @@ struct ShardGeom {
 
 enum : uint32_t { kShardOverflow = 1u };
 
+// ---- owner: what it keeps about a received id between its lookup (forward) and its update (backward) --
+// The update of a step works on the SAME id blocks its lookup read, so the lookup leaves, per entry
+// (peer, table, slot) — indexed like the id inside the received id buffer, p * ids_block + id_off + s:
+//   * OwnRec: where the probe found the id (row handle, bucket slot, the slot's timestamp).  While
+//     Table::mut_epoch stands still the update reaches the row without reading a bucket line, and
+//     skips the timestamp store when the slot already carries the step's second (the multi-table
+//     step's forward -> backward hints, mhte_mstep_kernels.h).
+//   * world > 1: the id's slot in a per-table scratch hash that groups the entries of one id across
+//     the peers' blocks (an id occurs at most once per block).  Slot = key (2 words) | peer mask (2)
+//     | ent[world] (slot + 1 of the id in that peer's block).  ONE lane group — the lowest peer's —
+//     then applies every sender's gradient in rank order (the reference's one optimizer application
+//     per sender, NT/distributed_ps_sync.py:357-479) and hands the slot back empty, so the owner's
+//     update is ONE launch for all peers (the shape of MonolithMultiHashTableFusedOptimize,
+//     RT/ops/multi_hash_table_update_op.cc:247-308).  The peer mask is read with one 8-byte load: a
+//     group sees the id's entries either all registered or already consumed, never half.
+struct __attribute__((aligned(16))) OwnRec {
+  unsigned long long loc;   // bucket * 4 + slot
+  uint32_t row;             // kNoRow: the table did not hold the id (or it is the side-slot key)
+  uint32_t ts;
+};
+struct ShardX {
+  OwnRec* orec;             // [world][ids_block]
+  uint32_t* oslot;          // [world][ids_block] (world > 1)
+  uint32_t* xs;             // [T][xmask + 2] slots of xstride words (world > 1; the last slot of a table:
+                            // the key that marks an empty slot itself)
+  uint32_t xmask;
+  uint32_t xstride;         // words per slot: 4 + world rounded up to a multiple of 4
+  uint32_t hints;           // bit i: OwnRec of the launch's i-th table may be trusted (nothing touched the
+                            // table since the lookup wrote them)
+  uint32_t pad;
+};
+constexpr uint32_t kXKeyWords = 4;   // key + peer mask in front of a slot's entries
+
+__global__ __launch_bounds__(256) void shard_x_clear_kernel(uint32_t* xs, uint64_t nslots, uint32_t xstride) {
+  for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < nslots;
+       i += uint64_t(gridDim.x) * blockDim.x) {
+    uint32_t* sl = xs + i * xstride;
+    *reinterpret_cast<int64_t*>(sl) = kEmptyKey;
+    for (uint32_t w = 2; w < xstride; ++w) sl[w] = 0u;
+  }
+}
+
 // ---- owner: lookup of the received blocks ---------------------------------------------------------
 struct ShardOwnerArgs {
   ConstViews views;
   ShardGeom geo;
+  ShardX x;
   const int64_t* recv_ids;    // [world][ids_block]
   float* rows;                // lookup: out [world][rows_block]; upsert: gradients in
   uint32_t* flags;
@@ -76,6 +119,102 @@ __device__ __forceinline__ uint32_t shard_block_count(const ShardOwnerArgs& A, u
   return uint32_t(c);
 }
 
+// Lookup of one (peer, table) segment: two ids per lane group, all probes, then all row loads in flight
+// (lookup_role_u), + what the update will want to know (OwnRec) + (xs != nullptr: world > 1) the
+// registration of the id in the cross-peer scratch.  The registration's claim is issued behind the row
+// loads, so the rows leave while it is in flight.
+template <int G, int VEC>
+__device__ __forceinline__ void shard_lookup_loop(const TableView& tv, const int64_t* __restrict__ ids, uint32_t n,
+                                                  float* __restrict__ out, int count_hits,
+                                                  OwnRec* __restrict__ orec, uint32_t* __restrict__ oslot,
+                                                  uint32_t* __restrict__ xs, uint32_t xmask, uint32_t xstride,
+                                                  uint32_t p) {
+  constexpr int UNR = 2;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (G - 1);
+  const int gbase = lane & ~(G - 1);
+  const uint32_t ngroups = (n + 1u) / 2u;
+  uint64_t hits = 0;
+#pragma unroll 1
+  for (uint32_t grp = (blockIdx.x * 512u + threadIdx.x) / G; grp < ngroups; grp += gridDim.x * 512u / G) {
+    const uint32_t g0 = grp * UNR;
+    const bool mine_valid = j < UNR && g0 + uint32_t(j) < n;
+    const int64_t myid = mine_valid ? ids[g0 + j] : 0;
+    int64_t id[UNR], kk[UNR];
+    bool valid[UNR];
+    uint32_t row[UNR], tsv[UNR];
+    uint64_t i1[UNR], i2[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      id[u] = __shfl(myid, gbase + u);
+      valid[u] = g0 + u < n;
+      const uint64_t hv = hash_key(id[u]);
+      i1[u] = index_hash(tv.hp, hv);
+      i2[u] = alt_index(tv.hp, partial_key(hv), i1[u]);
+      const GBucket* b = global_bucket(tv.buckets + ((j & 4) ? i2[u] : i1[u]));
+      kk[u] = b->key[j & 3];
+      row[u] = b->row[j & 3];
+      tsv[u] = b->ts[j & 3];   // (same 64-byte line)
+    }
+    bool found[UNR];
+    const float* rp[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const bool use = valid[u] && j < 8 && id[u] != kEmptyKey;
+      const uint64_t m = group_mask_of<G>(__ballot(use && kk[u] == id[u]), gbase);
+      found[u] = m != 0;
+      const int src = found[u] ? (__ffsll(static_cast<long long>(m)) - 1) : 0;
+      uint32_t r = __shfl(use ? row[u] : kNoRow, gbase + src);
+      const uint32_t ots = __shfl(tsv[u], gbase + src);
+      const bool special = valid[u] && id[u] == kEmptyKey;
+      if (special) {
+        found[u] = tv.ctr->special_state == 1;
+        r = tv.ctr->special_row;
+      }
+      found[u] = found[u] && valid[u];
+      if (valid[u] && j == u) {   // (the side slot's key is left to the update's own path)
+        OwnRec rec;
+        rec.loc = (((src & 4) ? i2[u] : i1[u]) << 2) | uint64_t(src & 3);
+        rec.row = (found[u] && !special) ? r : kNoRow;
+        rec.ts = ots;
+        orec[g0 + u] = rec;
+      }
+      rp[u] = found[u] ? row_ptr(tv, r) : nullptr;
+      if (count_hits) hits += __popcll(__ballot(found[u] && j == 0));
+    }
+    for (uint32_t e = j * VEC; e < tv.dim; e += G * VEC) {
+      Vec<VEC> v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        vec_zero(v[u]);
+        if (found[u]) v[u].load(rp[u] + e);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+        if (valid[u]) store_stream<VEC>(out + size_t(g0 + u) * tv.dim + e, v[u]);
+    }
+    if (xs && mine_valid) {   // lane u of the group registers id u
+      uint32_t h = xmask + 1u;
+      if (myid != kEmptyKey) {
+        h = uint32_t(hash_key(myid) >> 20) & xmask;
+        for (;;) {
+          const unsigned long long old =
+              atomicCAS(reinterpret_cast<unsigned long long*>(xs + size_t(h) * xstride),
+                        static_cast<unsigned long long>(kEmptyKey), static_cast<unsigned long long>(myid));
+          if (old == static_cast<unsigned long long>(kEmptyKey) || old == static_cast<unsigned long long>(myid)) break;
+          h = (h + 1u) & xmask;
+        }
+      }
+      uint32_t* sl = xs + size_t(h) * xstride;
+      atomicOr(reinterpret_cast<unsigned long long*>(sl + 2), 1ull << p);
+      sl[kXKeyWords + p] = g0 + uint32_t(j) + 1u;
+      oslot[g0 + j] = h;
+    }
+  }
+  if (count_hits && hits && lane == __ffsll(static_cast<long long>(__ballot(1))) - 1)
+    atomicAdd(&tv.ctr->hits, (unsigned long long)hits);
+}
+
 // grid (x, world * tc): y = peer * tc + table of the launch
 template <int VW>
 __global__ __launch_bounds__(512) void shard_lookup_kernel(ShardOwnerArgs A) {
@@ -85,10 +224,14 @@ __global__ __launch_bounds__(512) void shard_lookup_kernel(ShardOwnerArgs A) {
   if (n == 0) return;
   const ShardTab tb = A.tab[t];
   const TableView& tv = deref_const(A.views + (A.t0 + t));
-  const int64_t* ids = A.recv_ids + size_t(p) * A.geo.ids_block + tb.id_off;
+  const size_t eb = size_t(p) * A.geo.ids_block + tb.id_off;
+  const int64_t* ids = A.recv_ids + eb;
   float* out = A.rows + size_t(p) * A.geo.rows_block + tb.row_off;
   const int ch = A.count_hits[t];
-#define MHTE_SEGL_CALL(G_, V_) seg_lookup_loop<G_, V_>(tv, ids, n, out, ch)
+  uint32_t* xs = A.x.xs ? A.x.xs + size_t(A.t0 + t) * (size_t(A.x.xmask) + 2u) * A.x.xstride : nullptr;
+  uint32_t* oslot = A.x.oslot ? A.x.oslot + eb : nullptr;
+#define MHTE_SEGL_CALL(G_, V_) \
+  shard_lookup_loop<G_, V_>(tv, ids, n, out, ch, A.x.orec + eb, oslot, xs, A.x.xmask, A.x.xstride, p)
   MHTE_SWITCH_G(VW, A.g[t] & ~kShapeGroupBit, MHTE_SEGL_CALL)
 #undef MHTE_SEGL_CALL
 }
@@ -177,6 +320,197 @@ __global__ __launch_bounds__(64) void shard_slow_kernel(ShardOwnerArgs A) {
     A.clear_ids[size_t(lane) * A.geo.ids_block + A.t0 + t] = 0;
 }
 
+// ---- owner: ONE launch applies every peer's gradient block -----------------------------------------
+// grid (x, world * tc): y = peer * tc + table of the launch, a lane group per (peer, slot).  The group of
+// the LOWEST peer that sent an id applies all of the id's entries, one optimizer step per sender in rank
+// order, and hands the cross-peer slot back empty; the other peers' groups of that id leave.  The row
+// is reached through the lookup's record when it can be trusted (no bucket line is read), otherwise
+// by probe / insert as seg_upsert_loop does.  Ids whose two buckets are full go to the table's pending
+// list as (slot, peer); shard_slow_all_kernel finishes them.
+template <int G, int VEC, bool GROUP>
+__device__ __forceinline__ void shard_apply_loop(const ShardOwnerArgs& A, const TableView& tv, uint32_t p,
+                                                 uint32_t t, uint32_t n) {
+  constexpr int NCH = 64 / G;   // chunks of G peers (world <= kMaxShards = 64)
+  const ShardTab tb = A.tab[t];
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (G - 1);
+  const int gbase = lane & ~(G - 1);
+  const uint32_t world = A.geo.world;
+  const bool multi = world > 1u;
+  const size_t eb = size_t(p) * A.geo.ids_block + tb.id_off;
+  const int64_t* ids = A.recv_ids + eb;
+  const OwnRec* orec = A.x.orec + eb;
+  uint32_t* const xs = multi ? A.x.xs + size_t(A.t0 + t) * (size_t(A.x.xmask) + 2u) * A.x.xstride : nullptr;
+  const bool trust = ((A.x.hints >> t) & 1u) != 0u;
+  const ApplyArgs& a = A.a[t];
+  const uint32_t ngroups_wg = 256 / G;
+#pragma unroll 1
+  for (uint32_t g0 = blockIdx.x * ngroups_wg; g0 < n; g0 += gridDim.x * ngroups_wg) {  // wave-uniform
+    const uint32_t g = g0 + threadIdx.x / G;
+    const bool valid = g < n;
+    const uint32_t gs = valid ? g : 0u;   // (loads from a safe index, masked afterwards)
+    const int64_t id = ids[gs];
+    const OwnRec rec = orec[gs];
+    uint32_t hs = 0;
+    if (multi) hs = A.x.oslot[eb + gs];
+    // ---- the id's entries; who applies them
+    unsigned long long pm = 1ull << p;
+    uint32_t ent[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) ent[c] = g + 1u;
+    bool mine = valid;
+    uint32_t* sl = nullptr;
+    if (multi) {
+      sl = xs + size_t(hs) * A.x.xstride;
+      pm = *reinterpret_cast<const unsigned long long*>(sl + 2);   // one 8-byte load: all or nothing
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const uint32_t q = uint32_t(c * G + j);
+        ent[c] = (uint32_t(c * G) < world && q < world) ? sl[kXKeyWords + q] : 0u;
+      }
+      if (!valid) pm = 0ull;
+      mine = ((pm >> p) & 1ull) != 0ull && (pm & ((1ull << p) - 1ull)) == 0ull;
+    }
+    // ---- the row: through the lookup's record, else probe / insert
+    const bool hinted = mine && trust && rec.row != kNoRow;
+    const bool need = mine && !hinted;
+    uint32_t r = rec.row;
+    bool is_new = false, deferred = false;
+    if (__any(need)) {
+      const Probe<G> pr = probe_issue<G>(tv, id, need, j);
+      const SlotResult sr = upsert_resolve<G>(tv, (Bucket*)pr.b, id, need, pr.k, pr.row, lane, a.ts);
+      if (need) {
+        r = sr.r;
+        is_new = sr.is_new;
+        deferred = sr.deferred;
+      }
+    }
+    if (hinted && j == 0 && rec.ts != a.ts)   // SetTimestamp(update_time): the slot is known, the line is not read
+      global_bucket(tv.buckets + (rec.loc >> 2))->ts[rec.loc & 3ull] = a.ts;
+    if (deferred && j == 0) {
+      const uint32_t slot = atomicAdd(&tv.ctr->n_pending, 1u);
+      A.pending[t][2 * slot] = g;
+      A.pending[t][2 * slot + 1] = p;
+    }
+    if (mine && !deferred) {
+      float* rp = row_ptr(tv, r);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        unsigned long long mc = pm >> (c * G);
+        if (G < 64) mc &= (1ull << G) - 1ull;
+        while (mc) {   // (group-uniform)
+          const int k = __ffsll(static_cast<long long>(mc)) - 1;
+          mc &= mc - 1ull;
+          const uint32_t sq = __shfl(ent[c], gbase + k) - 1u;
+          const float* values = A.rows + size_t(c * G + k) * A.geo.rows_block + tb.row_off;
+          apply_row<G, VEC, kOpOptimize, false, GROUP>(tv, rp, is_new, j, values, nullptr, 0u, 1u, int64_t(sq), a);
+          is_new = false;
+        }
+      }
+      if (multi) {   // the slot goes back empty (its entries are consumed)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const uint32_t q = uint32_t(c * G + j);
+          if (uint32_t(c * G) < world && q < world) sl[kXKeyWords + q] = 0u;
+        }
+        if (j == 0) {
+          *reinterpret_cast<unsigned long long*>(sl + 2) = 0ull;
+          *reinterpret_cast<int64_t*>(sl) = kEmptyKey;
+        }
+      }
+    }
+  }
+}
+
+template <int VW, bool GROUP = false>
+__global__ __launch_bounds__(256, GROUP ? 1 : MHTE_SEGU_OCC) void shard_apply_kernel(ShardOwnerArgs A) {
+  const uint32_t p = blockIdx.y / A.tc, t = blockIdx.y % A.tc;
+  if (!MHTE_SHAPE_IS(VW, A.g[t]) || ((A.g[t] & kShapeGroupBit) != 0u) != GROUP) return;
+  const uint32_t n = shard_block_count(A, p, t);
+  if (n == 0) return;
+  const TableView& tv = deref_const(A.views + (A.t0 + t));
+#define MHTE_SEGU_CALL(G_, V_) shard_apply_loop<G_, V_, GROUP>(A, tv, p, t, n)
+  MHTE_SWITCH_G(VW, A.g[t] & ~kShapeGroupBit, MHTE_SEGU_CALL)
+#undef MHTE_SEGU_CALL
+}
+
+// displacement pass behind shard_apply_kernel, one wavefront per table: every deferred id's entries in
+// rank order, as the fast path would have applied them; the last launch of a step, so it also clears
+// the headers of the step's send blocks (the next numbering into them counts from zero)
+__global__ __launch_bounds__(64) void shard_slow_all_kernel(ShardOwnerArgs A) {
+  __shared__ BfsSlot q[kMaxCuckooCount];
+  __shared__ CuckooRecord path[kMaxBfsPathLen];
+  const uint32_t t = blockIdx.x;
+  const int lane = threadIdx.x;
+  const TableView& tv = deref_const(A.views + (A.t0 + t));
+  const uint32_t np = tv.ctr->n_pending;
+  const ShardTab tb = A.tab[t];
+  const ApplyArgs& a = A.a[t];
+  const uint32_t world = A.geo.world;
+  const bool multi = world > 1u;
+  for (uint32_t i = 0; i < np; ++i) {
+    const uint32_t g = A.pending[t][2 * i], p = A.pending[t][2 * i + 1];
+    const size_t eb = size_t(p) * A.geo.ids_block + tb.id_off;
+    const int64_t id = A.recv_ids[eb + g];
+    uint32_t r;  // (only lane 0's value is read, after the search: not merged with a constant on purpose,
+                 // slowpath_role)
+    if (lane == 0) r = static_cast<uint32_t>(atomicAdd(&tv.ctr->alloc, (1ull << 32) | 1ull));
+    const long long pos = wave_insert_slot(tv.buckets, tv.hp, id, q, path, lane);
+    if (lane == 0) {
+      if (pos >= 0) {
+        Bucket* b = tv.buckets + (pos >> 2);
+        b->row[pos & 3] = r;
+        b->ts[pos & 3] = a.ts;
+      } else {
+        atomicAdd(&tv.ctr->alloc, ~((1ull << 32) - 1ull));
+        atomicOr(&tv.ctr->error, 1u);
+        atomicAdd(&tv.ctr->n_dropped, 1u);
+      }
+    }
+    r = __shfl(r, 0);
+    unsigned long long pm = 1ull << p;
+    uint32_t* sl = nullptr;
+    if (multi) {
+      sl = A.x.xs + (size_t(A.t0 + t) * (size_t(A.x.xmask) + 2u) + A.x.oslot[eb + g]) * A.x.xstride;
+      pm = *reinterpret_cast<const unsigned long long*>(sl + 2);
+    }
+    bool fresh = true;
+    while (pm) {
+      const int k = __ffsll(static_cast<long long>(pm)) - 1;
+      pm &= pm - 1ull;
+      const uint32_t sq = multi ? sl[kXKeyWords + k] - 1u : g;
+      const float* values = A.rows + size_t(k) * A.geo.rows_block + tb.row_off;
+      if (pos >= 0) {
+        const bool grp = (A.g[t] & kShapeGroupBit) != 0u;   // (rare path: both forms in one kernel)
+        if (A.g[t] & 1u) {
+          if (grp) apply_row<64, 1, kOpOptimize, false, true>(tv, row_ptr(tv, r), fresh, lane, values, nullptr, 0u,
+                                                              1u, int64_t(sq), a);
+          else apply_row<64, 1, kOpOptimize, false, false>(tv, row_ptr(tv, r), fresh, lane, values, nullptr, 0u,
+                                                           1u, int64_t(sq), a);
+        } else {
+          if (grp) apply_row<64, 4, kOpOptimize, false, true>(tv, row_ptr(tv, r), fresh, lane, values, nullptr, 0u,
+                                                              1u, int64_t(sq), a);
+          else apply_row<64, 4, kOpOptimize, false, false>(tv, row_ptr(tv, r), fresh, lane, values, nullptr, 0u,
+                                                           1u, int64_t(sq), a);
+        }
+        fresh = false;
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    if (multi) {
+      for (uint32_t w = kXKeyWords + uint32_t(lane); w < kXKeyWords + world; w += 64u) sl[w] = 0u;
+      if (lane == 0) {
+        *reinterpret_cast<unsigned long long*>(sl + 2) = 0ull;
+        *reinterpret_cast<int64_t*>(sl) = kEmptyKey;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
+  if (lane == 0 && np) tv.ctr->n_pending = 0;
+  if (A.zero_headers && uint32_t(lane) < world)
+    A.clear_ids[size_t(lane) * A.geo.ids_block + A.t0 + t] = 0;
+}
+
 // ---- sender: rows -> occurrences, occurrence gradients -> row slots ---------------------------------
 struct ShardGatherTab {
   uint32_t nblk_items;
@@ -242,6 +576,169 @@ __global__ __launch_bounds__(256) void shard_scatter_kernel(ShardGatherArgs A) {
   c.out = A.out + size_t(gt.io_off);
   shard_gather_ctl(c, s, cur, A.slot_off, A.n_max, t, A.tab[tl].dim, gt);
   shard_gather_switch<true, VW>(gt.gv, d, c, blockIdx.x, raw);
+}
+
+// ---- sender: rows back -> occurrences AND the run dedup of the next batch, ONE launch ----------------
+// (what mstep_fwd_dedup_kernel is to the unsharded step: the scatter is bound by HBM bandwidth, the
+// dedup by device-scope atomics; side by side they take about as long as the longer one.)
+// 1024-thread workgroups: the first F.nd are the dedup's persistent workgroups, the rest scatter —
+// the multi-table forward's role (mstep_scatter_role) with the table probe replaced by the row the
+// owner sent back: distinct ids UNR per lane group, heavy lists one work item per wavefront (run starts
+// by wave scan, no LDS, no barrier).
+template <int G, int BLOCK, int UNR, int VEC>
+__device__ __forceinline__ void shard_scatter_role(const RunView& d, const float* __restrict__ rows,
+                                                   const uint32_t* __restrict__ slot_off,
+                                                   float* __restrict__ out, uint32_t dim, int64_t n_max,
+                                                   uint32_t bid, uint32_t nblk, uint32_t item_split) {
+  constexpr int NG = BLOCK / G;
+  constexpr int GPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (G - 1);
+  const int gbase = lane & ~(G - 1);
+  const int grp = threadIdx.x / G;
+  const uint32_t e = uint32_t(j) * VEC;
+  const bool ev = e < dim;
+  const uint32_t n_unique = d.ctr[0];
+  const uint32_t n_items = d.ctr[2];
+  const int64_t nu = min(n_max, int64_t(n_unique));
+  constexpr int PER = (kStepLightMax + G - 1) / G;
+  const int64_t stride = int64_t(nblk) * NG * UNR;
+#pragma unroll 1
+  for (int64_t g0 = int64_t(bid) * NG * UNR; g0 < nu; g0 += stride) {  // workgroup-uniform
+    uint32_t cnt[UNR], hp[UNR], gs[UNR], ix[UNR];
+    bool valid[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t g = g0 + int64_t(grp) * UNR + u;
+      valid[u] = g < nu;
+      const int64_t gi = valid[u] ? g : 0;  // (loads from a safe index, masked afterwards)
+      cnt[u] = d.ucnt[gi];
+      hp[u] = d.upos[gi];
+      gs[u] = d.uslot[gi];
+      ix[u] = slot_off[gi];
+    }
+    Vec<VEC> v[UNR];
+    uint32_t x[UNR][PER];
+    bool flat[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (!valid[u]) cnt[u] = 0;
+      flat[u] = cnt[u] > 1 && cnt[u] <= uint32_t(kStepLightMax);
+      vec_zero(v[u]);
+      if (valid[u] && cnt[u] <= uint32_t(kStepLightMax) && ix[u] != 0xffffffffu && ev) v[u].load(rows + size_t(ix[u]) + e);
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const uint32_t idx = uint32_t(j) + uint32_t(q) * G;
+        x[u][q] = (flat[u] && idx < cnt[u]) ? d.hlist[size_t(gs[u]) * kLightMax + idx] : 0xffffffffu;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (cnt[u] == 1) {
+        if (ev) MHTE_SCATTER_STORE(out + int64_t(hp[u]) * dim + e, v[u]);
+      } else if (flat[u]) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+#pragma unroll 4
+          for (int t2 = 0; t2 < G; ++t2) {
+            const uint32_t p = __shfl(x[u][q], gbase + t2);
+            if (p != 0xffffffffu && ev) MHTE_SCATTER_STORE(out + int64_t(p) * dim + e, v[u]);
+          }
+        }
+      }
+    }
+  }
+  // ---- heavy lists: one work item per WAVEFRONT (mstep_scatter_role)
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll 1
+  for (uint32_t unit = bid * (BLOCK / 64) + wave; unit < n_items * item_split; unit += nblk * (BLOCK / 64)) {
+    const uint32_t w = unit / item_split, sub = unit % item_split;
+    const ItemHdr hd = d.item_hdr[w];
+    const uint32_t rval = d.item_runs[size_t(w) * 64 + lane];
+    const uint32_t b0 = hd.meta & 0xffu, nbk = (hd.meta >> 8) & 0xffu;
+    const uint32_t val = (uint32_t(lane) < nbk) ? rval : 0u;
+    uint32_t incl = run_cnt(val);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    const uint32_t excl = incl - run_cnt(val);
+    const uint32_t E = __shfl(incl, 63);
+    const uint32_t ixh = slot_off[hd.u];
+    Vec<VEC> v;
+    vec_zero(v);
+    if (ixh != 0xffffffffu && ev) v.load(rows + size_t(ixh) + e);
+#pragma unroll 1
+    for (uint32_t qb = sub * 64; qb < E; qb += 64 * item_split) {
+      const uint32_t q = qb + uint32_t(lane);
+      const bool has = q < E;
+      const uint32_t qq = has ? q : 0u;
+      uint32_t lo = 0, hi = 63;  // run lo with excl[lo] <= q < incl[lo]
+#pragma unroll
+      for (int it2 = 0; it2 < 6; ++it2) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        const bool le = uint32_t(__shfl(excl, int(mid))) <= qq;
+        lo = le ? mid : lo;
+        hi = le ? hi : mid - 1;
+      }
+      const uint32_t vr = __shfl(val, int(lo));
+      const uint32_t er = __shfl(excl, int(lo));
+      const uint32_t base = (b0 + lo) * kRdBlock;
+      uint32_t p = base + run_first(vr);
+      if (has && run_cnt(vr) != 1) p = base + uint32_t(d.seg[base + run_off(vr) + (qq - er)]);
+#pragma unroll 4
+      for (int t = 0; t < G; ++t) {
+        const int idx = t * GPW + (lane / G);
+        const uint32_t pt = __shfl(p, idx);
+        if (qb + uint32_t(idx) < E && ev) MHTE_SCATTER_STORE(out + int64_t(pt) * dim + e, v);
+      }
+    }
+  }
+}
+
+#ifndef MHTE_SHARD_SCATTER_UNR
+#define MHTE_SHARD_SCATTER_UNR 2
+#endif
+__global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void shard_scatter_dedup_kernel(
+    ShardGatherArgs A, MDedupArgs D, MFwdFuse F, uint32_t item_split) {
+  __shared__ __attribute__((aligned(16))) RdLds L;
+  WaveTrace wt(nullptr);
+  if (blockIdx.x < F.nd) {
+    const uint32_t total = D.blk_start[D.T];
+#pragma unroll 1
+    for (uint32_t w = blockIdx.x; w < total; w += F.nd) {
+      uint32_t t = 0;
+      while (t + 1 < D.T && D.blk_start[t + 1] <= w) ++t;
+      const MStepStatic& s = deref_const(D.st + t);
+      RunView d = s.rv[D.slot & 1u];
+      d.ids = D.ids + D.id_off[t];
+      d.n = D.id_off[t + 1] - D.id_off[t];
+      d.nblk = D.blk_start[t + 1] - D.blk_start[t];
+      rd_dedup_role(d, w - D.blk_start[t], L, wt);
+      __syncthreads();
+    }
+    return;
+  }
+  const uint32_t lin = blockIdx.x - F.nd;
+  uint32_t tl = 0;
+  while (tl + 1 < A.tc && F.fwd_start[tl + 1] <= lin) ++tl;
+  const ShardGatherTab gt = A.gt[tl];
+  const uint32_t bid = lin - F.fwd_start[tl];
+  const uint32_t nblk = F.fwd_start[tl + 1] - F.fwd_start[tl];
+  // (tables that move one float per lane are scattered by a launch of their own, shard_scatter_kernel<1>)
+  if (gt.n == 0 || bid >= nblk || !MHTE_SHAPE_IS(4, gt.gv)) return;
+  const uint32_t t = A.t0 + tl;
+  const MStepStatic& s = deref_const(A.st + t);
+  const uint32_t cur = A.slot & 1u;
+  const RunView d = s.rv[cur];
+  float* out = A.out + size_t(gt.io_off);
+  const uint32_t* so = A.slot_off + size_t(t) * A.n_max;
+  const uint32_t dim = A.tab[tl].dim;
+#define MHTE_SSC_CALL(G_, V_) \
+  shard_scatter_role<G_, kRdBlock, MHTE_SHARD_SCATTER_UNR, V_>(d, A.in, so, out, dim, s.n_max, bid, nblk, item_split)
+  MHTE_SWITCH_G(4, gt.gv, MHTE_SSC_CALL)
+#undef MHTE_SSC_CALL
 }
 
 // backward launch of the sender side, per table:

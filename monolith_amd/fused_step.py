@@ -258,6 +258,35 @@ class SparseStep:
                                   self.lrs, update_time, global_step, flags=_lib.MHTE_IDS_UNIQUE,
                                   n_max=self.batch)
 
+  def c_loop(self, ids_all: torch.Tensor, lo: int, hi: int, grad_pool, update_time0: int):
+    """Steps [lo, hi) of the contiguous batch array ``ids_all`` [n_batches, batch] enqueued by a plain C
+    loop over the C ABI (csrc/eager_loop.c, ``mhte_eager_step_loop``): forward(batch s, next = s + 1) and
+    backward(grad_pool[s % len], update_time0 + s) per step, no interpreter in between.  Batch ``lo`` must
+    have been deduplicated ahead by the previous step (``forward(.., next_ids=ids_all[lo])``); on return
+    batch ``hi`` is, so ``forward(ids_all[hi], ..)`` continues the pipeline."""
+    C = _lib.C
+    assert self._mode == "pipe" and ids_all.is_contiguous() and ids_all.shape[1] == self.batch
+    at = self._slot_of(self._batch_key(ids_all[lo]))
+    assert at is not None, "batch lo was not deduplicated ahead"
+    E = _lib.eager_lib()
+    ws = (C.c_void_p * 3)(*[w._h for w in self._ws])  # pylint: disable=protected-access
+    uid = (C.c_void_p * 3)(*[u.data_ptr() for u in self._uids])
+    nu = (C.c_void_p * 3)(*[u.data_ptr() for u in self._nu])
+    gp = (C.c_void_p * len(grad_pool))(*[g.data_ptr() for g in grad_pool])
+    lrs = np.ascontiguousarray(self.lrs, dtype=np.float32)
+    r = E.mhte_eager_step_loop(
+        self.table.handle, C.c_int32(self.idx), ws, uid, nu, C.c_int32(at), _lib.vp(ids_all),
+        C.c_int64(self.batch), C.c_int64(lo), C.c_int64(hi), _lib.vp(self.emb), gp,
+        C.c_int32(len(grad_pool)), _lib.vp(self.grad_u), lrs.ctypes.data_as(C.POINTER(C.c_float)),
+        C.c_int64(lrs.size), C.c_int64(int(update_time0)),
+        C.c_int32(_lib.MHTE_EXACT_ORDER if self.exact_order else 0),
+        C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if r < 0:
+      _lib.check(-r - 1)
+    self._key = [None, None, None]
+    self._key[r] = self._batch_key(ids_all[hi])
+    self._cur, self._nxt, self._ahead = r, None, None
+
   def quiesce(self):
     """Host-synchronise and forget the side-stream event.  Call before capturing steps into a
     hipGraph: a capture must not wait on events recorded outside it."""

@@ -420,6 +420,10 @@ class RefPs:
   def size(self):
     return int(self.L.ref_ps_size(self.h))
 
+  def hashpower(self, shard=0):
+    self.L.ref_ps_hashpower.restype = C.c_int64
+    return int(self.L.ref_ps_hashpower(self.h, C.c_int(shard)))
+
   def step(self, ids, grads, lr, update_time, want_emb=True):
     ids, grads = _i64(ids), _f32(grads)
     emb = np.empty((ids.size, self.dim), np.float32) if want_emb else None

@@ -383,6 +383,9 @@ void ref_ps_breakdown(void* h, double* out6) {
   for (int i = 0; i < 6; ++i) out6[i] = ps->phase_s[i];
 }
 void ref_ps_free(void* h) { delete static_cast<RefPs*>(h); }
+int64_t ref_ps_hashpower(void* h, int shard) {
+  return static_cast<RefPs*>(h)->shards[shard]->m.hashpower();
+}
 int64_t ref_ps_size(void* h) {
   RefPs* ps = static_cast<RefPs*>(h);
   int64_t s = 0;

@@ -475,3 +475,30 @@ def test_adagrad_avx_restatement_matches_the_committed_as_built_fixture():
       num, norm = O.adagrad_avx(num, norm, z["grad_d%d" % dim][s], float(z["lr"]), float(z["wd"]))
       np.testing.assert_array_equal(num, z["num_d%d" % dim][s])
       np.testing.assert_array_equal(norm, z["norm_d%d" % dim][s])
+
+
+def test_shared_reference_map_64_threads_through_two_doublings():
+  """Variant (ii) of the CPU baseline (bench.py --cpu-child ii): ONE reference cuckoohash_map upserted
+  by 64 threads while it doubles twice, from the capacity the baseline starts it at (2^18 slots = the
+  map's kMaxNumLocks buckets: the locks array is never replaced, so the reference's
+  `old_buckets_.swap(buckets_)` window — round 4's rc -11 of the 256-thread baseline, root-caused with
+  oracle/stress/shared_map_stress.cc — cannot open).  Every id inserted is found afterwards, the rows
+  are what a single-threaded replay of the same steps gives."""
+  if not O.ref_available(True):
+    pytest.skip("oracle/_ref not built")
+  rng = np.random.default_rng(5)
+  D, B, steps = 8, 65536, 11
+  ps = O.RefPs(64, D, O.OPT_ADAGRAD, 0.1, 0.0, 0.0, 1 << 18, avx=True, shared=True)
+  one = O.RefPs(1, D, O.OPT_ADAGRAD, 0.1, 0.0, 0.0, 1 << 18, avx=True, shared=True)
+  hp0 = ps.hashpower()
+  g = (rng.standard_normal((B, D)) * 0.01).astype(np.float32)
+  ids = None
+  for s in range(steps):
+    ids = rng.integers(1, 1 << 40, size=B, dtype=np.int64)
+    ps.step(ids, g, 0.001, 1_700_000_000 + s, want_emb=False)
+    one.step(ids, g, 0.001, 1_700_000_000 + s, want_emb=False)
+  assert ps.hashpower() >= hp0 + 2, (hp0, ps.hashpower())
+  assert ps.size() == one.size()
+  rows, hits = ps.lookup(ids)
+  assert hits == B
+  np.testing.assert_array_equal(rows, one.lookup(ids)[0])

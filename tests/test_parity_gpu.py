@@ -1636,6 +1636,35 @@ def test_pipeline_picks_up_slices_of_a_resident_id_array():
   assert tags == ["step_fwd_kernel", "step_bwd_kernel"] * 3, tags
 
 
+def test_c_loop_enqueues_the_same_steps_as_the_python_calls():
+  """bench.py's `eager_cpp` window: K pipelined steps enqueued by a plain C loop over the C ABI
+  (csrc/eager_loop.c, gcc, public header only) — the same two launches per step and the same table
+  afterwards as the Python calls, and the Python pipeline continues behind it."""
+  n, dim, steps = 4096, 16, 7
+  ids_all = ids_t(np.stack([S.id_batch(s, n, 50000, "zipf") for s in range(steps + 2)]))
+  pool = [val_t(S.grad_batch(s, n, dim)) for s in range(3)]
+  mts = [make({"a": adagrad_cfg(dim, 0.1, 0.1, initial_capacity=1 << 15)}) for _ in range(2)]
+  st = [SparseStep(mt, "a", n, exact_order=True) for mt in mts]
+  for s in range(steps):          # reference: one Python call pair per step
+    st[0].forward(ids_all[s], next_ids=ids_all[s + 1])
+    st[0].backward(pool[s % 3], S.update_time(s))
+  st[1].forward(ids_all[0], next_ids=ids_all[1])
+  st[1].backward(pool[0], S.update_time(0))
+  torch.cuda.synchronize()
+  _lib.profile_arm(32)
+  st[1].c_loop(ids_all, 1, steps - 1, pool, S.update_time(0))
+  torch.cuda.synchronize()
+  tags = [t for t, _ in _lib.profile_read()]
+  assert tags == ["step_fwd_kernel", "step_bwd_kernel"] * (steps - 2), tags
+  st[1].forward(ids_all[steps - 1], next_ids=ids_all[steps])     # picks the pipeline up
+  st[1].backward(pool[(steps - 1) % 3], S.update_time(steps - 1))
+  probe = ids_t(np.unique(ids_all[:steps].cpu().numpy()))
+  a = mts[0].lookup({"a": probe})["a"]
+  b = mts[1].lookup({"a": probe})["a"]
+  assert torch.equal(a, b)
+  assert mts[0].size("a") == mts[1].size("a")
+
+
 def test_restore_rejects_a_stale_shard_set(tmp_path):
   """Two saves under one basename with different shard counts leave two sets of files; the
   reference validates the set it globs (ValidateShardedFiles), so restore must fail instead of
