@@ -42,7 +42,7 @@ enum {
 
 const char* mhte_last_error(void);
 /* ABI version of this header; mhte_abi_version() must return the same value. */
-#define MHTE_ABI_VERSION 14
+#define MHTE_ABI_VERSION 15
 int32_t mhte_abi_version(void);
 
 /* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
@@ -234,6 +234,26 @@ mhte_status mhte_fused_optimize(mhte_multi_table* t, const int64_t* ids,
 mhte_status mhte_lookup_entry(mhte_multi_table* t, const int64_t* id, const int64_t* id_split,
                               int64_t n_split, char* entries, int64_t cap, int64_t* entry_offsets,
                               int64_t* needed, void* stream);
+/* MonolithHashTableSaveAsTensor (RT/ops/hash_table/misc_ops.cc:46-94; op :96-109): one table's entries
+ * as serialized EntryDump strings, `limit` at a time, resumable — the table iterated in Save's order
+ * (cuckoohash_map.hpp:740-773 partial_dump: bucket range of shard `shard_idx` of `num_shards`, resumed
+ * `offset` slots into it; the count is checked after an entry is taken, so limit <= 0 still yields one).
+ * *new_offset is the op's first output: behind the last entry when the limit stopped the scan, one
+ * bucket past the shard's range when the range ran out (call again until *n_entries == 0).
+ * entries / entry_offsets [host]: as mhte_lookup_entry (offsets_cap >= limit + 1 values).  Synchronises. */
+mhte_status mhte_table_save_as_tensor(mhte_multi_table* t, int32_t table, int32_t shard_idx,
+                                      int32_t num_shards, int64_t limit, int64_t offset, int64_t* new_offset,
+                                      char* entries, int64_t cap, int64_t* entry_offsets,
+                                      int64_t offsets_cap, int64_t* n_entries, int64_t* needed, void* stream);
+/* MonolithHashTableLookupGradient (RT/ops/hash_table_lookup_op.cc:110-147; op :254-270): the gradient of
+ * a lookup gathered back per (batch row, id) pair of a sparse id tensor:
+ *   out_ids[i] = id_values[i],  out_grads[i, :] = input_grads[id_indices[i * index_cols], :]
+ * id_indices [dev, n x index_cols] (column 0 = the batch row), id_values [dev, n], input_grads
+ * [dev, n_rows x dim] -> out_ids [dev, n], out_grads [dev, n x dim].  A row outside [0, n_rows) is
+ * InvalidArgument (its output row is zeros; the reference indexes unchecked).  Synchronises. */
+mhte_status mhte_lookup_gradient(const int64_t* id_indices, int64_t n, int64_t index_cols,
+                                 const int64_t* id_values, const float* input_grads, int64_t n_rows,
+                                 int32_t dim, int64_t* out_ids, float* out_grads, void* stream);
 /* MonolithMultiHashTableFeatureStat (RT/ops/multi_hash_table_save_restore_ops.cc:424-497,522-530):
  * entries per table name summed over the .meta sidecars of a checkpoint.  names [host, names_cap
  * bytes]: the names, each NUL-terminated, sorted; counts [host, cap]. */
@@ -721,6 +741,12 @@ mhte_status mhte_shard_step_unique_counts(mhte_shard_step* s, int64_t* counts, v
  * [3] = transport: 0 identity, 1 RCCL, 2 in-process group, 3 peer stores into fine-grained windows,
  * 4 peer stores into plain device memory (MHTE_SHARD_WINDOW=coarse) */
 mhte_status mhte_shard_step_info(mhte_shard_step* s, int64_t info[4]);
+/* out[0] / out[1] = kernel launches + exchanges (a peer-store push, a sync, an RCCL send / recv group; in
+ * an in-process group one per exchange) the step's last forward / backward call enqueued for this rank.
+ * With the one-launch owner update (the shape of MonolithMultiHashTableFusedOptimize,
+ * RT/ops/multi_hash_table_update_op.cc:247-308: every shard's segments in one op) the count does not
+ * depend on the world size; per 32 tables of the model. */
+mhte_status mhte_shard_step_launches(mhte_shard_step* s, int32_t out[2]);
 /* out[0] = ncclCommCount, out[1] = ncclCommUserRank of the step's own RCCL communicator (0, 0 when the
  * step has none: identity, peer stores, in-process group) — a launcher checks out[0] == world on
  * every rank before it trusts a multi-GPU number */

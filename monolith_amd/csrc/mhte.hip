@@ -356,7 +356,9 @@ struct DedupWs {
   // reservations of a numbered batch that is dropped instead of applied: the keys go back
   void drop_reservations(hipStream_t st) {
     if (r_prealloc && r_stage == 2 && r_res_ctr && table_counters_alive(r_res_ctr, r_res_serial))
-      rd_unreserve_kernel<<<32, 256, 0, st>>>(r_urec.p, rv.n_unique, rv.n, r_res_ctr);
+      // (the count is the workspace's own counter, ctr[0] — the user's n_unique buffer of the dropped batch
+      // may be gone by now)
+      rd_unreserve_kernel<<<32, 256, 0, st>>>(r_urec.p, rv.ctr, rv.n, r_res_ctr);
     r_prealloc = false;
     r_hints = false;
     r_res_ctr = nullptr;
@@ -2013,6 +2015,32 @@ mhte_status mhte_fused_gather_embeddings_by_input_gradient(float* fused_grad, in
   });
 }
 
+mhte_status mhte_lookup_gradient(const int64_t* id_indices, int64_t n, int64_t index_cols,
+                                 const int64_t* id_values, const float* input_grads, int64_t n_rows,
+                                 int32_t dim, int64_t* out_ids, float* out_grads, void* stream) {
+  return guard([&] {
+    if (n < 0 || index_cols < 1 || n_rows < 0 || dim < 0)
+      throw Error(MHTE_INVALID_ARGUMENT, "lookup_gradient: bad shape");
+    if (n == 0) return;
+    if (!id_indices || !id_values || !out_ids || (dim > 0 && (!input_grads || !out_grads)))
+      throw Error(MHTE_INVALID_ARGUMENT, "lookup_gradient: null argument");
+    hipStream_t st = S(stream);
+    static thread_local DevBuf<uint32_t> flag;
+    flag.reserve(1);
+    HIP_OK(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), st));
+    const int32_t vec4 = (dim % 4 == 0 && aligned16(input_grads) && aligned16(out_grads)) ? 1 : 0;
+    const uint32_t grid = uint32_t(std::min<int64_t>((n * 8 + 255) / 256, 1 << 16));
+    lookup_gradient_kernel<<<grid, 256, 0, st>>>(id_indices, n, index_cols, id_values, input_grads, n_rows, dim,
+                                                 vec4, out_ids, out_grads, flag.p);
+    HIP_OK(hipGetLastError());
+    uint32_t bad = 0;
+    HIP_OK(hipMemcpyAsync(&bad, flag.p, sizeof(bad), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (bad) throw Error(MHTE_INVALID_ARGUMENT, "lookup_gradient: id_indices[:, 0] holds a row outside [0, " +
+                                                std::to_string(n_rows) + ")");
+  });
+}
+
 mhte_status mhte_reduce_rows(const int64_t* indices, const float* values, int64_t n, int32_t dim,
                              int64_t batch, int32_t mode, int32_t indices_sorted, float* out,
                              void* stream) {
@@ -3055,7 +3083,10 @@ void mhte_dedup_ws_destroy(mhte_dedup_ws* ws) {
   if (ws && ws->ws.r_prealloc && ws->ws.r_stage == 2 && ws->ws.r_res_ctr) {
     // a numbered batch that was never applied: its row reservations' keys go back to the table
     // (the table may already be gone: its counters then are freed memory — only while it lives)
+    // (the numbering / probe that wrote the records ran on the caller's stream, which the null stream
+    // does not wait for: drain the device first, then count)
     (void)hipSetDevice(ws->ws.device);
+    (void)hipDeviceSynchronize();
     ws->ws.drop_reservations(nullptr);
     (void)hipDeviceSynchronize();
   }
@@ -4005,6 +4036,102 @@ mhte_status mhte_lookup_entry(mhte_multi_table* t, const int64_t* id, const int6
   });
 }
 
+mhte_status mhte_table_save_as_tensor(mhte_multi_table* t, int32_t table, int32_t shard_idx,
+                                      int32_t num_shards, int64_t limit, int64_t offset, int64_t* new_offset,
+                                      char* entries, int64_t cap, int64_t* entry_offsets,
+                                      int64_t offsets_cap, int64_t* n_entries, int64_t* needed, void* stream) {
+  return guard([&] {
+    Table& tb = table_at(t, table);
+    if (!new_offset || !n_entries || !needed) throw Error(MHTE_INVALID_ARGUMENT, "save_as_tensor: null argument");
+    if (num_shards < 1 || shard_idx < 0 || shard_idx >= num_shards || offset < 0)
+      throw Error(MHTE_INVALID_ARGUMENT, "save_as_tensor: shard " + std::to_string(shard_idx) + " of " +
+                                             std::to_string(num_shards) + ", offset " + std::to_string(offset));
+    HIP_OK(hipSetDevice(t->device));
+    hipStream_t st = S(stream);
+    std::lock_guard<std::mutex> g(tb.mu);
+    tb.finish_pending(st);
+    // cuckoohash_map.hpp:745-773: the shard's bucket range, the resume point inside it, at most `limit`
+    // entries (the count is checked AFTER an entry is taken: limit <= 0 still yields one)
+    const uint64_t hash_size = uint64_t(1) << tb.hp;
+    const uint64_t Q = hash_size / uint64_t(num_shards), R = hash_size % uint64_t(num_shards);
+    const uint64_t begin = uint64_t(shard_idx) * Q + std::min<uint64_t>(uint64_t(shard_idx), R);
+    const uint64_t end = begin + Q + (uint64_t(shard_idx) < R ? 1 : 0);
+    const uint64_t want = uint64_t(std::max<int64_t>(limit, 1));
+    const uint64_t s_end = end * kSlots;
+    uint64_t s0 = begin * kSlots + uint64_t(offset);
+    const size_t rf = tb.row_floats;
+    std::vector<int64_t> ids;
+    std::vector<int64_t> pos;
+    std::vector<uint32_t> ts;
+    std::vector<float> rows;
+    DevBuf<uint32_t> bc;
+    DevBuf<uint64_t> bo;
+    DevBuf<int64_t> d_ids, d_pos;
+    DevBuf<uint32_t> d_ts;
+    DevBuf<float> d_rows;
+    constexpr uint64_t kChunk = uint64_t(1) << 18;
+    while (s0 < s_end && ids.size() < want) {
+      const uint64_t s1 = std::min(s_end, s0 + kChunk);
+      const uint32_t nblocks = uint32_t((s1 - s0 + 1023) / 1024);
+      bc.reserve(nblocks);
+      bo.reserve(nblocks);
+      dump_count_kernel<<<nblocks, 256, 0, st>>>(tb.view, s0, s1, bc.p);
+      HIP_OK(hipGetLastError());
+      std::vector<uint32_t> hc(nblocks);
+      HIP_OK(hipMemcpyAsync(hc.data(), bc.p, sizeof(uint32_t) * nblocks, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipStreamSynchronize(st));
+      std::vector<uint64_t> ho(nblocks);
+      uint64_t acc = 0;
+      for (uint32_t i = 0; i < nblocks; ++i) {
+        ho[i] = acc;
+        acc += hc[i];
+      }
+      if (acc) {
+        d_ids.reserve(acc);
+        d_pos.reserve(acc);
+        d_ts.reserve(acc);
+        d_rows.reserve(acc * rf);
+        HIP_OK(hipMemcpyAsync(bo.p, ho.data(), sizeof(uint64_t) * nblocks, hipMemcpyHostToDevice, st));
+        dump_emit_kernel<<<nblocks, 256, 0, st>>>(tb.view, s0, s1, bo.p, d_ids.p, d_pos.p, d_ts.p, d_rows.p);
+        HIP_OK(hipGetLastError());
+        const size_t take = size_t(std::min<uint64_t>(acc, want - ids.size())), at = ids.size();
+        ids.resize(at + take);
+        pos.resize(at + take);
+        ts.resize(at + take);
+        rows.resize((at + take) * rf);
+        HIP_OK(hipMemcpyAsync(ids.data() + at, d_ids.p, take * 8, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(pos.data() + at, d_pos.p, take * 8, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(ts.data() + at, d_ts.p, take * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(rows.data() + at * rf, d_rows.p, take * rf * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+      }
+      s0 = s1;
+    }
+    // stopped on the limit: resume behind the last entry; ran off the shard's end: one bucket past it
+    // (":770 Using +1 here since end might equal to begin")
+    if (ids.size() >= want) *new_offset = int64_t(uint64_t(pos.back()) - begin * kSlots + 1);
+    else *new_offset = int64_t((end - begin + 1) * kSlots);
+    *n_entries = int64_t(ids.size());
+    const std::vector<ckpt::SegLayout> segs = seg_layout(tb);
+    std::string all, rec;
+    std::vector<int64_t> offs(1, 0);
+    for (size_t i = 0; i < ids.size(); ++i) {
+      ckpt::encode_entry(rec, ids[i], rows.data() + i * rf, segs, int(tb.dim), ts[i]);
+      all += rec;
+      offs.push_back(int64_t(all.size()));
+    }
+    *needed = int64_t(all.size());
+    if (int64_t(offs.size()) > offsets_cap || !entry_offsets)
+      throw Error(MHTE_INVALID_ARGUMENT, "save_as_tensor: entry_offsets holds " + std::to_string(offsets_cap) +
+                                             " values, need " + std::to_string(offs.size()));
+    memcpy(entry_offsets, offs.data(), offs.size() * sizeof(int64_t));
+    if (int64_t(all.size()) > cap || (!entries && !all.empty()))
+      throw Error(MHTE_INVALID_ARGUMENT, "save_as_tensor: entries buffer too small: need " +
+                                             std::to_string(all.size()));
+    if (!all.empty()) memcpy(entries, all.data(), all.size());
+  });
+}
+
 mhte_status mhte_feature_stat(const char* basename, char* names, int64_t names_cap, uint64_t* counts,
                               int32_t cap, int32_t* n_out) {
   return guard([&] {
@@ -4261,6 +4388,14 @@ mhte_status mhte_shard_step_info(mhte_shard_step* s, int64_t info[4]) {
     info[1] = int64_t(s->ss.x_block(kXIds));
     info[2] = int64_t(s->ss.x_block(kXRows));
     info[3] = s->ss.alias ? 0 : s->ss.ipc ? (s->ss.win_fine ? 3 : 4) : (s->ss.comm ? 1 : 2);
+  });
+}
+
+mhte_status mhte_shard_step_launches(mhte_shard_step* s, int32_t out[2]) {
+  return guard([&] {
+    if (!s || !out) throw Error(MHTE_INVALID_ARGUMENT, "null argument");
+    out[0] = int32_t(s->ss.launches_fwd);
+    out[1] = int32_t(s->ss.launches - s->ss.launches_fwd);
   });
 }
 

@@ -171,6 +171,26 @@ struct MultiStep {
                     "optimizers — GroupAdaGrad needs the whole segment; rows of whole float4s up to "
                     "256 floats, any other row layout up to 64)");
     }
+    // A table moved with one float4 per lane needs its slice of the flat embedding / gradient buffers on
+    // a 16-byte boundary, and the slice starts at the sum of n_t x dim_t of the tables in front of it —
+    // a multiple of four floats for EVERY batch only when every earlier dim is one.  A row of more than
+    // 64 floats has no one-float-per-lane form to fall back to (shape_code): such a model is refused
+    // here, not by a throw in the middle of a step whose outcome depends on the batch sizes (in the
+    // id-sharded step: after the exchanges were enqueued, with the peers left waiting).
+    {
+      bool odd_before = false;
+      for (uint32_t t = 0; t < T; ++t) {
+        const Table& tb = *m->tables[t];
+        if (tb.dim > 64 && odd_before)
+          throw Error(MHTE_INVALID_ARGUMENT,
+                      "multi step: table " + tb.name + " (" + std::to_string(tb.dim) + " floats per row) follows, in "
+                      "sorted-name order, a table whose dim is not a multiple of 4: its slice of the flat buffers "
+                      "would leave its 16-byte alignment for some batch sizes, and a row of more than 64 floats "
+                      "cannot fall back to one float per lane.  Rename the tables so that the wide ones come "
+                      "first, or pad the odd dims");
+        if (tb.dim % 4u) odd_before = true;
+      }
+    }
     {
       int cus = 0;
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)

@@ -31,6 +31,43 @@ struct GatherInputs {
 // reference's GpuAtomicAdd (rows that share an offset are added in arrival order).
 // A row whose offset and dim are multiples of 4 floats moves as float4s (in.aligned: the host
 // found every base pointer 16-byte aligned); any other row takes the scalar loop.
+// MonolithHashTableLookupGradient (RT/ops/hash_table_lookup_op.cc:110-147): out_ids[i] = id_values[i],
+// out_grads[i, :] = input_grads[id_indices[i, 0], :] — the gradient of the embedding of (batch row,
+// id) pairs gathered back by batch row; id_indices is the [n, index_cols] index matrix of a sparse
+// tensor, column 0 = the batch row.  A lane group of 8 per output row (float4s when dim and the
+// buffers allow, else one float per lane).  A row index outside [0, n_rows) reads zeros and raises a
+// flag the host turns into InvalidArgument (the reference indexes without a check).
+__global__ __launch_bounds__(256) void lookup_gradient_kernel(const int64_t* __restrict__ id_indices,
+                                                              int64_t n, int64_t index_cols,
+                                                              const int64_t* __restrict__ id_values,
+                                                              const float* __restrict__ input_grads,
+                                                              int64_t n_rows, int32_t dim, int32_t vec4,
+                                                              int64_t* __restrict__ out_ids,
+                                                              float* __restrict__ out_grads,
+                                                              uint32_t* __restrict__ bad) {
+  constexpr int G = 8;
+  const int j = threadIdx.x & (G - 1);
+  for (int64_t i = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G; i < n;
+       i += int64_t(gridDim.x) * blockDim.x / G) {
+    const int64_t row = id_indices[i * index_cols];
+    if (j == 0) out_ids[i] = id_values[i];
+    const bool ok = row >= 0 && row < n_rows;
+    if (!ok && j == 0) atomicOr(bad, 1u);
+    const float* src = input_grads + (ok ? row : 0) * int64_t(dim);
+    float* dst = out_grads + i * int64_t(dim);
+    if (vec4) {
+      for (int k = j * 4; k < dim; k += G * 4) {
+        Vec<4> v;
+        v.v[0] = v.v[1] = v.v[2] = v.v[3] = 0.f;
+        if (ok) v.load(src + k);
+        v.store(dst + k);
+      }
+    } else {
+      for (int k = j; k < dim; k += G) dst[k] = ok ? src[k] : 0.f;
+    }
+  }
+}
+
 template <bool GATHER>
 __global__ __launch_bounds__(256) void fused_gather_kernel(float* __restrict__ fused, GatherInputs in,
                                                            float scale) {

@@ -12,6 +12,7 @@
 #define MHTE_PROTO_CONFIG_H_
 
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -183,6 +184,16 @@ inline void parse_optimizer(const uint8_t* b, size_t n, Segment* s) {
     }
   }
   if (!have) throw ckpt::ProtoError("config: segment without an optimizer");
+  // A table created from the serialized config IS the reference's op: its Adagrad is the arithmetic the
+  // reference's own build runs (.bazelrc:63-68 -mavx -mfma, optimizer/BUILD -D_ENABLE_AVX: AdagradOptimize
+  // dispatches to Avx256AdagradOptimize, avx_utils.h:96-119,238-245 — fused multiply-adds and, with a
+  // weight decay, the raw gradient in the weight step inside a block of 8), opt_params[2] = 1
+  // (SegDesc.p[2], adagrad_step_avx).  MHTE_ADAGRAD_SCALAR=1 keeps the scalar loop of avx_utils.h:29-38
+  // (what the reference's unit tests pin, and the default of entry.AdagradOptimizer).
+  if ((s->c.opt_type & 0xff) == MHTE_OPT_ADAGRAD) {
+    const char* e = getenv("MHTE_ADAGRAD_SCALAR");
+    s->c.opt_params[2] = (e && atoi(e) != 0) ? 0.f : 1.f;
+  }
   if (sr16) s->c.opt_type |= MHTE_OPT_FLAG_STOCHASTIC_ROUNDING_FP16;
 }
 

@@ -133,6 +133,17 @@ struct ShardStep {
   bool legacy_owner = false;    // MHTE_SHARD_PER_PEER=1 (A/B), or a table has an occurrence filter: the
                                 // peers' blocks are applied by one launch pair each, in rank order
   uint32_t launches = 0;        // kernel launches + exchanges enqueued by the last forward + backward
+  // ---- sizing the owner's launches by what the peers actually send.  A (peer, table) block can hold the
+  // whole batch; a Zipf batch fills a fifth of it, N ranks a fifth of an N-th.  Workgroups sized for the
+  // capacity find no work: each still takes a slot, reads its block's count and leaves — three more
+  // dispatch rounds behind the useful ones (17.7 -> us per update launch at 65 536 ids).  The counts
+  // are on the device only, so the received blocks' headers are copied to pinned host memory behind
+  // every owner lookup — nobody waits for the copy; once it has landed it sizes the LATER steps'
+  // launches (grid-stride loops inside: any size is correct, a stale one merely slower).
+  int64_t* h_rcnt = nullptr;    // pinned [world][hdr_words]
+  hipEvent_t ev_rcnt = nullptr;
+  bool rcnt_pending = false;
+  std::vector<uint32_t> est_n;  // per table: ids expected in the fullest peer block (0: not known yet)
   uint32_t launches_fwd = 0;
   uint32_t* h_flags = nullptr;  // pinned, device-visible
   uint32_t* d_flags = nullptr;
@@ -142,12 +153,13 @@ struct ShardStep {
   // table) segment.  The counts are the id blocks' headers, copied to pinned host memory right
   // after the id exchange — a step ahead of their first use when the batch was prepared ahead, so
   // waiting for the copy costs nothing then.  In this mode the id blocks move exact-size as well
-  // (headers first, one host wait per id exchange).  Default off: the fixed-size form needs no host
-  // knowledge at all — at the price of whole blocks on the wire: with the default capacity (the
-  // whole batch per (peer, table): nothing can overflow) every rank keeps and moves
-  // O(world x T x batch) ids and rows per direction (26 tables x 65 536 ids x 8 ranks: ~110 MB of ids
-  // each way per step, GBs of row buffers) — give ids_per_peer_table or MHTE_SHARD_EXACT=1 at scale.
-  // Which form wins on real links is a measurement for an N > 1 box.
+  // (headers first, ONE HOST WAIT per id exchange: hipEventSynchronize inside the step — the exact RCCL
+  // form is host-synchronous, which also keeps its id exchange off the overlap stream).  It is the
+  // DEFAULT for RCCL with whole-batch blocks (world > 1, ids_per_peer_table <= 0): fixed-size blocks that
+  // can hold the whole batch would move O(world x T x batch) ids and rows per direction (26 tables x
+  // 65 536 ids x 8 ranks: ~110 MB of ids each way per step).  The fixed-size form (an explicit
+  // ids_per_peer_table, or MHTE_SHARD_EXACT=0) needs no host knowledge at all.  The peer-store
+  // transport — the default on one node — is exact-size without any host wait.
   bool exact = false;
   int64_t* h_cnt[2] = {nullptr, nullptr};   // per slot [2 (sent | received)][world][hdr]
   hipEvent_t ev_cnt[2] = {nullptr, nullptr};
@@ -202,6 +214,8 @@ struct ShardStep {
       if (slot_off[s]) (void)hipFree(slot_off[s]);
     }
     if (d_tab) (void)hipFree(d_tab);
+    if (h_rcnt) (void)hipHostFree(h_rcnt);
+    if (ev_rcnt) (void)hipEventDestroy(ev_rcnt);
     if (orec) (void)hipFree(orec);
     if (oslot) (void)hipFree(oslot);
     if (xs) (void)hipFree(xs);
@@ -288,6 +302,10 @@ struct ShardStep {
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&orec), size_t(geo.ids_block) * world * sizeof(OwnRec)));
     HIP_OK(hipMemset(orec, 0xff, size_t(geo.ids_block) * world * sizeof(OwnRec)));
     own_epoch.assign(T, 0);
+    est_n.assign(T, 0);
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&h_rcnt), size_t(world) * hdr * sizeof(int64_t), hipHostMallocDefault));
+    memset(h_rcnt, 0, size_t(world) * hdr * sizeof(int64_t));
+    HIP_OK(hipEventCreateWithFlags(&ev_rcnt, hipEventDisableTiming));
     if (world > 1) {
       HIP_OK(hipMalloc(reinterpret_cast<void**>(&oslot), size_t(geo.ids_block) * world * sizeof(uint32_t)));
       HIP_OK(hipMemset(oslot, 0, size_t(geo.ids_block) * world * sizeof(uint32_t)));
@@ -340,8 +358,19 @@ struct ShardStep {
 
   bool local_group_member() const { return world > 1 && comm == nullptr && !ipc; }
 
+  // (the wire format and the pipeline mode travel in the window handle: every rank is checked against
+  // every other at connect — so they cannot change behind a connected window of a world > 1)
+  void refuse_after_connect(bool changes, const char* what) const {
+    if (changes && ipc && ipc_connected && world > 1)
+      throw Error(MHTE_FAILED_PRECONDITION,
+                  std::string("shard step: ") + what + " must be chosen before the window handles are exchanged "
+                  "(ShardedMultiStep(grad_fp16= / overlap=), MHTE_SHARD_GRAD_FP16 / MHTE_SHARD_OVERLAP, or the "
+                  "setter between mhte_shard_step_create_ipc and mhte_shard_step_ipc_handle): the ranks agree on "
+                  "it at connect");
+  }
   void set_grad_bits(int bits) {
     if (bits != 16 && bits != 32) throw Error(MHTE_INVALID_ARGUMENT, "shard step: gradient wire is 32 or 16 bits");
+    refuse_after_connect(bits != grad_bits, "the gradient wire (fp16 / fp32)");
     if (bits == 16 && alias)
       throw Error(MHTE_INVALID_ARGUMENT, "shard step: the identity exchange (world 1) has no wire to narrow");
     if (bits == 16 && !snd_grads16) {
@@ -376,6 +405,7 @@ struct ShardStep {
   }
 
   void set_overlap(int mode) {
+    refuse_after_connect((mode != 0 ? 1 : 0) != overlap, "the overlap mode");
     overlap = mode != 0 ? 1 : 0;
     if (overlap && !aux) {
       // (lowest priority: the dense model's GEMMs on the caller's stream go first where both want a CU)
@@ -539,6 +569,7 @@ struct ShardStep {
                                                   std::max<size_t>(1, size_t(ms.num_cus) * 2 / size_t(world))))
                       : 1u;
     LAUNCH_HOT(kTagShardPush, shard_push_kernel, dim3(gx, uint32_t(world)), 256, st, A);
+    ++launches;
     HIP_OK(hipGetLastError());
     sig_pending[st == aux && aux ? 1 : 0] |= 1u << chan;
   }
@@ -567,6 +598,7 @@ struct ShardStep {
       A.hi = uint32_t(hi);
     }
     LAUNCH_HOT(kTagShardWait, shard_sync_kernel, 1, 64, st, A);
+    ++launches;
     HIP_OK(hipGetLastError());
   }
   // at the end of an API call: nothing this rank owes its peers stays unpublished
@@ -682,6 +714,7 @@ struct ShardStep {
     for (uint32_t t = 0; t < T; ++t) ms.n_slot[slot][t] = uint32_t(split[t + 1] - split[t]);
     ms.has_hints[slot] = false;
     ms.launch_dedup(ids, split, slot, 0, st);
+    launches += (T + uint32_t(kMaxStepTables) - 1) / uint32_t(kMaxStepTables);
     ms.stage[slot] = 1;
     disp[slot] = false;
     ids_exchanged[slot] = false;
@@ -761,6 +794,7 @@ struct ShardStep {
       if (!gx) continue;
       if (w4) LAUNCH_HOT(kTagShardBuild, shard_build_kernel<4>, dim3(gx, tc), 256, st, A);
       if (w1) LAUNCH_HOT(kTagShardBuild, shard_build_kernel<1>, dim3(gx, tc), 256, st, A);
+      launches += (w4 ? 1u : 0u) + (w1 ? 1u : 0u);
       HIP_OK(hipGetLastError());
     }
   }
@@ -790,8 +824,38 @@ struct ShardStep {
       if (!gx) continue;
       if (w4) LAUNCH_HOT(kTagShardGather, shard_scatter_kernel<4>, dim3(gx, tc), 256, st, A);
       if (w1) LAUNCH_HOT(kTagShardGather, shard_scatter_kernel<1>, dim3(gx, tc), 256, st, A);
+      launches += (w4 ? 1u : 0u) + (w1 ? 1u : 0u);
       HIP_OK(hipGetLastError());
     }
+  }
+
+  // the received blocks' counts, a step (or more) late: see est_n
+  void poll_counts() {
+    if (!rcnt_pending || hipEventQuery(ev_rcnt) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
+    rcnt_pending = false;
+    for (uint32_t t = 0; t < T; ++t) {
+      int64_t m = 0;
+      for (int p = 0; p < world; ++p) m = std::max(m, h_rcnt[size_t(p) * hdr_words + t]);
+      m = std::min<int64_t>(std::max<int64_t>(m, 0), int64_t(cap));
+      est_n[t] = uint32_t(std::min<int64_t>(int64_t(cap), m + m / 4 + 64));   // (+25 %: the next batch is another one)
+    }
+  }
+  void fetch_counts_lazily(int slot, hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (rcnt_pending || (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)) return;
+    const size_t w = size_t(hdr_words) * sizeof(int64_t);
+    HIP_OK(hipMemcpy2DAsync(h_rcnt, w, ids_recv[slot], size_t(geo.ids_block) * 8, w, size_t(world),
+                            hipMemcpyDeviceToHost, st));
+    HIP_OK(hipEventRecord(ev_rcnt, st));
+    rcnt_pending = true;
+  }
+  // ids a (peer, table) block of table t is sized for in the owner's launches
+  uint32_t sized_n(uint32_t t) const {
+    static const bool by_cap = getenv("MHTE_SHARD_SIZE_BY_CAP") != nullptr;   // (A/B: round 4's sizing)
+    return (by_cap || est_n[t] == 0) ? cap : std::min(cap, est_n[t]);
   }
 
   void clear_x(hipStream_t st) {
@@ -848,8 +912,12 @@ struct ShardStep {
     D.blk_start[T] = dblocks;
     F.nd = std::min<uint32_t>(dblocks, ms.fused_dedup_wgs ? ms.fused_dedup_wgs : uint32_t(ms.num_cus) / 2);
     F.period = 1;
+    // two 1024-thread workgroups per CU are resident; the dedup's take their share, the scatter gets the
+    // rest ONCE (the distinct ids are dealt out over whatever workgroups a table has: a second dispatch
+    // round would only add latency)
     const uint32_t slots = uint32_t(2 * ms.num_cus);
-    const uint32_t room = std::max<uint32_t>(slots > F.nd ? slots - F.nd : 8u, 8u) * ms.scatter_ovs;
+    static const uint32_t ovs_env = getenv("MHTE_SHARD_SCATTER_OVS") ? uint32_t(std::max(1, atoi(getenv("MHTE_SHARD_SCATTER_OVS")))) : 1u;
+    const uint32_t room = std::max<uint32_t>(slots > F.nd ? slots - F.nd : 8u, 8u) * ovs_env;
     for (uint32_t t = 0; t < T; ++t) {
       F.fwd_start[t] = lin;
       const ShardGatherTab& g = A.gt[t];
@@ -909,6 +977,7 @@ struct ShardStep {
       x_dirty = true;
     }
     own_slot = slot;
+    poll_counts();
     for (uint32_t t = 0; t < T; ++t) own_epoch[t] = mt->tables[t]->mut_epoch;
     for (uint32_t t0 = 0; t0 < T; t0 += uint32_t(kMaxStepTables)) {
       const uint32_t tc = chunk_tables(t0);
@@ -917,7 +986,7 @@ struct ShardStep {
       if (per_peer) A.x.xs = nullptr, A.x.oslot = nullptr;   // (no registration: nobody would consume it)
       uint32_t gx = 1;
       for (uint32_t i = 0; i < tc; ++i)
-        gx = std::max(gx, uint32_t((uint64_t((cap + 1) / 2) * shape_lanes(A.g[i]) + 511) / 512));
+        gx = std::max(gx, uint32_t((uint64_t((sized_n(t0 + i) + 1) / 2) * shape_lanes(A.g[i]) + 511) / 512));
       // (grid-stride inside: enough workgroups to fill the chip a few times over, not one per slot)
       const uint32_t fill = std::max<uint32_t>(8, uint32_t(ms.num_cus) * 16 / (uint32_t(world) * tc));
       gx = std::min(gx, fill);
@@ -928,6 +997,7 @@ struct ShardStep {
       launches += (w4 ? 1u : 0u) + (w1 ? 1u : 0u);
       HIP_OK(hipGetLastError());
     }
+    fetch_counts_lazily(slot, st);
   }
 
   void owner_apply(int slot, const float* lrs, int64_t update_time, int64_t global_step, hipStream_t st) {
@@ -939,6 +1009,7 @@ struct ShardStep {
     }
     sync_views(mt, st);
     wait_arrived(kXIds, slot, 0, world, st);
+    poll_counts();
     // one set of arguments per kMaxStepTables tables; the same for every peer but `peer` / `zero_headers`
     std::vector<OwnerChunk>& chunks = apply_chunks;
     chunks.resize((T + uint32_t(kMaxStepTables) - 1) / uint32_t(kMaxStepTables));
@@ -961,7 +1032,7 @@ struct ShardStep {
         a.sum_dups = 0;
         a.filter_mode = tb.flt_slots ? 1 : 0;   // an owner asks its filter about every id it does not hold
         a.global_step = global_step;
-        gx = std::max(gx, (cap + 256u / shape_lanes(A.g[i]) - 1) / (256u / shape_lanes(A.g[i])));
+        gx = std::max(gx, (sized_n(t0 + i) + 256u / shape_lanes(A.g[i]) - 1) / (256u / shape_lanes(A.g[i])));
         k.inst[A.g[i] & 1u][(A.g[i] >> 1) & 1u] = true;
       }
       const uint32_t fill = std::max<uint32_t>(8, uint32_t(ms.num_cus) * 16 / k.tc);
@@ -987,10 +1058,16 @@ struct ShardStep {
           if (own_slot == slot && own_epoch[t0 + i] == mt->tables[t0 + i]->mut_epoch) A.x.hints |= 1u << i;
         const uint32_t gx = std::max<uint32_t>(1u, std::min<uint32_t>(k.gx, std::max<uint32_t>(8, k.gx_fill / uint32_t(world))));
         const dim3 grid(gx, uint32_t(world) * k.tc);
-        if (k.inst[0][0]) LAUNCH_HOT(kTagShardUpsert, (shard_apply_kernel<4, false>), grid, 256, st, A);
-        if (k.inst[1][0]) LAUNCH_HOT(kTagShardUpsert, (shard_apply_kernel<1, false>), grid, 256, st, A);
-        if (k.inst[0][1]) LAUNCH_HOT(kTagShardUpsert, (shard_apply_kernel<4, true>), grid, 256, st, A);
-        if (k.inst[1][1]) LAUNCH_HOT(kTagShardUpsert, (shard_apply_kernel<1, true>), grid, 256, st, A);
+#define MHTE_APPLY_LAUNCH(W_, G_)                                                                         \
+  do {                                                                                                  \
+    if (world > 1) LAUNCH_HOT(kTagShardUpsert, (shard_apply_kernel<W_, G_, true>), grid, 256, st, A);   \
+    else LAUNCH_HOT(kTagShardUpsert, (shard_apply_kernel<W_, G_, false>), grid, 256, st, A);            \
+  } while (0)
+        if (k.inst[0][0]) MHTE_APPLY_LAUNCH(4, false);
+        if (k.inst[1][0]) MHTE_APPLY_LAUNCH(1, false);
+        if (k.inst[0][1]) MHTE_APPLY_LAUNCH(4, true);
+        if (k.inst[1][1]) MHTE_APPLY_LAUNCH(1, true);
+#undef MHTE_APPLY_LAUNCH
         shard_slow_all_kernel<<<k.tc, 64, 0, st>>>(A);
         HIP_OK(hipGetLastError());
         launches += uint32_t(k.inst[0][0]) + uint32_t(k.inst[1][0]) + uint32_t(k.inst[0][1]) + uint32_t(k.inst[1][1]) + 1u;
@@ -1000,7 +1077,10 @@ struct ShardStep {
     } else
     for (int p = 0; p < world; ++p) {
       wait_arrived(kXGrads, slot, p, p + 1, st);   // (a peer's block is applied as soon as it has landed)
-      if (grad_bits == 16) cvt<false>(ids_recv[slot], own_grads16, apply_grads(), p, 1, st);
+      if (grad_bits == 16) {
+        cvt<false>(ids_recv[slot], own_grads16, apply_grads(), p, 1, st);
+        ++launches;
+      }
       for (OwnerChunk& k : chunks) {
         ShardOwnerArgs& A = k.A;
         const uint32_t gx = k.gx, tc = k.tc;
@@ -1066,6 +1146,7 @@ struct ShardStep {
   // block p of the source goes to peer p, block p of the destination comes from peer p
   void exchange_rccl(int kind, int slot, hipStream_t st) {
     Rccl& R = Rccl::get();
+    ++launches;   // (one send / recv group; the exact-size id form: two)
     const char* src = static_cast<const char*>(x_src(kind, slot));
     char* dst = static_cast<char*>(x_dst(kind, slot));
     const size_t b = x_block(kind);
@@ -1122,6 +1203,8 @@ struct ShardStep {
 
 // the ranks of one process (all of them: a test, or one process driving several tables on one GPU)
 static void shard_exchange(ShardStep** S, int n, int kind, int slot, hipStream_t st) {
+  if (n > 1)   // (device copies stand in for the links: one exchange per rank and kind)
+    for (int r = 0; r < n; ++r) ++S[r]->launches;
   if (n == 1) {
     if (S[0]->alias) return;
     if (S[0]->ipc) S[0]->exchange_ipc(kind, slot, st);
@@ -1296,8 +1379,10 @@ static void shard_backward(ShardStep** S, int n, const float* const* grads, cons
     HIP_OK(hipSetDevice(S[r]->device));
     S[r]->prepare(st);
     S[r]->build_and_sum(build_next ? (cur ^ 1) : -1, cur, grads[r], st);
-    if (S[r]->grad_bits == 16)   // the sums leave as fp16
+    if (S[r]->grad_bits == 16) {   // the sums leave as fp16
       S[r]->cvt<true>(S[r]->ids_send[cur], S[r]->snd_grads, S[r]->snd_grads16, 0, S[r]->world, st);
+      ++S[r]->launches;
+    }
   }
   shard_exchange(S, n, kXGrads, cur, st);
   if (build_next) {

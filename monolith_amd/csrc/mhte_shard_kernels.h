@@ -327,16 +327,19 @@ __global__ __launch_bounds__(64) void shard_slow_kernel(ShardOwnerArgs A) {
 // is reached through the lookup's record when it can be trusted (no bucket line is read), otherwise
 // by probe / insert as seg_upsert_loop does.  Ids whose two buckets are full go to the table's pending
 // list as (slot, peer); shard_slow_all_kernel finishes them.
-template <int G, int VEC, bool GROUP>
+// (the cross-peer form at three wavefronts per SIMD: at four it spills 38 registers)
+#ifndef MHTE_SEGX_OCC
+#define MHTE_SEGX_OCC 3
+#endif
+template <int G, int VEC, bool GROUP, bool MULTI>
 __device__ __forceinline__ void shard_apply_loop(const ShardOwnerArgs& A, const TableView& tv, uint32_t p,
                                                  uint32_t t, uint32_t n) {
-  constexpr int NCH = 64 / G;   // chunks of G peers (world <= kMaxShards = 64)
   const ShardTab tb = A.tab[t];
   const int lane = threadIdx.x & 63;
   const int j = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
   const uint32_t world = A.geo.world;
-  const bool multi = world > 1u;
+  constexpr bool multi = MULTI;   // (an instance of its own: the one-rank / no-duplicate form keeps its registers)
   const size_t eb = size_t(p) * A.geo.ids_block + tb.id_off;
   const int64_t* ids = A.recv_ids + eb;
   const OwnRec* orec = A.x.orec + eb;
@@ -353,21 +356,12 @@ __device__ __forceinline__ void shard_apply_loop(const ShardOwnerArgs& A, const 
     const OwnRec rec = orec[gs];
     uint32_t hs = 0;
     if (multi) hs = A.x.oslot[eb + gs];
-    // ---- the id's entries; who applies them
+    // ---- the id's entries (one per peer that sent it); who applies them
     unsigned long long pm = 1ull << p;
-    uint32_t ent[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) ent[c] = g + 1u;
     bool mine = valid;
-    uint32_t* sl = nullptr;
     if (multi) {
-      sl = xs + size_t(hs) * A.x.xstride;
+      const uint32_t* sl = xs + size_t(hs) * A.x.xstride;
       pm = *reinterpret_cast<const unsigned long long*>(sl + 2);   // one 8-byte load: all or nothing
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const uint32_t q = uint32_t(c * G + j);
-        ent[c] = (uint32_t(c * G) < world && q < world) ? sl[kXKeyWords + q] : 0u;
-      }
       if (!valid) pm = 0ull;
       mine = ((pm >> p) & 1ull) != 0ull && (pm & ((1ull << p) - 1ull)) == 0ull;
     }
@@ -376,7 +370,8 @@ __device__ __forceinline__ void shard_apply_loop(const ShardOwnerArgs& A, const 
     const bool need = mine && !hinted;
     uint32_t r = rec.row;
     bool is_new = false, deferred = false;
-    if (__any(need)) {
+    {   // (every lane: wave ballots inside; a group that needs no probe issues no load — under `if (__any(need))`
+        // the float4 instance spills six registers)
       const Probe<G> pr = probe_issue<G>(tv, id, need, j);
       const SlotResult sr = upsert_resolve<G>(tv, (Bucket*)pr.b, id, need, pr.k, pr.row, lane, a.ts);
       if (need) {
@@ -385,7 +380,7 @@ __device__ __forceinline__ void shard_apply_loop(const ShardOwnerArgs& A, const 
         deferred = sr.deferred;
       }
     }
-    if (hinted && j == 0 && rec.ts != a.ts)   // SetTimestamp(update_time): the slot is known, the line is not read
+    if (hinted && j == 0 && rec.ts != a.ts)   // SetTimestamp(update_time): the slot is known, its line is not read
       global_bucket(tv.buckets + (rec.loc >> 2))->ts[rec.loc & 3ull] = a.ts;
     if (deferred && j == 0) {
       const uint32_t slot = atomicAdd(&tv.ctr->n_pending, 1u);
@@ -394,25 +389,25 @@ __device__ __forceinline__ void shard_apply_loop(const ShardOwnerArgs& A, const 
     }
     if (mine && !deferred) {
       float* rp = row_ptr(tv, r);
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        unsigned long long mc = pm >> (c * G);
-        if (G < 64) mc &= (1ull << G) - 1ull;
-        while (mc) {   // (group-uniform)
-          const int k = __ffsll(static_cast<long long>(mc)) - 1;
-          mc &= mc - 1ull;
-          const uint32_t sq = __shfl(ent[c], gbase + k) - 1u;
-          const float* values = A.rows + size_t(c * G + k) * A.geo.rows_block + tb.row_off;
-          apply_row<G, VEC, kOpOptimize, false, GROUP>(tv, rp, is_new, j, values, nullptr, 0u, 1u, int64_t(sq), a);
-          is_new = false;
-        }
+      // the senders, ascending: one optimizer step each.  The first is this group's own entry; the
+      // others' slots are fetched when their turn comes (the slot's lines are in the L2 by then, and
+      // nothing of them has to stay in registers across the row update)
+      uint32_t q = p, sq = g;
+#pragma unroll 1
+      for (;;) {   // (group-uniform)
+        const float* values = A.rows + size_t(q) * A.geo.rows_block + tb.row_off;
+        apply_row<G, VEC, kOpOptimize, false, GROUP>(tv, rp, is_new, j, values, nullptr, 0u, 1u, int64_t(sq), a);
+        is_new = false;
+        if (!multi || q >= 63u) break;
+        const uint32_t* sl = xs + size_t(hs) * A.x.xstride;
+        const unsigned long long rest = *reinterpret_cast<const unsigned long long*>(sl + 2) & ~((2ull << q) - 1ull);
+        if (!rest) break;
+        q = uint32_t(__ffsll(static_cast<long long>(rest)) - 1);
+        sq = sl[kXKeyWords + q] - 1u;
       }
       if (multi) {   // the slot goes back empty (its entries are consumed)
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          const uint32_t q = uint32_t(c * G + j);
-          if (uint32_t(c * G) < world && q < world) sl[kXKeyWords + q] = 0u;
-        }
+        uint32_t* sl = xs + size_t(hs) * A.x.xstride;
+        for (uint32_t q = uint32_t(j); q < world; q += G) sl[kXKeyWords + q] = 0u;
         if (j == 0) {
           *reinterpret_cast<unsigned long long*>(sl + 2) = 0ull;
           *reinterpret_cast<int64_t*>(sl) = kEmptyKey;
@@ -422,14 +417,16 @@ __device__ __forceinline__ void shard_apply_loop(const ShardOwnerArgs& A, const 
   }
 }
 
-template <int VW, bool GROUP = false>
-__global__ __launch_bounds__(256, GROUP ? 1 : MHTE_SEGU_OCC) void shard_apply_kernel(ShardOwnerArgs A) {
+// MULTI: the world has more than one rank (the cross-peer scratch is consulted)
+template <int VW, bool GROUP = false, bool MULTI = false>
+__global__ __launch_bounds__(256, GROUP ? 1 : (MULTI ? MHTE_SEGX_OCC : MHTE_SEGU_OCC)) void shard_apply_kernel(
+    ShardOwnerArgs A) {
   const uint32_t p = blockIdx.y / A.tc, t = blockIdx.y % A.tc;
   if (!MHTE_SHAPE_IS(VW, A.g[t]) || ((A.g[t] & kShapeGroupBit) != 0u) != GROUP) return;
   const uint32_t n = shard_block_count(A, p, t);
   if (n == 0) return;
   const TableView& tv = deref_const(A.views + (A.t0 + t));
-#define MHTE_SEGU_CALL(G_, V_) shard_apply_loop<G_, V_, GROUP>(A, tv, p, t, n)
+#define MHTE_SEGU_CALL(G_, V_) shard_apply_loop<G_, V_, GROUP, MULTI>(A, tv, p, t, n)
   MHTE_SWITCH_G(VW, A.g[t] & ~kShapeGroupBit, MHTE_SEGU_CALL)
 #undef MHTE_SEGU_CALL
 }
@@ -602,14 +599,17 @@ __device__ __forceinline__ void shard_scatter_role(const RunView& d, const float
   const uint32_t n_items = d.ctr[2];
   const int64_t nu = min(n_max, int64_t(n_unique));
   constexpr int PER = (kStepLightMax + G - 1) / G;
-  const int64_t stride = int64_t(nblk) * NG * UNR;
+  // Unique index g = w * nblk + bid for the workgroup's w-th group-id: consecutive indices land in
+  // DIFFERENT workgroups, so the U distinct ids of a batch (a fifth of its positions under Zipf) keep
+  // every workgroup — every CU — busy with a few groups instead of filling the first U / (NG * UNR)
+  // workgroups and leaving the others empty (measured: the fused launch took the sum of its two roles).
 #pragma unroll 1
-  for (int64_t g0 = int64_t(bid) * NG * UNR; g0 < nu; g0 += stride) {  // workgroup-uniform
+  for (int64_t w0 = 0; w0 * int64_t(nblk) < nu; w0 += int64_t(NG) * UNR) {  // workgroup-uniform
     uint32_t cnt[UNR], hp[UNR], gs[UNR], ix[UNR];
     bool valid[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const int64_t g = g0 + int64_t(grp) * UNR + u;
+      const int64_t g = (w0 + int64_t(grp) * UNR + u) * int64_t(nblk) + int64_t(bid);
       valid[u] = g < nu;
       const int64_t gi = valid[u] ? g : 0;  // (loads from a safe index, masked afterwards)
       cnt[u] = d.ucnt[gi];
@@ -649,9 +649,10 @@ __device__ __forceinline__ void shard_scatter_role(const RunView& d, const float
     }
   }
   // ---- heavy lists: one work item per WAVEFRONT (mstep_scatter_role)
+  // (unit k * nblk + bid: the items too are dealt out one per workgroup first)
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll 1
-  for (uint32_t unit = bid * (BLOCK / 64) + wave; unit < n_items * item_split; unit += nblk * (BLOCK / 64)) {
+  for (uint32_t unit = wave * nblk + bid; unit < n_items * item_split; unit += nblk * (BLOCK / 64)) {
     const uint32_t w = unit / item_split, sub = unit % item_split;
     const ItemHdr hd = d.item_hdr[w];
     const uint32_t rval = d.item_runs[size_t(w) * 64 + lane];
@@ -698,7 +699,7 @@ __device__ __forceinline__ void shard_scatter_role(const RunView& d, const float
 }
 
 #ifndef MHTE_SHARD_SCATTER_UNR
-#define MHTE_SHARD_SCATTER_UNR 2
+#define MHTE_SHARD_SCATTER_UNR 1
 #endif
 __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void shard_scatter_dedup_kernel(
     ShardGatherArgs A, MDedupArgs D, MFwdFuse F, uint32_t item_split) {

@@ -420,7 +420,8 @@ class ShardedMultiStep:
   update_time)``."""
 
   def __init__(self, table, batch_per_table: int, group: Optional["dist.ProcessGroup"] = None,
-               ids_per_peer_table: int = 0, use_rccl: Optional[bool] = None, transport: str = "auto"):
+               ids_per_peer_table: int = 0, use_rccl: Optional[bool] = None, transport: str = "auto",
+               grad_fp16: Optional[bool] = None, overlap: Optional[bool] = None):
     from monolith_amd import _lib
     self._libmod = _lib
     self._lib = table._lib  # pylint: disable=protected-access
@@ -438,6 +439,9 @@ class ShardedMultiStep:
       transport = "rccl"
     self._group = group
     self._h = None
+    # the wire format / pipeline mode of a world > 1 are part of what the ranks agree on when the
+    # windows are connected: chosen here, applied before the handles are taken
+    self._grad_fp16, self._overlap = grad_fp16, overlap
     self.transport_note = None    # why the first choice of transport was not taken (auto)
     if transport == "ipc" or (transport == "auto" and self.world > 1):
       err = self._create_ipc(ids_per_peer_table)
@@ -465,6 +469,10 @@ class ShardedMultiStep:
     self._h = h
     self._ahead = None
     self._keep = None
+    if self._grad_fp16 is not None and not (self.world == 1 and not use_rccl):
+      self.set_grad_fp16(self._grad_fp16)
+    if self._overlap is not None:
+      self.set_overlap(self._overlap)
 
   def _all_true(self, ok: bool) -> bool:
     if self.world == 1:
@@ -484,6 +492,10 @@ class ShardedMultiStep:
       _lib.check(self._lib.mhte_shard_step_create_ipc(
           self.table.handle, C.c_int64(self.batch), C.c_int32(self.rank), C.c_int32(self.world),
           C.c_int64(int(ids_per_peer_table)), C.byref(h)))
+      if self._grad_fp16 is not None:
+        _lib.check(self._lib.mhte_shard_step_set_grad_bits(h, C.c_int32(16 if self._grad_fp16 else 32)))
+      if self._overlap is not None:
+        _lib.check(self._lib.mhte_shard_step_set_overlap(h, C.c_int32(1 if self._overlap else 0)))
       _lib.check(self._lib.mhte_shard_step_ipc_handle(h, blob))
     except _lib.MhteError as e:
       err = e
@@ -552,6 +564,10 @@ class ShardedMultiStep:
          "transport": ("identity", "rccl", "group", "ipc", "ipc (coarse window)")[out[3]]}
     if self.transport_note:
       d["transport_note"] = self.transport_note
+    ln = (C.c_int32 * 2)()
+    self._libmod.check(self._lib.mhte_shard_step_launches(self._h, ln))
+    d["launches_per_step"] = int(ln[0]) + int(ln[1])     # (of the last forward + backward)
+    d["launches_forward"], d["launches_backward"] = int(ln[0]), int(ln[1])
     if out[3] == 1:
       d["rccl_ranks"], d["rccl_rank"] = self.comm_ranks()
     return d
@@ -647,6 +663,16 @@ class ShardedStepGroup:
       self.close()
     except Exception:  # pylint: disable=broad-except
       pass
+
+  def launches(self):
+    """Per rank: (kernel launches + exchanges) the last forward and the last backward enqueued
+    (mhte_shard_step_launches)."""
+    out = []
+    for h in self._hs:
+      ln = (C.c_int32 * 2)()
+      self._libmod.check(self._lib.mhte_shard_step_launches(h, ln))
+      out.append((int(ln[0]), int(ln[1])))
+    return out
 
   def forward(self, raggeds, next_raggeds=None, prefetched=False):
     """raggeds: one Ragged per rank -> list of flat embeddings."""

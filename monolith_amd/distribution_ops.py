@@ -10,7 +10,7 @@ Two API levels:
     dedup -> lookup -> scatter -> segment-sum -> optimize runs without a host round trip).
 """
 import ctypes as C
-from typing import List, NamedTuple, Optional
+from typing import List, NamedTuple, Optional, Tuple
 
 import numpy as np
 import torch
@@ -445,3 +445,28 @@ def fused_embedding_to_layout_grad(embeddings_list: List[torch.Tensor], fid_offs
       C.c_int32(len(slices)), _ptr_array(tg), lens, C.c_int32(len(tg)),
       C.c_int32(_lib.MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS if one_fid_unique_rows else 0), _stream()))
   return grads
+
+
+def lookup_gradient(id_indices: torch.Tensor, id_values: torch.Tensor,
+                    input_grads: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+  """MonolithHashTableLookupGradient (runtime/ops/hash_table_lookup_op.cc:110-147): the gradient of a
+  lookup gathered back per (batch row, id) pair of a sparse id tensor — ``ids[i] = id_values[i]``,
+  ``output_grads[i] = input_grads[id_indices[i, 0]]``.  ``id_indices`` [n, k] int64 (column 0 = the
+  batch row), ``id_values`` [n] int64, ``input_grads`` [rows, dim] float32."""
+  assert id_indices.dim() == 2 and id_values.dim() == 1 and input_grads.dim() == 2
+  if id_indices.shape[0] != id_values.shape[0]:
+    raise _lib.InvalidArgumentError(
+        _lib.MHTE_INVALID_ARGUMENT, "id_indices's first dim and id_values dim should be same. Got %dv.s. %d" %
+        (id_indices.shape[0], id_values.shape[0]))
+  dev = input_grads.device
+  idx = id_indices.to(dev, torch.int64).contiguous()
+  val = id_values.to(dev, torch.int64).contiguous()
+  g = input_grads.to(torch.float32).contiguous()
+  n, dim = int(val.numel()), int(g.shape[1])
+  out_ids = torch.empty(n, dtype=torch.int64, device=dev)
+  out = torch.empty((n, dim), dtype=torch.float32, device=dev)
+  _lib.check(_lib.lib().mhte_lookup_gradient(
+      _lib.vp(idx), _lib.C.c_int64(n), _lib.C.c_int64(int(idx.shape[1])), _lib.vp(val), _lib.vp(g),
+      _lib.C.c_int64(int(g.shape[0])), _lib.C.c_int32(dim), _lib.vp(out_ids), _lib.vp(out),
+      _lib.C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+  return out_ids, out

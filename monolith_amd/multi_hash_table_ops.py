@@ -497,6 +497,31 @@ class MultiHashTable:
       k += int(m)
     return {k_: v for k_, v in out.items() if k_ in slot_to_id}
 
+  def save_as_tensor(self, name_or_idx, shard_idx: int, num_shards: int, limit: int,
+                     offset: int) -> Tuple[int, List[bytes]]:
+    """MonolithHashTableSaveAsTensor (hash_table_ops.py:335-361 of the reference): up to ``limit``
+    serialized EntryDump strings of one table, shard ``shard_idx`` of ``num_shards`` of its bucket
+    array, resumed ``offset`` slots into the shard -> (new_offset, entries).  Iterate as
+    hash_table_utils.iterate_table_and_apply does: until a call returns fewer than ``limit``."""
+    i = name_or_idx if isinstance(name_or_idx, int) else self._index(name_or_idx)
+    n_off = max(int(limit), 1) + 1
+    offs = np.zeros(n_off, dtype=np.int64)
+    new_offset, n_ent, need = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    cap = max(1, int(limit)) * 64
+    while True:
+      buf = C.create_string_buffer(cap)
+      rc = self._lib.mhte_table_save_as_tensor(
+          self._h, C.c_int32(i), C.c_int32(int(shard_idx)), C.c_int32(int(num_shards)), C.c_int64(int(limit)),
+          C.c_int64(int(offset)), C.byref(new_offset), buf, C.c_int64(cap), _i64p(offs), C.c_int64(n_off),
+          C.byref(n_ent), C.byref(need), _stream())
+      if rc == _lib.MHTE_INVALID_ARGUMENT and need.value > cap:
+        cap = int(need.value)
+        continue
+      check(rc)
+      break
+    raw = buf.raw
+    return int(new_offset.value), [raw[offs[k]:offs[k + 1]] for k in range(int(n_ent.value))]
+
   @staticmethod
   def feature_stat(basename: str) -> Dict[str, int]:
     """MonolithMultiHashTableFeatureStat: entries per table name in a checkpoint's .meta files."""

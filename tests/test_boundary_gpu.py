@@ -101,6 +101,137 @@ def test_create_from_serialized_config_and_kats():
   assert st.size == 1
 
 
+def test_a_table_created_from_the_serialized_config_runs_adagrad_as_the_reference_is_built():
+  """the reference's build dispatches AdagradOptimize to its AVX2 form (avx_utils.h:96-119:
+  fused multiply-adds; with a weight decay the weight step uses the raw gradient inside each block of
+  8).  A table created from the serialized config — the reference's own op input — defaults to that
+  form: the same bits as entry.AdagradOptimizer(avx_semantics=True) (itself pinned to the reference's
+  -mavx2 -mfma build, test_adagrad_avx_form_matches_the_reference_as_built), and NOT the scalar
+  loop's when a weight decay is set."""
+  m = P.MultiEmbeddingHashTableConfig()
+  m.names.append("t")
+  c = m.configs.add()
+  c.cuckoo.SetInParent()
+  s = c.entry_config.segments.add()
+  s.dim_size = 20                       # two blocks of 8 + the scalar tail
+  s.init_config.zeros.dim_size = 20
+  s.opt_config.adagrad.learning_rate = 0.05
+  s.opt_config.adagrad.initial_accumulator_value = 0.1
+  s.opt_config.adagrad.weight_decay_factor = 0.1
+  mt = MultiHashTable.from_serialized_config(m.SerializeToString(), name_suffix=_name())
+  mk = lambda avx: MultiHashTable.from_configs({"t": entry.make_table_config([entry.CombineAsSegment(  # noqa: E731
+      20, entry.ZerosInitializer(), entry.AdagradOptimizer(0.05, 0.1, weight_decay_factor=0.1, avx_semantics=avx))])},
+                                                name_suffix=_name())
+  ref_avx, ref_scalar = mk(True), mk(False)
+  rng = np.random.default_rng(11)
+  ids = np.arange(1, 301, dtype=np.int64)
+  for _ in range(3):
+    g = val_t(rng.standard_normal((ids.size, 20)).astype(np.float32))
+    for t in (mt, ref_avx, ref_scalar):
+      t.apply_gradients({"t": (ids_t(ids), g)})
+  w = mt.lookup({"t": ids_t(ids)})["t"]
+  assert torch.equal(w, ref_avx.lookup({"t": ids_t(ids)})["t"])
+  assert not torch.equal(w, ref_scalar.lookup({"t": ids_t(ids)})["t"])
+
+
+def test_lookup_gradient_kat():
+  """MonolithHashTableLookupGradient (hash_table_lookup_op.cc:110-147): ids pass through, the gradient
+  row of entry i is input_grads[id_indices[i, 0]]; float4 and odd dims; a row outside the gradient
+  matrix is InvalidArgument; the two inputs must agree in length (the op's own check)."""
+  from monolith_amd.distribution_ops import lookup_gradient
+  rng = np.random.default_rng(2)
+  for dim in (1, 5, 16, 64):
+    rows, n = 37, 1000
+    idx = np.stack([rng.integers(0, rows, n), rng.integers(0, 9, n)], axis=1).astype(np.int64)
+    ids = rng.integers(-2**62, 2**62, n).astype(np.int64)
+    g = rng.standard_normal((rows, dim)).astype(np.float32)
+    out_ids, out = lookup_gradient(ids_t(idx), ids_t(ids), val_t(g))
+    np.testing.assert_array_equal(out_ids.cpu().numpy(), ids)
+    np.testing.assert_array_equal(out.cpu().numpy(), g[idx[:, 0]])
+  e_ids, e = lookup_gradient(ids_t(np.zeros((0, 2))), ids_t([]), val_t(np.zeros((3, 4))))
+  assert e_ids.numel() == 0 and tuple(e.shape) == (0, 4)
+  with pytest.raises(_lib.InvalidArgumentError, match="outside"):
+    lookup_gradient(ids_t([[0, 0], [3, 0]]), ids_t([7, 8]), val_t(np.ones((3, 4))))
+  with pytest.raises(_lib.InvalidArgumentError, match="should be same"):
+    lookup_gradient(ids_t([[0, 0]]), ids_t([7, 8]), val_t(np.ones((3, 4))))
+
+
+def test_save_as_tensor_walks_the_table_like_partial_dump():
+  """MonolithHashTableSaveAsTensor (ops/hash_table/misc_ops.cc:46-94) = cuckoohash_map::partial_dump
+  (cuckoohash_map.hpp:740-773) `limit` entries at a time: ids inserted one by one sit where the
+  reference map puts them (the oracle's dump gives (bucket * 4 + slot) of every key), so the sequence
+  of (new_offset, ids) of every call is checked against that walk restated here — over 1 and 3 shards,
+  limits that do and do not divide the counts, a limit of 0 (one entry, as the reference's count check
+  comes after the entry) — and every string is the id's LookupEntry string.  The reference's own test
+  (hash_table_ops_test.py:116-126): assign 3 ids, dump with limit 1000, every string parses."""
+  dim, n = 4, 300
+  mt = MultiHashTable.from_configs({"t": entry.make_table_config(
+      [entry.CombineAsSegment(dim, entry.ZerosInitializer(), entry.AdagradOptimizer(0.05, 0.1))],
+      entry.CuckooHashTableConfig(initial_capacity=1 << 10))}, name_suffix=_name())
+  ot = O.Table(O.segment(dim, O.OPT_ADAGRAD, p=(0.1, 0.0)), 1 << 10)
+  rng = np.random.default_rng(9)
+  ids = rng.choice(1 << 40, n, replace=False).astype(np.int64)
+  for k, i in enumerate(ids):      # one by one: placement is the reference's
+    v = rng.standard_normal((1, dim)).astype(np.float32)
+    mt.assign({"t": (ids_t([i]), val_t(v))}, req_time=1000 + k)
+    ot.assign(np.array([i]), v, 1000 + k)
+  o_ids, o_pos, _, _ = ot.dump()
+  hp = ot.hashpower()
+  assert int(mt.stats("t").hashpower) == hp
+  order = np.argsort(o_pos)
+  o_ids, o_pos = o_ids[order], o_pos[order]
+  strings = dict(zip(ids.tolist(), mt.lookup_entry({"t": ids_t(ids)})["t"]))
+
+  def walk(shard, total, limit, offset):   # partial_dump restated on the oracle's positions
+    hs = 1 << hp
+    Q, R = divmod(hs, total)
+    begin = shard * Q + min(shard, R)
+    end = begin + Q + (1 if shard < R else 0)
+    lo, hi = begin * 4 + offset, end * 4
+    got, count = [], 0
+    for key, pos in zip(o_ids, o_pos):
+      if pos < lo or pos >= hi:
+        continue
+      got.append(int(key))
+      count += 1
+      if count >= limit:
+        return pos - begin * 4 + 1, got
+    return (end - begin + 1) * 4, got
+
+  seen = []
+  for total, limit in ((1, 1000), (1, 7), (3, 16), (3, 0), (5, 1)):
+    got_all = []
+    for shard in range(total):
+      offset, calls = 0, 0
+      while True:
+        new_offset, ents = mt.save_as_tensor("t", shard, total, limit, offset)
+        exp_offset, exp_ids = walk(shard, total, limit, offset)
+        assert new_offset == exp_offset, (total, limit, shard, offset)
+        assert ents == [strings[i] for i in exp_ids], (total, limit, shard, offset)
+        got_all += exp_ids
+        calls += 1
+        if len(ents) < max(limit, 1):
+          break
+        offset = new_offset
+      assert calls >= 1
+    assert sorted(got_all) == sorted(ids.tolist()), (total, limit)
+    seen.append(len(got_all))
+  assert seen == [n] * 5
+  # the reference's own test: three ids, one call, strings that parse
+  small = MultiHashTable.from_configs({"s": entry.make_table_config(
+      [entry.CombineAsSegment(1, entry.ZerosInitializer(), entry.SgdOptimizer(1.0))])}, name_suffix=_name())
+  small.assign({"s": (ids_t([0, 1, 2]), val_t([[0.1], [0.2], [0.3]]))})
+  _, dump = small.save_as_tensor("s", 0, 1, 1000, 0)
+  nums = []
+  for d in dump:
+    e = P.EntryDump()
+    e.ParseFromString(d)
+    nums.append((e.id, list(e.num)))
+  assert sorted(nums) == [(0, [np.float32(0.1)]), (1, [np.float32(0.2)]), (2, [np.float32(0.3)])]
+  with pytest.raises(_lib.InvalidArgumentError):
+    small.save_as_tensor("s", 2, 2, 10, 0)
+
+
 def test_serialized_config_stochastic_rounding_float16():
   """OptimizerConfig.stochastic_rounding_float16 (optimizer.proto:228) in the serialized config: the
   segment's weights are binary16 values after an update, the other segment's are not rounded; on a

@@ -229,6 +229,28 @@ def test_multi_step_more_than_32_tables():
   step.close()
 
 
+def test_a_model_whose_flat_layout_can_misalign_a_wide_table_is_refused_at_creation():
+  """a table of more than 64 floats per row needs float4 lanes, i.e. its slice of the
+  flat embedding / gradient buffer on a 16-byte boundary — which a table of odd dim IN FRONT of it (sorted
+  by name) breaks for the batch sizes where n x dim is not a multiple of four.  Round 4 threw from the
+  middle of such a step (in the sharded step: after the exchanges were enqueued).  Now the model is
+  refused when the step is created; the same tables in the other order are fine, with odd batch sizes."""
+  from monolith_amd import _lib as L
+  from monolith_amd.distributed_ps_sync import ShardedMultiStep
+  bad = [Spec("a_bias16", [(1, "ftrl", 0.05), (16, "adagrad", 0.01)], 1), Spec("b_wide128", [(128, "adagrad", 0.01)], 2)]
+  mt = make(bad)
+  with pytest.raises(L.InvalidArgumentError, match="follows"):
+    MultiSparseStep(mt, 1024)
+  with pytest.raises(L.InvalidArgumentError, match="follows"):
+    ShardedMultiStep(mt, 1024)
+  good = [Spec("a_wide128", [(128, "adagrad", 0.01)], 1), Spec("b_bias16", [(1, "ftrl", 0.05), (16, "adagrad", 0.01)], 2)]
+  batches = [{"a_wide128": S.id_batch(10 + s, 701, 3000, "zipf", feature_slot=1),
+              "b_bias16": S.id_batch(20 + s, 333, 3000, "zipf", feature_slot=2)} for s in range(4)]
+  mt, ots, step = run_pipeline(good, batches, seeded_grads, True)
+  check_final(mt, ots, good, batches, True)
+  step.close()
+
+
 # =============================================================================== configs[4] shape
 @pytest.mark.parametrize("exact", [True, False])
 def test_multi_step_26_tables_matches_oracle(exact):

@@ -93,7 +93,23 @@ def test_group_bias_slice_rows_against_oracle(dist, world):
   _group_against_oracle(bias_slice_specs(), dist, world, False)
 
 
-def _group_against_oracle(specs, dist, world, grad_fp16, B=3000, steps=5):
+@pytest.mark.parametrize("world", [2, 5, 8])
+def test_group_launch_count_does_not_grow_with_the_world(world):
+  """The owner applies EVERY peer's gradient block in one launch (shard_apply_kernel: the lane group of
+  an id's lowest sender applies its entries in rank order — the reference's one optimizer application
+  per sender, distributed_ps_sync.py:357-479, in the one-op-over-all-shards shape of
+  multi_hash_table_update_op.cc:247-308), and the sender's scatter shares a launch with the next batch's
+  run dedup: a steady-state step is the same <= 8 launches + exchanges at N = 2, 5 and 8 — round 4's
+  step made 2 N + 6 owner launches.  Checked against the oracle like every other group test."""
+  counts = _group_against_oracle(dlrm_specs(8, initial_capacity=1 << 10), "zipf", world, False, B=2000, steps=4,
+                                 always_ahead=True)
+  steady = counts[1:]            # (the first step also deduplicates, numbers and sends its own batch)
+  assert all(c == steady[0] for c in steady), counts
+  assert steady[0] <= 8, counts
+  assert steady[0] == 8, counts  # lookup, rows, scatter|dedup; sums|numbering, gradients, ids, apply, displacement
+
+
+def _group_against_oracle(specs, dist, world, grad_fp16, B=3000, steps=5, always_ahead=False):
   by_name = sorted(specs, key=lambda s: s.name)
   universe = 200000 if dist == "uniform" else 7000
   exact = dist == "uniform"   # every id occurs <= 32 times in a batch: sums in occurrence order
@@ -112,8 +128,9 @@ def _group_against_oracle(specs, dist, world, grad_fp16, B=3000, steps=5):
   batches = [[rank_batch(s, r) for r in range(world)] for s in range(steps + 1)]
   rag = [[ragged_of(specs, mts[r], batches[s][r]) for r in range(world)] for s in range(steps + 1)]
   pre = False
+  launch_counts = []
   for s in range(steps):
-    ahead = s % 2 == 0
+    ahead = always_ahead or s % 2 == 0
     embs = grp.forward(rag[s], rag[s + 1] if ahead else None, prefetched=pre)
     pre = ahead
     flat = []
@@ -145,6 +162,9 @@ def _group_against_oracle(specs, dist, world, grad_fp16, B=3000, steps=5):
         ots[sp.name].optimize(uk, gu, sp.lrs(), S.update_time(s))
       flat.append(val_t(np.concatenate(fg)))
     grp.backward(flat, S.update_time(s))
+    per_rank = [f + b for f, b in grp.launches()]
+    assert all(c == per_rank[0] for c in per_rank) or not always_ahead, per_rank
+    launch_counts.append(max(per_rank))
   grp.check()
   # every owner holds exactly its ids, with the oracle's rows
   for sp in by_name:
@@ -160,6 +180,7 @@ def _group_against_oracle(specs, dist, world, grad_fp16, B=3000, steps=5):
     sizes = [int(mts[r].size(sp.name)) for r in range(world)]
     assert sum(sizes) == seen.size, (sp.name, sizes, seen.size)
   grp.close()
+  return launch_counts
 
 
 def test_world1_over_rccl():
