@@ -1240,7 +1240,16 @@ struct Table {
   const float* pend_grad = nullptr;
   ApplyArgs pend_args{};
   int pend_vec = 4;
-  void finish_pending(hipStream_t st) {
+  // a displacement pass somebody else owes this table (the id-sharded step runs the pass of its last owner
+  // update inside its NEXT owner lookup's launch, mhte_shard_host.h): whoever touches the table first — any
+  // op, a save, a doubling — makes it happen now
+  void (*ext_flush)(void*, hipStream_t) = nullptr;
+  void* ext_ctx = nullptr;
+  void finish_pending(hipStream_t st, bool skip_ext = false) {
+    if (ext_flush && !skip_ext) {
+      void (*f)(void*, hipStream_t) = ext_flush;
+      f(ext_ctx, st);   // (clears the hook of every table it covers)
+    }
     if (!pend_valid) return;
     pend_valid = false;
     ++mut_epoch;
@@ -1494,6 +1503,14 @@ mhte_status mhte_multi_table_create(const mhte_table_config* configs, int32_t n_
 
 void mhte_multi_table_destroy(mhte_multi_table* t) {
   if (t) {
+    // (a displacement pass an id-sharded step still owes these tables: run it while they exist — the
+    // step's destructor does the same if it goes first)
+    try {
+      (void)hipSetDevice(t->device);
+      for (auto& tb : t->tables)
+        if (tb->ext_flush) tb->finish_pending(nullptr);
+    } catch (...) {
+    }
     std::lock_guard<std::mutex> g(g_registry_mu);
     auto it = g_registry.find(t->shared_name);
     if (it != g_registry.end() && it->second == t) g_registry.erase(it);
@@ -4358,6 +4375,7 @@ mhte_status mhte_shard_step_check(mhte_shard_step* s, void* stream) {
   return guard([&] {
     if (!s) throw Error(MHTE_INVALID_ARGUMENT, "null shard step");
     HIP_OK(hipSetDevice(s->ss.device));
+    s->ss.flush_slow(mhte::S(stream));
     HIP_OK(hipStreamSynchronize(mhte::S(stream)));
     if (s->ss.aux) HIP_OK(hipStreamSynchronize(s->ss.aux));
     s->ss.check_flags();

@@ -39,7 +39,8 @@ constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 
 enum OptType : int32_t {
   kOptSgd = 0, kOptAdagrad = 1, kOptFtrl = 2,
-  // op-level kernels only (the fused training-step kernels take the three above):
+  // (the fused training-step kernels serve these through their FULL instances; GroupAdaGrad — whole-segment —
+  // through the op-level kernels, mhte_fused_optimize and the id-sharded step's owner side):
   kOptMomentum = 3, kOptAdadelta = 4, kOptRmsprop = 5, kOptRmspropV2 = 6, kOptAdam = 7, kOptAmsgrad = 8,
   kOptMovingAverage = 9, kOptBatchSoftmax = 10, kOptGroupAdagrad = 11,
   kOptCount = 12

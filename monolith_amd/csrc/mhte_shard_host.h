@@ -104,7 +104,8 @@ struct ShardStep {
   struct OwnerChunk {           // owner_apply: the arguments of tables [c * kMaxStepTables, ...)
     ShardOwnerArgs A;
     uint32_t tc, gx, gx_fill;
-    bool inst[2][2];            // [one float per lane][whole-segment optimizer]
+    bool inst[2][2];              // per-peer form
+    bool inst3[2][2][2];          // one-launch form: + [one segment of SGD / Adagrad / FTRL rows: the FAST instance]            // [one float per lane][whole-segment optimizer]
   };
   std::vector<OwnerChunk> apply_chunks;
   int64_t max_batch = 0;
@@ -132,6 +133,13 @@ struct ShardStep {
   std::vector<uint64_t> own_epoch;   // Table::mut_epoch when that lookup ran
   bool legacy_owner = false;    // MHTE_SHARD_PER_PEER=1 (A/B), or a table has an occurrence filter: the
                                 // peers' blocks are applied by one launch pair each, in rank order
+  // ---- the displacement pass of an owner update rides in the NEXT owner lookup's launch (its first
+  // workgroups; the lookups of a table gate on it — shard_lookup_kernel): a launch of its own cost ~6 us
+  // of a ~60 us step to find, five steps in six, an empty list.  Until that lookup is enqueued the pass
+  // is owed: the tables carry a hook (Table::ext_flush) that makes any other user of them run it first.
+  bool fold_slow = true;        // MHTE_SHARD_FOLD_SLOW=0: always a launch of its own (A/B)
+  bool slow_pending = false;
+  int slow_slot = -1;
   uint32_t launches = 0;        // kernel launches + exchanges enqueued by the last forward + backward
   // ---- sizing the owner's launches by what the peers actually send.  A (peer, table) block can hold the
   // whole batch; a Zipf batch fills a fifth of it, N ranks a fifth of an N-th.  Workgroups sized for the
@@ -201,6 +209,11 @@ struct ShardStep {
 
   ~ShardStep() {
     (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    try {
+      flush_slow(nullptr);
+    } catch (...) {
+    }
     (void)hipDeviceSynchronize();
     if (comm) (void)Rccl::get().CommDestroy(comm);
     if (aux) (void)hipStreamDestroy(aux);
@@ -316,6 +329,7 @@ struct ShardStep {
       clear_x(nullptr);
     }
     if (const char* e = getenv("MHTE_SHARD_PER_PEER")) legacy_owner = atoi(e) != 0;
+    if (const char* e = getenv("MHTE_SHARD_FOLD_SLOW")) fold_slow = atoi(e) != 0;
     if (const char* e = getenv("MHTE_SHARD_FUSE_SCATTER")) fuse_scatter = atoi(e) != 0;
     HIP_OK(hipMalloc(&own_rows, rb + 64));
     if (ipc) {
@@ -689,7 +703,7 @@ struct ShardStep {
     }
   }
 
-  void prepare(hipStream_t st) {
+  void prepare(hipStream_t st, bool keep_owed_pass = false) {
     check_flags();
     if (aux_pending)   // (descriptors are about to be re-uploaded: nothing of ours may still read them)
       for (uint32_t t = 0; t < T; ++t)
@@ -697,7 +711,7 @@ struct ShardStep {
           HIP_OK(hipStreamSynchronize(aux));
           break;
         }
-    for (auto& tb : mt->tables) tb->finish_pending(st);
+    for (auto& tb : mt->tables) tb->finish_pending(st, keep_owed_pass);
     sync_views(mt, st);
     ms.sync_static(st);
   }
@@ -767,6 +781,7 @@ struct ShardStep {
       gather_tabs(sum_slot);
     }   // (no sums: shape code 0, the numbering alone runs in the float4 instance)
     if (build_slot >= 0) {
+      flush_slow(st);   // (the owed pass clears send headers: it must not follow this numbering)
       if (hdr_dirty[build_slot])   // (a batch that was packed and never trained)
         HIP_OK(hipMemset2DAsync(ids_send[build_slot], size_t(geo.ids_block) * 8, 0, size_t(T) * 8,
                                 size_t(world), st));
@@ -858,6 +873,34 @@ struct ShardStep {
     return (by_cap || est_n[t] == 0) ? cap : std::min(cap, est_n[t]);
   }
 
+  static void flush_slow_cb(void* ctx, hipStream_t st) { static_cast<ShardStep*>(ctx)->flush_slow(st); }
+  void set_hooks(bool on) {
+    for (uint32_t t = 0; t < T; ++t) {
+      mt->tables[t]->ext_flush = on ? &ShardStep::flush_slow_cb : nullptr;
+      mt->tables[t]->ext_ctx = on ? this : nullptr;
+    }
+  }
+  // the owed displacement pass as a launch of its own (anything but the next owner lookup came first)
+  void flush_slow(hipStream_t st) {
+    if (!slow_pending) return;
+    slow_pending = false;
+    set_hooks(false);
+    for (OwnerChunk& k : apply_chunks) {
+      k.A.zero_headers = 1u;
+      shard_slow_all_kernel<<<k.tc, 64, 0, st>>>(k.A);
+      HIP_OK(hipGetLastError());
+      ++launches;
+    }
+    if (slow_slot >= 0) hdr_dirty[slow_slot] = false;
+  }
+  // the pass may ride in a lookup launch when every table's rows take the BASIC update code there
+  bool can_fold() const {
+    if (!fold_slow) return false;
+    for (uint32_t t = 0; t < T; ++t)
+      if (!mt->tables[t]->basic_opts() || mt->tables[t]->has_group_opt) return false;
+    return true;
+  }
+
   void clear_x(hipStream_t st) {
     if (!xs) return;
     const uint64_t nslots = uint64_t(T) * (uint64_t(xcap) + 1);
@@ -937,8 +980,11 @@ struct ShardStep {
       ++launches;
     }
     if (F.nd + lin) {
+      // (a heavy work item — ~256 occurrences of one id — is shared by four wavefronts: one wavefront walks
+      // it 64 positions at a time with a dependent position load per pass, and there are idle ones)
+      static const uint32_t split_env = getenv("MHTE_SHARD_ITEM_SPLIT") ? uint32_t(std::max(1, atoi(getenv("MHTE_SHARD_ITEM_SPLIT")))) : 4u;
       LAUNCH_HOT(kTagShardGather, shard_scatter_dedup_kernel, F.nd + lin, kRdBlock, st, A, D, F,
-                 std::max<uint32_t>(1, ms.item_target / kItemTarget));
+                 std::max<uint32_t>(split_env, ms.item_target / kItemTarget));
       ++launches;
     }
     HIP_OK(hipGetLastError());
@@ -963,9 +1009,12 @@ struct ShardStep {
     A.t0 = t0;
     A.tc = tc;
     fill_tabs(A.tab, t0, tc);
+    static const bool no_fast = getenv("MHTE_SHARD_NO_FAST_APPLY") != nullptr;   // (A/B)
     for (uint32_t i = 0; i < tc; ++i) {
-      A.g[i] = uint8_t(seg_shape_code(*mt->tables[t0 + i]));
-      A.count_hits[i] = mt->tables[t0 + i]->count_hits ? 1 : 0;
+      const Table& tb = *mt->tables[t0 + i];
+      A.g[i] = uint8_t(seg_shape_code(tb));
+      A.count_hits[i] = tb.count_hits ? 1 : 0;
+      A.fast[i] = (!no_fast && tb.basic_opts() && !tb.has_group_opt) ? 1 : 0;
     }
   }
 
@@ -979,23 +1028,44 @@ struct ShardStep {
     own_slot = slot;
     poll_counts();
     for (uint32_t t = 0; t < T; ++t) own_epoch[t] = mt->tables[t]->mut_epoch;
+    const bool fold = slow_pending && !per_peer;
+    if (slow_pending && !fold) flush_slow(st);
     for (uint32_t t0 = 0; t0 < T; t0 += uint32_t(kMaxStepTables)) {
       const uint32_t tc = chunk_tables(t0);
       ShardOwnerArgs A{};
       owner_args(A, slot, false, t0, tc);
       if (per_peer) A.x.xs = nullptr, A.x.oslot = nullptr;   // (no registration: nobody would consume it)
+      if (fold) {   // the previous update's displacement pass: that update's arguments for these tables
+        const ShardOwnerArgs& P = apply_chunks[t0 / uint32_t(kMaxStepTables)].A;
+        A.slow_on = 1u;
+        A.slow_ids = P.recv_ids;
+        A.slow_rows = P.rows;
+        A.zero_headers = 1u;
+        A.clear_ids = P.clear_ids;
+        for (uint32_t i = 0; i < tc; ++i) {
+          A.pending[i] = P.pending[i];
+          A.a[i] = P.a[i];
+        }
+      }
       uint32_t gx = 1;
       for (uint32_t i = 0; i < tc; ++i)
         gx = std::max(gx, uint32_t((uint64_t((sized_n(t0 + i) + 1) / 2) * shape_lanes(A.g[i]) + 511) / 512));
       // (grid-stride inside: enough workgroups to fill the chip a few times over, not one per slot)
       const uint32_t fill = std::max<uint32_t>(8, uint32_t(ms.num_cus) * 16 / (uint32_t(world) * tc));
       gx = std::min(gx, fill);
-      bool w4 = false, w1 = false;
+      bool w4 = fold, w1 = false;   // (the float4 instance runs the owed pass)
       for (uint32_t i = 0; i < tc; ++i) ((A.g[i] & 1u) ? w1 : w4) = true;
-      if (w4) LAUNCH_HOT(kTagShardLookup, shard_lookup_kernel<4>, dim3(gx, uint32_t(world) * tc), 512, st, A);
-      if (w1) LAUNCH_HOT(kTagShardLookup, shard_lookup_kernel<1>, dim3(gx, uint32_t(world) * tc), 512, st, A);
+      if (fold) gx = std::max(gx, tc);
+      const dim3 grid(gx, uint32_t(world) * tc + (fold ? 1u : 0u));
+      if (w4) LAUNCH_HOT(kTagShardLookup, shard_lookup_kernel<4>, grid, 512, st, A);
+      if (w1) LAUNCH_HOT(kTagShardLookup, shard_lookup_kernel<1>, grid, 512, st, A);
       launches += (w4 ? 1u : 0u) + (w1 ? 1u : 0u);
       HIP_OK(hipGetLastError());
+    }
+    if (fold) {
+      slow_pending = false;
+      set_hooks(false);
+      if (slow_slot >= 0) hdr_dirty[slow_slot] = false;
     }
     fetch_counts_lazily(slot, st);
   }
@@ -1034,6 +1104,7 @@ struct ShardStep {
         a.global_step = global_step;
         gx = std::max(gx, (sized_n(t0 + i) + 256u / shape_lanes(A.g[i]) - 1) / (256u / shape_lanes(A.g[i])));
         k.inst[A.g[i] & 1u][(A.g[i] >> 1) & 1u] = true;
+        k.inst3[A.g[i] & 1u][(A.g[i] >> 1) & 1u][A.fast[i] ? 1 : 0] = true;
       }
       const uint32_t fill = std::max<uint32_t>(8, uint32_t(ms.num_cus) * 16 / k.tc);
       k.gx_fill = fill;
@@ -1058,22 +1129,29 @@ struct ShardStep {
           if (own_slot == slot && own_epoch[t0 + i] == mt->tables[t0 + i]->mut_epoch) A.x.hints |= 1u << i;
         const uint32_t gx = std::max<uint32_t>(1u, std::min<uint32_t>(k.gx, std::max<uint32_t>(8, k.gx_fill / uint32_t(world))));
         const dim3 grid(gx, uint32_t(world) * k.tc);
-#define MHTE_APPLY_LAUNCH(W_, G_)                                                                         \
-  do {                                                                                                  \
-    if (world > 1) LAUNCH_HOT(kTagShardUpsert, (shard_apply_kernel<W_, G_, true>), grid, 256, st, A);   \
-    else LAUNCH_HOT(kTagShardUpsert, (shard_apply_kernel<W_, G_, false>), grid, 256, st, A);            \
+#define MHTE_APPLY_LAUNCH(W_, G_, F_)                                                                          \
+  do {                                                                                                       \
+    if (k.inst3[W_ == 1][G_][F_]) {                                                                          \
+      if (world > 1) LAUNCH_HOT(kTagShardUpsert, (shard_apply_kernel<W_, G_ != 0, true, F_ != 0>), grid, 256, st, A);  \
+      else LAUNCH_HOT(kTagShardUpsert, (shard_apply_kernel<W_, G_ != 0, false, F_ != 0>), grid, 256, st, A);           \
+      ++launches;                                                                                            \
+    }                                                                                                        \
   } while (0)
-        if (k.inst[0][0]) MHTE_APPLY_LAUNCH(4, false);
-        if (k.inst[1][0]) MHTE_APPLY_LAUNCH(1, false);
-        if (k.inst[0][1]) MHTE_APPLY_LAUNCH(4, true);
-        if (k.inst[1][1]) MHTE_APPLY_LAUNCH(1, true);
+        MHTE_APPLY_LAUNCH(4, 0, 1);
+        MHTE_APPLY_LAUNCH(1, 0, 1);
+        MHTE_APPLY_LAUNCH(4, 0, 0);
+        MHTE_APPLY_LAUNCH(1, 0, 0);
+        MHTE_APPLY_LAUNCH(4, 1, 0);
+        MHTE_APPLY_LAUNCH(1, 1, 0);
 #undef MHTE_APPLY_LAUNCH
-        shard_slow_all_kernel<<<k.tc, 64, 0, st>>>(A);
         HIP_OK(hipGetLastError());
-        launches += uint32_t(k.inst[0][0]) + uint32_t(k.inst[1][0]) + uint32_t(k.inst[0][1]) + uint32_t(k.inst[1][1]) + 1u;
       }
       x_dirty = false;
       own_slot = -1;
+      slow_pending = true;
+      slow_slot = slot;
+      if (can_fold()) set_hooks(true);   // the pass rides in the next owner lookup
+      else flush_slow(st);
     } else
     for (int p = 0; p < world; ++p) {
       wait_arrived(kXGrads, slot, p, p + 1, st);   // (a peer's block is applied as soon as it has landed)
@@ -1100,9 +1178,10 @@ struct ShardStep {
           break;
         }
     }
-    hdr_dirty[slot] = false;
+    if (!slow_pending) hdr_dirty[slot] = false;   // (an owed pass clears the headers when it runs)
     for (uint32_t t = 0; t < T; ++t) {
       ++mt->tables[t]->mut_epoch;
+      // (the eviction cadence is checked with the pass still owed: a scan that is due runs it first)
       mt->tables[t]->maybe_evict(st);
     }
   }
@@ -1310,7 +1389,7 @@ static void shard_forward(ShardStep** S, int n, const ShardFwd* a, int64_t n_spl
     HIP_OK(hipSetDevice(s.device));
     s.launches = 0;
     s.join_aux(st);
-    s.prepare(st);
+    s.prepare(st, /*keep_owed_pass=*/true);
     if (prefetched) {
       s.ms.cur ^= 1;
     } else {

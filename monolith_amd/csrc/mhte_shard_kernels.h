@@ -96,6 +96,12 @@ struct ShardOwnerArgs {
   uint32_t peer;              // upsert / slow: the block being applied
   uint32_t zero_headers;      // slow: 1 = clear the headers of `clear_ids` when done
   int64_t* clear_ids;
+  // the lookup launch that also runs the displacement pass of the PREVIOUS owner update (slow_on): that
+  // update's id blocks and gradient blocks; pending[] / a[] / g[] below are that update's too
+  const int64_t* slow_ids;
+  const float* slow_rows;
+  uint32_t slow_on;
+  uint32_t pad0;
   // a launch serves tables [t0, t0 + tc) of the model (the host chunks: kernel-argument budget); the
   // arrays below are indexed by the table's position in the launch, `views`, the header words and
   // the per-table device arrays by its index in the model
@@ -104,6 +110,8 @@ struct ShardOwnerArgs {
   ShardTab tab[kMaxStepTables];
   uint8_t g[kMaxStepTables];          // lane-group shape per table (MHTE_SWITCH_G; | kShapeGroupBit)
   uint8_t count_hits[kMaxStepTables];
+  uint8_t fast[kMaxStepTables];       // 1: SGD / Adagrad / FTRL rows — shard_apply_kernel's FAST
+                                      // instance (the step kernels' register-resident update) serves the table
   ApplyArgs a[kMaxStepTables];
 };
 static_assert(sizeof(ShardOwnerArgs) <= 4096, "kernel arguments exceed 4 KB");
@@ -119,27 +127,53 @@ __device__ __forceinline__ uint32_t shard_block_count(const ShardOwnerArgs& A, u
   return uint32_t(c);
 }
 
+template <bool GATED>
+__device__ __forceinline__ void shard_slow_all_role(const ShardOwnerArgs& A, uint32_t t, const int64_t* recv_ids,
+                                                    const float* rows, BfsSlot* q, CuckooRecord* path, int lane);
+
 // Lookup of one (peer, table) segment: two ids per lane group, all probes, then all row loads in flight
 // (lookup_role_u), + what the update will want to know (OwnRec) + (xs != nullptr: world > 1) the
 // registration of the id in the cross-peer scratch.  The registration's claim is issued behind the row
 // loads, so the rows leave while it is in flight.
 template <int G, int VEC>
-__device__ __forceinline__ void shard_lookup_loop(const TableView& tv, const int64_t* __restrict__ ids, uint32_t n,
+__device__ __forceinline__ void shard_lookup_loop(const ShardOwnerArgs& A, uint32_t p, uint32_t t,
+                                                  const TableView& tv, const int64_t* __restrict__ ids, uint32_t cap,
                                                   float* __restrict__ out, int count_hits,
                                                   OwnRec* __restrict__ orec, uint32_t* __restrict__ oslot,
                                                   uint32_t* __restrict__ xs, uint32_t xmask, uint32_t xstride,
-                                                  uint32_t p) {
+                                                  uint32_t /*p again*/) {
   constexpr int UNR = 2;
   const int lane = threadIdx.x & 63;
   const int j = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
-  const uint32_t ngroups = (n + 1u) / 2u;
+  // (the block's count is fetched WITH the first trip's ids — every index below the block's capacity
+  // is memory that exists — instead of in front of them: one dependent round trip less on a chain of four)
+  uint32_t n = cap;
+  bool have_n = false;
   uint64_t hits = 0;
 #pragma unroll 1
-  for (uint32_t grp = (blockIdx.x * 512u + threadIdx.x) / G; grp < ngroups; grp += gridDim.x * 512u / G) {
+  for (uint32_t grp = (blockIdx.x * 512u + threadIdx.x) / G; grp < (n + 1u) / 2u; grp += gridDim.x * 512u / G) {
     const uint32_t g0 = grp * UNR;
+    int64_t myid = (j < UNR && g0 + uint32_t(j) < cap) ? ids[g0 + j] : 0;
+    if (!have_n) {
+      n = shard_block_count(A, p, t);
+      have_n = true;
+      if (A.slow_on) {
+        // The displacement pass of the previous owner update runs in this launch (the first workgroups):
+        // no word of the table is read before it has finished — n_pending drops to 0 only after its
+        // stores were written back (release), and every load below is control-dependent on having seen
+        // the 0 (lookup_role's gate).  Usually the list is empty and this is one load beside the ids'.
+        // (the first look is a plain load: the L2s are clean at a launch's start, the count only falls
+        // inside it, so a 0 read now is the truth — and a plain load is a round trip shorter than an atomic)
+        if (*reinterpret_cast<const volatile unsigned int*>(&tv.ctr->n_pending) != 0u) {
+          while (__hip_atomic_load(&tv.ctr->n_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+            __builtin_amdgcn_s_sleep(8);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+      }
+    }
     const bool mine_valid = j < UNR && g0 + uint32_t(j) < n;
-    const int64_t myid = mine_valid ? ids[g0 + j] : 0;
+    if (!mine_valid) myid = 0;
     int64_t id[UNR], kk[UNR];
     bool valid[UNR];
     uint32_t row[UNR], tsv[UNR];
@@ -215,13 +249,22 @@ __device__ __forceinline__ void shard_lookup_loop(const TableView& tv, const int
     atomicAdd(&tv.ctr->hits, (unsigned long long)hits);
 }
 
-// grid (x, world * tc): y = peer * tc + table of the launch
+// grid (x, world * tc + slow_on): y = peer * tc + table of the launch (+ 1 with slow_on: row 0 — dispatched
+// first — is the displacement pass of the previous owner update, one wavefront per table; A.g / A.a /
+// A.pending describe that update's tables, which are this launch's)
 template <int VW>
 __global__ __launch_bounds__(512) void shard_lookup_kernel(ShardOwnerArgs A) {
-  const uint32_t p = blockIdx.y / A.tc, t = blockIdx.y % A.tc;
+  __shared__ BfsSlot sq[kMaxCuckooCount];
+  __shared__ CuckooRecord spath[kMaxBfsPathLen];
+  if (A.slow_on && blockIdx.y == 0) {
+    // (the float4 instance runs the pass for every table: the role picks the lane width per table)
+    if (VW == 4 && blockIdx.x < A.tc && threadIdx.x < 64)
+      shard_slow_all_role<true>(A, blockIdx.x, A.slow_ids, A.slow_rows, sq, spath, int(threadIdx.x));
+    return;
+  }
+  const uint32_t y = blockIdx.y - (A.slow_on ? 1u : 0u);
+  const uint32_t p = y / A.tc, t = y % A.tc;
   if (!MHTE_SHAPE_IS(VW, A.g[t])) return;
-  const uint32_t n = shard_block_count(A, p, t);
-  if (n == 0) return;
   const ShardTab tb = A.tab[t];
   const TableView& tv = deref_const(A.views + (A.t0 + t));
   const size_t eb = size_t(p) * A.geo.ids_block + tb.id_off;
@@ -231,7 +274,7 @@ __global__ __launch_bounds__(512) void shard_lookup_kernel(ShardOwnerArgs A) {
   uint32_t* xs = A.x.xs ? A.x.xs + size_t(A.t0 + t) * (size_t(A.x.xmask) + 2u) * A.x.xstride : nullptr;
   uint32_t* oslot = A.x.oslot ? A.x.oslot + eb : nullptr;
 #define MHTE_SEGL_CALL(G_, V_) \
-  shard_lookup_loop<G_, V_>(tv, ids, n, out, ch, A.x.orec + eb, oslot, xs, A.x.xmask, A.x.xstride, p)
+  shard_lookup_loop<G_, V_>(A, p, t, tv, ids, tb.cap, out, ch, A.x.orec + eb, oslot, xs, A.x.xmask, A.x.xstride, p)
   MHTE_SWITCH_G(VW, A.g[t] & ~kShapeGroupBit, MHTE_SEGL_CALL)
 #undef MHTE_SEGL_CALL
 }
@@ -333,7 +376,7 @@ __global__ __launch_bounds__(64) void shard_slow_kernel(ShardOwnerArgs A) {
 #endif
 template <int G, int VEC, bool GROUP, bool MULTI>
 __device__ __forceinline__ void shard_apply_loop(const ShardOwnerArgs& A, const TableView& tv, uint32_t p,
-                                                 uint32_t t, uint32_t n) {
+                                                 uint32_t t) {
   const ShardTab tb = A.tab[t];
   const int lane = threadIdx.x & 63;
   const int j = lane & (G - 1);
@@ -347,15 +390,22 @@ __device__ __forceinline__ void shard_apply_loop(const ShardOwnerArgs& A, const 
   const bool trust = ((A.x.hints >> t) & 1u) != 0u;
   const ApplyArgs& a = A.a[t];
   const uint32_t ngroups_wg = 256 / G;
+  // (the block's count arrives WITH the first trip's records, not in front of them: shard_lookup_loop)
+  uint32_t n = tb.cap;
+  bool have_n = false;
 #pragma unroll 1
   for (uint32_t g0 = blockIdx.x * ngroups_wg; g0 < n; g0 += gridDim.x * ngroups_wg) {  // wave-uniform
     const uint32_t g = g0 + threadIdx.x / G;
-    const bool valid = g < n;
-    const uint32_t gs = valid ? g : 0u;   // (loads from a safe index, masked afterwards)
+    const uint32_t gs = g < tb.cap ? g : 0u;   // (loads from an index that exists, masked afterwards)
     const int64_t id = ids[gs];
     const OwnRec rec = orec[gs];
     uint32_t hs = 0;
     if (multi) hs = A.x.oslot[eb + gs];
+    if (!have_n) {
+      n = shard_block_count(A, p, t);
+      have_n = true;
+    }
+    const bool valid = g < n;
     // ---- the id's entries (one per peer that sent it); who applies them
     unsigned long long pm = 1ull << p;
     bool mine = valid;
@@ -417,28 +467,147 @@ __device__ __forceinline__ void shard_apply_loop(const ShardOwnerArgs& A, const 
   }
 }
 
-// MULTI: the world has more than one rank (the cross-peer scratch is consulted)
-template <int VW, bool GROUP = false, bool MULTI = false>
-__global__ __launch_bounds__(256, GROUP ? 1 : (MULTI ? MHTE_SEGX_OCC : MHTE_SEGU_OCC)) void shard_apply_kernel(
+// The same for a table of SGD / Adagrad / FTRL rows (the shapes of BASELINE's configs), with
+// the update the step kernels use (optimize_row_pre: segment descriptor in scalar registers, row and
+// gradient in vector registers).  The sender's gradient row is fetched WITH the id and the lookup's record
+// (its address is the slot's), the row as soon as the record is there: two dependent round trips
+// (id | record | gradient -> row -> store) where apply_row makes four (.. -> descriptor -> row | gradient).
+template <int G, int VEC, bool MULTI, bool ONESEG>
+__device__ __forceinline__ void shard_apply_fast_loop(const ShardOwnerArgs& A, const TableView& tv, uint32_t p,
+                                                      uint32_t t) {
+  const ShardTab tb = A.tab[t];
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (G - 1);
+  const uint32_t world = A.geo.world;
+  constexpr bool multi = MULTI;
+  const size_t eb = size_t(p) * A.geo.ids_block + tb.id_off;
+  const int64_t* ids = A.recv_ids + eb;
+  const OwnRec* orec = A.x.orec + eb;
+  uint32_t* const xs = multi ? A.x.xs + size_t(A.t0 + t) * (size_t(A.x.xmask) + 2u) * A.x.xstride : nullptr;
+  const bool trust = ((A.x.hints >> t) & 1u) != 0u;
+  const ApplyArgs& a = A.a[t];
+  const float* my_rows = A.rows + size_t(p) * A.geo.rows_block + tb.row_off;
+  const uint32_t dim = tv.dim;
+  const uint32_t e = uint32_t(j) * VEC;
+  const bool ev = e < dim;
+  const uint32_t ngroups_wg = 256 / G;
+  uint32_t n = tb.cap;
+  bool have_n = false;
+#pragma unroll 1
+  for (uint32_t g0 = blockIdx.x * ngroups_wg; g0 < n; g0 += gridDim.x * ngroups_wg) {  // wave-uniform
+    const uint32_t g = g0 + threadIdx.x / G;
+    const uint32_t gs = g < tb.cap ? g : 0u;   // (loads from an index that exists, masked afterwards)
+    const int64_t id = ids[gs];
+    const OwnRec rec = orec[gs];
+    uint32_t hs = 0;
+    if (multi) hs = A.x.oslot[eb + gs];
+    Vec<VEC> gv;
+    vec_zero(gv);
+    if (ev) gv.load(my_rows + size_t(gs) * dim + e);
+    if (!have_n) {
+      n = shard_block_count(A, p, t);
+      have_n = true;
+    }
+    const bool valid = g < n;
+    unsigned long long pm = 1ull << p;
+    bool mine = valid;
+    if (multi) {
+      pm = *reinterpret_cast<const unsigned long long*>(xs + size_t(hs) * A.x.xstride + 2);
+      if (!valid) pm = 0ull;
+      mine = ((pm >> p) & 1ull) != 0ull && (pm & ((1ull << p) - 1ull)) == 0ull;
+    }
+    const bool hinted = mine && trust && rec.row != kNoRow;
+    const bool need = mine && !hinted;
+    RowRegs<VEC> rr;
+    vec_zero(rr.w);
+    vec_zero(rr.s1);
+    // (rows of the first slab are addressed without the slab table: rd_apply_role)
+    const bool slab0 = (rec.row >> tv.chunk_shift) == 0u;
+    if (hinted && slab0) row_prefetch<VEC, ONESEG>(tv, assume_global(tv.chunk0 + size_t(rec.row) * tv.row_floats), e, rr);
+    if (__any(hinted && !slab0)) {
+      if (hinted && !slab0) row_prefetch<VEC, ONESEG>(tv, row_ptr(tv, rec.row), e, rr);
+    }
+    uint32_t r = rec.row;
+    bool is_new = false, deferred = false, found_now = false;
+    {
+      const Probe<G> pr = probe_issue<G>(tv, id, need, j);
+      const SlotResult sr = upsert_resolve<G>(tv, (Bucket*)pr.b, id, need, pr.k, pr.row, lane, a.ts);
+      if (need) {
+        r = sr.r;
+        is_new = sr.is_new;
+        deferred = sr.deferred;
+        found_now = !sr.is_new && !sr.deferred;
+      }
+    }
+    if (hinted && j == 0 && rec.ts != a.ts)
+      global_bucket(tv.buckets + (rec.loc >> 2))->ts[rec.loc & 3ull] = a.ts;
+    if (deferred && j == 0) {
+      const uint32_t slot = atomicAdd(&tv.ctr->n_pending, 1u);
+      A.pending[t][2 * slot] = g;
+      A.pending[t][2 * slot + 1] = p;
+    }
+    if (mine && !deferred) {
+      float* rp = row_ptr(tv, r);
+      if (found_now) row_prefetch<VEC, ONESEG>(tv, rp, e, rr);   // (a resident id the record did not cover)
+      optimize_row_pre<VEC, ONESEG>(tv, rp, is_new, e, gv, a, rr);
+      if (multi) {
+        // the other senders of the id, ascending, one optimizer step each: their slots and gradients are
+        // fetched when their turn comes, the row is read back through the L2
+        uint32_t* sl = xs + size_t(hs) * A.x.xstride;
+        unsigned long long rest = pm & ~((2ull << p) - 1ull);
+        if (p >= 63u) rest = 0ull;
+#pragma unroll 1
+        while (rest) {   // (group-uniform)
+          const uint32_t q = uint32_t(__ffsll(static_cast<long long>(rest)) - 1);
+          rest &= rest - 1ull;
+          const uint32_t sq = sl[kXKeyWords + q] - 1u;
+          Vec<VEC> g2;
+          vec_zero(g2);
+          if (ev) g2.load(A.rows + size_t(q) * A.geo.rows_block + tb.row_off + size_t(sq) * dim + e);
+          optimize_row_reg<VEC, ONESEG>(tv, rp, false, e, g2, a);
+        }
+        for (uint32_t q = uint32_t(j); q < world; q += G) sl[kXKeyWords + q] = 0u;
+        if (j == 0) {
+          *reinterpret_cast<unsigned long long*>(sl + 2) = 0ull;
+          *reinterpret_cast<int64_t*>(sl) = kEmptyKey;
+        }
+      }
+    }
+  }
+}
+
+// MULTI: the world has more than one rank (the cross-peer scratch is consulted); FAST: the tables with
+// A.fast set (shard_apply_fast_loop), else the others
+template <int VW, bool GROUP = false, bool MULTI = false, bool FAST = false>
+__global__ __launch_bounds__(256, GROUP ? 1 : ((MULTI && !FAST) ? MHTE_SEGX_OCC : MHTE_SEGU_OCC)) void shard_apply_kernel(
     ShardOwnerArgs A) {
   const uint32_t p = blockIdx.y / A.tc, t = blockIdx.y % A.tc;
-  if (!MHTE_SHAPE_IS(VW, A.g[t]) || ((A.g[t] & kShapeGroupBit) != 0u) != GROUP) return;
-  const uint32_t n = shard_block_count(A, p, t);
-  if (n == 0) return;
+  if (!MHTE_SHAPE_IS(VW, A.g[t]) || ((A.g[t] & kShapeGroupBit) != 0u) != GROUP || (A.fast[t] != 0) != FAST) return;
   const TableView& tv = deref_const(A.views + (A.t0 + t));
-#define MHTE_SEGU_CALL(G_, V_) shard_apply_loop<G_, V_, GROUP, MULTI>(A, tv, p, t, n)
-  MHTE_SWITCH_G(VW, A.g[t] & ~kShapeGroupBit, MHTE_SEGU_CALL)
+  if constexpr (FAST) {
+    // (one segment — the usual row — reads its descriptor with scalar loads: seg_of)
+#define MHTE_SEGF_CALL(G_, V_)                                                      \
+  do {                                                                              \
+    if (tv.nseg == 1u) shard_apply_fast_loop<G_, V_, MULTI, true>(A, tv, p, t);     \
+    else shard_apply_fast_loop<G_, V_, MULTI, false>(A, tv, p, t);                  \
+  } while (0)
+    MHTE_SWITCH_G(VW, A.g[t] & ~kShapeGroupBit, MHTE_SEGF_CALL)
+#undef MHTE_SEGF_CALL
+  } else {
+#define MHTE_SEGU_CALL(G_, V_) shard_apply_loop<G_, V_, GROUP, MULTI>(A, tv, p, t)
+    MHTE_SWITCH_G(VW, A.g[t] & ~kShapeGroupBit, MHTE_SEGU_CALL)
 #undef MHTE_SEGU_CALL
+  }
 }
 
 // displacement pass behind shard_apply_kernel, one wavefront per table: every deferred id's entries in
-// rank order, as the fast path would have applied them; the last launch of a step, so it also clears
-// the headers of the step's send blocks (the next numbering into them counts from zero)
-__global__ __launch_bounds__(64) void shard_slow_all_kernel(ShardOwnerArgs A) {
-  __shared__ BfsSlot q[kMaxCuckooCount];
-  __shared__ CuckooRecord path[kMaxBfsPathLen];
-  const uint32_t t = blockIdx.x;
-  const int lane = threadIdx.x;
+// rank order, as the fast path would have applied them; then the headers of the step's send blocks are
+// cleared (the next numbering into them counts from zero).  Runs as the last launch of a step
+// (shard_slow_all_kernel) or — GATED — inside the NEXT owner lookup's launch, whose lookups of the table
+// wait for n_pending == 0 (slowpath_role's protocol: agent-scope release of the pass's stores, then the 0).
+template <bool GATED>
+__device__ __forceinline__ void shard_slow_all_role(const ShardOwnerArgs& A, uint32_t t, const int64_t* recv_ids,
+                                                    const float* rows, BfsSlot* q, CuckooRecord* path, int lane) {
   const TableView& tv = deref_const(A.views + (A.t0 + t));
   const uint32_t np = tv.ctr->n_pending;
   const ShardTab tb = A.tab[t];
@@ -448,7 +617,7 @@ __global__ __launch_bounds__(64) void shard_slow_all_kernel(ShardOwnerArgs A) {
   for (uint32_t i = 0; i < np; ++i) {
     const uint32_t g = A.pending[t][2 * i], p = A.pending[t][2 * i + 1];
     const size_t eb = size_t(p) * A.geo.ids_block + tb.id_off;
-    const int64_t id = A.recv_ids[eb + g];
+    const int64_t id = recv_ids[eb + g];
     uint32_t r;  // (only lane 0's value is read, after the search: not merged with a constant on purpose,
                  // slowpath_role)
     if (lane == 0) r = static_cast<uint32_t>(atomicAdd(&tv.ctr->alloc, (1ull << 32) | 1ull));
@@ -476,19 +645,28 @@ __global__ __launch_bounds__(64) void shard_slow_all_kernel(ShardOwnerArgs A) {
       const int k = __ffsll(static_cast<long long>(pm)) - 1;
       pm &= pm - 1ull;
       const uint32_t sq = multi ? sl[kXKeyWords + k] - 1u : g;
-      const float* values = A.rows + size_t(k) * A.geo.rows_block + tb.row_off;
+      const float* values = rows + size_t(k) * A.geo.rows_block + tb.row_off;
       if (pos >= 0) {
-        const bool grp = (A.g[t] & kShapeGroupBit) != 0u;   // (rare path: both forms in one kernel)
-        if (A.g[t] & 1u) {
-          if (grp) apply_row<64, 1, kOpOptimize, false, true>(tv, row_ptr(tv, r), fresh, lane, values, nullptr, 0u,
-                                                              1u, int64_t(sq), a);
-          else apply_row<64, 1, kOpOptimize, false, false>(tv, row_ptr(tv, r), fresh, lane, values, nullptr, 0u,
-                                                           1u, int64_t(sq), a);
+        if (GATED) {
+          // (inside the lookup launch only tables of SGD / Adagrad / FTRL rows: the BASIC update code keeps
+          // that launch's registers — with all twelve optimizers it went from 54 to 143 VGPRs)
+          if (A.g[t] & 1u) apply_row<64, 1, kOpOptimize, true, false>(tv, row_ptr(tv, r), fresh, lane, values, nullptr,
+                                                                      0u, 1u, int64_t(sq), a);
+          else apply_row<64, 4, kOpOptimize, true, false>(tv, row_ptr(tv, r), fresh, lane, values, nullptr, 0u, 1u,
+                                                          int64_t(sq), a);
         } else {
-          if (grp) apply_row<64, 4, kOpOptimize, false, true>(tv, row_ptr(tv, r), fresh, lane, values, nullptr, 0u,
-                                                              1u, int64_t(sq), a);
-          else apply_row<64, 4, kOpOptimize, false, false>(tv, row_ptr(tv, r), fresh, lane, values, nullptr, 0u,
-                                                           1u, int64_t(sq), a);
+          const bool grp = (A.g[t] & kShapeGroupBit) != 0u;   // (rare path: both forms in one kernel)
+          if (A.g[t] & 1u) {
+            if (grp) apply_row<64, 1, kOpOptimize, false, true>(tv, row_ptr(tv, r), fresh, lane, values, nullptr, 0u,
+                                                                1u, int64_t(sq), a);
+            else apply_row<64, 1, kOpOptimize, false, false>(tv, row_ptr(tv, r), fresh, lane, values, nullptr, 0u,
+                                                             1u, int64_t(sq), a);
+          } else {
+            if (grp) apply_row<64, 4, kOpOptimize, false, true>(tv, row_ptr(tv, r), fresh, lane, values, nullptr, 0u,
+                                                                1u, int64_t(sq), a);
+            else apply_row<64, 4, kOpOptimize, false, false>(tv, row_ptr(tv, r), fresh, lane, values, nullptr, 0u,
+                                                             1u, int64_t(sq), a);
+          }
         }
         fresh = false;
       }
@@ -503,9 +681,22 @@ __global__ __launch_bounds__(64) void shard_slow_all_kernel(ShardOwnerArgs A) {
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
-  if (lane == 0 && np) tv.ctr->n_pending = 0;
+  if (np) {
+    if (GATED) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (lane == 0) __hip_atomic_store(&tv.ctr->n_pending, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (lane == 0) {
+      tv.ctr->n_pending = 0;
+    }
+  }
   if (A.zero_headers && uint32_t(lane) < world)
     A.clear_ids[size_t(lane) * A.geo.ids_block + A.t0 + t] = 0;
+}
+
+__global__ __launch_bounds__(64) void shard_slow_all_kernel(ShardOwnerArgs A) {
+  __shared__ BfsSlot q[kMaxCuckooCount];
+  __shared__ CuckooRecord path[kMaxBfsPathLen];
+  shard_slow_all_role<false>(A, blockIdx.x, A.recv_ids, A.rows, q, path, threadIdx.x);
 }
 
 // ---- sender: rows -> occurrences, occurrence gradients -> row slots ---------------------------------

@@ -3,8 +3,10 @@ monolith/native_training/entry.py (reference :27-640) without protobuf: the same
 constructor arguments, lowered to the flat C structs of include/monolith_amd_hash_table.h instead of
 EmbeddingHashTableConfig protos (runtime/hash_table/embedding_hash_table.proto:23-95).
 
-What is present: the SGD / Adagrad / FTRL optimizers of the fused training step, the op-level ones
-(momentum, adadelta, rmsprop, adam, amsgrad, moving average, batch softmax, group-lasso adagrad), zeros / ones /
+What is present: every per-row optimizer of the reference — SGD / Adagrad / FTRL (the fused training step's
+BASIC kernel instances), momentum, adadelta, rmsprop, adam, amsgrad, moving average, batch softmax (its FULL
+instances) and the whole-segment group-lasso adagrad (op-level kernels, fused optimize, the sharded step's
+owner side) —, zeros / ones /
 constants initializers, cuckoo table config, per-feature-slot expire times and occurrence
 thresholds.  Asking for anything else raises (no silent downgrade)."""
 import dataclasses
@@ -95,7 +97,7 @@ class FtrlOptimizer(Optimizer):
 
 class MomentumOptimizer(Optimizer):
   """reference entry.py MomentumOptimizer; proto defaults lr 0.01, momentum 0.9, weight decay 0,
-  use_nesterov false (optimizer.proto:156-163).  Op-level kernels only."""
+  use_nesterov false (optimizer.proto:156-163).  Rides the fused training-step kernels too (their FULL instances)."""
   opt_type = _lib.OPT_MOMENTUM
 
   def __init__(self, learning_rate=None, weight_decay_factor=0.0, use_nesterov=False, momentum=None,
@@ -112,7 +114,7 @@ class MomentumOptimizer(Optimizer):
 
 class AdadeltaOptimizer(Optimizer):
   """proto defaults lr 0.01, averaging_ratio 0.9, epsilon 0.01, weight decay 0
-  (optimizer.proto:104-111).  Op-level kernels only."""
+  (optimizer.proto:104-111).  Rides the fused training-step kernels too (their FULL instances)."""
   opt_type = _lib.OPT_ADADELTA
 
   def __init__(self, learning_rate=None, weight_decay_factor=0.0, averaging_ratio=None, epsilon=None,
@@ -130,7 +132,7 @@ class AdadeltaOptimizer(Optimizer):
 class RmspropOptimizer(Optimizer):
   """proto defaults lr 0.01, weight decay 0, momentum 0.9 (optimizer.proto:186-191).  v1 steps
   with the CONFIG's learning rate (rmsprop_optimizer.cc:66); ``v2=True`` is RmspropV2
-  (:127-144), which uses the op's learning-rate input.  Op-level kernels only."""
+  (:127-144), which uses the op's learning-rate input.  Rides the fused training-step kernels too (their FULL instances)."""
 
   def __init__(self, learning_rate=None, weight_decay_factor=0.0, momentum=None, v2=False):
     self.opt_type = _lib.OPT_RMSPROPV2 if v2 else _lib.OPT_RMSPROP
@@ -145,7 +147,7 @@ class RmspropOptimizer(Optimizer):
 class AdamOptimizer(Optimizer):
   """proto defaults lr 0.01, beta1 0.9, beta2 0.99, weight decay 0, use_nesterov false,
   epsilon 0.01 (optimizer.proto:137-146); ``amsgrad=True`` is AmsgradOptimizer (same config
-  fields, :118-128).  Op-level kernels only."""
+  fields, :118-128).  Rides the fused training-step kernels too (their FULL instances)."""
 
   def __init__(self, learning_rate=None, beta1=None, beta2=None, weight_decay_factor=0.0,
                use_nesterov=False, epsilon=None, warmup_steps=0, amsgrad=False):
@@ -165,7 +167,7 @@ class AdamOptimizer(Optimizer):
 
 class MovingAverageOptimizer(Optimizer):
   """reference entry.py:247-256; proto default momentum 0.9 (optimizer.proto:169-172).  No state and
-  no learning rate: w <- momentum w + (1 - momentum) g.  Op-level kernels only."""
+  no learning rate: w <- momentum w + (1 - momentum) g.  Rides the fused training-step kernels too (their FULL instances)."""
   opt_type = _lib.OPT_MOVING_AVERAGE
   learning_rate = 0.0
 
@@ -179,7 +181,7 @@ class MovingAverageOptimizer(Optimizer):
 class BatchSoftmaxOptimizer(Optimizer):
   """reference entry.py:207-223; proto default learning_rate 0.1 (optimizer.proto:174-177).  A
   one-float segment holding the moving average of the steps between two occurrences of the id
-  (https://research.google/pubs/pub48840/); reads the ops' ``global_step``.  Op-level kernels only."""
+  (https://research.google/pubs/pub48840/); reads the ops' ``global_step``.  Rides the fused training-step kernels too (their FULL instances, DESIGN 4.10)."""
   opt_type = _lib.OPT_BATCH_SOFTMAX
 
   def __init__(self, learning_rate=None):
@@ -188,7 +190,9 @@ class BatchSoftmaxOptimizer(Optimizer):
 
 class AdaGradWithGroupLassoOptimizer(Optimizer):
   """reference entry.py:310-331 (GroupAdaGradOptimizerConfig, optimizer.proto:90-98: lr 0.01,
-  beta 0, initial_accumulator_value 0.1, l2 0, weight decay 0).  Op-level kernels only."""
+  beta 0, initial_accumulator_value 0.1, l2 0, weight decay 0).  The one whole-segment optimizer: the
+  op-level kernels, mhte_fused_optimize and the owner side of the id-sharded step apply it; the pipelined and
+  multi-table fused steps do not."""
   opt_type = _lib.OPT_GROUP_ADAGRAD
 
   def __init__(self, learning_rate=None, beta=None, initial_accumulator_value=None,
