@@ -203,6 +203,15 @@ struct ShardStep {
   hipEvent_t ev_in = nullptr, ev_aux = nullptr;
   bool aux_pending = false;             // work on `aux` the caller's stream has not waited for yet
   bool ids_exchanged[2] = {false, false};   // the slot's id blocks have been exchanged
+  // ---- direct peer stores (the default of the peer-store transport with the fp32 wire and no overlap
+  // stream; MHTE_SHARD_DIRECT=0: push / sync launches as in round 4): the owner lookup writes its rows,
+  // the sender's sums and numbering their gradients and ids, straight into the peers' windows, and the
+  // whole protocol waits in ONE one-wavefront launch per step phase (shard_sync2_kernel)
+  bool direct = false;
+  unsigned long long* d_peer_win = nullptr;   // [world] window addresses, on the device
+  uint32_t xa[kIpcChannels] = {};       // per channel: the exchange whose arrival was published AND awaited
+  uint32_t xc[kIpcChannels] = {};       // ... whose credit (my buffer is free for it) was published and awaited
+  int hdr_slot = -1;                    // id slot whose send headers go out with the next arrival
   uint32_t seq_sent[kIpcChannels] = {};               // exchanges pushed per channel
   uint32_t seq_waited[kIpcChannels][kMaxShards] = {}; // ... and waited for, per peer
   uint64_t timeout_ticks = 0;
@@ -227,6 +236,7 @@ struct ShardStep {
       if (slot_off[s]) (void)hipFree(slot_off[s]);
     }
     if (d_tab) (void)hipFree(d_tab);
+    if (d_peer_win) (void)hipFree(d_peer_win);
     if (h_rcnt) (void)hipHostFree(h_rcnt);
     if (ev_rcnt) (void)hipEventDestroy(ev_rcnt);
     if (orec) (void)hipFree(orec);
@@ -375,7 +385,7 @@ struct ShardStep {
   // (the wire format and the pipeline mode travel in the window handle: every rank is checked against
   // every other at connect — so they cannot change behind a connected window of a world > 1)
   void refuse_after_connect(bool changes, const char* what) const {
-    if (changes && ipc && ipc_connected && world > 1)
+    if (changes && ipc && ipc_connected && (world > 1 || direct))
       throw Error(MHTE_FAILED_PRECONDITION,
                   std::string("shard step: ") + what + " must be chosen before the window handles are exchanged "
                   "(ShardedMultiStep(grad_fp16= / overlap=), MHTE_SHARD_GRAD_FP16 / MHTE_SHARD_OVERLAP, or the "
@@ -496,7 +506,8 @@ struct ShardStep {
     uint32_t magic, rank, world, T, cap, ids_block, rows_block;
     int32_t pid;
     uint32_t grad_bits, overlap;  // the wire format and the pipeline mode: every rank the same
-    char pad[128 - 64 - 8 - 7 * 4 - 4 - 8];
+    uint32_t direct;              // ... and the form of the exchanges (direct stores / push launches)
+    char pad[128 - 64 - 8 - 7 * 4 - 4 - 8 - 4];
   };
   static_assert(sizeof(IpcBlob) == 128, "ipc handle blob");
   static constexpr uint32_t kIpcMagic = 0x6d687431u;
@@ -516,6 +527,7 @@ struct ShardStep {
     b.pid = int32_t(getpid());
     b.grad_bits = uint32_t(grad_bits);   // (set_grad_bits / set_overlap come BEFORE the handle is taken)
     b.overlap = uint32_t(overlap);
+    b.direct = want_direct() ? 1u : 0u;
     memcpy(out128, &b, sizeof(b));
   }
 
@@ -542,6 +554,10 @@ struct ShardStep {
                         std::to_string(b.grad_bits) + " bits / overlap " + std::to_string(b.overlap) +
                         ", this rank " + std::to_string(grad_bits) + " / " + std::to_string(overlap) +
                         " (mhte_shard_step_set_grad_bits / _set_overlap on every rank, before the handles are taken)");
+      if (b.direct != (want_direct() ? 1u : 0u))
+        throw Error(MHTE_INVALID_ARGUMENT, "shard step connect: rank " + std::to_string(p) + " runs the " +
+                                               (b.direct ? "direct-store" : "push-launch") + " form of the exchanges, this "
+                                               "rank the other (MHTE_SHARD_DIRECT must agree)");
       if (p == rank) continue;
       void* m = nullptr;
       hipError_t e = hipIpcOpenMemHandle(&m, b.h, hipIpcMemLazyEnablePeerAccess);
@@ -553,6 +569,17 @@ struct ShardStep {
       peer_win[p] = static_cast<char*>(m);
     }
     ipc_connected = true;
+    direct = want_direct();
+    if (direct) {
+      std::vector<unsigned long long> w(size_t(world), 0ull);
+      for (int p = 0; p < world; ++p) w[size_t(p)] = reinterpret_cast<unsigned long long>(peer_win[p]);
+      HIP_OK(hipMalloc(reinterpret_cast<void**>(&d_peer_win), sizeof(unsigned long long) * size_t(world)));
+      HIP_OK(hipMemcpy(d_peer_win, w.data(), sizeof(unsigned long long) * size_t(world), hipMemcpyHostToDevice));
+    }
+  }
+  bool want_direct() const {
+    static const bool off = getenv("MHTE_SHARD_DIRECT") && atoi(getenv("MHTE_SHARD_DIRECT")) == 0;
+    return ipc && !off && grad_bits == 32 && overlap == 0;
   }
 
   static uint32_t chan_of(int kind, int slot) {
@@ -617,10 +644,66 @@ struct ShardStep {
   }
   // at the end of an API call: nothing this rank owes its peers stays unpublished
   void flush_signals(hipStream_t st) {
+    if (direct) {
+      sync_point(0u, st);
+      return;
+    }
     if (ipc && sig_pending[st == aux && aux ? 1 : 0]) sync(uint32_t(kIpcChannels), 0, 0, st);
   }
 
+  // ---- direct mode: the one-wavefront sync point (shard_sync2_kernel).  Publishes the arrival of every
+  // exchange written since the last one (+ the headers of an id exchange) and the credits in `credit_mask`
+  // that are not out yet; waits for the same from every peer.
+  void sync_point(uint32_t credit_mask, hipStream_t st) {
+    ShardSync2Args A{};
+    for (int p = 0; p < world; ++p) A.win[p] = peer_win[p];
+    A.flags = d_flags;
+    A.timeout_ticks = timeout_ticks;
+    A.rank = uint32_t(rank);
+    A.world = uint32_t(world);
+    A.hdr_words = hdr_words;
+    A.ids_block = geo.ids_block;
+    for (uint32_t ch = 0; ch < uint32_t(kChTest); ++ch) {
+      if (xa[ch] != seq_sent[ch]) {
+        A.arr_chan[A.n_arr] = ch;
+        A.arr_seq[A.n_arr++] = seq_sent[ch];
+        xa[ch] = seq_sent[ch];
+        if (ch <= uint32_t(kChIds1) && hdr_slot == int(ch)) {   // (kChIds0 / kChIds1 = id slot 0 / 1)
+          A.hdr_src = ids_send[hdr_slot];
+          A.hdr_dst_off = win_off_ids[hdr_slot] + size_t(rank) * size_t(geo.ids_block) * 8;
+          hdr_slot = -1;
+        }
+      }
+      if (((credit_mask >> ch) & 1u) && xc[ch] != seq_sent[ch] + 1u) {
+        A.cred_chan[A.n_cred] = ch;
+        A.cred_seq[A.n_cred++] = seq_sent[ch] + 1u;
+        xc[ch] = seq_sent[ch] + 1u;
+      }
+    }
+    if (!A.n_arr && !A.n_cred) return;
+    LAUNCH_HOT(kTagShardWait, shard_sync2_kernel, 1, 64, st, A);
+    HIP_OK(hipGetLastError());
+    ++launches;
+  }
+  // before a launch that stores exchange seq_sent[ch] + 1 of the channels in `mask` into the peers' windows
+  void require_credits(uint32_t mask, hipStream_t st) {
+    uint32_t missing = 0;
+    for (uint32_t ch = 0; ch < uint32_t(kChTest); ++ch)
+      if (((mask >> ch) & 1u) && xc[ch] != seq_sent[ch] + 1u) missing |= 1u << ch;
+    if (missing) sync_point(missing, st);
+  }
+  // before a consumer of the channels' latest exchanges (more_credits: what is free to hand out at this point)
+  void require_arrived(uint32_t mask, uint32_t more_credits, hipStream_t st) {
+    for (uint32_t ch = 0; ch < uint32_t(kChTest); ++ch)
+      if (((mask >> ch) & 1u) && xa[ch] != seq_sent[ch]) {
+        sync_point(more_credits, st);
+        return;
+      }
+  }
+  static uint32_t chbit(int kind, int slot) { return 1u << chan_of(kind, slot); }
+
   void exchange_ipc(int kind, int slot, hipStream_t st) {
+    if (direct) return;   // (the producer launch stored into the peers' windows itself)
     const uint32_t ch = chan_of(kind, slot);
     if (kind == kXIds)
       push(ch, ids_send[slot], ids_send[slot], win_off_ids[slot], true, st);
@@ -633,8 +716,12 @@ struct ShardStep {
   }
 
   // before a consumer of what peers [lo, hi) sent on (kind, slot): hold the stream until it landed
-  void wait_arrived(int kind, int slot, int lo, int hi, hipStream_t st) {
+  void wait_arrived(int kind, int slot, int lo, int hi, hipStream_t st, uint32_t more_credits = 0u) {
     if (!ipc) return;
+    if (direct) {
+      require_arrived(chbit(kind, slot), more_credits, st);
+      return;
+    }
     const uint32_t ch = chan_of(kind, slot);
     int a = hi, b = lo;
     for (int p = lo; p < hi; ++p)
@@ -773,6 +860,12 @@ struct ShardStep {
     A.flags = d_flags;
     A.n_max = uint32_t(max_batch);
     gt_all.assign(T, ShardGatherTab{});
+    if (direct) {   // sums and ids go straight into the owners' windows
+      require_credits((sum_slot >= 0 ? chbit(kXGrads, sum_slot) : 0u) | (build_slot >= 0 ? chbit(kXIds, build_slot) : 0u), st);
+      A.peer_win = d_peer_win;
+      A.peer_grads_off = win_off_grads + size_t(rank) * size_t(geo.rows_block) * sizeof(float);
+      if (build_slot >= 0) A.peer_ids_off = win_off_ids[build_slot] + size_t(rank) * size_t(geo.ids_block) * sizeof(int64_t);
+    }
     if (sum_slot >= 0) {
       A.grads = grads;
       A.rows_out = snd_grads;
@@ -812,10 +905,19 @@ struct ShardStep {
       launches += (w4 ? 1u : 0u) + (w1 ? 1u : 0u);
       HIP_OK(hipGetLastError());
     }
+    if (direct) {   // (the exchanges these launches were: every rank counts them alike, whatever it sent)
+      if (sum_slot >= 0) ++seq_sent[kChGrads];
+      if (build_slot >= 0) {
+        ++seq_sent[chan_of(kXIds, build_slot)];
+        hdr_slot = build_slot;
+      }
+    }
   }
 
   void scatter(float* out, int slot, hipStream_t st) {
-    wait_arrived(kXRows, slot, 0, world, st);
+    // (direct mode: at this point the gradient buffer and the other slot's id buffer are free for the
+    // peers — their last consumers, the previous update and its displacement pass, are enqueued)
+    wait_arrived(kXRows, slot, 0, world, st, chbit(kXGrads, slot) | chbit(kXIds, slot ^ 1));
     ShardGatherArgs A{};
     A.st = ConstStatics(ms.d_st);
     A.in = snd_rows;
@@ -922,7 +1024,7 @@ struct ShardStep {
   bool fuse_scatter = true;     // MHTE_SHARD_FUSE_SCATTER=0: two launches (A/B)
   void scatter_dedup(float* out, int slot, const int64_t* ids_next, const int64_t* split_next, int slot_next,
                      hipStream_t st) {
-    wait_arrived(kXRows, slot, 0, world, st);
+    wait_arrived(kXRows, slot, 0, world, st, chbit(kXGrads, slot) | chbit(kXIds, slot ^ 1));
     if (ms.stage[slot_next] == 1) ms.clear_slots(1u << slot_next, st);
     for (uint32_t t = 0; t < T; ++t) ms.n_slot[slot_next][t] = uint32_t(split_next[t + 1] - split_next[t]);
     ms.has_hints[slot_next] = false;
@@ -1019,7 +1121,8 @@ struct ShardStep {
   }
 
   void owner_lookup(int slot, hipStream_t st) {
-    wait_arrived(kXIds, slot, 0, world, st);
+    wait_arrived(kXIds, slot, 0, world, st, chbit(kXRows, slot));
+    if (direct) require_credits(chbit(kXRows, slot), st);   // (the rows go straight into the peers' windows)
     const bool per_peer = per_peer_owner();
     if (xs && !per_peer) {
       if (x_dirty) clear_x(st);   // (a batch that was looked up and never trained left its ids registered)
@@ -1035,6 +1138,10 @@ struct ShardStep {
       ShardOwnerArgs A{};
       owner_args(A, slot, false, t0, tc);
       if (per_peer) A.x.xs = nullptr, A.x.oslot = nullptr;   // (no registration: nobody would consume it)
+      if (direct) {
+        A.peer_win = d_peer_win;
+        A.peer_rows_off = win_off_rows + size_t(rank) * size_t(geo.rows_block) * sizeof(float);
+      }
       if (fold) {   // the previous update's displacement pass: that update's arguments for these tables
         const ShardOwnerArgs& P = apply_chunks[t0 / uint32_t(kMaxStepTables)].A;
         A.slow_on = 1u;
@@ -1067,6 +1174,7 @@ struct ShardStep {
       set_hooks(false);
       if (slow_slot >= 0) hdr_dirty[slow_slot] = false;
     }
+    if (direct) ++seq_sent[kChRows];
     fetch_counts_lazily(slot, st);
   }
 
@@ -1078,6 +1186,9 @@ struct ShardStep {
       tb.pending.reserve(2 * size_t(cap) * size_t(world) + 2);
     }
     sync_views(mt, st);
+    // (direct mode: ONE sync point for the gradients and — a step ahead — the next batch's ids; the row
+    // buffer is free for the peers' next lookups: this step's scatter is enqueued)
+    if (direct) require_arrived(chbit(kXGrads, slot) | chbit(kXIds, slot) | chbit(kXIds, slot ^ 1), chbit(kXRows, slot), st);
     wait_arrived(kXIds, slot, 0, world, st);
     poll_counts();
     // one set of arguments per kMaxStepTables tables; the same for every peer but `peer` / `zero_headers`

@@ -102,6 +102,10 @@ struct ShardOwnerArgs {
   const float* slow_rows;
   uint32_t slow_on;
   uint32_t pad0;
+  // lookup with direct peer stores: the rows of peer p's ids go straight into p's window — peer_win[p] +
+  // peer_rows_off (this rank's block of the row buffer there) — instead of rows + p * rows_block
+  const unsigned long long* peer_win;   // [world] device array; nullptr: `rows`
+  unsigned long long peer_rows_off;
   // a launch serves tables [t0, t0 + tc) of the model (the host chunks: kernel-argument budget); the
   // arrays below are indexed by the table's position in the launch, `views`, the header words and
   // the per-table device arrays by its index in the model
@@ -269,7 +273,8 @@ __global__ __launch_bounds__(512) void shard_lookup_kernel(ShardOwnerArgs A) {
   const TableView& tv = deref_const(A.views + (A.t0 + t));
   const size_t eb = size_t(p) * A.geo.ids_block + tb.id_off;
   const int64_t* ids = A.recv_ids + eb;
-  float* out = A.rows + size_t(p) * A.geo.rows_block + tb.row_off;
+  float* out = (A.peer_win ? reinterpret_cast<float*>(A.peer_win[p] + A.peer_rows_off)
+                           : A.rows + size_t(p) * A.geo.rows_block) + tb.row_off;
   const int ch = A.count_hits[t];
   uint32_t* xs = A.x.xs ? A.x.xs + size_t(A.t0 + t) * (size_t(A.x.xmask) + 2u) * A.x.xstride : nullptr;
   uint32_t* oslot = A.x.oslot ? A.x.oslot + eb : nullptr;
@@ -731,6 +736,9 @@ __device__ __forceinline__ void shard_gather_ctl(GatherCtl& c, const MStepStatic
   c.nblk_items = gt.nblk_items;
   c.nblk_ids = gt.nblk_ids;
   c.index_is_offset = 1;
+  c.peer_win = nullptr;
+  c.peer_out_off = 0;
+  c.rows_block = 1;
 }
 
 template <bool SCATTER, int VW>
@@ -950,6 +958,10 @@ struct ShardBuildArgs {
   uint32_t slot;
   uint32_t n_max;
   uint32_t t0;                    // tables [t0, t0 + gridDim.y) of the model; tab / n_build / gt by position
+  // direct peer stores (nullptr: send_ids / rows_out): ids into the owners' id buffers, sums into their
+  // gradient buffers
+  const unsigned long long* peer_win;   // [world] device array
+  unsigned long long peer_ids_off, peer_grads_off;
   ShardTab tab[kMaxStepTables];
   uint32_t n_build[kMaxStepTables];
   ShardGatherTab gt[kMaxStepTables];
@@ -971,6 +983,8 @@ __global__ __launch_bounds__(256) void shard_build_kernel(ShardBuildArgs A) {
     const ShardTab tb = A.tab[tl];
     PackCtl pc;
     pc.send_ids = A.send_ids;
+    pc.peer_win = A.peer_win;
+    pc.peer_ids_off = A.peer_ids_off;
     pc.slot_off = A.slot_off_build + size_t(t) * A.n_max;
     pc.flags = A.flags;
     pc.world = A.geo.world;
@@ -994,6 +1008,9 @@ __global__ __launch_bounds__(256) void shard_build_kernel(ShardBuildArgs A) {
   c.in = A.grads + size_t(gt.io_off);
   c.out = A.rows_out;
   shard_gather_ctl(c, s, cur, A.slot_off, A.n_max, t, A.tab[tl].dim, gt);
+  c.peer_win = A.peer_win;
+  c.peer_out_off = A.peer_grads_off;
+  c.rows_block = A.geo.rows_block;
   shard_gather_switch<false, VW>(gt.gv, d, c, bid, raw);
 }
 
@@ -1214,6 +1231,53 @@ struct ShardSyncArgs {
   uint32_t wait_chan;         // kIpcChannels: nothing to wait for
   uint32_t wait_seq, lo, hi;
 };
+
+// ---- direct peer stores: the data kernels write straight into the peers' windows (no push kernels);
+// every wait of the protocol sits in ONE one-wavefront launch per step phase.  At a sync point a rank
+//   * copies the headers (per-table counts) of an id exchange it has just written to the peers' id buffers,
+//   * publishes `arrived` for every exchange its earlier launches wrote (their stores are complete: the
+//     kernels have ended), and `credit` for every buffer of its own whose consumers are enqueued,
+//   * waits for the same set from every peer.
+// Every rank runs the same program, so what a rank waits for at a point is what its peers publish at
+// that same point — they publish before they wait: no cycle.  Spins are bounded (ipc_spin).
+struct ShardSync2Args {
+  char* win[kMaxShards];
+  uint32_t* flags;
+  uint64_t timeout_ticks;
+  uint32_t rank, world;
+  uint32_t n_arr, n_cred;
+  uint32_t arr_chan[kIpcChannels], arr_seq[kIpcChannels];
+  uint32_t cred_chan[kIpcChannels], cred_seq[kIpcChannels];
+  const int64_t* hdr_src;     // send blocks whose headers go out (nullptr: none): [world][ids_block]
+  uint64_t hdr_dst_off;       // byte offset of this rank's block of that id buffer inside a window
+  uint32_t hdr_words;         // words of a header (T rounded up)
+  uint32_t ids_block;
+};
+__global__ __launch_bounds__(64) void shard_sync2_kernel(ShardSync2Args A) {
+  const uint32_t lane = threadIdx.x;
+  if (A.hdr_src) {
+    for (uint32_t i = lane; i < A.world * A.hdr_words; i += 64u) {
+      const uint32_t p = i / A.hdr_words, w = i % A.hdr_words;
+      const int64_t v = A.hdr_src[size_t(p) * A.ids_block + w];
+      __builtin_nontemporal_store(v, reinterpret_cast<int64_t*>(A.win[p] + A.hdr_dst_off) + w);
+    }
+    __threadfence_system();
+  }
+  for (uint32_t k = 0; k < A.n_arr; ++k)
+    for (uint32_t p = lane; p < A.world; p += 64u) st_sys(ipc_arrived(A.win[p], A.arr_chan[k], A.rank), A.arr_seq[k]);
+  for (uint32_t k = 0; k < A.n_cred; ++k)
+    for (uint32_t p = lane; p < A.world; p += 64u) st_sys(ipc_credit(A.win[p], A.cred_chan[k], A.rank), A.cred_seq[k]);
+  char* mine = A.win[A.rank];
+  bool ok = true;
+  for (uint32_t k = 0; k < A.n_arr; ++k)
+    for (uint32_t p = lane; p < A.world; p += 64u)
+      ok = ipc_spin(ipc_arrived(mine, A.arr_chan[k], p), A.arr_seq[k], A.timeout_ticks) && ok;
+  for (uint32_t k = 0; k < A.n_cred; ++k)
+    for (uint32_t p = lane; p < A.world; p += 64u)
+      ok = ipc_spin(ipc_credit(mine, A.cred_chan[k], p), A.cred_seq[k], A.timeout_ticks) && ok;
+  if (!ok) atomicOr(A.flags, uint32_t(kShardPeerTimeout));
+  __threadfence_system();
+}
 
 __global__ __launch_bounds__(64) void shard_sync_kernel(ShardSyncArgs A) {
   for (uint32_t k = 0; k < A.n_sig; ++k)

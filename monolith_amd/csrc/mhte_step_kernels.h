@@ -610,6 +610,10 @@ __device__ __forceinline__ uint32_t shard_of_id(int64_t id, uint32_t nshards) {
 }
 struct PackCtl {
   int64_t* send_ids;     // [world][ids_block]
+  // direct peer stores (mhte_shard_host.h): the id goes straight into its owner's window — peer_win[owner]
+  // + peer_ids_off (this rank's block of the slot's id buffer there); the counts stay in send_ids' headers
+  const unsigned long long* peer_win;   // [world] device array of window addresses; nullptr: send_ids
+  unsigned long long peer_ids_off;
   uint32_t* slot_off;    // [n_max] of this table: float offset of unique index u's row slot
   uint32_t* flags;
   uint32_t world, ids_block, rows_block;
@@ -773,7 +777,10 @@ __device__ __forceinline__ void rd_build_role(const RunView& d, uint32_t light_m
         if (PACK) {
           const uint32_t sl = sh_pb[pown[q]] + prank[q];
           if (sl < pc->cap) {
-            pc->send_ids[size_t(pown[q]) * pc->ids_block + pc->id_off + sl] = key[q];
+            if (pc->peer_win)
+              reinterpret_cast<int64_t*>(pc->peer_win[pown[q]] + pc->peer_ids_off)[pc->id_off + sl] = key[q];
+            else
+              pc->send_ids[size_t(pown[q]) * pc->ids_block + pc->id_off + sl] = key[q];
             pc->slot_off[kq[q]] = pown[q] * pc->rows_block + pc->row_off + sl * pc->dim;
           } else {   // no room in the owner's block: zero row back, gradient dropped, flagged
             pc->slot_off[kq[q]] = 0xffffffffu;
@@ -1986,6 +1993,11 @@ struct GatherCtl {
   uint32_t nblk_ids;
   uint32_t index_is_offset;  // index[u] is a float offset into the rows (0xffffffff: no row — the
                              // id found no room in its peer block) instead of a row number
+  // SUM with direct peer stores: offset ix = owner * rows_block + r goes to peer_win[owner] + peer_out_off
+  // (this rank's block of the owner's gradient buffer) + r floats instead of out + ix
+  const unsigned long long* peer_win;   // nullptr: out
+  unsigned long long peer_out_off;
+  uint32_t rows_block;
 };
 
 // LDS of the gather role, for NG = 256 / G lane groups; the caller declares it
@@ -2000,6 +2012,14 @@ struct GatherLds {
 
 __device__ __forceinline__ int64_t gather_row_off(const GatherCtl& c, uint32_t ix) {
   return c.index_is_offset ? int64_t(ix) : int64_t(ix) * c.dim;
+}
+// where the sum of the row with offset / index ix is stored
+__device__ __forceinline__ float* gather_out_ptr(const GatherCtl& c, uint32_t ix) {
+  if (c.peer_win) {
+    const uint32_t owner = ix / c.rows_block;
+    return reinterpret_cast<float*>(c.peer_win[owner] + c.peer_out_off) + (ix - owner * c.rows_block);
+  }
+  return c.out + gather_row_off(c, ix);
 }
 
 template <int G, int VEC, bool SCATTER>
@@ -2085,7 +2105,7 @@ __device__ __forceinline__ void rd_gather_role(const RunView& d, const GatherCtl
           if (cnt > 1) sum_list_lds<VEC>(c.in, dim, e, ev, sh_pos[grp], cnt, acc);
           lds_wave_sync();
         }
-        if (valid && ev) acc.store(c.out + gather_row_off(c, ix) + e);
+        if (valid && ev) acc.store(gather_out_ptr(c, ix) + e);
       }
     }
     return;
@@ -2218,7 +2238,7 @@ __device__ __forceinline__ void rd_gather_role(const RunView& d, const GatherCtl
           }
         }
       }
-      if (fin && threadIdx.x < G && ev && ix != 0xffffffffu) tot.store(c.out + gather_row_off(c, ix) + e);
+      if (fin && threadIdx.x < G && ev && ix != 0xffffffffu) tot.store(gather_out_ptr(c, ix) + e);
     }
     lds_barrier();
   }
