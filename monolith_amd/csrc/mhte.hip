@@ -1195,9 +1195,28 @@ struct Table {
     v.trace = trace_region(kTagStepBwd, grid.x, 256);
     const RunView cur = ws.rv;
     const bool basic = basic_opts();
+    // one-segment tables of Momentum / Adadelta / RMSProp / Adam / AMSGrad rows with float4 lanes: the
+    // instance compiled for that optimizer alone (step_bwd_kernel<.., OPTK>: 61 -> 7-17 spilled registers for
+    // Adam, and the row fetched ahead as the SGD / Adagrad / FTRL instances do)
+    static const bool no_optk = getenv("MHTE_NO_OPTK") != nullptr;   // (A/B: the one FULL instance for all)
+    const int optk = (!basic && nseg == 1 && sh.VEC == 4 && !view.seg[0].sr16 && !no_optk) ? int(view.seg[0].opt) : -1;
+#define CALL_OPTK(G_, K_)                                                                                     \
+  LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, 4, true, true, K_>), grid, 256, st, nxt, nblk_build, v, cur, c, a, po, da)
 #define CALL(G_, V_) \
   do {                                                                                               \
-    if (!basic && nseg == 1) {                                                                       \
+    if (V_ == 4 && optk == kOptMomentum) {                                                           \
+      CALL_OPTK(G_, kOptMomentum);                                                                   \
+    } else if (V_ == 4 && optk == kOptAdadelta) {                                                    \
+      CALL_OPTK(G_, kOptAdadelta);                                                                   \
+    } else if (V_ == 4 && optk == kOptRmsprop) {                                                     \
+      CALL_OPTK(G_, kOptRmsprop);                                                                    \
+    } else if (V_ == 4 && optk == kOptRmspropV2) {                                                   \
+      CALL_OPTK(G_, kOptRmspropV2);                                                                  \
+    } else if (V_ == 4 && optk == kOptAdam) {                                                        \
+      CALL_OPTK(G_, kOptAdam);                                                                       \
+    } else if (V_ == 4 && optk == kOptAmsgrad) {                                                     \
+      CALL_OPTK(G_, kOptAmsgrad);                                                                    \
+    } else if (!basic && nseg == 1) {                                                                \
       LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, true, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a, po, da); \
     } else if (!basic) {                                                                             \
       LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, false, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a, po, da); \
@@ -1209,6 +1228,7 @@ struct Table {
   } while (0)
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
+#undef CALL_OPTK
     hipError_t le = hipGetLastError();
     ws.r_stage = 0;  // the apply leaves the scratch all-empty
     if (nblk_build) {

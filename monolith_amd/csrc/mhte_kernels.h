@@ -2758,12 +2758,42 @@ __device__ __forceinline__ void optimize_row_reg(const TableView& tv, float* rp,
 // the fused step kernels' FULL instantiations.  Kept apart from optimize_row_reg so that the kernels
 // of SGD / Adagrad / FTRL tables keep their register budget (the twelve-way switch costs ~20 VGPRs).
 // Arithmetic: the one source of apply_row (optimizer steps of mhte_core.h), one Optimize() call.
-template <int VEC, bool ONESEG = false>
+// the row of a one-segment table whose optimizer is a compile-time fact (OPTK): weights, its state vectors
+// and (adam / amsgrad) the two running powers, fetched while the gradient chain is in flight
+template <int VEC>
+struct RowRegsF {
+  Vec<VEC> w, s1, s2, s3;
+  float c1, c2;
+};
+template <int VEC, int OPTK>
+__device__ __forceinline__ void row_prefetch_full(const TableView& tv, const float* rp, uint32_t e,
+                                                  RowRegsF<VEC>& r) {
+  if (e >= tv.dim) return;
+  const int nv = opt_vectors(OPTK);
+  const uint32_t st = uint32_t(tv.seg[0].st_off), sdim = uint32_t(tv.seg[0].dim);
+  r.w.load(rp + e);
+  if (nv > 0) r.s1.load(rp + st + e);
+  if (nv > 1) r.s2.load(rp + st + sdim + e);
+  if (nv > 2) r.s3.load(rp + st + 2u * sdim + e);
+  if (opt_scalars(OPTK) != 0) {
+    const float* sc = rp + st + uint32_t(nv) * sdim;
+    r.c1 = *(const MHTE_GLOBAL float*)(sc);
+    r.c2 = *(const MHTE_GLOBAL float*)(sc + 1);
+  }
+}
+
+// OPTK >= 0: the (one-segment) table's optimizer is a compile-time fact of the caller's instance — only its
+// update rule, state vectors and hyper-parameters are compiled in (the eleven-way switch with everything
+// every rule needs live around it is what spills 54-114 registers in the step kernels' FULL instances).
+// pre: the row as row_prefetch_full fetched it (used unless is_new)
+template <int VEC, bool ONESEG = false, int OPTK = -1>
 __device__ __forceinline__ void optimize_row_reg_full(const TableView& tv, float* rp, bool is_new,
-                                                      uint32_t e, const Vec<VEC>& g, const ApplyArgs& a) {
+                                                      uint32_t e, const Vec<VEC>& g, const ApplyArgs& a,
+                                                      const RowRegsF<VEC>* pre = nullptr) {
   if (e >= tv.dim) return;
   uint32_t k = 0;
-  const SegDesc sd = seg_of<ONESEG>(tv, e, k);
+  SegDesc sd = seg_of<ONESEG>(tv, e, k);
+  if (OPTK >= 0) sd.opt = OPTK;
   const uint32_t le = e - sd.w_off;
   const float lr = a.lr[k];
   const int nv = opt_vectors(sd.opt);
@@ -2791,6 +2821,15 @@ __device__ __forceinline__ void optimize_row_reg_full(const TableView& tv, float
     }
     c1 = si.p[0];
     c2 = si.p[1];
+  } else if (pre) {
+    w = pre->w;
+    if (nv > 0) s1 = pre->s1;
+    if (nv > 1) s2 = pre->s2;
+    if (nv > 2) s3 = pre->s3;
+    if (scal) {
+      c1 = pre->c1;
+      c2 = pre->c2;
+    }
   } else {
     w.load(rp + e);
     if (nv > 0) s1.load(st1);

@@ -997,7 +997,10 @@ struct ShardStep {
   }
   // the pass may ride in a lookup launch when every table's rows take the BASIC update code there
   bool can_fold() const {
-    if (!fold_slow) return false;
+    // (a launch of its own is ~6 us beside one table's ~50 us step and ~15 us — a wavefront per table, each
+    // with its round trips — beside 26 tables' 450: measured 452 us folded against 465)
+    static const uint32_t max_t = getenv("MHTE_SHARD_FOLD_MAX_TABLES") ? uint32_t(atoi(getenv("MHTE_SHARD_FOLD_MAX_TABLES"))) : (1u << 30);
+    if (!fold_slow || T > max_t) return false;
     for (uint32_t t = 0; t < T; ++t)
       if (!mt->tables[t]->basic_opts() || mt->tables[t]->has_group_opt) return false;
     return true;
@@ -1154,9 +1157,13 @@ struct ShardStep {
           A.a[i] = P.a[i];
         }
       }
+      // ids per lane group in flight: 2 for a launch of a few (peer, table) blocks — its chain's length is
+      // what counts —, 4 for a model's: half the workgroups to dispatch for the same rows
+      static const int unr_env = getenv("MHTE_SHARD_LOOKUP_UNR") ? atoi(getenv("MHTE_SHARD_LOOKUP_UNR")) : 0;
+      const uint32_t unr = unr_env ? uint32_t(unr_env == 4 ? 4 : 2) : (uint32_t(world) * tc > 8u ? 4u : 2u);
       uint32_t gx = 1;
       for (uint32_t i = 0; i < tc; ++i)
-        gx = std::max(gx, uint32_t((uint64_t((sized_n(t0 + i) + 1) / 2) * shape_lanes(A.g[i]) + 511) / 512));
+        gx = std::max(gx, uint32_t((uint64_t((sized_n(t0 + i) + unr - 1) / unr) * shape_lanes(A.g[i]) + 511) / 512));
       // (grid-stride inside: enough workgroups to fill the chip a few times over, not one per slot)
       const uint32_t fill = std::max<uint32_t>(8, uint32_t(ms.num_cus) * 16 / (uint32_t(world) * tc));
       gx = std::min(gx, fill);
@@ -1164,8 +1171,16 @@ struct ShardStep {
       for (uint32_t i = 0; i < tc; ++i) ((A.g[i] & 1u) ? w1 : w4) = true;
       if (fold) gx = std::max(gx, tc);
       const dim3 grid(gx, uint32_t(world) * tc + (fold ? 1u : 0u));
-      if (w4) LAUNCH_HOT(kTagShardLookup, shard_lookup_kernel<4>, grid, 512, st, A);
-      if (w1) LAUNCH_HOT(kTagShardLookup, shard_lookup_kernel<1>, grid, 512, st, A);
+#define MHTE_LOOKUP_LAUNCH(W_)                                                                                   \
+  do {                                                                                                           \
+    if (fold && unr == 4) LAUNCH_HOT(kTagShardLookup, (shard_lookup_kernel<W_, true, 4>), grid, 512, st, A);     \
+    else if (fold) LAUNCH_HOT(kTagShardLookup, (shard_lookup_kernel<W_, true, 2>), grid, 512, st, A);            \
+    else if (unr == 4) LAUNCH_HOT(kTagShardLookup, (shard_lookup_kernel<W_, false, 4>), grid, 512, st, A);       \
+    else LAUNCH_HOT(kTagShardLookup, (shard_lookup_kernel<W_, false, 2>), grid, 512, st, A);                     \
+  } while (0)
+      if (w4) MHTE_LOOKUP_LAUNCH(4);
+      if (w1) MHTE_LOOKUP_LAUNCH(1);
+#undef MHTE_LOOKUP_LAUNCH
       launches += (w4 ? 1u : 0u) + (w1 ? 1u : 0u);
       HIP_OK(hipGetLastError());
     }

@@ -139,14 +139,13 @@ __device__ __forceinline__ void shard_slow_all_role(const ShardOwnerArgs& A, uin
 // (lookup_role_u), + what the update will want to know (OwnRec) + (xs != nullptr: world > 1) the
 // registration of the id in the cross-peer scratch.  The registration's claim is issued behind the row
 // loads, so the rows leave while it is in flight.
-template <int G, int VEC>
+template <int G, int VEC, int UNR>
 __device__ __forceinline__ void shard_lookup_loop(const ShardOwnerArgs& A, uint32_t p, uint32_t t,
                                                   const TableView& tv, const int64_t* __restrict__ ids, uint32_t cap,
                                                   float* __restrict__ out, int count_hits,
                                                   OwnRec* __restrict__ orec, uint32_t* __restrict__ oslot,
                                                   uint32_t* __restrict__ xs, uint32_t xmask, uint32_t xstride,
                                                   uint32_t /*p again*/) {
-  constexpr int UNR = 2;
   const int lane = threadIdx.x & 63;
   const int j = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
@@ -156,7 +155,7 @@ __device__ __forceinline__ void shard_lookup_loop(const ShardOwnerArgs& A, uint3
   bool have_n = false;
   uint64_t hits = 0;
 #pragma unroll 1
-  for (uint32_t grp = (blockIdx.x * 512u + threadIdx.x) / G; grp < (n + 1u) / 2u; grp += gridDim.x * 512u / G) {
+  for (uint32_t grp = (blockIdx.x * 512u + threadIdx.x) / G; grp < (n + UNR - 1u) / UNR; grp += gridDim.x * 512u / G) {
     const uint32_t g0 = grp * UNR;
     int64_t myid = (j < UNR && g0 + uint32_t(j) < cap) ? ids[g0 + j] : 0;
     if (!have_n) {
@@ -256,17 +255,21 @@ __device__ __forceinline__ void shard_lookup_loop(const ShardOwnerArgs& A, uint3
 // grid (x, world * tc + slow_on): y = peer * tc + table of the launch (+ 1 with slow_on: row 0 — dispatched
 // first — is the displacement pass of the previous owner update, one wavefront per table; A.g / A.a /
 // A.pending describe that update's tables, which are this launch's)
-template <int VW>
+// SLOW: the instance that can carry the owed pass (its update code costs the lookups registers: 74 VGPRs
+// against 52 — the host folds the pass in only where a launch of its own would show, a model of a few tables)
+// UNR: ids per lane group in flight (2: one table's launch, where the chain's length is what counts; 4: a
+// model's — half the workgroups to dispatch for the same rows)
+template <int VW, bool SLOW = false, int UNR = 2>
 __global__ __launch_bounds__(512) void shard_lookup_kernel(ShardOwnerArgs A) {
-  __shared__ BfsSlot sq[kMaxCuckooCount];
-  __shared__ CuckooRecord spath[kMaxBfsPathLen];
-  if (A.slow_on && blockIdx.y == 0) {
+  __shared__ BfsSlot sq[SLOW ? kMaxCuckooCount : 1];
+  __shared__ CuckooRecord spath[SLOW ? kMaxBfsPathLen : 1];
+  if (SLOW && A.slow_on && blockIdx.y == 0) {
     // (the float4 instance runs the pass for every table: the role picks the lane width per table)
     if (VW == 4 && blockIdx.x < A.tc && threadIdx.x < 64)
       shard_slow_all_role<true>(A, blockIdx.x, A.slow_ids, A.slow_rows, sq, spath, int(threadIdx.x));
     return;
   }
-  const uint32_t y = blockIdx.y - (A.slow_on ? 1u : 0u);
+  const uint32_t y = blockIdx.y - ((SLOW && A.slow_on) ? 1u : 0u);
   const uint32_t p = y / A.tc, t = y % A.tc;
   if (!MHTE_SHAPE_IS(VW, A.g[t])) return;
   const ShardTab tb = A.tab[t];
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(512) void shard_lookup_kernel(ShardOwnerArgs A) {
   uint32_t* xs = A.x.xs ? A.x.xs + size_t(A.t0 + t) * (size_t(A.x.xmask) + 2u) * A.x.xstride : nullptr;
   uint32_t* oslot = A.x.oslot ? A.x.oslot + eb : nullptr;
 #define MHTE_SEGL_CALL(G_, V_) \
-  shard_lookup_loop<G_, V_>(A, p, t, tv, ids, tb.cap, out, ch, A.x.orec + eb, oslot, xs, A.x.xmask, A.x.xstride, p)
+  shard_lookup_loop<G_, V_, UNR>(A, p, t, tv, ids, tb.cap, out, ch, A.x.orec + eb, oslot, xs, A.x.xmask, A.x.xstride, p)
   MHTE_SWITCH_G(VW, A.g[t] & ~kShapeGroupBit, MHTE_SEGL_CALL)
 #undef MHTE_SEGL_CALL
 }

@@ -1347,7 +1347,7 @@ struct ApplyLds {
 // FULL: the table uses per-element optimizers beyond SGD / Adagrad / FTRL (optimize_row_reg_full; no
 // row prefetch: the state layout is the optimizer's); the host picks the instantiation.
 // (HINT: kept for the call sites' sake — every launch takes hints when ApplyCtl carries them)
-template <int G, int VEC, bool ONESEG, bool HINT = false, bool FULL = false>
+template <int G, int VEC, bool ONESEG, bool HINT = false, bool FULL = false, int OPTK = -1>
 __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView& d,
                                               const ApplyCtl& c, const ApplyArgs& a, uint32_t bid,
                                               WaveTrace& wt, ApplyLds& L) {
@@ -1453,6 +1453,21 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       RowRegs<VEC> rr;
       vec_zero(rr.w);
       vec_zero(rr.s1);
+      // (FULL with the optimizer known at compile time, OPTK: its row is fetched ahead too — the FULL form
+      // otherwise pays a dependent round trip for the row behind everything else)
+#ifdef MHTE_NO_FULL_PREFETCH
+      constexpr bool PF = false;
+#else
+      constexpr bool PF = FULL && OPTK >= 0 && OPTK != kOptAmsgrad;   // (AMSGrad's three state vectors: 49 spilled)
+#endif
+      RowRegsF<VEC> rf;
+      if constexpr (PF) {
+        vec_zero(rf.w);
+        vec_zero(rf.s1);
+        vec_zero(rf.s2);
+        vec_zero(rf.s3);
+        rf.c1 = rf.c2 = 0.f;
+      }
       // the row of a hinted id.  Rows of the first slab — all of them in a table created with
       // reserve_rows — are addressed without reading the slab table: row_ptr's load of the slab
       // pointer sits under a branch, and the wait where that branch ends would hold the row loads
@@ -1460,8 +1475,15 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       const bool slab0 = (hrow >> tv.chunk_shift) == 0u;
       if (hinted && slab0 && !FULL)
         row_prefetch<VEC, ONESEG>(tv, assume_global(tv.chunk0 + size_t(hrow) * tv.row_floats), e, rr);
+      if constexpr (PF) {
+        if (hinted && slab0)
+          row_prefetch_full<VEC, OPTK>(tv, assume_global(tv.chunk0 + size_t(hrow) * tv.row_floats), e, rf);
+      }
       if (__any(hinted && !slab0)) {
         if (hinted && !slab0 && !FULL) row_prefetch<VEC, ONESEG>(tv, row_ptr(tv, hrow), e, rr);
+        if constexpr (PF) {
+          if (hinted && !slab0) row_prefetch_full<VEC, OPTK>(tv, row_ptr(tv, hrow), e, rf);
+        }
       }
       if (it == 0) wt.mark(0);
       const bool single = valid && cnt == 1;
@@ -1515,6 +1537,9 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       if (__any(pre)) {
         const uint32_t frow = __shfl(pr.row, gbase + (uf.owner < 0 ? 0 : uf.owner));
         if (pre && !FULL) row_prefetch<VEC, ONESEG>(tv, row_ptr(tv, frow), e, rr);
+        if constexpr (PF) {
+          if (pre) row_prefetch_full<VEC, OPTK>(tv, row_ptr(tv, frow), e, rf);
+        }
       }
       if (__any(flat)) {
         uint32_t xr[PER];
@@ -1607,13 +1632,17 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       if (valid && !sr.deferred) {
         rp = row_ptr(tv, sr.r);
         if (!FULL && !sr.is_new && !pre && !hinted) row_prefetch<VEC, ONESEG>(tv, rp, e, rr);  // (the side slot's row)
+        if constexpr (PF) {
+          if (!sr.is_new && !pre && !hinted) row_prefetch_full<VEC, OPTK>(tv, rp, e, rf);
+        }
       }
       if (it == 0) wt.mark(3);
       if (sr.deferred) {
         if (ev) acc.store(c.grad_u + g * int64_t(dim) + e);
         if (j == 0) defer_id(tv, c.pending, uint32_t(g));
       } else if (valid) {
-        if (FULL) optimize_row_reg_full<VEC, ONESEG>(tv, rp, sr.is_new, e, acc, a);
+        if constexpr (PF) optimize_row_reg_full<VEC, ONESEG, OPTK>(tv, rp, sr.is_new, e, acc, a, &rf);
+        else if (FULL) optimize_row_reg_full<VEC, ONESEG, OPTK>(tv, rp, sr.is_new, e, acc, a);
         else optimize_row_pre<VEC, ONESEG>(tv, rp, sr.is_new, e, acc, a, rr);
       }
       if (it == 0) wt.mark(4);
@@ -1813,7 +1842,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
         if (ev) tot.store(c.grad_u + int64_t(hd.u) * dim + ed);
         if (j == 0) defer_id(tv, c.pending, hd.u);
       } else if (valid) {
-        if (FULL) optimize_row_reg_full<VEC, ONESEG>(tv, row_ptr(tv, sr.r), sr.is_new, e, tot, a);
+        if (FULL) optimize_row_reg_full<VEC, ONESEG, OPTK>(tv, row_ptr(tv, sr.r), sr.is_new, e, tot, a);
         else optimize_row_reg<VEC, ONESEG>(tv, row_ptr(tv, sr.r), sr.is_new, e, tot, a);
       }
     }
@@ -1930,7 +1959,7 @@ union __attribute__((aligned(16))) StepBwdLds {
   ApplyLds apply;
   RdLds4 dedup;
 };
-template <int G, int VEC, bool ONESEG, bool FULL = false>
+template <int G, int VEC, bool ONESEG, bool FULL = false, int OPTK = -1>
 __global__ __launch_bounds__(256, kBwdBlocksPerCu) void step_bwd_kernel(RunView nxt, uint32_t nblk_build,
                                                        TableView tv, RunView cur, ApplyCtl c,
                                                        ApplyArgs a, ProbeOut po, DedupArgs da) {
@@ -1963,7 +1992,7 @@ __global__ __launch_bounds__(256, kBwdBlocksPerCu) void step_bwd_kernel(RunView 
     return;
   }
   bid -= nblk_build;
-  rd_apply_role<G, VEC, ONESEG, false, FULL>(tv, cur, c, a, bid, wt, L.apply);
+  rd_apply_role<G, VEC, ONESEG, false, FULL, OPTK>(tv, cur, c, a, bid, wt, L.apply);
   wt.end(bid < c.nblk_items ? 7u : 8u);
 }
 
