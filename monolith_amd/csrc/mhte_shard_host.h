@@ -860,6 +860,9 @@ struct ShardStep {
     A.flags = d_flags;
     A.n_max = uint32_t(max_batch);
     gt_all.assign(T, ShardGatherTab{});
+    // (an owed displacement pass reads the id and gradient blocks of its update and clears send headers: it
+    // runs before this rank tells its peers that those buffers are free, and before this numbering)
+    if (build_slot >= 0) flush_slow(st);
     if (direct) {   // sums and ids go straight into the owners' windows
       require_credits((sum_slot >= 0 ? chbit(kXGrads, sum_slot) : 0u) | (build_slot >= 0 ? chbit(kXIds, build_slot) : 0u), st);
       A.peer_win = d_peer_win;
@@ -996,7 +999,10 @@ struct ShardStep {
     if (slow_slot >= 0) hdr_dirty[slow_slot] = false;
   }
   // the pass may ride in a lookup launch when every table's rows take the BASIC update code there
+  // ... and with ONE rank only: with more, the pass needs the cross-peer slots of its deferred ids (oslot /
+  // xs), which the lookup of the same launch is already rewriting for the next batch
   bool can_fold() const {
+    if (world > 1) return false;
     // (a launch of its own is ~6 us beside one table's ~50 us step and ~15 us — a wavefront per table, each
     // with its round trips — beside 26 tables' 450: measured 452 us folded against 465)
     static const uint32_t max_t = getenv("MHTE_SHARD_FOLD_MAX_TABLES") ? uint32_t(atoi(getenv("MHTE_SHARD_FOLD_MAX_TABLES"))) : (1u << 30);
@@ -1157,10 +1163,7 @@ struct ShardStep {
           A.a[i] = P.a[i];
         }
       }
-      // ids per lane group in flight: 2 for a launch of a few (peer, table) blocks — its chain's length is
-      // what counts —, 4 for a model's: half the workgroups to dispatch for the same rows
-      static const int unr_env = getenv("MHTE_SHARD_LOOKUP_UNR") ? atoi(getenv("MHTE_SHARD_LOOKUP_UNR")) : 0;
-      const uint32_t unr = unr_env ? uint32_t(unr_env == 4 ? 4 : 2) : (uint32_t(world) * tc > 8u ? 4u : 2u);
+      const uint32_t unr = 2u;   // ids per lane group in flight (4: measured no faster on 26 tables, profiles/r05)
       uint32_t gx = 1;
       for (uint32_t i = 0; i < tc; ++i)
         gx = std::max(gx, uint32_t((uint64_t((sized_n(t0 + i) + unr - 1) / unr) * shape_lanes(A.g[i]) + 511) / 512));
@@ -1171,12 +1174,10 @@ struct ShardStep {
       for (uint32_t i = 0; i < tc; ++i) ((A.g[i] & 1u) ? w1 : w4) = true;
       if (fold) gx = std::max(gx, tc);
       const dim3 grid(gx, uint32_t(world) * tc + (fold ? 1u : 0u));
-#define MHTE_LOOKUP_LAUNCH(W_)                                                                                   \
-  do {                                                                                                           \
-    if (fold && unr == 4) LAUNCH_HOT(kTagShardLookup, (shard_lookup_kernel<W_, true, 4>), grid, 512, st, A);     \
-    else if (fold) LAUNCH_HOT(kTagShardLookup, (shard_lookup_kernel<W_, true, 2>), grid, 512, st, A);            \
-    else if (unr == 4) LAUNCH_HOT(kTagShardLookup, (shard_lookup_kernel<W_, false, 4>), grid, 512, st, A);       \
-    else LAUNCH_HOT(kTagShardLookup, (shard_lookup_kernel<W_, false, 2>), grid, 512, st, A);                     \
+#define MHTE_LOOKUP_LAUNCH(W_)                                                                      \
+  do {                                                                                              \
+    if (fold) LAUNCH_HOT(kTagShardLookup, (shard_lookup_kernel<W_, true, 2>), grid, 512, st, A);    \
+    else LAUNCH_HOT(kTagShardLookup, (shard_lookup_kernel<W_, false, 2>), grid, 512, st, A);        \
   } while (0)
       if (w4) MHTE_LOOKUP_LAUNCH(4);
       if (w1) MHTE_LOOKUP_LAUNCH(1);
