@@ -125,9 +125,11 @@ def build_library(force=False, verbose=False):
     print(" ".join(cmd))
   if os.path.exists(_HASH_FILE):
     os.remove(_HASH_FILE)
+  src_hash = _source_hash()   # (of what the compiler is about to read: an edit during the minutes of the
+                              # build must leave the library stale, not blessed)
   subprocess.check_call(cmd)
   with open(_HASH_FILE, "w") as f:
-    f.write(_source_hash() + "\n")
+    f.write(src_hash + "\n")
   build_eager_loop()
   return _SO
 

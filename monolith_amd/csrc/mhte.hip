@@ -513,6 +513,80 @@ static double lib_now() {
 // its caller's thread); read by Table::upsert for the one optimizer that uses it (batch softmax)
 static thread_local int64_t t_global_step = 0;
 
+// Host-side bound on how full the head split of a sliding filter can be (the role keys_upper plays for
+// the table's doubling): every consulting launch adds at most its id count; the window can only have to
+// move once the bound reaches the split's capacity, and only then do filter_advance_kernel /
+// filter_clear_kernel follow the launch — and the true count is fetched (one asynchronous 8-KB copy,
+// polled, never waited for) to start the bound over.  Launches recorded into a hipGraph are replayed
+// without the host seeing them: a filter that was ever consulted under capture keeps the two launches
+// behind every consulting launch, as round 4 did everywhere.
+struct FilterBudget {
+  std::mutex mu;
+  uint32_t split_cap = 0;
+  uint64_t head_upper = 0;
+  uint64_t adds_since_fetch = 0;
+  uint64_t gen = 0, fetch_gen = 0;
+  bool known = true, fetching = false, every_launch = false;
+  FilterState* h_state = nullptr;   // pinned
+  hipEvent_t ev = nullptr;
+  uint64_t skipped = 0, maintained = 0;   // (statistics)
+  FilterBudget() {
+    static const bool always = getenv("MHTE_FILTER_MAINTAIN_ALWAYS") != nullptr;   // (A/B: round 4's behaviour)
+    every_launch = always;
+  }
+  ~FilterBudget() {
+    if (ev) (void)hipEventDestroy(ev);
+    if (h_state) (void)hipHostFree(h_state);
+  }
+  void invalidate() {   // the device state was rewritten (restore)
+    std::lock_guard<std::mutex> g(mu);
+    known = false;
+    ++gen;
+  }
+  bool due(uint64_t adds, hipStream_t st) {
+    std::lock_guard<std::mutex> g(mu);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) every_launch = true;
+    if (every_launch) return true;
+    if (fetching && hipEventQuery(ev) == hipSuccess) {
+      fetching = false;
+      if (fetch_gen == gen) {
+        head_upper = uint64_t(filter_split_elements(*h_state, h_state->head)) + adds_since_fetch;
+        known = true;
+      }
+    }
+    if (adds == ~0ull) {
+      known = false;   // (a launch that does not say how many ids it had)
+    } else {
+      head_upper += adds;
+      adds_since_fetch += adds;
+    }
+    const bool need = !known || fetching || head_upper + 1u >= uint64_t(split_cap);
+    ++(need ? maintained : skipped);
+    return need;
+  }
+  void refetch(const FilterState* d_state, hipStream_t st) {
+    std::lock_guard<std::mutex> g(mu);
+    if (every_launch || fetching) return;
+    if (!h_state && hipHostMalloc(reinterpret_cast<void**>(&h_state), sizeof(FilterState)) != hipSuccess) {
+      every_launch = true;
+      return;
+    }
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+      every_launch = true;
+      return;
+    }
+    if (hipMemcpyAsync(h_state, d_state, sizeof(FilterState), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipEventRecord(ev, st) != hipSuccess) {
+      every_launch = true;
+      return;
+    }
+    fetching = true;
+    fetch_gen = gen;
+    adds_since_fetch = 0;
+  }
+};
+
 struct Table {
   std::string name;
   int device = 0;
@@ -552,12 +626,19 @@ struct Table {
   uint64_t flt_total = 0;
   uint32_t* flt_state = nullptr;
   uint32_t flt_nsplit = 0, flt_stride = 0, flt_cap = 0;
+  FilterBudget* flt_budget = nullptr;   // the filter's host-side bound on its head split (sliding filters)
   // after a launch that consulted the filter: move the sliding window on if the head split filled
-  // up (filter_advance_kernel) and clear the split that becomes the look-ahead one
-  void filter_maintain(hipStream_t st) {
+  // up (filter_advance_kernel) and clear the split that becomes the look-ahead one.  `adds_upper`: how
+  // many ids the launch can have added to the filter at most (its id count); with it the two launches
+  // are skipped while the head split cannot be full yet (FilterBudget) — they were 2 of the filtered
+  // step's 4 launches and did nothing in all but one step of a few hundred.
+  void filter_maintain(hipStream_t st, uint64_t adds_upper = ~0ull) {
     if (!flt_slots) return;
+    const bool sliding = flt_nsplit != 0u && flt_budget != nullptr;
+    if (sliding && !flt_budget->due(adds_upper, st)) return;
     filter_advance_kernel<<<1, 64, 0, st>>>(view);
     filter_clear_kernel<<<256, 256, 0, st>>>(view);
+    if (sliding) flt_budget->refetch(reinterpret_cast<const FilterState*>(flt_state), st);
   }
   // in-op grouping scratch (ids not declared unique)
   DedupWs dd;
@@ -901,7 +982,7 @@ struct Table {
     } else {
       slowpath_kernel<1, OP><<<1, 64, 0, st>>>(view, ids, values, seg_off, seg_pos, a, status, pend, skp);
     }
-    if (a.filter_mode) filter_maintain(st);
+    if (a.filter_mode) filter_maintain(st, uint64_t(n));
     HIP_OK(hipGetLastError());
   }
 
@@ -997,7 +1078,7 @@ struct Table {
     pend_grad = grad_u;
     pend_args = a;
     pend_vec = sh.VEC;
-    filter_maintain(st);
+    filter_maintain(st, uint64_t(n_max));
     if (!defer_slowpath) finish_pending(st);
   }
 
@@ -1199,12 +1280,23 @@ struct Table {
     // instance compiled for that optimizer alone (step_bwd_kernel<.., OPTK>: 61 -> 7-17 spilled registers for
     // Adam, and the row fetched ahead as the SGD / Adagrad / FTRL instances do)
     static const bool no_optk = getenv("MHTE_NO_OPTK") != nullptr;   // (A/B: the one FULL instance for all)
-    const int optk = (!basic && nseg == 1 && sh.VEC == 4 && !view.seg[0].sr16 && !no_optk) ? int(view.seg[0].opt) : -1;
+    // a table with an admission filter: the instances that consult it (FILT; the others carry no filter code —
+    // with it the headline instance kept 11 spilled registers, without it 2)
+    const bool filt = flt_slots != nullptr;
+    const int optk =
+        (!basic && nseg == 1 && sh.VEC == 4 && !view.seg[0].sr16 && !no_optk && !filt) ? int(view.seg[0].opt) : -1;
+#define CALL_FILT(G_, V_, S_, F_)                                                                                \
+  LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, V_, S_, F_, -1, true>), grid, 256, st, nxt, nblk_build, v, cur, c, a, po, da)
 #define CALL_OPTK(G_, K_)                                                                                     \
   LAUNCH_HOT(kTagStepBwd, (step_bwd_kernel<G_, 4, true, true, K_>), grid, 256, st, nxt, nblk_build, v, cur, c, a, po, da)
 #define CALL(G_, V_) \
   do {                                                                                               \
-    if (V_ == 4 && optk == kOptMomentum) {                                                           \
+    if (filt) {                                                                                      \
+      if (basic && nseg == 1) CALL_FILT(G_, V_, true, false);                                        \
+      else if (basic) CALL_FILT(G_, V_, false, false);                                               \
+      else if (nseg == 1) CALL_FILT(G_, V_, true, true);                                             \
+      else CALL_FILT(G_, V_, false, true);                                                           \
+    } else if (V_ == 4 && optk == kOptMomentum) {                                                    \
       CALL_OPTK(G_, kOptMomentum);                                                                   \
     } else if (V_ == 4 && optk == kOptAdadelta) {                                                    \
       CALL_OPTK(G_, kOptAdadelta);                                                                   \
@@ -1229,6 +1321,7 @@ struct Table {
     DISPATCH_G_VEC(sh, CALL);
 #undef CALL
 #undef CALL_OPTK
+#undef CALL_FILT
     hipError_t le = hipGetLastError();
     ws.r_stage = 0;  // the apply leaves the scratch all-empty
     if (nblk_build) {
@@ -1243,7 +1336,7 @@ struct Table {
       if (ws_next) ws_next->r_clean_cap = 0;
       HIP_OK(le);
     }
-    filter_maintain(st);
+    filter_maintain(st, uint64_t(n));
     // the displacement pass rides in the next step_forward (or runs on its own if anything else
     // touches the table first)
     pend_valid = true;
@@ -1364,6 +1457,7 @@ struct mhte_hash_filter {
   uint64_t total = 0;              // hash range of a split = split_capacity * 1.2
   uint64_t capacity = 0;           // the filter's (constructor argument)
   uint32_t nsplit = 0, stride = 0, split_cap = 0, split_num_arg = 0;
+  mhte::FilterBudget budget;       // when the window can have to move (sliding filters)
   mhte::TableView view() const {   // (a view that only carries the filter: the filter's own kernels)
     mhte::TableView v{};
     v.flt_slots = slots;
@@ -2165,6 +2259,7 @@ mhte_status mhte_hash_filter_create(uint64_t capacity, int32_t split_num, int32_
     HIP_OK(hipMemset(f->slots, 0, words * sizeof(uint32_t)));
     HIP_OK(hipMalloc(&f->state, sizeof(FilterState)));
     HIP_OK(hipMemset(f->state, 0, sizeof(FilterState)));
+    f->budget.split_cap = f->split_cap;
     *out = f.release();
   });
 }
@@ -2183,6 +2278,7 @@ mhte_status mhte_multi_table_set_filter(mhte_multi_table* t, mhte_hash_filter* f
       tb->flt_nsplit = f ? f->nsplit : 0;
       tb->flt_stride = f ? f->stride : 0;
       tb->flt_cap = f ? f->split_cap : 0;
+      tb->flt_budget = f ? &f->budget : nullptr;
       tb->refresh_view();
     }
   });
@@ -2218,7 +2314,8 @@ mhte_status mhte_hash_filter_stats(mhte_hash_filter* f, int64_t* out, int32_t ca
     if (cap < 4 + int32_t(f->nsplit)) throw Error(MHTE_INVALID_ARGUMENT, "filter stats: out holds 4 + split count words");
     HIP_OK(hipSetDevice(f->device));
     hipStream_t st = S(stream);
-    FilterState hs;
+    std::unique_ptr<FilterState> hs_heap(new FilterState);   // (256 KB: not on the stack)
+    FilterState& hs = *hs_heap;
     HIP_OK(hipMemcpyAsync(&hs, f->state, sizeof(hs), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     out[0] = hs.head;
@@ -2235,7 +2332,8 @@ mhte_status mhte_hash_filter_save(mhte_hash_filter* f, const char* basename, voi
     if (f->nsplit == 0) return;   // probabilistic: split_num() == 0, the save op writes no file
     HIP_OK(hipSetDevice(f->device));
     hipStream_t st = S(stream);
-    FilterState hs;
+    std::unique_ptr<FilterState> hs_heap(new FilterState);   // (256 KB: not on the stack)
+    FilterState& hs = *hs_heap;
     HIP_OK(hipMemcpyAsync(&hs, f->state, sizeof(hs), hipMemcpyDeviceToHost, st));
     std::vector<uint32_t> words(size_t(f->nsplit) * f->stride);
     HIP_OK(hipMemcpyAsync(words.data(), f->slots, words.size() * 4, hipMemcpyDeviceToHost, st));
@@ -2288,7 +2386,8 @@ mhte_status mhte_hash_filter_restore(mhte_hash_filter* f, const char* basename, 
     if (f->nsplit == 0) return;   // probabilistic: stateless
     HIP_OK(hipSetDevice(f->device));
     hipStream_t st = S(stream);
-    FilterState hs;
+    std::unique_ptr<FilterState> hs_heap(new FilterState);   // (256 KB: not on the stack)
+    FilterState& hs = *hs_heap;
     memset(&hs, 0, sizeof(hs));
     std::vector<uint32_t> words(size_t(f->nsplit) * f->stride, 0u);
     try {
@@ -2368,6 +2467,7 @@ mhte_status mhte_hash_filter_restore(mhte_hash_filter* f, const char* basename, 
                     "slice), re-create the filter");
     HIP_OK(hipMemcpyAsync(f->slots, words.data(), words.size() * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(f->state, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
+    f->budget.invalidate();   // (the head split's fill is whatever the dump says)
     HIP_OK(hipStreamSynchronize(st));
   });
 }
@@ -3599,6 +3699,98 @@ static void layout_launch(bool forward, const float* const* embeddings, const in
     }
   } blob;
   blob.st = st;
+  // ---- forward, copy form, one launch: do the slices (plus zero runs for the columns between them) write
+  // every float of their outputs?  Then layout_rows_kernel writes the zeros too and the fill in front
+  // of it — a pass over the whole output: 268 MB at configs[4]'s shape — is left out for those outputs.
+  static const bool rows_form = !(getenv("MHTE_LAYOUT_ROWS") && atoi(getenv("MHTE_LAYOUT_ROWS")) == 0);
+  std::vector<char> out_written(size_t(std::max(n_outputs, 0)), 0);
+  std::vector<LayoutTask> zero_runs;
+  if (forward && !ext && rows_form && (flags & MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS) != 0 && n_fid == n_feature &&
+      n_slices > 0 && n_slices <= kMaxLayoutTasks && batch > 0) {
+    bool ok = true;
+    int64_t cols = 0;
+    for (int32_t i = 0; ok && i < n_slices; ++i) {
+      const mhte_layout_slice& sc = slices[i];
+      ok = sc.out_type != 2 && sc.pooling != kPoolFirstN && sc.out_index >= 0 && sc.out_index < n_outputs &&
+           sc.dim > 0 && sc.start >= 0 && sc.out_offset >= 0 && sc.out_row_floats > 0 &&
+           ((sc.start | sc.dim | sc.out_offset | sc.out_row_floats) & 3) == 0 && aligned16(outputs[sc.out_index]);
+      cols += sc.dim / 4;
+    }
+    for (int32_t i = 0; ok && i < n_emb; ++i) ok = (emb_stride[i] & 3) == 0 && aligned16(embeddings[i]);
+    std::vector<char> covered(size_t(n_outputs), 0);
+    for (int32_t o = 0; ok && o < n_outputs; ++o) {
+      std::vector<std::pair<int32_t, int32_t>> runs;   // (offset, width) of the slices of output o
+      int32_t stride = 0;
+      for (int32_t i = 0; ok && i < n_slices; ++i)
+        if (slices[i].out_index == o) {
+          if (stride && stride != slices[i].out_row_floats) ok = false;
+          stride = slices[i].out_row_floats;
+          runs.emplace_back(slices[i].out_offset, slices[i].dim);
+        }
+      if (!ok || runs.empty()) continue;
+      if (output_len[o] != int64_t(batch) * stride) continue;   // (rows beyond the batch: the fill stays)
+      std::sort(runs.begin(), runs.end());
+      int32_t pos = 0;
+      std::vector<LayoutTask> gaps;
+      bool tiles = true;
+      for (auto& r : runs) {
+        if (r.first < pos) { tiles = false; break; }            // overlapping slices: the fill stays
+        if (r.first > pos) {
+          LayoutTask z{};
+          z.nfl_idx = -2;
+          z.dim = r.first - pos;
+          z.pooling = kPoolZeroFill;
+          z.out_index = o;
+          z.out_offset = pos;
+          z.out_stride = stride;
+          gaps.push_back(z);
+        }
+        pos = r.first + r.second;
+      }
+      if (!tiles || pos > stride) continue;
+      if (pos < stride) {
+        LayoutTask z{};
+        z.nfl_idx = -2;
+        z.dim = stride - pos;
+        z.pooling = kPoolZeroFill;
+        z.out_index = o;
+        z.out_offset = pos;
+        z.out_stride = stride;
+        gaps.push_back(z);
+      }
+      int64_t gcols = 0;
+      for (auto& z : gaps) gcols += z.dim / 4;
+      if (size_t(n_slices) + zero_runs.size() + gaps.size() > size_t(kMaxLayoutTasks) ||
+          cols + gcols > kLayoutRowsMaxF)
+        continue;
+      cols += gcols;
+      zero_runs.insert(zero_runs.end(), gaps.begin(), gaps.end());
+      covered[size_t(o)] = 1;
+    }
+    if (ok && cols <= kLayoutRowsMaxF) out_written = covered;
+    else zero_runs.clear();
+  }
+  auto zero_buffers = [&](float* const* bufs, const int64_t* lens, int32_t n, const std::vector<char>* skip) {
+    LayoutZeroArgs Z{};
+    int32_t m = 0;
+    uint64_t longest = 0;
+    auto flush = [&] {
+      if (m == 0 || longest == 0) { m = 0; longest = 0; return; }
+      const uint32_t gx = uint32_t(std::min<uint64_t>(512, (longest + 4095) / 4096));
+      layout_zero_args_kernel<<<dim3(gx, uint32_t(m)), 256, 0, st>>>(Z);
+      HIP_OK(hipGetLastError());
+      m = 0;
+      longest = 0;
+    };
+    for (int32_t i = 0; i < n; ++i) {
+      if (lens[i] <= 0 || (skip && (*skip)[size_t(i)])) continue;
+      Z.p[m] = bufs[i];
+      Z.len[m] = uint64_t(lens[i]);
+      longest = std::max(longest, Z.len[m]);
+      if (++m == kLayoutZeroBufs) flush();
+    }
+    flush();
+  };
   LayoutArgs A{};
   if (ext) {
     const size_t o_emb = 0, o_out = o_emb + size_t(n_emb) * 8, o_len = o_out + size_t(n_outputs) * 8,
@@ -3637,14 +3829,10 @@ static void layout_launch(bool forward, const float* const* embeddings, const in
       HIP_OK(hipGetLastError());
     }
   } else {
-    if (forward) {  // SetZeroFunctor: rows without fids stay zero
-      for (int32_t i = 0; i < n_outputs; ++i)
-        if (output_len[i] > 0) HIP_OK(hipMemsetAsync(outputs[i], 0, size_t(output_len[i]) * 4, st));
-    } else {
-      for (int32_t i = 0; i < n_emb; ++i)
-        if (emb_count[i] > 0)
-          HIP_OK(hipMemsetAsync(const_cast<float*>(embeddings[i]), 0, size_t(emb_count[i]) * 4, st));
-    }
+    // SetZeroFunctor: rows without fids stay zero (one launch over all buffers; outputs the copy launch
+    // below writes in full are left to it)
+    if (forward) zero_buffers(outputs, output_len, n_outputs, &out_written);
+    else zero_buffers(const_cast<float* const*>(embeddings), emb_count, n_emb, nullptr);
   }
   if (batch == 0 || n_slices == 0) return;
   if (!ext) {
@@ -3805,6 +3993,19 @@ static void layout_launch(bool forward, const float* const* embeddings, const in
       nt += span;
       k += span;
     }
+    // (the zero runs of outputs this launch writes in full: slices like any other)
+    const bool whole_rows = !zero_runs.empty() || std::find(out_written.begin(), out_written.end(), 1) != out_written.end();
+    if (whole_rows) {
+      for (auto& z : zero_runs) {
+        A.task[nt] = z;
+        A.unit[nu].first = uint16_t(nt);
+        A.unit[nu].count = 1;
+        A.unit[nu].addn = 0;
+        ++nu;
+        ++nt;
+      }
+      A.zero_missing = 1;
+    }
     A.n_units = nu;
     const dim3 grid(uint32_t((int64_t(batch) * 16 + 255) / 256), uint32_t(nu));
     // one fid per feature instance (asserted by the caller), copies of float4-aligned slices: the
@@ -3817,7 +4018,17 @@ static void layout_launch(bool forward, const float* const* embeddings, const in
     }
     for (int32_t q = 0; fast && q < nu; ++q) fast = A.unit[q].count == 1;
     for (int32_t i = 0; fast && i < n_emb; ++i) fast = (emb_stride[i] & 3) == 0 && aligned16(embeddings[i]);
-    if (fast) {
+    // ... a workgroup per 16 batch rows over all slices of the launch when a row's float4 columns fit its
+    // column table (layout_rows_kernel; MHTE_LAYOUT_ROWS=0: a lane group per (slice, row), round 2's form)
+    int64_t cols = 0;
+    for (int32_t q = 0; q < nu; ++q) cols += A.task[A.unit[q].first].dim / 4;
+    if (fast && rows_form && cols > 0 && cols <= kLayoutRowsMaxF) {
+      const dim3 rgrid(uint32_t((int64_t(batch) + kLayoutRowsR - 1) / kLayoutRowsR));
+      if (forward) layout_rows_kernel<true><<<rgrid, 256, 0, st>>>(A);
+      else layout_rows_kernel<false><<<rgrid, 256, 0, st>>>(A);
+    } else if (whole_rows) {
+      throw Error(MHTE_INTERNAL, "layout: the launch that was to write whole output rows cannot run");
+    } else if (fast) {
       if (forward) layout_copy_kernel<true><<<grid, 256, 0, st>>>(A);
       else layout_copy_kernel<false><<<grid, 256, 0, st>>>(A);
     } else {
@@ -3900,7 +4111,8 @@ mhte_status mhte_hash_filter_create_probabilistic(int32_t equal_probability, uin
     HIP_OK(hipMalloc(&f->slots, 64 * sizeof(uint32_t)));   // (never read: "a filter is attached")
     HIP_OK(hipMemset(f->slots, 0, 64 * sizeof(uint32_t)));
     HIP_OK(hipMalloc(&f->state, sizeof(FilterState)));
-    FilterState hs;
+    std::unique_ptr<FilterState> hs_heap(new FilterState);   // (256 KB: not on the stack)
+    FilterState& hs = *hs_heap;
     memset(&hs, 0, sizeof(hs));
     if (seed == 0)   // (the reference seeds with time(0), xorshift.h:29-31)
       seed = uint64_t(std::chrono::steady_clock::now().time_since_epoch().count()) | 1ull;

@@ -215,6 +215,7 @@ constexpr int kFilterProbe = 16;           // SlidingHashFilter::MAX_STEP
 constexpr int kFilterForward = 2;          // max_forward_step_
 constexpr int kFilterMaxSplits = 64;
 constexpr int kFilterWays = 32;
+constexpr int kFilterWayStride = 32;      // words between two partial counts of a split (a 128-byte line each)
 
 struct FilterState {           // device words behind TableView::flt_state
   uint32_t head;
@@ -223,12 +224,16 @@ struct FilterState {           // device words behind TableView::flt_state
   uint32_t pad;
   unsigned long long failure_count;
   // elements per split, kept as kFilterWays partial counts (an id adds to way home % kFilterWays):
-  // a step that starts 40 000 slots would otherwise queue 40 000 adds on ONE word
-  uint32_t num_elements[kFilterMaxSplits][kFilterWays];
+  // a step that starts 40 000 slots would otherwise queue 40 000 adds on ONE word.  Round 5: each
+  // partial count in a 128-byte line of its own — atomics on one LINE are served one after the other
+  // like atomics on one word (≈ 5 ns each), and the 32 counts of a split sat in one line: the 6 000 new
+  // slots of a cold step were 30 µs of queued adds, the whole difference between the filtered and the
+  // unfiltered step.
+  uint32_t num_elements[kFilterMaxSplits][kFilterWays * kFilterWayStride];
 };
 __device__ __host__ inline uint32_t filter_split_elements(const FilterState& fs, uint32_t sp) {
   uint32_t n = 0;
-  for (int w = 0; w < kFilterWays; ++w) n += fs.num_elements[sp][w];
+  for (int w = 0; w < kFilterWays; ++w) n += fs.num_elements[sp][w * kFilterWayStride];
   return n;
 }
 
@@ -391,12 +396,157 @@ __device__ __forceinline__ uint32_t filter_consult(const TableView& tv, int64_t 
     decide(old_count, &first, &adds);
     const uint32_t c1 = min(kFilterMaxCount, old_count + min(adds, kFilterMaxCount));
     if (atomicCAS(slot, 0u, (sign << 4) | c1) == 0u) {
-      atomicAdd(&fs->num_elements[sp][home & uint64_t(kFilterWays - 1)], 1u);
+      atomicAdd(&fs->num_elements[sp][(home & uint64_t(kFilterWays - 1)) * kFilterWayStride], 1u);
       return first;
     }
     // the slot went to another id meanwhile: look again
   }
   return 0u;
+}
+
+// The same consultation by a lane GROUP (round 5; the fused step's id-major groups).  filter_consult
+// walks up to 2 + (nsplit - 2) splits of 16 slots one dependent load after the other on ONE lane — six
+// round trips in front of the insert of every id the table does not hold yet, which is what made the
+// filtered step 2.2x the unfiltered one.  Here lanes 0-15 of the group each fetch one slot of the
+// probe window of every split at once (filter_probe_issue, issued beside the table probe of the same
+// trip), the group's ballots replay HashFilter::find's "first slot that is empty or carries the
+// signature" on the loaded words, and lane 0 makes the one CAS: one round trip behind the loads.
+// Anything the loaded window cannot settle — a CAS that lost its slot, an older split beyond
+// kFilterBack — goes to the serial form, which starts over (as its own retry does).
+constexpr int kFilterBack = 6;   // older splits fetched ahead (nsplit <= 8: all of them)
+template <int G>
+struct FilterProbe {
+  static constexpr int PERW = (kFilterProbe + G - 1) / G;   // window slots per lane (2 with 8 lanes)
+  uint32_t w[(kFilterForward + kFilterBack) * PERW];
+};
+template <int G>
+__device__ __forceinline__ FilterProbe<G> filter_probe_issue(const TableView& tv, int64_t id, bool active, int j,
+                                                             uint32_t head, uint32_t hinc) {
+  FilterProbe<G> fp;
+  constexpr int PERW = FilterProbe<G>::PERW;
+  const uint32_t S = tv.flt_nsplit;
+  const uint64_t home = active ? filter_home(id, tv.flt_total) : 0ull;
+  const uint32_t nb = min(min(hinc, S - uint32_t(kFilterForward)), uint32_t(kFilterBack));
+#pragma unroll
+  for (int s = 0; s < kFilterForward; ++s) {
+    const uint32_t* split = tv.flt_slots + size_t((head + uint32_t(s)) % S) * tv.flt_stride + home;
+#pragma unroll
+    for (int q = 0; q < PERW; ++q)
+      fp.w[s * PERW + q] =
+          __hip_atomic_load(&split[(j + q * G) & (kFilterProbe - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // older splits: nothing writes them while they are behind the head (plain, cached loads), and only the
+  // `nb` the window has moved over exist (a filter that has not moved yet fetches none: the six fetches
+  // were 2.6 us of a 37-us filtered step, profiles/r05/filter_step.md)
+#pragma unroll
+  for (int i = 0; i < kFilterBack; ++i) {
+    if (uint32_t(i) < nb) {
+      const uint32_t sp = (head + S - 1u - uint32_t(i)) % S;
+      const uint32_t* split = tv.flt_slots + size_t(sp) * tv.flt_stride + home;
+#pragma unroll
+      for (int q = 0; q < PERW; ++q)
+        fp.w[(kFilterForward + i) * PERW + q] = split[(j + q * G) & (kFilterProbe - 1)];
+    }   // (else: left as it is — the consultation does not look at it; a value merged in here would
+        //  make the compiler wait for the loads where the branch ends)
+  }
+  return fp;
+}
+// first slot of split s's window that is empty or carries `sign` (-1: none) and the word there
+template <int G>
+__device__ __forceinline__ int filter_window_first(const FilterProbe<G>& fp, int s, uint32_t sign, int j, int gbase,
+                                                   uint32_t* word) {
+  constexpr int PERW = FilterProbe<G>::PERW;
+  uint64_t m = 0;
+#pragma unroll
+  for (int q = 0; q < PERW; ++q) {
+    const uint32_t w = fp.w[s * PERW + q];
+    const bool hit = (j + q * G) < kFilterProbe && (w == 0u || (w >> 4) == sign);
+    m |= group_mask_of<G>(__ballot(hit), gbase) << (q * G);
+  }
+  m &= (1ull << kFilterProbe) - 1ull;
+  const int p = m ? __ffsll(static_cast<long long>(m)) - 1 : -1;
+  uint32_t v = 0;
+#pragma unroll
+  for (int q = 0; q < PERW; ++q) {
+    const uint32_t x = __shfl(fp.w[s * PERW + q], gbase + ((p < 0 ? 0 : p) & (G - 1)));
+    if (p >= q * G && p < (q + 1) * G) v = x;
+  }
+  *word = v;
+  return p;
+}
+// Every lane of the group calls this (group-uniform arguments; `act`: the group has an id to ask
+// about — the ballots inside run whatever `act` says; `serial`: the windows in `fp` are not this
+// id's (a hint that failed after they were fetched; a probabilistic filter, which has none) — lane 0
+// asks the serial form).  Returns what filter_consult returns, in every lane of the group.
+template <int G>
+__device__ __forceinline__ uint32_t filter_consult_group(const TableView& tv, int64_t id, uint32_t k, int mode,
+                                                         bool contained, bool act, bool serial,
+                                                         const FilterProbe<G>& fp, int j, int gbase, uint32_t head,
+                                                         uint32_t hinc) {
+  const uint32_t S = tv.flt_nsplit;
+  const uint32_t sign = filter_sign(id);
+  // the windows, replayed on the loaded words (ballots: all lanes, before anything diverges)
+  uint32_t v0, v1;
+  const int p0 = filter_window_first<G>(fp, 0, sign, j, gbase, &v0);
+  const int p1 = filter_window_first<G>(fp, 1, sign, j, gbase, &v1);
+  const uint32_t nb_all = S >= uint32_t(kFilterForward) ? min(hinc, S - uint32_t(kFilterForward)) : 0u;
+  const uint32_t nb = min(nb_all, uint32_t(kFilterBack));
+  uint32_t old_count = 0;
+  bool older_found = false;
+#pragma unroll
+  for (int i = 0; i < kFilterBack; ++i) {
+    uint32_t wv;
+    const int p = filter_window_first<G>(fp, kFilterForward + i, sign, j, gbase, &wv);
+    if (uint32_t(i) < nb && !older_found && p >= 0 && wv != 0u) {   // (an empty slot first: not in this split)
+      old_count = wv & kFilterMaxCount;
+      older_found = true;
+    }
+  }
+  uint32_t first = 0;
+  bool ask = act && j == 0 && k != 0;
+  if (ask && !serial) {
+    const int32_t thr_i = occurrence_threshold(tv, id);
+    if (thr_i > 0 && !(contained && mode != 3)) {
+      const uint32_t thr = uint32_t(thr_i);
+      FilterState* fs = reinterpret_cast<FilterState*>(tv.flt_state);
+      const uint64_t home = filter_home(id, tv.flt_total);
+      auto decide = [&](uint32_t c0, uint32_t* f1, uint32_t* adds) {
+        if (mode == 2) {
+          *f1 = (c0 < thr) ? k : 0u;
+          *adds = k;
+        } else if (mode == 3) {
+          *f1 = (c0 >= thr) ? 0u : min(k, thr - c0);
+          *adds = k;
+        } else {
+          *f1 = (c0 >= thr) ? 0u : (thr - c0);
+          *adds = min(k, *f1 + 1u);
+          *f1 = min(*f1, k);
+        }
+      };
+      const int pos = p0 >= 0 ? p0 : p1;
+      const uint32_t sp = (head + (p0 >= 0 ? 0u : 1u)) % S;
+      const uint32_t v = p0 >= 0 ? v0 : v1;
+      uint32_t adds;
+      if (pos < 0) {                                   // no usable slot: "seen max_count times"
+        atomicAdd(&fs->failure_count, 1ull);
+        decide(kFilterMaxCount, &first, &adds);
+      } else if (v == 0u && nb_all > nb && !older_found) {
+        serial = true;                                 // older splits beyond the fetched ones
+      } else {
+        uint32_t* slot = tv.flt_slots + size_t(sp) * tv.flt_stride + home + uint32_t(pos);
+        const uint32_t c0 = v != 0u ? (v & kFilterMaxCount) : old_count;
+        decide(c0, &first, &adds);
+        const uint32_t c1 = min(kFilterMaxCount, c0 + min(adds, kFilterMaxCount));
+        if (atomicCAS(slot, v, (sign << 4) | c1) == v) {
+          if (v == 0u) atomicAdd(&fs->num_elements[sp][(home & uint64_t(kFilterWays - 1)) * kFilterWayStride], 1u);
+        } else {
+          serial = true;                               // the slot changed meanwhile: look again
+        }
+      }
+    }
+  }
+  if (ask && serial) first = filter_consult(tv, id, k, mode, contained);
+  return __shfl(first, gbase);
 }
 
 // SlidingHashFilter::get (:93-114)
@@ -450,7 +600,7 @@ __global__ void filter_advance_kernel(TableView tv) {
     fs->head = (fs->head + 1u) % tv.flt_nsplit;
     fs->head_increment += 1u;
     const uint32_t c = (fs->head + uint32_t(kFilterForward) - 1u) % tv.flt_nsplit;
-    for (int w = 0; w < kFilterWays; ++w) fs->num_elements[c][w] = 0;
+    for (int w = 0; w < kFilterWays; ++w) fs->num_elements[c][w * kFilterWayStride] = 0;
     fs->clear_req = c + 1u;
   }
 }

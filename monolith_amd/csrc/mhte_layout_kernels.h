@@ -25,6 +25,7 @@ constexpr int kMaxLayoutOut = 32;     // arguments, output tensors likewise; mor
                                       // test has ~1000 and 153): pointer tables in device memory
 
 enum LayoutPooling : int32_t { kPoolSum = 0, kPoolMean = 1, kPoolFirstN = 3 };  // example.proto:176-180
+constexpr int32_t kPoolZeroFill = 100;   // (internal) a run of output columns no slice writes: layout_rows_kernel zeroes it
 
 struct LayoutTask {
   int32_t nfl_idx;       // SliceConfig.feature_idx
@@ -48,6 +49,8 @@ struct LayoutArgs {
   const int32_t* feature_offset;
   const uint32_t* nfl_offset;
   int32_t n_fid, n_feature, n_nfl, batch, n_emb, n_units;
+  int32_t zero_missing;   // layout_rows_kernel<true>: a (slice, row) without a fid is written as zeros (the
+                          // output was not zero-filled beforehand: the launch writes every column of it)
   // when the model has more matrices / outputs than the inline arrays hold: the same four tables in
   // device memory (x_emb != nullptr), uploaded by the host for the call
   const float* const* x_emb;
@@ -78,6 +81,29 @@ __global__ __launch_bounds__(256) void layout_zero_kernel(float* const* buf, con
   const uint64_t n = len[blockIdx.y];
   for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x)
     p[i] = 0.f;
+}
+
+// the same for up to kLayoutZeroBufs buffers named in the kernel arguments, 16 bytes per lane where the
+// buffer allows it (hipMemsetAsync moved the 268 MB of a configs[4] layout output at 1.3 TB/s, and the
+// gradient side took one call per matrix)
+constexpr int kLayoutZeroBufs = 64;
+struct LayoutZeroArgs {
+  float* p[kLayoutZeroBufs];
+  uint64_t len[kLayoutZeroBufs];   // floats
+};
+__global__ __launch_bounds__(256) void layout_zero_args_kernel(LayoutZeroArgs Z) {
+  float* p = Z.p[blockIdx.y];
+  const uint64_t n = Z.len[blockIdx.y];
+  const uint64_t tid = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, nth = uint64_t(gridDim.x) * blockDim.x;
+  if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+    Vec<4> z;
+    vec_zero(z);
+    const uint64_t n4 = n >> 2;
+    for (uint64_t i = tid; i < n4; i += nth) z.store(p + i * 4);
+    for (uint64_t i = (n4 << 2) + tid; i < n; i += nth) p[i] = 0.f;
+  } else {
+    for (uint64_t i = tid; i < n; i += nth) p[i] = 0.f;
+  }
 }
 
 // GetFeatureInfo + the feature's fid range for batch row b (fused_embedding_to_layout.h:56-76,
@@ -127,6 +153,105 @@ __global__ __launch_bounds__(256) void layout_copy_kernel(LayoutArgs A) {
       v.load(orow + e);
       v.store(erow + e);
     }
+  }
+}
+
+// The same copies, a workgroup per kLayoutRowsR batch rows over ALL slices of the launch (round 5).
+// layout_copy_kernel gives a 16-lane group one (slice, batch row): four dependent round trips
+// (nfl_offset -> feature_offset -> fid_offset -> the row) in front of 64-256 bytes, 12 of the 16 lanes idle
+// on a dim-16 slice, and the pieces of one output row written by 26 workgroups of different XCDs at
+// different times: 2.2-2.5 TB/s of the two streams at configs[4]'s shape.  Here the workgroup first resolves
+// its (slice, row) pairs — one thread per pair, every chain in flight at once, source and destination
+// addresses into LDS — then walks the float4 columns of its output rows flat, consecutive lanes on
+// consecutive columns across slice boundaries: whole 128-byte lines of a CONCAT row leave one workgroup,
+// every lane moves 16 bytes, kLayoutRowsUnroll independent loads in flight per lane.
+constexpr int kLayoutRowsR = 16;
+constexpr int kLayoutRowsMaxF = 2048;   // float4 columns of one batch row over the launch's slices
+constexpr int kLayoutRowsUnroll = 4;
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void layout_rows_kernel(LayoutArgs A) {
+  constexpr int R = kLayoutRowsR;
+  __shared__ unsigned long long s_src[kMaxLayoutTasks * R];   // embedding side (0: no row)
+  __shared__ unsigned long long s_dst[kMaxLayoutTasks * R];   // output side
+  __shared__ uint16_t s_cstart[kMaxLayoutTasks + 1];
+  __shared__ uint8_t s_ctask[kLayoutRowsMaxF];
+  const int nu = A.n_units;
+  const int32_t b0 = int32_t(blockIdx.x) * R;
+  if (threadIdx.x < 64) {   // float4 columns in front of slice q (an inclusive scan over <= 64 slices)
+    const int q = threadIdx.x;
+    uint32_t w = q < nu ? uint32_t(A.task[A.unit[q].first].dim) >> 2 : 0u;
+    uint32_t incl = w;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = __shfl_up(incl, o);
+      if (q >= o) incl += v;
+    }
+    if (q <= nu) s_cstart[q] = uint16_t(incl - w);
+  }
+  for (int p = threadIdx.x; p < nu * R; p += 256) {
+    const int q = p / R, r = p % R;
+    const int32_t b = b0 + r;
+    const LayoutTask t = A.task[A.unit[q].first];
+    // src: the embedding side; 0 = nothing to move, 1 = zeros (forward: a run of columns no slice writes,
+    // or — in a launch that writes whole output rows instead of a zero fill beforehand — a row without a fid)
+    unsigned long long src = 0ull, dst = 0ull;
+    int32_t f0 = 0, f1 = 0;
+    if (b < A.batch) {
+      dst = reinterpret_cast<unsigned long long>(layout_out(A, t.out_index) + int64_t(b) * t.out_stride +
+                                                 t.out_offset);
+      if (FORWARD && t.pooling == kPoolZeroFill) {
+        src = 1ull;
+      } else if (layout_fid_range(A, t.nfl_idx, b, &f0, &f1)) {
+        const unsigned long long fo = A.fid_offset[f0];
+        const uint32_t i1 = uint32_t(fo >> 32), i2 = uint32_t(fo);
+        if (i1 < uint32_t(A.n_emb))
+          src = reinterpret_cast<unsigned long long>(layout_emb(A, i1) + uint64_t(i2) * layout_stride(A, i1) +
+                                                     uint32_t(t.start));
+      }
+      if (!src && FORWARD && A.zero_missing) src = 1ull;
+    }
+    s_src[p] = src;
+    s_dst[p] = dst;
+  }
+  __syncthreads();
+  const uint32_t F = s_cstart[nu];
+  for (uint32_t c = threadIdx.x; c < F; c += 256) {   // column -> slice
+    uint32_t lo = 0, hi = uint32_t(nu) - 1u;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi + 1u) >> 1;
+      if (s_cstart[mid] <= c) lo = mid;
+      else hi = mid - 1u;
+    }
+    s_ctask[c] = uint8_t(lo);
+  }
+  __syncthreads();
+  const uint32_t total = uint32_t(R) * F;
+  for (uint32_t i0 = threadIdx.x; i0 < total; i0 += 256u * kLayoutRowsUnroll) {
+    Vec<4> v[kLayoutRowsUnroll];
+    float* to[kLayoutRowsUnroll];
+#pragma unroll
+    for (int u = 0; u < kLayoutRowsUnroll; ++u) {
+      const uint32_t i = i0 + uint32_t(u) * 256u;
+      to[u] = nullptr;
+      if (i < total) {
+        const uint32_t r = i / F, c = i - r * F;
+        const uint32_t q = s_ctask[c];
+        const uint32_t e = (c - s_cstart[q]) * 4u;
+        const unsigned long long src = s_src[q * R + r], dst = s_dst[q * R + r];
+        if (src > 1ull) {
+          float* const ep = reinterpret_cast<float*>(src) + e;
+          float* const op = reinterpret_cast<float*>(dst) + e;
+          v[u].load(FORWARD ? ep : op);
+          to[u] = FORWARD ? op : ep;
+        } else if (FORWARD && src == 1ull) {
+          vec_zero(v[u]);
+          to[u] = reinterpret_cast<float*>(dst) + e;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kLayoutRowsUnroll; ++u)
+      if (to[u]) v[u].store(to[u]);
   }
 }
 

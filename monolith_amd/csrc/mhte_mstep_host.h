@@ -511,9 +511,12 @@ struct MultiStep {
         HIP_OK(hipGetLastError());
         for (uint32_t k = 0; k < tc; ++k)
           if (A.tab[k].apply) ++mt->tables[t0 + k]->mut_epoch;
+        uint64_t asked = 0;   // ids the launch can have put to the filter
+        for (uint32_t k = 0; k < tc; ++k)
+          if (A.tab[k].apply && mt->tables[t0 + k]->flt_slots) asked += A.tab[k].n;
         for (uint32_t k = 0; k < tc; ++k)
           if (A.tab[k].apply && mt->tables[t0 + k]->flt_slots) {
-            mt->tables[t0 + k]->filter_maintain(st);   // (one filter for all tables: once is enough)
+            mt->tables[t0 + k]->filter_maintain(st, asked);   // (one filter for all tables: once is enough)
             break;
           }
       }

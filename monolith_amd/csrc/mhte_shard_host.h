@@ -4,16 +4,20 @@
 // One process per GPU; rank r owns {id : floormod(id, N) == r} of EVERY table of the model
 // (NT/distributed_ps.py:289) as a complete local mhte_multi_table.  A step on a rank:
 //
-//   forward   owner lookup of the received id blocks            1 launch
-//             exchange rows  (owner -> sender)                  RCCL group of N send/recv pairs
-//             scatter rows to the occurrences                   1 launch
-//             run dedup of the NEXT batch (depends on ids only, 1 launch
-//             NT/distributed_ps_sync.py:199-203)
-//   backward  per-id gradient sums into the row slots |         1 launch
+//   forward   owner lookup of the received id blocks: rows straight into     1 launch
+//               the senders' row blocks, a record per id for the update
+//               (+ the displacement pass the last update owes: one rank)
+//             sync point (peer stores)  |  RCCL group of N send/recv pairs     1 launch | 1 group
+//             scatter rows to the occurrences | run dedup of the NEXT batch    1 launch
+//               (depends on ids only, NT/distributed_ps_sync.py:199-203)
+//   backward  per-id gradient sums straight into the owners' gradient blocks | 1 launch
 //               numbering + owner packing of the next batch
-//             exchange gradients (sender -> owner)              RCCL group
-//             exchange the next batch's id blocks               RCCL group
-//             per peer, in rank order: upsert, displacement     2 launches each
+//             sync point  |  RCCL groups (gradients, next id blocks)           1 launch | 2 groups
+//             owner: every sender's block, rank order per id, ONE launch       1 launch
+//             displacement pass of everything that launch deferred             1 launch (N > 1, or FULL rows)
+//   7 launches with peer stores at any N; 4-5 with one rank and no transport.  (Round 4: a push and a sync
+//   launch per exchange and an upsert + displacement pair per sender: 11 at N = 2, 23 at N = 8.  Tables with
+//   an admission filter and MHTE_SHARD_PER_PEER=1 keep the per-sender pair; MHTE_SHARD_DIRECT=0 the pushes.)
 //   (a batch that was not prepared ahead costs two more launches in its forward)
 //
 // Everything the host decides is a function of the configured capacities: no count crosses to the
@@ -144,7 +148,9 @@ struct ShardStep {
   // ---- sizing the owner's launches by what the peers actually send.  A (peer, table) block can hold the
   // whole batch; a Zipf batch fills a fifth of it, N ranks a fifth of an N-th.  Workgroups sized for the
   // capacity find no work: each still takes a slot, reads its block's count and leaves — three more
-  // dispatch rounds behind the useful ones (17.7 -> us per update launch at 65 536 ids).  The counts
+  // dispatch rounds behind the useful ones (measured by itself at one table of 65 536 ids: no change, the
+  // launch's time is its dependency chain; kept for models of many tables, where the empty workgroups
+  // are T times as many).  The counts
   // are on the device only, so the received blocks' headers are copied to pinned host memory behind
   // every owner lookup — nobody waits for the copy; once it has landed it sizes the LATER steps'
   // launches (grid-stride loops inside: any size is correct, a stale one merely slower).

@@ -1347,7 +1347,10 @@ struct ApplyLds {
 // FULL: the table uses per-element optimizers beyond SGD / Adagrad / FTRL (optimize_row_reg_full; no
 // row prefetch: the state layout is the optimizer's); the host picks the instantiation.
 // (HINT: kept for the call sites' sake — every launch takes hints when ApplyCtl carries them)
-template <int G, int VEC, bool ONESEG, bool HINT = false, bool FULL = false, int OPTK = -1>
+// FILT: 0 = the table has no admission filter (no filter code in the instance), 1 = it has one and the
+// lane group consults it (filter_consult_group), -1 = decided at run time, serial form (the multi-table
+// launch, whose tables differ).
+template <int G, int VEC, bool ONESEG, bool HINT = false, bool FULL = false, int OPTK = -1, int FILT = -1>
 __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView& d,
                                               const ApplyCtl& c, const ApplyArgs& a, uint32_t bid,
                                               WaveTrace& wt, ApplyLds& L) {
@@ -1425,6 +1428,15 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
           if (c.uts) huts = inb ? c.uts[g] : 0u;
         }
       }
+      // sliding admission filter: the window's position, fetched with the trip (it only moves between
+      // launches) — the group fetches the filter's slots beside the table probe below
+      const bool fgroup = FILT == 1 && tv.flt_slots != nullptr && tv.flt_nsplit != 0u;
+      uint32_t fhead = 0, fhinc = 0;
+      if (fgroup) {
+        const FilterState* fs0 = reinterpret_cast<const FilterState*>(tv.flt_state);
+        fhead = fs0->head;
+        fhinc = fs0->head_increment;
+      }
       // (every reservation of the batch is consumed by this launch — inserted, or its key given back:
       // one thread takes them off the table's count of outstanding ones)
       if (!HINT && it == 0 && k == 0 && threadIdx.x == 0) {
@@ -1441,6 +1453,11 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       const bool ts_known = c.uts != nullptr && huts == a.ts;   // (multi-table step: the slot already
                                                                 // carries this second — no store, no check)
       Probe<G> pr = probe_issue<G>(tv, id, valid && !hinted, j);
+      const bool fact = valid && !hinted;   // (the filter windows below are this id's)
+      FilterProbe<G> fp;                    // (not initialised without a sliding filter: never read then)
+      if constexpr (FILT == 1) {
+        if (fgroup) fp = filter_probe_issue<G>(tv, id, fact, j, fhead, fhinc);
+      }
       // (a group without a hint — or an index past the count, whose record is stale — checks bucket
       // 0's first key: every lane loads, unconditionally, from an address that exists)
       // (the bucket pointer is formed here and again at the timestamp store below: kept live across the
@@ -1521,14 +1538,23 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       // admission filter (one consultation with the occurrence count: BatchOptimize with dedup,
       // tf_bridge.cc:300-310): an id that is not in the table yet and has not been seen often
       // enough is dropped — no insert, no update
-      if (tv.flt_slots) {
-        bool contained = group_mask_of<G>(__ballot(valid && id != kEmptyKey && j < 8 && pr.k == id), gbase) != 0;
-        if (valid && id == kEmptyKey) contained = tv.ctr->special_state == 1;
-        if (hinted) contained = true;
-        uint32_t first = 0;
-        if (valid && j == 0) first = filter_consult(tv, id, cnt, 2, contained);
-        if (__shfl(first, gbase) != 0u) valid = false;
-        hinted = hinted && valid;
+      if constexpr (FILT != 0) {
+        if (tv.flt_slots) {
+          bool contained = group_mask_of<G>(__ballot(valid && id != kEmptyKey && j < 8 && pr.k == id), gbase) != 0;
+          if (valid && id == kEmptyKey) contained = tv.ctr->special_state == 1;
+          if (hinted) contained = true;
+          uint32_t first = 0;
+          if constexpr (FILT == 1) {
+            // (a group whose hint failed fetched no windows, a probabilistic filter has none: serial form)
+            first = filter_consult_group<G>(tv, id, cnt, 2, contained, valid, !fgroup || !fact, fp, j, gbase, fhead,
+                                            fhinc);
+          } else {
+            if (valid && j == 0) first = filter_consult(tv, id, cnt, 2, contained);
+            first = __shfl(first, gbase);
+          }
+          if (first != 0u) valid = false;
+          hinted = hinted && valid;
+        }
       }
       // round trip 3 (ids without a hint): slot claim + row handle of a new id | the row of a found
       // one | (below) the gradients of a list — all in flight together
@@ -1815,13 +1841,16 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
       bool valid = threadIdx.x < G;
       bool hok = ihint && __shfl(vkey == hd.id ? 1 : 0, 0) != 0;
       if (ihint && !hok) pr = probe_issue<G>(tv, hd.id, valid, j);   // (rare: the entry moved or left)
-      if (tv.flt_slots) {  // (as in the id-major groups; the list's length is its count)
-        bool contained = group_mask_of<G>(__ballot(valid && hd.id != kEmptyKey && j < 8 && pr.k == hd.id), gbase) != 0;
-        if (valid && hd.id == kEmptyKey) contained = tv.ctr->special_state == 1;
-        if (hok) contained = true;
-        uint32_t first = 0;
-        if (valid && j == 0) first = filter_consult(tv, hd.id, d.ucnt[hd.u], 2, contained);
-        if (__shfl(first, gbase) != 0u) valid = false;
+      if constexpr (FILT != 0) {
+        if (tv.flt_slots) {  // (as in the id-major groups; the list's length is its count)
+          bool contained =
+              group_mask_of<G>(__ballot(valid && hd.id != kEmptyKey && j < 8 && pr.k == hd.id), gbase) != 0;
+          if (valid && hd.id == kEmptyKey) contained = tv.ctr->special_state == 1;
+          if (hok) contained = true;
+          uint32_t first = 0;
+          if (valid && j == 0) first = filter_consult(tv, hd.id, d.ucnt[hd.u], 2, contained);
+          if (__shfl(first, gbase) != 0u) valid = false;
+        }
       }
       SlotResult sr;
       if (hok) {
@@ -1959,7 +1988,8 @@ union __attribute__((aligned(16))) StepBwdLds {
   ApplyLds apply;
   RdLds4 dedup;
 };
-template <int G, int VEC, bool ONESEG, bool FULL = false, int OPTK = -1>
+// FILT: the table consults an admission filter (its own instances: the others carry no filter code)
+template <int G, int VEC, bool ONESEG, bool FULL = false, int OPTK = -1, bool FILT = false>
 __global__ __launch_bounds__(256, kBwdBlocksPerCu) void step_bwd_kernel(RunView nxt, uint32_t nblk_build,
                                                        TableView tv, RunView cur, ApplyCtl c,
                                                        ApplyArgs a, ProbeOut po, DedupArgs da) {
@@ -1992,7 +2022,7 @@ __global__ __launch_bounds__(256, kBwdBlocksPerCu) void step_bwd_kernel(RunView 
     return;
   }
   bid -= nblk_build;
-  rd_apply_role<G, VEC, ONESEG, false, FULL, OPTK>(tv, cur, c, a, bid, wt, L.apply);
+  rd_apply_role<G, VEC, ONESEG, false, FULL, OPTK, FILT ? 1 : 0>(tv, cur, c, a, bid, wt, L.apply);
   wt.end(bid < c.nblk_items ? 7u : 8u);
 }
 

@@ -829,3 +829,33 @@ def test_fused_embedding_to_layout_copy_form():
   gb = D.fused_embedding_to_layout_grad(embs, fo, fe, nf, B, [g], cfgs, one_fid_unique_rows=True)
   for x, y, w in zip(ga, gb, torch.split(g, dims, dim=1)):
     assert torch.equal(x, y) and torch.equal(x, w)
+
+
+def test_fused_embedding_to_layout_whole_rows_form_needs_no_zero_fill():
+  """Round 5: with one fid per feature instance the forward writes whole output rows from one workgroup
+  per 16 batch rows (layout_rows_kernel) — the padding columns behind the last slice included, so the
+  zero fill in front of the launch is left out.  The output memory is poisoned first; a batch that is
+  not a multiple of 16 rows; against the general form and against the concatenation itself."""
+  from monolith_amd import distribution_ops as D
+  rng = np.random.default_rng(5)
+  B, dims, kin = 1003, [16, 32, 64, 16], 256
+  names = ["a", "b", "c", "d"]
+  feats = {n: D.FeatureConfig(n, D.PoolingType.SUM, [d]) for n, d in zip(names, dims)}
+  cfgs = D.FeatureConfigs(feats, {"x": D.OutConfig([D.SliceConfig(n, 0, d) for n, d in zip(names, dims)],
+                                                     D.OutType.CONCAT, [[-1, kin]])})
+  embs = [torch.tensor(rng.standard_normal((B, d)).astype(np.float32)).cuda() for d in dims]
+  T = len(dims)
+  fo = (torch.arange(T, dtype=torch.int64).repeat_interleave(B) << 32 | torch.arange(B).repeat(T)).cuda()
+  fe = torch.arange(T * B, dtype=torch.int32).cuda()
+  nf = (torch.arange(T, dtype=torch.int32) * B).cuda()
+  want = torch.cat(embs + [torch.zeros(B, kin - sum(dims), device="cuda")], dim=1)
+  for _ in range(3):
+    poison = torch.full((B, kin), float("nan"), device="cuda")   # (the allocator hands this block out again)
+    del poison
+    got = D.fused_embedding_to_layout(embs, fo, fe, nf, B, cfgs, one_fid_unique_rows=True)[0]
+    assert torch.equal(got, want)
+  assert torch.equal(D.fused_embedding_to_layout(embs, fo, fe, nf, B, cfgs)[0], want)
+  g = torch.tensor(rng.standard_normal((B, kin)).astype(np.float32)).cuda()
+  gb = D.fused_embedding_to_layout_grad(embs, fo, fe, nf, B, [g], cfgs, one_fid_unique_rows=True)
+  for y, w in zip(gb, torch.split(g[:, :sum(dims)], dims, dim=1)):
+    assert torch.equal(y, w)
