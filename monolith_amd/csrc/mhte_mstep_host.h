@@ -494,8 +494,14 @@ struct MultiStep {
       bool fam[2][2][2] = {};
       for (uint32_t k = 0; k < tc; ++k)
         fam[A.tab[k].full ? 1 : 0][A.tab[k].gv & 1u][h_st[t0 + k].oneseg ? 1 : 0] = true;
-#define MHTE_BWD_LAUNCH(F_, W_, O_)  \
-  if (fam[F_][W_ == 1][O_]) LAUNCH_HOT(kTagMStepBwd, (mstep_bwd_kernel<F_ != 0, W_, O_ != 0>), dim3(gx, tc), 256, st, A)
+      // ... and the instances with the admission filter's code only when a table of the launch has a filter
+      bool filt = false;
+      for (uint32_t k = 0; k < tc; ++k) filt = filt || mt->tables[t0 + k]->flt_slots != nullptr;
+#define MHTE_BWD_LAUNCH(F_, W_, O_)                                                                              \
+  if (fam[F_][W_ == 1][O_]) {                                                                                    \
+    if (filt) LAUNCH_HOT(kTagMStepBwd, (mstep_bwd_kernel<F_ != 0, W_, O_ != 0, true>), dim3(gx, tc), 256, st, A); \
+    else LAUNCH_HOT(kTagMStepBwd, (mstep_bwd_kernel<F_ != 0, W_, O_ != 0, false>), dim3(gx, tc), 256, st, A);   \
+  }
       MHTE_BWD_LAUNCH(0, 4, 1);
       MHTE_BWD_LAUNCH(0, 4, 0);
       MHTE_BWD_LAUNCH(0, 1, 1);

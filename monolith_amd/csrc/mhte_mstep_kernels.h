@@ -491,11 +491,15 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
 // ---------------------------------------------------------------------------------------------
 // backward: per table   numbering + heavy work list of the NEXT batch | apply of this batch
 // ---------------------------------------------------------------------------------------------
-template <bool ONESEG, bool FULL, int VW>
+// FILT: a table of the launch consults an admission filter (rd_apply_role's run-time form, -1); without
+// one the instance carries no filter code (0): the float4 one-segment BASIC instance went from 38 spilled
+// VGPRs and 472 spilled SGPRs to 4 and 181 when the code left (round 5)
+template <bool ONESEG, bool FULL, int VW, bool FILT>
 __device__ __forceinline__ void mstep_apply_switch(uint32_t gv, const TableView& tv, const RunView& d,
                                                    const ApplyCtl& c, const ApplyArgs& a,
                                                    uint32_t bid, WaveTrace& wt, ApplyLds& L) {
-#define MHTE_BWD_CALL(G_, V_) rd_apply_role<G_, V_, ONESEG, true, FULL>(tv, d, c, a, bid, wt, L)
+#define MHTE_BWD_CALL(G_, V_) \
+  rd_apply_role<G_, V_, ONESEG, true, FULL, -1, FILT ? -1 : 0>(tv, d, c, a, bid, wt, L)
   MHTE_SWITCH_G(VW, gv, MHTE_BWD_CALL)
 #undef MHTE_BWD_CALL
 }
@@ -505,7 +509,7 @@ __device__ __forceinline__ void mstep_apply_switch(uint32_t gv, const TableView&
 #endif
 // One instance per (optimizer family, lane width, one segment / several): a table is served by its
 // instance, the host launches the instances the model has tables for (one, for configs[4]).
-template <bool FULL, int VW, bool ONESEG>
+template <bool FULL, int VW, bool ONESEG, bool FILT = false>
 __global__ __launch_bounds__(256, MHTE_MBWD_OCC) void mstep_bwd_kernel(MBwdArgs A) {
   __shared__ ApplyLds L;
   const uint32_t t = blockIdx.y;
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(256, MHTE_MBWD_OCC) void mstep_bwd_kernel(MBwdArgs 
   c.uloc = bt.hints ? s.uloc[cur] : nullptr;
   c.uts = bt.hints ? s.uts[cur] : nullptr;
   c.trusted = 1;   // (the host hands the hints over only while Table::mut_epoch is unchanged)
-  mstep_apply_switch<ONESEG, FULL, VW>(bt.gv, tv, d, c, bt.a, bid, wt, L);
+  mstep_apply_switch<ONESEG, FULL, VW, FILT>(bt.gv, tv, d, c, bt.a, bid, wt, L);
   wt.end(bid < bt.nblk_items ? 7u : 8u);
 }
 
