@@ -21,7 +21,7 @@ bench)
   cat $OUT/bench.json; tail -5 $OUT/bench.err ;;
 prof)
   rm -rf /tmp/prof && timeout -k 5 600 rocprofv3 --kernel-trace --stats -d /tmp/prof -o trace -- \
-    python bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err
+    python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extra-windows > $OUT/prof_bench.json 2> $OUT/prof.err
   echo "prof rc=$?"; find /tmp/prof -type f | head -20
   for f in $(find /tmp/prof -name '*kernel_stats*.csv'); do cp $f $OUT/; done
   db=$(find /tmp/prof -name '*.db' | head -1)
@@ -42,7 +42,7 @@ trace)
 pmc)
   for c in "FETCH_SIZE" "WRITE_SIZE"; do
     rm -rf /tmp/pmc_$c && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o pmc -- \
-      python bench.py --steps 40 --warmup 10 --no-cpu-baseline --launch eager > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err
+      python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-extra-windows --launch eager > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err
     echo "pmc $c rc=$?"
     find /tmp/pmc_$c -type f | head
     for f in $(find /tmp/pmc_$c -name '*counter_collection*.csv'); do python scripts/pmc_csv.py $f > $OUT/pmc_${c}.md; head -30 $OUT/pmc_${c}.md; done
