@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
+#include <hipcub/hipcub.hpp>   // (device radix sort / run-length encode / scan: AuxWs::group_sorted)
 
 #include <algorithm>
 #include <chrono>
@@ -2019,6 +2020,64 @@ struct AuxWs {
     Use(AuxWs& w, hipStream_t s) : ws(w), st(s) { ws.enter(st); }
     ~Use() { (void)hipEventRecord(ws.done, st); }
   };
+  // The same lists for keys known to lie in [0, 2^key_bits), key_bits <= 31 (round 5): a
+  // STABLE radix sort of (key, position) pairs — equal keys keep their positions ascending —, the runs of
+  // the sorted keys, and a prefix sum of their lengths.  The list-building dedup below is a hash table with
+  // two device atomics per key and five launches over all n keys; the sort moves 8 bytes per key and pass
+  // and needs no atomic per key: 1 M keys 330 -> ≈ 70 us (profiles/r05/pooling_group_ab.md).  Keys come out
+  // ascending instead of in first-occurrence order; the consumers write one output row per key and do not
+  // care.  The sort, the run-length encoding and the scan are rocPRIM's through hipCUB (library primitives,
+  // as hipBLASLt would be for a plain GEMM); keys outside the range are dropped, which is what the
+  // consumers did with them.  MHTE_GROUP_DD=1 keeps the dedup form (A/B).
+  DevBuf<uint32_t> k32a, k32b, posa, runs_key, runs_len, nruns;
+  DevBuf<char> cub_tmp;
+  static bool use_sort() {
+    static const bool dd_form = getenv("MHTE_GROUP_DD") != nullptr && atoi(getenv("MHTE_GROUP_DD")) != 0;
+    return !dd_form;
+  }
+  void group_sorted(const int64_t* k, int64_t n, int key_bits, hipStream_t st) {
+    if (key_bits < 1) key_bits = 1;
+    if (!use_sort() || key_bits > 31 || n > int64_t(0x7fffffff)) {
+      group(k, n, st);
+      return;
+    }
+    uids.reserve(size_t(n) + 1);
+    seg_off.reserve(size_t(n) + 2);
+    seg_pos.reserve(size_t(n) + 1);
+    nu.reserve(4);
+    k32a.reserve(size_t(n));
+    k32b.reserve(size_t(n));
+    posa.reserve(size_t(n));
+    runs_key.reserve(size_t(n) + 1);
+    runs_len.reserve(size_t(n) + 2);
+    nruns.reserve(4);
+    const uint32_t limit = 1u << key_bits;
+    const int ni = int(n);
+    group_keys32_kernel<<<dim3(uint32_t((n + 255) / 256)), 256, 0, st>>>(k, n, limit, k32a.p, posa.p);
+    HIP_OK(hipGetLastError());
+    size_t t1 = 0, t2 = 0, t3 = 0;
+    // (rocPRIM's default picks a merge sort up to 1 M items — ten merge passes of two launches each, 150 us for
+    // exactly 1 M pairs; the Onesweep radix sort is what this wants at every size)
+    using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                               rocprim::default_config, 4096>;
+    HIP_OK(rocprim::radix_sort_pairs<SortCfg>(nullptr, t1, k32a.p, k32b.p, posa.p, seg_pos.p, size_t(ni), 0u,
+                                              unsigned(key_bits + 1), st));
+    HIP_OK(hipcub::DeviceRunLengthEncode::Encode(nullptr, t2, k32b.p, runs_key.p, runs_len.p, nruns.p, ni, st));
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, t3, runs_len.p, seg_off.p, ni + 1, st));
+    cub_tmp.reserve(std::max(t1, std::max(t2, t3)) + 256);
+    size_t tb = cub_tmp.cap;
+    HIP_OK(rocprim::radix_sort_pairs<SortCfg>(cub_tmp.p, tb, k32a.p, k32b.p, posa.p, seg_pos.p, size_t(ni), 0u,
+                                              unsigned(key_bits + 1), st));
+    // (run lengths beyond the run count are never read by a consumer, but the scan walks n + 1 of them)
+    HIP_OK(hipMemsetAsync(runs_len.p, 0, (size_t(n) + 2) * sizeof(uint32_t), st));
+    tb = cub_tmp.cap;
+    HIP_OK(hipcub::DeviceRunLengthEncode::Encode(cub_tmp.p, tb, k32b.p, runs_key.p, runs_len.p, nruns.p, ni, st));
+    tb = cub_tmp.cap;
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp.p, tb, runs_len.p, seg_off.p, ni + 1, st));
+    group_finish_kernel<<<dim3(uint32_t(std::min<int64_t>((n + 255) / 256, 1024))), 256, 0, st>>>(
+        runs_key.p, nruns.p, limit, uids.p, nu.p);
+    HIP_OK(hipGetLastError());
+  }
   // distinct keys + their positions in ascending order -> uids / seg_off / seg_pos / nu
   void group(const int64_t* k, int64_t n, hipStream_t st) {
     uids.reserve(size_t(n) + 1);
@@ -2081,8 +2140,10 @@ static int current_device() {
 template <bool GATHER>
 static void fused_gather(float* fused, int32_t n_inputs, const int32_t* const* offsets,
                          const int64_t* n, const int32_t* dims, float* const* rows, float scale,
-                         hipStream_t st) {
+                         hipStream_t st, int64_t fused_len = int64_t(1) << 31) {
   if (n_inputs < 0) throw Error(MHTE_INVALID_ARGUMENT, "n_inputs must be >= 0");
+  int key_bits = 1;   // (offsets are int32 and lie inside the fused buffer)
+  while (key_bits < 31 && (int64_t(1) << key_bits) < fused_len) ++key_bits;
   for (int32_t i0 = 0; i0 < n_inputs; i0 += kMaxGatherInputs) {
     GatherInputs in{};
     in.n_inputs = std::min<int32_t>(kMaxGatherInputs, n_inputs - i0);
@@ -2108,9 +2169,15 @@ static void fused_gather(float* fused, int32_t n_inputs, const int32_t* const* o
       AuxWs::Use use_(ws, st);
       ws.keys.reserve(size_t(acc));
       gather_keys_kernel<<<dim3(uint32_t((acc + 255) / 256)), 256, 0, st>>>(in, ws.keys.p);
-      ws.group(ws.keys.p, acc, st);
-      gather_grad_lists_kernel<<<dim3(uint32_t((acc * 8 + 255) / 256)), 256, 0, st>>>(
-          fused, in, scale, ws.uids.p, ws.nu.p, ws.seg_off.p, ws.seg_pos.p);
+      ws.group_sorted(ws.keys.p, acc, key_bits, st);   // (a key is a float offset into the fused buffer)
+      bool vec = in.aligned != 0;
+      for (int32_t k = 0; k < in.n_inputs; ++k) vec = vec && (in.dim[k] & 3) == 0;
+      if (vec)
+        gather_grad_lists_vec_kernel<<<dim3(uint32_t(((acc + kGatherGradKeys - 1) / kGatherGradKeys * 16 + 255) / 256)), 256, 0, st>>>(
+            fused, in, scale, ws.uids.p, ws.nu.p, ws.seg_off.p, ws.seg_pos.p);
+      else
+        gather_grad_lists_kernel<<<dim3(uint32_t((acc * 8 + 255) / 256)), 256, 0, st>>>(
+            fused, in, scale, ws.uids.p, ws.nu.p, ws.seg_off.p, ws.seg_pos.p);
       HIP_OK(hipGetLastError());
       continue;
     }
@@ -2140,9 +2207,16 @@ mhte_status mhte_fused_gather_embeddings_by_input_gradient(float* fused_grad, in
                                                            float scale, void* stream) {
   return guard([&] {
     if (fused_len < 0) throw Error(MHTE_INVALID_ARGUMENT, "fused_len must be >= 0");
-    if (fused_len) HIP_OK(hipMemsetAsync(fused_grad, 0, size_t(fused_len) * sizeof(float), S(stream)));
+    if (fused_len) {   // (16-byte stores from a full grid: hipMemsetAsync moves a large buffer at 1.3 TB/s)
+      LayoutZeroArgs Z{};
+      Z.p[0] = fused_grad;
+      Z.len[0] = uint64_t(fused_len);
+      const uint32_t gx = uint32_t(std::min<uint64_t>(2048, (uint64_t(fused_len) + 4095) / 4096));
+      layout_zero_args_kernel<<<dim3(gx, 1), 256, 0, S(stream)>>>(Z);
+      HIP_OK(hipGetLastError());
+    }
     fused_gather<false>(fused_grad, n_inputs, offsets, n, dims, const_cast<float* const*>(grads),
-                        scale, S(stream));
+                        scale, S(stream), fused_len > 0 ? fused_len : 1);
   });
 }
 
@@ -2196,7 +2270,10 @@ mhte_status mhte_reduce_rows(const int64_t* indices, const float* values, int64_
         AuxWs& ws = AuxWs::of(current_device());
         std::lock_guard<std::mutex> g(ws.mu);
         AuxWs::Use use_(ws, st);
-        ws.group(indices, n, st);
+        int bits = 1;
+        while (bits < 31 && (int64_t(1) << bits) < batch) ++bits;   // (an index is a row of `out`: < batch)
+        if ((int64_t(1) << bits) >= batch) ws.group_sorted(indices, n, bits, st);
+        else ws.group(indices, n, st);
         const dim3 grid(uint32_t((n * 16 + 255) / 256));
         if (dim % 4 == 0 && aligned16(values) && aligned16(out))
           reduce_rows_lists_kernel<4><<<grid, 256, 0, st>>>(ws.uids.p, ws.nu.p, ws.seg_off.p, ws.seg_pos.p, values,

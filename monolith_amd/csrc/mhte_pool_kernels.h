@@ -238,6 +238,26 @@ __global__ __launch_bounds__(256) void reduce_rows_lists_kernel(const int64_t* _
   }
 }
 
+// ---- grouping rows by a bounded key with a stable radix sort (AuxWs::group_sorted, round 5) ----------
+// keys in [0, limit) -> 32-bit sort keys, everything else -> `limit` (sorted last, dropped); value = position
+__global__ __launch_bounds__(256) void group_keys32_kernel(const int64_t* __restrict__ k, int64_t n, uint32_t limit,
+                                                           uint32_t* __restrict__ k32, uint32_t* __restrict__ pos) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = k[i];
+  k32[i] = (v >= 0 && v < int64_t(limit)) ? uint32_t(v) : limit;
+  pos[i] = uint32_t(i);
+}
+// runs of the sorted keys -> the int64 key list the consumers read; the run of dropped keys is cut off
+__global__ __launch_bounds__(256) void group_finish_kernel(const uint32_t* __restrict__ uniq,
+                                                           const uint32_t* __restrict__ nruns, uint32_t limit,
+                                                           int64_t* __restrict__ uids, uint32_t* __restrict__ nu) {
+  const uint32_t n = *nruns;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    uids[i] = int64_t(uniq[i]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *nu = (n && uniq[n - 1] == limit) ? n - 1u : n;
+}
+
 // gradient of FusedGatherEmbeddingsByInput without atomics: key of global row r = its float offset
 __global__ __launch_bounds__(256) void gather_keys_kernel(GatherInputs in, int64_t* __restrict__ keys) {
   const int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -250,6 +270,133 @@ __global__ __launch_bounds__(256) void gather_keys_kernel(GatherInputs in, int64
 // reference scales every addend (map_id_to_embedding.cu.cc:98-107), then added to fused_grad (plain
 // read-modify-write: one group owns the destination; launches of further input chunks follow in
 // stream order)
+// ... the same with 16 lanes per key moving float4s (every input's rows and the fused buffer 16-byte
+// aligned, every dim a multiple of 4 — the host checks): the scalar form below walks a row 8 floats at a
+// time and looks the input of every addend up in the kernel-argument table again for every pass (219 us for
+// 1 M keys of one row each); here the input table sits in LDS, a lane keeps one float4 column of the row, and
+// the addends of a key are fetched four at a time.  Same arithmetic: acc = acc + x * scale in row order, then
+// one read-modify-write of the destination.
+constexpr int kGatherGradKeys = 4;   // keys a lane group works on at once (their round trips overlap)
+__global__ __launch_bounds__(256) void gather_grad_lists_vec_kernel(float* __restrict__ fused, GatherInputs in,
+                                                                    float scale,
+                                                                    const int64_t* __restrict__ keys,
+                                                                    const uint32_t* __restrict__ n_keys,
+                                                                    const uint32_t* __restrict__ seg_off,
+                                                                    const uint32_t* __restrict__ seg_pos) {
+  constexpr int G = 16, K = kGatherGradKeys;
+  __shared__ long long s_start[kMaxGatherInputs + 1];
+  __shared__ const float* s_rows[kMaxGatherInputs];
+  __shared__ int s_dim[kMaxGatherInputs];
+  if (threadIdx.x <= uint32_t(in.n_inputs)) s_start[threadIdx.x] = in.start[threadIdx.x];
+  if (threadIdx.x < uint32_t(in.n_inputs)) {
+    s_rows[threadIdx.x] = in.rows[threadIdx.x];
+    s_dim[threadIdx.x] = in.dim[threadIdx.x];
+  }
+  __syncthreads();
+  const int j = threadIdx.x & (G - 1);
+  const int64_t nk = int64_t(*n_keys);
+  const int n_in = in.n_inputs;
+  auto input_of = [&](long long r) {
+    int i = 0;
+    while (i + 1 < n_in && s_start[i + 1] <= r) ++i;
+    return i;
+  };
+  // group g of the grid takes keys g * K .. g * K + K - 1: a wavefront that handled one key per lane group
+  // lived for four dependent round trips and moved 4 x 256 bytes (206 us for 1 M keys: 32 rounds of
+  // wavefronts); with K keys per group the same round trips carry K times the rows
+  const int64_t u0 = ((int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G) * K;
+  if (u0 >= nk) return;
+  int64_t off[K];
+  uint32_t s0[K], s1[K];
+#pragma unroll
+  for (int t = 0; t < K; ++t) {   // round trip 1: key and list bounds of the K keys
+    const int64_t u = min(u0 + t, nk - 1);
+    off[t] = keys[u];
+    s0[t] = seg_off[u];
+    s1[t] = (u0 + t < nk) ? seg_off[u + 1] : s0[t];   // (a key past the end: an empty list)
+  }
+  long long r0[K];
+#pragma unroll
+  for (int t = 0; t < K; ++t) r0[t] = seg_pos[s0[t] < s1[t] ? s0[t] : 0u];   // round trip 2: first row of each
+  int i0[K], dim[K];
+  bool fast[K];   // one addend, aligned destination: the common shape — everything of the K keys in flight
+#pragma unroll
+  for (int t = 0; t < K; ++t) {
+    i0[t] = input_of(r0[t]);
+    dim[t] = s_dim[i0[t]];
+    fast[t] = s1[t] == s0[t] + 1u && (off[t] & 3) == 0 && dim[t] <= G * 4;
+  }
+  Vec<4> v[K], f[K];
+#pragma unroll
+  for (int t = 0; t < K; ++t) {   // round trip 3: the row and the destination of every fast key
+    vec_zero(v[t]);
+    vec_zero(f[t]);
+    if (fast[t] && j * 4 < dim[t]) {
+      v[t].load(s_rows[i0[t]] + (r0[t] - s_start[i0[t]]) * dim[t] + j * 4);
+      f[t].load(fused + off[t] + j * 4);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < K; ++t) {
+    if (fast[t] && j * 4 < dim[t]) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) f[t].v[c] = f[t].v[c] + (0.f + v[t].v[c] * scale);
+      f[t].store(fused + off[t] + j * 4);
+    }
+  }
+  // the other keys (several addends, an unaligned destination, a row wider than the group): one at a time
+#pragma unroll 1
+  for (int t = 0; t < K; ++t) {
+    if (fast[t] || s0[t] >= s1[t]) continue;
+    const int64_t o = off[t];
+    const int d0 = dim[t];
+    if (o & 3) {   // a destination that is not 16-byte aligned: one float per lane
+      for (int k = j; k < d0; k += G) {
+        float acc = 0.f;
+        for (uint32_t q = s0[t]; q < s1[t]; ++q) {
+          const long long r = seg_pos[q];
+          const int i = input_of(r);
+          if (k < s_dim[i]) acc += s_rows[i][(r - s_start[i]) * s_dim[i] + k] * scale;
+        }
+        fused[o + k] += acc;
+      }
+      continue;
+    }
+    for (int k = j * 4; k < d0; k += G * 4) {
+      Vec<4> acc;
+      vec_zero(acc);
+      for (uint32_t q = s0[t]; q < s1[t]; q += 4) {
+        Vec<4> w[4];
+        bool has[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          vec_zero(w[x]);
+          has[x] = false;
+          if (q + x < s1[t]) {
+            const long long r = seg_pos[q + x];
+            const int i = input_of(r);
+            const int d = s_dim[i];
+            if (k < d) {
+              w[x].load(s_rows[i] + (r - s_start[i]) * d + k);
+              has[x] = true;
+            }
+          }
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+          if (has[x]) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc.v[c] = acc.v[c] + w[x].v[c] * scale;
+          }
+      }
+      Vec<4> g2;
+      g2.load(fused + o + k);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) g2.v[c] = g2.v[c] + acc.v[c];
+      g2.store(fused + o + k);
+    }
+  }
+}
 __global__ __launch_bounds__(256) void gather_grad_lists_kernel(float* __restrict__ fused, GatherInputs in,
                                                                 float scale,
                                                                 const int64_t* __restrict__ keys,
