@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void layout_copy_kernel(LayoutArgs A) {
 // every lane moves 16 bytes, kLayoutRowsUnroll independent loads in flight per lane.
 constexpr int kLayoutRowsR = 16;
 constexpr int kLayoutRowsMaxF = 2048;   // float4 columns of one batch row over the launch's slices
-constexpr int kLayoutRowsUnroll = 4;
+constexpr int kLayoutRowsUnroll = 8;
 template <bool FORWARD>
 __global__ __launch_bounds__(256) void layout_rows_kernel(LayoutArgs A) {
   constexpr int R = kLayoutRowsR;
@@ -225,19 +225,21 @@ __global__ __launch_bounds__(256) void layout_rows_kernel(LayoutArgs A) {
     s_ctask[c] = uint8_t(lo);
   }
   __syncthreads();
-  const uint32_t total = uint32_t(R) * F;
-  for (uint32_t i0 = threadIdx.x; i0 < total; i0 += 256u * kLayoutRowsUnroll) {
-    Vec<4> v[kLayoutRowsUnroll];
-    float* to[kLayoutRowsUnroll];
+  // a thread keeps its float4 column (slice and offset inside it: looked up once) and walks the workgroup's
+  // rows, kLayoutRowsUnroll of them in flight; for a given row consecutive lanes are consecutive columns
+  for (uint32_t c = threadIdx.x; c < F; c += 256u) {
+    const uint32_t q = s_ctask[c];
+    const uint32_t e = (c - s_cstart[q]) * 4u;
+    const unsigned long long* const srcs = s_src + q * R;
+    const unsigned long long* const dsts = s_dst + q * R;
 #pragma unroll
-    for (int u = 0; u < kLayoutRowsUnroll; ++u) {
-      const uint32_t i = i0 + uint32_t(u) * 256u;
-      to[u] = nullptr;
-      if (i < total) {
-        const uint32_t r = i / F, c = i - r * F;
-        const uint32_t q = s_ctask[c];
-        const uint32_t e = (c - s_cstart[q]) * 4u;
-        const unsigned long long src = s_src[q * R + r], dst = s_dst[q * R + r];
+    for (int r0 = 0; r0 < R; r0 += kLayoutRowsUnroll) {
+      Vec<4> v[kLayoutRowsUnroll];
+      float* to[kLayoutRowsUnroll];
+#pragma unroll
+      for (int u = 0; u < kLayoutRowsUnroll; ++u) {
+        const unsigned long long src = srcs[r0 + u], dst = dsts[r0 + u];
+        to[u] = nullptr;
         if (src > 1ull) {
           float* const ep = reinterpret_cast<float*>(src) + e;
           float* const op = reinterpret_cast<float*>(dst) + e;
@@ -248,10 +250,10 @@ __global__ __launch_bounds__(256) void layout_rows_kernel(LayoutArgs A) {
           to[u] = reinterpret_cast<float*>(dst) + e;
         }
       }
-    }
 #pragma unroll
-    for (int u = 0; u < kLayoutRowsUnroll; ++u)
-      if (to[u]) v[u].store(to[u]);
+      for (int u = 0; u < kLayoutRowsUnroll; ++u)
+        if (to[u]) v[u].store(to[u]);
+    }
   }
 }
 
