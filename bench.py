@@ -769,15 +769,21 @@ def main():
     fid = ((ranks * mult) & ((1 << 48) - 1)) | (1 << 48)
     if world > 1:
       fid = fid[torch.remainder(fid, world) == rank]
-    n = min(fid.numel(), resident - filled)
-    fid = fid[:n].contiguous()
-    rg = mt.get_ragged_id({"emb": fid})
-    _lib.check(mt._lib.mhte_assign(mt.handle, _lib.vp(fid),
-                                   rg.row_splits.ctypes.data_as(_lib.C.POINTER(_lib.C.c_int64)),
-                                   _lib.C.c_int64(2), _lib.vp(zeros), _lib.C.c_int64(n * D),
-                                   _lib.C.c_int64(S.update_time(0)),
-                                   _lib.C.c_int32(_lib.MHTE_IDS_UNIQUE), None))
-    filled += n
+    # (about `chunk` of the chunk * world candidates are this rank's — by chance a few more, and the rows
+    # buffer holds `chunk`: they go in pieces.  Taking them in one call read past the buffer: a memory fault
+    # waiting for the right neighbour, seen with three ranks)
+    for o in range(0, fid.numel(), chunk):
+      n = min(fid.numel() - o, chunk, resident - filled)
+      if n <= 0:
+        break
+      part = fid[o:o + n].contiguous()
+      rg = mt.get_ragged_id({"emb": part})
+      _lib.check(mt._lib.mhte_assign(mt.handle, _lib.vp(part),
+                                     rg.row_splits.ctypes.data_as(_lib.C.POINTER(_lib.C.c_int64)),
+                                     _lib.C.c_int64(2), _lib.vp(zeros), _lib.C.c_int64(n * D),
+                                     _lib.C.c_int64(S.update_time(0)),
+                                     _lib.C.c_int32(_lib.MHTE_IDS_UNIQUE), None))
+      filled += n
   torch.cuda.synchronize()
   del zeros
   torch.cuda.empty_cache()
