@@ -332,10 +332,11 @@ def main_dlrm(args):
   if sharded:
     # every table through the id-sharded step with one rank: the floor of the multi-GPU step
     from monolith_amd.distributed_ps_sync import ShardedMultiStep
+    # (overlap is a creation-time choice: with the peer-store transport the wire mode is part of what the
+    # ranks agree on at connect, and the direct-store form refuses a change behind it)
     step = ShardedMultiStep(mt, B, ids_per_peer_table=args.ids_per_peer,
-                            transport="ipc" if args.transport == "ipc" else "auto")
-    if args.overlap:
-      step.set_overlap(True)
+                            transport="ipc" if args.transport == "ipc" else "auto",
+                            overlap=True if args.overlap else None)
   else:
     step = MultiSparseStep(mt, B, exact_order=args.exact_order)
   applied = []
