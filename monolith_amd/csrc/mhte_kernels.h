@@ -419,14 +419,17 @@ struct FilterProbe {
   static constexpr int PERW = (kFilterProbe + G - 1) / G;   // window slots per lane (2 with 8 lanes)
   uint32_t w[(kFilterForward + kFilterBack) * PERW];
 };
+// (back0: the first of the older splits to fetch — 0 = the one right behind the head; a filter with more than
+// kFilterBack older splits is walked kFilterBack at a time)
 template <int G>
 __device__ __forceinline__ FilterProbe<G> filter_probe_issue(const TableView& tv, int64_t id, bool active, int j,
-                                                             uint32_t head, uint32_t hinc) {
+                                                             uint32_t head, uint32_t hinc, uint32_t back0 = 0u) {
   FilterProbe<G> fp;
   constexpr int PERW = FilterProbe<G>::PERW;
   const uint32_t S = tv.flt_nsplit;
   const uint64_t home = active ? filter_home(id, tv.flt_total) : 0ull;
-  const uint32_t nb = min(min(hinc, S - uint32_t(kFilterForward)), uint32_t(kFilterBack));
+  const uint32_t nb_all = min(hinc, S - uint32_t(kFilterForward));
+  const uint32_t nb = nb_all > back0 ? min(nb_all - back0, uint32_t(kFilterBack)) : 0u;
 #pragma unroll
   for (int s = 0; s < kFilterForward; ++s) {
     const uint32_t* split = tv.flt_slots + size_t((head + uint32_t(s)) % S) * tv.flt_stride + home;
@@ -441,7 +444,7 @@ __device__ __forceinline__ FilterProbe<G> filter_probe_issue(const TableView& tv
 #pragma unroll
   for (int i = 0; i < kFilterBack; ++i) {
     if (uint32_t(i) < nb) {
-      const uint32_t sp = (head + S - 1u - uint32_t(i)) % S;
+      const uint32_t sp = (head + S - 1u - ((back0 + uint32_t(i)) % S)) % S;
       const uint32_t* split = tv.flt_slots + size_t(sp) * tv.flt_stride + home;
 #pragma unroll
       for (int q = 0; q < PERW; ++q)
@@ -474,79 +477,105 @@ __device__ __forceinline__ int filter_window_first(const FilterProbe<G>& fp, int
   *word = v;
   return p;
 }
-// Every lane of the group calls this (group-uniform arguments; `act`: the group has an id to ask
-// about — the ballots inside run whatever `act` says; `serial`: the windows in `fp` are not this
-// id's (a hint that failed after they were fetched; a probabilistic filter, which has none) — lane 0
-// asks the serial form).  Returns what filter_consult returns, in every lane of the group.
+// Every lane of the group calls this (group-uniform arguments; `act`: the group has an id to ask about — the
+// ballots inside run whatever `act` says; `have`: `fp` holds this id's windows, fetched ahead — otherwise (a
+// hint that failed after the fetch, a caller that did not fetch) the first pass fetches them).  A CAS that lost
+// its slot, and older splits beyond the kFilterBack fetched at a time, go round the loop again with fresh
+// windows (HashFilter's own retry; no second, serial copy of the walk in the kernel).  Returns what
+// filter_consult returns, in every lane of the group.
 template <int G>
 __device__ __forceinline__ uint32_t filter_consult_group(const TableView& tv, int64_t id, uint32_t k, int mode,
-                                                         bool contained, bool act, bool serial,
-                                                         const FilterProbe<G>& fp, int j, int gbase, uint32_t head,
+                                                         bool contained, bool act, bool have,
+                                                         FilterProbe<G> fp, int j, int gbase, uint32_t head,
                                                          uint32_t hinc) {
+  const int32_t thr_i = occurrence_threshold(tv, id);
+  if (tv.flt_nsplit == 0u) {   // probabilistic filter (stateless): lane 0 draws
+    uint32_t f0 = 0;
+    if (act && j == 0 && k != 0) f0 = prob_consult(tv, id, k, mode, contained, uint32_t(thr_i < 0 ? 0 : thr_i));
+    return __shfl(f0, gbase);
+  }
   const uint32_t S = tv.flt_nsplit;
   const uint32_t sign = filter_sign(id);
-  // the windows, replayed on the loaded words (ballots: all lanes, before anything diverges)
-  uint32_t v0, v1;
-  const int p0 = filter_window_first<G>(fp, 0, sign, j, gbase, &v0);
-  const int p1 = filter_window_first<G>(fp, 1, sign, j, gbase, &v1);
-  const uint32_t nb_all = S >= uint32_t(kFilterForward) ? min(hinc, S - uint32_t(kFilterForward)) : 0u;
-  const uint32_t nb = min(nb_all, uint32_t(kFilterBack));
-  uint32_t old_count = 0;
-  bool older_found = false;
-#pragma unroll
-  for (int i = 0; i < kFilterBack; ++i) {
-    uint32_t wv;
-    const int p = filter_window_first<G>(fp, kFilterForward + i, sign, j, gbase, &wv);
-    if (uint32_t(i) < nb && !older_found && p >= 0 && wv != 0u) {   // (an empty slot first: not in this split)
-      old_count = wv & kFilterMaxCount;
-      older_found = true;
+  const uint32_t thr = uint32_t(thr_i > 0 ? thr_i : 0);
+  const uint32_t nb_all = min(hinc, S - uint32_t(kFilterForward));
+  bool pending = act && k != 0 && thr_i > 0 && !(contained && mode != 3);   // (group-uniform)
+  uint32_t first = 0, back0 = 0;
+  auto decide = [&](uint32_t c0, uint32_t* f1, uint32_t* adds) {
+    if (mode == 2) {
+      *f1 = (c0 < thr) ? k : 0u;
+      *adds = k;
+    } else if (mode == 3) {
+      *f1 = (c0 >= thr) ? 0u : min(k, thr - c0);
+      *adds = k;
+    } else {
+      *f1 = (c0 >= thr) ? 0u : (thr - c0);
+      *adds = min(k, *f1 + 1u);
+      *f1 = min(*f1, k);
     }
-  }
-  uint32_t first = 0;
-  bool ask = act && j == 0 && k != 0;
-  if (ask && !serial) {
-    const int32_t thr_i = occurrence_threshold(tv, id);
-    if (thr_i > 0 && !(contained && mode != 3)) {
-      const uint32_t thr = uint32_t(thr_i);
+  };
+#pragma unroll 1
+  for (int attempt = 0; attempt < 256 && __any(pending); ++attempt) {
+    if (__any(pending && !have)) {
+      const FilterProbe<G> f2 = filter_probe_issue<G>(tv, id, pending && !have, j, head, hinc, back0);
+      if (pending && !have) fp = f2;
+    }
+    have = false;   // (whatever happens below, a further pass needs fresh windows)
+    // the windows, replayed on the loaded words (ballots: every lane of the wavefront)
+    uint32_t v0, v1;
+    const int p0 = filter_window_first<G>(fp, 0, sign, j, gbase, &v0);
+    const int p1 = filter_window_first<G>(fp, 1, sign, j, gbase, &v1);
+    const uint32_t nb = nb_all > back0 ? min(nb_all - back0, uint32_t(kFilterBack)) : 0u;
+    uint32_t old_count = 0;
+    bool older_found = false;
+#pragma unroll
+    for (int i = 0; i < kFilterBack; ++i) {
+      uint32_t wv;
+      const int p = filter_window_first<G>(fp, kFilterForward + i, sign, j, gbase, &wv);
+      if (uint32_t(i) < nb && !older_found && p >= 0 && wv != 0u) {   // (an empty slot first: not in this split)
+        old_count = wv & kFilterMaxCount;
+        older_found = true;
+      }
+    }
+    // lane 0 of a pending group acts; status: 0 = settled, 1 = look again from the head, 2 = the next older splits
+    uint32_t status = 0, f1 = 0;
+    if (pending && j == 0) {
       FilterState* fs = reinterpret_cast<FilterState*>(tv.flt_state);
       const uint64_t home = filter_home(id, tv.flt_total);
-      auto decide = [&](uint32_t c0, uint32_t* f1, uint32_t* adds) {
-        if (mode == 2) {
-          *f1 = (c0 < thr) ? k : 0u;
-          *adds = k;
-        } else if (mode == 3) {
-          *f1 = (c0 >= thr) ? 0u : min(k, thr - c0);
-          *adds = k;
-        } else {
-          *f1 = (c0 >= thr) ? 0u : (thr - c0);
-          *adds = min(k, *f1 + 1u);
-          *f1 = min(*f1, k);
-        }
-      };
       const int pos = p0 >= 0 ? p0 : p1;
       const uint32_t sp = (head + (p0 >= 0 ? 0u : 1u)) % S;
       const uint32_t v = p0 >= 0 ? v0 : v1;
       uint32_t adds;
       if (pos < 0) {                                   // no usable slot: "seen max_count times"
         atomicAdd(&fs->failure_count, 1ull);
-        decide(kFilterMaxCount, &first, &adds);
-      } else if (v == 0u && nb_all > nb && !older_found) {
-        serial = true;                                 // older splits beyond the fetched ones
+        decide(kFilterMaxCount, &f1, &adds);
+      } else if (v == 0u && !older_found && back0 + nb < nb_all) {
+        status = 2;                                    // older splits beyond the fetched ones
       } else {
         uint32_t* slot = tv.flt_slots + size_t(sp) * tv.flt_stride + home + uint32_t(pos);
         const uint32_t c0 = v != 0u ? (v & kFilterMaxCount) : old_count;
-        decide(c0, &first, &adds);
+        decide(c0, &f1, &adds);
         const uint32_t c1 = min(kFilterMaxCount, c0 + min(adds, kFilterMaxCount));
         if (atomicCAS(slot, v, (sign << 4) | c1) == v) {
           if (v == 0u) atomicAdd(&fs->num_elements[sp][(home & uint64_t(kFilterWays - 1)) * kFilterWayStride], 1u);
         } else {
-          serial = true;                               // the slot changed meanwhile: look again
+          status = 1;                                  // the slot changed meanwhile: look again
         }
       }
     }
+    status = __shfl(status, gbase);
+    f1 = __shfl(f1, gbase);
+    if (pending) {
+      if (status == 0u) {
+        first = f1;
+        pending = false;
+      } else if (status == 1u) {
+        back0 = 0;
+      } else {
+        back0 += uint32_t(kFilterBack);
+      }
+    }
   }
-  if (ask && serial) first = filter_consult(tv, id, k, mode, contained);
-  return __shfl(first, gbase);
+  return first;
 }
 
 // SlidingHashFilter::get (:93-114)

@@ -1545,8 +1545,8 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
           if (hinted) contained = true;
           uint32_t first = 0;
           if constexpr (FILT == 1) {
-            // (a group whose hint failed fetched no windows, a probabilistic filter has none: serial form)
-            first = filter_consult_group<G>(tv, id, cnt, 2, contained, valid, !fgroup || !fact, fp, j, gbase, fhead,
+            // (a group whose hint failed fetched no windows: the consultation fetches them itself)
+            first = filter_consult_group<G>(tv, id, cnt, 2, contained, valid, fgroup && fact, fp, j, gbase, fhead,
                                             fhinc);
           } else {
             if (valid && j == 0) first = filter_consult(tv, id, cnt, 2, contained);
@@ -1848,8 +1848,20 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
           if (valid && hd.id == kEmptyKey) contained = tv.ctr->special_state == 1;
           if (hok) contained = true;
           uint32_t first = 0;
-          if (valid && j == 0) first = filter_consult(tv, hd.id, d.ucnt[hd.u], 2, contained);
-          if (__shfl(first, gbase) != 0u) valid = false;
+          if constexpr (FILT == 1) {   // (the lane group's form: no second, serial copy of the walk in the kernel)
+            uint32_t ih = 0, ii = 0;
+            if (tv.flt_nsplit != 0u) {
+              const FilterState* fs0 = reinterpret_cast<const FilterState*>(tv.flt_state);
+              ih = fs0->head;
+              ii = fs0->head_increment;
+            }
+            FilterProbe<G> fp0;   // (not fetched ahead here: the consultation's first pass does it)
+            first = filter_consult_group<G>(tv, hd.id, d.ucnt[hd.u], 2, contained, valid, false, fp0, j, gbase, ih, ii);
+          } else {
+            if (valid && j == 0) first = filter_consult(tv, hd.id, d.ucnt[hd.u], 2, contained);
+            first = __shfl(first, gbase);
+          }
+          if (first != 0u) valid = false;
         }
       }
       SlotResult sr;

@@ -367,6 +367,45 @@ def _filter_table(flt, thr):
   return MultiHashTable.from_configs({"t": cfg}, name_suffix=_name(), hash_filter=flt)
 
 
+def test_pipelined_step_consults_a_filter_with_many_splits_like_the_model():
+  """The fused step's lane-group consultation (filter_consult_group) over a filter of 12 splits: it fetches the
+  windows of 6 older splits at a time, so an id whose last count lies further back — or nowhere — takes the
+  second pass; a single id per launch makes every add comparable with the restatement, add by add.  Counts and
+  admissions against oracle.SlidingFilter while the window goes round more than once."""
+  from monolith_amd.fused_step import SparseStep
+  thr = 3
+  flt = HashFilter(capacity=330, split_num=12)            # 12 splits of 30
+  mt = _filter_table(flt, thr)
+  model = SlidingModel(330, 12)
+  rng = np.random.default_rng(11)
+  universe = (rng.integers(1, 2**40, 1200).astype(np.int64) | (1 << 48))
+  seq = []
+  for k in range(900):
+    # a drifting working set with a long memory: ids come back after the window has moved many splits on
+    lo = k // 2
+    back = int(rng.integers(0, 60)) if rng.random() < 0.7 else int(rng.integers(0, 400))
+    seq.append(int(universe[max(0, lo + 30 - back)]))
+  dev = [ids_t([f]) for f in seq] + [ids_t([seq[-1]])]
+  step = SparseStep(mt, "t", 1, exact_order=True)
+  g1 = val_t([[1.0]])
+  admitted = set()
+  for i, fid in enumerate(seq):
+    step.forward(dev[i], next_ids=dev[i + 1])
+    step.backward(g1, 1_700_000_000 + i)
+    if fid not in admitted:
+      if model.add(fid, 1) >= thr:
+        admitted.add(fid)
+      model.advance_if_full()
+    if i % 150 == 149 or i == len(seq) - 1:
+      probe = np.unique(np.array(seq[:i + 1], dtype=np.int64))
+      got = flt.get(ids_t(probe)).cpu().numpy()
+      np.testing.assert_array_equal(got, [model.get(int(x)) for x in probe], err_msg="step %d" % i)
+      present = mt.contains("t", ids_t(probe)).cpu().numpy()
+      np.testing.assert_array_equal(present, [int(x) in admitted for x in probe])
+  st = model.state()
+  assert st["head_increment"] > 12 and len(admitted) > 20
+
+
 def test_sliding_hash_filter_window_against_model(tmp_path):
   """Ids seen again and again while the window moves on (capacity 300 -> 5 splits of 75): counts
   carry over from older splits, fall out of the window after nsplit - 2 moves, and the table admits
