@@ -193,7 +193,9 @@ static unsigned long long* trace_region(int32_t tag, uint32_t grid, uint32_t blo
   return p;
 }
 struct Prof {
-  std::vector<hipEvent_t> ev;  // 2 per recorded launch
+  std::vector<hipEvent_t> ev;  // 2 per recorded launch, created when the pass is armed (creating them at the
+                               // launch made the timed launches the slowest to enqueue: on a slow host the
+                               // queue drained between them and the kernels themselves ran slower)
   std::vector<int32_t> tag;
   int32_t armed = 0;
 };
@@ -202,13 +204,9 @@ static thread_local Prof g_prof;
 #define LAUNCH_HOT(TAG, KERNEL, GRID, BLOCK, ST, ...)                                          \
   do {                                                                                         \
     if (g_prof.armed > 0) {                                                                    \
-      hipEvent_t e0__, e1__;                                                                   \
-      HIP_OK(hipEventCreate(&e0__));                                                           \
-      HIP_OK(hipEventCreate(&e1__));                                                           \
-      hipExtLaunchKernelGGL((KERNEL), dim3(GRID), dim3(BLOCK), 0, (ST), e0__, e1__, 0,         \
-                            __VA_ARGS__);                                                      \
-      g_prof.ev.push_back(e0__);                                                               \
-      g_prof.ev.push_back(e1__);                                                               \
+      const size_t i__ = g_prof.tag.size();                                                    \
+      hipExtLaunchKernelGGL((KERNEL), dim3(GRID), dim3(BLOCK), 0, (ST), g_prof.ev[2 * i__],    \
+                            g_prof.ev[2 * i__ + 1], 0, __VA_ARGS__);                           \
       g_prof.tag.push_back(TAG);                                                               \
       --g_prof.armed;                                                                          \
     } else {                                                                                   \
@@ -4791,6 +4789,10 @@ mhte_status mhte_profile_arm(int32_t n) {
     for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
     g_prof.ev.clear();
     g_prof.tag.clear();
+    g_prof.armed = 0;
+    g_prof.ev.resize(size_t(2 * n), nullptr);
+    for (auto& e : g_prof.ev) HIP_OK(hipEventCreate(&e));
+    g_prof.tag.reserve(size_t(n));
     g_prof.armed = n;
   });
 }
