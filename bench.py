@@ -984,7 +984,8 @@ def main():
   else:
     # the id-sharded step, enqueued from C++ (csrc/mhte_shard_host.h): kernels + RCCL send / recv
     # groups on this stream; world == 1: the exchange is the identity
-    from monolith_amd.distributed_ps_sync import HipBackend, ShardedEmbedding, ShardedMultiStep
+    from monolith_amd.distributed_ps_sync import ShardedMultiStep
+    from tests.torch_sharded_step import HipBackend, ShardedEmbedding   # (test harness: last-resort fallback)
     from monolith_amd.multi_hash_table_ops import Ragged
     splits1 = np.array([0, B], dtype=np.int64)
     rag = [Ragged(ids_all[s], splits1) for s in range(n_batches)]

@@ -117,7 +117,7 @@ def _stale():
 def build_library(force=False, verbose=False):
   """hipcc --offload-arch=gfx950 cross-compiles without a GPU; output stays in-tree."""
   if not force and not _stale():
-    build_eager_loop()
+    _try_build_eager_loop(verbose)
     return _SO
   cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared",
          "-fPIC", "-o", _SO, _SRC]
@@ -130,7 +130,7 @@ def build_library(force=False, verbose=False):
   subprocess.check_call(cmd)
   with open(_HASH_FILE, "w") as f:
     f.write(src_hash + "\n")
-  build_eager_loop()
+  _try_build_eager_loop(verbose)
   return _SO
 
 
@@ -140,9 +140,24 @@ _EAGER_SO = os.path.join(_DIR, "libmhte_eager.so")
 _EAGER_SRC = os.path.join(_DIR, "csrc", "eager_loop.c")
 
 
+_HEADER = os.path.join(_DIR, "..", "include", "monolith_amd_hash_table.h")
+
+
+def _try_build_eager_loop(verbose=False):
+  """The helper is a benchmark aid: its build must not make the engine unavailable — a
+  failure is reported and eager_lib() tries again when the helper is asked for."""
+  try:
+    build_eager_loop()
+  except (OSError, subprocess.CalledProcessError) as e:
+    if verbose:
+      print("libmhte_eager.so not built (%s); bench.py's eager_cpp timing will retry" % e)
+
+
 def build_eager_loop(force=False):
+  # stale when older than its source, the public header it is compiled against, or the engine it binds
+  deps = [d for d in (_EAGER_SRC, _HEADER, _SO) if os.path.exists(d)]
   if (not force and os.path.exists(_EAGER_SO) and
-      os.path.getmtime(_EAGER_SO) >= os.path.getmtime(_EAGER_SRC)):
+      all(os.path.getmtime(_EAGER_SO) >= os.path.getmtime(d) for d in deps)):
     return _EAGER_SO
   subprocess.check_call(["gcc", "-O2", "-std=c99", "-Wall", "-shared", "-fPIC",
                          "-I", os.path.join(_DIR, "..", "include"), _EAGER_SRC, "-o", _EAGER_SO,
@@ -160,9 +175,11 @@ def eager_lib():
     lib()
     if _OVERRIDE:   # (libmhte_eager.so binds the in-tree libmhte.so: two copies of the engine in one process)
       raise MhteError(MHTE_UNAVAILABLE, "libmhte_eager.so is not used with MHTE_LIBRARY")
-    if not os.path.exists(_EAGER_SO):
-      build_eager_loop()
+    build_eager_loop()
     E = C.CDLL(_EAGER_SO)
+    if not hasattr(E, "mhte_eager_abi_version") or E.mhte_eager_abi_version() != ABI_VERSION:
+      build_eager_loop(force=True)   # (built against another version of the header)
+      raise MhteError(MHTE_UNAVAILABLE, "libmhte_eager.so was stale (ABI); rebuilt — start the process again")
     E.mhte_eager_step_loop.restype = C.c_int32
     _eager = E
   return _eager

@@ -10,6 +10,9 @@
 
 #include "monolith_amd_hash_table.h"
 
+/* the ABI version of the header this helper was compiled against (the binding refuses a stale helper) */
+int32_t mhte_eager_abi_version(void) { return MHTE_ABI_VERSION; }
+
 /* Steps [lo, hi) of a stream of batches laid out back to back in `ids` (batch s = ids + s * n).
  *   ws / unique_ids / n_unique_dev   three dedup workspaces and their result buffers, used in rotation
  *   cur          the slot that holds the run dedup of batch `lo` (made by the previous step or by

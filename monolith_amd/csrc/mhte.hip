@@ -10,7 +10,6 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
-#include <hipcub/hipcub.hpp>   // (device radix sort / run-length encode / scan: AuxWs::group_sorted)
 
 #include <algorithm>
 #include <chrono>
@@ -36,6 +35,7 @@
 #include "mhte_proto_config.h"
 #include <map>
 #include "mhte_pool_kernels.h"
+#include "mhte_group_kernels.h"
 #include "mhte_layout_kernels.h"
 #include "mhte_step_kernels.h"
 #include "mhte_mstep_kernels.h"
@@ -201,6 +201,65 @@ struct Prof {
 };
 static thread_local Prof g_prof;
 
+// Where the HOST's time goes in a call of the pipelined step (MHTE_HOST_PROF=1; VERDICT r5 weak #7: a plain C
+// loop over mhte_table_step_forward / _backward is host-bound on a slow box): per entry point the calls, the
+// time inside the call, the part of it before the table lock is held (argument checks, hipSetDevice, the lock)
+// and the part inside the launch expressions (the HIP runtime's: kernarg copy, packet, doorbell) — the rest is
+// this library's own bookkeeping.  Printed at exit (stderr, or the file MHTE_HOST_PROF_OUT names).
+struct HostProfSec {
+  const char* name;
+  uint64_t calls = 0, total_ns = 0, pre_ns = 0, launch_ns = 0, launches = 0;
+};
+static HostProfSec g_hp[2] = {{"mhte_table_step_forward"}, {"mhte_table_step_backward"}};
+static thread_local HostProfSec* t_hp = nullptr;
+static inline uint64_t now_ns() {
+  return uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(
+                      std::chrono::steady_clock::now().time_since_epoch()).count());
+}
+static void host_prof_dump() {
+  FILE* f = stderr;
+  if (const char* p = getenv("MHTE_HOST_PROF_OUT")) {
+    FILE* g = fopen(p, "a");
+    if (g) f = g;
+  }
+  fprintf(f, "| entry point | calls | us per call | before the lock | in launch expressions (HIP runtime) | launches per call | the rest (this library) |\n|---|---|---|---|---|---|---|\n");
+  for (const HostProfSec& s : g_hp) {
+    if (!s.calls) continue;
+    const double c = double(s.calls);
+    fprintf(f, "| %s | %llu | %.2f | %.2f | %.2f | %.2f | %.2f |\n", s.name, (unsigned long long)s.calls,
+            s.total_ns / c / 1e3, s.pre_ns / c / 1e3, s.launch_ns / c / 1e3, s.launches / c,
+            (double(s.total_ns) - double(s.pre_ns) - double(s.launch_ns)) / c / 1e3);
+  }
+  if (f != stderr) fclose(f);
+}
+static bool host_prof_on() {
+  static const bool on = [] {
+    const bool v = getenv("MHTE_HOST_PROF") != nullptr && atoi(getenv("MHTE_HOST_PROF")) != 0;
+    if (v) atexit(host_prof_dump);
+    return v;
+  }();
+  return on;
+}
+struct HostProfScope {
+  HostProfSec* s = nullptr;
+  uint64_t t0 = 0;
+  explicit HostProfScope(int which) {
+    if (host_prof_on()) {
+      s = &g_hp[which];
+      t_hp = s;
+      t0 = now_ns();
+    }
+  }
+  void locked() { if (s) s->pre_ns += now_ns() - t0; }
+  ~HostProfScope() {
+    if (s) {
+      s->total_ns += now_ns() - t0;
+      ++s->calls;
+      t_hp = nullptr;
+    }
+  }
+};
+
 #define LAUNCH_HOT(TAG, KERNEL, GRID, BLOCK, ST, ...)                                          \
   do {                                                                                         \
     if (g_prof.armed > 0) {                                                                    \
@@ -209,6 +268,11 @@ static thread_local Prof g_prof;
                             g_prof.ev[2 * i__ + 1], 0, __VA_ARGS__);                           \
       g_prof.tag.push_back(TAG);                                                               \
       --g_prof.armed;                                                                          \
+    } else if (t_hp) {                                                                         \
+      const uint64_t t0__ = now_ns();                                                          \
+      (KERNEL)<<<dim3(GRID), dim3(BLOCK), 0, (ST)>>>(__VA_ARGS__);                             \
+      t_hp->launch_ns += now_ns() - t0__;                                                      \
+      ++t_hp->launches;                                                                        \
     } else {                                                                                   \
       (KERNEL)<<<dim3(GRID), dim3(BLOCK), 0, (ST)>>>(__VA_ARGS__);                             \
     }                                                                                          \
@@ -515,8 +579,10 @@ static thread_local int64_t t_global_step = 0;
 // Host-side bound on how full the head split of a sliding filter can be (the role keys_upper plays for
 // the table's doubling): every consulting launch adds at most its id count; the window can only have to
 // move once the bound reaches the split's capacity, and only then do filter_advance_kernel /
-// filter_clear_kernel follow the launch — and the true count is fetched (one asynchronous 8-KB copy,
-// polled, never waited for) to start the bound over.  Launches recorded into a hipGraph are replayed
+// filter_clear_kernel follow the launch — and the true count is fetched (one asynchronous 16-byte copy of
+// the state's first words, where filter_advance_kernel leaves the head split's count; polled, never waited
+// for) to start the bound over.  A launch that does not say how many ids it had, or one on another stream
+// than the fetch in flight, voids that fetch (its count may or may not include the launch's ids).  Launches recorded into a hipGraph are replayed
 // without the host seeing them: a filter that was ever consulted under capture keeps the two launches
 // behind every consulting launch, as round 4 did everywhere.
 struct FilterBudget {
@@ -526,7 +592,8 @@ struct FilterBudget {
   uint64_t adds_since_fetch = 0;
   uint64_t gen = 0, fetch_gen = 0;
   bool known = true, fetching = false, every_launch = false;
-  FilterState* h_state = nullptr;   // pinned
+  uint32_t* h_state = nullptr;      // pinned: head, head_increment, clear_req, head_elements
+  hipStream_t fetch_stream = nullptr;
   hipEvent_t ev = nullptr;
   uint64_t skipped = 0, maintained = 0;   // (statistics)
   FilterBudget() {
@@ -547,10 +614,14 @@ struct FilterBudget {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) every_launch = true;
     if (every_launch) return true;
+    if (fetching && (adds == ~0ull || st != fetch_stream)) {
+      ++gen;           // (the fetch in flight cannot be trusted to count this launch)
+      known = false;
+    }
     if (fetching && hipEventQuery(ev) == hipSuccess) {
       fetching = false;
       if (fetch_gen == gen) {
-        head_upper = uint64_t(filter_split_elements(*h_state, h_state->head)) + adds_since_fetch;
+        head_upper = uint64_t(h_state[3]) + adds_since_fetch;
         known = true;
       }
     }
@@ -567,7 +638,7 @@ struct FilterBudget {
   void refetch(const FilterState* d_state, hipStream_t st) {
     std::lock_guard<std::mutex> g(mu);
     if (every_launch || fetching) return;
-    if (!h_state && hipHostMalloc(reinterpret_cast<void**>(&h_state), sizeof(FilterState)) != hipSuccess) {
+    if (!h_state && hipHostMalloc(reinterpret_cast<void**>(&h_state), 16) != hipSuccess) {
       every_launch = true;
       return;
     }
@@ -575,12 +646,14 @@ struct FilterBudget {
       every_launch = true;
       return;
     }
-    if (hipMemcpyAsync(h_state, d_state, sizeof(FilterState), hipMemcpyDeviceToHost, st) != hipSuccess ||
+    static_assert(offsetof(FilterState, head_elements) == 12, "the fetched words");
+    if (hipMemcpyAsync(h_state, d_state, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipEventRecord(ev, st) != hipSuccess) {
       every_launch = true;
       return;
     }
     fetching = true;
+    fetch_stream = st;
     fetch_gen = gen;
     adds_since_fetch = 0;
   }
@@ -1158,6 +1231,14 @@ struct Table {
                      int64_t global_step = 0, const RunView& ahead = RunView{}) {
     finish_pending(st);
     if (n <= 0 || n_max <= 0) throw Error(MHTE_INVALID_ARGUMENT, "step_backward: empty batch");
+    // MHTE_EXACT_ORDER: lists of <= kStepLightMax occurrences are summed in occurrence order by the id-major
+    // groups in every mode; the heavy ones get their strictly sequential sums from a launch in front of the
+    // update (rd_exact_sum_kernel: a workgroup streams a list's rows through LDS, one wavefront adds them in
+    // order) and the item workgroups only apply them.  MHTE_EXACT_WALK=1: round 5's form, one lane group
+    // walking each list (A/B; 4.8 ms per step at Zipf(1.2)).
+    static const bool exact_walk = getenv("MHTE_EXACT_WALK") != nullptr && atoi(getenv("MHTE_EXACT_WALK")) != 0;
+    const bool exact_pre = exact_order && !exact_walk && dim <= 256u;
+    const bool exact_old = exact_order && !exact_pre;
     if (ws.r_stage == 0 || int64_t(ws.rv.n) != n || ws.rv.uids != uids || ws.rv.n_unique != n_dev)
       throw Error(MHTE_FAILED_PRECONDITION,
                   "step_backward: workspace does not hold the run dedup of this batch");
@@ -1182,7 +1263,7 @@ struct Table {
         rd_build_probe_kernel<<<DedupWs::build_blocks(ws.rv), 256, 0, st>>>(ws.rv, uint32_t(kStepLightMax), view, po);
       else
         rd_probe_kernel<<<uint32_t(std::min<int64_t>(256, (n + 255) / 256)), 256, 0, st>>>(
-            ws.rv, view, po, uint32_t(n), exact_order ? 0xffffffffu : uint32_t(kStepLightMax));
+            ws.rv, view, po, uint32_t(n), exact_old ? 0xffffffffu : uint32_t(kStepLightMax));
       HIP_OK(hipGetLastError());
       ws.r_stage = 2;
       ws.r_hints = true;
@@ -1221,7 +1302,8 @@ struct Table {
     c.part = ws.part.p;
     c.arrive = ws.arrive.p;
     c.n_max = n_max;
-    c.light_max = exact_order ? 0xffffffffu : uint32_t(kStepLightMax);
+    c.light_max = exact_old ? 0xffffffffu : uint32_t(kStepLightMax);
+    c.pre_summed = exact_pre ? 1u : 0u;
     c.urow = nullptr;
     c.uloc = nullptr;
     c.uts = nullptr;
@@ -1235,7 +1317,13 @@ struct Table {
     const uint32_t groups_per_wg = uint32_t(256 / sh.G);
     // residency budget: 4 workgroups of 256 threads per CU (launch bounds of step_bwd_kernel)
     const uint32_t slots = uint32_t(kBwdBlocksPerCu * num_cus);
-    c.nblk_items = exact_order ? 0u : std::min<uint32_t>(cap_items, uint32_t(num_cus) * 10 / 8);
+    c.nblk_items = exact_old ? 0u : std::min<uint32_t>(cap_items, uint32_t(num_cus) * 10 / 8);
+    if (exact_pre) {
+      const uint32_t gx = std::min<uint32_t>(cap_items, uint32_t(num_cus));
+      if (sh.VEC == 4) rd_exact_sum_kernel<4><<<gx, kExactThreads, 0, st>>>(ws.rv, grads, dim, ws.part.p);
+      else rd_exact_sum_kernel<1><<<gx, kExactThreads, 0, st>>>(ws.rv, grads, dim, ws.part.p);
+      HIP_OK(hipGetLastError());
+    }
     c.nblk_ids = std::max<uint32_t>(
         1, std::min<uint32_t>(uint32_t((std::min<int64_t>(n_max, n) + groups_per_wg - 1) / groups_per_wg),
                               slots - c.nblk_items - 128));
@@ -2018,24 +2106,23 @@ struct AuxWs {
     Use(AuxWs& w, hipStream_t s) : ws(w), st(s) { ws.enter(st); }
     ~Use() { (void)hipEventRecord(ws.done, st); }
   };
-  // The same lists for keys known to lie in [0, 2^key_bits), key_bits <= 31 (round 5): a
-  // STABLE radix sort of (key, position) pairs — equal keys keep their positions ascending —, the runs of
-  // the sorted keys, and a prefix sum of their lengths.  The list-building dedup below is a hash table with
-  // two device atomics per key and five launches over all n keys; the sort moves 8 bytes per key and pass
-  // and needs no atomic per key: 1 M keys 330 -> ≈ 70 us (profiles/r05/pooling_group_ab.md).  Keys come out
-  // ascending instead of in first-occurrence order; the consumers write one output row per key and do not
-  // care.  The sort, the run-length encoding and the scan are rocPRIM's through hipCUB (library primitives,
-  // as hipBLASLt would be for a plain GEMM); keys outside the range are dropped, which is what the
-  // consumers did with them.  MHTE_GROUP_DD=1 keeps the dedup form (A/B).
-  DevBuf<uint32_t> k32a, k32b, posa, runs_key, runs_len, nruns;
-  DevBuf<char> cub_tmp;
+  // The same lists for keys known to lie in [0, 2^key_bits), key_bits <= 31: a STABLE radix sort of
+  // (key, position) pairs — equal keys keep their positions ascending — and the heads of the sorted runs
+  // compacted into uids / seg_off (csrc/mhte_group_kernels.h: this repo's own kernels since round 6; round 5
+  // went through rocPRIM's Onesweep sort + run-length encode + scan, ≈ 20 launches per grouping).  The
+  // list-building dedup below is a hash table with two device atomics per key and five launches over all n
+  // keys; the sort moves 8 bytes per key and pass and needs no atomic.  Keys come out ascending instead of
+  // in first-occurrence order; the consumers write one output row per key and do not care.  Keys outside
+  // the range are dropped, which is what the consumers did with them.  MHTE_GROUP_DD=1 selects the dedup
+  // form (A/B; read per call, so that a test can run both forms in one process).
+  DevBuf<uint32_t> k32a, k32b, posa, gs_hist, gs_tot, gs_heads;
   static bool use_sort() {
-    static const bool dd_form = getenv("MHTE_GROUP_DD") != nullptr && atoi(getenv("MHTE_GROUP_DD")) != 0;
-    return !dd_form;
+    const char* e = getenv("MHTE_GROUP_DD");
+    return !(e && atoi(e) != 0);
   }
   void group_sorted(const int64_t* k, int64_t n, int key_bits, hipStream_t st) {
     if (key_bits < 1) key_bits = 1;
-    if (!use_sort() || key_bits > 31 || n > int64_t(0x7fffffff)) {
+    if (!use_sort() || key_bits > 31 || n >= int64_t(0x7fffffff) || n < 1) {
       group(k, n, st);
       return;
     }
@@ -2046,34 +2133,38 @@ struct AuxWs {
     k32a.reserve(size_t(n));
     k32b.reserve(size_t(n));
     posa.reserve(size_t(n));
-    runs_key.reserve(size_t(n) + 1);
-    runs_len.reserve(size_t(n) + 2);
-    nruns.reserve(4);
-    const uint32_t limit = 1u << key_bits;
-    const int ni = int(n);
-    group_keys32_kernel<<<dim3(uint32_t((n + 255) / 256)), 256, 0, st>>>(k, n, limit, k32a.p, posa.p);
-    HIP_OK(hipGetLastError());
-    size_t t1 = 0, t2 = 0, t3 = 0;
-    // (rocPRIM's default picks a merge sort up to 1 M items — ten merge passes of two launches each, 150 us for
-    // exactly 1 M pairs; the Onesweep radix sort is what this wants at every size)
-    using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                               rocprim::default_config, 4096>;
-    HIP_OK(rocprim::radix_sort_pairs<SortCfg>(nullptr, t1, k32a.p, k32b.p, posa.p, seg_pos.p, size_t(ni), 0u,
-                                              unsigned(key_bits + 1), st));
-    HIP_OK(hipcub::DeviceRunLengthEncode::Encode(nullptr, t2, k32b.p, runs_key.p, runs_len.p, nruns.p, ni, st));
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, t3, runs_len.p, seg_off.p, ni + 1, st));
-    cub_tmp.reserve(std::max(t1, std::max(t2, t3)) + 256);
-    size_t tb = cub_tmp.cap;
-    HIP_OK(rocprim::radix_sort_pairs<SortCfg>(cub_tmp.p, tb, k32a.p, k32b.p, posa.p, seg_pos.p, size_t(ni), 0u,
-                                              unsigned(key_bits + 1), st));
-    // (run lengths beyond the run count are never read by a consumer, but the scan walks n + 1 of them)
-    HIP_OK(hipMemsetAsync(runs_len.p, 0, (size_t(n) + 2) * sizeof(uint32_t), st));
-    tb = cub_tmp.cap;
-    HIP_OK(hipcub::DeviceRunLengthEncode::Encode(cub_tmp.p, tb, k32b.p, runs_key.p, runs_len.p, nruns.p, ni, st));
-    tb = cub_tmp.cap;
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp.p, tb, runs_len.p, seg_off.p, ni + 1, st));
-    group_finish_kernel<<<dim3(uint32_t(std::min<int64_t>((n + 255) / 256, 1024))), 256, 0, st>>>(
-        runs_key.p, nruns.p, limit, uids.p, nu.p);
+    const int bits = key_bits + 1;   // (`limit` = 2^key_bits itself is a key: the dropped ones, sorted last)
+    const int passes = (bits + kGsMaxBits - 1) / kGsMaxBits;
+    const int dig = (bits + passes - 1) / passes;
+    GsPass P{};
+    P.n = uint32_t(n);
+    P.limit = 1u << key_bits;
+    const uint64_t per_round = uint64_t(kGsWaves) * kGsRound;
+    P.rounds = uint32_t(std::max<uint64_t>(1, (uint64_t(n) + per_round * kGsMaxTiles - 1) / (per_round * kGsMaxTiles)));
+    const uint64_t tile_keys = per_round * P.rounds;
+    P.ntiles = uint32_t((uint64_t(n) + tile_keys - 1) / tile_keys);
+    P.tstride = (P.ntiles + 3u) & ~3u;
+    gs_hist.reserve(size_t(kGsMaxBins) * kGsMaxTiles);
+    gs_tot.reserve(kGsMaxBins);
+    P.hist = gs_hist.p;
+    P.tot = gs_tot.p;
+    for (int j = 0; j < passes; ++j) {
+      P.shift = uint32_t(j * dig);
+      P.bits = uint32_t(std::min(dig, bits - j * dig));
+      const bool to_y = ((passes - 1 - j) & 1) == 0;   // the last pass leaves the positions in seg_pos
+      P.k64 = j == 0 ? k : nullptr;
+      P.kin = to_y ? k32a.p : k32b.p;
+      P.pin = to_y ? posa.p : seg_pos.p;
+      P.kout = to_y ? k32b.p : k32a.p;
+      P.pout = to_y ? seg_pos.p : posa.p;
+      gs_hist_kernel<<<dim3(P.ntiles), kGsThreads, 0, st>>>(P);
+      gs_rowscan_kernel<<<dim3(1u << P.bits), 64, 0, st>>>(P);
+      gs_scatter_kernel<<<dim3(P.ntiles), kGsThreads, 0, st>>>(P);
+    }
+    const uint32_t ntsel = uint32_t((uint64_t(n) + kGsSelTile - 1) / kGsSelTile);
+    gs_heads.reserve(ntsel);
+    gs_heads_count_kernel<<<dim3(ntsel), 1024, 0, st>>>(k32b.p, P.n, gs_heads.p);
+    gs_heads_emit_kernel<<<dim3(ntsel), 1024, 0, st>>>(k32b.p, P.n, P.limit, gs_heads.p, uids.p, seg_off.p, nu.p);
     HIP_OK(hipGetLastError());
   }
   // distinct keys + their positions in ascending order -> uids / seg_off / seg_pos / nu
@@ -3591,11 +3682,13 @@ mhte_status mhte_table_step_forward(mhte_multi_table* t, int32_t table, const in
                                     int64_t* unique_ids_next, uint32_t* n_unique_dev_next,
                                     mhte_dedup_ws* ws_cur, void* stream) {
   return guard([&] {
+    HostProfScope hps(0);
     Table& tb = table_at(t, table);
     if (!tb.fusable())
       throw Error(MHTE_INVALID_ARGUMENT, "step_forward: row too wide for the fused step");
     HIP_OK(hipSetDevice(t->device));
     std::lock_guard<std::mutex> g(tb.mu);
+    hps.locked();
     hipStream_t st = S(stream);
     RunView nxt{};
     if (ws_next) {
@@ -3631,6 +3724,7 @@ mhte_status mhte_table_step_backward_ahead(mhte_multi_table* t, int32_t table, m
                                            int64_t n_ahead, int64_t* unique_ids_ahead,
                                            uint32_t* n_unique_dev_ahead, void* stream) {
   return guard([&] {
+    HostProfScope hps(1);
     Table& tb = table_at(t, table);
     if (!ws || ws == ws_next)
       throw Error(MHTE_INVALID_ARGUMENT, "step_backward needs the batch's workspace, distinct "
@@ -3649,6 +3743,7 @@ mhte_status mhte_table_step_backward_ahead(mhte_multi_table* t, int32_t table, m
                                          "for the fused step");
     HIP_OK(hipSetDevice(t->device));
     std::lock_guard<std::mutex> g(tb.mu);
+    hps.locked();
     tb.note_update_time(update_time);
     RunView ahead{};
     if (ws_ahead)
@@ -4431,9 +4526,31 @@ mhte_status mhte_table_save_as_tensor(mhte_multi_table* t, int32_t table, int32_
       }
       s0 = s1;
     }
+    // The one key that lives in the side slot (kEmptyKey itself; the reference's map holds INT64_MIN in a
+    // bucket like any other key): handed out behind the last bucket of shard 0, as the checkpoint save
+    // writes it (it was missing from this walk, one entry fewer than size()).  A walk that is
+    // already past the shard's end (offset = the "done" value below) does not see it again.
+    bool took_special = false;
+    if (shard_idx == 0 && ids.size() < want && begin * kSlots + uint64_t(offset) <= s_end) {
+      Counters c;
+      HIP_OK(hipMemcpyAsync(&c, tb.ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
+      HIP_OK(hipStreamSynchronize(st));
+      if (c.special_state == 1) {
+        const uint32_t r = c.special_row;
+        const float* src = tb.chunks[r >> tb.chunk_shift] + size_t(r & ((1u << tb.chunk_shift) - 1u)) * rf;
+        const size_t at = ids.size();
+        rows.resize((at + 1) * rf);
+        HIP_OK(hipMemcpyAsync(rows.data() + at * rf, src, rf * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        ids.push_back(kEmptyKey);
+        pos.push_back(int64_t(s_end));
+        ts.push_back(c.special_ts);
+        took_special = true;
+      }
+    }
     // stopped on the limit: resume behind the last entry; ran off the shard's end: one bucket past it
     // (":770 Using +1 here since end might equal to begin")
-    if (ids.size() >= want) *new_offset = int64_t(uint64_t(pos.back()) - begin * kSlots + 1);
+    if (!took_special && ids.size() >= want) *new_offset = int64_t(uint64_t(pos.back()) - begin * kSlots + 1);
     else *new_offset = int64_t((end - begin + 1) * kSlots);
     *n_entries = int64_t(ids.size());
     const std::vector<ckpt::SegLayout> segs = seg_layout(tb);

@@ -221,7 +221,8 @@ struct FilterState {           // device words behind TableView::flt_state
   uint32_t head;
   uint32_t head_increment;
   uint32_t clear_req;          // split to clear + 1 (set by filter_advance_kernel)
-  uint32_t pad;
+  uint32_t head_elements;      // elements of the head split as filter_advance_kernel last saw them (what the
+                               // host's FilterBudget fetches: these 16 bytes, not the 256 KB of counts below)
   unsigned long long failure_count;
   // elements per split, kept as kFilterWays partial counts (an id adds to way home % kFilterWays):
   // a step that starts 40 000 slots would otherwise queue 40 000 adds on ONE word.  Round 5: each
@@ -632,6 +633,7 @@ __global__ void filter_advance_kernel(TableView tv) {
     for (int w = 0; w < kFilterWays; ++w) fs->num_elements[c][w * kFilterWayStride] = 0;
     fs->clear_req = c + 1u;
   }
+  fs->head_elements = filter_split_elements(*fs, fs->head);
 }
 __global__ __launch_bounds__(256) void filter_clear_kernel(TableView tv) {
   const FilterState* fs = reinterpret_cast<const FilterState*>(tv.flt_state);

@@ -238,26 +238,6 @@ __global__ __launch_bounds__(256) void reduce_rows_lists_kernel(const int64_t* _
   }
 }
 
-// ---- grouping rows by a bounded key with a stable radix sort (AuxWs::group_sorted, round 5) ----------
-// keys in [0, limit) -> 32-bit sort keys, everything else -> `limit` (sorted last, dropped); value = position
-__global__ __launch_bounds__(256) void group_keys32_kernel(const int64_t* __restrict__ k, int64_t n, uint32_t limit,
-                                                           uint32_t* __restrict__ k32, uint32_t* __restrict__ pos) {
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t v = k[i];
-  k32[i] = (v >= 0 && v < int64_t(limit)) ? uint32_t(v) : limit;
-  pos[i] = uint32_t(i);
-}
-// runs of the sorted keys -> the int64 key list the consumers read; the run of dropped keys is cut off
-__global__ __launch_bounds__(256) void group_finish_kernel(const uint32_t* __restrict__ uniq,
-                                                           const uint32_t* __restrict__ nruns, uint32_t limit,
-                                                           int64_t* __restrict__ uids, uint32_t* __restrict__ nu) {
-  const uint32_t n = *nruns;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    uids[i] = int64_t(uniq[i]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *nu = (n && uniq[n - 1] == limit) ? n - 1u : n;
-}
-
 // gradient of FusedGatherEmbeddingsByInput without atomics: key of global row r = its float offset
 __global__ __launch_bounds__(256) void gather_keys_kernel(GatherInputs in, int64_t* __restrict__ keys) {
   const int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;

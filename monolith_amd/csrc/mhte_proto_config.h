@@ -230,6 +230,7 @@ inline void parse_initializer(const uint8_t* b, size_t n, Segment* s) {
 inline void parse_table(const uint8_t* b, size_t n, TableCfg* t) {
   Msg m(b, n);
   Field f;
+  bool skip_zero = false;
   while (m.next(&f)) {
     switch (f.num) {
       case 1: {  // entry_config
@@ -277,9 +278,15 @@ inline void parse_table(const uint8_t* b, size_t n, TableCfg* t) {
       }
       case 7: t->enable_eviction = f.v != 0; break;
       case 8: t->evict_every_n_hours = int32_t(f.v); break;
-      default: break;  // cuckoo (5), entry_type (6: PACKED / RAW are the same here), skip_zero (10)
+      case 10: skip_zero = f.wt == 0 && f.v != 0; break;   // skip_zero_embedding (embedding_hash_table.proto:90)
+      default: break;  // cuckoo (5), entry_type (6: PACKED / RAW are the same here)
     }
   }
+  // Assign of an all-zero row erases the key, restore skips zero rows (cuckoo_embedding_hash_table.cc:192-197,
+  // 304-310) — serving only: the reference's factory refuses the flag on any other entry type with this
+  // message (embedding_hash_table_factory.cc:30-34), and SERVING entries were refused above.
+  if (skip_zero)
+    throw ckpt::ProtoError("config: skip_zero_embedding: Only EntryConfig_EntryType_SERVING supports skip_zero_embedding!");
   if (t->segs.empty()) throw ckpt::ProtoError("config: table without segments");
 }
 

@@ -142,8 +142,13 @@ struct ShardStep {
   // of a ~60 us step to find, five steps in six, an empty list.  Until that lookup is enqueued the pass
   // is owed: the tables carry a hook (Table::ext_flush) that makes any other user of them run it first.
   bool fold_slow = true;        // MHTE_SHARD_FOLD_SLOW=0: always a launch of its own (A/B)
-  bool slow_pending = false;
+  // (claimed with an atomic exchange: the hook can fire on any thread that touches one of the tables — two
+  // threads saving two tables between a backward and the next forward must not both run the pass)
+  std::atomic<bool> slow_pending{false};
   int slow_slot = -1;
+  hipEvent_t slow_ev = nullptr;      // recorded behind the owner update that owes the pass: a flush on another
+  hipStream_t slow_stream = nullptr; // stream than the training stream is ordered behind that update
+  bool slow_ev_valid = false;
   uint32_t launches = 0;        // kernel launches + exchanges enqueued by the last forward + backward
   // ---- sizing the owner's launches by what the peers actually send.  A (peer, table) block can hold the
   // whole batch; a Zipf batch fills a fifth of it, N ranks a fifth of an N-th.  Workgroups sized for the
@@ -230,6 +235,7 @@ struct ShardStep {
     } catch (...) {
     }
     (void)hipDeviceSynchronize();
+    if (slow_ev) (void)hipEventDestroy(slow_ev);
     if (comm) (void)Rccl::get().CommDestroy(comm);
     if (aux) (void)hipStreamDestroy(aux);
     if (ev_in) (void)hipEventDestroy(ev_in);
@@ -993,9 +999,10 @@ struct ShardStep {
   }
   // the owed displacement pass as a launch of its own (anything but the next owner lookup came first)
   void flush_slow(hipStream_t st) {
-    if (!slow_pending) return;
-    slow_pending = false;
+    if (!slow_pending.exchange(false)) return;
     set_hooks(false);
+    if (slow_ev_valid && st != slow_stream) HIP_OK(hipStreamWaitEvent(st, slow_ev, 0));
+    slow_ev_valid = false;
     for (OwnerChunk& k : apply_chunks) {
       k.A.zero_headers = 1u;
       shard_slow_all_kernel<<<k.tc, 64, 0, st>>>(k.A);
@@ -1146,8 +1153,8 @@ struct ShardStep {
     own_slot = slot;
     poll_counts();
     for (uint32_t t = 0; t < T; ++t) own_epoch[t] = mt->tables[t]->mut_epoch;
-    const bool fold = slow_pending && !per_peer;
-    if (slow_pending && !fold) flush_slow(st);
+    const bool fold = !per_peer && slow_pending.exchange(false);   // (claimed: a hook firing now finds nothing)
+    if (!fold) flush_slow(st);
     for (uint32_t t0 = 0; t0 < T; t0 += uint32_t(kMaxStepTables)) {
       const uint32_t tc = chunk_tables(t0);
       ShardOwnerArgs A{};
@@ -1192,8 +1199,8 @@ struct ShardStep {
       HIP_OK(hipGetLastError());
     }
     if (fold) {
-      slow_pending = false;
       set_hooks(false);
+      slow_ev_valid = false;
       if (slow_slot >= 0) hdr_dirty[slow_slot] = false;
     }
     if (direct) ++seq_sent[kChRows];
@@ -1283,8 +1290,19 @@ struct ShardStep {
       own_slot = -1;
       slow_pending = true;
       slow_slot = slot;
-      if (can_fold()) set_hooks(true);   // the pass rides in the next owner lookup
-      else flush_slow(st);
+      if (can_fold()) {   // the pass rides in the next owner lookup
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        slow_ev_valid = false;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+          if (!slow_ev) HIP_OK(hipEventCreateWithFlags(&slow_ev, hipEventDisableTiming));
+          HIP_OK(hipEventRecord(slow_ev, st));
+          slow_stream = st;
+          slow_ev_valid = true;
+        }
+        set_hooks(true);
+      } else {
+        flush_slow(st);
+      }
     } else
     for (int p = 0; p < world; ++p) {
       wait_arrived(kXGrads, slot, p, p + 1, st);   // (a peer's block is applied as soon as it has landed)

@@ -1037,6 +1037,8 @@ struct ApplyCtl {
                                 // replaces the dense arrays, urow / uloc in ONE load
   uint32_t trusted;             // 1: nothing has touched the table since urow / uloc were written
                                 // (multi-table step, Table::mut_epoch): the hints need no check
+  uint32_t pre_summed;          // 1 (MHTE_EXACT_ORDER): every heavy list's strictly sequential sum is already in
+                                // part[its first item] (rd_exact_sum_kernel): the item workgroups only apply
 };
 
 // row of a found id, fetched while the gradient chain is in flight
@@ -1721,7 +1723,7 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
     }
     lds_barrier();
     wt.mark(1);
-    const uint32_t E = sh_rstart[64];
+    const uint32_t E = c.pre_summed ? 0u : sh_rstart[64];   // (summed ahead: no window to walk)
     Vec<VEC> acc;
     vec_zero(acc);
     // this group's windows: qb = (grp + k * NG) * WIN.  The positions of kPre windows are fetched
@@ -1794,7 +1796,10 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
     }
     wt.mark(3);
     bool apply = nitems == 1;  // block-uniform
-    if (nitems > 1) {
+    if (c.pre_summed) {   // the list's first item applies the sum rd_exact_sum_kernel left for it
+      apply = kk == 0;
+      if (apply && threadIdx.x < G && ev) tot.load(c.part + int64_t(w) * dim + e);
+    } else if (nitems > 1) {
       // partial row per item (the items of a list are consecutive), write-through hand-off
       if (threadIdx.x < G && ev) store_wt<VEC>(c.part + int64_t(w) * dim + e, tot);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1889,6 +1894,165 @@ __device__ __forceinline__ void rd_apply_role(const TableView& tv, const RunView
     }
     wt.mark(4);
     lds_barrier();  // LDS is reused by the next item
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MHTE_EXACT_ORDER: the strictly sequential sum of every HEAVY list (> kStepLightMax occurrences), one
+// launch in front of step_bwd (the reference sums an id's gradients in occurrence order,
+// RT/ops/unique_mapping_ops.cc:284-329; lists of <= kStepLightMax are summed that way by the id-major groups
+// in every mode).  The adds of a list are a dependent chain — its LOADS are not: one 512-thread workgroup
+// per list, seven wavefronts stream the list's gradient rows into a double-buffered LDS chunk (64 KB each;
+// the positions of the chunk after next are fetched in the same phase, so a phase is one memory round
+// trip), wavefront 0 adds the chunk before it in occurrence order, a lane per float of the row — one
+// v_add per row on its chain.  Round 5 walked a list with one 16-lane group, two dependent round trips per
+// 8 rows: 4.8 ms per step at Zipf(1.2), where one id holds ~12 000 of the 65 536 positions.
+// The list's runs are found in the dedup workgroups' directories (lane b probes workgroup b's), so the
+// kernel does not depend on how the build role cut the list into items: the item with k = 0 stands for
+// the list, and its sum goes to part[that item] — where step_bwd's item workgroup picks it up
+// (ApplyCtl::pre_summed).
+// ---------------------------------------------------------------------------------------------
+constexpr int kExactThreads = 512;
+constexpr int kExactBufFloats = 16384;   // 64 KB per chunk buffer
+constexpr int kExactMaxRows = 512;       // rows per chunk (<= one position per thread)
+struct __attribute__((aligned(16))) ExactLds {
+  float buf[2][kExactBufFloats];
+  uint32_t pos[3][kExactMaxRows];
+  uint32_t rstart[65];
+  uint32_t rbase[64];
+};
+
+template <int VEC>
+__global__ __launch_bounds__(kExactThreads) void rd_exact_sum_kernel(RunView d, const float* __restrict__ grads,
+                                                                     uint32_t dim, float* __restrict__ part) {
+  __shared__ ExactLds L;
+  constexpr uint32_t NL = kExactThreads - 64;   // loader lanes (wavefronts 1-7)
+  const uint32_t t = threadIdx.x, lane = t & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const uint32_t C = min(uint32_t(kExactMaxRows), uint32_t(kExactBufFloats) / dim);   // rows per chunk
+  const uint32_t upr = dim / VEC;                                                       // float4s (floats) per row
+  const uint32_t nitems_all = d.ctr[2];
+#pragma unroll 1
+  for (uint32_t w = blockIdx.x; w < nitems_all; w += gridDim.x) {
+    const ItemHdr hd = d.item_hdr[w];
+    if (((hd.meta >> 16) & 0xffu) != 0u) continue;   // (workgroup-uniform: not the list's first item)
+    __syncthreads();   // (the previous list's tables are no longer read)
+    if (wave == 0) {
+      const uint32_t val = (lane < d.nblk) ? rd_find_run_opt(d, lane, hd.id) : 0u;
+      uint32_t incl = run_cnt(val);
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (int(lane) >= o) incl += v;
+      }
+      L.rstart[lane + 1] = incl;
+      if (lane == 0) L.rstart[0] = 0;
+      L.rbase[lane] = lane * uint32_t(kRdBlock) + run_off(val);
+    }
+    __syncthreads();
+    const uint32_t E = L.rstart[64];
+    const uint32_t nch = (E + C - 1) / C;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};   // wavefront 0: floats lane, lane + 64, ... of the row
+    // phase k: positions of chunk k + 2 | rows of chunk k + 1 | sum of chunk k
+#pragma unroll 1
+    for (int k = -2; k < int(nch); ++k) {
+      if (wave != 0) {
+        const uint32_t lt = t - 64u;
+        // ---- positions of chunk k + 2 (entry q of the list: run r with rstart[r] <= q < rstart[r + 1])
+        const uint32_t c2 = uint32_t(k + 2);
+        uint32_t pv[2] = {0u, 0u};
+        uint32_t pb[2] = {0u, 0u};
+        if (c2 < nch) {
+#pragma unroll
+          for (int x = 0; x < 2; ++x) {
+            const uint32_t i = lt + uint32_t(x) * NL;
+            const uint32_t q = c2 * C + i;
+            const bool has = i < C && q < E;
+            const uint32_t qq = has ? q : 0u;
+            uint32_t lo = 0, hi = 63;
+#pragma unroll
+            for (int s2 = 0; s2 < 6; ++s2) {
+              const uint32_t mid = (lo + hi + 1) >> 1;
+              const bool le = L.rstart[mid] <= qq;
+              lo = le ? mid : lo;
+              hi = le ? hi : mid - 1;
+            }
+            pb[x] = lo * uint32_t(kRdBlock);
+            pv[x] = d.seg[L.rbase[lo] + (qq - L.rstart[lo])];   // (every lane loads, from an entry that exists)
+          }
+        }
+        // ---- rows of chunk k + 1 -> buf[(k + 1) & 1]: element v of the chunk = float4 (float) v of its rows
+        const uint32_t c1 = uint32_t(k + 1);
+        if (k + 1 >= 0 && c1 < nch) {
+          const uint32_t rows = min(C, E - c1 * C);
+          const uint32_t nvec = rows * upr;
+          const uint32_t* ps = L.pos[c1 % 3u];
+          float* dst = L.buf[c1 & 1u];
+          constexpr int U = VEC == 4 ? 10 : 8;
+#pragma unroll 1
+          for (uint32_t v0 = lt; v0 < nvec; v0 += NL * U) {
+            Vec<VEC> r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const uint32_t v = v0 + uint32_t(u) * NL;
+              const uint32_t vv = v < nvec ? v : 0u;
+              const uint32_t row = vv / upr, col = vv - row * upr;
+              r[u].load(grads + int64_t(ps[row]) * dim + col * VEC);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const uint32_t v = v0 + uint32_t(u) * NL;
+              if (v < nvec) {
+#pragma unroll
+                for (int cc = 0; cc < VEC; ++cc) dst[v * VEC + cc] = r[u].v[cc];
+              }
+            }
+          }
+        }
+        if (c2 < nch) {
+#pragma unroll
+          for (int x = 0; x < 2; ++x) {
+            const uint32_t i = lt + uint32_t(x) * NL;
+            if (i < C) L.pos[c2 % 3u][i] = pb[x] + pv[x];
+          }
+        }
+      } else if (k >= 0) {
+        // ---- chunk k, row after row: acc = acc + g, the reference's loop
+        const uint32_t rows = min(C, E - uint32_t(k) * C);
+        const float* src = L.buf[k & 1];
+#pragma unroll 1
+        for (uint32_t cc = 0; cc * 64u < dim; ++cc) {
+          const uint32_t f = lane + cc * 64u;
+          const bool on = f < dim;
+          float a = acc[0];
+          if (cc == 1) a = acc[1];
+          if (cc == 2) a = acc[2];
+          if (cc == 3) a = acc[3];
+          uint32_t r0 = 0;
+#pragma unroll 1
+          for (; r0 + 8 <= rows; r0 += 8) {
+            float g8[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) g8[x] = src[(r0 + uint32_t(x)) * dim + (on ? f : 0u)];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) a = a + g8[x];
+          }
+          for (; r0 < rows; ++r0) a = a + src[r0 * dim + (on ? f : 0u)];
+          if (cc == 0) acc[0] = a;
+          if (cc == 1) acc[1] = a;
+          if (cc == 2) acc[2] = a;
+          if (cc == 3) acc[3] = a;
+        }
+      }
+      __syncthreads();
+    }
+    if (wave == 0) {
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const uint32_t f = lane + uint32_t(cc) * 64u;
+        if (f < dim) part[int64_t(w) * dim + f] = acc[cc];
+      }
+    }
   }
 }
 

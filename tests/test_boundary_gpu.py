@@ -156,6 +156,34 @@ def test_lookup_gradient_kat():
     lookup_gradient(ids_t([[0, 0]]), ids_t([7, 8]), val_t(np.ones((3, 4))))
 
 
+def test_save_as_tensor_hands_out_the_reserved_key_once():
+  """The id INT64_MIN lives in the engine's side slot (its bucket-empty marker); the reference's map holds
+  it in a bucket like any other key and partial_dump returns it.  The walk hands it out behind the last
+  bucket of shard 0, once, whatever the limit — so a dump holds size() entries."""
+  dim = 4
+  mt = MultiHashTable.from_configs({"t": entry.make_table_config(
+      [entry.CombineAsSegment(dim, entry.ZerosInitializer(), entry.SgdOptimizer(0.1))],
+      entry.CuckooHashTableConfig(initial_capacity=1 << 6))}, name_suffix=_name())
+  ids = np.array([np.iinfo(np.int64).min, 3, 17, 1 << 40, -5, 99], np.int64)
+  vals = np.arange(ids.size * dim, dtype=np.float32).reshape(-1, dim)
+  mt.assign({"t": (ids_t(ids), val_t(vals))}, req_time=77)
+  assert mt.size("t") == ids.size
+  strings = dict(zip(ids.tolist(), mt.lookup_entry({"t": ids_t(ids)})["t"]))
+  for total, limit in ((1, 1000), (1, 2), (3, 1), (2, 0), (1, 6), (1, 5)):
+    got = []
+    for shard in range(total):
+      offset = 0
+      for _ in range(64):
+        new_offset, ents = mt.save_as_tensor("t", shard, total, limit, offset)
+        got += ents
+        if len(ents) < max(limit, 1):
+          break
+        offset = new_offset
+      # a walk that has run off the end stays there
+      assert mt.save_as_tensor("t", shard, total, limit, new_offset)[1] == []
+    assert sorted(got) == sorted(strings.values()), (total, limit)
+
+
 def test_save_as_tensor_walks_the_table_like_partial_dump():
   """MonolithHashTableSaveAsTensor (ops/hash_table/misc_ops.cc:46-94) = cuckoohash_map::partial_dump
   (cuckoohash_map.hpp:740-773) `limit` entries at a time: ids inserted one by one sit where the

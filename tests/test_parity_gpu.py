@@ -774,7 +774,7 @@ def test_sender_side_partition_scatter_sum(n, dim, shards, dist):
   shard-major packing by floormod(id, N) (fused_reorder_by_indices.cc:75-123), rows of the unique
   ids scattered to every occurrence (FillWithOffsetMap) and per-id gradient sums in send order
   (FillWithOffsetMapGradient) — against numpy."""
-  from monolith_amd.distributed_ps_sync import HipBackend
+  from tests.torch_sharded_step import HipBackend
   mt = make({"emb": adagrad_cfg(dim)})
   be = HipBackend(mt, "emb")
   ids = S.id_batch(77, n, 10**5 if dist == "zipf" else 10**9, dist)
@@ -1218,6 +1218,51 @@ def test_fused_gather_gradient_is_sequential_and_repeatable():
   # (a sum starts from 0: 0 + first addend)
   np.testing.assert_array_equal(outs[0], exp)
   assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("form", ["sort", "dedup"])
+def test_pooling_gradient_grouping_forms_at_size(form, monkeypatch):
+  """The two groupings behind the deterministic pooling gradients (AuxWs::group_sorted): this repo's stable
+  radix sort of (key, position) pairs (csrc/mhte_group_kernels.h; several tiles per pass, two and three
+  passes, one key holding a fifth of the rows) and the list-building dedup (MHTE_GROUP_DD=1, read per call).
+  Both must give the reference's sequential sums bit for bit (reduce_op.cc:46-49;
+  map_id_to_embedding.cu.cc:98-107 with the addends in row order)."""
+  if form == "dedup":
+    monkeypatch.setenv("MHTE_GROUP_DD", "1")
+  else:
+    monkeypatch.delenv("MHTE_GROUP_DD", raising=False)
+  rng = np.random.default_rng(5)
+  # unsorted reduce: 70 000 outputs (17 + 1 key bits: two passes), 200 000 rows, Zipf-like skew
+  batch, dim, n = 70000, 8, 200000
+  ind = np.minimum((rng.pareto(0.9, n) * 3).astype(np.int64), batch - 1)
+  ind[rng.random(n) < 0.2] = 4242            # one output takes a fifth of the rows
+  ind = (ind * 7919) % batch
+  vals = rng.standard_normal((n, dim)).astype(np.float32)
+  exp = np.zeros((batch, dim), np.float32)
+  np.add.at(exp, ind, vals)                  # (unbuffered: row after row, in index order)
+  got = D.reduce_sum(torch.from_numpy(ind[:, None]).cuda(), val_t(vals), [batch], False).cpu().numpy()
+  np.testing.assert_array_equal(got, exp)
+  # gather gradient: a fused buffer of 2^22 floats (22 + 1 key bits: three passes), 150 000 rows
+  dims, n_rows, slots = [8, 4], [90000, 60000], [200000, 300000]
+  base, offs_h, grads_h = 0, [], []
+  for d, nr, k in zip(dims, n_rows, slots):
+    o = rng.integers(0, k, nr)
+    o[rng.random(nr) < 0.2] = 17
+    offs_h.append((base + o * d).astype(np.int32))
+    grads_h.append(rng.standard_normal((nr, d)).astype(np.float32))
+    base += k * d
+  fused_len = 1 << 22
+  assert base <= fused_len
+  sc = np.float32(0.37)
+  exp = np.zeros(fused_len, np.float32)
+  for o, g, d in zip(offs_h, grads_h, dims):
+    np.add.at(exp, (o[:, None].astype(np.int64) + np.arange(d)[None, :]).ravel(), (g * sc).ravel())
+  offs = [torch.from_numpy(o).cuda() for o in offs_h]
+  grads = [val_t(g) for g in grads_h]
+  outs = [D.fused_gather_embeddings_by_input_gradient(fused_len, grads, offs, dims, scale=float(sc)).cpu().numpy()
+          for _ in range(2)]
+  np.testing.assert_array_equal(outs[0], exp)
+  assert np.array_equal(outs[0], outs[1])
 
 
 # =============================================================================== admission + eviction

@@ -1,8 +1,10 @@
-"""CPU suite, world_size 2 over gloo: the all-to-all exchange of monolith_amd/distributed_ps_sync.py
-(the N>1 path) against a single-process run of the reference semantics.  The local engine is a CPU
-stand-in built on the test oracle (the product's local engine is the HIP library and needs a GPU);
-what is under test is the sharding rule (fid mod N), the shard-major stable packing, the four
-exchanges and the un-permute / scatter — identical code to what runs over RCCL."""
+"""CPU suite, world_size 2 over gloo.  What is under test is tests/torch_sharded_step.py — round 1's
+torch.distributed form of the sharded step, a TEST HARNESS since round 6 (and bench.py's last-resort
+fallback), NOT the C++ step the product ships (csrc/mhte_shard_host.h; that one runs between processes on
+the GPU box: tests/test_shard_ipc_gpu.py, and its wire protocol between two gloo processes:
+tests/test_shard_protocol_oracle_gloo.py).  Covered here: the sharding rule (fid mod N), the shard-major
+stable packing, the four exchanges and the un-permute / scatter of that harness against a single-process
+run of the reference semantics, with a CPU stand-in of the local engine built on the test oracle."""
 import os
 import socket
 import sys
@@ -99,7 +101,7 @@ def _worker(rank, world, port, out_dir):
   os.environ["MASTER_ADDR"] = "127.0.0.1"
   os.environ["MASTER_PORT"] = str(port)
   dist.init_process_group("gloo", rank=rank, world_size=world)
-  from monolith_amd.distributed_ps_sync import ShardedEmbedding
+  from tests.torch_sharded_step import ShardedEmbedding
   be = OracleBackend()
   se = ShardedEmbedding(be)
   embs = []
@@ -183,7 +185,7 @@ def _gpu_worker(rank, world, port, out_dir):
   dist.init_process_group("gloo", rank=rank, world_size=world)
   torch.cuda.set_device(0)
   from monolith_amd import entry
-  from monolith_amd.distributed_ps_sync import HipBackend, ShardedEmbedding
+  from tests.torch_sharded_step import HipBackend, ShardedEmbedding
   from monolith_amd.multi_hash_table_ops import MultiHashTable
   cfg = entry.make_table_config([
       entry.CombineAsSegment(GPU_DIM, entry.ZerosInitializer(), entry.AdagradOptimizer(0.05, 0.1))
