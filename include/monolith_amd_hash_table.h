@@ -42,7 +42,7 @@ enum {
 
 const char* mhte_last_error(void);
 /* ABI version of this header; mhte_abi_version() must return the same value. */
-#define MHTE_ABI_VERSION 15
+#define MHTE_ABI_VERSION 16
 int32_t mhte_abi_version(void);
 
 /* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
@@ -747,6 +747,15 @@ mhte_status mhte_shard_step_info(mhte_shard_step* s, int64_t info[4]);
  * RT/ops/multi_hash_table_update_op.cc:247-308: every shard's segments in one op) the count does not
  * depend on the world size; per 32 tables of the model. */
 mhte_status mhte_shard_step_launches(mhte_shard_step* s, int32_t out[2]);
+/* What the step's last forward + backward put on the wire through send / recv pairs (the RCCL transport and the
+ * in-process group, whose device copies stand for the pairs; 0 for identity / peer stores):
+ * out[0] = pairs in total, [1] = exchanges, [2] = the most pairs any one exchange took, [3] = times the HOST
+ * waited for the id blocks' counts inside the two calls.  The exact-size form (RCCL with whole-batch blocks)
+ * packs the occupied part of a peer's table segments back to back: one pair per peer and exchange — [2] <=
+ * world (+ world when the next batch's id headers ride in the gradient exchange's group), not world x T —
+ * and a batch that was prepared a step ahead finds its counts on the host: [3] = 0.  The reference moves
+ * every exchange as ONE all-to-all-v per tensor (native_training/distributed_ps_sync.py:131-159,357-479). */
+mhte_status mhte_shard_step_wire_stats(mhte_shard_step* s, int64_t out[4]);
 /* out[0] = ncclCommCount, out[1] = ncclCommUserRank of the step's own RCCL communicator (0, 0 when the
  * step has none: identity, peer stores, in-process group) — a launcher checks out[0] == world on
  * every rank before it trusts a multi-GPU number */

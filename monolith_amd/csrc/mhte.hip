@@ -2115,7 +2115,8 @@ struct AuxWs {
   // in first-occurrence order; the consumers write one output row per key and do not care.  Keys outside
   // the range are dropped, which is what the consumers did with them.  MHTE_GROUP_DD=1 selects the dedup
   // form (A/B; read per call, so that a test can run both forms in one process).
-  DevBuf<uint32_t> k32a, k32b, posa, gs_hist, gs_tot, gs_heads;
+  DevBuf<uint32_t> k32b, gs_hist, gs_tot, gs_heads;
+  DevBuf<uint2> gs_kva, gs_kvb;
   static bool use_sort() {
     const char* e = getenv("MHTE_GROUP_DD");
     return !(e && atoi(e) != 0);
@@ -2130,9 +2131,7 @@ struct AuxWs {
     seg_off.reserve(size_t(n) + 2);
     seg_pos.reserve(size_t(n) + 1);
     nu.reserve(4);
-    k32a.reserve(size_t(n));
     k32b.reserve(size_t(n));
-    posa.reserve(size_t(n));
     const int bits = key_bits + 1;   // (`limit` = 2^key_bits itself is a key: the dropped ones, sorted last)
     const int passes = (bits + kGsMaxBits - 1) / kGsMaxBits;
     const int dig = (bits + passes - 1) / passes;
@@ -2148,15 +2147,18 @@ struct AuxWs {
     gs_tot.reserve(kGsMaxBins);
     P.hist = gs_hist.p;
     P.tot = gs_tot.p;
+    if (passes > 1) gs_kva.reserve(size_t(n));
+    if (passes > 2) gs_kvb.reserve(size_t(n));
     for (int j = 0; j < passes; ++j) {
       P.shift = uint32_t(j * dig);
       P.bits = uint32_t(std::min(dig, bits - j * dig));
-      const bool to_y = ((passes - 1 - j) & 1) == 0;   // the last pass leaves the positions in seg_pos
+      // (key, position) words ping-pong between two buffers; the last pass writes the consumers' arrays
+      const bool last = j == passes - 1;
       P.k64 = j == 0 ? k : nullptr;
-      P.kin = to_y ? k32a.p : k32b.p;
-      P.pin = to_y ? posa.p : seg_pos.p;
-      P.kout = to_y ? k32b.p : k32a.p;
-      P.pout = to_y ? seg_pos.p : posa.p;
+      P.kvin = j == 0 ? nullptr : ((j & 1) ? gs_kva.p : gs_kvb.p);
+      P.kvout = last ? nullptr : ((j & 1) ? gs_kvb.p : gs_kva.p);
+      P.kout = k32b.p;
+      P.pout = seg_pos.p;
       gs_hist_kernel<<<dim3(P.ntiles), kGsThreads, 0, st>>>(P);
       gs_rowscan_kernel<<<dim3(1u << P.bits), 64, 0, st>>>(P);
       gs_scatter_kernel<<<dim3(P.ntiles), kGsThreads, 0, st>>>(P);
@@ -4838,6 +4840,16 @@ mhte_status mhte_shard_step_launches(mhte_shard_step* s, int32_t out[2]) {
     if (!s || !out) throw Error(MHTE_INVALID_ARGUMENT, "null argument");
     out[0] = int32_t(s->ss.launches_fwd);
     out[1] = int32_t(s->ss.launches - s->ss.launches_fwd);
+  });
+}
+
+mhte_status mhte_shard_step_wire_stats(mhte_shard_step* s, int64_t out[4]) {
+  return guard([&] {
+    if (!s || !out) throw Error(MHTE_INVALID_ARGUMENT, "null argument");
+    out[0] = int64_t(s->ss.wire_pairs);
+    out[1] = int64_t(s->ss.wire_exchanges);
+    out[2] = int64_t(s->ss.wire_pairs_max);
+    out[3] = int64_t(s->ss.host_waits);
   });
 }
 

@@ -10,7 +10,7 @@
 // row order, so equal keys have to keep their positions ascending — a STABLE sort.
 //
 // One pass (digit of <= 10 bits, three launches):
-//   gs_hist      a workgroup (4 wavefronts) counts the digits of its tile of 8 192 keys in LDS and stores the
+//   gs_hist      a workgroup (4 wavefronts) counts the digits of its tile of 4 096 keys in LDS and stores the
 //                column H[bin][tile]
 //   gs_rowscan   one wavefront per bin: exclusive prefix of its row over the tiles, row total -> tot[bin]
 //   gs_scatter   the tile again: every WAVEFRONT owns a contiguous quarter of the tile, keys held in
@@ -19,7 +19,9 @@
 //                wavefront walks its keys 64 at a time IN ORDER: lanes with equal digits find each other
 //                with one ballot per digit bit (rank = equal-digit lanes below), the lowest of them moves the
 //                bin's cursor in LDS.  Stability needs no sorting inside the tile and no atomics at all.
-// Keys beyond the register-held tile size (n > 4 M) are walked in rounds of the same shape.
+// Between passes a key and its position travel as ONE 8-byte word (half the scattered stores of a pass); the
+// last pass writes the sorted keys and the positions as the two arrays the consumers read.
+// Keys beyond the register-held tile size (n > 2 M) are walked in rounds of the same shape.
 // Then gs_heads_count / gs_heads_emit compact the heads of the runs (two launches).
 // 1 M keys of 18 bits: 2 passes = 8 launches; 27 bits: 3 passes = 11 launches.
 #ifndef MHTE_GROUP_KERNELS_H_
@@ -31,8 +33,10 @@ namespace mhte {
 
 constexpr int kGsWaves = 4;                   // wavefronts per workgroup
 constexpr int kGsThreads = kGsWaves * 64;
-constexpr int kGsIters = 32;                  // 64-key steps a wavefront holds in registers per round
-constexpr int kGsRound = kGsIters * 64;       // keys per wavefront and round (2 048)
+constexpr int kGsIters = 16;                  // 64-key steps a wavefront holds in registers per round
+constexpr int kGsRound = kGsIters * 64;       // keys per wavefront and round (1 024: a tile of 4 096 keys — 1 M keys
+                                              // are 256 workgroups, one per CU; with 8 192 per tile half the chip
+                                              // took the scattered stores of a pass: 24.6 us per gs_scatter launch)
 constexpr int kGsMaxBits = 10;                // digit bits per pass
 constexpr int kGsMaxBins = 1 << kGsMaxBits;
 constexpr int kGsMaxTiles = 512;              // (gs_rowscan: 8 row entries per lane)
@@ -40,9 +44,9 @@ constexpr int kGsSelTile = 4096;              // sorted keys per workgroup of th
 
 struct GsPass {
   const int64_t* k64;      // first pass: the caller's keys, position = index (keys outside [0, limit) -> limit)
-  const uint32_t* kin;     // later passes: keys / positions as the previous pass left them
-  const uint32_t* pin;
-  uint32_t* kout;
+  const uint2* kvin;       // later passes: (key, position) words as the previous pass left them
+  uint2* kvout;            // every pass but the last: (key, position) words
+  uint32_t* kout;          // the last pass: sorted keys | their positions
   uint32_t* pout;
   uint32_t* hist;          // [bins][tstride]
   uint32_t* tot;           // [bins]
@@ -52,12 +56,13 @@ struct GsPass {
   uint32_t ntiles, tstride;
 };
 
-__device__ __forceinline__ uint32_t gs_load_key(const GsPass& P, uint32_t i) {
+// (key, position) of entry i of the pass's input
+__device__ __forceinline__ uint2 gs_load(const GsPass& P, uint32_t i) {
   if (P.k64) {
     const int64_t v = P.k64[i];
-    return (v >= 0 && v < int64_t(P.limit)) ? uint32_t(v) : P.limit;
+    return make_uint2((v >= 0 && v < int64_t(P.limit)) ? uint32_t(v) : P.limit, i);
   }
-  return P.kin[i];
+  return P.kvin[i];
 }
 
 __global__ __launch_bounds__(kGsThreads) void gs_hist_kernel(GsPass P) {
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(kGsThreads) void gs_hist_kernel(GsPass P) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const uint32_t i = i0 + uint32_t(q) * kGsThreads;
-      k[q] = gs_load_key(P, i < hi ? i : lo);
+      k[q] = gs_load(P, i < hi ? i : lo).x;
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q)
@@ -160,8 +165,9 @@ __global__ __launch_bounds__(kGsThreads) void gs_scatter_kernel(GsPass P) {
 #pragma unroll
     for (int it = 0; it < kGsIters; ++it) {
       const uint32_t i = base + uint32_t(it) * 64u;
-      k[it] = gs_load_key(P, i < whi ? i : 0u);
-      p[it] = P.k64 ? i : P.pin[i < whi ? i : 0u];
+      const uint2 kv = gs_load(P, i < whi ? i : 0u);
+      k[it] = kv.x;
+      p[it] = kv.y;
     }
 #pragma unroll
     for (int it = 0; it < kGsIters; ++it)
@@ -186,8 +192,9 @@ __global__ __launch_bounds__(kGsThreads) void gs_scatter_kernel(GsPass P) {
 #pragma unroll
       for (int it = 0; it < kGsIters; ++it) {
         const uint32_t i = base + uint32_t(it) * 64u;
-        k[it] = gs_load_key(P, i < whi ? i : 0u);
-        p[it] = P.k64 ? i : P.pin[i < whi ? i : 0u];
+        const uint2 kv = gs_load(P, i < whi ? i : 0u);
+        k[it] = kv.x;
+        p[it] = kv.y;
       }
     }
 #pragma unroll
@@ -205,8 +212,12 @@ __global__ __launch_bounds__(kGsThreads) void gs_scatter_kernel(GsPass P) {
         const uint32_t c = cur[w][d];
         if (below == 0) cur[w][d] = c + uint32_t(__popcll(peers));
         const uint32_t o = c + uint32_t(__popcll(below));
-        P.kout[o] = k[it];
-        P.pout[o] = p[it];
+        if (P.kvout) {
+          P.kvout[o] = make_uint2(k[it], p[it]);
+        } else {
+          P.kout[o] = k[it];
+          P.pout[o] = p[it];
+        }
       }
       // (LDS operations of one wavefront execute in order: the next step's read sees this step's write)
     }

@@ -547,6 +547,8 @@ __global__ __launch_bounds__(256, MHTE_MBWD_OCC) void mstep_bwd_kernel(MBwdArgs 
   c.uloc = bt.hints ? s.uloc[cur] : nullptr;
   c.uts = bt.hints ? s.uts[cur] : nullptr;
   c.trusted = 1;   // (the host hands the hints over only while Table::mut_epoch is unchanged)
+  c.urec = nullptr;
+  c.pre_summed = 0;   // (MHTE_EXACT_ORDER here: every list walked by its lane group, light_max = all)
   mstep_apply_switch<ONESEG, FULL, VW, FILT>(bt.gv, tv, d, c, bt.a, bid, wt, L);
   wt.end(bid < bt.nblk_items ? 7u : 8u);
 }

@@ -182,6 +182,19 @@ struct ShardStep {
   bool exact = false;
   int64_t* h_cnt[2] = {nullptr, nullptr};   // per slot [2 (sent | received)][world][hdr]
   hipEvent_t ev_cnt[2] = {nullptr, nullptr};
+  // Round 6 — the exact form on the wire: ONE ncclSend / ncclRecv pair per peer and exchange.  The occupied
+  // parts of a peer's (table) segments are packed back to back into `stage_snd` (shard_pack_kernel), the pair
+  // moves the packed stream into `stage_rcv`, the receiver spreads it over its block again: pack + group +
+  // unpack = 3 launches per exchange instead of world x T pairs (208 per exchange at 8 ranks x 26 tables).
+  // And the id exchange's host wait has left the step: the HEADERS of batch s + 1 cross in the group of
+  // batch s's gradient exchange (backward), their counts are on their way to the host from then on, and the
+  // packed ids follow at the start of the next forward — by then the counts have long landed (a batch that was
+  // not prepared ahead still waits, and `host_waits` counts it).
+  char* stage_snd = nullptr;
+  char* stage_rcv = nullptr;
+  bool ids_hdr_sent[2] = {false, false};    // the slot's id HEADERS have crossed, its ids have not
+  // what the last forward + backward put on the wire (mhte_shard_step_wire_stats)
+  uint64_t wire_pairs = 0, wire_exchanges = 0, wire_pairs_max = 0, host_waits = 0;
   uint32_t hdr_words = 0;
   bool hdr_dirty[2] = {false, false};   // the slot's send headers hold counts
   bool disp[2] = {false, false};        // the slot's batch has been dispatched (ids exchanged)
@@ -266,6 +279,8 @@ struct ShardStep {
       if (h_cnt[s]) (void)hipHostFree(h_cnt[s]);
       if (ev_cnt[s]) (void)hipEventDestroy(ev_cnt[s]);
     }
+    if (stage_snd) (void)hipFree(stage_snd);
+    if (stage_rcv) (void)hipFree(stage_rcv);
   }
 
   void init(mhte_multi_table* m, int64_t mb, int rank_, int world_, int64_t ids_per_peer_table,
@@ -379,6 +394,11 @@ struct ShardStep {
         memset(h_cnt[s], 0, size_t(2) * world * hdr * sizeof(int64_t));
         HIP_OK(hipEventCreateWithFlags(&ev_cnt[s], hipEventDisableTiming));
       }
+    if (exact) {
+      const size_t sb = std::max(ib, rb) + 64;
+      HIP_OK(hipMalloc(reinterpret_cast<void**>(&stage_snd), sb));
+      HIP_OK(hipMalloc(reinterpret_cast<void**>(&stage_rcv), sb));
+    }
     if (const char* e = getenv("MHTE_SHARD_OVERLAP")) set_overlap(atoi(e));
     // (a job-wide setting: the world-1 identity step has no wire to narrow and ignores it)
     if (const char* e = getenv("MHTE_SHARD_GRAD_FP16"))
@@ -469,6 +489,7 @@ struct ShardStep {
     dedup(ids, split, slot, aux);
     build_and_sum(slot, -1, nullptr, aux);
     ids_exchanged[slot] = false;
+    ids_hdr_sent[slot] = false;
     if (alias) {
       ids_exchanged[slot] = true;
     } else if (ipc) {
@@ -831,6 +852,7 @@ struct ShardStep {
     ms.stage[slot] = 1;
     disp[slot] = false;
     ids_exchanged[slot] = false;
+    ids_hdr_sent[slot] = false;
   }
 
   // -> gt_all[T]: the workgroup shares are of the whole model (every chunk's launches run together)
@@ -1115,6 +1137,7 @@ struct ShardStep {
     ms.stage[slot_next] = 1;
     disp[slot_next] = false;
     ids_exchanged[slot_next] = false;
+    ids_hdr_sent[slot_next] = false;
   }
 
   // arguments of the owner-side launches for tables [t0, t0 + tc)
@@ -1373,54 +1396,115 @@ struct ShardStep {
     return uint32_t(std::min<int64_t>(std::max<int64_t>(c, 0), int64_t(cap)));
   }
 
-  // block p of the source goes to peer p, block p of the destination comes from peer p
-  void exchange_rccl(int kind, int slot, hipStream_t st) {
+  // ---- the exact form's pieces ---------------------------------------------------------------------------
+  // the slot's counts on the host (its headers were fetched behind their exchange): not a wait when the batch
+  // was prepared ahead
+  void counts_ready(int slot) {
+    if (hipEventQuery(ev_cnt[slot]) != hipSuccess) {
+      ++host_waits;
+      HIP_OK(hipEventSynchronize(ev_cnt[slot]));
+    }
+  }
+  // bytes of the packed stream between this rank and peer p: `sent` = sized by the ids this rank sent p
+  size_t packed_bytes(int kind, int slot, bool sent, int p) const {
+    size_t n = 0;
+    for (uint32_t t = 0; t < T; ++t)
+      n += size_t(shard_packed_bytes(seg_rows(slot, sent, p, t), tab[t].dim, kind == kXIds,
+                                     kind == kXGrads && grad_bits == 16));
+    return n;
+  }
+  template <bool UNPACK>
+  void pack(int kind, const void* src, void* dst, const int64_t* counts, hipStream_t st) {
+    ShardPackArgs A{};
+    A.src = static_cast<const char*>(src);
+    A.dst = static_cast<char*>(dst);
+    A.counts = counts;
+    A.geo = geo;
+    A.ids = kind == kXIds ? 1u : 0u;
+    A.half = (kind == kXGrads && grad_bits == 16) ? 1u : 0u;
+    A.tab = d_tab;
+    const uint32_t gx = std::max<uint32_t>(4, uint32_t(ms.num_cus) * 4 / uint32_t(world));
+    shard_pack_kernel<UNPACK><<<dim3(gx, uint32_t(world)), 256, 0, st>>>(A);
+    HIP_OK(hipGetLastError());
+    ++launches;
+  }
+  // which id buffer's headers size what this rank SENDS in an exchange of `kind` (the other one sizes what it
+  // receives): gradient sums and ids go out for the ids this rank sent, rows for the ids it was sent
+  const int64_t* counts_out(int kind, int slot) const { return kind == kXRows ? ids_recv[slot] : ids_send[slot]; }
+  const int64_t* counts_in(int kind, int slot) const { return kind == kXRows ? ids_send[slot] : ids_recv[slot]; }
+  void note_pairs(uint64_t pairs) {
+    wire_pairs += pairs;
+    ++wire_exchanges;
+    wire_pairs_max = std::max(wire_pairs_max, pairs);
+  }
+  // the HEADERS of the slot's id blocks inside an open send / recv group
+  void group_id_headers(Rccl& R, int slot, hipStream_t st) {
+    const size_t b = x_block(kXIds), hb = size_t(hdr_words) * sizeof(int64_t);
+    const char* src = static_cast<const char*>(x_src(kXIds, slot));
+    char* dst = static_cast<char*>(x_dst(kXIds, slot));
+    for (int p = 0; p < world; ++p) {
+      R.ok(R.Send(src + size_t(p) * b, hb, ncclInt8, p, comm, st), "Send");
+      R.ok(R.Recv(dst + size_t(p) * b, hb, ncclInt8, p, comm, st), "Recv");
+    }
+  }
+  // the packed payload of one exchange: pack, ONE pair per peer, unpack
+  void exchange_packed(int kind, int slot, hipStream_t st, int hdr_slot = -1) {
     Rccl& R = Rccl::get();
-    ++launches;   // (one send / recv group; the exact-size id form: two)
+    counts_ready(slot);
+    const bool out_sent = kind != kXRows;
+    pack<false>(kind, x_src(kind, slot), stage_snd, counts_out(kind, slot), st);
+    const size_t b = x_block(kind);
+    uint64_t pairs = 0;
+    R.ok(R.GroupStart(), "GroupStart");
+    for (int p = 0; p < world; ++p) {
+      const size_t ns = packed_bytes(kind, slot, out_sent, p), nr = packed_bytes(kind, slot, !out_sent, p);
+      if (ns) R.ok(R.Send(stage_snd + size_t(p) * b, ns, ncclInt8, p, comm, st), "Send");
+      if (nr) R.ok(R.Recv(stage_rcv + size_t(p) * b, nr, ncclInt8, p, comm, st), "Recv");
+      pairs += (ns || nr) ? 1u : 0u;
+    }
+    if (hdr_slot >= 0) {   // the next batch's id headers ride in this group
+      group_id_headers(R, hdr_slot, st);
+      pairs += uint64_t(world);
+    }
+    R.ok(R.GroupEnd(), "GroupEnd");
+    ++launches;
+    note_pairs(pairs);
+    pack<true>(kind, stage_rcv, x_dst(kind, slot), counts_in(kind, slot), st);
+    if (hdr_slot >= 0) {
+      fetch_counts(hdr_slot, st);
+      ids_hdr_sent[hdr_slot] = true;
+    }
+  }
+
+  // block p of the source goes to peer p, block p of the destination comes from peer p
+  // hdr_slot (exact form, gradient exchange only): the id HEADERS of that slot's batch cross in the same group
+  void exchange_rccl(int kind, int slot, hipStream_t st, int hdr_slot = -1) {
+    Rccl& R = Rccl::get();
     const char* src = static_cast<const char*>(x_src(kind, slot));
     char* dst = static_cast<char*>(x_dst(kind, slot));
     const size_t b = x_block(kind);
     if (exact && kind != kXIds) {
-      HIP_OK(hipEventSynchronize(ev_cnt[slot]));   // (long done unless the batch was not prepared ahead)
-      const bool out_sent = kind == kXGrads;       // gradients: what I sent ids for; rows: what I was asked
-      R.ok(R.GroupStart(), "GroupStart");
-      for (int p = 0; p < world; ++p)
-        for (uint32_t t = 0; t < T; ++t) {
-          const size_t es = x_elem(kind);
-          const size_t off = size_t(p) * b + size_t(tab[t].row_off) * es;
-          const size_t ns = size_t(seg_rows(slot, out_sent, p, t)) * tab[t].dim * es;
-          const size_t nr = size_t(seg_rows(slot, !out_sent, p, t)) * tab[t].dim * es;
-          if (ns) R.ok(R.Send(src + off, ns, ncclInt8, p, comm, st), "Send");
-          if (nr) R.ok(R.Recv(dst + off, nr, ncclInt8, p, comm, st), "Recv");
-        }
-      R.ok(R.GroupEnd(), "GroupEnd");
+      exchange_packed(kind, slot, st, hdr_slot);
       return;
     }
     if (exact && kind == kXIds) {
       // the id blocks exact-size too (whole-batch blocks are world x T x batch ids per rank: ~110 MB
-      // each way at 26 tables x 65 536 ids x 8 ranks): the headers cross first, their counts come to
-      // the host, then every (peer, table) segment moves at its occupied size
-      const size_t hb = size_t(hdr_words) * sizeof(int64_t);
-      R.ok(R.GroupStart(), "GroupStart");
-      for (int p = 0; p < world; ++p) {
-        R.ok(R.Send(src + size_t(p) * b, hb, ncclInt8, p, comm, st), "Send");
-        R.ok(R.Recv(dst + size_t(p) * b, hb, ncclInt8, p, comm, st), "Recv");
+      // each way at 26 tables x 65 536 ids x 8 ranks): the headers cross first (with the previous
+      // batch's gradient exchange when this batch was prepared ahead), their counts come to the host,
+      // then the occupied part of every segment, packed: one pair per peer
+      if (!ids_hdr_sent[slot]) {
+        R.ok(R.GroupStart(), "GroupStart");
+        group_id_headers(R, slot, st);
+        R.ok(R.GroupEnd(), "GroupEnd");
+        ++launches;
+        note_pairs(uint64_t(world));
+        fetch_counts(slot, st);
       }
-      R.ok(R.GroupEnd(), "GroupEnd");
-      fetch_counts(slot, st);
-      HIP_OK(hipEventSynchronize(ev_cnt[slot]));
-      R.ok(R.GroupStart(), "GroupStart");
-      for (int p = 0; p < world; ++p)
-        for (uint32_t t = 0; t < T; ++t) {
-          const size_t off = size_t(p) * b + size_t(tab[t].id_off) * sizeof(int64_t);
-          const size_t ns = size_t(seg_rows(slot, true, p, t)) * sizeof(int64_t);
-          const size_t nr = size_t(seg_rows(slot, false, p, t)) * sizeof(int64_t);
-          if (ns) R.ok(R.Send(src + off, ns, ncclInt8, p, comm, st), "Send");
-          if (nr) R.ok(R.Recv(dst + off, nr, ncclInt8, p, comm, st), "Recv");
-        }
-      R.ok(R.GroupEnd(), "GroupEnd");
+      ids_hdr_sent[slot] = false;
+      exchange_packed(kXIds, slot, st);
       return;
     }
+    ++launches;   // (one send / recv group)
     R.ok(R.GroupStart(), "GroupStart");
     for (int p = 0; p < world; ++p) {
       R.ok(R.Send(src + size_t(p) * b, b, ncclInt8, p, comm, st), "Send");
@@ -1431,63 +1515,69 @@ struct ShardStep {
   }
 };
 
-// the ranks of one process (all of them: a test, or one process driving several tables on one GPU)
-static void shard_exchange(ShardStep** S, int n, int kind, int slot, hipStream_t st) {
+// the ranks of one process (all of them: a test, or one process driving several tables on one GPU): device
+// copies stand in for the links, everything else — the packing, the header / payload split of the exact form,
+// the counts on the host — is the code the RCCL transport runs
+static void group_id_headers(ShardStep** S, int n, int slot, hipStream_t st) {
+  const size_t hb = size_t(S[0]->hdr_words) * sizeof(int64_t);
+  for (int r = 0; r < n; ++r)
+    for (int p = 0; p < n; ++p) {
+      const size_t b = S[r]->x_block(kXIds);
+      HIP_OK(hipMemcpyAsync(static_cast<char*>(S[p]->x_dst(kXIds, slot)) + size_t(r) * b,
+                            static_cast<const char*>(S[r]->x_src(kXIds, slot)) + size_t(p) * b, hb,
+                            hipMemcpyDeviceToDevice, st));
+    }
+  for (int r = 0; r < n; ++r) {
+    S[r]->fetch_counts(slot, st);
+    S[r]->ids_hdr_sent[slot] = true;
+    S[r]->note_pairs(uint64_t(n));
+  }
+}
+static void group_packed(ShardStep** S, int n, int kind, int slot, hipStream_t st) {
+  for (int r = 0; r < n; ++r) {
+    S[r]->counts_ready(slot);
+    S[r]->pack<false>(kind, S[r]->x_src(kind, slot), S[r]->stage_snd, S[r]->counts_out(kind, slot), st);
+  }
+  for (int r = 0; r < n; ++r) {
+    uint64_t pairs = 0;
+    for (int p = 0; p < n; ++p) {
+      const size_t b = S[r]->x_block(kind);
+      const size_t nb = S[r]->packed_bytes(kind, slot, kind != kXRows, p);   // what rank r sends to p
+      if (nb) HIP_OK(hipMemcpyAsync(S[p]->stage_rcv + size_t(r) * b, S[r]->stage_snd + size_t(p) * b, nb,
+                                    hipMemcpyDeviceToDevice, st));
+      pairs += nb ? 1u : 0u;
+    }
+    S[r]->note_pairs(pairs);
+  }
+  for (int r = 0; r < n; ++r)
+    S[r]->pack<true>(kind, S[r]->stage_rcv, S[r]->x_dst(kind, slot), S[r]->counts_in(kind, slot), st);
+}
+// hdr_slot (exact form, gradient exchange): the id HEADERS of that slot's batch cross with this exchange
+static void shard_exchange(ShardStep** S, int n, int kind, int slot, hipStream_t st, int hdr_slot = -1) {
   if (n > 1)   // (device copies stand in for the links: one exchange per rank and kind)
     for (int r = 0; r < n; ++r) ++S[r]->launches;
   if (n == 1) {
     if (S[0]->alias) return;
     if (S[0]->ipc) S[0]->exchange_ipc(kind, slot, st);
-    else S[0]->exchange_rccl(kind, slot, st);
+    else S[0]->exchange_rccl(kind, slot, st, S[0]->exact ? hdr_slot : -1);
     return;
   }
-  if (S[0]->exact && kind == kXIds) {
-    // (as exchange_rccl: headers, counts to the host, then the occupied part of every segment)
-    const size_t hb = size_t(S[0]->hdr_words) * sizeof(int64_t);
-    for (int r = 0; r < n; ++r)
-      for (int p = 0; p < n; ++p) {
-        const size_t b = S[r]->x_block(kind);
-        HIP_OK(hipMemcpyAsync(static_cast<char*>(S[p]->x_dst(kind, slot)) + size_t(r) * b,
-                              static_cast<const char*>(S[r]->x_src(kind, slot)) + size_t(p) * b, hb,
-                              hipMemcpyDeviceToDevice, st));
-      }
-    for (int r = 0; r < n; ++r) S[r]->fetch_counts(slot, st);
-    for (int r = 0; r < n; ++r) HIP_OK(hipEventSynchronize(S[r]->ev_cnt[slot]));
-    for (int r = 0; r < n; ++r)
-      for (int p = 0; p < n; ++p) {
-        const size_t b = S[r]->x_block(kind);
-        for (uint32_t t = 0; t < S[r]->T; ++t) {
-          const size_t off = size_t(S[r]->tab[t].id_off) * sizeof(int64_t);
-          const size_t nb = size_t(S[r]->seg_rows(slot, true, p, t)) * sizeof(int64_t);
-          if (nb)
-            HIP_OK(hipMemcpyAsync(static_cast<char*>(S[p]->x_dst(kind, slot)) + size_t(r) * b + off,
-                                  static_cast<const char*>(S[r]->x_src(kind, slot)) + size_t(p) * b + off, nb,
-                                  hipMemcpyDeviceToDevice, st));
-        }
-      }
+  if (S[0]->exact) {
+    if (kind == kXIds) {
+      if (!S[0]->ids_hdr_sent[slot]) group_id_headers(S, n, slot, st);
+      for (int r = 0; r < n; ++r) S[r]->ids_hdr_sent[slot] = false;
+    }
+    group_packed(S, n, kind, slot, st);
+    if (kind != kXIds && hdr_slot >= 0) group_id_headers(S, n, hdr_slot, st);
     return;
   }
-  const bool exact = S[0]->exact && kind != kXIds;
-  if (exact)
-    for (int r = 0; r < n; ++r) HIP_OK(hipEventSynchronize(S[r]->ev_cnt[slot]));
   for (int r = 0; r < n; ++r)
     for (int p = 0; p < n; ++p) {
       const size_t b = S[r]->x_block(kind);
       char* dst = static_cast<char*>(S[p]->x_dst(kind, slot)) + size_t(r) * b;
       const char* src = static_cast<const char*>(S[r]->x_src(kind, slot)) + size_t(p) * b;
-      if (!exact) {
-        HIP_OK(hipMemcpyAsync(dst, src, b, hipMemcpyDeviceToDevice, st));
-        continue;
-      }
-      // what rank r sends to p: gradients of the ids r sent to p / rows of the ids p sent to r
-      for (uint32_t t = 0; t < S[r]->T; ++t) {
-        const size_t off = size_t(S[r]->tab[t].row_off) * S[r]->x_elem(kind);
-        const size_t nb = size_t(S[r]->seg_rows(slot, kind == kXGrads, p, t)) * S[r]->tab[t].dim * S[r]->x_elem(kind);
-        if (nb) HIP_OK(hipMemcpyAsync(dst + off, src + off, nb, hipMemcpyDeviceToDevice, st));
-      }
+      HIP_OK(hipMemcpyAsync(dst, src, b, hipMemcpyDeviceToDevice, st));
     }
-  if (kind == kXIds)
-    for (int r = 0; r < n; ++r) S[r]->fetch_counts(slot, st);
 }
 
 static void shard_check_group(ShardStep** S, int n) {
@@ -1539,6 +1629,7 @@ static void shard_forward(ShardStep** S, int n, const ShardFwd* a, int64_t n_spl
     ShardStep& s = *S[r];
     HIP_OK(hipSetDevice(s.device));
     s.launches = 0;
+    s.wire_pairs = s.wire_exchanges = s.wire_pairs_max = s.host_waits = 0;
     s.join_aux(st);
     s.prepare(st, /*keep_owed_pass=*/true);
     if (prefetched) {
@@ -1614,8 +1705,12 @@ static void shard_backward(ShardStep** S, int n, const float* const* grads, cons
       ++S[r]->launches;
     }
   }
-  shard_exchange(S, n, kXGrads, cur, st);
-  if (build_next) {
+  // the exact form (RCCL with whole-batch blocks): only the next batch's id HEADERS cross here, in the gradient
+  // exchange's group; its packed ids follow at the next forward, when their counts have reached the host — no
+  // host wait inside the step (round 5 waited for the counts right here)
+  const bool split_ids = build_next && S[0]->exact && !S[0]->alias && !S[0]->ipc;
+  shard_exchange(S, n, kXGrads, cur, st, split_ids ? (cur ^ 1) : -1);
+  if (build_next && !split_ids) {
     shard_exchange(S, n, kXIds, cur ^ 1, st);
     for (int r = 0; r < n; ++r) S[r]->ids_exchanged[cur ^ 1] = true;
   }

@@ -1134,6 +1134,67 @@ __global__ __launch_bounds__(256) void shard_push_kernel(ShardPushArgs A) {
   }
 }
 
+// ---- RCCL transport, exact-size form: ONE send / recv pair per peer and exchange (round 6) -----------------
+// A (peer, table) segment of a wire block sits at a fixed offset and is occupied from its start; what crosses
+// is the occupied part.  Round 5 issued one ncclSend / ncclRecv pair per (peer, table) — 208 pairs per
+// exchange at 8 ranks x 26 tables.  Now the occupied parts of a peer's segments are packed back to back into
+// a staging block by this kernel (PACK; every segment rounded up to 16 bytes), ONE pair per peer moves the
+// packed stream, and the receiver spreads it over its block again (UNPACK) — the counts are the id blocks'
+// headers, read on the device, the same ones the host sizes the pair with.  grid (x, world), y = peer.
+struct ShardPackArgs {
+  const char* src;            // [world][block]
+  char* dst;                  // [world][block]
+  const int64_t* counts;      // [world][ids_block]: the headers that size the segments
+  ShardGeom geo;
+  uint32_t ids;               // 1: id blocks (the int64 slots; the header is not part of the stream)
+  uint32_t half;              // row blocks of 16-bit elements (the fp16 gradient wire)
+  const ShardTab* tab;        // [T], device memory
+};
+// bytes of the occupied part of a segment on the wire, rounded up to 16 (the host computes the same)
+__host__ __device__ __forceinline__ uint64_t shard_packed_bytes(uint32_t n, uint32_t dim, bool ids, bool half) {
+  const uint64_t b = ids ? uint64_t(n) * 8u : uint64_t(n) * dim * (half ? 2u : 4u);
+  return (b + 15u) & ~uint64_t(15);
+}
+// exactly `bytes` bytes (all offsets on the wire are multiples of 4): 16-byte pieces where both sides are
+// aligned for them, 4-byte pieces otherwise (fp16 blocks of odd-dim tables), then the last bytes
+__device__ __forceinline__ void pack_copy(char* dst, const char* src, uint64_t bytes, uint32_t first, uint32_t stride) {
+  if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) == 0u) {
+    const uint4* s = reinterpret_cast<const uint4*>(src);
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    const uint64_t n16 = bytes / 16u;
+    for (uint64_t i = first; i < n16; i += stride) d[i] = s[i];
+    for (uint64_t i = n16 * 16u + first; i < bytes; i += stride) dst[i] = src[i];
+  } else {
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    const uint64_t n4 = bytes / 4u;
+    for (uint64_t i = first; i < n4; i += stride) d[i] = s[i];
+    for (uint64_t i = n4 * 4u + first; i < bytes; i += stride) dst[i] = src[i];
+  }
+}
+template <bool UNPACK>
+__global__ __launch_bounds__(256) void shard_pack_kernel(ShardPackArgs A) {
+  const uint32_t p = blockIdx.y;
+  const size_t es = A.half ? 2 : 4;
+  const size_t blk = A.ids ? size_t(A.geo.ids_block) * 8 : size_t(A.geo.rows_block) * es;
+  const char* src = A.src + size_t(p) * blk;
+  char* dst = A.dst + size_t(p) * blk;
+  const int64_t* hdr = A.counts + size_t(p) * A.geo.ids_block;
+  const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  uint64_t poff = 0;
+  for (uint32_t t = 0; t < A.geo.T; ++t) {
+    const ShardTab tb = A.tab[t];
+    const uint64_t c = uint64_t(hdr[t]);
+    const uint32_t n = c > tb.cap ? tb.cap : uint32_t(c);
+    if (!n) continue;
+    const uint64_t bytes = A.ids ? uint64_t(n) * 8u : uint64_t(n) * tb.dim * es;   // (the occupied part, exactly:
+    const size_t uoff = A.ids ? size_t(tb.id_off) * 8 : size_t(tb.row_off) * es;   //  the next segment is not touched)
+    if (UNPACK) pack_copy(dst + uoff, src + poff, bytes, first, stride);
+    else pack_copy(dst + poff, src + uoff, bytes, first, stride);
+    poff += shard_packed_bytes(n, tb.dim, A.ids != 0, A.half != 0);
+  }
+}
+
 // The fp16 gradient wire (the reference's optional cast of the gradient all-to-all,
 // NT/distributed_ps_sync.py:47,334-337: `grad_flat` goes out as tf.float16 and is cast back by the
 // owner): NARROW = sender, fp32 sums -> fp16 (round to nearest even) before the exchange; !NARROW =

@@ -242,6 +242,13 @@ class ShardedMultiStep:
       d["rccl_ranks"], d["rccl_rank"] = self.comm_ranks()
     return d
 
+  def wire_stats(self):
+    """(send / recv pairs, exchanges, most pairs in one exchange, host waits for counts) of the last forward +
+    backward (mhte_shard_step_wire_stats): the exact-size RCCL form packs a peer's segments into one pair."""
+    out = (C.c_int64 * 4)()
+    self._libmod.check(self._lib.mhte_shard_step_wire_stats(self._h, out))
+    return {"pairs": int(out[0]), "exchanges": int(out[1]), "pairs_max": int(out[2]), "host_waits": int(out[3])}
+
   def comm_ranks(self):
     """(ncclCommCount, ncclCommUserRank) of the step's own RCCL communicator; (0, 0) without one."""
     out = (C.c_int32 * 2)()
@@ -342,6 +349,15 @@ class ShardedStepGroup:
       ln = (C.c_int32 * 2)()
       self._libmod.check(self._lib.mhte_shard_step_launches(h, ln))
       out.append((int(ln[0]), int(ln[1])))
+    return out
+
+  def wire_stats(self):
+    """Per rank: mhte_shard_step_wire_stats of the last forward + backward (device copies stand for the pairs)."""
+    out = []
+    for h in self._hs:
+      w = (C.c_int64 * 4)()
+      self._libmod.check(self._lib.mhte_shard_step_wire_stats(h, w))
+      out.append({"pairs": int(w[0]), "exchanges": int(w[1]), "pairs_max": int(w[2]), "host_waits": int(w[3])})
     return out
 
   def forward(self, raggeds, next_raggeds=None, prefetched=False):
