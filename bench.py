@@ -24,6 +24,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The HIP runtime keeps the kernel arguments of an EAGER launch in host memory unless told otherwise (the nodes
+# of a hipGraph get theirs in device memory).  The step kernels take ~1.5 KB of arguments each and read them
+# with scalar loads: over PCIe those reads made step_bwd 19.8 us instead of 15.7 in the event-timed pass and the
+# eager C loop 46.8 us per step instead of 38.4 (profiles/r06/host_enqueue.md).  The runtime's own switch, set
+# before it is loaded; a process that embeds the library (the TF shim of INTEGRATION.md) exports the same.  The
+# graph-replayed headline does not depend on it.  An explicit setting of the caller wins.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable copy
 PROBE_BYTES = 72        # keys+tags of both candidate buckets
 
@@ -1415,7 +1423,10 @@ def main():
                        "the same %d steps enqueued by a plain C loop over mhte_table_step_forward / _backward "
                        "(csrc/eager_loop.c: what a TF OpKernel pair pays without a graph); exact_order = the "
                        "bit-exact mode (MHTE_EXACT_ORDER: every duplicate list summed strictly in occurrence "
-                       "order), hipGraph replay" % K,
+                       "order; since round 6 the heavy lists are streamed through LDS by rd_exact_sum_kernel), "
+                       "hipGraph replay.  HIP_FORCE_DEV_KERNARG=%s: the runtime's switch for where an eager launch's "
+                       "kernel arguments live (1 = device memory, set by this script unless the caller set it)"
+                       % (K, os.environ.get("HIP_FORCE_DEV_KERNARG", "")),
         "reference_window": None if not ref_key else {
             "steps": steps_of[ref_key], "launch": ref_key.split("_")[0],
             "ms_per_step": round(results[ref_key] / steps_of[ref_key] * 1e3, 5),

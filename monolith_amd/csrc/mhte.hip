@@ -2228,10 +2228,12 @@ static int current_device() {
   return d;
 }
 
+// zeroed (gradient only): the caller has just filled `fused` with zeros — the first launch may store without
+// reading the destination
 template <bool GATHER>
 static void fused_gather(float* fused, int32_t n_inputs, const int32_t* const* offsets,
                          const int64_t* n, const int32_t* dims, float* const* rows, float scale,
-                         hipStream_t st, int64_t fused_len = int64_t(1) << 31) {
+                         hipStream_t st, int64_t fused_len = int64_t(1) << 31, bool zeroed = false) {
   if (n_inputs < 0) throw Error(MHTE_INVALID_ARGUMENT, "n_inputs must be >= 0");
   int key_bits = 1;   // (offsets are int32 and lie inside the fused buffer)
   while (key_bits < 31 && (int64_t(1) << key_bits) < fused_len) ++key_bits;
@@ -2265,7 +2267,7 @@ static void fused_gather(float* fused, int32_t n_inputs, const int32_t* const* o
       for (int32_t k = 0; k < in.n_inputs; ++k) vec = vec && (in.dim[k] & 3) == 0;
       if (vec)
         gather_grad_lists_vec_kernel<<<dim3(uint32_t(((acc + kGatherGradKeys - 1) / kGatherGradKeys * 16 + 255) / 256)), 256, 0, st>>>(
-            fused, in, scale, ws.uids.p, ws.nu.p, ws.seg_off.p, ws.seg_pos.p);
+            fused, in, scale, ws.uids.p, ws.nu.p, ws.seg_off.p, ws.seg_pos.p, (zeroed && i0 == 0) ? 1 : 0);
       else
         gather_grad_lists_kernel<<<dim3(uint32_t((acc * 8 + 255) / 256)), 256, 0, st>>>(
             fused, in, scale, ws.uids.p, ws.nu.p, ws.seg_off.p, ws.seg_pos.p);
@@ -2307,7 +2309,7 @@ mhte_status mhte_fused_gather_embeddings_by_input_gradient(float* fused_grad, in
       HIP_OK(hipGetLastError());
     }
     fused_gather<false>(fused_grad, n_inputs, offsets, n, dims, const_cast<float* const*>(grads),
-                        scale, S(stream), fused_len > 0 ? fused_len : 1);
+                        scale, S(stream), fused_len > 0 ? fused_len : 1, /*zeroed=*/fused_len > 0);
   });
 }
 

@@ -257,12 +257,16 @@ __global__ __launch_bounds__(256) void gather_keys_kernel(GatherInputs in, int64
 // the addends of a key are fetched four at a time.  Same arithmetic: acc = acc + x * scale in row order, then
 // one read-modify-write of the destination.
 constexpr int kGatherGradKeys = 4;   // keys a lane group works on at once (their round trips overlap)
+// fresh: the fused buffer is known to be all zeros (the entry point has just filled it and this is its first
+// launch): a destination is then stored without being read first — 0 + acc is acc bit for bit, a sum that
+// started as 0 + x is never -0 — a third of the launch's bytes (round 6: 126 -> ~100 us for 1 M keys).
 __global__ __launch_bounds__(256) void gather_grad_lists_vec_kernel(float* __restrict__ fused, GatherInputs in,
                                                                     float scale,
                                                                     const int64_t* __restrict__ keys,
                                                                     const uint32_t* __restrict__ n_keys,
                                                                     const uint32_t* __restrict__ seg_off,
-                                                                    const uint32_t* __restrict__ seg_pos) {
+                                                                    const uint32_t* __restrict__ seg_pos,
+                                                                    int fresh) {
   constexpr int G = 16, K = kGatherGradKeys;
   __shared__ long long s_start[kMaxGatherInputs + 1];
   __shared__ const float* s_rows[kMaxGatherInputs];
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(256) void gather_grad_lists_vec_kernel(float* __res
     vec_zero(f[t]);
     if (fast[t] && j * 4 < dim[t]) {
       v[t].load(s_rows[i0[t]] + (r0[t] - s_start[i0[t]]) * dim[t] + j * 4);
-      f[t].load(fused + off[t] + j * 4);
+      if (!fresh) f[t].load(fused + off[t] + j * 4);
     }
   }
 #pragma unroll
@@ -370,7 +374,8 @@ __global__ __launch_bounds__(256) void gather_grad_lists_vec_kernel(float* __res
           }
       }
       Vec<4> g2;
-      g2.load(fused + o + k);
+      vec_zero(g2);
+      if (!fresh) g2.load(fused + o + k);
 #pragma unroll
       for (int c = 0; c < 4; ++c) g2.v[c] = g2.v[c] + acc.v[c];
       g2.store(fused + o + k);
