@@ -909,7 +909,6 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
   WaveTrace wt(nullptr);
   if (blockIdx.x < F.nd) {
     const uint32_t total = D.blk_start[D.T];
-    bool pre = false;
 #pragma unroll 1
     for (uint32_t w = blockIdx.x; w < total; w += F.nd) {
       uint32_t t = 0;
@@ -919,17 +918,7 @@ __global__ __launch_bounds__(kRdBlock, 8) __attribute__((amdgpu_num_sgpr(80))) v
       d.ids = D.ids + D.id_off[t];
       d.n = D.id_off[t + 1] - D.id_off[t];
       d.nblk = D.blk_start[t + 1] - D.blk_start[t];
-      RdNext nx{D.ids, 0u, 0u};   // this workgroup's next block: its ids are fetched during this one
-      const uint32_t w2 = w + F.nd;
-      if (w2 < total) {
-        uint32_t t2 = t;
-        while (t2 + 1 < D.T && D.blk_start[t2 + 1] <= w2) ++t2;
-        nx.ids = D.ids + D.id_off[t2];
-        nx.n = D.id_off[t2 + 1] - D.id_off[t2];
-        nx.bid = w2 - D.blk_start[t2];
-      }
-      rd_dedup_role(d, w - D.blk_start[t], L, wt, &nx, pre);
-      pre = w2 < total;
+      rd_dedup_role(d, w - D.blk_start[t], L, wt);
       __syncthreads();
     }
     return;

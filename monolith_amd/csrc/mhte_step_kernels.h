@@ -144,16 +144,6 @@ struct RdLds {
   uint32_t bmpre[kMaxLongRuns][32];
   uint8_t lslot[kRdStride + 3];
   uint32_t nlong;
-  // persistent dedup workgroups (multi-table and sharded steps): the ids of the workgroup's NEXT block, fetched
-  // while this block's atomics are in flight — the next block starts with its ids in LDS instead of with a
-  // memory round trip (round 6: ~1.5 us of every block's ~8.5 us chain, 13 blocks per workgroup at 26 tables)
-  unsigned long long nid[kRdBlock];
-};
-// the block a persistent dedup workgroup takes after the current one (n = 0: none)
-struct RdNext {
-  const int64_t* ids;
-  uint32_t n;
-  uint32_t bid;
 };
 
 // probe start of an id in a workgroup's dumped table (the side entry for kEmptyKey)
@@ -161,10 +151,8 @@ __device__ __forceinline__ uint32_t rd_home(int64_t id) {
   return uint32_t(hash_key(id) >> 40) & (kRdLds - 1);
 }
 
-// nx / pre (persistent workgroups only): nx = the workgroup's next block, whose ids this call fetches into
-// L.nid; pre = this block's ids are already there (the previous call fetched them)
 __device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, RdLds& L,
-                                              WaveTrace& wt, const RdNext* nx = nullptr, bool pre = false) {
+                                              WaveTrace& wt) {
   const uint32_t t = threadIdx.x;
   for (uint32_t i = t; i < uint32_t(kRdStride); i += kRdBlock) {
     L.key[i] = static_cast<unsigned long long>(kEmptyKey);
@@ -176,7 +164,7 @@ __device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, Rd
   if (bid == 0 && t < 4) d.ctr[t] = 0;  // counters of the build role, which runs after this launch
   const uint32_t p = bid * kRdBlock + t;
   const bool valid = p < d.n;
-  const int64_t id = valid ? (pre ? static_cast<int64_t>(L.nid[t]) : d.ids[p]) : 0;   // round trip 1
+  const int64_t id = valid ? d.ids[p] : 0;   // round trip 1
   lds_barrier();
   uint32_t ls = 0, arr = 0;
   if (valid) {
@@ -284,12 +272,6 @@ __device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, Rd
     d.seg[bid * kRdBlock + o + rank] = uint16_t(t);
   }
   wt.mark(3);
-  // (the next block's ids: in flight beside this block's atomics, parked in LDS at the end)
-  int64_t idn = 0;
-  if (nx) {
-    const uint32_t p2 = nx->bid * kRdBlock + t;
-    idn = nx->ids[(nx->n && p2 < nx->n) ? p2 : 0u];
-  }
   // ---- now the CAS: the home slot was free or already held the id (usual), else linear probing.
   // The count bump returns the number of occurrences other workgroups have registered so far =
   // where this run goes in the id's position list; it is in flight during the table dump.
@@ -327,7 +309,6 @@ __device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, Rd
         d.hlist[size_t(gs) * kLightMax + lbase + i] = bid * kRdBlock + uint32_t(L.pos[o + i]);
     }
   }
-  if (nx) L.nid[t] = static_cast<unsigned long long>(idn);
   wt.mark(4);
 }
 
