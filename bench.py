@@ -1339,7 +1339,14 @@ def main():
              "note": "phases: single-threaded worker-side dedup (std::unordered_map) and shard "
                      "partition, then %d threads: lookup, scatter to occurrences, duplicate-gradient "
                      "sum, optimize.  (ii) = ONE reference map shared by the threads, contiguous "
-                     "chunks of the distinct ids (the fused ops' Shard() loop)" % cores}
+                     "chunks of the distinct ids (the fused ops' Shard() loop)" % cores,
+             "single_threaded_ms": (lambda ph: None if not ph else round(
+                 sum(ph.get(k, 0.0) for k in ("dedup", "partition")), 3))(v1.get("phase_ms_median")),
+             "single_threaded_note": "of variant (i)'s median step, this many ms are the worker-side front end "
+                                     "(dedup + shard partition) on ONE thread — the reference's worker does the "
+                                     "same on its own (unique_mapping_ops.cc:51-155); the per-shard phases use "
+                                     "all %d threads.  The GPU / CPU ratio moves with the box's host "
+                                     "(12.8-21.9 M/s over the boxes seen): not a figure of merit" % cores}
     except Exception as e:  # pylint: disable=broad-except
       cpu = {"value": None, "unit": "lookups+updates/s", "cores": os.cpu_count(), "kind": "reference",
              "sample": "failed: %r" % (e,)}

@@ -1265,6 +1265,22 @@ def test_pooling_gradient_grouping_forms_at_size(form, monkeypatch):
   assert np.array_equal(outs[0], outs[1])
 
 
+def test_pooling_gradient_grouping_beyond_the_register_held_tiles():
+  """csrc/mhte_group_kernels.h keeps a wavefront's 1 024 keys of a tile in registers; beyond 512 tiles (2 M
+  keys) a wavefront walks its keys in ROUNDS of that shape (`GsPass::rounds` > 1: the keys are read again for the
+  walk).  2.6 M unsorted rows into 100 000 outputs, one output holding a tenth of them: the reference's
+  sequential sums (reduce_op.cc:46-49), bit for bit."""
+  rng = np.random.default_rng(11)
+  batch, dim, n = 100000, 4, 2600000
+  ind = rng.integers(0, batch, n)
+  ind[rng.random(n) < 0.1] = 777
+  vals = rng.standard_normal((n, dim)).astype(np.float32)
+  exp = np.zeros((batch, dim), np.float32)
+  np.add.at(exp, ind, vals)
+  got = D.reduce_sum(torch.from_numpy(ind[:, None]).cuda(), val_t(vals), [batch], False).cpu().numpy()
+  np.testing.assert_array_equal(got, exp)
+
+
 # =============================================================================== admission + eviction
 def _filtered_cfg(dim, opt, default_thr, slot_thr=None, **kw):
   return entry.make_table_config(
