@@ -815,7 +815,7 @@ def main():
   # 200-step window of the same mode: `reference_window` in the JSON line
   REFW = 200 if (K < 200 and not sharded) else 0
   n_batches = ((W + K) + (Wg + K) + 2 * reps + 14 + PROF_WARM + REFW +
-               (0 if args.no_extra_windows else (W + K + 1) + 2 * (Wg + K + 8))) if not sharded else (K + W + 24)
+               (0 if args.no_extra_windows else (W + K + 1) + REFW + 2 * (Wg + K + 8))) if not sharded else (K + W + 24)
   ids_host = np.stack([S.id_batch(s * world + rank, B, V, "zipf") for s in range(n_batches)])
   ids_all = torch.from_numpy(ids_host).to(dev)
   NG = max(1, args.grad_pool)
@@ -948,8 +948,17 @@ def main():
         run_c_loop(cur, cur + K)
         barrier()
         extra_windows["eager_cpp"] = (time.perf_counter() - t) / K * 1e3
-        _gc.enable()
         cur += K
+        if REFW:
+          # (a 20-step window of eager launches is mostly the queue's start-up after a drained device: the same C
+          # loop over the reference window's 200 steps — profiles/r06/host_enqueue.md)
+          barrier()
+          t = time.perf_counter()
+          run_c_loop(cur, cur + REFW)
+          barrier()
+          extra_windows["eager_cpp_%d_steps" % REFW] = (time.perf_counter() - t) / REFW * 1e3
+          cur += REFW
+        _gc.enable()
       except Exception as e:  # pylint: disable=broad-except
         extra_windows["eager_cpp_error"] = repr(e)[:200]
         print("eager_cpp window failed: %r" % (e,), file=sys.stderr)
