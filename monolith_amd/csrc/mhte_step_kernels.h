@@ -293,13 +293,6 @@ __device__ __forceinline__ void rd_dedup_role(const RunView& d, uint32_t bid, Rd
     // find their runs by probing every workgroup's directory, rd_find_run_opt)
     lbase = uint32_t(atomicAdd(&d.hs[gs].cp, (static_cast<unsigned long long>(p) << 32) |
                                                  static_cast<unsigned long long>(L.cnt[ls])));
-#ifdef MHTE_EXPERIMENT_EXTRA_ATOMICS
-    // (timing-only experiment, never shipped: MHTE_EXPERIMENT_EXTRA_ATOMICS more device-scope atomics per run, on
-    // the run's position-list line — how much of the role's time is its atomics?  Corrupts lists of 32.)
-#pragma unroll
-    for (int x_ = 0; x_ < MHTE_EXPERIMENT_EXTRA_ATOMICS; ++x_)
-      atomicAdd(&d.hlist[size_t(gs) * kLightMax + (kLightMax - 1 - x_)], 1u);
-#endif
   }
   // ---- the LDS table is the workgroup's run directory
   for (uint32_t i = t; i < uint32_t(kRdStride); i += kRdBlock) {
