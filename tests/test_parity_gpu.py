@@ -1281,6 +1281,46 @@ def test_pooling_gradient_grouping_beyond_the_register_held_tiles():
   np.testing.assert_array_equal(got, exp)
 
 
+def test_pooling_gradient_grouping_many_keys_and_wide_keys():
+  """The grouping's two shapes the size test above does not reach (csrc/mhte_group_kernels.h): more than 2 M
+  keys — a wavefront then walks its share of a tile in ROUNDS of 1 024 keys instead of holding it in registers —
+  and keys of 31 bits — four passes of 8 bits, the (key, position) words ping-ponging twice.  Same checks:
+  the reference's sequential sums bit for bit (reduce_op.cc:46-49; map_id_to_embedding.cu.cc:98-107)."""
+  rng = np.random.default_rng(11)
+  # 2.6 M unsorted rows of dim 4 into 300 000 outputs (19 + 1 key bits: two passes, two rounds per wavefront)
+  batch, dim, n = 300000, 4, 2600000
+  ind = rng.integers(0, batch, n)
+  ind[rng.random(n) < 0.1] = 77
+  vals = rng.standard_normal((n, dim)).astype(np.float32)
+  exp = np.zeros((batch, dim), np.float32)
+  np.add.at(exp, ind, vals)
+  got = D.reduce_sum(torch.from_numpy(ind[:, None]).cuda(), val_t(vals), [batch], False).cpu().numpy()
+  np.testing.assert_array_equal(got, exp)
+  del exp, got, vals
+  # a fused buffer of 2^30 + 64 floats (4 GB): offsets are 31-bit keys, 31 + 1 bits = four passes
+  fused_len = (1 << 30) + 64
+  d, nr = 4, 120000
+  o = rng.integers(0, fused_len // d - 1, nr).astype(np.int64)
+  o[rng.random(nr) < 0.05] = (1 << 28) + 5          # one destination far up takes 5 % of the rows
+  o[:3] = [0, fused_len // d - 1, (1 << 29) + 1]    # both ends of the buffer
+  offs = (o * d).astype(np.int64)
+  g = rng.standard_normal((nr, d)).astype(np.float32)
+  sc = np.float32(1.5)
+  acc = {}
+  gs_ = g * sc
+  for j in range(nr):
+    a = acc.get(int(offs[j]))
+    acc[int(offs[j])] = (np.float32(0) + gs_[j]) if a is None else a + gs_[j]
+  out = D.fused_gather_embeddings_by_input_gradient(fused_len, [val_t(g)], [torch.from_numpy(offs.astype(np.int32)).cuda()],
+                                                    [d], scale=float(sc))
+  keys = np.fromiter(acc.keys(), dtype=np.int64)
+  idx = torch.from_numpy((keys[:, None] + np.arange(d)[None, :]).ravel()).cuda()
+  got = out[idx].cpu().numpy().reshape(-1, d)
+  np.testing.assert_array_equal(got, np.stack([acc[int(k)] for k in keys]))
+  # nothing else was written: the touched floats carry the whole sum of absolute values
+  assert float(out.abs().sum(dtype=torch.float64)) == pytest.approx(float(np.abs(got.astype(np.float64)).sum()), rel=1e-12)
+
+
 # =============================================================================== admission + eviction
 def _filtered_cfg(dim, opt, default_thr, slot_thr=None, **kw):
   return entry.make_table_config(
