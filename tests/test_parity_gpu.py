@@ -1302,7 +1302,7 @@ def test_pooling_gradient_grouping_many_keys_and_wide_keys():
   d, nr = 4, 120000
   o = rng.integers(0, fused_len // d - 1, nr).astype(np.int64)
   o[rng.random(nr) < 0.05] = (1 << 28) + 5          # one destination far up takes 5 % of the rows
-  o[:3] = [0, fused_len // d - 1, (1 << 29) + 1]    # both ends of the buffer
+  o[:3] = [0, fused_len // d - 1, (1 << 27) + 1]    # both ends of the buffer
   offs = (o * d).astype(np.int64)
   g = rng.standard_normal((nr, d)).astype(np.float32)
   sc = np.float32(1.5)
@@ -1313,9 +1313,17 @@ def test_pooling_gradient_grouping_many_keys_and_wide_keys():
     acc[int(offs[j])] = (np.float32(0) + gs_[j]) if a is None else a + gs_[j]
   out = D.fused_gather_embeddings_by_input_gradient(fused_len, [val_t(g)], [torch.from_numpy(offs.astype(np.int32)).cuda()],
                                                     [d], scale=float(sc))
-  keys = np.fromiter(acc.keys(), dtype=np.int64)
-  idx = torch.from_numpy((keys[:, None] + np.arange(d)[None, :]).ravel()).cuda()
-  got = out[idx].cpu().numpy().reshape(-1, d)
+  keys = np.sort(np.fromiter(acc.keys(), dtype=np.int64))
+  # (read back through views of 2^27 floats: torch's advanced indexing of a tensor beyond 2^31 bytes raises a
+  # hardware exception on this stack (HSA_STATUS_ERROR_EXCEPTION 0x1016 in its index kernel) and is not what is under test)
+  CH = 1 << 27
+  got = np.empty((keys.size, d), np.float32)
+  for c0 in range(0, fused_len, CH):
+    sel = np.nonzero((keys >= c0) & (keys < c0 + CH))[0]
+    if sel.size:
+      view = out[c0:min(fused_len, c0 + CH)]
+      idx = torch.from_numpy(((keys[sel] - c0)[:, None] + np.arange(d)[None, :]).ravel()).cuda()
+      got[sel] = view[idx].cpu().numpy().reshape(-1, d)
   np.testing.assert_array_equal(got, np.stack([acc[int(k)] for k in keys]))
   # nothing else was written: the touched floats carry the whole sum of absolute values
   assert float(out.abs().sum(dtype=torch.float64)) == pytest.approx(float(np.abs(got.astype(np.float64)).sum()), rel=1e-12)
