@@ -445,7 +445,7 @@ struct MultiStep {
       A.grads = p.grads;
       A.cur = uint32_t(slot_cur);
       uint32_t gx = 0;
-      bool any_apply = false;
+      bool any_apply = false, any_exact = false;
       for (uint32_t k = 0; k < tc; ++k) {
         const uint32_t t = t0 + k;
         MBwdTab& bt = A.tab[k];
@@ -467,13 +467,22 @@ struct MultiStep {
           bt.a.sum_dups = 1;
           bt.a.filter_mode = 1;
           bt.a.global_step = p.global_step;
-          bt.light_max = p.exact_order ? 0xffffffffu : uint32_t(kStepLightMax);
+          // MHTE_EXACT_ORDER: the heavy lists' sums come from mstep_exact_sum_kernel, launched in front (as in the
+          // single-table step; MHTE_EXACT_WALK=1: round 5's form, every list walked by its lane group)
+          static const bool exact_walk = getenv("MHTE_EXACT_WALK") != nullptr && atoi(getenv("MHTE_EXACT_WALK")) != 0;
+          const bool exact_pre = p.exact_order && !exact_walk && tb.dim <= 256u;
+          const bool exact_old = p.exact_order && !exact_pre;
+          if (exact_pre) {
+            bt.apply |= 2u;
+            any_exact = true;
+          }
+          bt.light_max = exact_old ? 0xffffffffu : uint32_t(kStepLightMax);
           bt.hints = (has_hints[slot_cur] && fwd_epoch[slot_cur][t] == tb.mut_epoch) ? 1u : 0u;
           bt.gv = shape_code(tb, uint64_t(bt.grad_off));
           const uint32_t groups_per_wg = 256u / shape_lanes(bt.gv);
           const uint32_t cap_items = DedupWs::max_items(n);
-          bt.nblk_items = p.exact_order ? 0u
-                                        : std::min<uint32_t>(cap_items, std::min<uint32_t>(
+          bt.nblk_items = exact_old ? 0u
+                                    : std::min<uint32_t>(cap_items, std::min<uint32_t>(
                                               uint32_t(num_cus) * 10 / 8, std::max<uint32_t>(8, share / 4)));
           const uint32_t need = (n + groups_per_wg - 1) / groups_per_wg;
           const uint32_t room = share > bt.nblk_items + std::min<uint32_t>(128, share / 8) + 16
@@ -486,6 +495,10 @@ struct MultiStep {
         gx = std::max(gx, blocks);
       }
       if (gx == 0) continue;
+      if (any_exact) {   // (one 135-KB workgroup per CU: the chip's CUs dealt over the launch's tables)
+        mstep_exact_sum_kernel<<<dim3(std::max<uint32_t>(4, uint32_t(num_cus) / tc), tc), kExactThreads, 0, st>>>(A);
+        HIP_OK(hipGetLastError());
+      }
       A.trace = trace_region(kTagMStepBwd, gx * tc, 256);
       // one launch per optimizer family present (the BASIC instantiation keeps the register budget
       // of SGD / Adagrad / FTRL tables; a workgroup of the other family's table leaves at once)

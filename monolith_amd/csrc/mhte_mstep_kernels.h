@@ -106,7 +106,9 @@ struct MFwdArgs {
 
 struct MBwdTab {
   uint32_t grad_off;           // floats
-  uint32_t apply;              // 0: nothing to apply for this table (empty batch / build only)
+  uint32_t apply;              // 0: nothing to apply for this table (empty batch / build only); bit 0: apply,
+                               // bit 1 (MHTE_EXACT_ORDER): the heavy lists' strictly sequential sums are in
+                               // part[] (mstep_exact_sum_kernel, launched in front): the item workgroups only apply
   uint32_t nblk_items, nblk_ids;
   uint32_t build_next;         // 1: slot cur ^ 1 holds a deduplicated batch to number
   uint32_t light_max;
@@ -548,9 +550,26 @@ __global__ __launch_bounds__(256, MHTE_MBWD_OCC) void mstep_bwd_kernel(MBwdArgs 
   c.uts = bt.hints ? s.uts[cur] : nullptr;
   c.trusted = 1;   // (the host hands the hints over only while Table::mut_epoch is unchanged)
   c.urec = nullptr;
-  c.pre_summed = 0;   // (MHTE_EXACT_ORDER here: every list walked by its lane group, light_max = all)
+  c.pre_summed = (bt.apply >> 1) & 1u;
   mstep_apply_switch<ONESEG, FULL, VW, FILT>(bt.gv, tv, d, c, bt.a, bid, wt, L);
   wt.end(bid < bt.nblk_items ? 7u : 8u);
+}
+
+// MHTE_EXACT_ORDER for the multi-table step (round 6): every table's heavy lists summed strictly in occurrence
+// order in front of mstep_bwd — rd_exact_sum_role, the single-table step's kernel, per table (blockIdx.y)
+__global__ __launch_bounds__(kExactThreads) void mstep_exact_sum_kernel(MBwdArgs A) {
+  __shared__ ExactLds L;
+  const uint32_t t = blockIdx.y;
+  const MBwdTab& bt = A.tab[t];
+  if (!(bt.apply & 2u)) return;
+  const MStepStatic& s = deref_const(A.st + t);
+  const TableView& tv = deref_const(A.views + t);
+  const uint32_t cur = A.cur & 1u;
+  RunView d = s.rv[cur];
+  d.nblk = (bt.n + kRdBlock - 1) / kRdBlock;
+  const float* grads = A.grads + size_t(bt.grad_off);
+  if (bt.gv & 1u) rd_exact_sum_role<1>(d, grads, tv.dim, s.part[cur], blockIdx.x, gridDim.x, L);
+  else rd_exact_sum_role<4>(d, grads, tv.dim, s.part[cur], blockIdx.x, gridDim.x, L);
 }
 
 // displacement pass of every table's update: one workgroup per table, kSlowWaves deferred ids at a

@@ -1922,10 +1922,10 @@ struct __attribute__((aligned(16))) ExactLds {
   uint32_t rbase[64];
 };
 
+// wg / nwg: this workgroup's index among the nwg that share the batch's heavy lists
 template <int VEC>
-__global__ __launch_bounds__(kExactThreads) void rd_exact_sum_kernel(RunView d, const float* __restrict__ grads,
-                                                                     uint32_t dim, float* __restrict__ part) {
-  __shared__ ExactLds L;
+__device__ __forceinline__ void rd_exact_sum_role(const RunView& d, const float* __restrict__ grads, uint32_t dim,
+                                                  float* __restrict__ part, uint32_t wg, uint32_t nwg, ExactLds& L) {
   constexpr uint32_t NL = kExactThreads - 64;   // loader lanes (wavefronts 1-7)
   const uint32_t t = threadIdx.x, lane = t & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1933,7 +1933,7 @@ __global__ __launch_bounds__(kExactThreads) void rd_exact_sum_kernel(RunView d, 
   const uint32_t upr = dim / VEC;                                                       // float4s (floats) per row
   const uint32_t nitems_all = d.ctr[2];
 #pragma unroll 1
-  for (uint32_t w = blockIdx.x; w < nitems_all; w += gridDim.x) {
+  for (uint32_t w = wg; w < nitems_all; w += nwg) {
     const ItemHdr hd = d.item_hdr[w];
     if (((hd.meta >> 16) & 0xffu) != 0u) continue;   // (workgroup-uniform: not the list's first item)
     __syncthreads();   // (the previous list's tables are no longer read)
@@ -2054,6 +2054,12 @@ __global__ __launch_bounds__(kExactThreads) void rd_exact_sum_kernel(RunView d, 
       }
     }
   }
+}
+template <int VEC>
+__global__ __launch_bounds__(kExactThreads) void rd_exact_sum_kernel(RunView d, const float* __restrict__ grads,
+                                                                     uint32_t dim, float* __restrict__ part) {
+  __shared__ ExactLds L;
+  rd_exact_sum_role<VEC>(d, grads, dim, part, blockIdx.x, gridDim.x, L);
 }
 
 // ---------------------------------------------------------------------------------------------
