@@ -42,7 +42,7 @@ enum {
 
 const char* mhte_last_error(void);
 /* ABI version of this header; mhte_abi_version() must return the same value. */
-#define MHTE_ABI_VERSION 16
+#define MHTE_ABI_VERSION 17
 int32_t mhte_abi_version(void);
 
 /* ---- configuration (flat C form of RT/hash_table/embedding_hash_table.proto) --------------- */
@@ -733,6 +733,14 @@ mhte_status mhte_shard_step_set_overlap(mhte_shard_step* s, int32_t mode);
  * tf.float16 around the gradient all-to-all, NT/distributed_ps_sync.py:47,334-337); every rank of the
  * world must make the same choice, before its first backward.  bits 32: fp32 (default). */
 mhte_status mhte_shard_step_set_grad_bits(mhte_shard_step* s, int32_t bits);
+/* on != 0: this rank's per-id gradient sums are the reference's SEQUENTIAL sums for every duplicate list
+ * (MonolithFillWithOffsetMapGradient adds an id's gradients in occurrence order,
+ * RT/ops/unique_mapping_ops.cc:284-329) — lists of up to 32 occurrences are summed that way in any mode; with
+ * this the heavy ones are too (one more launch in front of the sums: a workgroup streams a list's rows through LDS,
+ * one wavefront adds them in order), instead of a fixed tree within 1e-6 of it.  Every owner's rows are then the
+ * reference's bit for bit (its senders applied in rank order, distributed_ps_sync.py:357-479).  A per-rank
+ * choice; takes effect at the next backward. */
+mhte_status mhte_shard_step_set_exact_order(mhte_shard_step* s, int32_t on);
 /* waits for the stream, then reports a block overflow of the steps enqueued so far */
 mhte_status mhte_shard_step_check(mhte_shard_step* s, void* stream);
 /* distinct ids per table of this rank's forward batch (host int64[T]); synchronises */

@@ -26,7 +26,7 @@ MHTE_SUM_DUPLICATES = 2
 MHTE_EXACT_ORDER = 1       # flags of mhte_table_sum_optimize_n
 MHTE_DEFER_SLOWPATH = 2
 MHTE_LAYOUT_ONE_FID_UNIQUE_ROWS = 1
-ABI_VERSION = 16           # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
+ABI_VERSION = 17           # MHTE_ABI_VERSION of include/monolith_amd_hash_table.h
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 OPT_MOMENTUM, OPT_ADADELTA, OPT_RMSPROP, OPT_RMSPROPV2, OPT_ADAM, OPT_AMSGRAD = 3, 4, 5, 6, 7, 8
@@ -207,7 +207,7 @@ EXPORTS = [
     "mhte_multi_step_backward", "mhte_multi_step_unique_counts",
     "mhte_shard_unique_id", "mhte_shard_step_create", "mhte_shard_step_destroy",
     "mhte_shard_step_create_ipc", "mhte_shard_step_ipc_handle", "mhte_shard_step_ipc_connect",
-    "mhte_shard_step_ipc_selftest", "mhte_shard_step_set_overlap", "mhte_shard_step_set_grad_bits", "mhte_shard_step_forward", "mhte_shard_step_backward", "mhte_shard_step_check",
+    "mhte_shard_step_ipc_selftest", "mhte_shard_step_set_overlap", "mhte_shard_step_set_grad_bits", "mhte_shard_step_set_exact_order", "mhte_shard_step_forward", "mhte_shard_step_backward", "mhte_shard_step_check",
     "mhte_shard_step_info", "mhte_shard_step_launches", "mhte_shard_step_wire_stats", "mhte_shard_step_comm_ranks", "mhte_shard_step_unique_counts", "mhte_shard_group_forward", "mhte_shard_group_backward",
     "mhte_multi_table_create_from_proto", "mhte_multi_table_find", "mhte_multi_table_is_initialized",
     "mhte_hash_filter_create_from_proto", "mhte_lookup_entry", "mhte_feature_stat",

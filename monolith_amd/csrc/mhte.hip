@@ -4799,6 +4799,14 @@ mhte_status mhte_shard_step_set_grad_bits(mhte_shard_step* s, int32_t bits) {
   });
 }
 
+mhte_status mhte_shard_step_set_exact_order(mhte_shard_step* s, int32_t on) {
+  return guard([&] {
+    if (!s) throw Error(MHTE_INVALID_ARGUMENT, "null shard step");
+    auto locks = lock_tables(&s, 1);
+    s->ss.exact_order = on != 0;
+  });
+}
+
 mhte_status mhte_shard_step_check(mhte_shard_step* s, void* stream) {
   return guard([&] {
     if (!s) throw Error(MHTE_INVALID_ARGUMENT, "null shard step");

@@ -568,8 +568,9 @@ __global__ __launch_bounds__(kExactThreads) void mstep_exact_sum_kernel(MBwdArgs
   RunView d = s.rv[cur];
   d.nblk = (bt.n + kRdBlock - 1) / kRdBlock;
   const float* grads = A.grads + size_t(bt.grad_off);
-  if (bt.gv & 1u) rd_exact_sum_role<1>(d, grads, tv.dim, s.part[cur], blockIdx.x, gridDim.x, L);
-  else rd_exact_sum_role<4>(d, grads, tv.dim, s.part[cur], blockIdx.x, gridDim.x, L);
+  const ExactToPart dst{s.part[cur], tv.dim};
+  if (bt.gv & 1u) rd_exact_sum_role<1>(d, grads, tv.dim, dst, blockIdx.x, gridDim.x, L);
+  else rd_exact_sum_role<4>(d, grads, tv.dim, dst, blockIdx.x, gridDim.x, L);
 }
 
 // displacement pass of every table's update: one workgroup per table, kSlowWaves deferred ids at a

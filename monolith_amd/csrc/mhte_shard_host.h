@@ -180,6 +180,9 @@ struct ShardStep {
   // ids_per_peer_table, or MHTE_SHARD_EXACT=0) needs no host knowledge at all.  The peer-store
   // transport — the default on one node — is exact-size without any host wait.
   bool exact = false;
+  // mhte_shard_step_set_exact_order: the sender's per-id gradient sums strictly in occurrence order for EVERY list
+  // (lists of <= 32 are in any mode): shard_exact_sum_kernel in front of the sums' launch
+  bool exact_order = false;
   int64_t* h_cnt[2] = {nullptr, nullptr};   // per slot [2 (sent | received)][world][hdr]
   hipEvent_t ev_cnt[2] = {nullptr, nullptr};
   // Round 6 — the exact form on the wire: ONE ncclSend / ncclRecv pair per peer and exchange.  The occupied
@@ -937,6 +940,11 @@ struct ShardStep {
         ((A.gt[i].gv & 1u) ? w1 : w4) = true;
       }
       if (!gx) continue;
+      A.exact = (exact_order && sum_slot >= 0) ? 1u : 0u;
+      if (A.exact) {   // (one 135-KB workgroup per CU: the chip's CUs dealt over the launch's tables)
+        shard_exact_sum_kernel<<<dim3(std::max<uint32_t>(4, uint32_t(ms.num_cus) / tc), tc), kExactThreads, 0, st>>>(A);
+        ++launches;
+      }
       if (w4) LAUNCH_HOT(kTagShardBuild, shard_build_kernel<4>, dim3(gx, tc), 256, st, A);
       if (w1) LAUNCH_HOT(kTagShardBuild, shard_build_kernel<1>, dim3(gx, tc), 256, st, A);
       launches += (w4 ? 1u : 0u) + (w1 ? 1u : 0u);

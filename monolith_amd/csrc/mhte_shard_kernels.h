@@ -742,6 +742,7 @@ __device__ __forceinline__ void shard_gather_ctl(GatherCtl& c, const MStepStatic
   c.peer_win = nullptr;
   c.peer_out_off = 0;
   c.rows_block = 1;
+  c.pre_summed = 0;
 }
 
 template <bool SCATTER, int VW>
@@ -961,6 +962,8 @@ struct ShardBuildArgs {
   uint32_t slot;
   uint32_t n_max;
   uint32_t t0;                    // tables [t0, t0 + gridDim.y) of the model; tab / n_build / gt by position
+  uint32_t exact;                 // 1 (mhte_shard_step_set_exact_order): heavy lists summed strictly in occurrence
+                                  // order by shard_exact_sum_kernel, launched in front of this one
   // direct peer stores (nullptr: send_ids / rows_out): ids into the owners' id buffers, sums into their
   // gradient buffers
   const unsigned long long* peer_win;   // [world] device array
@@ -1014,7 +1017,41 @@ __global__ __launch_bounds__(256) void shard_build_kernel(ShardBuildArgs A) {
   c.peer_win = A.peer_win;
   c.peer_out_off = A.peer_grads_off;
   c.rows_block = A.geo.rows_block;
+  c.pre_summed = A.exact;
   shard_gather_switch<false, VW>(gt.gv, d, c, bid, raw);
+}
+
+// Exact order on the sender side of the sharded step (round 6): every table's heavy lists summed strictly in
+// occurrence order — rd_exact_sum_role, the single-table step's kernel — straight into the row slot the sum
+// travels in (the owner's gradient block with peer stores), in front of shard_build_kernel, whose item
+// workgroups then leave.  With it every sender's per-id sum is the reference's sequential sum
+// (RT/ops/unique_mapping_ops.cc:284-329) bit for bit, and so is every owner's row.
+struct ExactToSlot {
+  GatherCtl c;
+  __device__ __forceinline__ float* operator()(uint32_t, const ItemHdr& hd) const {
+    const uint32_t ix = c.index[hd.u];
+    return ix == 0xffffffffu ? nullptr : gather_out_ptr(c, ix);
+  }
+};
+__global__ __launch_bounds__(kExactThreads) void shard_exact_sum_kernel(ShardBuildArgs A) {
+  __shared__ ExactLds L;
+  const uint32_t tl = blockIdx.y, t = A.t0 + tl;
+  const ShardGatherTab gt = A.gt[tl];
+  if (gt.n == 0) return;
+  const MStepStatic& s = deref_const(A.st + t);
+  const uint32_t cur = A.slot & 1u;
+  RunView d = s.rv[cur];
+  d.nblk = (gt.n + kRdBlock - 1) / kRdBlock;
+  ExactToSlot dst;
+  dst.c.in = A.grads + size_t(gt.io_off);
+  dst.c.out = A.rows_out;
+  shard_gather_ctl(dst.c, s, cur, A.slot_off, A.n_max, t, A.tab[tl].dim, gt);
+  dst.c.peer_win = A.peer_win;
+  dst.c.peer_out_off = A.peer_grads_off;
+  dst.c.rows_block = A.geo.rows_block;
+  const float* grads = A.grads + size_t(gt.io_off);
+  if (gt.gv & 1u) rd_exact_sum_role<1>(d, grads, A.tab[tl].dim, dst, blockIdx.x, gridDim.x, L);
+  else rd_exact_sum_role<4>(d, grads, A.tab[tl].dim, dst, blockIdx.x, gridDim.x, L);
 }
 
 // ---- peer-store transport: one process per GPU, every rank maps every other rank's WINDOW ----------

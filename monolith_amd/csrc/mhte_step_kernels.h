@@ -1922,10 +1922,11 @@ struct __attribute__((aligned(16))) ExactLds {
   uint32_t rbase[64];
 };
 
-// wg / nwg: this workgroup's index among the nwg that share the batch's heavy lists
-template <int VEC>
+// wg / nwg: this workgroup's index among the nwg that share the batch's heavy lists.  dst_of(item, header) = where
+// the list's sum goes (dim floats; nullptr: nowhere)
+template <int VEC, class DST>
 __device__ __forceinline__ void rd_exact_sum_role(const RunView& d, const float* __restrict__ grads, uint32_t dim,
-                                                  float* __restrict__ part, uint32_t wg, uint32_t nwg, ExactLds& L) {
+                                                  DST dst_of, uint32_t wg, uint32_t nwg, ExactLds& L) {
   constexpr uint32_t NL = kExactThreads - 64;   // loader lanes (wavefronts 1-7)
   const uint32_t t = threadIdx.x, lane = t & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -2047,19 +2048,26 @@ __device__ __forceinline__ void rd_exact_sum_role(const RunView& d, const float*
       __syncthreads();
     }
     if (wave == 0) {
+      float* const dst = dst_of(w, hd);
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         const uint32_t f = lane + uint32_t(cc) * 64u;
-        if (f < dim) part[int64_t(w) * dim + f] = acc[cc];
+        if (dst && f < dim) dst[f] = acc[cc];
       }
     }
   }
 }
+// the list's sum into part[its first item]: where the apply role's item workgroup picks it up
+struct ExactToPart {
+  float* part;
+  uint32_t dim;
+  __device__ __forceinline__ float* operator()(uint32_t w, const ItemHdr&) const { return part + int64_t(w) * dim; }
+};
 template <int VEC>
 __global__ __launch_bounds__(kExactThreads) void rd_exact_sum_kernel(RunView d, const float* __restrict__ grads,
                                                                      uint32_t dim, float* __restrict__ part) {
   __shared__ ExactLds L;
-  rd_exact_sum_role<VEC>(d, grads, dim, part, blockIdx.x, gridDim.x, L);
+  rd_exact_sum_role<VEC>(d, grads, dim, ExactToPart{part, dim}, blockIdx.x, gridDim.x, L);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2239,6 +2247,8 @@ struct GatherCtl {
   const unsigned long long* peer_win;   // nullptr: out
   unsigned long long peer_out_off;
   uint32_t rows_block;
+  uint32_t pre_summed;   // SUM, 1 (exact order): the heavy lists' strictly sequential sums are already where
+                         // they belong (shard_exact_sum_kernel, launched in front): the item workgroups leave
 };
 
 // LDS of the gather role, for NG = 256 / G lane groups; the caller declares it
@@ -2382,6 +2392,10 @@ __device__ __forceinline__ void rd_gather_role(const RunView& d, const GatherCtl
       if (lane == 0) sh_rstart[0] = 0;
     }
     lds_barrier();
+    if (!SCATTER && c.pre_summed) {   // (workgroup-uniform: nothing to sum, nothing to hand over)
+      lds_barrier();
+      continue;
+    }
     const uint32_t E = sh_rstart[64];
     Vec<VEC> acc, row;
     vec_zero(acc);

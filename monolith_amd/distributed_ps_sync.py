@@ -221,6 +221,11 @@ class ShardedMultiStep:
     self._libmod.check(self._lib.mhte_shard_step_set_overlap(self._h, C.c_int32(1 if on else 0)))
     return self
 
+  def set_exact_order(self, on: bool = True):
+    """Every duplicate list of this rank summed strictly in occurrence order (mhte_shard_step_set_exact_order):
+    the owners' rows are then the reference's bit for bit.  Takes effect at the next backward."""
+    self._libmod.check(self._lib.mhte_shard_step_set_exact_order(self._h, C.c_int32(1 if on else 0)))
+
   def set_grad_fp16(self, on: bool = True):
     """The gradient exchange in fp16 (mhte_shard_step_set_grad_bits; the reference's optional cast of
     the gradient all-to-all): a numerics change, every rank must choose the same."""
@@ -350,6 +355,11 @@ class ShardedStepGroup:
       self._libmod.check(self._lib.mhte_shard_step_launches(h, ln))
       out.append((int(ln[0]), int(ln[1])))
     return out
+
+  def set_exact_order(self, on: bool = True):
+    """Every rank's duplicate lists summed strictly in occurrence order (mhte_shard_step_set_exact_order)."""
+    for h in self._hs:
+      self._libmod.check(self._lib.mhte_shard_step_set_exact_order(h, C.c_int32(1 if on else 0)))
 
   def wire_stats(self):
     """Per rank: mhte_shard_step_wire_stats of the last forward + backward (device copies stand for the pairs)."""

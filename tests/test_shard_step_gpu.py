@@ -111,12 +111,14 @@ def test_group_launch_count_does_not_grow_with_the_world(world, n_tables, expect
   assert steady[0] == expect, counts
 
 
-def _group_against_oracle(specs, dist, world, grad_fp16, B=3000, steps=5, always_ahead=False):
+def _group_against_oracle(specs, dist, world, grad_fp16, B=3000, steps=5, always_ahead=False, exact_order=False):
   by_name = sorted(specs, key=lambda s: s.name)
   universe = 200000 if dist == "uniform" else 7000
-  exact = dist == "uniform"   # every id occurs <= 32 times in a batch: sums in occurrence order
+  exact = dist == "uniform" or exact_order   # every id occurs <= 32 times in a batch: sums in occurrence order
   mts = [make(specs) for _ in range(world)]
   grp = ShardedStepGroup(mts, B)
+  if exact_order:
+    grp.set_exact_order(True)
   geo = shard_block_geometry(mts[0].get_table_dim_sizes(), B, world)
   info = _info_of(grp)
   assert (info[0], info[1], info[2]) == (geo["cap"], 8 * geo["ids_block"], 4 * geo["rows_block"])
@@ -183,6 +185,18 @@ def _group_against_oracle(specs, dist, world, grad_fp16, B=3000, steps=5, always
     assert sum(sizes) == seen.size, (sp.name, sizes, seen.size)
   grp.close()
   return launch_counts
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_exact_order_makes_the_sharded_step_bit_exact_under_zipf(world):
+  """mhte_shard_step_set_exact_order (round 6): Zipf batches hold lists of hundreds of occurrences, which the
+  sender otherwise sums as a fixed tree (within 1e-6 of the sequential sum).  With exact order every sender's
+  per-id sum is the reference's sequential sum (unique_mapping_ops.cc:284-329) and every owner's row — one
+  optimizer application per sender, in rank order (distributed_ps_sync.py:357-479) — equals the oracle's bit for
+  bit: embeddings of every step and the final rows are compared with assert_array_equal.  Eight tables of dims
+  16 / 32 / 64 (Adagrad, SGD, and a two-segment FTRL + Adagrad row) in one model."""
+  specs = dlrm_specs(8, initial_capacity=1 << 10)
+  _group_against_oracle(specs, "zipf", world, False, B=4000, steps=4, exact_order=True)
 
 
 def test_world1_over_rccl():
