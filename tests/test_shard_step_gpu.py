@@ -199,6 +199,38 @@ def test_exact_order_makes_the_sharded_step_bit_exact_under_zipf(world):
   _group_against_oracle(specs, "zipf", world, False, B=4000, steps=4, exact_order=True)
 
 
+@pytest.mark.parametrize("transport", ["auto", "ipc"])
+def test_exact_order_one_rank_equals_the_exact_multi_table_step(transport):
+  """One rank through the identity exchange and through the peer-store transport to itself (the sums then go
+  straight into the window, gather_out_ptr's peer path): with exact order on both sides the sharded step and the
+  multi-table step (MHTE_EXACT_ORDER, mstep_exact_sum_kernel) leave the same bits under Zipf — embeddings of
+  every step and every row."""
+  specs = dlrm_specs(7, initial_capacity=1 << 12)
+  by_name = sorted(specs, key=lambda s: s.name)
+  B, steps = 6000, 5
+  batches = [batch_of(specs, 40 + s, B, 3000) for s in range(steps + 1)]   # (Zipf: lists of hundreds)
+  mt_a, mt_b = make(specs), make(specs)
+  ref = MultiSparseStep(mt_a, B, exact_order=True)
+  shd = ShardedMultiStep(mt_b, B, transport=transport)
+  shd.set_exact_order(True)
+  assert shd.info()["transport"].startswith("ipc" if transport == "ipc" else "identity")
+  rag_a = [ragged_of(specs, mt_a, b) for b in batches]
+  rag_b = [ragged_of(specs, mt_b, b) for b in batches]
+  for s in range(steps):
+    ea = ref.forward(rag_a[s], rag_a[s + 1])
+    eb = shd.forward(rag_b[s], rag_b[s + 1])
+    assert torch.equal(ea, eb), "forward step %d" % s
+    g = val_t(np.concatenate([grads_of(s, 0, sp, B).ravel() for sp in by_name]))
+    ref.backward(g, S.update_time(s))
+    shd.backward(g, S.update_time(s))
+  shd.check()
+  allids = {sp.name: np.unique(np.concatenate([b[sp.name] for b in batches])) for sp in specs}
+  ra, rb = ragged_of(specs, mt_a, allids), ragged_of(specs, mt_b, allids)
+  assert torch.equal(mt_a.raw_lookup(ra), mt_b.raw_lookup(rb))
+  ref.close()
+  shd.close()
+
+
 def test_world1_over_rccl():
   specs = dlrm_specs(4, initial_capacity=1 << 10)
   by_name = sorted(specs, key=lambda s: s.name)
